@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — regenerates tests/golden/*.npz from the compiled reference.
+
+Run in the authoring container only (needs /root/reference and `make -C oracle ref whitebox`):
+
+    python oracle/gen_fixtures.py
+
+White-box fixtures: oracle/_ref/whitebox (oracle/whitebox.cpp linked against the reference's own
+objects) dumps inputs/outputs of the reference's private hot-path members on small synthetic alignments.
+Black-box fixtures: oracle/_ref/VeryFastTree runs with `-threads 1 -verbose 3 -log` and the join order /
+stage log-likelihoods are parsed from its log.
+
+Only data (inputs + expected outputs) is written to tests/golden/.
+"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from veryfasttree_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+WHITEBOX = os.path.join(HERE, "_ref", "whitebox")
+REFBIN = os.path.join(HERE, "_ref", "VeryFastTree")
+
+DTYPES = {b"f": np.float32, b"d": np.float64, b"i": np.int32, b"q": np.int64, b"b": np.uint8}
+
+
+def read_vfx(path):
+    out = {}
+    with open(path, "rb") as fh:
+        assert fh.read(4) == b"VFX1"
+        while True:
+            head = fh.read(4)
+            if not head:
+                break
+            (nl,) = struct.unpack("<I", head)
+            name = fh.read(nl).decode()
+            dt = DTYPES[fh.read(1)]
+            (nd,) = struct.unpack("<I", fh.read(4))
+            dims = struct.unpack("<%dQ" % nd, fh.read(8 * nd)) if nd else ()
+            count = int(np.prod(dims)) if nd else 1
+            data = np.frombuffer(fh.read(count * np.dtype(dt).itemsize), dtype=dt)
+            out[name] = data.reshape(dims) if nd else data.reshape(())
+    return out
+
+
+WHITEBOX_CASES = [
+    # name, mode, n_seq, n_pos, n_codes, mu, gap, seed
+    ("wb_nt_f32", "nt_f32", 160, 96, 4, 0.06, 0.04, 11),
+    ("wb_nt_f32_gappy", "nt_f32", 48, 40, 4, 0.15, 0.30, 12),
+    ("wb_nt_f64", "nt_f64", 40, 48, 4, 0.08, 0.05, 13),
+    ("wb_aa_f32", "aa_f32", 56, 48, 20, 0.10, 0.05, 14),
+    ("wb_aa_f64", "aa_f64", 56, 48, 20, 0.10, 0.05, 15),
+]
+
+
+def gen_whitebox(tmp):
+    for name, mode, n, L, nc, mu, gap, seed in WHITEBOX_CASES:
+        codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if nc == 20 else synth.ALPHABET_NT)
+        vfx = os.path.join(tmp, name + ".vfx")
+        subprocess.run([WHITEBOX, mode, fa, vfx, str(seed)], check=True)
+        d = read_vfx(vfx)
+        d["input.codes"] = codes  # the alignment as generated (before the reference's uniquify)
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, **d)
+        print("%-20s %4d arrays  %7.1f KiB" % (name, len(d), os.path.getsize(dst) / 1024.0))
+
+
+BLACKBOX_CASES = [
+    # name, flags, n_seq, n_pos, n_codes, mu, gap, seed
+    ("bb_nt_c1", ["-nt", "-fastest"], 16, 100, 4, 0.05, 0.0, 1),  # BASELINE config 1
+    ("bb_nt_200", ["-nt"], 200, 120, 4, 0.05, 0.02, 21),
+    ("bb_nt_600_fastest", ["-nt", "-fastest"], 600, 100, 4, 0.04, 0.02, 22),
+    ("bb_nt_1500", ["-nt"], 1500, 80, 4, 0.03, 0.01, 23),
+]
+
+
+def gen_blackbox(tmp):
+    for name, flags, n, L, nc, mu, gap, seed in BLACKBOX_CASES:
+        codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+        log = os.path.join(tmp, name + ".log")
+        cmd = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-verbose", "3", "-noml", "-nome", "-nosupport",
+                                  "-log", log, fa]
+        res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        joins = []
+        text = open(log).read() + "\n" + res.stderr.decode(errors="replace")
+        for m in re.finditer(r"^Join\t(\d+)\t(\d+)\t(\S+)\tlambda\t\S+\tselfw\t\S+\t\S+\tnew\t(\d+)", text, re.M):
+            joins.append((int(m.group(1)), int(m.group(2)), int(m.group(4)), float(m.group(3))))
+        seen, uniq = set(), []
+        for j in joins:  # log + stderr may both carry the lines
+            if j[2] not in seen:
+                seen.add(j[2])
+                uniq.append(j)
+        joins = uniq
+        assert joins, "no Join lines for " + name
+        ja = np.array([(a, b, c) for a, b, c, _ in joins], dtype=np.int64)
+        jc = np.array([c for _, _, _, c in joins], dtype=np.float64)
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, codes=codes, joins=ja, join_criterion=jc,
+                            newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        print("%-20s %5d joins  %7.1f KiB" % (name, len(joins), os.path.getsize(dst) / 1024.0))
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    which = sys.argv[1:] or ["whitebox", "blackbox"]
+    with tempfile.TemporaryDirectory() as tmp:
+        if "whitebox" in which:
+            gen_whitebox(tmp)
+        if "blackbox" in which:
+            gen_blackbox(tmp)
+
+
+if __name__ == "__main__":
+    main()
