@@ -1,0 +1,157 @@
+/*
+ * vft_hip.h — C ABI of the MI355X (gfx950) profile-operations backend for VeryFastTree.
+ *
+ * This is the drop-in boundary.  The reference selects a backend through the template slot
+ * `Operations<Precision>` (src/NeighbourJoining.h:19-22,256; registration src/impl/VeryFastTreeFloatCuda.cpp:1-7,
+ * src/VeryFastTree.cpp:305-314) whose ten methods work on one 4- or 20-element vector at a time
+ * (src/operations/BasicOperations.h:20-39).  That granularity cannot feed a GPU
+ * (src/operations/CudaOperations.cu:19-27 pays an allocation and two copies per 4 floats), so this backend keeps
+ * the slot (veryfasttree_amd/host/HipOperations.h satisfies the trait) and lifts the hot loops that wrap those
+ * calls to whole-profile, batched entry points.  Each entry point below names the reference member it replaces.
+ *
+ * Conventions
+ *   - plain C, opaque context, int return code (0 = VFT_OK); vft_last_error() gives the text.
+ *   - "real" arrays are float when the context precision is 4, double when it is 8 (the reference's numeric_t).
+ *   - node ids follow the reference: leaves 0..nSeqs-1 in unique-sequence order, internal nodes nSeqs..maxnodes-1
+ *     in creation order (NJ.tcc:2904-2909).  Codes are the reference's: 0..nCodes-1, NOCODE = 127.
+ *   - host-side dense profile = w[nPos], codes[nPos], f[nPos*nCodes]; f is read/written only for columns where
+ *     the reference holds a vector (codes == NOCODE && w > 0, NJ.tcc:2040-2042).
+ *   - every call is asynchronous on the context's stream unless it returns data to host memory, in which case
+ *     it synchronises that stream before returning.  Pointers named d_* are DEVICE pointers supplied by the
+ *     caller (e.g. torch tensors) and are written on the stream without synchronising.
+ *   - there is no CPU fallback: without a HIP device vft_create fails.
+ */
+#ifndef VFT_HIP_H
+#define VFT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFT_OK 0
+#define VFT_ERR_INVALID 1   /* bad argument */
+#define VFT_ERR_HIP 2       /* a HIP runtime call failed */
+#define VFT_ERR_STATE 3     /* call sequence error (e.g. sweep before leaves were uploaded) */
+#define VFT_NOCODE 127
+
+typedef struct vft_ctx vft_ctx;
+
+typedef struct {
+    int32_t device;        /* HIP device ordinal */
+    int32_t precision;     /* 4 = float, 8 = double: the reference's Precision template argument */
+    int32_t n_codes;       /* 4 (nt) or 20 (aa): Options::nCodes */
+    int32_t reserved;
+    int64_t n_seqs;        /* unique sequences */
+    int64_t n_pos;         /* alignment columns */
+    int64_t max_nodes;     /* 2*n_seqs in the reference (NJ.tcc:229-231) */
+} vft_config;
+
+/* One hit of a one-vs-all sweep, in sorted order (the reference's Besthit, NJ.h:192-204, with 32-bit ids). */
+typedef struct {
+    int32_t j;             /* target node, -1 = empty */
+    float dist;            /* numeric_t narrowed to float only for precision 4; see vft_sweep for precision 8 */
+    float weight;
+    float criterion;
+} vft_hit_f32;
+
+typedef struct {
+    int64_t j;
+    double dist, weight, criterion;
+} vft_hit_f64;
+
+/* ---- life cycle (replaces CudaOperations::configCuda, CudaOperations.cu:169-175) */
+int vft_create(vft_ctx **out, const vft_config *cfg);
+int vft_destroy(vft_ctx *ctx);
+const char *vft_last_error(const vft_ctx *ctx);
+/* hipStream_t to launch on (NULL = the context's own stream).  Lets a caller use torch's current stream. */
+int vft_set_stream(vft_ctx *ctx, void *hip_stream);
+int vft_synchronize(vft_ctx *ctx);
+
+/* ---- inputs */
+/* Leaf profiles from codes[n_seqs][n_pos] (what seqsToProfiles builds, NJ.tcc:382-457). */
+int vft_upload_leaves(vft_ctx *ctx, const uint8_t *codes);
+/* Distance matrix used by the NJ phase for amino acids (DistanceMatrix.h:15-33); arrays are nCodes x nCodes
+   row-major / nCodes long.  Not calling it means %-different distances (the -nt default, VeryFastTree.cpp:96-98). */
+int vft_set_distance_matrix(vft_ctx *ctx, const void *distances, const void *codefreq, const void *eigenval,
+                            const void *eigentot);
+/* Transition matrix tables for the ML phase (TransitionMatrix.h:65-76).  codefreq has nCodes+1 rows, the last
+   one being the NOCODE (gap) row.  Passing NULLs selects Jukes-Cantor (nt only). */
+int vft_set_transition_matrix(vft_ctx *ctx, const void *stat, const void *statinv, const void *eigenval,
+                              const void *codefreq, const void *eigeninv, const void *eigeninvT);
+/* Rate categories (NJ.h Rates: rates[n_rates], ratecat[n_pos]). */
+int vft_set_rates(vft_ctx *ctx, const void *rates, int32_t n_rates, const int64_t *ratecat);
+/* ML tolerances that the reference reads from Options inside the hot loops (Constants.h:26-39). */
+int vft_set_ml_limits(vft_ctx *ctx, double min_branch_length, double min_rel_branch_length,
+                      double fpost_total_tolerance);
+
+/* ---- per-node NJ state kept on the device (NJ.h:268-287).  `first..first+count` is a node-id range. */
+int vft_set_parents(vft_ctx *ctx, int64_t first, int64_t count, const int64_t *parent);
+int vft_set_node_scalars(vft_ctx *ctx, int64_t first, int64_t count, const void *diameter, const void *selfweight,
+                         const void *selfdist);
+int vft_get_node_scalars(vft_ctx *ctx, int64_t first, int64_t count, void *diameter, void *selfweight, void *selfdist);
+int vft_set_out_distances(vft_ctx *ctx, int64_t first, int64_t count, const void *out_dist,
+                          const int64_t *n_out_active);
+int vft_get_out_distances(vft_ctx *ctx, int64_t first, int64_t count, void *out_dist, int64_t *n_out_active);
+int vft_set_max_node(vft_ctx *ctx, int64_t maxnode);           /* NJ.h: maxnode, the next id to allocate */
+
+/* ---- profiles */
+int vft_profile_upload(vft_ctx *ctx, int64_t node, const void *w, const uint8_t *codes, const void *f);
+int vft_profile_download(vft_ctx *ctx, int64_t node, void *w, uint8_t *codes, void *f);
+/* averageProfile (NJ.tcc:2067-2135) for a batch of independent joins: out[k] = avg(a[k], b[k], weight[k]);
+   weight < 0 means unweighted (0.5).  Also stores the new node's self-distance/self-weight
+   (profileDist(new,new), NJ.tcc:3039-3042) on the device. */
+int vft_average_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                         const double *bionj_weight);
+
+/* ---- out-profile (NJ.tcc:729-815, 943-1010) */
+int vft_out_profile_full(vft_ctx *ctx, int64_t n_active, const int64_t *active_ids);
+int vft_out_profile_update(vft_ctx *ctx, int64_t old1, int64_t old2, int64_t newnode, int64_t n_active_old);
+int vft_out_profile_upload(vft_ctx *ctx, const void *w, const void *f, const void *codedist);
+int vft_out_profile_download(vft_ctx *ctx, void *w, void *f, void *codedist);
+/* setOutDistance (NJ.tcc:1012-1083) for a list of nodes (all active nodes when ids == NULL). */
+int vft_out_distances(vft_ctx *ctx, int64_t n, const int64_t *ids, int64_t n_active, double totdiam);
+
+/* ---- distances
+ * vft_sweep = setBestHit (NJ.tcc:3571-3646): node `query` against every node < maxnode, each pair through
+ * setDistCriterion (NJ.tcc:1115-1124: seqDist NJ.tcc:1601-1624 for leaf x leaf, profileDist NJ.tcc:1167-1190
+ * otherwise, minus diameters) and setCriterion (NJ.tcc:1085-1107, including the lazy refresh of out-distances
+ * staler than n_diff_allow), followed by the reference's sort (psort + CompareHitsByCriterion, Utils.h:126-146,
+ * NJ.tcc:7301-7306: ascending criterion, ties by descending node id) truncated to the first `k` hits.
+ * hits: k records of vft_hit_f32 / vft_hit_f64 (by context precision) in HOST memory, may be NULL.
+ * d_hits: same records in DEVICE memory, may be NULL (no synchronisation when hits == NULL).
+ * best_j: argmin excluding the query itself (the `bestjoin` out-parameter), may be NULL.
+ */
+int vft_sweep(vft_ctx *ctx, int64_t query, int64_t n_active, int64_t n_diff_allow, double totdiam, int32_t k,
+              void *hits, void *d_hits, int64_t *best_j);
+/* Restrict sweeps/out-distance passes to node ids [lo, hi): the shard a rank owns in a multi-GPU run
+   (default [0, max_nodes)).  Hits keep global ids. */
+int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);
+/* The full, unsorted result of the last sweep for ids [first, first+count): what `allhits[]` holds. */
+int vft_sweep_results(vft_ctx *ctx, int64_t first, int64_t count, void *dist, void *weight, void *criterion);
+/* setDistCriterion on an explicit pair list — transferBestHits / uniqueBestHits / getBestFromTopHits
+   (NJ.tcc:4580-4613, 4786-4833, 4267-4298).  Outputs are host arrays of the context precision. */
+int vft_pair_distances(vft_ctx *ctx, int64_t n, const int64_t *i, const int64_t *j, int64_t n_active,
+                       int64_t n_diff_allow, double totdiam, void *dist, void *weight, void *criterion);
+
+/* ---- likelihood (ML phase)
+ * pairLogLk (NJ.tcc:1192-1447) for n independent pairs; site_lk (n x n_pos doubles, host) may be NULL, when
+ * given it receives the per-site likelihoods lkAB (what the reference multiplies into site_likelihoods[]).
+ */
+int vft_pair_loglk(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, const double *length,
+                   double *loglk, double *site_lk);
+/* posteriorProfile (NJ.tcc:2137-2447) for n independent triples: out[k] = posterior(a[k], b[k], len1[k], len2[k]).
+   A whole tree level of recomputeMLProfiles (NJ.tcc:3516-3539) is one call. */
+int vft_posterior_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                           const double *len1, const double *len2);
+
+/* ---- measurement helpers used by bench.py (HIP events on the context's stream) */
+int vft_timer_start(vft_ctx *ctx);
+int vft_timer_stop_ms(vft_ctx *ctx, float *ms);
+/* name and average duration (ms) of the dominant kernel's launches since the last vft_timer_start */
+int vft_sweep_kernel_ms(vft_ctx *ctx, float *avg_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

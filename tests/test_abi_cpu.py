@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol include/vft_hip.h
+declares, and refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from veryfasttree_amd import build
+    build.build()
+    from veryfasttree_amd import backend
+    return backend.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vft_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vft_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_lists_every_symbol():
+    from veryfasttree_amd import backend
+    assert sorted(backend.EXPORTS) == declared_symbols()
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from veryfasttree_amd import HipProfileOps, VftError
+    with pytest.raises(VftError):
+        HipProfileOps(8, 16, 4, np.float32)
+
+
+def test_bad_config_is_rejected(lib):
+    from veryfasttree_amd import HipProfileOps, VftError
+    with pytest.raises(VftError):
+        HipProfileOps(8, 16, 5, np.float32)

@@ -1,0 +1,269 @@
+"""ctypes binding of the C ABI (include/vft_hip.h) — the only way Python reaches the HIP backend.
+
+There is no CPU fallback: if the shared library is missing or no HIP device is present, construction raises.
+Method names follow the reference members they replace (src/NeighbourJoining.tcc), so that the parity tests read
+like calls into the reference.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvft_hip.so")
+NOCODE = 127
+
+P = C.c_void_p
+I64 = C.c_int64
+I32 = C.c_int32
+
+EXPORTS = [
+    "vft_create", "vft_destroy", "vft_last_error", "vft_set_stream", "vft_synchronize", "vft_upload_leaves",
+    "vft_set_distance_matrix", "vft_set_transition_matrix", "vft_set_rates", "vft_set_ml_limits", "vft_set_parents",
+    "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_set_max_node",
+    "vft_profile_upload", "vft_profile_download", "vft_average_profiles", "vft_out_profile_full",
+    "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
+    "vft_set_shard", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
+    "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms",
+]
+
+
+class VftError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("device", I32), ("precision", I32), ("n_codes", I32), ("reserved", I32), ("n_seqs", I64),
+                ("n_pos", I64), ("max_nodes", I64)]
+
+
+HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32), ("criterion", np.float32)])
+HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
+
+_lib = None
+
+
+def load_library():
+    """Load libvft_hip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VftError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.vft_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(P)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class HipProfileOps:
+    """Device-resident profile arena + the batched profile operations of the hot path."""
+
+    def __init__(self, n_seqs, n_pos, n_codes=4, dtype=np.float32, max_nodes=None, device=0):
+        self.lib = load_library()
+        self.dt = np.dtype(dtype)
+        if self.dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise VftError("dtype must be float32 or float64")
+        self.n_seqs, self.n_pos, self.n_codes = int(n_seqs), int(n_pos), int(n_codes)
+        self.max_nodes = int(max_nodes if max_nodes is not None else 2 * n_seqs)
+        cfg = _Config(device, self.dt.itemsize, n_codes, 0, n_seqs, n_pos, self.max_nodes)
+        self.ctx = P()
+        rc = self.lib.vft_create(C.byref(self.ctx), C.byref(cfg))
+        if rc != 0:
+            msg = self.lib.vft_last_error(self.ctx).decode() if self.ctx else "vft_create failed"
+            if self.ctx:
+                self.lib.vft_destroy(self.ctx)
+                self.ctx = None
+            raise VftError(msg)
+        self.hit_dtype = HIT_F32 if self.dt == np.float32 else HIT_F64
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vft_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VftError(self.lib.vft_last_error(self.ctx).decode())
+
+    def real(self, a):
+        return np.ascontiguousarray(a, dtype=self.dt)
+
+    # ---- plumbing
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.vft_set_stream(self.ctx, P(stream_handle)))
+
+    def synchronize(self):
+        self._chk(self.lib.vft_synchronize(self.ctx))
+
+    def set_shard(self, lo, hi):
+        self._chk(self.lib.vft_set_shard(self.ctx, I64(lo), I64(hi)))
+
+    def set_max_node(self, maxnode):
+        self._chk(self.lib.vft_set_max_node(self.ctx, I64(maxnode)))
+
+    # ---- inputs
+    def upload_leaves(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert codes.shape == (self.n_seqs, self.n_pos)
+        self._chk(self.lib.vft_upload_leaves(self.ctx, _ptr(codes)))
+
+    def set_distance_matrix(self, distances, codefreq, eigenval, eigentot):
+        a = [self.real(x) for x in (distances, codefreq, eigenval, eigentot)]
+        self._chk(self.lib.vft_set_distance_matrix(self.ctx, *[_ptr(x) for x in a]))
+
+    def set_transition_matrix(self, stat=None, statinv=None, eigenval=None, codefreq=None, eigeninv=None,
+                              eigeninvT=None):
+        if stat is None:
+            self._chk(self.lib.vft_set_transition_matrix(self.ctx, None, None, None, None, None, None))
+            return
+        a = [self.real(x) for x in (stat, statinv, eigenval, codefreq, eigeninv, eigeninvT)]
+        self._chk(self.lib.vft_set_transition_matrix(self.ctx, *[_ptr(x) for x in a]))
+
+    def set_rates(self, rates, ratecat):
+        rates = self.real(rates)
+        ratecat = _i64(ratecat)
+        self._chk(self.lib.vft_set_rates(self.ctx, _ptr(rates), I32(len(rates)), _ptr(ratecat)))
+
+    def set_ml_limits(self, min_len, min_rel, fpost_tol):
+        self._chk(self.lib.vft_set_ml_limits(self.ctx, C.c_double(min_len), C.c_double(min_rel), C.c_double(fpost_tol)))
+
+    def set_parents(self, first, parent):
+        parent = _i64(parent)
+        self._chk(self.lib.vft_set_parents(self.ctx, I64(first), I64(len(parent)), _ptr(parent)))
+
+    def set_node_scalars(self, first, diameter=None, selfweight=None, selfdist=None):
+        arrs = [None if x is None else self.real(x) for x in (diameter, selfweight, selfdist)]
+        n = max(len(x) for x in arrs if x is not None)
+        self._chk(self.lib.vft_set_node_scalars(self.ctx, I64(first), I64(n), *[_ptr(x) for x in arrs]))
+
+    def get_node_scalars(self, first, count):
+        d, sw, sd = (np.zeros(count, self.dt) for _ in range(3))
+        self._chk(self.lib.vft_get_node_scalars(self.ctx, I64(first), I64(count), _ptr(d), _ptr(sw), _ptr(sd)))
+        return d, sw, sd
+
+    def set_out_distances(self, first, out_dist, n_out_active):
+        od = self.real(out_dist)
+        na = _i64(n_out_active)
+        self._chk(self.lib.vft_set_out_distances(self.ctx, I64(first), I64(len(od)), _ptr(od), _ptr(na)))
+
+    def get_out_distances(self, first, count):
+        od = np.zeros(count, self.dt)
+        na = np.zeros(count, np.int64)
+        self._chk(self.lib.vft_get_out_distances(self.ctx, I64(first), I64(count), _ptr(od), _ptr(na)))
+        return od, na
+
+    # ---- profiles
+    def profile_upload(self, node, prof):
+        w, c, f = self.real(prof[0]), np.ascontiguousarray(prof[1], np.uint8), self.real(prof[2])
+        self._chk(self.lib.vft_profile_upload(self.ctx, I64(node), _ptr(w), _ptr(c), _ptr(f)))
+
+    def profile_download(self, node):
+        w = np.zeros(self.n_pos, self.dt)
+        c = np.zeros(self.n_pos, np.uint8)
+        f = np.zeros((self.n_pos, self.n_codes), self.dt)
+        self._chk(self.lib.vft_profile_download(self.ctx, I64(node), _ptr(w), _ptr(c), _ptr(f)))
+        return w, c, f
+
+    def averageProfile(self, out, a, b, bionj_weight=None):
+        """NJ.tcc:2067 for a batch: out[k] = average(a[k], b[k])."""
+        out, a, b = _i64(out), _i64(a), _i64(b)
+        bw = None if bionj_weight is None else np.ascontiguousarray(bionj_weight, np.float64)
+        self._chk(self.lib.vft_average_profiles(self.ctx, I64(len(out)), _ptr(out), _ptr(a), _ptr(b), _ptr(bw)))
+
+    # ---- out-profile
+    def outProfile(self, active_ids):
+        """NJ.tcc:729: out-profile of the listed nodes, accumulated in list order."""
+        ids = _i64(active_ids)
+        self._chk(self.lib.vft_out_profile_full(self.ctx, I64(len(ids)), _ptr(ids)))
+
+    def updateOutProfile(self, old1, old2, new, n_active_old):
+        """NJ.tcc:943."""
+        self._chk(self.lib.vft_out_profile_update(self.ctx, I64(old1), I64(old2), I64(new), I64(n_active_old)))
+
+    def out_profile_upload(self, w, f, cd=None):
+        w, f = self.real(w), self.real(f)
+        cd = None if cd is None else self.real(cd)
+        self._chk(self.lib.vft_out_profile_upload(self.ctx, _ptr(w), _ptr(f), _ptr(cd)))
+
+    def out_profile_download(self, with_codedist=False):
+        w = np.zeros(self.n_pos, self.dt)
+        f = np.zeros((self.n_pos, self.n_codes), self.dt)
+        cd = np.zeros((self.n_pos, self.n_codes), self.dt) if with_codedist else None
+        self._chk(self.lib.vft_out_profile_download(self.ctx, _ptr(w), _ptr(f), _ptr(cd)))
+        return (w, np.full(self.n_pos, NOCODE, np.uint8), f), cd
+
+    def setOutDistance(self, ids, n_active, totdiam):
+        """NJ.tcc:1012 for a list of nodes (None: every active node)."""
+        ids = None if ids is None else _i64(ids)
+        n = 0 if ids is None else len(ids)
+        self._chk(self.lib.vft_out_distances(self.ctx, I64(n), _ptr(ids), I64(n_active), C.c_double(totdiam)))
+
+    # ---- distances
+    def setBestHit(self, query, n_active, n_diff_allow, totdiam, k, want_best=True, d_hits=None, want_hits=True):
+        """NJ.tcc:3571 + the reference's sort, truncated to k hits.  Returns (hits, best_j)."""
+        hits = np.zeros(k, self.hit_dtype) if want_hits else None
+        best = I64(-1)
+        self._chk(self.lib.vft_sweep(self.ctx, I64(query), I64(n_active), I64(n_diff_allow), C.c_double(totdiam),
+                                     I32(k), _ptr(hits), P(d_hits) if d_hits else None,
+                                     C.byref(best) if want_best else None))
+        return hits, best.value
+
+    def sweep_results(self, first, count):
+        d, w, c = (np.zeros(count, self.dt) for _ in range(3))
+        self._chk(self.lib.vft_sweep_results(self.ctx, I64(first), I64(count), _ptr(d), _ptr(w), _ptr(c)))
+        return d, w, c
+
+    def setDistCriterion(self, i, j, n_active, n_diff_allow, totdiam):
+        """NJ.tcc:1115 over a pair list.  Returns (dist, weight, criterion)."""
+        i, j = _i64(i), _i64(j)
+        n = len(i)
+        d, w, c = (np.zeros(n, self.dt) for _ in range(3))
+        self._chk(self.lib.vft_pair_distances(self.ctx, I64(n), _ptr(i), _ptr(j), I64(n_active), I64(n_diff_allow),
+                                              C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
+        return d, w, c
+
+    # ---- likelihood
+    def pairLogLk(self, a, b, length, site_lk=False):
+        """NJ.tcc:1192 for a batch of pairs.  Returns loglk[n] (and site likelihoods [n, n_pos])."""
+        a, b = _i64(a), _i64(b)
+        length = np.ascontiguousarray(length, np.float64)
+        out = np.zeros(len(a), np.float64)
+        site = np.zeros((len(a), self.n_pos), np.float64) if site_lk else None
+        self._chk(self.lib.vft_pair_loglk(self.ctx, I64(len(a)), _ptr(a), _ptr(b), _ptr(length), _ptr(out), _ptr(site)))
+        return (out, site) if site_lk else out
+
+    def posteriorProfile(self, out, a, b, len1, len2):
+        """NJ.tcc:2137 for a batch of triples."""
+        out, a, b = _i64(out), _i64(a), _i64(b)
+        l1 = np.ascontiguousarray(len1, np.float64)
+        l2 = np.ascontiguousarray(len2, np.float64)
+        self._chk(self.lib.vft_posterior_profiles(self.ctx, I64(len(out)), _ptr(out), _ptr(a), _ptr(b), _ptr(l1),
+                                                  _ptr(l2)))
+
+    # ---- measurement
+    def timer_start(self):
+        self._chk(self.lib.vft_timer_start(self.ctx))
+
+    def timer_stop_ms(self):
+        ms = C.c_float(0)
+        self._chk(self.lib.vft_timer_stop_ms(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def sweep_kernel_ms(self):
+        ms, n = C.c_float(0), I64(0)
+        self._chk(self.lib.vft_sweep_kernel_ms(self.ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

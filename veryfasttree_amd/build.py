@@ -1,0 +1,34 @@
+"""Builds the HIP extension in-tree (veryfasttree_amd/lib/libvft_hip.so) with hipcc for gfx950.
+
+-ffp-contract=off is part of the numerics contract: distance sums must not be fused.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libvft_hip.so")
+SOURCES = [os.path.join(CSRC, "vft_api.hip")]
+HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_profile.h", "vft_kernels_ml.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = SOURCES + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "vft_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc] + FLAGS + ["-o", LIB] + SOURCES, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,930 @@
+// C-ABI implementation (include/vft_hip.h): context, arena allocation, launches.
+// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/vft_hip.h"
+#include "vft_kernels_ml.h"
+#include "vft_kernels_nj.h"
+#include "vft_kernels_profile.h"
+
+struct vft_ctx {
+    vft_config cfg;
+    VftDims d;
+    hipStream_t stream = nullptr, ownStream = nullptr;
+    char err[512] = {0};
+    size_t rs = 4;   // sizeof(real)
+    int64_t maxnode = 0, shardLo = 0, shardHi = 0;
+    int64_t nProfTiles = 0, nLeafTiles = 0;
+    bool leavesUp = false;
+
+    // arena
+    uint4 *leafT = nullptr, *profC = nullptr;
+    void *profW = nullptr, *profF = nullptr;
+    int32_t *parent = nullptr, *nOutActive = nullptr;
+    void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
+    void *outW = nullptr, *outF = nullptr, *outCD = nullptr;
+    // query staging (node query and out-profile-as-query)
+    void *qW[2] = {nullptr, nullptr}, *qF[2] = {nullptr, nullptr};
+    uint8_t *qC[2] = {nullptr, nullptr};
+    uint4 *qEnc[2] = {nullptr, nullptr};
+    // sweep outputs
+    void *swDist = nullptr, *swWeight = nullptr, *swCrit = nullptr;
+    uint64_t *swKey = nullptr;
+    unsigned long long *partMin = nullptr, *partMax = nullptr;
+    int nPart = 0;
+    // select scratch
+    SelectState *sel = nullptr;
+    unsigned int *slices = nullptr;
+    uint64_t *candKey = nullptr;
+    int32_t *candId = nullptr;
+    void *dHits = nullptr;
+    int64_t *dBest = nullptr;
+    int32_t hitsCap = 0;
+    // models
+    void *dm[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool hasDm = false;
+    void *tm[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool hasTm = false;
+    void *rates = nullptr;
+    int32_t *ratecat = nullptr;
+    int32_t nRates = 0;
+    double minLen = 5e-4, minRel = 2.5e-4, fpostTol = 1e-10;
+    // generic device scratch (index lists, staging)
+    void *scratch = nullptr;
+    size_t scratchBytes = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;
+    size_t kevUsed = 0;
+    bool timeKernels = false;
+};
+
+static int fail(vft_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return fail(c, VFT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+#define LAUNCHCHK(c)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                                   \
+        if (e_ != hipSuccess) return fail(c, VFT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n) {
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **) p, n * sizeof(T));
+    return e;
+}
+static hipError_t dallocb(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 1); }
+
+static int ensure_scratch(vft_ctx *c, size_t bytes) {
+    if (bytes <= c->scratchBytes) return VFT_OK;
+    if (c->scratch) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratchBytes = 0;
+    }
+    size_t want = bytes + bytes / 2 + 4096;
+    HIPCHK(c, hipMalloc(&c->scratch, want));
+    c->scratchBytes = want;
+    return VFT_OK;
+}
+
+template <typename REAL>
+static Arena<REAL> arena(const vft_ctx *c) {
+    Arena<REAL> A;
+    A.d = c->d;
+    A.leafT = c->leafT;
+    A.profW = (REAL *) c->profW;
+    A.profF = (REAL *) c->profF;
+    A.profC = c->profC;
+    A.parent = c->parent;
+    A.diameter = (REAL *) c->diameter;
+    A.selfweight = (REAL *) c->selfweight;
+    A.selfdist = (REAL *) c->selfdist;
+    A.outDist = (REAL *) c->outDist;
+    A.nOutActive = c->nOutActive;
+    A.outW = (REAL *) c->outW;
+    A.outF = (REAL *) c->outF;
+    A.outCD = c->hasDm ? (REAL *) c->outCD : nullptr;
+    A.dmDist = c->hasDm ? (const REAL *) c->dm[0] : nullptr;
+    A.dmCodeFreq = c->hasDm ? (const REAL *) c->dm[1] : nullptr;
+    A.dmEigenval = c->hasDm ? (const REAL *) c->dm[2] : nullptr;
+    A.dmEigentot = c->hasDm ? (const REAL *) c->dm[3] : nullptr;
+    A.tmStat = c->hasTm ? (const REAL *) c->tm[0] : nullptr;
+    A.tmStatInv = c->hasTm ? (const REAL *) c->tm[1] : nullptr;
+    A.tmEigenval = c->hasTm ? (const REAL *) c->tm[2] : nullptr;
+    A.tmCodeFreq = c->hasTm ? (const REAL *) c->tm[3] : nullptr;
+    A.tmEigenInv = c->hasTm ? (const REAL *) c->tm[4] : nullptr;
+    A.tmEigenInvT = c->hasTm ? (const REAL *) c->tm[5] : nullptr;
+    A.rates = (const REAL *) c->rates;
+    A.ratecat = c->ratecat;
+    A.nRates = c->nRates;
+    return A;
+}
+
+template <typename REAL>
+static QueryBuf<REAL> qbuf(const vft_ctx *c, int which) {
+    QueryBuf<REAL> q;
+    q.w = (REAL *) c->qW[which];
+    q.code = c->qC[which];
+    q.f = (REAL *) c->qF[which];
+    q.enc = c->qEnc[which];
+    return q;
+}
+
+template <typename REAL>
+static SweepOut<REAL> sweepout(const vft_ctx *c) {
+    SweepOut<REAL> o;
+    o.dist = (REAL *) c->swDist;
+    o.weight = (REAL *) c->swWeight;
+    o.crit = (REAL *) c->swCrit;
+    o.key = c->swKey;
+    o.partMin = c->partMin;
+    o.partMax = c->partMax;
+    return o;
+}
+
+// precision x alphabet dispatch: BODY sees REAL and NC
+#define VFT_DISPATCH(c, ...)                                                           \
+    do {                                                                               \
+        if ((c)->cfg.precision == 4) {                                                 \
+            typedef float REAL;                                                        \
+            if ((c)->cfg.n_codes == 4) { constexpr int NC = 4; __VA_ARGS__; }          \
+            else { constexpr int NC = 20; __VA_ARGS__; }                               \
+        } else {                                                                       \
+            typedef double REAL;                                                       \
+            if ((c)->cfg.n_codes == 4) { constexpr int NC = 4; __VA_ARGS__; }          \
+            else { constexpr int NC = 20; __VA_ARGS__; }                               \
+        }                                                                              \
+    } while (0)
+
+// statement-safe launch wrapper (hipLaunchKernelGGL is a do/while macro)
+template <typename... KArgs, typename... Args>
+static inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args... args) {
+    hipLaunchKernelGGL(k, g, b, shm, s, static_cast<KArgs>(args)...);
+}
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned) ((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------- life cycle
+extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
+    if (!out || !cfg) return VFT_ERR_INVALID;
+    *out = nullptr;
+    vft_ctx *c = new (std::nothrow) vft_ctx();
+    if (!c) return VFT_ERR_INVALID;
+    c->cfg = *cfg;
+    auto bail = [&](int code) {
+        // keep the context alive so the caller can read the error text
+        *out = c;
+        return code;
+    };
+    if ((cfg->precision != 4 && cfg->precision != 8) || (cfg->n_codes != 4 && cfg->n_codes != 20) || cfg->n_seqs < 1 ||
+        cfg->n_pos < 1 || cfg->max_nodes < cfg->n_seqs || cfg->max_nodes >= (1ll << 31))
+        return bail(fail(c, VFT_ERR_INVALID, "vft_create: bad configuration"));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return bail(fail(c, VFT_ERR_HIP, "vft_create: no HIP device (this backend has no CPU fallback)"));
+    if (cfg->device < 0 || cfg->device >= ndev) return bail(fail(c, VFT_ERR_INVALID, "vft_create: bad device ordinal"));
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(c, VFT_ERR_HIP, "hipSetDevice failed"));
+    c->rs = (size_t) cfg->precision;
+    VftDims &d = c->d;
+    d.nSeqs = cfg->n_seqs;
+    d.nPos = cfg->n_pos;
+    d.maxNodes = cfg->max_nodes;
+    d.nCodes = cfg->n_codes;
+    d.nChunk = (int32_t) ((cfg->n_pos + VFT_CHUNK - 1) / VFT_CHUNK);
+    d.firstProfTile = cfg->n_seqs / VFT_TILE;
+    d.nTiles = (cfg->max_nodes + VFT_TILE - 1) / VFT_TILE;
+    c->nLeafTiles = (cfg->n_seqs + VFT_TILE - 1) / VFT_TILE;
+    c->nProfTiles = d.nTiles - d.firstProfTile;
+    c->maxnode = cfg->n_seqs;
+    c->shardLo = 0;
+    c->shardHi = cfg->max_nodes;
+    const size_t rs = c->rs;
+    const int64_t N = d.nTiles * VFT_TILE;   // padded node count
+    const int64_t nPosPad = (int64_t) d.nChunk * VFT_CHUNK;
+#define CR(call)                                                                            \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return bail(fail(c, VFT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); \
+    } while (0)
+    CR(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
+    c->stream = c->ownStream;
+    CR(dalloc(&c->leafT, (size_t) c->nLeafTiles * d.nChunk * VFT_TILE));
+    CR(dallocb(&c->profW, (size_t) c->nProfTiles * d.nPos * VFT_TILE * rs));
+    CR(dallocb(&c->profF, (size_t) c->nProfTiles * d.nPos * VFT_TILE * d.nCodes * rs));
+    CR(dalloc(&c->profC, (size_t) c->nProfTiles * d.nChunk * VFT_TILE));
+    CR(hipMemset(c->profW, 0, (size_t) c->nProfTiles * d.nPos * VFT_TILE * rs));
+    CR(hipMemset(c->profC, 0x7F, (size_t) c->nProfTiles * d.nChunk * VFT_TILE * sizeof(uint4)));
+    CR(dalloc(&c->parent, (size_t) N));
+    CR(dalloc(&c->nOutActive, (size_t) N));
+    // padding ids beyond max_nodes are permanently inactive
+    {
+        std::vector<int32_t> par((size_t) N, 0);
+        for (int64_t i = 0; i < cfg->max_nodes; i++) par[(size_t) i] = -1;
+        CR(hipMemcpy(c->parent, par.data(), (size_t) N * 4, hipMemcpyHostToDevice));
+    }
+    CR(hipMemset(c->nOutActive, 0, (size_t) N * 4));
+    void **reals[] = {&c->diameter, &c->selfweight, &c->selfdist, &c->outDist, &c->swDist, &c->swWeight, &c->swCrit};
+    for (void **p : reals) {
+        CR(dallocb(p, (size_t) N * rs));
+        CR(hipMemset(*p, 0, (size_t) N * rs));
+    }
+    CR(dalloc(&c->swKey, (size_t) N));
+    CR(dallocb(&c->outW, (size_t) d.nPos * rs));
+    CR(dallocb(&c->outF, (size_t) d.nPos * d.nCodes * rs));
+    CR(dallocb(&c->outCD, (size_t) d.nPos * d.nCodes * rs));
+    for (int q = 0; q < 2; q++) {
+        CR(dallocb(&c->qW[q], (size_t) nPosPad * rs));
+        CR(dallocb(&c->qF[q], (size_t) nPosPad * d.nCodes * rs));
+        CR(dalloc(&c->qC[q], (size_t) nPosPad));
+        CR(dalloc(&c->qEnc[q], (size_t) d.nChunk));
+    }
+    c->nPart = (int) cdiv(N, VFT_WG);
+    CR(dalloc(&c->partMin, (size_t) c->nPart));
+    CR(dalloc(&c->partMax, (size_t) c->nPart));
+    CR(dalloc(&c->sel, 1));
+    CR(dalloc(&c->slices, (size_t) VFT_SEL_WGS * VFT_NBINS));
+    CR(dalloc(&c->candKey, (size_t) VFT_CAND_CAP));
+    CR(dalloc(&c->candId, (size_t) VFT_CAND_CAP));
+    CR(dalloc(&c->dBest, 1));
+    c->hitsCap = VFT_CAND_CAP;
+    CR(dallocb(&c->dHits, (size_t) c->hitsCap * sizeof(vft_hit_f64)));
+    for (int i = 0; i < 4; i++) CR(dallocb(&c->dm[i], (size_t) 21 * 20 * 8));
+    for (int i = 0; i < 6; i++) CR(dallocb(&c->tm[i], (size_t) 21 * 20 * 8));
+    CR(dallocb(&c->rates, (size_t) VFT_MAXRATES * 8));
+    CR(dalloc(&c->ratecat, (size_t) d.nPos));
+    {
+        // one rate category with rate 1.0 (Rates(1, nPos) in the NJ constructor, NJ.tcc:226)
+        double one64 = 1.0;
+        float one32 = 1.0f;
+        CR(hipMemcpy(c->rates, rs == 4 ? (void *) &one32 : (void *) &one64, rs, hipMemcpyHostToDevice));
+        CR(hipMemset(c->ratecat, 0, (size_t) d.nPos * 4));
+        c->nRates = 1;
+    }
+    if (cfg->precision == 8) {
+        c->minLen = 5e-9;
+        c->minRel = 2.5e-9;
+        c->fpostTol = 1e-20;
+    }
+    CR(hipEventCreate(&c->ev0));
+    CR(hipEventCreate(&c->ev1));
+    // the final sort of the select pipeline needs more than the default 64 KiB of LDS
+    {
+        const int ldsBytes = VFT_CAND_CAP * 12;
+        CR(hipFuncSetAttribute((const void *) k_select_finish<float, vft_hit_f32>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+        CR(hipFuncSetAttribute((const void *) k_select_finish<double, vft_hit_f64>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+    }
+#undef CR
+    *out = c;
+    return VFT_OK;
+}
+
+extern "C" int vft_destroy(vft_ctx *c) {
+    if (!c) return VFT_OK;
+    if (c->ownStream) hipStreamSynchronize(c->ownStream);
+    void *ptrs[] = {c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
+                    c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
+                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit, c->swKey,
+                    c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dHits, c->dBest, c->dm[0],
+                    c->dm[1], c->dm[2], c->dm[3], c->tm[0], c->tm[1], c->tm[2], c->tm[3], c->tm[4], c->tm[5],
+                    c->rates, c->ratecat, c->scratch};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    for (hipEvent_t e : c->kev) hipEventDestroy(e);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+    return VFT_OK;
+}
+
+extern "C" const char *vft_last_error(const vft_ctx *c) { return c ? c->err : "null context"; }
+
+extern "C" int vft_set_stream(vft_ctx *c, void *s) {
+    if (!c) return VFT_ERR_INVALID;
+    c->stream = s ? (hipStream_t) s : c->ownStream;
+    return VFT_OK;
+}
+
+extern "C" int vft_synchronize(vft_ctx *c) {
+    if (!c) return VFT_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- inputs
+extern "C" int vft_upload_leaves(vft_ctx *c, const uint8_t *codes) {
+    if (!c || !codes) return VFT_ERR_INVALID;
+    const VftDims &d = c->d;
+    const size_t n = (size_t) c->nLeafTiles * d.nChunk * VFT_TILE * 16;
+    std::vector<uint8_t> host(n, d.nCodes == 4 ? 0 : VFT_NOCODE_);
+    for (int64_t i = 0; i < d.nSeqs; i++) {
+        const int64_t tile = i >> 6;
+        const int lane = (int) (i & 63);
+        const uint8_t *row = codes + (size_t) i * d.nPos;
+        for (int64_t p = 0; p < d.nPos; p++) {
+            const uint8_t code = row[p];
+            if (code != VFT_NOCODE && code >= d.nCodes)
+                return fail(c, VFT_ERR_INVALID, "vft_upload_leaves: code %d at seq %lld pos %lld", (int) code,
+                            (long long) i, (long long) p);
+            host[(size_t) vft_leaf_idx(d, tile, (int) (p >> 4), lane) * 16 + (p & 15)] = vft_encode(code, d.nCodes);
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->leafT, host.data(), n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->leavesUp = true;
+    return VFT_OK;
+}
+
+static int upload_tables(vft_ctx *c, void **dst, const void *const *src, const size_t *counts, int n) {
+    for (int i = 0; i < n; i++) {
+        if (!src[i]) return fail(c, VFT_ERR_INVALID, "model table %d is NULL", i);
+        HIPCHK(c, hipMemcpyAsync(dst[i], src[i], counts[i] * c->rs, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_set_distance_matrix(vft_ctx *c, const void *distances, const void *codefreq, const void *eigenval,
+                                       const void *eigentot) {
+    if (!c) return VFT_ERR_INVALID;
+    if (!distances) {
+        c->hasDm = false;
+        return VFT_OK;
+    }
+    const size_t nc = (size_t) c->d.nCodes;
+    const void *src[4] = {distances, codefreq, eigenval, eigentot};
+    const size_t cnt[4] = {nc * nc, nc * nc, nc, nc};
+    int r = upload_tables(c, c->dm, src, cnt, 4);
+    if (r) return r;
+    c->hasDm = true;
+    return VFT_OK;
+}
+
+extern "C" int vft_set_transition_matrix(vft_ctx *c, const void *stat, const void *statinv, const void *eigenval,
+                                         const void *codefreq, const void *eigeninv, const void *eigeninvT) {
+    if (!c) return VFT_ERR_INVALID;
+    if (!stat) {
+        if (c->d.nCodes != 4) return fail(c, VFT_ERR_INVALID, "Jukes-Cantor needs a nucleotide alphabet");
+        c->hasTm = false;
+        return VFT_OK;
+    }
+    const size_t nc = (size_t) c->d.nCodes;
+    const void *src[6] = {stat, statinv, eigenval, codefreq, eigeninv, eigeninvT};
+    const size_t cnt[6] = {nc, nc, nc, (nc + 1) * nc, nc * nc, nc * nc};
+    int r = upload_tables(c, c->tm, src, cnt, 6);
+    if (r) return r;
+    c->hasTm = true;
+    return VFT_OK;
+}
+
+extern "C" int vft_set_rates(vft_ctx *c, const void *rates, int32_t nRates, const int64_t *ratecat) {
+    if (!c || !rates || !ratecat || nRates < 1 || nRates > VFT_MAXRATES)
+        return fail(c, VFT_ERR_INVALID, "vft_set_rates: bad arguments");
+    std::vector<int32_t> rc((size_t) c->d.nPos);
+    for (int64_t p = 0; p < c->d.nPos; p++) {
+        if (ratecat[p] < 0 || ratecat[p] >= nRates) return fail(c, VFT_ERR_INVALID, "vft_set_rates: category out of range");
+        rc[(size_t) p] = (int32_t) ratecat[p];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->rates, rates, (size_t) nRates * c->rs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ratecat, rc.data(), rc.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nRates = nRates;
+    return VFT_OK;
+}
+
+extern "C" int vft_set_ml_limits(vft_ctx *c, double minLen, double minRel, double fpostTol) {
+    if (!c) return VFT_ERR_INVALID;
+    c->minLen = minLen;
+    c->minRel = minRel;
+    c->fpostTol = fpostTol;
+    return VFT_OK;
+}
+
+static int range_ok(vft_ctx *c, int64_t first, int64_t count) {
+    if (first < 0 || count < 0 || first + count > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "node range out of bounds");
+    return VFT_OK;
+}
+
+extern "C" int vft_set_parents(vft_ctx *c, int64_t first, int64_t count, const int64_t *parent) {
+    if (!c || !parent) return VFT_ERR_INVALID;
+    if (int r = range_ok(c, first, count)) return r;
+    std::vector<int32_t> p((size_t) count);
+    for (int64_t i = 0; i < count; i++) p[(size_t) i] = parent[i] < 0 ? -1 : (int32_t) parent[i];
+    HIPCHK(c, hipMemcpyAsync(c->parent + first, p.data(), (size_t) count * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_set_node_scalars(vft_ctx *c, int64_t first, int64_t count, const void *diameter,
+                                    const void *selfweight, const void *selfdist) {
+    if (!c) return VFT_ERR_INVALID;
+    if (int r = range_ok(c, first, count)) return r;
+    const size_t rs = c->rs;
+    if (diameter) HIPCHK(c, hipMemcpyAsync((char *) c->diameter + first * rs, diameter, count * rs, hipMemcpyHostToDevice, c->stream));
+    if (selfweight) HIPCHK(c, hipMemcpyAsync((char *) c->selfweight + first * rs, selfweight, count * rs, hipMemcpyHostToDevice, c->stream));
+    if (selfdist) HIPCHK(c, hipMemcpyAsync((char *) c->selfdist + first * rs, selfdist, count * rs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_get_node_scalars(vft_ctx *c, int64_t first, int64_t count, void *diameter, void *selfweight,
+                                    void *selfdist) {
+    if (!c) return VFT_ERR_INVALID;
+    if (int r = range_ok(c, first, count)) return r;
+    const size_t rs = c->rs;
+    if (diameter) HIPCHK(c, hipMemcpyAsync(diameter, (char *) c->diameter + first * rs, count * rs, hipMemcpyDeviceToHost, c->stream));
+    if (selfweight) HIPCHK(c, hipMemcpyAsync(selfweight, (char *) c->selfweight + first * rs, count * rs, hipMemcpyDeviceToHost, c->stream));
+    if (selfdist) HIPCHK(c, hipMemcpyAsync(selfdist, (char *) c->selfdist + first * rs, count * rs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+static int32_t clamp_i32(int64_t v) { return v > 0x7FFFFFFF ? 0x7FFFFFFF : (v < 0 ? 0 : (int32_t) v); }
+
+extern "C" int vft_set_out_distances(vft_ctx *c, int64_t first, int64_t count, const void *outDist,
+                                     const int64_t *nOutActive) {
+    if (!c) return VFT_ERR_INVALID;
+    if (int r = range_ok(c, first, count)) return r;
+    if (outDist) HIPCHK(c, hipMemcpyAsync((char *) c->outDist + first * c->rs, outDist, count * c->rs, hipMemcpyHostToDevice, c->stream));
+    std::vector<int32_t> n32;
+    if (nOutActive) {
+        n32.resize((size_t) count);
+        for (int64_t i = 0; i < count; i++) n32[(size_t) i] = clamp_i32(nOutActive[i]);
+        HIPCHK(c, hipMemcpyAsync(c->nOutActive + first, n32.data(), (size_t) count * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_get_out_distances(vft_ctx *c, int64_t first, int64_t count, void *outDist, int64_t *nOutActive) {
+    if (!c) return VFT_ERR_INVALID;
+    if (int r = range_ok(c, first, count)) return r;
+    if (outDist) HIPCHK(c, hipMemcpyAsync(outDist, (char *) c->outDist + first * c->rs, count * c->rs, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> n32((size_t) count);
+    if (nOutActive) HIPCHK(c, hipMemcpyAsync(n32.data(), c->nOutActive + first, (size_t) count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nOutActive)
+        for (int64_t i = 0; i < count; i++) nOutActive[i] = n32[(size_t) i];
+    return VFT_OK;
+}
+
+extern "C" int vft_set_max_node(vft_ctx *c, int64_t maxnode) {
+    if (!c || maxnode < c->d.nSeqs || maxnode > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_set_max_node: out of range");
+    c->maxnode = maxnode;
+    return VFT_OK;
+}
+
+extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
+    if (!c || lo < 0 || hi < lo || hi > c->d.maxNodes || (lo % VFT_TILE) != 0)
+        return fail(c, VFT_ERR_INVALID, "vft_set_shard: need 0 <= lo <= hi <= max_nodes and lo %% 64 == 0");
+    c->shardLo = lo;
+    c->shardHi = hi;
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- profiles
+static int internal_ok(vft_ctx *c, int64_t node) {
+    if (node < c->d.nSeqs || node >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "node %lld is not an internal node", (long long) node);
+    return VFT_OK;
+}
+
+extern "C" int vft_profile_upload(vft_ctx *c, int64_t node, const void *w, const uint8_t *codes, const void *f) {
+    if (!c || !w || !codes || !f) return VFT_ERR_INVALID;
+    if (int r = internal_ok(c, node)) return r;
+    const VftDims &d = c->d;
+    const size_t rs = c->rs, wB = d.nPos * rs, fB = d.nPos * d.nCodes * rs, cB = (size_t) d.nPos;
+    if (int r = ensure_scratch(c, wB + fB + cB + 64)) return r;
+    char *s = (char *) c->scratch;
+    HIPCHK(c, hipMemcpyAsync(s, w, wB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + wB, f, fB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + wB + fB, codes, cB, hipMemcpyHostToDevice, c->stream));
+    VFT_DISPATCH(c, (launch((k_profile_scatter<REAL, NC>), dim3(cdiv(d.nPos, 256)), dim3(256), 0, c->stream,
+                                        arena<REAL>(c), node, (const REAL *) s, (const uint8_t *) (s + wB + fB),
+                                        (const REAL *) (s + wB))));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_profile_download(vft_ctx *c, int64_t node, void *w, uint8_t *codes, void *f) {
+    if (!c || !w || !codes || !f) return VFT_ERR_INVALID;
+    if (node < 0 || node >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad node");
+    const VftDims &d = c->d;
+    const size_t rs = c->rs, wB = d.nPos * rs, fB = d.nPos * d.nCodes * rs, cB = (size_t) d.nPos;
+    if (int r = ensure_scratch(c, wB + fB + cB + 64)) return r;
+    char *s = (char *) c->scratch;
+    VFT_DISPATCH(c, (launch((k_profile_gather<REAL, NC>), dim3(cdiv(d.nPos, 256)), dim3(256), 0, c->stream,
+                                        arena<REAL>(c), node, (REAL *) s, (uint8_t *) (s + wB + fB), (REAL *) (s + wB))));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(w, s, wB, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(f, s + wB, fB, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(codes, s + wB + fB, cB, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+template <typename REAL, int NC>
+__global__ void k_selfdist(Arena<REAL> A, const int64_t *nodes, int64_t n) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    REAL d, w;
+    vft_pair_generic<REAL, NC>(A, nodes[t], nodes[t], false, d, w);
+    A.selfdist[nodes[t]] = d;
+    A.selfweight[nodes[t]] = w;
+}
+
+extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                                    const double *bionj) {
+    if (!c || n < 0 || !out || !a || !b) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    for (int64_t k = 0; k < n; k++) {
+        if (int r = internal_ok(c, out[k])) return r;
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad child id");
+    }
+    const size_t idB = (size_t) n * 8;
+    if (int r = ensure_scratch(c, 4 * idB)) return r;
+    char *s = (char *) c->scratch;
+    HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
+    if (bionj) HIPCHK(c, hipMemcpyAsync(s + 3 * idB, bionj, idB, hipMemcpyHostToDevice, c->stream));
+    const int64_t maxY = 65535;
+    for (int64_t k0 = 0; k0 < n; k0 += maxY) {
+        const int64_t cnt = n - k0 < maxY ? n - k0 : maxY;
+        VFT_DISPATCH(c, (launch((k_average<REAL, NC>), dim3(cdiv(c->d.nPos, 128), (unsigned) cnt), dim3(128), 0,
+                                            c->stream, arena<REAL>(c), (const int64_t *) s + k0,
+                                            (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
+                                            bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr,
+                                            c->fpostTol)));
+        LAUNCHCHK(c);
+    }
+    VFT_DISPATCH(c, (launch((k_selfdist<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream, arena<REAL>(c),
+                                        (const int64_t *) s, n)));
+    LAUNCHCHK(c);
+    // the id lists live in scratch: do not let a later call overwrite them before the kernels have read them
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- out-profile
+extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
+    if (!c || n < 1 || !ids) return VFT_ERR_INVALID;
+    if (int r = ensure_scratch(c, (size_t) n * 8)) return r;
+    HIPCHK(c, hipMemcpyAsync(c->scratch, ids, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+    VFT_DISPATCH(c, (launch((k_outprofile_full<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,
+                                        arena<REAL>(c), (const int64_t *) c->scratch, n, c->fpostTol)));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_out_profile_update(vft_ctx *c, int64_t old1, int64_t old2, int64_t newn, int64_t nActiveOld) {
+    if (!c || nActiveOld < 2) return VFT_ERR_INVALID;
+    VFT_DISPATCH(c, (launch((k_outprofile_update<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,
+                                        arena<REAL>(c), old1, old2, newn, nActiveOld, c->fpostTol)));
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+extern "C" int vft_out_profile_upload(vft_ctx *c, const void *w, const void *f, const void *cd) {
+    if (!c || !w || !f) return VFT_ERR_INVALID;
+    const size_t rs = c->rs;
+    HIPCHK(c, hipMemcpyAsync(c->outW, w, c->d.nPos * rs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->outF, f, c->d.nPos * c->d.nCodes * rs, hipMemcpyHostToDevice, c->stream));
+    if (cd) HIPCHK(c, hipMemcpyAsync(c->outCD, cd, c->d.nPos * c->d.nCodes * rs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_out_profile_download(vft_ctx *c, void *w, void *f, void *cd) {
+    if (!c) return VFT_ERR_INVALID;
+    const size_t rs = c->rs;
+    if (w) HIPCHK(c, hipMemcpyAsync(w, c->outW, c->d.nPos * rs, hipMemcpyDeviceToHost, c->stream));
+    if (f) HIPCHK(c, hipMemcpyAsync(f, c->outF, c->d.nPos * c->d.nCodes * rs, hipMemcpyDeviceToHost, c->stream));
+    if (cd) HIPCHK(c, hipMemcpyAsync(cd, c->outCD, c->d.nPos * c->d.nCodes * rs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// launches the out-distance refresh over [lo,hi) (ids == nullptr) or over a device id list
+static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int64_t nActive, int64_t nDiffAllow,
+                                double totdiam, bool force) {
+    SweepArgs s{};
+    s.query = -1;
+    s.lo = c->shardLo;
+    s.hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
+    s.nActive = nActive;
+    s.nDiffAllow = nDiffAllow;
+    s.totdiam = totdiam;
+    s.queryIsLeaf = 0;
+    s.force = force ? 1 : 0;
+    if (dIds) {
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream,
+                                            arena<REAL>(c), dIds, n, s)));
+        LAUNCHCHK(c);
+        return VFT_OK;
+    }
+    if (s.hi <= s.lo) return VFT_OK;
+    const int64_t span = s.hi - s.lo;
+    if (c->cfg.n_codes == 4 && !c->hasDm) {
+        const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+        if (c->cfg.precision == 4) {
+            launch((k_outprofile_as_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
+                               arena<float>(c), qbuf<float>(c, 1));
+            launch((k_sweep_nt<float, MODE_OUTDIST>), dim3(cdiv(span, VFT_WG)), dim3(VFT_WG), 0, c->stream,
+                               arena<float>(c), qbuf<float>(c, 1), s, sweepout<float>(c));
+        } else {
+            launch((k_outprofile_as_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
+                               arena<double>(c), qbuf<double>(c, 1));
+            launch((k_sweep_nt<double, MODE_OUTDIST>), dim3(cdiv(span, VFT_WG)), dim3(VFT_WG), 0, c->stream,
+                               arena<double>(c), qbuf<double>(c, 1), s, sweepout<double>(c));
+        }
+    } else {
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, 64)), dim3(64), 0, c->stream,
+                                            arena<REAL>(c), (const int64_t *) nullptr, span, s)));
+    }
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+extern "C" int vft_out_distances(vft_ctx *c, int64_t n, const int64_t *ids, int64_t nActive, double totdiam) {
+    if (!c || nActive < 2) return VFT_ERR_INVALID;
+    if (ids) {
+        if (n <= 0) return VFT_OK;
+        if (int r = ensure_scratch(c, (size_t) n * 8)) return r;
+        HIPCHK(c, hipMemcpyAsync(c->scratch, ids, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        if (int r = launch_out_distances(c, (const int64_t *) c->scratch, n, nActive, 0, totdiam, true)) return r;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return VFT_OK;
+    }
+    return launch_out_distances(c, nullptr, 0, nActive, 0, totdiam, true);
+}
+
+// ---------------------------------------------------------------------------------------------- sweep
+static void kernel_event(vft_ctx *c) {
+    if (!c->timeKernels) return;
+    if (c->kevUsed == c->kev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->kev.push_back(e);
+    }
+    hipEventRecord(c->kev[c->kevUsed++], c->stream);
+}
+
+template <typename REAL, typename HIT>
+static int run_select(vft_ctx *c, int64_t lo, int64_t hi, int32_t k, int64_t query, bool wantBest) {
+    launch(k_select_range, dim3(1), dim3(1024), 0, c->stream, c->sel, c->partMin, c->partMax, c->nPart);
+    for (int round = 0; round < 8; round++) {
+        launch(k_select_hist, dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, c->swKey, lo, hi, c->sel, c->slices);
+        launch(k_select_thresh, dim3(1), dim3(VFT_NBINS), 0, c->stream, c->sel, c->slices, VFT_SEL_WGS,
+                           (unsigned int) k);
+        launch(k_select_collect, dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, c->swKey, lo, hi, c->sel,
+                           c->candKey, c->candId);
+        launch((k_select_finish<REAL, HIT>), dim3(1), dim3(1024), VFT_CAND_CAP * 12, c->stream, c->sel,
+                           c->candKey, c->candId, (const REAL *) c->swDist, (const REAL *) c->swWeight,
+                           (const REAL *) c->swCrit, k, query, (HIT *) c->dHits, wantBest ? c->dBest : (int64_t *) nullptr);
+        LAUNCHCHK(c);
+        if (round == 0 && !c->timeKernels) {
+            // common case: no overflow; checked lazily by the caller through sel->overflow after its own sync
+        }
+        SelectState st;
+        HIPCHK(c, hipMemcpyAsync(&st, c->sel, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!st.overflow) return VFT_OK;
+        if (st.shift == 0 && round > 0) return fail(c, VFT_ERR_STATE, "top-k select: more than %d exactly tied hits", VFT_CAND_CAP);
+        launch(k_select_refine, dim3(1), dim3(1), 0, c->stream, c->sel);
+    }
+    return fail(c, VFT_ERR_STATE, "top-k select did not converge");
+}
+
+extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam, int32_t k,
+                         void *hits, void *dHitsOut, int64_t *bestJ) {
+    if (!c) return VFT_ERR_INVALID;
+    if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_sweep before vft_upload_leaves");
+    if (query < 0 || query >= c->maxnode || nActive < 3 || k < 0 || k > c->hitsCap)
+        return fail(c, VFT_ERR_INVALID, "vft_sweep: bad arguments (query %lld, nActive %lld, k %d)", (long long) query,
+                    (long long) nActive, (int) k);
+    const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
+    // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098)
+    if (int r = launch_out_distances(c, nullptr, 0, nActive, nDiffAllow, totdiam, false)) return r;
+    {
+        if (int r = ensure_scratch(c, 8)) return r;
+        HIPCHK(c, hipMemcpyAsync(c->scratch, &query, 8, hipMemcpyHostToDevice, c->stream));
+        SweepArgs s{};
+        s.query = -1;
+        s.lo = 0;
+        s.hi = c->maxnode;
+        s.nActive = nActive;
+        s.nDiffAllow = nDiffAllow;
+        s.totdiam = totdiam;
+        s.force = 0;
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(1), dim3(64), 0, c->stream, arena<REAL>(c),
+                                            (const int64_t *) c->scratch, (int64_t) 1, s)));
+        LAUNCHCHK(c);
+    }
+    // 2. the sweep itself
+    SweepArgs s{};
+    s.query = query;
+    s.lo = lo;
+    s.hi = hi;
+    s.nActive = nActive;
+    s.nDiffAllow = nDiffAllow;
+    s.totdiam = totdiam;
+    s.queryIsLeaf = query < c->d.nSeqs ? 1 : 0;
+    const int64_t span = hi > lo ? hi - lo : 0;
+    const unsigned grid = cdiv(span > 0 ? span : 1, VFT_WG);
+    c->nPart = (int) grid;
+    const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+    if (c->cfg.n_codes == 4 && !c->hasDm) {
+        if (c->cfg.precision == 4) {
+            launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
+                               query, qbuf<float>(c, 0));
+            kernel_event(c);
+            launch((k_sweep_nt<float, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<float>(c),
+                               qbuf<float>(c, 0), s, sweepout<float>(c));
+            kernel_event(c);
+        } else {
+            launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
+                               arena<double>(c), query, qbuf<double>(c, 0));
+            kernel_event(c);
+            launch((k_sweep_nt<double, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<double>(c),
+                               qbuf<double>(c, 0), s, sweepout<double>(c));
+            kernel_event(c);
+        }
+    } else {
+        kernel_event(c);
+        VFT_DISPATCH(c, (launch((k_sweep_generic<REAL, NC>), dim3(grid), dim3(VFT_WG), 0, c->stream,
+                                            arena<REAL>(c), s, sweepout<REAL>(c))));
+        kernel_event(c);
+    }
+    LAUNCHCHK(c);
+    if (k == 0) return VFT_OK;
+    // 3. top-k in the reference's sort order
+    int r;
+    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, lo, hi, k, query, bestJ != nullptr);
+    else r = run_select<double, vft_hit_f64>(c, lo, hi, k, query, bestJ != nullptr);
+    if (r) return r;
+    const size_t hb = (size_t) k * (c->cfg.precision == 4 ? sizeof(vft_hit_f32) : sizeof(vft_hit_f64));
+    if (dHitsOut) HIPCHK(c, hipMemcpyAsync(dHitsOut, c->dHits, hb, hipMemcpyDeviceToDevice, c->stream));
+    if (hits) HIPCHK(c, hipMemcpyAsync(hits, c->dHits, hb, hipMemcpyDeviceToHost, c->stream));
+    if (bestJ) HIPCHK(c, hipMemcpyAsync(bestJ, c->dBest, 8, hipMemcpyDeviceToHost, c->stream));
+    if (hits || bestJ) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_sweep_results(vft_ctx *c, int64_t first, int64_t count, void *dist, void *weight, void *crit) {
+    if (!c) return VFT_ERR_INVALID;
+    if (int r = range_ok(c, first, count)) return r;
+    const size_t rs = c->rs;
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, (char *) c->swDist + first * rs, count * rs, hipMemcpyDeviceToHost, c->stream));
+    if (weight) HIPCHK(c, hipMemcpyAsync(weight, (char *) c->swWeight + first * rs, count * rs, hipMemcpyDeviceToHost, c->stream));
+    if (crit) HIPCHK(c, hipMemcpyAsync(crit, (char *) c->swCrit + first * rs, count * rs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive,
+                                  int64_t nDiffAllow, double totdiam, void *dist, void *weight, void *crit) {
+    if (!c || n < 0 || !pi || !pj) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_pair_distances before vft_upload_leaves");
+    for (int64_t t = 0; t < n; t++)
+        if (pi[t] < 0 || pi[t] >= c->maxnode || pj[t] < 0 || pj[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "pair %lld out of range", (long long) t);
+    const size_t rs = c->rs, idB = (size_t) n * 8, oB = (size_t) n * rs;
+    if (int r = ensure_scratch(c, 2 * idB + 3 * oB + 64)) return r;
+    char *s = (char *) c->scratch;
+    int64_t *dI = (int64_t *) s, *dJ = (int64_t *) (s + idB);
+    char *o = s + 2 * idB;
+    HIPCHK(c, hipMemcpyAsync(dI, pi, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dJ, pj, idB, hipMemcpyHostToDevice, c->stream));
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = nDiffAllow;
+    sa.totdiam = totdiam;
+    VFT_DISPATCH(c, {
+        Arena<REAL> A = arena<REAL>(c);
+        launch((k_pairs_refresh<REAL, NC>), dim3(cdiv(2 * n, 64)), dim3(64), 0, c->stream, A, dI, dJ, n, sa);
+        launch((k_pairs_stamp<REAL>), dim3(cdiv(2 * n, 256)), dim3(256), 0, c->stream, A, dI, dJ, n, sa);
+        launch((k_pairs<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream, A, dI, dJ, n, nActive, (REAL *) o,
+                           (REAL *) (o + oB), (REAL *) (o + 2 * oB));
+    });
+    LAUNCHCHK(c);
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, o, oB, hipMemcpyDeviceToHost, c->stream));
+    if (weight) HIPCHK(c, hipMemcpyAsync(weight, o + oB, oB, hipMemcpyDeviceToHost, c->stream));
+    if (crit) HIPCHK(c, hipMemcpyAsync(crit, o + 2 * oB, oB, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- likelihood
+extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int64_t *b, const double *length,
+                              double *loglk, double *siteLk) {
+    if (!c || n < 0 || !a || !b || !length || !loglk) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
+    const size_t idB = (size_t) n * 8, sB = siteLk ? (size_t) n * c->d.nPos * 8 : 0;
+    if (int r = ensure_scratch(c, 4 * idB + sB + 64)) return r;
+    char *s = (char *) c->scratch;
+    HIPCHK(c, hipMemcpyAsync(s, a, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + idB, b, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + 2 * idB, length, idB, hipMemcpyHostToDevice, c->stream));
+    double *dOut = (double *) (s + 3 * idB);
+    double *dSite = siteLk ? (double *) (s + 4 * idB) : nullptr;
+    VFT_DISPATCH(c, (launch((k_pair_loglk<REAL, NC>), dim3((unsigned) n), dim3(VFT_ML_WG), 0, c->stream,
+                                        arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB),
+                                        (const double *) (s + 2 * idB), n, c->minRel, dOut, dSite)));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(loglk, dOut, idB, hipMemcpyDeviceToHost, c->stream));
+    if (siteLk) HIPCHK(c, hipMemcpyAsync(siteLk, dSite, sB, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                                      const double *len1, const double *len2) {
+    if (!c || n < 0 || !out || !a || !b || !len1 || !len2) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
+    for (int64_t k = 0; k < n; k++)
+        if (int r = internal_ok(c, out[k])) return r;
+    const size_t idB = (size_t) n * 8;
+    if (int r = ensure_scratch(c, 5 * idB + 64)) return r;
+    char *s = (char *) c->scratch;
+    HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + 3 * idB, len1, idB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + 4 * idB, len2, idB, hipMemcpyHostToDevice, c->stream));
+    const int64_t maxY = 65535;
+    for (int64_t k0 = 0; k0 < n; k0 += maxY) {
+        const int64_t cnt = n - k0 < maxY ? n - k0 : maxY;
+        VFT_DISPATCH(c, (launch((k_posterior<REAL, NC>), dim3(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt),
+                                            dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
+                                            (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
+                                            (const double *) (s + 3 * idB) + k0, (const double *) (s + 4 * idB) + k0,
+                                            c->minLen, c->minRel)));
+        LAUNCHCHK(c);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- timing
+extern "C" int vft_timer_start(vft_ctx *c) {
+    if (!c) return VFT_ERR_INVALID;
+    c->kevUsed = 0;
+    c->timeKernels = true;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_timer_stop_ms(vft_ctx *c, float *ms) {
+    if (!c || !ms) return VFT_ERR_INVALID;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    c->timeKernels = false;
+    return VFT_OK;
+}
+
+extern "C" int vft_sweep_kernel_ms(vft_ctx *c, float *avgMs, int64_t *launches) {
+    if (!c || !avgMs || !launches) return VFT_ERR_INVALID;
+    double total = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < c->kevUsed; i += 2) {
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(c->kev[i + 1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->kev[i], c->kev[i + 1]));
+        total += ms;
+        n++;
+    }
+    *avgMs = n ? (float) (total / (double) n) : 0.f;
+    *launches = n;
+    return VFT_OK;
+}

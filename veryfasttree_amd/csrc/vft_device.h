@@ -1,0 +1,192 @@
+// Device-side view of the arena and the per-column primitives shared by every kernel.
+// All arithmetic follows the reference's types literally (see oracle/vft_oracle_impl.h for the same statements
+// on the CPU and the NeighbourJoining.tcc lines they mirror); the file is compiled with -ffp-contract=off so
+// no multiply-add is ever fused.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vft_layout.h"
+
+template <typename REAL>
+struct Arena {
+    VftDims d;
+    const uint4 *leafT;
+    REAL *profW;
+    REAL *profF;
+    uint4 *profC;
+    int32_t *parent;
+    REAL *diameter, *selfweight, *selfdist, *outDist;
+    int32_t *nOutActive;
+    // out-profile, row-major: outW[nPos], outF[nPos][nCodes], outCD[nPos][nCodes] (only with a distance matrix)
+    REAL *outW, *outF, *outCD;
+    // distance matrix (NULL when %-different distances are used)
+    const REAL *dmDist, *dmCodeFreq, *dmEigenval, *dmEigentot;
+    // transition matrix (NULL for Jukes-Cantor): codefreq has nCodes+1 rows
+    const REAL *tmStat, *tmStatInv, *tmEigenval, *tmCodeFreq, *tmEigenInv, *tmEigenInvT;
+    const REAL *rates;
+    const int32_t *ratecat;
+    int32_t nRates;
+};
+
+__device__ __forceinline__ uint32_t vft_byte(const uint4 &v, int b) {
+    const uint32_t w = b < 8 ? (b < 4 ? v.x : v.y) : (b < 12 ? v.z : v.w);
+    return (w >> ((b & 3) * 8)) & 0xFFu;
+}
+
+// reference code (0..nCodes-1 or 127) of a stored leaf byte
+template <int NC>
+__device__ __forceinline__ int vft_decode(uint32_t enc) {
+    if (NC != 4) return (int) enc;
+    return (enc & 0x10u) ? (__ffs((int) (enc & 0xFu)) - 1) : VFT_NOCODE_;
+}
+
+// One alignment column of one node, in the reference's terms.
+template <typename REAL, int NC>
+struct Col {
+    REAL w;
+    int code;
+    bool vec;      // the reference holds a frequency vector here (code == NOCODE && w > 0)
+    REAL f[NC];    // valid only when vec
+};
+
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node, int64_t p, Col<REAL, NC> &c) {
+    const int lane = (int) (node & (VFT_TILE - 1));
+    const int64_t tile = node >> 6;
+    if (node < A.d.nSeqs) {
+        const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, (int) (p >> 4), lane)];
+        c.code = vft_decode<NC>(vft_byte(t, (int) (p & 15)));
+        c.w = c.code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
+        c.vec = false;
+    } else {
+        const int64_t pt = tile - A.d.firstProfTile;
+        c.w = A.profW[vft_w_idx(A.d, pt, p, lane)];
+        const uint4 t = A.profC[vft_c_idx(A.d, pt, (int) (p >> 4), lane)];
+        c.code = (int) vft_byte(t, (int) (p & 15));
+        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+        if (c.vec) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) c.f[k] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, lane)];
+        }
+    }
+}
+
+template <typename REAL, int NC>
+__device__ __forceinline__ REAL vft_pick(const REAL (&f)[NC], int code) {
+    REAL v = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k++) v = (k == code) ? f[k] : v;
+    return v;
+}
+
+// SSE128 / AVX256 horizontal order: four strided accumulators, then (s0+s1)+(s2+s3)
+template <typename REAL, int NC>
+__device__ __forceinline__ REAL vft_red4_mul3(const REAL *a, const REAL *b, const REAL *c) {
+    REAL s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NC; i += 4)
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            REAL p = a[i + l] * b[i + l];
+            p = p * c[i + l];
+            s[l] = p + s[l];
+        }
+    const REAL lo = s[0] + s[1], hi = s[2] + s[3];
+    return lo + hi;
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ REAL vft_red4_mul(const REAL *a, const REAL *b) {
+    REAL s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NC; i += 4)
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            REAL p = a[i + l] * b[i + l];
+            s[l] = p + s[l];
+        }
+    const REAL lo = s[0] + s[1], hi = s[2] + s[3];
+    return lo + hi;
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ REAL vft_red4_sum(const REAL *a) {
+    REAL s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NC; i += 4)
+#pragma unroll
+        for (int l = 0; l < 4; l++) s[l] = a[i + l] + s[l];
+    const REAL lo = s[0] + s[1], hi = s[2] + s[3];
+    return lo + hi;
+}
+
+// profileDistPiece (NJ.tcc:900-941).  cd2 = codeDist row of profile 2 for this column, or nullptr.
+template <typename REAL, int NC>
+__device__ __forceinline__ double vft_piece(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2,
+                                            const REAL *cd2) {
+    if (A.dmDist) {
+        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) return (double) A.dmDist[c1.code * NC + c2.code];
+        if (cd2 != nullptr && c1.code != VFT_NOCODE_) return (double) cd2[c1.code];
+        REAL f1[NC], f2[NC], ev[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            f1[k] = c1.vec ? c1.f[k] : A.dmCodeFreq[(c1.code == VFT_NOCODE_ ? 0 : c1.code) * NC + k];
+            f2[k] = c2.vec ? c2.f[k] : A.dmCodeFreq[(c2.code == VFT_NOCODE_ ? 0 : c2.code) * NC + k];
+            ev[k] = A.dmEigenval[k];
+        }
+        if ((!c1.vec && c1.code == VFT_NOCODE_) || (!c2.vec && c2.code == VFT_NOCODE_)) return 10.0;
+        return (double) vft_red4_mul3<REAL, NC>(f1, f2, ev);
+    }
+    if (c1.code != VFT_NOCODE_) {
+        if (c2.code != VFT_NOCODE_) return c1.code == c2.code ? 0.0 : 1.0;
+        if (!c2.vec) return 10.0;
+        return 1.0 - (double) vft_pick<REAL, NC>(c2.f, c1.code);
+    }
+    if (c2.code != VFT_NOCODE_) {
+        if (!c1.vec) return 10.0;
+        return 1.0 - (double) vft_pick<REAL, NC>(c1.f, c2.code);
+    }
+    if (!c1.vec || !c2.vec) return 10.0;
+    double piece = 1.0;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const REAL p = c1.f[k] * c2.f[k];
+        piece -= (double) p;
+    }
+    return piece;
+}
+
+// setOutDistance's closed form (NJ.tcc:1046-1053): numeric_t products, one double division.
+template <typename REAL>
+__device__ __forceinline__ REAL vft_out_distance(REAL dist, REAL weight, int64_t nActive, REAL selfweight,
+                                                 REAL selfdist, REAL diameter, double totdiam) {
+    const REAL t1 = dist * weight;
+    const REAL t2 = t1 * (REAL) nActive;
+    const REAL t3 = selfweight * selfdist;
+    const REAL t4 = t2 - t3;
+    const REAL topr = (REAL) (nActive - 1) * t4;
+    const REAL b1 = weight * (REAL) nActive;
+    const REAL botr = b1 - selfweight;
+    const double top = topr, bottom = botr;
+    const double pd = top / bottom;
+    const REAL dn = diameter * (REAL) (nActive - 1);
+    const double r = bottom > 0.01 ? pd - (double) dn - (totdiam - (double) diameter) : 3.0;
+    return (REAL) r;
+}
+
+// setCriterion's formula with the stale out-distance rescale (NJ.tcc:1099-1107)
+template <typename REAL>
+__device__ __forceinline__ REAL vft_criterion(REAL dist, REAL outI, int64_t nOutI, REAL outJ, int64_t nOutJ,
+                                              int64_t nActive) {
+    double oi = outI, oj = outJ;
+    if (nOutI != nActive) oi *= (double) (nActive - 1) / (double) (nOutI - 1);
+    if (nOutJ != nActive) oj *= (double) (nActive - 1) / (double) (nOutJ - 1);
+    return (REAL) ((double) dist - (oi + oj) / (double) (nActive - 2));
+}
+
+// Sort key of a hit: ascending criterion, ties by DESCENDING node id.  Smaller key = earlier.
+__device__ __forceinline__ uint32_t vft_order_f32(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t vft_order_f64(double x) {
+    const uint64_t u = (uint64_t) __double_as_longlong(x);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}

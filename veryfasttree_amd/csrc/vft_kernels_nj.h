@@ -1,0 +1,629 @@
+// NJ-phase kernels: one-vs-all sweeps (setBestHit), pair lists (transferBestHits & co), out-distances,
+// average / out-profile maintenance and the top-k selection that replaces the reference's full sort.
+//
+// Parity rule for every distance: ONE lane owns ONE (query,target) pair and walks the alignment columns in
+// order, accumulating `top` and `denom` in double exactly as profileDist does (NJ.tcc:1167-1190).  There is no
+// cross-lane reduction, so results are bit-identical to the CPU and independent of launch geometry; the
+// tile-transposed layout (vft_layout.h) is what makes that access pattern fully coalesced.
+#pragma once
+#include "vft_device.h"
+
+#define VFT_WG 256
+
+// ------------------------------------------------------------------------------------------------ query staging
+// Row-major copy of the query profile, read wave-uniformly (scalar loads) by the sweep kernels.
+template <typename REAL>
+struct QueryBuf {
+    REAL *w;        // [nPosPad]
+    uint8_t *code;  // [nPosPad] reference codes
+    REAL *f;        // [nPosPad][nCodes]; nt: one-hot for code columns (see k_extract_query)
+    uint4 *enc;     // [nChunk] encoded leaf bytes (valid when the query is a leaf)
+};
+
+template <typename REAL, int NC>
+__global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nPosPad = (int64_t) A.d.nChunk * VFT_CHUNK;
+    if (p >= nPosPad) return;
+    REAL w = 0;
+    int code = VFT_NOCODE_;
+    REAL f[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) f[k] = 0;
+    if (p < A.d.nPos) {
+        Col<REAL, NC> c;
+        vft_load_col<REAL, NC>(A, node, p, c);
+        w = c.w;
+        code = c.code;
+        if (c.vec) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) f[k] = c.f[k];
+        } else if (NC == 4 && code != VFT_NOCODE_) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) f[k] = (k == code) ? (REAL) 1 : (REAL) 0;
+        }
+    }
+    q.w[p] = w;
+    q.code[p] = (uint8_t) code;
+#pragma unroll
+    for (int k = 0; k < NC; k++) q.f[p * NC + k] = f[k];
+    if (node < A.d.nSeqs && p < A.d.nChunk) {
+        q.enc[p] = A.leafT[vft_leaf_idx(A.d, node >> 6, (int) p, (int) (node & 63))];
+    }
+}
+
+// The out-profile as a query (every column NOCODE with a vector, NJ.tcc:743-747).
+template <typename REAL, int NC>
+__global__ void k_outprofile_as_query(Arena<REAL> A, QueryBuf<REAL> q) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nPosPad = (int64_t) A.d.nChunk * VFT_CHUNK;
+    if (p >= nPosPad) return;
+    const bool in = p < A.d.nPos;
+    q.w[p] = in ? A.outW[p] : (REAL) 0;
+    q.code[p] = VFT_NOCODE_;
+#pragma unroll
+    for (int k = 0; k < NC; k++) q.f[p * NC + k] = in ? A.outF[p * NC + k] : (REAL) 0;
+}
+
+// ------------------------------------------------------------------------------------------------ sweep (nt)
+struct SweepArgs {
+    int64_t query;       // node id, or -1 when the query is the out-profile (MODE_OUTDIST)
+    int64_t lo, hi;      // target id range [lo, hi), lo % 64 == 0
+    int64_t nActive, nDiffAllow;
+    double totdiam;
+    int32_t queryIsLeaf;
+    int32_t force;       // MODE_OUTDIST: refresh every listed node regardless of staleness
+};
+
+template <typename REAL>
+struct SweepOut {
+    REAL *dist, *weight, *crit;   // [maxNodes], indexed by target id
+    uint64_t *key;                // primary sort key (0xFFFF.. for inactive targets)
+    unsigned long long *partMin;  // [gridDim.x] per-workgroup min / max of the active keys: reduced by
+    unsigned long long *partMax;  // k_select_range, so that the sweep issues no global atomics at all
+};
+
+// per-workgroup (min,max) of the keys produced by this launch; every thread of the workgroup must call it
+__device__ __forceinline__ void vft_block_minmax(unsigned long long kmin, unsigned long long kmax,
+                                                 unsigned long long *partMin, unsigned long long *partMax) {
+    __shared__ unsigned long long smin[VFT_WG / 64], smax[VFT_WG / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = kmin;
+        smax[threadIdx.x >> 6] = kmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < VFT_WG / 64; w++) {
+            kmin = smin[w] < kmin ? smin[w] : kmin;
+            kmax = smax[w] > kmax ? smax[w] : kmax;
+        }
+        partMin[blockIdx.x] = kmin;
+        partMax[blockIdx.x] = kmax;
+    }
+}
+
+enum { MODE_CRIT = 0, MODE_OUTDIST = 1 };
+
+// %-different distance of two leaves from their encoded bytes (seqDist, NJ.tcc:1601-1612): integer counts.
+__device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int &nUse, int &nSame) {
+    const uint32_t x = a.x & b.x, y = a.y & b.y, z = a.z & b.z, w = a.w & b.w;
+    nUse += __popc(x & 0x10101010u) + __popc(y & 0x10101010u) + __popc(z & 0x10101010u) + __popc(w & 0x10101010u);
+    nSame += __popc(x & 0x0F0F0F0Fu) + __popc(y & 0x0F0F0F0Fu) + __popc(z & 0x0F0F0F0Fu) + __popc(w & 0x0F0F0F0Fu);
+}
+
+// Nucleotide, no distance matrix (the -nt default).  NC == 4, dense one-hot frequency vectors, see DESIGN.md.
+template <typename REAL, int MODE>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
+    const int64_t j = s.lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    const int lane = (int) (j & 63);
+    const int64_t tile = j >> 6;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    bool work = j < s.hi;
+    if (work) {
+        const bool active = A.parent[j] < 0;
+        if (MODE == MODE_CRIT) {
+            if (!active) {   // NJ.tcc:3586-3590: illegal/empty join
+                O.dist[j] = (REAL) 1e20;
+                O.crit[j] = (REAL) 1e20;
+                O.weight[j] = 0;
+                O.key[j] = ~0ull;
+                work = false;
+            }
+        } else {
+            work = active && (s.force || ((int64_t) A.nOutActive[j] - s.nActive > s.nDiffAllow)) &&
+                   (int64_t) A.nOutActive[j] != s.nActive;
+        }
+    }
+    if (work) {
+        const int64_t nPos = A.d.nPos;
+        const bool targetLeaf = j < A.d.nSeqs;
+        REAL dist, weight;
+        if (MODE == MODE_CRIT && s.queryIsLeaf && targetLeaf) {
+            int nUse = 0, nSame = 0;
+            for (int c = 0; c < A.d.nChunk; c++) {
+                const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
+                vft_seq_counts(t, Q.enc[c], nUse, nSame);
+            }
+            const double top = (double) (nUse - nSame);
+            weight = (REAL) (double) nUse;
+            dist = (REAL) (nUse > 0 ? top / (double) nUse : 1.0);
+        } else {
+            double top = 0, denom = 0;
+            if (targetLeaf) {
+                for (int c = 0; c < A.d.nChunk; c++) {
+                    const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
+                    const int64_t p0 = (int64_t) c * VFT_CHUNK;
+#pragma unroll
+                    for (int b = 0; b < VFT_CHUNK; b++) {
+                        const int64_t p = p0 + b;
+                        if (p < nPos) {
+                            const REAL wq = Q.w[p];
+                            const uint32_t enc = vft_byte(t, b);
+                            if (wq > 0 && (enc & 0x10u)) {
+                                // target weight is 1, its vector one-hot: piece = 1 - fq[code] (NJ.tcc:924,930)
+                                const double wgt = (double) wq;
+                                denom += wgt;
+                                const REAL *fq = Q.f + p * 4;
+                                const REAL f01 = (enc & 1u) ? fq[0] : fq[1];
+                                const REAL f23 = (enc & 4u) ? fq[2] : fq[3];
+                                const REAL fqc = (enc & 3u) ? f01 : f23;
+                                const double piece = 1.0 - (double) fqc;
+                                top += wgt * piece;
+                            }
+                        }
+                    }
+                }
+            } else {
+                const int64_t pt = tile - A.d.firstProfTile;
+                const REAL *wT = A.profW + vft_w_idx(A.d, pt, 0, lane);
+                const REAL *fT = A.profF + vft_f_idx<REAL>(A.d, pt, 0, 0, lane);
+                constexpr int G = 16 / (int) sizeof(REAL);   // values per 16-byte group
+                constexpr int NG = 4 / G;                    // groups per column (1 for float, 2 for double)
+                for (int64_t p = 0; p < nPos; p++) {
+                    const REAL wt = wT[p * VFT_TILE];
+                    REAL ft[4];
+#pragma unroll
+                    for (int g = 0; g < NG; g++)
+#pragma unroll
+                        for (int e = 0; e < G; e++) ft[g * G + e] = fT[((p * NG + g) * VFT_TILE) * G + e];
+                    const REAL wq = Q.w[p];
+                    if (wq > 0 && wt > 0) {
+                        const REAL ww = wq * wt;   // numeric_t product, NJ.tcc:1176
+                        const double wgt = (double) ww;
+                        denom += wgt;
+                        double piece = 1.0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const REAL pr = Q.f[p * 4 + k] * ft[k];   // NJ.tcc:935
+                            piece -= (double) pr;
+                        }
+                        top += wgt * piece;
+                    }
+                }
+            }
+            weight = (REAL) (denom > 0 ? denom : 0.01);
+            dist = (REAL) (denom > 0 ? top / denom : 1.0);
+        }
+        if (MODE == MODE_CRIT) {
+            if (!(s.queryIsLeaf && targetLeaf)) {
+                const REAL dd = A.diameter[s.query] + A.diameter[j];
+                dist = dist - dd;   // NJ.tcc:1120
+            }
+            const REAL crit = vft_criterion<REAL>(dist, A.outDist[s.query], A.nOutActive[s.query], A.outDist[j],
+                                                  A.nOutActive[j], s.nActive);
+            O.dist[j] = dist;
+            O.weight[j] = weight;
+            O.crit[j] = crit;
+            uint64_t key;
+            if (sizeof(REAL) == 4)
+                key = ((uint64_t) vft_order_f32((float) crit) << 32) | (uint64_t) (0xFFFFFFFFu - (uint32_t) j);
+            else
+                key = vft_order_f64((double) crit);
+            O.key[j] = key;
+            kmin = kmax = key;
+        } else {
+            A.outDist[j] = vft_out_distance<REAL>(dist, weight, s.nActive, A.selfweight[j], A.selfdist[j],
+                                                  A.diameter[j], s.totdiam);
+            A.nOutActive[j] = (int32_t) s.nActive;
+        }
+    }
+    if (MODE == MODE_CRIT) vft_block_minmax(kmin, kmax, O.partMin, O.partMax);
+}
+
+// ------------------------------------------------------------------------------------------------ generic pair
+// profileDist / seqDist for an arbitrary (i, j), any alphabet, with or without a distance matrix.
+// cdOut: the pair's second profile is the out-profile (row-major arrays in A.out*), used by setOutDistance.
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_generic(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, REAL &dist,
+                                                 REAL &weight) {
+    const int64_t nPos = A.d.nPos;
+    if (!jIsOut && i < A.d.nSeqs && j < A.d.nSeqs) {   // seqDist, NJ.tcc:1601-1624
+        double top = 0;
+        int64_t nUse = 0;
+        int nDiff = 0;
+        const int li = (int) (i & 63), lj = (int) (j & 63);
+        for (int c = 0; c < A.d.nChunk; c++) {
+            const uint4 a = A.leafT[vft_leaf_idx(A.d, i >> 6, c, li)];
+            const uint4 b = A.leafT[vft_leaf_idx(A.d, j >> 6, c, lj)];
+            for (int t = 0; t < VFT_CHUNK; t++) {
+                if ((int64_t) c * VFT_CHUNK + t >= nPos) break;
+                const int ca = vft_decode<NC>(vft_byte(a, t)), cb = vft_decode<NC>(vft_byte(b, t));
+                if (ca != VFT_NOCODE_ && cb != VFT_NOCODE_) {
+                    nUse++;
+                    if (A.dmDist) top += (double) A.dmDist[ca * NC + cb];
+                    else if (ca != cb) nDiff++;
+                }
+            }
+        }
+        if (!A.dmDist) top = (double) nDiff;
+        weight = (REAL) (double) nUse;
+        dist = (REAL) (nUse > 0 ? top / (double) nUse : 1.0);
+        return;
+    }
+    double top = 0, denom = 0;
+    for (int64_t p = 0; p < nPos; p++) {
+        Col<REAL, NC> c1, c2;
+        vft_load_col<REAL, NC>(A, i, p, c1);
+        if (jIsOut) {
+            c2.w = A.outW[p];
+            c2.code = VFT_NOCODE_;
+            c2.vec = c2.w > 0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) c2.f[k] = A.outF[p * NC + k];
+        } else {
+            vft_load_col<REAL, NC>(A, j, p, c2);
+        }
+        if (c1.w > 0 && c2.w > 0) {
+            const REAL ww = c1.w * c2.w;
+            const double wgt = (double) ww;
+            denom += wgt;
+            const double piece = vft_piece<REAL, NC>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr);
+            top += wgt * piece;
+        }
+    }
+    weight = (REAL) (denom > 0 ? denom : 0.01);
+    dist = (REAL) (denom > 0 ? top / denom : 1.0);
+}
+
+// setOutDistance for a list of nodes, or (ids == nullptr) for every active node of [lo,hi).  Unless s.force is
+// set only nodes staler than nDiffAllow are recomputed (setCriterion's lazy refresh, NJ.tcc:1092-1098).
+template <typename REAL, int NC>
+__global__ void k_out_distances(Arena<REAL> A, const int64_t *ids, int64_t n, SweepArgs s) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t v;
+    if (ids) {
+        if (t >= n) return;
+        v = ids[t];
+    } else {
+        v = s.lo + t;
+        if (v >= s.hi || A.parent[v] >= 0) return;
+    }
+    if (!s.force && !((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
+    if ((int64_t) A.nOutActive[v] == s.nActive) return;   // NJ.tcc:1013-1015
+    REAL d, w;
+    vft_pair_generic<REAL, NC>(A, v, -1, true, d, w);
+    A.outDist[v] = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+    A.nOutActive[v] = (int32_t) s.nActive;
+}
+
+// Generic one-vs-all sweep (any alphabet / matrix): lane per target, query fixed.
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_generic(Arena<REAL> A, SweepArgs s, SweepOut<REAL> O) {
+    const int64_t j = s.lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    if (j < s.hi) {
+        if (A.parent[j] >= 0) {
+            O.dist[j] = (REAL) 1e20;
+            O.crit[j] = (REAL) 1e20;
+            O.weight[j] = 0;
+            O.key[j] = ~0ull;
+        } else {
+            REAL dist, weight;
+            vft_pair_generic<REAL, NC>(A, s.query, j, false, dist, weight);
+            if (!(s.query < A.d.nSeqs && j < A.d.nSeqs)) {
+                const REAL dd = A.diameter[s.query] + A.diameter[j];
+                dist = dist - dd;
+            }
+            const REAL crit = vft_criterion<REAL>(dist, A.outDist[s.query], A.nOutActive[s.query], A.outDist[j],
+                                                  A.nOutActive[j], s.nActive);
+            O.dist[j] = dist;
+            O.weight[j] = weight;
+            O.crit[j] = crit;
+            uint64_t key;
+            if (sizeof(REAL) == 4)
+                key = ((uint64_t) vft_order_f32((float) crit) << 32) | (uint64_t) (0xFFFFFFFFu - (uint32_t) j);
+            else
+                key = vft_order_f64((double) crit);
+            O.key[j] = key;
+            kmin = kmax = key;
+        }
+    }
+    vft_block_minmax(kmin, kmax, O.partMin, O.partMax);
+}
+
+// setDistCriterion over an explicit pair list.  Out-distances must have been refreshed by k_pairs_refresh first.
+template <typename REAL, int NC>
+__global__ void k_pairs(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, int64_t nActive, REAL *dist,
+                        REAL *weight, REAL *crit) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t i = pi[t], j = pj[t];
+    REAL d, w;
+    vft_pair_generic<REAL, NC>(A, i, j, false, d, w);
+    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+        const REAL dd = A.diameter[i] + A.diameter[j];
+        d = d - dd;
+    }
+    dist[t] = d;
+    weight[t] = w;
+    crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], nActive);
+}
+
+// Lazy out-distance refresh of every node named in a pair list (setCriterion, NJ.tcc:1092-1098).  A node may be
+// named many times: the refresh is idempotent and all writers store the same value.
+template <typename REAL, int NC>
+__global__ void k_pairs_refresh(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, SweepArgs s) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const int64_t v = t < n ? pi[t] : pj[t - n];
+    if (!((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
+    REAL d, w;
+    vft_pair_generic<REAL, NC>(A, v, -1, true, d, w);
+    const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+    // two-phase: values first, staleness stamps in k_pairs_stamp, so that concurrent readers of nOutActive in
+    // this launch keep seeing "stale" and recompute the identical value instead of racing on a half-update
+    A.outDist[v] = od;
+}
+template <typename REAL>
+__global__ void k_pairs_stamp(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, SweepArgs s) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const int64_t v = t < n ? pi[t] : pj[t - n];
+    if ((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow) A.nOutActive[v] = (int32_t) s.nActive;
+}
+
+// ------------------------------------------------------------------------------------------------ top-k select
+// The reference sorts all N hits of a sweep and keeps the first 2m (NJ.tcc:3810, 4541).  Here: a linear
+// histogram of the primary keys between their min and max, the bin holding the k-th smallest, a compaction of
+// everything at or below that bin, and a single-workgroup bitonic sort of those few candidates by
+// (key asc, id desc) — the same total order.  No kernel issues more than one global atomic per workgroup
+// (same-address atomics cost ~12 ns each on this chip, MI355X_MICROARCH.md "fanin").
+#define VFT_NBINS 1024
+#define VFT_SEL_WGS 128
+#define VFT_CAND_CAP 8192
+
+struct SelectState {
+    unsigned long long lo, hi;   // key range being binned: bin = (key - lo) >> shift; keys < lo are "in"
+    unsigned int shift;
+    unsigned int threshBin;      // bins <= threshBin are collected
+    unsigned int nCand;
+    unsigned int overflow;
+    unsigned int nBelow;         // #keys in bins < threshBin
+    unsigned int nThresh;        // #keys in threshBin
+    unsigned int nIn;            // #keys < lo (refinement rounds)
+    unsigned int pad;
+};
+
+__device__ __forceinline__ unsigned int vft_bin(unsigned long long key, unsigned long long lo, unsigned int shift) {
+    const unsigned long long b = (key - lo) >> shift;
+    return b >= VFT_NBINS ? VFT_NBINS - 1 : (unsigned int) b;
+}
+
+__device__ __forceinline__ void vft_set_range(SelectState *S, unsigned long long lo, unsigned long long hi) {
+    unsigned int shift = 0;
+    if (hi > lo) {
+        const unsigned long long span = hi - lo;
+        while (shift < 63 && (span >> shift) >= VFT_NBINS) shift++;
+    }
+    S->lo = lo;
+    S->hi = hi;
+    S->shift = shift;
+}
+
+// one workgroup: reduce the sweep's per-workgroup (min,max) partials and set up round one
+__global__ __launch_bounds__(1024) void k_select_range(SelectState *S, const unsigned long long *partMin,
+                                                       const unsigned long long *partMax, int nPart) {
+    __shared__ unsigned long long smin[1024], smax[1024];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (int t = threadIdx.x; t < nPart; t += 1024) {
+        kmin = partMin[t] < kmin ? partMin[t] : kmin;
+        kmax = partMax[t] > kmax ? partMax[t] : kmax;
+    }
+    smin[threadIdx.x] = kmin;
+    smax[threadIdx.x] = kmax;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int) threadIdx.x < off) {
+            if (smin[threadIdx.x + off] < smin[threadIdx.x]) smin[threadIdx.x] = smin[threadIdx.x + off];
+            if (smax[threadIdx.x + off] > smax[threadIdx.x]) smax[threadIdx.x] = smax[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        vft_set_range(S, smin[0], smax[0]);
+        S->nCand = 0;
+        S->overflow = 0;
+        S->nIn = 0;
+    }
+}
+
+// refinement (rare): the threshold bin alone holds more candidates than the final sort can take
+__global__ void k_select_refine(SelectState *S) {
+    const unsigned long long lo = S->lo + ((unsigned long long) S->threshBin << S->shift);
+    unsigned long long hi = lo + ((1ull << S->shift) - 1ull);
+    if (S->threshBin == VFT_NBINS - 1 || hi > S->hi || hi < lo) hi = S->hi;
+    S->nIn += S->nBelow;
+    vft_set_range(S, lo, hi);
+    S->nCand = 0;
+    S->overflow = 0;
+}
+
+// VFT_SEL_WGS workgroups, each writes its own histogram slice (plain stores)
+__global__ __launch_bounds__(VFT_WG) void k_select_hist(const uint64_t *key, int64_t lo, int64_t hi, const SelectState *S,
+                                                        unsigned int *slices) {
+    __shared__ unsigned int lh[VFT_NBINS];
+    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) lh[t] = 0;
+    __syncthreads();
+    const unsigned long long klo = S->lo, khi = S->hi;
+    const unsigned int shift = S->shift;
+    for (int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x; j < hi; j += (int64_t) gridDim.x * VFT_WG) {
+        const unsigned long long k = key[j];
+        if (k >= klo && k <= khi) atomicAdd(&lh[vft_bin(k, klo, shift)], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) slices[(int64_t) blockIdx.x * VFT_NBINS + t] = lh[t];
+}
+
+// one workgroup of VFT_NBINS threads: column sums, scan, the bin that holds the need-th smallest key
+__global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(SelectState *S, const unsigned int *slices, int nSlices,
+                                                             unsigned int k) {
+    __shared__ unsigned int part[VFT_NBINS];
+    const int t = threadIdx.x;
+    unsigned int mine = 0;
+    for (int w = 0; w < nSlices; w++) mine += slices[(int64_t) w * VFT_NBINS + t];
+    part[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < VFT_NBINS; off <<= 1) {   // inclusive scan
+        const unsigned int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const unsigned int total = part[VFT_NBINS - 1];
+    unsigned int need = k > S->nIn ? k - S->nIn : 0;
+    if (need > total) need = total;
+    const unsigned int before = t ? part[t - 1] : 0;
+    if (need > 0 && before < need && before + mine >= need) {
+        S->threshBin = (unsigned int) t;
+        S->nBelow = before;
+        S->nThresh = mine;
+    }
+    if (t == 0 && need == 0) {   // nothing (more) to pick from this range
+        S->threshBin = 0;
+        S->nBelow = 0;
+        S->nThresh = 0;
+        if (total == 0) S->threshBin = VFT_NBINS;   // collect nothing from the range
+    }
+}
+
+__global__ __launch_bounds__(VFT_WG) void k_select_collect(const uint64_t *key, int64_t lo, int64_t hi, SelectState *S,
+                                                           uint64_t *candKey, int32_t *candId) {
+    __shared__ unsigned int lcount, lbase;
+    __shared__ uint64_t lkey[VFT_CAND_CAP / 8];
+    __shared__ int32_t lid[VFT_CAND_CAP / 8];
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+    const unsigned long long klo = S->lo, khi = S->hi;
+    const unsigned int shift = S->shift, tb = S->threshBin;
+    for (int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x; j < hi; j += (int64_t) gridDim.x * VFT_WG) {
+        const unsigned long long k = key[j];
+        if (k == ~0ull || k > khi) continue;
+        if (k < klo || (tb < VFT_NBINS && vft_bin(k, klo, shift) <= tb)) {
+            const unsigned int slot = atomicAdd(&lcount, 1u);   // LDS atomic
+            if (slot < VFT_CAND_CAP / 8) {
+                lkey[slot] = k;
+                lid[slot] = (int32_t) j;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int n = lcount;
+    if (n > VFT_CAND_CAP / 8) {
+        if (threadIdx.x == 0) S->overflow = 1;
+        return;
+    }
+    if (threadIdx.x == 0) lbase = n ? atomicAdd(&S->nCand, n) : 0;   // one global atomic per workgroup
+    __syncthreads();
+    const unsigned int base = lbase;
+    if (base + n > VFT_CAND_CAP) {
+        if (threadIdx.x == 0) S->overflow = 1;
+        return;
+    }
+    for (unsigned int t = threadIdx.x; t < n; t += VFT_WG) {
+        candKey[base + t] = lkey[t];
+        candId[base + t] = lid[t];
+    }
+}
+
+// one workgroup: bitonic sort of the candidates by (key asc, id desc), then the first k hits and the argmin.
+// dynamic LDS: VFT_CAND_CAP * (8 + 4) bytes
+template <typename REAL, typename HIT>
+__global__ __launch_bounds__(1024) void k_select_finish(const SelectState *S, const uint64_t *candKey,
+                                                        const int32_t *candId, const REAL *dist, const REAL *weight,
+                                                        const REAL *crit, int32_t k, int64_t query, HIT *hits,
+                                                        int64_t *bestJ) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *sk = (uint64_t *) smem;
+    int32_t *si = (int32_t *) (smem + (size_t) VFT_CAND_CAP * 8);
+    const unsigned int n = S->nCand < VFT_CAND_CAP ? S->nCand : VFT_CAND_CAP;
+    unsigned int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (unsigned int t = threadIdx.x; t < np2; t += 1024) {
+        sk[t] = t < n ? candKey[t] : ~0ull;
+        si[t] = t < n ? candId[t] : -1;
+    }
+    __syncthreads();
+    for (unsigned int size = 2; size <= np2; size <<= 1) {
+        for (unsigned int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned int t = threadIdx.x; t < np2 / 2; t += 1024) {
+                const unsigned int a = 2 * t - (t & (stride - 1));
+                const unsigned int b = a + stride;
+                const bool up = (a & size) == 0;
+                const uint64_t ka = sk[a], kb = sk[b];
+                const int32_t ia = si[a], ib = si[b];
+                // "a after b" in the target order: larger key, or equal key and smaller id
+                const bool aAfterB = ka > kb || (ka == kb && ia < ib);
+                if (aAfterB == up) {
+                    sk[a] = kb;
+                    sk[b] = ka;
+                    si[a] = ib;
+                    si[b] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < k; t += 1024) {
+        HIT h;
+        if ((unsigned int) t < n) {
+            const int32_t j = si[t];
+            h.j = j;
+            h.dist = dist[j];
+            h.weight = weight[j];
+            h.criterion = crit[j];
+        } else {
+            h.j = -1;
+            h.dist = (REAL) 1e20;
+            h.weight = 0;
+            h.criterion = (REAL) 1e20;
+        }
+        hits[t] = h;
+    }
+    if (threadIdx.x == 0 && bestJ) {
+        // bestjoin (NJ.tcc:3625-3637): strict '<' scanning ids upwards => smallest id among the minimal criteria
+        int64_t best = -1;
+        REAL bc = (REAL) 1e20;
+        for (unsigned int t = 0; t < n; t++) {
+            const int32_t j = si[t];
+            if (j == (int32_t) query) continue;
+            const REAL c = crit[j];
+            if (best < 0) {
+                if (!(c < (REAL) 1e20)) break;
+                best = j;
+                bc = c;
+            } else if (c == bc) {
+                if (j < best) best = j;
+            } else {
+                break;
+            }
+        }
+        *bestJ = best;
+    }
+}

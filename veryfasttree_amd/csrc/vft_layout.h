@@ -1,0 +1,55 @@
+// HBM layout of the profile arena.  Everything a sweep streams is stored "tile-transposed":
+// 64 consecutive node ids form a tile, and inside a tile the 64 nodes' values for one alignment column are
+// contiguous, so that a wavefront whose lane l owns node 64*t+l issues one fully coalesced 16-byte-per-lane
+// load per column group while every lane walks its own profile in the reference's column order.
+#pragma once
+#include <stdint.h>
+
+#define VFT_TILE 64        // nodes per tile = wavefront width on gfx950
+#define VFT_CHUNK 16       // alignment columns per 16-byte code chunk
+#define VFT_NOCODE_ 127
+
+#if defined(__HIPCC__)
+#define VFT_HD __host__ __device__ __forceinline__
+#else
+#define VFT_HD inline
+#endif
+
+struct VftDims {
+    int64_t nSeqs, nPos, maxNodes;
+    int32_t nCodes;
+    int32_t nChunk;        // ceil(nPos / 16)
+    int64_t firstProfTile; // nSeqs / 64: first tile that can hold an internal node
+    int64_t nTiles;        // ceil(maxNodes / 64)
+};
+
+// ---- leaf codes: uint4 leafT[tile][chunk][lane]; byte b of the uint4 is column chunk*16+b (encoded, see vft_encode)
+VFT_HD int64_t vft_leaf_idx(const VftDims &d, int64_t tile, int32_t chunk, int32_t lane) {
+    return (tile * d.nChunk + chunk) * VFT_TILE + lane;
+}
+
+// nt leaves are stored as 0x10 | (1 << code) and gaps as 0, so that for two encoded bytes a,b:
+//   (a & b & 0x10) != 0  <=> both present,   (a & b & 0x0F) != 0 <=> same base
+// aa leaves keep the reference code (0..19, 127).
+VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
+    if (nCodes != 4) return code;
+    return code == VFT_NOCODE_ ? 0 : (uint8_t) (0x10 | (1u << code));
+}
+
+// ---- internal profiles (tile index is relative to firstProfTile)
+//   REAL  profW[ptile][pos][lane]
+//   REAL  profF[ptile][pos][group][lane][G]   G = 16 / sizeof(REAL) values per 16-byte group, nCodes/G groups
+//   uint4 profC[ptile][chunk][lane]           raw reference codes, 16 columns per uint4
+VFT_HD int64_t vft_w_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t lane) {
+    return (ptile * d.nPos + pos) * VFT_TILE + lane;
+}
+template <typename REAL> VFT_HD constexpr int vft_group() { return 16 / (int) sizeof(REAL); }
+template <typename REAL>
+VFT_HD int64_t vft_f_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t k, int32_t lane) {
+    const int G = vft_group<REAL>();
+    const int nGroups = d.nCodes / G;
+    return (((ptile * d.nPos + pos) * nGroups + k / G) * VFT_TILE + lane) * G + (k % G);
+}
+VFT_HD int64_t vft_c_idx(const VftDims &d, int64_t ptile, int32_t chunk, int32_t lane) {
+    return (ptile * d.nChunk + chunk) * VFT_TILE + lane;
+}
