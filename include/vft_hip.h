@@ -98,6 +98,8 @@ int vft_set_max_node(vft_ctx *ctx, int64_t maxnode);           /* NJ.h: maxnode,
 /* ---- profiles */
 int vft_profile_upload(vft_ctx *ctx, int64_t node, const void *w, const uint8_t *codes, const void *f);
 int vft_profile_download(vft_ctx *ctx, int64_t node, void *w, uint8_t *codes, void *f);
+/* number of frequency vectors each node holds (Profile::nVectors, NJ.h:137): leaves have none */
+int vft_profile_nvectors(vft_ctx *ctx, int64_t first, int64_t count, int64_t *nvec);
 /* averageProfile (NJ.tcc:2067-2135) for a batch of independent joins: out[k] = avg(a[k], b[k], weight[k]);
    weight < 0 means unweighted (0.5).  Also stores the new node's self-distance/self-weight
    (profileDist(new,new), NJ.tcc:3039-3042) on the device. */

@@ -21,7 +21,7 @@ EXPORTS = [
     "vft_create", "vft_destroy", "vft_last_error", "vft_set_stream", "vft_synchronize", "vft_upload_leaves",
     "vft_set_distance_matrix", "vft_set_transition_matrix", "vft_set_rates", "vft_set_ml_limits", "vft_set_parents",
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_set_max_node",
-    "vft_profile_upload", "vft_profile_download", "vft_average_profiles", "vft_out_profile_full",
+    "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_set_shard", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
     "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms",
@@ -177,6 +177,11 @@ class HipProfileOps:
         f = np.zeros((self.n_pos, self.n_codes), self.dt)
         self._chk(self.lib.vft_profile_download(self.ctx, I64(node), _ptr(w), _ptr(c), _ptr(f)))
         return w, c, f
+
+    def profile_nvectors(self, first, count):
+        out = np.zeros(count, np.int64)
+        self._chk(self.lib.vft_profile_nvectors(self.ctx, I64(first), I64(count), _ptr(out)))
+        return out
 
     def averageProfile(self, out, a, b, bionj_weight=None):
         """NJ.tcc:2067 for a batch: out[k] = average(a[k], b[k])."""

@@ -550,6 +550,35 @@ extern "C" int vft_profile_download(vft_ctx *c, int64_t node, void *w, uint8_t *
 }
 
 template <typename REAL, int NC>
+__global__ void k_nvectors(Arena<REAL> A, int64_t first, int64_t count, int64_t *out) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int64_t v = first + t;
+    int64_t n = 0;
+    if (v >= A.d.nSeqs) {
+        for (int64_t p = 0; p < A.d.nPos; p++) {
+            Col<REAL, NC> c;
+            vft_load_col<REAL, NC>(A, v, p, c);
+            n += c.vec ? 1 : 0;
+        }
+    }
+    out[t] = n;
+}
+
+extern "C" int vft_profile_nvectors(vft_ctx *c, int64_t first, int64_t count, int64_t *nvec) {
+    if (!c || !nvec) return VFT_ERR_INVALID;
+    if (first < 0 || count < 0 || first + count > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "node range out of bounds");
+    if (count == 0) return VFT_OK;
+    if (int r = ensure_scratch(c, (size_t) count * 8)) return r;
+    VFT_DISPATCH(c, launch((k_nvectors<REAL, NC>), dim3(cdiv(count, 64)), dim3(64), 0, c->stream, arena<REAL>(c), first, count,
+                           (int64_t *) c->scratch));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(nvec, c->scratch, (size_t) count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+template <typename REAL, int NC>
 __global__ void k_selfdist(Arena<REAL> A, const int64_t *nodes, int64_t n) {
     const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
