@@ -129,6 +129,9 @@ int vft_sweep(vft_ctx *ctx, int64_t query, int64_t n_active, int64_t n_diff_allo
 /* Restrict sweeps/out-distance passes to node ids [lo, hi): the shard a rank owns in a multi-GPU run
    (default [0, max_nodes)).  Hits keep global ids. */
 int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);
+/* Diagnostics of the last sweep's top-k selection: info[0] = candidates that were rank-sorted, info[1] = extra
+   refinement rounds that were needed (0 in the common case). */
+int vft_sweep_info(vft_ctx *ctx, int64_t info[2]);
 /* The full, unsorted result of the last sweep for ids [first, first+count): what `allhits[]` holds. */
 int vft_sweep_results(vft_ctx *ctx, int64_t first, int64_t count, void *dist, void *weight, void *criterion);
 /* setDistCriterion on an explicit pair list — transferBestHits / uniqueBestHits / getBestFromTopHits

@@ -23,7 +23,7 @@ EXPORTS = [
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_set_shard", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
+    "vft_set_shard", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
     "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms",
 ]
 
@@ -226,6 +226,11 @@ class HipProfileOps:
                                      I32(k), _ptr(hits), P(d_hits) if d_hits else None,
                                      C.byref(best) if want_best else None))
         return hits, best.value
+
+    def sweep_info(self):
+        info = (I64 * 2)()
+        self._chk(self.lib.vft_sweep_info(self.ctx, info))
+        return int(info[0]), int(info[1])
 
     def sweep_results(self, first, count):
         d, w, c = (np.zeros(count, self.dt) for _ in range(3))

@@ -36,16 +36,16 @@ struct vft_ctx {
     uint4 *qEnc[2] = {nullptr, nullptr};
     // sweep outputs
     void *swDist = nullptr, *swWeight = nullptr, *swCrit = nullptr;
-    uint64_t *swKey = nullptr;
-    unsigned long long *partMin = nullptr, *partMax = nullptr;
+    void *partMin = nullptr, *partMax = nullptr;
     int nPart = 0;
     // select scratch
     SelectState *sel = nullptr;
     unsigned int *slices = nullptr;
     uint64_t *candKey = nullptr;
     int32_t *candId = nullptr;
-    void *dHits = nullptr;
-    int64_t *dBest = nullptr;
+    char *dRes = nullptr;    // SelectHeader followed by the k hit records
+    char *hRes = nullptr;    // pinned, device-mapped host mirror of dRes, written by k_select_best (zero-copy)
+    char *hResDev = nullptr; // device address of hRes
     int32_t hitsCap = 0;
     // models
     void *dm[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -159,9 +159,8 @@ static SweepOut<REAL> sweepout(const vft_ctx *c) {
     o.dist = (REAL *) c->swDist;
     o.weight = (REAL *) c->swWeight;
     o.crit = (REAL *) c->swCrit;
-    o.key = c->swKey;
-    o.partMin = c->partMin;
-    o.partMax = c->partMax;
+    o.partMin = (REAL *) c->partMin;
+    o.partMax = (REAL *) c->partMax;
     return o;
 }
 
@@ -252,7 +251,6 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
         CR(dallocb(p, (size_t) N * rs));
         CR(hipMemset(*p, 0, (size_t) N * rs));
     }
-    CR(dalloc(&c->swKey, (size_t) N));
     CR(dallocb(&c->outW, (size_t) d.nPos * rs));
     CR(dallocb(&c->outF, (size_t) d.nPos * d.nCodes * rs));
     CR(dallocb(&c->outCD, (size_t) d.nPos * d.nCodes * rs));
@@ -263,15 +261,17 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
         CR(dalloc(&c->qEnc[q], (size_t) d.nChunk));
     }
     c->nPart = (int) cdiv(N, VFT_WG);
-    CR(dalloc(&c->partMin, (size_t) c->nPart));
-    CR(dalloc(&c->partMax, (size_t) c->nPart));
+    CR(dallocb(&c->partMin, (size_t) c->nPart * 8));
+    CR(dallocb(&c->partMax, (size_t) c->nPart * 8));
     CR(dalloc(&c->sel, 1));
     CR(dalloc(&c->slices, (size_t) VFT_SEL_WGS * VFT_NBINS));
     CR(dalloc(&c->candKey, (size_t) VFT_CAND_CAP));
     CR(dalloc(&c->candId, (size_t) VFT_CAND_CAP));
-    CR(dalloc(&c->dBest, 1));
     c->hitsCap = VFT_CAND_CAP;
-    CR(dallocb(&c->dHits, (size_t) c->hitsCap * sizeof(vft_hit_f64)));
+    CR(dallocb((void **) &c->dRes, sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64)));
+    CR(hipHostMalloc((void **) &c->hRes, sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64), hipHostMallocMapped));
+    CR(hipHostGetDevicePointer((void **) &c->hResDev, c->hRes, 0));
+    memset(c->hRes, 0, sizeof(SelectHeader));
     for (int i = 0; i < 4; i++) CR(dallocb(&c->dm[i], (size_t) 21 * 20 * 8));
     for (int i = 0; i < 6; i++) CR(dallocb(&c->tm[i], (size_t) 21 * 20 * 8));
     CR(dallocb(&c->rates, (size_t) VFT_MAXRATES * 8));
@@ -291,14 +291,6 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     }
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
-    // the final sort of the select pipeline needs more than the default 64 KiB of LDS
-    {
-        const int ldsBytes = VFT_CAND_CAP * 12;
-        CR(hipFuncSetAttribute((const void *) k_select_finish<float, vft_hit_f32>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
-        CR(hipFuncSetAttribute((const void *) k_select_finish<double, vft_hit_f64>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
-    }
 #undef CR
     *out = c;
     return VFT_OK;
@@ -309,12 +301,13 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
     void *ptrs[] = {c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
-                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit, c->swKey,
-                    c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dHits, c->dBest, c->dm[0],
+                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit,
+                    c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
                     c->dm[1], c->dm[2], c->dm[3], c->tm[0], c->tm[1], c->tm[2], c->tm[3], c->tm[4], c->tm[5],
                     c->rates, c->ratecat, c->scratch};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (c->hRes) hipHostFree(c->hRes);
     for (hipEvent_t e : c->kev) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -727,26 +720,28 @@ static void kernel_event(vft_ctx *c) {
 }
 
 template <typename REAL, typename HIT>
-static int run_select(vft_ctx *c, int64_t lo, int64_t hi, int32_t k, int64_t query, bool wantBest) {
-    launch(k_select_range, dim3(1), dim3(1024), 0, c->stream, c->sel, c->partMin, c->partMax, c->nPart);
-    for (int round = 0; round < 8; round++) {
-        launch(k_select_hist, dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, c->swKey, lo, hi, c->sel, c->slices);
-        launch(k_select_thresh, dim3(1), dim3(VFT_NBINS), 0, c->stream, c->sel, c->slices, VFT_SEL_WGS,
-                           (unsigned int) k);
-        launch(k_select_collect, dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, c->swKey, lo, hi, c->sel,
-                           c->candKey, c->candId);
-        launch((k_select_finish<REAL, HIT>), dim3(1), dim3(1024), VFT_CAND_CAP * 12, c->stream, c->sel,
-                           c->candKey, c->candId, (const REAL *) c->swDist, (const REAL *) c->swWeight,
-                           (const REAL *) c->swCrit, k, query, (HIT *) c->dHits, wantBest ? c->dBest : (int64_t *) nullptr);
+static int run_select(vft_ctx *c, int64_t lo, int64_t hi, int32_t k, int64_t query) {
+    SelectHeader *dHdr = (SelectHeader *) c->dRes;
+    HIT *dHits = (HIT *) (c->dRes + sizeof(SelectHeader));
+    launch((k_select_range<REAL>), dim3(1), dim3(1024), 0, c->stream, c->sel, (const REAL *) c->partMin,
+           (const REAL *) c->partMax, c->nPart);
+    for (int round = 0; round <= VFT_MAX_LEVEL; round++) {
+        launch((k_select_hist<REAL>), dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, (const REAL *) c->swCrit, lo, hi,
+               c->sel, c->slices);
+        launch(k_select_thresh, dim3(1), dim3(VFT_NBINS), 0, c->stream, c->sel, c->slices, VFT_SEL_WGS, (unsigned int) k);
+        launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, (const REAL *) c->swCrit, lo, hi,
+               c->sel, c->candKey, c->candId);
+        launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG), dim3(VFT_WG), 0, c->stream, c->sel, c->candKey,
+               c->candId, (const REAL *) c->swDist, (const REAL *) c->swWeight, (const REAL *) c->swCrit, k, dHits);
+        launch((k_select_best<REAL, HIT>), dim3(1), dim3(VFT_WG), 0, c->stream, c->sel, dHits, k, query, dHdr,
+               (SelectHeader *) c->hResDev, (HIT *) (c->hResDev + sizeof(SelectHeader)));
         LAUNCHCHK(c);
-        if (round == 0 && !c->timeKernels) {
-            // common case: no overflow; checked lazily by the caller through sel->overflow after its own sync
-        }
-        SelectState st;
-        HIPCHK(c, hipMemcpyAsync(&st, c->sel, sizeof(st), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!st.overflow) return VFT_OK;
-        if (st.shift == 0 && round > 0) return fail(c, VFT_ERR_STATE, "top-k select: more than %d exactly tied hits", VFT_CAND_CAP);
+        const SelectHeader *h = (const SelectHeader *) c->hRes;
+        if (!h->overflow) return VFT_OK;
+        // rare: the threshold bin alone has more candidates than the rank sort takes; narrow the key range to it
+        if (round == VFT_MAX_LEVEL)
+            return fail(c, VFT_ERR_STATE, "top-k select: more than %d hits tied at the k-th criterion", VFT_CAND_CAP);
         launch(k_select_refine, dim3(1), dim3(1), 0, c->stream, c->sel);
     }
     return fail(c, VFT_ERR_STATE, "top-k select did not converge");
@@ -814,16 +809,24 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     }
     LAUNCHCHK(c);
     if (k == 0) return VFT_OK;
-    // 3. top-k in the reference's sort order
+    // 3. top-k in the reference's sort order; header + hits come back in one pinned copy
+    if (bestJ && k < 2) return fail(c, VFT_ERR_INVALID, "vft_sweep: best_j needs k >= 2");
     int r;
-    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, lo, hi, k, query, bestJ != nullptr);
-    else r = run_select<double, vft_hit_f64>(c, lo, hi, k, query, bestJ != nullptr);
+    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, lo, hi, k, query);
+    else r = run_select<double, vft_hit_f64>(c, lo, hi, k, query);
     if (r) return r;
     const size_t hb = (size_t) k * (c->cfg.precision == 4 ? sizeof(vft_hit_f32) : sizeof(vft_hit_f64));
-    if (dHitsOut) HIPCHK(c, hipMemcpyAsync(dHitsOut, c->dHits, hb, hipMemcpyDeviceToDevice, c->stream));
-    if (hits) HIPCHK(c, hipMemcpyAsync(hits, c->dHits, hb, hipMemcpyDeviceToHost, c->stream));
-    if (bestJ) HIPCHK(c, hipMemcpyAsync(bestJ, c->dBest, 8, hipMemcpyDeviceToHost, c->stream));
-    if (hits || bestJ) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dHitsOut) HIPCHK(c, hipMemcpyAsync(dHitsOut, c->dRes + sizeof(SelectHeader), hb, hipMemcpyDeviceToDevice, c->stream));
+    if (hits) memcpy(hits, c->hRes + sizeof(SelectHeader), hb);
+    if (bestJ) *bestJ = (int64_t) ((const SelectHeader *) c->hRes)->bestJ;
+    return VFT_OK;
+}
+
+extern "C" int vft_sweep_info(vft_ctx *c, int64_t info[2]) {
+    if (!c || !info) return VFT_ERR_INVALID;
+    const SelectHeader *h = (const SelectHeader *) c->hRes;
+    info[0] = h->nCand;
+    info[1] = h->shift;
     return VFT_OK;
 }
 

@@ -77,35 +77,34 @@ struct SweepArgs {
 
 template <typename REAL>
 struct SweepOut {
-    REAL *dist, *weight, *crit;   // [maxNodes], indexed by target id
-    uint64_t *key;                // primary sort key (0xFFFF.. for inactive targets)
-    unsigned long long *partMin;  // [gridDim.x] per-workgroup min / max of the active keys: reduced by
-    unsigned long long *partMax;  // k_select_range, so that the sweep issues no global atomics at all
+    REAL *dist, *weight, *crit;   // [maxNodes], indexed by target id; inactive targets hold the 1e20 sentinel
+    REAL *partMin, *partMax;      // [gridDim.x] per-workgroup min / max criterion of the active targets, reduced
+                                  // by k_select_range: the sweep issues no global atomics at all
 };
 
-// per-workgroup (min,max) of the keys produced by this launch; every thread of the workgroup must call it
-__device__ __forceinline__ void vft_block_minmax(unsigned long long kmin, unsigned long long kmax,
-                                                 unsigned long long *partMin, unsigned long long *partMax) {
-    __shared__ unsigned long long smin[VFT_WG / 64], smax[VFT_WG / 64];
+// per-workgroup (min,max) of the criteria produced by this launch; every thread of the workgroup must call it
+template <typename REAL>
+__device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *partMin, REAL *partMax) {
+    __shared__ REAL smin[VFT_WG / 64], smax[VFT_WG / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
-        kmin = a < kmin ? a : kmin;
-        kmax = b > kmax ? b : kmax;
+        const REAL a = __shfl_xor(cmin, off, 64), b = __shfl_xor(cmax, off, 64);
+        cmin = a < cmin ? a : cmin;
+        cmax = b > cmax ? b : cmax;
     }
     if ((threadIdx.x & 63) == 0) {
-        smin[threadIdx.x >> 6] = kmin;
-        smax[threadIdx.x >> 6] = kmax;
+        smin[threadIdx.x >> 6] = cmin;
+        smax[threadIdx.x >> 6] = cmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < VFT_WG / 64; w++) {
-            kmin = smin[w] < kmin ? smin[w] : kmin;
-            kmax = smax[w] > kmax ? smax[w] : kmax;
+            cmin = smin[w] < cmin ? smin[w] : cmin;
+            cmax = smax[w] > cmax ? smax[w] : cmax;
         }
-        partMin[blockIdx.x] = kmin;
-        partMax[blockIdx.x] = kmax;
+        partMin[blockIdx.x] = cmin;
+        partMax[blockIdx.x] = cmax;
     }
 }
 
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
     const int64_t j = s.lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
     const int lane = (int) (j & 63);
     const int64_t tile = j >> 6;
-    unsigned long long kmin = ~0ull, kmax = 0ull;
+    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
     bool work = j < s.hi;
     if (work) {
         const bool active = A.parent[j] < 0;
@@ -133,7 +132,6 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                 O.dist[j] = (REAL) 1e20;
                 O.crit[j] = (REAL) 1e20;
                 O.weight[j] = 0;
-                O.key[j] = ~0ull;
                 work = false;
             }
         } else {
@@ -221,20 +219,14 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
             O.dist[j] = dist;
             O.weight[j] = weight;
             O.crit[j] = crit;
-            uint64_t key;
-            if (sizeof(REAL) == 4)
-                key = ((uint64_t) vft_order_f32((float) crit) << 32) | (uint64_t) (0xFFFFFFFFu - (uint32_t) j);
-            else
-                key = vft_order_f64((double) crit);
-            O.key[j] = key;
-            kmin = kmax = key;
+            cmin = cmax = crit;
         } else {
             A.outDist[j] = vft_out_distance<REAL>(dist, weight, s.nActive, A.selfweight[j], A.selfdist[j],
                                                   A.diameter[j], s.totdiam);
             A.nOutActive[j] = (int32_t) s.nActive;
         }
     }
-    if (MODE == MODE_CRIT) vft_block_minmax(kmin, kmax, O.partMin, O.partMax);
+    if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
 }
 
 // ------------------------------------------------------------------------------------------------ generic pair
@@ -317,13 +309,12 @@ __global__ void k_out_distances(Arena<REAL> A, const int64_t *ids, int64_t n, Sw
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_generic(Arena<REAL> A, SweepArgs s, SweepOut<REAL> O) {
     const int64_t j = s.lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
-    unsigned long long kmin = ~0ull, kmax = 0ull;
+    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
     if (j < s.hi) {
         if (A.parent[j] >= 0) {
             O.dist[j] = (REAL) 1e20;
             O.crit[j] = (REAL) 1e20;
             O.weight[j] = 0;
-            O.key[j] = ~0ull;
         } else {
             REAL dist, weight;
             vft_pair_generic<REAL, NC>(A, s.query, j, false, dist, weight);
@@ -336,16 +327,10 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_generic(Arena<REAL> A, SweepAr
             O.dist[j] = dist;
             O.weight[j] = weight;
             O.crit[j] = crit;
-            uint64_t key;
-            if (sizeof(REAL) == 4)
-                key = ((uint64_t) vft_order_f32((float) crit) << 32) | (uint64_t) (0xFFFFFFFFu - (uint32_t) j);
-            else
-                key = vft_order_f64((double) crit);
-            O.key[j] = key;
-            kmin = kmax = key;
+            cmin = cmax = crit;
         }
     }
-    vft_block_minmax(kmin, kmax, O.partMin, O.partMax);
+    vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
 }
 
 // setDistCriterion over an explicit pair list.  Out-distances must have been refreshed by k_pairs_refresh first.
@@ -390,54 +375,57 @@ __global__ void k_pairs_stamp(Arena<REAL> A, const int64_t *pi, const int64_t *p
 }
 
 // ------------------------------------------------------------------------------------------------ top-k select
-// The reference sorts all N hits of a sweep and keeps the first 2m (NJ.tcc:3810, 4541).  Here: a linear
-// histogram of the primary keys between their min and max, the bin holding the k-th smallest, a compaction of
-// everything at or below that bin, and a single-workgroup bitonic sort of those few candidates by
-// (key asc, id desc) — the same total order.  No kernel issues more than one global atomic per workgroup
-// (same-address atomics cost ~12 ns each on this chip, MI355X_MICROARCH.md "fanin").
+// The reference sorts all N hits of a sweep and keeps the first 2m (NJ.tcc:3810, 4541).  Here the k best are
+// selected without sorting N records: criteria are mapped monotonically onto a 50-bit fixed-point value
+//     VK(x) = floor((x - min) * 1024 / (max - min) * 2^40)        (monotone in x, equal x -> equal VK)
+// and a radix-1024 select runs on VK from the top digit down: one histogram, the digit that holds the k-th
+// smallest, a compaction of everything at or below it, and a rank sort of those few candidates by
+// (criterion asc, id desc) — the reference's total order.  One round suffices unless more candidates than
+// VFT_CAND_CAP share the threshold digit; then the host narrows to that digit and repeats (rare).
+// No kernel issues more than one global atomic per workgroup (same-address atomics cost ~12 ns each on this
+// chip, MI355X_MICROARCH.md "fanin").
 #define VFT_NBINS 1024
+#define VFT_DIGIT_BITS 10
+#define VFT_VK_FRAC_BITS 40
+#define VFT_MAX_LEVEL 4
 #define VFT_SEL_WGS 128
 #define VFT_CAND_CAP 8192
 
 struct SelectState {
-    unsigned long long lo, hi;   // key range being binned: bin = (key - lo) >> shift; keys < lo are "in"
-    unsigned int shift;
-    unsigned int threshBin;      // bins <= threshBin are collected
+    double lo, scale;            // VK(x) = (x - lo) * scale, scale = 1024 * 2^40 / (max - min) (slightly shrunk)
+    unsigned long long prefix;   // digits chosen so far (VK >> (shift + 10) must equal it to be binned)
+    unsigned int level;          // 0 .. VFT_MAX_LEVEL
+    unsigned int threshBin;      // digits <= threshBin are collected (VFT_NBINS: collect nothing from the range)
     unsigned int nCand;
     unsigned int overflow;
-    unsigned int nBelow;         // #keys in bins < threshBin
-    unsigned int nThresh;        // #keys in threshBin
-    unsigned int nIn;            // #keys < lo (refinement rounds)
+    unsigned int nBelow;         // #values with a smaller digit than threshBin in this round
+    unsigned int nThresh;        // #values in threshBin
+    unsigned int nIn;            // #values below the prefix (already known to be among the k smallest)
     unsigned int pad;
 };
 
-__device__ __forceinline__ unsigned int vft_bin(unsigned long long key, unsigned long long lo, unsigned int shift) {
-    const unsigned long long b = (key - lo) >> shift;
-    return b >= VFT_NBINS ? VFT_NBINS - 1 : (unsigned int) b;
+__device__ __forceinline__ unsigned long long vft_vk(double x, double lo, double scale) {
+    const double y = (x - lo) * scale;
+    const double top = 1125899906842623.0;   // 2^50 - 1
+    return y <= 0.0 ? 0ull : (y >= top ? (unsigned long long) top : (unsigned long long) y);
+}
+__device__ __forceinline__ unsigned int vft_level_shift(unsigned int level) {
+    return (unsigned int) (VFT_VK_FRAC_BITS - VFT_DIGIT_BITS * (int) level);
 }
 
-__device__ __forceinline__ void vft_set_range(SelectState *S, unsigned long long lo, unsigned long long hi) {
-    unsigned int shift = 0;
-    if (hi > lo) {
-        const unsigned long long span = hi - lo;
-        while (shift < 63 && (span >> shift) >= VFT_NBINS) shift++;
-    }
-    S->lo = lo;
-    S->hi = hi;
-    S->shift = shift;
-}
-
-// one workgroup: reduce the sweep's per-workgroup (min,max) partials and set up round one
-__global__ __launch_bounds__(1024) void k_select_range(SelectState *S, const unsigned long long *partMin,
-                                                       const unsigned long long *partMax, int nPart) {
-    __shared__ unsigned long long smin[1024], smax[1024];
-    unsigned long long kmin = ~0ull, kmax = 0ull;
+// one workgroup: reduce the sweep's per-workgroup (min,max) criteria and set up round one
+template <typename REAL>
+__global__ __launch_bounds__(1024) void k_select_range(SelectState *S, const REAL *partMin, const REAL *partMax,
+                                                       int nPart) {
+    __shared__ double smin[1024], smax[1024];
+    double cmin = 1e30, cmax = -1e30;
     for (int t = threadIdx.x; t < nPart; t += 1024) {
-        kmin = partMin[t] < kmin ? partMin[t] : kmin;
-        kmax = partMax[t] > kmax ? partMax[t] : kmax;
+        const double a = (double) partMin[t], b = (double) partMax[t];
+        cmin = a < cmin ? a : cmin;
+        cmax = b > cmax ? b : cmax;
     }
-    smin[threadIdx.x] = kmin;
-    smax[threadIdx.x] = kmax;
+    smin[threadIdx.x] = cmin;
+    smax[threadIdx.x] = cmax;
     __syncthreads();
     for (int off = 512; off > 0; off >>= 1) {
         if ((int) threadIdx.x < off) {
@@ -447,47 +435,77 @@ __global__ __launch_bounds__(1024) void k_select_range(SelectState *S, const uns
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        vft_set_range(S, smin[0], smax[0]);
+        const double lo = smin[0], hi = smax[0];
+        const double span = hi > lo ? hi - lo : 1.0;
+        S->lo = lo;
+        S->scale = 1023.9990234375 * 1099511627776.0 / span;   // (1024 - 2^-10) * 2^40 / span: VK < 2^50
+        S->prefix = 0;
+        S->level = 0;
         S->nCand = 0;
         S->overflow = 0;
         S->nIn = 0;
     }
 }
 
-// refinement (rare): the threshold bin alone holds more candidates than the final sort can take
+// refinement (rare): descend into the threshold digit
 __global__ void k_select_refine(SelectState *S) {
-    const unsigned long long lo = S->lo + ((unsigned long long) S->threshBin << S->shift);
-    unsigned long long hi = lo + ((1ull << S->shift) - 1ull);
-    if (S->threshBin == VFT_NBINS - 1 || hi > S->hi || hi < lo) hi = S->hi;
     S->nIn += S->nBelow;
-    vft_set_range(S, lo, hi);
+    S->prefix = (S->prefix << VFT_DIGIT_BITS) | S->threshBin;
+    S->level += 1;
     S->nCand = 0;
     S->overflow = 0;
 }
 
 // VFT_SEL_WGS workgroups, each writes its own histogram slice (plain stores)
-__global__ __launch_bounds__(VFT_WG) void k_select_hist(const uint64_t *key, int64_t lo, int64_t hi, const SelectState *S,
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_select_hist(const REAL *crit, int64_t lo, int64_t hi, const SelectState *S,
                                                         unsigned int *slices) {
     __shared__ unsigned int lh[VFT_NBINS];
     for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) lh[t] = 0;
     __syncthreads();
-    const unsigned long long klo = S->lo, khi = S->hi;
-    const unsigned int shift = S->shift;
-    for (int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x; j < hi; j += (int64_t) gridDim.x * VFT_WG) {
-        const unsigned long long k = key[j];
-        if (k >= klo && k <= khi) atomicAdd(&lh[vft_bin(k, klo, shift)], 1u);
+    const double vlo = S->lo, scale = S->scale;
+    const unsigned long long prefix = S->prefix;
+    const unsigned int shift = vft_level_shift(S->level);
+    const int64_t stride = (int64_t) gridDim.x * VFT_WG;
+    int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    for (; j + 3 * stride < hi; j += 4 * stride) {   // four independent loads in flight per thread
+        REAL c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = crit[j + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (c[u] < (REAL) 1e20) {
+                const unsigned long long vk = vft_vk((double) c[u], vlo, scale);
+                if ((vk >> (shift + VFT_DIGIT_BITS)) == prefix) atomicAdd(&lh[(vk >> shift) & (VFT_NBINS - 1)], 1u);
+            }
+        }
+    }
+    for (; j < hi; j += stride) {
+        const REAL c = crit[j];
+        if (c < (REAL) 1e20) {
+            const unsigned long long vk = vft_vk((double) c, vlo, scale);
+            if ((vk >> (shift + VFT_DIGIT_BITS)) == prefix) atomicAdd(&lh[(vk >> shift) & (VFT_NBINS - 1)], 1u);
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) slices[(int64_t) blockIdx.x * VFT_NBINS + t] = lh[t];
 }
 
-// one workgroup of VFT_NBINS threads: column sums, scan, the bin that holds the need-th smallest key
+// one workgroup of VFT_NBINS threads: column sums, scan, the digit that holds the need-th smallest value
 __global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(SelectState *S, const unsigned int *slices, int nSlices,
                                                              unsigned int k) {
     __shared__ unsigned int part[VFT_NBINS];
     const int t = threadIdx.x;
     unsigned int mine = 0;
-    for (int w = 0; w < nSlices; w++) mine += slices[(int64_t) w * VFT_NBINS + t];
+    int w = 0;
+    for (; w + 8 <= nSlices; w += 8) {   // eight independent loads in flight per thread
+        unsigned int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = slices[(int64_t) (w + u) * VFT_NBINS + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) mine += v[u];
+    }
+    for (; w < nSlices; w++) mine += slices[(int64_t) w * VFT_NBINS + t];
     part[t] = mine;
     __syncthreads();
     for (int off = 1; off < VFT_NBINS; off <<= 1) {   // inclusive scan
@@ -506,29 +524,33 @@ __global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(SelectState *S, con
         S->nThresh = mine;
     }
     if (t == 0 && need == 0) {   // nothing (more) to pick from this range
-        S->threshBin = 0;
+        S->threshBin = VFT_NBINS;
         S->nBelow = 0;
         S->nThresh = 0;
-        if (total == 0) S->threshBin = VFT_NBINS;   // collect nothing from the range
     }
 }
 
-__global__ __launch_bounds__(VFT_WG) void k_select_collect(const uint64_t *key, int64_t lo, int64_t hi, SelectState *S,
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_select_collect(const REAL *crit, int64_t lo, int64_t hi, SelectState *S,
                                                            uint64_t *candKey, int32_t *candId) {
     __shared__ unsigned int lcount, lbase;
     __shared__ uint64_t lkey[VFT_CAND_CAP / 8];
     __shared__ int32_t lid[VFT_CAND_CAP / 8];
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
-    const unsigned long long klo = S->lo, khi = S->hi;
-    const unsigned int shift = S->shift, tb = S->threshBin;
+    const double vlo = S->lo, scale = S->scale;
+    const unsigned long long prefix = S->prefix;
+    const unsigned int shift = vft_level_shift(S->level), tb = S->threshBin;
     for (int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x; j < hi; j += (int64_t) gridDim.x * VFT_WG) {
-        const unsigned long long k = key[j];
-        if (k == ~0ull || k > khi) continue;
-        if (k < klo || (tb < VFT_NBINS && vft_bin(k, klo, shift) <= tb)) {
+        const REAL c = crit[j];
+        if (!(c < (REAL) 1e20)) continue;
+        const unsigned long long vk = vft_vk((double) c, vlo, scale);
+        const unsigned long long up = vk >> (shift + VFT_DIGIT_BITS);
+        if (up < prefix || (up == prefix && tb < VFT_NBINS && ((vk >> shift) & (VFT_NBINS - 1)) <= tb)) {
             const unsigned int slot = atomicAdd(&lcount, 1u);   // LDS atomic
             if (slot < VFT_CAND_CAP / 8) {
-                lkey[slot] = k;
+                // total-order key of the candidate: criterion ascending (ties resolved by id in the rank sort)
+                lkey[slot] = sizeof(REAL) == 4 ? (uint64_t) vft_order_f32((float) c) : vft_order_f64((double) c);
                 lid[slot] = (int32_t) j;
             }
         }
@@ -552,78 +574,106 @@ __global__ __launch_bounds__(VFT_WG) void k_select_collect(const uint64_t *key, 
     }
 }
 
-// one workgroup: bitonic sort of the candidates by (key asc, id desc), then the first k hits and the argmin.
-// dynamic LDS: VFT_CAND_CAP * (8 + 4) bytes
+// What the host reads back after a sweep: one small block, one copy, one synchronisation.
+struct SelectHeader {
+    unsigned int nCand, overflow, shift, pad;
+    long long bestJ;
+    long long pad2;
+};
+
+// Rank sort of the candidates: a candidate's position in the (criterion asc, id desc) order is the number of
+// candidates that precede it.  n is a few thousand, so the n^2 comparisons are cheap when spread wide: 16 lanes
+// share one candidate (each scans 1/16 of the list, staged through LDS), partial ranks are summed with shuffles.
+// A single-workgroup bitonic sort of the same list takes ~50 us (80 barriers); this takes a few.
+#define VFT_RANK_TILE 2048
+#define VFT_RANK_LANES 16
 template <typename REAL, typename HIT>
-__global__ __launch_bounds__(1024) void k_select_finish(const SelectState *S, const uint64_t *candKey,
+__global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelectState *S, const uint64_t *candKey,
                                                         const int32_t *candId, const REAL *dist, const REAL *weight,
-                                                        const REAL *crit, int32_t k, int64_t query, HIT *hits,
-                                                        int64_t *bestJ) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *sk = (uint64_t *) smem;
-    int32_t *si = (int32_t *) (smem + (size_t) VFT_CAND_CAP * 8);
+                                                        const REAL *crit, int32_t k, HIT *hits) {
+    __shared__ uint64_t sk[VFT_RANK_TILE];
+    __shared__ int32_t si[VFT_RANK_TILE];
     const unsigned int n = S->nCand < VFT_CAND_CAP ? S->nCand : VFT_CAND_CAP;
-    unsigned int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (unsigned int t = threadIdx.x; t < np2; t += 1024) {
-        sk[t] = t < n ? candKey[t] : ~0ull;
-        si[t] = t < n ? candId[t] : -1;
-    }
-    __syncthreads();
-    for (unsigned int size = 2; size <= np2; size <<= 1) {
-        for (unsigned int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (unsigned int t = threadIdx.x; t < np2 / 2; t += 1024) {
-                const unsigned int a = 2 * t - (t & (stride - 1));
-                const unsigned int b = a + stride;
-                const bool up = (a & size) == 0;
-                const uint64_t ka = sk[a], kb = sk[b];
-                const int32_t ia = si[a], ib = si[b];
-                // "a after b" in the target order: larger key, or equal key and smaller id
-                const bool aAfterB = ka > kb || (ka == kb && ia < ib);
-                if (aAfterB == up) {
-                    sk[a] = kb;
-                    sk[b] = ka;
-                    si[a] = ib;
-                    si[b] = ia;
-                }
+    const unsigned int perWg = VFT_WG / VFT_RANK_LANES;
+    if (blockIdx.x * perWg >= (n > (unsigned int) k ? n : (unsigned int) k)) return;   // whole workgroup idle
+    const unsigned int cand = blockIdx.x * perWg + threadIdx.x / VFT_RANK_LANES;
+    const unsigned int sub = threadIdx.x % VFT_RANK_LANES;
+    const bool mine = cand < n;
+    const uint64_t myKey = mine ? candKey[cand] : 0;
+    const int32_t myId = mine ? candId[cand] : 0;
+    unsigned int rank = 0;
+    for (unsigned int base = 0; base < n; base += VFT_RANK_TILE) {
+        __syncthreads();
+        for (unsigned int u = threadIdx.x; u < VFT_RANK_TILE; u += VFT_WG) {
+            sk[u] = base + u < n ? candKey[base + u] : ~0ull;
+            si[u] = base + u < n ? candId[base + u] : -1;
+        }
+        __syncthreads();
+        const unsigned int lim = n - base < VFT_RANK_TILE ? n - base : VFT_RANK_TILE;
+        if (mine) {
+#pragma unroll 8
+            for (unsigned int u = sub; u < lim; u += VFT_RANK_LANES) {
+                const uint64_t ku = sk[u];
+                const int32_t iu = si[u];
+                // u precedes me: smaller key, or equal key and larger id
+                rank += (ku < myKey || (ku == myKey && iu > myId)) ? 1u : 0u;
             }
-            __syncthreads();
         }
     }
-    for (int t = threadIdx.x; t < k; t += 1024) {
+#pragma unroll
+    for (int off = VFT_RANK_LANES / 2; off > 0; off >>= 1) rank += __shfl_xor(rank, off, VFT_RANK_LANES);
+    if (sub != 0) return;
+    if (mine && rank < (unsigned int) k) {
         HIT h;
-        if ((unsigned int) t < n) {
-            const int32_t j = si[t];
-            h.j = j;
-            h.dist = dist[j];
-            h.weight = weight[j];
-            h.criterion = crit[j];
+        h.j = myId;
+        h.dist = dist[myId];
+        h.weight = weight[myId];
+        h.criterion = crit[myId];
+        hits[rank] = h;
+    }
+    if (cand >= n && cand < (unsigned int) k) {   // fewer candidates than requested: empty records
+        HIT h;
+        h.j = -1;
+        h.dist = (REAL) 1e20;
+        h.weight = 0;
+        h.criterion = (REAL) 1e20;
+        hits[cand] = h;
+    }
+}
+
+// bestjoin (NJ.tcc:3625-3637): strict '<' while scanning ids upwards => the smallest id among the minimal criteria,
+// the query itself excluded.  Also publishes header + hits into the host-mapped result block: the host gets its
+// answer with one stream synchronisation and no DMA copy (a 32 KB hipMemcpy D2H goes through SDMA here and costs
+// hundreds of microseconds of latency; zero-copy stores over PCIe cost a few).
+template <typename REAL, typename HIT>
+__global__ __launch_bounds__(VFT_WG) void k_select_best(const SelectState *S, const HIT *hits, int32_t k, int64_t query,
+                                                        SelectHeader *hdr, SelectHeader *hostHdr, HIT *hostHits) {
+    for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = hits[t];
+    if (threadIdx.x != 0) return;
+    const unsigned int n = S->nCand < (unsigned int) k ? S->nCand : (unsigned int) k;
+    long long best = -1;
+    REAL bc = (REAL) 1e20;
+    for (unsigned int t = 0; t < n; t++) {
+        const long long j = (long long) hits[t].j;
+        if (j == query || j < 0) continue;
+        const REAL c = hits[t].criterion;
+        if (best < 0) {
+            if (!(c < (REAL) 1e20)) break;
+            best = j;
+            bc = c;
+        } else if (c == bc) {
+            if (j < best) best = j;
         } else {
-            h.j = -1;
-            h.dist = (REAL) 1e20;
-            h.weight = 0;
-            h.criterion = (REAL) 1e20;
+            break;
         }
-        hits[t] = h;
     }
-    if (threadIdx.x == 0 && bestJ) {
-        // bestjoin (NJ.tcc:3625-3637): strict '<' scanning ids upwards => smallest id among the minimal criteria
-        int64_t best = -1;
-        REAL bc = (REAL) 1e20;
-        for (unsigned int t = 0; t < n; t++) {
-            const int32_t j = si[t];
-            if (j == (int32_t) query) continue;
-            const REAL c = crit[j];
-            if (best < 0) {
-                if (!(c < (REAL) 1e20)) break;
-                best = j;
-                bc = c;
-            } else if (c == bc) {
-                if (j < best) best = j;
-            } else {
-                break;
-            }
-        }
-        *bestJ = best;
-    }
+    SelectHeader h;
+    h.nCand = S->nCand;
+    h.overflow = S->overflow;
+    h.shift = S->level;
+    h.pad = 0;
+    h.bestJ = best;
+    h.pad2 = 0;
+    *hdr = h;
+    *hostHdr = h;
 }
