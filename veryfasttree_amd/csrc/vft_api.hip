@@ -27,6 +27,11 @@ struct vft_ctx {
     // arena
     uint4 *leafT = nullptr, *profC = nullptr;
     void *profW = nullptr, *profF = nullptr;
+    unsigned long long *vecMask = nullptr;
+    // host-side bookkeeping for the packed vector rows: which nodes have been written, and the highest written
+    // lane of every tile (a batch may use the append path only above it)
+    std::vector<uint8_t> written;
+    std::vector<int8_t> tileMaxLane;
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
     void *outW = nullptr, *outF = nullptr, *outCD = nullptr;
@@ -118,6 +123,7 @@ static Arena<REAL> arena(const vft_ctx *c) {
     A.profW = (REAL *) c->profW;
     A.profF = (REAL *) c->profF;
     A.profC = c->profC;
+    A.vecMask = c->vecMask;
     A.parent = c->parent;
     A.diameter = (REAL *) c->diameter;
     A.selfweight = (REAL *) c->selfweight;
@@ -236,6 +242,10 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(dallocb(&c->profF, (size_t) c->nProfTiles * d.nPos * VFT_TILE * d.nCodes * rs));
     CR(dalloc(&c->profC, (size_t) c->nProfTiles * d.nChunk * VFT_TILE));
     CR(hipMemset(c->profW, 0, (size_t) c->nProfTiles * d.nPos * VFT_TILE * rs));
+    CR(dalloc(&c->vecMask, (size_t) c->nProfTiles * d.nPos));
+    CR(hipMemset(c->vecMask, 0, (size_t) c->nProfTiles * d.nPos * 8));
+    c->written.assign((size_t) N, 0);
+    c->tileMaxLane.assign((size_t) d.nTiles, -1);
     CR(hipMemset(c->profC, 0x7F, (size_t) c->nProfTiles * d.nChunk * VFT_TILE * sizeof(uint4)));
     CR(dalloc(&c->parent, (size_t) N));
     CR(dalloc(&c->nOutActive, (size_t) N));
@@ -299,7 +309,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
-    void *ptrs[] = {c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
+    void *ptrs[] = {c->vecMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
                     c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit,
                     c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
@@ -502,6 +512,24 @@ extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
 }
 
 // ---------------------------------------------------------------------------------------------- profiles
+// may `nodes` be written through the append path (phase A + k_commit_vectors) in ONE launch?
+static bool append_safe(const vft_ctx *c, const int64_t *nodes, int64_t n) {
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t v = nodes[k];
+        if (c->written[(size_t) v]) return false;
+        if ((int) c->tileMaxLane[(size_t) (v >> 6)] >= (int) (v & 63)) return false;
+    }
+    return true;
+}
+static void mark_written(vft_ctx *c, const int64_t *nodes, int64_t n) {
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t v = nodes[k];
+        c->written[(size_t) v] = 1;
+        int8_t &m = c->tileMaxLane[(size_t) (v >> 6)];
+        if ((int) (v & 63) > (int) m) m = (int8_t) (v & 63);
+    }
+}
+
 static int internal_ok(vft_ctx *c, int64_t node) {
     if (node < c->d.nSeqs || node >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "node %lld is not an internal node", (long long) node);
     return VFT_OK;
@@ -522,6 +550,7 @@ extern "C" int vft_profile_upload(vft_ctx *c, int64_t node, const void *w, const
                                         (const REAL *) (s + wB))));
     LAUNCHCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    mark_written(c, &node, 1);
     return VFT_OK;
 }
 
@@ -589,25 +618,38 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         if (int r = internal_ok(c, out[k])) return r;
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad child id");
     }
+    // Batches that only append (the NJ join loop) go through in chunks of whole launches; anything that rewrites a
+    // node or lands below a written lane of its tile is written one node per launch (packed rows shift).
+    const bool append = append_safe(c, out, n);
+    const int64_t chunk = append ? 16384 : 1;
+    const size_t rs = c->rs;
+    const size_t stashB = append ? (size_t) chunk * c->d.nPos * c->d.nCodes * rs : 0;
     const size_t idB = (size_t) n * 8;
-    if (int r = ensure_scratch(c, 4 * idB)) return r;
+    if (int r = ensure_scratch(c, 4 * idB + stashB + 256)) return r;
     char *s = (char *) c->scratch;
+    char *stash = s + 4 * idB;
+    stash += (256 - ((uintptr_t) stash & 255)) & 255;
     HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
     if (bionj) HIPCHK(c, hipMemcpyAsync(s + 3 * idB, bionj, idB, hipMemcpyHostToDevice, c->stream));
-    const int64_t maxY = 65535;
-    for (int64_t k0 = 0; k0 < n; k0 += maxY) {
-        const int64_t cnt = n - k0 < maxY ? n - k0 : maxY;
-        VFT_DISPATCH(c, (launch((k_average<REAL, NC>), dim3(cdiv(c->d.nPos, 128), (unsigned) cnt), dim3(128), 0,
-                                            c->stream, arena<REAL>(c), (const int64_t *) s + k0,
-                                            (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
-                                            bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr,
-                                            c->fpostTol)));
+    for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+        const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
+        VFT_DISPATCH(c, {
+            Arena<REAL> A = arena<REAL>(c);
+            const dim3 grid(cdiv(c->d.nPos, 128), (unsigned) cnt);
+            launch((k_average<REAL, NC>), grid, dim3(128), 0, c->stream, A, (const int64_t *) s + k0,
+                   (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
+                   bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr, c->fpostTol,
+                   append ? (REAL *) stash : (REAL *) nullptr);
+            if (append) launch((k_commit_vectors<REAL, NC>), grid, dim3(128), 0, c->stream, A, (const int64_t *) s + k0,
+                               (const REAL *) stash);
+        });
         LAUNCHCHK(c);
     }
-    VFT_DISPATCH(c, (launch((k_selfdist<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream, arena<REAL>(c),
-                                        (const int64_t *) s, n)));
+    mark_written(c, out, n);
+    VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream, arena<REAL>(c),
+                           (const int64_t *) s, n));
     LAUNCHCHK(c);
     // the id lists live in scratch: do not let a later call overwrite them before the kernels have read them
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -674,6 +716,10 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
     }
     if (s.hi <= s.lo) return VFT_OK;
     const int64_t span = s.hi - s.lo;
+    {
+        const int64_t leafEnd = (c->d.nSeqs < s.hi ? c->d.nSeqs : s.hi);
+        s.nLeafWG = leafEnd > s.lo ? (int32_t) ((leafEnd - s.lo) / VFT_WG) : 0;
+    }
     if (c->cfg.n_codes == 4 && !c->hasDm) {
         const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
         if (c->cfg.precision == 4) {
@@ -781,6 +827,10 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     s.nDiffAllow = nDiffAllow;
     s.totdiam = totdiam;
     s.queryIsLeaf = query < c->d.nSeqs ? 1 : 0;
+    {
+        const int64_t leafEnd = (c->d.nSeqs < hi ? c->d.nSeqs : hi);
+        s.nLeafWG = leafEnd > lo ? (int32_t) ((leafEnd - lo) / VFT_WG) : 0;
+    }
     const int64_t span = hi > lo ? hi - lo : 0;
     const unsigned grid = cdiv(span > 0 ? span : 1, VFT_WG);
     c->nPart = (int) grid;
@@ -905,24 +955,34 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
     for (int64_t k = 0; k < n; k++)
         if (int r = internal_ok(c, out[k])) return r;
+    const bool append = append_safe(c, out, n);
+    const int64_t chunk = append ? 16384 : 1;
+    const size_t stashB = append ? (size_t) chunk * c->d.nPos * c->d.nCodes * c->rs : 0;
     const size_t idB = (size_t) n * 8;
-    if (int r = ensure_scratch(c, 5 * idB + 64)) return r;
+    if (int r = ensure_scratch(c, 5 * idB + stashB + 256)) return r;
     char *s = (char *) c->scratch;
+    char *stash = s + 5 * idB;
+    stash += (256 - ((uintptr_t) stash & 255)) & 255;
     HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 3 * idB, len1, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 4 * idB, len2, idB, hipMemcpyHostToDevice, c->stream));
-    const int64_t maxY = 65535;
-    for (int64_t k0 = 0; k0 < n; k0 += maxY) {
-        const int64_t cnt = n - k0 < maxY ? n - k0 : maxY;
-        VFT_DISPATCH(c, (launch((k_posterior<REAL, NC>), dim3(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt),
-                                            dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
-                                            (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
-                                            (const double *) (s + 3 * idB) + k0, (const double *) (s + 4 * idB) + k0,
-                                            c->minLen, c->minRel)));
+    for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+        const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
+        VFT_DISPATCH(c, {
+            Arena<REAL> A = arena<REAL>(c);
+            const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
+            launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, A, (const int64_t *) s + k0,
+                   (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
+                   (const double *) (s + 3 * idB) + k0, (const double *) (s + 4 * idB) + k0, c->minLen, c->minRel,
+                   append ? (REAL *) stash : (REAL *) nullptr);
+            if (append) launch((k_commit_vectors<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, A,
+                               (const int64_t *) s + k0, (const REAL *) stash);
+        });
         LAUNCHCHK(c);
     }
+    mark_written(c, out, n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }

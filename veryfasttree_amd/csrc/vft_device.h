@@ -13,6 +13,7 @@ struct Arena {
     REAL *profW;
     REAL *profF;
     uint4 *profC;
+    unsigned long long *vecMask;
     int32_t *parent;
     REAL *diameter, *selfweight, *selfdist, *outDist;
     int32_t *nOutActive;
@@ -64,8 +65,10 @@ __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node,
         c.code = (int) vft_byte(t, (int) (p & 15));
         c.vec = c.w > 0 && c.code == VFT_NOCODE_;
         if (c.vec) {
+            const unsigned long long mask = A.vecMask[vft_mask_idx(A.d, pt, p)];
+            const int slot = __popcll(mask & ((1ull << lane) - 1ull));
 #pragma unroll
-            for (int k = 0; k < NC; k++) c.f[k] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, lane)];
+            for (int k = 0; k < NC; k++) c.f[k] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, slot)];
         }
     }
 }
@@ -179,6 +182,27 @@ __device__ __forceinline__ REAL vft_criterion(REAL dist, REAL outI, int64_t nOut
     if (nOutI != nActive) oi *= (double) (nActive - 1) / (double) (nOutI - 1);
     if (nOutJ != nActive) oj *= (double) (nActive - 1) / (double) (nOutJ - 1);
     return (REAL) ((double) dist - (oi + oj) / (double) (nActive - 2));
+}
+
+// Wave-uniform, read-only data (the staged query) goes through the scalar cache: a 16/32-byte s_load per column
+// instead of per-lane vector loads.  The constant address space tells the compiler the data cannot change under
+// the kernel, a vector type keeps it from splitting the load into per-lane selects of addresses.
+template <typename REAL> struct UVec4;
+template <> struct UVec4<float> {
+    typedef float __attribute__((ext_vector_type(4))) type;
+};
+template <> struct UVec4<double> {
+    typedef double __attribute__((ext_vector_type(4))) type;
+};
+template <typename REAL>
+__device__ __forceinline__ typename UVec4<REAL>::type vft_uniform_load4(const REAL *p) {
+    typedef const __attribute__((address_space(4))) typename UVec4<REAL>::type *cp_t;
+    return *(cp_t) p;
+}
+template <typename REAL>
+__device__ __forceinline__ REAL vft_uniform_load(const REAL *p) {
+    typedef const __attribute__((address_space(4))) REAL *cp_t;
+    return *(cp_t) p;
 }
 
 // Sort key of a hit: ascending criterion, ties by DESCENDING node id.  Smaller key = earlier.

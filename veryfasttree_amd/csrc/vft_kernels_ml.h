@@ -157,7 +157,8 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
                                                          const int64_t *bN, const double *len1A, const double *len2A,
-                                                         double minLen, double minRel) {
+                                                         double minLen, double minRel,
+                                                         REAL *stash /* non-null: append path */) {
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
     const int64_t k = blockIdx.y;
@@ -316,7 +317,6 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
             }
         }
     }
-    // posterior profiles never use the nt one-hot convention for "code" columns with fractional weight in the
-    // sweep kernels (ML phase has no sweeps), but vft_store_col keeps the arena invariant anyway.
-    vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
+    if (stash) vft_store_col_append<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * NC);
+    else vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
 }

@@ -73,6 +73,8 @@ struct SweepArgs {
     double totdiam;
     int32_t queryIsLeaf;
     int32_t force;       // MODE_OUTDIST: refresh every listed node regardless of staleness
+    int32_t nLeafWG;     // workgroups [0, nLeafWG) of a k_sweep_nt launch see leaf targets only
+    int32_t pad;
 };
 
 template <typename REAL>
@@ -117,7 +119,56 @@ __device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int
     nSame += __popc(x & 0x0F0F0F0Fu) + __popc(y & 0x0F0F0F0Fu) + __popc(z & 0x0F0F0F0Fu) + __popc(w & 0x0F0F0F0Fu);
 }
 
-// Nucleotide, no distance matrix (the -nt default).  NC == 4, dense one-hot frequency vectors, see DESIGN.md.
+// Nucleotide, no distance matrix (the -nt default).  NC == 4.
+// Leaf targets against a PROFILE query (an internal node or the out-profile), workgroups that hold leaves only.
+// A leaf column is a code with weight 1, so its contribution to (top, denom) depends only on (column, code):
+//     code c:  denom += (double) wq,   top += (double) wq * (1.0 - (double) fq[c])     (NJ.tcc:1176-1182, 922-930)
+//     gap:     nothing (adding +0.0 to the running double sums is exact)
+// The 5 x nPos table of those addends is built once per workgroup in LDS; each lane then walks its leaf's columns
+// in the reference's order doing one LDS read and two double adds per column — same bits as evaluating the
+// products per lane, a fifth of the instructions.
+#define VFT_PTILE 256
+template <typename REAL>
+__device__ __forceinline__ void vft_leaf_vs_profile(const Arena<REAL> &A, const QueryBuf<REAL> &Q, int64_t tile, int lane,
+                                                    bool work, double &top, double &denom) {
+    __shared__ double2 tab[VFT_PTILE * 5];
+    const int64_t nPos = A.d.nPos;
+    for (int64_t p0 = 0; p0 < nPos; p0 += VFT_PTILE) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < VFT_PTILE * 5; e += VFT_WG) {
+            const int64_t p = p0 + e / 5;
+            const int c = e % 5;
+            double2 v = make_double2(0.0, 0.0);
+            if (p < nPos && c < 4) {
+                const REAL wq = Q.w[p];
+                if (wq > 0) {
+                    const double wgt = (double) wq;
+                    const double piece = 1.0 - (double) Q.f[p * 4 + c];
+                    v = make_double2(wgt * piece, wgt);
+                }
+            }
+            tab[e] = v;
+        }
+        __syncthreads();
+        if (work) {
+            const int c0 = (int) (p0 / VFT_CHUNK);
+            const int c1 = (int) (((p0 + VFT_PTILE < nPos ? p0 + VFT_PTILE : nPos) + VFT_CHUNK - 1) / VFT_CHUNK);
+            for (int c = c0; c < c1; c++) {
+                const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
+                const double2 *row = tab + (int64_t) (c - c0) * VFT_CHUNK * 5;
+#pragma unroll
+                for (int b = 0; b < VFT_CHUNK; b++) {
+                    // stored byte: 0x10 | one-hot nibble, 0 for a gap -> table column 0..3, or 4 for a gap
+                    const int idx = __ffs((int) (vft_byte(t, b) | 0x10u)) - 1;
+                    const double2 v = row[b * 5 + idx];   // padding columns hold zeros
+                    denom += v.y;
+                    top += v.x;
+                }
+            }
+        }
+    }
+}
+
 template <typename REAL, int MODE>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
     const int64_t j = s.lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
@@ -139,11 +190,18 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                    (int64_t) A.nOutActive[j] != s.nActive;
         }
     }
+    // workgroup-uniform: leaf-only workgroups with a profile query take the LDS-table path
+    const bool tablePath = (int) blockIdx.x < s.nLeafWG && !(MODE == MODE_CRIT && s.queryIsLeaf);
+    double topT = 0, denomT = 0;
+    if (tablePath) vft_leaf_vs_profile<REAL>(A, Q, tile, lane, work, topT, denomT);
     if (work) {
         const int64_t nPos = A.d.nPos;
         const bool targetLeaf = j < A.d.nSeqs;
         REAL dist, weight;
-        if (MODE == MODE_CRIT && s.queryIsLeaf && targetLeaf) {
+        if (tablePath) {
+            weight = (REAL) (denomT > 0 ? denomT : 0.01);
+            dist = (REAL) (denomT > 0 ? topT / denomT : 1.0);
+        } else if (MODE == MODE_CRIT && s.queryIsLeaf && targetLeaf) {
             int nUse = 0, nSame = 0;
             for (int c = 0; c < A.d.nChunk; c++) {
                 const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
@@ -162,15 +220,15 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                     for (int b = 0; b < VFT_CHUNK; b++) {
                         const int64_t p = p0 + b;
                         if (p < nPos) {
-                            const REAL wq = Q.w[p];
+                            const REAL wq = vft_uniform_load<REAL>(Q.w + p);
                             const uint32_t enc = vft_byte(t, b);
                             if (wq > 0 && (enc & 0x10u)) {
                                 // target weight is 1, its vector one-hot: piece = 1 - fq[code] (NJ.tcc:924,930)
                                 const double wgt = (double) wq;
                                 denom += wgt;
-                                const REAL *fq = Q.f + p * 4;
-                                const REAL f01 = (enc & 1u) ? fq[0] : fq[1];
-                                const REAL f23 = (enc & 4u) ? fq[2] : fq[3];
+                                const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
+                                const REAL f01 = (enc & 1u) ? fq.x : fq.y;
+                                const REAL f23 = (enc & 4u) ? fq.z : fq.w;
                                 const REAL fqc = (enc & 3u) ? f01 : f23;
                                 const double piece = 1.0 - (double) fqc;
                                 top += wgt * piece;
@@ -179,30 +237,80 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                     }
                 }
             } else {
+                // internal targets: dense weights + codes, vectors packed per (tile, column) by lane rank
                 const int64_t pt = tile - A.d.firstProfTile;
                 const REAL *wT = A.profW + vft_w_idx(A.d, pt, 0, lane);
-                const REAL *fT = A.profF + vft_f_idx<REAL>(A.d, pt, 0, 0, lane);
+                const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, lane);
+                // masks are wave-uniform and never written by this kernel: read them through the scalar cache
+                typedef const __attribute__((address_space(4))) unsigned long long *smask_t;
+                // (the 64 lanes of a wave share one tile; readfirstlane tells the compiler so)
+                const int64_t ptU = (int64_t) __builtin_amdgcn_readfirstlane((int) pt);
+                const smask_t mT = (smask_t) (A.vecMask + vft_mask_idx(A.d, ptU, 0));
+                const REAL *fT = A.profF + vft_f_idx<REAL>(A.d, pt, 0, 0, 0);
                 constexpr int G = 16 / (int) sizeof(REAL);   // values per 16-byte group
                 constexpr int NG = 4 / G;                    // groups per column (1 for float, 2 for double)
-                for (int64_t p = 0; p < nPos; p++) {
-                    const REAL wt = wT[p * VFT_TILE];
-                    REAL ft[4];
+                for (int c = 0; c < A.d.nChunk; c++) {
+                    const int64_t p0 = (int64_t) c * VFT_CHUNK;
+                    // phase 1: issue every load of this 16-column chunk before touching any result, so that
+                    // ~1.3 KB per lane-row x 16 rows are in flight per wave instead of one row at a time
+                    const uint4 codes = cT[(int64_t) c * VFT_TILE];
+                    REAL wts[VFT_CHUNK];
+                    REAL fts[VFT_CHUNK][4];
+                    bool hv[VFT_CHUNK];
+                    unsigned long long masks[VFT_CHUNK];
 #pragma unroll
-                    for (int g = 0; g < NG; g++)
+                    for (int b = 0; b < VFT_CHUNK; b++) masks[b] = mT[p0 + b < nPos ? p0 + b : nPos - 1];
 #pragma unroll
-                        for (int e = 0; e < G; e++) ft[g * G + e] = fT[((p * NG + g) * VFT_TILE) * G + e];
-                    const REAL wq = Q.w[p];
-                    if (wq > 0 && wt > 0) {
-                        const REAL ww = wq * wt;   // numeric_t product, NJ.tcc:1176
-                        const double wgt = (double) ww;
-                        denom += wgt;
-                        double piece = 1.0;
+                    for (int b = 0; b < VFT_CHUNK; b++) {
+                        const int64_t p = p0 + b < nPos ? p0 + b : nPos - 1;   // clamp: the tail chunk re-reads the last column
+                        const unsigned long long mask = masks[b];
+                        wts[b] = wT[p * VFT_TILE];
+                        hv[b] = (mask >> lane) & 1ull;
+                        const int slot = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (mask >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((unsigned int) mask, 0u));
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const REAL pr = Q.f[p * 4 + k] * ft[k];   // NJ.tcc:935
-                            piece -= (double) pr;
+                        for (int k = 0; k < 4; k++) fts[b][k] = 0;
+                        if (hv[b]) {
+#pragma unroll
+                            for (int g = 0; g < NG; g++)
+#pragma unroll
+                                for (int e = 0; e < G; e++)
+                                    fts[b][g * G + e] = fT[((p * NG + g) * VFT_TILE + slot) * G + e];
                         }
-                        top += wgt * piece;
+                    }
+                    // phase 2: the reference's column loop (NJ.tcc:1172-1183), in order
+#pragma unroll
+                    for (int b = 0; b < VFT_CHUNK; b++) {
+                        const int64_t p = p0 + b;
+                        if (p < nPos) {
+                            const REAL wq = vft_uniform_load<REAL>(Q.w + p);
+                            const REAL wt = wts[b];
+                            if (wq > 0 && wt > 0) {
+                                const REAL ww = wq * wt;   // numeric_t product, NJ.tcc:1176
+                                const double wgt = (double) ww;
+                                denom += wgt;
+                                const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
+                                double piece = 1.0;
+                                if (hv[b]) {
+                                    // NJ.tcc:933-937: piece -= f1[k] * f2[k], numeric_t products
+                                    const REAL p0_ = fq.x * fts[b][0], p1_ = fq.y * fts[b][1];
+                                    const REAL p2_ = fq.z * fts[b][2], p3_ = fq.w * fts[b][3];
+                                    piece -= (double) p0_;
+                                    piece -= (double) p1_;
+                                    piece -= (double) p2_;
+                                    piece -= (double) p3_;
+                                } else {
+                                    // target holds a plain code: 1 - fq[code] (NJ.tcc:922-930; fq is one-hot
+                                    // when the query column is a code too)
+                                    const uint32_t cd = vft_byte(codes, b);
+                                    const REAL f01 = (cd & 1u) ? fq.y : fq.x;
+                                    const REAL f23 = (cd & 1u) ? fq.w : fq.z;
+                                    const REAL fqc = (cd & 2u) ? f23 : f01;
+                                    piece = 1.0 - (double) fqc;
+                                }
+                                top += wgt * piece;
+                            }
+                        }
                     }
                 }
             }

@@ -5,6 +5,9 @@
 #pragma once
 #include "vft_device.h"
 
+// Write one column of one node.  The vectors of a (tile, column) row are packed by lane order, so a write that
+// adds or removes a vector moves the vectors of the higher lanes by one slot.  NOT safe for two nodes of the same
+// tile concurrently: callers either write one node per launch or use the append path below.
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_store_col(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
                                               const REAL *f) {
@@ -14,13 +17,65 @@ __device__ __forceinline__ void vft_store_col(const Arena<REAL> &A, int64_t node
     uint8_t *cb = (uint8_t *) (A.profC + vft_c_idx(A.d, pt, (int) (p >> 4), lane));
     cb[p & 15] = (uint8_t) code;
     const bool vec = w > 0 && code == VFT_NOCODE_;
+    const int64_t mi = vft_mask_idx(A.d, pt, p);
+    const unsigned long long old = A.vecMask[mi];
+    const unsigned long long bit = 1ull << lane;
+    const bool had = (old & bit) != 0;
+    const int slot = __popcll(old & (bit - 1ull));
+    const int nHigher = lane == 63 ? 0 : __popcll(old >> (lane + 1));
+    if (vec && !had) {
+        for (int s = slot + nHigher - 1; s >= slot; s--)
 #pragma unroll
-    for (int k = 0; k < NC; k++) {
-        REAL v = vec ? f[k] : (REAL) 0;
-        // nt: code columns carry the one-hot vector the sweep kernel multiplies with
-        if (NC == 4 && !vec && code != VFT_NOCODE_) v = (k == code) ? (REAL) 1 : (REAL) 0;
-        A.profF[vft_f_idx<REAL>(A.d, pt, p, k, lane)] = v;
+            for (int k = 0; k < NC; k++)
+                A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s + 1)] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s)];
+        A.vecMask[mi] = old | bit;
+    } else if (!vec && had) {
+        for (int s = slot + 1; s <= slot + nHigher; s++)
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s - 1)] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s)];
+        A.vecMask[mi] = old & ~bit;
     }
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) A.profF[vft_f_idx<REAL>(A.d, pt, p, k, slot)] = f[k];
+    }
+}
+
+// Append path, phase A: for nodes that have never been written and sit above every written lane of their tile
+// (the NJ join loop only ever appends: newnode = maxnode++, NJ.tcc:2904).  Any number of such nodes may be written
+// in one launch: weights/codes go to their final place, the mask bit is OR-ed in, the vector is parked in `stash`
+// ([batch][nPos][NC]) until k_commit_vectors knows the final slot.
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_store_col_append(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
+                                                     const REAL *f, REAL *stash) {
+    const int lane = (int) (node & 63);
+    const int64_t pt = (node >> 6) - A.d.firstProfTile;
+    A.profW[vft_w_idx(A.d, pt, p, lane)] = w;
+    uint8_t *cb = (uint8_t *) (A.profC + vft_c_idx(A.d, pt, (int) (p >> 4), lane));
+    cb[p & 15] = (uint8_t) code;
+    if (w > 0 && code == VFT_NOCODE_) {
+        atomicOr(&A.vecMask[vft_mask_idx(A.d, pt, p)], 1ull << lane);
+#pragma unroll
+        for (int k = 0; k < NC; k++) stash[k] = f[k];
+    }
+}
+
+// Append path, phase B: every mask bit of the batch is set, slots are final.
+template <typename REAL, int NC>
+__global__ void k_commit_vectors(Arena<REAL> A, const int64_t *nodes, const REAL *stash) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    const int64_t k = blockIdx.y;
+    const int64_t node = nodes[k];
+    const int lane = (int) (node & 63);
+    const int64_t pt = (node >> 6) - A.d.firstProfTile;
+    const unsigned long long mask = A.vecMask[vft_mask_idx(A.d, pt, p)];
+    if (!((mask >> lane) & 1ull)) return;
+    const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+    const REAL *src = stash + (k * A.d.nPos + p) * NC;
+#pragma unroll
+    for (int q = 0; q < NC; q++) A.profF[vft_f_idx<REAL>(A.d, pt, p, q, slot)] = src[q];
 }
 
 // staging (row-major w[nPos], c[nPos], f[nPos][NC]) -> arena
@@ -99,7 +154,7 @@ __device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *f
 // averageProfile (NJ.tcc:2067-2135): grid.y = join index, threads over columns
 template <typename REAL, int NC>
 __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN,
-                          const double *bionj, double tol) {
+                          const double *bionj, double tol, REAL *stash /* non-null: append path */) {
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
     const int64_t k = blockIdx.y;
@@ -122,7 +177,8 @@ __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
             vft_normalize_freq<REAL, NC>(A, f, tol);
         }
     }
-    vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
+    if (stash) vft_store_col_append<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * NC);
+    else vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
 }
 
 // setCodeDist for one column of the out-profile (NJ.tcc:873-898)

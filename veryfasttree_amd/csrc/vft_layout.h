@@ -37,18 +37,24 @@ VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
 }
 
 // ---- internal profiles (tile index is relative to firstProfTile)
-//   REAL  profW[ptile][pos][lane]
-//   REAL  profF[ptile][pos][group][lane][G]   G = 16 / sizeof(REAL) values per 16-byte group, nCodes/G groups
-//   uint4 profC[ptile][chunk][lane]           raw reference codes, 16 columns per uint4
+//   REAL  profW[ptile][pos][lane]             weights, dense
+//   uint4 profC[ptile][chunk][lane]           raw reference codes, 16 columns per uint4, dense
+//   u64   vecMask[ptile][pos]                 bit l set <=> node 64*tile+l holds a frequency vector at this column
+//   REAL  profF[ptile][pos][group][slot][G]   the vectors of one (tile, column), PACKED: the vector of lane l sits
+//                                             in slot popcount(vecMask & ((1<<l)-1)); G = 16/sizeof(REAL) values
+//                                             per 16-byte group, nCodes/G groups.  A wavefront therefore reads
+//                                             only the vectors that exist (the reference's sparse profiles,
+//                                             NJ.h:126-141) and still reads them as one contiguous run.
+VFT_HD int64_t vft_mask_idx(const VftDims &d, int64_t ptile, int64_t pos) { return ptile * d.nPos + pos; }
 VFT_HD int64_t vft_w_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t lane) {
     return (ptile * d.nPos + pos) * VFT_TILE + lane;
 }
 template <typename REAL> VFT_HD constexpr int vft_group() { return 16 / (int) sizeof(REAL); }
 template <typename REAL>
-VFT_HD int64_t vft_f_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t k, int32_t lane) {
+VFT_HD int64_t vft_f_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t k, int32_t slot) {
     const int G = vft_group<REAL>();
     const int nGroups = d.nCodes / G;
-    return (((ptile * d.nPos + pos) * nGroups + k / G) * VFT_TILE + lane) * G + (k % G);
+    return (((ptile * d.nPos + pos) * nGroups + k / G) * VFT_TILE + slot) * G + (k % G);
 }
 VFT_HD int64_t vft_c_idx(const VftDims &d, int64_t ptile, int32_t chunk, int32_t lane) {
     return (ptile * d.nChunk + chunk) * VFT_TILE + lane;
