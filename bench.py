@@ -25,6 +25,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# small device->host copies (merged hit lists in the multi-GPU path) go through blit kernels instead of the SDMA
+# engines, whose fixed latency is hundreds of microseconds on this platform; must be set before HIP initialises
+os.environ.setdefault("HSA_ENABLE_SDMA", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -86,7 +89,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from veryfasttree_amd import HipProfileOps, synth
-    from veryfasttree_amd.workload import TopHitsState, merge_hits
+    from veryfasttree_amd.workload import TopHitsState, merge_hits, shard_range
 
     n, L = args.n_seqs, args.n_pos
     n_join = n // 4
@@ -97,9 +100,7 @@ def main():
     ops = HipProfileOps(n, L, 4, np.float32, device=local_rank)
     state = TopHitsState(ops, codes, n_join)
     # shard the target id range over the ranks at tile boundaries
-    tiles = (state.maxnode + 63) // 64
-    lo = (tiles * rank // world) * 64
-    hi = min((tiles * (rank + 1) // world) * 64, state.maxnode)
+    lo, hi = shard_range(state.maxnode, rank, world)
     ops.set_shard(lo, hi)
     seeds = []
     leaf_act = state.active[state.active < n]
@@ -159,8 +160,14 @@ def main():
     frac_shard = (hi - lo) / float(state.maxnode)
     alg_launch = alg_bytes * frac_shard
     achieved = alg_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM traffic of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
+    # process): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, bytes per launch
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and (n, L, world) == (1000000, 200, 1):
+        traffic = json.load(open(tpath)).get("k_sweep_nt<float,MODE_CRIT>", {}).get("bytes_per_launch")
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=None, kernel="k_sweep_nt<float,MODE_CRIT>", launches=int(launches),
+                    traffic=traffic, kernel="k_sweep_nt<float,MODE_CRIT>", launches=int(launches),
                     avg_launch_ms=kern_ms, algorithmic_bytes_per_launch=int(alg_launch),
                     moved_bytes_per_launch=int(moved_bytes * frac_shard),
                     achieved_moved_gbs=moved_bytes * frac_shard / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,

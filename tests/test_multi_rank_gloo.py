@@ -1,0 +1,92 @@
+"""The N>1 path on CPU: two gloo ranks shard the target id range of a sweep, each keeps its local top-k in the
+reference's order, the lists are all-gathered and merged — the result must equal the single-rank top-k.
+Per-shard sweeps are produced by the oracle here (no GPU in this suite); on the GPU the same records come from
+vft_sweep(d_hits=...) and the same merge runs (bench.py)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as G
+from oracle import Oracle
+from veryfasttree_amd.backend import HIT_F32
+from veryfasttree_amd.workload import merge_hits, shard_range
+
+
+def _local_topk(crit, dist_, weight, lo, hi, k):
+    orc = Oracle(np.float32)
+    sub = crit[lo:hi]
+    order = orc.sort_hits(sub)
+    order = order[sub[order] < np.float32(1e20)][:k] + lo
+    h = np.zeros(k, HIT_F32)
+    h["j"] = -1
+    h["criterion"] = 1e20
+    h["dist"] = 1e20
+    n = len(order)
+    h["j"][:n] = order
+    h["criterion"][:n] = crit[order]
+    h["dist"][:n] = dist_[order]
+    h["weight"][:n] = weight[order]
+    return h
+
+
+def _worker(rank, world, port, k, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = G.load("wb_nt_f32")
+    key = "mid1.sweep1"
+    crit, dd, ww = d[key + ".crit"], d[key + ".dist"], d[key + ".weight"]
+    lo, hi = shard_range(len(crit), rank, world)
+    mine = _local_topk(crit, dd, ww, lo, hi, k)
+    t_mine = torch.from_numpy(mine.view(np.uint8).copy())
+    t_all = torch.zeros(world * t_mine.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(t_all, t_mine)
+    allh = t_all.numpy().view(HIT_F32).reshape(world, k)
+    merged = merge_hits(list(allh), k)
+    if rank == 0:
+        np.save(out, merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_topk_equals_single_rank(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    k = 24
+    out = str(tmp_path / "merged.npy")
+    mp.spawn(_worker, args=(2, port, k, out), nprocs=2, join=True)
+    merged = np.load(out)
+    d = G.load("wb_nt_f32")
+    key = "mid1.sweep1"
+    crit = d[key + ".crit"]
+    want = d[key + ".sorted_j"]          # the reference's own sort of the whole sweep
+    want = want[crit[want] < np.float32(1e20)][:k]
+    assert np.array_equal(merged["j"][:len(want)], want)
+    assert np.array_equal(merged["criterion"][:len(want)], crit[want])
+
+
+def test_shard_ranges_tile_aligned_and_cover():
+    for maxnode in (1, 63, 64, 65, 1000, 1500000):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = shard_range(maxnode, r, world)
+                assert lo % 64 == 0 and lo == prev and hi >= lo
+                prev = hi
+            assert prev == maxnode
+
+
+def test_merge_breaks_ties_by_descending_id():
+    a = np.zeros(3, HIT_F32)
+    a["j"] = [5, 9, -1]
+    a["criterion"] = [0.5, 0.7, 1e20]
+    b = np.zeros(3, HIT_F32)
+    b["j"] = [70, 64, 66]
+    b["criterion"] = [0.5, 0.5, 0.9]
+    m = merge_hits([a, b], 4)
+    assert list(m["j"]) == [70, 64, 5, 9]

@@ -1,0 +1,213 @@
+// HipOperations<Precision> — the MI355X backend in the reference's own plug-in slot.
+//
+// VeryFastTree selects its vector backend with a template-template parameter:
+//     template<typename Precision, template<class> class Operations> class NeighbourJoining   (src/NeighbourJoining.h:19-22)
+//     Operations<Precision> operations;                                                      (src/NeighbourJoining.h:256)
+// and registers one by instantiating VeyFastTreeImpl<P, XOperations> (src/impl/VeryFastTreeFloatCuda.cpp:1-7) plus an
+// `-ext` branch in src/VeryFastTree.cpp:305-314.  This header is what a maintainer drops next to
+// src/operations/CudaOperations.h: it satisfies the trait of src/operations/BasicOperations.h:16-39 (ALIGNMENT,
+// Allocator, numeric_t and the ten per-vector methods, implemented on the host exactly like BasicOperations because a
+// 4- or 20-element vector is not a GPU-sized unit of work — src/operations/CudaOperations.cu:19-27 shows what happens
+// otherwise) and adds the BATCHED profile operations that the hot loops of NeighbourJoining.tcc are lifted to.
+// Every batched member forwards to the C ABI of include/vft_hip.h; INTEGRATION.md lists the call sites.
+//
+// Host code only (C++11, like the reference).  Links against veryfasttree_amd/lib/libvft_hip.so.
+#ifndef VERYFASTTREE_HIPOPERATIONS_H
+#define VERYFASTTREE_HIPOPERATIONS_H
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vft_hip.h"
+
+namespace veryfasttree {
+
+    template<typename Precision>
+    class HipOperations {
+    public:
+        /* same contract as BasicOperations: no alignment beyond sizeof(Precision) is needed on the host side,
+           the device arena has its own layout (veryfasttree_amd/csrc/vft_layout.h) */
+        static constexpr int ALIGNMENT = sizeof(Precision);
+        using Allocator = std::allocator<Precision>;
+        typedef Precision numeric_t;
+
+        HipOperations() : ctx(nullptr) {}
+
+        ~HipOperations() { if (ctx) vft_destroy(ctx); }
+
+        HipOperations(const HipOperations &) = delete;
+
+        HipOperations &operator=(const HipOperations &) = delete;
+
+        /* ---- the ten primitives of the trait (BasicOperations.tcc:6-120), host side, scalar semantics.
+           They remain for the call sites that are not lifted (NJ.tcc:782, 825-857, 2034-2035, ...). */
+        inline void vector_multiply(numeric_t f1[], numeric_t f2[], int64_t n, numeric_t fOut[]) {
+            for (int64_t i = 0; i < n; i++) fOut[i] = f1[i] * f2[i];
+        }
+
+        inline numeric_t vector_multiply_sum(numeric_t f1[], numeric_t f2[], int64_t n) {
+            numeric_t out = 0.0;
+            for (int64_t i = 0; i < n; i++) out += f1[i] * f2[i];
+            return out;
+        }
+
+        inline numeric_t vector_multiply3_sum(numeric_t f1[], numeric_t f2[], numeric_t f3[], int64_t n) {
+            numeric_t sum = 0.0;
+            for (int64_t i = 0; i < n; i++) sum += f1[i] * f2[i] * f3[i];
+            return sum;
+        }
+
+        inline numeric_t vector_dot_product_rot(numeric_t f1[], numeric_t f2[], numeric_t fBy[], int64_t n) {
+            numeric_t out1 = 0.0, out2 = 0.0;
+            for (int64_t i = 0; i < n; i++) {
+                out1 += f1[i] * fBy[i];
+                out2 += f2[i] * fBy[i];
+            }
+            return out1 * out2;
+        }
+
+        inline void vector_add(numeric_t fTot[], numeric_t fAdd[], int64_t n) {
+            for (int64_t i = 0; i < n; i++) fTot[i] += fAdd[i];
+        }
+
+        inline numeric_t vector_sum(numeric_t f1[], int64_t n) {
+            numeric_t out = 0.0;
+            for (int64_t i = 0; i < n; i++) out += f1[i];
+            return out;
+        }
+
+        inline void vector_multiply_by(numeric_t f[], numeric_t fBy, int64_t n, numeric_t fOut[]) {
+            for (int64_t i = 0; i < n; i++) fOut[i] = f[i] * fBy;
+        }
+
+        inline void vector_add_mult(numeric_t fTot[], numeric_t fAdd[], numeric_t weight, int64_t n) {
+            for (int64_t i = 0; i < n; i++) fTot[i] += fAdd[i] * weight;
+        }
+
+        template<int row>
+        inline void matrix_by_vector4(numeric_t mat[][row], numeric_t vec[], numeric_t out[]) {
+            for (int64_t j = 0; j < 4; j++) {
+                double sum = 0;
+                for (int64_t k = 0; k < 4; k++) sum += vec[k] * mat[k][j];
+                out[j] = sum;
+            }
+        }
+
+        inline void fastexp(numeric_t fTot[], int64_t n, int lvl) {
+            (void) lvl; /* level 0 semantics (BasicOperations.tcc:123-127); the device builds its own P(t) tables */
+            for (int64_t k = 0; k < n; k++) fTot[k] = (numeric_t) std::exp((double) fTot[k]);
+        }
+
+        /* ---- batched extension: device-resident profiles.  Errors surface as std::invalid_argument so that the
+           reference's main() reports them cleanly (main.cpp:673-678 only catches that type). */
+        void configHip(int device, int64_t nSeqs, int64_t nPos, int nCodes, int64_t maxNodes) {
+            vft_config cfg;
+            cfg.device = device;
+            cfg.precision = (int32_t) sizeof(Precision);
+            cfg.n_codes = nCodes;
+            cfg.reserved = 0;
+            cfg.n_seqs = nSeqs;
+            cfg.n_pos = nPos;
+            cfg.max_nodes = maxNodes;
+            if (ctx) vft_destroy(ctx);
+            ctx = nullptr;
+            int rc = vft_create(&ctx, &cfg);
+            if (rc != VFT_OK) {
+                std::string msg = ctx ? vft_last_error(ctx) : "vft_create failed";
+                if (ctx) vft_destroy(ctx);
+                ctx = nullptr;
+                throw std::invalid_argument("HipOperations: " + msg);
+            }
+        }
+
+        bool ready() const { return ctx != nullptr; }
+
+        /* seqsToProfiles (NJ.tcc:382-457): codes[nSeqs][nPos], NOCODE = 127 */
+        void uploadLeaves(const uint8_t *codes) { chk(vft_upload_leaves(ctx, codes)); }
+
+        void setDistanceMatrix(const numeric_t *distances, const numeric_t *codeFreq, const numeric_t *eigenval,
+                               const numeric_t *eigentot) {
+            chk(vft_set_distance_matrix(ctx, distances, codeFreq, eigenval, eigentot));
+        }
+
+        void setTransitionMatrix(const numeric_t *stat, const numeric_t *statinv, const numeric_t *eigenval,
+                                 const numeric_t *codeFreq, const numeric_t *eigeninv, const numeric_t *eigeninvT) {
+            chk(vft_set_transition_matrix(ctx, stat, statinv, eigenval, codeFreq, eigeninv, eigeninvT));
+        }
+
+        void setRates(const numeric_t *rates, int32_t nRates, const int64_t *ratecat) {
+            chk(vft_set_rates(ctx, rates, nRates, ratecat));
+        }
+
+        void setParents(int64_t first, int64_t count, const int64_t *parent) {
+            chk(vft_set_parents(ctx, first, count, parent));
+        }
+
+        void setNodeScalars(int64_t first, int64_t count, const numeric_t *diameter, const numeric_t *selfweight,
+                            const numeric_t *selfdist) {
+            chk(vft_set_node_scalars(ctx, first, count, diameter, selfweight, selfdist));
+        }
+
+        void setMaxNode(int64_t maxnode) { chk(vft_set_max_node(ctx, maxnode)); }
+
+        /* averageProfile + the new node's self distance (NJ.tcc:3008, 3039-3042) */
+        void averageProfiles(int64_t n, const int64_t *out, const int64_t *a, const int64_t *b, const double *bionjWeight) {
+            chk(vft_average_profiles(ctx, n, out, a, b, bionjWeight));
+        }
+
+        /* outProfile / updateOutProfile (NJ.tcc:3012-3036) */
+        void outProfile(int64_t nActive, const int64_t *activeIds) { chk(vft_out_profile_full(ctx, nActive, activeIds)); }
+
+        void updateOutProfile(int64_t old1, int64_t old2, int64_t newNode, int64_t nActiveOld) {
+            chk(vft_out_profile_update(ctx, old1, old2, newNode, nActiveOld));
+        }
+
+        /* setOutDistance over a list (NJ.tcc:257-260, 2897-2898, 4451-4464); ids == nullptr: every active node */
+        void setOutDistances(int64_t n, const int64_t *ids, int64_t nActive, double totdiam) {
+            chk(vft_out_distances(ctx, n, ids, nActive, totdiam));
+        }
+
+        /* setBestHit + psort + the first k hits (NJ.tcc:3801-3811, 3927-3930, 4470-4471) */
+        template<typename HitRecord>
+        void setBestHit(int64_t node, int64_t nActive, int64_t nDiffAllow, double totdiam, int32_t k, HitRecord *hits,
+                        int64_t *bestJ) {
+            static_assert(sizeof(HitRecord) == (sizeof(Precision) == 4 ? sizeof(vft_hit_f32) : sizeof(vft_hit_f64)),
+                          "hit record must be vft_hit_f32 / vft_hit_f64");
+            chk(vft_sweep(ctx, node, nActive, nDiffAllow, totdiam, k, hits, nullptr, bestJ));
+        }
+
+        /* setDistCriterion over a pair list: transferBestHits / uniqueBestHits / getBestFromTopHits
+           (NJ.tcc:4580-4613, 4786-4833, 4267-4298) */
+        void setDistCriterion(int64_t n, const int64_t *i, const int64_t *j, int64_t nActive, int64_t nDiffAllow,
+                              double totdiam, numeric_t *dist, numeric_t *weight, numeric_t *criterion) {
+            chk(vft_pair_distances(ctx, n, i, j, nActive, nDiffAllow, totdiam, dist, weight, criterion));
+        }
+
+        /* pairLogLk for one level of treeLogLk (NJ.tcc:5123) or one Brent evaluation (NJ.tcc:1449-1458) */
+        void pairLogLk(int64_t n, const int64_t *a, const int64_t *b, const double *length, double *loglk,
+                       double *siteLikelihoods) {
+            chk(vft_pair_loglk(ctx, n, a, b, length, loglk, siteLikelihoods));
+        }
+
+        /* posteriorProfile for one level of recomputeMLProfiles (NJ.tcc:3516-3539) */
+        void posteriorProfiles(int64_t n, const int64_t *out, const int64_t *a, const int64_t *b, const double *len1,
+                               const double *len2) {
+            chk(vft_posterior_profiles(ctx, n, out, a, b, len1, len2));
+        }
+
+        vft_ctx *context() { return ctx; }
+
+    private:
+        vft_ctx *ctx;
+
+        void chk(int rc) {
+            if (rc != VFT_OK) throw std::invalid_argument(std::string("HipOperations: ") + vft_last_error(ctx));
+        }
+    };
+}
+
+#endif

@@ -63,12 +63,22 @@ class TopHitsState:
         per_leaf = self.n_pos * 1 + 2 * S + S + 8
         b = leaves * per_leaf + int(len(internal) * (self.n_pos * (S + 1) + 2 * S + S + 8) + int(nvec.sum()) * V)
         phi = float(nvec.mean()) / self.n_pos if len(internal) else 0.0
-        # bytes the current kernels really move per target (dense vectors, codes padded to 16 columns):
-        # reads parent(4) outDist(S) nOutActive(4) diameter(S), writes dist/weight/criterion (3S) + sort key (8)
-        E = 4 + S + 4 + S + 3 * S + 8
-        leaf_bytes = ((self.n_pos + 15) // 16) * 16
-        moved = leaves * (leaf_bytes + E) + len(internal) * (self.n_pos * (S + V) + E)
+        # bytes the kernels really move per target (packed vector rows: only existing vectors are read; codes are
+        # padded to 16 columns; one 8-byte vector mask per 64 targets and column):
+        # epilogue reads parent(4) outDist(S) nOutActive(4) diameter(S), writes dist/weight/criterion (3S)
+        E = 4 + S + 4 + S + 3 * S
+        pad_pos = ((self.n_pos + 15) // 16) * 16
+        moved = leaves * (pad_pos + E) + len(internal) * (self.n_pos * S + pad_pos + self.n_pos // 8 + E) \
+            + int(nvec.sum()) * V
         return b, phi, moved
+
+
+def shard_range(maxnode, rank, world):
+    """Tile-aligned target id range [lo, hi) of `rank` (what vft_set_shard takes)."""
+    tiles = (maxnode + 63) // 64
+    lo = (tiles * rank // world) * 64
+    hi = min((tiles * (rank + 1) // world) * 64, maxnode)
+    return lo, hi
 
 
 def merge_hits(all_hits, k):
