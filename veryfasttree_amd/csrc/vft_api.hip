@@ -219,6 +219,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     d.maxNodes = cfg->max_nodes;
     d.nCodes = cfg->n_codes;
     d.nChunk = (int32_t) ((cfg->n_pos + VFT_CHUNK - 1) / VFT_CHUNK);
+    d.nPosPad = (int64_t) d.nChunk * VFT_CHUNK;
     d.firstProfTile = cfg->n_seqs / VFT_TILE;
     d.nTiles = (cfg->max_nodes + VFT_TILE - 1) / VFT_TILE;
     c->nLeafTiles = (cfg->n_seqs + VFT_TILE - 1) / VFT_TILE;
@@ -238,12 +239,12 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
     CR(dalloc(&c->leafT, (size_t) c->nLeafTiles * d.nChunk * VFT_TILE));
-    CR(dallocb(&c->profW, (size_t) c->nProfTiles * d.nPos * VFT_TILE * rs));
-    CR(dallocb(&c->profF, (size_t) c->nProfTiles * d.nPos * VFT_TILE * d.nCodes * rs));
+    CR(dallocb(&c->profW, (size_t) c->nProfTiles * d.nPosPad * VFT_TILE * rs));
+    CR(dallocb(&c->profF, (size_t) c->nProfTiles * d.nPosPad * VFT_TILE * d.nCodes * rs));
     CR(dalloc(&c->profC, (size_t) c->nProfTiles * d.nChunk * VFT_TILE));
-    CR(hipMemset(c->profW, 0, (size_t) c->nProfTiles * d.nPos * VFT_TILE * rs));
-    CR(dalloc(&c->vecMask, (size_t) c->nProfTiles * d.nPos));
-    CR(hipMemset(c->vecMask, 0, (size_t) c->nProfTiles * d.nPos * 8));
+    CR(hipMemset(c->profW, 0, (size_t) c->nProfTiles * d.nPosPad * VFT_TILE * rs));
+    CR(dalloc(&c->vecMask, (size_t) c->nProfTiles * d.nPosPad));
+    CR(hipMemset(c->vecMask, 0, (size_t) c->nProfTiles * d.nPosPad * 8));
     c->written.assign((size_t) N, 0);
     c->tileMaxLane.assign((size_t) d.nTiles, -1);
     CR(hipMemset(c->profC, 0x7F, (size_t) c->nProfTiles * d.nChunk * VFT_TILE * sizeof(uint4)));

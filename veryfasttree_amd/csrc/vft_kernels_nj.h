@@ -193,7 +193,10 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
     // workgroup-uniform: leaf-only workgroups with a profile query take the LDS-table path
     const bool tablePath = (int) blockIdx.x < s.nLeafWG && !(MODE == MODE_CRIT && s.queryIsLeaf);
     double topT = 0, denomT = 0;
-    if (tablePath) vft_leaf_vs_profile<REAL>(A, Q, tile, lane, work, topT, denomT);
+    if (tablePath) {
+        // a workgroup with nothing to do (all targets inactive, or no stale out-distance) skips the table build
+        if (__syncthreads_or(work ? 1 : 0)) vft_leaf_vs_profile<REAL>(A, Q, tile, lane, work, topT, denomT);
+    }
     if (work) {
         const int64_t nPos = A.d.nPos;
         const bool targetLeaf = j < A.d.nSeqs;
@@ -252,17 +255,18 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                 for (int c = 0; c < A.d.nChunk; c++) {
                     const int64_t p0 = (int64_t) c * VFT_CHUNK;
                     // phase 1: issue every load of this 16-column chunk before touching any result, so that
-                    // ~1.3 KB per lane-row x 16 rows are in flight per wave instead of one row at a time
+                    // ~1.3 KB per lane-row x 16 rows are in flight per wave instead of one row at a time.
+                    // Columns beyond nPos exist in the arena (stride nPosPad) with weight 0 and mask 0.
                     const uint4 codes = cT[(int64_t) c * VFT_TILE];
                     REAL wts[VFT_CHUNK];
                     REAL fts[VFT_CHUNK][4];
                     bool hv[VFT_CHUNK];
                     unsigned long long masks[VFT_CHUNK];
 #pragma unroll
-                    for (int b = 0; b < VFT_CHUNK; b++) masks[b] = mT[p0 + b < nPos ? p0 + b : nPos - 1];
+                    for (int b = 0; b < VFT_CHUNK; b++) masks[b] = mT[p0 + b];
 #pragma unroll
                     for (int b = 0; b < VFT_CHUNK; b++) {
-                        const int64_t p = p0 + b < nPos ? p0 + b : nPos - 1;   // clamp: the tail chunk re-reads the last column
+                        const int64_t p = p0 + b;
                         const unsigned long long mask = masks[b];
                         wts[b] = wT[p * VFT_TILE];
                         hv[b] = (mask >> lane) & 1ull;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                                                __builtin_amdgcn_mbcnt_lo((unsigned int) mask, 0u));
 #pragma unroll
                         for (int k = 0; k < 4; k++) fts[b][k] = 0;
-                        if (hv[b]) {
+                        if (hv[b]) {   // (unconditional loads from a clamped slot measured slower: +8 %)
 #pragma unroll
                             for (int g = 0; g < NG; g++)
 #pragma unroll
@@ -278,39 +282,34 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                                     fts[b][g * G + e] = fT[((p * NG + g) * VFT_TILE + slot) * G + e];
                         }
                     }
-                    // phase 2: the reference's column loop (NJ.tcc:1172-1183), in order
+                    // phase 2: the reference's column loop (NJ.tcc:1172-1183), in order and branch-free:
+                    // a column that the reference skips (a weight <= 0) adds +0.0 to both double sums, which is
+                    // exact; a lane without a vector multiplies zeros in the vector formula and takes the code one.
 #pragma unroll
                     for (int b = 0; b < VFT_CHUNK; b++) {
                         const int64_t p = p0 + b;
-                        if (p < nPos) {
-                            const REAL wq = vft_uniform_load<REAL>(Q.w + p);
-                            const REAL wt = wts[b];
-                            if (wq > 0 && wt > 0) {
-                                const REAL ww = wq * wt;   // numeric_t product, NJ.tcc:1176
-                                const double wgt = (double) ww;
-                                denom += wgt;
-                                const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
-                                double piece = 1.0;
-                                if (hv[b]) {
-                                    // NJ.tcc:933-937: piece -= f1[k] * f2[k], numeric_t products
-                                    const REAL p0_ = fq.x * fts[b][0], p1_ = fq.y * fts[b][1];
-                                    const REAL p2_ = fq.z * fts[b][2], p3_ = fq.w * fts[b][3];
-                                    piece -= (double) p0_;
-                                    piece -= (double) p1_;
-                                    piece -= (double) p2_;
-                                    piece -= (double) p3_;
-                                } else {
-                                    // target holds a plain code: 1 - fq[code] (NJ.tcc:922-930; fq is one-hot
-                                    // when the query column is a code too)
-                                    const uint32_t cd = vft_byte(codes, b);
-                                    const REAL f01 = (cd & 1u) ? fq.y : fq.x;
-                                    const REAL f23 = (cd & 1u) ? fq.w : fq.z;
-                                    const REAL fqc = (cd & 2u) ? f23 : f01;
-                                    piece = 1.0 - (double) fqc;
-                                }
-                                top += wgt * piece;
-                            }
-                        }
+                        const REAL wq = vft_uniform_load<REAL>(Q.w + p);
+                        const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
+                        const REAL wt = wts[b];
+                        const REAL ww = wq * wt;   // numeric_t product, NJ.tcc:1176
+                        const double wgt = (wq > 0 && wt > 0) ? (double) ww : 0.0;
+                        // NJ.tcc:933-937: piece = 1 - sum f1[k] * f2[k], numeric_t products, double subtractions
+                        const REAL q0 = fq.x * fts[b][0], q1 = fq.y * fts[b][1];
+                        const REAL q2 = fq.z * fts[b][2], q3 = fq.w * fts[b][3];
+                        double pieceV = 1.0 - (double) q0;
+                        pieceV -= (double) q1;
+                        pieceV -= (double) q2;
+                        pieceV -= (double) q3;
+                        // target holds a plain code: 1 - fq[code] (NJ.tcc:922-930; fq is one-hot when the query
+                        // column is a code too)
+                        const uint32_t cd = vft_byte(codes, b);
+                        const REAL f01 = (cd & 1u) ? fq.y : fq.x;
+                        const REAL f23 = (cd & 1u) ? fq.w : fq.z;
+                        const REAL fqc = (cd & 2u) ? f23 : f01;
+                        const double pieceC = 1.0 - (double) fqc;
+                        const double piece = hv[b] ? pieceV : pieceC;
+                        denom += wgt;
+                        top += wgt * piece;
                     }
                 }
             }

@@ -19,6 +19,8 @@ struct VftDims {
     int64_t nSeqs, nPos, maxNodes;
     int32_t nCodes;
     int32_t nChunk;        // ceil(nPos / 16)
+    int64_t nPosPad;       // nChunk * 16: column stride of the internal-profile arrays; padding columns keep
+                           // weight 0 / mask 0, so kernels may run whole chunks without bounds checks
     int64_t firstProfTile; // nSeqs / 64: first tile that can hold an internal node
     int64_t nTiles;        // ceil(maxNodes / 64)
 };
@@ -45,16 +47,16 @@ VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
 //                                             per 16-byte group, nCodes/G groups.  A wavefront therefore reads
 //                                             only the vectors that exist (the reference's sparse profiles,
 //                                             NJ.h:126-141) and still reads them as one contiguous run.
-VFT_HD int64_t vft_mask_idx(const VftDims &d, int64_t ptile, int64_t pos) { return ptile * d.nPos + pos; }
+VFT_HD int64_t vft_mask_idx(const VftDims &d, int64_t ptile, int64_t pos) { return ptile * d.nPosPad + pos; }
 VFT_HD int64_t vft_w_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t lane) {
-    return (ptile * d.nPos + pos) * VFT_TILE + lane;
+    return (ptile * d.nPosPad + pos) * VFT_TILE + lane;
 }
 template <typename REAL> VFT_HD constexpr int vft_group() { return 16 / (int) sizeof(REAL); }
 template <typename REAL>
 VFT_HD int64_t vft_f_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t k, int32_t slot) {
     const int G = vft_group<REAL>();
     const int nGroups = d.nCodes / G;
-    return (((ptile * d.nPos + pos) * nGroups + k / G) * VFT_TILE + slot) * G + (k % G);
+    return (((ptile * d.nPosPad + pos) * nGroups + k / G) * VFT_TILE + slot) * G + (k % G);
 }
 VFT_HD int64_t vft_c_idx(const VftDims &d, int64_t ptile, int32_t chunk, int32_t lane) {
     return (ptile * d.nChunk + chunk) * VFT_TILE + lane;
