@@ -81,6 +81,7 @@ BLACKBOX_CASES = [
     ("bb_nt_c1", ["-nt", "-fastest"], 16, 100, 4, 0.05, 0.0, 1),  # BASELINE config 1
     ("bb_nt_200", ["-nt"], 200, 120, 4, 0.05, 0.02, 21),
     ("bb_nt_600_fastest", ["-nt", "-fastest"], 600, 100, 4, 0.04, 0.02, 22),
+    ("bb_nt_600_fastest_no2nd", ["-nt", "-fastest", "-no2nd"], 600, 100, 4, 0.04, 0.02, 22),
     ("bb_nt_1500", ["-nt"], 1500, 80, 4, 0.03, 0.01, 23),
 ]
 

@@ -1,0 +1,33 @@
+"""Join order of the host NJ driver running on the HIP backend, against the reference's `Join` lines
+(integer join order bit-exact: the north star's NJ-phase parity bar)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from test_nj_driver_cpu import unique_codes
+from veryfasttree_amd.nj_driver import NJDriver
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,fastest,limit", [("bb_nt_c1", True, None), ("bb_nt_200", False, None),
+                                                ("bb_nt_600_fastest_no2nd", True, None),
+                                                ("bb_nt_1500", False, None)])
+def test_join_order_matches_reference_on_gpu(name, fastest, limit):
+    from veryfasttree_amd import HipProfileOps
+    d = G.load(name)
+    codes = unique_codes(d["codes"])
+    ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+    drv = NJDriver(ops, codes, fastest=fastest)
+    if fastest:
+        drv.tophits_refresh = 0.5   # main.cpp:339-343: -fastest
+    joins = drv.run(max_joins=limit)
+    want = d["joins"][:len(joins)]
+    got = np.array([(a, b, c) for a, b, c, _ in joins], dtype=np.int64)
+    assert len(got) == len(d["joins"]) or limit is not None
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, "first differing join %d: got %s want %s" % (bad[0], got[bad[0]], want[bad[0]])
+    # criteria printed by the reference with %.6f
+    crit = np.array([c for _, _, _, c in joins])
+    assert np.allclose(crit, d["join_criterion"][:len(joins)], atol=1e-6)
+    ops.close()
