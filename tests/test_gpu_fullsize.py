@@ -1,0 +1,97 @@
+"""Full-size GPU checks at BASELINE.json's configurations through size-independent properties, plus spot checks
+against the oracle on sampled pairs (the oracle cannot sweep 10^5..10^6 targets in seconds)."""
+import numpy as np
+import pytest
+
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(n, L, seed, mu=0.03, gap=0.01):
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.workload import TopHitsState
+    codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
+    ops = HipProfileOps(n, L, 4, np.float32)
+    return codes, ops, TopHitsState(ops, codes, n // 4)
+
+
+@pytest.mark.parametrize("n,L,seed", [(100000, 500, 3), (1000000, 200, 4)])   # BASELINE configs C3 and C4
+def test_sweep_properties_at_full_size(n, L, seed):
+    from veryfasttree_amd.workload import merge_hits, shard_range
+    codes, ops, st = _state(n, L, seed)
+    orc = Oracle(np.float32)
+    m = int(0.5 + np.sqrt(n))
+    k = 2 * m
+    rng = np.random.default_rng(seed)
+    leaf_q = int(st.active[st.active < n][rng.integers(0, 1000)])
+    int_q = int(st.active[st.active >= n][rng.integers(0, 1000)])
+    for q in (leaf_q, int_q):
+        hits, best = ops.setBestHit(q, st.n_active, st.n_diff_allow, st.totdiam, k)
+        dist, weight, crit = ops.sweep_results(0, st.maxnode)
+        # 1. inactive targets carry the sentinel, active ones do not
+        inactive = st.parent < 0
+        assert np.all(crit[~inactive] == np.float32(1e20)) and np.all(crit[inactive] < np.float32(1e20))
+        # 2. the k hits are exactly the k smallest under (criterion asc, id desc), in that order
+        ids = np.nonzero(inactive)[0]
+        order = ids[np.lexsort((-ids, crit[ids]))][:k]
+        assert np.array_equal(hits["j"], order)
+        assert np.array_equal(hits["criterion"], crit[order]) and np.array_equal(hits["dist"], dist[order])
+        # 3. bestjoin = smallest id among the minimal criteria, the query excluded
+        others = ids[ids != q]
+        cmin = crit[others].min()
+        assert best == others[crit[others] == cmin].min()
+        # 4. the pair-list path (transferBestHits) gives the same numbers as the sweep for the same pairs
+        sample = rng.choice(ids, 4096, replace=False)
+        d2, w2, c2 = ops.setDistCriterion(np.full(len(sample), q), sample, st.n_active, st.n_diff_allow, st.totdiam)
+        assert np.array_equal(d2, dist[sample]) and np.array_equal(w2, weight[sample]) and np.array_equal(c2, crit[sample])
+        # 5. symmetry: dist(q, j) == dist(j, q)
+        d3, w3, _ = ops.setDistCriterion(sample, np.full(len(sample), q), st.n_active, st.n_diff_allow, st.totdiam)
+        assert np.array_equal(d3, d2) and np.array_equal(w3, w2)
+        # 6. oracle spot check on 64 sampled targets (leaf and internal)
+        pq = ops.profile_download(q)
+        diam = ops.get_node_scalars(0, st.maxnode)[0]
+        for j in sample[:64]:
+            j = int(j)
+            if q < n and j < n:
+                od, ow = orc.seqdist(codes[q], codes[j], 4)
+            else:
+                od, ow = orc.profiledist(pq, ops.profile_download(j))
+                od = np.float32(od - np.float32(diam[q] + diam[j]))
+            assert od == dist[j] and ow == weight[j], (q, j)
+        # 7. sharding: per-shard top-k merged == unsharded top-k (what the multi-GPU path relies on)
+        parts = []
+        for r in range(4):
+            lo, hi = shard_range(st.maxnode, r, 4)
+            ops.set_shard(lo, hi)
+            h, _ = ops.setBestHit(q, st.n_active, st.n_diff_allow, st.totdiam, k, want_best=False)
+            parts.append(h)
+        ops.set_shard(0, st.maxnode)
+        merged = merge_hits(parts, k)
+        assert np.array_equal(merged["j"], hits["j"]) and np.array_equal(merged["criterion"], hits["criterion"])
+    # 8. self distance of a leaf is 0 with weight = ungapped columns
+    some = st.active[st.active < n][:256]
+    d, w, _ = ops.setDistCriterion(some, some, st.n_active, st.n_diff_allow, st.totdiam)
+    assert np.all(d == 0) and np.array_equal(w, (codes[some] != 127).sum(1).astype(np.float32))
+    ops.close()
+
+
+def test_join_then_sweep_round_trip_at_c3_size():
+    """averageProfile -> out-profile update -> sweep from the new node: idempotent under re-evaluation, and the
+    joined children disappear from the hit list."""
+    n, L = 100000, 500
+    codes, ops, st = _state(n, L, 33)
+    a, b = int(st.active[10]), int(st.active[11])
+    new = st.maxnode
+    ops.set_max_node(new + 1)
+    ops.averageProfile([new], [a], [b])
+    ops.set_parents(a, [new]); ops.set_parents(b, [new])
+    ops.updateOutProfile(a, b, new, st.n_active)
+    ops.set_out_distances(new, np.zeros(1, np.float32), [10 * n])
+    n_active = st.n_active - 1
+    h1, b1 = ops.setBestHit(new, n_active, int(n_active * 0.01), st.totdiam, 600)
+    h2, b2 = ops.setBestHit(new, n_active, int(n_active * 0.01), st.totdiam, 600)
+    assert np.array_equal(h1, h2) and b1 == b2
+    assert a not in h1["j"] and b not in h1["j"] and new in h1["j"]
+    assert np.all(np.diff(h1["criterion"]) >= 0)
+    ops.close()
