@@ -1,0 +1,37 @@
+/*
+ * vft_host.h — C entry point of the C++ host NJ driver (veryfasttree_amd/host/NJDriver.h), for callers that are not
+ * C++ (tests, bench).  The driver itself is what a VeryFastTree build with `-ext HIP` would run in place of
+ * NeighbourJoining::fastNJ (src/NeighbourJoining.tcc:2796-3155); it only talks to the device through vft_hip.h.
+ */
+#ifndef VFT_HOST_H
+#define VFT_HOST_H
+#include "vft_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t fastest;            /* -fastest (main.cpp:339-343): also sets tophits_refresh = 0.5 in the caller */
+    int32_t reserved;
+    double tophits_mult;        /* Options::tophitsMult      (1.0) */
+    double tophits_close;       /* Options::tophitsClose     (-1 = log2N/(log2N+2)) */
+    double tophits_refresh;     /* Options::tophitsRefresh   (0.8) */
+    double topvisible_mult;     /* Options::topvisibleMult   (1.5) */
+    double stale_out_limit;     /* Options::staleOutLimit    (0.01) */
+    double f_reset_out_profile; /* Options::fResetOutProfile (0.02) */
+    int32_t n_reset_out_profile;/* Options::nResetOutProfile (200) */
+    int32_t reserved2;
+} vft_nj_options;
+
+/* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
+   joins: up to n_seqs-3 rows of (i, j, newnode) with i < j, in join order; criterion[k] = the join's criterion.
+   max_joins < 0 means all.  Returns VFT_OK or an error code; err (may be NULL) receives the message. */
+int vft_nj_run(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos, int32_t precision,
+               const vft_nj_options *opt, int64_t max_joins, int64_t *joins, double *criterion, int64_t *n_joins,
+               char *err, int32_t err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

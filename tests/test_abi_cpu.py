@@ -31,6 +31,16 @@ def test_header_symbols_are_exported(lib):
     assert not missing, missing
 
 
+def test_host_driver_library_exports_its_header(lib):
+    from veryfasttree_amd import backend
+    host = backend.load_host_library()
+    text = open(os.path.join(ROOT, "include", "vft_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vft_nj_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(backend.HOST_EXPORTS)
+    assert all(hasattr(host, n) for n in names)
+
+
 def test_python_binding_lists_every_symbol():
     from veryfasttree_amd import backend
     assert sorted(backend.EXPORTS) == declared_symbols()

@@ -31,3 +31,21 @@ def test_join_order_matches_reference_on_gpu(name, fastest, limit):
     crit = np.array([c for _, _, _, c in joins])
     assert np.allclose(crit, d["join_criterion"][:len(joins)], atol=1e-6)
     ops.close()
+
+
+@pytest.mark.parametrize("name,fastest", [("bb_nt_c1", True), ("bb_nt_200", False), ("bb_nt_600_fastest_no2nd", True),
+                                          ("bb_nt_1500", False)])
+def test_cpp_host_driver_join_order_on_gpu(name, fastest):
+    """The C++ host driver (veryfasttree_amd/host/NJDriver.h through include/vft_host.h) over the C ABI."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_run
+    d = G.load(name)
+    codes = unique_codes(d["codes"])
+    ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+    joins, crit = nj_run(ops, codes, fastest=fastest)
+    want = d["joins"]
+    assert len(joins) == len(want)
+    bad = np.nonzero((joins != want).any(axis=1))[0]
+    assert len(bad) == 0, "first differing join %d: got %s want %s" % (bad[0], joins[bad[0]], want[bad[0]])
+    assert np.allclose(crit, d["join_criterion"], atol=1e-6)
+    ops.close()

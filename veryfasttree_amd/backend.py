@@ -40,7 +40,49 @@ class _Config(C.Structure):
 HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32), ("criterion", np.float32)])
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
+HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
+HOST_EXPORTS = ["vft_nj_run"]
+
+
+class _NJOptions(C.Structure):
+    _fields_ = [("fastest", I32), ("reserved", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
+                ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
+                ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("reserved2", I32)]
+
+
 _lib = None
+_host_lib = None
+
+
+def load_host_library():
+    """libvft_host.so: the C++ host NJ driver (include/vft_host.h)."""
+    global _host_lib
+    if _host_lib is None:
+        load_library()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise VftError("host driver %s is missing: run build()" % HOST_LIB_PATH)
+        _host_lib = C.CDLL(HOST_LIB_PATH)
+    return _host_lib
+
+
+def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None):
+    """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n])."""
+    lib = load_host_library()
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, L = codes.shape
+    opt = _NJOptions(1 if fastest else 0, 0, 1.0, -1.0,
+                     tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
+                     200, 0)
+    joins = np.zeros((max(n - 3, 1), 3), np.int64)
+    crit = np.zeros(max(n - 3, 1), np.float64)
+    nj = I64(0)
+    err = C.create_string_buffer(512)
+    rc = lib.vft_nj_run(ops.ctx, _ptr(codes), I64(n), I64(L), I32(ops.dt.itemsize), C.byref(opt), I64(max_joins),
+                        _ptr(joins), _ptr(crit), C.byref(nj), err, I32(512))
+    if rc != 0:
+        raise VftError(err.value.decode() or "vft_nj_run failed")
+    return joins[:nj.value], crit[:nj.value]
+
 
 
 def load_library():

@@ -13,6 +13,20 @@ HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_prof
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
+HOST_LIB = os.path.join(HERE, "lib", "libvft_host.so")
+HOST_SOURCES = [os.path.join(HERE, "host", "nj_driver.cpp")]
+HOST_DEPS = HOST_SOURCES + [os.path.join(HERE, "host", "NJDriver.h"), os.path.join(HERE, "..", "include", "vft_host.h")]
+
+
+def build_host(force=False):
+    """The C++ host driver: plain g++, links against the HIP library next to it."""
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in HOST_DEPS + [LIB]):
+        return HOST_LIB
+    subprocess.run(["g++", "-O2", "-std=c++11", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB] + HOST_SOURCES +
+                   ["-L" + os.path.dirname(LIB), "-lvft_hip", "-Wl,-rpath,$ORIGIN"], check=True)
+    return HOST_LIB
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -22,11 +36,11 @@ def needs_build():
 
 
 def build(force=False):
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc] + FLAGS + ["-o", LIB] + SOURCES, check=True)
+    if force or needs_build():
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.run([hipcc] + FLAGS + ["-o", LIB] + SOURCES, check=True)
+    build_host(force)
     return LIB
 
 

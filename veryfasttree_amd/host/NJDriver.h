@@ -1,0 +1,751 @@
+// Host driver of the neighbour-joining phase over the C ABI (include/vft_hip.h): the CALLER of the hot path.
+//
+// fastNJ's top-hits bookkeeping (src/NeighbourJoining.tcc "NJ.tcc" :2796-3155, :3746-4833) restated so that every
+// profile operation goes through a batched device call, while the control flow and the scalar formulas the
+// reference evaluates on the host (criterion :1099-1107, branch lengths :2911-2916, diameters :3003) stay here, with
+// the reference's float/double mix.  Join order is pinned against the reference's `Join` lines
+// (tests/golden/bb_*.npz; tests/test_gpu_nj_driver.py).  The same logic exists as a Python prototype
+// (veryfasttree_amd/nj_driver.py) that also runs on the CPU oracle for debugging.
+//
+// Scope: deterministic single-thread semantics, default options and `-fastest -no2nd` (first-level top hits, no
+// constraints, no BIONJ weighting, top-hits on: m >= 4 and 2m < nSeqs).
+//
+// Device-side lazy state: out-distances are refreshed on the device inside sweeps / pair lists exactly when the
+// reference refreshes them (setCriterion, NJ.tcc:1092-1098).  The host mirrors the staleness stamps by applying the
+// same deterministic rule and fetches a refreshed VALUE only when a host-side criterion needs it (`dirty`).
+#ifndef VERYFASTTREE_NJDRIVER_H
+#define VERYFASTTREE_NJDRIVER_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vft_hip.h"
+
+namespace veryfasttree {
+
+    struct NJOptions {
+        bool fastest = false;
+        double tophitsMult = 1.0, tophitsClose = -1.0, tophitsRefresh = 0.8, topvisibleMult = 1.5;
+        double staleOutLimit = 0.01, fResetOutProfile = 0.02;
+        int nResetOutProfile = 200;
+    };
+
+    template<typename REAL>
+    class NJDriver {
+    public:
+        struct Join {
+            int64_t i, j, newnode;
+            REAL criterion;
+        };
+
+        NJDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const NJOptions &opt)
+                : ctx(ctx), opt(opt), nSeqs(nSeqs), nPos(nPos), maxnodes(2 * nSeqs), maxnode(nSeqs), totdiam(0.0) {
+            parent.assign(maxnodes, -1);
+            child0.assign(maxnodes, -1);
+            child1.assign(maxnodes, -1);
+            diameter.assign(maxnodes, 0);
+            branchlength.assign(maxnodes, 0);
+            outDist.assign(maxnodes, 0);
+            nOut.assign(maxnodes, 10 * nSeqs);
+            dirty.assign(maxnodes, 0);
+            selfweightLeaf.resize(nSeqs);
+            for (int64_t i = 0; i < nSeqs; i++) {
+                int64_t c = 0;
+                for (int64_t p = 0; p < nPos; p++) c += codes[i * nPos + p] != VFT_NOCODE;
+                selfweightLeaf[i] = (REAL) c;
+            }
+            /* NJ constructor, NJ.tcc:233-260 */
+            chk(vft_upload_leaves(ctx, codes));
+            std::vector<REAL> z(nSeqs, 0);
+            chk(vft_set_node_scalars(ctx, 0, nSeqs, z.data(), selfweightLeaf.data(), z.data()));
+            chk(vft_set_max_node(ctx, nSeqs));
+            std::vector<int64_t> ids(nSeqs);
+            for (int64_t i = 0; i < nSeqs; i++) ids[i] = i;
+            chk(vft_out_profile_full(ctx, nSeqs, ids.data()));
+            std::vector<int64_t> stale(nSeqs, 10 * nSeqs);
+            chk(vft_set_out_distances(ctx, 0, nSeqs, z.data(), stale.data()));
+            chk(vft_out_distances(ctx, 0, nullptr, nSeqs, 0.0));
+            chk(vft_synchronize(ctx));
+            fetchAll(nSeqs);
+        }
+
+        const std::vector<Join> &run(int64_t maxJoins = -1) {
+            int64_t m = opt.tophitsMult > 0 ? (int64_t) (0.5 + opt.tophitsMult * std::sqrt((double) nSeqs)) : 0;
+            if (m < 4 || 2 * m >= nSeqs)
+                throw std::invalid_argument("NJDriver: top-hits are off for this size; the visible-set path is not ported");
+            initTopHits(m);
+            setAllLeafTopHits();
+            resetTopVisible(nSeqs);
+            int64_t nActiveReset = nSeqs;
+            for (int64_t nActive = nSeqs; nActive > 3; nActive--) {
+                if (maxJoins >= 0 && (int64_t) joins.size() >= maxJoins) break;
+                Besthit join = topHitNJSearch(nActive);
+                setOutDistance(join.i, nActive);
+                setOutDistance(join.j, nActive);
+                std::vector<Besthit *> one(1, &join);
+                setDistCriterionBatch(nActive, one);
+                const int64_t newnode = maxnode++;
+                const int64_t i = join.i, j = join.j;
+                parent[i] = parent[j] = newnode;
+                child0[newnode] = std::min(i, j);
+                child1[newnode] = std::max(i, j);
+                joins.push_back(Join{std::min(i, j), std::max(i, j), newnode, join.criterion});
+                const double distIJ = join.dist;
+                const REAL od = value(i) - value(j);
+                const double deltaDist = od / (double) (nActive - 2);
+                branchlength[i] = (REAL) ((distIJ + deltaDist) / 2);
+                branchlength[j] = (REAL) ((distIJ - deltaDist) / 2);
+                const double bw = 0.5;
+                const REAL bi = branchlength[i] + diameter[i], bj = branchlength[j] + diameter[j];
+                diameter[newnode] = (REAL) (bw * bi + (1 - bw) * bj);
+                chk(vft_set_max_node(ctx, maxnode));
+                chk(vft_average_profiles(ctx, 1, &newnode, &i, &j, nullptr));
+                chk(vft_set_parents(ctx, i, 1, &newnode));
+                chk(vft_set_parents(ctx, j, 1, &newnode));
+                chk(vft_set_node_scalars(ctx, newnode, 1, &diameter[newnode], nullptr, nullptr));
+                const int64_t changed = nActiveReset - (nActive - 1);
+                if (changed >= opt.nResetOutProfile && changed >= opt.fResetOutProfile * nActiveReset) {
+                    std::vector<int64_t> active;
+                    double tot = 0;
+                    for (int64_t v = 0; v < maxnode; v++)
+                        if (parent[v] < 0) {
+                            active.push_back(v);
+                            tot += diameter[v];
+                        }
+                    totdiam = tot;
+                    chk(vft_out_profile_full(ctx, (int64_t) active.size(), active.data()));
+                    nActiveReset = nActive - 1;
+                } else {
+                    chk(vft_out_profile_update(ctx, i, j, newnode, nActive));
+                    const REAL dd = diameter[newnode] - diameter[i] - diameter[j];
+                    totdiam += dd;
+                }
+                REAL zero = 0;
+                int64_t staleStamp = 10 * nSeqs;
+                chk(vft_set_out_distances(ctx, newnode, 1, &zero, &staleStamp));
+                outDist[newnode] = 0;
+                nOut[newnode] = staleStamp;
+                dirty[newnode] = 0;
+                topHitJoin(newnode, nActive - 1);
+            }
+            return joins;
+        }
+
+        std::vector<Join> joins;
+
+    private:
+        struct Besthit {
+            int64_t i = -1, j = -1;
+            REAL weight = 0, dist = (REAL) 1e20, criterion = (REAL) 1e20;
+        };
+        struct Hit {
+            int64_t j;
+            REAL dist;
+        };
+        typedef typename std::conditional<sizeof(REAL) == 4, vft_hit_f32, vft_hit_f64>::type DevHit;
+
+        vft_ctx *ctx;
+        NJOptions opt;
+        int64_t nSeqs, nPos, maxnodes, maxnode;
+        double totdiam;
+        std::vector<int64_t> parent, child0, child1, nOut;
+        std::vector<REAL> diameter, branchlength, outDist, selfweightLeaf;
+        std::vector<uint8_t> dirty;
+        /* top hits (NJ.h:206-248) */
+        int64_t m = 0, q = 0, topvisibleAge = 0;
+        std::vector<std::vector<Hit> > hits;
+        std::vector<int64_t> age, topvisible;
+        std::vector<Hit> visible;
+
+        void chk(int rc) {
+            if (rc != VFT_OK) throw std::invalid_argument(std::string("NJDriver: ") + vft_last_error(ctx));
+        }
+
+        /* ---- out-distance mirror */
+        int64_t nDiffAllow(int64_t nActive) const {
+            return opt.tophitsMult > 0 ? (int64_t) (nActive * opt.staleOutLimit) : 0;
+        }
+
+        void fetchAll(int64_t upto) {
+            chk(vft_get_out_distances(ctx, 0, upto, outDist.data(), nOut.data()));
+            std::fill(dirty.begin(), dirty.begin() + upto, 0);
+        }
+
+        REAL value(int64_t v) {
+            if (dirty[v]) {
+                int64_t stamp;
+                chk(vft_get_out_distances(ctx, v, 1, &outDist[v], &stamp));
+                dirty[v] = 0;
+            }
+            return outDist[v];
+        }
+
+        /* the device refreshed v iff it was staler than allowed (same rule as NJ.tcc:1092-1098) */
+        void noteLazy(int64_t v, int64_t nActive, int64_t allow) {
+            if (nOut[v] - nActive > allow) {
+                nOut[v] = nActive;
+                dirty[v] = 1;
+            }
+        }
+
+        void noteSweep(int64_t nActive) {
+            const int64_t allow = nDiffAllow(nActive);
+            for (int64_t v = 0; v < maxnode; v++)
+                if (parent[v] < 0) noteLazy(v, nActive, allow);
+        }
+
+        void setOutDistance(int64_t node, int64_t nActive) {
+            if (nOut[node] == nActive) return;
+            chk(vft_out_distances(ctx, 1, &node, nActive, totdiam));
+            nOut[node] = nActive;
+            dirty[node] = 1;
+        }
+
+        void setCriterion(int64_t nActive, Besthit &hit) { /* NJ.tcc:1085-1113 */
+            if (hit.i < 0 || hit.j < 0 || parent[hit.i] >= 0 || parent[hit.j] >= 0) return;
+            const int64_t allow = nDiffAllow(nActive);
+            if (nOut[hit.i] - nActive > allow) setOutDistance(hit.i, nActive);
+            if (nOut[hit.j] - nActive > allow) setOutDistance(hit.j, nActive);
+            double outI = value(hit.i);
+            if (nOut[hit.i] != nActive) outI *= (nActive - 1) / (double) (nOut[hit.i] - 1);
+            double outJ = value(hit.j);
+            if (nOut[hit.j] != nActive) outJ *= (nActive - 1) / (double) (nOut[hit.j] - 1);
+            hit.criterion = (REAL) (hit.dist - (outI + outJ) / (double) (nActive - 2));
+        }
+
+        void setDistCriterionBatch(int64_t nActive, std::vector<Besthit *> &list) { /* NJ.tcc:1115-1124 */
+            if (list.empty()) return;
+            const int64_t n = (int64_t) list.size();
+            std::vector<int64_t> pi(n), pj(n);
+            std::vector<REAL> d(n), w(n), c(n);
+            for (int64_t t = 0; t < n; t++) {
+                pi[t] = list[t]->i;
+                pj[t] = list[t]->j;
+            }
+            const int64_t allow = nDiffAllow(nActive);
+            chk(vft_pair_distances(ctx, n, pi.data(), pj.data(), nActive, allow, totdiam, d.data(), w.data(), c.data()));
+            for (int64_t t = 0; t < n; t++) {
+                list[t]->dist = d[t];
+                list[t]->weight = w[t];
+                list[t]->criterion = c[t];
+                noteLazy(pi[t], nActive, allow);
+                noteLazy(pj[t], nActive, allow);
+            }
+        }
+
+        int64_t activeAncestor(int64_t node) const {
+            if (node < 0) return node;
+            while (parent[node] >= 0) node = parent[node];
+            return node;
+        }
+
+        /* ---- sorting with the reference's tie rule: ascending key, ties by DESCENDING position */
+        static void sortByCriterion(std::vector<Besthit> &v) {
+            std::vector<int64_t> order(v.size());
+            for (size_t t = 0; t < v.size(); t++) order[t] = (int64_t) t;
+            std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+                if (v[a].criterion != v[b].criterion) return v[a].criterion < v[b].criterion;
+                return a > b;
+            });
+            std::vector<Besthit> out(v.size());
+            for (size_t t = 0; t < v.size(); t++) out[t] = v[order[t]];
+            v.swap(out);
+        }
+
+        static void sortByIJ(std::vector<Besthit> &v) {
+            std::vector<int64_t> order(v.size());
+            for (size_t t = 0; t < v.size(); t++) order[t] = (int64_t) t;
+            std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+                if (v[a].i != v[b].i) return v[a].i < v[b].i;
+                if (v[a].j != v[b].j) return v[a].j < v[b].j;
+                return a > b;
+            });
+            std::vector<Besthit> out(v.size());
+            for (size_t t = 0; t < v.size(); t++) out[t] = v[order[t]];
+            v.swap(out);
+        }
+
+        /* ---- top-hits structures */
+        void initTopHits(int64_t m_) {
+            m = m_;
+            q = 0;
+            hits.assign(maxnodes, std::vector<Hit>());
+            age.assign(maxnodes, 0);
+            visible.assign(maxnodes, Hit{-1, (REAL) 1e20});
+            topvisible.assign((size_t) (0.5 + opt.topvisibleMult * m), -1);
+            topvisibleAge = 0;
+        }
+
+        std::vector<Besthit> hitsToBestHits(const std::vector<Hit> &l, int64_t node) const {
+            std::vector<Besthit> out(l.size());
+            for (size_t t = 0; t < l.size(); t++) {
+                out[t].i = node;
+                out[t].j = l[t].j;
+                out[t].dist = l[t].dist;
+                out[t].criterion = (REAL) 1e20;
+                out[t].weight = -1;
+            }
+            return out;
+        }
+
+        void sortSaveBestHits(int64_t node, std::vector<Besthit> &bh, int64_t nIn, int64_t nOutWanted, bool sort = true) {
+            /* NJ.tcc:4535-4578 */
+            if (sort) sortByCriterion(bh);
+            nIn = std::min<int64_t>(nIn, (int64_t) bh.size());
+            int64_t nSave = 0, jLast = -1;
+            for (int64_t t = 0; t < nIn && nSave < nOutWanted; t++) {
+                if (bh[t].i < 0) continue;
+                const int64_t j = bh[t].j;
+                if (j != node && j != jLast && j >= 0) {
+                    nSave++;
+                    jLast = j;
+                }
+            }
+            std::vector<Hit> &l = hits[node];
+            l.clear();
+            jLast = -1;
+            for (int64_t t = 0; t < nIn && (int64_t) l.size() < nSave; t++) {
+                const int64_t j = bh[t].j;
+                if (j != node && j != jLast && j >= 0) {
+                    l.push_back(Hit{j, bh[t].dist});
+                    jLast = j;
+                }
+            }
+        }
+
+        std::vector<Besthit> transferBestHits(int64_t nActive, int64_t node, const std::vector<Besthit> &old, int64_t nOld,
+                                              bool updateDistances) { /* NJ.tcc:4580-4613 */
+            std::vector<Besthit> out((size_t) nOld);
+            std::vector<Besthit *> todoDist, todoCrit;
+            for (int64_t t = 0; t < nOld; t++) {
+                const Besthit &o = old[t];
+                Besthit &h = out[t];
+                h.i = node;
+                h.j = activeAncestor(o.j);
+                h.dist = o.dist;
+                h.weight = o.weight;
+                h.criterion = o.criterion;
+                if (h.j < 0 || h.j == node) {
+                    h.weight = 0;
+                    h.dist = (REAL) -1e20;
+                    h.criterion = (REAL) 1e20;
+                } else if (h.i != o.i || h.j != o.j) {
+                    if (updateDistances) todoDist.push_back(&h);
+                    else {
+                        h.dist = (REAL) -1e20;
+                        h.criterion = (REAL) 1e20;
+                    }
+                } else {
+                    if (updateDistances) todoCrit.push_back(&h);
+                    else h.criterion = (REAL) 1e20;
+                }
+            }
+            setDistCriterionBatch(nActive, todoDist);
+            for (Besthit *h: todoCrit) setCriterion(nActive, *h);
+            return out;
+        }
+
+        bool updateBestHit(Besthit &hit, bool updateDist, std::vector<Besthit *> *todo) { /* NJ.tcc:1626-1648 */
+            const int64_t i = activeAncestor(hit.i), j = activeAncestor(hit.j);
+            if (i < 0 || j < 0 || i == j) {
+                hit.i = hit.j = -1;
+                hit.weight = 0;
+                hit.dist = hit.criterion = (REAL) 1e20;
+                return false;
+            }
+            if (i != hit.i || j != hit.j) {
+                hit.i = i;
+                hit.j = j;
+                if (updateDist) todo->push_back(&hit);
+                else {
+                    hit.dist = (REAL) -1e20;
+                    hit.criterion = (REAL) 1e20;
+                }
+            }
+            return true;
+        }
+
+        std::vector<Besthit> uniqueBestHits(int64_t nActive, std::vector<Besthit> &combined) { /* NJ.tcc:4786-4833 */
+            for (Besthit &h: combined) updateBestHit(h, false, nullptr);
+            sortByIJ(combined);
+            std::vector<Besthit> out;
+            out.reserve(combined.size());
+            int64_t last = -1;
+            for (size_t t = 0; t < combined.size(); t++) {
+                const Besthit &h = combined[t];
+                if (h.i < 0 || h.j < 0) continue;
+                if (last >= 0 && combined[last].i == h.i && combined[last].j == h.j) continue;
+                out.push_back(h);
+                last = (int64_t) t;
+            }
+            std::vector<Besthit *> todo;
+            std::vector<uint8_t> isTodo(out.size(), 0);
+            for (size_t t = 0; t < out.size(); t++)
+                if (out[t].dist < 0.0) {
+                    todo.push_back(&out[t]);
+                    isTodo[t] = 1;
+                }
+            setDistCriterionBatch(nActive, todo);
+            for (size_t t = 0; t < out.size(); t++)
+                if (!isTodo[t]) setCriterion(nActive, out[t]);
+            return out;
+        }
+
+        bool getVisible(int64_t nActive, int64_t node, Besthit &out) { /* NJ.tcc:546-557 */
+            if (node < 0 || parent[node] >= 0) return false;
+            const Hit &v = visible[node];
+            if (v.j < 0 || parent[v.j] >= 0) return false;
+            out.i = node;
+            out.j = v.j;
+            out.dist = v.dist;
+            out.criterion = (REAL) 1e20;
+            out.weight = -1;
+            setCriterion(nActive, out);
+            return true;
+        }
+
+        void updateTopVisible(int64_t nActive, int64_t iIn, const Hit &hit) { /* NJ.tcc:4660-4726 */
+            bool placed = false;
+            for (size_t t = 0; t < topvisible.size() && !placed; t++) {
+                const int64_t node = topvisible[t];
+                if (node == iIn) placed = true;
+                else if (node < 0 || parent[node] >= 0) {
+                    placed = true;
+                    topvisible[t] = iIn;
+                }
+            }
+            int64_t posWorst = -1;
+            double critWorst = -1e20;
+            if (!placed) {
+                for (size_t t = 0; t < topvisible.size() && !placed; t++) {
+                    const int64_t node = topvisible[t];
+                    Besthit vis;
+                    if (!getVisible(nActive, node, vis)) {
+                        topvisible[t] = iIn;
+                        placed = true;
+                    } else if (vis.i == hit.j && vis.j == iIn) {
+                        placed = true;
+                    } else if (vis.criterion >= critWorst) {
+                        posWorst = (int64_t) t;
+                        critWorst = vis.criterion;
+                    }
+                }
+            }
+            if (!placed && posWorst >= 0) {
+                Besthit b;
+                b.i = iIn;
+                b.j = hit.j;
+                b.dist = hit.dist;
+                b.weight = -1;
+                setCriterion(nActive, b);
+                if (b.criterion < critWorst) topvisible[posWorst] = iIn;
+            }
+        }
+
+        void updateVisible(int64_t nActive, const std::vector<Besthit> &list, int64_t count) { /* NJ.tcc:4633-4657 */
+            for (int64_t t = 0; t < count; t++) {
+                const Besthit &hit = list[t];
+                if (hit.i < 0) continue;
+                Besthit vis;
+                const bool ok = getVisible(nActive, hit.j, vis);
+                if (!ok || hit.criterion < vis.criterion) {
+                    Hit &v = visible[hit.j];
+                    v.j = hit.i;
+                    v.dist = hit.dist;
+                    updateTopVisible(nActive, hit.j, v);
+                }
+            }
+        }
+
+        void resetTopVisible(int64_t nActive) { /* NJ.tcc:4728-4784 */
+            /* the reference sorts a value-initialised array of nActive records of which only nVisible are filled:
+               the zero records take part in the sort and only the first nVisible sorted positions are considered */
+            std::vector<Besthit> vis((size_t) nActive);
+            for (Besthit &b: vis) {
+                b.i = b.j = 0;
+                b.weight = b.dist = b.criterion = 0;
+            }
+            int64_t nVisible = 0;
+            for (int64_t node = 0; node < maxnode; node++) {
+                if (parent[node] >= 0) continue;
+                Besthit v;
+                if (getVisible(nActive, node, v)) vis[nVisible++] = v;
+            }
+            sortByCriterion(vis);
+            std::vector<int64_t> inTop((size_t) maxnodes, -1);
+            size_t save = 0;
+            for (int64_t t = 0; t < nVisible && save < topvisible.size(); t++) {
+                const Besthit &v = vis[t];
+                if (inTop[v.i] != v.j) {
+                    topvisible[save++] = v.i;
+                    inTop[v.i] = v.j;
+                    inTop[v.j] = v.i;
+                }
+            }
+            while (save < topvisible.size()) topvisible[save++] = -1;
+            topvisibleAge = 0;
+        }
+
+        /* one-vs-all sweep -> the first k records of the reference's sorted besthits array */
+        std::vector<Besthit> sweep(int64_t node, int64_t nActive, int32_t k) {
+            std::vector<DevHit> dev((size_t) k);
+            chk(vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, k, dev.data(), nullptr, nullptr));
+            noteSweep(nActive);
+            std::vector<Besthit> out((size_t) k);
+            for (int32_t t = 0; t < k; t++) {
+                out[t].i = dev[t].j >= 0 ? node : -1;
+                out[t].j = dev[t].j;
+                out[t].weight = (REAL) dev[t].weight;
+                out[t].dist = (REAL) dev[t].dist;
+                out[t].criterion = (REAL) dev[t].criterion;
+            }
+            return out;
+        }
+
+        void setAllLeafTopHits() { /* NJ.tcc:3746-4119, threads == 1 branch, first-level lists */
+            const int64_t n = nSeqs;
+            double close = opt.tophitsClose;
+            if (close < 0) {
+                if (opt.fastest && n >= 50000) close = 0.99;
+                else {
+                    const double logN = std::log((double) n) / std::log(2.0);
+                    close = logN / (logN + 2.0);
+                }
+            }
+            std::vector<int64_t> nGaps(n), seeds(n);
+            for (int64_t i = 0; i < n; i++) {
+                nGaps[i] = (int64_t) (0.5 + nPos - selfweightLeaf[i]);
+                seeds[i] = i;
+            }
+            /* CompareSeeds (NJ.tcc:7285-7299) with the psort tie rule */
+            std::sort(seeds.begin(), seeds.end(), [&](int64_t a, int64_t b) {
+                if (nGaps[a] != nGaps[b]) return nGaps[a] < nGaps[b];
+                if (outDist[a] != outDist[b]) return outDist[a] < outDist[b];
+                return a > b;
+            });
+            std::vector<uint8_t> visited(n, 0);
+            for (int64_t s = 0; s < n; s++) {
+                const int64_t seed = seeds[s];
+                if (visited[seed]) continue;
+                visited[seed] = 1;
+                std::vector<Besthit> best = sweep(seed, n, (int32_t) (2 * m));
+                std::vector<Besthit> copy(best);
+                sortSaveBestHits(seed, copy, (int64_t) copy.size(), m, false);
+                const double neardist = best[2 * m - 1].dist * close;
+                double nearweight = 0;
+                for (int64_t t = 0; t < 2 * m; t++) nearweight += best[t].weight;
+                nearweight = nearweight / (2.0 * m);
+                nearweight *= (1.0 - 2.0 * neardist / 3.0);
+                const double nearcover = 1.0 - neardist / 2.0;
+                for (int64_t iClose = 0; iClose < m; iClose++) {
+                    const Besthit &ch = best[iClose];
+                    const int64_t cn = ch.j;
+                    if (cn < 0 || visited[cn]) continue;
+                    const bool isClose = ch.dist <= neardist &&
+                                         (ch.weight >= nearweight || ch.weight >= (nPos - nGaps[cn]) * nearcover);
+                    const bool identical = ch.dist < 1e-6 && std::fabs(ch.weight - (nPos - nGaps[seed])) < 1e-5 &&
+                                           std::fabs(ch.weight - (nPos - nGaps[cn])) < 1e-5;
+                    if (isClose || identical || (opt.fastest && iClose < (q + 1) / 2)) {
+                        std::vector<Besthit> nb = transferBestHits(n, cn, best, 2 * m, true);
+                        visited[cn] = 1;
+                        sortSaveBestHits(cn, nb, 2 * m, m);
+                    }
+                }
+            }
+            for (int64_t node = 0; node < n; node++) visible[node] = hits[node][0];
+            /* checking phase, NJ.tcc:4052-4119 */
+            const int64_t nCheck = q > 0 ? q : (int64_t) (0.5 + 2.0 * std::sqrt((double) m));
+            for (int64_t node = 0; node < n; node++) {
+                for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
+                    Besthit bh;
+                    bh.i = node;
+                    bh.j = hits[node][iHit].j;
+                    bh.dist = hits[node][iHit].dist;
+                    bh.weight = -1;
+                    setCriterion(n, bh);
+                    std::vector<Hit> &lT = hits[bh.j];
+                    Besthit chk2;
+                    chk2.i = bh.j;
+                    chk2.j = lT[nCheck - 1].j;
+                    chk2.dist = lT[nCheck - 1].dist;
+                    chk2.weight = -1;
+                    setCriterion(n, chk2);
+                    if (chk2.criterion < bh.criterion) continue;
+                    bool found = false;
+                    for (const Hit &h: lT) found = found || h.j == node;
+                    if (found) continue;
+                    int64_t iWorst = -1;
+                    double dWorst = -1e20;
+                    for (size_t t = 0; t < lT.size(); t++) {
+                        Besthit b2;
+                        b2.i = bh.j;
+                        b2.j = lT[t].j;
+                        b2.dist = lT[t].dist;
+                        b2.weight = -1;
+                        setCriterion(n, b2);
+                        if (b2.criterion > dWorst) {
+                            iWorst = (int64_t) t;
+                            dWorst = b2.criterion;
+                        }
+                    }
+                    if (dWorst > bh.criterion) {
+                        lT[iWorst].j = node;
+                        lT[iWorst].dist = bh.dist;
+                        Besthit v;
+                        getVisible(n, bh.j, v);
+                        if (bh.criterion < v.criterion) visible[bh.j] = lT[iWorst];
+                    }
+                }
+            }
+        }
+
+        Besthit getBestFromTopHits(int64_t node, int64_t nActive) { /* NJ.tcc:4267-4298 */
+            if (!opt.fastest) setOutDistance(node, nActive);
+            Besthit best;
+            best.i = best.j = -1;
+            std::vector<Besthit> cand = hitsToBestHits(hits[node], node);
+            std::vector<uint8_t> ok(cand.size(), 0);
+            std::vector<Besthit *> todo;
+            for (size_t t = 0; t < cand.size(); t++) ok[t] = updateBestHit(cand[t], true, &todo) ? 1 : 0;
+            setDistCriterionBatch(nActive, todo);
+            for (size_t t = 0; t < cand.size(); t++) {
+                if (!ok[t]) continue;
+                setCriterion(nActive, cand[t]);
+                if (cand[t].criterion < best.criterion) best = cand[t];
+            }
+            return best;
+        }
+
+        Besthit topHitNJSearch(int64_t nActive) { /* NJ.tcc:4137-4262 */
+            int64_t bestNode;
+            for (;;) {
+                int64_t nCand = 0;
+                bestNode = -1;
+                double bestCrit = 1e20;
+                for (int64_t node: topvisible) {
+                    Besthit v;
+                    if (getVisible(nActive, node, v)) {
+                        nCand++;
+                        if (bestNode < 0 || v.criterion < bestCrit) {
+                            bestNode = node;
+                            bestCrit = v.criterion;
+                        }
+                    }
+                }
+                topvisibleAge++;
+                if (2 * topvisibleAge > m || (3 * nCand < (int64_t) topvisible.size() && 3 * nCand < nActive)) {
+                    if (topvisibleAge <= 2) {
+                        for (int64_t node = 0; node < maxnode; node++) {
+                            if (parent[node] >= 0) continue;
+                            Hit &v = visible[node];
+                            int64_t newj = activeAncestor(v.j);
+                            if (newj >= 0 && newj != v.j) {
+                                if (newj == node) {
+                                    newj = 0;
+                                    while (parent[newj] >= 0 || newj == node) newj++;
+                                }
+                                Besthit bh;
+                                bh.i = node;
+                                bh.j = newj;
+                                std::vector<Besthit *> one(1, &bh);
+                                setDistCriterionBatch(nActive, one);
+                                v.j = newj;
+                                v.dist = bh.dist;
+                            }
+                        }
+                    }
+                    resetTopVisible(nActive);
+                    continue;
+                }
+                break;
+            }
+            Besthit join;
+            getVisible(nActive, bestNode, join);
+            if (opt.fastest) return join;
+            Besthit join2 = join;
+            bool changed;
+            do {
+                changed = false;
+                Besthit best = getBestFromTopHits(join2.i, nActive);
+                if (best.j != join2.j && best.criterion < join2.criterion) {
+                    changed = true;
+                    join2 = best;
+                }
+                best = getBestFromTopHits(join2.j, nActive);
+                if (best.j != join2.i && best.criterion < join2.criterion) {
+                    changed = true;
+                    join2 = best;
+                }
+                join = join2;
+            } while (changed);
+            return join;
+        }
+
+        void topHitJoin(int64_t newnode, int64_t nActive) { /* NJ.tcc:4306-4533, first-level lists */
+            const int64_t c0 = child0[newnode], c1 = child1[newnode];
+            std::vector<Besthit> combined = hitsToBestHits(hits[c0], c0);
+            std::vector<Besthit> second = hitsToBestHits(hits[c1], c1);
+            combined.insert(combined.end(), second.begin(), second.end());
+            std::vector<Besthit> unique = uniqueBestHits(nActive, combined);
+            const int64_t nUnique = (int64_t) unique.size();
+            hits[c0].clear();
+            hits[c1].clear();
+            age[newnode] = (age[c0] + age[c1] + 1) / 2 + 1;
+            const int64_t ageLimit = std::max<int64_t>(1, (int64_t) (0.5 + std::log((double) m) / std::log(2.0)));
+            const bool useUnique = nUnique == nActive - 1 ||
+                                   (age[newnode] <= ageLimit && nUnique >= (int64_t) (0.5 + m * opt.tophitsRefresh));
+            if (useUnique) {
+                const int64_t nSave = std::min(nUnique, m);
+                sortSaveBestHits(newnode, unique, nUnique, nSave);
+                visible[newnode] = hits[newnode][0];
+                updateTopVisible(nActive, newnode, visible[newnode]);
+                updateVisible(nActive, unique, nSave);
+                return;
+            }
+            /* refresh */
+            age[newnode] = 0;
+            if (opt.fastest) {
+                for (int64_t node = 0; node < maxnode; node++)
+                    if (parent[node] < 0) {
+                        Besthit bh;
+                        bh.i = bh.j = node;
+                        bh.dist = 0;
+                        setCriterion(nActive, bh);
+                    }
+            } else {
+                chk(vft_out_distances(ctx, 0, nullptr, nActive, totdiam));
+                for (int64_t v = 0; v < maxnode; v++)
+                    if (parent[v] < 0 && nOut[v] != nActive) {
+                        nOut[v] = nActive;
+                        dirty[v] = 1;
+                    }
+            }
+            std::vector<Besthit> all = sweep(newnode, nActive, (int32_t) (2 * m));
+            std::vector<Besthit> copy(all);
+            sortSaveBestHits(newnode, copy, (int64_t) copy.size(), m, false);
+            for (int64_t iHit = 0; iHit < m && iHit < (int64_t) all.size(); iHit++) {
+                if (all[iHit].i < 0) continue;
+                const int64_t node = all[iHit].j;
+                if (parent[node] >= 0) continue;
+                const int64_t nOld = (int64_t) hits[node].size();
+                age[node] = 0;
+                std::vector<Besthit> both = hitsToBestHits(hits[node], node);
+                for (Besthit &b: both) setCriterion(nActive, b);
+                const int64_t nNew = m;
+                std::vector<Besthit> tr = transferBestHits(nActive, node, all, 2 * nNew, false);
+                both.insert(both.end(), tr.begin(), tr.end());
+                both.resize((size_t) (nOld + 2 * nNew));
+                std::vector<Besthit> unique2 = uniqueBestHits(nActive, both);
+                sortSaveBestHits(node, unique2, (int64_t) unique2.size(), nNew);
+                visible[node] = hits[node][0];
+            }
+            resetTopVisible(nActive);
+        }
+    };
+}
+
+#endif

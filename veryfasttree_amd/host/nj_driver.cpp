@@ -1,0 +1,47 @@
+// C entry point of the host NJ driver (include/vft_host.h).  Plain C++11, no HIP: links against libvft_hip.so.
+#include "../../include/vft_host.h"
+
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "NJDriver.h"
+
+template<typename REAL>
+static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
+                         int64_t maxJoins, int64_t *joins, double *criterion) {
+    veryfasttree::NJOptions opt;
+    if (o) {
+        opt.fastest = o->fastest != 0;
+        opt.tophitsMult = o->tophits_mult;
+        opt.tophitsClose = o->tophits_close;
+        opt.tophitsRefresh = o->tophits_refresh;
+        opt.topvisibleMult = o->topvisible_mult;
+        opt.staleOutLimit = o->stale_out_limit;
+        opt.fResetOutProfile = o->f_reset_out_profile;
+        opt.nResetOutProfile = o->n_reset_out_profile;
+    }
+    veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, opt);
+    const auto &js = drv.run(maxJoins);
+    for (size_t k = 0; k < js.size(); k++) {
+        joins[3 * k] = js[k].i;
+        joins[3 * k + 1] = js[k].j;
+        joins[3 * k + 2] = js[k].newnode;
+        if (criterion) criterion[k] = js[k].criterion;
+    }
+    return (int64_t) js.size();
+}
+
+extern "C" int vft_nj_run(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
+                          const vft_nj_options *opt, int64_t maxJoins, int64_t *joins, double *criterion,
+                          int64_t *nJoins, char *err, int32_t errLen) {
+    if (!ctx || !codes || !joins || !nJoins) return VFT_ERR_INVALID;
+    try {
+        *nJoins = precision == 8 ? runDriver<double>(ctx, codes, nSeqs, nPos, opt, maxJoins, joins, criterion)
+                                 : runDriver<float>(ctx, codes, nSeqs, nPos, opt, maxJoins, joins, criterion);
+        return VFT_OK;
+    } catch (const std::exception &e) {
+        if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
+        return VFT_ERR_STATE;
+    }
+}
