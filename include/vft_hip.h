@@ -17,7 +17,8 @@
  *   - host-side dense profile = w[nPos], codes[nPos], f[nPos*nCodes]; f is read/written only for columns where
  *     the reference holds a vector (codes == NOCODE && w > 0, NJ.tcc:2040-2042).
  *   - every call is asynchronous on the context's stream unless it returns data to host memory, in which case
- *     it synchronises that stream before returning.  Pointers named d_* are DEVICE pointers supplied by the
+ *     it synchronises that stream before returning.  Small inputs (id lists, per-node scalars) are staged in a
+ *     host-mapped ring, so they need no synchronisation either; host arrays passed in may be reused on return.  Pointers named d_* are DEVICE pointers supplied by the
  *     caller (e.g. torch tensors) and are written on the stream without synchronising.
  *   - there is no CPU fallback: without a HIP device vft_create fails.
  */
@@ -93,6 +94,10 @@ int vft_get_node_scalars(vft_ctx *ctx, int64_t first, int64_t count, void *diame
 int vft_set_out_distances(vft_ctx *ctx, int64_t first, int64_t count, const void *out_dist,
                           const int64_t *n_out_active);
 int vft_get_out_distances(vft_ctx *ctx, int64_t first, int64_t count, void *out_dist, int64_t *n_out_active);
+/* Host-mapped mirrors of outDistances[] / nOutDistActive[] (real / int32, indexed by node id): every refresh a
+   kernel performs is also stored here, so host code can evaluate setCriterion (NJ.tcc:1099-1107) without a copy.
+   Contents are valid after vft_synchronize() or after any call that returned data to host memory. */
+int vft_out_distance_mirror(vft_ctx *ctx, const void **out_dist, const int32_t **n_out_active);
 int vft_set_max_node(vft_ctx *ctx, int64_t maxnode);           /* NJ.h: maxnode, the next id to allocate */
 
 /* ---- profiles */

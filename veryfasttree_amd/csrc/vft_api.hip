@@ -64,6 +64,14 @@ struct vft_ctx {
     // generic device scratch (index lists, staging)
     void *scratch = nullptr;
     size_t scratchBytes = 0;
+    // host-mapped command/response ring: small id lists go to the device and small results come back through
+    // zero-copy pinned memory instead of hipMemcpy (whose fixed latency dominates a join's worth of tiny calls)
+    char *hIO = nullptr, *dIO = nullptr;
+    size_t ioCap = 8u << 20, ioHead = 0;
+    unsigned long long *hFlag = nullptr, *dFlag = nullptr, signalSeq = 0;
+    // host-mapped mirrors of outDist / nOutActive, written by the kernels that refresh them
+    void *hOutDist = nullptr, *dOutDistM = nullptr;
+    int32_t *hNOut = nullptr, *dNOutM = nullptr;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
@@ -130,6 +138,8 @@ static Arena<REAL> arena(const vft_ctx *c) {
     A.selfdist = (REAL *) c->selfdist;
     A.outDist = (REAL *) c->outDist;
     A.nOutActive = c->nOutActive;
+    A.mOutDist = (REAL *) c->dOutDistM;
+    A.mNOut = c->dNOutM;
     A.outW = (REAL *) c->outW;
     A.outF = (REAL *) c->outF;
     A.outCD = c->hasDm ? (REAL *) c->outCD : nullptr;
@@ -191,6 +201,44 @@ static inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t shm, hipSt
 }
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned) ((a + b - 1) / b); }
+
+// Completion signal in mapped host memory: waiting for the stream by spinning on a word a trailing 1-thread kernel
+// writes costs ~10 us; hipStreamSynchronize costs ~80 us here, and a join makes several round trips.
+__global__ void k_signal(unsigned long long *flag, unsigned long long seq) {
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int wait_stream(vft_ctx *c) {
+    const unsigned long long seq = ++c->signalSeq;
+    launch(k_signal, dim3(1), dim3(1), 0, c->stream, c->dFlag, seq);
+    LAUNCHCHK(c);
+    volatile unsigned long long *f = c->hFlag;
+    for (long spins = 0;; spins++) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= seq) return VFT_OK;
+        if (spins > 2000000) {   // ~ a second: fall back to the runtime (also surfaces asynchronous errors)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return VFT_OK;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// Bump allocation in the mapped ring.  Wrapping waits for the stream: everything that was reading older slots is done.
+static int io_alloc(vft_ctx *c, size_t bytes, char **host, char **dev) {
+    bytes = (bytes + 255) & ~(size_t) 255;
+    if (bytes > c->ioCap) return fail(c, VFT_ERR_INVALID, "request of %zu bytes exceeds the mapped I/O ring", bytes);
+    if (c->ioHead + bytes > c->ioCap) {
+        if (int r = wait_stream(c)) return r;
+        c->ioHead = 0;
+    }
+    *host = c->hIO + c->ioHead;
+    *dev = c->dIO + c->ioHead;
+    c->ioHead += bytes;
+    return VFT_OK;
+}
+
+
+static int raise_pair_kernel_lds(vft_ctx *c);   // defined next to the kernels it configures
 
 // ---------------------------------------------------------------------------------------------- life cycle
 extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
@@ -283,6 +331,17 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipHostMalloc((void **) &c->hRes, sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64), hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->hResDev, c->hRes, 0));
     memset(c->hRes, 0, sizeof(SelectHeader));
+    CR(hipHostMalloc((void **) &c->hFlag, 64, hipHostMallocMapped));
+    CR(hipHostGetDevicePointer((void **) &c->dFlag, c->hFlag, 0));
+    *c->hFlag = 0;
+    CR(hipHostMalloc((void **) &c->hIO, c->ioCap, hipHostMallocMapped));
+    CR(hipHostGetDevicePointer((void **) &c->dIO, c->hIO, 0));
+    CR(hipHostMalloc(&c->hOutDist, (size_t) N * rs, hipHostMallocMapped));
+    CR(hipHostGetDevicePointer(&c->dOutDistM, c->hOutDist, 0));
+    CR(hipHostMalloc((void **) &c->hNOut, (size_t) N * 4, hipHostMallocMapped));
+    CR(hipHostGetDevicePointer((void **) &c->dNOutM, c->hNOut, 0));
+    memset(c->hOutDist, 0, (size_t) N * rs);
+    memset(c->hNOut, 0, (size_t) N * 4);
     for (int i = 0; i < 4; i++) CR(dallocb(&c->dm[i], (size_t) 21 * 20 * 8));
     for (int i = 0; i < 6; i++) CR(dallocb(&c->tm[i], (size_t) 21 * 20 * 8));
     CR(dallocb(&c->rates, (size_t) VFT_MAXRATES * 8));
@@ -302,6 +361,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     }
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
+    if (int r = raise_pair_kernel_lds(c)) return bail(r);
 #undef CR
     *out = c;
     return VFT_OK;
@@ -319,6 +379,10 @@ extern "C" int vft_destroy(vft_ctx *c) {
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->hRes) hipHostFree(c->hRes);
+    if (c->hIO) hipHostFree(c->hIO);
+    if (c->hFlag) hipHostFree(c->hFlag);
+    if (c->hOutDist) hipHostFree(c->hOutDist);
+    if (c->hNOut) hipHostFree(c->hNOut);
     for (hipEvent_t e : c->kev) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -337,8 +401,7 @@ extern "C" int vft_set_stream(vft_ctx *c, void *s) {
 
 extern "C" int vft_synchronize(vft_ctx *c) {
     if (!c) return VFT_ERR_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VFT_OK;
+    return wait_stream(c);
 }
 
 // ---------------------------------------------------------------------------------------------- inputs
@@ -435,25 +498,46 @@ static int range_ok(vft_ctx *c, int64_t first, int64_t count) {
     return VFT_OK;
 }
 
+#define VFT_SMALL_BYTES (256u << 10)
+
+// dst[first .. first+count) = src (host), stream-ordered, no host synchronisation for small ranges
+template <typename T>
+static int store_range(vft_ctx *c, T *dst, T *mirror, const T *src, int64_t first, int64_t count) {
+    const size_t bytes = (size_t) count * sizeof(T);
+    if (bytes <= VFT_SMALL_BYTES) {
+        char *h, *d;
+        if (int r = io_alloc(c, bytes, &h, &d)) return r;
+        memcpy(h, src, bytes);
+        launch((k_store_range<T>), dim3(cdiv(count, 256)), dim3(256), 0, c->stream, dst, mirror, (const T *) d, first, count);
+        LAUNCHCHK(c);
+        return VFT_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(dst + first, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
 extern "C" int vft_set_parents(vft_ctx *c, int64_t first, int64_t count, const int64_t *parent) {
     if (!c || !parent) return VFT_ERR_INVALID;
     if (int r = range_ok(c, first, count)) return r;
     std::vector<int32_t> p((size_t) count);
     for (int64_t i = 0; i < count; i++) p[(size_t) i] = parent[i] < 0 ? -1 : (int32_t) parent[i];
-    HIPCHK(c, hipMemcpyAsync(c->parent + first, p.data(), (size_t) count * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VFT_OK;
+    return store_range<int32_t>(c, c->parent, nullptr, p.data(), first, count);
 }
 
 extern "C" int vft_set_node_scalars(vft_ctx *c, int64_t first, int64_t count, const void *diameter,
                                     const void *selfweight, const void *selfdist) {
     if (!c) return VFT_ERR_INVALID;
     if (int r = range_ok(c, first, count)) return r;
-    const size_t rs = c->rs;
-    if (diameter) HIPCHK(c, hipMemcpyAsync((char *) c->diameter + first * rs, diameter, count * rs, hipMemcpyHostToDevice, c->stream));
-    if (selfweight) HIPCHK(c, hipMemcpyAsync((char *) c->selfweight + first * rs, selfweight, count * rs, hipMemcpyHostToDevice, c->stream));
-    if (selfdist) HIPCHK(c, hipMemcpyAsync((char *) c->selfdist + first * rs, selfdist, count * rs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const void *src[3] = {diameter, selfweight, selfdist};
+    void *dst[3] = {c->diameter, c->selfweight, c->selfdist};
+    for (int k = 0; k < 3; k++) {
+        if (!src[k]) continue;
+        int r;
+        if (c->rs == 4) r = store_range<float>(c, (float *) dst[k], nullptr, (const float *) src[k], first, count);
+        else r = store_range<double>(c, (double *) dst[k], nullptr, (const double *) src[k], first, count);
+        if (r) return r;
+    }
     return VFT_OK;
 }
 
@@ -475,14 +559,29 @@ extern "C" int vft_set_out_distances(vft_ctx *c, int64_t first, int64_t count, c
                                      const int64_t *nOutActive) {
     if (!c) return VFT_ERR_INVALID;
     if (int r = range_ok(c, first, count)) return r;
-    if (outDist) HIPCHK(c, hipMemcpyAsync((char *) c->outDist + first * c->rs, outDist, count * c->rs, hipMemcpyHostToDevice, c->stream));
-    std::vector<int32_t> n32;
-    if (nOutActive) {
-        n32.resize((size_t) count);
-        for (int64_t i = 0; i < count; i++) n32[(size_t) i] = clamp_i32(nOutActive[i]);
-        HIPCHK(c, hipMemcpyAsync(c->nOutActive + first, n32.data(), (size_t) count * 4, hipMemcpyHostToDevice, c->stream));
+    // bulk host-side sets must not race with refresh kernels still in flight that write the mirrors; a single
+    // fresh node (the join loop's newnode) cannot be touched by an earlier kernel
+    if (count > 1) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (outDist) {
+        int r;
+        if (c->rs == 4) r = store_range<float>(c, (float *) c->outDist, nullptr, (const float *) outDist, first, count);
+        else r = store_range<double>(c, (double *) c->outDist, nullptr, (const double *) outDist, first, count);
+        if (r) return r;
+        memcpy((char *) c->hOutDist + first * c->rs, outDist, (size_t) count * c->rs);   // host side of the mirror
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nOutActive) {
+        std::vector<int32_t> n32((size_t) count);
+        for (int64_t i = 0; i < count; i++) n32[(size_t) i] = clamp_i32(nOutActive[i]);
+        if (int r = store_range<int32_t>(c, c->nOutActive, nullptr, n32.data(), first, count)) return r;
+        memcpy(c->hNOut + first, n32.data(), (size_t) count * 4);
+    }
+    return VFT_OK;
+}
+
+extern "C" int vft_out_distance_mirror(vft_ctx *c, const void **outDist, const int32_t **nOutActive) {
+    if (!c || !outDist || !nOutActive) return VFT_ERR_INVALID;
+    *outDist = c->hOutDist;
+    *nOutActive = c->hNOut;
     return VFT_OK;
 }
 
@@ -602,13 +701,34 @@ extern "C" int vft_profile_nvectors(vft_ctx *c, int64_t first, int64_t count, in
 }
 
 template <typename REAL, int NC>
-__global__ void k_selfdist(Arena<REAL> A, const int64_t *nodes, int64_t n) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(VFT_WG) void k_selfdist(Arena<REAL> A, const int64_t *nodes, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;
     REAL d, w;
-    vft_pair_generic<REAL, NC>(A, nodes[t], nodes[t], false, d, w);
+    vft_pair_wave<REAL, NC>(A, nodes[t], nodes[t], false, vft_pw_lds(pwLds, A.d.nPosPad, 0),
+                            vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((threadIdx.x & 63) != 0) return;
     A.selfdist[nodes[t]] = d;
     A.selfweight[nodes[t]] = w;
+}
+
+// dynamic LDS of the wave-per-item kernels
+static size_t pw_lds_bytes(const vft_ctx *c) { return (size_t) VFT_PW_WAVES * 2 * c->d.nPosPad * sizeof(double); }
+
+// long alignments: those kernels stage 2 doubles per column and wave, which can exceed the default dynamic-LDS limit
+static int raise_pair_kernel_lds(vft_ctx *c) {
+    const size_t bytes = pw_lds_bytes(c);
+    if (bytes <= (48u << 10)) return VFT_OK;
+    if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging");
+    VFT_DISPATCH(c, {
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distance_one<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_selfdist<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+    });
+    return VFT_OK;
 }
 
 extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
@@ -625,15 +745,27 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
     const int64_t chunk = append ? 16384 : 1;
     const size_t rs = c->rs;
     const size_t stashB = append ? (size_t) chunk * c->d.nPos * c->d.nCodes * rs : 0;
-    const size_t idB = (size_t) n * 8;
-    if (int r = ensure_scratch(c, 4 * idB + stashB + 256)) return r;
-    char *s = (char *) c->scratch;
-    char *stash = s + 4 * idB;
+    const size_t idB = (((size_t) n * 8) + 255) & ~(size_t) 255;
+    const bool smallIds = 4 * idB <= VFT_SMALL_BYTES;
+    if (int r = ensure_scratch(c, (smallIds ? 0 : 4 * idB) + stashB + 512)) return r;
+    char *s, *stash;
+    if (smallIds) {
+        char *h;
+        if (int r = io_alloc(c, 4 * idB, &h, &s)) return r;
+        memcpy(h, out, (size_t) n * 8);
+        memcpy(h + idB, a, (size_t) n * 8);
+        memcpy(h + 2 * idB, b, (size_t) n * 8);
+        if (bionj) memcpy(h + 3 * idB, bionj, (size_t) n * 8);
+        stash = (char *) c->scratch;
+    } else {
+        s = (char *) c->scratch;
+        stash = s + 4 * idB;
+        HIPCHK(c, hipMemcpyAsync(s, out, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + idB, a, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        if (bionj) HIPCHK(c, hipMemcpyAsync(s + 3 * idB, bionj, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+    }
     stash += (256 - ((uintptr_t) stash & 255)) & 255;
-    HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
-    if (bionj) HIPCHK(c, hipMemcpyAsync(s + 3 * idB, bionj, idB, hipMemcpyHostToDevice, c->stream));
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
         VFT_DISPATCH(c, {
@@ -649,11 +781,11 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         LAUNCHCHK(c);
     }
     mark_written(c, out, n);
-    VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream, arena<REAL>(c),
-                           (const int64_t *) s, n));
+    VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
+                           arena<REAL>(c), (const int64_t *) s, n));
     LAUNCHCHK(c);
-    // the id lists live in scratch: do not let a later call overwrite them before the kernels have read them
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // id lists in the mapped ring are protected by its wrap-around synchronisation; only the scratch path must wait
+    if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }
 
@@ -710,8 +842,8 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
     s.queryIsLeaf = 0;
     s.force = force ? 1 : 0;
     if (dIds) {
-        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream,
-                                            arena<REAL>(c), dIds, n, s)));
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+                                c->stream, arena<REAL>(c), dIds, n, s)));
         LAUNCHCHK(c);
         return VFT_OK;
     }
@@ -735,8 +867,8 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
                                arena<double>(c), qbuf<double>(c, 1), s, sweepout<double>(c));
         }
     } else {
-        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, 64)), dim3(64), 0, c->stream,
-                                            arena<REAL>(c), (const int64_t *) nullptr, span, s)));
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+                                c->stream, arena<REAL>(c), (const int64_t *) nullptr, span, s)));
     }
     LAUNCHCHK(c);
     return VFT_OK;
@@ -746,6 +878,23 @@ extern "C" int vft_out_distances(vft_ctx *c, int64_t n, const int64_t *ids, int6
     if (!c || nActive < 2) return VFT_ERR_INVALID;
     if (ids) {
         if (n <= 0) return VFT_OK;
+        if (n == 1) {
+            if (ids[0] < 0 || ids[0] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_out_distances: bad node");
+            SweepArgs s{};
+            s.nActive = nActive;
+            s.totdiam = totdiam;
+            s.force = 1;
+            VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(64), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+                                   arena<REAL>(c), ids[0], s));
+            LAUNCHCHK(c);
+            return VFT_OK;
+        }
+        char *h, *d;
+        if ((size_t) n * 8 <= VFT_SMALL_BYTES) {
+            if (int r = io_alloc(c, (size_t) n * 8, &h, &d)) return r;
+            memcpy(h, ids, (size_t) n * 8);
+            return launch_out_distances(c, (const int64_t *) d, n, nActive, 0, totdiam, true);
+        }
         if (int r = ensure_scratch(c, (size_t) n * 8)) return r;
         HIPCHK(c, hipMemcpyAsync(c->scratch, ids, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
         if (int r = launch_out_distances(c, (const int64_t *) c->scratch, n, nActive, 0, totdiam, true)) return r;
@@ -783,7 +932,7 @@ static int run_select(vft_ctx *c, int64_t lo, int64_t hi, int32_t k, int64_t que
         launch((k_select_best<REAL, HIT>), dim3(1), dim3(VFT_WG), 0, c->stream, c->sel, dHits, k, query, dHdr,
                (SelectHeader *) c->hResDev, (HIT *) (c->hResDev + sizeof(SelectHeader)));
         LAUNCHCHK(c);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int r = wait_stream(c)) return r;
         const SelectHeader *h = (const SelectHeader *) c->hRes;
         if (!h->overflow) return VFT_OK;
         // rare: the threshold bin alone has more candidates than the rank sort takes; narrow the key range to it
@@ -805,18 +954,13 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098)
     if (int r = launch_out_distances(c, nullptr, 0, nActive, nDiffAllow, totdiam, false)) return r;
     {
-        if (int r = ensure_scratch(c, 8)) return r;
-        HIPCHK(c, hipMemcpyAsync(c->scratch, &query, 8, hipMemcpyHostToDevice, c->stream));
         SweepArgs s{};
-        s.query = -1;
-        s.lo = 0;
-        s.hi = c->maxnode;
         s.nActive = nActive;
         s.nDiffAllow = nDiffAllow;
         s.totdiam = totdiam;
         s.force = 0;
-        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(1), dim3(64), 0, c->stream, arena<REAL>(c),
-                                            (const int64_t *) c->scratch, (int64_t) 1, s)));
+        VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(64), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+                               arena<REAL>(c), query, s));
         LAUNCHCHK(c);
     }
     // 2. the sweep itself
@@ -899,28 +1043,46 @@ extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, cons
     if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_pair_distances before vft_upload_leaves");
     for (int64_t t = 0; t < n; t++)
         if (pi[t] < 0 || pi[t] >= c->maxnode || pj[t] < 0 || pj[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "pair %lld out of range", (long long) t);
-    const size_t rs = c->rs, idB = (size_t) n * 8, oB = (size_t) n * rs;
-    if (int r = ensure_scratch(c, 2 * idB + 3 * oB + 64)) return r;
-    char *s = (char *) c->scratch;
-    int64_t *dI = (int64_t *) s, *dJ = (int64_t *) (s + idB);
-    char *o = s + 2 * idB;
-    HIPCHK(c, hipMemcpyAsync(dI, pi, idB, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dJ, pj, idB, hipMemcpyHostToDevice, c->stream));
+    const size_t rs = c->rs, idB = (((size_t) n * 8) + 255) & ~(size_t) 255, oB = (((size_t) n * rs) + 255) & ~(size_t) 255;
+    const bool small = 2 * idB + 3 * oB <= VFT_SMALL_BYTES;
+    char *hBase = nullptr, *dBase = nullptr;
+    if (small) {
+        if (int r = io_alloc(c, 2 * idB + 3 * oB, &hBase, &dBase)) return r;
+        memcpy(hBase, pi, (size_t) n * 8);
+        memcpy(hBase + idB, pj, (size_t) n * 8);
+    } else {
+        if (int r = ensure_scratch(c, 2 * idB + 3 * oB + 64)) return r;
+        dBase = (char *) c->scratch;
+        HIPCHK(c, hipMemcpyAsync(dBase, pi, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dBase + idB, pj, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    int64_t *dI = (int64_t *) dBase, *dJ = (int64_t *) (dBase + idB);
+    char *o = dBase + 2 * idB;
     SweepArgs sa{};
     sa.nActive = nActive;
     sa.nDiffAllow = nDiffAllow;
     sa.totdiam = totdiam;
     VFT_DISPATCH(c, {
         Arena<REAL> A = arena<REAL>(c);
-        launch((k_pairs_refresh<REAL, NC>), dim3(cdiv(2 * n, 64)), dim3(64), 0, c->stream, A, dI, dJ, n, sa);
+        launch((k_pairs_refresh<REAL, NC>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream, A, dI,
+               dJ, n, sa);
         launch((k_pairs_stamp<REAL>), dim3(cdiv(2 * n, 256)), dim3(256), 0, c->stream, A, dI, dJ, n, sa);
-        launch((k_pairs<REAL, NC>), dim3(cdiv(n, 64)), dim3(64), 0, c->stream, A, dI, dJ, n, nActive, (REAL *) o,
-                           (REAL *) (o + oB), (REAL *) (o + 2 * oB));
+        launch((k_pairs<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream, A, dI, dJ, n,
+               nActive, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB));
     });
     LAUNCHCHK(c);
-    if (dist) HIPCHK(c, hipMemcpyAsync(dist, o, oB, hipMemcpyDeviceToHost, c->stream));
-    if (weight) HIPCHK(c, hipMemcpyAsync(weight, o + oB, oB, hipMemcpyDeviceToHost, c->stream));
-    if (crit) HIPCHK(c, hipMemcpyAsync(crit, o + 2 * oB, oB, hipMemcpyDeviceToHost, c->stream));
+    if (small) {
+        // results were written straight into mapped host memory
+        if (int r = wait_stream(c)) return r;
+        const char *ho = hBase + 2 * idB;
+        if (dist) memcpy(dist, ho, (size_t) n * rs);
+        if (weight) memcpy(weight, ho + oB, (size_t) n * rs);
+        if (crit) memcpy(crit, ho + 2 * oB, (size_t) n * rs);
+        return VFT_OK;
+    }
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, o, (size_t) n * rs, hipMemcpyDeviceToHost, c->stream));
+    if (weight) HIPCHK(c, hipMemcpyAsync(weight, o + oB, (size_t) n * rs, hipMemcpyDeviceToHost, c->stream));
+    if (crit) HIPCHK(c, hipMemcpyAsync(crit, o + 2 * oB, (size_t) n * rs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }

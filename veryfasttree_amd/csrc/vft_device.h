@@ -17,6 +17,10 @@ struct Arena {
     int32_t *parent;
     REAL *diameter, *selfweight, *selfdist, *outDist;
     int32_t *nOutActive;
+    // host-mapped mirrors of outDist / nOutActive (zero-copy): every refresh also lands in host memory, so the
+    // host driver evaluates criteria (NJ.tcc:1099-1107) without fetching anything
+    REAL *mOutDist;
+    int32_t *mNOut;
     // out-profile, row-major: outW[nPos], outF[nPos][nCodes], outCD[nPos][nCodes] (only with a distance matrix)
     REAL *outW, *outF, *outCD;
     // distance matrix (NULL when %-different distances are used)

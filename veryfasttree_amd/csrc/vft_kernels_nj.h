@@ -328,9 +328,12 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
             O.crit[j] = crit;
             cmin = cmax = crit;
         } else {
-            A.outDist[j] = vft_out_distance<REAL>(dist, weight, s.nActive, A.selfweight[j], A.selfdist[j],
-                                                  A.diameter[j], s.totdiam);
+            const REAL od = vft_out_distance<REAL>(dist, weight, s.nActive, A.selfweight[j], A.selfdist[j],
+                                                   A.diameter[j], s.totdiam);
+            A.outDist[j] = od;
             A.nOutActive[j] = (int32_t) s.nActive;
+            A.mOutDist[j] = od;
+            A.mNOut[j] = (int32_t) s.nActive;
         }
     }
     if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
@@ -391,11 +394,92 @@ __device__ __forceinline__ void vft_pair_generic(const Arena<REAL> &A, int64_t i
     dist = (REAL) (denom > 0 ? top / denom : 1.0);
 }
 
+// Wave-cooperative evaluation of ONE pair, for short lists (pair lists, single out-distances, self distances) where a
+// lane-per-pair walk would be a chain of ~nPos dependent memory latencies.  The per-column addends
+//     wgt_p = (double)(numeric_t)(w1*w2)   and   term_p = wgt_p * piece_p          (NJ.tcc:1176-1182)
+// do not depend on each other, so the 64 lanes compute them for 64 columns at a time into LDS; lane 0 then adds them
+// up IN COLUMN ORDER (denom += wgt_p; top += term_p), which is exactly the reference's sequence of double
+// additions — columns it skips contribute +0.0, which is exact.  All 64 lanes must call; results are broadcast.
+// sW / sT: this wave's LDS scratch, nPosPad doubles each.
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
+                                              double *sT, REAL &dist, REAL &weight) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nPos = A.d.nPos;
+    const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
+    if (leaves && !A.dmDist && NC == 4) {   // seqDist, integer counts: any order
+        int nUse = 0, nSame = 0;
+        for (int c = lane; c < A.d.nChunk; c += 64)
+            vft_seq_counts(A.leafT[vft_leaf_idx(A.d, i >> 6, c, (int) (i & 63))],
+                           A.leafT[vft_leaf_idx(A.d, j >> 6, c, (int) (j & 63))], nUse, nSame);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nUse += __shfl_xor(nUse, off, 64);
+            nSame += __shfl_xor(nSame, off, 64);
+        }
+        weight = (REAL) (double) nUse;
+        dist = (REAL) (nUse > 0 ? (double) (nUse - nSame) / (double) nUse : 1.0);
+        return;
+    }
+    for (int64_t p = lane; p < nPos; p += 64) {
+        Col<REAL, NC> c1, c2;
+        vft_load_col<REAL, NC>(A, i, p, c1);
+        if (jIsOut) {
+            c2.w = A.outW[p];
+            c2.code = VFT_NOCODE_;
+            c2.vec = c2.w > 0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) c2.f[k] = A.outF[p * NC + k];
+        } else {
+            vft_load_col<REAL, NC>(A, j, p, c2);
+        }
+        double wgt = 0.0, term = 0.0;
+        if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
+            if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
+                wgt = 1.0;
+                term = A.dmDist ? (double) A.dmDist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
+            }
+        } else if (c1.w > 0 && c2.w > 0) {
+            const REAL ww = c1.w * c2.w;
+            wgt = (double) ww;
+            term = wgt * vft_piece<REAL, NC>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr);
+        }
+        sW[p] = wgt;
+        sT[p] = term;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double top = 0, denom = 0;
+    if (lane == 0) {
+        for (int64_t p = 0; p < nPos; p++) {
+            denom += sW[p];
+            top += sT[p];
+        }
+    }
+    top = __shfl(top, 0, 64);
+    denom = __shfl(denom, 0, 64);
+    if (leaves) {
+        weight = (REAL) denom;   // nUse
+        dist = (REAL) (denom > 0 ? top / denom : 1.0);
+    } else {
+        weight = (REAL) (denom > 0 ? denom : 0.01);
+        dist = (REAL) (denom > 0 ? top / denom : 1.0);
+    }
+}
+
+#define VFT_PW_WAVES 4   // pairs per 256-thread workgroup in the wave-per-item kernels
+// dynamic LDS of those kernels: VFT_PW_WAVES * 2 * nPosPad doubles
+__device__ __forceinline__ double *vft_pw_lds(double *base, int64_t nPosPad, int which) {
+    return base + ((int64_t) (threadIdx.x >> 6) * 2 + which) * nPosPad;
+}
+
 // setOutDistance for a list of nodes, or (ids == nullptr) for every active node of [lo,hi).  Unless s.force is
 // set only nodes staler than nDiffAllow are recomputed (setCriterion's lazy refresh, NJ.tcc:1092-1098).
 template <typename REAL, int NC>
-__global__ void k_out_distances(Arena<REAL> A, const int64_t *ids, int64_t n, SweepArgs s) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(VFT_WG) void k_out_distances(Arena<REAL> A, const int64_t *ids, int64_t n, SweepArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);   // wave-uniform item index
     int64_t v;
     if (ids) {
         if (t >= n) return;
@@ -407,9 +491,38 @@ __global__ void k_out_distances(Arena<REAL> A, const int64_t *ids, int64_t n, Sw
     if (!s.force && !((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
     if ((int64_t) A.nOutActive[v] == s.nActive) return;   // NJ.tcc:1013-1015
     REAL d, w;
-    vft_pair_generic<REAL, NC>(A, v, -1, true, d, w);
-    A.outDist[v] = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+    vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((threadIdx.x & 63) != 0) return;
+    const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+    A.outDist[v] = od;
     A.nOutActive[v] = (int32_t) s.nActive;
+    A.mOutDist[v] = od;
+    A.mNOut[v] = (int32_t) s.nActive;
+}
+
+// the same for ONE node passed by value (the query of a sweep): no id list to ship
+template <typename REAL, int NC>
+__global__ __launch_bounds__(64) void k_out_distance_one(Arena<REAL> A, int64_t v, SweepArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    if (!s.force && !((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
+    if ((int64_t) A.nOutActive[v] == s.nActive) return;
+    REAL d, w;
+    vft_pair_wave<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
+    if (threadIdx.x != 0) return;
+    const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+    A.outDist[v] = od;
+    A.nOutActive[v] = (int32_t) s.nActive;
+    A.mOutDist[v] = od;
+    A.mNOut[v] = (int32_t) s.nActive;
+}
+
+// small stream-ordered state writes (no host synchronisation): dst[first + t] = src[t], with optional mirrors
+template <typename T>
+__global__ void k_store_range(T *dst, T *mirror, const T *src, int64_t first, int64_t count) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    dst[first + t] = src[t];
+    if (mirror) mirror[first + t] = src[t];
 }
 
 // Generic one-vs-all sweep (any alphabet / matrix): lane per target, query fixed.
@@ -442,13 +555,15 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_generic(Arena<REAL> A, SweepAr
 
 // setDistCriterion over an explicit pair list.  Out-distances must have been refreshed by k_pairs_refresh first.
 template <typename REAL, int NC>
-__global__ void k_pairs(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, int64_t nActive, REAL *dist,
-                        REAL *weight, REAL *crit) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(VFT_WG) void k_pairs(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
+                                                  int64_t nActive, REAL *dist, REAL *weight, REAL *crit) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;
     const int64_t i = pi[t], j = pj[t];
     REAL d, w;
-    vft_pair_generic<REAL, NC>(A, i, j, false, d, w);
+    vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((threadIdx.x & 63) != 0) return;
     if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
         const REAL dd = A.diameter[i] + A.diameter[j];
         d = d - dd;
@@ -461,24 +576,31 @@ __global__ void k_pairs(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int
 // Lazy out-distance refresh of every node named in a pair list (setCriterion, NJ.tcc:1092-1098).  A node may be
 // named many times: the refresh is idempotent and all writers store the same value.
 template <typename REAL, int NC>
-__global__ void k_pairs_refresh(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, SweepArgs s) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(VFT_WG) void k_pairs_refresh(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
+                                                          SweepArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= 2 * n) return;
     const int64_t v = t < n ? pi[t] : pj[t - n];
     if (!((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
     REAL d, w;
-    vft_pair_generic<REAL, NC>(A, v, -1, true, d, w);
+    vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((threadIdx.x & 63) != 0) return;
     const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
     // two-phase: values first, staleness stamps in k_pairs_stamp, so that concurrent readers of nOutActive in
     // this launch keep seeing "stale" and recompute the identical value instead of racing on a half-update
     A.outDist[v] = od;
+    A.mOutDist[v] = od;
 }
 template <typename REAL>
 __global__ void k_pairs_stamp(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, SweepArgs s) {
     const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * n) return;
     const int64_t v = t < n ? pi[t] : pj[t - n];
-    if ((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow) A.nOutActive[v] = (int32_t) s.nActive;
+    if ((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow) {
+        A.nOutActive[v] = (int32_t) s.nActive;
+        A.mNOut[v] = (int32_t) s.nActive;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ top-k select

@@ -11,16 +11,22 @@
 // constraints, no BIONJ weighting, top-hits on: m >= 4 and 2m < nSeqs).
 //
 // Device-side lazy state: out-distances are refreshed on the device inside sweeps / pair lists exactly when the
-// reference refreshes them (setCriterion, NJ.tcc:1092-1098).  The host mirrors the staleness stamps by applying the
-// same deterministic rule and fetches a refreshed VALUE only when a host-side criterion needs it (`dirty`).
+// reference refreshes them (setCriterion, NJ.tcc:1092-1098).  Every refresh is also stored by the kernels into
+// host-mapped mirrors (vft_out_distance_mirror), which this driver reads directly; it only has to make sure the
+// stream has drained (`pending`) after calls that do not return data.
 #ifndef VERYFASTTREE_NJDRIVER_H
 #define VERYFASTTREE_NJDRIVER_H
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vft_hip.h"
@@ -49,9 +55,6 @@ namespace veryfasttree {
             child1.assign(maxnodes, -1);
             diameter.assign(maxnodes, 0);
             branchlength.assign(maxnodes, 0);
-            outDist.assign(maxnodes, 0);
-            nOut.assign(maxnodes, 10 * nSeqs);
-            dirty.assign(maxnodes, 0);
             selfweightLeaf.resize(nSeqs);
             for (int64_t i = 0; i < nSeqs; i++) {
                 int64_t c = 0;
@@ -59,18 +62,21 @@ namespace veryfasttree {
                 selfweightLeaf[i] = (REAL) c;
             }
             /* NJ constructor, NJ.tcc:233-260 */
-            chk(vft_upload_leaves(ctx, codes));
+            chkT("vft_upload_leaves", [&]() { return vft_upload_leaves(ctx, codes); });
             std::vector<REAL> z(nSeqs, 0);
-            chk(vft_set_node_scalars(ctx, 0, nSeqs, z.data(), selfweightLeaf.data(), z.data()));
-            chk(vft_set_max_node(ctx, nSeqs));
+            chkT("vft_set_node_scalars", [&]() { return vft_set_node_scalars(ctx, 0, nSeqs, z.data(), selfweightLeaf.data(), z.data()); });
+            chkT("vft_set_max_node", [&]() { return vft_set_max_node(ctx, nSeqs); });
             std::vector<int64_t> ids(nSeqs);
             for (int64_t i = 0; i < nSeqs; i++) ids[i] = i;
-            chk(vft_out_profile_full(ctx, nSeqs, ids.data()));
+            chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, nSeqs, ids.data()); });
             std::vector<int64_t> stale(nSeqs, 10 * nSeqs);
-            chk(vft_set_out_distances(ctx, 0, nSeqs, z.data(), stale.data()));
-            chk(vft_out_distances(ctx, 0, nullptr, nSeqs, 0.0));
-            chk(vft_synchronize(ctx));
-            fetchAll(nSeqs);
+            chkT("vft_set_out_distances", [&]() { return vft_set_out_distances(ctx, 0, nSeqs, z.data(), stale.data()); });
+            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, 0, nullptr, nSeqs, 0.0); });
+            chkT("vft_synchronize", [&]() { return vft_synchronize(ctx); });
+            const void *od;
+            chkT("vft_out_distance_mirror", [&]() { return vft_out_distance_mirror(ctx, &od, &mN); });
+            mOut = (const REAL *) od;
+            pending = false;
         }
 
         const std::vector<Join> &run(int64_t maxJoins = -1) {
@@ -102,11 +108,11 @@ namespace veryfasttree {
                 const double bw = 0.5;
                 const REAL bi = branchlength[i] + diameter[i], bj = branchlength[j] + diameter[j];
                 diameter[newnode] = (REAL) (bw * bi + (1 - bw) * bj);
-                chk(vft_set_max_node(ctx, maxnode));
-                chk(vft_average_profiles(ctx, 1, &newnode, &i, &j, nullptr));
-                chk(vft_set_parents(ctx, i, 1, &newnode));
-                chk(vft_set_parents(ctx, j, 1, &newnode));
-                chk(vft_set_node_scalars(ctx, newnode, 1, &diameter[newnode], nullptr, nullptr));
+                chkT("vft_set_max_node", [&]() { return vft_set_max_node(ctx, maxnode); });
+                chkT("vft_average_profiles", [&]() { return vft_average_profiles(ctx, 1, &newnode, &i, &j, nullptr); });
+                chkT("vft_set_parents", [&]() { return vft_set_parents(ctx, i, 1, &newnode); });
+                chkT("vft_set_parents", [&]() { return vft_set_parents(ctx, j, 1, &newnode); });
+                chkT("vft_set_node_scalars", [&]() { return vft_set_node_scalars(ctx, newnode, 1, &diameter[newnode], nullptr, nullptr); });
                 const int64_t changed = nActiveReset - (nActive - 1);
                 if (changed >= opt.nResetOutProfile && changed >= opt.fResetOutProfile * nActiveReset) {
                     std::vector<int64_t> active;
@@ -117,19 +123,16 @@ namespace veryfasttree {
                             tot += diameter[v];
                         }
                     totdiam = tot;
-                    chk(vft_out_profile_full(ctx, (int64_t) active.size(), active.data()));
+                    chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, (int64_t) active.size(), active.data()); });
                     nActiveReset = nActive - 1;
                 } else {
-                    chk(vft_out_profile_update(ctx, i, j, newnode, nActive));
+                    chkT("vft_out_profile_update", [&]() { return vft_out_profile_update(ctx, i, j, newnode, nActive); });
                     const REAL dd = diameter[newnode] - diameter[i] - diameter[j];
                     totdiam += dd;
                 }
                 REAL zero = 0;
                 int64_t staleStamp = 10 * nSeqs;
-                chk(vft_set_out_distances(ctx, newnode, 1, &zero, &staleStamp));
-                outDist[newnode] = 0;
-                nOut[newnode] = staleStamp;
-                dirty[newnode] = 0;
+                chkT("vft_set_out_distances", [&]() { return vft_set_out_distances(ctx, newnode, 1, &zero, &staleStamp); });   /* NJ.tcc:254: "unreasonably high" */
                 topHitJoin(newnode, nActive - 1);
             }
             return joins;
@@ -152,9 +155,11 @@ namespace veryfasttree {
         NJOptions opt;
         int64_t nSeqs, nPos, maxnodes, maxnode;
         double totdiam;
-        std::vector<int64_t> parent, child0, child1, nOut;
-        std::vector<REAL> diameter, branchlength, outDist, selfweightLeaf;
-        std::vector<uint8_t> dirty;
+        std::vector<int64_t> parent, child0, child1;
+        std::vector<REAL> diameter, branchlength, selfweightLeaf;
+        const REAL *mOut = nullptr;     /* host-mapped mirrors written by the device */
+        const int32_t *mN = nullptr;
+        bool pending = false;           /* a call that may refresh out-distances has not been waited for yet */
         /* top hits (NJ.h:206-248) */
         int64_t m = 0, q = 0, topvisibleAge = 0;
         std::vector<std::vector<Hit> > hits;
@@ -165,55 +170,106 @@ namespace veryfasttree {
             if (rc != VFT_OK) throw std::invalid_argument(std::string("NJDriver: ") + vft_last_error(ctx));
         }
 
+        /* optional per-entry-point wall-clock accounting (VFT_NJ_PROFILE=1) */
+        struct Acc {
+            double seconds = 0;
+            int64_t calls = 0;
+        };
+        std::map<std::string, Acc> acc;
+        bool profiling = std::getenv("VFT_NJ_PROFILE") != nullptr;
+
+        template<typename F>
+        void chkT(const char *name, F f) {
+            if (!profiling) {
+                chk(f());
+                return;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = f();
+            Acc &a = acc[name];
+            a.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            a.calls++;
+            chk(rc);
+        }
+
+    public:
+        void report() const {
+            if (!profiling) return;
+            for (const auto &kv: acc)
+                fprintf(stderr, "  %-28s %9lld calls %9.3f s  %8.1f us/call\n", kv.first.c_str(), (long long) kv.second.calls,
+                        kv.second.seconds, 1e6 * kv.second.seconds / (double) (kv.second.calls ? kv.second.calls : 1));
+        }
+
+    private:
+
         /* ---- out-distance mirror */
         int64_t nDiffAllow(int64_t nActive) const {
             return opt.tophitsMult > 0 ? (int64_t) (nActive * opt.staleOutLimit) : 0;
         }
 
-        void fetchAll(int64_t upto) {
-            chk(vft_get_out_distances(ctx, 0, upto, outDist.data(), nOut.data()));
-            std::fill(dirty.begin(), dirty.begin() + upto, 0);
+        void drain() {
+            if (pending) {
+                chkT("vft_synchronize", [&]() { return vft_synchronize(ctx); });
+                pending = false;
+            }
         }
 
         REAL value(int64_t v) {
-            if (dirty[v]) {
-                int64_t stamp;
-                chk(vft_get_out_distances(ctx, v, 1, &outDist[v], &stamp));
-                dirty[v] = 0;
-            }
-            return outDist[v];
+            drain();
+            return mOut[v];
         }
 
-        /* the device refreshed v iff it was staler than allowed (same rule as NJ.tcc:1092-1098) */
-        void noteLazy(int64_t v, int64_t nActive, int64_t allow) {
-            if (nOut[v] - nActive > allow) {
-                nOut[v] = nActive;
-                dirty[v] = 1;
-            }
+        int64_t stamp(int64_t v) {
+            drain();
+            return mN[v];
         }
 
-        void noteSweep(int64_t nActive) {
+        /* Batched form of the lazy refresh inside setCriterion: `pairs` lists the (i, j) a loop is ABOUT to pass to
+           setCriterion, all of them, unconditionally (loops with early exits must not use this).  The refresh of a
+           node depends only on the node, nActive, the out-profile and totdiam, none of which change inside such a
+           loop, so refreshing the stale ones up front in one device call is the same computation. */
+        void prefetchStale(int64_t nActive, const std::vector<std::pair<int64_t, int64_t> > &pairs) {
+            drain();
             const int64_t allow = nDiffAllow(nActive);
-            for (int64_t v = 0; v < maxnode; v++)
-                if (parent[v] < 0) noteLazy(v, nActive, allow);
+            std::vector<int64_t> ids;
+            for (const auto &pr: pairs) {
+                const int64_t i = pr.first, j = pr.second;
+                if (i < 0 || j < 0 || parent[i] >= 0 || parent[j] >= 0) continue;
+                if (mN[i] - nActive > allow) ids.push_back(i);
+                if (mN[j] - nActive > allow) ids.push_back(j);
+            }
+            if (ids.empty()) return;
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            const int64_t n = (int64_t) ids.size();
+            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, n, ids.data(), nActive, totdiam); });
+            pending = true;
+        }
+
+        void prefetchVisible(int64_t nActive, const std::vector<int64_t> &nodes) {
+            std::vector<std::pair<int64_t, int64_t> > pairs;
+            for (int64_t node: nodes) {
+                if (node < 0 || parent[node] >= 0) continue;
+                pairs.push_back(std::make_pair(node, visible[node].j));
+            }
+            prefetchStale(nActive, pairs);
         }
 
         void setOutDistance(int64_t node, int64_t nActive) {
-            if (nOut[node] == nActive) return;
-            chk(vft_out_distances(ctx, 1, &node, nActive, totdiam));
-            nOut[node] = nActive;
-            dirty[node] = 1;
+            if (stamp(node) == nActive) return;
+            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, 1, &node, nActive, totdiam); });
+            pending = true;
         }
 
         void setCriterion(int64_t nActive, Besthit &hit) { /* NJ.tcc:1085-1113 */
             if (hit.i < 0 || hit.j < 0 || parent[hit.i] >= 0 || parent[hit.j] >= 0) return;
             const int64_t allow = nDiffAllow(nActive);
-            if (nOut[hit.i] - nActive > allow) setOutDistance(hit.i, nActive);
-            if (nOut[hit.j] - nActive > allow) setOutDistance(hit.j, nActive);
+            if (stamp(hit.i) - nActive > allow) setOutDistance(hit.i, nActive);
+            if (stamp(hit.j) - nActive > allow) setOutDistance(hit.j, nActive);
             double outI = value(hit.i);
-            if (nOut[hit.i] != nActive) outI *= (nActive - 1) / (double) (nOut[hit.i] - 1);
+            if (stamp(hit.i) != nActive) outI *= (nActive - 1) / (double) (stamp(hit.i) - 1);
             double outJ = value(hit.j);
-            if (nOut[hit.j] != nActive) outJ *= (nActive - 1) / (double) (nOut[hit.j] - 1);
+            if (stamp(hit.j) != nActive) outJ *= (nActive - 1) / (double) (stamp(hit.j) - 1);
             hit.criterion = (REAL) (hit.dist - (outI + outJ) / (double) (nActive - 2));
         }
 
@@ -226,14 +282,13 @@ namespace veryfasttree {
                 pi[t] = list[t]->i;
                 pj[t] = list[t]->j;
             }
-            const int64_t allow = nDiffAllow(nActive);
-            chk(vft_pair_distances(ctx, n, pi.data(), pj.data(), nActive, allow, totdiam, d.data(), w.data(), c.data()));
+            chkT("vft_pair_distances", [&]() { return vft_pair_distances(ctx, n, pi.data(), pj.data(), nActive, nDiffAllow(nActive), totdiam, d.data(), w.data(),
+                                   c.data()); });
+            pending = false;   /* the call returned data: the stream has drained */
             for (int64_t t = 0; t < n; t++) {
                 list[t]->dist = d[t];
                 list[t]->weight = w[t];
                 list[t]->criterion = c[t];
-                noteLazy(pi[t], nActive, allow);
-                noteLazy(pj[t], nActive, allow);
             }
         }
 
@@ -345,6 +400,11 @@ namespace veryfasttree {
                 }
             }
             setDistCriterionBatch(nActive, todoDist);
+            if (!todoCrit.empty()) {
+                std::vector<std::pair<int64_t, int64_t> > pairs;
+                for (Besthit *h: todoCrit) pairs.push_back(std::make_pair(h->i, h->j));
+                prefetchStale(nActive, pairs);
+            }
             for (Besthit *h: todoCrit) setCriterion(nActive, *h);
             return out;
         }
@@ -390,6 +450,12 @@ namespace veryfasttree {
                     isTodo[t] = 1;
                 }
             setDistCriterionBatch(nActive, todo);
+            {
+                std::vector<std::pair<int64_t, int64_t> > pairs;
+                for (size_t t = 0; t < out.size(); t++)
+                    if (!isTodo[t]) pairs.push_back(std::make_pair(out[t].i, out[t].j));
+                prefetchStale(nActive, pairs);
+            }
             for (size_t t = 0; t < out.size(); t++)
                 if (!isTodo[t]) setCriterion(nActive, out[t]);
             return out;
@@ -447,6 +513,12 @@ namespace veryfasttree {
         }
 
         void updateVisible(int64_t nActive, const std::vector<Besthit> &list, int64_t count) { /* NJ.tcc:4633-4657 */
+            {
+                std::vector<int64_t> nodes;
+                for (int64_t t = 0; t < count; t++)
+                    if (list[t].i >= 0) nodes.push_back(list[t].j);
+                prefetchVisible(nActive, nodes);
+            }
             for (int64_t t = 0; t < count; t++) {
                 const Besthit &hit = list[t];
                 if (hit.i < 0) continue;
@@ -470,6 +542,12 @@ namespace veryfasttree {
                 b.weight = b.dist = b.criterion = 0;
             }
             int64_t nVisible = 0;
+            {
+                std::vector<int64_t> nodes;
+                for (int64_t node = 0; node < maxnode; node++)
+                    if (parent[node] < 0) nodes.push_back(node);
+                prefetchVisible(nActive, nodes);
+            }
             for (int64_t node = 0; node < maxnode; node++) {
                 if (parent[node] >= 0) continue;
                 Besthit v;
@@ -493,8 +571,8 @@ namespace veryfasttree {
         /* one-vs-all sweep -> the first k records of the reference's sorted besthits array */
         std::vector<Besthit> sweep(int64_t node, int64_t nActive, int32_t k) {
             std::vector<DevHit> dev((size_t) k);
-            chk(vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, k, dev.data(), nullptr, nullptr));
-            noteSweep(nActive);
+            chkT("vft_sweep", [&]() { return vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, k, dev.data(), nullptr, nullptr); });
+            pending = false;
             std::vector<Besthit> out((size_t) k);
             for (int32_t t = 0; t < k; t++) {
                 out[t].i = dev[t].j >= 0 ? node : -1;
@@ -524,7 +602,7 @@ namespace veryfasttree {
             /* CompareSeeds (NJ.tcc:7285-7299) with the psort tie rule */
             std::sort(seeds.begin(), seeds.end(), [&](int64_t a, int64_t b) {
                 if (nGaps[a] != nGaps[b]) return nGaps[a] < nGaps[b];
-                if (outDist[a] != outDist[b]) return outDist[a] < outDist[b];
+                if (mOut[a] != mOut[b]) return mOut[a] < mOut[b];
                 return a > b;
             });
             std::vector<uint8_t> visited(n, 0);
@@ -612,6 +690,12 @@ namespace veryfasttree {
             std::vector<Besthit *> todo;
             for (size_t t = 0; t < cand.size(); t++) ok[t] = updateBestHit(cand[t], true, &todo) ? 1 : 0;
             setDistCriterionBatch(nActive, todo);
+            {
+                std::vector<std::pair<int64_t, int64_t> > pairs;
+                for (size_t t = 0; t < cand.size(); t++)
+                    if (ok[t]) pairs.push_back(std::make_pair(cand[t].i, cand[t].j));
+                prefetchStale(nActive, pairs);
+            }
             for (size_t t = 0; t < cand.size(); t++) {
                 if (!ok[t]) continue;
                 setCriterion(nActive, cand[t]);
@@ -626,6 +710,7 @@ namespace veryfasttree {
                 int64_t nCand = 0;
                 bestNode = -1;
                 double bestCrit = 1e20;
+                prefetchVisible(nActive, topvisible);
                 for (int64_t node: topvisible) {
                     Besthit v;
                     if (getVisible(nActive, node, v)) {
@@ -709,20 +794,11 @@ namespace veryfasttree {
             /* refresh */
             age[newnode] = 0;
             if (opt.fastest) {
-                for (int64_t node = 0; node < maxnode; node++)
-                    if (parent[node] < 0) {
-                        Besthit bh;
-                        bh.i = bh.j = node;
-                        bh.dist = 0;
-                        setCriterion(nActive, bh);
-                    }
+                /* NJ.tcc:4454-4459 touches every active node with setCriterion, i.e. refreshes exactly the out-distances
+                   that are staler than allowed: that is the lazy pre-pass vft_sweep runs before the sweep below */
             } else {
-                chk(vft_out_distances(ctx, 0, nullptr, nActive, totdiam));
-                for (int64_t v = 0; v < maxnode; v++)
-                    if (parent[v] < 0 && nOut[v] != nActive) {
-                        nOut[v] = nActive;
-                        dirty[v] = 1;
-                    }
+                chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, 0, nullptr, nActive, totdiam); });
+                pending = true;
             }
             std::vector<Besthit> all = sweep(newnode, nActive, (int32_t) (2 * m));
             std::vector<Besthit> copy(all);
@@ -734,6 +810,11 @@ namespace veryfasttree {
                 const int64_t nOld = (int64_t) hits[node].size();
                 age[node] = 0;
                 std::vector<Besthit> both = hitsToBestHits(hits[node], node);
+                {
+                    std::vector<std::pair<int64_t, int64_t> > pairs;
+                    for (const Besthit &b: both) pairs.push_back(std::make_pair(b.i, b.j));
+                    prefetchStale(nActive, pairs);
+                }
                 for (Besthit &b: both) setCriterion(nActive, b);
                 const int64_t nNew = m;
                 std::vector<Besthit> tr = transferBestHits(nActive, node, all, 2 * nNew, false);

@@ -23,6 +23,7 @@ static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int6
     }
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, opt);
     const auto &js = drv.run(maxJoins);
+    drv.report();
     for (size_t k = 0; k < js.size(); k++) {
         joins[3 * k] = js[k].i;
         joins[3 * k + 1] = js[k].j;
