@@ -13,7 +13,7 @@ extern "C" {
 
 typedef struct {
     int32_t fastest;            /* -fastest (main.cpp:339-343): also sets tophits_refresh = 0.5 in the caller */
-    int32_t reserved;
+    int32_t use_tophits_2nd;    /* Options::useTopHits2nd: on with -fastest at one thread (VeryFastTree.cpp:87-91) */
     double tophits_mult;        /* Options::tophitsMult      (1.0) */
     double tophits_close;       /* Options::tophitsClose     (-1 = log2N/(log2N+2)) */
     double tophits_refresh;     /* Options::tophitsRefresh   (0.8) */
@@ -21,7 +21,9 @@ typedef struct {
     double stale_out_limit;     /* Options::staleOutLimit    (0.01) */
     double f_reset_out_profile; /* Options::fResetOutProfile (0.02) */
     int32_t n_reset_out_profile;/* Options::nResetOutProfile (200) */
-    int32_t reserved2;
+    int32_t tophits2_safety;    /* Options::tophits2Safety   (3) */
+    double tophits2_mult;       /* Options::tophits2Mult     (1.0) */
+    double tophits2_refresh;    /* Options::tophits2Refresh  (0.6) */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

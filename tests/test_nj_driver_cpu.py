@@ -21,14 +21,15 @@ def unique_codes(codes):
     return codes[keep]
 
 
-@pytest.mark.parametrize("name,fastest,limit", [("bb_nt_c1", True, None), ("bb_nt_200", False, None),
-                                                ("bb_nt_600_fastest_no2nd", True, None),
-                                                ("bb_nt_1500", False, 450)])
-def test_join_order_matches_reference(name, fastest, limit):
+@pytest.mark.parametrize("name,fastest,second,limit", [("bb_nt_c1", True, True, None), ("bb_nt_200", False, False, None),
+                                                       ("bb_nt_600_fastest_no2nd", True, False, None),
+                                                       ("bb_nt_600_fastest", True, True, None),
+                                                       ("bb_nt_1500", False, False, 450)])
+def test_join_order_matches_reference(name, fastest, second, limit):
     d = G.load(name)
     codes = unique_codes(d["codes"])
     ops = OracleOps(codes.shape[0], codes.shape[1], 4, np.float32)
-    drv = NJDriver(ops, codes, fastest=fastest)
+    drv = NJDriver(ops, codes, fastest=fastest, use_tophits_2nd=second)
     if fastest:
         drv.tophits_refresh = 0.5   # main.cpp:339-343: -fastest
     joins = drv.run(max_joins=limit)

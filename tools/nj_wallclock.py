@@ -18,7 +18,7 @@ codes = codes[np.sort(first)]
 print("unique sequences:", codes.shape[0])
 ops = HipProfileOps(codes.shape[0], L, 4, np.float32)
 t0 = time.perf_counter()
-joins, crit = nj_run(ops, codes, fastest=fastest)
+joins, crit = nj_run(ops, codes, fastest=fastest, second_level=False)
 t_gpu = time.perf_counter() - t0
 print("GPU NJ phase: %.2f s for %d joins" % (t_gpu, len(joins)))
 ref = os.path.join(ROOT, "oracle", "_ref", "VeryFastTree")

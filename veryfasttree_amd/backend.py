@@ -45,9 +45,10 @@ HOST_EXPORTS = ["vft_nj_run"]
 
 
 class _NJOptions(C.Structure):
-    _fields_ = [("fastest", I32), ("reserved", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
+    _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
-                ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("reserved2", I32)]
+                ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double)]
 
 
 _lib = None
@@ -65,14 +66,17 @@ def load_host_library():
     return _host_lib
 
 
-def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None):
-    """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n])."""
+def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None):
+    """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n]).
+    second_level defaults to `fastest`, as in the reference at one thread (-fastest turns -2nd on)."""
     lib = load_host_library()
     codes = np.ascontiguousarray(codes, np.uint8)
     n, L = codes.shape
-    opt = _NJOptions(1 if fastest else 0, 0, 1.0, -1.0,
+    if second_level is None:
+        second_level = fastest
+    opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0,
                      tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
-                     200, 0)
+                     200, 3, 1.0, 0.6)
     joins = np.zeros((max(n - 3, 1), 3), np.int64)
     crit = np.zeros(max(n - 3, 1), np.float64)
     nj = I64(0)

@@ -32,6 +32,8 @@ struct vft_ctx {
     // lane of every tile (a batch may use the append path only above it)
     std::vector<uint8_t> written;
     std::vector<int8_t> tileMaxLane;
+    std::vector<int32_t> hParent;          // host copy of parent[], to recognise "all active nodes, ascending" lists
+    unsigned long long *tileMask = nullptr;
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
     void *outW = nullptr, *outF = nullptr, *outCD = nullptr;
@@ -294,6 +296,9 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(dalloc(&c->vecMask, (size_t) c->nProfTiles * d.nPosPad));
     CR(hipMemset(c->vecMask, 0, (size_t) c->nProfTiles * d.nPosPad * 8));
     c->written.assign((size_t) N, 0);
+    c->hParent.assign((size_t) N, 0);
+    for (int64_t i = 0; i < cfg->max_nodes; i++) c->hParent[(size_t) i] = -1;
+    CR(dalloc(&c->tileMask, (size_t) d.nTiles));
     c->tileMaxLane.assign((size_t) d.nTiles, -1);
     CR(hipMemset(c->profC, 0x7F, (size_t) c->nProfTiles * d.nChunk * VFT_TILE * sizeof(uint4)));
     CR(dalloc(&c->parent, (size_t) N));
@@ -370,7 +375,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
-    void *ptrs[] = {c->vecMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
+    void *ptrs[] = {c->tileMask, c->vecMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
                     c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit,
                     c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
@@ -521,7 +526,10 @@ extern "C" int vft_set_parents(vft_ctx *c, int64_t first, int64_t count, const i
     if (!c || !parent) return VFT_ERR_INVALID;
     if (int r = range_ok(c, first, count)) return r;
     std::vector<int32_t> p((size_t) count);
-    for (int64_t i = 0; i < count; i++) p[(size_t) i] = parent[i] < 0 ? -1 : (int32_t) parent[i];
+    for (int64_t i = 0; i < count; i++) {
+        p[(size_t) i] = parent[i] < 0 ? -1 : (int32_t) parent[i];
+        c->hParent[(size_t) (first + i)] = p[(size_t) i];
+    }
     return store_range<int32_t>(c, c->parent, nullptr, p.data(), first, count);
 }
 
@@ -792,6 +800,31 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
 // ---------------------------------------------------------------------------------------------- out-profile
 extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
     if (!c || n < 1 || !ids) return VFT_ERR_INVALID;
+    // fast path: nucleotide, no matrix, and the list is exactly the active nodes below maxnode in ascending order
+    // (what the join loop passes, NJ.tcc:3017-3031)
+    bool tiled = c->cfg.n_codes == 4 && !c->hasDm;
+    if (tiled) {
+        int64_t k = 0;
+        for (int64_t v = 0; v < c->maxnode && tiled; v++) {
+            if (c->hParent[(size_t) v] >= 0) continue;
+            if (k >= n || ids[k] != v) tiled = false;
+            k++;
+        }
+        if (k != n) tiled = false;
+    }
+    if (tiled) {
+        const int64_t nTiles = (c->maxnode + 63) / 64;
+        launch(k_tile_active_masks, dim3(cdiv(nTiles, 4)), dim3(256), 0, c->stream, (const int32_t *) c->parent, c->maxnode,
+               c->tileMask, nTiles);
+        if (c->cfg.precision == 4)
+            launch((k_outprofile_full_tiled<float>), dim3((unsigned) c->d.nChunk), dim3(VFT_WG_PROF), 0, c->stream,
+                   arena<float>(c), (const unsigned long long *) c->tileMask, nTiles, n, c->fpostTol);
+        else
+            launch((k_outprofile_full_tiled<double>), dim3((unsigned) c->d.nChunk), dim3(VFT_WG_PROF), 0, c->stream,
+                   arena<double>(c), (const unsigned long long *) c->tileMask, nTiles, n, c->fpostTol);
+        LAUNCHCHK(c);
+        return VFT_OK;
+    }
     if (int r = ensure_scratch(c, (size_t) n * 8)) return r;
     HIPCHK(c, hipMemcpyAsync(c->scratch, ids, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
     VFT_DISPATCH(c, (launch((k_outprofile_full<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,

@@ -5,6 +5,8 @@
 #pragma once
 #include "vft_device.h"
 
+#define VFT_WG_PROF 256
+
 // Write one column of one node.  The vectors of a (tile, column) row are packed by lane order, so a write that
 // adds or removes a vector moves the vectors of the higher lanes by one slot.  NOT safe for two nodes of the same
 // tile concurrently: callers either write one node per launch or use the append path below.
@@ -254,4 +256,151 @@ __global__ void k_outprofile_update(Arena<REAL> A, int64_t old1, int64_t old2, i
 #pragma unroll
     for (int k = 0; k < NC; k++) A.outF[p * NC + k] = f[k];
     vft_out_codedist<REAL, NC>(A, p, f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// outProfile over ALL active nodes in ascending id order (what the join loop passes, NJ.tcc:3017-3031), nucleotide,
+// no distance matrix.  The accumulation over profiles is order-sensitive (float sums, NJ.tcc:738-784), so each
+// (column, chain) — chain 0 the weight, chains 1..4 the four frequencies — is one thread walking the nodes in order;
+// what is parallel is the 16 columns x 5 chains of a workgroup and the cooperative, coalesced staging of every tile
+// (64 nodes x 16 columns: weights, codes, vector mask, packed vectors) through LDS, prefetched one tile ahead.
+// k_outprofile_full does the same through per-thread gathers and is ~8x slower; it remains for arbitrary id lists and
+// for the matrix / amino-acid case.
+__global__ void k_tile_active_masks(const int32_t *parent, int64_t maxnode, unsigned long long *tileMask, int64_t nTiles) {
+    const int64_t t = (int64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (t >= nTiles) return;
+    const int64_t v = t * 64 + (threadIdx.x & 63);
+    const bool act = v < maxnode && parent[v] < 0;
+    const unsigned long long m = __ballot(act);
+    if ((threadIdx.x & 63) == 0) tileMask[t] = m;
+}
+
+template <typename REAL>
+struct OutTileRegs {
+    REAL w[4];
+    uint4 codes;
+    unsigned long long mask;
+    REAL f[4][4];
+};
+
+template <typename REAL>
+__device__ __forceinline__ void vft_outtile_load(const Arena<REAL> &A, int64_t tile, int chunk, OutTileRegs<REAL> &r) {
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t) chunk * VFT_CHUNK;
+    r.mask = 0;
+    // lanes below nSeqs are leaves (codes from leafT); the tile that straddles nSeqs has both kinds
+    if (tid < 64 && tile * 64 + tid < A.d.nSeqs) r.codes = A.leafT[vft_leaf_idx(A.d, tile, chunk, tid)];
+    if (tile * 64 + 63 < A.d.nSeqs) return;   // pure leaf tile
+    const int64_t pt = tile - A.d.firstProfTile;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int idx = tid * 4 + u;           // (column, lane) of the 16 x 64 weight block
+        r.w[u] = A.profW[vft_w_idx(A.d, pt, p0 + (idx >> 6), idx & 63)];
+    }
+    if (tid < 64 && tile * 64 + tid >= A.d.nSeqs) r.codes = A.profC[vft_c_idx(A.d, pt, chunk, tid)];
+    const int col = tid >> 4;
+    r.mask = A.vecMask[vft_mask_idx(A.d, pt, p0 + col)];
+    const int cnt = __popcll(r.mask);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int slot = (tid & 15) + 16 * u;
+        if (slot < cnt) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) r.f[u][k] = A.profF[vft_f_idx<REAL>(A.d, pt, p0 + col, k, slot)];
+        }
+    }
+}
+
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REAL> A, const unsigned long long *tileMask,
+                                                                       int64_t nTiles, int64_t nActive, double tol) {
+    __shared__ REAL sW[VFT_CHUNK][64];
+    __shared__ uint4 sCodes[64];
+    __shared__ unsigned long long sMask[VFT_CHUNK];
+    __shared__ REAL sF[VFT_CHUNK][64][4];
+    __shared__ REAL sRes[VFT_CHUNK][5];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int64_t p0 = (int64_t) chunk * VFT_CHUNK;
+    const double inweight = 1.0 / (double) nActive;
+    const int col = tid / 5, chain = tid % 5;   // threads 0..79 run the chains
+    REAL acc = 0;
+    // first non-empty tile
+    int64_t t = 0;
+    while (t < nTiles && tileMask[t] == 0) t++;
+    OutTileRegs<REAL> regs;
+    if (t < nTiles) vft_outtile_load<REAL>(A, t, chunk, regs);
+    while (t < nTiles) {
+        const unsigned long long active = tileMask[t];
+        const bool leafTile = t * 64 + 63 < A.d.nSeqs;
+        __syncthreads();   // previous tile's chains are done with the LDS buffers
+        if (leafTile) {
+            if (tid < 64) sCodes[tid] = regs.codes;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = tid * 4 + u;
+                sW[idx >> 6][idx & 63] = regs.w[u];
+            }
+            if (tid < 64) sCodes[tid] = regs.codes;
+            if ((tid & 15) == 0) sMask[tid >> 4] = regs.mask;
+            const int cnt = __popcll(regs.mask);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int slot = (tid & 15) + 16 * u;
+                if (slot < cnt) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sF[tid >> 4][slot][k] = regs.f[u][k];
+                }
+            }
+        }
+        __syncthreads();
+        // prefetch the next non-empty tile into registers while the chains run
+        int64_t tn = t + 1;
+        while (tn < nTiles && tileMask[tn] == 0) tn++;
+        if (tn < nTiles) vft_outtile_load<REAL>(A, tn, chunk, regs);
+        if (tid < VFT_CHUNK * 5 && p0 + col < A.d.nPos) {
+            unsigned long long m = active;
+            while (m) {
+                const int l = __ffsll((long long) m) - 1;
+                m &= m - 1;
+                REAL w;
+                int code;
+                if (leafTile || t * 64 + l < A.d.nSeqs) {
+                    const uint32_t enc = vft_byte(sCodes[l], col);
+                    code = vft_decode<4>(enc);
+                    w = code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
+                } else {
+                    w = sW[col][l];
+                    code = (int) vft_byte(sCodes[l], col);
+                }
+                if (chain == 0) {
+                    acc = (REAL) ((double) acc + (double) w * inweight);               // NJ.tcc:741
+                } else if (w > 0) {
+                    const int k = chain - 1;
+                    if (code != VFT_NOCODE_) {
+                        if (code == k) acc = (REAL) ((double) acc + (double) w);       // addToFreq, NJ.tcc:831
+                    } else {
+                        const int slot = __popcll(sMask[col] & ((1ull << l) - 1ull));
+                        const REAL pr = sF[col][slot][k] * w;                          // vector_add_mult, NJ.tcc:825
+                        acc = acc + pr;
+                    }
+                }
+            }
+        }
+        t = tn;
+    }
+    __syncthreads();
+    if (tid < VFT_CHUNK * 5) sRes[col][chain] = acc;
+    __syncthreads();
+    if (tid < VFT_CHUNK && p0 + tid < A.d.nPos) {
+        const int64_t p = p0 + tid;
+        REAL wo = sRes[tid][0];
+        if (wo <= 0) wo = (REAL) 1e-20;
+        REAL f[4] = {sRes[tid][1], sRes[tid][2], sRes[tid][3], sRes[tid][4]};
+        vft_normalize_freq<REAL, 4>(A, f, tol);
+        A.outW[p] = wo;
+#pragma unroll
+        for (int k = 0; k < 4; k++) A.outF[p * 4 + k] = f[k];
+    }
 }

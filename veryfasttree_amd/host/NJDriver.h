@@ -7,8 +7,8 @@
 // (tests/golden/bb_*.npz; tests/test_gpu_nj_driver.py).  The same logic exists as a Python prototype
 // (veryfasttree_amd/nj_driver.py) that also runs on the CPU oracle for debugging.
 //
-// Scope: deterministic single-thread semantics, default options and `-fastest -no2nd` (first-level top hits, no
-// constraints, no BIONJ weighting, top-hits on: m >= 4 and 2m < nSeqs).
+// Scope: deterministic single-thread semantics, default options, `-fastest` (with its second-level top-hit lists) and
+// `-fastest -no2nd`; no constraints, no BIONJ weighting, top-hits on (m >= 4 and 2m < nSeqs).
 //
 // Device-side lazy state: out-distances are refreshed on the device inside sweeps / pair lists exactly when the
 // reference refreshes them (setCriterion, NJ.tcc:1092-1098).  Every refresh is also stored by the kernels into
@@ -38,6 +38,10 @@ namespace veryfasttree {
         double tophitsMult = 1.0, tophitsClose = -1.0, tophitsRefresh = 0.8, topvisibleMult = 1.5;
         double staleOutLimit = 0.01, fResetOutProfile = 0.02;
         int nResetOutProfile = 200;
+        /* second-level top hits: -fastest at one thread (main.cpp:339-343, VeryFastTree.cpp:87-91, Options.h:31-35) */
+        bool useTopHits2nd = false;
+        double tophits2Mult = 1.0, tophits2Refresh = 0.6;
+        int tophits2Safety = 3;
     };
 
     template<typename REAL>
@@ -163,7 +167,7 @@ namespace veryfasttree {
         /* top hits (NJ.h:206-248) */
         int64_t m = 0, q = 0, topvisibleAge = 0;
         std::vector<std::vector<Hit> > hits;
-        std::vector<int64_t> age, topvisible;
+        std::vector<int64_t> age, topvisible, hitSource;
         std::vector<Hit> visible;
 
         void chk(int rc) {
@@ -327,7 +331,9 @@ namespace veryfasttree {
         /* ---- top-hits structures */
         void initTopHits(int64_t m_) {
             m = m_;
-            q = 0;
+            q = (int64_t) (0.5 + opt.tophits2Mult * std::sqrt((double) m));   /* NJ.tcc:199-204 */
+            if (!opt.useTopHits2nd || q >= m) q = 0;
+            hitSource.assign(maxnodes, -1);
             hits.assign(maxnodes, std::vector<Hit>());
             age.assign(maxnodes, 0);
             visible.assign(maxnodes, Hit{-1, (REAL) 1e20});
@@ -627,10 +633,26 @@ namespace veryfasttree {
                                          (ch.weight >= nearweight || ch.weight >= (nPos - nGaps[cn]) * nearcover);
                     const bool identical = ch.dist < 1e-6 && std::fabs(ch.weight - (nPos - nGaps[seed])) < 1e-5 &&
                                            std::fabs(ch.weight - (nPos - nGaps[cn])) < 1e-5;
-                    if (isClose || identical || (opt.fastest && iClose < (q + 1) / 2)) {
+                    if (opt.useTopHits2nd && iClose < q && (isClose || identical)) {
+                        const int64_t nUse = std::min<int64_t>(q * opt.tophits2Safety, 2 * m);
+                        std::vector<Besthit> bc = transferBestHits(n, cn, best, nUse, true);
+                        visited[cn] = 1;
+                        sortSaveBestHits(cn, bc, nUse, q);
+                        hitSource[cn] = seed;
+                    } else if (isClose || identical || (opt.fastest && iClose < (q + 1) / 2)) {
                         std::vector<Besthit> nb = transferBestHits(n, cn, best, 2 * m, true);
                         visited[cn] = 1;
-                        sortSaveBestHits(cn, nb, 2 * m, m);
+                        sortSaveBestHits(cn, nb, 2 * m, m);   /* sorts nb in place, like the reference */
+                        /* second level of transfer, NJ.tcc:3993-4012 */
+                        for (int64_t iClose2 = 0; iClose2 < q && iClose2 < 2 * m; iClose2++) {
+                            const int64_t cn2 = nb[iClose2].j;
+                            if (cn2 < 0 || visited[cn2]) continue;
+                            const int64_t nUse = std::min<int64_t>(q * opt.tophits2Safety, 2 * m);
+                            std::vector<Besthit> bc2 = transferBestHits(n, cn2, nb, nUse, true);
+                            visited[cn2] = 1;
+                            sortSaveBestHits(cn2, bc2, nUse, q);
+                            hitSource[cn2] = cn;
+                        }
                     }
                 }
             }
@@ -773,18 +795,41 @@ namespace veryfasttree {
         void topHitJoin(int64_t newnode, int64_t nActive) { /* NJ.tcc:4306-4533, first-level lists */
             const int64_t c0 = child0[newnode], c1 = child1[newnode];
             std::vector<Besthit> combined = hitsToBestHits(hits[c0], c0);
-            std::vector<Besthit> second = hitsToBestHits(hits[c1], c1);
-            combined.insert(combined.end(), second.begin(), second.end());
+            std::vector<Besthit> fromC1 = hitsToBestHits(hits[c1], c1);
+            combined.insert(combined.end(), fromC1.begin(), fromC1.end());
             std::vector<Besthit> unique = uniqueBestHits(nActive, combined);
             const int64_t nUnique = (int64_t) unique.size();
             hits[c0].clear();
             hits[c1].clear();
             age[newnode] = (age[c0] + age[c1] + 1) / 2 + 1;
             const int64_t ageLimit = std::max<int64_t>(1, (int64_t) (0.5 + std::log((double) m) / std::log(2.0)));
-            const bool useUnique = nUnique == nActive - 1 ||
-                                   (age[newnode] <= ageLimit && nUnique >= (int64_t) (0.5 + m * opt.tophitsRefresh));
+            bool second = hitSource[c0] >= 0 && hitSource[c1] >= 0;
+            const int64_t need = second ? (int64_t) (0.5 + opt.tophits2Refresh * q) : (int64_t) (0.5 + m * opt.tophitsRefresh);
+            bool useUnique = nUnique == nActive - 1 || (age[newnode] <= ageLimit && nUnique >= need);
+            if (!useUnique && second && age[newnode] <= ageLimit) {
+                /* switch from 2nd-level to 1st-level top hits, NJ.tcc:4364-4410 */
+                int64_t source = activeAncestor(hitSource[c0]);
+                if (source == newnode) source = activeAncestor(hitSource[c1]);
+                if (source != newnode && source >= 0 && hitSource[source] < 0) {
+                    std::vector<Besthit> merge(unique);
+                    Besthit first;
+                    first.i = newnode;
+                    first.j = source;
+                    merge.push_back(first);
+                    std::vector<Besthit> more = hitsToBestHits(hits[source], newnode);
+                    merge.insert(merge.end(), more.begin(), more.end());
+                    std::vector<Besthit *> todo;
+                    for (size_t t = (size_t) nUnique; t < merge.size(); t++) todo.push_back(&merge[t]);
+                    setDistCriterionBatch(nActive, todo);
+                    unique = uniqueBestHits(nActive, merge);
+                    /* the reference tests the OLD nUnique here (NJ.tcc:4402) */
+                    useUnique = nUnique >= (int64_t) (0.5 + m * opt.tophitsRefresh);
+                    second = false;
+                }
+            }
             if (useUnique) {
-                const int64_t nSave = std::min(nUnique, m);
+                if (second) hitSource[newnode] = hitSource[c0];
+                const int64_t nSave = std::min(nUnique, second ? q : m);
                 sortSaveBestHits(newnode, unique, nUnique, nSave);
                 visible[newnode] = hits[newnode][0];
                 updateTopVisible(nActive, newnode, visible[newnode]);
@@ -816,7 +861,8 @@ namespace veryfasttree {
                     prefetchStale(nActive, pairs);
                 }
                 for (Besthit &b: both) setCriterion(nActive, b);
-                const int64_t nNew = m;
+                if (nActive <= 2 * m) hitSource[node] = -1;   /* abandon the 2nd-level heuristic */
+                const int64_t nNew = hitSource[node] >= 0 ? q : m;
                 std::vector<Besthit> tr = transferBestHits(nActive, node, all, 2 * nNew, false);
                 both.insert(both.end(), tr.begin(), tr.end());
                 both.resize((size_t) (nOld + 2 * nNew));

@@ -20,6 +20,10 @@ static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int6
         opt.staleOutLimit = o->stale_out_limit;
         opt.fResetOutProfile = o->f_reset_out_profile;
         opt.nResetOutProfile = o->n_reset_out_profile;
+        opt.useTopHits2nd = o->use_tophits_2nd != 0;
+        opt.tophits2Safety = o->tophits2_safety;
+        opt.tophits2Mult = o->tophits2_mult;
+        opt.tophits2Refresh = o->tophits2_refresh;
     }
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, opt);
     const auto &js = drv.run(maxJoins);

@@ -42,7 +42,8 @@ def sort_by_ij(hits):
 
 class NJDriver:
     def __init__(self, ops, codes, fastest=False, tophits_mult=1.0, tophits_close=-1.0, tophits_refresh=0.8,
-                 topvisible_mult=1.5, stale_out_limit=0.01, n_reset_out_profile=200, f_reset_out_profile=0.02):
+                 topvisible_mult=1.5, stale_out_limit=0.01, n_reset_out_profile=200, f_reset_out_profile=0.02,
+                 use_tophits_2nd=False, tophits2_mult=1.0, tophits2_safety=3, tophits2_refresh=0.6):
         self.ops = ops
         self.dt = np.dtype(ops.dt).type
         self.n_seqs, self.n_pos = codes.shape
@@ -52,6 +53,9 @@ class NJDriver:
         self.tophits_mult, self.tophits_close, self.tophits_refresh = tophits_mult, tophits_close, tophits_refresh
         self.topvisible_mult, self.stale_out_limit = topvisible_mult, stale_out_limit
         self.n_reset_out_profile, self.f_reset_out_profile = n_reset_out_profile, f_reset_out_profile
+        # second-level top hits: -fastest at one thread (main.cpp:339-343, VeryFastTree.cpp:87-91, Options.h:31-35)
+        self.use_tophits_2nd, self.tophits2_mult = use_tophits_2nd, tophits2_mult
+        self.tophits2_safety, self.tophits2_refresh = tophits2_safety, tophits2_refresh
         n = self.n_seqs
         dt = self.dt
         self.parent = np.full(self.maxnodes, -1, np.int64)
@@ -127,7 +131,9 @@ class NJDriver:
     # ---- top-hits structures (NJ.h:206-248)
     def init_tophits(self, m):
         self.m = m
-        self.q = 0
+        self.q = int(0.5 + self.tophits2_mult * math.sqrt(m))   # NJ.tcc:199-204
+        if not self.use_tophits_2nd or self.q >= m:
+            self.q = 0
         self.hits = [[] for _ in range(self.maxnodes)]          # list of [j, dist]
         self.hit_source = [-1] * self.maxnodes
         self.age = [0] * self.maxnodes
@@ -346,10 +352,25 @@ class NJDriver:
                                                             float(ch.weight) >= (self.n_pos - n_gaps[cn]) * nearcover)
                 identical = (float(ch.dist) < 1e-6 and abs(float(ch.weight) - (self.n_pos - n_gaps[seed])) < 1e-5
                              and abs(float(ch.weight) - (self.n_pos - n_gaps[cn])) < 1e-5)
-                if is_close or identical or (self.fastest and i_close < (self.q + 1) // 2):
+                if self.use_tophits_2nd and i_close < self.q and (is_close or identical):
+                    n_use = min(self.q * self.tophits2_safety, 2 * m)
+                    bc = self.transfer_best_hits(n, cn, best_seed, n_use, True)
+                    visited[cn] = True
+                    self.sort_save_best_hits(cn, bc, n_use, self.q)
+                    self.hit_source[cn] = seed
+                elif is_close or identical or (self.fastest and i_close < (self.q + 1) // 2):
                     nb = self.transfer_best_hits(n, cn, best_seed, 2 * m, True)
                     visited[cn] = True
-                    self.sort_save_best_hits(cn, nb, 2 * m, m)
+                    self.sort_save_best_hits(cn, nb, 2 * m, m)      # sorts nb in place, like the reference
+                    # second level of transfer (NJ.tcc:3993-4012): no closeness test, q is small
+                    for i_close2 in range(min(self.q, 2 * m)):
+                        cn2 = nb[i_close2].j
+                        if cn2 >= 0 and not visited[cn2]:
+                            n_use = min(self.q * self.tophits2_safety, 2 * m)
+                            bc2 = self.transfer_best_hits(n, cn2, nb, n_use, True)
+                            visited[cn2] = True
+                            self.sort_save_best_hits(cn2, bc2, n_use, self.q)
+                            self.hit_source[cn2] = cn
         for node in range(n):
             self.visible[node] = list(self.hits[node][0])
         # checking phase (NJ.tcc:4052-4119)
@@ -443,7 +464,7 @@ class NJDriver:
                 break
         return join
 
-    # ---- topHitJoin (NJ.tcc:4306-4533), first-level lists only
+    # ---- topHitJoin (NJ.tcc:4306-4533)
     def top_hit_join(self, newnode, n_active):
         c0, c1 = self.child[newnode]
         combined = self.hits_to_besthits(self.hits[c0], c0) + self.hits_to_besthits(self.hits[c1], c1)
@@ -452,10 +473,30 @@ class NJDriver:
         self.hits[c0], self.hits[c1] = [], []
         self.age[newnode] = (self.age[c0] + self.age[c1] + 1) // 2 + 1
         age_limit = max(1, int(0.5 + math.log(float(self.m)) / math.log(2.0)))
-        use_unique = n_unique == n_active - 1 or (self.age[newnode] <= age_limit and
-                                                  n_unique >= int(0.5 + self.m * self.tophits_refresh))
+        second = self.hit_source[c0] >= 0 and self.hit_source[c1] >= 0
+        need = int(0.5 + self.tophits2_refresh * self.q) if second else int(0.5 + self.m * self.tophits_refresh)
+        use_unique = n_unique == n_active - 1 or (self.age[newnode] <= age_limit and n_unique >= need)
+        if not use_unique and second and self.age[newnode] <= age_limit:
+            # switch from 2nd-level to 1st-level top hits (NJ.tcc:4364-4410)
+            source = self.active_ancestor(self.hit_source[c0])
+            if source == newnode:
+                source = self.active_ancestor(self.hit_source[c1])
+            if source != newnode and source >= 0 and self.hit_source[source] < 0:
+                merge = [h.copy() for h in unique]
+                first = Besthit(newnode, source)
+                self.set_dist_criterion_batch(n_active, [first])
+                merge.append(first)
+                more = self.hits_to_besthits(self.hits[source], newnode)
+                self.set_dist_criterion_batch(n_active, more)
+                merge += more
+                unique = self.unique_best_hits(n_active, merge)
+                # the reference tests the OLD nUnique here (NJ.tcc:4402: nUnique is not refreshed after the merge)
+                use_unique = n_unique >= int(0.5 + self.m * self.tophits_refresh)
+                second = False
         if use_unique:
-            n_save = min(n_unique, self.m)
+            if second:
+                self.hit_source[newnode] = self.hit_source[c0]
+            n_save = min(n_unique, self.q if second else self.m)
             self.sort_save_best_hits(newnode, unique, n_unique, n_save)
             self.visible[newnode] = list(self.hits[newnode][0])
             self.update_top_visible(n_active, newnode, self.visible[newnode])
@@ -488,7 +529,9 @@ class NJDriver:
             both = self.hits_to_besthits(old, node)
             for b in both:
                 self.set_criterion(n_active, b)
-            n_new = self.m
+            if n_active <= 2 * self.m:
+                self.hit_source[node] = -1     # abandon the 2nd-level heuristic
+            n_new = self.q if self.hit_source[node] >= 0 else self.m
             both += self.transfer_best_hits(n_active, node, allhits, 2 * n_new, False)
             unique2 = self.unique_best_hits(n_active, both[:n_old + 2 * n_new])
             self.sort_save_best_hits(node, unique2, len(unique2), n_new)
