@@ -84,10 +84,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (not used by the driver): run the multi-rank flow on ONE GPU with gloo + host tensors
+    backend = os.environ.get("VFT_BENCH_BACKEND", "nccl")
+    if os.environ.get("VFT_BENCH_SAME_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from veryfasttree_amd import HipProfileOps, synth
     from veryfasttree_amd.workload import TopHitsState, merge_hits, shard_range
 
@@ -113,7 +120,7 @@ def main():
     hit_dt = ops.hit_dtype
     if world > 1:
         d_mine = torch.zeros(k * hit_dt.itemsize, dtype=torch.uint8, device="cuda")
-        d_all = torch.zeros(world * k * hit_dt.itemsize, dtype=torch.uint8, device="cuda")
+        d_all = torch.zeros(world * k * hit_dt.itemsize, dtype=torch.uint8, device="cuda" if backend == "nccl" else "cpu")
         ops.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def one_step():
@@ -124,9 +131,15 @@ def main():
             else:
                 ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False,
                                d_hits=d_mine.data_ptr(), want_hits=False)
-                dist.all_gather_into_tensor(d_all, d_mine)
-                allh = d_all.cpu().numpy().view(hit_dt).reshape(world, k)
-                hits = merge_hits(list(allh), k)
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(d_all, d_mine)      # RCCL over xGMI: k records per rank
+                    gathered = d_all
+                else:
+                    torch.cuda.current_stream().synchronize()
+                    dist.all_gather_into_tensor(d_all, d_mine.cpu())
+                    gathered = d_all.cuda()
+                # merge on the device with the (criterion asc, id desc) rule; k records come back zero-copy
+                hits = ops.merge_hits(gathered.data_ptr(), world, k)
             out.append(hits)
         return out
 
@@ -144,7 +157,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

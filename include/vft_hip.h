@@ -69,6 +69,11 @@ const char *vft_last_error(const vft_ctx *ctx);
 int vft_set_stream(vft_ctx *ctx, void *hip_stream);
 int vft_synchronize(vft_ctx *ctx);
 
+/* Plain device buffers for callers that do not bring their own allocator (the d_* arguments below). */
+int vft_device_malloc(vft_ctx *ctx, int64_t bytes, void **d_ptr);
+int vft_device_free(vft_ctx *ctx, void *d_ptr);
+int vft_device_upload(vft_ctx *ctx, void *d_dst, const void *src, int64_t bytes);
+
 /* ---- inputs */
 /* Leaf profiles from codes[n_seqs][n_pos] (what seqsToProfiles builds, NJ.tcc:382-457). */
 int vft_upload_leaves(vft_ctx *ctx, const uint8_t *codes);
@@ -134,6 +139,10 @@ int vft_sweep(vft_ctx *ctx, int64_t query, int64_t n_active, int64_t n_diff_allo
 /* Restrict sweeps/out-distance passes to node ids [lo, hi): the shard a rank owns in a multi-GPU run
    (default [0, max_nodes)).  Hits keep global ids. */
 int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);
+/* Multi-GPU merge: d_all holds n_lists sorted lists of k records each (every rank's vft_sweep d_hits, all-gathered,
+   DEVICE memory).  Produces the k best records under the same (criterion asc, id desc) order into hits (host, may be
+   NULL) and d_out (device, may be NULL) — the result a single-rank sweep over the union of the shards would give. */
+int vft_merge_hits(vft_ctx *ctx, const void *d_all, int32_t n_lists, int32_t k, void *hits, void *d_out);
 /* Diagnostics of the last sweep's top-k selection: info[0] = candidates that were rank-sorted, info[1] = extra
    refinement rounds that were needed (0 in the common case). */
 int vft_sweep_info(vft_ctx *ctx, int64_t info[2]);

@@ -69,6 +69,11 @@ def test_sweep_properties_at_full_size(n, L, seed):
         ops.set_shard(0, st.maxnode)
         merged = merge_hits(parts, k)
         assert np.array_equal(merged["j"], hits["j"]) and np.array_equal(merged["criterion"], hits["criterion"])
+        # the same merge on the device (what bench.py does after the RCCL all-gather)
+        d_all = ops.device_buffer(np.concatenate(parts))
+        dev = ops.merge_hits(d_all, 4, k)
+        ops.device_free(d_all)
+        assert np.array_equal(dev, hits)
     # 8. self distance of a leaf is 0 with weight = ungapped columns
     some = st.active[st.active < n][:256]
     d, w, _ = ops.setDistCriterion(some, some, st.n_active, st.n_diff_allow, st.totdiam)

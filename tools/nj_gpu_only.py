@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""NJ phase on the GPU only (no reference run): nj_gpu_only.py N L [fastest] [second]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from veryfasttree_amd import HipProfileOps, synth
+from veryfasttree_amd.backend import nj_run
+n, L = int(sys.argv[1]), int(sys.argv[2])
+fastest = len(sys.argv) > 3 and sys.argv[3] == "fastest"
+second = len(sys.argv) > 4 and sys.argv[4] == "second"
+codes = synth.random_descent_codes(n, L, 4, 0.03, 0.01, seed=3)
+_, first = np.unique(codes, axis=0, return_index=True)
+codes = codes[np.sort(first)]
+ops = HipProfileOps(codes.shape[0], L, 4, np.float32)
+t0 = time.perf_counter()
+joins, crit = nj_run(ops, codes, fastest=fastest, second_level=second)
+print("GPU NJ phase: %.2f s for %d joins (%d unique seqs, L=%d, fastest=%s, 2nd=%s)" % (time.perf_counter() - t0, len(joins), codes.shape[0], L, fastest, second))

@@ -18,12 +18,12 @@ I64 = C.c_int64
 I32 = C.c_int32
 
 EXPORTS = [
-    "vft_create", "vft_destroy", "vft_last_error", "vft_set_stream", "vft_synchronize", "vft_upload_leaves",
+    "vft_device_malloc", "vft_device_free", "vft_device_upload", "vft_create", "vft_destroy", "vft_last_error", "vft_set_stream", "vft_synchronize", "vft_upload_leaves",
     "vft_set_distance_matrix", "vft_set_transition_matrix", "vft_set_rates", "vft_set_ml_limits", "vft_set_parents",
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_set_shard", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
+    "vft_set_shard", "vft_merge_hits", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
     "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms",
 ]
 
@@ -272,6 +272,23 @@ class HipProfileOps:
                                      I32(k), _ptr(hits), P(d_hits) if d_hits else None,
                                      C.byref(best) if want_best else None))
         return hits, best.value
+
+    def device_buffer(self, array):
+        """Copy a host array into a fresh device buffer; returns the device address (free with device_free)."""
+        a = np.ascontiguousarray(array)
+        p = P()
+        self._chk(self.lib.vft_device_malloc(self.ctx, I64(a.nbytes), C.byref(p)))
+        self._chk(self.lib.vft_device_upload(self.ctx, p, _ptr(a), I64(a.nbytes)))
+        return p.value
+
+    def device_free(self, addr):
+        self._chk(self.lib.vft_device_free(self.ctx, P(addr)))
+
+    def merge_hits(self, d_all, n_lists, k):
+        """Merge all-gathered per-shard hit lists (device pointer) into the global top-k, on the device."""
+        hits = np.zeros(k, self.hit_dtype)
+        self._chk(self.lib.vft_merge_hits(self.ctx, P(d_all), I32(n_lists), I32(k), _ptr(hits), None))
+        return hits
 
     def sweep_info(self):
         info = (I64 * 2)()

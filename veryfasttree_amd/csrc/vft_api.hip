@@ -409,6 +409,26 @@ extern "C" int vft_synchronize(vft_ctx *c) {
     return wait_stream(c);
 }
 
+extern "C" int vft_device_malloc(vft_ctx *c, int64_t bytes, void **p) {
+    if (!c || !p || bytes < 0) return VFT_ERR_INVALID;
+    HIPCHK(c, hipMalloc(p, bytes ? (size_t) bytes : 1));
+    return VFT_OK;
+}
+
+extern "C" int vft_device_free(vft_ctx *c, void *p) {
+    if (!c) return VFT_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(p));
+    return VFT_OK;
+}
+
+extern "C" int vft_device_upload(vft_ctx *c, void *dst, const void *src, int64_t bytes) {
+    if (!c || !dst || !src || bytes < 0) return VFT_ERR_INVALID;
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t) bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- inputs
 extern "C" int vft_upload_leaves(vft_ctx *c, const uint8_t *codes) {
     if (!c || !codes) return VFT_ERR_INVALID;
@@ -1048,6 +1068,29 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     if (hits) memcpy(hits, c->hRes + sizeof(SelectHeader), hb);
     if (bestJ) *bestJ = (int64_t) ((const SelectHeader *) c->hRes)->bestJ;
     return VFT_OK;
+}
+
+template <typename REAL, typename HIT>
+static int merge_hits_impl(vft_ctx *c, const void *dAll, int32_t nLists, int32_t k, void *hits, void *dOut) {
+    const int32_t n = nLists * k;
+    HIT *dHits = (HIT *) (c->dRes + sizeof(SelectHeader));
+    HIT *hHitsDev = (HIT *) (c->hResDev + sizeof(SelectHeader));
+    launch((k_fill_empty_hits<REAL, HIT>), dim3(cdiv(k, 256)), dim3(256), 0, c->stream, dHits, hHitsDev, k);
+    launch((k_merge_hits<REAL, HIT>), dim3(cdiv((int64_t) n * VFT_RANK_LANES, VFT_WG)), dim3(VFT_WG), 0, c->stream,
+           (const HIT *) dAll, n, k, dHits, hHitsDev);
+    LAUNCHCHK(c);
+    if (dOut) HIPCHK(c, hipMemcpyAsync(dOut, dHits, (size_t) k * sizeof(HIT), hipMemcpyDeviceToDevice, c->stream));
+    if (hits) {
+        if (int r = wait_stream(c)) return r;
+        memcpy(hits, c->hRes + sizeof(SelectHeader), (size_t) k * sizeof(HIT));
+    }
+    return VFT_OK;
+}
+
+extern "C" int vft_merge_hits(vft_ctx *c, const void *dAll, int32_t nLists, int32_t k, void *hits, void *dOut) {
+    if (!c || !dAll || nLists < 1 || k < 1 || k > c->hitsCap) return fail(c, VFT_ERR_INVALID, "vft_merge_hits: bad arguments");
+    if (c->cfg.precision == 4) return merge_hits_impl<float, vft_hit_f32>(c, dAll, nLists, k, hits, dOut);
+    return merge_hits_impl<double, vft_hit_f64>(c, dAll, nLists, k, hits, dOut);
 }
 
 extern "C" int vft_sweep_info(vft_ctx *c, int64_t info[2]) {

@@ -906,3 +906,58 @@ __global__ __launch_bounds__(VFT_WG) void k_select_best(const SelectState *S, co
     *hdr = h;
     *hostHdr = h;
 }
+
+// Merge of per-shard hit lists (multi-GPU: each rank's sorted top-k, all-gathered): rank sort of the n = lists * k
+// records by (criterion asc, id desc), empty records (j < 0) last; the first k go to `out` and to the host-mapped
+// block.  Same 16-lanes-per-candidate scheme as k_select_rank.
+template <typename REAL, typename HIT>
+__global__ __launch_bounds__(VFT_WG) void k_merge_hits(const HIT *all, int32_t n, int32_t k, HIT *out, HIT *hostOut) {
+    __shared__ REAL sc[VFT_RANK_TILE];
+    __shared__ long long sj[VFT_RANK_TILE];
+    const unsigned int perWg = VFT_WG / VFT_RANK_LANES;
+    const unsigned int cand = blockIdx.x * perWg + threadIdx.x / VFT_RANK_LANES;
+    const unsigned int sub = threadIdx.x % VFT_RANK_LANES;
+    const bool mine = cand < (unsigned int) n;
+    const REAL myC = mine ? all[cand].criterion : (REAL) 0;
+    const long long myJ = mine ? (long long) all[cand].j : -1;
+    unsigned int rank = 0;
+    for (unsigned int base = 0; base < (unsigned int) n; base += VFT_RANK_TILE) {
+        __syncthreads();
+        for (unsigned int u = threadIdx.x; u < VFT_RANK_TILE; u += VFT_WG) {
+            const bool in = base + u < (unsigned int) n;
+            sc[u] = in ? all[base + u].criterion : (REAL) 0;
+            sj[u] = in ? (long long) all[base + u].j : -1;
+        }
+        __syncthreads();
+        const unsigned int lim = (unsigned int) n - base < VFT_RANK_TILE ? (unsigned int) n - base : VFT_RANK_TILE;
+        if (mine && myJ >= 0) {
+#pragma unroll 8
+            for (unsigned int u = sub; u < lim; u += VFT_RANK_LANES) {
+                const long long ju = sj[u];
+                const REAL cu = sc[u];
+                // u precedes me: it is a real record with a smaller criterion, or the same criterion and a larger id
+                rank += (ju >= 0 && (cu < myC || (cu == myC && ju > myJ))) ? 1u : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = VFT_RANK_LANES / 2; off > 0; off >>= 1) rank += __shfl_xor(rank, off, VFT_RANK_LANES);
+    if (sub != 0 || !mine || myJ < 0) return;
+    if (rank < (unsigned int) k) {
+        out[rank] = all[cand];
+        hostOut[rank] = all[cand];
+    }
+}
+
+template <typename REAL, typename HIT>
+__global__ void k_fill_empty_hits(HIT *out, HIT *hostOut, int32_t k) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k) return;
+    HIT h;
+    h.j = -1;
+    h.dist = (REAL) 1e20;
+    h.weight = 0;
+    h.criterion = (REAL) 1e20;
+    out[t] = h;
+    hostOut[t] = h;
+}
