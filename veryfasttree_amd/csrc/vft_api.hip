@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -1025,6 +1026,7 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     s.nDiffAllow = nDiffAllow;
     s.totdiam = totdiam;
     s.queryIsLeaf = query < c->d.nSeqs ? 1 : 0;
+    if (const char *dbg = getenv("VFT_SWEEP_ABLATE")) s.pad = atoi(dbg);   // kernel ablation switches (tools only)
     {
         const int64_t leafEnd = (c->d.nSeqs < hi ? c->d.nSeqs : hi);
         s.nLeafWG = leafEnd > lo ? (int32_t) ((leafEnd - lo) / VFT_WG) : 0;
@@ -1038,15 +1040,17 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
             launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
                                query, qbuf<float>(c, 0));
             kernel_event(c);
+            // (k_sweep_nt<.., MODE_CRIT_LEAFQ>, one float per vector for leaf seeds, measured 99 us vs 105 us in
+            //  its first form and slower after refactoring: not used until it earns its keep)
             launch((k_sweep_nt<float, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<float>(c),
-                               qbuf<float>(c, 0), s, sweepout<float>(c));
+                   qbuf<float>(c, 0), s, sweepout<float>(c));
             kernel_event(c);
         } else {
             launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), query, qbuf<double>(c, 0));
             kernel_event(c);
             launch((k_sweep_nt<double, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<double>(c),
-                               qbuf<double>(c, 0), s, sweepout<double>(c));
+                   qbuf<double>(c, 0), s, sweepout<double>(c));
             kernel_event(c);
         }
     } else {
