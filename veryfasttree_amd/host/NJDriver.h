@@ -42,6 +42,9 @@ namespace veryfasttree {
         bool useTopHits2nd = false;
         double tophits2Mult = 1.0, tophits2Refresh = 0.6;
         int tophits2Safety = 3;
+        /* OpenMP threads for the host-only parts of a top-hits refresh (the reference parallelises the same loop,
+           NJ.tcc:4476); results do not depend on it */
+        int hostThreads = 16;
     };
 
     template<typename REAL>
@@ -274,6 +277,17 @@ namespace veryfasttree {
             if (stamp(hit.i) != nActive) outI *= (nActive - 1) / (double) (stamp(hit.i) - 1);
             double outJ = value(hit.j);
             if (stamp(hit.j) != nActive) outJ *= (nActive - 1) / (double) (stamp(hit.j) - 1);
+            hit.criterion = (REAL) (hit.dist - (outI + outJ) / (double) (nActive - 2));
+        }
+
+        /* setCriterion for pairs whose out-distances are known to be fresh enough (prefetchStale + drain done): pure host
+           arithmetic, safe inside OpenMP regions */
+        void criterionFresh(int64_t nActive, Besthit &hit) const {
+            if (hit.i < 0 || hit.j < 0 || parent[hit.i] >= 0 || parent[hit.j] >= 0) return;
+            double outI = mOut[hit.i];
+            if (mN[hit.i] != nActive) outI *= (nActive - 1) / (double) (mN[hit.i] - 1);
+            double outJ = mOut[hit.j];
+            if (mN[hit.j] != nActive) outJ *= (nActive - 1) / (double) (mN[hit.j] - 1);
             hit.criterion = (REAL) (hit.dist - (outI + outJ) / (double) (nActive - 2));
         }
 
@@ -554,11 +568,20 @@ namespace veryfasttree {
                     if (parent[node] < 0) nodes.push_back(node);
                 prefetchVisible(nActive, nodes);
             }
+            drain();
             for (int64_t node = 0; node < maxnode; node++) {
                 if (parent[node] >= 0) continue;
-                Besthit v;
-                if (getVisible(nActive, node, v)) vis[nVisible++] = v;
+                const Hit &hv = visible[node];
+                if (hv.j < 0 || parent[hv.j] >= 0) continue;   /* getVisible fails, NJ.tcc:550-552 */
+                Besthit &v = vis[nVisible++];
+                v.i = node;
+                v.j = hv.j;
+                v.dist = hv.dist;
+                v.weight = -1;
+                v.criterion = (REAL) 1e20;
             }
+#pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
+            for (int64_t t = 0; t < nVisible; t++) criterionFresh(nActive, vis[t]);
             sortByCriterion(vis);
             std::vector<int64_t> inTop((size_t) maxnodes, -1);
             size_t save = 0;
@@ -848,27 +871,95 @@ namespace veryfasttree {
             std::vector<Besthit> all = sweep(newnode, nActive, (int32_t) (2 * m));
             std::vector<Besthit> copy(all);
             sortSaveBestHits(newnode, copy, (int64_t) copy.size(), m, false);
+            /* NJ.tcc:4477-4515 — the reference runs this loop as an OpenMP parallel for: iterations only touch their
+               own node's list.  Here: the host parts run in parallel per node, every distance that must be recomputed,
+               for ALL nodes, goes to the device as ONE pair list, and every lazy out-distance refresh as one id list. */
+            struct Work {
+                int64_t node, nNew;
+                std::vector<Besthit> both, out;
+                std::vector<uint8_t> isTodo;
+            };
+            std::vector<Work> work;
             for (int64_t iHit = 0; iHit < m && iHit < (int64_t) all.size(); iHit++) {
                 if (all[iHit].i < 0) continue;
                 const int64_t node = all[iHit].j;
                 if (parent[node] >= 0) continue;
-                const int64_t nOld = (int64_t) hits[node].size();
                 age[node] = 0;
-                std::vector<Besthit> both = hitsToBestHits(hits[node], node);
-                {
-                    std::vector<std::pair<int64_t, int64_t> > pairs;
-                    for (const Besthit &b: both) pairs.push_back(std::make_pair(b.i, b.j));
-                    prefetchStale(nActive, pairs);
-                }
-                for (Besthit &b: both) setCriterion(nActive, b);
                 if (nActive <= 2 * m) hitSource[node] = -1;   /* abandon the 2nd-level heuristic */
-                const int64_t nNew = hitSource[node] >= 0 ? q : m;
-                std::vector<Besthit> tr = transferBestHits(nActive, node, all, 2 * nNew, false);
-                both.insert(both.end(), tr.begin(), tr.end());
-                both.resize((size_t) (nOld + 2 * nNew));
-                std::vector<Besthit> unique2 = uniqueBestHits(nActive, both);
-                sortSaveBestHits(node, unique2, (int64_t) unique2.size(), nNew);
-                visible[node] = hits[node][0];
+                Work w;
+                w.node = node;
+                w.nNew = hitSource[node] >= 0 ? q : m;
+                work.push_back(std::move(w));
+            }
+            const int64_t nW = (int64_t) work.size();
+            {   /* setCriterion on every old hit (NJ.tcc:4491-4494): refresh what is stale, once, for all nodes */
+                std::vector<std::pair<int64_t, int64_t> > pairs;
+                for (const Work &w: work)
+                    for (const Hit &h: hits[w.node]) pairs.push_back(std::make_pair(w.node, h.j));
+                prefetchStale(nActive, pairs);
+                drain();
+            }
+#pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
+            for (int64_t t = 0; t < nW; t++) {
+                Work &w = work[t];
+                const int64_t nOld = (int64_t) hits[w.node].size();
+                w.both = hitsToBestHits(hits[w.node], w.node);
+                for (Besthit &b: w.both) criterionFresh(nActive, b);
+                /* transferBestHits(..., updateDistances = false), NJ.tcc:4580-4613: host only */
+                for (int64_t u = 0; u < 2 * w.nNew; u++) {
+                    const Besthit &o = all[u];
+                    Besthit h;
+                    h.i = w.node;
+                    h.j = activeAncestor(o.j);
+                    h.dist = o.dist;
+                    h.weight = o.weight;
+                    h.criterion = o.criterion;
+                    if (h.j < 0 || h.j == w.node) {
+                        h.weight = 0;
+                        h.dist = (REAL) -1e20;
+                        h.criterion = (REAL) 1e20;
+                    } else if (h.i != o.i || h.j != o.j) {
+                        h.dist = (REAL) -1e20;
+                        h.criterion = (REAL) 1e20;
+                    } else {
+                        h.criterion = (REAL) 1e20;
+                    }
+                    w.both.push_back(h);
+                }
+                w.both.resize((size_t) (nOld + 2 * w.nNew));
+                /* uniqueBestHits, host part (NJ.tcc:4786-4817) */
+                for (Besthit &h: w.both) updateBestHit(h, false, nullptr);
+                sortByIJ(w.both);
+                int64_t last = -1;
+                for (size_t u = 0; u < w.both.size(); u++) {
+                    const Besthit &h = w.both[u];
+                    if (h.i < 0 || h.j < 0) continue;
+                    if (last >= 0 && w.both[last].i == h.i && w.both[last].j == h.j) continue;
+                    w.out.push_back(h);
+                    last = (int64_t) u;
+                }
+                w.isTodo.assign(w.out.size(), 0);
+                for (size_t u = 0; u < w.out.size(); u++) w.isTodo[u] = w.out[u].dist < 0.0 ? 1 : 0;
+            }
+            {   /* uniqueBestHits, device part (NJ.tcc:4822-4831): one pair list, one id list */
+                std::vector<Besthit *> todo;
+                std::vector<std::pair<int64_t, int64_t> > rest;
+                for (Work &w: work)
+                    for (size_t u = 0; u < w.out.size(); u++) {
+                        if (w.isTodo[u]) todo.push_back(&w.out[u]);
+                        else rest.push_back(std::make_pair(w.out[u].i, w.out[u].j));
+                    }
+                setDistCriterionBatch(nActive, todo);
+                prefetchStale(nActive, rest);
+                drain();
+            }
+#pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
+            for (int64_t t = 0; t < nW; t++) {
+                Work &w = work[t];
+                for (size_t u = 0; u < w.out.size(); u++)
+                    if (!w.isTodo[u]) criterionFresh(nActive, w.out[u]);
+                sortSaveBestHits(w.node, w.out, (int64_t) w.out.size(), w.nNew);
+                visible[w.node] = hits[w.node][0];
             }
             resetTopVisible(nActive);
         }
