@@ -83,6 +83,7 @@ BLACKBOX_CASES = [
     ("bb_nt_600_fastest", ["-nt", "-fastest"], 600, 100, 4, 0.04, 0.02, 22),
     ("bb_nt_600_fastest_no2nd", ["-nt", "-fastest", "-no2nd"], 600, 100, 4, 0.04, 0.02, 22),
     ("bb_nt_1500", ["-nt"], 1500, 80, 4, 0.03, 0.01, 23),
+    ("bb_nt_300_double", ["-nt", "-double-precision"], 300, 90, 4, 0.05, 0.03, 24),
 ]
 
 

@@ -35,14 +35,15 @@ def test_join_order_matches_reference_on_gpu(name, fastest, limit):
 
 @pytest.mark.parametrize("name,fastest,second", [("bb_nt_c1", True, True), ("bb_nt_200", False, False),
                                                  ("bb_nt_600_fastest_no2nd", True, False),
-                                                 ("bb_nt_600_fastest", True, True), ("bb_nt_1500", False, False)])
+                                                 ("bb_nt_600_fastest", True, True), ("bb_nt_1500", False, False),
+                                                 ("bb_nt_300_double", False, False)])
 def test_cpp_host_driver_join_order_on_gpu(name, fastest, second):
     """The C++ host driver (veryfasttree_amd/host/NJDriver.h through include/vft_host.h) over the C ABI."""
     from veryfasttree_amd import HipProfileOps
     from veryfasttree_amd.backend import nj_run
     d = G.load(name)
     codes = unique_codes(d["codes"])
-    ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+    ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float64 if "double" in name else np.float32)
     joins, crit = nj_run(ops, codes, fastest=fastest, second_level=second)
     want = d["joins"]
     assert len(joins) == len(want)

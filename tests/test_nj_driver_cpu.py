@@ -24,11 +24,12 @@ def unique_codes(codes):
 @pytest.mark.parametrize("name,fastest,second,limit", [("bb_nt_c1", True, True, None), ("bb_nt_200", False, False, None),
                                                        ("bb_nt_600_fastest_no2nd", True, False, None),
                                                        ("bb_nt_600_fastest", True, True, None),
-                                                       ("bb_nt_1500", False, False, 450)])
+                                                       ("bb_nt_1500", False, False, 450),
+                                                       ("bb_nt_300_double", False, False, None)])
 def test_join_order_matches_reference(name, fastest, second, limit):
     d = G.load(name)
     codes = unique_codes(d["codes"])
-    ops = OracleOps(codes.shape[0], codes.shape[1], 4, np.float32)
+    ops = OracleOps(codes.shape[0], codes.shape[1], 4, np.float64 if "double" in name else np.float32)
     drv = NJDriver(ops, codes, fastest=fastest, use_tophits_2nd=second)
     if fastest:
         drv.tophits_refresh = 0.5   # main.cpp:339-343: -fastest
