@@ -28,7 +28,7 @@ struct vft_ctx {
     // arena
     uint4 *leafT = nullptr, *profC = nullptr;
     void *profW = nullptr, *profF = nullptr;
-    unsigned long long *vecMask = nullptr;
+    unsigned long long *vecMask = nullptr, *wMask = nullptr;
     // host-side bookkeeping for the packed vector rows: which nodes have been written, and the highest written
     // lane of every tile (a batch may use the append path only above it)
     std::vector<uint8_t> written;
@@ -135,6 +135,7 @@ static Arena<REAL> arena(const vft_ctx *c) {
     A.profF = (REAL *) c->profF;
     A.profC = c->profC;
     A.vecMask = c->vecMask;
+    A.wMask = c->wMask;
     A.parent = c->parent;
     A.diameter = (REAL *) c->diameter;
     A.selfweight = (REAL *) c->selfweight;
@@ -296,6 +297,8 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipMemset(c->profW, 0, (size_t) c->nProfTiles * d.nPosPad * VFT_TILE * rs));
     CR(dalloc(&c->vecMask, (size_t) c->nProfTiles * d.nPosPad));
     CR(hipMemset(c->vecMask, 0, (size_t) c->nProfTiles * d.nPosPad * 8));
+    CR(dalloc(&c->wMask, (size_t) c->nProfTiles * d.nPosPad));
+    CR(hipMemset(c->wMask, 0, (size_t) c->nProfTiles * d.nPosPad * 8));
     c->written.assign((size_t) N, 0);
     c->hParent.assign((size_t) N, 0);
     for (int64_t i = 0; i < cfg->max_nodes; i++) c->hParent[(size_t) i] = -1;
@@ -376,7 +379,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
-    void *ptrs[] = {c->tileMask, c->vecMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
+    void *ptrs[] = {c->tileMask, c->vecMask, c->wMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
                     c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit,
                     c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
@@ -773,7 +776,7 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
     const bool append = append_safe(c, out, n);
     const int64_t chunk = append ? 16384 : 1;
     const size_t rs = c->rs;
-    const size_t stashB = append ? (size_t) chunk * c->d.nPos * c->d.nCodes * rs : 0;
+    const size_t stashB = append ? (size_t) chunk * c->d.nPos * (c->d.nCodes + 1) * rs : 0;
     const size_t idB = (((size_t) n * 8) + 255) & ~(size_t) 255;
     const bool smallIds = 4 * idB <= VFT_SMALL_BYTES;
     if (int r = ensure_scratch(c, (smallIds ? 0 : 4 * idB) + stashB + 512)) return r;
@@ -1040,8 +1043,6 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
             launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
                                query, qbuf<float>(c, 0));
             kernel_event(c);
-            // (k_sweep_nt<.., MODE_CRIT_LEAFQ>, one float per vector for leaf seeds, measured 99 us vs 105 us in
-            //  its first form and slower after refactoring: not used until it earns its keep)
             launch((k_sweep_nt<float, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<float>(c),
                    qbuf<float>(c, 0), s, sweepout<float>(c));
             kernel_event(c);
@@ -1200,7 +1201,7 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
         if (int r = internal_ok(c, out[k])) return r;
     const bool append = append_safe(c, out, n);
     const int64_t chunk = append ? 16384 : 1;
-    const size_t stashB = append ? (size_t) chunk * c->d.nPos * c->d.nCodes * c->rs : 0;
+    const size_t stashB = append ? (size_t) chunk * c->d.nPos * (c->d.nCodes + 1) * c->rs : 0;
     const size_t idB = (size_t) n * 8;
     if (int r = ensure_scratch(c, 5 * idB + stashB + 256)) return r;
     char *s = (char *) c->scratch;

@@ -14,6 +14,7 @@ struct Arena {
     REAL *profF;
     uint4 *profC;
     unsigned long long *vecMask;
+    unsigned long long *wMask;
     int32_t *parent;
     REAL *diameter, *selfweight, *selfdist, *outDist;
     int32_t *nOutActive;
@@ -44,6 +45,12 @@ __device__ __forceinline__ int vft_decode(uint32_t enc) {
     return (enc & 0x10u) ? (__ffs((int) (enc & 0xFu)) - 1) : VFT_NOCODE_;
 }
 
+// weight of a column that stores none (vft_layout.h): 1 under a code or a vector, 0 for an empty gap
+template <typename REAL>
+__device__ __forceinline__ REAL vft_implicit_weight(int code, bool hasVector) {
+    return (hasVector || code != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;
+}
+
 // One alignment column of one node, in the reference's terms.
 template <typename REAL, int NC>
 struct Col {
@@ -64,13 +71,17 @@ __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node,
         c.vec = false;
     } else {
         const int64_t pt = tile - A.d.firstProfTile;
-        c.w = A.profW[vft_w_idx(A.d, pt, p, lane)];
+        const int64_t mi = vft_mask_idx(A.d, pt, p);
+        const unsigned long long mask = A.vecMask[mi], wm = A.wMask[mi];
+        const unsigned long long below = (1ull << lane) - 1ull;
         const uint4 t = A.profC[vft_c_idx(A.d, pt, (int) (p >> 4), lane)];
         c.code = (int) vft_byte(t, (int) (p & 15));
-        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+        const bool hv = (mask >> lane) & 1ull;
+        if ((wm >> lane) & 1ull) c.w = A.profW[vft_w_idx(A.d, pt, p, __popcll(wm & below))];
+        else c.w = vft_implicit_weight<REAL>(c.code, hv);
+        c.vec = c.w > 0 && c.code == VFT_NOCODE_;   // == hv (vft_store_col)
         if (c.vec) {
-            const unsigned long long mask = A.vecMask[vft_mask_idx(A.d, pt, p)];
-            const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+            const int slot = __popcll(mask & below);
 #pragma unroll
             for (int k = 0; k < NC; k++) c.f[k] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, slot)];
         }

@@ -110,9 +110,7 @@ __device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *par
     }
 }
 
-// MODE_CRIT_LEAFQ is MODE_CRIT with the knowledge that the query is a leaf (every seed of setAllLeafTopHits): its
-// columns are plain codes with weight 1, so against a profile column only ONE frequency matters (NJ.tcc:922-930)
-enum { MODE_CRIT = 0, MODE_OUTDIST = 1, MODE_CRIT_LEAFQ = 2 };
+enum { MODE_CRIT = 0, MODE_OUTDIST = 1 };
 
 // %-different distance of two leaves from their encoded bytes (seqDist, NJ.tcc:1601-1612): integer counts.
 __device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int &nUse, int &nSame) {
@@ -122,68 +120,62 @@ __device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int
 }
 
 // Nucleotide, no distance matrix (the -nt default).  NC == 4.
-// ---- internal targets: one 16-column chunk of one tile, as registers of the lane that owns the target
-// QLEAF (the query is a leaf): only f[cq] of a vector is needed (piece = 1 - f2[code1], NJ.tcc:924).
-template <typename REAL, bool QLEAF>
+// ---- internal targets: one 16-column chunk of one tile, as registers of the lane that owns the target.
+// Every column is brought to the "both sides hold a vector" form of profileDistPiece (NJ.tcc:933-937):
+//     piece = 1 - f1[0]*f2[0] - f1[1]*f2[1] - f1[2]*f2[2] - f1[3]*f2[3]   (numeric_t products, double subtractions)
+// with a plain code c replaced by its one-hot vector.  That is bit-identical to the reference's special cases
+// (c1==c2 ? 0 : 1,  1 - f2[c1],  1 - f1[c2]; NJ.tcc:920-930): a product with 0 or 1 is exact and subtracting the
+// resulting +-0.0 from the running double never changes it.  One code path instead of four, no per-lane selects.
+template <typename REAL>
 struct IntChunk {
     REAL w[VFT_CHUNK];
-    REAL f[VFT_CHUNK][QLEAF ? 1 : 4];
-    uint4 codes;      // the target's codes of these 16 columns
-    uint4 qcodes;     // QLEAF: the query's codes of these 16 columns (wave-uniform)
-    uint32_t hv;      // bit b: the target holds a vector at column b
+    REAL f[VFT_CHUNK][4];
 };
 
 typedef const __attribute__((address_space(4))) unsigned long long *vft_smask_t;
 
-template <typename REAL, bool QLEAF>
-__device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL, QLEAF> &r, int c, const REAL *wT, const uint4 *cT,
-                                                   vft_smask_t mT, const REAL *fT, const QueryBuf<REAL> &Q, int lane,
-                                                   int dbg = 0) {
+// codes: the target's 16 codes of this chunk (loaded one chunk ahead so that the defaults below do not wait on it)
+template <typename REAL>
+__device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, const uint4 codes, const REAL *wT,
+                                                   vft_smask_t mV, vft_smask_t mW, const REAL *fT, int dbg = 0) {
     constexpr int G = 16 / (int) sizeof(REAL);   // values per 16-byte group
     constexpr int NG = 4 / G;                    // groups per column (1 for float, 2 for double)
     const int64_t p0 = (int64_t) c * VFT_CHUNK;
-    r.codes = cT[(int64_t) c * VFT_TILE];
-    if (QLEAF) {
-        typedef unsigned int __attribute__((ext_vector_type(4))) u4_t;
-        const u4_t qv = *(const __attribute__((address_space(4))) u4_t *) (Q.code + p0);
-        r.qcodes.x = qv.x; r.qcodes.y = qv.y; r.qcodes.z = qv.z; r.qcodes.w = qv.w;
-    }
-    unsigned long long masks[VFT_CHUNK];
+    unsigned long long masksV[VFT_CHUNK], masksW[VFT_CHUNK];
 #pragma unroll
-    for (int b = 0; b < VFT_CHUNK; b++) masks[b] = mT[p0 + b];   // wave-uniform: scalar loads
-    r.hv = 0;
+    for (int b = 0; b < VFT_CHUNK; b++) {   // wave-uniform: scalar loads
+        masksV[b] = mV[p0 + b];
+        masksW[b] = mW[p0 + b];
+    }
 #pragma unroll
     for (int b = 0; b < VFT_CHUNK; b++) {
         const int64_t p = p0 + b;
-        const unsigned long long mask = masks[b];
-        r.w[b] = (dbg & 2) ? (REAL) 1 : wT[p * VFT_TILE];
-        const bool hv = ((mask >> lane) & 1ull) && !(dbg & 1);
-        r.hv |= (hv ? 1u : 0u) << b;
-        const int slot = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (mask >> 32),
-                               __builtin_amdgcn_mbcnt_lo((unsigned int) mask, 0u));
-        if (QLEAF) {
-            const uint32_t cq = vft_byte(r.qcodes, b) & 3u;   // a gap (127 & 3) is masked out by its weight 0
-            r.f[b][0] = 0;
-            if (hv) r.f[b][0] = fT[((p * NG + (int) (cq / G)) * VFT_TILE + slot) * G + (int) (cq % G)];
-        } else {
+        // the masks are wave-uniform SGPR pairs: inverse_ballot turns them into the lane predicate for free
+        const bool hv = __builtin_amdgcn_inverse_ballot_w64(masksV[b]) && !(dbg & 1);
+        const bool hw = __builtin_amdgcn_inverse_ballot_w64(masksW[b]) && !(dbg & 2);
+        const int slotV = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (masksV[b] >> 32),
+                                __builtin_amdgcn_mbcnt_lo((unsigned int) masksV[b], 0u));
+        const int slotW = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (masksW[b] >> 32),
+                                __builtin_amdgcn_mbcnt_lo((unsigned int) masksW[b], 0u));
+        const uint32_t cd = vft_byte(codes, b);
+        r.w[b] = (hv || cd != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;   // implicit weight (vft_layout.h)
+        if (hw) r.w[b] = wT[p * VFT_TILE + slotW];
 #pragma unroll
-            for (int k = 0; k < (QLEAF ? 1 : 4); k++) r.f[b][k] = 0;
-            if (hv) {   // (unconditional loads from a clamped slot measured slower: +8 %)
+        for (int k = 0; k < 4; k++) r.f[b][k] = (cd == (uint32_t) k) ? (REAL) 1 : (REAL) 0;
+        if (hv) {   // (unconditional loads from a clamped slot measured slower: +8 %)
 #pragma unroll
-                for (int g = 0; g < NG; g++)
+            for (int g = 0; g < NG; g++)
 #pragma unroll
-                    for (int e = 0; e < G; e++)
-                        r.f[b][(QLEAF ? 0 : g * G + e)] = fT[((p * NG + g) * VFT_TILE + slot) * G + e];
-            }
+                for (int e = 0; e < G; e++) r.f[b][g * G + e] = fT[((p * NG + g) * VFT_TILE + slotV) * G + e];
         }
     }
 }
 
-// The reference's column loop (NJ.tcc:1172-1183) over the 16 columns, in order and branch-free: a column that the
-// reference skips (a weight <= 0) adds +0.0 to both double sums, which is exact; a lane without a vector takes the
-// code formula.  Padding columns (beyond nPos) exist in the arena with weight 0 and mask 0.
-template <typename REAL, bool QLEAF>
-__device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL, QLEAF> &r, int c, const QueryBuf<REAL> &Q,
+// The reference's column loop (NJ.tcc:1172-1183) over the 16 columns, in order and branch-free.  The reference skips
+// a column when either weight is <= 0; weights are never negative, so the product is +0.0 there and adding
+// (+0.0, +0.0 * piece) to the two double sums is exact.  Padding columns (beyond nPos) have weight 0 on both sides.
+template <typename REAL>
+__device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL> &r, int c, const QueryBuf<REAL> &Q,
                                                       double &top, double &denom, int dbg = 0) {
     const int64_t p0 = (int64_t) c * VFT_CHUNK;
     if (dbg & 4) {   // ablation: no arithmetic, just consume the loaded values
@@ -194,35 +186,15 @@ __device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL, QLEAF
 #pragma unroll
     for (int b = 0; b < VFT_CHUNK; b++) {
         const int64_t p = p0 + b;
-        const REAL wt = r.w[b];
-        const bool hv = (r.hv >> b) & 1u;
-        double wgt, pieceV, pieceC;
-        if (QLEAF) {
-            const uint32_t cq = vft_byte(r.qcodes, b);
-            // leaf weight is 1: w1 * w2 == w2 exactly (NJ.tcc:1176)
-            wgt = (cq != VFT_NOCODE_ && wt > 0) ? (double) wt : 0.0;
-            pieceV = 1.0 - (double) r.f[b][0];
-            pieceC = (vft_byte(r.codes, b) == cq) ? 0.0 : 1.0;
-        } else {
-            const REAL wq = vft_uniform_load<REAL>(Q.w + p);
-            const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
-            const REAL ww = wq * wt;   // numeric_t product, NJ.tcc:1176
-            wgt = (wq > 0 && wt > 0) ? (double) ww : 0.0;
-            // NJ.tcc:933-937: piece = 1 - sum f1[k] * f2[k], numeric_t products, double subtractions
-            const REAL q0 = fq.x * r.f[b][0], q1 = fq.y * r.f[b][QLEAF ? 0 : 1];
-            const REAL q2 = fq.z * r.f[b][QLEAF ? 0 : 2], q3 = fq.w * r.f[b][QLEAF ? 0 : 3];
-            pieceV = 1.0 - (double) q0;
-            pieceV -= (double) q1;
-            pieceV -= (double) q2;
-            pieceV -= (double) q3;
-            // target holds a plain code: 1 - fq[code] (NJ.tcc:922-930; fq is one-hot when the query column is a code)
-            const uint32_t cd = vft_byte(r.codes, b);
-            const REAL f01 = (cd & 1u) ? fq.y : fq.x;
-            const REAL f23 = (cd & 1u) ? fq.w : fq.z;
-            const REAL fqc = (cd & 2u) ? f23 : f01;
-            pieceC = 1.0 - (double) fqc;
-        }
-        const double piece = hv ? pieceV : pieceC;
+        const REAL wq = vft_uniform_load<REAL>(Q.w + p);
+        const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
+        const REAL ww = wq * r.w[b];   // numeric_t product, NJ.tcc:1176
+        const double wgt = (double) ww;
+        const REAL q0 = fq.x * r.f[b][0], q1 = fq.y * r.f[b][1], q2 = fq.z * r.f[b][2], q3 = fq.w * r.f[b][3];
+        double piece = 1.0 - (double) q0;
+        piece -= (double) q1;
+        piece -= (double) q2;
+        piece -= (double) q3;
         denom += wgt;
         top += wgt * piece;
     }
@@ -279,9 +251,13 @@ __device__ __forceinline__ void vft_leaf_vs_profile(const Arena<REAL> &A, const 
 
 template <typename REAL, int MODE_>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
-    constexpr int MODE = MODE_ == MODE_OUTDIST ? MODE_OUTDIST : MODE_CRIT;
-    constexpr bool QLEAF = MODE_ == MODE_CRIT_LEAFQ;
-    const int64_t j = s.lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    constexpr int MODE = MODE_;
+    // Heavy first: the workgroups of internal targets (HBM-bound, ~10x the bytes of a leaf) are dispatched before
+    // the leaf-only ones (LDS/VALU-bound), which then fill the idle issue slots instead of running ahead of them.
+    const int nHeavyWG = (int) gridDim.x - s.nLeafWG;
+    const int wg = (s.pad & 8) ? (int) blockIdx.x   // (ablation: plain order)
+                   : (int) blockIdx.x < nHeavyWG ? s.nLeafWG + (int) blockIdx.x : (int) blockIdx.x - nHeavyWG;
+    const int64_t j = s.lo + (int64_t) wg * VFT_WG + threadIdx.x;
     const int lane = (int) (j & 63);
     const int64_t tile = j >> 6;
     REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
@@ -301,7 +277,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
         }
     }
     // workgroup-uniform: leaf-only workgroups with a profile query take the LDS-table path
-    const bool tablePath = (int) blockIdx.x < s.nLeafWG && !(MODE == MODE_CRIT && s.queryIsLeaf);
+    const bool tablePath = wg < s.nLeafWG && !(MODE == MODE_CRIT && s.queryIsLeaf);
     double topT = 0, denomT = 0;
     if (tablePath) {
         // a workgroup with nothing to do (all targets inactive, or no stale out-distance) skips the table build
@@ -350,26 +326,25 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                     }
                 }
             } else {
-                // internal targets: dense weights + codes, vectors packed per (tile, column) by lane rank
+                // internal targets: codes dense; explicit weights and vectors packed per (tile, column) by lane rank
                 const int64_t pt = tile - A.d.firstProfTile;
-                const REAL *wT = A.profW + vft_w_idx(A.d, pt, 0, lane);
+                const REAL *wT = A.profW + vft_w_idx(A.d, pt, 0, 0);
                 const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, lane);
                 // masks are wave-uniform and never written by this kernel: read them through the scalar cache
                 // (the 64 lanes of a wave share one tile; readfirstlane tells the compiler so)
                 const int64_t ptU = (int64_t) __builtin_amdgcn_readfirstlane((int) pt);
-                const vft_smask_t mT = (vft_smask_t) (A.vecMask + vft_mask_idx(A.d, ptU, 0));
+                const vft_smask_t mV = (vft_smask_t) (A.vecMask + vft_mask_idx(A.d, ptU, 0));
+                const vft_smask_t mW = (vft_smask_t) (A.wMask + vft_mask_idx(A.d, ptU, 0));
                 const REAL *fT = A.profF + vft_f_idx<REAL>(A.d, pt, 0, 0, 0);
-                constexpr int G = 16 / (int) sizeof(REAL);   // values per 16-byte group
-                constexpr int NG = 4 / G;                    // groups per column (1 for float, 2 for double)
-                // 16-column chunks: every load of a chunk is issued before its first result is used
-                // Measured on the 1M workload (tools/microbench_sweep.py, VFT_SWEEP_ABLATE): loads alone 96 us
-                // (5.0 TB/s), arithmetic alone 74 us, together 105 us - the two overlap across the 4 waves per SIMD.
-                // Prefetching chunk c+1 while consuming chunk c (register double buffering) was SLOWER (125 us): the
-                // extra registers cost more than the already-overlapped latency gives back.
-                IntChunk<REAL, QLEAF> ca;
+                // 16-column chunks: every load of a chunk is issued before its first result is used; the codes run
+                // one chunk ahead.  (Register double buffering of the whole chunk was slower: 125 vs 99 us.)
+                IntChunk<REAL> ca;
+                uint4 codes = cT[0];
                 for (int c = 0; c < A.d.nChunk; c++) {
-                    vft_int_chunk_load<REAL, QLEAF>(ca, c, wT, cT, mT, fT, Q, lane, s.pad);
-                    vft_int_chunk_consume<REAL, QLEAF>(ca, c, Q, top, denom, s.pad);
+                    const uint4 cur = codes;
+                    if (c + 1 < A.d.nChunk) codes = cT[(int64_t) (c + 1) * VFT_TILE];
+                    vft_int_chunk_load<REAL>(ca, c, cur, wT, mV, mW, fT, s.pad);
+                    vft_int_chunk_consume<REAL>(ca, c, Q, top, denom, s.pad);
                 }
             }
             weight = (REAL) (denom > 0 ? denom : 0.01);

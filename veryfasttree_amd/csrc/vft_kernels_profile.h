@@ -7,37 +7,47 @@
 
 #define VFT_WG_PROF 256
 
-// Write one column of one node.  The vectors of a (tile, column) row are packed by lane order, so a write that
-// adds or removes a vector moves the vectors of the higher lanes by one slot.  NOT safe for two nodes of the same
-// tile concurrently: callers either write one node per launch or use the append path below.
+// Write one column of one node.  The explicit weights and the vectors of a (tile, column) row are packed by lane
+// order, so a write that adds or removes one moves the entries of the higher lanes by one slot.  NOT safe for two
+// nodes of the same tile concurrently: callers either write one node per launch or use the append path below.
+// Moves the packed entries (NV values each, at slot s -> idx(k, s)) of the lanes above `lane` when `lane` gains or
+// loses its entry; returns the slot of `lane`.
+template <int NV, typename IDX>
+__device__ __forceinline__ int vft_packed_update(unsigned long long *maskp, int lane, bool want, IDX idx) {
+    const unsigned long long old = *maskp;
+    const unsigned long long bit = 1ull << lane;
+    const bool had = (old & bit) != 0;
+    const int slot = __popcll(old & (bit - 1ull));
+    const int nHigher = lane == 63 ? 0 : __popcll(old >> (lane + 1));
+    if (want && !had) {
+        for (int s = slot + nHigher - 1; s >= slot; s--)
+#pragma unroll
+            for (int k = 0; k < NV; k++) *idx(k, s + 1) = *idx(k, s);
+        *maskp = old | bit;
+    } else if (!want && had) {
+        for (int s = slot + 1; s <= slot + nHigher; s++)
+#pragma unroll
+            for (int k = 0; k < NV; k++) *idx(k, s - 1) = *idx(k, s);
+        *maskp = old & ~bit;
+    }
+    return slot;
+}
+
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_store_col(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
                                               const REAL *f) {
     const int lane = (int) (node & 63);
     const int64_t pt = (node >> 6) - A.d.firstProfTile;
-    A.profW[vft_w_idx(A.d, pt, p, lane)] = w;
     uint8_t *cb = (uint8_t *) (A.profC + vft_c_idx(A.d, pt, (int) (p >> 4), lane));
     cb[p & 15] = (uint8_t) code;
     const bool vec = w > 0 && code == VFT_NOCODE_;
+    const bool explicitW = !(w == vft_implicit_weight<REAL>(code, vec));
     const int64_t mi = vft_mask_idx(A.d, pt, p);
-    const unsigned long long old = A.vecMask[mi];
-    const unsigned long long bit = 1ull << lane;
-    const bool had = (old & bit) != 0;
-    const int slot = __popcll(old & (bit - 1ull));
-    const int nHigher = lane == 63 ? 0 : __popcll(old >> (lane + 1));
-    if (vec && !had) {
-        for (int s = slot + nHigher - 1; s >= slot; s--)
-#pragma unroll
-            for (int k = 0; k < NC; k++)
-                A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s + 1)] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s)];
-        A.vecMask[mi] = old | bit;
-    } else if (!vec && had) {
-        for (int s = slot + 1; s <= slot + nHigher; s++)
-#pragma unroll
-            for (int k = 0; k < NC; k++)
-                A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s - 1)] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s)];
-        A.vecMask[mi] = old & ~bit;
-    }
+    const int slotW = vft_packed_update<1>(&A.wMask[mi], lane, explicitW,
+                                           [&](int, int s) { return &A.profW[vft_w_idx(A.d, pt, p, s)]; });
+    if (explicitW) A.profW[vft_w_idx(A.d, pt, p, slotW)] = w;
+    const int slot = vft_packed_update<NC>(&A.vecMask[mi], lane, vec,
+                                           [&](int k, int s) { return &A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s)]; });
     if (vec) {
 #pragma unroll
         for (int k = 0; k < NC; k++) A.profF[vft_f_idx<REAL>(A.d, pt, p, k, slot)] = f[k];
@@ -46,17 +56,21 @@ __device__ __forceinline__ void vft_store_col(const Arena<REAL> &A, int64_t node
 
 // Append path, phase A: for nodes that have never been written and sit above every written lane of their tile
 // (the NJ join loop only ever appends: newnode = maxnode++, NJ.tcc:2904).  Any number of such nodes may be written
-// in one launch: weights/codes go to their final place, the mask bit is OR-ed in, the vector is parked in `stash`
-// ([batch][nPos][NC]) until k_commit_vectors knows the final slot.
+// in one launch: codes go to their final place, the mask bits are OR-ed in, the vector and an explicit weight are
+// parked in `stash` ([batch][nPos][NC + 1]) until k_commit_vectors knows the final slots.
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_store_col_append(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
                                                      const REAL *f, REAL *stash) {
     const int lane = (int) (node & 63);
     const int64_t pt = (node >> 6) - A.d.firstProfTile;
-    A.profW[vft_w_idx(A.d, pt, p, lane)] = w;
     uint8_t *cb = (uint8_t *) (A.profC + vft_c_idx(A.d, pt, (int) (p >> 4), lane));
     cb[p & 15] = (uint8_t) code;
-    if (w > 0 && code == VFT_NOCODE_) {
+    const bool vec = w > 0 && code == VFT_NOCODE_;
+    if (!(w == vft_implicit_weight<REAL>(code, vec))) {
+        atomicOr(&A.wMask[vft_mask_idx(A.d, pt, p)], 1ull << lane);
+        stash[NC] = w;
+    }
+    if (vec) {
         atomicOr(&A.vecMask[vft_mask_idx(A.d, pt, p)], 1ull << lane);
 #pragma unroll
         for (int k = 0; k < NC; k++) stash[k] = f[k];
@@ -72,10 +86,14 @@ __global__ void k_commit_vectors(Arena<REAL> A, const int64_t *nodes, const REAL
     const int64_t node = nodes[k];
     const int lane = (int) (node & 63);
     const int64_t pt = (node >> 6) - A.d.firstProfTile;
-    const unsigned long long mask = A.vecMask[vft_mask_idx(A.d, pt, p)];
+    const int64_t mi = vft_mask_idx(A.d, pt, p);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const REAL *src = stash + (k * A.d.nPos + p) * (NC + 1);
+    const unsigned long long wm = A.wMask[mi];
+    if ((wm >> lane) & 1ull) A.profW[vft_w_idx(A.d, pt, p, __popcll(wm & below))] = src[NC];
+    const unsigned long long mask = A.vecMask[mi];
     if (!((mask >> lane) & 1ull)) return;
-    const int slot = __popcll(mask & ((1ull << lane) - 1ull));
-    const REAL *src = stash + (k * A.d.nPos + p) * NC;
+    const int slot = __popcll(mask & below);
 #pragma unroll
     for (int q = 0; q < NC; q++) A.profF[vft_f_idx<REAL>(A.d, pt, p, q, slot)] = src[q];
 }
@@ -179,7 +197,7 @@ __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
             vft_normalize_freq<REAL, NC>(A, f, tol);
         }
     }
-    if (stash) vft_store_col_append<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * NC);
+    if (stash) vft_store_col_append<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
     else vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
 }
 
@@ -279,7 +297,7 @@ template <typename REAL>
 struct OutTileRegs {
     REAL w[4];
     uint4 codes;
-    unsigned long long mask;
+    unsigned long long mask, wmask;
     REAL f[4][4];
 };
 
@@ -294,12 +312,13 @@ __device__ __forceinline__ void vft_outtile_load(const Arena<REAL> &A, int64_t t
     const int64_t pt = tile - A.d.firstProfTile;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const int idx = tid * 4 + u;           // (column, lane) of the 16 x 64 weight block
+        const int idx = tid * 4 + u;           // (column, slot) of the 16 x 64 block of packed explicit weights
         r.w[u] = A.profW[vft_w_idx(A.d, pt, p0 + (idx >> 6), idx & 63)];
     }
     if (tid < 64 && tile * 64 + tid >= A.d.nSeqs) r.codes = A.profC[vft_c_idx(A.d, pt, chunk, tid)];
     const int col = tid >> 4;
     r.mask = A.vecMask[vft_mask_idx(A.d, pt, p0 + col)];
+    r.wmask = A.wMask[vft_mask_idx(A.d, pt, p0 + col)];
     const int cnt = __popcll(r.mask);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REA
                                                                        int64_t nTiles, int64_t nActive, double tol) {
     __shared__ REAL sW[VFT_CHUNK][64];
     __shared__ uint4 sCodes[64];
-    __shared__ unsigned long long sMask[VFT_CHUNK];
+    __shared__ unsigned long long sMask[VFT_CHUNK], sWMask[VFT_CHUNK];
     __shared__ REAL sF[VFT_CHUNK][64][4];
     __shared__ REAL sRes[VFT_CHUNK][5];
     const int tid = threadIdx.x;
@@ -343,7 +362,10 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REA
                 sW[idx >> 6][idx & 63] = regs.w[u];
             }
             if (tid < 64) sCodes[tid] = regs.codes;
-            if ((tid & 15) == 0) sMask[tid >> 4] = regs.mask;
+            if ((tid & 15) == 0) {
+                sMask[tid >> 4] = regs.mask;
+                sWMask[tid >> 4] = regs.wmask;
+            }
             const int cnt = __popcll(regs.mask);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -371,8 +393,10 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REA
                     code = vft_decode<4>(enc);
                     w = code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
                 } else {
-                    w = sW[col][l];
                     code = (int) vft_byte(sCodes[l], col);
+                    const unsigned long long below = (1ull << l) - 1ull, wm = sWMask[col];
+                    w = ((wm >> l) & 1ull) ? sW[col][__popcll(wm & below)]
+                                           : vft_implicit_weight<REAL>(code, (sMask[col] >> l) & 1ull);
                 }
                 if (chain == 0) {
                     acc = (REAL) ((double) acc + (double) w * inweight);               // NJ.tcc:741

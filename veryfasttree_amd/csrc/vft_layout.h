@@ -39,7 +39,12 @@ VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
 }
 
 // ---- internal profiles (tile index is relative to firstProfTile)
-//   REAL  profW[ptile][pos][lane]             weights, dense
+//   u64   wMask[ptile][pos]                   bit l set <=> node 64*tile+l stores an EXPLICIT weight at this column.
+//                                             Without the bit the weight is implied: 1 if the column holds a code
+//                                             or a vector, 0 if it is an empty gap (what leaves and almost every
+//                                             column of a low-gap alignment have, NJ.tcc:2078-2112)
+//   REAL  profW[ptile][pos][slot]             the explicit weights of one (tile, column), PACKED by lane rank in
+//                                             wMask exactly like the vectors below
 //   uint4 profC[ptile][chunk][lane]           raw reference codes, 16 columns per uint4, dense
 //   u64   vecMask[ptile][pos]                 bit l set <=> node 64*tile+l holds a frequency vector at this column
 //   REAL  profF[ptile][pos][group][slot][G]   the vectors of one (tile, column), PACKED: the vector of lane l sits
@@ -48,8 +53,8 @@ VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
 //                                             only the vectors that exist (the reference's sparse profiles,
 //                                             NJ.h:126-141) and still reads them as one contiguous run.
 VFT_HD int64_t vft_mask_idx(const VftDims &d, int64_t ptile, int64_t pos) { return ptile * d.nPosPad + pos; }
-VFT_HD int64_t vft_w_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t lane) {
-    return (ptile * d.nPosPad + pos) * VFT_TILE + lane;
+VFT_HD int64_t vft_w_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t slot) {
+    return (ptile * d.nPosPad + pos) * VFT_TILE + slot;
 }
 template <typename REAL> VFT_HD constexpr int vft_group() { return 16 / (int) sizeof(REAL); }
 template <typename REAL>
