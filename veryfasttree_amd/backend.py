@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvft_hip.so")
+# VFT_HIP_LIB: kernel-variant experiments of tools/ only (another build of the same library)
+LIB_PATH = os.environ.get("VFT_HIP_LIB") or os.path.join(HERE, "lib", "libvft_hip.so")
 NOCODE = 127
 
 P = C.c_void_p

@@ -42,6 +42,7 @@ struct vft_ctx {
     void *qW[2] = {nullptr, nullptr}, *qF[2] = {nullptr, nullptr};
     uint8_t *qC[2] = {nullptr, nullptr};
     uint4 *qEnc[2] = {nullptr, nullptr};
+    double2 *qTab[2] = {nullptr, nullptr};
     // sweep outputs
     void *swDist = nullptr, *swWeight = nullptr, *swCrit = nullptr;
     void *partMin = nullptr, *partMax = nullptr;
@@ -170,6 +171,7 @@ static QueryBuf<REAL> qbuf(const vft_ctx *c, int which) {
     q.code = c->qC[which];
     q.f = (REAL *) c->qF[which];
     q.enc = c->qEnc[which];
+    q.tab = c->qTab[which];
     return q;
 }
 
@@ -327,6 +329,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
         CR(dallocb(&c->qF[q], (size_t) nPosPad * d.nCodes * rs));
         CR(dalloc(&c->qC[q], (size_t) nPosPad));
         CR(dalloc(&c->qEnc[q], (size_t) d.nChunk));
+        CR(dalloc(&c->qTab[q], (size_t) nPosPad * 5));
     }
     c->nPart = (int) cdiv(N, VFT_WG);
     CR(dallocb(&c->partMin, (size_t) c->nPart * 8));
@@ -381,7 +384,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
     void *ptrs[] = {c->tileMask, c->vecMask, c->wMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
-                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->swDist, c->swWeight, c->swCrit,
+                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->qTab[0], c->qTab[1], c->swDist, c->swWeight, c->swCrit,
                     c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
                     c->dm[1], c->dm[2], c->dm[3], c->tm[0], c->tm[1], c->tm[2], c->tm[3], c->tm[4], c->tm[5],
                     c->rates, c->ratecat, c->scratch};
@@ -886,6 +889,14 @@ extern "C" int vft_out_profile_download(vft_ctx *c, void *w, void *f, void *cd) 
     return VFT_OK;
 }
 
+// k_sweep_nt geometry: table workgroups (VFT_LEAF_SPAN leaves each) when the query is a profile, then VFT_WG ids each
+static unsigned sweep_nt_grid(vft_ctx *c, SweepArgs &s, bool tablePath) {
+    const int64_t leafEnd = c->d.nSeqs < s.hi ? c->d.nSeqs : s.hi;
+    s.nLeafWG = (tablePath && leafEnd > s.lo) ? (int32_t) ((leafEnd - s.lo) / VFT_LEAF_SPAN) : 0;
+    const int64_t rest = (s.hi > s.lo ? s.hi - s.lo : 0) - (int64_t) s.nLeafWG * VFT_LEAF_SPAN;
+    return (unsigned) s.nLeafWG + cdiv(rest > 0 ? rest : 1, VFT_WG);
+}
+
 // launches the out-distance refresh over [lo,hi) (ids == nullptr) or over a device id list
 static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int64_t nActive, int64_t nDiffAllow,
                                 double totdiam, bool force) {
@@ -906,21 +917,18 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
     }
     if (s.hi <= s.lo) return VFT_OK;
     const int64_t span = s.hi - s.lo;
-    {
-        const int64_t leafEnd = (c->d.nSeqs < s.hi ? c->d.nSeqs : s.hi);
-        s.nLeafWG = leafEnd > s.lo ? (int32_t) ((leafEnd - s.lo) / VFT_WG) : 0;
-    }
     if (c->cfg.n_codes == 4 && !c->hasDm) {
         const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+        const unsigned grid = sweep_nt_grid(c, s, true);
         if (c->cfg.precision == 4) {
             launch((k_outprofile_as_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<float>(c), qbuf<float>(c, 1));
-            launch((k_sweep_nt<float, MODE_OUTDIST>), dim3(cdiv(span, VFT_WG)), dim3(VFT_WG), 0, c->stream,
+            launch((k_sweep_nt<float, MODE_OUTDIST>), dim3(grid), dim3(VFT_WG), 0, c->stream,
                                arena<float>(c), qbuf<float>(c, 1), s, sweepout<float>(c));
         } else {
             launch((k_outprofile_as_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), qbuf<double>(c, 1));
-            launch((k_sweep_nt<double, MODE_OUTDIST>), dim3(cdiv(span, VFT_WG)), dim3(VFT_WG), 0, c->stream,
+            launch((k_sweep_nt<double, MODE_OUTDIST>), dim3(grid), dim3(VFT_WG), 0, c->stream,
                                arena<double>(c), qbuf<double>(c, 1), s, sweepout<double>(c));
         }
     } else {
@@ -1030,12 +1038,9 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     s.totdiam = totdiam;
     s.queryIsLeaf = query < c->d.nSeqs ? 1 : 0;
     if (const char *dbg = getenv("VFT_SWEEP_ABLATE")) s.pad = atoi(dbg);   // kernel ablation switches (tools only)
-    {
-        const int64_t leafEnd = (c->d.nSeqs < hi ? c->d.nSeqs : hi);
-        s.nLeafWG = leafEnd > lo ? (int32_t) ((leafEnd - lo) / VFT_WG) : 0;
-    }
     const int64_t span = hi > lo ? hi - lo : 0;
-    const unsigned grid = cdiv(span > 0 ? span : 1, VFT_WG);
+    const bool ntPath = c->cfg.n_codes == 4 && !c->hasDm;
+    const unsigned grid = ntPath ? sweep_nt_grid(c, s, !s.queryIsLeaf) : cdiv(span > 0 ? span : 1, VFT_WG);
     c->nPart = (int) grid;
     const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
     if (c->cfg.n_codes == 4 && !c->hasDm) {

@@ -18,7 +18,25 @@ struct QueryBuf {
     uint8_t *code;  // [nPosPad] reference codes
     REAL *f;        // [nPosPad][nCodes]; nt: one-hot for code columns (see k_extract_query)
     uint4 *enc;     // [nChunk] encoded leaf bytes (valid when the query is a leaf)
+    double2 *tab;   // [nPosPad][5] nt: what a LEAF target adds to (top, denom) at this column, by its code 0..3 / gap
 };
+
+// A leaf column is a code with weight 1, so against a profile query its contribution depends only on (column, code):
+//     code c:  denom += (double) wq,   top += (double) wq * (1.0 - (double) fq[c])     (NJ.tcc:1176-1182, 922-930)
+//     gap (or wq <= 0):  +0.0 to both, which is exact
+template <typename REAL>
+__device__ __forceinline__ void vft_query_tab(const QueryBuf<REAL> &q, int64_t p, REAL wq, const REAL *f) {
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        double2 v = make_double2(0.0, 0.0);
+        if (c < 4 && wq > 0) {
+            const double wgt = (double) wq;
+            const double piece = 1.0 - (double) f[c < 4 ? c : 0];
+            v = make_double2(wgt * piece, wgt);
+        }
+        q.tab[p * 5 + c] = v;
+    }
+}
 
 template <typename REAL, int NC>
 __global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
@@ -47,6 +65,7 @@ __global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
     q.code[p] = (uint8_t) code;
 #pragma unroll
     for (int k = 0; k < NC; k++) q.f[p * NC + k] = f[k];
+    if (NC == 4) vft_query_tab<REAL>(q, p, w, f);
     if (node < A.d.nSeqs && p < A.d.nChunk) {
         q.enc[p] = A.leafT[vft_leaf_idx(A.d, node >> 6, (int) p, (int) (node & 63))];
     }
@@ -61,8 +80,13 @@ __global__ void k_outprofile_as_query(Arena<REAL> A, QueryBuf<REAL> q) {
     const bool in = p < A.d.nPos;
     q.w[p] = in ? A.outW[p] : (REAL) 0;
     q.code[p] = VFT_NOCODE_;
+    REAL f[NC];
 #pragma unroll
-    for (int k = 0; k < NC; k++) q.f[p * NC + k] = in ? A.outF[p * NC + k] : (REAL) 0;
+    for (int k = 0; k < NC; k++) {
+        f[k] = in ? A.outF[p * NC + k] : (REAL) 0;
+        q.f[p * NC + k] = f[k];
+    }
+    if (NC == 4) vft_query_tab<REAL>(q, p, in ? A.outW[p] : (REAL) 0, f);
 }
 
 // ------------------------------------------------------------------------------------------------ sweep (nt)
@@ -126,29 +150,32 @@ __device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int
 // with a plain code c replaced by its one-hot vector.  That is bit-identical to the reference's special cases
 // (c1==c2 ? 0 : 1,  1 - f2[c1],  1 - f1[c2]; NJ.tcc:920-930): a product with 0 or 1 is exact and subtracting the
 // resulting +-0.0 from the running double never changes it.  One code path instead of four, no per-lane selects.
+#ifndef VFT_SUB
+#define VFT_SUB 8   // columns loaded and consumed together (a divisor of VFT_CHUNK)
+#endif
 template <typename REAL>
 struct IntChunk {
-    REAL w[VFT_CHUNK];
-    REAL f[VFT_CHUNK][4];
+    REAL w[VFT_SUB];
+    REAL f[VFT_SUB][4];
 };
 
 typedef const __attribute__((address_space(4))) unsigned long long *vft_smask_t;
 
 // codes: the target's 16 codes of this chunk (loaded one chunk ahead so that the defaults below do not wait on it)
 template <typename REAL>
-__device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, const uint4 codes, const REAL *wT,
+__device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, int sub, const uint4 codes, const REAL *wT,
                                                    vft_smask_t mV, vft_smask_t mW, const REAL *fT, int dbg = 0) {
     constexpr int G = 16 / (int) sizeof(REAL);   // values per 16-byte group
     constexpr int NG = 4 / G;                    // groups per column (1 for float, 2 for double)
-    const int64_t p0 = (int64_t) c * VFT_CHUNK;
-    unsigned long long masksV[VFT_CHUNK], masksW[VFT_CHUNK];
+    const int64_t p0 = (int64_t) c * VFT_CHUNK + sub * VFT_SUB;
+    unsigned long long masksV[VFT_SUB], masksW[VFT_SUB];
 #pragma unroll
-    for (int b = 0; b < VFT_CHUNK; b++) {   // wave-uniform: scalar loads
+    for (int b = 0; b < VFT_SUB; b++) {   // wave-uniform: scalar loads
         masksV[b] = mV[p0 + b];
         masksW[b] = mW[p0 + b];
     }
 #pragma unroll
-    for (int b = 0; b < VFT_CHUNK; b++) {
+    for (int b = 0; b < VFT_SUB; b++) {
         const int64_t p = p0 + b;
         // the masks are wave-uniform SGPR pairs: inverse_ballot turns them into the lane predicate for free
         const bool hv = __builtin_amdgcn_inverse_ballot_w64(masksV[b]) && !(dbg & 1);
@@ -157,7 +184,7 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, con
                                 __builtin_amdgcn_mbcnt_lo((unsigned int) masksV[b], 0u));
         const int slotW = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (masksW[b] >> 32),
                                 __builtin_amdgcn_mbcnt_lo((unsigned int) masksW[b], 0u));
-        const uint32_t cd = vft_byte(codes, b);
+        const uint32_t cd = vft_byte(codes, sub * VFT_SUB + b);
         r.w[b] = (hv || cd != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;   // implicit weight (vft_layout.h)
         if (hw) r.w[b] = wT[p * VFT_TILE + slotW];
 #pragma unroll
@@ -175,16 +202,16 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, con
 // a column when either weight is <= 0; weights are never negative, so the product is +0.0 there and adding
 // (+0.0, +0.0 * piece) to the two double sums is exact.  Padding columns (beyond nPos) have weight 0 on both sides.
 template <typename REAL>
-__device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL> &r, int c, const QueryBuf<REAL> &Q,
+__device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL> &r, int c, int sub, const QueryBuf<REAL> &Q,
                                                       double &top, double &denom, int dbg = 0) {
-    const int64_t p0 = (int64_t) c * VFT_CHUNK;
+    const int64_t p0 = (int64_t) c * VFT_CHUNK + sub * VFT_SUB;
     if (dbg & 4) {   // ablation: no arithmetic, just consume the loaded values
 #pragma unroll
-        for (int b = 0; b < VFT_CHUNK; b++) top += (double) r.w[b] + (double) r.f[b][0];
+        for (int b = 0; b < VFT_SUB; b++) top += (double) r.w[b] + (double) r.f[b][0];
         return;
     }
 #pragma unroll
-    for (int b = 0; b < VFT_CHUNK; b++) {
+    for (int b = 0; b < VFT_SUB; b++) {
         const int64_t p = p0 + b;
         const REAL wq = vft_uniform_load<REAL>(Q.w + p);
         const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
@@ -200,51 +227,183 @@ __device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL> &r, i
     }
 }
 
-// Leaf targets against a PROFILE query (an internal node or the out-profile), workgroups that hold leaves only.
+// Epilogue of one (query, target) distance: setDistCriterion's diameter correction and criterion (NJ.tcc:1115-1124)
+// or, for the out-profile as query, setOutDistance (NJ.tcc:1046-1053).
+template <typename REAL, int MODE>
+__device__ __forceinline__ void vft_sweep_finish(const Arena<REAL> &A, const SweepArgs &s, const SweepOut<REAL> &O,
+                                                 int64_t j, REAL dist, REAL weight, bool seqPair, REAL &cmin, REAL &cmax) {
+    if (MODE == MODE_CRIT) {
+        if (!seqPair) {
+            const REAL dd = A.diameter[s.query] + A.diameter[j];
+            dist = dist - dd;   // NJ.tcc:1120
+        }
+        const REAL crit = vft_criterion<REAL>(dist, A.outDist[s.query], A.nOutActive[s.query], A.outDist[j],
+                                              A.nOutActive[j], s.nActive);
+        O.dist[j] = dist;
+        O.weight[j] = weight;
+        O.crit[j] = crit;
+        cmin = crit < cmin ? crit : cmin;
+        cmax = crit > cmax ? crit : cmax;
+    } else {
+        const REAL od = vft_out_distance<REAL>(dist, weight, s.nActive, A.selfweight[j], A.selfdist[j], A.diameter[j],
+                                               s.totdiam);
+        A.outDist[j] = od;
+        A.nOutActive[j] = (int32_t) s.nActive;
+        A.mOutDist[j] = od;
+        A.mNOut[j] = (int32_t) s.nActive;
+    }
+}
+
+// does target j need a distance in this launch?  MODE_CRIT: every active node (the others get the reference's
+// "illegal join" sentinel, NJ.tcc:3586-3590); MODE_OUTDIST: active nodes whose out-distance is too stale.
+template <typename REAL, int MODE>
+__device__ __forceinline__ bool vft_sweep_wants(const Arena<REAL> &A, const SweepArgs &s, const SweepOut<REAL> &O, int64_t j) {
+    const bool active = A.parent[j] < 0;
+    if (MODE == MODE_CRIT) {
+        if (!active) {
+            O.dist[j] = (REAL) 1e20;
+            O.crit[j] = (REAL) 1e20;
+            O.weight[j] = 0;
+        }
+        return active;
+    }
+    return active && (s.force || ((int64_t) A.nOutActive[j] - s.nActive > s.nDiffAllow)) &&
+           (int64_t) A.nOutActive[j] != s.nActive;
+}
+
+// Leaf targets against a PROFILE query (an internal node or the out-profile): one workgroup per VFT_LEAF_SPAN
+// consecutive leaves.
 // A leaf column is a code with weight 1, so its contribution to (top, denom) depends only on (column, code):
 //     code c:  denom += (double) wq,   top += (double) wq * (1.0 - (double) fq[c])     (NJ.tcc:1176-1182, 922-930)
 //     gap:     nothing (adding +0.0 to the running double sums is exact)
 // The 5 x nPos table of those addends is built once per workgroup in LDS; each lane then walks its leaf's columns
-// in the reference's order doing one LDS read and two double adds per column — same bits as evaluating the
+// in the reference's order doing one LDS read and two double adds per column - same bits as evaluating the
 // products per lane, a fifth of the instructions.
+// Joined leaves are scattered through the id space (half of them late in a run), so the workgroup first COMPACTS
+// the leaves that need a distance into an LDS list and hands them out densely: no idle lanes in the column loop.
 #define VFT_PTILE 256
-template <typename REAL>
-__device__ __forceinline__ void vft_leaf_vs_profile(const Arena<REAL> &A, const QueryBuf<REAL> &Q, int64_t tile, int lane,
-                                                    bool work, double &top, double &denom) {
-    __shared__ double2 tab[VFT_PTILE * 5];
+#define VFT_LEAF_SPAN 1024
+// one 16-column chunk of NBT leaves against the LDS table row
+template <int NBT>
+__device__ __forceinline__ void vft_leaf_table_chunk(const double2 *row, const uint4 *t, double *top, double *denom) {
+    // groups of GC columns: all LDS reads of a group (~8) are issued before the first add needs one
+    constexpr int GC = NBT == 1 ? 8 : NBT == 2 ? 4 : 2;
+#pragma unroll
+    for (int g = 0; g < VFT_CHUNK; g += GC) {
+        double2 v[NBT][GC];
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++)
+#pragma unroll
+            for (int q = 0; q < GC; q++) {
+                // stored byte: 0x10 | one-hot nibble, 0 for a gap -> table column 0..3, or 4 for a gap
+                const int idx = __ffs((int) (vft_byte(t[bt], g + q) | 0x10u)) - 1;
+                v[bt][q] = row[(g + q) * 5 + idx];   // padding columns hold zeros
+            }
+#pragma unroll
+        for (int q = 0; q < GC; q++)
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) {
+                denom[bt] += v[bt][q].y;
+                top[bt] += v[bt][q].x;
+            }
+    }
+}
+
+template <typename REAL, int NBT>
+__device__ __forceinline__ void vft_leaf_table_walk(const Arena<REAL> &A, const QueryBuf<REAL> &Q, double2 *tab,
+                                                    const int64_t *tj, double *top, double *denom) {
+    const int tid = threadIdx.x;
     const int64_t nPos = A.d.nPos;
+    const uint4 *lp[NBT];
+#pragma unroll
+    for (int bt = 0; bt < NBT; bt++) lp[bt] = A.leafT + vft_leaf_idx(A.d, tj[bt] >> 6, 0, (int) (tj[bt] & 63));
     for (int64_t p0 = 0; p0 < nPos; p0 += VFT_PTILE) {
         __syncthreads();
-        for (int e = threadIdx.x; e < VFT_PTILE * 5; e += VFT_WG) {
-            const int64_t p = p0 + e / 5;
-            const int c = e % 5;
-            double2 v = make_double2(0.0, 0.0);
-            if (p < nPos && c < 4) {
-                const REAL wq = Q.w[p];
-                if (wq > 0) {
-                    const double wgt = (double) wq;
-                    const double piece = 1.0 - (double) Q.f[p * 4 + c];
-                    v = make_double2(wgt * piece, wgt);
-                }
-            }
-            tab[e] = v;
+        {   // the table of this position tile (written by k_extract_query): independent, coalesced 16-byte loads
+            const int64_t nTab = ((int64_t) A.d.nChunk * VFT_CHUNK - p0) * 5;
+            for (int e = tid; e < VFT_PTILE * 5; e += VFT_WG)
+                tab[e] = e < nTab ? Q.tab[p0 * 5 + e] : make_double2(0.0, 0.0);
         }
         __syncthreads();
-        if (work) {
-            const int c0 = (int) (p0 / VFT_CHUNK);
-            const int c1 = (int) (((p0 + VFT_PTILE < nPos ? p0 + VFT_PTILE : nPos) + VFT_CHUNK - 1) / VFT_CHUNK);
-            for (int c = c0; c < c1; c++) {
-                const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
-                const double2 *row = tab + (int64_t) (c - c0) * VFT_CHUNK * 5;
+        const int c0 = (int) (p0 / VFT_CHUNK);
+        const int c1 = (int) (((p0 + VFT_PTILE < nPos ? p0 + VFT_PTILE : nPos) + VFT_CHUNK - 1) / VFT_CHUNK);
+        // the leaves' bytes run one chunk ahead of the table walk (a chunk is ~0.3 us of work, a load ~1 us away):
+        // explicit ping-pong between two register sets, so that a wait only covers the older set (vmcnt is in-order)
+        uint4 ta[NBT], tb[NBT];
 #pragma unroll
-                for (int b = 0; b < VFT_CHUNK; b++) {
-                    // stored byte: 0x10 | one-hot nibble, 0 for a gap -> table column 0..3, or 4 for a gap
-                    const int idx = __ffs((int) (vft_byte(t, b) | 0x10u)) - 1;
-                    const double2 v = row[b * 5 + idx];   // padding columns hold zeros
-                    denom += v.y;
-                    top += v.x;
-                }
-            }
+        for (int bt = 0; bt < NBT; bt++) ta[bt] = lp[bt][(int64_t) c0 * VFT_TILE];
+        for (int c = c0; c < c1; c += 2) {
+            const int cb = c + 1 < c1 ? c + 1 : c, ca = c + 2 < c1 ? c + 2 : c;
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) tb[bt] = lp[bt][(int64_t) cb * VFT_TILE];
+            __builtin_amdgcn_sched_barrier(0);   // keep the loads above the chunk they overlap with
+            vft_leaf_table_chunk<NBT>(tab + (int64_t) (c - c0) * VFT_CHUNK * 5, ta, top, denom);
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) ta[bt] = lp[bt][(int64_t) ca * VFT_TILE];
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < c1) vft_leaf_table_chunk<NBT>(tab + (int64_t) (c + 1 - c0) * VFT_CHUNK * 5, tb, top, denom);
+        }
+    }
+}
+
+template <typename REAL, int MODE>
+__device__ __forceinline__ void vft_leaf_table_wg(const Arena<REAL> &A, const QueryBuf<REAL> &Q, const SweepArgs &s,
+                                                  const SweepOut<REAL> &O, int64_t base, REAL &cmin, REAL &cmax) {
+    constexpr int NB = VFT_LEAF_SPAN / VFT_WG, NW = VFT_WG / 64;
+    __shared__ double2 tab[VFT_PTILE * 5];
+    __shared__ unsigned short list[VFT_LEAF_SPAN];
+    __shared__ int segCnt[NB * NW];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // 1. compaction (order-preserving, so neighbouring list entries are neighbours in memory)
+    unsigned long long bal[NB];
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        bal[r] = __ballot(vft_sweep_wants<REAL, MODE>(A, s, O, base + r * VFT_WG + tid));
+        if ((tid & 63) == 0) segCnt[r * NW + wave] = __popcll(bal[r]);
+    }
+    __syncthreads();
+    int nAct = 0, off[NB];
+#pragma unroll
+    for (int seg = 0; seg < NB * NW; seg++) {
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (seg == r * NW + wave) off[r] = nAct;
+        nAct += segCnt[seg];
+    }
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (bal[r] >> 32),
+                               __builtin_amdgcn_mbcnt_lo((unsigned int) bal[r], 0u));
+        if ((bal[r] >> (tid & 63)) & 1ull) list[off[r] + rank] = (unsigned short) (r * VFT_WG + tid);
+    }
+    __syncthreads();
+    if (nAct == 0) return;   // workgroup-uniform
+    const int nBatch = (nAct + VFT_WG - 1) / VFT_WG;
+    // 2. this thread's leaves (one per batch) and their column walk; the number of batches is made a compile-time
+    //    constant so that the loads running one chunk ahead can be waited for individually (vmcnt is in-order)
+    int64_t tj[NB];
+    double top[NB], denom[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; bt++) {
+        const int idx = bt * VFT_WG + tid;
+        tj[bt] = base + list[idx < nAct ? idx : 0];   // lanes beyond the list redo entry 0 and drop the result
+        top[bt] = 0;
+        denom[bt] = 0;
+    }
+    if (s.pad & 32) return;     // (ablation: compaction only)
+    if (!(s.pad & 16)) switch (nBatch) {   // (ablation 16: no column walk)
+    case 1: vft_leaf_table_walk<REAL, 1>(A, Q, tab, tj, top, denom); break;
+    case 2: vft_leaf_table_walk<REAL, 2>(A, Q, tab, tj, top, denom); break;
+    case 3: vft_leaf_table_walk<REAL, 3>(A, Q, tab, tj, top, denom); break;
+    default: vft_leaf_table_walk<REAL, 4>(A, Q, tab, tj, top, denom); break;
+    }
+    // 3. epilogue
+#pragma unroll
+    for (int bt = 0; bt < NB; bt++) {
+        if (bt * VFT_WG + tid < nAct) {
+            const REAL weight = (REAL) (denom[bt] > 0 ? denom[bt] : 0.01);
+            const REAL dist = (REAL) (denom[bt] > 0 ? top[bt] / denom[bt] : 1.0);
+            vft_sweep_finish<REAL, MODE>(A, s, O, tj[bt], dist, weight, false, cmin, cmax);
         }
     }
 }
@@ -252,45 +411,27 @@ __device__ __forceinline__ void vft_leaf_vs_profile(const Arena<REAL> &A, const 
 template <typename REAL, int MODE_>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
     constexpr int MODE = MODE_;
-    // Heavy first: the workgroups of internal targets (HBM-bound, ~10x the bytes of a leaf) are dispatched before
-    // the leaf-only ones (LDS/VALU-bound), which then fill the idle issue slots instead of running ahead of them.
+    // Workgroup roles: s.nLeafWG "table" workgroups cover VFT_LEAF_SPAN leaves each (profile query only), the others
+    // VFT_WG consecutive ids each.  Heavy first: the workgroups of internal targets (HBM-bound, ~10x the bytes of a
+    // leaf) are dispatched before the table ones (LDS/VALU-bound), which then fill the idle issue slots.
     const int nHeavyWG = (int) gridDim.x - s.nLeafWG;
     const int wg = (s.pad & 8) ? (int) blockIdx.x   // (ablation: plain order)
                    : (int) blockIdx.x < nHeavyWG ? s.nLeafWG + (int) blockIdx.x : (int) blockIdx.x - nHeavyWG;
-    const int64_t j = s.lo + (int64_t) wg * VFT_WG + threadIdx.x;
+    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
+    if (wg < s.nLeafWG) {   // workgroup-uniform
+        vft_leaf_table_wg<REAL, MODE>(A, Q, s, O, s.lo + (int64_t) wg * VFT_LEAF_SPAN, cmin, cmax);
+        if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
+        return;
+    }
+    const int64_t j = s.lo + (int64_t) s.nLeafWG * VFT_LEAF_SPAN + (int64_t) (wg - s.nLeafWG) * VFT_WG + threadIdx.x;
     const int lane = (int) (j & 63);
     const int64_t tile = j >> 6;
-    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
-    bool work = j < s.hi;
-    if (work) {
-        const bool active = A.parent[j] < 0;
-        if (MODE == MODE_CRIT) {
-            if (!active) {   // NJ.tcc:3586-3590: illegal/empty join
-                O.dist[j] = (REAL) 1e20;
-                O.crit[j] = (REAL) 1e20;
-                O.weight[j] = 0;
-                work = false;
-            }
-        } else {
-            work = active && (s.force || ((int64_t) A.nOutActive[j] - s.nActive > s.nDiffAllow)) &&
-                   (int64_t) A.nOutActive[j] != s.nActive;
-        }
-    }
-    // workgroup-uniform: leaf-only workgroups with a profile query take the LDS-table path
-    const bool tablePath = wg < s.nLeafWG && !(MODE == MODE_CRIT && s.queryIsLeaf);
-    double topT = 0, denomT = 0;
-    if (tablePath) {
-        // a workgroup with nothing to do (all targets inactive, or no stale out-distance) skips the table build
-        if (__syncthreads_or(work ? 1 : 0)) vft_leaf_vs_profile<REAL>(A, Q, tile, lane, work, topT, denomT);
-    }
+    const bool work = j < s.hi && vft_sweep_wants<REAL, MODE>(A, s, O, j);
     if (work) {
         const int64_t nPos = A.d.nPos;
         const bool targetLeaf = j < A.d.nSeqs;
         REAL dist, weight;
-        if (tablePath) {
-            weight = (REAL) (denomT > 0 ? denomT : 0.01);
-            dist = (REAL) (denomT > 0 ? topT / denomT : 1.0);
-        } else if (MODE == MODE_CRIT && s.queryIsLeaf && targetLeaf) {
+        if (MODE == MODE_CRIT && s.queryIsLeaf && targetLeaf) {
             int nUse = 0, nSame = 0;
             for (int c = 0; c < A.d.nChunk; c++) {
                 const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
@@ -327,48 +468,34 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                 }
             } else {
                 // internal targets: codes dense; explicit weights and vectors packed per (tile, column) by lane rank
-                const int64_t pt = tile - A.d.firstProfTile;
+                // the 64 lanes of a wave share one tile: readfirstlane makes every base address below wave-uniform
+                // (SGPR base + 32-bit lane offset addressing; masks through the scalar cache)
+                const int64_t pt = (int64_t) __builtin_amdgcn_readfirstlane((int) (tile - A.d.firstProfTile));
                 const REAL *wT = A.profW + vft_w_idx(A.d, pt, 0, 0);
-                const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, lane);
-                // masks are wave-uniform and never written by this kernel: read them through the scalar cache
-                // (the 64 lanes of a wave share one tile; readfirstlane tells the compiler so)
-                const int64_t ptU = (int64_t) __builtin_amdgcn_readfirstlane((int) pt);
-                const vft_smask_t mV = (vft_smask_t) (A.vecMask + vft_mask_idx(A.d, ptU, 0));
-                const vft_smask_t mW = (vft_smask_t) (A.wMask + vft_mask_idx(A.d, ptU, 0));
+                const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, 0);
+                const vft_smask_t mV = (vft_smask_t) (A.vecMask + vft_mask_idx(A.d, pt, 0));
+                const vft_smask_t mW = (vft_smask_t) (A.wMask + vft_mask_idx(A.d, pt, 0));
                 const REAL *fT = A.profF + vft_f_idx<REAL>(A.d, pt, 0, 0, 0);
-                // 16-column chunks: every load of a chunk is issued before its first result is used; the codes run
-                // one chunk ahead.  (Register double buffering of the whole chunk was slower: 125 vs 99 us.)
+                // VFT_SUB-column groups: every load of a group is issued before its first result is used; the codes
+                // run one 16-column chunk ahead (issued after the group's loads so that nothing waits on them).
                 IntChunk<REAL> ca;
-                uint4 codes = cT[0];
-                for (int c = 0; c < A.d.nChunk; c++) {
-                    const uint4 cur = codes;
-                    if (c + 1 < A.d.nChunk) codes = cT[(int64_t) (c + 1) * VFT_TILE];
-                    vft_int_chunk_load<REAL>(ca, c, cur, wT, mV, mW, fT, s.pad);
-                    vft_int_chunk_consume<REAL>(ca, c, Q, top, denom, s.pad);
+                uint4 cur = cT[lane];
+                const int nChunk = A.d.nChunk;
+                for (int c = 0; c < nChunk; c++) {
+                    uint4 nxt;
+#pragma unroll
+                    for (int sub = 0; sub < VFT_CHUNK / VFT_SUB; sub++) {
+                        vft_int_chunk_load<REAL>(ca, c, sub, cur, wT, mV, mW, fT, s.pad);
+                        if (sub == 0) nxt = cT[(int64_t) (c + 1 < nChunk ? c + 1 : c) * VFT_TILE + lane];
+                        vft_int_chunk_consume<REAL>(ca, c, sub, Q, top, denom, s.pad);
+                    }
+                    cur = nxt;
                 }
             }
             weight = (REAL) (denom > 0 ? denom : 0.01);
             dist = (REAL) (denom > 0 ? top / denom : 1.0);
         }
-        if (MODE == MODE_CRIT) {
-            if (!(s.queryIsLeaf && targetLeaf)) {
-                const REAL dd = A.diameter[s.query] + A.diameter[j];
-                dist = dist - dd;   // NJ.tcc:1120
-            }
-            const REAL crit = vft_criterion<REAL>(dist, A.outDist[s.query], A.nOutActive[s.query], A.outDist[j],
-                                                  A.nOutActive[j], s.nActive);
-            O.dist[j] = dist;
-            O.weight[j] = weight;
-            O.crit[j] = crit;
-            cmin = cmax = crit;
-        } else {
-            const REAL od = vft_out_distance<REAL>(dist, weight, s.nActive, A.selfweight[j], A.selfdist[j],
-                                                   A.diameter[j], s.totdiam);
-            A.outDist[j] = od;
-            A.nOutActive[j] = (int32_t) s.nActive;
-            A.mOutDist[j] = od;
-            A.mNOut[j] = (int32_t) s.nActive;
-        }
+        vft_sweep_finish<REAL, MODE>(A, s, O, j, dist, weight, s.queryIsLeaf && targetLeaf, cmin, cmax);
     }
     if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
 }
