@@ -167,8 +167,11 @@ int vft_posterior_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const in
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */
 int vft_timer_start(vft_ctx *ctx);
 int vft_timer_stop_ms(vft_ctx *ctx, float *ms);
-/* name and average duration (ms) of the dominant kernel's launches since the last vft_timer_start */
+/* average duration (ms) of the dominant kernel's launches since the last vft_timer_start: k_sweep_nt, the sweep over
+   internal-profile targets (and over every target when the seed is a leaf) */
 int vft_sweep_kernel_ms(vft_ctx *ctx, float *avg_ms, int64_t *launches);
+/* same for the sweep's second launch, k_sweep_nt_table (leaf targets of a profile seed; 0 ms when it did not run) */
+int vft_sweep_table_kernel_ms(vft_ctx *ctx, float *avg_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -26,4 +26,6 @@ for targets, (lo, hi) in (("internal", (n64, st.maxnode)), ("leaf", (0, (n // 10
             ops.setBestHit(q_int, st.n_active, st.n_diff_allow, st.totdiam, 0, want_best=False, want_hits=False)
         ops.timer_stop_ms()
         ms, nl = ops.sweep_kernel_ms()
-        print("%-9s targets, internal seed, ablate=%d: sweep kernel %.1f us" % (targets, ab, ms * 1e3))
+        ms2, _ = ops.sweep_table_kernel_ms()
+        print("%-9s targets, internal seed, ablate=%d: k_sweep_nt %.1f us + k_sweep_nt_table %.1f us = %.1f us" % (
+            targets, ab, ms * 1e3, ms2 * 1e3, (ms + ms2) * 1e3))

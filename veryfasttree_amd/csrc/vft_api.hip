@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../include/vft_hip.h"
@@ -28,11 +30,8 @@ struct vft_ctx {
     // arena
     uint4 *leafT = nullptr, *profC = nullptr;
     void *profW = nullptr, *profF = nullptr;
-    unsigned long long *vecMask = nullptr, *wMask = nullptr;
-    // host-side bookkeeping for the packed vector rows: which nodes have been written, and the highest written
-    // lane of every tile (a batch may use the append path only above it)
-    std::vector<uint8_t> written;
-    std::vector<int8_t> tileMaxLane;
+    ColMask *colMask = nullptr;
+    ColOff *colOff = nullptr;
     std::vector<int32_t> hParent;          // host copy of parent[], to recognise "all active nodes, ascending" lists
     unsigned long long *tileMask = nullptr;
     int32_t *parent = nullptr, *nOutActive = nullptr;
@@ -135,8 +134,8 @@ static Arena<REAL> arena(const vft_ctx *c) {
     A.profW = (REAL *) c->profW;
     A.profF = (REAL *) c->profF;
     A.profC = c->profC;
-    A.vecMask = c->vecMask;
-    A.wMask = c->wMask;
+    A.colMask = c->colMask;
+    A.colOff = c->colOff;
     A.parent = c->parent;
     A.diameter = (REAL *) c->diameter;
     A.selfweight = (REAL *) c->selfweight;
@@ -297,15 +296,13 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(dallocb(&c->profF, (size_t) c->nProfTiles * d.nPosPad * VFT_TILE * d.nCodes * rs));
     CR(dalloc(&c->profC, (size_t) c->nProfTiles * d.nChunk * VFT_TILE));
     CR(hipMemset(c->profW, 0, (size_t) c->nProfTiles * d.nPosPad * VFT_TILE * rs));
-    CR(dalloc(&c->vecMask, (size_t) c->nProfTiles * d.nPosPad));
-    CR(hipMemset(c->vecMask, 0, (size_t) c->nProfTiles * d.nPosPad * 8));
-    CR(dalloc(&c->wMask, (size_t) c->nProfTiles * d.nPosPad));
-    CR(hipMemset(c->wMask, 0, (size_t) c->nProfTiles * d.nPosPad * 8));
-    c->written.assign((size_t) N, 0);
+    CR(dalloc(&c->colMask, (size_t) c->nProfTiles * d.nPosPad));
+    CR(hipMemset(c->colMask, 0, (size_t) c->nProfTiles * d.nPosPad * sizeof(ColMask)));
+    CR(dalloc(&c->colOff, (size_t) c->nProfTiles * d.nPosPad));
+    CR(hipMemset(c->colOff, 0, (size_t) c->nProfTiles * d.nPosPad * sizeof(ColOff)));
     c->hParent.assign((size_t) N, 0);
     for (int64_t i = 0; i < cfg->max_nodes; i++) c->hParent[(size_t) i] = -1;
     CR(dalloc(&c->tileMask, (size_t) d.nTiles));
-    c->tileMaxLane.assign((size_t) d.nTiles, -1);
     CR(hipMemset(c->profC, 0x7F, (size_t) c->nProfTiles * d.nChunk * VFT_TILE * sizeof(uint4)));
     CR(dalloc(&c->parent, (size_t) N));
     CR(dalloc(&c->nOutActive, (size_t) N));
@@ -382,7 +379,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
-    void *ptrs[] = {c->tileMask, c->vecMask, c->wMask, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
+    void *ptrs[] = {c->tileMask, c->colMask, c->colOff, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
                     c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->qTab[0], c->qTab[1], c->swDist, c->swWeight, c->swCrit,
                     c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
@@ -647,22 +644,68 @@ extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
 }
 
 // ---------------------------------------------------------------------------------------------- profiles
-// may `nodes` be written through the append path (phase A + k_commit_vectors) in ONE launch?
-static bool append_safe(const vft_ctx *c, const int64_t *nodes, int64_t n) {
-    for (int64_t k = 0; k < n; k++) {
-        const int64_t v = nodes[k];
-        if (c->written[(size_t) v]) return false;
-        if ((int) c->tileMaxLane[(size_t) (v >> 6)] >= (int) (v & 63)) return false;
-    }
-    return true;
+// Writing nodes = producing kernel (codes -> profC, columns -> stash) + k_tile_commit per touched tile.
+struct CommitPlan {
+    int64_t chunk;      // nodes per producing launch
+    size_t stashB;      // stash bytes (chunk nodes)
+    size_t metaB;       // order[] + segFirst[] when they do not fit the mapped ring
+    size_t stride;      // commit scratch per tile
+    size_t totalB;      // stashB + metaB + VFT_COMMIT_SEGS * stride
+};
+#define VFT_COMMIT_SEGS 256
+static CommitPlan commit_plan(const vft_ctx *c, int64_t n) {
+    CommitPlan p;
+    const size_t perNode = (size_t) c->d.nPos * (size_t) (c->d.nCodes + 1) * c->rs;
+    int64_t chunk = (int64_t) ((256u << 20) / perNode);
+    chunk = chunk < 64 ? 64 : chunk > 16384 ? 16384 : chunk;
+    p.chunk = n < chunk ? (n > 0 ? n : 1) : chunk;
+    p.stashB = (((size_t) p.chunk * perNode) + 255) & ~(size_t) 255;
+    p.metaB = (((size_t) (2 * p.chunk + 2) * 4) + 255) & ~(size_t) 255;
+    p.stride = vft_commit_scratch_bytes(c->d, c->rs);
+    const int64_t segs = p.chunk < VFT_COMMIT_SEGS ? p.chunk : VFT_COMMIT_SEGS;
+    p.totalB = p.stashB + p.metaB + (size_t) segs * p.stride;
+    return p;
 }
-static void mark_written(vft_ctx *c, const int64_t *nodes, int64_t n) {
-    for (int64_t k = 0; k < n; k++) {
-        const int64_t v = nodes[k];
-        c->written[(size_t) v] = 1;
-        int8_t &m = c->tileMaxLane[(size_t) (v >> 6)];
-        if ((int) (v & 63) > (int) m) m = (int8_t) (v & 63);
+
+// hNodes/dNodes: the cnt node ids of this launch (host copy / device copy, batch order); base: device memory laid
+// out as [stash | meta | commit scratch] according to `plan`.
+static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNodes, const int64_t *dNodes, int64_t cnt,
+                        char *base) {
+    std::vector<std::pair<int64_t, int32_t>> tk((size_t) cnt);
+    for (int64_t k = 0; k < cnt; k++) tk[(size_t) k] = std::make_pair(hNodes[k] >> 6, (int32_t) k);
+    std::stable_sort(tk.begin(), tk.end(),
+                     [](const std::pair<int64_t, int32_t> &x, const std::pair<int64_t, int32_t> &y) { return x.first < y.first; });
+    std::vector<int32_t> meta((size_t) cnt);
+    std::vector<int32_t> segFirst;
+    for (int64_t i = 0; i < cnt; i++) {
+        meta[(size_t) i] = tk[(size_t) i].second;
+        if (i == 0 || tk[(size_t) i].first != tk[(size_t) i - 1].first) segFirst.push_back((int32_t) i);
     }
+    segFirst.push_back((int32_t) cnt);
+    const int64_t nSeg = (int64_t) segFirst.size() - 1;
+    meta.insert(meta.end(), segFirst.begin(), segFirst.end());
+    const size_t bytes = meta.size() * 4;
+    char *dMeta;
+    bool viaScratch = false;
+    if (bytes <= VFT_SMALL_BYTES) {
+        char *h;
+        if (int r = io_alloc(c, bytes, &h, &dMeta)) return r;
+        memcpy(h, meta.data(), bytes);
+    } else {
+        dMeta = base + plan.stashB;
+        HIPCHK(c, hipMemcpyAsync(dMeta, meta.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        viaScratch = true;
+    }
+    const int32_t *dOrder = (const int32_t *) dMeta, *dSeg = dOrder + cnt;
+    char *cs = base + plan.stashB + plan.metaB;
+    for (int64_t g0 = 0; g0 < nSeg; g0 += VFT_COMMIT_SEGS) {
+        const int64_t g = nSeg - g0 < VFT_COMMIT_SEGS ? nSeg - g0 : VFT_COMMIT_SEGS;
+        VFT_DISPATCH(c, (launch((k_tile_commit<REAL, NC>), dim3((unsigned) g), dim3(VFT_COMMIT_WG), 0, c->stream,
+                                arena<REAL>(c), dNodes, dOrder, dSeg + g0, (const REAL *) base, cs, plan.stride)));
+        LAUNCHCHK(c);
+    }
+    if (viaScratch) HIPCHK(c, hipStreamSynchronize(c->stream));   // meta[] is a local
+    return VFT_OK;
 }
 
 static int internal_ok(vft_ctx *c, int64_t node) {
@@ -675,17 +718,23 @@ extern "C" int vft_profile_upload(vft_ctx *c, int64_t node, const void *w, const
     if (int r = internal_ok(c, node)) return r;
     const VftDims &d = c->d;
     const size_t rs = c->rs, wB = d.nPos * rs, fB = d.nPos * d.nCodes * rs, cB = (size_t) d.nPos;
-    if (int r = ensure_scratch(c, wB + fB + cB + 64)) return r;
+    const size_t inB = (wB + fB + cB + 255) & ~(size_t) 255;
+    const CommitPlan plan = commit_plan(c, 1);
+    if (int r = ensure_scratch(c, inB + plan.totalB + 256)) return r;
     char *s = (char *) c->scratch;
+    char *base = s + inB;
     HIPCHK(c, hipMemcpyAsync(s, w, wB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + wB, f, fB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + wB + fB, codes, cB, hipMemcpyHostToDevice, c->stream));
+    char *hId, *dId;
+    if (int r = io_alloc(c, 8, &hId, &dId)) return r;
+    memcpy(hId, &node, 8);
     VFT_DISPATCH(c, (launch((k_profile_scatter<REAL, NC>), dim3(cdiv(d.nPos, 256)), dim3(256), 0, c->stream,
                                         arena<REAL>(c), node, (const REAL *) s, (const uint8_t *) (s + wB + fB),
-                                        (const REAL *) (s + wB))));
+                                        (const REAL *) (s + wB), (REAL *) base)));
     LAUNCHCHK(c);
+    if (int r = commit_nodes(c, plan, &node, (const int64_t *) dId, 1, base)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    mark_written(c, &node, 1);
     return VFT_OK;
 }
 
@@ -774,16 +823,12 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         if (int r = internal_ok(c, out[k])) return r;
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad child id");
     }
-    // Batches that only append (the NJ join loop) go through in chunks of whole launches; anything that rewrites a
-    // node or lands below a written lane of its tile is written one node per launch (packed rows shift).
-    const bool append = append_safe(c, out, n);
-    const int64_t chunk = append ? 16384 : 1;
-    const size_t rs = c->rs;
-    const size_t stashB = append ? (size_t) chunk * c->d.nPos * (c->d.nCodes + 1) * rs : 0;
+    const CommitPlan plan = commit_plan(c, n);
+    const int64_t chunk = plan.chunk;
     const size_t idB = (((size_t) n * 8) + 255) & ~(size_t) 255;
     const bool smallIds = 4 * idB <= VFT_SMALL_BYTES;
-    if (int r = ensure_scratch(c, (smallIds ? 0 : 4 * idB) + stashB + 512)) return r;
-    char *s, *stash;
+    if (int r = ensure_scratch(c, (smallIds ? 0 : 4 * idB) + plan.totalB + 512)) return r;
+    char *s, *base;
     if (smallIds) {
         char *h;
         if (int r = io_alloc(c, 4 * idB, &h, &s)) return r;
@@ -791,31 +836,27 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         memcpy(h + idB, a, (size_t) n * 8);
         memcpy(h + 2 * idB, b, (size_t) n * 8);
         if (bionj) memcpy(h + 3 * idB, bionj, (size_t) n * 8);
-        stash = (char *) c->scratch;
+        base = (char *) c->scratch;
     } else {
         s = (char *) c->scratch;
-        stash = s + 4 * idB;
+        base = s + 4 * idB;
         HIPCHK(c, hipMemcpyAsync(s, out, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(s + idB, a, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
         if (bionj) HIPCHK(c, hipMemcpyAsync(s + 3 * idB, bionj, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
     }
-    stash += (256 - ((uintptr_t) stash & 255)) & 255;
+    base += (256 - ((uintptr_t) base & 255)) & 255;
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
         VFT_DISPATCH(c, {
-            Arena<REAL> A = arena<REAL>(c);
             const dim3 grid(cdiv(c->d.nPos, 128), (unsigned) cnt);
-            launch((k_average<REAL, NC>), grid, dim3(128), 0, c->stream, A, (const int64_t *) s + k0,
+            launch((k_average<REAL, NC>), grid, dim3(128), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
                    (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
-                   bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr, c->fpostTol,
-                   append ? (REAL *) stash : (REAL *) nullptr);
-            if (append) launch((k_commit_vectors<REAL, NC>), grid, dim3(128), 0, c->stream, A, (const int64_t *) s + k0,
-                               (const REAL *) stash);
+                   bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr, c->fpostTol, (REAL *) base);
         });
         LAUNCHCHK(c);
+        if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
-    mark_written(c, out, n);
     VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
                            arena<REAL>(c), (const int64_t *) s, n));
     LAUNCHCHK(c);
@@ -897,6 +938,20 @@ static unsigned sweep_nt_grid(vft_ctx *c, SweepArgs &s, bool tablePath) {
     return (unsigned) s.nLeafWG + cdiv(rest > 0 ? rest : 1, VFT_WG);
 }
 
+static void kernel_event(vft_ctx *c);
+// the two launches of one nt sweep (vft_kernels_nj.h); events: before, between, after
+template <typename REAL, int MODE>
+static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, int whichQuery, bool timed) {
+    const unsigned nHeavy = grid - (unsigned) s.nLeafWG;
+    if (timed) kernel_event(c);
+    if (nHeavy) launch((k_sweep_nt<REAL, MODE>), dim3(nHeavy), dim3(VFT_WG), 0, c->stream, arena<REAL>(c),
+                       qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c));
+    if (timed) kernel_event(c);
+    if (s.nLeafWG) launch((k_sweep_nt_table<REAL, MODE>), dim3((unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream,
+                          arena<REAL>(c), qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c));
+    if (timed) kernel_event(c);
+}
+
 // launches the out-distance refresh over [lo,hi) (ids == nullptr) or over a device id list
 static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int64_t nActive, int64_t nDiffAllow,
                                 double totdiam, bool force) {
@@ -923,13 +978,11 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
         if (c->cfg.precision == 4) {
             launch((k_outprofile_as_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<float>(c), qbuf<float>(c, 1));
-            launch((k_sweep_nt<float, MODE_OUTDIST>), dim3(grid), dim3(VFT_WG), 0, c->stream,
-                               arena<float>(c), qbuf<float>(c, 1), s, sweepout<float>(c));
+            launch_sweep_nt<float, MODE_OUTDIST>(c, s, grid, 1, false);
         } else {
             launch((k_outprofile_as_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), qbuf<double>(c, 1));
-            launch((k_sweep_nt<double, MODE_OUTDIST>), dim3(grid), dim3(VFT_WG), 0, c->stream,
-                               arena<double>(c), qbuf<double>(c, 1), s, sweepout<double>(c));
+            launch_sweep_nt<double, MODE_OUTDIST>(c, s, grid, 1, false);
         }
     } else {
         VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
@@ -970,7 +1023,7 @@ extern "C" int vft_out_distances(vft_ctx *c, int64_t n, const int64_t *ids, int6
 }
 
 // ---------------------------------------------------------------------------------------------- sweep
-static void kernel_event(vft_ctx *c) {
+static void kernel_event(vft_ctx *c) {   // three per sweep: before / between / after its two kernels
     if (!c->timeKernels) return;
     if (c->kevUsed == c->kev.size()) {
         hipEvent_t e;
@@ -1047,22 +1100,17 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         if (c->cfg.precision == 4) {
             launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
                                query, qbuf<float>(c, 0));
-            kernel_event(c);
-            launch((k_sweep_nt<float, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<float>(c),
-                   qbuf<float>(c, 0), s, sweepout<float>(c));
-            kernel_event(c);
+            launch_sweep_nt<float, MODE_CRIT>(c, s, grid, 0, true);
         } else {
             launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), query, qbuf<double>(c, 0));
-            kernel_event(c);
-            launch((k_sweep_nt<double, MODE_CRIT>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<double>(c),
-                   qbuf<double>(c, 0), s, sweepout<double>(c));
-            kernel_event(c);
+            launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true);
         }
     } else {
         kernel_event(c);
         VFT_DISPATCH(c, (launch((k_sweep_generic<REAL, NC>), dim3(grid), dim3(VFT_WG), 0, c->stream,
                                             arena<REAL>(c), s, sweepout<REAL>(c))));
+        kernel_event(c);
         kernel_event(c);
     }
     LAUNCHCHK(c);
@@ -1204,14 +1252,13 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
     for (int64_t k = 0; k < n; k++)
         if (int r = internal_ok(c, out[k])) return r;
-    const bool append = append_safe(c, out, n);
-    const int64_t chunk = append ? 16384 : 1;
-    const size_t stashB = append ? (size_t) chunk * c->d.nPos * (c->d.nCodes + 1) * c->rs : 0;
+    const CommitPlan plan = commit_plan(c, n);
+    const int64_t chunk = plan.chunk;
     const size_t idB = (size_t) n * 8;
-    if (int r = ensure_scratch(c, 5 * idB + stashB + 256)) return r;
+    if (int r = ensure_scratch(c, 5 * idB + plan.totalB + 512)) return r;
     char *s = (char *) c->scratch;
-    char *stash = s + 5 * idB;
-    stash += (256 - ((uintptr_t) stash & 255)) & 255;
+    char *base = s + 5 * idB;
+    base += (256 - ((uintptr_t) base & 255)) & 255;
     HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
@@ -1220,18 +1267,15 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
         VFT_DISPATCH(c, {
-            Arena<REAL> A = arena<REAL>(c);
             const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
-            launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, A, (const int64_t *) s + k0,
+            launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
                    (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
                    (const double *) (s + 3 * idB) + k0, (const double *) (s + 4 * idB) + k0, c->minLen, c->minRel,
-                   append ? (REAL *) stash : (REAL *) nullptr);
-            if (append) launch((k_commit_vectors<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, A,
-                               (const int64_t *) s + k0, (const REAL *) stash);
+                   (REAL *) base);
         });
         LAUNCHCHK(c);
+        if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
-    mark_written(c, out, n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }
@@ -1254,18 +1298,22 @@ extern "C" int vft_timer_stop_ms(vft_ctx *c, float *ms) {
     return VFT_OK;
 }
 
-extern "C" int vft_sweep_kernel_ms(vft_ctx *c, float *avgMs, int64_t *launches) {
+static int sweep_kernel_ms(vft_ctx *c, int which, float *avgMs, int64_t *launches) {
     if (!c || !avgMs || !launches) return VFT_ERR_INVALID;
     double total = 0;
     int64_t n = 0;
-    for (size_t i = 0; i + 1 < c->kevUsed; i += 2) {
+    for (size_t i = 0; i + 2 < c->kevUsed; i += 3) {
         float ms = 0;
-        HIPCHK(c, hipEventSynchronize(c->kev[i + 1]));
-        HIPCHK(c, hipEventElapsedTime(&ms, c->kev[i], c->kev[i + 1]));
+        HIPCHK(c, hipEventSynchronize(c->kev[i + which + 1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->kev[i + which], c->kev[i + which + 1]));
         total += ms;
         n++;
     }
     *avgMs = n ? (float) (total / (double) n) : 0.f;
     *launches = n;
     return VFT_OK;
+}
+extern "C" int vft_sweep_kernel_ms(vft_ctx *c, float *avgMs, int64_t *launches) { return sweep_kernel_ms(c, 0, avgMs, launches); }
+extern "C" int vft_sweep_table_kernel_ms(vft_ctx *c, float *avgMs, int64_t *launches) {
+    return sweep_kernel_ms(c, 1, avgMs, launches);
 }

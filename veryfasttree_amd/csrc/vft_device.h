@@ -13,8 +13,8 @@ struct Arena {
     REAL *profW;
     REAL *profF;
     uint4 *profC;
-    unsigned long long *vecMask;
-    unsigned long long *wMask;
+    ColMask *colMask;
+    ColOff *colOff;
     int32_t *parent;
     REAL *diameter, *selfweight, *selfdist, *outDist;
     int32_t *nOutActive;
@@ -71,19 +71,20 @@ __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node,
         c.vec = false;
     } else {
         const int64_t pt = tile - A.d.firstProfTile;
-        const int64_t mi = vft_mask_idx(A.d, pt, p);
-        const unsigned long long mask = A.vecMask[mi], wm = A.wMask[mi];
+        const int64_t mi = vft_meta_idx(A.d, pt, p);
+        const ColMask m = A.colMask[mi];
+        const ColOff o = A.colOff[mi];
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint4 t = A.profC[vft_c_idx(A.d, pt, (int) (p >> 4), lane)];
         c.code = (int) vft_byte(t, (int) (p & 15));
-        const bool hv = (mask >> lane) & 1ull;
-        if ((wm >> lane) & 1ull) c.w = A.profW[vft_w_idx(A.d, pt, p, __popcll(wm & below))];
+        const bool hv = (m.vec >> lane) & 1ull;
+        if ((m.w >> lane) & 1ull) c.w = A.profW[vft_wstream_base(A.d, pt) + o.w + __popcll(m.w & below)];
         else c.w = vft_implicit_weight<REAL>(c.code, hv);
-        c.vec = c.w > 0 && c.code == VFT_NOCODE_;   // == hv (vft_store_col)
+        c.vec = c.w > 0 && c.code == VFT_NOCODE_;   // == hv (k_tile_commit)
         if (c.vec) {
-            const int slot = __popcll(mask & below);
+            const REAL *src = A.profF + vft_fstream_base(A.d, pt) + (int64_t) (o.vec + __popcll(m.vec & below)) * NC;
 #pragma unroll
-            for (int k = 0; k < NC; k++) c.f[k] = A.profF[vft_f_idx<REAL>(A.d, pt, p, k, slot)];
+            for (int k = 0; k < NC; k++) c.f[k] = src[k];
         }
     }
 }

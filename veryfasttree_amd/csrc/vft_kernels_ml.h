@@ -317,6 +317,5 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
             }
         }
     }
-    if (stash) vft_store_col_append<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
-    else vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
+    vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
 }

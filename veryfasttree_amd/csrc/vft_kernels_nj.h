@@ -110,7 +110,7 @@ struct SweepOut {
 
 // per-workgroup (min,max) of the criteria produced by this launch; every thread of the workgroup must call it
 template <typename REAL>
-__device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *partMin, REAL *partMax) {
+__device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *partMin, REAL *partMax, int part) {
     __shared__ REAL smin[VFT_WG / 64], smax[VFT_WG / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -129,8 +129,8 @@ __device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *par
             cmin = smin[w] < cmin ? smin[w] : cmin;
             cmax = smax[w] > cmax ? smax[w] : cmax;
         }
-        partMin[blockIdx.x] = cmin;
-        partMax[blockIdx.x] = cmax;
+        partMin[part] = cmin;
+        partMax[part] = cmax;
     }
 }
 
@@ -159,41 +159,43 @@ struct IntChunk {
     REAL f[VFT_SUB][4];
 };
 
-typedef const __attribute__((address_space(4))) unsigned long long *vft_smask_t;
+// the per-column metadata of a tile is wave-uniform: read through the scalar cache as (4 + 2)-dword loads
+typedef unsigned int __attribute__((ext_vector_type(4))) vft_u4_t;
+typedef unsigned int __attribute__((ext_vector_type(2))) vft_u2_t;
+typedef const __attribute__((address_space(4))) vft_u4_t *vft_smask_t;   // ColMask {vec lo, vec hi, w lo, w hi}
+typedef const __attribute__((address_space(4))) vft_u2_t *vft_soff_t;    // ColOff {vec, w}
 
 // codes: the target's 16 codes of this chunk (loaded one chunk ahead so that the defaults below do not wait on it)
+// wT / fT: the tile's explicit-weight / vector streams (vft_layout.h)
 template <typename REAL>
 __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, int sub, const uint4 codes, const REAL *wT,
-                                                   vft_smask_t mV, vft_smask_t mW, const REAL *fT, int dbg = 0) {
-    constexpr int G = 16 / (int) sizeof(REAL);   // values per 16-byte group
-    constexpr int NG = 4 / G;                    // groups per column (1 for float, 2 for double)
+                                                   vft_smask_t mM, vft_soff_t mO, const REAL *fT, int dbg = 0) {
     const int64_t p0 = (int64_t) c * VFT_CHUNK + sub * VFT_SUB;
-    unsigned long long masksV[VFT_SUB], masksW[VFT_SUB];
+    vft_u4_t mk[VFT_SUB];
+    vft_u2_t of[VFT_SUB];
 #pragma unroll
     for (int b = 0; b < VFT_SUB; b++) {   // wave-uniform: scalar loads
-        masksV[b] = mV[p0 + b];
-        masksW[b] = mW[p0 + b];
+        mk[b] = mM[p0 + b];
+        of[b] = mO[p0 + b];
     }
 #pragma unroll
     for (int b = 0; b < VFT_SUB; b++) {
-        const int64_t p = p0 + b;
-        // the masks are wave-uniform SGPR pairs: inverse_ballot turns them into the lane predicate for free
-        const bool hv = __builtin_amdgcn_inverse_ballot_w64(masksV[b]) && !(dbg & 1);
-        const bool hw = __builtin_amdgcn_inverse_ballot_w64(masksW[b]) && !(dbg & 2);
-        const int slotV = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (masksV[b] >> 32),
-                                __builtin_amdgcn_mbcnt_lo((unsigned int) masksV[b], 0u));
-        const int slotW = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (masksW[b] >> 32),
-                                __builtin_amdgcn_mbcnt_lo((unsigned int) masksW[b], 0u));
+        const unsigned long long mv = ((unsigned long long) mk[b].y << 32) | mk[b].x;
+        const unsigned long long mw = ((unsigned long long) mk[b].w << 32) | mk[b].z;
+        // the masks are wave-uniform SGPR pairs: inverse_ballot turns them into the lane predicate for free, and
+        // mbcnt starts counting at the column's offset into the stream
+        const bool hv = __builtin_amdgcn_inverse_ballot_w64(mv) && !(dbg & 1);
+        const bool hw = __builtin_amdgcn_inverse_ballot_w64(mw) && !(dbg & 2);
+        const uint32_t slotV = __builtin_amdgcn_mbcnt_hi(mk[b].y, __builtin_amdgcn_mbcnt_lo(mk[b].x, of[b].x));
+        const uint32_t slotW = __builtin_amdgcn_mbcnt_hi(mk[b].w, __builtin_amdgcn_mbcnt_lo(mk[b].z, of[b].y));
         const uint32_t cd = vft_byte(codes, sub * VFT_SUB + b);
         r.w[b] = (hv || cd != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;   // implicit weight (vft_layout.h)
-        if (hw) r.w[b] = wT[p * VFT_TILE + slotW];
+        if (hw) r.w[b] = wT[slotW];
 #pragma unroll
         for (int k = 0; k < 4; k++) r.f[b][k] = (cd == (uint32_t) k) ? (REAL) 1 : (REAL) 0;
-        if (hv) {   // (unconditional loads from a clamped slot measured slower: +8 %)
+        if (hv) {
 #pragma unroll
-            for (int g = 0; g < NG; g++)
-#pragma unroll
-                for (int e = 0; e < G; e++) r.f[b][g * G + e] = fT[((p * NG + g) * VFT_TILE + slotV) * G + e];
+            for (int k = 0; k < 4; k++) r.f[b][k] = fT[slotV * 4u + k];
         }
     }
 }
@@ -408,22 +410,22 @@ __device__ __forceinline__ void vft_leaf_table_wg(const Arena<REAL> &A, const Qu
     }
 }
 
+// A sweep is two launches: k_sweep_nt over every id that is not covered by a table workgroup (internal targets, all
+// targets of a leaf query, range remainders), then k_sweep_nt_table over s.nLeafWG spans of VFT_LEAF_SPAN leaves
+// (profile query only).  Separate kernels so that each gets its own register budget / occupancy: the first is
+// HBM-bound and wants loads in flight, the second LDS/VALU-bound.  part = index into the per-workgroup min/max.
+template <typename REAL, int MODE>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_nt_table(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
+    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
+    vft_leaf_table_wg<REAL, MODE>(A, Q, s, O, s.lo + (int64_t) blockIdx.x * VFT_LEAF_SPAN, cmin, cmax);
+    if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
+}
+
 template <typename REAL, int MODE_>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
     constexpr int MODE = MODE_;
-    // Workgroup roles: s.nLeafWG "table" workgroups cover VFT_LEAF_SPAN leaves each (profile query only), the others
-    // VFT_WG consecutive ids each.  Heavy first: the workgroups of internal targets (HBM-bound, ~10x the bytes of a
-    // leaf) are dispatched before the table ones (LDS/VALU-bound), which then fill the idle issue slots.
-    const int nHeavyWG = (int) gridDim.x - s.nLeafWG;
-    const int wg = (s.pad & 8) ? (int) blockIdx.x   // (ablation: plain order)
-                   : (int) blockIdx.x < nHeavyWG ? s.nLeafWG + (int) blockIdx.x : (int) blockIdx.x - nHeavyWG;
     REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
-    if (wg < s.nLeafWG) {   // workgroup-uniform
-        vft_leaf_table_wg<REAL, MODE>(A, Q, s, O, s.lo + (int64_t) wg * VFT_LEAF_SPAN, cmin, cmax);
-        if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
-        return;
-    }
-    const int64_t j = s.lo + (int64_t) s.nLeafWG * VFT_LEAF_SPAN + (int64_t) (wg - s.nLeafWG) * VFT_WG + threadIdx.x;
+    const int64_t j = s.lo + (int64_t) s.nLeafWG * VFT_LEAF_SPAN + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
     const int lane = (int) (j & 63);
     const int64_t tile = j >> 6;
     const bool work = j < s.hi && vft_sweep_wants<REAL, MODE>(A, s, O, j);
@@ -467,15 +469,15 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                     }
                 }
             } else {
-                // internal targets: codes dense; explicit weights and vectors packed per (tile, column) by lane rank
+                // internal targets: codes dense; explicit weights and vectors from the tile's packed streams
                 // the 64 lanes of a wave share one tile: readfirstlane makes every base address below wave-uniform
                 // (SGPR base + 32-bit lane offset addressing; masks through the scalar cache)
                 const int64_t pt = (int64_t) __builtin_amdgcn_readfirstlane((int) (tile - A.d.firstProfTile));
-                const REAL *wT = A.profW + vft_w_idx(A.d, pt, 0, 0);
+                const REAL *wT = A.profW + vft_wstream_base(A.d, pt);
                 const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, 0);
-                const vft_smask_t mV = (vft_smask_t) (A.vecMask + vft_mask_idx(A.d, pt, 0));
-                const vft_smask_t mW = (vft_smask_t) (A.wMask + vft_mask_idx(A.d, pt, 0));
-                const REAL *fT = A.profF + vft_f_idx<REAL>(A.d, pt, 0, 0, 0);
+                const vft_smask_t mM = (vft_smask_t) (A.colMask + vft_meta_idx(A.d, pt, 0));
+                const vft_soff_t mO = (vft_soff_t) (A.colOff + vft_meta_idx(A.d, pt, 0));
+                const REAL *fT = A.profF + vft_fstream_base(A.d, pt);
                 // VFT_SUB-column groups: every load of a group is issued before its first result is used; the codes
                 // run one 16-column chunk ahead (issued after the group's loads so that nothing waits on them).
                 IntChunk<REAL> ca;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                     uint4 nxt;
 #pragma unroll
                     for (int sub = 0; sub < VFT_CHUNK / VFT_SUB; sub++) {
-                        vft_int_chunk_load<REAL>(ca, c, sub, cur, wT, mV, mW, fT, s.pad);
+                        vft_int_chunk_load<REAL>(ca, c, sub, cur, wT, mM, mO, fT, s.pad);
                         if (sub == 0) nxt = cT[(int64_t) (c + 1 < nChunk ? c + 1 : c) * VFT_TILE + lane];
                         vft_int_chunk_consume<REAL>(ca, c, sub, Q, top, denom, s.pad);
                     }
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
         }
         vft_sweep_finish<REAL, MODE>(A, s, O, j, dist, weight, s.queryIsLeaf && targetLeaf, cmin, cmax);
     }
-    if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
+    if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, s.nLeafWG + (int) blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ generic pair
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_generic(Arena<REAL> A, SweepAr
             cmin = cmax = crit;
         }
     }
-    vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax);
+    vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
 }
 
 // setDistCriterion over an explicit pair list.  Out-distances must have been refreshed by k_pairs_refresh first.

@@ -7,106 +7,150 @@
 
 #define VFT_WG_PROF 256
 
-// Write one column of one node.  The explicit weights and the vectors of a (tile, column) row are packed by lane
-// order, so a write that adds or removes one moves the entries of the higher lanes by one slot.  NOT safe for two
-// nodes of the same tile concurrently: callers either write one node per launch or use the append path below.
-// Moves the packed entries (NV values each, at slot s -> idx(k, s)) of the lanes above `lane` when `lane` gains or
-// loses its entry; returns the slot of `lane`.
-template <int NV, typename IDX>
-__device__ __forceinline__ int vft_packed_update(unsigned long long *maskp, int lane, bool want, IDX idx) {
-    const unsigned long long old = *maskp;
-    const unsigned long long bit = 1ull << lane;
-    const bool had = (old & bit) != 0;
-    const int slot = __popcll(old & (bit - 1ull));
-    const int nHigher = lane == 63 ? 0 : __popcll(old >> (lane + 1));
-    if (want && !had) {
-        for (int s = slot + nHigher - 1; s >= slot; s--)
-#pragma unroll
-            for (int k = 0; k < NV; k++) *idx(k, s + 1) = *idx(k, s);
-        *maskp = old | bit;
-    } else if (!want && had) {
-        for (int s = slot + 1; s <= slot + nHigher; s++)
-#pragma unroll
-            for (int k = 0; k < NV; k++) *idx(k, s - 1) = *idx(k, s);
-        *maskp = old & ~bit;
-    }
-    return slot;
-}
-
+// ---------------------------------------------------------------------------------------------------------------
+// Writing profiles.  A kernel that produces nodes (average, posterior, upload) writes each column's code straight
+// into profC (dense, per lane) and parks (f[0..NC), w) in a row-major stash [batch][nPos][NC + 1]; k_tile_commit
+// then rebuilds the packed streams of every tile that received nodes (vft_layout.h).
 template <typename REAL, int NC>
-__device__ __forceinline__ void vft_store_col(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
-                                              const REAL *f) {
+__device__ __forceinline__ void vft_stash_col(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
+                                              const REAL *f, REAL *stashRow) {
     const int lane = (int) (node & 63);
     const int64_t pt = (node >> 6) - A.d.firstProfTile;
     uint8_t *cb = (uint8_t *) (A.profC + vft_c_idx(A.d, pt, (int) (p >> 4), lane));
     cb[p & 15] = (uint8_t) code;
-    const bool vec = w > 0 && code == VFT_NOCODE_;
-    const bool explicitW = !(w == vft_implicit_weight<REAL>(code, vec));
-    const int64_t mi = vft_mask_idx(A.d, pt, p);
-    const int slotW = vft_packed_update<1>(&A.wMask[mi], lane, explicitW,
-                                           [&](int, int s) { return &A.profW[vft_w_idx(A.d, pt, p, s)]; });
-    if (explicitW) A.profW[vft_w_idx(A.d, pt, p, slotW)] = w;
-    const int slot = vft_packed_update<NC>(&A.vecMask[mi], lane, vec,
-                                           [&](int k, int s) { return &A.profF[vft_f_idx<REAL>(A.d, pt, p, k, s)]; });
-    if (vec) {
 #pragma unroll
-        for (int k = 0; k < NC; k++) A.profF[vft_f_idx<REAL>(A.d, pt, p, k, slot)] = f[k];
-    }
+    for (int k = 0; k < NC; k++) stashRow[k] = f[k];
+    stashRow[NC] = w;
 }
 
-// Append path, phase A: for nodes that have never been written and sit above every written lane of their tile
-// (the NJ join loop only ever appends: newnode = maxnode++, NJ.tcc:2904).  Any number of such nodes may be written
-// in one launch: codes go to their final place, the mask bits are OR-ed in, the vector and an explicit weight are
-// parked in `stash` ([batch][nPos][NC + 1]) until k_commit_vectors knows the final slots.
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_store_col_append(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code,
-                                                     const REAL *f, REAL *stash) {
-    const int lane = (int) (node & 63);
-    const int64_t pt = (node >> 6) - A.d.firstProfTile;
-    uint8_t *cb = (uint8_t *) (A.profC + vft_c_idx(A.d, pt, (int) (p >> 4), lane));
-    cb[p & 15] = (uint8_t) code;
-    const bool vec = w > 0 && code == VFT_NOCODE_;
-    if (!(w == vft_implicit_weight<REAL>(code, vec))) {
-        atomicOr(&A.wMask[vft_mask_idx(A.d, pt, p)], 1ull << lane);
-        stash[NC] = w;
-    }
-    if (vec) {
-        atomicOr(&A.vecMask[vft_mask_idx(A.d, pt, p)], 1ull << lane);
-#pragma unroll
-        for (int k = 0; k < NC; k++) stash[k] = f[k];
-    }
+// bytes of scratch one workgroup of k_tile_commit needs (new masks, offsets and both streams of one tile)
+static inline size_t vft_commit_scratch_bytes(const VftDims &d, size_t rs) {
+    const size_t cap = (size_t) d.nPosPad * VFT_TILE;
+    const size_t b = (size_t) d.nPosPad * (sizeof(ColMask) + sizeof(ColOff)) + cap * (size_t) (d.nCodes + 1) * rs;
+    return (b + 255) & ~(size_t) 255;
 }
 
-// Append path, phase B: every mask bit of the batch is set, slots are final.
+#define VFT_COMMIT_WG 256
+// One workgroup per tile that received nodes.  order[segFirst[s] .. segFirst[s+1]) are the batch indices (into
+// nodes[] / the stash) of the nodes of segment s, all in one tile.  The tile's new masks, prefix offsets and streams
+// are assembled in scratch from (old streams of the untouched lanes) + (stash of the written lanes) and then copied
+// over the old ones, so nodes may be appended or rewritten in any lane, any number per launch.
 template <typename REAL, int NC>
-__global__ void k_commit_vectors(Arena<REAL> A, const int64_t *nodes, const REAL *stash) {
-    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.d.nPos) return;
-    const int64_t k = blockIdx.y;
-    const int64_t node = nodes[k];
-    const int lane = (int) (node & 63);
-    const int64_t pt = (node >> 6) - A.d.firstProfTile;
-    const int64_t mi = vft_mask_idx(A.d, pt, p);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const REAL *src = stash + (k * A.d.nPos + p) * (NC + 1);
-    const unsigned long long wm = A.wMask[mi];
-    if ((wm >> lane) & 1ull) A.profW[vft_w_idx(A.d, pt, p, __popcll(wm & below))] = src[NC];
-    const unsigned long long mask = A.vecMask[mi];
-    if (!((mask >> lane) & 1ull)) return;
-    const int slot = __popcll(mask & below);
+__global__ __launch_bounds__(VFT_COMMIT_WG) void k_tile_commit(Arena<REAL> A, const int64_t *nodes, const int32_t *order,
+                                                               const int32_t *segFirst, const REAL *stash, char *scratch,
+                                                               size_t scratchStride) {
+    __shared__ int sLaneK[VFT_TILE];
+    __shared__ unsigned long long sWrite;
+    __shared__ uint32_t sCntV[VFT_COMMIT_WG], sCntW[VFT_COMMIT_WG], sTot[2];
+    const int tid = threadIdx.x;
+    const int first = segFirst[blockIdx.x], cnt = segFirst[blockIdx.x + 1] - first;
+    if (tid < VFT_TILE) sLaneK[tid] = -1;
+    __syncthreads();
+    if (tid < cnt) {
+        const int k = order[first + tid];
+        sLaneK[(int) (nodes[k] & 63)] = k;
+    }
+    __syncthreads();
+    if (tid < VFT_TILE) {
+        const unsigned long long wm = __ballot(sLaneK[tid] >= 0);
+        if (tid == 0) sWrite = wm;
+    }
+    __syncthreads();
+    const unsigned long long W = sWrite;
+    const int64_t pt = (nodes[order[first]] >> 6) - A.d.firstProfTile;
+    const int64_t nPos = A.d.nPos, nPosPad = A.d.nPosPad, mi0 = vft_meta_idx(A.d, pt, 0);
+    const int64_t fBase = vft_fstream_base(A.d, pt), wBase = vft_wstream_base(A.d, pt);
+    char *sc = scratch + (size_t) blockIdx.x * scratchStride;
+    ColMask *nm = (ColMask *) sc;
+    ColOff *no = (ColOff *) (nm + nPosPad);
+    REAL *fS = (REAL *) (no + nPosPad);
+    REAL *wS = fS + (size_t) nPosPad * VFT_TILE * NC;
+    // 1. new masks; every thread owns a contiguous run of columns
+    const int64_t PP = (nPosPad + VFT_COMMIT_WG - 1) / VFT_COMMIT_WG;
+    const int64_t pa = (int64_t) tid * PP, pb = pa + PP < nPosPad ? pa + PP : nPosPad;
+    uint32_t cV = 0, cW = 0;
+    for (int64_t p = pa; p < pb; p++) {
+        const ColMask old = A.colMask[mi0 + p];
+        unsigned long long nv = old.vec & ~W, nw = old.w & ~W;
+        if (p < nPos) {
+            unsigned long long m = W;
+            while (m) {
+                const int L = __ffsll((long long) m) - 1;
+                m &= m - 1;
+                const REAL w = stash[((int64_t) sLaneK[L] * nPos + p) * (NC + 1) + NC];
+                const int code = (int) vft_byte(A.profC[vft_c_idx(A.d, pt, (int) (p >> 4), L)], (int) (p & 15));
+                const bool vec = w > 0 && code == VFT_NOCODE_;
+                if (vec) nv |= 1ull << L;
+                if (!(w == vft_implicit_weight<REAL>(code, vec))) nw |= 1ull << L;
+            }
+        }
+        nm[p].vec = nv;
+        nm[p].w = nw;
+        cV += (uint32_t) __popcll(nv);
+        cW += (uint32_t) __popcll(nw);
+    }
+    sCntV[tid] = cV;
+    sCntW[tid] = cW;
+    __syncthreads();
+    if (tid == 0) {   // exclusive scan over the 256 runs
+        uint32_t aV = 0, aW = 0;
+        for (int t = 0; t < VFT_COMMIT_WG; t++) {
+            const uint32_t v = sCntV[t], w = sCntW[t];
+            sCntV[t] = aV;
+            sCntW[t] = aW;
+            aV += v;
+            aW += w;
+        }
+        sTot[0] = aV;
+        sTot[1] = aW;
+    }
+    __syncthreads();
+    // 2. offsets and streams into scratch
+    uint32_t oV = sCntV[tid], oW = sCntW[tid];
+    for (int64_t p = pa; p < pb; p++) {
+        const ColMask m = nm[p], old = A.colMask[mi0 + p];
+        const ColOff oo = A.colOff[mi0 + p];
+        no[p].vec = oV;
+        no[p].w = oW;
+        unsigned long long bits = m.vec;
+        while (bits) {
+            const int L = __ffsll((long long) bits) - 1;
+            bits &= bits - 1;
+            const REAL *src = ((W >> L) & 1ull)
+                                  ? stash + ((int64_t) sLaneK[L] * nPos + p) * (NC + 1)
+                                  : A.profF + fBase + (int64_t) (oo.vec + __popcll(old.vec & ((1ull << L) - 1ull))) * NC;
 #pragma unroll
-    for (int q = 0; q < NC; q++) A.profF[vft_f_idx<REAL>(A.d, pt, p, q, slot)] = src[q];
+            for (int k = 0; k < NC; k++) fS[(int64_t) oV * NC + k] = src[k];
+            oV++;
+        }
+        bits = m.w;
+        while (bits) {
+            const int L = __ffsll((long long) bits) - 1;
+            bits &= bits - 1;
+            wS[oW++] = ((W >> L) & 1ull) ? stash[((int64_t) sLaneK[L] * nPos + p) * (NC + 1) + NC]
+                                         : A.profW[wBase + oo.w + __popcll(old.w & ((1ull << L) - 1ull))];
+        }
+    }
+    __syncthreads();   // every read of the old streams is done, scratch is complete
+    // 3. copy over the tile (coalesced)
+    for (int64_t i = tid; i < nPosPad; i += VFT_COMMIT_WG) {
+        A.colMask[mi0 + i] = nm[i];
+        A.colOff[mi0 + i] = no[i];
+    }
+    const int64_t nF = (int64_t) sTot[0] * NC, nW = sTot[1];
+    for (int64_t i = tid; i < nF; i += VFT_COMMIT_WG) A.profF[fBase + i] = fS[i];
+    for (int64_t i = tid; i < nW; i += VFT_COMMIT_WG) A.profW[wBase + i] = wS[i];
 }
 
 // staging (row-major w[nPos], c[nPos], f[nPos][NC]) -> arena
 template <typename REAL, int NC>
-__global__ void k_profile_scatter(Arena<REAL> A, int64_t node, const REAL *w, const uint8_t *c, const REAL *f) {
+__global__ void k_profile_scatter(Arena<REAL> A, int64_t node, const REAL *w, const uint8_t *c, const REAL *f, REAL *stash) {
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
     REAL fv[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) fv[k] = f[p * NC + k];
-    vft_store_col<REAL, NC>(A, node, p, w[p], (int) c[p], fv);
+    vft_stash_col<REAL, NC>(A, node, p, w[p], (int) c[p], fv, stash + p * (NC + 1));
 }
 
 template <typename REAL, int NC>
@@ -197,8 +241,7 @@ __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
             vft_normalize_freq<REAL, NC>(A, f, tol);
         }
     }
-    if (stash) vft_store_col_append<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
-    else vft_store_col<REAL, NC>(A, outN[k], p, wo, co, f);
+    vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
 }
 
 // setCodeDist for one column of the out-profile (NJ.tcc:873-898)
@@ -310,22 +353,24 @@ __device__ __forceinline__ void vft_outtile_load(const Arena<REAL> &A, int64_t t
     if (tid < 64 && tile * 64 + tid < A.d.nSeqs) r.codes = A.leafT[vft_leaf_idx(A.d, tile, chunk, tid)];
     if (tile * 64 + 63 < A.d.nSeqs) return;   // pure leaf tile
     const int64_t pt = tile - A.d.firstProfTile;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int idx = tid * 4 + u;           // (column, slot) of the 16 x 64 block of packed explicit weights
-        r.w[u] = A.profW[vft_w_idx(A.d, pt, p0 + (idx >> 6), idx & 63)];
-    }
     if (tid < 64 && tile * 64 + tid >= A.d.nSeqs) r.codes = A.profC[vft_c_idx(A.d, pt, chunk, tid)];
+    // 16 threads per column fetch that column's run of the tile's streams: slot s of the run -> thread (s & 15)
     const int col = tid >> 4;
-    r.mask = A.vecMask[vft_mask_idx(A.d, pt, p0 + col)];
-    r.wmask = A.wMask[vft_mask_idx(A.d, pt, p0 + col)];
-    const int cnt = __popcll(r.mask);
+    const int64_t mi = vft_meta_idx(A.d, pt, p0 + col);
+    const ColMask m = A.colMask[mi];
+    const ColOff o = A.colOff[mi];
+    r.mask = m.vec;
+    r.wmask = m.w;
+    const int cnt = __popcll(m.vec), cntW = __popcll(m.w);
+    const REAL *fS = A.profF + vft_fstream_base(A.d, pt) + (int64_t) o.vec * 4;
+    const REAL *wS = A.profW + vft_wstream_base(A.d, pt) + o.w;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int slot = (tid & 15) + 16 * u;
+        if (slot < cntW) r.w[u] = wS[slot];
         if (slot < cnt) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) r.f[u][k] = A.profF[vft_f_idx<REAL>(A.d, pt, p0 + col, k, slot)];
+            for (int k = 0; k < 4; k++) r.f[u][k] = fS[slot * 4 + k];
         }
     }
 }
@@ -356,20 +401,16 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REA
         if (leafTile) {
             if (tid < 64) sCodes[tid] = regs.codes;
         } else {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int idx = tid * 4 + u;
-                sW[idx >> 6][idx & 63] = regs.w[u];
-            }
             if (tid < 64) sCodes[tid] = regs.codes;
             if ((tid & 15) == 0) {
                 sMask[tid >> 4] = regs.mask;
                 sWMask[tid >> 4] = regs.wmask;
             }
-            const int cnt = __popcll(regs.mask);
+            const int cnt = __popcll(regs.mask), cntW = __popcll(regs.wmask);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int slot = (tid & 15) + 16 * u;
+                if (slot < cntW) sW[tid >> 4][slot] = regs.w[u];
                 if (slot < cnt) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) sF[tid >> 4][slot][k] = regs.f[u][k];

@@ -39,30 +39,26 @@ VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
 }
 
 // ---- internal profiles (tile index is relative to firstProfTile)
-//   u64   wMask[ptile][pos]                   bit l set <=> node 64*tile+l stores an EXPLICIT weight at this column.
-//                                             Without the bit the weight is implied: 1 if the column holds a code
-//                                             or a vector, 0 if it is an empty gap (what leaves and almost every
-//                                             column of a low-gap alignment have, NJ.tcc:2078-2112)
-//   REAL  profW[ptile][pos][slot]             the explicit weights of one (tile, column), PACKED by lane rank in
-//                                             wMask exactly like the vectors below
-//   uint4 profC[ptile][chunk][lane]           raw reference codes, 16 columns per uint4, dense
-//   u64   vecMask[ptile][pos]                 bit l set <=> node 64*tile+l holds a frequency vector at this column
-//   REAL  profF[ptile][pos][group][slot][G]   the vectors of one (tile, column), PACKED: the vector of lane l sits
-//                                             in slot popcount(vecMask & ((1<<l)-1)); G = 16/sizeof(REAL) values
-//                                             per 16-byte group, nCodes/G groups.  A wavefront therefore reads
-//                                             only the vectors that exist (the reference's sparse profiles,
-//                                             NJ.h:126-141) and still reads them as one contiguous run.
-VFT_HD int64_t vft_mask_idx(const VftDims &d, int64_t ptile, int64_t pos) { return ptile * d.nPosPad + pos; }
-VFT_HD int64_t vft_w_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t slot) {
-    return (ptile * d.nPosPad + pos) * VFT_TILE + slot;
-}
-template <typename REAL> VFT_HD constexpr int vft_group() { return 16 / (int) sizeof(REAL); }
-template <typename REAL>
-VFT_HD int64_t vft_f_idx(const VftDims &d, int64_t ptile, int64_t pos, int32_t k, int32_t slot) {
-    const int G = vft_group<REAL>();
-    const int nGroups = d.nCodes / G;
-    return (((ptile * d.nPosPad + pos) * nGroups + k / G) * VFT_TILE + slot) * G + (k % G);
-}
+//   uint4 profC[ptile][chunk][lane]      raw reference codes, 16 columns per uint4, dense
+//   ColMask colMask[ptile][pos]          .vec: bit l set <=> node 64*tile+l holds a frequency vector at this column
+//                                        .w:   bit l set <=> node 64*tile+l stores an EXPLICIT weight at this column.
+//                                              Without the bit the weight is implied: 1 if the column holds a code
+//                                              or a vector, 0 if it is an empty gap (what leaves and almost every
+//                                              column of a low-gap alignment have, NJ.tcc:2078-2112)
+//   ColOff  colOff[ptile][pos]           .vec / .w: how many vectors / explicit weights the tile holds in the columns
+//                                              before this one (exclusive prefix sums of the mask popcounts)
+//   REAL  profF[ptile][slot][nCodes]     the tile's vectors as ONE contiguous stream in (column, lane) order: the
+//                                        vector of lane l at column p sits in slot
+//                                              colOff[p].vec + popcount(colMask[p].vec & ((1<<l)-1))
+//   REAL  profW[ptile][slot]             the tile's explicit weights, same scheme with the .w members
+// A wavefront walking the columns of its tile therefore reads exactly the vectors that exist (the reference's
+// sparse profiles, NJ.h:126-141) as one ascending, hole-free address stream.  Streams are rebuilt per tile by
+// k_tile_commit whenever nodes of the tile are written (vft_kernels_profile.h); capacity is the dense worst case.
+struct ColMask { unsigned long long vec, w; };
+struct ColOff { uint32_t vec, w; };
+VFT_HD int64_t vft_meta_idx(const VftDims &d, int64_t ptile, int64_t pos) { return ptile * d.nPosPad + pos; }
+VFT_HD int64_t vft_wstream_base(const VftDims &d, int64_t ptile) { return ptile * d.nPosPad * VFT_TILE; }
+VFT_HD int64_t vft_fstream_base(const VftDims &d, int64_t ptile) { return ptile * d.nPosPad * VFT_TILE * d.nCodes; }
 VFT_HD int64_t vft_c_idx(const VftDims &d, int64_t ptile, int32_t chunk, int32_t lane) {
     return (ptile * d.nChunk + chunk) * VFT_TILE + lane;
 }
