@@ -164,27 +164,42 @@ def main():
     ops_per_step = len(seeds) * state.n_active
     value = ops_per_step * args.steps / elapsed
 
-    # dominant kernel: k_sweep_nt<float, MODE_CRIT>, timed with HIP events on its own stream over one more step
+    # A sweep is two kernels (vft_kernels_nj.h): k_sweep_nt - every target of a leaf seed, the internal-profile
+    # targets of a profile seed - and k_sweep_nt_table - the leaf targets of a profile seed.  Both are timed with HIP
+    # events on their own stream over one more step; k_sweep_nt is the dominant one (roofline), the other is reported
+    # beside it, and "sweep" prices the whole sweep (both kernels) against the same peak.
     ops.timer_start()
     one_step()
     ops.timer_stop_ms()
     kern_ms, launches = ops.sweep_kernel_ms()
-    alg_bytes, phi, moved_bytes = state.algorithmic_bytes_per_sweep()
-    frac_shard = (hi - lo) / float(state.maxnode)
-    alg_launch = alg_bytes * frac_shard
-    achieved = alg_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    tab_ms, _ = ops.sweep_table_kernel_ms()
+    ab = state.algorithmic_bytes_per_sweep(lo, hi)
+    n_leaf_seeds = sum(1 for q in seeds if q < n)
+    n_prof_seeds = len(seeds) - n_leaf_seeds
+    # leaf seed: k_sweep_nt sees all targets; profile seed: the internal ones (+ < 1024 leaves of the range remainder)
+    alg_main = (n_leaf_seeds * (ab["leaf"] + ab["internal"]) + n_prof_seeds * ab["internal"]) / float(len(seeds))
+    moved_main = (n_leaf_seeds * (ab["moved_leaf"] + ab["moved_internal"]) + n_prof_seeds * ab["moved_internal"]) / float(len(seeds))
+    alg_tab = n_prof_seeds * ab["leaf"] / float(len(seeds))          # tab_ms is averaged over all sweeps as well
+    achieved = alg_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # HBM traffic of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
     # process): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, bytes per launch
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (n, L, world) == (1000000, 200, 1):
         traffic = json.load(open(tpath)).get("k_sweep_nt<float,MODE_CRIT>", {}).get("bytes_per_launch")
+    both_ms = kern_ms + tab_ms
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, kernel="k_sweep_nt<float,MODE_CRIT>", launches=int(launches),
-                    avg_launch_ms=kern_ms, algorithmic_bytes_per_launch=int(alg_launch),
-                    moved_bytes_per_launch=int(moved_bytes * frac_shard),
-                    achieved_moved_gbs=moved_bytes * frac_shard / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
-                    phi=phi)
+                    avg_launch_ms=kern_ms, algorithmic_bytes_per_launch=int(alg_main),
+                    moved_bytes_per_launch=int(moved_main),
+                    achieved_moved_gbs=moved_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
+                    phi=ab["phi"],
+                    table_kernel=dict(kernel="k_sweep_nt_table<float,MODE_CRIT>", avg_ms_per_sweep=tab_ms,
+                                      algorithmic_bytes_per_sweep=int(alg_tab), bound="lds",
+                                      achieved_gbs=alg_tab / (tab_ms * 1e-3) / 1e9 if tab_ms > 0 else 0.0),
+                    sweep=dict(avg_ms=both_ms, algorithmic_bytes=int(ab["leaf"] + ab["internal"]),
+                               achieved_gbs=(ab["leaf"] + ab["internal"]) / (both_ms * 1e-3) / 1e9 if both_ms > 0 else 0.0,
+                               frac=(ab["leaf"] + ab["internal"]) / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if both_ms > 0 else 0.0))
 
     line = dict(metric="profile-ops/sec", value=value, unit="profile-ops/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,

@@ -26,7 +26,9 @@ for name, lo, hi in (("leaf targets", 0, n64), ("internal targets", n64, st.maxn
             ops.setBestHit(q, st.n_active, st.n_diff_allow, st.totdiam, 0, want_best=False, want_hits=False)
         tot = ops.timer_stop_ms()
         ms, nl = ops.sweep_kernel_ms()
-        print("%-18s %-14s sweep kernel %.1f us (x%d)   whole call %.1f us" % (name, qn, ms * 1e3, nl, tot * 100))
+        ms2, _ = ops.sweep_table_kernel_ms()
+        print("%-18s %-14s k_sweep_nt %.1f us + k_sweep_nt_table %.1f us (x%d)   whole call %.1f us" % (
+            name, qn, ms * 1e3, ms2 * 1e3, nl, tot * 100))
 ops.set_shard(0, st.maxnode)
 for k in (0, 200, 2000):
     t0 = time.perf_counter()

@@ -930,12 +930,16 @@ extern "C" int vft_out_profile_download(vft_ctx *c, void *w, void *f, void *cd) 
     return VFT_OK;
 }
 
-// k_sweep_nt geometry: table workgroups (VFT_LEAF_SPAN leaves each) when the query is a profile, then VFT_WG ids each
+// geometry of the two launches of an nt sweep over [s.lo, s.hi): with a profile query k_sweep_nt_table takes the
+// leaves (VFT_LEAF_SPAN per workgroup) and k_sweep_nt starts at the tile that holds the first internal node; with a
+// leaf query k_sweep_nt takes everything.  Returns the total number of workgroups (= min/max partials).
 static unsigned sweep_nt_grid(vft_ctx *c, SweepArgs &s, bool tablePath) {
     const int64_t leafEnd = c->d.nSeqs < s.hi ? c->d.nSeqs : s.hi;
-    s.nLeafWG = (tablePath && leafEnd > s.lo) ? (int32_t) ((leafEnd - s.lo) / VFT_LEAF_SPAN) : 0;
-    const int64_t rest = (s.hi > s.lo ? s.hi - s.lo : 0) - (int64_t) s.nLeafWG * VFT_LEAF_SPAN;
-    return (unsigned) s.nLeafWG + cdiv(rest > 0 ? rest : 1, VFT_WG);
+    s.leafEnd = leafEnd;
+    s.nLeafWG = (tablePath && leafEnd > s.lo) ? (int32_t) cdiv(leafEnd - s.lo, VFT_LEAF_SPAN) : 0;
+    s.heavyLo = s.nLeafWG ? (leafEnd / VFT_TILE) * VFT_TILE : s.lo;
+    const int64_t rest = s.hi > s.heavyLo ? s.hi - s.heavyLo : 0;
+    return (unsigned) s.nLeafWG + (rest > 0 ? cdiv(rest, VFT_WG) : 0u);
 }
 
 static void kernel_event(vft_ctx *c);
@@ -947,7 +951,7 @@ static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, int w
     if (nHeavy) launch((k_sweep_nt<REAL, MODE>), dim3(nHeavy), dim3(VFT_WG), 0, c->stream, arena<REAL>(c),
                        qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c));
     if (timed) kernel_event(c);
-    if (s.nLeafWG) launch((k_sweep_nt_table<REAL, MODE>), dim3((unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream,
+    if (s.nLeafWG) launch((k_sweep_nt_table<REAL, (MODE == MODE_OUTDIST ? MODE_OUTDIST : MODE_CRIT)>), dim3((unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream,
                           arena<REAL>(c), qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c));
     if (timed) kernel_event(c);
 }
@@ -1100,11 +1104,13 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         if (c->cfg.precision == 4) {
             launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
                                query, qbuf<float>(c, 0));
-            launch_sweep_nt<float, MODE_CRIT>(c, s, grid, 0, true);
+            if (s.queryIsLeaf) launch_sweep_nt<float, MODE_CRIT_LEAFQ>(c, s, grid, 0, true);
+            else launch_sweep_nt<float, MODE_CRIT>(c, s, grid, 0, true);
         } else {
             launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), query, qbuf<double>(c, 0));
-            launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true);
+            if (s.queryIsLeaf) launch_sweep_nt<double, MODE_CRIT_LEAFQ>(c, s, grid, 0, true);
+            else launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true);
         }
     } else {
         kernel_event(c);

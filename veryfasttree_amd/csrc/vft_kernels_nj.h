@@ -97,8 +97,10 @@ struct SweepArgs {
     double totdiam;
     int32_t queryIsLeaf;
     int32_t force;       // MODE_OUTDIST: refresh every listed node regardless of staleness
-    int32_t nLeafWG;     // workgroups [0, nLeafWG) of a k_sweep_nt launch see leaf targets only
+    int32_t nLeafWG;     // workgroups of k_sweep_nt_table (VFT_LEAF_SPAN leaves each); 0 when the query is a leaf
     int32_t pad;
+    int64_t leafEnd;     // k_sweep_nt_table covers the ids [lo, leafEnd)
+    int64_t heavyLo;     // k_sweep_nt covers [heavyLo, hi) (a multiple of 64) except the ids below leafEnd
 };
 
 template <typename REAL>
@@ -134,7 +136,9 @@ __device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *par
     }
 }
 
-enum { MODE_CRIT = 0, MODE_OUTDIST = 1 };
+// MODE_CRIT_LEAFQ is MODE_CRIT with the knowledge that the query is a leaf (every seed of setAllLeafTopHits): its
+// columns are plain codes with weight 1, so against a profile column only ONE frequency matters (NJ.tcc:922-930)
+enum { MODE_CRIT = 0, MODE_OUTDIST = 1, MODE_CRIT_LEAFQ = 2 };
 
 // %-different distance of two leaves from their encoded bytes (seqDist, NJ.tcc:1601-1612): integer counts.
 __device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int &nUse, int &nSame) {
@@ -153,10 +157,19 @@ __device__ __forceinline__ void vft_seq_counts(const uint4 a, const uint4 b, int
 #ifndef VFT_SUB
 #define VFT_SUB 8   // columns loaded and consumed together (a divisor of VFT_CHUNK)
 #endif
+// code of query column p0 + b (p0 a multiple of 4, b a constant): scalar dword load + scalar bit-field extract
 template <typename REAL>
+__device__ __forceinline__ uint32_t vft_query_code(const QueryBuf<REAL> &Q, int64_t p0, int b) {
+    const uint32_t w = vft_uniform_load<uint32_t>((const uint32_t *) (Q.code + p0 + (b & ~3)));
+    return (w >> ((b & 3) * 8)) & 0xFFu;
+}
+
+// QLEAF (the query is a leaf, code cq per column): piece = 1 - f2[cq] (NJ.tcc:924) and f2 of a plain target code is
+// (cd == cq), so one value per column is enough.
+template <typename REAL, bool QLEAF>
 struct IntChunk {
     REAL w[VFT_SUB];
-    REAL f[VFT_SUB][4];
+    REAL f[VFT_SUB][QLEAF ? 1 : 4];
 };
 
 // the per-column metadata of a tile is wave-uniform: read through the scalar cache as (4 + 2)-dword loads
@@ -167,9 +180,10 @@ typedef const __attribute__((address_space(4))) vft_u2_t *vft_soff_t;    // ColO
 
 // codes: the target's 16 codes of this chunk (loaded one chunk ahead so that the defaults below do not wait on it)
 // wT / fT: the tile's explicit-weight / vector streams (vft_layout.h)
-template <typename REAL>
-__device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, int sub, const uint4 codes, const REAL *wT,
-                                                   vft_smask_t mM, vft_soff_t mO, const REAL *fT, int dbg = 0) {
+template <typename REAL, bool QLEAF>
+__device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL, QLEAF> &r, int c, int sub, const uint4 codes,
+                                                   const REAL *wT, vft_smask_t mM, vft_soff_t mO, const REAL *fT,
+                                                   const QueryBuf<REAL> &Q, int dbg = 0) {
     const int64_t p0 = (int64_t) c * VFT_CHUNK + sub * VFT_SUB;
     vft_u4_t mk[VFT_SUB];
     vft_u2_t of[VFT_SUB];
@@ -191,11 +205,18 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, int
         const uint32_t cd = vft_byte(codes, sub * VFT_SUB + b);
         r.w[b] = (hv || cd != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;   // implicit weight (vft_layout.h)
         if (hw) r.w[b] = wT[slotW];
+        if (QLEAF) {
+            // wave-uniform query code; a gap (127) is masked out by its weight 0, any in-range index will do
+            const uint32_t cq = vft_query_code<REAL>(Q, p0, b);
+            r.f[b][0] = (cd == cq) ? (REAL) 1 : (REAL) 0;
+            if (hv) r.f[b][0] = fT[slotV * 4u + (cq & 3u)];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) r.f[b][k] = (cd == (uint32_t) k) ? (REAL) 1 : (REAL) 0;
-        if (hv) {
+            for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = (cd == (uint32_t) k) ? (REAL) 1 : (REAL) 0;
+            if (hv) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) r.f[b][k] = fT[slotV * 4u + k];
+                for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = fT[slotV * 4u + k];
+            }
         }
     }
 }
@@ -203,9 +224,9 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL> &r, int c, int
 // The reference's column loop (NJ.tcc:1172-1183) over the 16 columns, in order and branch-free.  The reference skips
 // a column when either weight is <= 0; weights are never negative, so the product is +0.0 there and adding
 // (+0.0, +0.0 * piece) to the two double sums is exact.  Padding columns (beyond nPos) have weight 0 on both sides.
-template <typename REAL>
-__device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL> &r, int c, int sub, const QueryBuf<REAL> &Q,
-                                                      double &top, double &denom, int dbg = 0) {
+template <typename REAL, bool QLEAF>
+__device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL, QLEAF> &r, int c, int sub,
+                                                      const QueryBuf<REAL> &Q, double &top, double &denom, int dbg = 0) {
     const int64_t p0 = (int64_t) c * VFT_CHUNK + sub * VFT_SUB;
     if (dbg & 4) {   // ablation: no arithmetic, just consume the loaded values
 #pragma unroll
@@ -215,11 +236,21 @@ __device__ __forceinline__ void vft_int_chunk_consume(const IntChunk<REAL> &r, i
 #pragma unroll
     for (int b = 0; b < VFT_SUB; b++) {
         const int64_t p = p0 + b;
+        if (QLEAF) {
+            // the leaf's weight is 1 (0 at a gap): w1 * w2 is w2 (or 0) exactly (NJ.tcc:1176)
+            const uint32_t cq = vft_query_code<REAL>(Q, p0, b);
+            const double wgt = (double) (cq != VFT_NOCODE_ ? r.w[b] : (REAL) 0);
+            const double piece = 1.0 - (double) r.f[b][0];
+            denom += wgt;
+            top += wgt * piece;
+            continue;
+        }
         const REAL wq = vft_uniform_load<REAL>(Q.w + p);
         const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
         const REAL ww = wq * r.w[b];   // numeric_t product, NJ.tcc:1176
         const double wgt = (double) ww;
-        const REAL q0 = fq.x * r.f[b][0], q1 = fq.y * r.f[b][1], q2 = fq.z * r.f[b][2], q3 = fq.w * r.f[b][3];
+        const REAL q0 = fq.x * r.f[b][0], q1 = fq.y * r.f[b][QLEAF ? 0 : 1], q2 = fq.z * r.f[b][QLEAF ? 0 : 2];
+        const REAL q3 = fq.w * r.f[b][QLEAF ? 0 : 3];
         double piece = 1.0 - (double) q0;
         piece -= (double) q1;
         piece -= (double) q2;
@@ -360,7 +391,8 @@ __device__ __forceinline__ void vft_leaf_table_wg(const Arena<REAL> &A, const Qu
     unsigned long long bal[NB];
 #pragma unroll
     for (int r = 0; r < NB; r++) {
-        bal[r] = __ballot(vft_sweep_wants<REAL, MODE>(A, s, O, base + r * VFT_WG + tid));
+        const int64_t j = base + r * VFT_WG + tid;
+        bal[r] = __ballot(j < s.leafEnd && vft_sweep_wants<REAL, MODE>(A, s, O, j));
         if ((tid & 63) == 0) segCnt[r * NW + wave] = __popcll(bal[r]);
     }
     __syncthreads();
@@ -423,12 +455,16 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_table(Arena<REAL> A, QueryB
 
 template <typename REAL, int MODE_>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
-    constexpr int MODE = MODE_;
+    constexpr bool QLEAF = MODE_ == MODE_CRIT_LEAFQ;
+    constexpr int MODE = QLEAF ? MODE_CRIT : MODE_;
     REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
-    const int64_t j = s.lo + (int64_t) s.nLeafWG * VFT_LEAF_SPAN + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    // highest ids first: the workgroups of internal targets (~10x the bytes of a leaf) start before the leaf ones,
+    // which then fill the idle slots instead of running ahead of them
+    const int wg = (int) gridDim.x - 1 - (int) blockIdx.x;
+    const int64_t j = s.heavyLo + (int64_t) wg * VFT_WG + threadIdx.x;
     const int lane = (int) (j & 63);
     const int64_t tile = j >> 6;
-    const bool work = j < s.hi && vft_sweep_wants<REAL, MODE>(A, s, O, j);
+    const bool work = j < s.hi && !(s.nLeafWG && j < s.leafEnd) && vft_sweep_wants<REAL, MODE>(A, s, O, j);
     if (work) {
         const int64_t nPos = A.d.nPos;
         const bool targetLeaf = j < A.d.nSeqs;
@@ -443,32 +479,9 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
             weight = (REAL) (double) nUse;
             dist = (REAL) (nUse > 0 ? top / (double) nUse : 1.0);
         } else {
+            // leaf targets of a profile query belong to k_sweep_nt_table: everything left here is an internal node
             double top = 0, denom = 0;
-            if (targetLeaf) {
-                for (int c = 0; c < A.d.nChunk; c++) {
-                    const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
-                    const int64_t p0 = (int64_t) c * VFT_CHUNK;
-#pragma unroll
-                    for (int b = 0; b < VFT_CHUNK; b++) {
-                        const int64_t p = p0 + b;
-                        if (p < nPos) {
-                            const REAL wq = vft_uniform_load<REAL>(Q.w + p);
-                            const uint32_t enc = vft_byte(t, b);
-                            if (wq > 0 && (enc & 0x10u)) {
-                                // target weight is 1, its vector one-hot: piece = 1 - fq[code] (NJ.tcc:924,930)
-                                const double wgt = (double) wq;
-                                denom += wgt;
-                                const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(Q.f + p * 4);
-                                const REAL f01 = (enc & 1u) ? fq.x : fq.y;
-                                const REAL f23 = (enc & 4u) ? fq.z : fq.w;
-                                const REAL fqc = (enc & 3u) ? f01 : f23;
-                                const double piece = 1.0 - (double) fqc;
-                                top += wgt * piece;
-                            }
-                        }
-                    }
-                }
-            } else {
+            {
                 // internal targets: codes dense; explicit weights and vectors from the tile's packed streams
                 // the 64 lanes of a wave share one tile: readfirstlane makes every base address below wave-uniform
                 // (SGPR base + 32-bit lane offset addressing; masks through the scalar cache)
@@ -480,16 +493,16 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                 const REAL *fT = A.profF + vft_fstream_base(A.d, pt);
                 // VFT_SUB-column groups: every load of a group is issued before its first result is used; the codes
                 // run one 16-column chunk ahead (issued after the group's loads so that nothing waits on them).
-                IntChunk<REAL> ca;
+                IntChunk<REAL, QLEAF> ca;
                 uint4 cur = cT[lane];
                 const int nChunk = A.d.nChunk;
                 for (int c = 0; c < nChunk; c++) {
                     uint4 nxt;
 #pragma unroll
                     for (int sub = 0; sub < VFT_CHUNK / VFT_SUB; sub++) {
-                        vft_int_chunk_load<REAL>(ca, c, sub, cur, wT, mM, mO, fT, s.pad);
+                        vft_int_chunk_load<REAL, QLEAF>(ca, c, sub, cur, wT, mM, mO, fT, Q, s.pad);
                         if (sub == 0) nxt = cT[(int64_t) (c + 1 < nChunk ? c + 1 : c) * VFT_TILE + lane];
-                        vft_int_chunk_consume<REAL>(ca, c, sub, Q, top, denom, s.pad);
+                        vft_int_chunk_consume<REAL, QLEAF>(ca, c, sub, Q, top, denom, s.pad);
                     }
                     cur = nxt;
                 }
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
         }
         vft_sweep_finish<REAL, MODE>(A, s, O, j, dist, weight, s.queryIsLeaf && targetLeaf, cmin, cmax);
     }
-    if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, s.nLeafWG + (int) blockIdx.x);
+    if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, s.nLeafWG + wg);
 }
 
 // ------------------------------------------------------------------------------------------------ generic pair

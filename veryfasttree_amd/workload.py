@@ -50,27 +50,33 @@ class TopHitsState:
         ops.synchronize()
         self.n_diff_allow = int(self.n_active * 0.01)   # Options::staleOutLimit, NJ.tcc:1091
 
-    def algorithmic_bytes_per_sweep(self):
-        """target side + output only.
+    def algorithmic_bytes_per_sweep(self, lo=0, hi=None):
+        """SURVEY.md §8(d), target side + output only, for the targets in [lo, hi).
         seqDist / profile-vs-leaf: nPos*1 + 2S; profileDist: nPos*(S + 1 + phi*V) + 2S; + (S + 8) for the fused
-        criterion epilogue (outDistance + nOutDistActive) per target."""
+        criterion epilogue (outDistance + nOutDistActive) per target.
+        Returns a dict: leaf / internal = algorithmic bytes of the active leaf / internal targets, moved_leaf /
+        moved_internal = what the kernels really read and write for them, phi = mean vector density."""
         S = self.ops.dt.itemsize
         V = self.ops.n_codes * S
-        act = self.active
+        hi = self.maxnode if hi is None else hi
+        act = self.active[(self.active >= lo) & (self.active < hi)]
         leaves = int((act < self.n_seqs).sum())
         internal = act[act >= self.n_seqs]
-        nvec = self.ops.profile_nvectors(self.n_seqs, self.n_join)[internal - self.n_seqs]
+        nvec_all = self.ops.profile_nvectors(self.n_seqs, self.n_join)
+        nvec = nvec_all[internal - self.n_seqs]
         per_leaf = self.n_pos * 1 + 2 * S + S + 8
-        b = leaves * per_leaf + int(len(internal) * (self.n_pos * (S + 1) + 2 * S + S + 8) + int(nvec.sum()) * V)
+        b_leaf = leaves * per_leaf
+        b_int = int(len(internal) * (self.n_pos * (S + 1) + 2 * S + S + 8) + int(nvec.sum()) * V)
         phi = float(nvec.mean()) / self.n_pos if len(internal) else 0.0
-        # bytes the kernels really move per target (packed vector rows: only existing vectors are read; codes are
-        # padded to 16 columns; one 8-byte vector mask per 64 targets and column):
+        # bytes the kernels really move per target (tile streams: only existing vectors and explicit weights are
+        # read; codes are padded to 16 columns; 24 bytes of masks + offsets per 64 targets and column):
         # epilogue reads parent(4) outDist(S) nOutActive(4) diameter(S), writes dist/weight/criterion (3S)
         E = 4 + S + 4 + S + 3 * S
         pad_pos = ((self.n_pos + 15) // 16) * 16
-        moved = leaves * (pad_pos + E) + len(internal) * (self.n_pos * S + pad_pos + self.n_pos // 8 + E) \
-            + int(nvec.sum()) * V
-        return b, phi, moved
+        m_leaf = leaves * (pad_pos + E)
+        m_int = len(internal) * (pad_pos + (24 * pad_pos) // 64 + E) + int(nvec.sum()) * V
+        return dict(leaf=b_leaf, internal=b_int, moved_leaf=m_leaf, moved_internal=m_int, phi=phi,
+                    n_leaf=leaves, n_internal=int(len(internal)))
 
 
 def shard_range(maxnode, rank, world):
