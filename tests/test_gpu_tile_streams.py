@@ -1,0 +1,89 @@
+"""GPU: the packed tile streams (vft_layout.h) survive writes in any order.
+
+Profiles are uploaded into random lanes of several tiles in random order, some of them several times with a different
+vector / explicit-weight pattern, and every node must read back exactly as last written; averages of the uploaded nodes
+must equal the CPU oracle's.  Exercises k_tile_commit's insert / replace / remove paths, which the NJ join loop (append
+only) never takes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NOCODE = 127
+
+
+def random_profile(rng, n_pos, n_codes, dt, p_vec, p_gap, p_oddw):
+    """A profile in the reference's terms: code or NOCODE per column; a vector where NOCODE and weight > 0."""
+    codes = rng.integers(0, n_codes, n_pos).astype(np.uint8)
+    kind = rng.random(n_pos)
+    w = np.ones(n_pos, dt)
+    f = np.zeros((n_pos, n_codes), dt)
+    vec = kind < p_vec
+    gap = (kind >= p_vec) & (kind < p_vec + p_gap)
+    codes[vec | gap] = NOCODE
+    w[gap] = 0
+    fv = rng.random((n_pos, n_codes)).astype(dt)
+    fv /= fv.sum(1, keepdims=True)
+    f[vec] = fv[vec]
+    odd = rng.random(n_pos) < p_oddw          # explicit weights, on code and vector columns alike
+    w[odd & ~gap] = rng.random(int((odd & ~gap).sum())).astype(dt) * 0.9 + 0.05
+    return w, codes, f
+
+
+@pytest.mark.parametrize("n_codes,dt", [(4, np.float32), (4, np.float64), (20, np.float32)])
+def test_random_order_writes_read_back(n_codes, dt):
+    from veryfasttree_amd import HipProfileOps, synth
+    rng = np.random.default_rng(11 + n_codes)
+    n_seqs, n_pos = 100, 77                     # nSeqs % 64 != 0: the first profile tile is shared with leaves
+    codes = synth.random_descent_codes(n_seqs, n_pos, n_codes, 0.1, 0.05, seed=3)
+    ops = HipProfileOps(n_seqs, n_pos, n_codes, dt)
+    ops.upload_leaves(codes)
+    ids = np.arange(n_seqs, 2 * n_seqs)
+    ops.set_max_node(2 * n_seqs)
+    last = {}
+    order = np.concatenate([rng.permutation(ids), rng.permutation(ids)[:60], rng.permutation(ids)[:30]])
+    for step, v in enumerate(order):
+        # later rounds change the sparsity pattern: vectors and explicit weights appear and disappear
+        p_vec = [0.3, 0.05, 0.6][min(step // len(ids), 2)]
+        prof = random_profile(rng, n_pos, n_codes, dt, p_vec, 0.1, 0.2)
+        ops.profile_upload(int(v), prof)
+        last[int(v)] = prof
+    for v in ids:
+        w, c, f = ops.profile_download(int(v))
+        ew, ec, ef = last[int(v)]
+        vec = (ec == NOCODE) & (ew > 0)
+        assert np.array_equal(c, ec), v
+        assert np.array_equal(w, ew), v
+        assert np.array_equal(f[vec], ef[vec]), v
+        assert ops.profile_nvectors(int(v), 1)[0] == int(vec.sum())
+
+
+def test_batched_average_into_scattered_tiles_matches_oracle():
+    from veryfasttree_amd import HipProfileOps, synth
+    from oracle import Oracle
+    rng = np.random.default_rng(5)
+    n_seqs, n_pos, n_codes, dt = 300, 90, 4, np.float32
+    codes = synth.random_descent_codes(n_seqs, n_pos, n_codes, 0.2, 0.1, seed=9)
+    ops = HipProfileOps(n_seqs, n_pos, n_codes, dt)
+    ops.upload_leaves(codes)
+    ops.set_max_node(2 * n_seqs)
+    orc = Oracle(dt)
+    # one launch writes nodes scattered over five tiles in shuffled order; a second rewrites a third of them
+    out = rng.permutation(np.arange(n_seqs, 2 * n_seqs))[:200]
+    a = rng.integers(0, n_seqs, len(out))
+    b = rng.integers(0, n_seqs, len(out))
+    ops.averageProfile(out, a, b)
+    redo = out[::3]
+    a2 = rng.integers(0, n_seqs, len(redo))
+    ops.averageProfile(redo, a2, out[1::3][:len(redo)])   # children: leaves and already written internal nodes
+    expect = {}
+    leaf = [orc.leaf_profile(codes[i], n_codes) for i in range(n_seqs)]
+    for k, v in enumerate(out):
+        expect[int(v)] = orc.average_profile(leaf[a[k]], leaf[b[k]])
+    snapshot = dict(expect)
+    for k, v in enumerate(redo):
+        expect[int(v)] = orc.average_profile(leaf[a2[k]], snapshot[int(out[1::3][k])])
+    for v, (ew, ec, ef) in expect.items():
+        w, c, f = ops.profile_download(v)
+        vec = (ec == NOCODE) & (ew > 0)
+        assert np.array_equal(c, ec) and np.array_equal(w, ew) and np.array_equal(f[vec], ef[vec]), v
