@@ -811,6 +811,7 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distance_one<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_selfdist<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_sweep_wave<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     });
     return VFT_OK;
 }
@@ -1113,9 +1114,19 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
             else launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true);
         }
     } else {
+        // amino acids / distance matrix.  Measured on C5 (50k x 300, f64): lane-per-target costs ~nPos dependent
+        // latencies whatever the target count (~0.9 ms), wave-per-target ~50 us per 2048 targets: the crossover is
+        // at ~32k targets.  (Neither is tuned: the aa arena wants its own kernel)
         kernel_event(c);
-        VFT_DISPATCH(c, (launch((k_sweep_generic<REAL, NC>), dim3(grid), dim3(VFT_WG), 0, c->stream,
-                                            arena<REAL>(c), s, sweepout<REAL>(c))));
+        if (span <= 32768) {
+            const unsigned wgrid = (unsigned) std::min<int64_t>(cdiv(span > 0 ? span : 1, VFT_PW_WAVES), 256 * 16);
+            c->nPart = (int) wgrid;
+            VFT_DISPATCH(c, (launch((k_sweep_wave<REAL, NC>), dim3(wgrid), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
+                                    arena<REAL>(c), s, sweepout<REAL>(c))));
+        } else {
+            VFT_DISPATCH(c, (launch((k_sweep_generic<REAL, NC>), dim3(grid), dim3(VFT_WG), 0, c->stream,
+                                    arena<REAL>(c), s, sweepout<REAL>(c))));
+        }
         kernel_event(c);
         kernel_event(c);
     }

@@ -626,15 +626,14 @@ __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double top = 0, denom = 0;
-    if (lane == 0) {
-        for (int64_t p = 0; p < nPos; p++) {
-            denom += sW[p];
-            top += sT[p];
-        }
+    // lane 0 adds the `top` terms, lane 1 the `denom` terms: two independent chains, each in column order
+    double acc = 0;
+    if (lane < 2) {
+        const double *src = lane == 0 ? sT : sW;
+        for (int64_t p = 0; p < nPos; p++) acc += src[p];
     }
-    top = __shfl(top, 0, 64);
-    denom = __shfl(denom, 0, 64);
+    const double top = __shfl(acc, 0, 64);
+    const double denom = __shfl(acc, 1, 64);
     if (leaves) {
         weight = (REAL) denom;   // nUse
         dist = (REAL) (denom > 0 ? top / denom : 1.0);
@@ -724,6 +723,45 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_generic(Arena<REAL> A, SweepAr
             O.weight[j] = weight;
             O.crit[j] = crit;
             cmin = cmax = crit;
+        }
+    }
+    vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
+}
+
+// Generic one-vs-all sweep, wave-cooperative: amino-acid alignments are short lists of wide columns (C5: 37 500
+// active targets x 300 columns x 20 codes), which a lane-per-target walk leaves 85 % of the machine idle on and turns
+// into ~nPos dependent memory latencies per lane.  Here a WAVE owns a target (grid-stride over [lo, hi)): its lanes
+// evaluate the columns' addends in parallel and lane 0 adds them in column order (vft_pair_wave, still bit-exact).
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_wave(Arena<REAL> A, SweepArgs s, SweepOut<REAL> O) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int lane = threadIdx.x & 63;
+    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
+    const int64_t stride = (int64_t) gridDim.x * VFT_PW_WAVES;
+    for (int64_t j = s.lo + (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6); j < s.hi; j += stride) {
+        if (A.parent[j] >= 0) {   // wave-uniform
+            if (lane == 0) {
+                O.dist[j] = (REAL) 1e20;
+                O.crit[j] = (REAL) 1e20;
+                O.weight[j] = 0;
+            }
+            continue;
+        }
+        REAL dist, weight;
+        vft_pair_wave<REAL, NC>(A, s.query, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1),
+                                dist, weight);
+        if (lane == 0) {
+            if (!(s.query < A.d.nSeqs && j < A.d.nSeqs)) {
+                const REAL dd = A.diameter[s.query] + A.diameter[j];
+                dist = dist - dd;
+            }
+            const REAL crit = vft_criterion<REAL>(dist, A.outDist[s.query], A.nOutActive[s.query], A.outDist[j],
+                                                  A.nOutActive[j], s.nActive);
+            O.dist[j] = dist;
+            O.weight[j] = weight;
+            O.crit[j] = crit;
+            cmin = crit < cmin ? crit : cmin;
+            cmax = crit > cmax ? crit : cmax;
         }
     }
     vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
