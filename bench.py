@@ -96,7 +96,7 @@ def main():
         else:
             dist.init_process_group(backend)
     from veryfasttree_amd import HipProfileOps, synth
-    from veryfasttree_amd.workload import TopHitsState, merge_hits, shard_range
+    from veryfasttree_amd.workload import TopHitsState, merge_hits, shard_range, sweep_cost_weights
 
     n, L = args.n_seqs, args.n_pos
     n_join = n // 4
@@ -107,7 +107,8 @@ def main():
     ops = HipProfileOps(n, L, 4, np.float32, device=local_rank)
     state = TopHitsState(ops, codes, n_join)
     # shard the target id range over the ranks at tile boundaries
-    lo, hi = shard_range(state.maxnode, rank, world)
+    # (by cost, not by id count: the joined leaves sit at the low ids and an internal profile costs ~5.5 leaves)
+    lo, hi = shard_range(state.maxnode, rank, world, sweep_cost_weights(state.parent, n))
     ops.set_shard(lo, hi)
     seeds = []
     leaf_act = state.active[state.active < n]

@@ -79,12 +79,33 @@ class TopHitsState:
                     n_leaf=leaves, n_internal=int(len(internal)))
 
 
-def shard_range(maxnode, rank, world):
-    """Tile-aligned target id range [lo, hi) of `rank` (what vft_set_shard takes)."""
+def shard_range(maxnode, rank, world, weights=None):
+    """Tile-aligned target id range [lo, hi) of `rank` (what vft_set_shard takes).
+    weights (optional, one cost per node id): boundaries are placed so that every rank gets the same total cost
+    instead of the same number of ids - an internal profile costs ~5.5x a leaf in the sweep and joined nodes nothing,
+    and late in a run the low ids are almost all joined."""
     tiles = (maxnode + 63) // 64
-    lo = (tiles * rank // world) * 64
-    hi = min((tiles * (rank + 1) // world) * 64, maxnode)
-    return lo, hi
+    if weights is None:
+        lo = (tiles * rank // world) * 64
+        hi = min((tiles * (rank + 1) // world) * 64, maxnode)
+        return lo, hi
+    w = np.zeros(tiles * 64, np.float64)
+    w[:maxnode] = np.asarray(weights, np.float64)[:maxnode]
+    cum = np.concatenate([[0.0], np.cumsum(w.reshape(tiles, 64).sum(axis=1))])
+    cuts = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, tiles
+    for r in range(1, world + 1):          # monotone, tile granularity
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts[rank] * 64, min(cuts[rank + 1] * 64, maxnode)
+
+
+def sweep_cost_weights(parent, n_seqs):
+    """Relative cost of each node id as a sweep target (measured): joined 0.02, active leaf 1,
+    active internal profile 5.5."""
+    parent = np.asarray(parent)
+    w = np.where(parent < 0, 1.0, 0.02)
+    w[n_seqs:] = np.where(parent[n_seqs:] < 0, 5.5, 0.02)
+    return w
 
 
 def merge_hits(all_hits, k):
