@@ -130,7 +130,9 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
         }
         if (siteLk) siteLk[k * A.d.nPos + p] = lkAB;
         lk *= lkAB;
-        while (lk < VFT_LK_UNDERFLOW) {
+        // (lk > 0: the reference asserts lkAB > 0 and would spin forever otherwise, NJ.tcc:1257-1262; profiles that
+        //  are not in the model's eigenbasis can produce that, and a kernel must terminate)
+        while (lk < VFT_LK_UNDERFLOW && lk > 0) {
             lk *= VFT_LK_UNDERFLOW_INV;
             loglk -= VFT_LOG_LK_UNDERFLOW;
         }
