@@ -104,6 +104,11 @@ int vft_get_out_distances(vft_ctx *ctx, int64_t first, int64_t count, void *out_
    Contents are valid after vft_synchronize() or after any call that returned data to host memory. */
 int vft_out_distance_mirror(vft_ctx *ctx, const void **out_dist, const int32_t **n_out_active);
 int vft_set_max_node(vft_ctx *ctx, int64_t maxnode);           /* NJ.h: maxnode, the next id to allocate */
+/* The state change of one join in one stream-ordered launch (NJ.tcc:2904-2909, 3003-3007, 254): parent[i] = parent[j]
+   = newnode, diameter[newnode], outDistances[newnode] = 0 with nOutDistActive[newnode] = stale_stamp ("unreasonably
+   high"), maxnode = max(maxnode, newnode + 1).  Equivalent to vft_set_max_node + 2 x vft_set_parents +
+   vft_set_node_scalars + vft_set_out_distances for that node. */
+int vft_join_nodes(vft_ctx *ctx, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t stale_stamp);
 
 /* ---- profiles */
 int vft_profile_upload(vft_ctx *ctx, int64_t node, const void *w, const uint8_t *codes, const void *f);

@@ -72,6 +72,7 @@ struct vft_ctx {
     char *hIO = nullptr, *dIO = nullptr;
     size_t ioCap = 8u << 20, ioHead = 0;
     unsigned long long *hFlag = nullptr, *dFlag = nullptr, signalSeq = 0;
+    unsigned int *doneCtr = nullptr;   // completion counter of k_pairs_fused
     // host-mapped mirrors of outDist / nOutActive, written by the kernels that refresh them
     void *hOutDist = nullptr, *dOutDistM = nullptr;
     int32_t *hNOut = nullptr, *dNOutM = nullptr;
@@ -213,10 +214,15 @@ __global__ void k_signal(unsigned long long *flag, unsigned long long seq) {
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+static int wait_flag(vft_ctx *c, unsigned long long seq);
 static int wait_stream(vft_ctx *c) {
     const unsigned long long seq = ++c->signalSeq;
     launch(k_signal, dim3(1), dim3(1), 0, c->stream, c->dFlag, seq);
     LAUNCHCHK(c);
+    return wait_flag(c, seq);
+}
+// spins on the host-mapped flag until the stream has published `seq`
+static int wait_flag(vft_ctx *c, unsigned long long seq) {
     volatile unsigned long long *f = c->hFlag;
     for (long spins = 0;; spins++) {
         if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= seq) return VFT_OK;
@@ -343,6 +349,8 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipHostMalloc((void **) &c->hFlag, 64, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dFlag, c->hFlag, 0));
     *c->hFlag = 0;
+    CR(dalloc(&c->doneCtr, 1));
+    CR(hipMemset(c->doneCtr, 0, 4));
     CR(hipHostMalloc((void **) &c->hIO, c->ioCap, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dIO, c->hIO, 0));
     CR(hipHostMalloc(&c->hOutDist, (size_t) N * rs, hipHostMallocMapped));
@@ -390,6 +398,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hRes) hipHostFree(c->hRes);
     if (c->hIO) hipHostFree(c->hIO);
     if (c->hFlag) hipHostFree(c->hFlag);
+    if (c->doneCtr) hipFree(c->doneCtr);
     if (c->hOutDist) hipHostFree(c->hOutDist);
     if (c->hNOut) hipHostFree(c->hNOut);
     for (hipEvent_t e : c->kev) hipEventDestroy(e);
@@ -635,6 +644,23 @@ extern "C" int vft_set_max_node(vft_ctx *c, int64_t maxnode) {
     return VFT_OK;
 }
 
+extern "C" int vft_join_nodes(vft_ctx *c, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t staleStamp) {
+    if (!c) return VFT_ERR_INVALID;
+    if (i < 0 || j < 0 || i == j || i >= c->maxnode || j >= c->maxnode || newnode < c->d.nSeqs || newnode >= c->d.maxNodes)
+        return fail(c, VFT_ERR_INVALID, "vft_join_nodes: bad ids (%lld, %lld -> %lld)", (long long) i, (long long) j, (long long) newnode);
+    if (newnode >= c->maxnode) c->maxnode = newnode + 1;
+    c->hParent[(size_t) i] = c->hParent[(size_t) j] = (int32_t) newnode;
+    const int32_t stamp = clamp_i32(staleStamp);
+    // host side of the mirrors: no earlier kernel can touch a node that did not exist
+    if (c->rs == 4) ((float *) c->hOutDist)[newnode] = 0.f;
+    else ((double *) c->hOutDist)[newnode] = 0.0;
+    c->hNOut[newnode] = stamp;
+    if (c->rs == 4) launch((k_join_nodes<float>), dim3(1), dim3(1), 0, c->stream, arena<float>(c), i, j, newnode, (float) diameter, stamp);
+    else launch((k_join_nodes<double>), dim3(1), dim3(1), 0, c->stream, arena<double>(c), i, j, newnode, diameter, stamp);
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
 extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
     if (!c || lo < 0 || hi < lo || hi > c->d.maxNodes || (lo % VFT_TILE) != 0)
         return fail(c, VFT_ERR_INVALID, "vft_set_shard: need 0 <= lo <= hi <= max_nodes and lo %% 64 == 0");
@@ -807,6 +833,7 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
     if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging");
     VFT_DISPATCH(c, {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distance_one<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
@@ -1213,18 +1240,18 @@ extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, cons
     sa.nActive = nActive;
     sa.nDiffAllow = nDiffAllow;
     sa.totdiam = totdiam;
-    VFT_DISPATCH(c, {
-        Arena<REAL> A = arena<REAL>(c);
-        launch((k_pairs_refresh<REAL, NC>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream, A, dI,
-               dJ, n, sa);
-        launch((k_pairs_stamp<REAL>), dim3(cdiv(2 * n, 256)), dim3(256), 0, c->stream, A, dI, dJ, n, sa);
-        launch((k_pairs<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream, A, dI, dJ, n,
-               nActive, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB));
-    });
+    // two launches: lazy refresh of the named nodes, then distances + criteria + the completion flag (lists that fit
+    // the mapped ring)
+    const unsigned long long seq = small ? ++c->signalSeq : 0ull;
+    VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+                            c->stream, arena<REAL>(c), dI, dJ, n, sa)));
+    VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
+                            arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB), c->doneCtr,
+                            small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     LAUNCHCHK(c);
     if (small) {
-        // results were written straight into mapped host memory
-        if (int r = wait_stream(c)) return r;
+        // results were written straight into mapped host memory; the kernel's last wave raises the flag
+        if (int r = wait_flag(c, seq)) return r;
         const char *ho = hBase + 2 * idB;
         if (dist) memcpy(dist, ho, (size_t) n * rs);
         if (weight) memcpy(weight, ho + oB, (size_t) n * rs);

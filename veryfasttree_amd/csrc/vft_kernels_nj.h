@@ -577,6 +577,40 @@ __device__ __forceinline__ void vft_pair_generic(const Arena<REAL> &A, int64_t i
 // up IN COLUMN ORDER (denom += wgt_p; top += term_p), which is exactly the reference's sequence of double
 // additions — columns it skips contribute +0.0, which is exact.  All 64 lanes must call; results are broadcast.
 // sW / sT: this wave's LDS scratch, nPosPad doubles each.
+// one column of the pair (i, j) — or (i, out-profile) — as the reference sees it
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_load(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, int64_t p,
+                                              Col<REAL, NC> &c1, Col<REAL, NC> &c2) {
+    vft_load_col<REAL, NC>(A, i, p, c1);
+    if (jIsOut) {
+        c2.w = A.outW[p];
+        c2.code = VFT_NOCODE_;
+        c2.vec = c2.w > 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) c2.f[k] = A.outF[p * NC + k];
+    } else {
+        vft_load_col<REAL, NC>(A, j, p, c2);
+    }
+}
+// its addends to (denom, top), parked in LDS for the in-order sum
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
+                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT) {
+    double wgt = 0.0, term = 0.0;
+    if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
+        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
+            wgt = 1.0;
+            term = A.dmDist ? (double) A.dmDist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
+        }
+    } else if (c1.w > 0 && c2.w > 0) {
+        const REAL ww = c1.w * c2.w;
+        wgt = (double) ww;
+        term = wgt * vft_piece<REAL, NC>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr);
+    }
+    sW[p] = wgt;
+    sT[p] = term;
+}
+
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
                                               double *sT, REAL &dist, REAL &weight) {
@@ -597,40 +631,34 @@ __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, i
         dist = (REAL) (nUse > 0 ? (double) (nUse - nSame) / (double) nUse : 1.0);
         return;
     }
-    for (int64_t p = lane; p < nPos; p += 64) {
-        Col<REAL, NC> c1, c2;
-        vft_load_col<REAL, NC>(A, i, p, c1);
-        if (jIsOut) {
-            c2.w = A.outW[p];
-            c2.code = VFT_NOCODE_;
-            c2.vec = c2.w > 0;
-#pragma unroll
-            for (int k = 0; k < NC; k++) c2.f[k] = A.outF[p * NC + k];
-        } else {
-            vft_load_col<REAL, NC>(A, j, p, c2);
-        }
-        double wgt = 0.0, term = 0.0;
-        if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
-            if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
-                wgt = 1.0;
-                term = A.dmDist ? (double) A.dmDist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
-            }
-        } else if (c1.w > 0 && c2.w > 0) {
-            const REAL ww = c1.w * c2.w;
-            wgt = (double) ww;
-            term = wgt * vft_piece<REAL, NC>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr);
-        }
-        sW[p] = wgt;
-        sT[p] = term;
+    // two columns per lane and trip: both columns' loads are issued before the first is consumed (the loop is a
+    // chain of dependent memory latencies otherwise: mask -> offsets -> stream)
+    for (int64_t p = lane; p < nPos; p += 128) {
+        const int64_t pb = p + 64;
+        const bool hasB = pb < nPos;
+        Col<REAL, NC> a1, a2, b1, b2;
+        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2);
+        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2);
+        vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
+        if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // lane 0 adds the `top` terms, lane 1 the `denom` terms: two independent chains, each in column order
+    // (the adds are one dependent chain, the LDS reads are not: 8 of them are in flight per group)
     double acc = 0;
     if (lane < 2) {
         const double *src = lane == 0 ? sT : sW;
-        for (int64_t p = 0; p < nPos; p++) acc += src[p];
+        int64_t p = 0;
+        for (; p + 8 <= nPos; p += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[p + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; p < nPos; p++) acc += src[p];
     }
     const double top = __shfl(acc, 0, 64);
     const double denom = __shfl(acc, 1, 64);
@@ -689,6 +717,17 @@ __global__ __launch_bounds__(64) void k_out_distance_one(Arena<REAL> A, int64_t 
     A.nOutActive[v] = (int32_t) s.nActive;
     A.mOutDist[v] = od;
     A.mNOut[v] = (int32_t) s.nActive;
+}
+
+// The state change of one join (NJ.tcc:2904-2909, 3003-3007, 254): children get their parent, the new node its
+// diameter and an "unreasonably stale" out-distance.  One 1-thread kernel instead of five range stores.
+template <typename REAL>
+__global__ void k_join_nodes(Arena<REAL> A, int64_t i, int64_t j, int64_t newnode, REAL diameter, int32_t staleStamp) {
+    A.parent[i] = (int32_t) newnode;
+    A.parent[j] = (int32_t) newnode;
+    A.diameter[newnode] = diameter;
+    A.outDist[newnode] = 0;
+    A.nOutActive[newnode] = staleStamp;
 }
 
 // small stream-ordered state writes (no host synchronisation): dst[first + t] = src[t], with optional mirrors
@@ -787,6 +826,38 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs(Arena<REAL> A, const int64_t *
     crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], nActive);
 }
 
+// setDistCriterion over an explicit pair list whose out-distances k_pairs_refresh has brought up to date: distance and
+// criterion per pair, results straight into (mapped) memory; the last wave to finish publishes `seq` to the host's
+// flag, which replaces a trailing signal kernel (the small lists of the join loop are latency-bound: every launch
+// saved is ~6 us of a ~50 us call).
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
+                                                        SweepArgs s, REAL *dist, REAL *weight, REAL *crit,
+                                                        unsigned int *doneCtr, unsigned long long *flag,
+                                                        unsigned long long seq) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int64_t i = pi[t], j = pj[t];
+    REAL d, w;
+    vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((threadIdx.x & 63) != 0) return;
+    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+        const REAL dd = A.diameter[i] + A.diameter[j];
+        d = d - dd;
+    }
+    dist[t] = d;
+    weight[t] = w;
+    crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], s.nActive);
+    if (flag) {
+        __threadfence_system();
+        if (atomicAdd(doneCtr, 1u) == (unsigned int) (n - 1)) {
+            *doneCtr = 0;   // launches on this stream are ordered: the next list starts from zero
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Lazy out-distance refresh of every node named in a pair list (setCriterion, NJ.tcc:1092-1098).  A node may be
 // named many times: the refresh is idempotent and all writers store the same value.
 template <typename REAL, int NC>
@@ -796,25 +867,18 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh(Arena<REAL> A, const i
     const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= 2 * n) return;
     const int64_t v = t < n ? pi[t] : pj[t - n];
-    if (!((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
+    // value first, staleness stamp after a release fence; a wave that already sees the stamp skips the work, one that
+    // still sees "stale" recomputes the identical value (it depends only on the node and the out-profile)
+    const int32_t nOut = __hip_atomic_load(&A.nOutActive[v], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (!((int64_t) nOut - s.nActive > s.nDiffAllow)) return;
     REAL d, w;
     vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
     if ((threadIdx.x & 63) != 0) return;
     const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
-    // two-phase: values first, staleness stamps in k_pairs_stamp, so that concurrent readers of nOutActive in
-    // this launch keep seeing "stale" and recompute the identical value instead of racing on a half-update
     A.outDist[v] = od;
     A.mOutDist[v] = od;
-}
-template <typename REAL>
-__global__ void k_pairs_stamp(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n, SweepArgs s) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * n) return;
-    const int64_t v = t < n ? pi[t] : pj[t - n];
-    if ((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow) {
-        A.nOutActive[v] = (int32_t) s.nActive;
-        A.mNOut[v] = (int32_t) s.nActive;
-    }
+    A.mNOut[v] = (int32_t) s.nActive;
+    __hip_atomic_store(&A.nOutActive[v], (int32_t) s.nActive, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------ top-k select

@@ -97,10 +97,11 @@ namespace veryfasttree {
             for (int64_t nActive = nSeqs; nActive > 3; nActive--) {
                 if (maxJoins >= 0 && (int64_t) joins.size() >= maxJoins) break;
                 Besthit join = topHitNJSearch(nActive);
-                setOutDistance(join.i, nActive);
-                setOutDistance(join.j, nActive);
+                /* setOutDistance(i), setOutDistance(j), setDistCriterion(join) (NJ.tcc:2897-2901) as ONE pair list of
+                   length 1 with nDiffAllow = 0: the lazy refresh then fires for every stamp != nActive, i.e. it is the
+                   unconditional setOutDistance, and the pair kernel follows in the same call */
                 std::vector<Besthit *> one(1, &join);
-                setDistCriterionBatch(nActive, one);
+                setDistCriterionBatch(nActive, one, 0);
                 const int64_t newnode = maxnode++;
                 const int64_t i = join.i, j = join.j;
                 parent[i] = parent[j] = newnode;
@@ -115,11 +116,8 @@ namespace veryfasttree {
                 const double bw = 0.5;
                 const REAL bi = branchlength[i] + diameter[i], bj = branchlength[j] + diameter[j];
                 diameter[newnode] = (REAL) (bw * bi + (1 - bw) * bj);
-                chkT("vft_set_max_node", [&]() { return vft_set_max_node(ctx, maxnode); });
+                chkT("vft_join_nodes", [&]() { return vft_join_nodes(ctx, i, j, newnode, (double) diameter[newnode], 10 * nSeqs); });   /* NJ.tcc:254: "unreasonably high" */
                 chkT("vft_average_profiles", [&]() { return vft_average_profiles(ctx, 1, &newnode, &i, &j, nullptr); });
-                chkT("vft_set_parents", [&]() { return vft_set_parents(ctx, i, 1, &newnode); });
-                chkT("vft_set_parents", [&]() { return vft_set_parents(ctx, j, 1, &newnode); });
-                chkT("vft_set_node_scalars", [&]() { return vft_set_node_scalars(ctx, newnode, 1, &diameter[newnode], nullptr, nullptr); });
                 const int64_t changed = nActiveReset - (nActive - 1);
                 if (changed >= opt.nResetOutProfile && changed >= opt.fResetOutProfile * nActiveReset) {
                     std::vector<int64_t> active;
@@ -137,9 +135,6 @@ namespace veryfasttree {
                     const REAL dd = diameter[newnode] - diameter[i] - diameter[j];
                     totdiam += dd;
                 }
-                REAL zero = 0;
-                int64_t staleStamp = 10 * nSeqs;
-                chkT("vft_set_out_distances", [&]() { return vft_set_out_distances(ctx, newnode, 1, &zero, &staleStamp); });   /* NJ.tcc:254: "unreasonably high" */
                 topHitJoin(newnode, nActive - 1);
             }
             return joins;
@@ -172,6 +167,7 @@ namespace veryfasttree {
         std::vector<std::vector<Hit> > hits;
         std::vector<int64_t> age, topvisible, hitSource;
         std::vector<Hit> visible;
+        std::vector<int64_t> inTopScratch;   /* resetTopVisible: all -1 between calls */
 
         void chk(int rc) {
             if (rc != VFT_OK) throw std::invalid_argument(std::string("NJDriver: ") + vft_last_error(ctx));
@@ -184,6 +180,23 @@ namespace veryfasttree {
         };
         std::map<std::string, Acc> acc;
         bool profiling = std::getenv("VFT_NJ_PROFILE") != nullptr;
+
+        /* inclusive wall-clock of a host section (VFT_NJ_PROFILE=1); device calls made inside are also listed on
+           their own lines */
+        struct Section {
+            NJDriver *d;
+            const char *name;
+            std::chrono::steady_clock::time_point t0;
+            Section(NJDriver *d_, const char *n) : d(d_->profiling ? d_ : nullptr), name(n) {
+                if (d) t0 = std::chrono::steady_clock::now();
+            }
+            ~Section() {
+                if (!d) return;
+                Acc &a = d->acc[name];
+                a.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                a.calls++;
+            }
+        };
 
         template<typename F>
         void chkT(const char *name, F f) {
@@ -291,8 +304,9 @@ namespace veryfasttree {
             hit.criterion = (REAL) (hit.dist - (outI + outJ) / (double) (nActive - 2));
         }
 
-        void setDistCriterionBatch(int64_t nActive, std::vector<Besthit *> &list) { /* NJ.tcc:1115-1124 */
+        void setDistCriterionBatch(int64_t nActive, std::vector<Besthit *> &list, int64_t allow = -1) { /* NJ.tcc:1115-1124 */
             if (list.empty()) return;
+            if (allow < 0) allow = nDiffAllow(nActive);
             const int64_t n = (int64_t) list.size();
             std::vector<int64_t> pi(n), pj(n);
             std::vector<REAL> d(n), w(n), c(n);
@@ -300,7 +314,7 @@ namespace veryfasttree {
                 pi[t] = list[t]->i;
                 pj[t] = list[t]->j;
             }
-            chkT("vft_pair_distances", [&]() { return vft_pair_distances(ctx, n, pi.data(), pj.data(), nActive, nDiffAllow(nActive), totdiam, d.data(), w.data(),
+            chkT("vft_pair_distances", [&]() { return vft_pair_distances(ctx, n, pi.data(), pj.data(), nActive, allow, totdiam, d.data(), w.data(),
                                    c.data()); });
             pending = false;   /* the call returned data: the stream has drained */
             for (int64_t t = 0; t < n; t++) {
@@ -554,6 +568,7 @@ namespace veryfasttree {
         }
 
         void resetTopVisible(int64_t nActive) { /* NJ.tcc:4728-4784 */
+            Section sec(this, "[host] resetTopVisible (incl. device)");
             /* the reference sorts a value-initialised array of nActive records of which only nVisible are filled:
                the zero records take part in the sort and only the first nVisible sorted positions are considered */
             std::vector<Besthit> vis((size_t) nActive);
@@ -582,17 +597,37 @@ namespace veryfasttree {
             }
 #pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nVisible; t++) criterionFresh(nActive, vis[t]);
-            sortByCriterion(vis);
-            std::vector<int64_t> inTop((size_t) maxnodes, -1);
+            /* Only a prefix of the sorted array is ever looked at (until the top-visible list is full), and the order
+               (criterion ascending, ties by descending position) is total: select + sort that prefix, doubling it
+               in the rare case it does not suffice, instead of sorting nActive records every m/2 joins. */
+            std::vector<int64_t> order((size_t) nActive);
+            for (int64_t t = 0; t < nActive; t++) order[(size_t) t] = t;
+            auto before = [&](int64_t a, int64_t b) {
+                if (vis[a].criterion != vis[b].criterion) return vis[a].criterion < vis[b].criterion;
+                return a > b;
+            };
+            if (inTopScratch.size() != (size_t) maxnodes) inTopScratch.assign((size_t) maxnodes, -1);
+            std::vector<int64_t> &inTop = inTopScratch;
+            std::vector<int64_t> touched;
             size_t save = 0;
-            for (int64_t t = 0; t < nVisible && save < topvisible.size(); t++) {
-                const Besthit &v = vis[t];
+            int64_t sorted = 0, t = 0;
+            while (t < nVisible && save < topvisible.size()) {
+                if (t == sorted) {
+                    const int64_t upto = std::min<int64_t>(nActive, std::max<int64_t>(2 * sorted, 4 * (int64_t) topvisible.size() + 64));
+                    if (upto < nActive) std::nth_element(order.begin() + sorted, order.begin() + upto, order.end(), before);
+                    std::sort(order.begin() + sorted, order.begin() + upto, before);
+                    sorted = upto;
+                }
+                const Besthit &v = vis[(size_t) order[(size_t) t++]];
                 if (inTop[v.i] != v.j) {
                     topvisible[save++] = v.i;
                     inTop[v.i] = v.j;
                     inTop[v.j] = v.i;
+                    touched.push_back(v.i);
+                    touched.push_back(v.j);
                 }
             }
+            for (int64_t v: touched) inTop[(size_t) v] = -1;
             while (save < topvisible.size()) topvisible[save++] = -1;
             topvisibleAge = 0;
         }
@@ -614,6 +649,7 @@ namespace veryfasttree {
         }
 
         void setAllLeafTopHits() { /* NJ.tcc:3746-4119, threads == 1 branch, first-level lists */
+            Section sec(this, "[host] setAllLeafTopHits (incl. device)");
             const int64_t n = nSeqs;
             double close = opt.tophitsClose;
             if (close < 0) {
@@ -648,6 +684,72 @@ namespace veryfasttree {
                 nearweight = nearweight / (2.0 * m);
                 nearweight *= (1.0 - 2.0 * neardist / 3.0);
                 const double nearcover = 1.0 - neardist / 2.0;
+                if (q == 0) {
+                    /* Without second-level lists the close neighbours of a seed do not influence each other
+                       (NJ.tcc:3957-3992): their transferBestHits are ONE pair list on the device, and the per-neighbour
+                       sort + save runs in parallel on the host.  Same pairs, same values, same lists. */
+                    std::vector<int64_t> cns;
+                    for (int64_t iClose = 0; iClose < m; iClose++) {
+                        const Besthit &ch = best[iClose];
+                        const int64_t cn = ch.j;
+                        if (cn < 0 || visited[cn]) continue;
+                        const bool isClose = ch.dist <= neardist &&
+                                             (ch.weight >= nearweight || ch.weight >= (nPos - nGaps[cn]) * nearcover);
+                        const bool identical = ch.dist < 1e-6 && std::fabs(ch.weight - (nPos - nGaps[seed])) < 1e-5 &&
+                                               std::fabs(ch.weight - (nPos - nGaps[cn])) < 1e-5;
+                        if (isClose || identical) {
+                            cns.push_back(cn);
+                            visited[cn] = 1;
+                        }
+                    }
+                    const int64_t K = 2 * m, nNb = (int64_t) cns.size();
+                    std::vector<int64_t> pi, pj, first((size_t) nNb + 1, 0);
+                    pi.reserve((size_t) (nNb * K));
+                    pj.reserve((size_t) (nNb * K));
+                    for (int64_t a = 0; a < nNb; a++) {
+                        for (int64_t t = 0; t < K; t++) {
+                            const int64_t j = best[t].j;
+                            if (j < 0 || j == cns[a]) continue;
+                            pi.push_back(cns[a]);
+                            pj.push_back(j);
+                        }
+                        first[(size_t) a + 1] = (int64_t) pi.size();
+                    }
+                    const int64_t nPairs = (int64_t) pi.size();
+                    std::vector<REAL> pd((size_t) nPairs), pw((size_t) nPairs), pc((size_t) nPairs);
+                    const int64_t maxCall = 1 << 22;
+                    for (int64_t p0 = 0; p0 < nPairs; p0 += maxCall) {
+                        const int64_t cnt = std::min<int64_t>(maxCall, nPairs - p0);
+                        chkT("vft_pair_distances", [&]() {
+                            return vft_pair_distances(ctx, cnt, pi.data() + p0, pj.data() + p0, n, nDiffAllow(n), totdiam,
+                                                      pd.data() + p0, pw.data() + p0, pc.data() + p0);
+                        });
+                    }
+                    pending = false;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(opt.hostThreads)
+                    for (int64_t a = 0; a < nNb; a++) {
+                        const int64_t cn = cns[(size_t) a];
+                        std::vector<Besthit> nb((size_t) K);
+                        int64_t u = first[(size_t) a];
+                        for (int64_t t = 0; t < K; t++) {
+                            Besthit &h = nb[(size_t) t];
+                            h.i = cn;
+                            h.j = best[t].j;
+                            if (h.j < 0 || h.j == cn) {   /* transferBestHits, NJ.tcc:4593-4597 */
+                                h.weight = 0;
+                                h.dist = (REAL) -1e20;
+                                h.criterion = (REAL) 1e20;
+                            } else {
+                                h.dist = pd[(size_t) u];
+                                h.weight = pw[(size_t) u];
+                                h.criterion = pc[(size_t) u];
+                                u++;
+                            }
+                        }
+                        sortSaveBestHits(cn, nb, K, m);
+                    }
+                    continue;
+                }
                 for (int64_t iClose = 0; iClose < m; iClose++) {
                     const Besthit &ch = best[iClose];
                     const int64_t cn = ch.j;
@@ -750,6 +852,7 @@ namespace veryfasttree {
         }
 
         Besthit topHitNJSearch(int64_t nActive) { /* NJ.tcc:4137-4262 */
+            Section sec(this, "[host] topHitNJSearch (incl. device)");
             int64_t bestNode;
             for (;;) {
                 int64_t nCand = 0;
@@ -816,6 +919,7 @@ namespace veryfasttree {
         }
 
         void topHitJoin(int64_t newnode, int64_t nActive) { /* NJ.tcc:4306-4533, first-level lists */
+            Section sec(this, "[host] topHitJoin (incl. device)");
             const int64_t c0 = child0[newnode], c1 = child1[newnode];
             std::vector<Besthit> combined = hitsToBestHits(hits[c0], c0);
             std::vector<Besthit> fromC1 = hitsToBestHits(hits[c1], c1);
