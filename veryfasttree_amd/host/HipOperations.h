@@ -154,6 +154,11 @@ namespace veryfasttree {
 
         void setMaxNode(int64_t maxnode) { chk(vft_set_max_node(ctx, maxnode)); }
 
+        /* the state change of one join (NJ.tcc:2904-2909, 3003-3007, 254) in one launch */
+        void joinNodes(int64_t i, int64_t j, int64_t newnode, numeric_t diameter, int64_t staleStamp) {
+            chk(vft_join_nodes(ctx, i, j, newnode, (double) diameter, staleStamp));
+        }
+
         /* averageProfile + the new node's self distance (NJ.tcc:3008, 3039-3042) */
         void averageProfiles(int64_t n, const int64_t *out, const int64_t *a, const int64_t *b, const double *bionjWeight) {
             chk(vft_average_profiles(ctx, n, out, a, b, bionjWeight));
