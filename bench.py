@@ -88,7 +88,9 @@ def main():
     backend = os.environ.get("VFT_BENCH_BACKEND", "nccl")
     if os.environ.get("VFT_BENCH_SAME_DEVICE"):
         local_rank = 0
-    if world > 1:
+    # test hook: take the multi-rank code path (RCCL all-gather + device merge) even with one rank
+    use_dist = world > 1 or bool(os.environ.get("VFT_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -119,7 +121,7 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     hit_dt = ops.hit_dtype
-    if world > 1:
+    if use_dist:
         d_mine = torch.zeros(k * hit_dt.itemsize, dtype=torch.uint8, device="cuda")
         d_all = torch.zeros(world * k * hit_dt.itemsize, dtype=torch.uint8, device="cuda" if backend == "nccl" else "cpu")
         ops.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -127,7 +129,7 @@ def main():
     def one_step():
         out = []
         for q in seeds:
-            if world == 1:
+            if not use_dist:
                 hits, _ = ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False)
             else:
                 ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False,
@@ -145,7 +147,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -157,7 +159,7 @@ def main():
         last = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -220,7 +222,7 @@ def main():
     assert np.all(np.diff(hv["criterion"]) >= 0) and len(np.unique(hv["j"])) == len(hv)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
