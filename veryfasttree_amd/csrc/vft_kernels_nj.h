@@ -211,8 +211,12 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL, QLEAF> &r, int
             r.f[b][0] = (cd == cq) ? (REAL) 1 : (REAL) 0;
             if (hv) r.f[b][0] = fT[slotV * 4u + (cq & 3u)];
         } else {
+            // one-hot of a plain code without compares: byte k of `oh` is (code == k), read by v_cvt_f32_ubyteK.
+            // (a gap, 127, aliases code 3 here: harmless, its lane has weight 0 and any finite piece gives +0.0)
+            uint32_t oh;   // (asm: keeps the compiler from turning the byte reads back into compare + select)
+            asm("v_lshlrev_b32 %0, %1, 1" : "=v"(oh) : "v"((cd & 3u) * 8u));
 #pragma unroll
-            for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = (cd == (uint32_t) k) ? (REAL) 1 : (REAL) 0;
+            for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = (REAL) ((oh >> (8 * k)) & 0xFFu);
             if (hv) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = fT[slotV * 4u + k];
