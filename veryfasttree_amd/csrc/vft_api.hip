@@ -266,6 +266,9 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     if ((cfg->precision != 4 && cfg->precision != 8) || (cfg->n_codes != 4 && cfg->n_codes != 20) || cfg->n_seqs < 1 ||
         cfg->n_pos < 1 || cfg->max_nodes < cfg->n_seqs || cfg->max_nodes >= (1ll << 31))
         return bail(fail(c, VFT_ERR_INVALID, "vft_create: bad configuration"));
+    // a tile's vector stream is addressed with 32-bit byte offsets (k_sweep_nt): 64 nodes x nPos x nCodes reals < 4 GiB
+    if ((double) (cfg->n_pos + VFT_CHUNK) * VFT_TILE * cfg->n_codes * cfg->precision >= 4294967296.0)
+        return bail(fail(c, VFT_ERR_INVALID, "vft_create: alignment too long (%lld columns)", (long long) cfg->n_pos));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return bail(fail(c, VFT_ERR_HIP, "vft_create: no HIP device (this backend has no CPU fallback)"));

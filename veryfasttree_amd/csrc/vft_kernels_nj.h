@@ -204,12 +204,15 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL, QLEAF> &r, int
         const uint32_t slotW = __builtin_amdgcn_mbcnt_hi(mk[b].w, __builtin_amdgcn_mbcnt_lo(mk[b].z, of[b].y));
         const uint32_t cd = vft_byte(codes, sub * VFT_SUB + b);
         r.w[b] = (hv || cd != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;   // implicit weight (vft_layout.h)
-        if (hw) r.w[b] = wT[slotW];
+        // 32-bit byte offsets into the tile's streams (a tile's stream is < 4 GB: vft_create checks nPos): the loads
+        // take the SGPR base + VGPR offset form instead of 64-bit per-lane address arithmetic
+        const char *wB = (const char *) wT, *fB = (const char *) fT;
+        if (hw) r.w[b] = *(const REAL *) (wB + slotW * (uint32_t) sizeof(REAL));
         if (QLEAF) {
             // wave-uniform query code; a gap (127) is masked out by its weight 0, any in-range index will do
             const uint32_t cq = vft_query_code<REAL>(Q, p0, b);
             r.f[b][0] = (cd == cq) ? (REAL) 1 : (REAL) 0;
-            if (hv) r.f[b][0] = fT[slotV * 4u + (cq & 3u)];
+            if (hv) r.f[b][0] = *(const REAL *) (fB + (slotV * 4u + (cq & 3u)) * (uint32_t) sizeof(REAL));
         } else {
             // one-hot of a plain code without compares: byte k of `oh` is (code == k), read by v_cvt_f32_ubyteK.
             // (a gap, 127, aliases code 3 here: harmless, its lane has weight 0 and any finite piece gives +0.0)
@@ -219,7 +222,8 @@ __device__ __forceinline__ void vft_int_chunk_load(IntChunk<REAL, QLEAF> &r, int
             for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = (REAL) ((oh >> (8 * k)) & 0xFFu);
             if (hv) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) r.f[b][QLEAF ? 0 : k] = fT[slotV * 4u + k];
+                for (int k = 0; k < 4; k++)
+                    r.f[b][QLEAF ? 0 : k] = *(const REAL *) (fB + (slotV * 4u + (uint32_t) k) * (uint32_t) sizeof(REAL));
             }
         }
     }
