@@ -87,3 +87,43 @@ def test_batched_average_into_scattered_tiles_matches_oracle():
         w, c, f = ops.profile_download(v)
         vec = (ec == NOCODE) & (ew > 0)
         assert np.array_equal(c, ec) and np.array_equal(w, ew) and np.array_equal(f[vec], ef[vec]), v
+
+
+def test_join_nodes_equals_the_separate_state_calls():
+    """vft_join_nodes = set_max_node + 2 x set_parents + set_node_scalars(diameter) + set_out_distances for one join:
+    the same sweep results (sentinels for the joined children, criterion inputs of the new node) either way."""
+    from veryfasttree_amd import HipProfileOps, synth
+    n_seqs, n_pos = 200, 64
+    codes = synth.random_descent_codes(n_seqs, n_pos, 4, 0.1, 0.05, seed=21)
+    results = []
+    for fused in (False, True):
+        ops = HipProfileOps(n_seqs, n_pos, 4, np.float32)
+        ops.upload_leaves(codes)
+        ops.set_node_scalars(0, np.zeros(n_seqs, np.float32), (codes != NOCODE).sum(1).astype(np.float32),
+                             np.zeros(n_seqs, np.float32))
+        ops.set_max_node(n_seqs)
+        ops.outProfile(np.arange(n_seqs))
+        ops.set_out_distances(0, np.zeros(n_seqs, np.float32), np.full(n_seqs, 10 * n_seqs, np.int64))
+        ops.setOutDistance(None, n_seqs, 0.0)
+        new, i, j, diam = n_seqs, 17, 101, np.float32(0.03125)
+        if fused:
+            ops.join_nodes(i, j, new, float(diam), 10 * n_seqs)
+        else:
+            ops.set_max_node(new + 1)
+            ops.set_parents(i, [new])
+            ops.set_parents(j, [new])
+            ops.set_node_scalars(new, diameter=np.array([diam], np.float32))
+            ops.set_out_distances(new, np.zeros(1, np.float32), np.array([10 * n_seqs], np.int64))
+        ops.averageProfile([new], [i], [j])
+        ops.updateOutProfile(i, j, new, n_seqs)
+        hits, best = ops.setBestHit(new, n_seqs - 1, 1, float(diam), 40)
+        d, w, c = ops.sweep_results(0, new + 1)
+        od, na = ops.get_out_distances(0, new + 1)
+        results.append((hits.copy(), best, d, w, c, od, na, ops.get_node_scalars(0, new + 1)))
+    a, b = results
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
+    for x, y in zip(a[2:7], b[2:7]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[7], b[7]):
+        assert np.array_equal(x, y)
+    assert a[2][17] == np.float32(1e20) and a[2][101] == np.float32(1e20)      # joined children: sentinel

@@ -207,6 +207,10 @@ class HipProfileOps:
         na = _i64(n_out_active)
         self._chk(self.lib.vft_set_out_distances(self.ctx, I64(first), I64(len(od)), _ptr(od), _ptr(na)))
 
+    def join_nodes(self, i, j, newnode, diameter, stale_stamp):
+        """The state change of one join in one launch (NJ.tcc:2904-2909, 3003-3007, 254)."""
+        self._chk(self.lib.vft_join_nodes(self.ctx, I64(i), I64(j), I64(newnode), C.c_double(diameter), I64(stale_stamp)))
+
     def get_out_distances(self, first, count):
         od = np.zeros(count, self.dt)
         na = np.zeros(count, np.int64)
