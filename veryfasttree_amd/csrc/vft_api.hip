@@ -826,6 +826,18 @@ __global__ __launch_bounds__(VFT_WG) void k_selfdist(Arena<REAL> A, const int64_
     A.selfweight[nodes[t]] = w;
 }
 
+// one node, whole workgroup (the join loop's case)
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_selfdist_one(Arena<REAL> A, const int64_t *nodes) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t v = nodes[0];
+    REAL d, w;
+    vft_pair_block<REAL, NC>(A, v, v, false, pwLds, pwLds + A.d.nPosPad, d, w);
+    if (threadIdx.x != 0) return;
+    A.selfdist[v] = d;
+    A.selfweight[v] = w;
+}
+
 // dynamic LDS of the wave-per-item kernels
 static size_t pw_lds_bytes(const vft_ctx *c) { return (size_t) VFT_PW_WAVES * 2 * c->d.nPosPad * sizeof(double); }
 
@@ -836,11 +848,14 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
     if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging");
     VFT_DISPATCH(c, {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distance_one<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_selfdist<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_selfdist_one<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_sweep_wave<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     });
     return VFT_OK;
@@ -888,8 +903,13 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         LAUNCHCHK(c);
         if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
-    VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
-                           arena<REAL>(c), (const int64_t *) s, n));
+    if (n == 1) {
+        VFT_DISPATCH(c, launch((k_selfdist_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+                               arena<REAL>(c), (const int64_t *) s));
+    } else {
+        VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
+                               arena<REAL>(c), (const int64_t *) s, n));
+    }
     LAUNCHCHK(c);
     // id lists in the mapped ring are protected by its wrap-around synchronisation; only the scratch path must wait
     if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1037,7 +1057,7 @@ extern "C" int vft_out_distances(vft_ctx *c, int64_t n, const int64_t *ids, int6
             s.nActive = nActive;
             s.totdiam = totdiam;
             s.force = 1;
-            VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(64), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+            VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
                                    arena<REAL>(c), ids[0], s));
             LAUNCHCHK(c);
             return VFT_OK;
@@ -1112,7 +1132,7 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         s.nDiffAllow = nDiffAllow;
         s.totdiam = totdiam;
         s.force = 0;
-        VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(64), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+        VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
                                arena<REAL>(c), query, s));
         LAUNCHCHK(c);
     }
@@ -1246,11 +1266,26 @@ extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, cons
     // two launches: lazy refresh of the named nodes, then distances + criteria + the completion flag (lists that fit
     // the mapped ring)
     const unsigned long long seq = small ? ++c->signalSeq : 0ull;
-    VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
-                            c->stream, arena<REAL>(c), dI, dJ, n, sa)));
-    VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
-                            arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB), c->doneCtr,
-                            small ? c->dFlag : (unsigned long long *) nullptr, seq)));
+    if (n <= 2048) {   // short list: a workgroup per pair (all of them resident at once)
+        const size_t lds = pw_lds_bytes(c) / VFT_PW_WAVES;
+        // The host-mapped stamp mirror can only lag towards "staler" (kernels in flight make nodes fresher, host-side
+        // sets update it at once): if it shows no stale node there is none, and the refresh launch is skipped.
+        bool anyStale = false;
+        for (int64_t t = 0; t < n && !anyStale; t++)
+            anyStale = (int64_t) c->hNOut[pi[t]] - nActive > nDiffAllow || (int64_t) c->hNOut[pj[t]] - nActive > nDiffAllow;
+        if (anyStale)
+            VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, true>), dim3((unsigned) (2 * n)), dim3(VFT_WG), lds, c->stream,
+                                    arena<REAL>(c), dI, dJ, n, sa)));
+        VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, true>), dim3((unsigned) n), dim3(VFT_WG), lds, c->stream,
+                                arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB),
+                                c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
+    } else {
+        VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG),
+                                pw_lds_bytes(c), c->stream, arena<REAL>(c), dI, dJ, n, sa)));
+        VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+                                c->stream, arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB),
+                                (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
+    }
     LAUNCHCHK(c);
     if (small) {
         // results were written straight into mapped host memory; the kernel's last wave raises the flag

@@ -679,6 +679,51 @@ __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, i
     }
 }
 
+// The same for ONE pair handled by a whole workgroup (single out-distances and self distances of the join loop: the
+// wave version spends ~nPos/64 dependent memory round trips on them, this one nPos/blockDim.x).  Every thread of the
+// workgroup must call; sW / sT: nPosPad doubles each; the results are broadcast.
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
+                                               double *sT, REAL &dist, REAL &weight) {
+    __shared__ double res[2];
+    const int64_t nPos = A.d.nPos;
+    const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
+    // two columns per thread and trip, loads of both issued before the first is consumed (as in vft_pair_wave)
+    for (int64_t p = threadIdx.x; p < nPos; p += 2 * (int64_t) blockDim.x) {
+        const int64_t pb = p + blockDim.x;
+        const bool hasB = pb < nPos;
+        Col<REAL, NC> a1, a2, b1, b2;
+        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2);
+        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2);
+        vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
+        if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {   // thread 0: `top`, thread 1: `denom`, each in column order
+        const double *src = threadIdx.x == 0 ? sT : sW;
+        double acc = 0;
+        int64_t p = 0;
+        for (; p + 8 <= nPos; p += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[p + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; p < nPos; p++) acc += src[p];
+        res[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const double top = res[0], denom = res[1];
+    if (leaves) {
+        weight = (REAL) denom;   // nUse
+        dist = (REAL) (denom > 0 ? top / denom : 1.0);
+    } else {
+        weight = (REAL) (denom > 0 ? denom : 0.01);
+        dist = (REAL) (denom > 0 ? top / denom : 1.0);
+    }
+}
+
 #define VFT_PW_WAVES 4   // pairs per 256-thread workgroup in the wave-per-item kernels
 // dynamic LDS of those kernels: VFT_PW_WAVES * 2 * nPosPad doubles
 __device__ __forceinline__ double *vft_pw_lds(double *base, int64_t nPosPad, int which) {
@@ -711,14 +756,15 @@ __global__ __launch_bounds__(VFT_WG) void k_out_distances(Arena<REAL> A, const i
     A.mNOut[v] = (int32_t) s.nActive;
 }
 
-// the same for ONE node passed by value (the query of a sweep): no id list to ship
+// the same for ONE node passed by value (the query of a sweep, the nodes of a join): no id list to ship, and the
+// whole workgroup walks the columns
 template <typename REAL, int NC>
-__global__ __launch_bounds__(64) void k_out_distance_one(Arena<REAL> A, int64_t v, SweepArgs s) {
+__global__ __launch_bounds__(VFT_WG) void k_out_distance_one(Arena<REAL> A, int64_t v, SweepArgs s) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
-    if (!s.force && !((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
+    if (!s.force && !((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;   // workgroup-uniform
     if ((int64_t) A.nOutActive[v] == s.nActive) return;
     REAL d, w;
-    vft_pair_wave<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
+    vft_pair_block<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
     if (threadIdx.x != 0) return;
     const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
     A.outDist[v] = od;
@@ -838,18 +884,20 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs(Arena<REAL> A, const int64_t *
 // criterion per pair, results straight into (mapped) memory; the last wave to finish publishes `seq` to the host's
 // flag, which replaces a trailing signal kernel (the small lists of the join loop are latency-bound: every launch
 // saved is ~6 us of a ~50 us call).
-template <typename REAL, int NC>
+// WGPAIR: one workgroup per pair instead of one wave (short lists: halves the dependent round trips per pair again)
+template <typename REAL, int NC, bool WGPAIR>
 __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
                                                         SweepArgs s, REAL *dist, REAL *weight, REAL *crit,
                                                         unsigned int *doneCtr, unsigned long long *flag,
                                                         unsigned long long seq) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
-    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
+    const int64_t t = WGPAIR ? (int64_t) blockIdx.x : (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;
     const int64_t i = pi[t], j = pj[t];
     REAL d, w;
-    vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
-    if ((threadIdx.x & 63) != 0) return;
+    if (WGPAIR) vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, w);
+    else vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((WGPAIR ? threadIdx.x : (threadIdx.x & 63)) != 0) return;
     if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
         const REAL dd = A.diameter[i] + A.diameter[j];
         d = d - dd;
@@ -868,20 +916,21 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
 
 // Lazy out-distance refresh of every node named in a pair list (setCriterion, NJ.tcc:1092-1098).  A node may be
 // named many times: the refresh is idempotent and all writers store the same value.
-template <typename REAL, int NC>
+template <typename REAL, int NC, bool WGPAIR>
 __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
                                                           SweepArgs s) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
-    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
+    const int64_t t = WGPAIR ? (int64_t) blockIdx.x : (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= 2 * n) return;
     const int64_t v = t < n ? pi[t] : pj[t - n];
     // value first, staleness stamp after a release fence; a wave that already sees the stamp skips the work, one that
     // still sees "stale" recomputes the identical value (it depends only on the node and the out-profile)
     const int32_t nOut = __hip_atomic_load(&A.nOutActive[v], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if (!((int64_t) nOut - s.nActive > s.nDiffAllow)) return;
+    if (!((int64_t) nOut - s.nActive > s.nDiffAllow)) return;   // uniform over the wave / workgroup
     REAL d, w;
-    vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
-    if ((threadIdx.x & 63) != 0) return;
+    if (WGPAIR) vft_pair_block<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
+    else vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((WGPAIR ? threadIdx.x : (threadIdx.x & 63)) != 0) return;
     const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
     A.outDist[v] = od;
     A.mOutDist[v] = od;
