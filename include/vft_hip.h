@@ -157,6 +157,10 @@ int vft_sweep_results(vft_ctx *ctx, int64_t first, int64_t count, void *dist, vo
    (NJ.tcc:4580-4613, 4786-4833, 4267-4298).  Outputs are host arrays of the context precision. */
 int vft_pair_distances(vft_ctx *ctx, int64_t n, const int64_t *i, const int64_t *j, int64_t n_active,
                        int64_t n_diff_allow, double totdiam, void *dist, void *weight, void *criterion);
+/* profileDist / seqDist itself (NJ.tcc:1167-1190, 1601-1624) for n pairs: the raw distance and weight, without the
+   diameter correction and criterion of setDistCriterion.  The three distances that root the tree at the end of fastNJ
+   (NJ.tcc:3110-3120) and every ME-phase distance are this call. */
+int vft_profile_distances(vft_ctx *ctx, int64_t n, const int64_t *i, const int64_t *j, void *dist, void *weight);
 
 /* ---- likelihood (ML phase)
  * pairLogLk (NJ.tcc:1192-1447) for n independent pairs; site_lk (n x n_pos doubles, host) may be NULL, when

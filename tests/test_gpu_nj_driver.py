@@ -51,3 +51,20 @@ def test_cpp_host_driver_join_order_on_gpu(name, fastest, second):
     assert len(bad) == 0, "first differing join %d: got %s want %s" % (bad[0], joins[bad[0]], want[bad[0]])
     assert np.allclose(crit, d["join_criterion"], atol=1e-6)
     ops.close()
+
+
+@pytest.mark.parametrize("name,fastest,second,dt", [("bb_nt_c1", True, True, np.float32), ("bb_nt_200", False, False, np.float32),
+                                                    ("bb_nt_600_fastest_no2nd", True, False, np.float32),
+                                                    ("bb_nt_600_fastest", True, True, np.float32),
+                                                    ("bb_nt_1500", False, False, np.float32),
+                                                    ("bb_nt_300_double", False, False, np.float64)])
+def test_nj_tree_string_equals_the_reference(name, fastest, second, dt):
+    """End to end: duplicates included, fastNJ to the root, branch lengths, printNJ -- the exact "NJ\t<tree>" line of the
+    reference's log (NJ.tcc:2706-2794, 3098-3120)."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load(name)
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    tree = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt), codes_all, names, fastest=fastest, second_level=second, dtype=dt)
+    assert tree == bytes(d["nj_newick"]).decode()

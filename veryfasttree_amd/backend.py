@@ -25,7 +25,7 @@ EXPORTS = [
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_set_shard", "vft_merge_hits", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
-    "vft_join_nodes", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
+    "vft_join_nodes", "vft_profile_distances", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
 ]
 
 
@@ -42,7 +42,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run"]
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick"]
 
 
 class _NJOptions(C.Structure):
@@ -88,6 +88,49 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
         raise VftError(err.value.decode() or "vft_nj_run failed")
     return joins[:nj.value], crit[:nj.value]
 
+
+
+def uniquify(codes):
+    """First-occurrence uniquify of alignment rows (Uniquify, Alignment.cpp:494-526).
+    Returns (unique_first[u] = row of unique sequence u, aln_next[k] = next row with the same sequence or -1)."""
+    codes = np.ascontiguousarray(codes, np.uint8)
+    first_of, unique_first, last = {}, [], {}
+    aln_next = np.full(len(codes), -1, np.int64)
+    for k, row in enumerate(codes):
+        key = row.tobytes()
+        if key not in first_of:
+            first_of[key] = k
+            unique_first.append(k)
+        else:
+            aln_next[last[key]] = k
+        last[key] = k
+    return np.array(unique_first, np.int64), aln_next
+
+
+def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32):
+    """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
+    make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences."""
+    lib = load_host_library()
+    codes_all = np.ascontiguousarray(codes_all, np.uint8)
+    unique_first, aln_next = uniquify(codes_all)
+    codes = np.ascontiguousarray(codes_all[unique_first])
+    n, L = codes.shape
+    ops = make_ops(n, L)
+    if second_level is None:
+        second_level = fastest
+    opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
+                     200, 3, 1.0, 0.6)
+    blob = b"".join(nm.encode() + b"\0" for nm in names)
+    cap = 64 * len(names) + len(blob) + 1024
+    out = C.create_string_buffer(cap)
+    olen = I64(0)
+    err = C.create_string_buffer(512)
+    rc = lib.vft_nj_newick(ops.ctx, _ptr(codes), I64(n), I64(L), I32(np.dtype(dtype).itemsize), C.byref(opt),
+                           _ptr(unique_first), _ptr(aln_next), I64(len(codes_all)), blob, out, I64(cap),
+                           C.byref(olen), err, I32(512))
+    if rc != 0:
+        raise VftError(err.value.decode() or "vft_nj_newick failed")
+    return out.value.decode()
 
 
 def load_library():
@@ -313,6 +356,13 @@ class HipProfileOps:
         self._chk(self.lib.vft_pair_distances(self.ctx, I64(n), _ptr(i), _ptr(j), I64(n_active), I64(n_diff_allow),
                                               C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
         return d, w, c
+
+    def profileDist(self, i, j):
+        """NJ.tcc:1167 / 1601 over a pair list: raw (dist, weight), no diameter correction, no criterion."""
+        i, j = _i64(i), _i64(j)
+        d, w = np.zeros(len(i), self.dt), np.zeros(len(i), self.dt)
+        self._chk(self.lib.vft_profile_distances(self.ctx, I64(len(i)), _ptr(i), _ptr(j), _ptr(d), _ptr(w)))
+        return d, w
 
     # ---- likelihood
     def pairLogLk(self, a, b, length, site_lk=False):

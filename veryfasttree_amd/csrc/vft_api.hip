@@ -1237,8 +1237,17 @@ extern "C" int vft_sweep_results(vft_ctx *c, int64_t first, int64_t count, void 
     return VFT_OK;
 }
 
+static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive, int64_t nDiffAllow,
+                          double totdiam, void *dist, void *weight, void *crit, bool raw);
 extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive,
                                   int64_t nDiffAllow, double totdiam, void *dist, void *weight, void *crit) {
+    return pair_distances(c, n, pi, pj, nActive, nDiffAllow, totdiam, dist, weight, crit, false);
+}
+extern "C" int vft_profile_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, void *dist, void *weight) {
+    return pair_distances(c, n, pi, pj, 3, 0, 0.0, dist, weight, nullptr, true);
+}
+static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive, int64_t nDiffAllow,
+                          double totdiam, void *dist, void *weight, void *crit, bool raw) {
     if (!c || n < 0 || !pi || !pj) return VFT_ERR_INVALID;
     if (n == 0) return VFT_OK;
     if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_pair_distances before vft_upload_leaves");
@@ -1263,6 +1272,7 @@ extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, cons
     sa.nActive = nActive;
     sa.nDiffAllow = nDiffAllow;
     sa.totdiam = totdiam;
+    sa.force = raw ? 1 : 0;
     // two launches: lazy refresh of the named nodes, then distances + criteria + the completion flag (lists that fit
     // the mapped ring)
     const unsigned long long seq = small ? ++c->signalSeq : 0ull;
@@ -1271,7 +1281,7 @@ extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, cons
         // The host-mapped stamp mirror can only lag towards "staler" (kernels in flight make nodes fresher, host-side
         // sets update it at once): if it shows no stale node there is none, and the refresh launch is skipped.
         bool anyStale = false;
-        for (int64_t t = 0; t < n && !anyStale; t++)
+        for (int64_t t = 0; t < n && !anyStale && !raw; t++)
             anyStale = (int64_t) c->hNOut[pi[t]] - nActive > nDiffAllow || (int64_t) c->hNOut[pj[t]] - nActive > nDiffAllow;
         if (anyStale)
             VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, true>), dim3((unsigned) (2 * n)), dim3(VFT_WG), lds, c->stream,
@@ -1280,8 +1290,9 @@ extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, cons
                                 arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB),
                                 c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     } else {
-        VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG),
-                                pw_lds_bytes(c), c->stream, arena<REAL>(c), dI, dJ, n, sa)));
+        if (!raw)
+            VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG),
+                                    pw_lds_bytes(c), c->stream, arena<REAL>(c), dI, dJ, n, sa)));
         VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB),
                                 (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));

@@ -898,13 +898,18 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     if (WGPAIR) vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, w);
     else vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
     if ((WGPAIR ? threadIdx.x : (threadIdx.x & 63)) != 0) return;
-    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
-        const REAL dd = A.diameter[i] + A.diameter[j];
-        d = d - dd;
+    if (s.force) {   // raw profileDist / seqDist (vft_profile_distances): no diameter correction, no criterion
+        dist[t] = d;
+        weight[t] = w;
+    } else {
+        if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+            const REAL dd = A.diameter[i] + A.diameter[j];
+            d = d - dd;
+        }
+        dist[t] = d;
+        weight[t] = w;
+        crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], s.nActive);
     }
-    dist[t] = d;
-    weight[t] = w;
-    crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], s.nActive);
     if (flag) {
         __threadfence_system();
         if (atomicAdd(doneCtr, 1u) == (unsigned int) (n - 1)) {

@@ -142,7 +142,87 @@ namespace veryfasttree {
 
         std::vector<Join> joins;
 
+        /* The end of fastNJ (NJ.tcc:3098-3120): a root for the 3 remaining nodes; their branch lengths from the three
+           raw profile distances.  Call after run() has gone all the way (nActive == 3). */
+        void finishRoot() {
+            int64_t top[3], nTop = 0;
+            for (int64_t v = 0; v < maxnode; v++)
+                if (parent[v] < 0) {
+                    if (nTop == 3) throw std::invalid_argument("NJDriver::finishRoot: more than 3 active nodes");
+                    top[nTop++] = v;
+                }
+            if (nTop != 3) throw std::invalid_argument("NJDriver::finishRoot: fewer than 3 active nodes");
+            root = maxnode++;
+            for (int k = 0; k < 3; k++) parent[top[k]] = root;
+            rootChild[0] = top[0];
+            rootChild[1] = top[1];
+            rootChild[2] = top[2];
+            const int64_t pi[3] = {top[0], top[0], top[1]}, pj[3] = {top[1], top[2], top[2]};
+            REAL d[3], w[3];
+            chkT("vft_profile_distances", [&]() { return vft_profile_distances(ctx, 3, pi, pj, d, w); });
+            const double d01 = d[0] - diameter[top[0]] - diameter[top[1]];
+            const double d02 = d[1] - diameter[top[0]] - diameter[top[2]];
+            const double d12 = d[2] - diameter[top[1]] - diameter[top[2]];
+            branchlength[top[0]] = (REAL) ((d01 + d02 - d12) / 2);
+            branchlength[top[1]] = (REAL) ((d01 + d12 - d02) / 2);
+            branchlength[top[2]] = (REAL) ((d02 + d12 - d01) / 2);
+        }
+
+        /* printNJ (NJ.tcc:2706-2794, no supports, no quoting): depth-first, children in stored order, leaf names with
+           their duplicates expanded as (a:0.0,b:0.0), lengths as %.5f (float) / %.9f (double).
+           names[k] = name of alignment row k; uniqueFirst[u] = row of unique sequence u; alnNext[k] = next row with the
+           same sequence or -1 (Alignment.cpp:494-526). */
+        std::string newick(const std::vector<std::string> &names, const std::vector<int64_t> &uniqueFirst,
+                           const std::vector<int64_t> &alnNext) const {
+            if (root < 0) throw std::invalid_argument("NJDriver::newick before finishRoot");
+            const char *fmt = sizeof(REAL) == 4 ? "%.5f" : "%.9f";
+            std::string out;
+            char buf[64];
+            auto firstChildOf = [&](int64_t p) { return p == root ? rootChild[0] : child0[p]; };
+            std::vector<std::pair<int64_t, int> > stack;
+            stack.push_back(std::make_pair(root, 0));
+            while (!stack.empty()) {
+                const int64_t node = stack.back().first;
+                const int end = stack.back().second;
+                stack.pop_back();
+                if (node < nSeqs) {
+                    if (firstChildOf(parent[node]) != node) out += ",";
+                    const int64_t first = uniqueFirst[(size_t) node];
+                    if (alnNext[(size_t) first] == -1) out += names[(size_t) first];
+                    else {
+                        out += "(" + names[(size_t) first] + ":0.0";
+                        for (int64_t k = alnNext[(size_t) first]; k >= 0; k = alnNext[(size_t) k]) out += "," + names[(size_t) k] + ":0.0";
+                        out += ")";
+                    }
+                    snprintf(buf, sizeof buf, fmt, (double) branchlength[(size_t) node]);
+                    out += ":";
+                    out += buf;
+                } else if (end) {
+                    if (node == root) out += ")";
+                    else {
+                        snprintf(buf, sizeof buf, fmt, (double) branchlength[(size_t) node]);
+                        out += "):";
+                        out += buf;
+                    }
+                } else {
+                    if (node != root && firstChildOf(parent[node]) != node) out += ",";
+                    out += "(";
+                    stack.push_back(std::make_pair(node, 1));
+                    if (node == root) {
+                        for (int k = 2; k >= 0; k--) stack.push_back(std::make_pair(rootChild[k], 0));
+                    } else {
+                        stack.push_back(std::make_pair(child1[(size_t) node], 0));
+                        stack.push_back(std::make_pair(child0[(size_t) node], 0));
+                    }
+                }
+            }
+            out += ";";
+            return out;
+        }
+
     private:
+        int64_t root = -1, rootChild[3] = {-1, -1, -1};
+
         struct Besthit {
             int64_t i = -1, j = -1;
             REAL weight = 0, dist = (REAL) 1e20, criterion = (REAL) 1e20;

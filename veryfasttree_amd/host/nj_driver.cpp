@@ -2,14 +2,15 @@
 #include "../../include/vft_host.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 #include <type_traits>
 
 #include "NJDriver.h"
 
-template<typename REAL>
-static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
-                         int64_t maxJoins, int64_t *joins, double *criterion) {
+static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
     if (o) {
         opt.fastest = o->fastest != 0;
@@ -25,6 +26,46 @@ static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int6
         opt.tophits2Mult = o->tophits2_mult;
         opt.tophits2Refresh = o->tophits2_refresh;
     }
+    return opt;
+}
+
+template<typename REAL>
+static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
+                           const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll, const char *names) {
+    veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
+    drv.run(-1);
+    drv.finishRoot();
+    drv.report();
+    std::vector<std::string> nm;
+    const char *p = names;
+    for (int64_t k = 0; k < nAll; k++) {
+        nm.push_back(std::string(p));
+        p += nm.back().size() + 1;
+    }
+    return drv.newick(nm, std::vector<int64_t>(uniqueFirst, uniqueFirst + nSeqs), std::vector<int64_t>(alnNext, alnNext + nAll));
+}
+
+extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
+                             const vft_nj_options *opt, const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll,
+                             const char *names, char *out, int64_t outCap, int64_t *outLen, char *err, int32_t errLen) {
+    if (!ctx || !codes || !uniqueFirst || !alnNext || !names || !outLen) return VFT_ERR_INVALID;
+    try {
+        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, uniqueFirst, alnNext, nAll, names)
+                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, uniqueFirst, alnNext, nAll, names);
+        *outLen = (int64_t) t.size();
+        if (out && outCap > (int64_t) t.size()) memcpy(out, t.c_str(), t.size() + 1);
+        else if (out) return VFT_ERR_INVALID;   /* outLen tells how much is needed */
+        return VFT_OK;
+    } catch (const std::exception &e) {
+        if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
+        return VFT_ERR_STATE;
+    }
+}
+
+template<typename REAL>
+static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
+                         int64_t maxJoins, int64_t *joins, double *criterion) {
+    const veryfasttree::NJOptions opt = toOptions(o);
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, opt);
     const auto &js = drv.run(maxJoins);
     drv.report();
