@@ -35,11 +35,15 @@ int vft_nj_run(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos
 
 /* The whole NJ phase and its tree: fastNJ to the end (root over the last 3 nodes, NJ.tcc:3098-3120) printed the way
    the reference prints it (printNJ, NJ.tcc:2706-2794; no supports): what the reference logs as "NJ\t<tree>".
+   me_lengths != 0: also updateBranchLengths (NJ.tcc:6514-6595, log-corrected minimum-evolution lengths) before
+   printing - the "ME_Lengths" tree, which is the final output of `-noml -nome -nosupport`; the context must then have
+   been created with max_nodes >= 3 * n_seqs (the up-profiles live on the device).
    codes: the n_seqs UNIQUE sequences in first-occurrence order; unique_first[u] = alignment row of unique sequence u;
    aln_next[k] = next alignment row with the same sequence or -1 (Uniquify, Alignment.cpp:494-526); names: n_all
    NUL-terminated names back to back.  out may be NULL to query the length (out_len, without the terminator). */
 int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos, int32_t precision,
-                  const vft_nj_options *opt, const int64_t *unique_first, const int64_t *aln_next, int64_t n_all,
+                  const vft_nj_options *opt, int32_t me_lengths, const int64_t *unique_first, const int64_t *aln_next,
+                  int64_t n_all,
                   const char *names, char *out, int64_t out_cap, int64_t *out_len, char *err, int32_t err_len);
 
 #ifdef __cplusplus

@@ -68,3 +68,8 @@ def test_nj_tree_string_equals_the_reference(name, fastest, second, dt):
     names = ["s%d" % k for k in range(len(codes_all))]
     tree = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt), codes_all, names, fastest=fastest, second_level=second, dtype=dt)
     assert tree == bytes(d["nj_newick"]).decode()
+    # ... and with the minimum-evolution branch lengths (updateBranchLengths, NJ.tcc:6514-6595): the reference's final
+    # output for -noml -nome -nosupport
+    final = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
+                      second_level=second, dtype=dt, me_lengths=True)
+    assert final == bytes(d["newick"]).decode().strip()

@@ -107,9 +107,10 @@ def uniquify(codes):
     return np.array(unique_first, np.int64), aln_next
 
 
-def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32):
+def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
-    make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences."""
+    make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
+    then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
     lib = load_host_library()
     codes_all = np.ascontiguousarray(codes_all, np.uint8)
     unique_first, aln_next = uniquify(codes_all)
@@ -126,7 +127,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     olen = I64(0)
     err = C.create_string_buffer(512)
     rc = lib.vft_nj_newick(ops.ctx, _ptr(codes), I64(n), I64(L), I32(np.dtype(dtype).itemsize), C.byref(opt),
-                           _ptr(unique_first), _ptr(aln_next), I64(len(codes_all)), blob, out, I64(cap),
+                           I32(1 if me_lengths else 0), _ptr(unique_first), _ptr(aln_next), I64(len(codes_all)), blob, out, I64(cap),
                            C.byref(olen), err, I32(512))
     if rc != 0:
         raise VftError(err.value.decode() or "vft_nj_newick failed")

@@ -168,6 +168,117 @@ namespace veryfasttree {
             branchlength[top[2]] = (REAL) ((d02 + d12 - d01) / 2);
         }
 
+        /* updateBranchLengths (NJ.tcc:6514-6595) on the finished NJ topology, as the pipeline does before it prints a
+           minimum-evolution tree (VeryFastTreeImpl.tcc:205-213): every branch length from log-corrected profile
+           distances between the node's children / sibling / up-profile (correctedPairDistances NJ.tcc:1460-1488,
+           logCorrect :322-330; -nj weighting, no pseudocounts: the defaults).  The up-profile of an internal node X
+           (getUpProfile :3382-3434, useML = false) is average(sibling(X), up(parent X)), or the average of the two
+           other children of the root; it lives on the device as node X + nSeqs, so the context must have been created
+           with max_nodes >= 3 * nSeqs.  Up-profiles go level by level (one vft_average_profiles per depth), all
+           distances are ONE vft_profile_distances list. */
+        void updateBranchLengths() {
+            if (root < 0) throw std::invalid_argument("NJDriver::updateBranchLengths before finishRoot");
+            const int64_t upOff = nSeqs;
+            auto isInternal = [&](int64_t v) { return v >= nSeqs && v != root; };
+            auto up = [&](int64_t v) { return v + upOff; };
+            auto siblingOf = [&](int64_t v) { const int64_t p = parent[v]; return child0[p] == v ? child1[p] : child0[p]; };
+            auto rootSibs = [&](int64_t v, int64_t sibs[2]) {
+                int n = 0;
+                for (int k = 0; k < 3; k++)
+                    if (rootChild[k] != v) sibs[n++] = rootChild[k];
+            };
+            chkT("vft_set_max_node", [&]() { return vft_set_max_node(ctx, maxnode + upOff); });
+            /* 1. up-profiles, breadth first from the root */
+            std::vector<int64_t> level;
+            for (int k = 0; k < 3; k++)
+                if (isInternal(rootChild[k])) level.push_back(rootChild[k]);
+            while (!level.empty()) {
+                std::vector<int64_t> out, a, b, next;
+                for (int64_t x: level) {
+                    out.push_back(up(x));
+                    if (parent[x] == root) {
+                        int64_t sibs[2];
+                        rootSibs(x, sibs);
+                        a.push_back(sibs[0]);
+                        b.push_back(sibs[1]);
+                    } else {
+                        a.push_back(siblingOf(x));
+                        b.push_back(up(parent[x]));
+                    }
+                    if (isInternal(child0[x])) next.push_back(child0[x]);
+                    if (isInternal(child1[x])) next.push_back(child1[x]);
+                }
+                chkT("vft_average_profiles", [&]() { return vft_average_profiles(ctx, (int64_t) out.size(), out.data(), a.data(), b.data(), nullptr); });
+                level.swap(next);
+            }
+            /* 2. every distance of every branch, in correctedPairDistances' order (i < j over A, B, C[, D]) */
+            std::vector<int64_t> pi, pj, firstPair((size_t) maxnode + 1, 0);
+            for (int64_t v = 0; v < maxnode; v++) {
+                firstPair[(size_t) v] = (int64_t) pi.size();
+                if (v == root) continue;
+                int64_t q[4], nq;
+                if (v < nSeqs) {
+                    q[0] = v;
+                    if (parent[v] == root) {
+                        int64_t sibs[2];
+                        rootSibs(v, sibs);
+                        q[1] = sibs[0];
+                        q[2] = sibs[1];
+                    } else {
+                        q[1] = siblingOf(v);
+                        q[2] = up(parent[v]);
+                    }
+                    nq = 3;
+                } else {
+                    q[0] = child0[v];
+                    q[1] = child1[v];
+                    if (parent[v] == root) {
+                        int64_t sibs[2];
+                        rootSibs(v, sibs);
+                        q[2] = sibs[0];
+                        q[3] = sibs[1];
+                    } else {
+                        q[2] = siblingOf(v);
+                        q[3] = up(parent[v]);
+                    }
+                    nq = 4;
+                }
+                for (int64_t x = 0; x < nq; x++)
+                    for (int64_t y = x + 1; y < nq; y++) {
+                        pi.push_back(q[x]);
+                        pj.push_back(q[y]);
+                    }
+            }
+            firstPair[(size_t) maxnode] = (int64_t) pi.size();
+            const int64_t nPairs = (int64_t) pi.size();
+            std::vector<REAL> pd((size_t) nPairs), pw((size_t) nPairs);
+            const int64_t maxCall = 1 << 22;
+            for (int64_t p0 = 0; p0 < nPairs; p0 += maxCall) {
+                const int64_t cnt = std::min<int64_t>(maxCall, nPairs - p0);
+                chkT("vft_profile_distances", [&]() { return vft_profile_distances(ctx, cnt, pi.data() + p0, pj.data() + p0, pd.data() + p0, pw.data() + p0); });
+            }
+            /* 3. branch lengths (double arithmetic, stored as numeric_t) */
+            auto logCorrect = [&](double dist) {   /* Jukes-Cantor: nucleotides without a distance matrix */
+                const double maxscore = 3.0;
+                dist = dist < 0.74 ? -0.75 * std::log(1.0 - dist * 4.0 / 3.0) : maxscore;
+                return dist < maxscore ? dist : maxscore;
+            };
+            for (int64_t v = 0; v < maxnode; v++) {
+                if (v == root) continue;
+                const int64_t f = firstPair[(size_t) v];
+                if (v < nSeqs) {
+                    const double dAB = logCorrect((double) pd[(size_t) f]), dAC = logCorrect((double) pd[(size_t) f + 1]),
+                                 dBC = logCorrect((double) pd[(size_t) f + 2]);
+                    branchlength[(size_t) v] = (REAL) ((dAB + dAC - dBC) / 2.0);
+                } else {
+                    double d[6];
+                    for (int k = 0; k < 6; k++) d[k] = logCorrect((double) pd[(size_t) f + k]);
+                    /* qAB 0, qAC 1, qAD 2, qBC 3, qBD 4, qCD 5 */
+                    branchlength[(size_t) v] = (REAL) ((d[1] + d[2] + d[3] + d[4]) / 4.0 - (d[0] + d[5]) / 2.0);
+                }
+            }
+        }
+
         /* printNJ (NJ.tcc:2706-2794, no supports, no quoting): depth-first, children in stored order, leaf names with
            their duplicates expanded as (a:0.0,b:0.0), lengths as %.5f (float) / %.9f (double).
            names[k] = name of alignment row k; uniqueFirst[u] = row of unique sequence u; alnNext[k] = next row with the
