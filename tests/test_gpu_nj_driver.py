@@ -73,3 +73,15 @@ def test_nj_tree_string_equals_the_reference(name, fastest, second, dt):
     final = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
                       second_level=second, dtype=dt, me_lengths=True)
     assert final == bytes(d["newick"]).decode().strip()
+
+
+def test_fasta_to_newick_tool_matches_the_reference_output():
+    """tools/nj_tree.py on the FASTA of bb_nt_200 prints what `VeryFastTree -nt -noml -nome -nosupport` printed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = os.path.join(root, "tests", "golden", "bb_nt_200.fa")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nj_tree.py"), fa], check=True,
+                         stdout=subprocess.PIPE, timeout=300).stdout.decode().strip()
+    assert out == bytes(G.load("bb_nt_200")["newick"]).decode().strip()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""FASTA (nucleotides) -> Newick on one MI355X: the tree `VeryFastTree -nt [-fastest] -noml -nome -nosupport` prints.
+
+    python tools/nj_tree.py in.fasta [-fastest] [-double] [-nj-lengths] > tree.nwk
+
+Neighbour joining with top hits on the device (veryfasttree_amd/host/NJDriver.h), the root, minimum-evolution branch
+lengths (updateBranchLengths) and printNJ; -nj-lengths keeps the NJ branch lengths (the reference's "NJ" log line).
+Sequence normalisation and uniquify follow Alignment.cpp:453-526 (U -> T, '.' -> '-', duplicates by sequence string in
+first-occurrence order)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from veryfasttree_amd import HipProfileOps
+from veryfasttree_amd.backend import nj_newick
+from veryfasttree_amd.synth import ALPHABET_NT, NOCODE
+
+
+def read_fasta(path):
+    names, seqs, cur = [], [], []
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if names:
+                    seqs.append("".join(cur))
+                names.append(line[1:].split()[0] if line[1:].split() else "")
+                cur = []
+            elif names:
+                cur.append(line.strip())
+    if names:
+        seqs.append("".join(cur))
+    return names, seqs
+
+
+def main():
+    args = sys.argv[1:]
+    if not args or args[0].startswith("-"):
+        sys.exit(__doc__)
+    fastest, double, nj_len = "-fastest" in args, "-double" in args, "-nj-lengths" in args
+    names, seqs = read_fasta(args[0])
+    if len({len(s) for s in seqs}) != 1:
+        sys.exit("sequences have different lengths: not an alignment")
+    seqs = [s.upper().replace("U", "T").replace(".", "-") for s in seqs]
+    first_of, last, unique_first = {}, {}, []
+    aln_next = np.full(len(seqs), -1, np.int64)
+    for k, s in enumerate(seqs):
+        if s not in first_of:
+            first_of[s] = k
+            unique_first.append(k)
+        else:
+            aln_next[last[s]] = k
+        last[s] = k
+    lut = np.full(256, NOCODE, np.uint8)
+    for i, ch in enumerate(ALPHABET_NT):
+        lut[ord(ch)] = i
+    codes_all = np.stack([lut[np.frombuffer(s.encode("ascii", "replace"), np.uint8)] for s in seqs])
+    n_unique = len(unique_first)
+    if n_unique < 16:
+        sys.exit("fewer than 16 unique sequences: the top-hits heuristic this driver implements is off there")
+    dt = np.float64 if double else np.float32
+    tree = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
+                     dtype=dt, me_lengths=not nj_len, unique=(np.array(unique_first, np.int64), aln_next))
+    print(tree)
+
+
+if __name__ == "__main__":
+    main()

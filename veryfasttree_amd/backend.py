@@ -107,13 +107,18 @@ def uniquify(codes):
     return np.array(unique_first, np.int64), aln_next
 
 
-def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False):
+def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
+              unique=None):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
     lib = load_host_library()
     codes_all = np.ascontiguousarray(codes_all, np.uint8)
-    unique_first, aln_next = uniquify(codes_all)
+    # unique = (unique_first, aln_next) when the caller has uniquified the sequence STRINGS like the reference does
+    # (two different characters may share a code); otherwise rows with equal codes are taken as duplicates
+    unique_first, aln_next = unique if unique is not None else uniquify(codes_all)
+    unique_first = np.ascontiguousarray(unique_first, np.int64)
+    aln_next = np.ascontiguousarray(aln_next, np.int64)
     codes = np.ascontiguousarray(codes_all[unique_first])
     n, L = codes.shape
     ops = make_ops(n, L)
