@@ -24,6 +24,9 @@ typedef struct {
     int32_t tophits2_safety;    /* Options::tophits2Safety   (3) */
     double tophits2_mult;       /* Options::tophits2Mult     (1.0) */
     double tophits2_refresh;    /* Options::tophits2Refresh  (0.6) */
+    int32_t scoredist;          /* logCorrect (NJ.tcc:322-330): 0 = Jukes-Cantor (nucleotides without a matrix),
+                                   1 = scoredist-like (amino acids, or any alphabet with a distance matrix) */
+    int32_t reserved;
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

@@ -84,6 +84,7 @@ BLACKBOX_CASES = [
     ("bb_nt_600_fastest_no2nd", ["-nt", "-fastest", "-no2nd"], 600, 100, 4, 0.04, 0.02, 22),
     ("bb_nt_1500", ["-nt"], 1500, 80, 4, 0.03, 0.01, 23),
     ("bb_nt_300_double", ["-nt", "-double-precision"], 300, 90, 4, 0.05, 0.03, 24),
+    ("bb_aa_300", [], 300, 80, 20, 0.10, 0.03, 25),   # protein: BLOSUM45-derived distance matrix (the default)
 ]
 
 
@@ -91,7 +92,7 @@ def gen_blackbox(tmp):
     for name, flags, n, L, nc, mu, gap, seed in BLACKBOX_CASES:
         codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
         fa = os.path.join(tmp, name + ".fa")
-        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if nc == 20 else synth.ALPHABET_NT)
         log = os.path.join(tmp, name + ".log")
         cmd = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-verbose", "3", "-noml", "-nome", "-nosupport",
                                   "-log", log, fa]

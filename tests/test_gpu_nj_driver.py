@@ -85,3 +85,24 @@ def test_fasta_to_newick_tool_matches_the_reference_output():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "nj_tree.py"), fa], check=True,
                          stdout=subprocess.PIPE, timeout=300).stdout.decode().strip()
     assert out == bytes(G.load("bb_nt_200")["newick"]).decode().strip()
+
+
+def test_amino_acid_alignment_with_distance_matrix_end_to_end():
+    """Protein alignment, BLOSUM45-derived distance matrix (the reference's default for amino acids): join order, the
+    NJ tree and the final -noml -nome -nosupport tree, through the generic (any alphabet / matrix) kernels."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick, nj_run
+    d = G.load("bb_aa_300")
+    dm = G.load("wb_aa_f32")
+
+    def make(n, L):
+        ops = HipProfileOps(n, L, 20, np.float32, max_nodes=3 * n)
+        ops.set_distance_matrix(dm["dmat.distances"], dm["dmat.codefreq"], dm["dmat.eigenval"], dm["dmat.eigentot"])
+        return ops
+
+    codes = unique_codes(d["codes"])
+    joins, crit = nj_run(make(*codes.shape), codes)
+    assert np.array_equal(joins, d["joins"])
+    names = ["s%d" % k for k in range(len(d["codes"]))]
+    assert nj_newick(make, d["codes"], names, scoredist=True) == bytes(d["nj_newick"]).decode()
+    assert nj_newick(make, d["codes"], names, scoredist=True, me_lengths=True) == bytes(d["newick"]).decode().strip()

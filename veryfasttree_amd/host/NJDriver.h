@@ -45,6 +45,8 @@ namespace veryfasttree {
         /* OpenMP threads for the host-only parts of a top-hits refresh (the reference parallelises the same loop,
            NJ.tcc:4476); results do not depend on it */
         int hostThreads = 16;
+        /* logCorrect of the minimum-evolution lengths: scoredist-like instead of Jukes-Cantor (amino acids / matrix) */
+        bool scoredist = false;
     };
 
     template<typename REAL>
@@ -258,9 +260,10 @@ namespace veryfasttree {
                 chkT("vft_profile_distances", [&]() { return vft_profile_distances(ctx, cnt, pi.data() + p0, pj.data() + p0, pd.data() + p0, pw.data() + p0); });
             }
             /* 3. branch lengths (double arithmetic, stored as numeric_t) */
-            auto logCorrect = [&](double dist) {   /* Jukes-Cantor: nucleotides without a distance matrix */
+            auto logCorrect = [&](double dist) {   /* NJ.tcc:322-330 */
                 const double maxscore = 3.0;
-                dist = dist < 0.74 ? -0.75 * std::log(1.0 - dist * 4.0 / 3.0) : maxscore;
+                if (!opt.scoredist) dist = dist < 0.74 ? -0.75 * std::log(1.0 - dist * 4.0 / 3.0) : maxscore;   /* Jukes-Cantor */
+                else dist = dist < 0.99 ? -1.3 * std::log(1.0 - dist) : maxscore;                              /* scoredist-like */
                 return dist < maxscore ? dist : maxscore;
             };
             for (int64_t v = 0; v < maxnode; v++) {

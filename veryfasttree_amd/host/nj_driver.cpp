@@ -25,6 +25,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.tophits2Safety = o->tophits2_safety;
         opt.tophits2Mult = o->tophits2_mult;
         opt.tophits2Refresh = o->tophits2_refresh;
+        opt.scoredist = o->scoredist != 0;
     }
     return opt;
 }
