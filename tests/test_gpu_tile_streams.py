@@ -127,3 +127,29 @@ def test_join_nodes_equals_the_separate_state_calls():
     for x, y in zip(a[7], b[7]):
         assert np.array_equal(x, y)
     assert a[2][17] == np.float32(1e20) and a[2][101] == np.float32(1e20)      # joined children: sentinel
+
+
+@pytest.mark.parametrize("n_pos", [2600, 6000])
+def test_long_alignments_sweep_equals_pair_list_and_oracle(n_pos):
+    """Alignments longer than 2560 columns: the wave-per-item kernels run with fewer waves per workgroup (their LDS
+    staging grows with the length).  The sweep (lane per target, no LDS) and the pair list (wave / workgroup per pair)
+    are independent implementations and must agree bit for bit; a few pairs are checked against the CPU oracle."""
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.workload import TopHitsState
+    from oracle import Oracle
+    n = 192
+    codes = synth.random_descent_codes(n, n_pos, 4, 0.05, 0.02, seed=31)
+    ops = HipProfileOps(n, n_pos, 4, np.float32)
+    st = TopHitsState(ops, codes, 48)
+    q = int(st.active[st.active >= n][5])
+    ops.setBestHit(q, st.n_active, st.n_diff_allow, st.totdiam, 16)
+    d, w, c = ops.sweep_results(0, st.maxnode)
+    others = st.active[st.active != q]
+    pd, pw, pc = ops.setDistCriterion(np.full(len(others), q), others, st.n_active, st.n_diff_allow, st.totdiam)
+    assert np.array_equal(pd, d[others]) and np.array_equal(pw, w[others]) and np.array_equal(pc, c[others])
+    rd, rw = ops.profileDist(np.full(4, q), others[[0, 7, 100, 120]])
+    orc = Oracle(np.float32)
+    pq = ops.profile_download(q)
+    for k, j in enumerate(others[[0, 7, 100, 120]]):
+        ed, ew = orc.profiledist(pq, ops.profile_download(int(j)))
+        assert rd[k] == ed and rw[k] == ew

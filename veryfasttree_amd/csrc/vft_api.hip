@@ -73,6 +73,8 @@ struct vft_ctx {
     size_t ioCap = 8u << 20, ioHead = 0;
     unsigned long long *hFlag = nullptr, *dFlag = nullptr, signalSeq = 0;
     unsigned int *doneCtr = nullptr;   // completion counter of k_pairs_fused
+    int pwWaves = 4;                   // items (waves) per workgroup of the wave-per-item kernels: 4, or fewer when the
+                                       // LDS staging of a long alignment would not fit (raise_pair_kernel_lds)
     // host-mapped mirrors of outDist / nOutActive, written by the kernels that refresh them
     void *hOutDist = nullptr, *dOutDistM = nullptr;
     int32_t *hNOut = nullptr, *dNOutM = nullptr;
@@ -839,13 +841,16 @@ __global__ __launch_bounds__(VFT_WG) void k_selfdist_one(Arena<REAL> A, const in
 }
 
 // dynamic LDS of the wave-per-item kernels
-static size_t pw_lds_bytes(const vft_ctx *c) { return (size_t) VFT_PW_WAVES * 2 * c->d.nPosPad * sizeof(double); }
+static size_t pw_lds_bytes(const vft_ctx *c) { return (size_t) c->pwWaves * 2 * c->d.nPosPad * sizeof(double); }
 
 // long alignments: those kernels stage 2 doubles per column and wave, which can exceed the default dynamic-LDS limit
 static int raise_pair_kernel_lds(vft_ctx *c) {
+    // 2 x nPosPad doubles per item: 4 items per workgroup up to 2560 columns, 2 up to 5120, 1 up to 10240
+    c->pwWaves = 4;
+    while (c->pwWaves > 1 && pw_lds_bytes(c) > (160u << 10)) c->pwWaves >>= 1;
     const size_t bytes = pw_lds_bytes(c);
     if (bytes <= (48u << 10)) return VFT_OK;
-    if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging");
+    if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging (%lld columns, limit 10240)", (long long) c->d.nPos);
     VFT_DISPATCH(c, {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
@@ -904,10 +909,10 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
     if (n == 1) {
-        VFT_DISPATCH(c, launch((k_selfdist_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+        VFT_DISPATCH(c, launch((k_selfdist_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / c->pwWaves, c->stream,
                                arena<REAL>(c), (const int64_t *) s));
     } else {
-        VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
+        VFT_DISPATCH(c, launch((k_selfdist<REAL, NC>), dim3(cdiv(n, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
                                arena<REAL>(c), (const int64_t *) s, n));
     }
     LAUNCHCHK(c);
@@ -1020,7 +1025,7 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
     s.queryIsLeaf = 0;
     s.force = force ? 1 : 0;
     if (dIds) {
-        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(n, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), dIds, n, s)));
         LAUNCHCHK(c);
         return VFT_OK;
@@ -1040,7 +1045,7 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
             launch_sweep_nt<double, MODE_OUTDIST>(c, s, grid, 1, false);
         }
     } else {
-        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+        VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), (const int64_t *) nullptr, span, s)));
     }
     LAUNCHCHK(c);
@@ -1057,7 +1062,7 @@ extern "C" int vft_out_distances(vft_ctx *c, int64_t n, const int64_t *ids, int6
             s.nActive = nActive;
             s.totdiam = totdiam;
             s.force = 1;
-            VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+            VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / c->pwWaves, c->stream,
                                    arena<REAL>(c), ids[0], s));
             LAUNCHCHK(c);
             return VFT_OK;
@@ -1132,7 +1137,7 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         s.nDiffAllow = nDiffAllow;
         s.totdiam = totdiam;
         s.force = 0;
-        VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / VFT_PW_WAVES, c->stream,
+        VFT_DISPATCH(c, launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / c->pwWaves, c->stream,
                                arena<REAL>(c), query, s));
         LAUNCHCHK(c);
     }
@@ -1169,9 +1174,9 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         // at ~32k targets.  (Neither is tuned: the aa arena wants its own kernel)
         kernel_event(c);
         if (span <= 32768) {
-            const unsigned wgrid = (unsigned) std::min<int64_t>(cdiv(span > 0 ? span : 1, VFT_PW_WAVES), 256 * 16);
+            const unsigned wgrid = (unsigned) std::min<int64_t>(cdiv(span > 0 ? span : 1, c->pwWaves), 256 * 16);
             c->nPart = (int) wgrid;
-            VFT_DISPATCH(c, (launch((k_sweep_wave<REAL, NC>), dim3(wgrid), dim3(VFT_WG), pw_lds_bytes(c), c->stream,
+            VFT_DISPATCH(c, (launch((k_sweep_wave<REAL, NC>), dim3(wgrid), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
                                     arena<REAL>(c), s, sweepout<REAL>(c))));
         } else {
             VFT_DISPATCH(c, (launch((k_sweep_generic<REAL, NC>), dim3(grid), dim3(VFT_WG), 0, c->stream,
@@ -1277,7 +1282,7 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     // the mapped ring)
     const unsigned long long seq = small ? ++c->signalSeq : 0ull;
     if (n <= 2048) {   // short list: a workgroup per pair (all of them resident at once)
-        const size_t lds = pw_lds_bytes(c) / VFT_PW_WAVES;
+        const size_t lds = pw_lds_bytes(c) / c->pwWaves;
         // The host-mapped stamp mirror can only lag towards "staler" (kernels in flight make nodes fresher, host-side
         // sets update it at once): if it shows no stale node there is none, and the refresh launch is skipped.
         bool anyStale = false;
@@ -1291,9 +1296,9 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
                                 c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     } else {
         if (!raw)
-            VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, VFT_PW_WAVES)), dim3(VFT_WG),
+            VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, c->pwWaves)), dim3(64 * c->pwWaves),
                                     pw_lds_bytes(c), c->stream, arena<REAL>(c), dI, dJ, n, sa)));
-        VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, VFT_PW_WAVES)), dim3(VFT_WG), pw_lds_bytes(c),
+        VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB),
                                 (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     }

@@ -724,8 +724,9 @@ __device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, 
     }
 }
 
-#define VFT_PW_WAVES 4   // pairs per 256-thread workgroup in the wave-per-item kernels
-// dynamic LDS of those kernels: VFT_PW_WAVES * 2 * nPosPad doubles
+// wave-per-item kernels: a workgroup holds blockDim.x / 64 items (4 by default; the host launches fewer waves per
+// workgroup for long alignments so that the staging fits the 160 KB of LDS); dynamic LDS = waves * 2 * nPosPad doubles
+#define VFT_PW_WAVES ((int) (blockDim.x >> 6))
 __device__ __forceinline__ double *vft_pw_lds(double *base, int64_t nPosPad, int which) {
     return base + ((int64_t) (threadIdx.x >> 6) * 2 + which) * nPosPad;
 }
