@@ -129,16 +129,20 @@ def test_join_nodes_equals_the_separate_state_calls():
     assert a[2][17] == np.float32(1e20) and a[2][101] == np.float32(1e20)      # joined children: sentinel
 
 
-@pytest.mark.parametrize("n_pos", [2600, 6000])
-def test_long_alignments_sweep_equals_pair_list_and_oracle(n_pos):
+@pytest.mark.parametrize("n_pos,gap", [(2600, 0.02), (6000, 0.02), (5, 0.3), (16, 0.4), (17, 0.6)])
+def test_long_short_and_gappy_alignments_sweep_equals_pair_list_and_oracle(n_pos, gap):
     """Alignments longer than 2560 columns: the wave-per-item kernels run with fewer waves per workgroup (their LDS
-    staging grows with the length).  The sweep (lane per target, no LDS) and the pair list (wave / workgroup per pair)
+    staging grows with the length).  Very short and very gappy ones: rows that are almost or entirely gaps, columns
+    that are all gaps, fewer columns than one 16-column chunk.  The sweep (lane per target, no LDS) and the pair list (wave / workgroup per pair)
     are independent implementations and must agree bit for bit; a few pairs are checked against the CPU oracle."""
     from veryfasttree_amd import HipProfileOps, synth
     from veryfasttree_amd.workload import TopHitsState
     from oracle import Oracle
     n = 192
-    codes = synth.random_descent_codes(n, n_pos, 4, 0.05, 0.02, seed=31)
+    codes = synth.random_descent_codes(n, n_pos, 4, 0.05, gap, seed=31)
+    if gap > 0.1:
+        codes[5] = NOCODE          # an empty sequence
+        codes[:, 0] = NOCODE       # an empty column
     ops = HipProfileOps(n, n_pos, 4, np.float32)
     st = TopHitsState(ops, codes, 48)
     q = int(st.active[st.active >= n][5])
