@@ -49,6 +49,10 @@ int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_
                   int64_t n_all,
                   const char *names, char *out, int64_t out_cap, int64_t *out_len, char *err, int32_t err_len);
 
+/* The first n values of the random stream the bootstrap columns are drawn from (Knuth's ran_array at its default
+   seed, as the reference uses it, Knuth.cpp:95-111): exported so that tests can pin the host generator. */
+void vft_knuth_stream(double *out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

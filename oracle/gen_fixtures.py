@@ -76,6 +76,16 @@ def gen_whitebox(tmp):
         print("%-20s %4d arrays  %7.1f KiB" % (name, len(d), os.path.getsize(dst) / 1024.0))
 
 
+def gen_knuth(tmp):
+    """5000 values of the reference's knuth_rand() stream (Knuth.cpp; never re-seeded by the pipeline)."""
+    vfx = os.path.join(tmp, "knuth.vfx")
+    subprocess.run([WHITEBOX, "knuth", "-", vfx], check=True)
+    d = read_vfx(vfx)
+    dst = os.path.join(GOLDEN, "wb_knuth.npz")
+    np.savez_compressed(dst, **d)
+    print("%-20s %4d arrays  %7.1f KiB" % ("wb_knuth", len(d), os.path.getsize(dst) / 1024.0))
+
+
 BLACKBOX_CASES = [
     # name, flags, n_seq, n_pos, n_codes, mu, gap, seed
     ("bb_nt_c1", ["-nt", "-fastest"], 16, 100, 4, 0.05, 0.0, 1),  # BASELINE config 1
@@ -123,12 +133,14 @@ def gen_blackbox(tmp):
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
         if "blackbox" in which:
             gen_blackbox(tmp)
+        if "knuth" in which:
+            gen_knuth(tmp)
 
 
 if __name__ == "__main__":

@@ -41,3 +41,21 @@ int64_t vfto_profile_hash(const void *w, const unsigned char *c, const void *f, 
     }
     return (int64_t) h;
 }
+
+
+/* ---- Knuth's ran_array as the reference uses it (vft_knuth.h) */
+#include "vft_knuth.h"
+/* out[0..n) = the reference's knuth_rand() stream from its default state (seed 314159) */
+void vfto_knuth_stream(double *out, int64_t n) {
+    vft_knuth g;
+    vft_knuth_start(&g, 314159L);
+    for (int64_t i = 0; i < n; i++) out[i] = vft_knuth_rand(&g);
+}
+/* Knuth's own self-test: ran_start(310952), `rounds` refills of `len` values -> first value of the last refill */
+long vfto_knuth_selftest(int rounds, int len) {
+    static long a[2009];
+    vft_knuth g;
+    vft_knuth_start(&g, 310952L);
+    for (int m = 0; m <= rounds; m++) vft_knuth_array(&g, a, len);
+    return a[0];
+}

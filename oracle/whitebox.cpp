@@ -35,6 +35,8 @@
 #include <string>
 #include <vector>
 
+#include "Knuth.h"
+
 using namespace veryfasttree;
 
 /* ---------------------------------------------------------------- container writer */
@@ -585,6 +587,13 @@ int main(int argc, char **argv) {
         return 2;
     }
     std::string mode = argv[1];
+    if (mode == "knuth") {   /* the reference's random stream (Knuth.cpp: knuth_rand, never re-seeded by the pipeline) */
+        Dump d(argv[3]);
+        std::vector<double> r(5000);
+        for (double &x: r) x = knuth_rand();
+        d.vec("knuth.rand", r);
+        return 0;
+    }
     uint64_t seed = argc > 4 ? strtoull(argv[4], nullptr, 10) : 1;
     omp_set_num_threads(1);
 

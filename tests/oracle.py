@@ -208,3 +208,15 @@ def tolerances(dtype):
     if np.dtype(dtype) == np.float32:
         return 5.0e-4, 2.5e-4, 1.0e-10
     return 5.0e-9, 2.5e-9, 1.0e-20
+
+
+def knuth_stream(n):
+    """The reference's knuth_rand() stream from its default state (oracle/vft_knuth.h)."""
+    out = np.zeros(n, np.float64)
+    _lib.vfto_knuth_stream(_ptr(out), I64(n))
+    return out
+
+
+def knuth_selftest(rounds, length):
+    _lib.vfto_knuth_selftest.restype = C.c_long
+    return int(_lib.vfto_knuth_selftest(C.c_int(rounds), C.c_int(length)))

@@ -36,7 +36,7 @@ def test_host_driver_library_exports_its_header(lib):
     host = backend.load_host_library()
     text = open(os.path.join(ROOT, "include", "vft_host.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = sorted(set(re.findall(r"\b(vft_nj_[a-z0-9_]+)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth)_[a-z0-9_]+)\s*\(", text)))
     assert names == sorted(backend.HOST_EXPORTS)
     assert all(hasattr(host, n) for n in names)
 
@@ -59,3 +59,17 @@ def test_bad_config_is_rejected(lib):
     from veryfasttree_amd import HipProfileOps, VftError
     with pytest.raises(VftError):
         HipProfileOps(8, 16, 5, np.float32)
+
+
+def test_host_knuth_generator_matches_the_reference_stream():
+    """veryfasttree_amd/host/KnuthRng.h (the product's column resampler) against 5000 values of the reference's
+    knuth_rand() stream (tests/golden/wb_knuth.npz)."""
+    import ctypes as C
+    import numpy as np
+    import golden_util as G
+    from veryfasttree_amd.backend import load_host_library
+    lib = load_host_library()
+    ref = G.load("wb_knuth")["knuth.rand"]
+    out = np.zeros(len(ref), np.float64)
+    lib.vft_knuth_stream(out.ctypes.data_as(C.c_void_p), C.c_int64(len(ref)))
+    assert np.array_equal(out, ref)

@@ -210,3 +210,13 @@ def test_ml_profiles_loglk_and_loose_calls(fx):
                                       float(d[model + ".post.len2"][k]), d["ml.rates"], d["ml.ratecat"], tm,
                                       min_len, min_rel)
             assert G.profiles_equal(o, G.fixture_profile(d, "%s.post%d" % (model, k))), (model, k)
+
+
+def test_knuth_ran_array_restatement_is_pinned():
+    """oracle/vft_knuth.h against Knuth's published check value (TAOCP 3.6, rng.c) and against 5000 values of the
+    reference's own stream (tests/golden/wb_knuth.npz, oracle/whitebox.cpp mode `knuth`)."""
+    import oracle as O
+    assert O.knuth_selftest(2009, 1009) == 995235265
+    assert O.knuth_selftest(1009, 2009) == 995235265
+    ref = G.load("wb_knuth")["knuth.rand"]
+    assert np.array_equal(O.knuth_stream(len(ref)), ref)

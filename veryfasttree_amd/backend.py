@@ -42,7 +42,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick"]
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_knuth_stream"]
 
 
 class _NJOptions(C.Structure):

@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "NJDriver.h"
+#include "KnuthRng.h"
 
 static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
@@ -63,6 +64,11 @@ extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, 
         if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
         return VFT_ERR_STATE;
     }
+}
+
+extern "C" void vft_knuth_stream(double *out, int64_t n) {
+    veryfasttree::KnuthRng g;
+    for (int64_t i = 0; i < n; i++) out[i] = g.rand();
 }
 
 template<typename REAL>
