@@ -173,6 +173,12 @@ int vft_pair_loglk(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, 
 int vft_posterior_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
                            const double *len1, const double *len2);
 
+/* Local-bootstrap supports (splitSupport, NJ.tcc:607-702) of n splits (a[k], b[k]) | (c[k], d[k]): col holds n_boot
+   resamples of n_pos column indices each ([n_boot][n_pos], host; resampleColumns NJ.tcc:705-727); support[k] = the
+   fraction of resamples in which the split beats both alternative pairings of the four profiles. */
+int vft_split_supports(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, const int64_t *c, const int64_t *d,
+                       int32_t n_boot, const int32_t *col, double *support);
+
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */
 int vft_timer_start(vft_ctx *ctx);
 int vft_timer_stop_ms(vft_ctx *ctx, float *ms);

@@ -41,12 +41,14 @@ int vft_nj_run(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos
    me_lengths != 0: also updateBranchLengths (NJ.tcc:6514-6595, log-corrected minimum-evolution lengths) before
    printing - the "ME_Lengths" tree, which is the final output of `-noml -nome -nosupport`; the context must then have
    been created with max_nodes >= 3 * n_seqs (the up-profiles live on the device).
+   n_bootstrap > 0: also the local-bootstrap supports of the internal splits (reliabilityNJ, NJ.tcc:3191-3238; the
+   reference's default is 1000), printed as ")0.987:length"; needs max_nodes >= 3 * n_seqs as well.
    codes: the n_seqs UNIQUE sequences in first-occurrence order; unique_first[u] = alignment row of unique sequence u;
    aln_next[k] = next alignment row with the same sequence or -1 (Uniquify, Alignment.cpp:494-526); names: n_all
    NUL-terminated names back to back.  out may be NULL to query the length (out_len, without the terminator). */
 int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos, int32_t precision,
-                  const vft_nj_options *opt, int32_t me_lengths, const int64_t *unique_first, const int64_t *aln_next,
-                  int64_t n_all,
+                  const vft_nj_options *opt, int32_t me_lengths, int32_t n_bootstrap, const int64_t *unique_first,
+                  const int64_t *aln_next, int64_t n_all,
                   const char *names, char *out, int64_t out_cap, int64_t *out_len, char *err, int32_t err_len);
 
 /* The first n values of the random stream the bootstrap columns are drawn from (Knuth's ran_array at its default

@@ -121,12 +121,16 @@ def gen_blackbox(tmp):
         # the tree as fastNJ leaves it, NJ branch lengths included (logTree("NJ"), VeryFastTreeImpl.tcc:143)
         mnj = re.search(r"^NJ\t(\(.*;)\s*$", text, re.M)
         assert mnj, "no NJ tree line for " + name
+        # the same pipeline with the default local-bootstrap supports (1000 resamples, reliabilityNJ)
+        cmd2 = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-noml", "-nome", fa]
+        res2 = subprocess.run(cmd2, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         ja = np.array([(a, b, c) for a, b, c, _ in joins], dtype=np.int64)
         jc = np.array([c for _, _, _, c in joins], dtype=np.float64)
         dst = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(dst, codes=codes, joins=ja, join_criterion=jc,
                             newick=np.frombuffer(res.stdout, dtype=np.uint8),
                             nj_newick=np.frombuffer(mnj.group(1).encode(), dtype=np.uint8),
+                            newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
                             flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
         print("%-20s %5d joins  %7.1f KiB" % (name, len(joins), os.path.getsize(dst) / 1024.0))
 

@@ -73,18 +73,24 @@ def test_nj_tree_string_equals_the_reference(name, fastest, second, dt):
     final = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
                       second_level=second, dtype=dt, me_lengths=True)
     assert final == bytes(d["newick"]).decode().strip()
+    # ... and with the default local-bootstrap supports (reliabilityNJ, 1000 resamples of Knuth's generator): the
+    # reference's output for -noml -nome
+    boot = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
+                     second_level=second, dtype=dt, me_lengths=True, n_bootstrap=1000)
+    assert boot == bytes(d["newick_support"]).decode().strip()
 
 
 def test_fasta_to_newick_tool_matches_the_reference_output():
-    """tools/nj_tree.py on the FASTA of bb_nt_200 prints what `VeryFastTree -nt -noml -nome -nosupport` printed."""
+    """tools/nj_tree.py on the FASTA of bb_nt_200 prints what `VeryFastTree -nt -noml -nome [-nosupport]` printed."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     fa = os.path.join(root, "tests", "golden", "bb_nt_200.fa")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nj_tree.py"), fa], check=True,
-                         stdout=subprocess.PIPE, timeout=300).stdout.decode().strip()
-    assert out == bytes(G.load("bb_nt_200")["newick"]).decode().strip()
+    for flags, key in (([], "newick_support"), (["-nosupport"], "newick")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "nj_tree.py"), fa] + flags, check=True,
+                             stdout=subprocess.PIPE, timeout=300).stdout.decode().strip()
+        assert out == bytes(G.load("bb_nt_200")[key]).decode().strip()
 
 
 def test_amino_acid_alignment_with_distance_matrix_end_to_end():
@@ -106,3 +112,5 @@ def test_amino_acid_alignment_with_distance_matrix_end_to_end():
     names = ["s%d" % k for k in range(len(d["codes"]))]
     assert nj_newick(make, d["codes"], names, scoredist=True) == bytes(d["nj_newick"]).decode()
     assert nj_newick(make, d["codes"], names, scoredist=True, me_lengths=True) == bytes(d["newick"]).decode().strip()
+    assert nj_newick(make, d["codes"], names, scoredist=True, me_lengths=True, n_bootstrap=1000) == \
+        bytes(d["newick_support"]).decode().strip()

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""FASTA (nucleotides) -> Newick on one MI355X: the tree `VeryFastTree -nt [-fastest] -noml -nome -nosupport` prints.
+"""FASTA (nucleotides) -> Newick on one MI355X: the tree `VeryFastTree -nt [-fastest] -noml -nome [-nosupport]` prints.
 
-    python tools/nj_tree.py in.fasta [-fastest] [-double] [-nj-lengths] > tree.nwk
+    python tools/nj_tree.py in.fasta [-fastest] [-double] [-nosupport] [-nj-lengths] > tree.nwk
 
 Neighbour joining with top hits on the device (veryfasttree_amd/host/NJDriver.h), the root, minimum-evolution branch
-lengths (updateBranchLengths) and printNJ; -nj-lengths keeps the NJ branch lengths (the reference's "NJ" log line).
+lengths (updateBranchLengths), local-bootstrap supports (1000 resamples, reliabilityNJ) and printNJ; -nj-lengths keeps
+the NJ branch lengths and prints no supports (the reference's "NJ" log line).
 Sequence normalisation and uniquify follow Alignment.cpp:453-526 (U -> T, '.' -> '-', duplicates by sequence string in
 first-occurrence order)."""
 import os, sys
@@ -38,6 +39,7 @@ def main():
     if not args or args[0].startswith("-"):
         sys.exit(__doc__)
     fastest, double, nj_len = "-fastest" in args, "-double" in args, "-nj-lengths" in args
+    n_boot = 0 if ("-nosupport" in args or nj_len) else 1000
     names, seqs = read_fasta(args[0])
     if len({len(s) for s in seqs}) != 1:
         sys.exit("sequences have different lengths: not an alignment")
@@ -60,7 +62,7 @@ def main():
         sys.exit("fewer than 16 unique sequences: the top-hits heuristic this driver implements is off there")
     dt = np.float64 if double else np.float32
     tree = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
-                     dtype=dt, me_lengths=not nj_len, unique=(np.array(unique_first, np.int64), aln_next))
+                     dtype=dt, me_lengths=not nj_len, unique=(np.array(unique_first, np.int64), aln_next), n_bootstrap=n_boot)
     print(tree)
 
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_set_shard", "vft_merge_hits", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
-    "vft_join_nodes", "vft_profile_distances", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
+    "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
 ]
 
 
@@ -108,7 +108,7 @@ def uniquify(codes):
 
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
-              unique=None, scoredist=False):
+              unique=None, scoredist=False, n_bootstrap=0):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -132,7 +132,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     olen = I64(0)
     err = C.create_string_buffer(512)
     rc = lib.vft_nj_newick(ops.ctx, _ptr(codes), I64(n), I64(L), I32(np.dtype(dtype).itemsize), C.byref(opt),
-                           I32(1 if me_lengths else 0), _ptr(unique_first), _ptr(aln_next), I64(len(codes_all)), blob, out, I64(cap),
+                           I32(1 if me_lengths else 0), I32(n_bootstrap), _ptr(unique_first), _ptr(aln_next), I64(len(codes_all)), blob, out, I64(cap),
                            C.byref(olen), err, I32(512))
     if rc != 0:
         raise VftError(err.value.decode() or "vft_nj_newick failed")

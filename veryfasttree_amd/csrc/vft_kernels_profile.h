@@ -469,3 +469,86 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REA
         for (int k = 0; k < 4; k++) A.outF[p * 4 + k] = f[k];
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Local-bootstrap support of the split (A,B)|(C,D) around an internal node (splitSupport, NJ.tcc:607-702): the six
+// pairwise distances of the quartet are recomputed over nBoot column resamples (the same resamples for every node)
+// and the split counts as supported when it beats both alternatives.  One workgroup per node: its threads first
+// compute the per-column weights and weighted distance pieces of the six pairs into LDS, then every thread walks
+// whole resamples (the sums are in sample order, in double, as in the reference).  colT is the resample table
+// transposed, [nPos][nBoot], so that the threads of a workgroup read it coalesced.
+// The decision `support1 > 0 && support2 > 0` goes through log() (logCorrect), and the device's log and glibc's differ
+// in the last bit now and then: resamples whose margins are within `eps` of zero are NOT decided here but appended to
+// `flagged` (node index + the six uncorrected distances) for the host to decide with its own libm, so that the counts
+// equal the reference's exactly.  counts[k] = resamples decided "supported" on the device.
+#define VFT_SUPPORT_WG 256
+#define VFT_SUPPORT_REC 7   // doubles per flagged record
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_SUPPORT_WG) void k_split_support(Arena<REAL> A, const int64_t *nA, const int64_t *nB,
+                                                                  const int64_t *nC, const int64_t *nD, int64_t n,
+                                                                  const int32_t *colT, int32_t nBoot, int32_t scoredist,
+                                                                  double eps, unsigned int *counts,
+                                                                  unsigned int *nFlagged, double *flagged,
+                                                                  unsigned int flagCap) {
+    extern __shared__ __attribute__((aligned(16))) double spLds[];   // [6][nPos] pieces, then [6][nPos] weights
+    __shared__ unsigned int nSupport;
+    const int64_t k = blockIdx.x;
+    if (k >= n) return;
+    const int64_t nPos = A.d.nPos;
+    double *sP = spLds, *sW = spLds + 6 * nPos;
+    if (threadIdx.x == 0) nSupport = 0;
+    const int64_t q[4] = {nA[k], nB[k], nC[k], nD[k]};
+    for (int64_t p = threadIdx.x; p < nPos; p += blockDim.x) {
+        Col<REAL, NC> c[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) vft_load_col<REAL, NC>(A, q[e], p, c[e]);
+        int j = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = x + 1; y < 4; y++, j++) {   // qAB, qAC, qAD, qBC, qBD, qCD
+                const REAL ww = c[x].w * c[y].w;      // numeric_t product, NJ.tcc:624-629
+                const double w = (double) ww;
+                sW[j * nPos + p] = w;
+                sP[j * nPos + p] = w * vft_piece<REAL, NC>(A, c[x], c[y], nullptr);
+            }
+    }
+    __syncthreads();
+    for (int32_t b = threadIdx.x; b < nBoot; b += blockDim.x) {
+        double totp[6] = {0, 0, 0, 0, 0, 0}, totw[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t i = 0; i < nPos; i++) {
+            const int32_t col = colT[i * nBoot + b];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                totp[j] += sP[j * nPos + col];
+                totw[j] += sW[j * nPos + col];
+            }
+        }
+        double raw[6], d[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double x = totw[j] > 0.01 ? totp[j] / totw[j] : 3.0;
+            raw[j] = x;
+            // logCorrect, NJ.tcc:322-330
+            if (scoredist) x = x < 0.99 ? -1.3 * log(1.0 - x) : 3.0;
+            else x = x < 0.74 ? -0.75 * log(1.0 - x * 4.0 / 3.0) : 3.0;
+            d[j] = x < 3.0 ? x : 3.0;
+        }
+        const double support1 = d[1] + d[4] - d[0] - d[5];   // AC + BD - AB - CD
+        const double support2 = d[2] + d[3] - d[0] - d[5];   // AD + BC - AB - CD
+        if (fabs(support1) < eps || fabs(support2) < eps) {
+            const unsigned int slot = atomicAdd(nFlagged, 1u);
+            if (slot < flagCap) {
+                double *rec = flagged + (size_t) slot * VFT_SUPPORT_REC;
+                rec[0] = (double) k;
+#pragma unroll
+                for (int j = 0; j < 6; j++) rec[1 + j] = raw[j];
+            }
+        } else if (support1 > 0 && support2 > 0) {
+            atomicAdd(&nSupport, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[k] = nSupport;
+}

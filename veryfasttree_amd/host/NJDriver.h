@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/vft_hip.h"
+#include "KnuthRng.h"
 
 namespace veryfasttree {
 
@@ -170,6 +171,77 @@ namespace veryfasttree {
             branchlength[top[2]] = (REAL) ((d02 + d12 - d01) / 2);
         }
 
+        /* up-profiles of all internal nodes on the device (node X -> id X + nSeqs), breadth first from the root:
+           one vft_average_profiles per depth (getUpProfile, NJ.tcc:3382-3434, useML = false, -nj weighting) */
+        void ensureUpProfiles() {
+            if (upReady) return;
+            if (root < 0) throw std::invalid_argument("NJDriver: up-profiles before finishRoot");
+            auto isInternal = [&](int64_t v) { return v >= nSeqs && v != root; };
+            chkT("vft_set_max_node", [&]() { return vft_set_max_node(ctx, maxnode + nSeqs); });
+            std::vector<int64_t> level;
+            for (int k = 0; k < 3; k++)
+                if (isInternal(rootChild[k])) level.push_back(rootChild[k]);
+            while (!level.empty()) {
+                std::vector<int64_t> out, a, b, next;
+                for (int64_t x: level) {
+                    int64_t cd[2];
+                    quartetCD(x, cd);
+                    out.push_back(x + nSeqs);
+                    a.push_back(cd[0]);
+                    b.push_back(cd[1]);
+                    if (isInternal(child0[x])) next.push_back(child0[x]);
+                    if (isInternal(child1[x])) next.push_back(child1[x]);
+                }
+                chkT("vft_average_profiles", [&]() { return vft_average_profiles(ctx, (int64_t) out.size(), out.data(), a.data(), b.data(), nullptr); });
+                level.swap(next);
+            }
+            upReady = true;
+        }
+
+        /* C and D of setupABCD (NJ.tcc:1942-1975) for node x: the two other children of the root, or the sibling and
+           the up-profile of the parent */
+        void quartetCD(int64_t x, int64_t cd[2]) const {
+            const int64_t p = parent[x];
+            if (p == root) {
+                int n = 0;
+                for (int k = 0; k < 3; k++)
+                    if (rootChild[k] != x) cd[n++] = rootChild[k];
+            } else {
+                cd[0] = child0[p] == x ? child1[p] : child0[p];
+                cd[1] = p + nSeqs;
+            }
+        }
+
+        /* reliabilityNJ (NJ.tcc:3191-3238): local-bootstrap support of every internal split from nBootstrap column
+           resamples drawn from Knuth's generator (resampleColumns, NJ.tcc:705-727); all nodes in one device call */
+        void computeSupports(int32_t nBootstrap) {
+            if (nSeqs <= 3 || nBootstrap <= 0) return;
+            ensureUpProfiles();
+            KnuthRng rng;
+            std::vector<int32_t> col((size_t) nBootstrap * nPos);
+            for (size_t t = 0; t < col.size(); t++) {
+                int64_t pos = (int64_t) (rng.rand() * nPos);
+                if (pos < 0) pos = 0;
+                else if (pos == nPos) pos = nPos - 1;
+                col[t] = (int32_t) pos;
+            }
+            std::vector<int64_t> nodes, a, b, c, d;
+            for (int64_t v = nSeqs; v < maxnode; v++) {
+                if (v == root) continue;
+                int64_t cd[2];
+                quartetCD(v, cd);
+                nodes.push_back(v);
+                a.push_back(child0[v]);
+                b.push_back(child1[v]);
+                c.push_back(cd[0]);
+                d.push_back(cd[1]);
+            }
+            std::vector<double> sup(nodes.size());
+            chkT("vft_split_supports", [&]() { return vft_split_supports(ctx, (int64_t) nodes.size(), a.data(), b.data(), c.data(), d.data(), nBootstrap, col.data(), sup.data()); });
+            support.assign((size_t) maxnodes, -1.0);
+            for (size_t t = 0; t < nodes.size(); t++) support[(size_t) nodes[t]] = sup[t];
+        }
+
         /* updateBranchLengths (NJ.tcc:6514-6595) on the finished NJ topology, as the pipeline does before it prints a
            minimum-evolution tree (VeryFastTreeImpl.tcc:205-213): every branch length from log-corrected profile
            distances between the node's children / sibling / up-profile (correctedPairDistances NJ.tcc:1460-1488,
@@ -181,7 +253,6 @@ namespace veryfasttree {
         void updateBranchLengths() {
             if (root < 0) throw std::invalid_argument("NJDriver::updateBranchLengths before finishRoot");
             const int64_t upOff = nSeqs;
-            auto isInternal = [&](int64_t v) { return v >= nSeqs && v != root; };
             auto up = [&](int64_t v) { return v + upOff; };
             auto siblingOf = [&](int64_t v) { const int64_t p = parent[v]; return child0[p] == v ? child1[p] : child0[p]; };
             auto rootSibs = [&](int64_t v, int64_t sibs[2]) {
@@ -189,30 +260,7 @@ namespace veryfasttree {
                 for (int k = 0; k < 3; k++)
                     if (rootChild[k] != v) sibs[n++] = rootChild[k];
             };
-            chkT("vft_set_max_node", [&]() { return vft_set_max_node(ctx, maxnode + upOff); });
-            /* 1. up-profiles, breadth first from the root */
-            std::vector<int64_t> level;
-            for (int k = 0; k < 3; k++)
-                if (isInternal(rootChild[k])) level.push_back(rootChild[k]);
-            while (!level.empty()) {
-                std::vector<int64_t> out, a, b, next;
-                for (int64_t x: level) {
-                    out.push_back(up(x));
-                    if (parent[x] == root) {
-                        int64_t sibs[2];
-                        rootSibs(x, sibs);
-                        a.push_back(sibs[0]);
-                        b.push_back(sibs[1]);
-                    } else {
-                        a.push_back(siblingOf(x));
-                        b.push_back(up(parent[x]));
-                    }
-                    if (isInternal(child0[x])) next.push_back(child0[x]);
-                    if (isInternal(child1[x])) next.push_back(child1[x]);
-                }
-                chkT("vft_average_profiles", [&]() { return vft_average_profiles(ctx, (int64_t) out.size(), out.data(), a.data(), b.data(), nullptr); });
-                level.swap(next);
-            }
+            ensureUpProfiles();
             /* 2. every distance of every branch, in correctedPairDistances' order (i < j over A, B, C[, D]) */
             std::vector<int64_t> pi, pj, firstPair((size_t) maxnode + 1, 0);
             for (int64_t v = 0; v < maxnode; v++) {
@@ -314,8 +362,11 @@ namespace veryfasttree {
                 } else if (end) {
                     if (node == root) out += ")";
                     else {
+                        if (!support.empty()) {   /* bShowSupport, NJ.tcc:2776-2777 */
+                            snprintf(buf, sizeof buf, ")%.3f:", support[(size_t) node]);
+                            out += buf;
+                        } else out += "):";
                         snprintf(buf, sizeof buf, fmt, (double) branchlength[(size_t) node]);
-                        out += "):";
                         out += buf;
                     }
                 } else {
@@ -336,6 +387,8 @@ namespace veryfasttree {
 
     private:
         int64_t root = -1, rootChild[3] = {-1, -1, -1};
+        bool upReady = false;
+        std::vector<double> support;   /* per node, filled by computeSupports */
 
         struct Besthit {
             int64_t i = -1, j = -1;

@@ -33,12 +33,13 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
 
 template<typename REAL>
 static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
-                           bool meLengths, const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll,
-                           const char *names) {
+                           bool meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext,
+                           int64_t nAll, const char *names) {
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
     drv.run(-1);
     drv.finishRoot();
     if (meLengths) drv.updateBranchLengths();
+    if (nBootstrap > 0) drv.computeSupports(nBootstrap);
     drv.report();
     std::vector<std::string> nm;
     const char *p = names;
@@ -50,12 +51,12 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
 }
 
 extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
-                             const vft_nj_options *opt, int32_t meLengths, const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll,
+                             const vft_nj_options *opt, int32_t meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll,
                              const char *names, char *out, int64_t outCap, int64_t *outLen, char *err, int32_t errLen) {
     if (!ctx || !codes || !uniqueFirst || !alnNext || !names || !outLen) return VFT_ERR_INVALID;
     try {
-        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, uniqueFirst, alnNext, nAll, names)
-                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, uniqueFirst, alnNext, nAll, names);
+        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names)
+                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names);
         *outLen = (int64_t) t.size();
         if (out && outCap > (int64_t) t.size()) memcpy(out, t.c_str(), t.size() + 1);
         else if (out) return VFT_ERR_INVALID;   /* outLen tells how much is needed */
