@@ -1398,21 +1398,19 @@ extern "C" int vft_split_supports(vft_ctx *c, int64_t n, const int64_t *a, const
             if (v < 0 || v >= nPos) return fail(c, VFT_ERR_INVALID, "vft_split_supports: column index out of range");
             colT[(size_t) i * nBoot + r] = v;
         }
-    const size_t idB = (((size_t) n * 8) + 255) & ~(size_t) 255, colB = ((colT.size() * 4) + 255) & ~(size_t) 255;
-    const size_t cntB = (((size_t) n * 4) + 255) & ~(size_t) 255;
-    const unsigned int flagCap = (unsigned int) std::min<size_t>((size_t) n * 64 + 65536, (size_t) 1 << 24);
+    // Nodes go in chunks small enough that even if EVERY resample of every node of a chunk were a near-tie the flagged
+    // buffer could not overflow (zero-distance quartets of near-duplicate sequences tie in all their resamples).
+    const unsigned int flagCap = 1u << 22;   // 4M records = 235 MB
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t) flagCap / nBoot));
+    const size_t idB = (((size_t) chunk * 8) + 255) & ~(size_t) 255, colB = ((colT.size() * 4) + 255) & ~(size_t) 255;
+    const size_t cntB = (((size_t) chunk * 4) + 255) & ~(size_t) 255;
     const size_t flagB = (size_t) flagCap * VFT_SUPPORT_REC * 8;
     if (int r = ensure_scratch(c, 4 * idB + colB + cntB + 256 + flagB + 512)) return r;
     char *s = (char *) c->scratch;
-    HIPCHK(c, hipMemcpyAsync(s, a, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s + idB, b, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s + 2 * idB, cc, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s + 3 * idB, d, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 4 * idB, colT.data(), colT.size() * 4, hipMemcpyHostToDevice, c->stream));
     unsigned int *dCnt = (unsigned int *) (s + 4 * idB + colB);
     unsigned int *dNFlag = (unsigned int *) (s + 4 * idB + colB + cntB);
     double *dFlag = (double *) (s + 4 * idB + colB + cntB + 256);
-    HIPCHK(c, hipMemsetAsync(dNFlag, 0, 4, c->stream));
     const int32_t scoredist = (c->cfg.n_codes == 4 && !c->hasDm) ? 0 : 1;   // logCorrect's choice, NJ.tcc:324
     // margins below eps are decided on the host with its own libm (the device's log may differ in the last bit);
     // a distance is < 3, so errors of a few 1e-16 cannot reach 1e-9
@@ -1420,34 +1418,44 @@ extern "C" int vft_split_supports(vft_ctx *c, int64_t n, const int64_t *a, const
     VFT_DISPATCH(c, {
         if (lds > (48u << 10))
             HIPCHK(c, hipFuncSetAttribute((const void *) k_split_support<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        launch((k_split_support<REAL, NC>), dim3((unsigned) n), dim3(VFT_SUPPORT_WG), lds, c->stream, arena<REAL>(c),
-               (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB), (const int64_t *) (s + 3 * idB),
-               n, (const int32_t *) (s + 4 * idB), nBoot, scoredist, eps, dCnt, dNFlag, dFlag, flagCap);
     });
-    LAUNCHCHK(c);
-    std::vector<unsigned int> cnt((size_t) n);
-    unsigned int nFlag = 0;
-    HIPCHK(c, hipMemcpyAsync(cnt.data(), dCnt, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&nFlag, dNFlag, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nFlag > flagCap) return fail(c, VFT_ERR_STATE, "vft_split_supports: %u near-tie resamples exceed the buffer of %u", nFlag, flagCap);
-    if (nFlag) {
-        std::vector<double> rec((size_t) nFlag * VFT_SUPPORT_REC);
-        HIPCHK(c, hipMemcpy(rec.data(), dFlag, rec.size() * 8, hipMemcpyDeviceToHost));
-        for (unsigned int f = 0; f < nFlag; f++) {
-            const double *r = &rec[(size_t) f * VFT_SUPPORT_REC];
-            double dd[6];
-            for (int j = 0; j < 6; j++) {   // logCorrect (NJ.tcc:322-330) with the host's log
-                double x = r[1 + j];
-                if (scoredist) x = x < 0.99 ? -1.3 * std::log(1.0 - x) : 3.0;
-                else x = x < 0.74 ? -0.75 * std::log(1.0 - x * 4.0 / 3.0) : 3.0;
-                dd[j] = x < 3.0 ? x : 3.0;
+    std::vector<unsigned int> cnt((size_t) chunk);
+    std::vector<double> rec;
+    for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+        const int64_t m = std::min<int64_t>(chunk, n - k0);
+        HIPCHK(c, hipMemcpyAsync(s, a + k0, (size_t) m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + idB, b + k0, (size_t) m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + 2 * idB, cc + k0, (size_t) m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + 3 * idB, d + k0, (size_t) m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(dNFlag, 0, 4, c->stream));
+        VFT_DISPATCH(c, (launch((k_split_support<REAL, NC>), dim3((unsigned) m), dim3(VFT_SUPPORT_WG), lds, c->stream,
+                                arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
+                                (const int64_t *) (s + 3 * idB), m, (const int32_t *) (s + 4 * idB), nBoot, scoredist, eps, dCnt,
+                                dNFlag, dFlag, flagCap)));
+        LAUNCHCHK(c);
+        unsigned int nFlag = 0;
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), dCnt, (size_t) m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&nFlag, dNFlag, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nFlag > flagCap) return fail(c, VFT_ERR_STATE, "vft_split_supports: flagged-resample buffer overflow (%u)", nFlag);
+        if (nFlag) {
+            rec.resize((size_t) nFlag * VFT_SUPPORT_REC);
+            HIPCHK(c, hipMemcpy(rec.data(), dFlag, rec.size() * 8, hipMemcpyDeviceToHost));
+            for (unsigned int f = 0; f < nFlag; f++) {
+                const double *r = &rec[(size_t) f * VFT_SUPPORT_REC];
+                double dd[6];
+                for (int j = 0; j < 6; j++) {   // logCorrect (NJ.tcc:322-330) with the host's log
+                    double x = r[1 + j];
+                    if (scoredist) x = x < 0.99 ? -1.3 * std::log(1.0 - x) : 3.0;
+                    else x = x < 0.74 ? -0.75 * std::log(1.0 - x * 4.0 / 3.0) : 3.0;
+                    dd[j] = x < 3.0 ? x : 3.0;
+                }
+                const double s1 = dd[1] + dd[4] - dd[0] - dd[5], s2 = dd[2] + dd[3] - dd[0] - dd[5];
+                if (s1 > 0 && s2 > 0) cnt[(size_t) r[0]]++;
             }
-            const double s1 = dd[1] + dd[4] - dd[0] - dd[5], s2 = dd[2] + dd[3] - dd[0] - dd[5];
-            if (s1 > 0 && s2 > 0) cnt[(size_t) r[0]]++;
         }
+        for (int64_t k = 0; k < m; k++) support[k0 + k] = (double) cnt[(size_t) k] / (double) nBoot;
     }
-    for (int64_t k = 0; k < n; k++) support[k] = (double) cnt[(size_t) k] / (double) nBoot;
     return VFT_OK;
 }
 
