@@ -95,6 +95,10 @@ BLACKBOX_CASES = [
     ("bb_nt_1500", ["-nt"], 1500, 80, 4, 0.03, 0.01, 23),
     ("bb_nt_300_double", ["-nt", "-double-precision"], 300, 90, 4, 0.05, 0.03, 24),
     ("bb_aa_300", [], 300, 80, 20, 0.10, 0.03, 25),   # protein: BLOSUM45-derived distance matrix (the default)
+    # tiny inputs: no top hits (m < 4), the visible-set search of fastNJ (NJ.tcc:2846-2852, 3049-3090, 3686-3744)
+    ("bb_nt_10", ["-nt"], 10, 60, 4, 0.15, 0.02, 26),
+    ("bb_nt_5", ["-nt"], 5, 40, 4, 0.2, 0.0, 27),
+    ("bb_nt_12_fastest", ["-nt", "-fastest"], 12, 50, 4, 0.15, 0.05, 28),
 ]
 
 

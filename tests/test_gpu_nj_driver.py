@@ -114,3 +114,22 @@ def test_amino_acid_alignment_with_distance_matrix_end_to_end():
     assert nj_newick(make, d["codes"], names, scoredist=True, me_lengths=True) == bytes(d["newick"]).decode().strip()
     assert nj_newick(make, d["codes"], names, scoredist=True, me_lengths=True, n_bootstrap=1000) == \
         bytes(d["newick_support"]).decode().strip()
+
+
+@pytest.mark.parametrize("name,fastest", [("bb_nt_10", False), ("bb_nt_5", False), ("bb_nt_12_fastest", True)])
+def test_tiny_inputs_without_top_hits(name, fastest):
+    """Fewer than 13 sequences: fastNJ runs without top hits (NJ.tcc:2827-2834) - every node keeps its best hit, found by
+    one-vs-all sweeps, with hill climbing unless -fastest.  Join order and all three tree strings."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick, nj_run
+    d = G.load(name)
+    codes = unique_codes(d["codes"])
+    assert len(codes) == len(d["codes"])
+    joins, crit = nj_run(HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32), codes, fastest=fastest)
+    assert np.array_equal(joins, d["joins"])
+    names = ["s%d" % k for k in range(len(codes))]
+    make = lambda n, L: HipProfileOps(n, L, 4, np.float32, max_nodes=3 * n)
+    assert nj_newick(make, codes, names, fastest=fastest) == bytes(d["nj_newick"]).decode()
+    assert nj_newick(make, codes, names, fastest=fastest, me_lengths=True) == bytes(d["newick"]).decode().strip()
+    assert nj_newick(make, codes, names, fastest=fastest, me_lengths=True, n_bootstrap=1000) == \
+        bytes(d["newick_support"]).decode().strip()

@@ -58,8 +58,8 @@ def main():
         lut[ord(ch)] = i
     codes_all = np.stack([lut[np.frombuffer(s.encode("ascii", "replace"), np.uint8)] for s in seqs])
     n_unique = len(unique_first)
-    if n_unique < 16:
-        sys.exit("fewer than 16 unique sequences: the top-hits heuristic this driver implements is off there")
+    if n_unique < 3:
+        sys.exit("fewer than 3 unique sequences")
     dt = np.float64 if double else np.float32
     tree = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
                      dtype=dt, me_lengths=not nj_len, unique=(np.array(unique_first, np.int64), aln_next), n_bootstrap=n_boot)

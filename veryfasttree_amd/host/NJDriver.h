@@ -90,16 +90,22 @@ namespace veryfasttree {
         }
 
         const std::vector<Join> &run(int64_t maxJoins = -1) {
+            if (nSeqs < 3) throw std::invalid_argument("NJDriver: fewer than 3 sequences");
             int64_t m = opt.tophitsMult > 0 ? (int64_t) (0.5 + opt.tophitsMult * std::sqrt((double) nSeqs)) : 0;
-            if (m < 4 || 2 * m >= nSeqs)
-                throw std::invalid_argument("NJDriver: top-hits are off for this size; the visible-set path is not ported");
-            initTopHits(m);
-            setAllLeafTopHits();
-            resetTopVisible(nSeqs);
+            /* NJ.tcc:2827-2834: no top hits on tiny inputs; the visible set then holds every node's best hit */
+            const bool noTop = m < 4 || 2 * m >= nSeqs;
+            if (noTop) {
+                visibleAll.assign((size_t) maxnodes, Besthit());
+                for (int64_t v = 0; v < nSeqs; v++) visibleAll[(size_t) v] = bestHitOf(v, nSeqs, nullptr);   /* NJ.tcc:2849-2851 */
+            } else {
+                initTopHits(m);
+                setAllLeafTopHits();
+                resetTopVisible(nSeqs);
+            }
             int64_t nActiveReset = nSeqs;
             for (int64_t nActive = nSeqs; nActive > 3; nActive--) {
                 if (maxJoins >= 0 && (int64_t) joins.size() >= maxJoins) break;
-                Besthit join = topHitNJSearch(nActive);
+                Besthit join = noTop ? fastNJSearch(nActive) : topHitNJSearch(nActive);
                 /* setOutDistance(i), setOutDistance(j), setDistCriterion(join) (NJ.tcc:2897-2901) as ONE pair list of
                    length 1 with nDiffAllow = 0: the lazy refresh then fires for every stamp != nActive, i.e. it is the
                    unconditional setOutDistance, and the pair kernel follows in the same call */
@@ -138,7 +144,8 @@ namespace veryfasttree {
                     const REAL dd = diameter[newnode] - diameter[i] - diameter[j];
                     totdiam += dd;
                 }
-                topHitJoin(newnode, nActive - 1);
+                if (noTop) visibleJoin(newnode, nActive - 1);
+                else topHitJoin(newnode, nActive - 1);
             }
             return joins;
         }
@@ -1096,6 +1103,81 @@ namespace veryfasttree {
                 if (cand[t].criterion < best.criterion) best = cand[t];
             }
             return best;
+        }
+
+        /* ---- tiny inputs: no top hits, the visible set of every node (NJ.tcc:2846-2852, 3049-3090, 3686-3744) */
+        std::vector<Besthit> visibleAll;
+
+        /* setBestHit (NJ.tcc:3571-3646): the best join partner of `node` (lowest criterion, lowest id on ties, never
+           itself); all: every active node's hit against `node`, indexed by id (besthitNew) */
+        Besthit bestHitOf(int64_t node, int64_t nActive, std::vector<Besthit> *all) {
+            const int32_t k = (int32_t) std::min<int64_t>(maxnode, 8192);
+            std::vector<Besthit> hits = sweep(node, nActive, k);
+            Besthit best;
+            best.i = node;
+            best.j = -1;
+            if (all) all->assign((size_t) maxnodes, Besthit());
+            for (const Besthit &h: hits) {
+                if (h.j < 0) continue;
+                if (all) (*all)[(size_t) h.j] = h;
+                if (h.j == node || parent[h.j] >= 0) continue;
+                if (best.j < 0 || h.criterion < best.criterion || (h.criterion == best.criterion && h.j < best.j)) {
+                    best.j = h.j;
+                    best.dist = h.dist;
+                    best.weight = h.weight;
+                    best.criterion = h.criterion;
+                }
+            }
+            return best;
+        }
+
+        Besthit fastNJSearch(int64_t nActive) { /* NJ.tcc:3686-3744 */
+            Besthit join;
+            for (int64_t v = 0; v < maxnode; v++) {
+                Besthit &b = visibleAll[(size_t) v];
+                if (b.j < 0 || parent[v] >= 0 || parent[b.j] >= 0) continue;
+                setCriterion(nActive, b);
+                if (b.criterion < join.criterion) join = b;
+            }
+            if (!opt.fastest) {
+                bool changed;
+                do {
+                    changed = false;
+                    visibleAll[(size_t) join.i] = bestHitOf(join.i, nActive, nullptr);
+                    if (visibleAll[(size_t) join.i].j != join.j) changed = true;
+                    join.j = visibleAll[(size_t) join.i].j;
+                    join.weight = visibleAll[(size_t) join.i].weight;
+                    join.dist = visibleAll[(size_t) join.i].dist;
+                    join.criterion = visibleAll[(size_t) join.i].criterion;
+                    visibleAll[(size_t) join.j] = bestHitOf(join.j, nActive, nullptr);
+                    if (visibleAll[(size_t) join.j].j != join.i) {
+                        changed = true;
+                        join.i = visibleAll[(size_t) join.j].j;
+                        join.weight = visibleAll[(size_t) join.j].weight;
+                        join.dist = visibleAll[(size_t) join.j].dist;
+                        join.criterion = visibleAll[(size_t) join.j].criterion;
+                    }
+                } while (changed);
+            }
+            return join;
+        }
+
+        void visibleJoin(int64_t newnode, int64_t nActive) { /* NJ.tcc:3049-3090; nActive = the count after the join */
+            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, 0, nullptr, nActive, totdiam); });
+            pending = true;
+            std::vector<Besthit> fromNew;
+            visibleAll[(size_t) newnode] = bestHitOf(newnode, nActive, &fromNew);
+            for (int64_t v = 0; v < maxnode; v++) {
+                if (parent[v] >= 0 || v == newnode) continue;
+                Besthit &b = visibleAll[(size_t) v];
+                const int64_t old = b.j;
+                if (parent[old] < 0) setCriterion(nActive, b);
+                if (parent[old] >= 0 || fromNew[(size_t) v].criterion < b.criterion) {
+                    b.j = newnode;
+                    b.dist = fromNew[(size_t) v].dist;
+                    b.criterion = fromNew[(size_t) v].criterion;
+                }
+            }
         }
 
         Besthit topHitNJSearch(int64_t nActive) { /* NJ.tcc:4137-4262 */
