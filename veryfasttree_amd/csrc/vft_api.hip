@@ -852,7 +852,6 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
     if (bytes <= (48u << 10)) return VFT_OK;
     if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging (%lld columns, limit 10240)", (long long) c->d.nPos);
     VFT_DISPATCH(c, {
-        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));

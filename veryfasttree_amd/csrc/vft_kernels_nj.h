@@ -861,26 +861,6 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_wave(Arena<REAL> A, SweepArgs 
     vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
 }
 
-// setDistCriterion over an explicit pair list.  Out-distances must have been refreshed by k_pairs_refresh first.
-template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_WG) void k_pairs(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
-                                                  int64_t nActive, REAL *dist, REAL *weight, REAL *crit) {
-    extern __shared__ __attribute__((aligned(16))) double pwLds[];
-    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
-    if (t >= n) return;
-    const int64_t i = pi[t], j = pj[t];
-    REAL d, w;
-    vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
-    if ((threadIdx.x & 63) != 0) return;
-    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
-        const REAL dd = A.diameter[i] + A.diameter[j];
-        d = d - dd;
-    }
-    dist[t] = d;
-    weight[t] = w;
-    crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], nActive);
-}
-
 // setDistCriterion over an explicit pair list whose out-distances k_pairs_refresh has brought up to date: distance and
 // criterion per pair, results straight into (mapped) memory; the last wave to finish publishes `seq` to the host's
 // flag, which replaces a trailing signal kernel (the small lists of the join loop are latency-bound: every launch
