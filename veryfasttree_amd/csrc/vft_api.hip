@@ -73,6 +73,9 @@ struct vft_ctx {
     size_t ioCap = 8u << 20, ioHead = 0;
     unsigned long long *hFlag = nullptr, *dFlag = nullptr, signalSeq = 0;
     unsigned int *doneCtr = nullptr;   // completion counter of k_pairs_fused
+    // Upper bound of nOutActive over the nodes of the shard (host bookkeeping; VFT_STAMP_UNKNOWN = no bound): lets
+    // vft_sweep skip its lazy out-distance pre-pass when provably no target can be stale.
+    int64_t maxStamp = (int64_t) 1 << 62;
     int pwWaves = 4;                   // items (waves) per workgroup of the wave-per-item kernels: 4, or fewer when the
                                        // LDS staging of a long alignment would not fit (raise_pair_kernel_lds)
     // host-mapped mirrors of outDist / nOutActive, written by the kernels that refresh them
@@ -617,7 +620,10 @@ extern "C" int vft_set_out_distances(vft_ctx *c, int64_t first, int64_t count, c
     }
     if (nOutActive) {
         std::vector<int32_t> n32((size_t) count);
-        for (int64_t i = 0; i < count; i++) n32[(size_t) i] = clamp_i32(nOutActive[i]);
+        for (int64_t i = 0; i < count; i++) {
+            n32[(size_t) i] = clamp_i32(nOutActive[i]);
+            if ((int64_t) n32[(size_t) i] > c->maxStamp) c->maxStamp = n32[(size_t) i];
+        }
         if (int r = store_range<int32_t>(c, c->nOutActive, nullptr, n32.data(), first, count)) return r;
         memcpy(c->hNOut + first, n32.data(), (size_t) count * 4);
     }
@@ -656,6 +662,7 @@ extern "C" int vft_join_nodes(vft_ctx *c, int64_t i, int64_t j, int64_t newnode,
     if (newnode >= c->maxnode) c->maxnode = newnode + 1;
     c->hParent[(size_t) i] = c->hParent[(size_t) j] = (int32_t) newnode;
     const int32_t stamp = clamp_i32(staleStamp);
+    if ((int64_t) stamp > c->maxStamp) c->maxStamp = stamp;
     // host side of the mirrors: no earlier kernel can touch a node that did not exist
     if (c->rs == 4) ((float *) c->hOutDist)[newnode] = 0.f;
     else ((double *) c->hOutDist)[newnode] = 0.0;
@@ -671,6 +678,7 @@ extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
         return fail(c, VFT_ERR_INVALID, "vft_set_shard: need 0 <= lo <= hi <= max_nodes and lo %% 64 == 0");
     c->shardLo = lo;
     c->shardHi = hi;
+    c->maxStamp = (int64_t) 1 << 62;   // the bound was about the previous range
     return VFT_OK;
 }
 
@@ -1030,6 +1038,12 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
         return VFT_OK;
     }
     if (s.hi <= s.lo) return VFT_OK;
+    // after this pass every active node of the shard carries a stamp of at most nActive (forced) / nActive + nDiffAllow
+    {
+        const int64_t bound = force ? nActive : nActive + nDiffAllow;
+        if (force) c->maxStamp = bound;
+        else if (bound < c->maxStamp) c->maxStamp = bound;
+    }
     const int64_t span = s.hi - s.lo;
     if (c->cfg.n_codes == 4 && !c->hasDm) {
         const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
@@ -1055,6 +1069,7 @@ extern "C" int vft_out_distances(vft_ctx *c, int64_t n, const int64_t *ids, int6
     if (!c || nActive < 2) return VFT_ERR_INVALID;
     if (ids) {
         if (n <= 0) return VFT_OK;
+        if (nActive > c->maxStamp) c->maxStamp = nActive;   // forced refreshes stamp the listed nodes with nActive
         if (n == 1) {
             if (ids[0] < 0 || ids[0] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_out_distances: bad node");
             SweepArgs s{};
@@ -1128,9 +1143,11 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         return fail(c, VFT_ERR_INVALID, "vft_sweep: bad arguments (query %lld, nActive %lld, k %d)", (long long) query,
                     (long long) nActive, (int) k);
     const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
-    // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098)
-    if (int r = launch_out_distances(c, nullptr, 0, nActive, nDiffAllow, totdiam, false)) return r;
-    {
+    // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098) - skipped when the
+    //    host's bookkeeping proves that nothing can be stale (seed after seed of setAllLeafTopHits, for instance)
+    if (c->maxStamp - nActive > nDiffAllow)
+        if (int r = launch_out_distances(c, nullptr, 0, nActive, nDiffAllow, totdiam, false)) return r;
+    if ((int64_t) c->hNOut[query] - nActive > nDiffAllow) {   // the mirror can only lag towards "staler"
         SweepArgs s{};
         s.nActive = nActive;
         s.nDiffAllow = nDiffAllow;
