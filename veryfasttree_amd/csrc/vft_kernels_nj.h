@@ -1191,6 +1191,9 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelectState *S, co
     }
 }
 
+// (Folding bestjoin + publication + the completion flag into the last workgroup of the rank sort, and the min/max
+//  reduction into the histogram kernel, were both tried: on this multi-XCD part every workgroup's agent-scope release
+//  fence costs an L2 write-back - the rank kernel went from 15 to 31 us - while a kernel boundary does it once.)
 // bestjoin (NJ.tcc:3625-3637): strict '<' while scanning ids upwards => the smallest id among the minimal criteria,
 // the query itself excluded.  Also publishes header + hits into the host-mapped result block: the host gets its
 // answer with one stream synchronisation and no DMA copy (a 32 KB hipMemcpy D2H goes through SDMA here and costs
