@@ -154,6 +154,17 @@ namespace veryfasttree {
 
         void setMaxNode(int64_t maxnode) { chk(vft_set_max_node(ctx, maxnode)); }
 
+        /* profileDist / seqDist over a pair list (NJ.tcc:1167-1190): raw distance and weight */
+        void profileDist(int64_t n, const int64_t *i, const int64_t *j, numeric_t *dist, numeric_t *weight) {
+            chk(vft_profile_distances(ctx, n, i, j, dist, weight));
+        }
+
+        /* splitSupport (NJ.tcc:607-702) for n quartets over nBoot column resamples (col: [nBoot][nPos]) */
+        void splitSupports(int64_t n, const int64_t *a, const int64_t *b, const int64_t *c, const int64_t *d, int32_t nBoot,
+                           const int32_t *col, double *support) {
+            chk(vft_split_supports(ctx, n, a, b, c, d, nBoot, col, support));
+        }
+
         /* the state change of one join (NJ.tcc:2904-2909, 3003-3007, 254) in one launch */
         void joinNodes(int64_t i, int64_t j, int64_t newnode, numeric_t diameter, int64_t staleStamp) {
             chk(vft_join_nodes(ctx, i, j, newnode, (double) diameter, staleStamp));
