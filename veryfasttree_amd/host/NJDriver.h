@@ -1253,7 +1253,11 @@ namespace veryfasttree {
             std::vector<Besthit> combined = hitsToBestHits(hits[c0], c0);
             std::vector<Besthit> fromC1 = hitsToBestHits(hits[c1], c1);
             combined.insert(combined.end(), fromC1.begin(), fromC1.end());
-            std::vector<Besthit> unique = uniqueBestHits(nActive, combined);
+            std::vector<Besthit> unique;
+            {
+                Section s2(this, "[host]   topHitJoin: uniqueBestHits (incl. device)");
+                unique = uniqueBestHits(nActive, combined);
+            }
             const int64_t nUnique = (int64_t) unique.size();
             hits[c0].clear();
             hits[c1].clear();
@@ -1286,10 +1290,19 @@ namespace veryfasttree {
             if (useUnique) {
                 if (second) hitSource[newnode] = hitSource[c0];
                 const int64_t nSave = std::min(nUnique, second ? q : m);
-                sortSaveBestHits(newnode, unique, nUnique, nSave);
+                {
+                    Section s2(this, "[host]   topHitJoin: sortSaveBestHits");
+                    sortSaveBestHits(newnode, unique, nUnique, nSave);
+                }
                 visible[newnode] = hits[newnode][0];
-                updateTopVisible(nActive, newnode, visible[newnode]);
-                updateVisible(nActive, unique, nSave);
+                {
+                    Section s2(this, "[host]   topHitJoin: updateTopVisible");
+                    updateTopVisible(nActive, newnode, visible[newnode]);
+                }
+                {
+                    Section s2(this, "[host]   topHitJoin: updateVisible (incl. device)");
+                    updateVisible(nActive, unique, nSave);
+                }
                 return;
             }
             /* refresh */
