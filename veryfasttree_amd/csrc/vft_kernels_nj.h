@@ -1091,9 +1091,9 @@ __global__ __launch_bounds__(VFT_WG) void k_select_collect(const REAL *crit, int
     const double vlo = S->lo, scale = S->scale;
     const unsigned long long prefix = S->prefix;
     const unsigned int shift = vft_level_shift(S->level), tb = S->threshBin;
-    for (int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x; j < hi; j += (int64_t) gridDim.x * VFT_WG) {
-        const REAL c = crit[j];
-        if (!(c < (REAL) 1e20)) continue;
+    const int64_t stride = (int64_t) gridDim.x * VFT_WG;
+    auto take = [&](int64_t j, REAL c) {
+        if (!(c < (REAL) 1e20)) return;
         const unsigned long long vk = vft_vk((double) c, vlo, scale);
         const unsigned long long up = vk >> (shift + VFT_DIGIT_BITS);
         if (up < prefix || (up == prefix && tb < VFT_NBINS && ((vk >> shift) & (VFT_NBINS - 1)) <= tb)) {
@@ -1104,7 +1104,16 @@ __global__ __launch_bounds__(VFT_WG) void k_select_collect(const REAL *crit, int
                 lid[slot] = (int32_t) j;
             }
         }
+    };
+    int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    for (; j + 3 * stride < hi; j += 4 * stride) {   // four independent loads in flight per thread
+        REAL c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = crit[j + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) take(j + u * stride, c[u]);
     }
+    for (; j < hi; j += stride) take(j, crit[j]);
     __syncthreads();
     const unsigned int n = lcount;
     if (n > VFT_CAND_CAP / 8) {
