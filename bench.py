@@ -122,28 +122,41 @@ def main():
 
     hit_dt = ops.hit_dtype
     if use_dist:
-        d_mine = torch.zeros(k * hit_dt.itemsize, dtype=torch.uint8, device="cuda")
-        d_all = torch.zeros(world * k * hit_dt.itemsize, dtype=torch.uint8, device="cuda" if backend == "nccl" else "cpu")
+        # per seed: this rank's k records, the ranks' lists all-gathered, the merged global list - all on the device
+        rec = k * hit_dt.itemsize
+        gdev = "cuda" if backend == "nccl" else "cpu"
+        d_mine = [torch.zeros(rec, dtype=torch.uint8, device="cuda") for _ in seeds]
+        d_all = [torch.zeros(world * rec, dtype=torch.uint8, device=gdev) for _ in seeds]
+        d_merged_all = torch.zeros(len(seeds) * rec, dtype=torch.uint8, device="cuda")
+        d_merged = [d_merged_all[s * rec:(s + 1) * rec] for s in range(len(seeds))]
+        h_merged = torch.empty(len(seeds) * rec, dtype=torch.uint8, pin_memory=True)
         ops.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def one_step():
         out = []
-        for q in seeds:
+        for s, q in enumerate(seeds):
             if not use_dist:
                 hits, _ = ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False)
+                out.append(hits)
+                continue
+            ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False,
+                           d_hits=d_mine[s].data_ptr(), want_hits=False)
+            if backend == "nccl":
+                # RCCL over xGMI: k records per rank; gather and merge are stream-ordered, the host moves on to the
+                # next seed's sweep and waits once per step
+                dist.all_gather_into_tensor(d_all[s], d_mine[s])
+                ops.merge_hits(d_all[s].data_ptr(), world, k, d_out=d_merged[s].data_ptr())
             else:
-                ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False,
-                               d_hits=d_mine.data_ptr(), want_hits=False)
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(d_all, d_mine)      # RCCL over xGMI: k records per rank
-                    gathered = d_all
-                else:
-                    torch.cuda.current_stream().synchronize()
-                    dist.all_gather_into_tensor(d_all, d_mine.cpu())
-                    gathered = d_all.cuda()
-                # merge on the device with the (criterion asc, id desc) rule; k records come back zero-copy
-                hits = ops.merge_hits(gathered.data_ptr(), world, k)
-            out.append(hits)
+                torch.cuda.current_stream().synchronize()
+                dist.all_gather_into_tensor(d_all[s], d_mine[s].cpu())
+                gathered = d_all[s].cuda()
+                ops.merge_hits(gathered.data_ptr(), world, k, d_out=d_merged[s].data_ptr())
+                torch.cuda.current_stream().synchronize()   # `gathered` must outlive the merge
+        if use_dist:
+            # merge on the device with the (criterion asc, id desc) rule; the lists come back once per step
+            h_merged.copy_(d_merged_all, non_blocking=True)   # one pinned copy per step for all seeds
+            torch.cuda.current_stream().synchronize()
+            out = [np.frombuffer(h_merged.numpy()[s * rec:(s + 1) * rec].tobytes(), dtype=hit_dt) for s in range(len(seeds))]
         return out
 
     def barrier():

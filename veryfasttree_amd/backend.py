@@ -338,8 +338,12 @@ class HipProfileOps:
     def device_free(self, addr):
         self._chk(self.lib.vft_device_free(self.ctx, P(addr)))
 
-    def merge_hits(self, d_all, n_lists, k):
-        """Merge all-gathered per-shard hit lists (device pointer) into the global top-k, on the device."""
+    def merge_hits(self, d_all, n_lists, k, d_out=None):
+        """Merge all-gathered per-shard hit lists (device pointer) into the global top-k, on the device.
+        d_out (device address): leave the result there and do not wait (stream-ordered); otherwise return it."""
+        if d_out is not None:
+            self._chk(self.lib.vft_merge_hits(self.ctx, P(d_all), I32(n_lists), I32(k), None, P(d_out)))
+            return None
         hits = np.zeros(k, self.hit_dtype)
         self._chk(self.lib.vft_merge_hits(self.ctx, P(d_all), I32(n_lists), I32(k), _ptr(hits), None))
         return hits
