@@ -121,43 +121,33 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     hit_dt = ops.hit_dtype
+    S = len(seeds)
+    seeds_arr = np.asarray(seeds, np.int64)
     if use_dist:
-        # per seed: this rank's k records, the ranks' lists all-gathered, the merged global list - all on the device
-        rec = k * hit_dt.itemsize
+        # per step: this rank's [S][k] records, the ranks' blocks all-gathered ([world][S][k]), one batched merge
+        rec = S * k * hit_dt.itemsize
         gdev = "cuda" if backend == "nccl" else "cpu"
-        d_mine = [torch.zeros(rec, dtype=torch.uint8, device="cuda") for _ in seeds]
-        d_all = [torch.zeros(world * rec, dtype=torch.uint8, device=gdev) for _ in seeds]
-        d_merged_all = torch.zeros(len(seeds) * rec, dtype=torch.uint8, device="cuda")
-        d_merged = [d_merged_all[s * rec:(s + 1) * rec] for s in range(len(seeds))]
-        h_merged = torch.empty(len(seeds) * rec, dtype=torch.uint8, pin_memory=True)
+        d_mine = torch.zeros(rec, dtype=torch.uint8, device="cuda")
+        d_all = torch.zeros(world * rec, dtype=torch.uint8, device=gdev)
         ops.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def one_step():
-        out = []
-        for s, q in enumerate(seeds):
-            if not use_dist:
-                hits, _ = ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False)
-                out.append(hits)
-                continue
-            ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, k, want_best=False,
-                           d_hits=d_mine[s].data_ptr(), want_hits=False)
-            if backend == "nccl":
-                # RCCL over xGMI: k records per rank; gather and merge are stream-ordered, the host moves on to the
-                # next seed's sweep and waits once per step
-                dist.all_gather_into_tensor(d_all[s], d_mine[s])
-                ops.merge_hits(d_all[s].data_ptr(), world, k, d_out=d_merged[s].data_ptr())
-            else:
-                torch.cuda.current_stream().synchronize()
-                dist.all_gather_into_tensor(d_all[s], d_mine[s].cpu())
-                gathered = d_all[s].cuda()
-                ops.merge_hits(gathered.data_ptr(), world, k, d_out=d_merged[s].data_ptr())
-                torch.cuda.current_stream().synchronize()   # `gathered` must outlive the merge
-        if use_dist:
-            # merge on the device with the (criterion asc, id desc) rule; the lists come back once per step
-            h_merged.copy_(d_merged_all, non_blocking=True)   # one pinned copy per step for all seeds
-            torch.cuda.current_stream().synchronize()
-            out = [np.frombuffer(h_merged.numpy()[s * rec:(s + 1) * rec].tobytes(), dtype=hit_dt) for s in range(len(seeds))]
-        return out
+        # the S seeds of a step go down in one call (vft_sweep_batch): S sweeps back to back on the stream, one batched
+        # top-k selection, one host wait - how the NJ driver refreshes the top-hit lists of a batch of seeds
+        if not use_dist:
+            hits, _ = ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k)
+            return hits
+        ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k, d_hits=d_mine.data_ptr(),
+                            want_hits=False)
+        if backend == "nccl":
+            # RCCL over xGMI: S*k records per rank, one all-gather per step; gather and merge are stream-ordered and
+            # the merged lists come back through the mapped result block with a single wait
+            dist.all_gather_into_tensor(d_all, d_mine)
+            return ops.merge_hits_batch(d_all.data_ptr(), world, S, k)
+        torch.cuda.current_stream().synchronize()
+        dist.all_gather_into_tensor(d_all, d_mine.cpu())
+        gathered = d_all.cuda()
+        return ops.merge_hits_batch(gathered.data_ptr(), world, S, k)
 
     def barrier():
         if use_dist:

@@ -141,6 +141,12 @@ int vft_out_distances(vft_ctx *ctx, int64_t n, const int64_t *ids, int64_t n_act
  */
 int vft_sweep(vft_ctx *ctx, int64_t query, int64_t n_active, int64_t n_diff_allow, double totdiam, int32_t k,
               void *hits, void *d_hits, int64_t *best_j);
+/* n_seeds sweeps in one call: hits = n_seeds x k records (host, may be NULL), d_hits likewise in device memory,
+   best_j[n_seeds].  Results are exactly those of n_seeds vft_sweep calls in this order; the top-k selections of the
+   batch share their launches and the call synchronises once.  For seeds that are independent of each other's results:
+   the speculative next seeds of setAllLeafTopHits (NJ.tcc:3772-3800), a multi-GPU exchange per batch. */
+int vft_sweep_batch(vft_ctx *ctx, int32_t n_seeds, const int64_t *queries, int64_t n_active, int64_t n_diff_allow,
+                    double totdiam, int32_t k, void *hits, void *d_hits, int64_t *best_j);
 /* Restrict sweeps/out-distance passes to node ids [lo, hi): the shard a rank owns in a multi-GPU run
    (default [0, max_nodes)).  Hits keep global ids. */
 int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);
@@ -148,6 +154,10 @@ int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);
    DEVICE memory).  Produces the k best records under the same (criterion asc, id desc) order into hits (host, may be
    NULL) and d_out (device, may be NULL) — the result a single-rank sweep over the union of the shards would give. */
 int vft_merge_hits(vft_ctx *ctx, const void *d_all, int32_t n_lists, int32_t k, void *hits, void *d_out);
+/* The same for batches (vft_sweep_batch on every rank, one all-gather): d_all = [n_lists][n_seeds][k] records, the
+   merged lists come back as [n_seeds][k] in hits (host, may be NULL) and d_out (device, may be NULL). */
+int vft_merge_hits_batch(vft_ctx *ctx, const void *d_all, int32_t n_lists, int32_t n_seeds, int32_t k, void *hits,
+                         void *d_out);
 /* Diagnostics of the last sweep's top-k selection: info[0] = candidates that were rank-sorted, info[1] = extra
    refinement rounds that were needed (0 in the common case). */
 int vft_sweep_info(vft_ctx *ctx, int64_t info[2]);

@@ -157,3 +157,59 @@ def test_long_short_and_gappy_alignments_sweep_equals_pair_list_and_oracle(n_pos
     for k, j in enumerate(others[[0, 7, 100, 120]]):
         ed, ew = orc.profiledist(pq, ops.profile_download(int(j)))
         assert rd[k] == ed and rw[k] == ew
+
+
+@pytest.mark.parametrize("n_codes,dt", [(4, np.float32), (4, np.float64), (20, np.float32)])
+def test_sweep_batch_equals_single_sweeps(n_codes, dt):
+    """vft_sweep_batch = the same sweeps seed after seed, one batched top-k selection: identical records and bestjoin,
+    for leaf and internal seeds mixed, with stale out-distances in play."""
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.workload import TopHitsState
+    n, L = 3000, 120
+    codes = synth.random_descent_codes(n, L, n_codes, 0.05, 0.03, seed=41)
+
+    def fresh():
+        ops = HipProfileOps(n, L, n_codes, dt)
+        if n_codes == 20:
+            dm = G_load("wb_aa_f32")
+            ops.set_distance_matrix(dm["dmat.distances"], dm["dmat.codefreq"], dm["dmat.eigenval"], dm["dmat.eigentot"])
+        st = TopHitsState(ops, codes, 700)
+        # make a third of the nodes stale beyond the allowance, so that the lazy refresh has work to do
+        od, na = ops.get_out_distances(0, st.maxnode)
+        na[::3] = st.n_active + st.n_diff_allow + 50
+        ops.set_out_distances(0, od, na)
+        return ops, st
+
+    ops1, st = fresh()
+    rng = np.random.default_rng(2)
+    seeds = np.concatenate([rng.choice(st.active[st.active < n], 5, replace=False),
+                            rng.choice(st.active[st.active >= n], 5, replace=False)])
+    rng.shuffle(seeds)
+    k = 64
+    single = [ops1.setBestHit(int(q), st.n_active, st.n_diff_allow, st.totdiam, k) for q in seeds]
+    ops2, _ = fresh()
+    hits, best = ops2.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    for s, (h1, b1) in enumerate(single):
+        assert b1 == best[s]
+        assert np.array_equal(h1, hits[s])
+    # and the refreshed out-distances ended up the same
+    a, b = ops1.get_out_distances(0, st.maxnode), ops2.get_out_distances(0, st.maxnode)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # sharded: every "rank" sweeps its target range for the whole batch, the [ranks][seeds][k] block is merged in one
+    # launch (what bench.py does after its one all-gather per step) and equals the unsharded lists
+    from veryfasttree_amd.workload import shard_range
+    parts = []
+    for r in range(3):
+        lo, hi = shard_range(st.maxnode, r, 3)
+        ops2.set_shard(lo, hi)
+        parts.append(ops2.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)[0])
+    ops2.set_shard(0, st.maxnode)
+    d_all = ops2.device_buffer(np.stack(parts))
+    merged = ops2.merge_hits_batch(d_all, 3, len(seeds), k)
+    ops2.device_free(d_all)
+    assert np.array_equal(merged, hits)
+
+
+def G_load(name):
+    import golden_util as G
+    return G.load(name)

@@ -24,7 +24,7 @@ EXPORTS = [
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_set_shard", "vft_merge_hits", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
+    "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
 ]
 
@@ -327,6 +327,16 @@ class HipProfileOps:
                                      C.byref(best) if want_best else None))
         return hits, best.value
 
+    def setBestHitBatch(self, queries, n_active, n_diff_allow, totdiam, k, d_hits=None, want_hits=True):
+        """Several seeds per call (vft_sweep_batch): returns (hits[n_seeds, k], best_j[n_seeds])."""
+        q = _i64(queries)
+        hits = np.zeros((len(q), k), self.hit_dtype) if want_hits else None
+        best = np.full(len(q), -1, np.int64)
+        self._chk(self.lib.vft_sweep_batch(self.ctx, I32(len(q)), _ptr(q), I64(n_active), I64(n_diff_allow),
+                                           C.c_double(totdiam), I32(k), _ptr(hits), P(d_hits) if d_hits else None,
+                                           _ptr(best) if k >= 2 else None))
+        return hits, best
+
     def device_buffer(self, array):
         """Copy a host array into a fresh device buffer; returns the device address (free with device_free)."""
         a = np.ascontiguousarray(array)
@@ -346,6 +356,13 @@ class HipProfileOps:
             return None
         hits = np.zeros(k, self.hit_dtype)
         self._chk(self.lib.vft_merge_hits(self.ctx, P(d_all), I32(n_lists), I32(k), _ptr(hits), None))
+        return hits
+
+    def merge_hits_batch(self, d_all, n_lists, n_seeds, k, d_out=None, want_hits=True):
+        """Merge all-gathered batches ([n_lists][n_seeds][k], device pointer): returns hits[n_seeds, k]."""
+        hits = np.zeros((n_seeds, k), self.hit_dtype) if want_hits else None
+        self._chk(self.lib.vft_merge_hits_batch(self.ctx, P(d_all), I32(n_lists), I32(n_seeds), I32(k), _ptr(hits),
+                                                P(d_out) if d_out else None))
         return hits
 
     def sweep_info(self):

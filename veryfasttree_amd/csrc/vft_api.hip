@@ -54,6 +54,20 @@ struct vft_ctx {
     char *dRes = nullptr;    // SelectHeader followed by the k hit records
     char *hRes = nullptr;    // pinned, device-mapped host mirror of dRes, written by k_select_best (zero-copy)
     char *hResDev = nullptr; // device address of hRes
+    // One set of sweep-result + selection buffers per seed of a batch (vft_sweep_batch); slot 0 aliases the members
+    // above, further slots are allocated on first use.
+    struct SweepSlotHost {
+        void *swDist = nullptr, *swWeight = nullptr, *swCrit = nullptr, *partMin = nullptr, *partMax = nullptr;
+        SelectState *sel = nullptr;
+        unsigned int *slices = nullptr;
+        uint64_t *candKey = nullptr;
+        int32_t *candId = nullptr;
+        char *dRes = nullptr, *hRes = nullptr, *hResDev = nullptr;
+        int nPart = 0;
+    };
+    std::vector<SweepSlotHost> slots;
+    char *dMerge = nullptr, *hMerge = nullptr, *hMergeDev = nullptr;   // result blocks of vft_merge_hits_batch
+    size_t mergeBytes = 0;
     int32_t hitsCap = 0;
     // models
     void *dm[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -181,13 +195,14 @@ static QueryBuf<REAL> qbuf(const vft_ctx *c, int which) {
 }
 
 template <typename REAL>
-static SweepOut<REAL> sweepout(const vft_ctx *c) {
+static SweepOut<REAL> sweepout(const vft_ctx *c, int slot = 0) {
+    const vft_ctx::SweepSlotHost &h = c->slots[(size_t) slot];
     SweepOut<REAL> o;
-    o.dist = (REAL *) c->swDist;
-    o.weight = (REAL *) c->swWeight;
-    o.crit = (REAL *) c->swCrit;
-    o.partMin = (REAL *) c->partMin;
-    o.partMax = (REAL *) c->partMax;
+    o.dist = (REAL *) h.swDist;
+    o.weight = (REAL *) h.swWeight;
+    o.crit = (REAL *) h.swCrit;
+    o.partMin = (REAL *) h.partMin;
+    o.partMax = (REAL *) h.partMax;
     return o;
 }
 
@@ -354,6 +369,22 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipHostMalloc((void **) &c->hRes, sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64), hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->hResDev, c->hRes, 0));
     memset(c->hRes, 0, sizeof(SelectHeader));
+    {
+        vft_ctx::SweepSlotHost s0;
+        s0.swDist = c->swDist;
+        s0.swWeight = c->swWeight;
+        s0.swCrit = c->swCrit;
+        s0.partMin = c->partMin;
+        s0.partMax = c->partMax;
+        s0.sel = c->sel;
+        s0.slices = c->slices;
+        s0.candKey = c->candKey;
+        s0.candId = c->candId;
+        s0.dRes = c->dRes;
+        s0.hRes = c->hRes;
+        s0.hResDev = c->hResDev;
+        c->slots.assign(1, s0);
+    }
     CR(hipHostMalloc((void **) &c->hFlag, 64, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dFlag, c->hFlag, 0));
     *c->hFlag = 0;
@@ -394,6 +425,15 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
+    if (c->dMerge) hipFree(c->dMerge);
+    if (c->hMerge) hipHostFree(c->hMerge);
+    for (size_t i = 1; i < c->slots.size(); i++) {   // slot 0 aliases members freed below
+        vft_ctx::SweepSlotHost &h = c->slots[i];
+        void *dev[] = {h.swDist, h.swWeight, h.swCrit, h.partMin, h.partMax, h.sel, h.slices, h.candKey, h.candId, h.dRes};
+        for (void *p: dev)
+            if (p) hipFree(p);
+        if (h.hRes) hipHostFree(h.hRes);
+    }
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
     void *ptrs[] = {c->tileMask, c->colMask, c->colOff, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
@@ -1008,14 +1048,14 @@ static unsigned sweep_nt_grid(vft_ctx *c, SweepArgs &s, bool tablePath) {
 static void kernel_event(vft_ctx *c);
 // the two launches of one nt sweep (vft_kernels_nj.h); events: before, between, after
 template <typename REAL, int MODE>
-static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, int whichQuery, bool timed) {
+static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, int whichQuery, bool timed, int slot = 0) {
     const unsigned nHeavy = grid - (unsigned) s.nLeafWG;
     if (timed) kernel_event(c);
     if (nHeavy) launch((k_sweep_nt<REAL, MODE>), dim3(nHeavy), dim3(VFT_WG), 0, c->stream, arena<REAL>(c),
-                       qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c));
+                       qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c, slot));
     if (timed) kernel_event(c);
     if (s.nLeafWG) launch((k_sweep_nt_table<REAL, (MODE == MODE_OUTDIST ? MODE_OUTDIST : MODE_CRIT)>), dim3((unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream,
-                          arena<REAL>(c), qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c));
+                          arena<REAL>(c), qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c, slot));
     if (timed) kernel_event(c);
 }
 
@@ -1107,41 +1147,89 @@ static void kernel_event(vft_ctx *c) {   // three per sweep: before / between / 
     hipEventRecord(c->kev[c->kevUsed++], c->stream);
 }
 
-template <typename REAL, typename HIT>
-static int run_select(vft_ctx *c, int64_t lo, int64_t hi, int32_t k, int64_t query) {
-    SelectHeader *dHdr = (SelectHeader *) c->dRes;
-    HIT *dHits = (HIT *) (c->dRes + sizeof(SelectHeader));
-    launch((k_select_range<REAL>), dim3(1), dim3(1024), 0, c->stream, c->sel, (const REAL *) c->partMin,
-           (const REAL *) c->partMax, c->nPart);
-    for (int round = 0; round <= VFT_MAX_LEVEL; round++) {
-        launch((k_select_hist<REAL>), dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, (const REAL *) c->swCrit, lo, hi,
-               c->sel, c->slices);
-        launch(k_select_thresh, dim3(1), dim3(VFT_NBINS), 0, c->stream, c->sel, c->slices, VFT_SEL_WGS, (unsigned int) k);
-        launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS), dim3(VFT_WG), 0, c->stream, (const REAL *) c->swCrit, lo, hi,
-               c->sel, c->candKey, c->candId);
-        launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG), dim3(VFT_WG), 0, c->stream, c->sel, c->candKey,
-               c->candId, (const REAL *) c->swDist, (const REAL *) c->swWeight, (const REAL *) c->swCrit, k, dHits);
-        launch((k_select_best<REAL, HIT>), dim3(1), dim3(VFT_WG), 0, c->stream, c->sel, dHits, k, query, dHdr,
-               (SelectHeader *) c->hResDev, (HIT *) (c->hResDev + sizeof(SelectHeader)));
-        LAUNCHCHK(c);
-        if (int r = wait_stream(c)) return r;
-        const SelectHeader *h = (const SelectHeader *) c->hRes;
-        if (!h->overflow) return VFT_OK;
-        // rare: the threshold bin alone has more candidates than the rank sort takes; narrow the key range to it
-        if (round == VFT_MAX_LEVEL)
-            return fail(c, VFT_ERR_STATE, "top-k select: more than %d hits tied at the k-th criterion", VFT_CAND_CAP);
-        launch(k_select_refine, dim3(1), dim3(1), 0, c->stream, c->sel);
+// makes sure the context owns `count` sets of sweep-result / selection buffers
+static int ensure_slots(vft_ctx *c, int count) {
+    const size_t rs = c->rs;
+    const int64_t N = ((c->d.maxNodes + VFT_TILE - 1) / VFT_TILE + 4) * VFT_TILE;   // same padding as vft_create
+    while ((int) c->slots.size() < count) {
+        vft_ctx::SweepSlotHost h;
+        void **reals[] = {&h.swDist, &h.swWeight, &h.swCrit};
+        for (void **p: reals) HIPCHK(c, hipMalloc(p, (size_t) N * rs));
+        const size_t nPartCap = (size_t) cdiv(N, VFT_WG);
+        HIPCHK(c, hipMalloc(&h.partMin, nPartCap * 8));
+        HIPCHK(c, hipMalloc(&h.partMax, nPartCap * 8));
+        HIPCHK(c, hipMalloc((void **) &h.sel, sizeof(SelectState)));
+        HIPCHK(c, hipMalloc((void **) &h.slices, (size_t) VFT_SEL_WGS * VFT_NBINS * 4));
+        HIPCHK(c, hipMalloc((void **) &h.candKey, (size_t) VFT_CAND_CAP * 8));
+        HIPCHK(c, hipMalloc((void **) &h.candId, (size_t) VFT_CAND_CAP * 4));
+        const size_t resB = sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64);
+        HIPCHK(c, hipMalloc((void **) &h.dRes, resB));
+        HIPCHK(c, hipHostMalloc((void **) &h.hRes, resB, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void **) &h.hResDev, h.hRes, 0));
+        memset(h.hRes, 0, sizeof(SelectHeader));
+        c->slots.push_back(h);
     }
-    return fail(c, VFT_ERR_STATE, "top-k select did not converge");
+    return VFT_OK;
 }
 
-extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam, int32_t k,
-                         void *hits, void *dHitsOut, int64_t *bestJ) {
-    if (!c) return VFT_ERR_INVALID;
-    if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_sweep before vft_upload_leaves");
-    if (query < 0 || query >= c->maxnode || nActive < 3 || k < 0 || k > c->hitsCap)
-        return fail(c, VFT_ERR_INVALID, "vft_sweep: bad arguments (query %lld, nActive %lld, k %d)", (long long) query,
-                    (long long) nActive, (int) k);
+// Top-k selection of K seeds at once (their sweep results sit in slots 0..K-1): one set of launches, blockIdx.y =
+// seed, one host synchronisation.  A seed whose threshold digit overflows the candidate buffer (rare) is finished
+// alone, one digit deeper, exactly as a single selection would.
+template <typename REAL, typename HIT>
+static int run_select(vft_ctx *c, int K, const int64_t *queries, int64_t lo, int64_t hi, int32_t k) {
+    std::vector<SelSlot> hs((size_t) K);
+    for (int s = 0; s < K; s++) {
+        const vft_ctx::SweepSlotHost &h = c->slots[(size_t) s];
+        SelSlot &d = hs[(size_t) s];
+        d.crit = h.swCrit;
+        d.dist = h.swDist;
+        d.weight = h.swWeight;
+        d.partMin = h.partMin;
+        d.partMax = h.partMax;
+        d.sel = h.sel;
+        d.slices = h.slices;
+        d.candKey = h.candKey;
+        d.candId = h.candId;
+        d.hits = h.dRes + sizeof(SelectHeader);
+        d.hdr = (SelectHeader *) h.dRes;
+        d.hostHdr = (SelectHeader *) h.hResDev;
+        d.hostHits = h.hResDev + sizeof(SelectHeader);
+        d.query = queries[s];
+        d.nPart = h.nPart;
+        d.pad = 0;
+    }
+    char *hS, *dS;
+    if (int r = io_alloc(c, hs.size() * sizeof(SelSlot), &hS, &dS)) return r;
+    memcpy(hS, hs.data(), hs.size() * sizeof(SelSlot));
+    const SelSlot *slots = (const SelSlot *) dS;
+    auto round = [&](const SelSlot *sl, unsigned ny) {
+        launch((k_select_hist<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi);
+        launch(k_select_thresh, dim3(1, ny), dim3(VFT_NBINS), 0, c->stream, sl, VFT_SEL_WGS, (unsigned int) k);
+        launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi);
+        launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG, ny), dim3(VFT_WG), 0, c->stream, sl, k);
+        launch((k_select_best<REAL, HIT>), dim3(1, ny), dim3(VFT_WG), 0, c->stream, sl, k);
+    };
+    launch((k_select_range<REAL>), dim3(1, (unsigned) K), dim3(1024), 0, c->stream, slots);
+    round(slots, (unsigned) K);
+    LAUNCHCHK(c);
+    if (int r = wait_stream(c)) return r;
+    for (int s = 0; s < K; s++) {
+        const SelectHeader *h = (const SelectHeader *) c->slots[(size_t) s].hRes;
+        // rare: the threshold bin alone has more candidates than the rank sort takes; narrow the key range to it
+        for (int level = 0; h->overflow; level++) {
+            if (level == VFT_MAX_LEVEL)
+                return fail(c, VFT_ERR_STATE, "top-k select: more than %d hits tied at the k-th criterion", VFT_CAND_CAP);
+            launch(k_select_refine, dim3(1, 1), dim3(1), 0, c->stream, slots + s);
+            round(slots + s, 1u);
+            LAUNCHCHK(c);
+            if (int r = wait_stream(c)) return r;
+        }
+    }
+    return VFT_OK;
+}
+
+// the lazy refresh, query staging and sweep kernels of ONE seed; its results go to the buffers of `slot`
+static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam) {
     const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
     // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098) - skipped when the
     //    host's bookkeeping proves that nothing can be stale (seed after seed of setAllLeafTopHits, for instance)
@@ -1171,18 +1259,19 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     const bool ntPath = c->cfg.n_codes == 4 && !c->hasDm;
     const unsigned grid = ntPath ? sweep_nt_grid(c, s, !s.queryIsLeaf) : cdiv(span > 0 ? span : 1, VFT_WG);
     c->nPart = (int) grid;
+    c->slots[(size_t) slot].nPart = (int) grid;
     const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
     if (c->cfg.n_codes == 4 && !c->hasDm) {
         if (c->cfg.precision == 4) {
             launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
                                query, qbuf<float>(c, 0));
-            if (s.queryIsLeaf) launch_sweep_nt<float, MODE_CRIT_LEAFQ>(c, s, grid, 0, true);
-            else launch_sweep_nt<float, MODE_CRIT>(c, s, grid, 0, true);
+            if (s.queryIsLeaf) launch_sweep_nt<float, MODE_CRIT_LEAFQ>(c, s, grid, 0, true, slot);
+            else launch_sweep_nt<float, MODE_CRIT>(c, s, grid, 0, true, slot);
         } else {
             launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), query, qbuf<double>(c, 0));
-            if (s.queryIsLeaf) launch_sweep_nt<double, MODE_CRIT_LEAFQ>(c, s, grid, 0, true);
-            else launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true);
+            if (s.queryIsLeaf) launch_sweep_nt<double, MODE_CRIT_LEAFQ>(c, s, grid, 0, true, slot);
+            else launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true, slot);
         }
     } else {
         // amino acids / distance matrix.  Measured on C5 (50k x 300, f64): lane-per-target costs ~nPos dependent
@@ -1192,22 +1281,40 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
         if (span <= 32768) {
             const unsigned wgrid = (unsigned) std::min<int64_t>(cdiv(span > 0 ? span : 1, c->pwWaves), 256 * 16);
             c->nPart = (int) wgrid;
+            c->slots[(size_t) slot].nPart = (int) wgrid;
             VFT_DISPATCH(c, (launch((k_sweep_wave<REAL, NC>), dim3(wgrid), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
-                                    arena<REAL>(c), s, sweepout<REAL>(c))));
+                                    arena<REAL>(c), s, sweepout<REAL>(c, slot))));
         } else {
             VFT_DISPATCH(c, (launch((k_sweep_generic<REAL, NC>), dim3(grid), dim3(VFT_WG), 0, c->stream,
-                                    arena<REAL>(c), s, sweepout<REAL>(c))));
+                                    arena<REAL>(c), s, sweepout<REAL>(c, slot))));
         }
         kernel_event(c);
         kernel_event(c);
     }
     LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+static int sweep_args_ok(vft_ctx *c, int64_t query, int64_t nActive, int32_t k) {
+    if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_sweep before vft_upload_leaves");
+    if (query < 0 || query >= c->maxnode || nActive < 3 || k < 0 || k > c->hitsCap)
+        return fail(c, VFT_ERR_INVALID, "vft_sweep: bad arguments (query %lld, nActive %lld, k %d)", (long long) query,
+                    (long long) nActive, (int) k);
+    return VFT_OK;
+}
+
+extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam, int32_t k,
+                         void *hits, void *dHitsOut, int64_t *bestJ) {
+    if (!c) return VFT_ERR_INVALID;
+    if (int r = sweep_args_ok(c, query, nActive, k)) return r;
+    if (int r = sweep_one(c, 0, query, nActive, nDiffAllow, totdiam)) return r;
     if (k == 0) return VFT_OK;
-    // 3. top-k in the reference's sort order; header + hits come back in one pinned copy
+    // top-k in the reference's sort order; header + hits come back through the host-mapped block
     if (bestJ && k < 2) return fail(c, VFT_ERR_INVALID, "vft_sweep: best_j needs k >= 2");
+    const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
     int r;
-    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, lo, hi, k, query);
-    else r = run_select<double, vft_hit_f64>(c, lo, hi, k, query);
+    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, 1, &query, lo, hi, k);
+    else r = run_select<double, vft_hit_f64>(c, 1, &query, lo, hi, k);
     if (r) return r;
     const size_t hb = (size_t) k * (c->cfg.precision == 4 ? sizeof(vft_hit_f32) : sizeof(vft_hit_f64));
     if (dHitsOut) HIPCHK(c, hipMemcpyAsync(dHitsOut, c->dRes + sizeof(SelectHeader), hb, hipMemcpyDeviceToDevice, c->stream));
@@ -1216,27 +1323,88 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
     return VFT_OK;
 }
 
+// Several seeds per call (setAllLeafTopHits sweeps seed after seed without anything changing in between, so a driver
+// can run the next unvisited seeds speculatively; a multi-GPU run then needs one exchange per batch instead of one per
+// seed - SURVEY section 8e).  The same kernels as vft_sweep, seed after seed on the stream, then ONE batched top-k
+// selection and ONE host synchronisation.  Results are exactly those of n_seeds vft_sweep calls.
+extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *queries, int64_t nActive, int64_t nDiffAllow,
+                               double totdiam, int32_t k, void *hits, void *dHitsOut, int64_t *bestJ) {
+    if (!c || !queries || nSeeds < 1 || nSeeds > 64 || k < 1) return VFT_ERR_INVALID;
+    if (bestJ && k < 2) return fail(c, VFT_ERR_INVALID, "vft_sweep_batch: best_j needs k >= 2");
+    for (int s = 0; s < nSeeds; s++)
+        if (int r = sweep_args_ok(c, queries[s], nActive, k)) return r;
+    if (int r = ensure_slots(c, nSeeds)) return r;
+    for (int s = 0; s < nSeeds; s++)
+        if (int r = sweep_one(c, s, queries[s], nActive, nDiffAllow, totdiam)) return r;
+    const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
+    int r;
+    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, nSeeds, queries, lo, hi, k);
+    else r = run_select<double, vft_hit_f64>(c, nSeeds, queries, lo, hi, k);
+    if (r) return r;
+    const size_t hb = (size_t) k * (c->cfg.precision == 4 ? sizeof(vft_hit_f32) : sizeof(vft_hit_f64));
+    for (int s = 0; s < nSeeds; s++) {
+        const vft_ctx::SweepSlotHost &h = c->slots[(size_t) s];
+        if (dHitsOut)
+            HIPCHK(c, hipMemcpyAsync((char *) dHitsOut + (size_t) s * hb, h.dRes + sizeof(SelectHeader), hb, hipMemcpyDeviceToDevice, c->stream));
+        if (hits) memcpy((char *) hits + (size_t) s * hb, h.hRes + sizeof(SelectHeader), hb);
+        if (bestJ) bestJ[s] = (int64_t) ((const SelectHeader *) h.hRes)->bestJ;
+    }
+    return VFT_OK;
+}
+
+// nSeeds == 1: the single-list entry point (results through slot 0's blocks); nSeeds > 1: [lists][nSeeds][k] in,
+// [nSeeds][k] out through the batch blocks
 template <typename REAL, typename HIT>
-static int merge_hits_impl(vft_ctx *c, const void *dAll, int32_t nLists, int32_t k, void *hits, void *dOut) {
+static int merge_hits_impl(vft_ctx *c, const void *dAll, int32_t nLists, int32_t nSeeds, int32_t k, void *hits, void *dOut) {
     const int32_t n = nLists * k;
-    HIT *dHits = (HIT *) (c->dRes + sizeof(SelectHeader));
-    HIT *hHitsDev = (HIT *) (c->hResDev + sizeof(SelectHeader));
-    launch((k_fill_empty_hits<REAL, HIT>), dim3(cdiv(k, 256)), dim3(256), 0, c->stream, dHits, hHitsDev, k);
-    launch((k_merge_hits<REAL, HIT>), dim3(cdiv((int64_t) n * VFT_RANK_LANES, VFT_WG)), dim3(VFT_WG), 0, c->stream,
-           (const HIT *) dAll, n, k, dHits, hHitsDev);
+    const size_t total = (size_t) nSeeds * k;
+    HIT *dHits, *hHitsDev;
+    const char *hHost;
+    if (nSeeds == 1) {
+        dHits = (HIT *) (c->dRes + sizeof(SelectHeader));
+        hHitsDev = (HIT *) (c->hResDev + sizeof(SelectHeader));
+        hHost = c->hRes + sizeof(SelectHeader);
+    } else {
+        const size_t need = total * sizeof(vft_hit_f64);
+        if (need > c->mergeBytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->dMerge) hipFree(c->dMerge);
+            if (c->hMerge) hipHostFree(c->hMerge);
+            c->dMerge = c->hMerge = c->hMergeDev = nullptr;
+            c->mergeBytes = 0;
+            HIPCHK(c, hipMalloc((void **) &c->dMerge, need));
+            HIPCHK(c, hipHostMalloc((void **) &c->hMerge, need, hipHostMallocMapped));
+            HIPCHK(c, hipHostGetDevicePointer((void **) &c->hMergeDev, c->hMerge, 0));
+            c->mergeBytes = need;
+        }
+        dHits = (HIT *) c->dMerge;
+        hHitsDev = (HIT *) c->hMergeDev;
+        hHost = c->hMerge;
+    }
+    launch((k_fill_empty_hits<REAL, HIT>), dim3(cdiv((int64_t) total, 256)), dim3(256), 0, c->stream, dHits, hHitsDev, (int32_t) total);
+    launch((k_merge_hits<REAL, HIT>), dim3(cdiv((int64_t) n * VFT_RANK_LANES, VFT_WG), (unsigned) nSeeds), dim3(VFT_WG), 0,
+           c->stream, (const HIT *) dAll, n, k, dHits, hHitsDev, nSeeds);
     LAUNCHCHK(c);
-    if (dOut) HIPCHK(c, hipMemcpyAsync(dOut, dHits, (size_t) k * sizeof(HIT), hipMemcpyDeviceToDevice, c->stream));
+    if (dOut) HIPCHK(c, hipMemcpyAsync(dOut, dHits, total * sizeof(HIT), hipMemcpyDeviceToDevice, c->stream));
     if (hits) {
         if (int r = wait_stream(c)) return r;
-        memcpy(hits, c->hRes + sizeof(SelectHeader), (size_t) k * sizeof(HIT));
+        memcpy(hits, hHost, total * sizeof(HIT));
     }
     return VFT_OK;
 }
 
 extern "C" int vft_merge_hits(vft_ctx *c, const void *dAll, int32_t nLists, int32_t k, void *hits, void *dOut) {
     if (!c || !dAll || nLists < 1 || k < 1 || k > c->hitsCap) return fail(c, VFT_ERR_INVALID, "vft_merge_hits: bad arguments");
-    if (c->cfg.precision == 4) return merge_hits_impl<float, vft_hit_f32>(c, dAll, nLists, k, hits, dOut);
-    return merge_hits_impl<double, vft_hit_f64>(c, dAll, nLists, k, hits, dOut);
+    if (c->cfg.precision == 4) return merge_hits_impl<float, vft_hit_f32>(c, dAll, nLists, 1, k, hits, dOut);
+    return merge_hits_impl<double, vft_hit_f64>(c, dAll, nLists, 1, k, hits, dOut);
+}
+
+extern "C" int vft_merge_hits_batch(vft_ctx *c, const void *dAll, int32_t nLists, int32_t nSeeds, int32_t k, void *hits,
+                                    void *dOut) {
+    if (!c || !dAll || nLists < 1 || nSeeds < 1 || nSeeds > 64 || k < 1 || k > c->hitsCap)
+        return fail(c, VFT_ERR_INVALID, "vft_merge_hits_batch: bad arguments");
+    if (c->cfg.precision == 4) return merge_hits_impl<float, vft_hit_f32>(c, dAll, nLists, nSeeds, k, hits, dOut);
+    return merge_hits_impl<double, vft_hit_f64>(c, dAll, nLists, nSeeds, k, hits, dOut);
 }
 
 extern "C" int vft_sweep_info(vft_ctx *c, int64_t info[2]) {

@@ -954,6 +954,23 @@ struct SelectState {
     unsigned int pad;
 };
 
+// Everything one seed's selection works on.  The selection kernels take an array of these and pick theirs by
+// blockIdx.y: a batch of seeds (vft_sweep_batch) is selected by ONE set of launches and ONE host synchronisation.
+struct SelectHeader;
+struct SelSlot {
+    const void *crit, *dist, *weight;   // the seed's sweep results, indexed by target id
+    const void *partMin, *partMax;      // per-workgroup min / max criteria of its sweep
+    SelectState *sel;
+    unsigned int *slices;               // [VFT_SEL_WGS][VFT_NBINS]
+    uint64_t *candKey;                  // [VFT_CAND_CAP]
+    int32_t *candId;
+    void *hits;                         // device: the k records
+    SelectHeader *hdr, *hostHdr;        // device / host-mapped header
+    void *hostHits;                     // host-mapped copy of the k records
+    int64_t query;
+    int32_t nPart, pad;
+};
+
 __device__ __forceinline__ unsigned long long vft_vk(double x, double lo, double scale) {
     const double y = (x - lo) * scale;
     const double top = 1125899906842623.0;   // 2^50 - 1
@@ -965,8 +982,11 @@ __device__ __forceinline__ unsigned int vft_level_shift(unsigned int level) {
 
 // one workgroup: reduce the sweep's per-workgroup (min,max) criteria and set up round one
 template <typename REAL>
-__global__ __launch_bounds__(1024) void k_select_range(SelectState *S, const REAL *partMin, const REAL *partMax,
-                                                       int nPart) {
+__global__ __launch_bounds__(1024) void k_select_range(const SelSlot *slots) {
+    const SelSlot &sl = slots[blockIdx.y];
+    SelectState *S = sl.sel;
+    const REAL *partMin = (const REAL *) sl.partMin, *partMax = (const REAL *) sl.partMax;
+    const int nPart = sl.nPart;
     __shared__ double smin[1024], smax[1024];
     double cmin = 1e30, cmax = -1e30;
     for (int t = threadIdx.x; t < nPart; t += 1024) {
@@ -998,7 +1018,8 @@ __global__ __launch_bounds__(1024) void k_select_range(SelectState *S, const REA
 }
 
 // refinement (rare): descend into the threshold digit
-__global__ void k_select_refine(SelectState *S) {
+__global__ void k_select_refine(const SelSlot *slots) {
+    SelectState *S = slots[blockIdx.y].sel;
     S->nIn += S->nBelow;
     S->prefix = (S->prefix << VFT_DIGIT_BITS) | S->threshBin;
     S->level += 1;
@@ -1008,8 +1029,11 @@ __global__ void k_select_refine(SelectState *S) {
 
 // VFT_SEL_WGS workgroups, each writes its own histogram slice (plain stores)
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_select_hist(const REAL *crit, int64_t lo, int64_t hi, const SelectState *S,
-                                                        unsigned int *slices) {
+__global__ __launch_bounds__(VFT_WG) void k_select_hist(const SelSlot *slots, int64_t lo, int64_t hi) {
+    const SelSlot &sl = slots[blockIdx.y];
+    const REAL *crit = (const REAL *) sl.crit;
+    const SelectState *S = sl.sel;
+    unsigned int *slices = sl.slices;
     __shared__ unsigned int lh[VFT_NBINS];
     for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) lh[t] = 0;
     __syncthreads();
@@ -1042,8 +1066,9 @@ __global__ __launch_bounds__(VFT_WG) void k_select_hist(const REAL *crit, int64_
 }
 
 // one workgroup of VFT_NBINS threads: column sums, scan, the digit that holds the need-th smallest value
-__global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(SelectState *S, const unsigned int *slices, int nSlices,
-                                                             unsigned int k) {
+__global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(const SelSlot *slots, int nSlices, unsigned int k) {
+    SelectState *S = slots[blockIdx.y].sel;
+    const unsigned int *slices = slots[blockIdx.y].slices;
     __shared__ unsigned int part[VFT_NBINS];
     const int t = threadIdx.x;
     unsigned int mine = 0;
@@ -1081,8 +1106,12 @@ __global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(SelectState *S, con
 }
 
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_select_collect(const REAL *crit, int64_t lo, int64_t hi, SelectState *S,
-                                                           uint64_t *candKey, int32_t *candId) {
+__global__ __launch_bounds__(VFT_WG) void k_select_collect(const SelSlot *slots, int64_t lo, int64_t hi) {
+    const SelSlot &sl = slots[blockIdx.y];
+    const REAL *crit = (const REAL *) sl.crit;
+    SelectState *S = sl.sel;
+    uint64_t *candKey = sl.candKey;
+    int32_t *candId = sl.candId;
     __shared__ unsigned int lcount, lbase;
     __shared__ uint64_t lkey[VFT_CAND_CAP / 8];
     __shared__ int32_t lid[VFT_CAND_CAP / 8];
@@ -1147,9 +1176,13 @@ struct SelectHeader {
 #define VFT_RANK_TILE 2048
 #define VFT_RANK_LANES 16
 template <typename REAL, typename HIT>
-__global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelectState *S, const uint64_t *candKey,
-                                                        const int32_t *candId, const REAL *dist, const REAL *weight,
-                                                        const REAL *crit, int32_t k, HIT *hits) {
+__global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, int32_t k) {
+    const SelSlot &sl = slots[blockIdx.y];
+    const SelectState *S = sl.sel;
+    const uint64_t *candKey = sl.candKey;
+    const int32_t *candId = sl.candId;
+    const REAL *dist = (const REAL *) sl.dist, *weight = (const REAL *) sl.weight, *crit = (const REAL *) sl.crit;
+    HIT *hits = (HIT *) sl.hits;
     __shared__ uint64_t sk[VFT_RANK_TILE];
     __shared__ int32_t si[VFT_RANK_TILE];
     const unsigned int n = S->nCand < VFT_CAND_CAP ? S->nCand : VFT_CAND_CAP;
@@ -1208,8 +1241,13 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelectState *S, co
 // answer with one stream synchronisation and no DMA copy (a 32 KB hipMemcpy D2H goes through SDMA here and costs
 // hundreds of microseconds of latency; zero-copy stores over PCIe cost a few).
 template <typename REAL, typename HIT>
-__global__ __launch_bounds__(VFT_WG) void k_select_best(const SelectState *S, const HIT *hits, int32_t k, int64_t query,
-                                                        SelectHeader *hdr, SelectHeader *hostHdr, HIT *hostHits) {
+__global__ __launch_bounds__(VFT_WG) void k_select_best(const SelSlot *slots, int32_t k) {
+    const SelSlot &sl = slots[blockIdx.y];
+    const SelectState *S = sl.sel;
+    const HIT *hits = (const HIT *) sl.hits;
+    const int64_t query = sl.query;
+    SelectHeader *hdr = sl.hdr, *hostHdr = sl.hostHdr;
+    HIT *hostHits = (HIT *) sl.hostHits;
     for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = hits[t];
     if (threadIdx.x != 0) return;
     const unsigned int n = S->nCand < (unsigned int) k ? S->nCand : (unsigned int) k;
@@ -1243,23 +1281,32 @@ __global__ __launch_bounds__(VFT_WG) void k_select_best(const SelectState *S, co
 // Merge of per-shard hit lists (multi-GPU: each rank's sorted top-k, all-gathered): rank sort of the n = lists * k
 // records by (criterion asc, id desc), empty records (j < 0) last; the first k go to `out` and to the host-mapped
 // block.  Same 16-lanes-per-candidate scheme as k_select_rank.
+// nSeeds > 1 (blockIdx.y = seed): `all` is [lists][nSeeds][k] - every rank's batch of lists, all-gathered - and the
+// merged list of seed s goes to out + s * k.
 template <typename REAL, typename HIT>
-__global__ __launch_bounds__(VFT_WG) void k_merge_hits(const HIT *all, int32_t n, int32_t k, HIT *out, HIT *hostOut) {
+__global__ __launch_bounds__(VFT_WG) void k_merge_hits(const HIT *all, int32_t n, int32_t k, HIT *out, HIT *hostOut,
+                                                       int32_t nSeeds) {
     __shared__ REAL sc[VFT_RANK_TILE];
     __shared__ long long sj[VFT_RANK_TILE];
+    const unsigned int seed = blockIdx.y;
+    auto rec = [&](unsigned int u) -> const HIT & {   // record u of this seed's n = lists * k candidates
+        return all[((size_t) (u / (unsigned int) k) * (unsigned int) nSeeds + seed) * (unsigned int) k + u % (unsigned int) k];
+    };
+    out += (size_t) seed * k;
+    hostOut += (size_t) seed * k;
     const unsigned int perWg = VFT_WG / VFT_RANK_LANES;
     const unsigned int cand = blockIdx.x * perWg + threadIdx.x / VFT_RANK_LANES;
     const unsigned int sub = threadIdx.x % VFT_RANK_LANES;
     const bool mine = cand < (unsigned int) n;
-    const REAL myC = mine ? all[cand].criterion : (REAL) 0;
-    const long long myJ = mine ? (long long) all[cand].j : -1;
+    const REAL myC = mine ? rec(cand).criterion : (REAL) 0;
+    const long long myJ = mine ? (long long) rec(cand).j : -1;
     unsigned int rank = 0;
     for (unsigned int base = 0; base < (unsigned int) n; base += VFT_RANK_TILE) {
         __syncthreads();
         for (unsigned int u = threadIdx.x; u < VFT_RANK_TILE; u += VFT_WG) {
             const bool in = base + u < (unsigned int) n;
-            sc[u] = in ? all[base + u].criterion : (REAL) 0;
-            sj[u] = in ? (long long) all[base + u].j : -1;
+            sc[u] = in ? rec(base + u).criterion : (REAL) 0;
+            sj[u] = in ? (long long) rec(base + u).j : -1;
         }
         __syncthreads();
         const unsigned int lim = (unsigned int) n - base < VFT_RANK_TILE ? (unsigned int) n - base : VFT_RANK_TILE;
@@ -1277,8 +1324,8 @@ __global__ __launch_bounds__(VFT_WG) void k_merge_hits(const HIT *all, int32_t n
     for (int off = VFT_RANK_LANES / 2; off > 0; off >>= 1) rank += __shfl_xor(rank, off, VFT_RANK_LANES);
     if (sub != 0 || !mine || myJ < 0) return;
     if (rank < (unsigned int) k) {
-        out[rank] = all[cand];
-        hostOut[rank] = all[cand];
+        out[rank] = rec(cand);
+        hostOut[rank] = rec(cand);
     }
 }
 
