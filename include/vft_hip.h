@@ -183,6 +183,28 @@ int vft_pair_loglk(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, 
 int vft_posterior_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
                            const double *len1, const double *len2);
 
+/* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
+ * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */
+int vft_branch_lengths_set(vft_ctx *ctx, int64_t first, int64_t count, const void *values);
+int vft_branch_lengths_get(vft_ctx *ctx, int64_t first, int64_t count, void *values);
+/* vft_posterior_profiles with len1[k] = branchlength[len_idx_a[k]], len2[k] = branchlength[len_idx_b[k]] read on the
+   device at execution time.  Stream-ordered (does not wait): recomputeMLProfiles' levels and the up-profiles of
+   getUpProfile(useML = true) (NJ.tcc:3382-3434) queue behind the optimiser launches that produce their lengths. */
+int vft_posterior_profiles_blen(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                                const int64_t *len_idx_a, const int64_t *len_idx_b);
+/* The body of traverseOptimizeAllBranchLengths' loop (NJ.tcc:5025-5064) for n independent splits, one workgroup each:
+   ids[3k..3k+2] = the three profiles around split k (children 0 and 1 + the up-profile, or the root's three children),
+   len_idx[3k..3k+2] = the branchlength[] slots they own.  Two passes over the three branches; branch i gets
+   MLPairOptimize(P_i, posteriorProfile(P_i+1, P_i+2)) = onedimenmin/Brent on pairLogLk (NJ.tcc:1790-1803, 7025-7178)
+   with ftol = MLFTolBranchLength, atol = MLMinBranchLengthTolerance, limits [MLMinBranchLength (vft_set_ml_limits), 6].
+   recompute[k] >= 0: afterwards that node's profile = posteriorProfile(ids[3k], ids[3k+1]) with the new lengths
+   (recomputeProfile, NJ.tcc:3436); -1 for the root (all entries of one call alike).  n_pos <= 2048 (nt) / 1024 (aa).
+   Stream-ordered. */
+int vft_ml_optimize_splits(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, const int64_t *recompute,
+                           double ftol, double atol);
+/* likelihood evaluations (pairLogLk calls of the reference) made by vft_ml_optimize_splits since the last query */
+int vft_ml_eval_count(vft_ctx *ctx, int64_t *evals);
+
 /* Local-bootstrap supports (splitSupport, NJ.tcc:607-702) of n splits (a[k], b[k]) | (c[k], d[k]): col holds n_boot
    resamples of n_pos column indices each ([n_boot][n_pos], host; resampleColumns NJ.tcc:705-727); support[k] = the
    fraction of resamples in which the split beats both alternative pairings of the four profiles. */

@@ -55,6 +55,19 @@ int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_
    seed, as the reference uses it, Knuth.cpp:95-111): exported so that tests can pin the host generator. */
 void vft_knuth_stream(double *out, int64_t n);
 
+/* Maximum-likelihood branch lengths on a fixed topology (`-mllen`: VeryFastTreeImpl.tcc:263-311 without the rate /
+   GTR re-estimation): optionally recomputeMLProfiles (NJ.tcc:3516), then `rounds` calls of optimizeAllBranchLengths
+   (NJ.tcc:5065), each followed by treeLogLk (NJ.tcc:5160).  The model (vft_set_rates, vft_set_transition_matrix,
+   vft_set_ml_limits) and the leaf / internal profiles must be on the device; the context needs max_nodes >= n_nodes +
+   n_seqs (up-profiles).  parent[n_nodes] (-1 at the root), child[n_nodes][3] (-1 = none; the root has three);
+   branchlength: numeric_t[n_nodes], in/out.  ftol = MLFTolBranchLength, atol = MLMinBranchLengthTolerance
+   (Constants.h:26-30).  n_leaf_gaps >= 0 applies treeLogLk's Jukes-Cantor correction for that many gap characters in
+   the leaves, < 0 none (matrix models).  loglk[rounds] (may be NULL) receives the tree log-likelihood after each
+   round, evals (may be NULL) the number of pairLogLk evaluations the line searches made. */
+int vft_ml_lengths(vft_ctx *ctx, int64_t n_seqs, int64_t n_nodes, int64_t n_pos, int32_t precision, const int64_t *parent,
+                   const int64_t *child, int64_t root, void *branchlength, int32_t recompute_first, int32_t rounds,
+                   double ftol, double atol, int64_t n_leaf_gaps, double *loglk, int64_t *evals, char *err, int32_t err_len);
+
 #ifdef __cplusplus
 }
 #endif

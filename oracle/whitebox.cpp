@@ -420,6 +420,18 @@ struct Harness {
         out.vec(name + ".post.b", pb);
         out.vec(name + ".post.len1", l1);
         out.vec(name + ".post.len2", l2);
+
+        /* optimizeAllBranchLengths (NJ.tcc:5065) twice from this state, with the tree likelihood after each round;
+           lengths and profiles are put back afterwards so that the blocks stay independent */
+        auto savedLen = nj.branchlength;
+        for (int round = 1; round <= 2; round++) {
+            nj.optimizeAllBranchLengths();
+            const std::string key = name + ".opt" + std::to_string(round);
+            out.vec(key + ".branchlength", std::vector<P>(nj.branchlength.begin(), nj.branchlength.begin() + nj.maxnode));
+            out.scalar<double>(key + ".treeloglk", nj.treeLogLk(nullptr));
+        }
+        nj.branchlength = savedLen;
+        nj.recomputeMLProfiles();
     }
 };
 

@@ -220,3 +220,34 @@ def test_knuth_ran_array_restatement_is_pinned():
     assert O.knuth_selftest(1009, 2009) == 995235265
     ref = G.load("wb_knuth")["knuth.rand"]
     assert np.array_equal(O.knuth_stream(len(ref)), ref)
+
+
+def _ml_tolerances(dtype):
+    """(MLFTolBranchLength, MLMinBranchLengthTolerance): Constants.h:26-30."""
+    return (0.001, 1.0e-4) if np.dtype(dtype) == np.float32 else (0.001, 1.0e-9)
+
+
+def test_ml_branch_length_rounds(fx):
+    """optimizeAllBranchLengths (NJ.tcc:5065) restated in oracle/ml_lengths.py: two rounds from the fixture's ML state
+    reproduce the reference's branch lengths and tree likelihoods."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ml_lengths as ML
+    d, orc = fx["d"], fx["orc"]
+    min_len, min_rel, _ = tolerances(orc.dt)
+    ftol, atol = _ml_tolerances(orc.dt)
+    child, n_child, parent, root = d["nj.child"], d["nj.nchild"], d["nj.parent"], int(d["nj.root"])
+    for model in _models(fx):
+        profs, tm = _ml_profiles(fx, model)
+        profs.append(None)   # the root has no profile
+        bl = d["nj.branchlength"].astype(orc.dt).copy()
+        for rnd in (1, 2):
+            ML.optimize_all_branch_lengths(orc, profs, child, n_child, parent, root, bl, d["ml.rates"], d["ml.ratecat"],
+                                           tm, min_len, min_rel, ftol, atol)
+            want = d["%s.opt%d.branchlength" % (model, rnd)]
+            # the line searches follow the reference evaluation by evaluation: lengths agree to rounding
+            assert np.allclose(bl[:root], want[:root], rtol=1e-5, atol=1e-9), (model, rnd)
+            ll = ML.tree_loglk(orc, profs, child, root, bl, d["ml.rates"], d["ml.ratecat"], tm, min_len, min_rel,
+                               d["leaf.codes"])
+            assert ll == pytest.approx(float(d["%s.opt%d.treeloglk" % (model, rnd)]), rel=1e-7), (model, rnd)

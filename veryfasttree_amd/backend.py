@@ -24,7 +24,7 @@ EXPORTS = [
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles",
+    "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_ml_optimize_splits", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
 ]
 
@@ -42,7 +42,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_knuth_stream"]
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_knuth_stream", "vft_ml_lengths"]
 
 
 class _NJOptions(C.Structure):
@@ -88,6 +88,26 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
         raise VftError(err.value.decode() or "vft_nj_run failed")
     return joins[:nj.value], crit[:nj.value]
 
+
+def ml_lengths(ops, n_seqs, parent, child, root, branchlength, rounds=1, recompute_first=True, n_leaf_gaps=-1,
+               ftol=0.001, atol=None):
+    """`-mllen` on a fixed topology through the C++ host driver (vft_ml_lengths): returns (branchlength after the
+    last round, loglk per round, likelihood evaluations).  atol defaults to MLMinBranchLengthTolerance of ops.dt."""
+    lib = load_host_library()
+    parent = np.ascontiguousarray(parent, np.int64)
+    child = np.ascontiguousarray(child, np.int64)
+    bl = np.ascontiguousarray(branchlength, ops.dt).copy()
+    if atol is None:
+        atol = 1.0e-4 if ops.dt == np.float32 else 1.0e-9
+    loglk = np.zeros(max(rounds, 1), np.float64)
+    evals = I64(0)
+    err = C.create_string_buffer(512)
+    rc = lib.vft_ml_lengths(ops.ctx, I64(n_seqs), I64(len(parent)), I64(ops.n_pos), I32(ops.dt.itemsize), _ptr(parent),
+                            _ptr(child), I64(root), _ptr(bl), I32(1 if recompute_first else 0), I32(rounds),
+                            C.c_double(ftol), C.c_double(atol), I64(n_leaf_gaps), _ptr(loglk), C.byref(evals), err, I32(512))
+    if rc != 0:
+        raise VftError(err.value.decode() or "vft_ml_lengths failed")
+    return bl, loglk[:rounds], evals.value
 
 
 def uniquify(codes):

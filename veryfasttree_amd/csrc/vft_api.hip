@@ -78,6 +78,8 @@ struct vft_ctx {
     int32_t *ratecat = nullptr;
     int32_t nRates = 0;
     double minLen = 5e-4, minRel = 2.5e-4, fpostTol = 1e-10;
+    void *blen = nullptr;              // branchlength[] (numeric_t) for the ML length optimiser
+    unsigned int *mlEvals = nullptr;   // likelihood evaluations made by k_ml_node_lengths
     // generic device scratch (index lists, staging)
     void *scratch = nullptr;
     size_t scratchBytes = 0;
@@ -425,6 +427,8 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
+    if (c->blen) hipFree(c->blen);
+    if (c->mlEvals) hipFree(c->mlEvals);
     if (c->dMerge) hipFree(c->dMerge);
     if (c->hMerge) hipHostFree(c->hMerge);
     for (size_t i = 1; i < c->slots.size(); i++) {   // slot 0 aliases members freed below
@@ -1559,6 +1563,183 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
         if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- ML branch lengths
+// branchlength[] of the tree on the device (numeric_t, NJ.h: branchlength): the ML length optimiser reads and writes it
+// in place, so a whole traversal is queued without a host round trip.
+static int ensure_blen(vft_ctx *c) {
+    if (c->blen) return VFT_OK;
+    HIPCHK(c, hipMalloc(&c->blen, (size_t) c->d.maxNodes * c->rs));
+    HIPCHK(c, hipMemsetAsync(c->blen, 0, (size_t) c->d.maxNodes * c->rs, c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_branch_lengths_set(vft_ctx *c, int64_t first, int64_t count, const void *values) {
+    if (!c || !values || first < 0 || count < 0 || first + count > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_branch_lengths_set: bad range");
+    if (int r = ensure_blen(c)) return r;
+    HIPCHK(c, hipMemcpyAsync((char *) c->blen + (size_t) first * c->rs, values, (size_t) count * c->rs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_branch_lengths_get(vft_ctx *c, int64_t first, int64_t count, void *values) {
+    if (!c || !values || first < 0 || count < 0 || first + count > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_branch_lengths_get: bad range");
+    if (int r = ensure_blen(c)) return r;
+    HIPCHK(c, hipMemcpyAsync(values, (char *) c->blen + (size_t) first * c->rs, (size_t) count * c->rs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+template <typename REAL>
+__global__ void k_gather_lengths(const REAL *blen, const int64_t *li1, const int64_t *li2, double *l1, double *l2, int64_t n) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    l1[k] = (double) blen[li1[k]];
+    l2[k] = (double) blen[li2[k]];
+}
+
+// posteriorProfile for a batch of independent nodes with the two branch lengths taken from the device array
+// (recomputeMLProfiles level by level, up-profiles of a traversal).  Stream-ordered: does not wait.
+extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                                           const int64_t *lenIdxA, const int64_t *lenIdxB) {
+    if (!c || n < 0 || !out || !a || !b || !lenIdxA || !lenIdxB) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
+    for (int64_t k = 0; k < n; k++) {
+        if (int r = internal_ok(c, out[k])) return r;
+        if (lenIdxA[k] < 0 || lenIdxA[k] >= c->d.maxNodes || lenIdxB[k] < 0 || lenIdxB[k] >= c->d.maxNodes)
+            return fail(c, VFT_ERR_INVALID, "vft_posterior_profiles_blen: branch-length index out of range");
+    }
+    if (int r = ensure_blen(c)) return r;
+    const CommitPlan plan = commit_plan(c, n);
+    const int64_t chunk = plan.chunk;
+    const size_t idB = (size_t) n * 8;
+    const bool smallIds = 7 * idB <= VFT_SMALL_BYTES;
+    if (int r = ensure_scratch(c, (smallIds ? 0 : 7 * idB) + plan.totalB + 512)) return r;
+    char *s, *base;
+    if (smallIds) {
+        char *h;
+        if (int r = io_alloc(c, 7 * idB, &h, &s)) return r;
+        memcpy(h, out, idB);
+        memcpy(h + idB, a, idB);
+        memcpy(h + 2 * idB, b, idB);
+        memcpy(h + 3 * idB, lenIdxA, idB);
+        memcpy(h + 4 * idB, lenIdxB, idB);
+        base = (char *) c->scratch;
+    } else {
+        s = (char *) c->scratch;
+        base = s + 7 * idB;
+        HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + 3 * idB, lenIdxA, idB, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s + 4 * idB, lenIdxB, idB, hipMemcpyHostToDevice, c->stream));
+    }
+    base += (256 - ((uintptr_t) base & 255)) & 255;
+    double *l1 = (double *) (s + 5 * idB), *l2 = (double *) (s + 6 * idB);
+    if (c->cfg.precision == 4)
+        launch((k_gather_lengths<float>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float *) c->blen,
+               (const int64_t *) (s + 3 * idB), (const int64_t *) (s + 4 * idB), l1, l2, n);
+    else
+        launch((k_gather_lengths<double>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const double *) c->blen,
+               (const int64_t *) (s + 3 * idB), (const int64_t *) (s + 4 * idB), l1, l2, n);
+    for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+        const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
+        VFT_DISPATCH(c, {
+            const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
+            launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
+                   (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0, (const double *) l1 + k0,
+                   (const double *) l2 + k0, c->minLen, c->minRel, (REAL *) base);
+        });
+        LAUNCHCHK(c);
+        if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
+    }
+    if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+template <typename REAL, int NC>
+static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
+                              double ftol, double atol, REAL *stash) {
+#define VFT_MLOPT_CASE(CPT)                                                                                             \
+    case CPT:                                                                                                           \
+        launch((k_ml_node_lengths<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c), \
+               dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, stash, c->mlEvals);                  \
+        break;
+    switch (cpt) {
+        VFT_MLOPT_CASE(1)
+        VFT_MLOPT_CASE(2)
+        VFT_MLOPT_CASE(4)
+        default:
+            if (NC == 4 && cpt == 8) {
+                launch((k_ml_node_lengths<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream,
+                       arena<REAL>(c), dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, stash, c->mlEvals);
+                break;
+            }
+            return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: alignment too long for the in-kernel optimiser");
+    }
+#undef VFT_MLOPT_CASE
+    return VFT_OK;
+}
+
+// The inner step of optimizeAllBranchLengths (NJ.tcc:5025-5064) for n independent splits: ids[3k..3k+2] are the three
+// profiles around split k (two children + the up-profile, or the three children of the root), len_idx[3k..] the
+// branch-length slots they own, recompute[k] the node whose posterior profile is rebuilt afterwards from ids[3k],
+// ids[3k+1] and their new lengths (-1: none, the root; all entries of a call must agree on that).  Stream-ordered.
+extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx,
+                                      const int64_t *recompute, double ftol, double atol) {
+    if (!c || n < 0 || !ids || !lenIdx || !recompute) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
+    const bool rec = recompute[0] >= 0;
+    for (int64_t k = 0; k < n; k++) {
+        if ((recompute[k] >= 0) != rec) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: mixed recompute flags");
+        if (rec)
+            if (int r = internal_ok(c, recompute[k])) return r;
+        for (int t = 0; t < 3; t++)
+            if (ids[3 * k + t] < 0 || ids[3 * k + t] >= c->maxnode || lenIdx[3 * k + t] < 0 || lenIdx[3 * k + t] >= c->d.maxNodes)
+                return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: split %lld out of range", (long long) k);
+    }
+    if (int r = ensure_blen(c)) return r;
+    if (!c->mlEvals) {
+        HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
+        HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
+    }
+    const int64_t per = cdiv(c->d.nPos, VFT_MLOPT_WG);
+    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
+    const CommitPlan plan = commit_plan(c, n);
+    if (rec && n > plan.chunk) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: at most %lld splits per call", (long long) plan.chunk);
+    const size_t idB = (size_t) n * 8;
+    if (7 * idB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: too many splits per call");
+    if (int r = ensure_scratch(c, plan.totalB + 512)) return r;
+    char *h, *s;
+    if (int r = io_alloc(c, 7 * idB, &h, &s)) return r;
+    memcpy(h, ids, 3 * idB);
+    memcpy(h + 3 * idB, lenIdx, 3 * idB);
+    memcpy(h + 6 * idB, recompute, idB);
+    char *base = (char *) c->scratch;
+    base += (256 - ((uintptr_t) base & 255)) & 255;
+    int r = VFT_OK;
+    VFT_DISPATCH(c, (r = ml_optimize_launch<REAL, NC>(c, n, cpt, (const int64_t *) s, (const int64_t *) (s + 3 * idB),
+                                                      (const int64_t *) (s + 6 * idB), ftol, atol, (REAL *) base)));
+    if (r) return r;
+    LAUNCHCHK(c);
+    if (rec) return commit_nodes(c, plan, recompute, (const int64_t *) (s + 6 * idB), n, base);
+    return VFT_OK;
+}
+
+// number of likelihood evaluations the optimiser has made since the last call (the reference's nLkCompute share)
+extern "C" int vft_ml_eval_count(vft_ctx *c, int64_t *evals) {
+    if (!c || !evals) return VFT_ERR_INVALID;
+    *evals = 0;
+    if (!c->mlEvals) return VFT_OK;
+    unsigned int v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->mlEvals, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *evals = (int64_t) v;
     return VFT_OK;
 }
 

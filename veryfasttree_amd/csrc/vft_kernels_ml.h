@@ -52,6 +52,72 @@ __device__ __forceinline__ void vft_model_freq(const Arena<REAL> &A, const Col<R
     }
 }
 
+// One column of pairLogLk (NJ.tcc:1202-1266 Jukes-Cantor, :1267-1439 matrix models): the likelihood of the column,
+// or false for gap against gap under a matrix model (likelihood 1, NJ.tcc:1277-1281).  pSame/pDiff resp. ee (the
+// exp(eigenvalue * rate * length) row) are those of the column's rate category.
+template <typename REAL, int NC>
+__device__ __forceinline__ bool vft_pair_lk_col(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2,
+                                                bool jc, double pSame, double pDiff, const REAL *ee, double &lkAB) {
+    lkAB = 0;
+    if (jc) {
+        const double wA = (double) c1.w, wB = (double) c2.w;
+        if (!c1.vec && !c2.vec) {
+            if (c1.code == VFT_NOCODE_) lkAB = 0.25;
+            else if (c2.code == VFT_NOCODE_) lkAB = 0.25;
+            else if (c1.code == c2.code) lkAB = pSame * wA * wB + 0.25 * (1 - wA * wB);
+            else lkAB = pDiff * wA * wB + 0.25 * (1 - wA * wB);
+        } else if (!c1.vec) {
+            if (c1.code == VFT_NOCODE_) lkAB = 0.25;
+            else lkAB = wA * (pDiff + (double) vft_pick<REAL, NC>(c2.f, c1.code) * (pSame - pDiff)) + (1.0 - wA) * 0.25;
+        } else if (!c2.vec) {
+            if (c2.code == VFT_NOCODE_) lkAB = 0.25;
+            else lkAB = wB * (pDiff + (double) vft_pick<REAL, NC>(c1.f, c2.code) * (pSame - pDiff)) + (1.0 - wB) * 0.25;
+        } else {
+#pragma unroll
+            for (int j = 0; j < (NC < 4 ? NC : 4); j++) {
+                const REAL om = (REAL) 1 - c1.f[j];   // int - numeric_t is numeric_t, NJ.tcc:1253
+                lkAB += (double) c2.f[j] * ((double) c1.f[j] * pSame + (double) om * pDiff);
+            }
+        }
+        return true;
+    }
+    if (c1.w == 0 && c2.w == 0 && c1.code == VFT_NOCODE_ && c2.code == VFT_NOCODE_) return false;
+    REAL fA[NC], fB[NC];
+    vft_model_freq<REAL, NC>(A, c1, true, fA);
+    vft_model_freq<REAL, NC>(A, c2, true, fB);
+    if (NC == 4) {
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            REAL pr = ee[j] * fA[j];   // numeric_t triple product, NJ.tcc:1305
+            pr = pr * fB[j];
+            lkAB += (double) pr;
+        }
+    } else {
+        REAL e[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) e[j] = ee[j];
+        lkAB = (double) vft_red4_mul3<REAL, NC>(e, fA, fB);   // NJ.tcc:1359
+    }
+    return true;
+}
+
+// the reference's running product with its underflow rescaling (NJ.tcc:1257-1262, :1314-1321)
+// (lk > 0: the reference asserts lkAB > 0 and would spin forever otherwise; profiles that are not in the model's
+//  eigenbasis can produce that, and a kernel must terminate)
+__device__ __forceinline__ void vft_lk_accumulate(double lkAB, bool jc, double &lk, double &loglk) {
+    lk *= lkAB;
+    while (lk < VFT_LK_UNDERFLOW && lk > 0) {
+        lk *= VFT_LK_UNDERFLOW_INV;
+        loglk -= VFT_LOG_LK_UNDERFLOW;
+    }
+    if (!jc) {
+        while (lk > VFT_LK_UNDERFLOW_INV) {
+            lk *= VFT_LK_UNDERFLOW;
+            loglk += VFT_LOG_LK_UNDERFLOW;
+        }
+    }
+}
+
 // pairLogLk (NJ.tcc:1192-1447).  One workgroup per pair, threads over columns.  Each thread keeps the
 // reference's running product with underflow rescaling for its own columns; the per-thread log-products are
 // then summed (wave shuffles + LDS).  Only the order of that final sum differs from the reference.
@@ -78,70 +144,13 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
         vft_load_col<REAL, NC>(A, a, p, c1);
         vft_load_col<REAL, NC>(A, b, p, c2);
         const int r = A.ratecat[p];
-        double lkAB = 0;
-        bool skip = false;
-        if (jc) {
-            const double wA = (double) c1.w, wB = (double) c2.w;
-            const double pSame = pS[r], pDiff = pD[r];
-            if (!c1.vec && !c2.vec) {
-                if (c1.code == VFT_NOCODE_) lkAB = 0.25;
-                else if (c2.code == VFT_NOCODE_) lkAB = 0.25;
-                else if (c1.code == c2.code) lkAB = pSame * wA * wB + 0.25 * (1 - wA * wB);
-                else lkAB = pDiff * wA * wB + 0.25 * (1 - wA * wB);
-            } else if (!c1.vec) {
-                if (c1.code == VFT_NOCODE_) lkAB = 0.25;
-                else lkAB = wA * (pDiff + (double) vft_pick<REAL, NC>(c2.f, c1.code) * (pSame - pDiff)) + (1.0 - wA) * 0.25;
-            } else if (!c2.vec) {
-                if (c2.code == VFT_NOCODE_) lkAB = 0.25;
-                else lkAB = wB * (pDiff + (double) vft_pick<REAL, NC>(c1.f, c2.code) * (pSame - pDiff)) + (1.0 - wB) * 0.25;
-            } else {
-#pragma unroll
-                for (int j = 0; j < (NC < 4 ? NC : 4); j++) {
-                    const REAL om = (REAL) 1 - c1.f[j];   // int - numeric_t is numeric_t, NJ.tcc:1253
-                    lkAB += (double) c2.f[j] * ((double) c1.f[j] * pSame + (double) om * pDiff);
-                }
-            }
-        } else {
-            if (c1.w == 0 && c2.w == 0 && c1.code == VFT_NOCODE_ && c2.code == VFT_NOCODE_) {
-                skip = true;   // gap against gap: likelihood 1 (NJ.tcc:1277-1281)
-            } else {
-                REAL fA[NC], fB[NC];
-                vft_model_freq<REAL, NC>(A, c1, true, fA);
-                vft_model_freq<REAL, NC>(A, c2, true, fB);
-                const REAL *ee = expeig + r * NC;
-                if (NC == 4) {
-#pragma unroll
-                    for (int j = 0; j < NC; j++) {
-                        REAL pr = ee[j] * fA[j];   // numeric_t triple product, NJ.tcc:1305
-                        pr = pr * fB[j];
-                        lkAB += (double) pr;
-                    }
-                } else {
-                    REAL e[NC];
-#pragma unroll
-                    for (int j = 0; j < NC; j++) e[j] = ee[j];
-                    lkAB = (double) vft_red4_mul3<REAL, NC>(e, fA, fB);   // NJ.tcc:1359
-                }
-            }
-        }
-        if (skip) {
+        double lkAB;
+        if (!vft_pair_lk_col<REAL, NC>(A, c1, c2, jc, pS[r], pD[r], expeig + r * NC, lkAB)) {
             if (siteLk) siteLk[k * A.d.nPos + p] = 1.0;
             continue;
         }
         if (siteLk) siteLk[k * A.d.nPos + p] = lkAB;
-        lk *= lkAB;
-        // (lk > 0: the reference asserts lkAB > 0 and would spin forever otherwise, NJ.tcc:1257-1262; profiles that
-        //  are not in the model's eigenbasis can produce that, and a kernel must terminate)
-        while (lk < VFT_LK_UNDERFLOW && lk > 0) {
-            lk *= VFT_LK_UNDERFLOW_INV;
-            loglk -= VFT_LOG_LK_UNDERFLOW;
-        }
-        if (!jc) {
-            while (lk > VFT_LK_UNDERFLOW_INV) {
-                lk *= VFT_LK_UNDERFLOW;
-                loglk += VFT_LOG_LK_UNDERFLOW;
-            }
-        }
+        vft_lk_accumulate(lkAB, jc, lk, loglk);
     }
     double part = loglk + log(lk);
 #pragma unroll
@@ -155,43 +164,19 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
     }
 }
 
-// posteriorProfile (NJ.tcc:2137-2447, exact ML).  grid.y = triple index, threads over columns.
+// One column of posteriorProfile (NJ.tcc:2185-2260 Jukes-Cantor incl. the "simple profile" shortcuts, :2262-2434 matrix
+// models, exact ML): weight, code and - when code == NOCODE and weight > 0 - the frequency vector of the parent.
+// PS/PD resp. e1/e2 belong to the column's rate category and the two branch lengths.
 template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
-                                                         const int64_t *bN, const double *len1A, const double *len2A,
-                                                         double minLen, double minRel,
-                                                         REAL *stash /* non-null: append path */) {
-    __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
-    __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
-    const int64_t k = blockIdx.y;
-    double len1 = len1A[k], len2 = len2A[k];
-    if (len1 < minLen) len1 = minLen;
-    if (len2 < minLen) len2 = minLen;
-    const bool jc = A.tmStat == nullptr;
-    if (jc) {
-        for (int r = threadIdx.x; r < A.nRates; r += blockDim.x) {
-            vft_psame_pdiff(len1, (double) A.rates[r], pS1[r], pD1[r]);
-            vft_psame_pdiff(len2, (double) A.rates[r], pS2[r], pD2[r]);
-        }
-    } else {
-        vft_exp_eigen_rates<REAL, NC>(A, len1, minRel, ee1);
-        vft_exp_eigen_rates<REAL, NC>(A, len2, minRel, ee2);
-    }
-    __syncthreads();
-    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.d.nPos) return;
-    Col<REAL, NC> c1, c2;
-    vft_load_col<REAL, NC>(A, aN[k], p, c1);
-    vft_load_col<REAL, NC>(A, bN[k], p, c2);
-    const int r = A.ratecat[p];
-    REAL wo = (REAL) 1.0;
-    int co = VFT_NOCODE_;
-    REAL f[NC];
+__device__ __forceinline__ void vft_posterior_col(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2,
+                                                  bool jc, double PS1, double PD1, double PS2, double PD2,
+                                                  const REAL *e1, const REAL *e2, REAL &wo, int &co, REAL *f) {
+    wo = (REAL) 1.0;
+    co = VFT_NOCODE_;
 #pragma unroll
     for (int j = 0; j < NC; j++) f[j] = 0;
     if (jc) {
         const double w1 = (double) c1.w, w2 = (double) c2.w;
-        const double PS1 = pS1[r], PD1 = pD1[r], PS2 = pS2[r], PD2 = pD2[r];
         bool simple = false;
         if (!c1.vec && !c2.vec) {
             if (c1.code == VFT_NOCODE_ && c2.code == VFT_NOCODE_) {
@@ -260,7 +245,6 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
             REAL f1[NC], f2[NC], fM1[NC], fM2[NC], fPost[NC];
             vft_model_freq<REAL, NC>(A, c1, false, f1);
             vft_model_freq<REAL, NC>(A, c2, false, f2);
-            const REAL *e1 = ee1 + r * NC, *e2 = ee2 + r * NC;
 #pragma unroll
             for (int j = 0; j < NC; j++) {
                 fM1[j] = f1[j] * e1[j];
@@ -319,5 +303,256 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
             }
         }
     }
+}
+
+// posteriorProfile (NJ.tcc:2137-2447, exact ML).  grid.y = triple index, threads over columns.
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
+                                                         const int64_t *bN, const double *len1A, const double *len2A,
+                                                         double minLen, double minRel,
+                                                         REAL *stash /* non-null: append path */) {
+    __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
+    __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
+    const int64_t k = blockIdx.y;
+    double len1 = len1A[k], len2 = len2A[k];
+    if (len1 < minLen) len1 = minLen;
+    if (len2 < minLen) len2 = minLen;
+    const bool jc = A.tmStat == nullptr;
+    if (jc) {
+        for (int r = threadIdx.x; r < A.nRates; r += blockDim.x) {
+            vft_psame_pdiff(len1, (double) A.rates[r], pS1[r], pD1[r]);
+            vft_psame_pdiff(len2, (double) A.rates[r], pS2[r], pD2[r]);
+        }
+    } else {
+        vft_exp_eigen_rates<REAL, NC>(A, len1, minRel, ee1);
+        vft_exp_eigen_rates<REAL, NC>(A, len2, minRel, ee2);
+    }
+    __syncthreads();
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    Col<REAL, NC> c1, c2;
+    vft_load_col<REAL, NC>(A, aN[k], p, c1);
+    vft_load_col<REAL, NC>(A, bN[k], p, c2);
+    const int r = A.ratecat[p];
+    REAL wo;
+    int co;
+    REAL f[NC];
+    vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, wo, co, f);
     vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// optimizeAllBranchLengths' inner step (NJ.tcc:5025-5060) for one split, entirely on the device: the three branches
+// around an internal node are optimised in turn, twice; for branch i the other two profiles are condensed into their
+// posterior (posteriorProfile, NJ.tcc:2137) and the branch length maximises pairLogLk(P_i, posterior, x)
+// (MLPairOptimize NJ.tcc:1790-1803 = onedimenmin + Brent, NJ.tcc:7025-7178).  One workgroup per split; every thread owns
+// CPT columns whose two profile columns stay in registers for the whole line search, so one likelihood evaluation is
+// a table rebuild (pSame/pDiff or exp(eigenvalue * rate * x) per rate category, in LDS), a few dozen VALU per column
+// and one workgroup reduction - no HBM traffic and no host round trip per evaluation.  Branch lengths live in a device
+// array (numeric_t, like the reference's branchlength[]), so consecutive splits of a traversal are just consecutive
+// launches on the stream.  Afterwards the node's own posterior from its two children and their new lengths
+// (recomputeProfile, NJ.tcc:3436-3473, useML) is left in the stash for k_tile_commit.
+#define VFT_MLOPT_WG 256
+#define VFT_MLOPT_MAXLEN 6.0
+
+// Brent's minimiser with the reference's bracketing (onedimenmin): all threads run it in lockstep on uniform values;
+// `eval` is a workgroup-collective call.
+template <typename EVAL>
+__device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin, double xguess, double xmax, double ftol,
+                                                        double atol) {
+    // initial bracket lo < mid < hi around the guess
+    double lo, mid, hi;
+    if (xguess == xmin) {
+        lo = xmin;
+        mid = 2.0 * xguess;
+        hi = 10.0 * xguess;
+    } else if (xguess <= 2.0 * xmin) {
+        lo = xmin;
+        mid = xguess;
+        hi = 5.0 * xguess;
+    } else {
+        lo = 0.5 * xguess;
+        mid = xguess;
+        hi = 2.0 * xguess;
+    }
+    if (hi > xmax) hi = xmax;
+    if (mid >= hi) mid = 0.5 * (lo + hi);
+    double fLo = eval(lo), fMid = eval(mid), fHi = eval(hi);
+    // widen towards the limits while the minimum is not inside
+    while (fLo < fMid && lo > xmin) {
+        lo = (lo + xmin) / 2.0;
+        if (lo < 2.0 * xmin) lo = xmin;
+        fLo = eval(lo);
+    }
+    while (fHi < fMid && hi < xmax) {
+        hi = (hi + xmax) / 2.0;
+        if (hi > xmax * 0.95) hi = xmax;
+        fHi = eval(hi);
+    }
+    // Brent: x = best point, w = second best, v = previous w; [a, b] brackets the minimum
+    const double golden = 0.3819660, zeps = 1.0e-10;
+    double a = lo < hi ? lo : hi, b = lo > hi ? lo : hi;
+    double x = mid, fx = fMid, w, fw, v, fv;
+    if (fLo < fHi) {
+        w = lo; fw = fLo; v = hi; fv = fHi;
+    } else {
+        w = hi; fw = fHi; v = lo; fv = fLo;
+    }
+    double step = 0.0, prevStep = 0.0;
+    for (int it = 0; it < 100; it++) {
+        const double xm = 0.5 * (a + b);
+        const double tol1 = ftol * fabs(x), tol2 = 2.0 * (tol1 + zeps);
+        if (fabs(x - xm) <= (tol2 - 0.5 * (b - a)) || fabs(a - b) < atol) break;
+        bool goldenStep = true;
+        if (fabs(prevStep) > tol1) {
+            // parabola through x, w, v
+            const double r = (x - w) * (fx - fv);
+            double q = (x - v) * (fx - fw);
+            double p = (x - v) * q - (x - w) * r;
+            q = 2.0 * (q - r);
+            if (q > 0.0) p = -p;
+            q = fabs(q);
+            const double before = prevStep;
+            prevStep = step;
+            if (!(fabs(p) >= fabs(0.5 * q * before) || p <= q * (a - x) || p >= q * (b - x))) {
+                step = p / q;
+                const double u = x + step;
+                if (u - a < tol2 || b - u < tol2) step = (xm - x) >= 0.0 ? fabs(tol1) : -fabs(tol1);
+                goldenStep = false;
+            }
+        }
+        if (goldenStep) {
+            prevStep = x >= xm ? a - x : b - x;
+            step = golden * prevStep;
+        }
+        const double u = fabs(step) >= tol1 ? x + step : x + (step >= 0.0 ? fabs(tol1) : -fabs(tol1));
+        const double fu = eval(u);
+        if (fu <= fx) {
+            if (u >= x) a = x; else b = x;
+            v = w; w = x; x = u;
+            fv = fw; fw = fx; fx = fu;
+        } else {
+            if (u < x) a = u; else b = u;
+            if (fu <= fw || w == x) {
+                v = w; w = u;
+                fv = fw; fw = fu;
+            } else if (fu <= fv || v == x || v == w) {
+                v = u;
+                fv = fu;
+            }
+        }
+    }
+    return x;
+}
+
+template <typename REAL, int NC, int CPT>
+__global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
+                                                                  const int64_t *recN, REAL *blen, double minLen,
+                                                                  double minRel, double ftol, double atol, REAL *stash,
+                                                                  unsigned int *evalCount) {
+    __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
+    __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
+    __shared__ double red[VFT_MLOPT_WG / 64];
+    const int64_t k = blockIdx.x;
+    const bool jc = A.tmStat == nullptr;
+    const int64_t nPos = A.d.nPos;
+    int rc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+        rc[c] = p < nPos ? A.ratecat[p] : 0;
+    }
+    // tables of the two branch lengths of a posterior, into LDS (the caller synchronises)
+    auto tables2 = [&](double l1, double l2) {
+        if (l1 < minLen) l1 = minLen;   // NJ.tcc:2150-2155
+        if (l2 < minLen) l2 = minLen;
+        if (jc) {
+            for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) {
+                vft_psame_pdiff(l1, (double) A.rates[r], pS1[r], pD1[r]);
+                vft_psame_pdiff(l2, (double) A.rates[r], pS2[r], pD2[r]);
+            }
+        } else {
+            vft_exp_eigen_rates<REAL, NC>(A, l1, minRel, ee1);
+            vft_exp_eigen_rates<REAL, NC>(A, l2, minRel, ee2);
+        }
+    };
+    unsigned int nEval = 0;
+    for (int round = 0; round < 6; round++) {   // 2 iterations x 3 branches (NJ.tcc:5038-5059)
+        const int i = round % 3, b1 = (i + 1) % 3, b2 = (i + 2) % 3;
+        const int64_t nI = ids[3 * k + i], n1 = ids[3 * k + b1], n2 = ids[3 * k + b2];
+        const int64_t lI = lenIdx[3 * k + i];
+        __syncthreads();   // the previous round's writes to blen[] and reads of the tables are done
+        tables2((double) blen[lenIdx[3 * k + b1]], (double) blen[lenIdx[3 * k + b2]]);
+        __syncthreads();
+        Col<REAL, NC> pA[CPT], pB[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            if (p < nPos) {
+                Col<REAL, NC> c1, c2;
+                vft_load_col<REAL, NC>(A, n1, p, c1);
+                vft_load_col<REAL, NC>(A, n2, p, c2);
+                const int r = rc[c];
+                vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC,
+                                            pB[c].w, pB[c].code, pB[c].f);
+                pB[c].vec = pB[c].code == VFT_NOCODE_ && pB[c].w > (REAL) 0;
+                vft_load_col<REAL, NC>(A, nI, p, pA[c]);
+            }
+        }
+        // -pairLogLk(P_i, posterior, x), collectively
+        auto negLogLk = [&](double x) -> double {
+            __syncthreads();
+            if (jc) {
+                for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r]);
+            } else {
+                vft_exp_eigen_rates<REAL, NC>(A, x, minRel, ee1);
+            }
+            __syncthreads();
+            double lk = 1.0, loglk = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPT; c++) {
+                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+                if (p < nPos) {
+                    const int r = rc[c];
+                    double lkAB;
+                    if (vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB))
+                        vft_lk_accumulate(lkAB, jc, lk, loglk);
+                }
+            }
+            double part = loglk + log(lk);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+            __syncthreads();
+            double tot = 0;
+#pragma unroll
+            for (int w = 0; w < VFT_MLOPT_WG / 64; w++) tot += red[w];
+            nEval++;
+            return -tot;
+        };
+        double len = (double) blen[lI];
+        if (len < minLen) len = minLen;
+        len = vft_min_branch_length(negLogLk, minLen, len, VFT_MLOPT_MAXLEN, ftol, atol);
+        if (threadIdx.x == 0) blen[lI] = (REAL) len;
+    }
+    if (evalCount && threadIdx.x == 0) atomicAdd(evalCount, nEval);
+    const int64_t rec = recN[k];
+    if (rec < 0) return;
+    __syncthreads();
+    tables2((double) blen[lenIdx[3 * k]], (double) blen[lenIdx[3 * k + 1]]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+        if (p < nPos) {
+            Col<REAL, NC> c1, c2;
+            vft_load_col<REAL, NC>(A, ids[3 * k], p, c1);
+            vft_load_col<REAL, NC>(A, ids[3 * k + 1], p, c2);
+            const int r = rc[c];
+            REAL wo, f[NC];
+            int co;
+            vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, wo, co, f);
+            vft_stash_col<REAL, NC>(A, rec, p, wo, co, f, stash + (k * nPos + p) * (NC + 1));
+        }
+    }
 }

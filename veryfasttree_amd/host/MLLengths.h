@@ -1,0 +1,171 @@
+// Maximum-likelihood branch lengths on a fixed topology: the host side of recomputeMLProfiles (NJ.tcc:3516-3539),
+// optimizeAllBranchLengths (NJ.tcc:5006-5113) and treeLogLk (NJ.tcc:5114-5259) over the C ABI of include/vft_hip.h.
+// Plain C++11, no HIP.
+//
+// The device keeps the profiles, the up-profiles (node X -> id X + nSeqs, as in NJDriver.h) and branchlength[]; the host
+// only decides WHAT runs in which order, which depends on the topology alone: the post-order walk, and the moment each
+// up-profile is (re)built - getUpProfile caches them and optimizeAllBranchLengths drops a node's entry once the node is
+// done (NJ.tcc:5061-5062), so an ancestor's up-profile dates from the first visit to its subtree.  Everything is queued
+// on the context's stream; a round is ~5 launches per internal node and no host synchronisation.
+#ifndef VFT_ML_LENGTHS_H
+#define VFT_ML_LENGTHS_H
+
+#include <cstdint>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vft_hip.h"
+
+namespace veryfasttree {
+
+    template<typename REAL>
+    class MLLengths {
+    public:
+        /* child: [nNodes][3] (-1 = none), parent: [nNodes] (-1 at the root); the context must have max_nodes >=
+           nNodes + nSeqs and the model (rates, transition matrix, ML limits) already set */
+        MLLengths(vft_ctx *ctx, int64_t nSeqs, int64_t nNodes, const int64_t *parentIn, const int64_t *childIn, int64_t root)
+                : ctx(ctx), nSeqs(nSeqs), nNodes(nNodes), root(root), parent(parentIn, parentIn + nNodes),
+                  child(childIn, childIn + 3 * nNodes) {
+            if (root < nSeqs || root >= nNodes || child[3 * root + 2] < 0) throw std::invalid_argument("MLLengths: the root must have three children");
+            chk(vft_set_max_node(ctx, nNodes + nSeqs));
+            /* the post-order walk (traversePostorder, NJ.tcc:3343-3380): children in stored order, then the node */
+            std::vector<std::pair<int64_t, int>> stack(1, std::make_pair(root, 0));
+            while (!stack.empty()) {
+                const int64_t v = stack.back().first;
+                const int k = stack.back().second;
+                if (k < 3 && child[3 * v + k] >= 0) {
+                    stack.back().second++;
+                    stack.push_back(std::make_pair(child[3 * v + k], 0));
+                } else {
+                    stack.pop_back();
+                    if (child[3 * v] >= 0) order.push_back(v);
+                }
+            }
+        }
+
+        void setLengths(const REAL *bl) { chk(vft_branch_lengths_set(ctx, 0, nNodes, bl)); }
+
+        void getLengths(REAL *bl) { chk(vft_branch_lengths_get(ctx, 0, nNodes, bl)); }
+
+        /* recomputeMLProfiles: every internal profile from its children, one device call per tree level */
+        void recomputeMLProfiles() {
+            std::vector<int64_t> level((size_t) nNodes, 0);
+            int64_t top = 0;
+            for (int64_t v: order) {
+                if (v == root) continue;
+                const int64_t a = child[3 * v], b = child[3 * v + 1];
+                level[(size_t) v] = 1 + std::max(level[(size_t) a], level[(size_t) b]);
+                top = std::max(top, level[(size_t) v]);
+            }
+            std::vector<std::vector<int64_t>> byLevel((size_t) top + 1);
+            for (int64_t v: order)
+                if (v != root) byLevel[(size_t) level[(size_t) v]].push_back(v);
+            for (int64_t lv = 1; lv <= top; lv++) {
+                const std::vector<int64_t> &out = byLevel[(size_t) lv];
+                std::vector<int64_t> a, b;
+                for (int64_t v: out) {
+                    a.push_back(child[3 * v]);
+                    b.push_back(child[3 * v + 1]);
+                }
+                chk(vft_posterior_profiles_blen(ctx, (int64_t) out.size(), out.data(), a.data(), b.data(), a.data(), b.data()));
+            }
+        }
+
+        /* one call of optimizeAllBranchLengths */
+        void optimizeRound(double ftol, double atol) {
+            std::vector<char> upHave((size_t) nNodes, 0);
+            std::vector<int64_t> path;
+            for (int64_t v: order) {
+                int64_t ids[3], li[3], rec;
+                if (v == root) {
+                    for (int k = 0; k < 3; k++) ids[k] = li[k] = child[3 * v + k];
+                    rec = -1;
+                } else {
+                    /* getUpProfile(v): missing up-profiles on the way from the root down to v */
+                    path.clear();
+                    for (int64_t x = v; x != root; x = parent[(size_t) x]) path.push_back(x);
+                    for (size_t t = path.size(); t-- > 0;) {
+                        const int64_t x = path[t];
+                        if (upHave[(size_t) x]) continue;
+                        int64_t c, d, lc, ld;
+                        const int64_t p = parent[(size_t) x];
+                        if (p == root) {   /* the two other children of the root */
+                            int64_t sibs[2];
+                            int n = 0;
+                            for (int k = 0; k < 3; k++)
+                                if (child[3 * root + k] != x) sibs[n++] = child[3 * root + k];
+                            c = lc = sibs[0];
+                            d = ld = sibs[1];
+                        } else {           /* the sibling and the parent's up-profile with the parent's branch */
+                            c = lc = child[3 * p] == x ? child[3 * p + 1] : child[3 * p];
+                            d = p + nSeqs;
+                            ld = p;
+                        }
+                        const int64_t out = x + nSeqs;
+                        chk(vft_posterior_profiles_blen(ctx, 1, &out, &c, &d, &lc, &ld));
+                        upHave[(size_t) x] = 1;
+                    }
+                    ids[0] = li[0] = child[3 * v];
+                    ids[1] = li[1] = child[3 * v + 1];
+                    ids[2] = v + nSeqs;
+                    li[2] = v;
+                    rec = v;
+                }
+                chk(vft_ml_optimize_splits(ctx, 1, ids, li, &rec, ftol, atol));
+                upHave[(size_t) v] = 0;   /* NJ.tcc:5062 */
+            }
+        }
+
+        /* treeLogLk without site likelihoods; nLeafGaps >= 0: the Jukes-Cantor correction (NJ.tcc:5236-5256) with that
+           many gap characters in the nSeqs x nPos leaves, < 0: a matrix model, no correction */
+        double treeLogLk(int64_t nPos, int64_t nLeafGaps) {
+            std::vector<REAL> bl((size_t) nNodes);
+            getLengths(bl.data());
+            std::vector<int64_t> a, b;
+            std::vector<double> len;
+            for (int64_t v = nSeqs; v < nNodes; v++) {
+                if (child[3 * v] < 0) continue;
+                a.push_back(child[3 * v]);
+                b.push_back(child[3 * v + 1]);
+                const REAL sum = bl[(size_t) a.back()] + bl[(size_t) b.back()];   /* numeric_t sum, NJ.tcc:5124 */
+                len.push_back((double) sum);
+            }
+            std::vector<double> ll(a.size());
+            chk(vft_pair_loglk(ctx, (int64_t) a.size(), a.data(), b.data(), len.data(), ll.data(), nullptr));
+            double total = 0;
+            for (double x: ll) total += x;
+            /* the third branch of the root against the posterior of the first two (NJ.tcc:5138-5151); the root's own
+               slot holds that temporary */
+            const int64_t r0 = child[3 * root], r1 = child[3 * root + 1], r2 = child[3 * root + 2];
+            const double l0 = (double) bl[(size_t) r0], l1 = (double) bl[(size_t) r1], l2 = (double) bl[(size_t) r2];
+            chk(vft_posterior_profiles(ctx, 1, &root, &r0, &r1, &l0, &l1));
+            double ll3 = 0;
+            chk(vft_pair_loglk(ctx, 1, &root, &r2, &l2, &ll3, nullptr));
+            total += ll3;
+            if (nLeafGaps >= 0) total += (double) (nLeafGaps - nPos) * std::log(4.0);
+            return total;
+        }
+
+        int64_t evaluations() {
+            int64_t n = 0;
+            chk(vft_ml_eval_count(ctx, &n));
+            return n;
+        }
+
+        int64_t splits() const { return (int64_t) order.size(); }
+
+    private:
+        void chk(int rc) {
+            if (rc != VFT_OK) throw std::runtime_error(std::string("MLLengths: ") + vft_last_error(ctx));
+        }
+
+        vft_ctx *ctx;
+        int64_t nSeqs, nNodes, root;
+        std::vector<int64_t> parent, child, order;
+    };
+
+}
+
+#endif

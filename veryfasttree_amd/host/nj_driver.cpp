@@ -10,6 +10,7 @@
 
 #include "NJDriver.h"
 #include "KnuthRng.h"
+#include "MLLengths.h"
 
 static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
@@ -95,6 +96,35 @@ extern "C" int vft_nj_run(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int
     try {
         *nJoins = precision == 8 ? runDriver<double>(ctx, codes, nSeqs, nPos, opt, maxJoins, joins, criterion)
                                  : runDriver<float>(ctx, codes, nSeqs, nPos, opt, maxJoins, joins, criterion);
+        return VFT_OK;
+    } catch (const std::exception &e) {
+        if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
+        return VFT_ERR_STATE;
+    }
+}
+
+template<typename REAL>
+static void runMLLengths(vft_ctx *ctx, int64_t nSeqs, int64_t nNodes, int64_t nPos, const int64_t *parent, const int64_t *child,
+                         int64_t root, void *bl, bool recomputeFirst, int32_t rounds, double ftol, double atol,
+                         int64_t nLeafGaps, double *loglk, int64_t *evals) {
+    veryfasttree::MLLengths<REAL> ml(ctx, nSeqs, nNodes, parent, child, root);
+    ml.setLengths((const REAL *) bl);
+    if (recomputeFirst) ml.recomputeMLProfiles();
+    for (int32_t r = 0; r < rounds; r++) {
+        ml.optimizeRound(ftol, atol);
+        if (loglk) loglk[r] = ml.treeLogLk(nPos, nLeafGaps);
+    }
+    ml.getLengths((REAL *) bl);
+    if (evals) *evals = ml.evaluations();
+}
+
+extern "C" int vft_ml_lengths(vft_ctx *ctx, int64_t nSeqs, int64_t nNodes, int64_t nPos, int32_t precision, const int64_t *parent,
+                              const int64_t *child, int64_t root, void *bl, int32_t recomputeFirst, int32_t rounds, double ftol,
+                              double atol, int64_t nLeafGaps, double *loglk, int64_t *evals, char *err, int32_t errLen) {
+    if (!ctx || !parent || !child || !bl || nSeqs < 3 || nNodes <= nSeqs || rounds < 0) return VFT_ERR_INVALID;
+    try {
+        if (precision == 8) runMLLengths<double>(ctx, nSeqs, nNodes, nPos, parent, child, root, bl, recomputeFirst != 0, rounds, ftol, atol, nLeafGaps, loglk, evals);
+        else runMLLengths<float>(ctx, nSeqs, nNodes, nPos, parent, child, root, bl, recomputeFirst != 0, rounds, ftol, atol, nLeafGaps, loglk, evals);
         return VFT_OK;
     } catch (const std::exception &e) {
         if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
