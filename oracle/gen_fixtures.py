@@ -139,9 +139,35 @@ def gen_blackbox(tmp):
         print("%-20s %5d joins  %7.1f KiB" % (name, len(joins), os.path.getsize(dst) / 1024.0))
 
 
+MLLEN_CASES = [
+    # name, flags, n_seq, n_pos, mu, gap, seed: `-nome -mllen -nocat -nosupport` (Jukes-Cantor, constant rates)
+    ("ml_nt_200", ["-nt"], 200, 120, 0.05, 0.02, 21),            # same alignment as bb_nt_200
+    ("ml_nt_400_double", ["-nt", "-double-precision"], 400, 150, 0.06, 0.03, 31),
+    ("ml_nt_30", ["-nt"], 30, 300, 0.10, 0.05, 32),
+]
+
+
+def gen_mllen(tmp):
+    """Black box: NJ + ME lengths + ML lengths on the fixed topology; pins TreeLogLk per round and the final tree."""
+    for name, flags, n, L, mu, gap, seed in MLLEN_CASES:
+        codes = synth.random_descent_codes(n, L, 4, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+        log = os.path.join(tmp, name + ".log")
+        cmd = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-nome", "-mllen", "-nocat", "-nosupport", "-log", log, fa]
+        res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        text = open(log).read()
+        ll = [float(m.group(1)) for m in re.finditer(r"^TreeLogLk\tLength\d+\t(\S+)\tMaxChange", text, re.M)]
+        assert ll, "no TreeLogLk lines for " + name
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, codes=codes, loglk=np.array(ll), newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        print("%-20s %2d rounds  final logLk %.4f  %7.1f KiB" % (name, len(ll), ll[-1], os.path.getsize(dst) / 1024.0))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "mllen"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -149,6 +175,8 @@ def main():
             gen_blackbox(tmp)
         if "knuth" in which:
             gen_knuth(tmp)
+        if "mllen" in which:
+            gen_mllen(tmp)
 
 
 if __name__ == "__main__":

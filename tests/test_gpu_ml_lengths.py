@@ -74,3 +74,29 @@ def test_single_round_lengths_after_first_round():
     assert ll[0] == pytest.approx(float(d["jc.opt1.treeloglk"]), rel=1e-8)
     assert np.allclose(got_bl[:root], d["jc.opt1.branchlength"][:root], rtol=5e-3, atol=1e-8)
     ops.close()
+
+
+@pytest.mark.parametrize("name,dt", [("ml_nt_200", np.float32), ("ml_nt_30", np.float32), ("ml_nt_400_double", np.float64)])
+def test_mllen_pipeline_matches_the_reference_run(name, dt):
+    """FASTA -> NJ -> ME lengths -> `-mllen -nocat` (Jukes-Cantor): the reference's TreeLogLk of every round within the
+    north star's 1e-4 relative (observed: all printed digits) and its final tree, lengths included."""
+    import re
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load(name)
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    tree, loglk = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, dtype=dt,
+                            me_lengths=True, mllen=True, return_loglk=True)
+    want = d["loglk"]
+    assert len(loglk) == len(want)
+    assert np.allclose(loglk, want, rtol=1e-4, atol=0)
+    assert np.allclose(loglk, want, rtol=0, atol=6e-5), (loglk, want)   # printed with %.4f
+    ref = bytes(d["newick"]).decode().strip()
+    strip = lambda t: re.sub(r":[0-9.eE+-]+", ":", t)
+    assert strip(tree) == strip(ref)                       # same topology and labels
+    got_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", tree)])
+    ref_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", ref)])
+    assert np.allclose(got_len, ref_len, rtol=5e-3, atol=2e-5 if dt == np.float32 else 1e-8)
+    # observed on MI355X: the trees are byte-identical (every Jukes-Cantor line search follows the reference's)
+    assert tree == ref, "lengths differing in the printed digits: %d of %d" % (int((got_len != ref_len).sum()), len(ref_len))

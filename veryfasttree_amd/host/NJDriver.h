@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/vft_hip.h"
+#include "MLLengths.h"
 #include "KnuthRng.h"
 
 namespace veryfasttree {
@@ -336,6 +337,59 @@ namespace veryfasttree {
                 }
             }
         }
+
+        /* `-mllen -nocat` under Jukes-Cantor (VeryFastTreeImpl.tcc:249-311): rounds of optimizeAllBranchLengths +
+           treeLogLk on the finished topology until the largest change of a length drops below 0.001, at most
+           round(log2 N) rounds; after the first round setMLRates with one category = recomputeMLProfiles
+           (NJ.tcc:5429-5436).  recomputeProfiles(tmatAsDist) at the start (VeryFastTreeImpl.tcc:253-256) is the identity
+           here: without a transition matrix the unweighted averages are the profiles the joins already made.
+           Call after updateBranchLengths; the context needs max_nodes >= 3 * nSeqs.  Returns the tree log-likelihood
+           after each round (the reference's "TreeLogLk Length<k>" log lines). */
+        std::vector<double> mlLengths() {
+            if (root < 0) throw std::invalid_argument("NJDriver::mlLengths before finishRoot");
+            const bool f32 = sizeof(REAL) == 4;
+            const REAL one = 1;
+            std::vector<int64_t> cat((size_t) nPos, 0);
+            chkT("vft_set_rates", [&]() { return vft_set_rates(ctx, &one, 1, cat.data()); });
+            chkT("vft_set_ml_limits", [&]() { return vft_set_ml_limits(ctx, f32 ? 5.0e-4 : 5.0e-9, f32 ? 2.5e-4 : 2.5e-9, f32 ? 1.0e-10 : 1.0e-20); });   /* Constants.h:26-39 */
+            const double ftol = 0.001, atol = f32 ? 1.0e-4 : 1.0e-9;
+            std::vector<int64_t> par((size_t) maxnode), ch((size_t) (3 * maxnode), -1);
+            for (int64_t v = 0; v < maxnode; v++) {
+                par[(size_t) v] = parent[(size_t) v];
+                if (v == root) {
+                    for (int k = 0; k < 3; k++) ch[(size_t) (3 * v + k)] = rootChild[k];
+                } else if (v >= nSeqs) {
+                    ch[(size_t) (3 * v)] = child0[(size_t) v];
+                    ch[(size_t) (3 * v + 1)] = child1[(size_t) v];
+                }
+            }
+            par[(size_t) root] = -1;
+            double nonGap = 0;
+            for (int64_t i = 0; i < nSeqs; i++) nonGap += (double) selfweightLeaf[(size_t) i];
+            const int64_t nLeafGaps = nSeqs * nPos - (int64_t) nonGap;
+            MLLengths<REAL> ml(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
+            upReady = false;   /* the up-profile slots now hold ML up-profiles */
+            ml.setLengths(branchlength.data());
+            std::vector<double> loglk;
+            const int64_t maxRound = (int64_t) (0.5 + std::log((double) nSeqs) / std::log(2.0));
+            std::vector<REAL> old((size_t) maxnode);
+            for (int64_t iRound = 1; iRound <= maxRound; iRound++) {
+                for (int64_t v = 0; v < maxnode; v++) old[(size_t) v] = branchlength[(size_t) v];
+                ml.optimizeRound(ftol, atol);
+                ml.getLengths(branchlength.data());
+                double dMaxChange = 0;
+                for (int64_t v = 0; v < maxnode; v++) dMaxChange = std::max(dMaxChange, std::fabs((double) old[(size_t) v] - (double) branchlength[(size_t) v]));
+                loglk.push_back(ml.treeLogLk(nPos, nLeafGaps));
+                /* (the reference never updates its dLastLogLk, so the likelihood clause of its test cannot fire) */
+                const bool converged = iRound > 1 && dMaxChange < 0.001;
+                if (iRound == 1) ml.recomputeMLProfiles();
+                if (converged) break;
+            }
+            mlEvaluations = ml.evaluations();
+            return loglk;
+        }
+
+        int64_t mlEvaluations = 0;
 
         /* printNJ (NJ.tcc:2706-2794, no supports, no quoting): depth-first, children in stored order, leaf names with
            their duplicates expanded as (a:0.0,b:0.0), lengths as %.5f (float) / %.9f (double).

@@ -35,12 +35,16 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
 template<typename REAL>
 static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
                            bool meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext,
-                           int64_t nAll, const char *names) {
+                           int64_t nAll, const char *names, std::vector<double> &loglk) {
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
     drv.run(-1);
     drv.finishRoot();
     if (meLengths) drv.updateBranchLengths();
     if (nBootstrap > 0) drv.computeSupports(nBootstrap);
+    if (o && o->mllen) {
+        if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: mllen needs me_lengths (updateBranchLengths runs first)");
+        loglk = drv.mlLengths();
+    }
     drv.report();
     std::vector<std::string> nm;
     const char *p = names;
@@ -51,13 +55,18 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     return drv.newick(nm, std::vector<int64_t>(uniqueFirst, uniqueFirst + nSeqs), std::vector<int64_t>(alnNext, alnNext + nAll));
 }
 
-extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
-                             const vft_nj_options *opt, int32_t meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll,
-                             const char *names, char *out, int64_t outCap, int64_t *outLen, char *err, int32_t errLen) {
+extern "C" int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
+                                const vft_nj_options *opt, int32_t meLengths, int32_t nBootstrap, const int64_t *uniqueFirst,
+                                const int64_t *alnNext, int64_t nAll, const char *names, char *out, int64_t outCap,
+                                int64_t *outLen, double *loglk, int32_t loglkCap, int32_t *nRounds, char *err, int32_t errLen) {
     if (!ctx || !codes || !uniqueFirst || !alnNext || !names || !outLen) return VFT_ERR_INVALID;
     try {
-        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names)
-                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names);
+        std::vector<double> ll;
+        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll)
+                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll);
+        if (nRounds) *nRounds = (int32_t) ll.size();
+        if (loglk)
+            for (size_t k = 0; k < ll.size() && (int32_t) k < loglkCap; k++) loglk[k] = ll[k];
         *outLen = (int64_t) t.size();
         if (out && outCap > (int64_t) t.size()) memcpy(out, t.c_str(), t.size() + 1);
         else if (out) return VFT_ERR_INVALID;   /* outLen tells how much is needed */
@@ -66,6 +75,18 @@ extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, 
         if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
         return VFT_ERR_STATE;
     }
+}
+
+extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
+                             const vft_nj_options *opt, int32_t meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext, int64_t nAll,
+                             const char *names, char *out, int64_t outCap, int64_t *outLen, char *err, int32_t errLen) {
+    vft_nj_options o;
+    if (opt) {
+        o = *opt;
+        o.mllen = 0;
+    }
+    return vft_nj_ml_newick(ctx, codes, nSeqs, nPos, precision, opt ? &o : nullptr, meLengths, nBootstrap, uniqueFirst, alnNext,
+                            nAll, names, out, outCap, outLen, nullptr, 0, nullptr, err, errLen);
 }
 
 extern "C" void vft_knuth_stream(double *out, int64_t n) {
