@@ -78,6 +78,8 @@ struct vft_ctx {
     int32_t *ratecat = nullptr;
     int32_t nRates = 0;
     double minLen = 5e-4, minRel = 2.5e-4, fpostTol = 1e-10;
+    uint8_t *mlIs = nullptr, *mlC = nullptr;   // dense ML rows (vft_layout.h), allocated by the first ML-phase write
+    void *mlW = nullptr, *mlF = nullptr;
     void *blen = nullptr;              // branchlength[] (numeric_t) for the ML length optimiser
     unsigned int *mlEvals = nullptr;   // likelihood evaluations made by k_ml_node_lengths
     // generic device scratch (index lists, staging)
@@ -182,6 +184,10 @@ static Arena<REAL> arena(const vft_ctx *c) {
     A.rates = (const REAL *) c->rates;
     A.ratecat = c->ratecat;
     A.nRates = c->nRates;
+    A.mlIs = c->mlIs;
+    A.mlW = (REAL *) c->mlW;
+    A.mlC = c->mlC;
+    A.mlF = (REAL *) c->mlF;
     return A;
 }
 
@@ -428,6 +434,10 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->blen) hipFree(c->blen);
+    if (c->mlIs) hipFree(c->mlIs);
+    if (c->mlC) hipFree(c->mlC);
+    if (c->mlW) hipFree(c->mlW);
+    if (c->mlF) hipFree(c->mlF);
     if (c->mlEvals) hipFree(c->mlEvals);
     if (c->dMerge) hipFree(c->dMerge);
     if (c->hMerge) hipHostFree(c->hMerge);
@@ -750,6 +760,24 @@ static CommitPlan commit_plan(const vft_ctx *c, int64_t n) {
     return p;
 }
 
+// Dense ML rows of the internal nodes (vft_layout.h): allocated by the first ML-phase write.
+static int ensure_ml_rows(vft_ctx *c) {
+    if (c->mlIs) return VFT_OK;
+    const size_t nodes = (size_t) (c->d.maxNodes - c->d.nSeqs), cols = nodes * (size_t) c->d.nPos;
+    HIPCHK(c, hipMalloc((void **) &c->mlW, cols * c->rs));
+    HIPCHK(c, hipMalloc((void **) &c->mlF, cols * (size_t) c->d.nCodes * c->rs));
+    HIPCHK(c, hipMalloc((void **) &c->mlC, cols));
+    HIPCHK(c, hipMalloc((void **) &c->mlIs, nodes));
+    HIPCHK(c, hipMemsetAsync(c->mlIs, 0, nodes, c->stream));
+    return VFT_OK;
+}
+
+// a node rewritten through the tile streams no longer has a dense ML row
+__global__ void k_clear_ml_rows(uint8_t *mlIs, const int64_t *nodes, int64_t n, int64_t nSeqs) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) mlIs[nodes[k] - nSeqs] = 0;
+}
+
 // hNodes/dNodes: the cnt node ids of this launch (host copy / device copy, batch order); base: device memory laid
 // out as [stash | meta | commit scratch] according to `plan`.
 static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNodes, const int64_t *dNodes, int64_t cnt,
@@ -781,6 +809,7 @@ static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNode
     }
     const int32_t *dOrder = (const int32_t *) dMeta, *dSeg = dOrder + cnt;
     char *cs = base + plan.stashB + plan.metaB;
+    if (c->mlIs) launch(k_clear_ml_rows, dim3(cdiv(cnt, 256)), dim3(256), 0, c->stream, c->mlIs, dNodes, cnt, c->d.nSeqs);
     for (int64_t g0 = 0; g0 < nSeg; g0 += VFT_COMMIT_SEGS) {
         const int64_t g = nSeg - g0 < VFT_COMMIT_SEGS ? nSeg - g0 : VFT_COMMIT_SEGS;
         VFT_DISPATCH(c, (launch((k_tile_commit<REAL, NC>), dim3((unsigned) g), dim3(VFT_COMMIT_WG), 0, c->stream,
@@ -1613,12 +1642,10 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
             return fail(c, VFT_ERR_INVALID, "vft_posterior_profiles_blen: branch-length index out of range");
     }
     if (int r = ensure_blen(c)) return r;
-    const CommitPlan plan = commit_plan(c, n);
-    const int64_t chunk = plan.chunk;
+    if (int r = ensure_ml_rows(c)) return r;
     const size_t idB = (size_t) n * 8;
     const bool smallIds = 7 * idB <= VFT_SMALL_BYTES;
-    if (int r = ensure_scratch(c, (smallIds ? 0 : 7 * idB) + plan.totalB + 512)) return r;
-    char *s, *base;
+    char *s;
     if (smallIds) {
         char *h;
         if (int r = io_alloc(c, 7 * idB, &h, &s)) return r;
@@ -1627,17 +1654,15 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
         memcpy(h + 2 * idB, b, idB);
         memcpy(h + 3 * idB, lenIdxA, idB);
         memcpy(h + 4 * idB, lenIdxB, idB);
-        base = (char *) c->scratch;
     } else {
+        if (int r = ensure_scratch(c, 7 * idB + 512)) return r;
         s = (char *) c->scratch;
-        base = s + 7 * idB;
         HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(s + 3 * idB, lenIdxA, idB, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(s + 4 * idB, lenIdxB, idB, hipMemcpyHostToDevice, c->stream));
     }
-    base += (256 - ((uintptr_t) base & 255)) & 255;
     double *l1 = (double *) (s + 5 * idB), *l2 = (double *) (s + 6 * idB);
     if (c->cfg.precision == 4)
         launch((k_gather_lengths<float>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float *) c->blen,
@@ -1645,16 +1670,17 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
     else
         launch((k_gather_lengths<double>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const double *) c->blen,
                (const int64_t *) (s + 3 * idB), (const int64_t *) (s + 4 * idB), l1, l2, n);
+    // the results go to the nodes' dense ML rows: no stash, no tile commit
+    const int64_t chunk = 32768;
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
         VFT_DISPATCH(c, {
             const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
             launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
                    (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0, (const double *) l1 + k0,
-                   (const double *) l2 + k0, c->minLen, c->minRel, (REAL *) base);
+                   (const double *) l2 + k0, c->minLen, c->minRel, (REAL *) nullptr);
         });
         LAUNCHCHK(c);
-        if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
     if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
@@ -1662,11 +1688,11 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
 
 template <typename REAL, int NC>
 static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
-                              double ftol, double atol, REAL *stash) {
+                              double ftol, double atol) {
 #define VFT_MLOPT_CASE(CPT)                                                                                             \
     case CPT:                                                                                                           \
         launch((k_ml_node_lengths<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c), \
-               dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, stash, c->mlEvals);                  \
+               dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);                  \
         break;
     switch (cpt) {
         VFT_MLOPT_CASE(1)
@@ -1675,7 +1701,7 @@ static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dId
         default:
             if (NC == 4 && cpt == 8) {
                 launch((k_ml_node_lengths<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream,
-                       arena<REAL>(c), dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, stash, c->mlEvals);
+                       arena<REAL>(c), dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);
                 break;
             }
             return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: alignment too long for the in-kernel optimiser");
@@ -1707,26 +1733,21 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
         HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
+    if (int r = ensure_ml_rows(c)) return r;
     const int64_t per = cdiv(c->d.nPos, VFT_MLOPT_WG);
     const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
-    const CommitPlan plan = commit_plan(c, n);
-    if (rec && n > plan.chunk) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: at most %lld splits per call", (long long) plan.chunk);
     const size_t idB = (size_t) n * 8;
     if (7 * idB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: too many splits per call");
-    if (int r = ensure_scratch(c, plan.totalB + 512)) return r;
     char *h, *s;
     if (int r = io_alloc(c, 7 * idB, &h, &s)) return r;
     memcpy(h, ids, 3 * idB);
     memcpy(h + 3 * idB, lenIdx, 3 * idB);
     memcpy(h + 6 * idB, recompute, idB);
-    char *base = (char *) c->scratch;
-    base += (256 - ((uintptr_t) base & 255)) & 255;
     int r = VFT_OK;
     VFT_DISPATCH(c, (r = ml_optimize_launch<REAL, NC>(c, n, cpt, (const int64_t *) s, (const int64_t *) (s + 3 * idB),
-                                                      (const int64_t *) (s + 6 * idB), ftol, atol, (REAL *) base)));
+                                                      (const int64_t *) (s + 6 * idB), ftol, atol)));
     if (r) return r;
     LAUNCHCHK(c);
-    if (rec) return commit_nodes(c, plan, recompute, (const int64_t *) (s + 6 * idB), n, base);
     return VFT_OK;
 }
 

@@ -31,6 +31,12 @@ struct Arena {
     const REAL *rates;
     const int32_t *ratecat;
     int32_t nRates;
+    // ML-phase profiles (vft_layout.h, "dense ML rows"): a node whose mlIs byte is set lives in mlW/mlC/mlF instead of
+    // the tile streams.  Indexed by (node - nSeqs) * nPos + p; NULL until the ML phase allocates them.
+    uint8_t *mlIs;
+    REAL *mlW;
+    uint8_t *mlC;
+    REAL *mlF;
 };
 
 __device__ __forceinline__ uint32_t vft_byte(const uint4 &v, int b) {
@@ -86,6 +92,37 @@ __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node,
 #pragma unroll
             for (int k = 0; k < NC; k++) c.f[k] = src[k];
         }
+    }
+}
+
+// ML-phase read: dense row if the node has one, the tile streams otherwise (leaves, NJ-phase averages)
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_load_col_ml(const Arena<REAL> &A, int64_t node, int64_t p, Col<REAL, NC> &c) {
+    if (node >= A.d.nSeqs && A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs]) {
+        const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
+        c.w = A.mlW[idx];
+        c.code = (int) A.mlC[idx];
+        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+        if (c.vec) {
+            const REAL *src = A.mlF + idx * NC;
+#pragma unroll
+            for (int k = 0; k < NC; k++) c.f[k] = src[k];
+        }
+        return;
+    }
+    vft_load_col<REAL, NC>(A, node, p, c);
+}
+
+// ML-phase write of one column into the node's dense row (the caller sets mlIs[node - nSeqs] once per node)
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_store_col_ml(const Arena<REAL> &A, int64_t node, int64_t p, REAL w, int code, const REAL *f) {
+    const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
+    A.mlW[idx] = w;
+    A.mlC[idx] = (uint8_t) code;
+    if (w > 0 && code == VFT_NOCODE_) {
+        REAL *dst = A.mlF + idx * NC;
+#pragma unroll
+        for (int k = 0; k < NC; k++) dst[k] = f[k];
     }
 }
 

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
     double lk = 1.0, loglk = 0.0;
     for (int64_t p = threadIdx.x; p < A.d.nPos; p += blockDim.x) {
         Col<REAL, NC> c1, c2;
-        vft_load_col<REAL, NC>(A, a, p, c1);
-        vft_load_col<REAL, NC>(A, b, p, c2);
+        vft_load_col_ml<REAL, NC>(A, a, p, c1);
+        vft_load_col_ml<REAL, NC>(A, b, p, c2);
         const int r = A.ratecat[p];
         double lkAB;
         if (!vft_pair_lk_col<REAL, NC>(A, c1, c2, jc, pS[r], pD[r], expeig + r * NC, lkAB)) {
@@ -310,7 +310,7 @@ template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
                                                          const int64_t *bN, const double *len1A, const double *len2A,
                                                          double minLen, double minRel,
-                                                         REAL *stash /* non-null: append path */) {
+                                                         REAL *stash /* null: write the node's dense ML row */) {
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
     const int64_t k = blockIdx.y;
@@ -331,14 +331,19 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
     Col<REAL, NC> c1, c2;
-    vft_load_col<REAL, NC>(A, aN[k], p, c1);
-    vft_load_col<REAL, NC>(A, bN[k], p, c2);
+    vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
+    vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
     const int r = A.ratecat[p];
     REAL wo;
     int co;
     REAL f[NC];
     vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, wo, co, f);
-    vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
+    if (stash) {
+        vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
+    } else {
+        vft_store_col_ml<REAL, NC>(A, outN[k], p, wo, co, f);
+        if (p == 0) A.mlIs[outN[k] - A.d.nSeqs] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
 // and one workgroup reduction - no HBM traffic and no host round trip per evaluation.  Branch lengths live in a device
 // array (numeric_t, like the reference's branchlength[]), so consecutive splits of a traversal are just consecutive
 // launches on the stream.  Afterwards the node's own posterior from its two children and their new lengths
-// (recomputeProfile, NJ.tcc:3436-3473, useML) is left in the stash for k_tile_commit.
+// (recomputeProfile, NJ.tcc:3436-3473, useML) is written to its dense ML row.
 #define VFT_MLOPT_WG 256
 #define VFT_MLOPT_MAXLEN 6.0
 
@@ -448,7 +453,7 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
 template <typename REAL, int NC, int CPT>
 __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
                                                                   const int64_t *recN, REAL *blen, double minLen,
-                                                                  double minRel, double ftol, double atol, REAL *stash,
+                                                                  double minRel, double ftol, double atol,
                                                                   unsigned int *evalCount) {
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
@@ -490,13 +495,13 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
             const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
             if (p < nPos) {
                 Col<REAL, NC> c1, c2;
-                vft_load_col<REAL, NC>(A, n1, p, c1);
-                vft_load_col<REAL, NC>(A, n2, p, c2);
+                vft_load_col_ml<REAL, NC>(A, n1, p, c1);
+                vft_load_col_ml<REAL, NC>(A, n2, p, c2);
                 const int r = rc[c];
                 vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC,
                                             pB[c].w, pB[c].code, pB[c].f);
                 pB[c].vec = pB[c].code == VFT_NOCODE_ && pB[c].w > (REAL) 0;
-                vft_load_col<REAL, NC>(A, nI, p, pA[c]);
+                vft_load_col_ml<REAL, NC>(A, nI, p, pA[c]);
             }
         }
         // -pairLogLk(P_i, posterior, x), collectively
@@ -546,13 +551,14 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
         const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
         if (p < nPos) {
             Col<REAL, NC> c1, c2;
-            vft_load_col<REAL, NC>(A, ids[3 * k], p, c1);
-            vft_load_col<REAL, NC>(A, ids[3 * k + 1], p, c2);
+            vft_load_col_ml<REAL, NC>(A, ids[3 * k], p, c1);
+            vft_load_col_ml<REAL, NC>(A, ids[3 * k + 1], p, c2);
             const int r = rc[c];
             REAL wo, f[NC];
             int co;
             vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, wo, co, f);
-            vft_stash_col<REAL, NC>(A, rec, p, wo, co, f, stash + (k * nPos + p) * (NC + 1));
+            vft_store_col_ml<REAL, NC>(A, rec, p, wo, co, f);
         }
     }
+    if (threadIdx.x == 0) A.mlIs[rec - A.d.nSeqs] = 1;
 }

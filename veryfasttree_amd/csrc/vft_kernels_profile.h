@@ -158,7 +158,7 @@ __global__ void k_profile_gather(Arena<REAL> A, int64_t node, REAL *w, uint8_t *
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
     Col<REAL, NC> col;
-    vft_load_col<REAL, NC>(A, node, p, col);
+    vft_load_col_ml<REAL, NC>(A, node, p, col);
     w[p] = col.w;
     c[p] = (uint8_t) col.code;
 #pragma unroll

@@ -2,6 +2,15 @@
 // 64 consecutive node ids form a tile, and inside a tile the 64 nodes' values for one alignment column are
 // contiguous, so that a wavefront whose lane l owns node 64*t+l issues one fully coalesced 16-byte-per-lane
 // load per column group while every lane walks its own profile in the reference's column order.
+// Dense ML rows.  The tile streams are built for the one-vs-all sweeps of the NJ phase; rewriting ONE node means
+// re-packing its tile (k_tile_commit: ~30 us at 200 columns, ~250 us at 1000).  The ML phase rewrites single nodes all
+// the time (recomputeProfile after every split, up-profiles) and never sweeps, so its writes go to a plain row per
+// internal node instead: mlW[(node - nSeqs) * nPos + p], mlC[...] (code), mlF[...][nCodes] (valid when the code is
+// NOCODE and the weight positive), with one byte mlIs[node - nSeqs] saying that the node's current profile is that
+// row.  ML kernels read through vft_load_col_ml (row if flagged, tile streams otherwise: leaves and the NJ-phase
+// averages the first ML round starts from); any write through the tile path (k_tile_commit) clears the flag.  NJ-phase
+// kernels never look at the rows.  Allocated on the first ML-phase write ((maxNodes - nSeqs) * nPos * (nCodes + 1)
+// numeric_t + 1 byte per column).
 #pragma once
 #include <stdint.h>
 
