@@ -417,6 +417,35 @@ class HipProfileOps:
         return d, w
 
     # ---- likelihood
+    # ---- ML branch lengths (device-resident branchlength[], dense ML rows)
+    def branch_lengths_set(self, first, values):
+        v = self.real(values)
+        self._chk(self.lib.vft_branch_lengths_set(self.ctx, I64(first), I64(len(v)), _ptr(v)))
+
+    def branch_lengths_get(self, first, count):
+        v = np.zeros(count, self.dt)
+        self._chk(self.lib.vft_branch_lengths_get(self.ctx, I64(first), I64(count), _ptr(v)))
+        return v
+
+    def posteriorProfileBlen(self, out, a, b, len_idx_a, len_idx_b):
+        """posteriorProfile with the lengths read from the device branchlength[]; results go to dense ML rows.
+        Stream-ordered (does not wait)."""
+        out, a, b, la, lb = _i64(out), _i64(a), _i64(b), _i64(len_idx_a), _i64(len_idx_b)
+        self._chk(self.lib.vft_posterior_profiles_blen(self.ctx, I64(len(out)), _ptr(out), _ptr(a), _ptr(b), _ptr(la), _ptr(lb)))
+
+    def mlOptimizeSplits(self, ids, len_idx, recompute, ftol=0.001, atol=None):
+        """vft_ml_optimize_splits: ids / len_idx are [n, 3]."""
+        ids, li, rec = _i64(ids).reshape(-1, 3), _i64(len_idx).reshape(-1, 3), _i64(recompute)
+        if atol is None:
+            atol = 1.0e-4 if self.dt == np.float32 else 1.0e-9
+        self._chk(self.lib.vft_ml_optimize_splits(self.ctx, I64(len(rec)), _ptr(ids), _ptr(li), _ptr(rec),
+                                                  C.c_double(ftol), C.c_double(atol)))
+
+    def ml_eval_count(self):
+        n = I64(0)
+        self._chk(self.lib.vft_ml_eval_count(self.ctx, C.byref(n)))
+        return n.value
+
     def pairLogLk(self, a, b, length, site_lk=False):
         """NJ.tcc:1192 for a batch of pairs.  Returns loglk[n] (and site likelihoods [n, n_pos])."""
         a, b = _i64(a), _i64(b)
