@@ -26,8 +26,10 @@ typedef struct {
     double tophits2_refresh;    /* Options::tophits2Refresh  (0.6) */
     int32_t scoredist;          /* logCorrect (NJ.tcc:322-330): 0 = Jukes-Cantor (nucleotides without a matrix),
                                    1 = scoredist-like (amino acids, or any alphabet with a distance matrix) */
-    int32_t mllen;              /* vft_nj_ml_newick: 1 = `-mllen -nocat` (ML branch lengths on the NJ topology,
-                                   Jukes-Cantor, constant rates); 0 = none */
+    int32_t mllen;              /* vft_nj_ml_newick: 0 = none; 1 = `-mllen -nocat` (ML branch lengths on the NJ topology,
+                                   Jukes-Cantor, constant rates); n >= 2 = `-mllen -cat n` (CAT approximation with n rate
+                                   categories fitted after the first round, setMLRates NJ.tcc:5429-5488; the
+                                   reference's default is 20) */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
@@ -56,11 +58,13 @@ int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_
    Jukes-Cantor (VeryFastTreeImpl.tcc:249-311: rounds of optimizeAllBranchLengths + treeLogLk until the lengths settle);
    the printed lengths are then the ML ones, as in the reference's output.  me_lengths must be set (the reference always
    runs updateBranchLengths first).  loglk[loglk_cap] (may be NULL) receives "TreeLogLk Length<k>" of each round,
-   n_rounds the number of rounds run. */
+   n_rounds the number of rounds run; rates[rates_cap] / n_rates / ratecat[n_pos] (each may be NULL) the fitted rate
+   categories - the reference's "Rates" and (0-based) "SiteCategories" log lines. */
 int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos, int32_t precision,
                      const vft_nj_options *opt, int32_t me_lengths, int32_t n_bootstrap, const int64_t *unique_first,
                      const int64_t *aln_next, int64_t n_all, const char *names, char *out, int64_t out_cap,
-                     int64_t *out_len, double *loglk, int32_t loglk_cap, int32_t *n_rounds, char *err, int32_t err_len);
+                     int64_t *out_len, double *loglk, int32_t loglk_cap, int32_t *n_rounds, double *rates,
+                     int32_t rates_cap, int32_t *n_rates, int32_t *ratecat, char *err, int32_t err_len);
 
 /* The first n values of the random stream the bootstrap columns are drawn from (Knuth's ran_array at its default
    seed, as the reference uses it, Knuth.cpp:95-111): exported so that tests can pin the host generator. */

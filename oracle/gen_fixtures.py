@@ -140,10 +140,14 @@ def gen_blackbox(tmp):
 
 
 MLLEN_CASES = [
-    # name, flags, n_seq, n_pos, mu, gap, seed: `-nome -mllen -nocat -nosupport` (Jukes-Cantor, constant rates)
-    ("ml_nt_200", ["-nt"], 200, 120, 0.05, 0.02, 21),            # same alignment as bb_nt_200
-    ("ml_nt_400_double", ["-nt", "-double-precision"], 400, 150, 0.06, 0.03, 31),
-    ("ml_nt_30", ["-nt"], 30, 300, 0.10, 0.05, 32),
+    # name, flags, n_seq, n_pos, mu, gap, seed: `-nome -mllen -nosupport` + flags (Jukes-Cantor)
+    ("ml_nt_200", ["-nt", "-nocat"], 200, 120, 0.05, 0.02, 21),            # same alignment as bb_nt_200
+    ("ml_nt_400_double", ["-nt", "-double-precision", "-nocat"], 400, 150, 0.06, 0.03, 31),
+    ("ml_nt_30", ["-nt", "-nocat"], 30, 300, 0.10, 0.05, 32),
+    # the default CAT approximation: 20 rate categories fitted after the first round (setMLRates)
+    ("ml_nt_200_cat", ["-nt"], 200, 120, 0.05, 0.02, 21),
+    ("ml_nt_300_cat", ["-nt"], 300, 400, 0.08, 0.02, 33),
+    ("ml_nt_150_double_cat", ["-nt", "-double-precision", "-cat", "8"], 150, 200, 0.08, 0.04, 34),
 ]
 
 
@@ -154,13 +158,17 @@ def gen_mllen(tmp):
         fa = os.path.join(tmp, name + ".fa")
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
         log = os.path.join(tmp, name + ".log")
-        cmd = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-nome", "-mllen", "-nocat", "-nosupport", "-log", log, fa]
+        cmd = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-nome", "-mllen", "-nosupport", "-log", log, fa]
         res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         text = open(log).read()
         ll = [float(m.group(1)) for m in re.finditer(r"^TreeLogLk\tLength\d+\t(\S+)\tMaxChange", text, re.M)]
         assert ll, "no TreeLogLk lines for " + name
+        rates = [float(x) for x in re.search(r"^Rates((?: \S+)+)$", text, re.M).group(1).split()]
+        cats = [int(x) - 1 for x in re.search(r"^SiteCategories((?: \d+)+)$", text, re.M).group(1).split()]
+        assert len(cats) == L
         dst = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(dst, codes=codes, loglk=np.array(ll), newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            rates=np.array(rates), ratecat=np.array(cats, dtype=np.int32),
                             flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
         print("%-20s %2d rounds  final logLk %.4f  %7.1f KiB" % (name, len(ll), ll[-1], os.path.getsize(dst) / 1024.0))
 

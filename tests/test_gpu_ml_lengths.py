@@ -100,3 +100,34 @@ def test_mllen_pipeline_matches_the_reference_run(name, dt):
     assert np.allclose(got_len, ref_len, rtol=5e-3, atol=2e-5 if dt == np.float32 else 1e-8)
     # observed on MI355X: the trees are byte-identical (every Jukes-Cantor line search follows the reference's)
     assert tree == ref, "lengths differing in the printed digits: %d of %d" % (int((got_len != ref_len).sum()), len(ref_len))
+
+
+@pytest.mark.parametrize("name,dt,ncat", [("ml_nt_200_cat", np.float32, 20), ("ml_nt_300_cat", np.float32, 20),
+                                          ("ml_nt_150_double_cat", np.float64, 8)])
+def test_mllen_with_cat_rates_matches_the_reference_run(name, dt, ncat):
+    """`-nome -mllen` with the CAT approximation (setMLRates, NJ.tcc:5429-5488, after the first round): the fitted
+    rates, the category of every site, TreeLogLk of every round and the final tree."""
+    import re
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load(name)
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    tree, loglk, rates, ratecat = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names,
+                                            dtype=dt, me_lengths=True, mllen=ncat, return_rates=True)
+    assert len(rates) == ncat
+    # a site whose two best categories tie to rounding could pick the other one; none does on these alignments
+    assert np.array_equal(ratecat, d["ratecat"])
+    assert np.allclose(rates, d["rates"], rtol=0, atol=1e-6)              # printed with %f
+    want = d["loglk"]
+    assert len(loglk) == len(want)
+    assert np.allclose(loglk, want, rtol=1e-4, atol=0)                    # the north star's bar
+    assert np.allclose(loglk, want, rtol=2e-6 if dt == np.float32 else 1e-8, atol=6e-5), (loglk, want)
+    ref = bytes(d["newick"]).decode().strip()
+    strip = lambda t: re.sub(r":[0-9.eE+-]+", ":", t)
+    assert strip(tree) == strip(ref)
+    got_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", tree)])
+    ref_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", ref)])
+    assert np.allclose(got_len, ref_len, rtol=5e-3, atol=2e-5 if dt == np.float32 else 1e-8)
+    # observed on MI355X: byte-identical trees here as well
+    assert tree == ref, "%s: %d of %d printed lengths differ" % (name, int((got_len != ref_len).sum()), len(ref_len))

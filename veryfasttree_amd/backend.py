@@ -128,7 +128,7 @@ def uniquify(codes):
 
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
-              unique=None, scoredist=False, n_bootstrap=0, mllen=False, return_loglk=False):
+              unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -145,7 +145,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     if second_level is None:
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
-                     200, 3, 1.0, 0.6, 1 if scoredist else 0, 1 if mllen else 0)
+                     200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen))
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)
@@ -153,12 +153,17 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     err = C.create_string_buffer(512)
     loglk = np.zeros(64, np.float64)
     n_rounds = I32(0)
+    rates = np.zeros(64, np.float64)
+    n_rates = I32(0)
+    ratecat = np.zeros(L, np.int32)
     rc = lib.vft_nj_ml_newick(ops.ctx, _ptr(codes), I64(n), I64(L), I32(np.dtype(dtype).itemsize), C.byref(opt),
                               I32(1 if me_lengths else 0), I32(n_bootstrap), _ptr(unique_first), _ptr(aln_next),
                               I64(len(codes_all)), blob, out, I64(cap), C.byref(olen), _ptr(loglk), I32(64),
-                              C.byref(n_rounds), err, I32(512))
+                              C.byref(n_rounds), _ptr(rates), I32(64), C.byref(n_rates), _ptr(ratecat), err, I32(512))
     if rc != 0:
         raise VftError(err.value.decode() or "vft_nj_ml_newick failed")
+    if return_rates:
+        return out.value.decode(), loglk[:n_rounds.value], rates[:n_rates.value], ratecat
     if return_loglk:
         return out.value.decode(), loglk[:n_rounds.value]
     return out.value.decode()

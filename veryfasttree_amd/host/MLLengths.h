@@ -11,6 +11,7 @@
 #define VFT_ML_LENGTHS_H
 
 #include <cstdint>
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -146,6 +147,100 @@ namespace veryfasttree {
             total += ll3;
             if (nLeafGaps >= 0) total += (double) (nLeafGaps - nPos) * std::log(4.0);
             return total;
+        }
+
+        /* treeLogLk's per-site part (NJ.tcc:5116-5134, :5172-5227): the product over all splits of the per-site pair
+           likelihoods, kept in range the reference's way, as a log.  Without the per-site Jukes-Cantor gap correction
+           (NJ.tcc:5247-5252), which is the same for every rate and so cannot change setMLRates' choice.
+           The pair likelihoods come back from the device split by split (vft_pair_loglk with site_lk); the running
+           products are host work for now. */
+        void siteLogLk(int64_t nPos, double *siteLoglk) {
+            std::vector<REAL> bl((size_t) nNodes);
+            getLengths(bl.data());
+            std::vector<int64_t> a, b;
+            std::vector<double> len;
+            for (int64_t v: order) {   /* post-order, the root last */
+                a.push_back(child[3 * v]);
+                b.push_back(child[3 * v + 1]);
+                const REAL sum = bl[(size_t) a.back()] + bl[(size_t) b.back()];
+                len.push_back((double) sum);
+            }
+            std::vector<double> lik((size_t) nPos, 1.0);
+            for (int64_t p = 0; p < nPos; p++) siteLoglk[p] = 0.0;
+            const double under = 1.0e-4, underInv = 1.0e4, logUnder = 9.21034037197618;   /* Constants.h:13-15 */
+            auto keepInRange = [&]() {
+                for (int64_t p = 0; p < nPos; p++)
+                    while (lik[(size_t) p] < under) {
+                        lik[(size_t) p] *= underInv;
+                        siteLoglk[p] -= logUnder;
+                    }
+            };
+            const int64_t n = (int64_t) a.size();
+            const int64_t chunk = std::max<int64_t>(1, (int64_t) ((256u << 20) / (8 * (size_t) nPos)));
+            std::vector<double> ll, site;
+            for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+                const int64_t cnt = std::min(chunk, n - k0);
+                ll.resize((size_t) cnt);
+                site.resize((size_t) (cnt * nPos));
+                chk(vft_pair_loglk(ctx, cnt, a.data() + k0, b.data() + k0, len.data() + k0, ll.data(), site.data()));
+                for (int64_t k = 0; k < cnt; k++) {
+                    const double *row = site.data() + (size_t) (k * nPos);
+                    for (int64_t p = 0; p < nPos; p++) lik[(size_t) p] *= row[p];
+                    keepInRange();
+                }
+            }
+            /* the root's third branch (NJ.tcc:5138-5151): multiplied in after the range check of the root's pair */
+            const int64_t r0 = child[3 * root], r1 = child[3 * root + 1], r2 = child[3 * root + 2];
+            const double l0 = (double) bl[(size_t) r0], l1 = (double) bl[(size_t) r1], l2 = (double) bl[(size_t) r2];
+            chk(vft_posterior_profiles(ctx, 1, &root, &r0, &r1, &l0, &l1));
+            double ll3 = 0;
+            site.resize((size_t) nPos);
+            chk(vft_pair_loglk(ctx, 1, &root, &r2, &l2, &ll3, site.data()));
+            for (int64_t p = 0; p < nPos; p++) siteLoglk[p] += std::log(lik[(size_t) p] * site[(size_t) p]);
+        }
+
+        /* setMLRates (NJ.tcc:5429-5488) for nCat > 1: the CAT approximation.  MLSiteRates (:5367-5378) spreads nCat
+           rates evenly in log space over [1/nCat, nCat]; MLSiteLikelihoodsByRate (:5381-5410) evaluates the tree's
+           site likelihoods with every site at each rate in turn; every site takes the rate with the best likelihood x
+           Gamma(3, 1/3) prior; the rates are rescaled to mean 1 over the sites; the profiles are rebuilt.
+           rates / ratecat receive the result (what the reference logs as "Rates" / "SiteCategories"). */
+        void setMLRates(int32_t nCat, int64_t nPos, std::vector<REAL> &rates, std::vector<int64_t> &ratecat) {
+            ratecat.assign((size_t) nPos, 0);
+            if (nCat <= 1) {
+                rates.assign(1, (REAL) 1);
+                chk(vft_set_rates(ctx, rates.data(), 1, ratecat.data()));
+                recomputeMLProfiles();
+                return;
+            }
+            rates.resize((size_t) nCat);
+            const double logNCat = std::log((double) nCat);
+            const double logd = (logNCat + logNCat) / (double) (nCat - 1);
+            for (int32_t i = 0; i < nCat; i++) rates[(size_t) i] = (REAL) std::exp(-logNCat + logd * (double) i);
+            std::vector<double> siteLoglk((size_t) (nPos * nCat));
+            for (int32_t i = 0; i < nCat; i++) {
+                chk(vft_set_rates(ctx, &rates[(size_t) i], 1, ratecat.data()));
+                recomputeMLProfiles();
+                siteLogLk(nPos, siteLoglk.data() + (size_t) (nPos * i));
+            }
+            double sumRates = 0;
+            for (int64_t p = 0; p < nPos; p++) {
+                int64_t best = -1;
+                double dBest = -1e20;
+                for (int32_t i = 0; i < nCat; i++) {
+                    const double r = (double) rates[(size_t) i];
+                    const double withPrior = siteLoglk[(size_t) (nPos * i + p)] + 2.0 * std::log(r) - 3.0 * r;
+                    if (withPrior > dBest) {
+                        best = i;
+                        dBest = withPrior;
+                    }
+                }
+                ratecat[(size_t) p] = best;
+                sumRates += (double) rates[(size_t) best];
+            }
+            const double avgRate = sumRates / (double) nPos;
+            for (int32_t i = 0; i < nCat; i++) rates[(size_t) i] = (REAL) ((double) rates[(size_t) i] / avgRate);
+            chk(vft_set_rates(ctx, rates.data(), nCat, ratecat.data()));
+            recomputeMLProfiles();
         }
 
         int64_t evaluations() {

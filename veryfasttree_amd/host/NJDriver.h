@@ -340,12 +340,12 @@ namespace veryfasttree {
 
         /* `-mllen -nocat` under Jukes-Cantor (VeryFastTreeImpl.tcc:249-311): rounds of optimizeAllBranchLengths +
            treeLogLk on the finished topology until the largest change of a length drops below 0.001, at most
-           round(log2 N) rounds; after the first round setMLRates with one category = recomputeMLProfiles
-           (NJ.tcc:5429-5436).  recomputeProfiles(tmatAsDist) at the start (VeryFastTreeImpl.tcc:253-256) is the identity
+           round(log2 N) rounds; after the first round setMLRates (NJ.tcc:5429-5488): with one category (-nocat) just
+           recomputeMLProfiles, with nRateCats > 1 the CAT approximation (MLLengths::setMLRates).  recomputeProfiles(tmatAsDist) at the start (VeryFastTreeImpl.tcc:253-256) is the identity
            here: without a transition matrix the unweighted averages are the profiles the joins already made.
            Call after updateBranchLengths; the context needs max_nodes >= 3 * nSeqs.  Returns the tree log-likelihood
            after each round (the reference's "TreeLogLk Length<k>" log lines). */
-        std::vector<double> mlLengths() {
+        std::vector<double> mlLengths(int32_t nRateCats = 1) {
             if (root < 0) throw std::invalid_argument("NJDriver::mlLengths before finishRoot");
             const bool f32 = sizeof(REAL) == 4;
             const REAL one = 1;
@@ -382,7 +382,7 @@ namespace veryfasttree {
                 loglk.push_back(ml.treeLogLk(nPos, nLeafGaps));
                 /* (the reference never updates its dLastLogLk, so the likelihood clause of its test cannot fire) */
                 const bool converged = iRound > 1 && dMaxChange < 0.001;
-                if (iRound == 1) ml.recomputeMLProfiles();
+                if (iRound == 1) ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);   /* VeryFastTreeImpl.tcc:299-305 */
                 if (converged) break;
             }
             mlEvaluations = ml.evaluations();
@@ -390,6 +390,8 @@ namespace veryfasttree {
         }
 
         int64_t mlEvaluations = 0;
+        std::vector<REAL> mlRates;           /* what the reference logs as "Rates" ... */
+        std::vector<int64_t> mlRateCat;      /* ... and "SiteCategories" (0-based here) */
 
         /* printNJ (NJ.tcc:2706-2794, no supports, no quoting): depth-first, children in stored order, leaf names with
            their duplicates expanded as (a:0.0,b:0.0), lengths as %.5f (float) / %.9f (double).

@@ -35,7 +35,8 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
 template<typename REAL>
 static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
                            bool meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext,
-                           int64_t nAll, const char *names, std::vector<double> &loglk) {
+                           int64_t nAll, const char *names, std::vector<double> &loglk, std::vector<double> &rates,
+                           std::vector<int64_t> &ratecat) {
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
     drv.run(-1);
     drv.finishRoot();
@@ -43,7 +44,9 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     if (nBootstrap > 0) drv.computeSupports(nBootstrap);
     if (o && o->mllen) {
         if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: mllen needs me_lengths (updateBranchLengths runs first)");
-        loglk = drv.mlLengths();
+        loglk = drv.mlLengths(o->mllen);
+        rates.assign(drv.mlRates.begin(), drv.mlRates.end());
+        ratecat = drv.mlRateCat;
     }
     drv.report();
     std::vector<std::string> nm;
@@ -58,12 +61,19 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
 extern "C" int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, int32_t precision,
                                 const vft_nj_options *opt, int32_t meLengths, int32_t nBootstrap, const int64_t *uniqueFirst,
                                 const int64_t *alnNext, int64_t nAll, const char *names, char *out, int64_t outCap,
-                                int64_t *outLen, double *loglk, int32_t loglkCap, int32_t *nRounds, char *err, int32_t errLen) {
+                                int64_t *outLen, double *loglk, int32_t loglkCap, int32_t *nRounds, double *ratesOut,
+                                int32_t ratesCap, int32_t *nRates, int32_t *ratecatOut, char *err, int32_t errLen) {
     if (!ctx || !codes || !uniqueFirst || !alnNext || !names || !outLen) return VFT_ERR_INVALID;
     try {
-        std::vector<double> ll;
-        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll)
-                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll);
+        std::vector<double> ll, rates;
+        std::vector<int64_t> ratecat;
+        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll, rates, ratecat)
+                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll, rates, ratecat);
+        if (nRates) *nRates = (int32_t) rates.size();
+        if (ratesOut)
+            for (size_t k = 0; k < rates.size() && (int32_t) k < ratesCap; k++) ratesOut[k] = rates[k];
+        if (ratecatOut)
+            for (size_t k = 0; k < ratecat.size(); k++) ratecatOut[k] = (int32_t) ratecat[k];
         if (nRounds) *nRounds = (int32_t) ll.size();
         if (loglk)
             for (size_t k = 0; k < ll.size() && (int32_t) k < loglkCap; k++) loglk[k] = ll[k];
@@ -86,7 +96,7 @@ extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, 
         o.mllen = 0;
     }
     return vft_nj_ml_newick(ctx, codes, nSeqs, nPos, precision, opt ? &o : nullptr, meLengths, nBootstrap, uniqueFirst, alnNext,
-                            nAll, names, out, outCap, outLen, nullptr, 0, nullptr, err, errLen);
+                            nAll, names, out, outCap, outLen, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, err, errLen);
 }
 
 extern "C" void vft_knuth_stream(double *out, int64_t n) {
