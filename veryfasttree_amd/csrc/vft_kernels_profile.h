@@ -30,7 +30,23 @@ static inline size_t vft_commit_scratch_bytes(const VftDims &d, size_t rs) {
     return (b + 255) & ~(size_t) 255;
 }
 
-#define VFT_COMMIT_WG 256
+#define VFT_COMMIT_WG 1024
+// coalesced copy of n elements with several loads in flight per thread (the single workgroup that owns a tile is
+// latency-bound otherwise: one load -> one store per iteration is a chain of L2 round trips)
+template <typename T>
+__device__ __forceinline__ void vft_block_copy(T *dst, const T *src, int64_t n) {
+    const int64_t step = VFT_COMMIT_WG;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * step < n; i += 8 * step) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[i + u * step];
+#pragma unroll
+        for (int u = 0; u < 8; u++) dst[i + u * step] = v[u];
+    }
+    for (; i < n; i += step) dst[i] = src[i];
+}
+
 // One workgroup per tile that received nodes.  order[segFirst[s] .. segFirst[s+1]) are the batch indices (into
 // nodes[] / the stash) of the nodes of segment s, all in one tile.  The tile's new masks, prefix offsets and streams
 // are assembled in scratch from (old streams of the untouched lanes) + (stash of the written lanes) and then copied
@@ -41,7 +57,7 @@ __global__ __launch_bounds__(VFT_COMMIT_WG) void k_tile_commit(Arena<REAL> A, co
                                                                size_t scratchStride) {
     __shared__ int sLaneK[VFT_TILE];
     __shared__ unsigned long long sWrite;
-    __shared__ uint32_t sCntV[VFT_COMMIT_WG], sCntW[VFT_COMMIT_WG], sTot[2];
+    __shared__ uint32_t sWaveV[VFT_COMMIT_WG / 64], sWaveW[VFT_COMMIT_WG / 64], sTot[2];
     const int tid = threadIdx.x;
     const int first = segFirst[blockIdx.x], cnt = segFirst[blockIdx.x + 1] - first;
     if (tid < VFT_TILE) sLaneK[tid] = -1;
@@ -67,7 +83,7 @@ __global__ __launch_bounds__(VFT_COMMIT_WG) void k_tile_commit(Arena<REAL> A, co
     REAL *wS = fS + (size_t) nPosPad * VFT_TILE * NC;
     // 1. new masks; every thread owns a contiguous run of columns
     const int64_t PP = (nPosPad + VFT_COMMIT_WG - 1) / VFT_COMMIT_WG;
-    const int64_t pa = (int64_t) tid * PP, pb = pa + PP < nPosPad ? pa + PP : nPosPad;
+    const int64_t pa = (int64_t) tid * PP < nPosPad ? (int64_t) tid * PP : nPosPad, pb = pa + PP < nPosPad ? pa + PP : nPosPad;
     uint32_t cV = 0, cW = 0;
     for (int64_t p = pa; p < pb; p++) {
         const ColMask old = A.colMask[mi0 + p];
@@ -89,15 +105,27 @@ __global__ __launch_bounds__(VFT_COMMIT_WG) void k_tile_commit(Arena<REAL> A, co
         cV += (uint32_t) __popcll(nv);
         cW += (uint32_t) __popcll(nw);
     }
-    sCntV[tid] = cV;
-    sCntW[tid] = cW;
+    // exclusive scan over the runs: inside the wavefront by shuffles, across the 16 wavefronts through LDS
+    uint32_t iV = cV, iW = cW;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(iV, off, 64), w = __shfl_up(iW, off, 64);
+        if ((tid & 63) >= off) {
+            iV += v;
+            iW += w;
+        }
+    }
+    if ((tid & 63) == 63) {
+        sWaveV[tid >> 6] = iV;
+        sWaveW[tid >> 6] = iW;
+    }
     __syncthreads();
-    if (tid == 0) {   // exclusive scan over the 256 runs
+    if (tid == 0) {
         uint32_t aV = 0, aW = 0;
-        for (int t = 0; t < VFT_COMMIT_WG; t++) {
-            const uint32_t v = sCntV[t], w = sCntW[t];
-            sCntV[t] = aV;
-            sCntW[t] = aW;
+        for (int t = 0; t < VFT_COMMIT_WG / 64; t++) {
+            const uint32_t v = sWaveV[t], w = sWaveW[t];
+            sWaveV[t] = aV;
+            sWaveW[t] = aW;
             aV += v;
             aW += w;
         }
@@ -105,41 +133,56 @@ __global__ __launch_bounds__(VFT_COMMIT_WG) void k_tile_commit(Arena<REAL> A, co
         sTot[1] = aW;
     }
     __syncthreads();
-    // 2. offsets and streams into scratch
-    uint32_t oV = sCntV[tid], oW = sCntW[tid];
-    for (int64_t p = pa; p < pb; p++) {
-        const ColMask m = nm[p], old = A.colMask[mi0 + p];
-        const ColOff oo = A.colOff[mi0 + p];
-        no[p].vec = oV;
-        no[p].w = oW;
-        unsigned long long bits = m.vec;
-        while (bits) {
-            const int L = __ffsll((long long) bits) - 1;
-            bits &= bits - 1;
-            const REAL *src = ((W >> L) & 1ull)
-                                  ? stash + ((int64_t) sLaneK[L] * nPos + p) * (NC + 1)
-                                  : A.profF + fBase + (int64_t) (oo.vec + __popcll(old.vec & ((1ull << L) - 1ull))) * NC;
-#pragma unroll
-            for (int k = 0; k < NC; k++) fS[(int64_t) oV * NC + k] = src[k];
-            oV++;
+    // 2. offsets of every column (each thread walks its own run) ...
+    {
+        uint32_t oV = sWaveV[tid >> 6] + iV - cV, oW = sWaveW[tid >> 6] + iW - cW;
+        for (int64_t p = pa; p < pb; p++) {
+            no[p].vec = oV;
+            no[p].w = oW;
+            oV += (uint32_t) __popcll(nm[p].vec);
+            oW += (uint32_t) __popcll(nm[p].w);
         }
-        bits = m.w;
-        while (bits) {
-            const int L = __ffsll((long long) bits) - 1;
-            bits &= bits - 1;
-            wS[oW++] = ((W >> L) & 1ull) ? stash[((int64_t) sLaneK[L] * nPos + p) * (NC + 1) + NC]
-                                         : A.profW[wBase + oo.w + __popcll(old.w & ((1ull << L) - 1ull))];
+    }
+    __syncthreads();
+    // ... and the streams into scratch, one wavefront per column, lane = node of the tile: every element is an
+    // independent copy (no serial walk over a column's bits), consecutive lanes write consecutive stream slots
+    {
+        const int L = tid & 63;
+        const unsigned long long below = (1ull << L) - 1ull;
+        const bool mine = (W >> L) & 1ull;
+        const int64_t stashRow = mine ? (int64_t) sLaneK[L] * nPos : 0;
+#pragma unroll 2
+        for (int64_t p = tid >> 6; p < nPos; p += VFT_COMMIT_WG / 64) {
+            const ColMask m = nm[p], old = A.colMask[mi0 + p];
+            const ColOff oo = A.colOff[mi0 + p], on = no[p];
+            if ((m.vec >> L) & 1ull) {
+                const REAL *src = mine ? stash + (stashRow + p) * (NC + 1)
+                                       : A.profF + fBase + (int64_t) (oo.vec + __popcll(old.vec & below)) * NC;
+                REAL *dst = fS + (int64_t) (on.vec + __popcll(m.vec & below)) * NC;
+                REAL v[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) v[k] = src[k];
+#pragma unroll
+                for (int k = 0; k < NC; k++) dst[k] = v[k];
+            }
+            if ((m.w >> L) & 1ull)
+                wS[on.w + __popcll(m.w & below)] = mine ? stash[(stashRow + p) * (NC + 1) + NC]
+                                                        : A.profW[wBase + oo.w + __popcll(old.w & below)];
         }
     }
     __syncthreads();   // every read of the old streams is done, scratch is complete
-    // 3. copy over the tile (coalesced)
-    for (int64_t i = tid; i < nPosPad; i += VFT_COMMIT_WG) {
-        A.colMask[mi0 + i] = nm[i];
-        A.colOff[mi0 + i] = no[i];
-    }
+    // 3. copy over the tile (coalesced, 16-byte elements where the sizes allow)
+    vft_block_copy<ColMask>(A.colMask + mi0, nm, nPosPad);
+    vft_block_copy<ColOff>(A.colOff + mi0, no, nPosPad);
     const int64_t nF = (int64_t) sTot[0] * NC, nW = sTot[1];
-    for (int64_t i = tid; i < nF; i += VFT_COMMIT_WG) A.profF[fBase + i] = fS[i];
-    for (int64_t i = tid; i < nW; i += VFT_COMMIT_WG) A.profW[wBase + i] = wS[i];
+    {
+        const int64_t per = 16 / (int64_t) sizeof(REAL), nF16 = nF / per;
+        vft_block_copy<uint4>((uint4 *) (A.profF + fBase), (const uint4 *) fS, nF16);
+        for (int64_t i = nF16 * per + tid; i < nF; i += VFT_COMMIT_WG) A.profF[fBase + i] = fS[i];
+        const int64_t nW16 = nW / per;
+        vft_block_copy<uint4>((uint4 *) (A.profW + wBase), (const uint4 *) wS, nW16);
+        for (int64_t i = nW16 * per + tid; i < nW; i += VFT_COMMIT_WG) A.profW[wBase + i] = wS[i];
+    }
 }
 
 // staging (row-major w[nPos], c[nPos], f[nPos][NC]) -> arena
