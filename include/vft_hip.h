@@ -202,6 +202,18 @@ int vft_posterior_profiles_blen(vft_ctx *ctx, int64_t n, const int64_t *out, con
    Stream-ordered. */
 int vft_ml_optimize_splits(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, const int64_t *recompute,
                            double ftol, double atol);
+/* testSplitsML (NJ.tcc:6800-6999) for n independent internal splits, one workgroup each: ids[4k..4k+3] = A, B, C, D of
+   setupABCD (NJ.tcc:1942-1975), len_idx[5k..5k+4] = the branchlength[] slots of A, B, C, D and of the split itself.
+   loglk[3k..3k+2] = quartet log-likelihood of AB|CD with the current lengths (MLQuartetLogLk, NJ.tcc:5412), of AC|BD
+   and of AD|BC after MLQuartetOptimize (NJ.tcc:1650-1788), the better alternative optimised a second time when it is
+   within close_limit (Constants::closeLogLkLimit = 5) of AB|CD or when always_second_pass (-mlacc 2).
+   n_boot > 0: support[k] = SHSupport (NJ.tcc:1126-1165) over the resamples col[n_boot][n_pos] (resampleColumns,
+   NJ.tcc:705-727); the caller sets the supports of bad splits to 0 (NJ.tcc:6956, 6992).  lengths (may be NULL):
+   [n][2][5] optimised A, B, C, D, I lengths of the two alternatives (what an NNI would adopt).
+   n_pos <= 1024; with n_boot > 0 also n_pos <= 2500. */
+int vft_ml_split_tests(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, double ftol, double atol,
+                       double close_limit, int32_t always_second_pass, double *loglk, int32_t n_boot, const int32_t *col,
+                       double *support, double *lengths);
 /* likelihood evaluations (pairLogLk calls of the reference) made by vft_ml_optimize_splits since the last query */
 int vft_ml_eval_count(vft_ctx *ctx, int64_t *evals);
 

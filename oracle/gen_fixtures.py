@@ -166,8 +166,14 @@ def gen_mllen(tmp):
         rates = [float(x) for x in re.search(r"^Rates((?: \S+)+)$", text, re.M).group(1).split()]
         cats = [int(x) - 1 for x in re.search(r"^SiteCategories((?: \d+)+)$", text, re.M).group(1).split()]
         assert len(cats) == L
+        # the same with the default SH-like supports (testSplitsML, 1000 resamples)
+        cmd2 = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-nome", "-mllen", fa]
+        res2 = subprocess.run(cmd2, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        mb = re.search(r"Bad splits: (\d+)/(\d+)", res2.stderr.decode(errors="replace"))
         dst = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(dst, codes=codes, loglk=np.array(ll), newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
+                            bad_splits=np.array([int(mb.group(1)), int(mb.group(2))], dtype=np.int64),
                             rates=np.array(rates), ratecat=np.array(cats, dtype=np.int32),
                             flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
         print("%-20s %2d rounds  final logLk %.4f  %7.1f KiB" % (name, len(ll), ll[-1], os.path.getsize(dst) / 1024.0))

@@ -12,6 +12,7 @@ n, L = int(sys.argv[1]), int(sys.argv[2])
 mu = float(sys.argv[3]) if len(sys.argv) > 3 else 0.03
 gap = float(sys.argv[4]) if len(sys.argv) > 4 else 0.01
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+nboot = int(os.environ.get("VFT_ML_BOOT", "0"))   # 1000 = the reference's default SH-like supports
 ncat = int(os.environ.get("VFT_ML_CAT", "1"))   # 1 = -nocat, 20 = the reference's default CAT approximation
 codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
 names = ["s%d" % k for k in range(n)]
@@ -20,11 +21,11 @@ t0 = time.perf_counter()
 nj_newick(make, codes, names, me_lengths=True)
 t_nj = time.perf_counter() - t0
 t0 = time.perf_counter()
-tree, loglk = nj_newick(make, codes, names, me_lengths=True, mllen=ncat, return_loglk=True)
+tree, loglk = nj_newick(make, codes, names, me_lengths=True, mllen=ncat, return_loglk=True, n_bootstrap=nboot)
 t_ml = time.perf_counter() - t0
 print("NJ + ME lengths                 %8.2f s" % t_nj)
-print("NJ + ME lengths + ML lengths (%d rate categories)   %8.2f s   -> ML stage %.2f s, %d rounds (%.2f s per round incl. treeLogLk)"
-      % (ncat, t_ml, t_ml - t_nj, len(loglk), (t_ml - t_nj) / max(len(loglk), 1)))
+print("NJ + ME lengths + ML lengths (%d rate categories, %d resamples)   %8.2f s   -> ML stage %.2f s, %d rounds (%.2f s per round incl. treeLogLk)"
+      % (ncat, nboot, t_ml, t_ml - t_nj, len(loglk), (t_ml - t_nj) / max(len(loglk), 1)))
 print("TreeLogLk per round: " + " ".join("%.4f" % x for x in loglk))
 if len(sys.argv) > 6:
     open(sys.argv[6], "w").write(tree + "\n")

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """FASTA (nucleotides) -> Newick on one MI355X: the tree `VeryFastTree -nt [-fastest] -noml -nome [-nosupport]` prints,
-or - with -mllen - the tree of `VeryFastTree -nt -nome -mllen [-nocat | -cat N] -nosupport` (Jukes-Cantor).
+or - with -mllen - the tree of `VeryFastTree -nt -nome -mllen [-nocat | -cat N] [-nosupport]` (Jukes-Cantor).
 
     python tools/nj_tree.py in.fasta [-fastest] [-double] [-nosupport] [-nj-lengths] [-mllen [-nocat | -cat N]] > tree.nwk
 
 Neighbour joining with top hits on the device (veryfasttree_amd/host/NJDriver.h), the root, minimum-evolution branch
 lengths (updateBranchLengths), local-bootstrap supports (1000 resamples, reliabilityNJ) and printNJ; -nj-lengths keeps
 the NJ branch lengths and prints no supports (the reference's "NJ" log line).  -mllen: maximum-likelihood branch
-lengths on that topology (optimizeAllBranchLengths rounds, CAT rate categories unless -nocat; no supports - the reference
-would compute SH-like ones, which are not built); the TreeLogLk of every round goes to stderr.
+lengths on that topology (optimizeAllBranchLengths rounds, CAT rate categories unless -nocat) and SH-like supports
+(testSplitsML, 1000 resamples) unless -nosupport; the TreeLogLk of every round goes to stderr.
 Sequence normalisation and uniquify follow Alignment.cpp:453-526 (U -> T, '.' -> '-', duplicates by sequence string in
 first-occurrence order)."""
 import os, sys
@@ -45,7 +45,7 @@ def main():
     mllen = 0
     if "-mllen" in args:
         mllen = 1 if "-nocat" in args else (int(args[args.index("-cat") + 1]) if "-cat" in args else 20)
-    n_boot = 0 if ("-nosupport" in args or nj_len or mllen) else 1000
+    n_boot = 0 if ("-nosupport" in args or nj_len) else 1000
     names, seqs = read_fasta(args[0])
     if len({len(s) for s in seqs}) != 1:
         sys.exit("sequences have different lengths: not an alignment")

@@ -1751,6 +1751,100 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
     return VFT_OK;
 }
 
+template <typename REAL, int NC>
+static int ml_split_test_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
+                                double closeLimit, int always2, double *dLoglk, double *dSite, double *dLen) {
+#define VFT_MLSPLIT_CASE(CPT)                                                                                           \
+    case CPT:                                                                                                           \
+        launch((k_ml_split_test<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c),   \
+               dIds, dLi, (const REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, always2, dLoglk, dSite,  \
+               dLen, c->mlEvals);                                                                                        \
+        break;
+    switch (cpt) {
+        VFT_MLSPLIT_CASE(1)
+        VFT_MLSPLIT_CASE(2)
+        VFT_MLSPLIT_CASE(4)
+        default:
+            return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the in-kernel quartet optimiser");
+    }
+#undef VFT_MLSPLIT_CASE
+    return VFT_OK;
+}
+
+// testSplitsML (NJ.tcc:6800-6999) for n independent splits: ids[4k..] = A, B (children), C, D (sibling side / up-profile)
+// of setupABCD, len_idx[5k..] = the branchlength[] slots of A, B, C, D and the split's own branch.  loglk[3k..] receives
+// the quartet log-likelihoods of AB|CD (current lengths), AC|BD and AD|BC (lengths optimised); with n_boot > 0 and
+// col ([n_boot][n_pos] resampled column indices) support[k] = SHSupport (NJ.tcc:1126-1165), the caller zeroes the
+// supports of bad splits.  lengths (may be NULL): the optimised [2][5] lengths of the two alternatives.
+extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, double ftol, double atol,
+                                  double closeLimit, int32_t alwaysSecondPass, double *loglk, int32_t nBoot, const int32_t *col,
+                                  double *support, double *lengths) {
+    if (!c || n < 0 || !ids || !lenIdx || !loglk || (nBoot > 0 && (!col || !support))) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
+    for (int64_t k = 0; k < n; k++) {
+        for (int t = 0; t < 4; t++)
+            if (ids[4 * k + t] < 0 || ids[4 * k + t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: split %lld out of range", (long long) k);
+        for (int t = 0; t < 5; t++)
+            if (lenIdx[5 * k + t] < 0 || lenIdx[5 * k + t] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: split %lld out of range", (long long) k);
+    }
+    if (int r = ensure_blen(c)) return r;
+    if (!c->mlEvals) {
+        HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
+        HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
+    }
+    const int64_t nPos = c->d.nPos;
+    const int64_t per = cdiv(nPos, VFT_MLOPT_WG);
+    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
+    if (nBoot > 0 && (nPos > 65535 || (size_t) 3 * nPos * sizeof(double) > 60000)) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the SH resampling kernel");
+    // chunks of splits: per split 3 x nPos site log-likelihoods
+    int64_t chunk = (int64_t) ((512u << 20) / ((size_t) 3 * nPos * sizeof(double)));
+    chunk = chunk < 1 ? 1 : chunk > n ? n : chunk;
+    const size_t idB = (size_t) chunk * 8;
+    const size_t colB = nBoot > 0 ? (((size_t) nBoot * nPos * 2 + 255) & ~(size_t) 255) : 0;
+    const size_t siteB = (size_t) chunk * 3 * nPos * sizeof(double);
+    // scratch: ids[4] | lenIdx[5] | loglk[3] | lengths[10] | support[1] | colT | site
+    const size_t headB = (23 * idB + 255) & ~(size_t) 255;
+    if (int r = ensure_scratch(c, headB + colB + siteB + 512)) return r;
+    char *s = (char *) c->scratch;
+    uint16_t *dCol = (uint16_t *) (s + headB);
+    double *dSite = (double *) (s + headB + colB);
+    if (nBoot > 0) {
+        std::vector<uint16_t> colT((size_t) nBoot * nPos);
+        for (int32_t b = 0; b < nBoot; b++)
+            for (int64_t j = 0; j < nPos; j++) {
+                const int32_t v = col[(size_t) b * nPos + j];
+                if (v < 0 || v >= nPos) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: resampled column out of range");
+                colT[(size_t) j * nBoot + b] = (uint16_t) v;
+            }
+        HIPCHK(c, hipMemcpyAsync(dCol, colT.data(), colT.size() * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+        const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
+        const size_t cB = (size_t) cnt * 8;
+        int64_t *dIds = (int64_t *) s, *dLi = (int64_t *) (s + 4 * idB);
+        double *dLoglk = (double *) (s + 9 * idB), *dLen = (double *) (s + 12 * idB), *dSup = (double *) (s + 22 * idB);
+        HIPCHK(c, hipMemcpyAsync(dIds, ids + 4 * k0, 4 * cB, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dLi, lenIdx + 5 * k0, 5 * cB, hipMemcpyHostToDevice, c->stream));
+        int r = VFT_OK;
+        VFT_DISPATCH(c, (r = ml_split_test_launch<REAL, NC>(c, cnt, cpt, dIds, dLi, ftol, atol, closeLimit, alwaysSecondPass, dLoglk,
+                                                            dSite, dLen)));
+        if (r) return r;
+        LAUNCHCHK(c);
+        if (nBoot > 0) {
+            launch(k_sh_support, dim3((unsigned) cnt), dim3(256), (size_t) 3 * nPos * sizeof(double), c->stream, (const double *) dSite,
+                   (const double *) dLoglk, (const uint16_t *) dCol, nPos, nBoot, dSup);
+            LAUNCHCHK(c);
+            HIPCHK(c, hipMemcpyAsync(support + k0, dSup, cB, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(loglk + 3 * k0, dLoglk, 3 * cB, hipMemcpyDeviceToHost, c->stream));
+        if (lengths) HIPCHK(c, hipMemcpyAsync(lengths + 10 * k0, dLen, 10 * cB, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return VFT_OK;
+}
+
 // number of likelihood evaluations the optimiser has made since the last call (the reference's nLkCompute share)
 extern "C" int vft_ml_eval_count(vft_ctx *c, int64_t *evals) {
     if (!c || !evals) return VFT_ERR_INVALID;

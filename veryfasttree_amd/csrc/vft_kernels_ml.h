@@ -364,7 +364,7 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
 // `eval` is a workgroup-collective call.
 template <typename EVAL>
 __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin, double xguess, double xmax, double ftol,
-                                                        double atol) {
+                                                        double atol, double &fBest) {
     // initial bracket lo < mid < hi around the guess
     double lo, mid, hi;
     if (xguess == xmin) {
@@ -447,6 +447,7 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
             }
         }
     }
+    fBest = fx;
     return x;
 }
 
@@ -537,7 +538,8 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
         };
         double len = (double) blen[lI];
         if (len < minLen) len = minLen;
-        len = vft_min_branch_length(negLogLk, minLen, len, VFT_MLOPT_MAXLEN, ftol, atol);
+        double fBest;
+        len = vft_min_branch_length(negLogLk, minLen, len, VFT_MLOPT_MAXLEN, ftol, atol, fBest);
         if (threadIdx.x == 0) blen[lI] = (REAL) len;
     }
     if (evalCount && threadIdx.x == 0) atomicAdd(evalCount, nEval);
@@ -561,4 +563,253 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
         }
     }
     if (threadIdx.x == 0) A.mlIs[rec - A.d.nSeqs] = 1;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// testSplitsML's per-split work (NJ.tcc:6856-6925), one workgroup per internal split, all splits of the tree in one
+// launch (the tree does not change): the quartet likelihood of the current topology AB|CD with its lengths
+// (MLQuartetLogLk, NJ.tcc:5412-5427) and of the two alternatives AC|BD, AD|BC after optimising their five branch
+// lengths (MLQuartetOptimize, NJ.tcc:1650-1788: internal branch, then A, B, C, D, each a Brent search against the
+// posterior of the other three), a second optimisation pass for the better alternative when it comes within
+// closeLogLkLimit of the current topology (or always, -mlacc 2), and the per-site log-likelihoods of the three
+// topologies for the SH-like resampling (k_sh_support).  The same quartet evaluation is the core of an ML NNI
+// (MLQuartetNNI, NJ.tcc:4885-5004).  Profiles are reloaded from the arena (L2) at every step; only the two profiles
+// of the current line search live in registers.
+template <typename REAL, int NC, int CPT>
+__global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_split_test(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
+                                                                const REAL *blen, double minLen, double minRel, double ftol,
+                                                                double atol, double closeLimit, int alwaysSecondPass,
+                                                                double *loglkOut, double *siteOut, double *lenOut,
+                                                                unsigned int *evalCount) {
+    __shared__ REAL ee[4][VFT_MAXRATES * NC];
+    __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
+    __shared__ double red[VFT_MLOPT_WG / 64];
+    const int64_t k = blockIdx.x;
+    const bool jc = A.tmStat == nullptr;
+    const int64_t nPos = A.d.nPos;
+    int rc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+        rc[c] = p < nPos ? A.ratecat[p] : 0;
+    }
+    unsigned int nEval = 0;
+    // P(t) tables of one branch length into slot s (callers synchronise); posteriorProfile clamps its lengths
+    auto table = [&](int s, double len, bool clamp) {
+        if (clamp && len < minLen) len = minLen;
+        if (jc) {
+            for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) vft_psame_pdiff(len, (double) A.rates[r], pS[s][r], pD[s][r]);
+        } else {
+            vft_exp_eigen_rates<REAL, NC>(A, len, minRel, ee[s]);
+        }
+    };
+    auto post = [&](const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, int s1, int s2, int r, Col<REAL, NC> &o) {
+        vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS[s1][r], pD[s1][r], pS[s2][r], pD[s2][r], ee[s1] + r * NC, ee[s2] + r * NC,
+                                    o.w, o.code, o.f);
+        o.vec = o.code == VFT_NOCODE_ && o.w > (REAL) 0;
+    };
+    // pairLogLk(X, Y, len) over the workgroup (table slot 0); site != nullptr: multiply the per-site likelihoods in
+    auto pairTotal = [&](const Col<REAL, NC> *X, const Col<REAL, NC> *Y, double len, double *site) -> double {
+        __syncthreads();
+        table(0, len, false);
+        __syncthreads();
+        double lk = 1.0, loglk = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            if (p < nPos) {
+                const int r = rc[c];
+                double lkAB;
+                if (vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB)) {
+                    vft_lk_accumulate(lkAB, jc, lk, loglk);
+                    if (site) site[c] *= lkAB;
+                }
+            }
+        }
+        double part = loglk + log(lk);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        double tot = 0;
+#pragma unroll
+        for (int w = 0; w < VFT_MLOPT_WG / 64; w++) tot += red[w];
+        nEval++;
+        return tot;
+    };
+    auto loadCols = [&](int64_t node, Col<REAL, NC> *dst) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            if (p < nPos) vft_load_col_ml<REAL, NC>(A, node, p, dst[c]);
+        }
+    };
+    auto storeSite = [&](int topo, const double *site) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            if (p < nPos) siteOut[(k * 3 + topo) * nPos + p] = log(site[c]);   // SHSupport takes the logs, NJ.tcc:1134-1137
+        }
+    };
+    const int64_t nA = ids[4 * k], nB = ids[4 * k + 1], nC = ids[4 * k + 2], nD = ids[4 * k + 3];
+    double base[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) base[t] = (double) blen[lenIdx[5 * k + t]];
+    double loglk[3];
+    Col<REAL, NC> X[CPT], Y[CPT], T[CPT];
+    double site[CPT];
+
+    // ---- AB|CD with the lengths as they are: pairLogLk(A,B) + pairLogLk(C,D) + pairLogLk(AB,CD)
+    {
+#pragma unroll
+        for (int c = 0; c < CPT; c++) site[c] = 1.0;
+        loadCols(nA, X);
+        loadCols(nB, Y);
+        double tot = pairTotal(X, Y, base[0] + base[1], site);
+        __syncthreads();
+        table(1, base[0], true);
+        table(2, base[1], true);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPT; c++) post(X[c], Y[c], 1, 2, rc[c], T[c]);   // AB
+        loadCols(nC, X);
+        loadCols(nD, Y);
+        tot += pairTotal(X, Y, base[2] + base[3], site);
+        __syncthreads();
+        table(1, base[2], true);
+        table(2, base[3], true);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            Col<REAL, NC> cd;
+            post(X[c], Y[c], 1, 2, rc[c], cd);
+            Y[c] = cd;                                                        // CD
+        }
+        tot += pairTotal(T, Y, base[4], site);
+        loglk[0] = tot;
+        storeSite(0, site);
+    }
+
+    // ---- the two alternatives: (a, b | c, d) = (A, C | B, D) and (A, D | C, B)
+    double len[2][5] = {{base[0], base[2], base[1], base[3], base[4]}, {base[0], base[3], base[2], base[1], base[4]}};
+    for (int pass = 0; pass < 3; pass++) {
+        int t = pass;
+        if (pass == 2) {
+            t = loglk[1] > loglk[2] ? 0 : 1;
+            if (!(alwaysSecondPass || loglk[1 + t] > loglk[0] - closeLimit)) break;
+        }
+        const int64_t qa = nA, qb = t == 0 ? nC : nD, qc = t == 0 ? nB : nC, qd = t == 0 ? nD : nB;
+        double *L = len[t];
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (L[j] < minLen) L[j] = minLen;
+        double negll = 0;
+        for (int step = 0; step < 5; step++) {
+            // pair1 -> X, pair2 -> Y for this step; branch optimised: I, A, B, C, D = slots 4, 0, 1, 2, 3
+            __syncthreads();
+            if (step <= 2) {
+                table(1, L[2], true);   // CD = posterior(C, D)
+                table(2, L[3], true);
+            } else {
+                table(1, L[0], true);   // AB = posterior(A, B)
+                table(2, L[1], true);
+            }
+            if (step == 0) {
+                table(3, L[0], true);
+                table(0, L[1], true);
+            } else {
+                // outer posterior: (B, CD: lB, lI) (A, CD: lA, lI) (AB, D: lI, lD) (AB, C: lI, lC)
+                table(3, step == 1 ? L[1] : step == 2 ? L[0] : L[4], true);
+                table(0, step <= 2 ? L[4] : step == 3 ? L[3] : L[2], true);
+            }
+            __syncthreads();
+            loadCols(step <= 2 ? qc : qa, X);
+            loadCols(step <= 2 ? qd : qb, Y);
+#pragma unroll
+            for (int c = 0; c < CPT; c++) post(X[c], Y[c], 1, 2, rc[c], T[c]);   // CD (steps 0-2) or AB (steps 3, 4)
+            if (step == 0) {
+                loadCols(qa, X);
+                loadCols(qb, Y);
+#pragma unroll
+                for (int c = 0; c < CPT; c++) {
+                    Col<REAL, NC> ab;
+                    post(X[c], Y[c], 3, 0, rc[c], ab);
+                    X[c] = ab;      // pair1 = AB
+                    Y[c] = T[c];    // pair2 = CD
+                }
+            } else if (step <= 2) {
+                loadCols(step == 1 ? qb : qa, X);
+#pragma unroll
+                for (int c = 0; c < CPT; c++) post(X[c], T[c], 3, 0, rc[c], Y[c]);   // BCD / ACD
+                loadCols(step == 1 ? qa : qb, X);                                   // pair1 = A / B
+            } else {
+                loadCols(step == 3 ? qd : qc, X);
+#pragma unroll
+                for (int c = 0; c < CPT; c++) post(T[c], X[c], 3, 0, rc[c], Y[c]);   // ABD / ABC
+                loadCols(step == 3 ? qc : qd, X);                                   // pair1 = C / D
+            }
+            auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr); };
+            const int slot = step == 0 ? 4 : step - 1;
+            L[slot] = vft_min_branch_length(negLogLk, minLen, L[slot], VFT_MLOPT_MAXLEN, ftol, atol, negll);
+        }
+        // total: pairLogLk(ABC, D) (= the last search's optimum) + pairLogLk(AB, C, lI + lC) + pairLogLk(A, B, lA + lB);
+        // X = D, Y = ABC, T = AB here
+#pragma unroll
+        for (int c = 0; c < CPT; c++) site[c] = 1.0;
+        pairTotal(Y, X, L[3], site);
+        double tot = -negll;
+        loadCols(qc, X);
+        tot += pairTotal(T, X, L[4] + L[2], site);
+        loadCols(qa, X);
+        loadCols(qb, Y);
+        tot += pairTotal(X, Y, L[0] + L[1], site);
+        loglk[1 + t] = tot;
+        storeSite(1 + t, site);
+    }
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < 3; t++) loglkOut[3 * k + t] = loglk[t];
+        if (lenOut)
+            for (int t = 0; t < 2; t++)
+                for (int j = 0; j < 5; j++) lenOut[(2 * k + t) * 5 + j] = len[t][j];
+        if (evalCount) atomicAdd(evalCount, nEval);
+    }
+}
+
+// SHSupport (NJ.tcc:1126-1165): the share of column resamples in which the gap between the best and the second best
+// of the three topologies' resampled log-likelihoods (each centred by its own total) stays below the observed gap.
+// One workgroup per split; its 3 x nPos site log-likelihoods sit in LDS, a thread per resample walks the resample's
+// columns in order (the reference's sequence of additions).  colT: [nPos][nBoot] (transposed, so that the threads of
+// a wavefront read consecutive entries).
+__global__ __launch_bounds__(256) void k_sh_support(const double *siteLoglk, const double *loglk, const uint16_t *colT,
+                                                    int64_t nPos, int32_t nBoot, double *support) {
+    extern __shared__ double sSite[];   // [3][nPos]
+    __shared__ unsigned int sCount;
+    const int64_t k = blockIdx.x;
+    for (int64_t i = threadIdx.x; i < 3 * nPos; i += blockDim.x) sSite[i] = siteLoglk[k * 3 * nPos + i];
+    if (threadIdx.x == 0) sCount = 0;
+    __syncthreads();
+    const double l0 = loglk[3 * k], l1 = loglk[3 * k + 1], l2 = loglk[3 * k + 2];
+    const double d1 = l0 - l1, d2 = l0 - l2;
+    const double delta = d1 < d2 ? d1 : d2;
+    unsigned int mine = 0;
+    for (int32_t b = threadIdx.x; b < nBoot; b += blockDim.x) {
+        double r0 = -l0, r1 = -l1, r2 = -l2;
+        for (int64_t j = 0; j < nPos; j++) {
+            const int64_t pos = colT[j * nBoot + b];
+            r0 += sSite[pos];
+            r1 += sSite[nPos + pos];
+            r2 += sSite[2 * nPos + pos];
+        }
+        const double r[3] = {r0, r1, r2};
+        int best = 0;
+        if (r[1] > r[best]) best = 1;
+        if (r[2] > r[best]) best = 2;
+        const double s1 = r[best] - r[(best + 1) % 3], s2 = r[best] - r[(best + 2) % 3];
+        const double rd = s1 < s2 ? s1 : s2;
+        if (rd < delta) mine++;
+    }
+    atomicAdd(&sCount, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) support[k] = (double) sCount / (double) nBoot;
 }

@@ -243,6 +243,98 @@ namespace veryfasttree {
             recomputeMLProfiles();
         }
 
+        /* all up-profiles at once, breadth first from the root (getUpProfile with useML, NJ.tcc:3382-3434, on a tree
+           that no longer changes): one vft_posterior_profiles_blen per depth */
+        void allUpProfiles() {
+            std::vector<int64_t> level;
+            for (int k = 0; k < 3; k++)
+                if (child[3 * root + k] >= nSeqs) level.push_back(child[3 * root + k]);
+            while (!level.empty()) {
+                std::vector<int64_t> out, a, b, la, lb, next;
+                for (int64_t x: level) {
+                    int64_t cd[2], lcd[2];
+                    quartetCD(x, cd, lcd);
+                    out.push_back(x + nSeqs);
+                    a.push_back(cd[0]);
+                    b.push_back(cd[1]);
+                    la.push_back(lcd[0]);
+                    lb.push_back(lcd[1]);
+                    for (int k = 0; k < 2; k++)
+                        if (child[3 * x + k] >= nSeqs) next.push_back(child[3 * x + k]);
+                }
+                chk(vft_posterior_profiles_blen(ctx, (int64_t) out.size(), out.data(), a.data(), b.data(), la.data(), lb.data()));
+                level.swap(next);
+            }
+        }
+
+        /* C and D of setupABCD (NJ.tcc:1942-1975) for node x - profile ids and the nodes whose branch lengths go with
+           them: the two other children of the root, or the sibling and the parent's up-profile */
+        void quartetCD(int64_t x, int64_t cd[2], int64_t lcd[2]) const {
+            const int64_t p = parent[(size_t) x];
+            if (p == root) {
+                int n = 0;
+                for (int k = 0; k < 3; k++)
+                    if (child[3 * root + k] != x) {
+                        cd[n] = lcd[n] = child[3 * root + k];
+                        n++;
+                    }
+            } else {
+                cd[0] = lcd[0] = child[3 * p] == x ? child[3 * p + 1] : child[3 * p];
+                cd[1] = p + nSeqs;
+                lcd[1] = p;
+            }
+        }
+
+        struct SplitTests {
+            int64_t nSplits = 0, nBadSplits = 0;
+            double worstDelta = 0;           /* dWorstDeltaUnconstrained */
+            std::vector<double> support;     /* per node, -1 where there is none */
+        };
+
+        /* testSplitsML (NJ.tcc:6800-6999) without constraints: every internal split's three quartet likelihoods in one
+           device call; a split is bad when an alternative beats it by more than treeLogLkDelta = 0.1; nBootstrap > 0:
+           SH-like supports from the resamples col[nBootstrap][nPos], 0 for bad splits */
+        SplitTests testSplits(double ftol, double atol, int32_t nBootstrap, const int32_t *col, bool alwaysSecondPass = false) {
+            allUpProfiles();
+            std::vector<int64_t> nodes, ids, li;
+            for (int64_t v: order) {   /* post-order, as the reference visits them */
+                if (v == root) continue;
+                int64_t cd[2], lcd[2];
+                quartetCD(v, cd, lcd);
+                nodes.push_back(v);
+                const int64_t q[4] = {child[3 * v], child[3 * v + 1], cd[0], cd[1]};
+                const int64_t l[5] = {child[3 * v], child[3 * v + 1], lcd[0], lcd[1], v};
+                ids.insert(ids.end(), q, q + 4);
+                li.insert(li.end(), l, l + 5);
+            }
+            const int64_t n = (int64_t) nodes.size();
+            std::vector<double> loglk((size_t) (3 * n)), sup((size_t) n, 0.0);
+            chk(vft_ml_split_tests(ctx, n, ids.data(), li.data(), ftol, atol, /*closeLogLkLimit*/5.0, alwaysSecondPass ? 1 : 0,
+                                   loglk.data(), nBootstrap, col, nBootstrap > 0 ? sup.data() : nullptr, nullptr));
+            SplitTests out;
+            out.support.assign((size_t) nNodes, -1.0);
+            for (int64_t k = 0; k < n; k++) {
+                const double *l = &loglk[(size_t) (3 * k)];
+                int choice;
+                if (l[0] >= l[1] && l[0] >= l[2]) choice = 0;
+                else if (l[1] >= l[0] && l[1] >= l[2]) choice = 1;
+                else choice = 2;
+                const bool bad = l[choice] > l[0] + 0.1;   /* Constants::treeLogLkDelta */
+                out.nSplits++;
+                if (bad) {
+                    out.nBadSplits++;
+                    out.worstDelta = std::max(out.worstDelta, l[choice] - l[0]);
+                }
+                if (nBootstrap > 0) out.support[(size_t) nodes[(size_t) k]] = bad ? 0.0 : sup[(size_t) k];
+            }
+            splitLoglk.swap(loglk);
+            splitNodes.swap(nodes);
+            return out;
+        }
+
+        std::vector<double> splitLoglk;     /* [3] per entry of splitNodes: AB|CD, AC|BD, AD|BC */
+        std::vector<int64_t> splitNodes;
+
         int64_t evaluations() {
             int64_t n = 0;
             chk(vft_ml_eval_count(ctx, &n));

@@ -345,7 +345,7 @@ namespace veryfasttree {
            here: without a transition matrix the unweighted averages are the profiles the joins already made.
            Call after updateBranchLengths; the context needs max_nodes >= 3 * nSeqs.  Returns the tree log-likelihood
            after each round (the reference's "TreeLogLk Length<k>" log lines). */
-        std::vector<double> mlLengths(int32_t nRateCats = 1) {
+        std::vector<double> mlLengths(int32_t nRateCats = 1, int32_t nBootstrap = 0) {
             if (root < 0) throw std::invalid_argument("NJDriver::mlLengths before finishRoot");
             const bool f32 = sizeof(REAL) == 4;
             const REAL one = 1;
@@ -385,11 +385,30 @@ namespace veryfasttree {
                 if (iRound == 1) ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);   /* VeryFastTreeImpl.tcc:299-305 */
                 if (converged) break;
             }
+            if (nBootstrap > 0 && nSeqs > 3) {
+                /* testSplitsML (VeryFastTreeImpl.tcc:396-398): SH-like supports from the same column resamples the
+                   minimum-evolution supports would use (resampleColumns, NJ.tcc:705-727: Knuth's generator from its
+                   default state) */
+                KnuthRng rng;
+                std::vector<int32_t> col((size_t) nBootstrap * nPos);
+                for (size_t t = 0; t < col.size(); t++) {
+                    int64_t pos = (int64_t) (rng.rand() * nPos);
+                    if (pos < 0) pos = 0;
+                    else if (pos == nPos) pos = nPos - 1;
+                    col[t] = (int32_t) pos;
+                }
+                const typename MLLengths<REAL>::SplitTests st = ml.testSplits(ftol, atol, nBootstrap, col.data());
+                support = st.support;
+                mlBadSplits = st.nBadSplits;
+                mlSplits = st.nSplits;
+                mlWorstDelta = st.worstDelta;
+            }
             mlEvaluations = ml.evaluations();
             return loglk;
         }
 
-        int64_t mlEvaluations = 0;
+        int64_t mlEvaluations = 0, mlBadSplits = 0, mlSplits = 0;   /* "Bad splits: b/n" of the reference's summary line */
+        double mlWorstDelta = 0;
         std::vector<REAL> mlRates;           /* what the reference logs as "Rates" ... */
         std::vector<int64_t> mlRateCat;      /* ... and "SiteCategories" (0-based here) */
 

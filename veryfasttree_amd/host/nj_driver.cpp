@@ -41,10 +41,11 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     drv.run(-1);
     drv.finishRoot();
     if (meLengths) drv.updateBranchLengths();
-    if (nBootstrap > 0) drv.computeSupports(nBootstrap);
-    if (o && o->mllen) {
+    const bool ml = o && o->mllen;
+    if (nBootstrap > 0 && !ml) drv.computeSupports(nBootstrap);
+    if (ml) {
         if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: mllen needs me_lengths (updateBranchLengths runs first)");
-        loglk = drv.mlLengths(o->mllen);
+        loglk = drv.mlLengths(o->mllen, nBootstrap);   /* with supports: SH-like (testSplitsML) instead of local bootstrap */
         rates.assign(drv.mlRates.begin(), drv.mlRates.end());
         ratecat = drv.mlRateCat;
     }
