@@ -214,6 +214,19 @@ int vft_ml_optimize_splits(vft_ctx *ctx, int64_t n, const int64_t *ids, const in
 int vft_ml_split_tests(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, double ftol, double atol,
                        double close_limit, int32_t always_second_pass, double *loglk, int32_t n_boot, const int32_t *col,
                        double *support, double *lengths);
+/* MLQuartetNNI (NJ.tcc:4885-5004), the evaluation of one maximum-likelihood NNI, for n independent quartets (DoNNI
+   evaluates one at a time): ids / len_idx as in vft_ml_split_tests.  Up to two rounds (ml_accuracy < 2; else
+   ml_accuracy rounds) of MLQuartetOptimize for AB|CD - with the star-topology test - AC|BD and AD|BC, dropping
+   alternatives that fall close_limit behind.  choice: 0 = keep AB|CD, 1 = AC|BD (swap B and C), 2 = AD|BC; criteria =
+   the three log-likelihoods (-1e20 for the alternatives after a successful star test).  The winner's branch lengths
+   are written to the device's branchlength[] as DoNNI assigns them (NJ.tcc:5889-5915). */
+typedef struct vft_quartet_nni {
+    double criteria[3];
+    int32_t choice;
+    int32_t star;
+} vft_quartet_nni;
+int vft_ml_quartet_nni(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, double ftol, double atol,
+                       double close_limit, int32_t ml_accuracy, vft_quartet_nni *results);
 /* likelihood evaluations (pairLogLk calls of the reference) made by vft_ml_optimize_splits since the last query */
 int vft_ml_eval_count(vft_ctx *ctx, int64_t *evals);
 

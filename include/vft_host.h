@@ -30,6 +30,10 @@ typedef struct {
                                    Jukes-Cantor, constant rates); n >= 2 = `-mllen -cat n` (CAT approximation with n rate
                                    categories fitted after the first round, setMLRates NJ.tcc:5429-5488; the
                                    reference's default is 20) */
+    int32_t me_nni;             /* 1 = minimum-evolution NNI rounds after fastNJ (DoNNI with useML = false, NJ.tcc:5797-6200;
+                                   round(4 log2 N) rounds or until a round changes nothing, VeryFastTreeImpl.tcc:160-185):
+                                   the reference's default without SPR moves (`-spr 0`); 0 = `-nome` */
+    int32_t ml_nni;             /* reserved for maximum-likelihood NNI rounds (0) */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

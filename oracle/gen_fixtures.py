@@ -179,9 +179,40 @@ def gen_mllen(tmp):
         print("%-20s %2d rounds  final logLk %.4f  %7.1f KiB" % (name, len(ll), ll[-1], os.path.getsize(dst) / 1024.0))
 
 
+MENNI_CASES = [
+    # name, flags, n_seq, n_pos, n_codes, mu, gap, seed: `-noml -spr 0` = NJ + minimum-evolution NNIs + ME lengths
+    ("nni_nt_200", ["-nt"], 200, 120, 4, 0.05, 0.02, 21),          # same alignment as bb_nt_200
+    ("nni_nt_500", ["-nt"], 500, 100, 4, 0.10, 0.05, 41),
+    ("nni_nt_300_double", ["-nt", "-double-precision"], 300, 90, 4, 0.08, 0.03, 42),
+    ("nni_nt_12", ["-nt"], 12, 60, 4, 0.2, 0.05, 43),
+]
+
+
+def gen_menni(tmp):
+    """Black box: the ME_NNI<k> trees of every round (topology pins), the final tree without and with supports."""
+    for name, flags, n, L, nc, mu, gap, seed in MENNI_CASES:
+        codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if nc == 20 else synth.ALPHABET_NT)
+        log = os.path.join(tmp, name + ".log")
+        base = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-noml", "-spr", "0"]
+        res = subprocess.run(base + ["-nosupport", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        text = open(log).read()
+        rounds = re.findall(r"^ME_NNI\d+\t(\(.*;)\s*$", text, re.M)
+        nni = int(re.search(r"^NNI: (\d+) SPR", res.stderr.decode(errors="replace") + text, re.M).group(1))
+        res2 = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, codes=codes, n_nni=np.int64(nni), n_rounds=np.int64(len(rounds)),
+                            last_round=np.frombuffer(rounds[-1].encode(), dtype=np.uint8),
+                            newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
+                            flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        print("%-20s %2d rounds %4d NNIs  %7.1f KiB" % (name, len(rounds), nni, os.path.getsize(dst) / 1024.0))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "mllen"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "mllen", "menni"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -191,6 +222,8 @@ def main():
             gen_knuth(tmp)
         if "mllen" in which:
             gen_mllen(tmp)
+        if "menni" in which:
+            gen_menni(tmp)
 
 
 if __name__ == "__main__":

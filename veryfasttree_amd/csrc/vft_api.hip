@@ -1752,22 +1752,66 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
 }
 
 template <typename REAL, int NC>
-static int ml_split_test_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
-                                double closeLimit, int always2, double *dLoglk, double *dSite, double *dLen) {
-#define VFT_MLSPLIT_CASE(CPT)                                                                                           \
+static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
+                             double closeLimit, int mlAccuracy, int mode, double *dLoglk, double *dSite, double *dLen,
+                             QuartetNNIResult *dNni) {
+#define VFT_MLQ_CASE(CPT)                                                                                               \
     case CPT:                                                                                                           \
-        launch((k_ml_split_test<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c),   \
-               dIds, dLi, (const REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, always2, dLoglk, dSite,  \
-               dLen, c->mlEvals);                                                                                        \
+        launch((k_ml_quartet<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c), dIds, \
+               dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, dLoglk, dSite, dLen, \
+               dNni, c->mlEvals);                                                                                        \
         break;
     switch (cpt) {
-        VFT_MLSPLIT_CASE(1)
-        VFT_MLSPLIT_CASE(2)
-        VFT_MLSPLIT_CASE(4)
+        VFT_MLQ_CASE(1)
+        VFT_MLQ_CASE(2)
+        VFT_MLQ_CASE(4)
         default:
-            return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the in-kernel quartet optimiser");
+            return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");
     }
-#undef VFT_MLSPLIT_CASE
+#undef VFT_MLQ_CASE
+    return VFT_OK;
+}
+
+static int quartet_args_ok(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, const char *who) {
+    for (int64_t k = 0; k < n; k++) {
+        for (int t = 0; t < 4; t++)
+            if (ids[4 * k + t] < 0 || ids[4 * k + t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "%s: quartet %lld out of range", who, (long long) k);
+        for (int t = 0; t < 5; t++)
+            if (lenIdx[5 * k + t] < 0 || lenIdx[5 * k + t] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "%s: quartet %lld out of range", who, (long long) k);
+    }
+    return VFT_OK;
+}
+
+// MLQuartetNNI (NJ.tcc:4885-5004) for n independent quartets (DoNNI evaluates one at a time: n = 1): results come back
+// through mapped host memory; the chosen pairing's branch lengths are written to the device's branchlength[].
+extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, double ftol, double atol,
+                                  double closeLimit, int32_t mlAccuracy, vft_quartet_nni *results) {
+    if (!c || n < 1 || !ids || !lenIdx || !results) return VFT_ERR_INVALID;
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
+    if (int r = quartet_args_ok(c, n, ids, lenIdx, "vft_ml_quartet_nni")) return r;
+    if (int r = ensure_blen(c)) return r;
+    if (!c->mlEvals) {
+        HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
+        HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
+    }
+    const int64_t per = cdiv(c->d.nPos, VFT_MLOPT_WG);
+    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
+    const size_t idB = (size_t) n * 8, resB = (size_t) n * sizeof(QuartetNNIResult);
+    static_assert(sizeof(QuartetNNIResult) == sizeof(vft_quartet_nni), "result record layout");
+    if (9 * idB + resB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_quartet_nni: too many quartets per call");
+    char *h, *s;
+    if (int r = io_alloc(c, ((9 * idB + 255) & ~(size_t) 255) + resB, &h, &s)) return r;
+    memcpy(h, ids, 4 * idB);
+    memcpy(h + 4 * idB, lenIdx, 5 * idB);
+    const size_t off = (9 * idB + 255) & ~(size_t) 255;
+    int r = VFT_OK;
+    VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, (const int64_t *) s, (const int64_t *) (s + 4 * idB), ftol, atol,
+                                                     closeLimit, mlAccuracy, 1, nullptr, nullptr, nullptr,
+                                                     (QuartetNNIResult *) (s + off))));
+    if (r) return r;
+    LAUNCHCHK(c);
+    if (int w = wait_stream(c)) return w;
+    memcpy(results, h + off, resB);
     return VFT_OK;
 }
 
@@ -1782,12 +1826,7 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
     if (!c || n < 0 || !ids || !lenIdx || !loglk || (nBoot > 0 && (!col || !support))) return VFT_ERR_INVALID;
     if (n == 0) return VFT_OK;
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
-    for (int64_t k = 0; k < n; k++) {
-        for (int t = 0; t < 4; t++)
-            if (ids[4 * k + t] < 0 || ids[4 * k + t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: split %lld out of range", (long long) k);
-        for (int t = 0; t < 5; t++)
-            if (lenIdx[5 * k + t] < 0 || lenIdx[5 * k + t] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: split %lld out of range", (long long) k);
-    }
+    if (int r = quartet_args_ok(c, n, ids, lenIdx, "vft_ml_split_tests")) return r;
     if (int r = ensure_blen(c)) return r;
     if (!c->mlEvals) {
         HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
@@ -1828,8 +1867,8 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMemcpyAsync(dIds, ids + 4 * k0, 4 * cB, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dLi, lenIdx + 5 * k0, 5 * cB, hipMemcpyHostToDevice, c->stream));
         int r = VFT_OK;
-        VFT_DISPATCH(c, (r = ml_split_test_launch<REAL, NC>(c, cnt, cpt, dIds, dLi, ftol, atol, closeLimit, alwaysSecondPass, dLoglk,
-                                                            dSite, dLen)));
+        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, cnt, cpt, dIds, dLi, ftol, atol, closeLimit, alwaysSecondPass ? 2 : 1, 0,
+                                                         dLoglk, dSite, dLen, nullptr)));
         if (r) return r;
         LAUNCHCHK(c);
         if (nBoot > 0) {

@@ -567,21 +567,30 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// testSplitsML's per-split work (NJ.tcc:6856-6925), one workgroup per internal split, all splits of the tree in one
-// launch (the tree does not change): the quartet likelihood of the current topology AB|CD with its lengths
-// (MLQuartetLogLk, NJ.tcc:5412-5427) and of the two alternatives AC|BD, AD|BC after optimising their five branch
-// lengths (MLQuartetOptimize, NJ.tcc:1650-1788: internal branch, then A, B, C, D, each a Brent search against the
-// posterior of the other three), a second optimisation pass for the better alternative when it comes within
-// closeLogLkLimit of the current topology (or always, -mlacc 2), and the per-site log-likelihoods of the three
-// topologies for the SH-like resampling (k_sh_support).  The same quartet evaluation is the core of an ML NNI
-// (MLQuartetNNI, NJ.tcc:4885-5004).  Profiles are reloaded from the arena (L2) at every step; only the two profiles
-// of the current line search live in registers.
+// Quartet likelihood kernel, one workgroup per internal split (nodes A, B below it, C beside it, D = the rest of the
+// tree through the up-profile; setupABCD NJ.tcc:1942-1975).  Building block: MLQuartetOptimize (NJ.tcc:1650-1788) of one
+// of the three pairings - internal branch, then A, B, C, D, each a Brent search (vft_min_branch_length) against the
+// posterior of the other three profiles - with the same in-register line search as k_ml_node_lengths; profiles are
+// reloaded from the arena (L2) at every step, only the two profiles of the current search live in registers.
+//   mode 0 - testSplitsML's per-split work (NJ.tcc:6856-6925): MLQuartetLogLk (NJ.tcc:5412-5427) of AB|CD with its
+//     current lengths, the two alternatives optimised, a second pass for the better one when it comes within
+//     closeLogLkLimit of AB|CD (or always, -mlacc 2), and the per-site log-likelihoods of the three topologies for the
+//     SH-like resampling (k_sh_support).  All splits of the (now fixed) tree in one launch.
+//   mode 1 - MLQuartetNNI (NJ.tcc:4885-5004), the evaluation of one ML NNI: up to two rounds of {AB|CD with the star
+//     topology test, AC|BD, AD|BC}, dropping alternatives that fall clearly behind; the winner's five branch lengths
+//     are written to branchlength[] on the device the way DoNNI does it (NJ.tcc:5889-5915: every node keeps its own
+//     optimised length; after a star test only the internal branch), choice and criteria go to the host.
+struct QuartetNNIResult {
+    double criteria[3];
+    int32_t choice, star;
+};
+
 template <typename REAL, int NC, int CPT>
-__global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_split_test(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
-                                                                const REAL *blen, double minLen, double minRel, double ftol,
-                                                                double atol, double closeLimit, int alwaysSecondPass,
-                                                                double *loglkOut, double *siteOut, double *lenOut,
-                                                                unsigned int *evalCount) {
+__global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
+                                                             double minLen, double minRel, double ftol, double atol,
+                                                             double closeLimit, int mlAccuracy, int mode, double *loglkOut,
+                                                             double *siteOut, double *lenOut, QuartetNNIResult *nniOut,
+                                                             unsigned int *evalCount) {
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
@@ -656,12 +665,12 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_split_test(Arena<REAL> A, c
     double base[5];
 #pragma unroll
     for (int t = 0; t < 5; t++) base[t] = (double) blen[lenIdx[5 * k + t]];
-    double loglk[3];
+    double crit[3] = {0, 0, 0};
     Col<REAL, NC> X[CPT], Y[CPT], T[CPT];
     double site[CPT];
 
-    // ---- AB|CD with the lengths as they are: pairLogLk(A,B) + pairLogLk(C,D) + pairLogLk(AB,CD)
-    {
+    if (mode == 0) {
+        // ---- AB|CD with the lengths as they are: pairLogLk(A,B) + pairLogLk(C,D) + pairLogLk(AB,CD)
 #pragma unroll
         for (int c = 0; c < CPT; c++) site[c] = 1.0;
         loadCols(nA, X);
@@ -687,24 +696,48 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_split_test(Arena<REAL> A, c
             Y[c] = cd;                                                        // CD
         }
         tot += pairTotal(T, Y, base[4], site);
-        loglk[0] = tot;
+        crit[0] = tot;
         storeSite(0, site);
     }
 
-    // ---- the two alternatives: (a, b | c, d) = (A, C | B, D) and (A, D | C, B)
-    double len[2][5] = {{base[0], base[2], base[1], base[3], base[4]}, {base[0], base[3], base[2], base[1], base[4]}};
-    for (int pass = 0; pass < 3; pass++) {
-        int t = pass;
-        if (pass == 2) {
-            t = loglk[1] > loglk[2] ? 0 : 1;
-            if (!(alwaysSecondPass || loglk[1 + t] > loglk[0] - closeLimit)) break;
+    // ---- MLQuartetOptimize jobs; pairing t: (a, b | c, d) = (A, B | C, D), (A, C | B, D), (A, D | C, B)
+    double len[3][5] = {{base[0], base[1], base[2], base[3], base[4]},
+                        {base[0], base[2], base[1], base[3], base[4]},
+                        {base[0], base[3], base[2], base[1], base[4]}};
+    const int nRounds = mlAccuracy < 2 ? 2 : mlAccuracy;
+    int phase = 0, round = 0;
+    bool consider1 = true, consider2 = true, star = false;
+    for (int guard = 0; guard < 64; guard++) {
+        int t;
+        if (mode == 0) {
+            if (guard == 0) t = 1;
+            else if (guard == 1) t = 2;
+            else if (guard == 2) {
+                t = crit[1] > crit[2] ? 1 : 2;
+                if (!(mlAccuracy > 1 || crit[t] > crit[0] - closeLimit)) break;
+            } else break;
+        } else {
+            if (phase == 3) {   // end of a round (NJ.tcc:4961-4983)
+                if (mlAccuracy < 2) {
+                    if (crit[1] < crit[0] - closeLimit || (len[1][4] <= 2.0 * minLen && crit[1] < crit[0])) consider1 = false;
+                    if (crit[2] < crit[0] - closeLimit || (len[2][4] <= 2.0 * minLen && crit[2] < crit[0])) consider2 = false;
+                    if (!consider1 && !consider2) break;
+                    if (crit[1] > crit[0] + closeLimit && crit[1] > crit[2] + closeLimit) break;
+                    if (crit[2] > crit[0] + closeLimit && crit[2] > crit[1] + closeLimit) break;
+                }
+                if (++round == nRounds) break;
+                phase = 0;
+            }
+            t = phase++;
+            if ((t == 1 && !consider1) || (t == 2 && !consider2)) continue;
         }
-        const int64_t qa = nA, qb = t == 0 ? nC : nD, qc = t == 0 ? nB : nC, qd = t == 0 ? nD : nB;
+        const int64_t qa = nA, qb = t == 0 ? nB : t == 1 ? nC : nD, qc = t == 1 ? nB : nC, qd = t == 2 ? nB : nD;
         double *L = len[t];
 #pragma unroll
         for (int j = 0; j < 5; j++)
             if (L[j] < minLen) L[j] = minLen;
         double negll = 0;
+        bool starHere = false;
         for (int step = 0; step < 5; step++) {
             // pair1 -> X, pair2 -> Y for this step; branch optimised: I, A, B, C, D = slots 4, 0, 1, 2, 3
             __syncthreads();
@@ -752,28 +785,78 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_split_test(Arena<REAL> A, c
             auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr); };
             const int slot = step == 0 ? 4 : step - 1;
             L[slot] = vft_min_branch_length(negLogLk, minLen, L[slot], VFT_MLOPT_MAXLEN, ftol, atol, negll);
+            if (step == 0 && mode == 1 && t == 0) {
+                // star topology test (NJ.tcc:1691-1700): is the internal branch worth more than closeLogLkLimit?
+                const double loglkStar = -negLogLk(minLen);
+                if (loglkStar < -negll - closeLimit) {
+                    starHere = true;
+                    break;
+                }
+            }
+        }
+        if (starHere) {
+            // -negloglk + pairLogLk(A, B, lA + lB) + pairLogLk(C, D, lC + lD)
+            loadCols(qa, X);
+            loadCols(qb, Y);
+            double tot = -negll + pairTotal(X, Y, L[0] + L[1], nullptr);
+            loadCols(qc, X);
+            loadCols(qd, Y);
+            tot += pairTotal(X, Y, L[2] + L[3], nullptr);
+            crit[0] = tot;
+            crit[1] = crit[2] = -1e20;
+            star = true;
+            break;
         }
         // total: pairLogLk(ABC, D) (= the last search's optimum) + pairLogLk(AB, C, lI + lC) + pairLogLk(A, B, lA + lB);
         // X = D, Y = ABC, T = AB here
+        double *sitep = mode == 0 ? site : nullptr;
+        if (sitep) {
 #pragma unroll
-        for (int c = 0; c < CPT; c++) site[c] = 1.0;
-        pairTotal(Y, X, L[3], site);
+            for (int c = 0; c < CPT; c++) site[c] = 1.0;
+            pairTotal(Y, X, L[3], sitep);
+        }
         double tot = -negll;
         loadCols(qc, X);
-        tot += pairTotal(T, X, L[4] + L[2], site);
+        tot += pairTotal(T, X, L[4] + L[2], sitep);
         loadCols(qa, X);
         loadCols(qb, Y);
-        tot += pairTotal(X, Y, L[0] + L[1], site);
-        loglk[1 + t] = tot;
-        storeSite(1 + t, site);
+        tot += pairTotal(X, Y, L[0] + L[1], sitep);
+        crit[t] = tot;
+        if (sitep) storeSite(t, site);
     }
-    if (threadIdx.x == 0) {
-        for (int t = 0; t < 3; t++) loglkOut[3 * k + t] = loglk[t];
+    if (threadIdx.x != 0) return;
+    if (evalCount) atomicAdd(evalCount, nEval);
+    if (mode == 0) {
+        for (int t = 0; t < 3; t++) loglkOut[3 * k + t] = crit[t];
         if (lenOut)
             for (int t = 0; t < 2; t++)
-                for (int j = 0; j < 5; j++) lenOut[(2 * k + t) * 5 + j] = len[t][j];
-        if (evalCount) atomicAdd(evalCount, nEval);
+                for (int j = 0; j < 5; j++) lenOut[(2 * k + t) * 5 + j] = len[1 + t][j];
+        return;
     }
+    // MLQuartetNNI's verdict (NJ.tcc:4989-5003) and DoNNI's branch-length update (NJ.tcc:5889-5915)
+    int choice = 0;
+    if (!star) {
+        if (crit[1] > crit[0] && crit[1] > crit[2]) choice = 1;
+        else if (crit[2] > crit[0] && crit[2] > crit[1]) choice = 2;
+    }
+    const int64_t *li = lenIdx + 5 * k;
+    if (star) {
+        blen[li[4]] = (REAL) len[0][4];
+    } else {
+        const double *L = len[choice];
+        blen[li[0]] = (REAL) L[0];                                   // A
+        blen[li[1]] = (REAL) (choice == 0 ? L[1] : choice == 1 ? L[2] : L[3]);   // B
+        blen[li[2]] = (REAL) (choice == 0 ? L[2] : choice == 1 ? L[1] : L[2]);   // C
+        blen[li[3]] = (REAL) (choice == 0 ? L[3] : choice == 1 ? L[3] : L[1]);   // D
+        blen[li[4]] = (REAL) L[4];
+    }
+    QuartetNNIResult r;
+    r.criteria[0] = crit[0];
+    r.criteria[1] = crit[1];
+    r.criteria[2] = crit[2];
+    r.choice = choice;
+    r.star = star ? 1 : 0;
+    nniOut[k] = r;
 }
 
 // SHSupport (NJ.tcc:1126-1165): the share of column resamples in which the gap between the best and the second best

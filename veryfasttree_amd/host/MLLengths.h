@@ -335,6 +335,148 @@ namespace veryfasttree {
         std::vector<double> splitLoglk;     /* [3] per entry of splitNodes: AB|CD, AC|BD, AD|BC */
         std::vector<int64_t> splitNodes;
 
+        /* ---------------------------------------------------------------------------------------------- NNIs
+           DoNNI (NJ.tcc:5797-6200, one thread, fastNNI, no constraints): a post-order walk over the internal nodes that
+           compares AB|CD with AC|BD and AD|BC around each - by log-corrected profile distances (chooseNNI,
+           NJ.tcc:4836-4883; useML = false) or by optimised quartet likelihoods (MLQuartetNNI, one
+           vft_ml_quartet_nni call; useML = true) - rearranges the tree on the spot and keeps the profiles around the node
+           current.  The tree changes under the walk, so the device work of a node is queued when the walk gets there
+           and the host waits for each verdict. */
+        struct NNIStats {
+            int64_t age, subtreeAge;
+            double delta, support;
+        };
+
+        void initNNIStats(std::vector<NNIStats> &stats) const {   /* NJ.tcc:7002-7016 */
+            stats.assign((size_t) nNodes, NNIStats{0, 0, 0.0, 0.0});
+            for (int64_t i = 0; i < nNodes; i++)
+                if (i == root || i < nSeqs) stats[(size_t) i].age = stats[(size_t) i].subtreeAge = 1000000;
+        }
+
+        struct NNIParams {
+            bool useML = false;
+            bool scoredist = false;      /* logCorrect flavour of the ME criterion (NJ.tcc:322-330) */
+            double ftol = 0.001, atol = 1e-4, minDelta = 1.0e-4 /* MEMinDelta */;
+            int32_t mlAccuracy = 1;
+        };
+
+        int64_t doNNI(const NNIParams &prm, std::vector<NNIStats> &stats, double &dMaxDelta) {
+            const double supportThreshold = prm.useML ? 0.1 /* treeLogLkDelta */ : prm.minDelta;
+            int64_t nNNIThisRound = 0;
+            dMaxDelta = 0.0;
+            if (nSeqs <= 3) return 0;
+            std::vector<char> traversal((size_t) nNodes, 0), upHave((size_t) nNodes, 0);
+            /* nodes whose subtree has been quiet for two rounds are not entered (NJ.tcc:6047-6075) */
+            for (int64_t node = nSeqs; node < nNodes; node++) {
+                const NNIStats &st = stats[(size_t) node];
+                if (node != root && st.age >= 2 && st.subtreeAge >= 2 && st.support > supportThreshold) {
+                    int64_t q[4];
+                    quartetNodes(node, q);
+                    int i;
+                    for (i = 0; i < 4; i++)
+                        if (stats[(size_t) q[i]].age == 0 && stats[(size_t) q[i]].support > supportThreshold) break;
+                    if (i == 4) traversal[(size_t) node] = 1;
+                }
+            }
+            int64_t node = root;
+            bool bUp = false;
+            while ((node = nextPostorder(node, traversal, &bUp, root)) >= 0) {
+                if (node < nSeqs || node == root) continue;
+                if (bUp) {   /* back at a node whose surroundings were rearranged: refresh it (NJ.tcc:5809-5820) */
+                    for (int k = 0; k < 2; k++) upHave[(size_t) child[3 * node + k]] = 0;
+                    upHave[(size_t) node] = 0;
+                    recomputeProfile(node, prm.useML);
+                    continue;
+                }
+                int64_t q[4];
+                quartetNodes(node, q);
+                const int64_t nodeA = q[0], nodeB = q[1], nodeC = q[2], nodeD = q[3], par = parent[(size_t) node];
+                int64_t idD = nodeD;   /* profile of D: the root's other child, or the parent's up-profile */
+                if (par != root) {
+                    ensureUpProfile(par, prm.useML, upHave);
+                    idD = par + nSeqs;
+                }
+                int choice = 0;
+                double criteria[3];
+                if (prm.useML) {
+                    const int64_t ids[4] = {nodeA, nodeB, nodeC, idD}, li[5] = {nodeA, nodeB, nodeC, nodeD, node};
+                    vft_quartet_nni r;
+                    chk(vft_ml_quartet_nni(ctx, 1, ids, li, prm.ftol, prm.atol, /*closeLogLkLimit*/5.0, prm.mlAccuracy, &r));
+                    choice = r.choice;
+                    for (int i = 0; i < 3; i++) criteria[i] = r.criteria[i];
+                    if (r.star) nStarTests++;
+                } else {
+                    /* correctedPairDistances (NJ.tcc:1460-1488) over A, B, C, D: AB AC AD BC BD CD */
+                    const int64_t pi[6] = {nodeA, nodeA, nodeA, nodeB, nodeB, nodeC}, pj[6] = {nodeB, nodeC, idD, nodeC, idD, idD};
+                    REAL d[6], w[6];
+                    chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
+                    double c[6];
+                    for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[i], prm.scoredist);
+                    criteria[0] = c[0] + c[5];
+                    criteria[1] = c[1] + c[4];
+                    criteria[2] = c[2] + c[3];
+                    if (criteria[1] < criteria[0] && criteria[1] <= criteria[2]) choice = 1;
+                    else if (criteria[2] < criteria[0] && criteria[2] <= criteria[1]) choice = 2;
+                    for (int i = 0; i < 3; i++) criteria[i] = -criteria[i];   /* higher is better, as for ML */
+                }
+                if (choice == 1) {          /* swap B and C */
+                    replaceChild(node, nodeB, nodeC);
+                    replaceChild(par, nodeC, nodeB);
+                } else if (choice == 2) {   /* swap A and C */
+                    replaceChild(node, nodeA, nodeC);
+                    replaceChild(par, nodeC, nodeA);
+                }
+                NNIStats &st = stats[(size_t) node];
+                if (choice == 0) {
+                    st.age++;
+                } else {
+                    nNNIThisRound++;
+                    st.age = 0;
+                    stats[(size_t) nodeA].age = stats[(size_t) nodeB].age = stats[(size_t) nodeC].age = stats[(size_t) nodeD].age = 0;
+                }
+                st.delta = criteria[choice] - criteria[0];
+                if (st.delta > dMaxDelta) dMaxDelta = st.delta;
+                st.support = 1e20;
+                for (int i = 0; i < 3; i++)
+                    if (choice != i && criteria[choice] - criteria[i] < st.support) st.support = criteria[choice] - criteria[i];
+                if (st.delta > supportThreshold) {
+                    st.subtreeAge = 0;
+                } else {
+                    st.subtreeAge++;
+                    for (int i = 0; i < 2; i++) {
+                        const int64_t ch = child[3 * node + i];
+                        if (st.subtreeAge > stats[(size_t) ch].subtreeAge) st.subtreeAge = stats[(size_t) ch].subtreeAge;
+                    }
+                }
+                if (choice == 0) {
+                    upHave[(size_t) nodeA] = upHave[(size_t) nodeB] = upHave[(size_t) nodeC] = 0;
+                    recomputeProfile(node, prm.useML);
+                } else {
+                    /* updateForNNI, fast flavour (NJ.tcc:1902-1926) */
+                    upHave[(size_t) node] = 0;
+                    for (int k = 0; k < 2; k++) upHave[(size_t) child[3 * node + k]] = 0;
+                    const int64_t ip = parent[(size_t) node];
+                    if (ip == root) {
+                        for (int k = 0; k < 3; k++)
+                            if (child[3 * root + k] != node) upHave[(size_t) child[3 * root + k]] = 0;
+                    } else {
+                        upHave[(size_t) ip] = 0;
+                        upHave[(size_t) siblingOf(node)] = 0;
+                    }
+                    if (ip != root && parent[(size_t) ip] != root) upHave[(size_t) siblingOf(ip)] = 0;   /* the uncle */
+                    recomputeProfile(node, prm.useML);
+                    recomputeProfile(ip, prm.useML);
+                }
+            }
+            rebuildOrder();
+            return nNNIThisRound;
+        }
+
+        int64_t nStarTests = 0;
+
+        const std::vector<int64_t> &children() const { return child; }
+        const std::vector<int64_t> &parents() const { return parent; }
+
         int64_t evaluations() {
             int64_t n = 0;
             chk(vft_ml_eval_count(ctx, &n));
@@ -344,6 +486,112 @@ namespace veryfasttree {
         int64_t splits() const { return (int64_t) order.size(); }
 
     private:
+        static double logCorrect(double dist, bool scoredist) {   /* NJ.tcc:322-330 */
+            const double maxscore = 3.0;
+            if (!scoredist) dist = dist < 0.74 ? -0.75 * std::log(1.0 - dist * 4.0 / 3.0) : maxscore;
+            else dist = dist < 0.99 ? -1.3 * std::log(1.0 - dist) : maxscore;
+            return dist < maxscore ? dist : maxscore;
+        }
+
+        int64_t siblingOf(int64_t v) const {   /* NJ.tcc:1977-1990: not defined below the root */
+            const int64_t p = parent[(size_t) v];
+            return child[3 * p] == v ? child[3 * p + 1] : child[3 * p];
+        }
+
+        /* nodeABCD of setupABCD (NJ.tcc:1942-1975): children, then the sibling and the parent - or the root's two
+           other children */
+        void quartetNodes(int64_t node, int64_t q[4]) const {
+            q[0] = child[3 * node];
+            q[1] = child[3 * node + 1];
+            const int64_t p = parent[(size_t) node];
+            if (p == root) {
+                int n = 2;
+                for (int k = 0; k < 3; k++)
+                    if (child[3 * root + k] != node) q[n++] = child[3 * root + k];
+            } else {
+                q[2] = siblingOf(node);
+                q[3] = p;
+            }
+        }
+
+        void replaceChild(int64_t par, int64_t oldChild, int64_t newChild) {   /* NJ.tcc:1929-1940 */
+            parent[(size_t) newChild] = par;
+            for (int k = 0; k < 3; k++)
+                if (child[3 * par + k] == oldChild) {
+                    child[3 * par + k] = newChild;
+                    return;
+                }
+            throw std::logic_error("MLLengths::replaceChild: not a child");
+        }
+
+        /* traversePostorder (NJ.tcc:3343-3380) on the tree as it is now */
+        int64_t nextPostorder(int64_t node, std::vector<char> &traversal, bool *up, int64_t branchRoot) const {
+            *up = false;
+            for (;;) {
+                bool found = false;
+                for (int k = 0; k < 3 && child[3 * node + k] >= 0; k++) {
+                    const int64_t c = child[3 * node + k];
+                    if (!traversal[(size_t) c]) {
+                        node = c;
+                        found = true;
+                        break;
+                    }
+                }
+                if (found) continue;
+                if (!traversal[(size_t) node]) {
+                    traversal[(size_t) node] = 1;
+                    return node;
+                }
+                if (node == branchRoot) return -1;
+                node = parent[(size_t) node];
+                if (traversal[(size_t) node]) {
+                    *up = true;
+                    return node;
+                }
+            }
+        }
+
+        /* getUpProfile (NJ.tcc:3382-3434): cached; missing ones are built from the root down */
+        void ensureUpProfile(int64_t node, bool useML, std::vector<char> &upHave) {
+            if (upHave[(size_t) node]) return;
+            std::vector<int64_t> path;
+            for (int64_t x = node; x != root; x = parent[(size_t) x]) path.push_back(x);
+            for (size_t t = path.size(); t-- > 0;) {
+                const int64_t x = path[t];
+                if (upHave[(size_t) x]) continue;
+                int64_t cd[2], lcd[2];
+                quartetCD(x, cd, lcd);
+                const int64_t out = x + nSeqs;
+                if (useML) chk(vft_posterior_profiles_blen(ctx, 1, &out, &cd[0], &cd[1], &lcd[0], &lcd[1]));
+                else chk(vft_average_profiles(ctx, 1, &out, &cd[0], &cd[1], nullptr));
+                upHave[(size_t) x] = 1;
+            }
+        }
+
+        /* recomputeProfile (NJ.tcc:3436-3473) without BIONJ weighting */
+        void recomputeProfile(int64_t node, bool useML) {
+            if (node < nSeqs || node == root) return;
+            const int64_t a = child[3 * node], b = child[3 * node + 1];
+            if (useML) chk(vft_posterior_profiles_blen(ctx, 1, &node, &a, &b, &a, &b));
+            else chk(vft_average_profiles(ctx, 1, &node, &a, &b, nullptr));
+        }
+
+        void rebuildOrder() {
+            order.clear();
+            std::vector<std::pair<int64_t, int>> stack(1, std::make_pair(root, 0));
+            while (!stack.empty()) {
+                const int64_t v = stack.back().first;
+                const int k = stack.back().second;
+                if (k < 3 && child[3 * v + k] >= 0) {
+                    stack.back().second++;
+                    stack.push_back(std::make_pair(child[3 * v + k], 0));
+                } else {
+                    stack.pop_back();
+                    if (child[3 * v] >= 0) order.push_back(v);
+                }
+            }
+        }
+
         void chk(int rc) {
             if (rc != VFT_OK) throw std::runtime_error(std::string("MLLengths: ") + vft_last_error(ctx));
         }

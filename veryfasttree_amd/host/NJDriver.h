@@ -48,6 +48,7 @@ namespace veryfasttree {
            NJ.tcc:4476); results do not depend on it */
         int hostThreads = 16;
         /* logCorrect of the minimum-evolution lengths: scoredist-like instead of Jukes-Cantor (amino acids / matrix) */
+        bool meNNI = false;
         bool scoredist = false;
     };
 
@@ -338,6 +339,66 @@ namespace veryfasttree {
             }
         }
 
+        /* parent[] / child[][3] of the finished tree in the layout MLLengths.h works on */
+        void treeArrays(std::vector<int64_t> &par, std::vector<int64_t> &ch) const {
+            par.assign((size_t) maxnode, -1);
+            ch.assign((size_t) (3 * maxnode), -1);
+            for (int64_t v = 0; v < maxnode; v++) {
+                par[(size_t) v] = parent[(size_t) v];
+                if (v == root) {
+                    for (int k = 0; k < 3; k++) ch[(size_t) (3 * v + k)] = rootChild[k];
+                } else if (v >= nSeqs) {
+                    ch[(size_t) (3 * v)] = child0[(size_t) v];
+                    ch[(size_t) (3 * v + 1)] = child1[(size_t) v];
+                }
+            }
+            par[(size_t) root] = -1;
+        }
+
+        /* the topology back from MLLengths.h after rearrangements (child order as the NNIs left it: printNJ walks it) */
+        void adoptTree(const std::vector<int64_t> &par, const std::vector<int64_t> &ch) {
+            for (int64_t v = 0; v < maxnode; v++) {
+                parent[(size_t) v] = v == root ? -1 : par[(size_t) v];
+                if (v == root) {
+                    for (int k = 0; k < 3; k++) rootChild[k] = ch[(size_t) (3 * v + k)];
+                } else if (v >= nSeqs) {
+                    child0[(size_t) v] = ch[(size_t) (3 * v)];
+                    child1[(size_t) v] = ch[(size_t) (3 * v + 1)];
+                }
+            }
+            upReady = false;
+        }
+
+        /* Minimum-evolution NNIs (VeryFastTreeImpl.tcc:160-185 without the interleaved SPR rounds, i.e. `-spr 0`): up to
+           round(4 log2 N) rounds of DoNNI(useML = false), stopping after a round that changes nothing.  Call after
+           finishRoot; the context needs max_nodes >= 3 * nSeqs (up-profiles).  Returns the number of NNIs made. */
+        int64_t meNNIRounds() {
+            if (root < 0) throw std::invalid_argument("NJDriver::meNNIRounds before finishRoot");
+            if (nSeqs <= 3) return 0;
+            std::vector<int64_t> par, ch;
+            treeArrays(par, ch);
+            MLLengths<REAL> tree(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
+            typename MLLengths<REAL>::NNIParams prm;
+            prm.useML = false;
+            prm.scoredist = opt.scoredist;
+            std::vector<typename MLLengths<REAL>::NNIStats> stats;
+            tree.initNNIStats(stats);
+            const int64_t nniToDo = (int64_t) (0.5 + 4.0 * std::log((double) nSeqs) / std::log(2.0));
+            int64_t total = 0;
+            meNNIRoundsDone = 0;
+            for (int64_t i = 0; i < nniToDo; i++) {
+                double maxDelta;
+                const int64_t nChange = tree.doNNI(prm, stats, maxDelta);
+                meNNIRoundsDone++;
+                total += nChange;
+                if (nChange == 0) break;
+            }
+            adoptTree(tree.parents(), tree.children());
+            return total;
+        }
+
+        int64_t meNNIRoundsDone = 0;
+
         /* `-mllen -nocat` under Jukes-Cantor (VeryFastTreeImpl.tcc:249-311): rounds of optimizeAllBranchLengths +
            treeLogLk on the finished topology until the largest change of a length drops below 0.001, at most
            round(log2 N) rounds; after the first round setMLRates (NJ.tcc:5429-5488): with one category (-nocat) just
@@ -353,17 +414,8 @@ namespace veryfasttree {
             chkT("vft_set_rates", [&]() { return vft_set_rates(ctx, &one, 1, cat.data()); });
             chkT("vft_set_ml_limits", [&]() { return vft_set_ml_limits(ctx, f32 ? 5.0e-4 : 5.0e-9, f32 ? 2.5e-4 : 2.5e-9, f32 ? 1.0e-10 : 1.0e-20); });   /* Constants.h:26-39 */
             const double ftol = 0.001, atol = f32 ? 1.0e-4 : 1.0e-9;
-            std::vector<int64_t> par((size_t) maxnode), ch((size_t) (3 * maxnode), -1);
-            for (int64_t v = 0; v < maxnode; v++) {
-                par[(size_t) v] = parent[(size_t) v];
-                if (v == root) {
-                    for (int k = 0; k < 3; k++) ch[(size_t) (3 * v + k)] = rootChild[k];
-                } else if (v >= nSeqs) {
-                    ch[(size_t) (3 * v)] = child0[(size_t) v];
-                    ch[(size_t) (3 * v + 1)] = child1[(size_t) v];
-                }
-            }
-            par[(size_t) root] = -1;
+            std::vector<int64_t> par, ch;
+            treeArrays(par, ch);
             double nonGap = 0;
             for (int64_t i = 0; i < nSeqs; i++) nonGap += (double) selfweightLeaf[(size_t) i];
             const int64_t nLeafGaps = nSeqs * nPos - (int64_t) nonGap;
