@@ -33,7 +33,9 @@ typedef struct {
     int32_t me_nni;             /* 1 = minimum-evolution NNI rounds after fastNJ (DoNNI with useML = false, NJ.tcc:5797-6200;
                                    round(4 log2 N) rounds or until a round changes nothing, VeryFastTreeImpl.tcc:160-185):
                                    the reference's default without SPR moves (`-spr 0`); 0 = `-nome` */
-    int32_t ml_nni;             /* reserved for maximum-likelihood NNI rounds (0) */
+    int32_t ml_nni;             /* vft_nj_ml_newick: n >= 1 = maximum-likelihood NNI rounds (DoNNI with useML = true; up to
+                                   round(2 log2 N) rounds, VeryFastTreeImpl.tcc:311-393) under Jukes-Cantor with n rate
+                                   categories (1 = `-nocat`, 20 = the default CAT approximation); 0 = `-noml` / `-mllen` */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

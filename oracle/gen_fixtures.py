@@ -210,9 +210,42 @@ def gen_menni(tmp):
         print("%-20s %2d rounds %4d NNIs  %7.1f KiB" % (name, len(rounds), nni, os.path.getsize(dst) / 1024.0))
 
 
+MLNNI_CASES = [
+    # name, flags, n_seq, n_pos, mu, gap, seed: maximum-likelihood NNIs under Jukes-Cantor, no SPR moves
+    ("mlnni_nt_200_nocat", ["-nt", "-nome", "-nocat"], 200, 120, 0.05, 0.02, 21),   # NJ topology + ML NNIs, constant rates
+    ("mlnni_nt_200", ["-nt", "-nome"], 200, 120, 0.05, 0.02, 21),                   # + CAT rates
+    ("mlnni_nt_300_spr0", ["-nt", "-spr", "0"], 300, 200, 0.08, 0.03, 51),          # ME NNIs + ML NNIs + CAT: default minus SPR
+    ("mlnni_nt_150_double", ["-nt", "-nome", "-double-precision"], 150, 150, 0.10, 0.04, 52),
+    ("mlnni_nt_20", ["-nt", "-spr", "0"], 20, 100, 0.15, 0.05, 53),
+]
+
+
+def gen_mlnni(tmp):
+    """Black box: TreeLogLk after every ML NNI round and after the final length pass, NNI counts, final trees."""
+    for name, flags, n, L, mu, gap, seed in MLNNI_CASES:
+        codes = synth.random_descent_codes(n, L, 4, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+        log = os.path.join(tmp, name + ".log")
+        base = [REFBIN] + flags + ["-threads", "1", "-seed", "1"]
+        res = subprocess.run(base + ["-nosupport", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        text = open(log).read()
+        ll = [float(m.group(1)) for m in re.finditer(r"^TreeLogLk\tML_NNI\d+\t(\S+)\tMaxChange", text, re.M)]
+        ll.append(float(re.search(r"^TreeLogLk\tML_Lengths2\t(\S+)", text, re.M).group(1)))
+        err = res.stderr.decode(errors="replace") + text
+        m = re.search(r"^NNI: (\d+) SPR: (\d+) ML-NNI: (\d+)", err, re.M)
+        res2 = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, codes=codes, loglk=np.array(ll), n_me_nni=np.int64(m.group(1)), n_ml_nni=np.int64(m.group(3)),
+                            newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
+                            flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        print("%-22s %2d ML NNI rounds %4d ML NNIs %4d ME NNIs  final logLk %.4f" % (name, len(ll) - 1, int(m.group(3)), int(m.group(1)), ll[-1]))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "mllen", "menni"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "mllen", "menni", "mlnni"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -224,6 +257,8 @@ def main():
             gen_mllen(tmp)
         if "menni" in which:
             gen_menni(tmp)
+        if "mlnni" in which:
+            gen_mlnni(tmp)
 
 
 if __name__ == "__main__":

@@ -28,3 +28,40 @@ def test_min_evolution_nnis_match_the_reference_run(name, dt):
     assert tree == ref
     boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=True, n_bootstrap=1000)
     assert boot == bytes(d["newick_support"]).decode().strip()
+
+
+@pytest.mark.parametrize("name,dt,ncat,me", [("mlnni_nt_20", np.float32, 20, True), ("mlnni_nt_200_nocat", np.float32, 1, False),
+                                             ("mlnni_nt_200", np.float32, 20, False),
+                                             ("mlnni_nt_150_double", np.float64, 20, False),
+                                             ("mlnni_nt_300_spr0", np.float32, 20, True)])
+def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me):
+    """`VeryFastTree -nt [-nome | -spr 0] [-nocat] [-nosupport]`: ML NNI rounds (DoNNI with MLQuartetNNI per node on the
+    device), CAT rates after the first round, final length pass, SH-like supports.  TreeLogLk after every round within
+    the north star's 1e-4 relative; the final topology is the reference's."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load(name)
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    make = lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n)
+    tree, loglk = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=me, ml_nni=ncat, return_loglk=True)
+    want = d["loglk"]
+    print(name, "rounds", len(loglk) - 1, "vs", len(want) - 1, "final", loglk[-1], want[-1])
+    assert len(loglk) == len(want)
+    assert np.allclose(loglk, want, rtol=1e-4, atol=0)
+    ref = bytes(d["newick"]).decode().strip()
+    strip = lambda t: re.sub(r":[0-9.eE+-]+", ":", t)
+    assert strip(tree) == strip(ref), "topology differs"
+    got_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", tree)])
+    ref_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", ref)])
+    assert np.allclose(got_len, ref_len, rtol=5e-3, atol=2e-5 if dt == np.float32 else 1e-8)
+    print(name, "printed lengths differing:", int((got_len != ref_len).sum()), "of", len(ref_len))
+    assert tree == ref     # observed on MI355X: byte-identical
+    boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=me, ml_nni=ncat, n_bootstrap=1000)
+    refb = bytes(d["newick_support"]).decode().strip()
+    sup = lambda t: np.array([float(x) for x in re.findall(r"\)([0-9.]+):", t)])
+    assert re.sub(r"\)[0-9.]+:", "):", re.sub(r":[0-9.eE+-]+", ":", boot)) == re.sub(r"\)[0-9.]+:", "):", re.sub(r":[0-9.eE+-]+", ":", refb))
+    ds = np.abs(sup(boot) - sup(refb))
+    print(name, "supports differing:", int((ds > 0).sum()), "of", len(ds), "max", ds.max() if len(ds) else 0)
+    assert ds.max() <= 0.002 + 1e-9
+    assert boot == refb    # observed on MI355X: byte-identical, supports included

@@ -74,6 +74,30 @@ namespace veryfasttree {
             }
         }
 
+        /* recomputeProfiles (NJ.tcc:3475-3500) without a matrix: every internal profile as the plain average of its
+           children, one vft_average_profiles per tree level (through the tile streams: clears the dense ML rows) */
+        void recomputeAverageProfiles() {
+            std::vector<int64_t> level((size_t) nNodes, 0);
+            int64_t top = 0;
+            for (int64_t v: order) {
+                if (v == root) continue;
+                level[(size_t) v] = 1 + std::max(level[(size_t) child[3 * v]], level[(size_t) child[3 * v + 1]]);
+                top = std::max(top, level[(size_t) v]);
+            }
+            std::vector<std::vector<int64_t>> byLevel((size_t) top + 1);
+            for (int64_t v: order)
+                if (v != root) byLevel[(size_t) level[(size_t) v]].push_back(v);
+            for (int64_t lv = 1; lv <= top; lv++) {
+                const std::vector<int64_t> &out = byLevel[(size_t) lv];
+                std::vector<int64_t> a, b;
+                for (int64_t v: out) {
+                    a.push_back(child[3 * v]);
+                    b.push_back(child[3 * v + 1]);
+                }
+                chk(vft_average_profiles(ctx, (int64_t) out.size(), out.data(), a.data(), b.data(), nullptr));
+            }
+        }
+
         /* one call of optimizeAllBranchLengths */
         void optimizeRound(double ftol, double atol) {
             std::vector<char> upHave((size_t) nNodes, 0);

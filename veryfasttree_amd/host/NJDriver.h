@@ -406,7 +406,8 @@ namespace veryfasttree {
            here: without a transition matrix the unweighted averages are the profiles the joins already made.
            Call after updateBranchLengths; the context needs max_nodes >= 3 * nSeqs.  Returns the tree log-likelihood
            after each round (the reference's "TreeLogLk Length<k>" log lines). */
-        std::vector<double> mlLengths(int32_t nRateCats = 1, int32_t nBootstrap = 0) {
+        std::vector<double> mlLengths(int32_t nRateCats = 1, int32_t nBootstrap = 0, bool mllen = true, bool mlNNI = false,
+                                      bool reaverage = false) {
             if (root < 0) throw std::invalid_argument("NJDriver::mlLengths before finishRoot");
             const bool f32 = sizeof(REAL) == 4;
             const REAL one = 1;
@@ -422,9 +423,13 @@ namespace veryfasttree {
             MLLengths<REAL> ml(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             upReady = false;   /* the up-profile slots now hold ML up-profiles */
             ml.setLengths(branchlength.data());
+            /* recomputeProfiles(tmatAsDist) (VeryFastTreeImpl.tcc:253-256): plain re-averaging under Jukes-Cantor - the
+               identity straight after fastNJ, needed after minimum-evolution NNIs (they leave some profiles stale) */
+            if (reaverage) ml.recomputeAverageProfiles();
             std::vector<double> loglk;
-            const int64_t maxRound = (int64_t) (0.5 + std::log((double) nSeqs) / std::log(2.0));
+            const int64_t maxRound = mllen ? (int64_t) (0.5 + std::log((double) nSeqs) / std::log(2.0)) : 0;
             std::vector<REAL> old((size_t) maxnode);
+            bool ratesSet = false;
             for (int64_t iRound = 1; iRound <= maxRound; iRound++) {
                 for (int64_t v = 0; v < maxnode; v++) old[(size_t) v] = branchlength[(size_t) v];
                 ml.optimizeRound(ftol, atol);
@@ -434,8 +439,47 @@ namespace veryfasttree {
                 loglk.push_back(ml.treeLogLk(nPos, nLeafGaps));
                 /* (the reference never updates its dLastLogLk, so the likelihood clause of its test cannot fire) */
                 const bool converged = iRound > 1 && dMaxChange < 0.001;
-                if (iRound == 1) ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);   /* VeryFastTreeImpl.tcc:299-305 */
+                if (iRound == 1) {
+                    ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);   /* VeryFastTreeImpl.tcc:299-305 */
+                    ratesSet = nRateCats > 1;
+                }
                 if (converged) break;
+            }
+            if (mlNNI && nSeqs > 3) {
+                /* maximum-likelihood NNIs (VeryFastTreeImpl.tcc:311-393): lengths first, then up to round(2 log2 N)
+                   rounds of DoNNI(useML) with the reference's convergence rule (one more round after the likelihood or
+                   the best NNI stops improving by 0.1, NNI statistics reset for the last one), the rate categories
+                   fitted after the first round, and a final pass over all lengths */
+                const int64_t MLnniToDo = (int64_t) (0.5 + 2.0 * std::log((double) nSeqs) / std::log(2.0));
+                ml.optimizeRound(ftol, atol);
+                typename MLLengths<REAL>::NNIParams prm;
+                prm.useML = true;
+                prm.ftol = ftol;
+                prm.atol = atol;
+                std::vector<typename MLLengths<REAL>::NNIStats> stats;
+                ml.initNNIStats(stats);
+                double lastloglk = -1e20;
+                bool bConverged = false;
+                mlNNIs = 0;
+                for (int64_t iMLnni = 0; iMLnni < MLnniToDo; iMLnni++) {
+                    double maxDelta;
+                    mlNNIs += ml.doNNI(prm, stats, maxDelta);
+                    const double ll = ml.treeLogLk(nPos, nLeafGaps);
+                    loglk.push_back(ll);
+                    const bool bConvergedHere = iMLnni > 0 && (ll < lastloglk + 0.1 || maxDelta < 0.1);
+                    if (bConverged) break;
+                    if (bConvergedHere) bConverged = true;
+                    if (bConverged || iMLnni == MLnniToDo - 2) ml.initNNIStats(stats);
+                    lastloglk = ll;
+                    if (iMLnni == 0 && !ratesSet) {
+                        ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);
+                        ratesSet = nRateCats > 1;
+                    }
+                }
+                ml.optimizeRound(ftol, atol);
+                loglk.push_back(ml.treeLogLk(nPos, nLeafGaps));   /* "TreeLogLk ML_Lengths2" */
+                ml.getLengths(branchlength.data());
+                adoptTree(ml.parents(), ml.children());
             }
             if (nBootstrap > 0 && nSeqs > 3) {
                 /* testSplitsML (VeryFastTreeImpl.tcc:396-398): SH-like supports from the same column resamples the
@@ -459,6 +503,7 @@ namespace veryfasttree {
             return loglk;
         }
 
+        int64_t mlNNIs = 0;
         int64_t mlEvaluations = 0, mlBadSplits = 0, mlSplits = 0;   /* "Bad splits: b/n" of the reference's summary line */
         double mlWorstDelta = 0;
         std::vector<REAL> mlRates;           /* what the reference logs as "Rates" ... */

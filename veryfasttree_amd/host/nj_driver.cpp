@@ -42,11 +42,13 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     drv.finishRoot();
     if (o && o->me_nni) drv.meNNIRounds();
     if (meLengths) drv.updateBranchLengths();
-    const bool ml = o && o->mllen;
+    const bool ml = o && (o->mllen || o->ml_nni);
     if (nBootstrap > 0 && !ml) drv.computeSupports(nBootstrap);
     if (ml) {
-        if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: mllen needs me_lengths (updateBranchLengths runs first)");
-        loglk = drv.mlLengths(o->mllen, nBootstrap);   /* with supports: SH-like (testSplitsML) instead of local bootstrap */
+        if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: the ML stage needs me_lengths (updateBranchLengths runs first)");
+        /* with supports: SH-like (testSplitsML) instead of the local bootstrap */
+        const int32_t nCat = o->mllen ? o->mllen : (o->ml_nni > 1 ? o->ml_nni : 1);
+        loglk = drv.mlLengths(nCat, nBootstrap, o->mllen != 0, o->ml_nni != 0, o->me_nni != 0);
         rates.assign(drv.mlRates.begin(), drv.mlRates.end());
         ratecat = drv.mlRateCat;
     }
