@@ -36,6 +36,9 @@ typedef struct {
     int32_t ml_nni;             /* vft_nj_ml_newick: n >= 1 = maximum-likelihood NNI rounds (DoNNI with useML = true; up to
                                    round(2 log2 N) rounds, VeryFastTreeImpl.tcc:311-393) under Jukes-Cantor with n rate
                                    categories (1 = `-nocat`, 20 = the default CAT approximation); 0 = `-noml` / `-mllen` */
+    int32_t spr;                /* with me_nni: rounds of minimum-evolution SPR moves between the NNI rounds (SPR,
+                                   NJ.tcc:6185-6404; the reference's default is 2, 0 = `-spr 0`) */
+    int32_t reserved;
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

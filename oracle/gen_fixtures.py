@@ -185,6 +185,11 @@ MENNI_CASES = [
     ("nni_nt_500", ["-nt"], 500, 100, 4, 0.10, 0.05, 41),
     ("nni_nt_300_double", ["-nt", "-double-precision"], 300, 90, 4, 0.08, 0.03, 42),
     ("nni_nt_12", ["-nt"], 12, 60, 4, 0.2, 0.05, 43),
+    # `-noml` with the default two SPR rounds between the NNI rounds
+    ("spr_nt_200", ["-nt", "-spr", "2"], 200, 120, 4, 0.05, 0.02, 21),
+    ("spr_nt_500", ["-nt", "-spr", "2"], 500, 100, 4, 0.10, 0.05, 41),
+    ("spr_nt_300_double", ["-nt", "-double-precision", "-spr", "2"], 300, 90, 4, 0.08, 0.03, 42),
+    ("spr_nt_12", ["-nt", "-spr", "2"], 12, 60, 4, 0.2, 0.05, 43),
 ]
 
 
@@ -195,19 +200,20 @@ def gen_menni(tmp):
         fa = os.path.join(tmp, name + ".fa")
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if nc == 20 else synth.ALPHABET_NT)
         log = os.path.join(tmp, name + ".log")
-        base = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-noml", "-spr", "0"]
+        base = [REFBIN] + flags + ["-threads", "1", "-seed", "1", "-noml"] + ([] if "-spr" in flags else ["-spr", "0"])
         res = subprocess.run(base + ["-nosupport", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         text = open(log).read()
         rounds = re.findall(r"^ME_NNI\d+\t(\(.*;)\s*$", text, re.M)
-        nni = int(re.search(r"^NNI: (\d+) SPR", res.stderr.decode(errors="replace") + text, re.M).group(1))
+        mm = re.search(r"^NNI: (\d+) SPR: (\d+)", res.stderr.decode(errors="replace") + text, re.M)
+        nni, nspr = int(mm.group(1)), int(mm.group(2))
         res2 = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dst = os.path.join(GOLDEN, name + ".npz")
-        np.savez_compressed(dst, codes=codes, n_nni=np.int64(nni), n_rounds=np.int64(len(rounds)),
+        np.savez_compressed(dst, codes=codes, n_nni=np.int64(nni), n_spr=np.int64(nspr), n_rounds=np.int64(len(rounds)),
                             last_round=np.frombuffer(rounds[-1].encode(), dtype=np.uint8),
                             newick=np.frombuffer(res.stdout, dtype=np.uint8),
                             newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
                             flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
-        print("%-20s %2d rounds %4d NNIs  %7.1f KiB" % (name, len(rounds), nni, os.path.getsize(dst) / 1024.0))
+        print("%-20s %2d rounds %4d NNIs %3d SPRs  %7.1f KiB" % (name, len(rounds), nni, nspr, os.path.getsize(dst) / 1024.0))
 
 
 MLNNI_CASES = [
@@ -217,6 +223,10 @@ MLNNI_CASES = [
     ("mlnni_nt_300_spr0", ["-nt", "-spr", "0"], 300, 200, 0.08, 0.03, 51),          # ME NNIs + ML NNIs + CAT: default minus SPR
     ("mlnni_nt_150_double", ["-nt", "-nome", "-double-precision"], 150, 150, 0.10, 0.04, 52),
     ("mlnni_nt_20", ["-nt", "-spr", "0"], 20, 100, 0.15, 0.05, 53),
+    # the reference's complete default pipeline for nucleotides (Jukes-Cantor + CAT): NJ, ME NNIs + 2 SPR rounds, ML NNIs
+    ("full_nt_200", ["-nt"], 200, 120, 0.05, 0.02, 21),
+    ("full_nt_300", ["-nt"], 300, 200, 0.08, 0.03, 51),
+    ("full_nt_250_double", ["-nt", "-double-precision"], 250, 150, 0.10, 0.04, 54),
 ]
 
 

@@ -10,32 +10,40 @@ import golden_util as G
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,dt", [("nni_nt_12", np.float32), ("nni_nt_200", np.float32), ("nni_nt_500", np.float32),
-                                     ("nni_nt_300_double", np.float64)])
-def test_min_evolution_nnis_match_the_reference_run(name, dt):
-    """`VeryFastTree -nt -noml -spr 0 [-nosupport]`: fastNJ, rounds of minimum-evolution NNIs, ME branch lengths,
-    local-bootstrap supports - the final trees byte for byte (topology after 5 ... 345 NNIs, lengths, supports)."""
+@pytest.mark.parametrize("name,dt,spr", [("nni_nt_12", np.float32, 0), ("nni_nt_200", np.float32, 0), ("nni_nt_500", np.float32, 0),
+                                         ("nni_nt_300_double", np.float64, 0), ("spr_nt_12", np.float32, 2),
+                                         ("spr_nt_200", np.float32, 2), ("spr_nt_500", np.float32, 2),
+                                         ("spr_nt_300_double", np.float64, 2)])
+def test_min_evolution_nnis_match_the_reference_run(name, dt, spr):
+    """`VeryFastTree -nt -noml [-spr 0] [-nosupport]`: fastNJ, rounds of minimum-evolution NNIs with 0 or the default 2
+    rounds of SPR moves in between, ME branch lengths, local-bootstrap supports - the final trees byte for byte
+    (topology after 5 ... 361 NNIs and up to 9 SPRs, lengths, supports)."""
     from veryfasttree_amd import HipProfileOps
     from veryfasttree_amd.backend import nj_newick
     d = G.load(name)
     codes_all = d["codes"]
     names = ["s%d" % k for k in range(len(codes_all))]
     make = lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n)
-    tree = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=True)
+    tree = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=True, spr=spr)
     ref = bytes(d["newick"]).decode().strip()
     strip = lambda t: re.sub(r":[0-9.eE+-]+", ":", t)
     assert strip(tree) == strip(ref), "topology differs"
     assert tree == ref
-    boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=True, n_bootstrap=1000)
+    boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=True, spr=spr, n_bootstrap=1000)
     assert boot == bytes(d["newick_support"]).decode().strip()
 
 
-@pytest.mark.parametrize("name,dt,ncat,me", [("mlnni_nt_20", np.float32, 20, True), ("mlnni_nt_200_nocat", np.float32, 1, False),
-                                             ("mlnni_nt_200", np.float32, 20, False),
-                                             ("mlnni_nt_150_double", np.float64, 20, False),
-                                             ("mlnni_nt_300_spr0", np.float32, 20, True)])
-def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me):
-    """`VeryFastTree -nt [-nome | -spr 0] [-nocat] [-nosupport]`: ML NNI rounds (DoNNI with MLQuartetNNI per node on the
+@pytest.mark.parametrize("name,dt,ncat,me,spr", [("mlnni_nt_20", np.float32, 20, True, 0),
+                                                 ("mlnni_nt_200_nocat", np.float32, 1, False, 0),
+                                                 ("mlnni_nt_200", np.float32, 20, False, 0),
+                                                 ("mlnni_nt_150_double", np.float64, 20, False, 0),
+                                                 ("mlnni_nt_300_spr0", np.float32, 20, True, 0),
+                                                 ("full_nt_200", np.float32, 20, True, 2),
+                                                 ("full_nt_300", np.float32, 20, True, 2),
+                                                 ("full_nt_250_double", np.float64, 20, True, 2)])
+def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me, spr):
+    """`VeryFastTree -nt [-nome | -spr 0] [-nocat] [-nosupport]` and plain `VeryFastTree -nt` (full_*: the complete
+    default pipeline - NJ, ME NNIs + SPRs, ML NNIs, CAT rates, SH-like supports): ML NNI rounds (DoNNI with MLQuartetNNI per node on the
     device), CAT rates after the first round, final length pass, SH-like supports.  TreeLogLk after every round within
     the north star's 1e-4 relative; the final topology is the reference's."""
     from veryfasttree_amd import HipProfileOps
@@ -44,7 +52,7 @@ def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me):
     codes_all = d["codes"]
     names = ["s%d" % k for k in range(len(codes_all))]
     make = lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n)
-    tree, loglk = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=me, ml_nni=ncat, return_loglk=True)
+    tree, loglk = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=me, spr=spr, ml_nni=ncat, return_loglk=True)
     want = d["loglk"]
     print(name, "rounds", len(loglk) - 1, "vs", len(want) - 1, "final", loglk[-1], want[-1])
     assert len(loglk) == len(want)
@@ -57,7 +65,7 @@ def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me):
     assert np.allclose(got_len, ref_len, rtol=5e-3, atol=2e-5 if dt == np.float32 else 1e-8)
     print(name, "printed lengths differing:", int((got_len != ref_len).sum()), "of", len(ref_len))
     assert tree == ref     # observed on MI355X: byte-identical
-    boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=me, ml_nni=ncat, n_bootstrap=1000)
+    boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, me_nni=me, spr=spr, ml_nni=ncat, n_bootstrap=1000)
     refb = bytes(d["newick_support"]).decode().strip()
     sup = lambda t: np.array([float(x) for x in re.findall(r"\)([0-9.]+):", t)])
     assert re.sub(r"\)[0-9.]+:", "):", re.sub(r":[0-9.eE+-]+", ":", boot)) == re.sub(r"\)[0-9.]+:", "):", re.sub(r":[0-9.eE+-]+", ":", refb))

@@ -430,15 +430,8 @@ namespace veryfasttree {
                     for (int i = 0; i < 3; i++) criteria[i] = r.criteria[i];
                     if (r.star) nStarTests++;
                 } else {
-                    /* correctedPairDistances (NJ.tcc:1460-1488) over A, B, C, D: AB AC AD BC BD CD */
-                    const int64_t pi[6] = {nodeA, nodeA, nodeA, nodeB, nodeB, nodeC}, pj[6] = {nodeB, nodeC, idD, nodeC, idD, idD};
-                    REAL d[6], w[6];
-                    chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
-                    double c[6];
-                    for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[i], prm.scoredist);
-                    criteria[0] = c[0] + c[5];
-                    criteria[1] = c[1] + c[4];
-                    criteria[2] = c[2] + c[3];
+                    int64_t qq[4];
+                    meCriteria(node, prm.scoredist, upHave, qq, criteria);
                     if (criteria[1] < criteria[0] && criteria[1] <= criteria[2]) choice = 1;
                     else if (criteria[2] < criteria[0] && criteria[2] <= criteria[1]) choice = 2;
                     for (int i = 0; i < 3; i++) criteria[i] = -criteria[i];   /* higher is better, as for ML */
@@ -476,24 +469,90 @@ namespace veryfasttree {
                     upHave[(size_t) nodeA] = upHave[(size_t) nodeB] = upHave[(size_t) nodeC] = 0;
                     recomputeProfile(node, prm.useML);
                 } else {
-                    /* updateForNNI, fast flavour (NJ.tcc:1902-1926) */
-                    upHave[(size_t) node] = 0;
-                    for (int k = 0; k < 2; k++) upHave[(size_t) child[3 * node + k]] = 0;
-                    const int64_t ip = parent[(size_t) node];
-                    if (ip == root) {
-                        for (int k = 0; k < 3; k++)
-                            if (child[3 * root + k] != node) upHave[(size_t) child[3 * root + k]] = 0;
-                    } else {
-                        upHave[(size_t) ip] = 0;
-                        upHave[(size_t) siblingOf(node)] = 0;
-                    }
-                    if (ip != root && parent[(size_t) ip] != root) upHave[(size_t) siblingOf(ip)] = 0;   /* the uncle */
-                    recomputeProfile(node, prm.useML);
-                    recomputeProfile(ip, prm.useML);
+                    updateForNNI(node, prm.useML, upHave);
                 }
             }
             rebuildOrder();
             return nNNIThisRound;
+        }
+
+        /* SPR (NJ.tcc:6185-6404, one thread, fast flavour): every node in post-order is moved along chains of up to
+           maxSPRLength minimum-evolution NNIs around its parent and its sibling (findSPRSteps, NJ.tcc:1805-1859; the
+           first step forced to AC or AD), keeping the prefix of the chain with the best total length change and
+           unwinding the rest (unwindSPRStep, NJ.tcc:1861-1879).  Returns the number of accepted moves. */
+        int64_t doSPR(bool scoredist, int maxSPRLength = 10) {
+            if (nSeqs <= 3 || maxSPRLength < 1) return 0;
+            std::vector<char> traversal((size_t) nNodes, 0), upHave((size_t) nNodes, 0);
+            std::vector<int64_t> nodeList;
+            {   /* the walk is fixed before anything moves */
+                int64_t node = root;
+                bool up;
+                while ((node = nextPostorder(node, traversal, &up, root, /*reportUp*/false)) >= 0) nodeList.push_back(node);
+            }
+            struct Step {
+                int64_t nodes[2];
+                double deltaLength;
+            };
+            std::vector<Step> steps((size_t) maxSPRLength);
+            int64_t nSPR = 0;
+            for (int64_t node: nodeList) {
+                if (node == root) continue;
+                int64_t nodeAround[2];
+                movePivots(node, nodeAround);
+                bool bChanged = false;
+                for (int iAround = 0; iAround < 2 && !bChanged; iAround++) {
+                    for (int acFirst = 0; acFirst < 2 && !bChanged; acFirst++) {
+                        /* findSPRSteps */
+                        int64_t around = nodeAround[iAround], chainLength = 0;
+                        for (; chainLength < maxSPRLength; chainLength++) {
+                            if (around < nSeqs || around == root) break;   /* nChild != 2 */
+                            int64_t q[4];
+                            double criteria[3];
+                            meCriteria(around, scoredist, upHave, q, criteria);
+                            Step &st = steps[(size_t) chainLength];
+                            if (chainLength == 0 ? acFirst != 0 : criteria[1] < criteria[2]) {
+                                st.deltaLength = criteria[1] - criteria[0];   /* swap B and C: AC together */
+                                st.nodes[0] = q[1];
+                                st.nodes[1] = q[2];
+                            } else {
+                                st.deltaLength = criteria[2] - criteria[0];   /* swap A and C: AD together */
+                                st.nodes[0] = q[0];
+                                st.nodes[1] = q[2];
+                            }
+                            replaceChild(around, st.nodes[0], st.nodes[1]);
+                            replaceChild(parent[(size_t) around], st.nodes[1], st.nodes[0]);
+                            updateForNNI(around, false, upHave);
+                            int64_t next[2];
+                            movePivots(node, next);
+                            around = next[next[0] == around ? 1 : 0];
+                        }
+                        double dMinDelta = 0.0, dTotDelta = 0.0;
+                        int64_t iCBest = -1;
+                        for (int64_t iC = 0; iC < chainLength; iC++) {
+                            dTotDelta += steps[(size_t) iC].deltaLength;
+                            if (dTotDelta < dMinDelta) {
+                                dMinDelta = dTotDelta;
+                                iCBest = iC;
+                            }
+                        }
+                        for (int64_t iC = chainLength - 1; iC > iCBest; iC--) {   /* unwindSPRStep */
+                            const Step &st = steps[(size_t) iC];
+                            const int64_t p0 = parent[(size_t) st.nodes[0]], p1 = parent[(size_t) st.nodes[1]];
+                            replaceChild(p0, st.nodes[0], st.nodes[1]);
+                            replaceChild(p1, st.nodes[1], st.nodes[0]);
+                            updateForNNI(parent[(size_t) p0] == p1 ? p0 : p1, false, upHave);
+                        }
+                        if (iCBest >= 0) bChanged = true;
+                    }
+                }
+                if (bChanged) {
+                    nSPR++;
+                    std::fill(upHave.begin(), upHave.end(), 0);
+                    for (int64_t anc = parent[(size_t) node]; anc >= 0; anc = parent[(size_t) anc]) recomputeProfile(anc, false);
+                }
+            }
+            rebuildOrder();
+            return nSPR;
         }
 
         int64_t nStarTests = 0;
@@ -548,8 +607,59 @@ namespace veryfasttree {
             throw std::logic_error("MLLengths::replaceChild: not a child");
         }
 
+        /* updateForNNI, fast flavour (NJ.tcc:1902-1926): drop the up-profiles around the rearranged node, refresh its
+           profile and its parent's */
+        void updateForNNI(int64_t node, bool useML, std::vector<char> &upHave) {
+            upHave[(size_t) node] = 0;
+            for (int k = 0; k < 2; k++) upHave[(size_t) child[3 * node + k]] = 0;
+            const int64_t ip = parent[(size_t) node];
+            if (ip == root) {
+                for (int k = 0; k < 3; k++)
+                    if (child[3 * root + k] != node) upHave[(size_t) child[3 * root + k]] = 0;
+            } else {
+                upHave[(size_t) ip] = 0;
+                upHave[(size_t) siblingOf(node)] = 0;
+            }
+            if (ip != root && parent[(size_t) ip] != root) upHave[(size_t) siblingOf(ip)] = 0;   /* the uncle */
+            recomputeProfile(node, useML);
+            recomputeProfile(ip, useML);
+        }
+
+        /* the two nodes a subtree can be moved around: its parent and its sibling, or its two siblings below the root */
+        void movePivots(int64_t node, int64_t out[2]) const {
+            const int64_t p = parent[(size_t) node];
+            if (p == root) {
+                int n = 0;
+                for (int k = 0; k < 3; k++)
+                    if (child[3 * root + k] != node) out[n++] = child[3 * root + k];
+            } else {
+                out[0] = p;
+                out[1] = siblingOf(node);
+            }
+        }
+
+        /* setupABCD + chooseNNI's criteria (NJ.tcc:4836-4846; lower is better): log-corrected distances AB+CD, AC+BD,
+           AD+BC over the four profiles around `node` */
+        void meCriteria(int64_t node, bool scoredist, std::vector<char> &upHave, int64_t q[4], double criteria[3]) {
+            quartetNodes(node, q);
+            const int64_t par = parent[(size_t) node];
+            int64_t idD = q[3];
+            if (par != root) {
+                ensureUpProfile(par, false, upHave);
+                idD = par + nSeqs;
+            }
+            const int64_t pi[6] = {q[0], q[0], q[0], q[1], q[1], q[2]}, pj[6] = {q[1], q[2], idD, q[2], idD, idD};
+            REAL d[6], w[6];
+            chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
+            double c[6];
+            for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[i], scoredist);
+            criteria[0] = c[0] + c[5];
+            criteria[1] = c[1] + c[4];
+            criteria[2] = c[2] + c[3];
+        }
+
         /* traversePostorder (NJ.tcc:3343-3380) on the tree as it is now */
-        int64_t nextPostorder(int64_t node, std::vector<char> &traversal, bool *up, int64_t branchRoot) const {
+        int64_t nextPostorder(int64_t node, std::vector<char> &traversal, bool *up, int64_t branchRoot, bool reportUp = true) const {
             *up = false;
             for (;;) {
                 bool found = false;
@@ -568,7 +678,7 @@ namespace veryfasttree {
                 }
                 if (node == branchRoot) return -1;
                 node = parent[(size_t) node];
-                if (traversal[(size_t) node]) {
+                if (reportUp && traversal[(size_t) node]) {
                     *up = true;
                     return node;
                 }

@@ -369,10 +369,11 @@ namespace veryfasttree {
             upReady = false;
         }
 
-        /* Minimum-evolution NNIs (VeryFastTreeImpl.tcc:160-185 without the interleaved SPR rounds, i.e. `-spr 0`): up to
-           round(4 log2 N) rounds of DoNNI(useML = false), stopping after a round that changes nothing.  Call after
+        /* Minimum-evolution NNIs and SPRs (VeryFastTreeImpl.tcc:160-205): up to round(4 log2 N) rounds of
+           DoNNI(useML = false), skipped once a round changes nothing, with `spr` rounds of subtree-prune-regraft moves
+           in between (the reference's default is 2; 0 = `-spr 0`).  Call after
            finishRoot; the context needs max_nodes >= 3 * nSeqs (up-profiles).  Returns the number of NNIs made. */
-        int64_t meNNIRounds() {
+        int64_t meNNIRounds(int32_t spr = 0) {
             if (root < 0) throw std::invalid_argument("NJDriver::meNNIRounds before finishRoot");
             if (nSeqs <= 3) return 0;
             std::vector<int64_t> par, ch;
@@ -384,19 +385,36 @@ namespace veryfasttree {
             std::vector<typename MLLengths<REAL>::NNIStats> stats;
             tree.initNNIStats(stats);
             const int64_t nniToDo = (int64_t) (0.5 + 4.0 * std::log((double) nSeqs) / std::log(2.0));
-            int64_t total = 0;
+            int64_t total = 0, sprRemaining = spr;
             meNNIRoundsDone = 0;
+            meSPRs = 0;
+            bool bConverged = false;
             for (int64_t i = 0; i < nniToDo; i++) {
-                double maxDelta;
-                const int64_t nChange = tree.doNNI(prm, stats, maxDelta);
-                meNNIRoundsDone++;
-                total += nChange;
-                if (nChange == 0) break;
+                if (!bConverged) {
+                    double maxDelta;
+                    const int64_t nChange = tree.doNNI(prm, stats, maxDelta);
+                    meNNIRoundsDone++;
+                    total += nChange;
+                    if (nChange == 0) bConverged = true;
+                }
+                /* SPR rounds sit between thirds of the NNI rounds (VeryFastTreeImpl.tcc:187-198) */
+                if (sprRemaining > 0 && nniToDo / (spr + 1) > 0 && ((i + 1) % (nniToDo / (spr + 1))) == 0) {
+                    meSPRs += tree.doSPR(opt.scoredist);
+                    sprRemaining--;
+                    bConverged = false;
+                    tree.initNNIStats(stats);
+                }
+                if (bConverged && sprRemaining == 0) break;
+            }
+            while (sprRemaining > 0) {
+                meSPRs += tree.doSPR(opt.scoredist);
+                sprRemaining--;
             }
             adoptTree(tree.parents(), tree.children());
             return total;
         }
 
+        int64_t meSPRs = 0;
         int64_t meNNIRoundsDone = 0;
 
         /* `-mllen -nocat` under Jukes-Cantor (VeryFastTreeImpl.tcc:249-311): rounds of optimizeAllBranchLengths +

@@ -40,7 +40,7 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
     drv.run(-1);
     drv.finishRoot();
-    if (o && o->me_nni) drv.meNNIRounds();
+    if (o && o->me_nni) drv.meNNIRounds(o->spr);
     if (meLengths) drv.updateBranchLengths();
     const bool ml = o && (o->mllen || o->ml_nni);
     if (nBootstrap > 0 && !ml) drv.computeSupports(nBootstrap);
