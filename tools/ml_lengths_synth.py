@@ -12,6 +12,7 @@ n, L = int(sys.argv[1]), int(sys.argv[2])
 mu = float(sys.argv[3]) if len(sys.argv) > 3 else 0.03
 gap = float(sys.argv[4]) if len(sys.argv) > 4 else 0.01
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+full = os.environ.get("VFT_FULL")   # "1": the complete default pipeline (ME NNIs + 2 SPR rounds, ML NNIs, CAT, SH supports)
 nboot = int(os.environ.get("VFT_ML_BOOT", "0"))   # 1000 = the reference's default SH-like supports
 ncat = int(os.environ.get("VFT_ML_CAT", "1"))   # 1 = -nocat, 20 = the reference's default CAT approximation
 codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
@@ -21,7 +22,7 @@ t0 = time.perf_counter()
 nj_newick(make, codes, names, me_lengths=True)
 t_nj = time.perf_counter() - t0
 t0 = time.perf_counter()
-tree, loglk = nj_newick(make, codes, names, me_lengths=True, mllen=ncat, return_loglk=True, n_bootstrap=nboot)
+tree, loglk = nj_newick(make, codes, names, me_lengths=True, return_loglk=True, **(dict(me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000) if full else dict(mllen=ncat, n_bootstrap=nboot)))
 t_ml = time.perf_counter() - t0
 print("NJ + ME lengths                 %8.2f s" % t_nj)
 print("NJ + ME lengths + ML lengths (%d rate categories, %d resamples)   %8.2f s   -> ML stage %.2f s, %d rounds (%.2f s per round incl. treeLogLk)"
