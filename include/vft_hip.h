@@ -183,6 +183,13 @@ int vft_pair_loglk(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, 
 int vft_posterior_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
                            const double *len1, const double *len2);
 
+/* Tree-refinement phase switch.  on != 0: vft_average_profiles writes plain per-node rows (vft_layout.h, "dense ML rows")
+   instead of the tile streams and skips the self distances - for everything after fastNJ (NNIs, SPRs, up-profiles,
+   branch lengths, supports), where single nodes are rewritten constantly and nothing sweeps.  vft_profile_distances,
+   vft_split_supports and the likelihood calls read either layout; one-vs-all sweeps must not target nodes written in
+   this mode. */
+int vft_set_profile_rows(vft_ctx *ctx, int32_t on);
+
 /* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */
 int vft_branch_lengths_set(vft_ctx *ctx, int64_t first, int64_t count, const void *values);

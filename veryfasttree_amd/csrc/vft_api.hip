@@ -78,6 +78,7 @@ struct vft_ctx {
     int32_t *ratecat = nullptr;
     int32_t nRates = 0;
     double minLen = 5e-4, minRel = 2.5e-4, fpostTol = 1e-10;
+    bool rowMode = false;                      // vft_set_profile_rows: averages write dense rows as well
     uint8_t *mlIs = nullptr, *mlC = nullptr;   // dense ML rows (vft_layout.h), allocated by the first ML-phase write
     void *mlW = nullptr, *mlF = nullptr;
     void *blen = nullptr;              // branchlength[] (numeric_t) for the ML length optimiser
@@ -954,7 +955,14 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
         if (int r = internal_ok(c, out[k])) return r;
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad child id");
     }
-    const CommitPlan plan = commit_plan(c, n);
+    const bool rows = c->rowMode;   // tree-refinement phase: plain rows, no tile re-pack, no self distances
+    if (rows)
+        if (int r = ensure_ml_rows(c)) return r;
+    CommitPlan plan = commit_plan(c, n);
+    if (rows) {
+        plan.chunk = 32768;
+        plan.totalB = 0;
+    }
     const int64_t chunk = plan.chunk;
     const size_t idB = (((size_t) n * 8) + 255) & ~(size_t) 255;
     const bool smallIds = 4 * idB <= VFT_SMALL_BYTES;
@@ -983,10 +991,16 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
             const dim3 grid(cdiv(c->d.nPos, 128), (unsigned) cnt);
             launch((k_average<REAL, NC>), grid, dim3(128), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
                    (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
-                   bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr, c->fpostTol, (REAL *) base);
+                   bionj ? (const double *) (s + 3 * idB) + k0 : (const double *) nullptr, c->fpostTol,
+                   rows ? (REAL *) nullptr : (REAL *) base);
         });
         LAUNCHCHK(c);
-        if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
+        if (!rows)
+            if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
+    }
+    if (rows) {
+        if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));
+        return VFT_OK;
     }
     if (n == 1) {
         VFT_DISPATCH(c, launch((k_selfdist_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / c->pwWaves, c->stream,
@@ -998,6 +1012,15 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
     LAUNCHCHK(c);
     // id lists in the mapped ring are protected by its wrap-around synchronisation; only the scratch path must wait
     if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// After the NJ phase nothing sweeps the internal profiles any more: vft_average_profiles then writes plain rows (the
+// layout of the ML phase, vft_layout.h) instead of re-packing a tile per node, and skips the self distances only the
+// out-distances of the NJ phase need.  Pair distances, split supports and the ML kernels read either layout.
+extern "C" int vft_set_profile_rows(vft_ctx *c, int32_t on) {
+    if (!c) return VFT_ERR_INVALID;
+    c->rowMode = on != 0;
     return VFT_OK;
 }
 
@@ -1694,9 +1717,8 @@ static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dId
         launch((k_ml_node_lengths<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c), \
                dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);                  \
         break;
-    switch (cpt) {
+    switch (cpt == 2 ? 4 : cpt) {
         VFT_MLOPT_CASE(1)
-        VFT_MLOPT_CASE(2)
         VFT_MLOPT_CASE(4)
         default:
             if (NC == 4 && cpt == 8) {
@@ -1761,9 +1783,8 @@ static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds
                dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, dLoglk, dSite, dLen, \
                dNni, c->mlEvals);                                                                                        \
         break;
-    switch (cpt) {
+    switch (cpt == 2 ? 4 : cpt) {   // two columns per thread run the four-column kernel (fewer instantiations to build)
         VFT_MLQ_CASE(1)
-        VFT_MLQ_CASE(2)
         VFT_MLQ_CASE(4)
         default:
             return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");

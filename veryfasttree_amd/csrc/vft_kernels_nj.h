@@ -589,7 +589,7 @@ __device__ __forceinline__ void vft_pair_generic(const Arena<REAL> &A, int64_t i
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_pair_load(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, int64_t p,
                                               Col<REAL, NC> &c1, Col<REAL, NC> &c2) {
-    vft_load_col<REAL, NC>(A, i, p, c1);
+    vft_load_col_ml<REAL, NC>(A, i, p, c1);
     if (jIsOut) {
         c2.w = A.outW[p];
         c2.code = VFT_NOCODE_;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void vft_pair_load(const Arena<REAL> &A, int64_t i, i
 #pragma unroll
         for (int k = 0; k < NC; k++) c2.f[k] = A.outF[p * NC + k];
     } else {
-        vft_load_col<REAL, NC>(A, j, p, c2);
+        vft_load_col_ml<REAL, NC>(A, j, p, c2);
     }
 }
 // its addends to (denom, top), parked in LDS for the in-order sum

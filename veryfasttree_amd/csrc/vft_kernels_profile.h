@@ -261,15 +261,15 @@ __device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *f
 // averageProfile (NJ.tcc:2067-2135): grid.y = join index, threads over columns
 template <typename REAL, int NC>
 __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN,
-                          const double *bionj, double tol, REAL *stash /* non-null: append path */) {
+                          const double *bionj, double tol, REAL *stash /* null: write the node's dense row */) {
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
     const int64_t k = blockIdx.y;
     double bw = bionj ? bionj[k] : -1.0;
     if (bw < 0) bw = 0.5;
     Col<REAL, NC> c1, c2;
-    vft_load_col<REAL, NC>(A, aN[k], p, c1);
-    vft_load_col<REAL, NC>(A, bN[k], p, c2);
+    vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
+    vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
     const REAL wo = (REAL) (bw * (double) c1.w + (1 - bw) * (double) c2.w);
     int co = VFT_NOCODE_;
     REAL f[NC];
@@ -284,7 +284,12 @@ __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
             vft_normalize_freq<REAL, NC>(A, f, tol);
         }
     }
-    vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
+    if (stash) {
+        vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
+    } else {
+        vft_store_col_ml<REAL, NC>(A, outN[k], p, wo, co, f);
+        if (p == 0) A.mlIs[outN[k] - A.d.nSeqs] = 1;
+    }
 }
 
 // setCodeDist for one column of the out-profile (NJ.tcc:873-898)
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(VFT_SUPPORT_WG) void k_split_support(Arena<REAL> A,
     for (int64_t p = threadIdx.x; p < nPos; p += blockDim.x) {
         Col<REAL, NC> c[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) vft_load_col<REAL, NC>(A, q[e], p, c[e]);
+        for (int e = 0; e < 4; e++) vft_load_col_ml<REAL, NC>(A, q[e], p, c[e]);
         int j = 0;
 #pragma unroll
         for (int x = 0; x < 4; x++)

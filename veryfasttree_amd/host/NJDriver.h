@@ -178,6 +178,9 @@ namespace veryfasttree {
             branchlength[top[0]] = (REAL) ((d01 + d02 - d12) / 2);
             branchlength[top[1]] = (REAL) ((d01 + d12 - d02) / 2);
             branchlength[top[2]] = (REAL) ((d02 + d12 - d01) / 2);
+            /* the NJ phase is over: from here on single profiles are rewritten (up-profiles, NNIs, SPRs) and nothing
+               sweeps them - plain rows instead of tile re-packs */
+            chkT("vft_set_profile_rows", [&]() { return vft_set_profile_rows(ctx, 1); });
         }
 
         /* up-profiles of all internal nodes on the device (node X -> id X + nSeqs), breadth first from the root:
