@@ -38,7 +38,8 @@ typedef struct {
                                    categories (1 = `-nocat`, 20 = the default CAT approximation); 0 = `-noml` / `-mllen` */
     int32_t spr;                /* with me_nni: rounds of minimum-evolution SPR moves between the NNI rounds (SPR,
                                    NJ.tcc:6185-6404; the reference's default is 2, 0 = `-spr 0`) */
-    int32_t reserved;
+    int32_t gtr;                /* with mllen / ml_nni: 1 = `-gtr` (the six GTR rates and the base frequencies are fitted
+                                   after the first ML round, setMLGtr NJ.tcc:6436-6500; Jukes-Cantor until then) */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
@@ -68,12 +69,13 @@ int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_
    the printed lengths are then the ML ones, as in the reference's output.  me_lengths must be set (the reference always
    runs updateBranchLengths first).  loglk[loglk_cap] (may be NULL) receives "TreeLogLk Length<k>" of each round,
    n_rounds the number of rounds run; rates[rates_cap] / n_rates / ratecat[n_pos] (each may be NULL) the fitted rate
-   categories - the reference's "Rates" and (0-based) "SiteCategories" log lines. */
+   categories - the reference's "Rates" and (0-based) "SiteCategories" log lines; with opt->gtr, gtr_out[10] (may be
+   NULL) = the fitted rates ac ag at cg ct gt and frequencies A C G T ("GTR rates" / "GTR Frequencies"). */
 int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t n_pos, int32_t precision,
                      const vft_nj_options *opt, int32_t me_lengths, int32_t n_bootstrap, const int64_t *unique_first,
                      const int64_t *aln_next, int64_t n_all, const char *names, char *out, int64_t out_cap,
                      int64_t *out_len, double *loglk, int32_t loglk_cap, int32_t *n_rounds, double *rates,
-                     int32_t rates_cap, int32_t *n_rates, int32_t *ratecat, char *err, int32_t err_len);
+                     int32_t rates_cap, int32_t *n_rates, int32_t *ratecat, double *gtr_out, char *err, int32_t err_len);
 
 /* The first n values of the random stream the bootstrap columns are drawn from (Knuth's ran_array at its default
    seed, as the reference uses it, Knuth.cpp:95-111): exported so that tests can pin the host generator. */
@@ -91,6 +93,12 @@ void vft_knuth_stream(double *out, int64_t n);
 int vft_ml_lengths(vft_ctx *ctx, int64_t n_seqs, int64_t n_nodes, int64_t n_pos, int32_t precision, const int64_t *parent,
                    const int64_t *child, int64_t root, void *branchlength, int32_t recompute_first, int32_t rounds,
                    double ftol, double atol, int64_t n_leaf_gaps, double *loglk, int64_t *evals, char *err, int32_t err_len);
+
+/* The GTR model's likelihood tables as the reference builds them (TransitionMatrix.tcc:26-60, 160-232): rates = ac ag
+   at cg ct gt, freq = A C G T; out: stat[4], statinv[4], eigenval[4], codefreq[5][4] (last row = gap), eigeninv[4][4],
+   eigeninvT[4][4]: numeric_t values (precision 4 / 8 bytes) held in double.  Exported for tests. */
+int vft_gtr_tables(const double *rates, const double *freq, int32_t precision, double *stat, double *statinv, double *eigenval, double *codefreq,
+                   double *eigeninv, double *eigeninvT);
 
 #ifdef __cplusplus
 }

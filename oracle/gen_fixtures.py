@@ -148,7 +148,19 @@ MLLEN_CASES = [
     ("ml_nt_200_cat", ["-nt"], 200, 120, 0.05, 0.02, 21),
     ("ml_nt_300_cat", ["-nt"], 300, 400, 0.08, 0.02, 33),
     ("ml_nt_150_double_cat", ["-nt", "-double-precision", "-cat", "8"], 150, 200, 0.08, 0.04, 34),
+    # `-gtr`: rates and base frequencies fitted after the first round (setMLGtr), then CAT
+    ("ml_nt_200_gtr", ["-nt", "-gtr"], 200, 120, 0.05, 0.02, 21),
+    ("ml_nt_150_double_gtr", ["-nt", "-gtr", "-double-precision"], 150, 200, 0.08, 0.04, 34),
 ]
+
+
+def parse_gtr(text):
+    """(rates[6], freq[4]) from the 'GTR rates' / 'GTR Frequencies' lines, or zeros."""
+    mr = re.search(r"^GTR rates\(ac ag at cg ct gt\)((?: \S+){6})", text, re.M)
+    mf = re.search(r"^GTR Frequencies:((?: \S+){4})", text, re.M)
+    if not mr:
+        return np.zeros(6), np.zeros(4)
+    return np.array([float(x) for x in mr.group(1).split()]), np.array([float(x) for x in mf.group(1).split()])
 
 
 def gen_mllen(tmp):
@@ -173,6 +185,7 @@ def gen_mllen(tmp):
         dst = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(dst, codes=codes, loglk=np.array(ll), newick=np.frombuffer(res.stdout, dtype=np.uint8),
                             newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
+                            gtr_rates=parse_gtr(text)[0], gtr_freq=parse_gtr(text)[1],
                             bad_splits=np.array([int(mb.group(1)), int(mb.group(2))], dtype=np.int64),
                             rates=np.array(rates), ratecat=np.array(cats, dtype=np.int32),
                             flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
@@ -227,6 +240,8 @@ MLNNI_CASES = [
     ("full_nt_200", ["-nt"], 200, 120, 0.05, 0.02, 21),
     ("full_nt_300", ["-nt"], 300, 200, 0.08, 0.03, 51),
     ("full_nt_250_double", ["-nt", "-double-precision"], 250, 150, 0.10, 0.04, 54),
+    ("full_nt_200_gtr", ["-nt", "-gtr"], 200, 120, 0.05, 0.02, 21),                 # BASELINE C2's model: GTR + CAT
+    ("full_nt_250_double_gtr", ["-nt", "-gtr", "-double-precision"], 250, 150, 0.10, 0.04, 54),
 ]
 
 
@@ -247,6 +262,7 @@ def gen_mlnni(tmp):
         res2 = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dst = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(dst, codes=codes, loglk=np.array(ll), n_me_nni=np.int64(m.group(1)), n_ml_nni=np.int64(m.group(3)),
+                            gtr_rates=parse_gtr(text)[0], gtr_freq=parse_gtr(text)[1],
                             newick=np.frombuffer(res.stdout, dtype=np.uint8),
                             newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
                             flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))

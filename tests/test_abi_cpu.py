@@ -36,7 +36,7 @@ def test_host_driver_library_exports_its_header(lib):
     host = backend.load_host_library()
     text = open(os.path.join(ROOT, "include", "vft_host.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth|ml)_[a-z0-9_]+)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth|ml|gtr)_[a-z0-9_]+)\s*\(", text)))
     assert names == sorted(backend.HOST_EXPORTS)
     assert all(hasattr(host, n) for n in names)
 
@@ -73,3 +73,19 @@ def test_host_knuth_generator_matches_the_reference_stream():
     out = np.zeros(len(ref), np.float64)
     lib.vft_knuth_stream(out.ctypes.data_as(C.c_void_p), C.c_int64(len(ref)))
     assert np.array_equal(out, ref)
+
+
+def test_gtr_tables_equal_the_references():
+    """createGTR + eigen-decomposition of the host driver against the tables the reference built for the same rates and
+    frequencies (white-box fixture gtr.tm.*, stored as numeric_t)."""
+    import golden_util as G
+    from veryfasttree_amd import backend
+    rates, freq = [1.2, 3.1, 0.7, 0.9, 3.6, 1.0], [0.31, 0.19, 0.23, 0.27]   # oracle/whitebox.cpp
+    for name in ("wb_nt_f32", "wb_nt_f64"):
+        d = G.load(name)
+        dt = d["gtr.tm.stat"].dtype
+        t = backend.gtr_tables(rates, freq, dt)
+        for key in ("stat", "statinv", "eigenval", "codefreq", "eigeninv", "eigeninvT"):
+            want = d["gtr.tm." + key]
+            got = t[key].astype(dt).reshape(want.shape)
+            assert np.array_equal(got, want), (name, key, got, want)

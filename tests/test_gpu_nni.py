@@ -73,3 +73,62 @@ def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me, spr):
     print(name, "supports differing:", int((ds > 0).sum()), "of", len(ds), "max", ds.max() if len(ds) else 0)
     assert ds.max() <= 0.002 + 1e-9
     assert boot == refb    # observed on MI355X: byte-identical, supports included
+
+
+@pytest.mark.parametrize("name,dt,full", [("ml_nt_200_gtr", np.float32, False), ("ml_nt_150_double_gtr", np.float64, False),
+                                          ("full_nt_200_gtr", np.float32, True), ("full_nt_250_double_gtr", np.float64, True)])
+def test_gtr_model_fitted_like_the_reference(name, dt, full):
+    """`-gtr`: Jukes-Cantor for the first ML round, then setMLGtr (NJ.tcc:6436-6500) fits base frequencies and the six
+    rates by line searches over the whole tree's likelihood and the run continues under GTR + CAT (BASELINE config C2's
+    model).  ml_*: `-nome -mllen`; full_*: the complete default pipeline.  Matrix-model likelihoods are float or double
+    dot products whose device exp differs from glibc in the last place: printed rates / frequencies, TreeLogLk within the
+    north star's 1e-4 relative, same topology; lengths to the search tolerance."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load(name)
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    make = lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n)
+    kw = dict(me_nni=True, spr=2, ml_nni=20) if full else dict(mllen=20)
+    tree, loglk, rates, freq = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, gtr=True, return_gtr=True, **kw)
+    print(name, "rates", np.round(rates, 4), "vs", d["gtr_rates"], "loglk", loglk, "vs", d["loglk"])
+    assert np.allclose(freq, d["gtr_freq"], rtol=0, atol=5.1e-5)      # printed with %.4f; frequencies are exact counts
+    assert np.allclose(rates, d["gtr_rates"], rtol=1e-2, atol=2e-4)   # the likelihood is flat in a rate at the 1e-3 level (ftol)
+    want = d["loglk"]
+    assert len(loglk) == len(want)
+    assert np.allclose(loglk, want, rtol=1e-4, atol=0)
+    ref = bytes(d["newick"]).decode().strip()
+    strip = lambda t: re.sub(r":[0-9.eE+-]+", ":", t)
+    if strip(tree) != strip(ref):
+        # float32 + matrix model + NNIs: an NNI whose two best quartets tie to float rounding can fall the other way.
+        # Seen on full_nt_200_gtr: a handful of splits, likelihood equal to 1e-6.  Double precision must not differ.
+        assert dt == np.float32 and full, "topology differs"
+        a, b = _splits(tree), _splits(ref)
+        print(name, "splits differing:", len(a ^ b) // 2, "of", len(b))
+        assert len(a ^ b) // 2 <= max(2, len(b) // 25)
+        return
+    got_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", tree)])
+    ref_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", ref)])
+    print(name, "printed lengths differing:", int((got_len != ref_len).sum()), "of", len(ref_len), "max abs", np.abs(got_len - ref_len).max())
+    assert np.allclose(got_len, ref_len, rtol=0.1, atol=3e-4 if dt == np.float32 else 1e-6)
+
+
+def _splits(newick):
+    """Non-trivial bipartitions of an unrooted Newick tree as frozensets of leaf names (the side without the first leaf)."""
+    names = re.findall(r"[(,]([^(),:;]+):", newick)
+    first, allset = names[0], frozenset(names)
+    stack, out = [], set()
+    for tok in re.findall(r"\(|\)|[^(),:;]+(?=:)|,", newick):
+        if tok == "(":
+            stack.append(set())
+        elif tok == ")":
+            top = stack.pop()
+            if stack:
+                stack[-1] |= top
+            side = frozenset(top) if first not in top else allset - frozenset(top)
+            if 1 < len(side) < len(allset) - 1:
+                out.add(side)
+        elif tok != ",":
+            if tok in allset and stack:
+                stack[-1].add(tok)
+    return out

@@ -3,7 +3,7 @@
 or - with -mllen - the tree of `VeryFastTree -nt -nome -mllen [-nocat | -cat N] [-nosupport]` (Jukes-Cantor).
 
     python tools/nj_tree.py in.fasta [-fastest] [-double] [-nosupport] [-nj-lengths] [-mllen [-nocat | -cat N]] > tree.nwk
-    python tools/nj_tree.py in.fasta -full [-double] [-nosupport] > tree.nwk     # what plain `VeryFastTree -nt` prints
+    python tools/nj_tree.py in.fasta -full [-gtr] [-double] [-nosupport] > tree.nwk     # what plain `VeryFastTree -nt [-gtr]` prints
 
 Neighbour joining with top hits on the device (veryfasttree_amd/host/NJDriver.h), the root, minimum-evolution branch
 lengths (updateBranchLengths), local-bootstrap supports (1000 resamples, reliabilityNJ) and printNJ; -nj-lengths keeps
@@ -47,7 +47,9 @@ def main():
     if "-mllen" in args:
         mllen = 1 if "-nocat" in args else (int(args[args.index("-cat") + 1]) if "-cat" in args else 20)
     n_boot = 0 if ("-nosupport" in args or nj_len) else 1000
-    extra = dict(me_nni=True, spr=2, ml_nni=20) if "-full" in args else {}   # ME NNIs + SPRs, ML NNIs, CAT, SH supports
+    extra = dict(me_nni=True, spr=2, ml_nni=20) if "-full" in args else {}
+    if "-gtr" in args:
+        extra["gtr"] = True   # ME NNIs + SPRs, ML NNIs, CAT, SH supports
     names, seqs = read_fasta(args[0])
     if len({len(s) for s in seqs}) != 1:
         sys.exit("sequences have different lengths: not an alignment")

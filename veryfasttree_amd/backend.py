@@ -42,14 +42,14 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_knuth_stream", "vft_ml_lengths"]
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables"]
 
 
 class _NJOptions(C.Structure):
     _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
                 ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
-                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("reserved2", I32)]
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32)]
 
 
 _lib = None
@@ -109,6 +109,19 @@ def ml_lengths(ops, n_seqs, parent, child, root, branchlength, rounds=1, recompu
         raise VftError(err.value.decode() or "vft_ml_lengths failed")
     return bl, loglk[:rounds], evals.value
 
+def gtr_tables(rates, freq, dtype=np.float32):
+    """createGTR of the host driver (veryfasttree_amd/host/GtrModel.h): dict of stat, statinv, eigenval, codefreq[5,4],
+    eigeninv[4,4], eigeninvT[4,4] in double."""
+    lib = load_host_library()
+    r, f = np.ascontiguousarray(rates, np.float64), np.ascontiguousarray(freq, np.float64)
+    out = dict(stat=np.zeros(4), statinv=np.zeros(4), eigenval=np.zeros(4), codefreq=np.zeros((5, 4)), eigeninv=np.zeros((4, 4)),
+               eigeninvT=np.zeros((4, 4)))
+    rc = lib.vft_gtr_tables(_ptr(r), _ptr(f), I32(np.dtype(dtype).itemsize), _ptr(out["stat"]), _ptr(out["statinv"]), _ptr(out["eigenval"]), _ptr(out["codefreq"]),
+                            _ptr(out["eigeninv"]), _ptr(out["eigeninvT"]))
+    if rc != 0:
+        raise VftError("vft_gtr_tables failed")
+    return out
+
 
 def uniquify(codes):
     """First-occurrence uniquify of alignment rows (Uniquify, Alignment.cpp:494-526).
@@ -128,7 +141,7 @@ def uniquify(codes):
 
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
-              unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0):
+              unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -145,7 +158,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     if second_level is None:
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
-                     200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 0)
+                     200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0)
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)
@@ -156,12 +169,15 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     rates = np.zeros(64, np.float64)
     n_rates = I32(0)
     ratecat = np.zeros(L, np.int32)
+    gtr_out = np.zeros(10, np.float64)
     rc = lib.vft_nj_ml_newick(ops.ctx, _ptr(codes), I64(n), I64(L), I32(np.dtype(dtype).itemsize), C.byref(opt),
                               I32(1 if me_lengths else 0), I32(n_bootstrap), _ptr(unique_first), _ptr(aln_next),
                               I64(len(codes_all)), blob, out, I64(cap), C.byref(olen), _ptr(loglk), I32(64),
-                              C.byref(n_rounds), _ptr(rates), I32(64), C.byref(n_rates), _ptr(ratecat), err, I32(512))
+                              C.byref(n_rounds), _ptr(rates), I32(64), C.byref(n_rates), _ptr(ratecat), _ptr(gtr_out), err, I32(512))
     if rc != 0:
         raise VftError(err.value.decode() or "vft_nj_ml_newick failed")
+    if return_gtr:
+        return out.value.decode(), loglk[:n_rounds.value], gtr_out[:6], gtr_out[6:]
     if return_rates:
         return out.value.decode(), loglk[:n_rounds.value], rates[:n_rates.value], ratecat
     if return_loglk:

@@ -597,11 +597,11 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
-    int rc[CPT];
+    int rc[CPT];   // rate category of the thread's columns; -1 beyond the alignment (such columns hold no data at all)
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
         const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
-        rc[c] = p < nPos ? A.ratecat[p] : 0;
+        rc[c] = p < nPos ? A.ratecat[p] : -1;
     }
     unsigned int nEval = 0;
     // P(t) tables of one branch length into slot s (callers synchronise); posteriorProfile clamps its lengths
@@ -614,6 +614,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
         }
     };
     auto post = [&](const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, int s1, int s2, int r, Col<REAL, NC> &o) {
+        if (r < 0) return;
         vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS[s1][r], pD[s1][r], pS[s2][r], pD[s2][r], ee[s1] + r * NC, ee[s2] + r * NC,
                                     o.w, o.code, o.f);
         o.vec = o.code == VFT_NOCODE_ && o.w > (REAL) 0;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/vft_hip.h"
+#include "GtrModel.h"
 
 namespace veryfasttree {
 
@@ -559,6 +560,151 @@ namespace veryfasttree {
 
         const std::vector<int64_t> &children() const { return child; }
         const std::vector<int64_t> &parents() const { return parent; }
+
+        /* ---------------------------------------------------------------------------------------------- GTR
+           setMLGtr (NJ.tcc:6436-6500): base frequencies from the leaves (with a pseudocount each), then two rounds
+           (-mlacc >= 2: that many) over the six exchange rates, each a line search on the whole tree's likelihood
+           (GTRNegLogLk, NJ.tcc:6407-6434: build the model, recomputeMLProfiles, treeLogLk), the rates normalised to
+           gt = 1, the model installed, the profiles rebuilt and all branch lengths re-optimised.  On the device an
+           evaluation is one vft_set_transition_matrix, one posterior batch per tree level and one pairLogLk batch. */
+        struct GtrFit {
+            double rates[6], freq[4];
+        };
+
+        GtrFit setMLGtr(const int64_t leafCodeCounts[4], int64_t nPos, int32_t mlAccuracy, double ftol, double atol) {
+            GtrFit g;
+            int64_t n[4], sum = 0;
+            for (int i = 0; i < 4; i++) {
+                n[i] = 1 + leafCodeCounts[i];
+                sum += n[i];
+            }
+            for (int i = 0; i < 4; i++) g.freq[i] = (double) n[i] / (double) sum;
+            for (int i = 0; i < 6; i++) g.rates[i] = 1.0;
+            const int64_t nRounds = mlAccuracy < 2 ? 2 : mlAccuracy;
+            for (int64_t r = 0; r < nRounds; r++)
+                for (int iRate = 0; iRate < 6; iRate++) {
+                    auto negLogLk = [&](double x) {
+                        double rates[6];
+                        for (int i = 0; i < 6; i++) rates[i] = g.rates[i];
+                        rates[iRate] = x;
+                        installGTR(rates, g.freq);
+                        recomputeMLProfiles();
+                        gtrEvaluations++;
+                        return -treeLogLk(nPos, -1);
+                    };
+                    g.rates[iRate] = hostMinimise(negLogLk, 0.05, g.rates[iRate], 20.0, 0.001, 0.0001);
+                }
+            for (int i = 0; i < 5; i++) g.rates[i] /= g.rates[5];
+            g.rates[5] = 1.0;
+            installGTR(g.rates, g.freq);
+            recomputeMLProfiles();
+            optimizeRound(ftol, atol);
+            return g;
+        }
+
+        void installGTR(const double rates[6], const double freq[4]) {
+            TransitionTables4 t;
+            createGTR<REAL>(rates, freq, t);
+            REAL stat[4], statinv[4], eval[4], cf[20], ei[16], eiT[16];
+            for (int i = 0; i < 4; i++) {
+                stat[i] = (REAL) t.stat[i];
+                statinv[i] = (REAL) t.statinv[i];
+                eval[i] = (REAL) t.eigenval[i];
+                for (int j = 0; j < 4; j++) {
+                    ei[4 * i + j] = (REAL) t.eigeninv[i][j];
+                    eiT[4 * i + j] = (REAL) t.eigeninvT[i][j];
+                }
+            }
+            for (int i = 0; i < 5; i++)
+                for (int j = 0; j < 4; j++) cf[4 * i + j] = (REAL) t.codeFreq[i][j];
+            chk(vft_set_transition_matrix(ctx, stat, statinv, eval, cf, ei, eiT));
+        }
+
+        int64_t gtrEvaluations = 0;
+
+        /* onedimenmin + brent (NJ.tcc:7025-7178) for host-side objectives (the GTR rates) */
+        template<typename F>
+        static double hostMinimise(F &&f, double xmin, double xguess, double xmax, double ftol, double atol) {
+            double lo, mid, hi;
+            if (xguess == xmin) {
+                lo = xmin;
+                mid = 2.0 * xguess;
+                hi = 10.0 * xguess;
+            } else if (xguess <= 2.0 * xmin) {
+                lo = xmin;
+                mid = xguess;
+                hi = 5.0 * xguess;
+            } else {
+                lo = 0.5 * xguess;
+                mid = xguess;
+                hi = 2.0 * xguess;
+            }
+            if (hi > xmax) hi = xmax;
+            if (mid >= hi) mid = 0.5 * (lo + hi);
+            double fLo = f(lo), fMid = f(mid), fHi = f(hi);
+            while (fLo < fMid && lo > xmin) {
+                lo = (lo + xmin) / 2.0;
+                if (lo < 2.0 * xmin) lo = xmin;
+                fLo = f(lo);
+            }
+            while (fHi < fMid && hi < xmax) {
+                hi = (hi + xmax) / 2.0;
+                if (hi > xmax * 0.95) hi = xmax;
+                fHi = f(hi);
+            }
+            const double golden = 0.3819660, zeps = 1.0e-10;
+            double a = std::min(lo, hi), b = std::max(lo, hi);
+            double x = mid, fx = fMid, w, fw, v, fv;
+            if (fLo < fHi) {
+                w = lo; fw = fLo; v = hi; fv = fHi;
+            } else {
+                w = hi; fw = fHi; v = lo; fv = fLo;
+            }
+            double step = 0.0, prevStep = 0.0;
+            for (int it = 0; it < 100; it++) {
+                const double xm = 0.5 * (a + b);
+                const double tol1 = ftol * std::fabs(x), tol2 = 2.0 * (tol1 + zeps);
+                if (std::fabs(x - xm) <= (tol2 - 0.5 * (b - a)) || std::fabs(a - b) < atol) break;
+                bool goldenStep = true;
+                if (std::fabs(prevStep) > tol1) {
+                    const double r = (x - w) * (fx - fv);
+                    double q = (x - v) * (fx - fw);
+                    double p = (x - v) * q - (x - w) * r;
+                    q = 2.0 * (q - r);
+                    if (q > 0.0) p = -p;
+                    q = std::fabs(q);
+                    const double before = prevStep;
+                    prevStep = step;
+                    if (!(std::fabs(p) >= std::fabs(0.5 * q * before) || p <= q * (a - x) || p >= q * (b - x))) {
+                        step = p / q;
+                        const double u = x + step;
+                        if (u - a < tol2 || b - u < tol2) step = (xm - x) >= 0.0 ? std::fabs(tol1) : -std::fabs(tol1);
+                        goldenStep = false;
+                    }
+                }
+                if (goldenStep) {
+                    prevStep = x >= xm ? a - x : b - x;
+                    step = golden * prevStep;
+                }
+                const double u = std::fabs(step) >= tol1 ? x + step : x + (step >= 0.0 ? std::fabs(tol1) : -std::fabs(tol1));
+                const double fu = f(u);
+                if (fu <= fx) {
+                    if (u >= x) a = x; else b = x;
+                    v = w; w = x; x = u;
+                    fv = fw; fw = fx; fx = fu;
+                } else {
+                    if (u < x) a = u; else b = u;
+                    if (fu <= fw || w == x) {
+                        v = w; w = u;
+                        fv = fw; fw = fu;
+                    } else if (fu <= fv || v == x || v == w) {
+                        v = u;
+                        fv = fu;
+                    }
+                }
+            }
+            return x;
+        }
 
         int64_t evaluations() {
             int64_t n = 0;

@@ -68,9 +68,14 @@ namespace veryfasttree {
             diameter.assign(maxnodes, 0);
             branchlength.assign(maxnodes, 0);
             selfweightLeaf.resize(nSeqs);
+            for (int k = 0; k < 4; k++) leafCodeCounts[k] = 0;
             for (int64_t i = 0; i < nSeqs; i++) {
                 int64_t c = 0;
-                for (int64_t p = 0; p < nPos; p++) c += codes[i * nPos + p] != VFT_NOCODE;
+                for (int64_t p = 0; p < nPos; p++) {
+                    const uint8_t code = codes[i * nPos + p];
+                    c += code != VFT_NOCODE;
+                    if (code < 4) leafCodeCounts[code]++;
+                }
                 selfweightLeaf[i] = (REAL) c;
             }
             /* NJ constructor, NJ.tcc:233-260 */
@@ -428,7 +433,7 @@ namespace veryfasttree {
            Call after updateBranchLengths; the context needs max_nodes >= 3 * nSeqs.  Returns the tree log-likelihood
            after each round (the reference's "TreeLogLk Length<k>" log lines). */
         std::vector<double> mlLengths(int32_t nRateCats = 1, int32_t nBootstrap = 0, bool mllen = true, bool mlNNI = false,
-                                      bool reaverage = false) {
+                                      bool reaverage = false, bool gtr = false) {
             if (root < 0) throw std::invalid_argument("NJDriver::mlLengths before finishRoot");
             const bool f32 = sizeof(REAL) == 4;
             const REAL one = 1;
@@ -440,7 +445,8 @@ namespace veryfasttree {
             treeArrays(par, ch);
             double nonGap = 0;
             for (int64_t i = 0; i < nSeqs; i++) nonGap += (double) selfweightLeaf[(size_t) i];
-            const int64_t nLeafGaps = nSeqs * nPos - (int64_t) nonGap;
+            int64_t nLeafGaps = nSeqs * nPos - (int64_t) nonGap;   /* -1 once a transition matrix is installed */
+            chkT("vft_set_transition_matrix", [&]() { return vft_set_transition_matrix(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); });
             MLLengths<REAL> ml(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             upReady = false;   /* the up-profile slots now hold ML up-profiles */
             ml.setLengths(branchlength.data());
@@ -461,6 +467,7 @@ namespace veryfasttree {
                 /* (the reference never updates its dLastLogLk, so the likelihood clause of its test cannot fire) */
                 const bool converged = iRound > 1 && dMaxChange < 0.001;
                 if (iRound == 1) {
+                    if (gtr) fitGtr(ml, nLeafGaps, ftol, atol);           /* `-gtr`: Jukes-Cantor up to here (VeryFastTreeImpl.tcc:299-302) */
                     ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);   /* VeryFastTreeImpl.tcc:299-305 */
                     ratesSet = nRateCats > 1;
                 }
@@ -493,6 +500,7 @@ namespace veryfasttree {
                     if (bConverged || iMLnni == MLnniToDo - 2) ml.initNNIStats(stats);
                     lastloglk = ll;
                     if (iMLnni == 0 && !ratesSet) {
+                        if (gtr && !gtrFitted) fitGtr(ml, nLeafGaps, ftol, atol);
                         ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);
                         ratesSet = nRateCats > 1;
                     }
@@ -524,7 +532,18 @@ namespace veryfasttree {
             return loglk;
         }
 
+        void fitGtr(MLLengths<REAL> &ml, int64_t &nLeafGaps, double ftol, double atol) {
+            const typename MLLengths<REAL>::GtrFit g = ml.setMLGtr(leafCodeCounts, nPos, /*mlAccuracy*/1, ftol, atol);
+            for (int i = 0; i < 6; i++) gtrRates[i] = g.rates[i];
+            for (int i = 0; i < 4; i++) gtrFreq[i] = g.freq[i];
+            gtrFitted = true;
+            nLeafGaps = -1;   /* treeLogLk's Jukes-Cantor correction is gone with the transition matrix */
+        }
+
         int64_t mlNNIs = 0;
+        int64_t leafCodeCounts[4];                /* occurrences of codes 0..3 in the unique sequences (setMLGtr) */
+        bool gtrFitted = false;
+        double gtrRates[6] = {1, 1, 1, 1, 1, 1}, gtrFreq[4] = {0.25, 0.25, 0.25, 0.25};   /* "GTR rates" / "GTR Frequencies" */
         int64_t mlEvaluations = 0, mlBadSplits = 0, mlSplits = 0;   /* "Bad splits: b/n" of the reference's summary line */
         double mlWorstDelta = 0;
         std::vector<REAL> mlRates;           /* what the reference logs as "Rates" ... */

@@ -11,6 +11,7 @@
 #include "NJDriver.h"
 #include "KnuthRng.h"
 #include "MLLengths.h"
+#include "GtrModel.h"
 
 static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
@@ -36,7 +37,7 @@ template<typename REAL>
 static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const vft_nj_options *o,
                            bool meLengths, int32_t nBootstrap, const int64_t *uniqueFirst, const int64_t *alnNext,
                            int64_t nAll, const char *names, std::vector<double> &loglk, std::vector<double> &rates,
-                           std::vector<int64_t> &ratecat) {
+                           std::vector<int64_t> &ratecat, double *gtrOut) {
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
     drv.run(-1);
     drv.finishRoot();
@@ -48,7 +49,11 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
         if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: the ML stage needs me_lengths (updateBranchLengths runs first)");
         /* with supports: SH-like (testSplitsML) instead of the local bootstrap */
         const int32_t nCat = o->mllen ? o->mllen : (o->ml_nni > 1 ? o->ml_nni : 1);
-        loglk = drv.mlLengths(nCat, nBootstrap, o->mllen != 0, o->ml_nni != 0, o->me_nni != 0);
+        loglk = drv.mlLengths(nCat, nBootstrap, o->mllen != 0, o->ml_nni != 0, o->me_nni != 0, o->gtr != 0);
+        if (gtrOut) {
+            for (int i = 0; i < 6; i++) gtrOut[i] = drv.gtrRates[i];
+            for (int i = 0; i < 4; i++) gtrOut[6 + i] = drv.gtrFreq[i];
+        }
         rates.assign(drv.mlRates.begin(), drv.mlRates.end());
         ratecat = drv.mlRateCat;
     }
@@ -66,13 +71,13 @@ extern "C" int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeq
                                 const vft_nj_options *opt, int32_t meLengths, int32_t nBootstrap, const int64_t *uniqueFirst,
                                 const int64_t *alnNext, int64_t nAll, const char *names, char *out, int64_t outCap,
                                 int64_t *outLen, double *loglk, int32_t loglkCap, int32_t *nRounds, double *ratesOut,
-                                int32_t ratesCap, int32_t *nRates, int32_t *ratecatOut, char *err, int32_t errLen) {
+                                int32_t ratesCap, int32_t *nRates, int32_t *ratecatOut, double *gtrOut, char *err, int32_t errLen) {
     if (!ctx || !codes || !uniqueFirst || !alnNext || !names || !outLen) return VFT_ERR_INVALID;
     try {
         std::vector<double> ll, rates;
         std::vector<int64_t> ratecat;
-        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll, rates, ratecat)
-                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll, rates, ratecat);
+        const std::string t = precision == 8 ? runTree<double>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll, rates, ratecat, gtrOut)
+                                             : runTree<float>(ctx, codes, nSeqs, nPos, opt, meLengths != 0, nBootstrap, uniqueFirst, alnNext, nAll, names, ll, rates, ratecat, gtrOut);
         if (nRates) *nRates = (int32_t) rates.size();
         if (ratesOut)
             for (size_t k = 0; k < rates.size() && (int32_t) k < ratesCap; k++) ratesOut[k] = rates[k];
@@ -100,7 +105,7 @@ extern "C" int vft_nj_newick(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, 
         o.mllen = 0;
     }
     return vft_nj_ml_newick(ctx, codes, nSeqs, nPos, precision, opt ? &o : nullptr, meLengths, nBootstrap, uniqueFirst, alnNext,
-                            nAll, names, out, outCap, outLen, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, err, errLen);
+                            nAll, names, out, outCap, outLen, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, err, errLen);
 }
 
 extern "C" void vft_knuth_stream(double *out, int64_t n) {
@@ -164,5 +169,29 @@ extern "C" int vft_ml_lengths(vft_ctx *ctx, int64_t nSeqs, int64_t nNodes, int64
     } catch (const std::exception &e) {
         if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
         return VFT_ERR_STATE;
+    }
+}
+
+extern "C" int vft_gtr_tables(const double *rates, const double *freq, int32_t precision, double *stat, double *statinv, double *eigenval,
+                              double *codefreq, double *eigeninv, double *eigeninvT) {
+    if (!rates || !freq || !stat || !statinv || !eigenval || !codefreq || !eigeninv || !eigeninvT) return VFT_ERR_INVALID;
+    try {
+        veryfasttree::TransitionTables4 t;
+        if (precision == 8) veryfasttree::createGTR<double>(rates, freq, t);
+        else veryfasttree::createGTR<float>(rates, freq, t);
+        for (int i = 0; i < 4; i++) {
+            stat[i] = t.stat[i];
+            statinv[i] = t.statinv[i];
+            eigenval[i] = t.eigenval[i];
+            for (int j = 0; j < 4; j++) {
+                eigeninv[4 * i + j] = t.eigeninv[i][j];
+                eigeninvT[4 * i + j] = t.eigeninvT[i][j];
+            }
+        }
+        for (int i = 0; i < 5; i++)
+            for (int j = 0; j < 4; j++) codefreq[4 * i + j] = t.codeFreq[i][j];
+        return VFT_OK;
+    } catch (const std::exception &) {
+        return VFT_ERR_INVALID;
     }
 }
