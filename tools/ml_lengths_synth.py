@@ -22,7 +22,7 @@ t0 = time.perf_counter()
 nj_newick(make, codes, names, me_lengths=True)
 t_nj = time.perf_counter() - t0
 t0 = time.perf_counter()
-tree, loglk = nj_newick(make, codes, names, me_lengths=True, return_loglk=True, **(dict(me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000) if full else dict(mllen=ncat, n_bootstrap=nboot)))
+tree, loglk = nj_newick(make, codes, names, me_lengths=True, return_loglk=True, **(dict(me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, gtr=bool(os.environ.get('VFT_GTR'))) if full else dict(mllen=ncat, n_bootstrap=nboot)))
 t_ml = time.perf_counter() - t0
 print("NJ + ME lengths                 %8.2f s" % t_nj)
 print("NJ + ME lengths + ML lengths (%d rate categories, %d resamples)   %8.2f s   -> ML stage %.2f s, %d rounds (%.2f s per round incl. treeLogLk)"
