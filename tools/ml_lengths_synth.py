@@ -17,12 +17,13 @@ nboot = int(os.environ.get("VFT_ML_BOOT", "0"))   # 1000 = the reference's defau
 ncat = int(os.environ.get("VFT_ML_CAT", "1"))   # 1 = -nocat, 20 = the reference's default CAT approximation
 codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
 names = ["s%d" % k for k in range(n)]
-make = lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m)
+DT = np.float64 if os.environ.get('VFT_DOUBLE') else np.float32
+make = lambda m, Lp: HipProfileOps(m, Lp, 4, DT, max_nodes=3 * m)
 t0 = time.perf_counter()
-nj_newick(make, codes, names, me_lengths=True)
+nj_newick(make, codes, names, me_lengths=True, dtype=DT)
 t_nj = time.perf_counter() - t0
 t0 = time.perf_counter()
-tree, loglk = nj_newick(make, codes, names, me_lengths=True, return_loglk=True, **(dict(me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, gtr=bool(os.environ.get('VFT_GTR'))) if full else dict(mllen=ncat, n_bootstrap=nboot)))
+tree, loglk = nj_newick(make, codes, names, me_lengths=True, return_loglk=True, dtype=DT, **(dict(me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, gtr=bool(os.environ.get('VFT_GTR'))) if full else dict(mllen=ncat, n_bootstrap=nboot)))
 t_ml = time.perf_counter() - t0
 print("NJ + ME lengths                 %8.2f s" % t_nj)
 print("NJ + ME lengths + ML lengths (%d rate categories, %d resamples)   %8.2f s   -> ML stage %.2f s, %d rounds (%.2f s per round incl. treeLogLk)"
