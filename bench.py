@@ -223,6 +223,14 @@ def main():
     h = last[0]
     hv = h[h["j"] >= 0]
     assert np.all(np.diff(hv["criterion"]) >= 0) and len(np.unique(hv["j"])) == len(hv)
+    # a checksum of the last step's lists (every seed: ids and criteria), so that runs with different rank counts can
+    # be compared: the sharded + merged lists must be the unsharded ones
+    import zlib
+    crc = 0
+    for hits in last:
+        crc = zlib.crc32(np.ascontiguousarray(hits["j"]).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(hits["criterion"]).tobytes(), crc)
+    line["hits_crc"] = crc
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

@@ -100,3 +100,27 @@ def test_join_then_sweep_round_trip_at_c3_size():
     assert a not in h1["j"] and b not in h1["j"] and new in h1["j"]
     assert np.all(np.diff(h1["criterion"]) >= 0)
     ops.close()
+
+
+def test_bench_two_ranks_on_one_device_agree_with_one_rank():
+    """bench.py's multi-rank flow (target-range shards, one batched all-gather per step, device merge) with two ranks
+    sharing the one GPU of the test box over gloo (VFT_BENCH_SAME_DEVICE / VFT_BENCH_BACKEND hooks): it must run, and
+    report the same number of profile-ops per step as the single-rank run of the same reduced workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VFT_BENCH_SAME_DEVICE="1", VFT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--steps", "2", "--warmup", "1", "--n-seqs", "200000", "--n-pos", "200", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, check=True, stdout=subprocess.PIPE,
+                         timeout=600).stdout.decode()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2"] + args,
+                         check=True, stdout=subprocess.PIPE, env=env, timeout=600).stdout.decode()
+    a = json.loads([l for l in one.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    assert a["config"]["active_nodes"] == b["config"]["active_nodes"] and a["config"]["top_k"] == b["config"]["top_k"]
+    assert b["value"] > 0
+    assert a["hits_crc"] == b["hits_crc"]   # the merged lists of the two shards are the single-rank lists
