@@ -1776,12 +1776,12 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
 template <typename REAL, int NC>
 static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
                              double closeLimit, int mlAccuracy, int mode, double *dLoglk, double *dSite, double *dLen,
-                             QuartetNNIResult *dNni) {
+                             QuartetNNIResult *dNni, QuartetNNIState *dState = nullptr) {
 #define VFT_MLQ_CASE(CPT)                                                                                               \
     case CPT:                                                                                                           \
-        launch((k_ml_quartet<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c), dIds, \
-               dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, dLoglk, dSite, dLen, \
-               dNni, c->mlEvals);                                                                                        \
+        launch((k_ml_quartet<REAL, NC, CPT>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(VFT_MLOPT_WG), 0, c->stream,  \
+               arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, \
+               dLoglk, dSite, dLen, dNni, dState, c->mlEvals);                                                           \
         break;
     switch (cpt == 2 ? 4 : cpt) {   // two columns per thread run the four-column kernel (fewer instantiations to build)
         VFT_MLQ_CASE(1)
@@ -1819,17 +1819,32 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
     const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
     const size_t idB = (size_t) n * 8, resB = (size_t) n * sizeof(QuartetNNIResult);
     static_assert(sizeof(QuartetNNIResult) == sizeof(vft_quartet_nni), "result record layout");
-    if (9 * idB + resB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_quartet_nni: too many quartets per call");
+    const size_t stB = ((size_t) n * sizeof(QuartetNNIState) + 255) & ~(size_t) 255;
+    if (9 * idB + resB + stB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_quartet_nni: too many quartets per call");
+    const size_t off = (9 * idB + 255) & ~(size_t) 255;
     char *h, *s;
-    if (int r = io_alloc(c, ((9 * idB + 255) & ~(size_t) 255) + resB, &h, &s)) return r;
+    if (int r = io_alloc(c, off + ((resB + 255) & ~(size_t) 255), &h, &s)) return r;
     memcpy(h, ids, 4 * idB);
     memcpy(h + 4 * idB, lenIdx, 5 * idB);
-    const size_t off = (9 * idB + 255) & ~(size_t) 255;
-    int r = VFT_OK;
-    VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, (const int64_t *) s, (const int64_t *) (s + 4 * idB), ftol, atol,
-                                                     closeLimit, mlAccuracy, 1, nullptr, nullptr, nullptr,
-                                                     (QuartetNNIResult *) (s + off))));
-    if (r) return r;
+    if (int r = ensure_scratch(c, stB + 512)) return r;
+    QuartetNNIState *dState = (QuartetNNIState *) c->scratch;
+    const int64_t *dIds = (const int64_t *) s, *dLi = (const int64_t *) (s + 4 * idB);
+    // init -> {round (a workgroup per pairing) -> decide} x rounds -> verdict, all queued; one wait at the end
+    const int nRounds = mlAccuracy < 2 ? 2 : mlAccuracy;
+    const dim3 g1(cdiv(n, 64)), b1(64);
+    if (c->cfg.precision == 4) launch((k_ml_nni_init<float>), g1, b1, 0, c->stream, dLi, (const float *) c->blen, dState, n);
+    else launch((k_ml_nni_init<double>), g1, b1, 0, c->stream, dLi, (const double *) c->blen, dState, n);
+    for (int round = 0; round < nRounds; round++) {
+        int r = VFT_OK;
+        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, dIds, dLi, ftol, atol, closeLimit, mlAccuracy, 2, nullptr, nullptr,
+                                                         nullptr, nullptr, dState)));
+        if (r) return r;
+        launch(k_ml_nni_decide, g1, b1, 0, c->stream, dState, n, c->minLen, closeLimit, (int) mlAccuracy, round == nRounds - 1 ? 1 : 0);
+    }
+    if (c->cfg.precision == 4)
+        launch((k_ml_nni_verdict<float>), g1, b1, 0, c->stream, (const QuartetNNIState *) dState, dLi, (float *) c->blen, (QuartetNNIResult *) (s + off), n);
+    else
+        launch((k_ml_nni_verdict<double>), g1, b1, 0, c->stream, (const QuartetNNIState *) dState, dLi, (double *) c->blen, (QuartetNNIResult *) (s + off), n);
     LAUNCHCHK(c);
     if (int w = wait_stream(c)) return w;
     memcpy(results, h + off, resB);

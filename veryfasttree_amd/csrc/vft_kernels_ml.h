@@ -585,12 +585,22 @@ struct QuartetNNIResult {
     int32_t choice, star;
 };
 
+// MLQuartetNNI spread over the chip (mode 2): the three pairings of a round do not depend on each other, so a round is
+// ONE launch with a workgroup per pairing; this record carries the quartet between the launches of
+// init -> round -> decide -> round -> verdict.  The star test belongs to AB|CD; when it fires the other two workgroups'
+// results are simply not used - what the one-thread reference would not have computed at all.
+struct QuartetNNIState {
+    double len[3][5];
+    double crit[3];
+    int32_t consider1, consider2, done, star;
+};
+
 template <typename REAL, int NC, int CPT>
 __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
                                                              double minLen, double minRel, double ftol, double atol,
                                                              double closeLimit, int mlAccuracy, int mode, double *loglkOut,
                                                              double *siteOut, double *lenOut, QuartetNNIResult *nniOut,
-                                                             unsigned int *evalCount) {
+                                                             QuartetNNIState *nniState, unsigned int *evalCount) {
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
@@ -708,9 +718,19 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     const int nRounds = mlAccuracy < 2 ? 2 : mlAccuracy;
     int phase = 0, round = 0;
     bool consider1 = true, consider2 = true, star = false;
+    if (mode == 2) {   // one pairing of one round: blockIdx.y
+        const QuartetNNIState &st = nniState[k];
+        const int t = (int) blockIdx.y;
+        if (st.done || (t == 1 && !st.consider1) || (t == 2 && !st.consider2)) return;
+#pragma unroll
+        for (int j = 0; j < 5; j++) len[t][j] = st.len[t][j];
+    }
     for (int guard = 0; guard < 64; guard++) {
         int t;
-        if (mode == 0) {
+        if (mode == 2) {
+            if (guard > 0) break;
+            t = (int) blockIdx.y;
+        } else if (mode == 0) {
             if (guard == 0) t = 1;
             else if (guard == 1) t = 2;
             else if (guard == 2) {
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
             auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr); };
             const int slot = step == 0 ? 4 : step - 1;
             L[slot] = vft_min_branch_length(negLogLk, minLen, L[slot], VFT_MLOPT_MAXLEN, ftol, atol, negll);
-            if (step == 0 && mode == 1 && t == 0) {
+            if (step == 0 && mode != 0 && t == 0) {
                 // star topology test (NJ.tcc:1691-1700): is the internal branch worth more than closeLogLkLimit?
                 const double loglkStar = -negLogLk(minLen);
                 if (loglkStar < -negll - closeLimit) {
@@ -827,6 +847,14 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     }
     if (threadIdx.x != 0) return;
     if (evalCount) atomicAdd(evalCount, nEval);
+    if (mode == 2) {
+        QuartetNNIState &st = nniState[k];
+        const int t = (int) blockIdx.y;
+        st.crit[t] = crit[t];
+        for (int j = 0; j < 5; j++) st.len[t][j] = len[t][j];
+        if (t == 0) st.star = star ? 1 : 0;
+        return;
+    }
     if (mode == 0) {
         for (int t = 0; t < 3; t++) loglkOut[3 * k + t] = crit[t];
         if (lenOut)
@@ -858,6 +886,77 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     r.choice = choice;
     r.star = star ? 1 : 0;
     nniOut[k] = r;
+}
+
+// MLQuartetNNI's bookkeeping around the parallel rounds (mode 2 of k_ml_quartet), one thread per quartet
+template <typename REAL>
+__global__ void k_ml_nni_init(const int64_t *lenIdx, const REAL *blen, QuartetNNIState *state, int64_t n) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double b[5];
+    for (int t = 0; t < 5; t++) b[t] = (double) blen[lenIdx[5 * k + t]];
+    QuartetNNIState &st = state[k];
+    const double l[3][5] = {{b[0], b[1], b[2], b[3], b[4]}, {b[0], b[2], b[1], b[3], b[4]}, {b[0], b[3], b[2], b[1], b[4]}};
+    for (int t = 0; t < 3; t++) {
+        st.crit[t] = 0;
+        for (int j = 0; j < 5; j++) st.len[t][j] = l[t][j];
+    }
+    st.consider1 = st.consider2 = 1;
+    st.done = st.star = 0;
+}
+
+// end of a round (NJ.tcc:4910-4916, :4961-4983)
+__global__ void k_ml_nni_decide(QuartetNNIState *state, int64_t n, double minLen, double closeLimit, int mlAccuracy, int lastRound) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    QuartetNNIState &st = state[k];
+    if (st.done) return;
+    if (st.star) {
+        st.crit[1] = st.crit[2] = -1e20;
+        st.done = 1;
+        return;
+    }
+    const double *c = st.crit;
+    if (mlAccuracy < 2) {
+        if (c[1] < c[0] - closeLimit || (st.len[1][4] <= 2.0 * minLen && c[1] < c[0])) st.consider1 = 0;
+        if (c[2] < c[0] - closeLimit || (st.len[2][4] <= 2.0 * minLen && c[2] < c[0])) st.consider2 = 0;
+        if (!st.consider1 && !st.consider2) st.done = 1;
+        else if (c[1] > c[0] + closeLimit && c[1] > c[2] + closeLimit) st.done = 1;
+        else if (c[2] > c[0] + closeLimit && c[2] > c[1] + closeLimit) st.done = 1;
+    }
+    if (lastRound) st.done = 1;
+}
+
+// the verdict (NJ.tcc:4989-5003) and DoNNI's branch-length update (NJ.tcc:5889-5915)
+template <typename REAL>
+__global__ void k_ml_nni_verdict(const QuartetNNIState *state, const int64_t *lenIdx, REAL *blen, QuartetNNIResult *out, int64_t n) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const QuartetNNIState &st = state[k];
+    const double *c = st.crit;
+    int choice = 0;
+    if (!st.star) {
+        if (c[1] > c[0] && c[1] > c[2]) choice = 1;
+        else if (c[2] > c[0] && c[2] > c[1]) choice = 2;
+    }
+    const int64_t *li = lenIdx + 5 * k;
+    if (st.star) {
+        blen[li[4]] = (REAL) st.len[0][4];
+    } else {
+        const double *L = st.len[choice];
+        blen[li[0]] = (REAL) L[0];
+        blen[li[1]] = (REAL) (choice == 0 ? L[1] : choice == 1 ? L[2] : L[3]);
+        blen[li[2]] = (REAL) (choice == 0 ? L[2] : choice == 1 ? L[1] : L[2]);
+        blen[li[3]] = (REAL) (choice == 0 ? L[3] : choice == 1 ? L[3] : L[1]);
+        blen[li[4]] = (REAL) L[4];
+    }
+    QuartetNNIResult r;
+    r.criteria[0] = c[0];
+    r.criteria[1] = c[1];
+    r.criteria[2] = c[2];
+    r.choice = choice;
+    r.star = st.star;
+    out[k] = r;
 }
 
 // SHSupport (NJ.tcc:1126-1165): the share of column resamples in which the gap between the best and the second best
