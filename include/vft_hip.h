@@ -190,6 +190,11 @@ int vft_posterior_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const in
    this mode. */
 int vft_set_profile_rows(vft_ctx *ctx, int32_t on);
 
+/* n unweighted averageProfile calls executed in order in ONE launch, where a later one may read an earlier one's output
+   (recomputeProfile of a node, then of its parent; up-profiles down a path; NJ.tcc:3382-3473).  Needs
+   vft_set_profile_rows(ctx, 1); n <= 256.  Stream-ordered. */
+int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b);
+
 /* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */
 int vft_branch_lengths_set(vft_ctx *ctx, int64_t first, int64_t count, const void *values);

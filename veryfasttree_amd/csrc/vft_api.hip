@@ -1015,6 +1015,40 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
     return VFT_OK;
 }
 
+// n unweighted averages in order, later ones may read earlier results (k_average_chain); profile-rows mode only.
+extern "C" int vft_average_chain(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b) {
+    if (!c || n < 0 || !out || !a || !b) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (!c->rowMode) return fail(c, VFT_ERR_STATE, "vft_average_chain needs vft_set_profile_rows(ctx, 1)");
+    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_average_chain: at most 256 averages per call");
+    for (int32_t k = 0; k < n; k++) {
+        if (int r = internal_ok(c, out[k])) return r;
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad child id");
+    }
+    if (int r = ensure_ml_rows(c)) return r;
+    const size_t idB = (size_t) n * 8;
+    char *h, *s;
+    if (int r = io_alloc(c, 3 * idB + (size_t) n, &h, &s)) return r;
+    memcpy(h, out, idB);
+    memcpy(h + idB, a, idB);
+    memcpy(h + 2 * idB, b, idB);
+    uint8_t *direct = (uint8_t *) (h + 3 * idB);
+    for (int32_t k = 0; k < n; k++) {
+        uint8_t d = 0;
+        for (int32_t j = 0; j < k; j++) {
+            if (out[j] == a[k]) d |= 1;
+            if (out[j] == b[k]) d |= 2;
+        }
+        direct[k] = d;
+    }
+    VFT_DISPATCH(c, launch((k_average_chain<REAL, NC>), dim3(cdiv(c->d.nPos, 128)), dim3(128), 0, c->stream, arena<REAL>(c),
+                           (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
+                           (const uint8_t *) (s + 3 * idB), n, c->fpostTol));
+    launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
 // After the NJ phase nothing sweeps the internal profiles any more: vft_average_profiles then writes plain rows (the
 // layout of the ML phase, vft_layout.h) instead of re-packing a tile per node, and skips the self distances only the
 // out-distances of the NJ phase need.  Pair distances, split supports and the ML kernels read either layout.

@@ -95,19 +95,25 @@ __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node,
     }
 }
 
+// one column of a node's dense row (vft_layout.h)
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_load_row(const Arena<REAL> &A, int64_t node, int64_t p, Col<REAL, NC> &c) {
+    const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
+    c.w = A.mlW[idx];
+    c.code = (int) A.mlC[idx];
+    c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+    if (c.vec) {
+        const REAL *src = A.mlF + idx * NC;
+#pragma unroll
+        for (int k = 0; k < NC; k++) c.f[k] = src[k];
+    }
+}
+
 // ML-phase read: dense row if the node has one, the tile streams otherwise (leaves, NJ-phase averages)
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_load_col_ml(const Arena<REAL> &A, int64_t node, int64_t p, Col<REAL, NC> &c) {
     if (node >= A.d.nSeqs && A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs]) {
-        const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
-        c.w = A.mlW[idx];
-        c.code = (int) A.mlC[idx];
-        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
-        if (c.vec) {
-            const REAL *src = A.mlF + idx * NC;
-#pragma unroll
-            for (int k = 0; k < NC; k++) c.f[k] = src[k];
-        }
+        vft_load_row<REAL, NC>(A, node, p, c);
         return;
     }
     vft_load_col<REAL, NC>(A, node, p, c);

@@ -258,21 +258,12 @@ __device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *f
     }
 }
 
-// averageProfile (NJ.tcc:2067-2135): grid.y = join index, threads over columns
+// averageProfile (NJ.tcc:2067-2135) of one column
 template <typename REAL, int NC>
-__global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN,
-                          const double *bionj, double tol, REAL *stash /* null: write the node's dense row */) {
-    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.d.nPos) return;
-    const int64_t k = blockIdx.y;
-    double bw = bionj ? bionj[k] : -1.0;
-    if (bw < 0) bw = 0.5;
-    Col<REAL, NC> c1, c2;
-    vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
-    vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
-    const REAL wo = (REAL) (bw * (double) c1.w + (1 - bw) * (double) c2.w);
-    int co = VFT_NOCODE_;
-    REAL f[NC];
+__device__ __forceinline__ void vft_average_col(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double bw,
+                                                double tol, REAL &wo, int &co, REAL *f) {
+    wo = (REAL) (bw * (double) c1.w + (1 - bw) * (double) c2.w);
+    co = VFT_NOCODE_;
 #pragma unroll
     for (int q = 0; q < NC; q++) f[q] = 0;
     if (wo > 0) {
@@ -284,12 +275,60 @@ __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
             vft_normalize_freq<REAL, NC>(A, f, tol);
         }
     }
+}
+
+// averageProfile: grid.y = join index, threads over columns
+template <typename REAL, int NC>
+__global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN,
+                          const double *bionj, double tol, REAL *stash /* null: write the node's dense row */) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    const int64_t k = blockIdx.y;
+    double bw = bionj ? bionj[k] : -1.0;
+    if (bw < 0) bw = 0.5;
+    Col<REAL, NC> c1, c2;
+    vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
+    vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
+    REAL wo, f[NC];
+    int co;
+    vft_average_col<REAL, NC>(A, c1, c2, bw, tol, wo, co, f);
     if (stash) {
         vft_stash_col<REAL, NC>(A, outN[k], p, wo, co, f, stash + (k * A.d.nPos + p) * (NC + 1));
     } else {
         vft_store_col_ml<REAL, NC>(A, outN[k], p, wo, co, f);
         if (p == 0) A.mlIs[outN[k] - A.d.nSeqs] = 1;
     }
+}
+
+// A CHAIN of n unweighted averages where later ones may read earlier results (recomputeProfile of a node and then of
+// its parent, up-profiles down a path): a column of an average depends on that column of its inputs only, so one thread
+// takes its column through the whole chain - one launch instead of n dependent ones.  Rows only (the refinement phase).
+// direct[k] bit 0 / 1: input a / b of op k is the output of an earlier op of this chain (its row flag may not be
+// visible to other workgroups yet, so it is read as a row unconditionally).
+template <typename REAL, int NC>
+__global__ void k_average_chain(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN, const uint8_t *direct,
+                                int32_t n, double tol) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    for (int32_t k = 0; k < n; k++) {
+        Col<REAL, NC> c1, c2;
+        const uint8_t d = direct[k];
+        if (d & 1) vft_load_row<REAL, NC>(A, aN[k], p, c1);
+        else vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
+        if (d & 2) vft_load_row<REAL, NC>(A, bN[k], p, c2);
+        else vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
+        REAL wo, f[NC];
+        int co;
+        vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
+        vft_store_col_ml<REAL, NC>(A, outN[k], p, wo, co, f);
+    }
+    // (the row flags are raised by k_mark_rows afterwards: raising them here would race with workgroups that are still
+    //  on an earlier op and read the same node through its flag)
+}
+
+__global__ void k_mark_rows(uint8_t *mlIs, const int64_t *nodes, int32_t n, int64_t nSeqs) {
+    const int32_t k = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < n) mlIs[nodes[k] - nSeqs] = 1;
 }
 
 // setCodeDist for one column of the out-profile (NJ.tcc:873-898)

@@ -473,6 +473,7 @@ namespace veryfasttree {
                     updateForNNI(node, prm.useML, upHave);
                 }
             }
+            flushAverages();
             rebuildOrder();
             return nNNIThisRound;
         }
@@ -552,6 +553,7 @@ namespace veryfasttree {
                     for (int64_t anc = parent[(size_t) node]; anc >= 0; anc = parent[(size_t) anc]) recomputeProfile(anc, false);
                 }
             }
+            flushAverages();
             rebuildOrder();
             return nSPR;
         }
@@ -796,6 +798,7 @@ namespace veryfasttree {
             }
             const int64_t pi[6] = {q[0], q[0], q[0], q[1], q[1], q[2]}, pj[6] = {q[1], q[2], idD, q[2], idD, idD};
             REAL d[6], w[6];
+            flushAverages();
             chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
             double c[6];
             for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[i], scoredist);
@@ -843,7 +846,7 @@ namespace veryfasttree {
                 quartetCD(x, cd, lcd);
                 const int64_t out = x + nSeqs;
                 if (useML) chk(vft_posterior_profiles_blen(ctx, 1, &out, &cd[0], &cd[1], &lcd[0], &lcd[1]));
-                else chk(vft_average_profiles(ctx, 1, &out, &cd[0], &cd[1], nullptr));
+                else queueAverage(out, cd[0], cd[1]);
                 upHave[(size_t) x] = 1;
             }
         }
@@ -853,8 +856,27 @@ namespace veryfasttree {
             if (node < nSeqs || node == root) return;
             const int64_t a = child[3 * node], b = child[3 * node + 1];
             if (useML) chk(vft_posterior_profiles_blen(ctx, 1, &node, &a, &b, &a, &b));
-            else chk(vft_average_profiles(ctx, 1, &node, &a, &b, nullptr));
+            else queueAverage(node, a, b);
         }
+
+        /* Minimum-evolution averages are queued and go down as one chain launch (vft_average_chain) right before
+           something reads profiles: a step of an NNI / SPR walk is then two launches (chain, distances) and one wait */
+        void queueAverage(int64_t out, int64_t a, int64_t b) {
+            qOut.push_back(out);
+            qA.push_back(a);
+            qB.push_back(b);
+            if (qOut.size() >= 128) flushAverages();
+        }
+
+        void flushAverages() {
+            if (qOut.empty()) return;
+            chk(vft_average_chain(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data()));
+            qOut.clear();
+            qA.clear();
+            qB.clear();
+        }
+
+        std::vector<int64_t> qOut, qA, qB;
 
         void rebuildOrder() {
             order.clear();
