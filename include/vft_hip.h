@@ -204,6 +204,9 @@ int vft_branch_lengths_get(vft_ctx *ctx, int64_t first, int64_t count, void *val
    getUpProfile(useML = true) (NJ.tcc:3382-3434) queue behind the optimiser launches that produce their lengths. */
 int vft_posterior_profiles_blen(vft_ctx *ctx, int64_t n, const int64_t *out, const int64_t *a, const int64_t *b,
                                 const int64_t *len_idx_a, const int64_t *len_idx_b);
+/* n vft_posterior_profiles_blen calls executed in order in ONE launch, later ones may read earlier outputs (n <= 256). */
+int vft_posterior_chain_blen(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                             const int64_t *len_idx_a, const int64_t *len_idx_b);
 /* The body of traverseOptimizeAllBranchLengths' loop (NJ.tcc:5025-5064) for n independent splits, one workgroup each:
    ids[3k..3k+2] = the three profiles around split k (children 0 and 1 + the up-profile, or the root's three children),
    len_idx[3k..3k+2] = the branchlength[] slots they own.  Two passes over the three branches; branch i gets

@@ -1743,6 +1743,47 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
     return VFT_OK;
 }
 
+// n posteriorProfile calls in order in one launch (k_posterior_chain), lengths from the device's branchlength[]
+extern "C" int vft_posterior_chain_blen(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                                        const int64_t *lenIdxA, const int64_t *lenIdxB) {
+    if (!c || n < 0 || !out || !a || !b || !lenIdxA || !lenIdxB) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_posterior_chain_blen: at most 256 posteriors per call");
+    if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
+    for (int32_t k = 0; k < n; k++) {
+        if (int r = internal_ok(c, out[k])) return r;
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes || lenIdxA[k] < 0 || lenIdxA[k] >= c->d.maxNodes ||
+            lenIdxB[k] < 0 || lenIdxB[k] >= c->d.maxNodes)
+            return fail(c, VFT_ERR_INVALID, "vft_posterior_chain_blen: index out of range");
+    }
+    if (int r = ensure_blen(c)) return r;
+    if (int r = ensure_ml_rows(c)) return r;
+    const size_t idB = (size_t) n * 8;
+    char *h, *s;
+    if (int r = io_alloc(c, 5 * idB + (size_t) n, &h, &s)) return r;
+    memcpy(h, out, idB);
+    memcpy(h + idB, a, idB);
+    memcpy(h + 2 * idB, b, idB);
+    memcpy(h + 3 * idB, lenIdxA, idB);
+    memcpy(h + 4 * idB, lenIdxB, idB);
+    uint8_t *direct = (uint8_t *) (h + 5 * idB);
+    for (int32_t k = 0; k < n; k++) {
+        uint8_t d = 0;
+        for (int32_t j = 0; j < k; j++) {
+            if (out[j] == a[k]) d |= 1;
+            if (out[j] == b[k]) d |= 2;
+        }
+        direct[k] = d;
+    }
+    VFT_DISPATCH(c, launch((k_posterior_chain<REAL, NC>), dim3(cdiv(c->d.nPos, VFT_ML_WG)), dim3(VFT_ML_WG), 0, c->stream,
+                           arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
+                           (const int64_t *) (s + 3 * idB), (const int64_t *) (s + 4 * idB), (const uint8_t *) (s + 5 * idB), n,
+                           (const REAL *) c->blen, c->minLen, c->minRel));
+    launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
 template <typename REAL, int NC>
 static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
                               double ftol, double atol) {

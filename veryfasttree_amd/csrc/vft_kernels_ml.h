@@ -346,6 +346,50 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
     }
 }
 
+// A CHAIN of n posteriorProfile calls in order where later ones may read earlier results (up-profiles down a path, a
+// node and then its parent after an NNI), the branch lengths read from the device's branchlength[] when the op runs:
+// as for k_average_chain a column depends on that column of its inputs only, so a thread takes its columns through the
+// whole chain; the P(t) tables of every op are rebuilt per workgroup.  Rows only; flags by k_mark_rows afterwards.
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_ML_WG) void k_posterior_chain(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
+                                                               const int64_t *bN, const int64_t *liA, const int64_t *liB,
+                                                               const uint8_t *direct, int32_t n, const REAL *blen,
+                                                               double minLen, double minRel) {
+    __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
+    __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
+    const bool jc = A.tmStat == nullptr;
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < A.d.nPos;
+    const int r = live ? A.ratecat[p] : 0;
+    for (int32_t k = 0; k < n; k++) {
+        double len1 = (double) blen[liA[k]], len2 = (double) blen[liB[k]];
+        if (len1 < minLen) len1 = minLen;
+        if (len2 < minLen) len2 = minLen;
+        __syncthreads();
+        if (jc) {
+            for (int q = threadIdx.x; q < A.nRates; q += blockDim.x) {
+                vft_psame_pdiff(len1, (double) A.rates[q], pS1[q], pD1[q]);
+                vft_psame_pdiff(len2, (double) A.rates[q], pS2[q], pD2[q]);
+            }
+        } else {
+            vft_exp_eigen_rates<REAL, NC>(A, len1, minRel, ee1);
+            vft_exp_eigen_rates<REAL, NC>(A, len2, minRel, ee2);
+        }
+        __syncthreads();
+        if (!live) continue;
+        Col<REAL, NC> c1, c2;
+        const uint8_t d = direct[k];
+        if (d & 1) vft_load_row<REAL, NC>(A, aN[k], p, c1);
+        else vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
+        if (d & 2) vft_load_row<REAL, NC>(A, bN[k], p, c2);
+        else vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
+        REAL wo, f[NC];
+        int co;
+        vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, wo, co, f);
+        vft_store_col_ml<REAL, NC>(A, outN[k], p, wo, co, f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // optimizeAllBranchLengths' inner step (NJ.tcc:5025-5060) for one split, entirely on the device: the three branches
 // around an internal node are optimised in turn, twice; for branch i the other two profiles are condensed into their

@@ -426,6 +426,7 @@ namespace veryfasttree {
                 if (prm.useML) {
                     const int64_t ids[4] = {nodeA, nodeB, nodeC, idD}, li[5] = {nodeA, nodeB, nodeC, nodeD, node};
                     vft_quartet_nni r;
+                    flushPosteriors();
                     chk(vft_ml_quartet_nni(ctx, 1, ids, li, prm.ftol, prm.atol, /*closeLogLkLimit*/5.0, prm.mlAccuracy, &r));
                     choice = r.choice;
                     for (int i = 0; i < 3; i++) criteria[i] = r.criteria[i];
@@ -474,6 +475,7 @@ namespace veryfasttree {
                 }
             }
             flushAverages();
+            flushPosteriors();
             rebuildOrder();
             return nNNIThisRound;
         }
@@ -845,7 +847,7 @@ namespace veryfasttree {
                 int64_t cd[2], lcd[2];
                 quartetCD(x, cd, lcd);
                 const int64_t out = x + nSeqs;
-                if (useML) chk(vft_posterior_profiles_blen(ctx, 1, &out, &cd[0], &cd[1], &lcd[0], &lcd[1]));
+                if (useML) queuePosterior(out, cd[0], cd[1], lcd[0], lcd[1]);
                 else queueAverage(out, cd[0], cd[1]);
                 upHave[(size_t) x] = 1;
             }
@@ -855,9 +857,32 @@ namespace veryfasttree {
         void recomputeProfile(int64_t node, bool useML) {
             if (node < nSeqs || node == root) return;
             const int64_t a = child[3 * node], b = child[3 * node + 1];
-            if (useML) chk(vft_posterior_profiles_blen(ctx, 1, &node, &a, &b, &a, &b));
+            if (useML) queuePosterior(node, a, b, a, b);
             else queueAverage(node, a, b);
         }
+
+        /* the same for the posteriors of the ML walk (vft_posterior_chain_blen); the branch lengths are read on the
+           device when the chain runs, i.e. after the verdict kernels queued before it */
+        void queuePosterior(int64_t out, int64_t a, int64_t b, int64_t la, int64_t lb) {
+            pOut.push_back(out);
+            pA.push_back(a);
+            pB.push_back(b);
+            pLa.push_back(la);
+            pLb.push_back(lb);
+            if (pOut.size() >= 128) flushPosteriors();
+        }
+
+        void flushPosteriors() {
+            if (pOut.empty()) return;
+            chk(vft_posterior_chain_blen(ctx, (int32_t) pOut.size(), pOut.data(), pA.data(), pB.data(), pLa.data(), pLb.data()));
+            pOut.clear();
+            pA.clear();
+            pB.clear();
+            pLa.clear();
+            pLb.clear();
+        }
+
+        std::vector<int64_t> pOut, pA, pB, pLa, pLb;
 
         /* Minimum-evolution averages are queued and go down as one chain launch (vft_average_chain) right before
            something reads profiles: a step of an NNI / SPR walk is then two launches (chain, distances) and one wait */
