@@ -1,3 +1,4 @@
+"""Diagnostic: two rounds of ML branch lengths on the white-box fixtures vs the reference, worst deviations per model."""
 import sys; sys.path.insert(0,"tests"); sys.path.insert(0,".")
 import numpy as np, golden_util as G
 from test_gpu_ml_lengths import _setup

@@ -1,3 +1,4 @@
+"""Diagnostic: one quartet of a white-box fixture through vft_ml_split_tests and vft_ml_quartet_nni (argv: fixture, model)."""
 import sys, ctypes as C
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, golden_util as G
