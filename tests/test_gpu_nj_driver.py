@@ -94,13 +94,14 @@ def test_fasta_to_newick_tool_matches_the_reference_output():
     # the same alignment through `-nome -mllen` without and with the CAT approximation (ml_nt_200*: same sequences)
     for flags, name, key in ((["-mllen", "-nocat", "-nosupport"], "ml_nt_200", "newick"),
                              (["-mllen", "-nosupport"], "ml_nt_200_cat", "newick"),
-                             (["-mllen"], "ml_nt_200_cat", "newick_support")):   # the reference's default for -nome -mllen
+                             (["-mllen"], "ml_nt_200_cat", "newick_support"),   # the reference's default for -nome -mllen
+                             (["-full"], "full_nt_200", "newick_support")):      # plain `VeryFastTree -nt`
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "nj_tree.py"), fa] + flags, check=True,
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         d = G.load(name)
         assert res.stdout.decode().strip() == bytes(d[key]).decode().strip()
         got = [float(l.split("\t")[2]) for l in res.stderr.decode().splitlines() if l.startswith("TreeLogLk")]
-        assert np.allclose(got, d["loglk"], rtol=0, atol=6e-5)
+        assert np.allclose(got, d["loglk"], rtol=0, atol=6e-5)   # (-full: the ML NNI rounds and the final length pass)
 
 
 def test_amino_acid_alignment_with_distance_matrix_end_to_end():
