@@ -188,3 +188,73 @@ def tree_loglk(orc, profs, child, root, bl, rates, ratecat, tm, min_len, min_rel
         gaps = int((leaf_codes == nocode).sum())
         total += (gaps - leaf_codes.shape[1]) * np.log(4.0)
     return total
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Quartet likelihoods (the evaluation behind testSplitsML and an ML NNI)
+#   quartet_loglk      MLQuartetLogLk     NeighbourJoining.tcc:5412-5427
+#   quartet_optimize   MLQuartetOptimize  NeighbourJoining.tcc:1650-1788 (no star test: testSplitsML passes nullptr)
+#   split_test         the per-split body of traverseTestSplitsML, NeighbourJoining.tcc:6885-6925
+# Pinned by tests/test_oracle_golden.py on the <model>.quartet<k>.* entries of the white-box fixtures.
+CLOSE_LOGLK_LIMIT = 5.0  # Constants::closeLogLkLimit
+
+
+def quartet_loglk(orc, pa, pb, pc, pd, lens, rates, ratecat, tm, min_len, min_rel, site=None):
+    post = lambda x, y, l1, l2: orc.posterior_profile(x, y, float(l1), float(l2), rates, ratecat, tm, min_len, min_rel)
+    pll = lambda x, y, l: orc.pair_loglk(x, y, float(l), rates, ratecat, tm, min_rel, site)
+    ab, cd = post(pa, pb, lens[0], lens[1]), post(pc, pd, lens[2], lens[3])
+    return pll(pa, pb, lens[0] + lens[1]) + pll(pc, pd, lens[2] + lens[3]) + pll(ab, cd, lens[4])
+
+
+def quartet_optimize(orc, pa, pb, pc, pd, lens, rates, ratecat, tm, min_len, min_rel, ftol, atol, site=None):
+    """lens = [A, B, C, D, I] is updated in place; returns the quartet log-likelihood."""
+    post = lambda x, y, l1, l2: orc.posterior_profile(x, y, float(l1), float(l2), rates, ratecat, tm, min_len, min_rel)
+    for j in range(5):
+        if lens[j] < min_len:
+            lens[j] = min_len
+    last = {}
+
+    def search(p1, p2, slot):
+        def f(x):
+            last["v"] = -orc.pair_loglk(p1, p2, x, rates, ratecat, tm, min_rel)
+            last["x"] = x
+            return last["v"]
+        vals = {}
+
+        def g(x):
+            v = f(x)
+            vals[x] = v
+            return v
+        lens[slot] = min_branch_length(g, min_len, lens[slot], MAX_BRANCH_LENGTH, ftol, atol)
+        return vals[lens[slot]]     # brent returns f at the point it returns
+
+    ab, cd = post(pa, pb, lens[0], lens[1]), post(pc, pd, lens[2], lens[3])
+    search(ab, cd, 4)
+    search(pa, post(pb, cd, lens[1], lens[4]), 0)
+    search(pb, post(pa, cd, lens[0], lens[4]), 1)
+    ab = post(pa, pb, lens[0], lens[1])
+    search(pc, post(ab, pd, lens[4], lens[3]), 2)
+    abc = post(ab, pc, lens[4], lens[2])
+    negloglk = search(pd, abc, 3)
+    if site is not None:
+        site[:] = 1.0
+        orc.pair_loglk(abc, pd, float(lens[3]), rates, ratecat, tm, min_rel, site)
+    return (-negloglk + orc.pair_loglk(ab, pc, float(lens[4] + lens[2]), rates, ratecat, tm, min_rel, site)
+            + orc.pair_loglk(pa, pb, float(lens[0] + lens[1]), rates, ratecat, tm, min_rel, site))
+
+
+def split_test(orc, pa, pb, pc, pd, lens, rates, ratecat, tm, min_len, min_rel, ftol, atol):
+    """Returns (loglk[3], lenAC, lenAD) as testSplitsML computes them for one split."""
+    l_ab = [lens[0], lens[1], lens[2], lens[3], lens[4]]
+    l_ac = [lens[0], lens[2], lens[1], lens[3], lens[4]]
+    l_ad = [lens[0], lens[3], lens[2], lens[1], lens[4]]
+    args = (rates, ratecat, tm, min_len, min_rel)
+    loglk = [quartet_loglk(orc, pa, pb, pc, pd, l_ab, *args),
+             quartet_optimize(orc, pa, pc, pb, pd, l_ac, *args, ftol, atol),
+             quartet_optimize(orc, pa, pd, pc, pb, l_ad, *args, ftol, atol)]
+    if loglk[1] > loglk[2]:
+        if loglk[1] > loglk[0] - CLOSE_LOGLK_LIMIT:
+            loglk[1] = quartet_optimize(orc, pa, pc, pb, pd, l_ac, *args, ftol, atol)
+    elif loglk[2] > loglk[0] - CLOSE_LOGLK_LIMIT:
+        loglk[2] = quartet_optimize(orc, pa, pd, pc, pb, l_ad, *args, ftol, atol)
+    return loglk, l_ac, l_ad

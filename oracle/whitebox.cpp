@@ -432,6 +432,49 @@ struct Harness {
         }
         nj.branchlength = savedLen;
         nj.recomputeMLProfiles();
+
+        /* testSplitsML's per-split evaluation (NJ.tcc:6856-6925) for a few splits: MLQuartetLogLk of AB|CD, MLQuartetOptimize
+           of AC|BD and AD|BC, second pass for the better alternative when close.  D's profile (the up-profile of the
+           parent, or the root's other child) is dumped so that a test can put it on the device. */
+        {
+            std::vector<std::unique_ptr<Profile>> upProfiles(nj.maxnodes);
+            std::vector<int64_t> picks;
+            for (int64_t v = nSeqs; v < nj.maxnode - 1 && picks.size() < 6; v += std::max<int64_t>(1, (nj.maxnode - 1 - nSeqs) / 6))
+                if (v != nj.root) picks.push_back(v);
+            out.vec(name + ".quartet.nodes", picks);
+            for (size_t k = 0; k < picks.size(); k++) {
+                const int64_t node = picks[k];
+                const std::string key = name + ".quartet" + std::to_string(k);
+                Profile *profiles4[4];
+                int64_t nodeABCD[4];
+                nj.setupABCD(node, profiles4, upProfiles.data(), nodeABCD, /*useML*/true);
+                out.vec(key + ".abcd", std::vector<int64_t>(nodeABCD, nodeABCD + 4));
+                dumpProfile(key + ".D", *profiles4[3]);
+                double len[5];
+                for (int i = 0; i < 4; i++) len[i] = nj.branchlength[nodeABCD[i]];
+                len[4] = nj.branchlength[node];
+                out.vec(key + ".len", std::vector<double>(len, len + 5));
+                double lenABvsCD[5] = {len[0], len[1], len[2], len[3], len[4]};
+                double lenACvsBD[5] = {len[0], len[2], len[1], len[3], len[4]};
+                double lenADvsBC[5] = {len[0], len[3], len[2], len[1], len[4]};
+                std::vector<double> site(3 * nPos);
+                double loglk[3];
+                loglk[0] = nj.MLQuartetLogLk(*profiles4[0], *profiles4[1], *profiles4[2], *profiles4[3], lenABvsCD, &site[0]);
+                loglk[1] = nj.MLQuartetOptimize(*profiles4[0], *profiles4[2], *profiles4[1], *profiles4[3], lenACvsBD, nullptr, &site[nPos]);
+                loglk[2] = nj.MLQuartetOptimize(*profiles4[0], *profiles4[3], *profiles4[2], *profiles4[1], lenADvsBC, nullptr, &site[2 * nPos]);
+                if (loglk[1] > loglk[2]) {
+                    if (loglk[1] > loglk[0] - Constants::closeLogLkLimit)
+                        loglk[1] = nj.MLQuartetOptimize(*profiles4[0], *profiles4[2], *profiles4[1], *profiles4[3], lenACvsBD, nullptr, &site[nPos]);
+                } else {
+                    if (loglk[2] > loglk[0] - Constants::closeLogLkLimit)
+                        loglk[2] = nj.MLQuartetOptimize(*profiles4[0], *profiles4[3], *profiles4[2], *profiles4[1], lenADvsBC, nullptr, &site[2 * nPos]);
+                }
+                out.vec(key + ".loglk", std::vector<double>(loglk, loglk + 3));
+                out.vec(key + ".lenAC", std::vector<double>(lenACvsBD, lenACvsBD + 5));
+                out.vec(key + ".lenAD", std::vector<double>(lenADvsBC, lenADvsBC + 5));
+                out.mat(key + ".site", site, 3, nPos);
+            }
+        }
     }
 };
 

@@ -162,3 +162,46 @@ def test_mllen_with_sh_like_supports(name, dt, ncat):
     assert (diff > 0).mean() <= 0.05
     # observed on MI355X: every support identical, i.e. the whole output byte-identical
     assert tree == ref
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_quartet_likelihoods_against_the_reference(name):
+    """k_ml_quartet, split-test mode, operator level: MLQuartetLogLk of AB|CD and MLQuartetOptimize of AC|BD / AD|BC (with
+    testSplitsML's second pass) for six splits per model against the reference's numbers; D's profile (an up-profile)
+    comes from the fixture."""
+    d = G.load(name)
+    n_seqs, root = int(d["nSeqs"]), int(d["nj.root"])
+    f32 = d["nj.branchlength"].dtype == np.float32
+    child, bl = d["nj.child"], d["nj.branchlength"]
+    nodes = G.internal_nodes(d)
+    level = np.zeros(root + 1, np.int64)
+    for v in nodes:
+        level[v] = 1 + max(level[child[v, 0]], level[child[v, 1]])
+    for model in (["lg"] if "_aa_" in name else ["jc", "gtr"]):
+        ops = _setup(d, model, 16)
+        ops.set_max_node(ops.max_nodes)
+        ops.branch_lengths_set(0, bl[:root + 1])
+        for lv in range(1, int(level.max()) + 1):   # recomputeMLProfiles
+            batch = np.array([v for v in nodes if level[v] == lv])
+            ops.posteriorProfileBlen(batch, child[batch, 0], child[batch, 1], child[batch, 0], child[batch, 1])
+        ids, li, want, want_ac, want_ad = [], [], [], [], []
+        for k, node in enumerate(d[model + ".quartet.nodes"]):
+            key = "%s.quartet%d" % (model, k)
+            a, b, c, dn = [int(x) for x in d[key + ".abcd"]]
+            slot = root + 1 + k                       # a free internal id for D's profile
+            ops.profile_upload(slot, G.fixture_profile(d, key + ".D"))
+            ids.append([a, b, c, slot])
+            li.append([a, b, c, dn, int(node)])
+            assert np.array_equal(d[key + ".len"], [bl[a], bl[b], bl[c], bl[dn], bl[int(node)]])
+            want.append(d[key + ".loglk"])
+            want_ac.append(d[key + ".lenAC"])
+            want_ad.append(d[key + ".lenAD"])
+        loglk, lengths = ops.mlSplitTests(ids, li)
+        want = np.array(want)
+        assert np.allclose(loglk[:, 0], want[:, 0], rtol=2e-6 if f32 else 1e-10), model
+        assert np.allclose(loglk[:, 1:], want[:, 1:], rtol=2e-5 if f32 else 1e-8), (model, loglk, want)
+        exact = model == "jc" or not f32
+        tol = dict(rtol=1e-4, atol=1e-7 if f32 else 1e-12) if exact else dict(rtol=0.1, atol=3e-4)
+        assert np.allclose(lengths[:, 0], np.array(want_ac), **tol), model
+        assert np.allclose(lengths[:, 1], np.array(want_ad), **tol), model
+        ops.close()

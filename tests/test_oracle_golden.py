@@ -251,3 +251,26 @@ def test_ml_branch_length_rounds(fx):
             ll = ML.tree_loglk(orc, profs, child, root, bl, d["ml.rates"], d["ml.ratecat"], tm, min_len, min_rel,
                                d["leaf.codes"])
             assert ll == pytest.approx(float(d["%s.opt%d.treeloglk" % (model, rnd)]), rel=1e-7), (model, rnd)
+
+
+def test_quartet_likelihoods_of_split_tests(fx):
+    """MLQuartetLogLk / MLQuartetOptimize as testSplitsML runs them (oracle/ml_lengths.py) against the reference's three
+    log-likelihoods and optimised lengths for six splits per model."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ml_lengths as ML
+    d, orc = fx["d"], fx["orc"]
+    min_len, min_rel, _ = tolerances(orc.dt)
+    ftol, atol = _ml_tolerances(orc.dt)
+    for model in _models(fx):
+        profs, tm = _ml_profiles(fx, model)
+        for k, node in enumerate(d[model + ".quartet.nodes"]):
+            key = "%s.quartet%d" % (model, k)
+            a, b, c, _ = [int(x) for x in d[key + ".abcd"]]
+            pd = G.fixture_profile(d, key + ".D")
+            loglk, l_ac, l_ad = ML.split_test(orc, profs[a], profs[b], profs[c], pd, [float(x) for x in d[key + ".len"]],
+                                              d["ml.rates"], d["ml.ratecat"], tm, min_len, min_rel, ftol, atol)
+            assert np.allclose(loglk, d[key + ".loglk"], rtol=1e-9, atol=0), (model, k, loglk, d[key + ".loglk"])
+            assert np.allclose(l_ac, d[key + ".lenAC"], rtol=1e-6, atol=1e-12), (model, k)
+            assert np.allclose(l_ad, d[key + ".lenAD"], rtol=1e-6, atol=1e-12), (model, k)

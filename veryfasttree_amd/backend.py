@@ -462,6 +462,18 @@ class HipProfileOps:
         self._chk(self.lib.vft_ml_optimize_splits(self.ctx, I64(len(rec)), _ptr(ids), _ptr(li), _ptr(rec),
                                                   C.c_double(ftol), C.c_double(atol)))
 
+    def mlSplitTests(self, ids, len_idx, always_second_pass=False, ftol=0.001, atol=None):
+        """vft_ml_split_tests without resampling: ids [n, 4], len_idx [n, 5] -> (loglk [n, 3], lengths [n, 2, 5])."""
+        ids, li = _i64(ids).reshape(-1, 4), _i64(len_idx).reshape(-1, 5)
+        if atol is None:
+            atol = 1.0e-4 if self.dt == np.float32 else 1.0e-9
+        n = len(ids)
+        loglk, lengths = np.zeros((n, 3)), np.zeros((n, 2, 5))
+        self._chk(self.lib.vft_ml_split_tests(self.ctx, I64(n), _ptr(ids), _ptr(li), C.c_double(ftol), C.c_double(atol),
+                                              C.c_double(5.0), I32(1 if always_second_pass else 0), _ptr(loglk), I32(0), None,
+                                              None, _ptr(lengths)))
+        return loglk, lengths
+
     def ml_eval_count(self):
         n = I64(0)
         self._chk(self.lib.vft_ml_eval_count(self.ctx, C.byref(n)))
