@@ -549,9 +549,10 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
                 vft_load_col_ml<REAL, NC>(A, nI, p, pA[c]);
             }
         }
-        // -pairLogLk(P_i, posterior, x), collectively
+        // -pairLogLk(P_i, posterior, x), collectively.  No barrier in front: the previous evaluation ended with one after
+        // every wave had read the tables, and the one below separates the first evaluation from the posterior above.
+        __syncthreads();
         auto negLogLk = [&](double x) -> double {
-            __syncthreads();
             if (jc) {
                 for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r]);
             } else {
@@ -674,8 +675,10 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
         o.vec = o.code == VFT_NOCODE_ && o.w > (REAL) 0;
     };
     // pairLogLk(X, Y, len) over the workgroup (table slot 0); site != nullptr: multiply the per-site likelihoods in
-    auto pairTotal = [&](const Col<REAL, NC> *X, const Col<REAL, NC> *Y, double len, double *site) -> double {
-        __syncthreads();
+    // (lead: barrier in front - needed unless the previous thing the workgroup did was another pairTotal, whose final
+    //  barrier already came after every wave's last table read)
+    auto pairTotal = [&](const Col<REAL, NC> *X, const Col<REAL, NC> *Y, double len, double *site, bool lead = true) -> double {
+        if (lead) __syncthreads();
         table(0, len, false);
         __syncthreads();
         double lk = 1.0, loglk = 0.0;
@@ -847,7 +850,8 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
                 for (int c = 0; c < CPT; c++) post(T[c], X[c], 3, 0, rc[c], Y[c]);   // ABD / ABC
                 loadCols(step == 3 ? qc : qd, X);                                   // pair1 = C / D
             }
-            auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr); };
+            __syncthreads();   // the posteriors above are done with the tables
+            auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr, false); };
             const int slot = step == 0 ? 4 : step - 1;
             L[slot] = vft_min_branch_length(negLogLk, minLen, L[slot], VFT_MLOPT_MAXLEN, ftol, atol, negll);
             if (step == 0 && mode != 0 && t == 0) {
