@@ -588,17 +588,29 @@ __device__ __forceinline__ void vft_pair_generic(const Arena<REAL> &A, int64_t i
 // one column of the pair (i, j) — or (i, out-profile) — as the reference sees it
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_pair_load(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, int64_t p,
-                                              Col<REAL, NC> &c1, Col<REAL, NC> &c2) {
-    vft_load_col_ml<REAL, NC>(A, i, p, c1);
+                                              Col<REAL, NC> &c1, Col<REAL, NC> &c2, bool iRow, bool jRow) {
+    if (iRow) vft_load_row<REAL, NC>(A, i, p, c1);
+    else vft_load_col<REAL, NC>(A, i, p, c1);
     if (jIsOut) {
         c2.w = A.outW[p];
         c2.code = VFT_NOCODE_;
         c2.vec = c2.w > 0;
 #pragma unroll
         for (int k = 0; k < NC; k++) c2.f[k] = A.outF[p * NC + k];
+    } else if (jRow) {
+        vft_load_row<REAL, NC>(A, j, p, c2);
     } else {
-        vft_load_col_ml<REAL, NC>(A, j, p, c2);
+        vft_load_col<REAL, NC>(A, j, p, c2);
     }
+}
+// does the node's current profile live in a plain row (refinement / ML phases, vft_layout.h)?  Looked up once per pair,
+// outside the column loop, so that the loop's loads stay independent of it.
+template <typename REAL>
+__device__ __forceinline__ bool vft_is_row(const Arena<REAL> &A, int64_t node) {
+#ifdef VFT_AB_NO_ROWS   // A/B builds only (tools): the pair kernels as they were before the rows existed
+    return false;
+#endif
+    return node >= A.d.nSeqs && A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs] != 0;
 }
 // its addends to (denom, top), parked in LDS for the in-order sum
 template <typename REAL, int NC>
@@ -641,12 +653,13 @@ __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, i
     }
     // two columns per lane and trip: both columns' loads are issued before the first is consumed (the loop is a
     // chain of dependent memory latencies otherwise: mask -> offsets -> stream)
+    const bool iRow = vft_is_row<REAL>(A, i), jRow = !jIsOut && vft_is_row<REAL>(A, j);
     for (int64_t p = lane; p < nPos; p += 128) {
         const int64_t pb = p + 64;
         const bool hasB = pb < nPos;
         Col<REAL, NC> a1, a2, b1, b2;
-        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2);
-        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2);
+        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2, iRow, jRow);
+        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2, iRow, jRow);
         vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
         if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
     }
@@ -689,12 +702,13 @@ __device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, 
     const int64_t nPos = A.d.nPos;
     const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
     // two columns per thread and trip, loads of both issued before the first is consumed (as in vft_pair_wave)
+    const bool iRow = vft_is_row<REAL>(A, i), jRow = !jIsOut && vft_is_row<REAL>(A, j);
     for (int64_t p = threadIdx.x; p < nPos; p += 2 * (int64_t) blockDim.x) {
         const int64_t pb = p + blockDim.x;
         const bool hasB = pb < nPos;
         Col<REAL, NC> a1, a2, b1, b2;
-        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2);
-        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2);
+        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2, iRow, jRow);
+        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2, iRow, jRow);
         vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
         if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
     }
