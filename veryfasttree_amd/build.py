@@ -8,9 +8,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvft_hip.so")
-SOURCES = [os.path.join(CSRC, "vft_api.hip")]
-HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_profile.h", "vft_kernels_ml.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+SOURCES = [os.path.join(CSRC, f) for f in ("vft_api.hip", "vft_ml_kernels_lengths.hip", "vft_ml_kernels_quartet32.hip",
+                                             "vft_ml_kernels_quartet64.hip")]
+HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_profile.h", "vft_kernels_ml.h"]   # deps of every unit
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 
 
 HOST_LIB = os.path.join(HERE, "lib", "libvft_host.so")
@@ -40,7 +41,16 @@ def build(force=False):
     if force or needs_build():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.run([hipcc] + FLAGS + ["-o", LIB] + SOURCES, check=True)
+        # one hipcc per translation unit, in parallel (the line-search kernels of vft_ml_kernels.hip take as long as
+        # everything else together), then the link
+        objs = [os.path.join(os.path.dirname(LIB), os.path.basename(src) + ".o") for src in SOURCES]
+        jobs = [subprocess.Popen([hipcc] + FLAGS + ["-c", "-o", obj, src]) for src, obj in zip(SOURCES, objs)]
+        for src, job in zip(SOURCES, jobs):
+            if job.wait() != 0:
+                raise subprocess.CalledProcessError(job.returncode, "hipcc -c " + src)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs, check=True)
+        for obj in objs:
+            os.remove(obj)
     build_host(force)
     return LIB
 

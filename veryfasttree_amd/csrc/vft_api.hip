@@ -14,6 +14,8 @@
 
 #include "../../include/vft_hip.h"
 #include "vft_kernels_ml.h"
+
+VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_nj.h"
 #include "vft_kernels_profile.h"
 

@@ -954,7 +954,7 @@ __global__ void k_ml_nni_init(const int64_t *lenIdx, const REAL *blen, QuartetNN
 }
 
 // end of a round (NJ.tcc:4910-4916, :4961-4983)
-__global__ void k_ml_nni_decide(QuartetNNIState *state, int64_t n, double minLen, double closeLimit, int mlAccuracy, int lastRound) {
+static __global__ void k_ml_nni_decide(QuartetNNIState *state, int64_t n, double minLen, double closeLimit, int mlAccuracy, int lastRound) {
     const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     QuartetNNIState &st = state[k];
@@ -1012,7 +1012,7 @@ __global__ void k_ml_nni_verdict(const QuartetNNIState *state, const int64_t *le
 // One workgroup per split; its 3 x nPos site log-likelihoods sit in LDS, a thread per resample walks the resample's
 // columns in order (the reference's sequence of additions).  colT: [nPos][nBoot] (transposed, so that the threads of
 // a wavefront read consecutive entries).
-__global__ __launch_bounds__(256) void k_sh_support(const double *siteLoglk, const double *loglk, const uint16_t *colT,
+static __global__ __launch_bounds__(256) void k_sh_support(const double *siteLoglk, const double *loglk, const uint16_t *colT,
                                                     int64_t nPos, int32_t nBoot, double *support) {
     extern __shared__ double sSite[];   // [3][nPos]
     __shared__ unsigned int sCount;
@@ -1044,3 +1044,41 @@ __global__ __launch_bounds__(256) void k_sh_support(const double *siteLoglk, con
     __syncthreads();
     if (threadIdx.x == 0) support[k] = (double) sCount / (double) nBoot;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The two line-search kernels are by far the largest pieces of device code.  They are instantiated in their own
+// translation units (vft_ml_kernels_*.hip) so that the library builds as parallel hipcc jobs; vft_api.hip only
+// declares the instances (`extern template`).
+#define VFT_ML_NODE_LENGTHS_INSTANCE(PFX, REAL, NC, CPT)                                                                  \
+    PFX template __global__ void k_ml_node_lengths<REAL, NC, CPT>(Arena<REAL>, const int64_t *, const int64_t *, const int64_t *, \
+                                                                 REAL *, double, double, double, double, unsigned int *);
+#define VFT_ML_QUARTET_INSTANCE(PFX, REAL, NC, CPT)                                                                        \
+    PFX template __global__ void k_ml_quartet<REAL, NC, CPT>(Arena<REAL>, const int64_t *, const int64_t *, REAL *, double, double, \
+                                                            double, double, double, int, int, double *, double *, double *,  \
+                                                            QuartetNNIResult *, QuartetNNIState *, unsigned int *);
+#define VFT_ML_NODE_LENGTHS_INSTANCES(PFX)                \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 1)        \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 4)        \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 8)        \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 1)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 4)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 1)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 4)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 8)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 1)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 4)
+#define VFT_ML_QUARTET_INSTANCES_F32(PFX)                 \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 1)             \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 4)             \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 1)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4)
+#define VFT_ML_QUARTET_INSTANCES_F64(PFX)                 \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 1)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 4)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 1)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4)
+#define VFT_ML_HEAVY_INSTANCES(PFX)        \
+    VFT_ML_NODE_LENGTHS_INSTANCES(PFX)     \
+    VFT_ML_QUARTET_INSTANCES_F32(PFX)      \
+    VFT_ML_QUARTET_INSTANCES_F64(PFX)

@@ -326,7 +326,7 @@ __global__ void k_average_chain(Arena<REAL> A, const int64_t *outN, const int64_
     //  on an earlier op and read the same node through its flag)
 }
 
-__global__ void k_mark_rows(uint8_t *mlIs, const int64_t *nodes, int32_t n, int64_t nSeqs) {
+static __global__ void k_mark_rows(uint8_t *mlIs, const int64_t *nodes, int32_t n, int64_t nSeqs) {
     const int32_t k = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
     if (k < n) mlIs[nodes[k] - nSeqs] = 1;
 }
@@ -414,7 +414,7 @@ __global__ void k_outprofile_update(Arena<REAL> A, int64_t old1, int64_t old2, i
 // (64 nodes x 16 columns: weights, codes, vector mask, packed vectors) through LDS, prefetched one tile ahead.
 // k_outprofile_full does the same through per-thread gathers and is ~8x slower; it remains for arbitrary id lists and
 // for the matrix / amino-acid case.
-__global__ void k_tile_active_masks(const int32_t *parent, int64_t maxnode, unsigned long long *tileMask, int64_t nTiles) {
+static __global__ void k_tile_active_masks(const int32_t *parent, int64_t maxnode, unsigned long long *tileMask, int64_t nTiles) {
     const int64_t t = (int64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (t >= nTiles) return;
     const int64_t v = t * 64 + (threadIdx.x & 63);
