@@ -175,6 +175,44 @@ namespace veryfasttree {
             chk(vft_average_profiles(ctx, n, out, a, b, bionjWeight));
         }
 
+        /* tree-refinement phase: averages into plain rows, chains of dependent averages in one launch */
+        void setProfileRows(bool on) { chk(vft_set_profile_rows(ctx, on ? 1 : 0)); }
+
+        void averageChain(int32_t n, const int64_t *out, const int64_t *a, const int64_t *b) { chk(vft_average_chain(ctx, n, out, a, b)); }
+
+        /* branchlength[] on the device and the ML operations that read it (optimizeAllBranchLengths NJ.tcc:5006-5113,
+           recomputeProfile :3436, getUpProfile :3382) */
+        void setBranchLengths(int64_t first, int64_t count, const numeric_t *v) { chk(vft_branch_lengths_set(ctx, first, count, v)); }
+
+        void getBranchLengths(int64_t first, int64_t count, numeric_t *v) { chk(vft_branch_lengths_get(ctx, first, count, v)); }
+
+        void posteriorProfilesBlen(int64_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *lenIdxA,
+                                   const int64_t *lenIdxB) {
+            chk(vft_posterior_profiles_blen(ctx, n, out, a, b, lenIdxA, lenIdxB));
+        }
+
+        void posteriorChainBlen(int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *lenIdxA,
+                                const int64_t *lenIdxB) {
+            chk(vft_posterior_chain_blen(ctx, n, out, a, b, lenIdxA, lenIdxB));
+        }
+
+        /* the loop body of optimizeAllBranchLengths for n independent splits (NJ.tcc:5025-5064) */
+        void mlOptimizeSplits(int64_t n, const int64_t *ids3, const int64_t *lenIdx3, const int64_t *recompute, double ftol, double atol) {
+            chk(vft_ml_optimize_splits(ctx, n, ids3, lenIdx3, recompute, ftol, atol));
+        }
+
+        /* testSplitsML + SHSupport for n splits (NJ.tcc:6856-6999, 1126-1165) */
+        void mlSplitTests(int64_t n, const int64_t *ids4, const int64_t *lenIdx5, double ftol, double atol, double closeLimit,
+                          bool alwaysSecondPass, double *loglk3, int32_t nBoot, const int32_t *col, double *support, double *lengths) {
+            chk(vft_ml_split_tests(ctx, n, ids4, lenIdx5, ftol, atol, closeLimit, alwaysSecondPass ? 1 : 0, loglk3, nBoot, col, support, lengths));
+        }
+
+        /* MLQuartetNNI (NJ.tcc:4885-5004) */
+        void mlQuartetNNI(int64_t n, const int64_t *ids4, const int64_t *lenIdx5, double ftol, double atol, double closeLimit,
+                          int32_t mlAccuracy, vft_quartet_nni *results) {
+            chk(vft_ml_quartet_nni(ctx, n, ids4, lenIdx5, ftol, atol, closeLimit, mlAccuracy, results));
+        }
+
         /* outProfile / updateOutProfile (NJ.tcc:3012-3036) */
         void outProfile(int64_t nActive, const int64_t *activeIds) { chk(vft_out_profile_full(ctx, nActive, activeIds)); }
 
