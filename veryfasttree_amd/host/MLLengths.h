@@ -1,6 +1,8 @@
-// Maximum-likelihood branch lengths on a fixed topology: the host side of recomputeMLProfiles (NJ.tcc:3516-3539),
-// optimizeAllBranchLengths (NJ.tcc:5006-5113) and treeLogLk (NJ.tcc:5114-5259) over the C ABI of include/vft_hip.h.
-// Plain C++11, no HIP.
+// Everything the pipeline does to a finished tree, on the host, over the C ABI of include/vft_hip.h (plain C++11, no
+// HIP).  It started as the maximum-likelihood branch lengths on a fixed topology - recomputeMLProfiles (NJ.tcc:3516-3539),
+// optimizeAllBranchLengths (NJ.tcc:5006-5113), treeLogLk (NJ.tcc:5114-5259) - and now also holds setMLRates
+// (:5429-5488), setMLGtr (:6436-6500), testSplitsML (:6800-6999), DoNNI with either criterion (:5797-6200) and SPR
+// (:6185-6404): one class owns parent[] / child[][3] and the up-profile cache, the device owns profiles and lengths.
 //
 // The device keeps the profiles, the up-profiles (node X -> id X + nSeqs, as in NJDriver.h) and branchlength[]; the host
 // only decides WHAT runs in which order, which depends on the topology alone: the post-order walk, and the moment each
