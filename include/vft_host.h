@@ -86,7 +86,9 @@ void vft_knuth_stream(double *out, int64_t n);
    (NJ.tcc:5065), each followed by treeLogLk (NJ.tcc:5160).  The model (vft_set_rates, vft_set_transition_matrix,
    vft_set_ml_limits) and the leaf / internal profiles must be on the device; the context needs max_nodes >= n_nodes +
    n_seqs (up-profiles).  parent[n_nodes] (-1 at the root), child[n_nodes][3] (-1 = none; the root has three);
-   branchlength: numeric_t[n_nodes], in/out.  ftol = MLFTolBranchLength, atol = MLMinBranchLengthTolerance
+   branchlength: numeric_t[n_nodes], in/out.  recompute_first: bit 0 = recomputeMLProfiles before the first round; bit 1 =
+   level-parallel rounds (MLLengths::optimizeRoundParallel: every tree height as one batch - not the one-thread order, so
+   lengths differ within the search tolerance, the way the reference's threaded mode differs).  ftol = MLFTolBranchLength, atol = MLMinBranchLengthTolerance
    (Constants.h:26-30).  n_leaf_gaps >= 0 applies treeLogLk's Jukes-Cantor correction for that many gap characters in
    the leaves, < 0 none (matrix models).  loglk[rounds] (may be NULL) receives the tree log-likelihood after each
    round, evals (may be NULL) the number of pairLogLk evaluations the line searches made. */

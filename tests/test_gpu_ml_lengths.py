@@ -205,3 +205,25 @@ def test_quartet_likelihoods_against_the_reference(name):
         assert np.allclose(lengths[:, 0], np.array(want_ac), **tol), model
         assert np.allclose(lengths[:, 1], np.array(want_ad), **tol), model
         ops.close()
+
+
+@pytest.mark.parametrize("name", ["wb_nt_f32", "wb_nt_f64", "wb_aa_f64"])
+def test_level_parallel_rounds_reach_the_same_likelihood(name):
+    """MLLengths::optimizeRoundParallel (a tree height per batch; not the one-thread order): after three rounds the
+    tree likelihood is within 1e-4 relative of three sequential rounds, and each branch length within the search
+    tolerance of the sequential one for most branches."""
+    from veryfasttree_amd import backend
+    d = G.load(name)
+    n_seqs, root = int(d["nSeqs"]), int(d["nj.root"])
+    for model in (["lg"] if "_aa_" in name else ["jc", "gtr"]):
+        gaps = int((d["leaf.codes"] == G.NOCODE).sum()) if model == "jc" else -1
+        res = []
+        for par in (False, True):
+            ops = _setup(d, model, 8)
+            res.append(backend.ml_lengths(ops, n_seqs, d["nj.parent"][:root + 1], d["nj.child"][:root + 1], root,
+                                          d["nj.branchlength"][:root + 1], rounds=3, n_leaf_gaps=gaps, parallel=par))
+            ops.close()
+        (bl_s, ll_s, _), (bl_p, ll_p, _) = res
+        assert ll_p[-1] == pytest.approx(ll_s[-1], rel=1e-4), (model, ll_s, ll_p)
+        assert ll_p[-1] > ll_p[0] - 1e-6 * abs(ll_p[0])      # the rounds do not lose likelihood
+        assert np.isclose(bl_p[:root], bl_s[:root], rtol=0.05, atol=2e-3).mean() > 0.9, model

@@ -90,7 +90,7 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
 
 
 def ml_lengths(ops, n_seqs, parent, child, root, branchlength, rounds=1, recompute_first=True, n_leaf_gaps=-1,
-               ftol=0.001, atol=None):
+               ftol=0.001, atol=None, parallel=False):
     """`-mllen` on a fixed topology through the C++ host driver (vft_ml_lengths): returns (branchlength after the
     last round, loglk per round, likelihood evaluations).  atol defaults to MLMinBranchLengthTolerance of ops.dt."""
     lib = load_host_library()
@@ -103,7 +103,7 @@ def ml_lengths(ops, n_seqs, parent, child, root, branchlength, rounds=1, recompu
     evals = I64(0)
     err = C.create_string_buffer(512)
     rc = lib.vft_ml_lengths(ops.ctx, I64(n_seqs), I64(len(parent)), I64(ops.n_pos), I32(ops.dt.itemsize), _ptr(parent),
-                            _ptr(child), I64(root), _ptr(bl), I32(1 if recompute_first else 0), I32(rounds),
+                            _ptr(child), I64(root), _ptr(bl), I32((1 if recompute_first else 0) | (2 if parallel else 0)), I32(rounds),
                             C.c_double(ftol), C.c_double(atol), I64(n_leaf_gaps), _ptr(loglk), C.byref(evals), err, I32(512))
     if rc != 0:
         raise VftError(err.value.decode() or "vft_ml_lengths failed")

@@ -146,6 +146,46 @@ namespace veryfasttree {
             }
         }
 
+        /* A level-parallel variant of optimizeAllBranchLengths for callers that do not need the one-thread order: all
+           up-profiles are built first (from the lengths as they are), then the splits of one tree height go down as ONE
+           vft_ml_optimize_splits batch, bottom-up, the root last.  Splits of the same height own disjoint branches and
+           only read finished children, so a batch is race-free; what differs from the sequential walk is that the
+           up-profiles do not see the updates made earlier in the same round (a Jacobi instead of a Gauss-Seidel sweep -
+           the kind of difference the reference's own -threads-level 3 mode has against one thread).  A round is
+           O(tree height) launches instead of O(nodes). */
+        void optimizeRoundParallel(double ftol, double atol) {
+            allUpProfiles();
+            std::vector<int64_t> height((size_t) nNodes, 0);
+            int64_t top = 0;
+            for (int64_t v: order) {
+                if (v == root) continue;
+                height[(size_t) v] = 1 + std::max(height[(size_t) child[3 * v]], height[(size_t) child[3 * v + 1]]);
+                top = std::max(top, height[(size_t) v]);
+            }
+            std::vector<std::vector<int64_t>> byHeight((size_t) top + 1);
+            for (int64_t v: order)
+                if (v != root) byHeight[(size_t) height[(size_t) v]].push_back(v);
+            const size_t maxBatch = 4096;
+            for (int64_t h = 1; h <= top; h++) {
+                const std::vector<int64_t> &lv = byHeight[(size_t) h];
+                for (size_t k0 = 0; k0 < lv.size(); k0 += maxBatch) {
+                    const size_t cnt = std::min(maxBatch, lv.size() - k0);
+                    std::vector<int64_t> ids, li, rec;
+                    for (size_t k = k0; k < k0 + cnt; k++) {
+                        const int64_t v = lv[k];
+                        const int64_t q[3] = {child[3 * v], child[3 * v + 1], v + nSeqs}, l[3] = {child[3 * v], child[3 * v + 1], v};
+                        ids.insert(ids.end(), q, q + 3);
+                        li.insert(li.end(), l, l + 3);
+                        rec.push_back(v);
+                    }
+                    chk(vft_ml_optimize_splits(ctx, (int64_t) cnt, ids.data(), li.data(), rec.data(), ftol, atol));
+                }
+            }
+            int64_t ids[3], rec = -1;
+            for (int k = 0; k < 3; k++) ids[k] = child[3 * root + k];
+            chk(vft_ml_optimize_splits(ctx, 1, ids, ids, &rec, ftol, atol));
+        }
+
         /* treeLogLk without site likelihoods; nLeafGaps >= 0: the Jukes-Cantor correction (NJ.tcc:5236-5256) with that
            many gap characters in the nSeqs x nPos leaves, < 0: a matrix model, no correction */
         double treeLogLk(int64_t nPos, int64_t nLeafGaps) {

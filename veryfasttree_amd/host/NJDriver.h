@@ -454,12 +454,17 @@ namespace veryfasttree {
                identity straight after fastNJ, needed after minimum-evolution NNIs (they leave some profiles stale) */
             if (reaverage) ml.recomputeAverageProfiles();
             std::vector<double> loglk;
+            const char *pl = std::getenv("VFT_ML_PARALLEL_LENGTHS");
+            const bool parallelLengths = pl && pl[0] == '1';
             const int64_t maxRound = mllen ? (int64_t) (0.5 + std::log((double) nSeqs) / std::log(2.0)) : 0;
             std::vector<REAL> old((size_t) maxnode);
             bool ratesSet = false;
             for (int64_t iRound = 1; iRound <= maxRound; iRound++) {
                 for (int64_t v = 0; v < maxnode; v++) old[(size_t) v] = branchlength[(size_t) v];
-                ml.optimizeRound(ftol, atol);
+                /* VFT_ML_PARALLEL_LENGTHS=1 (measurements only): the level-parallel rounds of MLLengths.h, which do not
+                   follow the one-thread order of the reference */
+                if (parallelLengths) ml.optimizeRoundParallel(ftol, atol);
+                else ml.optimizeRound(ftol, atol);
                 ml.getLengths(branchlength.data());
                 double dMaxChange = 0;
                 for (int64_t v = 0; v < maxnode; v++) dMaxChange = std::max(dMaxChange, std::fabs((double) old[(size_t) v] - (double) branchlength[(size_t) v]));

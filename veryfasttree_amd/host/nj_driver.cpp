@@ -145,13 +145,14 @@ extern "C" int vft_nj_run(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int
 
 template<typename REAL>
 static void runMLLengths(vft_ctx *ctx, int64_t nSeqs, int64_t nNodes, int64_t nPos, const int64_t *parent, const int64_t *child,
-                         int64_t root, void *bl, bool recomputeFirst, int32_t rounds, double ftol, double atol,
+                         int64_t root, void *bl, int32_t recomputeFirst, int32_t rounds, double ftol, double atol,
                          int64_t nLeafGaps, double *loglk, int64_t *evals) {
     veryfasttree::MLLengths<REAL> ml(ctx, nSeqs, nNodes, parent, child, root);
     ml.setLengths((const REAL *) bl);
-    if (recomputeFirst) ml.recomputeMLProfiles();
+    if (recomputeFirst & 1) ml.recomputeMLProfiles();
     for (int32_t r = 0; r < rounds; r++) {
-        ml.optimizeRound(ftol, atol);
+        if (recomputeFirst & 2) ml.optimizeRoundParallel(ftol, atol);
+        else ml.optimizeRound(ftol, atol);
         if (loglk) loglk[r] = ml.treeLogLk(nPos, nLeafGaps);
     }
     ml.getLengths((REAL *) bl);
@@ -163,8 +164,8 @@ extern "C" int vft_ml_lengths(vft_ctx *ctx, int64_t nSeqs, int64_t nNodes, int64
                               double atol, int64_t nLeafGaps, double *loglk, int64_t *evals, char *err, int32_t errLen) {
     if (!ctx || !parent || !child || !bl || nSeqs < 3 || nNodes <= nSeqs || rounds < 0) return VFT_ERR_INVALID;
     try {
-        if (precision == 8) runMLLengths<double>(ctx, nSeqs, nNodes, nPos, parent, child, root, bl, recomputeFirst != 0, rounds, ftol, atol, nLeafGaps, loglk, evals);
-        else runMLLengths<float>(ctx, nSeqs, nNodes, nPos, parent, child, root, bl, recomputeFirst != 0, rounds, ftol, atol, nLeafGaps, loglk, evals);
+        if (precision == 8) runMLLengths<double>(ctx, nSeqs, nNodes, nPos, parent, child, root, bl, recomputeFirst, rounds, ftol, atol, nLeafGaps, loglk, evals);
+        else runMLLengths<float>(ctx, nSeqs, nNodes, nPos, parent, child, root, bl, recomputeFirst, rounds, ftol, atol, nLeafGaps, loglk, evals);
         return VFT_OK;
     } catch (const std::exception &e) {
         if (err && errLen > 0) snprintf(err, (size_t) errLen, "%s", e.what());
