@@ -81,6 +81,8 @@ struct vft_ctx {
     int32_t nRates = 0;
     double minLen = 5e-4, minRel = 2.5e-4, fpostTol = 1e-10;
     bool rowMode = false;                      // vft_set_profile_rows: averages write dense rows as well
+    bool allRows = false;                      // every internal node is flagged as a row (no tile-path write since the
+                                               // switch): the chain calls then need not raise flags
     uint8_t *mlIs = nullptr, *mlC = nullptr;   // dense ML rows (vft_layout.h), allocated by the first ML-phase write
     void *mlW = nullptr, *mlF = nullptr;
     void *blen = nullptr;              // branchlength[] (numeric_t) for the ML length optimiser
@@ -812,7 +814,10 @@ static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNode
     }
     const int32_t *dOrder = (const int32_t *) dMeta, *dSeg = dOrder + cnt;
     char *cs = base + plan.stashB + plan.metaB;
-    if (c->mlIs) launch(k_clear_ml_rows, dim3(cdiv(cnt, 256)), dim3(256), 0, c->stream, c->mlIs, dNodes, cnt, c->d.nSeqs);
+    if (c->mlIs) {
+        launch(k_clear_ml_rows, dim3(cdiv(cnt, 256)), dim3(256), 0, c->stream, c->mlIs, dNodes, cnt, c->d.nSeqs);
+        c->allRows = false;
+    }
     for (int64_t g0 = 0; g0 < nSeg; g0 += VFT_COMMIT_SEGS) {
         const int64_t g = nSeg - g0 < VFT_COMMIT_SEGS ? nSeg - g0 : VFT_COMMIT_SEGS;
         VFT_DISPATCH(c, (launch((k_tile_commit<REAL, NC>), dim3((unsigned) g), dim3(VFT_COMMIT_WG), 0, c->stream,
@@ -1046,7 +1051,7 @@ extern "C" int vft_average_chain(vft_ctx *c, int32_t n, const int64_t *out, cons
     VFT_DISPATCH(c, launch((k_average_chain<REAL, NC>), dim3(cdiv(c->d.nPos, 128)), dim3(128), 0, c->stream, arena<REAL>(c),
                            (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
                            (const uint8_t *) (s + 3 * idB), n, c->fpostTol));
-    launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
+    if (!c->allRows) launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
     LAUNCHCHK(c);
     return VFT_OK;
 }
@@ -1057,6 +1062,20 @@ extern "C" int vft_average_chain(vft_ctx *c, int32_t n, const int64_t *out, cons
 extern "C" int vft_set_profile_rows(vft_ctx *c, int32_t on) {
     if (!c) return VFT_ERR_INVALID;
     c->rowMode = on != 0;
+    c->allRows = false;
+    if (!on) return VFT_OK;
+    // move every existing internal profile into its row and flag ALL internal ids (also the ones written later, e.g.
+    // up-profile slots): from here on a row write needs no flag bookkeeping
+    if (int r = ensure_ml_rows(c)) return r;
+    const int64_t cnt = c->maxnode - c->d.nSeqs;
+    for (int64_t k0 = 0; k0 < cnt; k0 += 32768) {
+        const int64_t n = cnt - k0 < 32768 ? cnt - k0 : 32768;
+        VFT_DISPATCH(c, launch((k_rows_from_tiles<REAL, NC>), dim3(cdiv(c->d.nPos, 128), (unsigned) n), dim3(128), 0, c->stream,
+                               arena<REAL>(c), c->d.nSeqs + k0));
+    }
+    HIPCHK(c, hipMemsetAsync(c->mlIs, 1, (size_t) (c->d.maxNodes - c->d.nSeqs), c->stream));
+    LAUNCHCHK(c);
+    c->allRows = true;
     return VFT_OK;
 }
 
@@ -1781,7 +1800,7 @@ extern "C" int vft_posterior_chain_blen(vft_ctx *c, int32_t n, const int64_t *ou
                            arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
                            (const int64_t *) (s + 3 * idB), (const int64_t *) (s + 4 * idB), (const uint8_t *) (s + 5 * idB), n,
                            (const REAL *) c->blen, c->minLen, c->minRel));
-    launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
+    if (!c->allRows) launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
     LAUNCHCHK(c);
     return VFT_OK;
 }

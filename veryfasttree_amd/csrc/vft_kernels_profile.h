@@ -326,6 +326,17 @@ __global__ void k_average_chain(Arena<REAL> A, const int64_t *outN, const int64_
     //  on an earlier op and read the same node through its flag)
 }
 
+// vft_set_profile_rows: every internal node's current profile copied from the tile streams into its plain row, once
+template <typename REAL, int NC>
+__global__ void k_rows_from_tiles(Arena<REAL> A, int64_t first) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    const int64_t node = first + blockIdx.y;
+    Col<REAL, NC> c;
+    vft_load_col<REAL, NC>(A, node, p, c);
+    vft_store_col_ml<REAL, NC>(A, node, p, c.w, c.code, c.f);
+}
+
 static __global__ void k_mark_rows(uint8_t *mlIs, const int64_t *nodes, int32_t n, int64_t nSeqs) {
     const int32_t k = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
     if (k < n) mlIs[nodes[k] - nSeqs] = 1;

@@ -207,8 +207,8 @@ namespace veryfasttree {
             /* the third branch of the root against the posterior of the first two (NJ.tcc:5138-5151); the root's own
                slot holds that temporary */
             const int64_t r0 = child[3 * root], r1 = child[3 * root + 1], r2 = child[3 * root + 2];
-            const double l0 = (double) bl[(size_t) r0], l1 = (double) bl[(size_t) r1], l2 = (double) bl[(size_t) r2];
-            chk(vft_posterior_profiles(ctx, 1, &root, &r0, &r1, &l0, &l1));
+            const double l2 = (double) bl[(size_t) r2];
+            chk(vft_posterior_profiles_blen(ctx, 1, &root, &r0, &r1, &r0, &r1));   /* lengths from the device: the same values */
             double ll3 = 0;
             chk(vft_pair_loglk(ctx, 1, &root, &r2, &l2, &ll3, nullptr));
             total += ll3;
@@ -258,8 +258,8 @@ namespace veryfasttree {
             }
             /* the root's third branch (NJ.tcc:5138-5151): multiplied in after the range check of the root's pair */
             const int64_t r0 = child[3 * root], r1 = child[3 * root + 1], r2 = child[3 * root + 2];
-            const double l0 = (double) bl[(size_t) r0], l1 = (double) bl[(size_t) r1], l2 = (double) bl[(size_t) r2];
-            chk(vft_posterior_profiles(ctx, 1, &root, &r0, &r1, &l0, &l1));
+            const double l2 = (double) bl[(size_t) r2];
+            chk(vft_posterior_profiles_blen(ctx, 1, &root, &r0, &r1, &r0, &r1));   /* lengths from the device: the same values */
             double ll3 = 0;
             site.resize((size_t) nPos);
             chk(vft_pair_loglk(ctx, 1, &root, &r2, &l2, &ll3, site.data()));
