@@ -90,3 +90,41 @@ def test_merge_breaks_ties_by_descending_id():
     b["criterion"] = [0.5, 0.5, 0.9]
     m = merge_hits([a, b], 4)
     assert list(m["j"]) == [70, 64, 5, 9]
+
+
+def _batch_worker(rank, world, port, k, out):
+    """The batched exchange of bench.py: every rank holds [seeds][k] records, ONE all-gather gives [ranks][seeds][k]."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = G.load("wb_nt_f32")
+    keys = ["mid1.sweep0", "mid1.sweep1", "mid1.sweep2"]
+    n = len(d[keys[0] + ".crit"])
+    lo, hi = shard_range(n, rank, world)
+    mine = np.stack([_local_topk(d[key + ".crit"], d[key + ".dist"], d[key + ".weight"], lo, hi, k) for key in keys])
+    t_mine = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+    t_all = torch.zeros(world * t_mine.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(t_all, t_mine)
+    allh = t_all.numpy().view(HIT_F32).reshape(world, len(keys), k)      # vft_merge_hits_batch's input layout
+    merged = np.stack([merge_hits([allh[r, s] for r in range(world)], k) for s in range(len(keys))])
+    if rank == 0:
+        np.save(out, merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batched_exchange_of_several_seeds(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    k = 24
+    out = str(tmp_path / "merged_batch.npy")
+    mp.spawn(_batch_worker, args=(2, port, k, out), nprocs=2, join=True)
+    merged = np.load(out)
+    d = G.load("wb_nt_f32")
+    for s, key in enumerate(["mid1.sweep0", "mid1.sweep1", "mid1.sweep2"]):
+        crit = d[key + ".crit"]
+        want = d[key + ".sorted_j"]
+        want = want[crit[want] < np.float32(1e20)][:k]
+        assert np.array_equal(merged[s]["j"][:len(want)], want), key
+        assert np.array_equal(merged[s]["criterion"][:len(want)], crit[want]), key
