@@ -40,6 +40,14 @@ typedef struct {
                                    NJ.tcc:6185-6404; the reference's default is 2, 0 = `-spr 0`) */
     int32_t gtr;                /* with mllen / ml_nni: 1 = `-gtr` (the six GTR rates and the base frequencies are fitted
                                    after the first ML round, setMLGtr NJ.tcc:6436-6500; Jukes-Cantor until then) */
+    int32_t aa_model;           /* amino-acid contexts (n_codes = 20): 0 = the caller installs its own matrices
+                                   (vft_set_distance_matrix / vft_set_transition_matrix); 1 = JTT92 (the reference's
+                                   default), 2 = WAG01 (`-wag`), 3 = LG08 (`-lg`) (VeryFastTreeImpl.tcc:96-108).  With a
+                                   model the driver installs the BLOSUM45-derived distance matrix for the NJ /
+                                   minimum-evolution phase (the reference's default for proteins, DistanceMatrix.tcc:33)
+                                   with scoredist log-correction, and before the ML stage re-averages every profile in
+                                   the model's eigen-basis (transMatToDistanceMat + recomputeProfiles,
+                                   VeryFastTreeImpl.tcc:253-256, 517-542) and installs the transition matrix */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
@@ -101,6 +109,21 @@ int vft_ml_lengths(vft_ctx *ctx, int64_t n_seqs, int64_t n_nodes, int64_t n_pos,
    eigeninvT[4][4]: numeric_t values (precision 4 / 8 bytes) held in double.  Exported for tests. */
 int vft_gtr_tables(const double *rates, const double *freq, int32_t precision, double *stat, double *statinv, double *eigenval, double *codefreq,
                    double *eigeninv, double *eigeninvT);
+
+/* The built-in amino-acid models as the reference builds them (createTransitionMatrixJTT92 / WAG01 / LG08,
+   TransitionMatrix.tcc:14-24, 158-232): model 1 = JTT, 2 = WAG, 3 = LG; out: stat[20], statinv[20], eigenval[20],
+   codefreq[21][20] (last row = gap), eigeninv[20][20], eigeninvT[20][20] - numeric_t values (precision 4 / 8 bytes) held
+   in double, what vft_set_transition_matrix takes after narrowing.  Exported for tests and for callers that drive the
+   C ABI themselves. */
+int vft_aa_model_tables(int32_t model, int32_t precision, double *stat, double *statinv, double *eigenval, double *codefreq,
+                        double *eigeninv, double *eigeninvT);
+/* The default protein distance matrix (matrixBLOSUM45 + setupDistanceMatrix, DistanceMatrix.tcc:33-36, 102-155):
+   distances[20][20], codefreq[20][20], eigenval[20], eigentot[20] as vft_set_distance_matrix takes them. */
+int vft_blosum45_tables(int32_t precision, double *distances, double *codefreq, double *eigenval, double *eigentot);
+/* transMatToDistanceMat (VeryFastTreeImpl.tcc:517-542) for a built-in model: the tables recomputeProfiles averages
+   with before the ML stage (distances and eigenvalues are zero, as in the reference). */
+int vft_aa_model_as_distance_tables(int32_t model, int32_t precision, double *distances, double *codefreq, double *eigenval,
+                                    double *eigentot);
 
 #ifdef __cplusplus
 }

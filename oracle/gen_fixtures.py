@@ -86,6 +86,17 @@ def gen_knuth(tmp):
     print("%-20s %4d arrays  %7.1f KiB" % ("wb_knuth", len(d), os.path.getsize(dst) / 1024.0))
 
 
+def gen_tables(tmp):
+    """The amino-acid model tables the reference builds (JTT / WAG / LG transition tables, BLOSUM45 distance tables) in
+    both precisions; the raw constants are not stored here (they are the product's data header)."""
+    vfx = os.path.join(tmp, "tables.vfx")
+    subprocess.run([WHITEBOX, "tables", "-", vfx], check=True)
+    d = {k: v for k, v in read_vfx(vfx).items() if ".raw." not in k}
+    dst = os.path.join(GOLDEN, "wb_aa_tables.npz")
+    np.savez_compressed(dst, **d)
+    print("%-20s %4d arrays  %7.1f KiB" % ("wb_aa_tables", len(d), os.path.getsize(dst) / 1024.0))
+
+
 BLACKBOX_CASES = [
     # name, flags, n_seq, n_pos, n_codes, mu, gap, seed
     ("bb_nt_c1", ["-nt", "-fastest"], 16, 100, 4, 0.05, 0.0, 1),  # BASELINE config 1
@@ -269,9 +280,65 @@ def gen_mlnni(tmp):
         print("%-22s %2d ML NNI rounds %4d ML NNIs %4d ME NNIs  final logLk %.4f" % (name, len(ll) - 1, int(m.group(3)), int(m.group(1)), ll[-1]))
 
 
+AA_CASES = [
+    # name, kind, flags, n_seq, n_pos, mu, gap, seed.  Protein alignments (BASELINE config C5's path): the BLOSUM45-derived
+    # distances in the NJ / ME phase, JTT (default) / WAG / LG + CAT in the ML phase.
+    ("nni_aa_150", "menni", ["-spr", "2"], 150, 80, 0.10, 0.03, 61),                       # -noml: ME NNIs + SPRs, scoredist
+    ("ml_aa_100_lg_double", "mllen", ["-lg", "-double-precision"], 100, 90, 0.10, 0.03, 62),   # -nome -mllen
+    ("ml_aa_120_jtt", "mllen", [], 120, 70, 0.12, 0.04, 63),
+    ("ml_aa_80_wag_nocat", "mllen", ["-wag", "-nocat"], 80, 60, 0.10, 0.02, 64),
+    ("full_aa_120_lg_double", "mlnni", ["-lg", "-double-precision"], 120, 100, 0.10, 0.03, 65),   # C5's exact flags
+    ("full_aa_150_lg", "mlnni", ["-lg"], 150, 80, 0.12, 0.04, 66),
+    ("full_aa_100_jtt", "mlnni", [], 100, 90, 0.10, 0.03, 67),                              # the reference's protein default
+    ("full_aa_90_wag_double", "mlnni", ["-wag", "-double-precision"], 90, 70, 0.08, 0.05, 68),
+]
+
+
+def gen_aa(tmp):
+    """Black box, proteins: the same three kinds of runs as gen_menni / gen_mllen / gen_mlnni."""
+    for name, kind, flags, n, L, mu, gap, seed in AA_CASES:
+        codes = synth.random_descent_codes(n, L, 20, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA)
+        log = os.path.join(tmp, name + ".log")
+        base = [REFBIN] + flags + ["-threads", "1", "-seed", "1"]
+        if kind == "menni":
+            base += ["-noml"]
+        elif kind == "mllen":
+            base += ["-nome", "-mllen"]
+        res = subprocess.run(base + ["-nosupport", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        text = open(log).read()
+        err = res.stderr.decode(errors="replace") + text
+        res2 = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        out = dict(codes=codes, newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                   newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
+                   flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        m = re.search(r"^NNI: (\d+) SPR: (\d+)(?: ML-NNI: (\d+))?", err, re.M)
+        nni, nspr = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        out["n_me_nni"], out["n_spr"] = np.int64(nni), np.int64(nspr)
+        if kind == "mllen":
+            ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\tLength\d+\t(\S+)\tMaxChange", text, re.M)]
+        elif kind == "mlnni":
+            ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\tML_NNI\d+\t(\S+)\tMaxChange", text, re.M)]
+            ll.append(float(re.search(r"^TreeLogLk\tML_Lengths2\t(\S+)", text, re.M).group(1)))
+            out["n_ml_nni"] = np.int64(m.group(3))
+        else:
+            ll = []
+        out["loglk"] = np.array(ll)
+        if kind != "menni":
+            out["rates"] = np.array([float(x) for x in re.search(r"^Rates((?: \S+)+)$", text, re.M).group(1).split()])
+            out["ratecat"] = np.array([int(x) - 1 for x in re.search(r"^SiteCategories((?: \d+)+)$", text, re.M).group(1).split()], dtype=np.int32)
+            mb = re.search(r"Bad splits: (\d+)/(\d+)", res2.stderr.decode(errors="replace"))
+            out["bad_splits"] = np.array([int(mb.group(1)), int(mb.group(2))], dtype=np.int64)
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, **out)
+        print("%-24s %-6s NNI %3d SPR %2d  loglk %s  %6.1f KiB" % (name, kind, nni, nspr,
+                                                                    " ".join("%.3f" % x for x in ll[-2:]), os.path.getsize(dst) / 1024.0))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "mllen", "menni", "mlnni"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -279,12 +346,16 @@ def main():
             gen_blackbox(tmp)
         if "knuth" in which:
             gen_knuth(tmp)
+        if "tables" in which:
+            gen_tables(tmp)
         if "mllen" in which:
             gen_mllen(tmp)
         if "menni" in which:
             gen_menni(tmp)
         if "mlnni" in which:
             gen_mlnni(tmp)
+        if "aa" in which:
+            gen_aa(tmp)
 
 
 if __name__ == "__main__":

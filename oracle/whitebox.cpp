@@ -636,6 +636,86 @@ static int run(Options &options, const std::string &fasta, const std::string &ou
     return 0;
 }
 
+/* Model constants and the tables the reference derives from them (TransitionMatrix.tcc:14-24, 158-232;
+   DistanceMatrix.tcc:33-36, 102-155), for the product's data header (tools/gen_aa_tables.py) and its CPU test. */
+template<typename P, int ALIGN>
+static void dumpModelTables(Dump &d, const Options &options, const std::string &suffix) {
+    const int n = 20;
+    for (int model = 0; model < 3; model++) {
+        TransitionMatrix<P, ALIGN> t;
+        const char *name = model == 0 ? "jtt" : model == 1 ? "wag" : "lg";
+        if (model == 0) t.createTransitionMatrixJTT92(options);
+        else if (model == 1) t.createTransitionMatrixWAG01(options);
+        else t.createTransitionMatrixLG08(options);
+        std::vector<P> stat(t.stat, t.stat + n), statinv(t.statinv, t.statinv + n), eval(t.eigenval, t.eigenval + n);
+        std::vector<P> cf((size_t) (n + 1) * n), einv((size_t) n * n), einvT((size_t) n * n);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < n; k++) {
+                cf[i * n + k] = t.codeFreq[i][k];
+                einv[i * n + k] = t.eigeninv[i][k];
+                einvT[i * n + k] = t.eigeninvT[i][k];
+            }
+        for (int k = 0; k < n; k++) cf[n * n + k] = t.codeFreq[NOCODE][k];
+        const std::string pre = std::string(name) + "." + suffix + ".";
+        d.vec(pre + "stat", stat);
+        d.vec(pre + "statinv", statinv);
+        d.vec(pre + "eigenval", eval);
+        d.mat(pre + "codefreq", cf, n + 1, n);
+        d.mat(pre + "eigeninv", einv, n, n);
+        d.mat(pre + "eigeninvT", einvT, n, n);
+    }
+    DistanceMatrix<P, ALIGN> dm;
+    std::ostringstream log;
+    dm.matrixBLOSUM45();
+    dm.setupDistanceMatrix(options, log);
+    std::vector<P> dd((size_t) n * n), ei((size_t) n * n), cf((size_t) n * n), ev(dm.eigenval, dm.eigenval + n),
+            et(dm.eigentot, dm.eigentot + n);
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < n; k++) {
+            dd[i * n + k] = dm.distances[i][k];
+            ei[i * n + k] = dm.eigeninv[i][k];
+            cf[i * n + k] = dm.codeFreq[i][k];
+        }
+    d.mat("blosum45." + suffix + ".distances", dd, n, n);
+    d.mat("blosum45." + suffix + ".eigeninv", ei, n, n);
+    d.mat("blosum45." + suffix + ".codefreq", cf, n, n);
+    d.vec("blosum45." + suffix + ".eigenval", ev);
+    d.vec("blosum45." + suffix + ".eigentot", et);
+}
+
+static int dumpTables(const char *path) {
+    Dump d(path);
+    Options options;
+    options.nCodes = 20;
+    const int n = 20;
+    typedef TransitionMatrix<double, 32> TM;
+    const double *stats[3] = {TM::statJTT92, TM::statWAG01, TM::statLG08};
+    const double (*mats[3])[MAXCODES] = {TM::matrixJTT92, TM::matrixWAG01, TM::matrixLG08};
+    const char *names[3] = {"jtt", "wag", "lg"};
+    for (int m = 0; m < 3; m++) {
+        std::vector<double> st(stats[m], stats[m] + n), mx((size_t) n * n);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < n; k++) mx[i * n + k] = mats[m][i][k];
+        d.vec(std::string(names[m]) + ".raw.stat", st);
+        d.mat(std::string(names[m]) + ".raw.matrix", mx, n, n);
+    }
+    {   /* BLOSUM45 as shipped: distances, eigeninv, eigenval (double literals; the float build narrows them) */
+        const DistanceMatrix<double, 32> &b = DistanceMatrix<double, 32>::_matrixBLOSUM45;
+        std::vector<double> dd((size_t) n * n), ei((size_t) n * n), ev(b.eigenval, b.eigenval + n);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < n; k++) {
+                dd[i * n + k] = b.distances[i][k];
+                ei[i * n + k] = b.eigeninv[i][k];
+            }
+        d.mat("blosum45.raw.distances", dd, n, n);
+        d.mat("blosum45.raw.eigeninv", ei, n, n);
+        d.vec("blosum45.raw.eigenval", ev);
+    }
+    dumpModelTables<float, 16>(d, options, "f32");    /* SSE128Operations::ALIGNMENT */
+    dumpModelTables<double, 32>(d, options, "f64");   /* AVX256Operations::ALIGNMENT */
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) {
         fprintf(stderr, "usage: whitebox <nt_f32|nt_f64|aa_f32|aa_f64> <fasta> <out.vfx> [seed]\n");
@@ -649,6 +729,7 @@ int main(int argc, char **argv) {
         d.vec("knuth.rand", r);
         return 0;
     }
+    if (mode == "tables") return dumpTables(argv[3]);
     uint64_t seed = argc > 4 ? strtoull(argv[4], nullptr, 10) : 1;
     omp_set_num_threads(1);
 

@@ -36,7 +36,7 @@ def test_host_driver_library_exports_its_header(lib):
     host = backend.load_host_library()
     text = open(os.path.join(ROOT, "include", "vft_host.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth|ml|gtr)_[a-z0-9_]+)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth|ml|gtr|aa|blosum45)_[a-z0-9_]+)\s*\(", text)))
     assert names == sorted(backend.HOST_EXPORTS)
     assert all(hasattr(host, n) for n in names)
 
@@ -89,3 +89,37 @@ def test_gtr_tables_equal_the_references():
             want = d["gtr.tm." + key]
             got = t[key].astype(dt).reshape(want.shape)
             assert np.array_equal(got, want), (name, key, got, want)
+
+
+def test_amino_acid_model_tables_equal_the_references():
+    """JTT92 / WAG01 / LG08 (host/AAModels.h: constants + eigen-decomposition) and the BLOSUM45-derived distance matrix
+    against the tables the reference builds (createTransitionMatrix{JTT92,WAG01,LG08}, matrixBLOSUM45 +
+    setupDistanceMatrix; tests/golden/wb_aa_tables.npz), bit for bit in both precisions; and the transition matrix in the
+    distance-matrix slots (transMatToDistanceMat, VeryFastTreeImpl.tcc:517-542)."""
+    import golden_util as G
+    from veryfasttree_amd import backend
+    d = G.load("wb_aa_tables")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        for model in ("jtt", "wag", "lg"):
+            t = backend.aa_model_tables(model, dt)
+            for key in ("stat", "statinv", "eigenval", "codefreq", "eigeninv", "eigeninvT"):
+                want = d["%s.%s.%s" % (model, tag, key)]
+                assert want.dtype == dt
+                got = t[key].astype(dt).reshape(want.shape)
+                assert np.array_equal(got, want), (model, tag, key)
+            # transMatToDistanceMat: codeFreq rows of the 20 codes, eigentot = row sums of eigeninv in numeric_t
+            td = backend.distance_tables(model, dt)
+            assert np.array_equal(td["codefreq"].astype(dt), d["%s.%s.codefreq" % (model, tag)][:20])
+            tot = np.zeros(20, dt)
+            for j in range(20):
+                tot = (tot + d["%s.%s.eigeninv" % (model, tag)][:, j]).astype(dt)
+            assert np.array_equal(td["eigentot"].astype(dt), tot)
+            assert not td["distances"].any() and not td["eigenval"].any()
+        b = backend.distance_tables(None, dt)
+        for key in ("distances", "codefreq", "eigenval", "eigentot"):
+            want = d["blosum45.%s.%s" % (tag, key)]
+            assert np.array_equal(b[key].astype(dt).reshape(want.shape), want), (tag, key)
+    # the white-box fixtures of round 1 carry the same BLOSUM45 / LG tables: cross-check
+    w = G.load("wb_aa_f64")
+    assert np.array_equal(backend.distance_tables(None, np.float64)["codefreq"], w["dmat.codefreq"])
+    assert np.array_equal(backend.aa_model_tables("lg", np.float64)["codefreq"], w["lg.tm.codefreq"])

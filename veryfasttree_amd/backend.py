@@ -42,14 +42,15 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables"]
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
+                "vft_aa_model_tables", "vft_blosum45_tables", "vft_aa_model_as_distance_tables"]
 
 
 class _NJOptions(C.Structure):
     _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
                 ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
-                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32)]
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32)]
 
 
 _lib = None
@@ -67,7 +68,10 @@ def load_host_library():
     return _host_lib
 
 
-def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False):
+AA_MODELS = {None: 0, "": 0, "jtt": 1, "wag": 2, "lg": 3}
+
+
+def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False, aa_model=None):
     """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n]).
     second_level defaults to `fastest`, as in the reference at one thread (-fastest turns -2nd on)."""
     lib = load_host_library()
@@ -77,7 +81,7 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0,
                      tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
-                     200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0)
+                     200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0, AA_MODELS[aa_model])
     joins = np.zeros((max(n - 3, 1), 3), np.int64)
     crit = np.zeros(max(n - 3, 1), np.float64)
     nj = I64(0)
@@ -123,6 +127,34 @@ def gtr_tables(rates, freq, dtype=np.float32):
     return out
 
 
+def aa_model_tables(model, dtype=np.float32):
+    """The built-in amino-acid model `model` ("jtt" / "wag" / "lg") as the host driver builds it (host/AAModels.h): dict of
+    stat, statinv, eigenval, codefreq[21,20], eigeninv[20,20], eigeninvT[20,20] in double."""
+    lib = load_host_library()
+    out = dict(stat=np.zeros(20), statinv=np.zeros(20), eigenval=np.zeros(20), codefreq=np.zeros((21, 20)),
+               eigeninv=np.zeros((20, 20)), eigeninvT=np.zeros((20, 20)))
+    rc = lib.vft_aa_model_tables(I32(AA_MODELS[model]), I32(np.dtype(dtype).itemsize), _ptr(out["stat"]), _ptr(out["statinv"]),
+                                 _ptr(out["eigenval"]), _ptr(out["codefreq"]), _ptr(out["eigeninv"]), _ptr(out["eigeninvT"]))
+    if rc != 0:
+        raise VftError("vft_aa_model_tables failed")
+    return out
+
+
+def distance_tables(model=None, dtype=np.float32):
+    """model None: the BLOSUM45-derived distance matrix (vft_blosum45_tables); else the model's transition matrix in the
+    distance-matrix slots (vft_aa_model_as_distance_tables).  dict of distances, codefreq [20,20], eigenval, eigentot."""
+    lib = load_host_library()
+    out = dict(distances=np.zeros((20, 20)), codefreq=np.zeros((20, 20)), eigenval=np.zeros(20), eigentot=np.zeros(20))
+    args = (_ptr(out["distances"]), _ptr(out["codefreq"]), _ptr(out["eigenval"]), _ptr(out["eigentot"]))
+    if model is None:
+        rc = lib.vft_blosum45_tables(I32(np.dtype(dtype).itemsize), *args)
+    else:
+        rc = lib.vft_aa_model_as_distance_tables(I32(AA_MODELS[model]), I32(np.dtype(dtype).itemsize), *args)
+    if rc != 0:
+        raise VftError("distance tables failed")
+    return out
+
+
 def uniquify(codes):
     """First-occurrence uniquify of alignment rows (Uniquify, Alignment.cpp:494-526).
     Returns (unique_first[u] = row of unique sequence u, aln_next[k] = next row with the same sequence or -1)."""
@@ -141,7 +173,8 @@ def uniquify(codes):
 
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
-              unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False):
+              unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False,
+              aa_model=None):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -158,7 +191,8 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     if second_level is None:
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
-                     200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0)
+                     200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0,
+                     AA_MODELS[aa_model])
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)

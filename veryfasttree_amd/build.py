@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 HOST_LIB = os.path.join(HERE, "lib", "libvft_host.so")
 HOST_SOURCES = [os.path.join(HERE, "host", "nj_driver.cpp")]
-HOST_DEPS = HOST_SOURCES + [os.path.join(HERE, "host", h) for h in ("NJDriver.h", "MLLengths.h", "KnuthRng.h", "GtrModel.h")] + \
+HOST_DEPS = HOST_SOURCES + [os.path.join(HERE, "host", h) for h in ("NJDriver.h", "MLLengths.h", "KnuthRng.h", "GtrModel.h", "AAModels.h", "AAModelData.h")] + \
     [os.path.join(HERE, "..", "include", "vft_host.h"), os.path.join(HERE, "..", "include", "vft_hip.h")]
 
 

@@ -12,11 +12,13 @@
 
 namespace veryfasttree {
 
-    struct TransitionTables4 {
-        double stat[4], statinv[4], eigenval[4];
-        double codeFreq[5][4];   /* row 4 = NOCODE */
-        double eigeninv[4][4], eigeninvT[4][4];
+    template<int N>
+    struct TransitionTables {
+        double stat[N], statinv[N], eigenval[N];
+        double codeFreq[N + 1][N];   /* row N = NOCODE */
+        double eigeninv[N][N], eigeninvT[N][N];
     };
+    typedef TransitionTables<4> TransitionTables4;
 
     namespace gtr_detail {
         inline double hypot2(double a, double b) {   /* sqrt(a^2 + b^2) without overflow, as the reference's pythag */
@@ -140,9 +142,54 @@ namespace veryfasttree {
         }
     }
 
-    /* rates: ac ag at cg ct gt; freq: A C G T.  REAL = numeric_t: the reference stores its tables in numeric_t and sums
-       the gap row from the stored values in numeric_t (TransitionMatrix.tcc:218-226), so the tables come back already
-       narrowed (held in double) */
+    /* createTransitionMatrix (TransitionMatrix.tcc:158-232) for any alphabet: matrix[i][j] off-diagonal rates (the
+       diagonal is ignored and set so that columns sum to 0), stat the stationary distribution.  REAL = numeric_t: the
+       reference stores its tables in numeric_t and sums the gap row from the stored values in numeric_t
+       (TransitionMatrix.tcc:218-226), so the tables come back already narrowed (held in double) */
+    template<typename REAL, int N>
+    inline void createTransitionTables(const double matrix[N][N], const double stat[N], TransitionTables<N> &t) {
+        const int n = N;
+        double sqrtstat[N];
+        for (int i = 0; i < n; i++) {
+            t.stat[i] = stat[i];
+            t.statinv[i] = 1.0 / stat[i];
+            sqrtstat[i] = std::sqrt(stat[i]);
+        }
+        double sym[N * N];
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) sym[n * i + j] = matrix[i][j];
+        for (int j = 0; j < n; j++) {   /* diagonals so that the columns sum to 0 */
+            double sum = 0;
+            sym[n * j + j] = 0;
+            for (int i = 0; i < n; i++) sum += sym[n * i + j];
+            sym[n * j + j] = -sum;
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) sym[n * i + j] *= sqrtstat[j] / sqrtstat[i];
+        double w[N * N], eval[N], e[N];
+        for (int i = 0; i < n * n; i++) w[i] = sym[i];
+        gtr_detail::tridiagonalise(w, n, eval, e);
+        gtr_detail::implicitQL(eval, e, n, w);
+        for (int i = 0; i < n; i++) {
+            t.stat[i] = (double) (REAL) t.stat[i];
+            t.statinv[i] = (double) (REAL) t.statinv[i];
+            t.eigenval[i] = (double) (REAL) eval[i];
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                t.eigeninv[i][j] = (double) (REAL) (w[n * i + j] / sqrtstat[j]);
+                t.eigeninvT[j][i] = t.eigeninv[i][j];
+            }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) t.codeFreq[i][j] = (double) (REAL) (w[j * n + i] * sqrtstat[i]);
+        for (int j = 0; j < n; j++) {
+            REAL acc = 0;
+            for (int i = 0; i < n; i++) acc += (REAL) t.codeFreq[i][j];
+            t.codeFreq[n][j] = (double) acc;
+        }
+    }
+
+    /* createGTR (TransitionMatrix.tcc:26-60).  rates: ac ag at cg ct gt; freq: A C G T */
     template<typename REAL>
     inline void createGTR(const double rates[6], const double freq[4], TransitionTables4 &t) {
         const int n = 4;
@@ -163,45 +210,7 @@ namespace veryfasttree {
         const double inv = 1.0 / total;
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) matrix[i][j] *= inv;
-        /* createTransitionMatrix */
-        double sqrtstat[4];
-        for (int i = 0; i < n; i++) {
-            t.stat[i] = freq[i];
-            t.statinv[i] = 1.0 / freq[i];
-            sqrtstat[i] = std::sqrt(freq[i]);
-        }
-        double sym[16];
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) sym[n * i + j] = matrix[i][j];
-        for (int j = 0; j < n; j++) {   /* diagonals so that the columns sum to 0 */
-            double sum = 0;
-            sym[n * j + j] = 0;
-            for (int i = 0; i < n; i++) sum += sym[n * i + j];
-            sym[n * j + j] = -sum;
-        }
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) sym[n * i + j] *= sqrtstat[j] / sqrtstat[i];
-        double w[16], eval[4], e[4];
-        for (int i = 0; i < n * n; i++) w[i] = sym[i];
-        gtr_detail::tridiagonalise(w, n, eval, e);
-        gtr_detail::implicitQL(eval, e, n, w);
-        for (int i = 0; i < n; i++) {
-            t.stat[i] = (double) (REAL) t.stat[i];
-            t.statinv[i] = (double) (REAL) t.statinv[i];
-            t.eigenval[i] = (double) (REAL) eval[i];
-        }
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) {
-                t.eigeninv[i][j] = (double) (REAL) (w[n * i + j] / sqrtstat[j]);
-                t.eigeninvT[j][i] = t.eigeninv[i][j];
-            }
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) t.codeFreq[i][j] = (double) (REAL) (w[j * n + i] * sqrtstat[i]);
-        for (int j = 0; j < n; j++) {
-            REAL acc = 0;
-            for (int i = 0; i < n; i++) acc += (REAL) t.codeFreq[i][j];
-            t.codeFreq[4][j] = (double) acc;
-        }
+        createTransitionTables<REAL, 4>(matrix, freq, t);
     }
 
 }

@@ -97,10 +97,66 @@ namespace veryfasttree {
             }
         }
 
+        /* exp in place with the reference's four accuracy levels (`-fastexp`, BasicOperations.tcc:122-216): 0 = libm in
+           double, 1 = libm in float, 2 / 3 = the Cephes rational approximation e^x = 2^m (1 + 2 r P(r^2) / (Q(r^2) - r P(r^2)))
+           evaluated in double / float with the power of two assembled from exponent bits.  The device kernels build
+           their P(t) tables at level 0 (the reference's default). */
         inline void fastexp(numeric_t fTot[], int64_t n, int lvl) {
-            (void) lvl; /* level 0 semantics (BasicOperations.tcc:123-127); the device builds its own P(t) tables */
-            for (int64_t k = 0; k < n; k++) fTot[k] = (numeric_t) std::exp((double) fTot[k]);
+            if (lvl == 0) {
+                for (int64_t k = 0; k < n; k++) fTot[k] = (numeric_t) std::exp((double) fTot[k]);
+            } else if (lvl == 1) {
+                for (int64_t k = 0; k < n; k++) fTot[k] = (numeric_t) std::exp((float) fTot[k]);
+            } else if (lvl == 2) {
+                for (int64_t k = 0; k < n; k++) {
+                    int64_t m;
+                    const double mant = cephesMantissa<double, int64_t>((double) fTot[k], m);
+                    union { double d; int64_t i; } u;
+                    u.i = (m + 1023) << 52;
+                    fTot[k] = (numeric_t) mant * u.d;
+                }
+            } else {
+                for (int64_t k = 0; k < n; k++) {
+                    int32_t m;
+                    const float mant = cephesMantissa<float, int32_t>((float) fTot[k], m);
+                    union { float f; int32_t i; } u;
+                    u.i = (m + 127) << 23;
+                    fTot[k] = (numeric_t) mant * u.f;
+                }
+            }
         }
+
+    private:
+        /* range reduction x = m ln2 + r (ln2 split in two constants), then the rational approximation, every step in T:
+           returns e^r, m by reference.  The operation order is the reference's (Horner in r^2), so results are
+           bit-identical to BasicOperations::fastexp. */
+        template<typename T, typename I>
+        static inline T cephesMantissa(T x, I &m) {
+            const T log2e = (T) 1.4426950408889634073599, ln2hi = (T) 6.93145751953125E-1, ln2lo = (T) 1.42860682030941723212E-6;
+            const T P[3] = {(T) 1.26177193074810590878E-4, (T) 3.02994407707441961300E-2, (T) 9.99999999999999999910E-1};
+            const T Q[4] = {(T) 3.00198505138664455042E-6, (T) 2.52448340349684104192E-3, (T) 2.27265548208155028766E-1,
+                            (T) 2.00000000000000000009E0};
+            const T fl = std::floor(log2e * x + (T) 0.5);
+            m = (I) fl;
+            x -= fl * ln2hi;
+            x -= fl * ln2lo;
+            const T xx = x * x;
+            T px = P[0];
+            for (int i = 1; i < 3; i++) {
+                px *= xx;
+                px += P[i];
+            }
+            px *= x;
+            T qx = Q[0];
+            for (int i = 1; i < 4; i++) {
+                qx *= xx;
+                qx += Q[i];
+            }
+            x = px / (qx - px);
+            x = (T) (1.0 + 2.0 * x);   /* in double, then narrowed: the reference's literals are double */
+            return x;
+        }
+
+    public:
 
         /* ---- batched extension: device-resident profiles.  Errors surface as std::invalid_argument so that the
            reference's main() reports them cleanly (main.cpp:673-678 only catches that type). */

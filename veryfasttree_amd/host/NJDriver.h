@@ -32,6 +32,7 @@
 #include "../../include/vft_hip.h"
 #include "MLLengths.h"
 #include "KnuthRng.h"
+#include "AAModels.h"
 
 namespace veryfasttree {
 
@@ -50,6 +51,9 @@ namespace veryfasttree {
         /* logCorrect of the minimum-evolution lengths: scoredist-like instead of Jukes-Cantor (amino acids / matrix) */
         bool meNNI = false;
         bool scoredist = false;
+        /* amino acids: 0 = matrices are the caller's business, else AAModel (JTT / WAG / LG): BLOSUM45-derived distances in
+           the NJ / ME phase, the model's transition matrix in the ML phase (VeryFastTreeImpl.tcc:96-108, 253-256) */
+        int aaModel = 0;
     };
 
     template<typename REAL>
@@ -78,6 +82,7 @@ namespace veryfasttree {
                 }
                 selfweightLeaf[i] = (REAL) c;
             }
+            if (opt.aaModel) installBlosum45();
             /* NJ constructor, NJ.tcc:233-260 */
             chkT("vft_upload_leaves", [&]() { return vft_upload_leaves(ctx, codes); });
             std::vector<REAL> z(nSeqs, 0);
@@ -446,13 +451,23 @@ namespace veryfasttree {
             double nonGap = 0;
             for (int64_t i = 0; i < nSeqs; i++) nonGap += (double) selfweightLeaf[(size_t) i];
             int64_t nLeafGaps = nSeqs * nPos - (int64_t) nonGap;   /* -1 once a transition matrix is installed */
-            chkT("vft_set_transition_matrix", [&]() { return vft_set_transition_matrix(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); });
+            if (opt.aaModel) {
+                if (gtr) throw std::invalid_argument("NJDriver::mlLengths: -gtr is a nucleotide model");
+                nLeafGaps = -1;   /* treeLogLk's gap correction is Jukes-Cantor only (NJ.tcc:5236) */
+            } else {
+                chkT("vft_set_transition_matrix", [&]() { return vft_set_transition_matrix(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); });
+            }
             MLLengths<REAL> ml(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             upReady = false;   /* the up-profile slots now hold ML up-profiles */
             ml.setLengths(branchlength.data());
             /* recomputeProfiles(tmatAsDist) (VeryFastTreeImpl.tcc:253-256): plain re-averaging under Jukes-Cantor - the
-               identity straight after fastNJ, needed after minimum-evolution NNIs (they leave some profiles stale) */
-            if (reaverage) ml.recomputeAverageProfiles();
+               identity straight after fastNJ, needed after minimum-evolution NNIs (they leave some profiles stale).  With
+               an amino-acid model the averages move from the BLOSUM45 eigen-basis into the model's (transMatToDistanceMat,
+               VeryFastTreeImpl.tcc:517-542), so every internal profile is rebuilt from the leaves up. */
+            if (opt.aaModel) {
+                installAAModel();
+                ml.recomputeAverageProfiles();
+            } else if (reaverage) ml.recomputeAverageProfiles();
             std::vector<double> loglk;
             const char *pl = std::getenv("VFT_ML_PARALLEL_LENGTHS");
             const bool parallelLengths = pl && pl[0] == '1';
@@ -642,6 +657,49 @@ namespace veryfasttree {
 
         void chk(int rc) {
             if (rc != VFT_OK) throw std::invalid_argument(std::string("NJDriver: ") + vft_last_error(ctx));
+        }
+
+        /* the reference's default distance matrix for proteins (VeryFastTree.cpp:96-98 keeps useMatrix on for 20 codes;
+           matrixBLOSUM45 + setupDistanceMatrix) */
+        void installBlosum45() {
+            DistanceTables20 d;
+            blosum45Tables<REAL>(d);
+            installDistanceTables(d);
+        }
+
+        void installDistanceTables(const DistanceTables20 &d) {
+            REAL dist[400], cf[400], ev[20], et[20];
+            for (int i = 0; i < 20; i++) {
+                ev[i] = (REAL) d.eigenval[i];
+                et[i] = (REAL) d.eigentot[i];
+                for (int j = 0; j < 20; j++) {
+                    dist[20 * i + j] = (REAL) d.distances[i][j];
+                    cf[20 * i + j] = (REAL) d.codeFreq[i][j];
+                }
+            }
+            chkT("vft_set_distance_matrix", [&]() { return vft_set_distance_matrix(ctx, dist, cf, ev, et); });
+        }
+
+        /* before the ML stage: the transition matrix as the averaging basis, then as the likelihood model */
+        void installAAModel() {
+            TransitionTables20 t;
+            createAAModel<REAL>(opt.aaModel, t);
+            DistanceTables20 d;
+            transitionAsDistanceTables<REAL>(t, d);
+            installDistanceTables(d);
+            REAL stat[20], statinv[20], eval[20], cf[21 * 20], ei[400], eiT[400];
+            for (int i = 0; i < 20; i++) {
+                stat[i] = (REAL) t.stat[i];
+                statinv[i] = (REAL) t.statinv[i];
+                eval[i] = (REAL) t.eigenval[i];
+                for (int j = 0; j < 20; j++) {
+                    ei[20 * i + j] = (REAL) t.eigeninv[i][j];
+                    eiT[20 * i + j] = (REAL) t.eigeninvT[i][j];
+                }
+            }
+            for (int i = 0; i < 21; i++)
+                for (int j = 0; j < 20; j++) cf[20 * i + j] = (REAL) t.codeFreq[i][j];
+            chkT("vft_set_transition_matrix", [&]() { return vft_set_transition_matrix(ctx, stat, statinv, eval, cf, ei, eiT); });
         }
 
         /* optional per-entry-point wall-clock accounting (VFT_NJ_PROFILE=1) */

@@ -12,6 +12,7 @@
 #include "KnuthRng.h"
 #include "MLLengths.h"
 #include "GtrModel.h"
+#include "AAModels.h"
 
 static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
@@ -28,7 +29,8 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.tophits2Safety = o->tophits2_safety;
         opt.tophits2Mult = o->tophits2_mult;
         opt.tophits2Refresh = o->tophits2_refresh;
-        opt.scoredist = o->scoredist != 0;
+        opt.scoredist = o->scoredist != 0 || o->aa_model != 0;
+        opt.aaModel = o->aa_model;
     }
     return opt;
 }
@@ -191,6 +193,77 @@ extern "C" int vft_gtr_tables(const double *rates, const double *freq, int32_t p
         }
         for (int i = 0; i < 5; i++)
             for (int j = 0; j < 4; j++) codefreq[4 * i + j] = t.codeFreq[i][j];
+        return VFT_OK;
+    } catch (const std::exception &) {
+        return VFT_ERR_INVALID;
+    }
+}
+
+template<typename REAL>
+static void aaModelOut(const veryfasttree::TransitionTables20 &t, double *stat, double *statinv, double *eigenval, double *codefreq,
+                       double *eigeninv, double *eigeninvT) {
+    for (int i = 0; i < 20; i++) {
+        stat[i] = t.stat[i];
+        statinv[i] = t.statinv[i];
+        eigenval[i] = t.eigenval[i];
+        for (int j = 0; j < 20; j++) {
+            eigeninv[20 * i + j] = t.eigeninv[i][j];
+            eigeninvT[20 * i + j] = t.eigeninvT[i][j];
+        }
+    }
+    for (int i = 0; i < 21; i++)
+        for (int j = 0; j < 20; j++) codefreq[20 * i + j] = t.codeFreq[i][j];
+}
+
+extern "C" int vft_aa_model_tables(int32_t model, int32_t precision, double *stat, double *statinv, double *eigenval, double *codefreq,
+                                   double *eigeninv, double *eigeninvT) {
+    if (!stat || !statinv || !eigenval || !codefreq || !eigeninv || !eigeninvT) return VFT_ERR_INVALID;
+    try {
+        veryfasttree::TransitionTables20 t;
+        if (precision == 8) veryfasttree::createAAModel<double>(model, t);
+        else veryfasttree::createAAModel<float>(model, t);
+        aaModelOut<double>(t, stat, statinv, eigenval, codefreq, eigeninv, eigeninvT);
+        return VFT_OK;
+    } catch (const std::exception &) {
+        return VFT_ERR_INVALID;
+    }
+}
+
+static void distanceTablesOut(const veryfasttree::DistanceTables20 &d, double *distances, double *codefreq, double *eigenval,
+                              double *eigentot) {
+    for (int i = 0; i < 20; i++) {
+        eigenval[i] = d.eigenval[i];
+        eigentot[i] = d.eigentot[i];
+        for (int j = 0; j < 20; j++) {
+            distances[20 * i + j] = d.distances[i][j];
+            codefreq[20 * i + j] = d.codeFreq[i][j];
+        }
+    }
+}
+
+extern "C" int vft_blosum45_tables(int32_t precision, double *distances, double *codefreq, double *eigenval, double *eigentot) {
+    if (!distances || !codefreq || !eigenval || !eigentot) return VFT_ERR_INVALID;
+    veryfasttree::DistanceTables20 d;
+    if (precision == 8) veryfasttree::blosum45Tables<double>(d);
+    else veryfasttree::blosum45Tables<float>(d);
+    distanceTablesOut(d, distances, codefreq, eigenval, eigentot);
+    return VFT_OK;
+}
+
+extern "C" int vft_aa_model_as_distance_tables(int32_t model, int32_t precision, double *distances, double *codefreq,
+                                               double *eigenval, double *eigentot) {
+    if (!distances || !codefreq || !eigenval || !eigentot) return VFT_ERR_INVALID;
+    try {
+        veryfasttree::TransitionTables20 t;
+        veryfasttree::DistanceTables20 d;
+        if (precision == 8) {
+            veryfasttree::createAAModel<double>(model, t);
+            veryfasttree::transitionAsDistanceTables<double>(t, d);
+        } else {
+            veryfasttree::createAAModel<float>(model, t);
+            veryfasttree::transitionAsDistanceTables<float>(t, d);
+        }
+        distanceTablesOut(d, distances, codefreq, eigenval, eigentot);
         return VFT_OK;
     } catch (const std::exception &) {
         return VFT_ERR_INVALID;
