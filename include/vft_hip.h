@@ -251,6 +251,11 @@ int vft_ml_eval_count(vft_ctx *ctx, int64_t *evals);
 int vft_split_supports(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, const int64_t *c, const int64_t *d,
                        int32_t n_boot, const int32_t *col, double *support);
 
+/* Diagnostics: out[i] = log(x[i]) evaluated on the device the way the ML kernels evaluate the final logarithm of a
+   float-precision matrix-model pairLogLk - glibc 2.35's algorithm (csrc/vft_glibc_log.h), not the device math library.
+   x, out: host arrays of n doubles (positive, normal). */
+int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
+
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */
 int vft_timer_start(vft_ctx *ctx);
 int vft_timer_stop_ms(vft_ctx *ctx, float *ms);

@@ -110,11 +110,15 @@ BLACKBOX_CASES = [
     ("bb_nt_10", ["-nt"], 10, 60, 4, 0.15, 0.02, 26),
     ("bb_nt_5", ["-nt"], 5, 40, 4, 0.2, 0.0, 27),
     ("bb_nt_12_fastest", ["-nt", "-fastest"], 12, 50, 4, 0.15, 0.05, 28),
+    # top hits switched off on an input with more nodes than the device's sorted-hit buffer (8192): allhits[] in full
+    ("bb_nt_4400_notop", ["-nt", "-notop"], 4400, 64, 4, 0.08, 0.02, 29),
 ]
 
 
-def gen_blackbox(tmp):
+def gen_blackbox(tmp, only=None):
     for name, flags, n, L, nc, mu, gap, seed in BLACKBOX_CASES:
+        if only and name not in only:
+            continue
         codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
         fa = os.path.join(tmp, name + ".fa")
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if nc == 20 else synth.ALPHABET_NT)
@@ -344,6 +348,8 @@ def main():
             gen_whitebox(tmp)
         if "blackbox" in which:
             gen_blackbox(tmp)
+        if any(w.startswith("bb_") for w in which):
+            gen_blackbox(tmp, [w for w in which if w.startswith("bb_")])
         if "knuth" in which:
             gen_knuth(tmp)
         if "tables" in which:

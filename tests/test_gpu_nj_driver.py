@@ -144,3 +144,16 @@ def test_tiny_inputs_without_top_hits(name, fastest):
     assert nj_newick(make, codes, names, fastest=fastest, me_lengths=True) == bytes(d["newick"]).decode().strip()
     assert nj_newick(make, codes, names, fastest=fastest, me_lengths=True, n_bootstrap=1000) == \
         bytes(d["newick_support"]).decode().strip()
+
+
+def test_no_top_hits_beyond_the_sorted_hit_buffer():
+    """`-notop` on 4395 unique sequences: maxnode passes 8192 (the device's sorted-hit buffer) half-way through, so every
+    node's best hit has to come from the full allhits[] arrays of the sweep (vft_sweep_results) - join order of all 4392
+    joins and the NJ tree."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick, nj_run
+    d = G.load("bb_nt_4400_notop")
+    codes = unique_codes(d["codes"])
+    assert 2 * len(codes) > 8192
+    joins, crit = nj_run(HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32), codes, tophits_mult=-1.0)
+    assert np.array_equal(joins, d["joins"])

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Sweep-kernel ablations on the 1M benchmark state (VFT_SWEEP_ABLATE bits: 1 no vector loads, 2 no weight loads,
-4 no arithmetic, 8 plain workgroup order).  Results of ablated runs are wrong by design; timing only."""
+4 no arithmetic, 8 plain workgroup order).  Results of ablated runs are wrong by design; timing only.
+The switches only exist in a library built with VFT_EXTRA_HIPCC_FLAGS=-DVFT_ABLATE (veryfasttree_amd/build.py);
+point VFT_HIP_LIB at that build - the product library ignores VFT_SWEEP_ABLATE."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,6 +4,7 @@ or - with -mllen - the tree of `VeryFastTree -nt -nome -mllen [-nocat | -cat N] 
 
     python tools/nj_tree.py in.fasta [-fastest] [-double] [-nosupport] [-nj-lengths] [-mllen [-nocat | -cat N]] > tree.nwk
     python tools/nj_tree.py in.fasta -full [-gtr] [-double] [-nosupport] > tree.nwk     # what plain `VeryFastTree -nt [-gtr]` prints
+    python tools/nj_tree.py in.fasta -full -lg -double > tree.nwk     # proteins: `VeryFastTree -lg -double-precision` (-aa / -jtt, -wag, -lg)
 
 Neighbour joining with top hits on the device (veryfasttree_amd/host/NJDriver.h), the root, minimum-evolution branch
 lengths (updateBranchLengths), local-bootstrap supports (1000 resamples, reliabilityNJ) and printNJ; -nj-lengths keeps
@@ -11,14 +12,14 @@ the NJ branch lengths and prints no supports (the reference's "NJ" log line).  -
 lengths on that topology (optimizeAllBranchLengths rounds, CAT rate categories unless -nocat) and SH-like supports
 (testSplitsML, 1000 resamples) unless -nosupport; the TreeLogLk of every round goes to stderr.
 Sequence normalisation and uniquify follow Alignment.cpp:453-526 (U -> T, '.' -> '-', duplicates by sequence string in
-first-occurrence order)."""
+first-occurrence order; N -> X for nucleotides)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from veryfasttree_amd import HipProfileOps
 from veryfasttree_amd.backend import nj_newick
-from veryfasttree_amd.synth import ALPHABET_NT, NOCODE
+from veryfasttree_amd.synth import ALPHABET_AA, ALPHABET_NT, NOCODE
 
 
 def read_fasta(path):
@@ -53,7 +54,14 @@ def main():
     names, seqs = read_fasta(args[0])
     if len({len(s) for s in seqs}) != 1:
         sys.exit("sequences have different lengths: not an alignment")
-    seqs = [s.upper().replace("U", "T").replace(".", "-") for s in seqs]
+    aa = None
+    for flag, model in (("-aa", "jtt"), ("-jtt", "jtt"), ("-wag", "wag"), ("-lg", "lg")):
+        if flag in args:
+            aa = model
+    # Alignment.cpp:453-471: '.' -> '-' always; for nucleotides U -> T and N -> X (before the sequences are uniquified)
+    seqs = [s.upper().replace(".", "-") for s in seqs]
+    if aa is None:
+        seqs = [s.replace("U", "T").replace("N", "X") for s in seqs]
     first_of, last, unique_first = {}, {}, []
     aln_next = np.full(len(seqs), -1, np.int64)
     for k, s in enumerate(seqs):
@@ -64,14 +72,16 @@ def main():
             aln_next[last[s]] = k
         last[s] = k
     lut = np.full(256, NOCODE, np.uint8)
-    for i, ch in enumerate(ALPHABET_NT):
+    for i, ch in enumerate(ALPHABET_AA if aa else ALPHABET_NT):
         lut[ord(ch)] = i
     codes_all = np.stack([lut[np.frombuffer(s.encode("ascii", "replace"), np.uint8)] for s in seqs])
     n_unique = len(unique_first)
     if n_unique < 3:
         sys.exit("fewer than 3 unique sequences")
     dt = np.float64 if double else np.float32
-    tree, loglk = nj_newick(lambda n, L: HipProfileOps(n, L, 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
+    if aa:
+        extra["aa_model"] = aa
+    tree, loglk = nj_newick(lambda n, L: HipProfileOps(n, L, 20 if aa else 4, dt, max_nodes=3 * n), codes_all, names, fastest=fastest,
                             dtype=dt, me_lengths=not nj_len, unique=(np.array(unique_first, np.int64), aln_next),
                             n_bootstrap=n_boot, mllen=mllen, return_loglk=True, **extra)
     for k, ll in enumerate(loglk):

@@ -26,6 +26,7 @@ EXPORTS = [
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
+    "vft_debug_log",
 ]
 
 
@@ -71,7 +72,8 @@ def load_host_library():
 AA_MODELS = {None: 0, "": 0, "jtt": 1, "wag": 2, "lg": 3}
 
 
-def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False, aa_model=None):
+def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False, aa_model=None,
+           tophits_mult=1.0):
     """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n]).
     second_level defaults to `fastest`, as in the reference at one thread (-fastest turns -2nd on)."""
     lib = load_host_library()
@@ -79,7 +81,7 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
     n, L = codes.shape
     if second_level is None:
         second_level = fastest
-    opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0,
+    opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, float(tophits_mult), -1.0,
                      tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0, AA_MODELS[aa_model])
     joins = np.zeros((max(n - 3, 1), 3), np.int64)
@@ -529,6 +531,13 @@ class HipProfileOps:
         l2 = np.ascontiguousarray(len2, np.float64)
         self._chk(self.lib.vft_posterior_profiles(self.ctx, I64(len(out)), _ptr(out), _ptr(a), _ptr(b), _ptr(l1),
                                                   _ptr(l2)))
+
+    def debug_log(self, x):
+        """log(x) as the ML kernels evaluate it on the device (glibc's algorithm): diagnostics."""
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros_like(x)
+        self._chk(self.lib.vft_debug_log(self.ctx, I64(x.size), _ptr(x), _ptr(out)))
+        return out
 
     # ---- measurement
     def timer_start(self):

@@ -480,6 +480,8 @@ extern "C" const char *vft_last_error(const vft_ctx *c) { return c ? c->err : "n
 
 extern "C" int vft_set_stream(vft_ctx *c, void *s) {
     if (!c) return VFT_ERR_INVALID;
+    // work queued on the stream being left (ring slots, the completion flag) must not race with the new one
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t) s : c->ownStream;
     return VFT_OK;
 }
@@ -1107,6 +1109,8 @@ extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
         LAUNCHCHK(c);
         return VFT_OK;
     }
+    for (int64_t k = 0; k < n; k++)
+        if (ids[k] < 0 || ids[k] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_out_profile_full: node %lld out of range", (long long) ids[k]);
     if (int r = ensure_scratch(c, (size_t) n * 8)) return r;
     HIPCHK(c, hipMemcpyAsync(c->scratch, ids, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
     VFT_DISPATCH(c, (launch((k_outprofile_full<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,
@@ -1118,6 +1122,8 @@ extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
 
 extern "C" int vft_out_profile_update(vft_ctx *c, int64_t old1, int64_t old2, int64_t newn, int64_t nActiveOld) {
     if (!c || nActiveOld < 2) return VFT_ERR_INVALID;
+    if (old1 < 0 || old1 >= c->d.maxNodes || old2 < 0 || old2 >= c->d.maxNodes || newn < c->d.nSeqs || newn >= c->d.maxNodes)
+        return fail(c, VFT_ERR_INVALID, "vft_out_profile_update: bad ids (%lld, %lld -> %lld)", (long long) old1, (long long) old2, (long long) newn);
     VFT_DISPATCH(c, (launch((k_outprofile_update<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,
                                         arena<REAL>(c), old1, old2, newn, nActiveOld, c->fpostTol)));
     LAUNCHCHK(c);
@@ -1318,7 +1324,7 @@ static int run_select(vft_ctx *c, int K, const int64_t *queries, int64_t lo, int
         launch(k_select_thresh, dim3(1, ny), dim3(VFT_NBINS), 0, c->stream, sl, VFT_SEL_WGS, (unsigned int) k);
         launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi);
         launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG, ny), dim3(VFT_WG), 0, c->stream, sl, k);
-        launch((k_select_best<REAL, HIT>), dim3(1, ny), dim3(VFT_WG), 0, c->stream, sl, k);
+        launch((k_select_best<REAL, HIT>), dim3(1, ny), dim3(VFT_WG), 0, c->stream, sl, k, lo, hi);
     };
     launch((k_select_range<REAL>), dim3(1, (unsigned) K), dim3(1024), 0, c->stream, slots);
     round(slots, (unsigned) K);
@@ -1347,6 +1353,7 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
     if (c->maxStamp - nActive > nDiffAllow)
         if (int r = launch_out_distances(c, nullptr, 0, nActive, nDiffAllow, totdiam, false)) return r;
     if ((int64_t) c->hNOut[query] - nActive > nDiffAllow) {   // the mirror can only lag towards "staler"
+        if (nActive > c->maxStamp) c->maxStamp = nActive;     // the refresh stamps the query with nActive
         SweepArgs s{};
         s.nActive = nActive;
         s.nDiffAllow = nDiffAllow;
@@ -1365,7 +1372,9 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
     s.nDiffAllow = nDiffAllow;
     s.totdiam = totdiam;
     s.queryIsLeaf = query < c->d.nSeqs ? 1 : 0;
-    if (const char *dbg = getenv("VFT_SWEEP_ABLATE")) s.pad = atoi(dbg);   // kernel ablation switches (tools only)
+#ifdef VFT_ABLATE   // tools-only build (tools/ablate_sweep.py): never in the product library
+    if (const char *dbg = getenv("VFT_SWEEP_ABLATE")) s.pad = atoi(dbg);
+#endif
     const int64_t span = hi > lo ? hi - lo : 0;
     const bool ntPath = c->cfg.n_codes == 4 && !c->hasDm;
     const unsigned grid = ntPath ? sweep_nt_grid(c, s, !s.queryIsLeaf) : cdiv(span > 0 ? span : 1, VFT_WG);
@@ -1583,6 +1592,7 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
         bool anyStale = false;
         for (int64_t t = 0; t < n && !anyStale && !raw; t++)
             anyStale = (int64_t) c->hNOut[pi[t]] - nActive > nDiffAllow || (int64_t) c->hNOut[pj[t]] - nActive > nDiffAllow;
+        if (anyStale && nActive > c->maxStamp) c->maxStamp = nActive;   // refreshed nodes are stamped with nActive
         if (anyStale)
             VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, true>), dim3((unsigned) (2 * n)), dim3(VFT_WG), lds, c->stream,
                                     arena<REAL>(c), dI, dJ, n, sa)));
@@ -1590,6 +1600,7 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
                                 arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB),
                                 c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     } else {
+        if (!raw && nActive > c->maxStamp) c->maxStamp = nActive;
         if (!raw)
             VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, c->pwWaves)), dim3(64 * c->pwWaves),
                                     pw_lds_bytes(c), c->stream, arena<REAL>(c), dI, dJ, n, sa)));
@@ -1620,6 +1631,8 @@ extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int
     if (!c || n < 0 || !a || !b || !length || !loglk) return VFT_ERR_INVALID;
     if (n == 0) return VFT_OK;
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
+    for (int64_t k = 0; k < n; k++)
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_pair_loglk: pair %lld out of range", (long long) k);
     const size_t idB = (size_t) n * 8, sB = siteLk ? (size_t) n * c->d.nPos * 8 : 0;
     if (int r = ensure_scratch(c, 4 * idB + sB + 64)) return r;
     char *s = (char *) c->scratch;
@@ -1643,8 +1656,10 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
     if (!c || n < 0 || !out || !a || !b || !len1 || !len2) return VFT_ERR_INVALID;
     if (n == 0) return VFT_OK;
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
-    for (int64_t k = 0; k < n; k++)
+    for (int64_t k = 0; k < n; k++) {
         if (int r = internal_ok(c, out[k])) return r;
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_posterior_profiles: child %lld out of range", (long long) k);
+    }
     const CommitPlan plan = commit_plan(c, n);
     const int64_t chunk = plan.chunk;
     const size_t idB = (size_t) n * 8;
@@ -1716,8 +1731,9 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
     for (int64_t k = 0; k < n; k++) {
         if (int r = internal_ok(c, out[k])) return r;
-        if (lenIdxA[k] < 0 || lenIdxA[k] >= c->d.maxNodes || lenIdxB[k] < 0 || lenIdxB[k] >= c->d.maxNodes)
-            return fail(c, VFT_ERR_INVALID, "vft_posterior_profiles_blen: branch-length index out of range");
+        if (lenIdxA[k] < 0 || lenIdxA[k] >= c->d.maxNodes || lenIdxB[k] < 0 || lenIdxB[k] >= c->d.maxNodes || a[k] < 0 ||
+            a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes)
+            return fail(c, VFT_ERR_INVALID, "vft_posterior_profiles_blen: index out of range");
     }
     if (int r = ensure_blen(c)) return r;
     if (int r = ensure_ml_rows(c)) return r;
@@ -2107,6 +2123,25 @@ extern "C" int vft_split_supports(vft_ctx *c, int64_t n, const int64_t *a, const
         }
         for (int64_t k = 0; k < m; k++) support[k0 + k] = (double) cnt[(size_t) k] / (double) nBoot;
     }
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- diagnostics
+__global__ void k_debug_log(const double *x, double *out, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = vft_glibc_log(x[i]);
+}
+
+extern "C" int vft_debug_log(vft_ctx *c, int64_t n, const double *x, double *out) {
+    if (!c || n < 0 || !x || !out) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (int r = ensure_scratch(c, (size_t) n * 16)) return r;
+    double *dx = (double *) c->scratch, *dy = dx + n;
+    HIPCHK(c, hipMemcpyAsync(dx, x, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+    launch(k_debug_log, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const double *) dx, dy, n);
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(out, dy, (size_t) n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }
 

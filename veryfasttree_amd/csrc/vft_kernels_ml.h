@@ -7,8 +7,10 @@
 #pragma once
 #include "vft_device.h"
 #include "vft_kernels_profile.h"
+#include "vft_glibc_log.h"
 
 #define VFT_ML_WG 128
+#define VFT_ML_STAGE 2048   /* columns staged in LDS per pass of the ordered likelihood total */
 #define VFT_MAXRATES 64
 #define VFT_LK_UNDERFLOW 1.0e-4              /* Constants.h:13 */
 #define VFT_LK_UNDERFLOW_INV 1.0e4           /* Constants.h:14 */
@@ -118,6 +120,47 @@ __device__ __forceinline__ void vft_lk_accumulate(double lkAB, bool jc, double &
     }
 }
 
+// The reference's total in the reference's order (NJ.tcc:1198-1201, :1257-1262 / :1314-1321, :1444): ONE running
+// product over all columns in column order with the underflow rescaling, one final log - glibc's log, bit for bit
+// (vft_glibc_log.h).  Float-precision matrix models need it: their likelihood is rough at the 1e-10 level, Brent's
+// searches use the values arithmetically, and a total that differs in the last place sends a search to another point
+// (the cause of the float32 -gtr topology drift of round 1).  The per-thread running products of
+// the fast path reorder the multiplications; they stay for Jukes-Cantor and for double precision, where the function
+// is smooth at that scale.
+//   stage[0..n): the columns' likelihoods in column order, VFT_LK_SKIP for columns the reference skips (gap against gap
+//   under a matrix model); written by all threads, a barrier, then this - called by ONE thread - walks them.
+#define VFT_LK_SKIP (-2.0)
+__device__ __forceinline__ void vft_lk_chain(const double *stage, int64_t n, bool jc, double &lk, double &loglk) {
+#pragma unroll 8
+    for (int64_t p = 0; p < n; p++) {
+        const double v = stage[p];
+        if (v == VFT_LK_SKIP) continue;
+        vft_lk_accumulate(v, jc, lk, loglk);
+    }
+}
+
+__device__ __forceinline__ double vft_lk_finish(double lk, double loglk) {
+    return loglk + (lk > 0.0 && lk < 1.0e300 ? vft_glibc_log(lk) : log(lk));
+}
+
+// the ordered total for kernels whose threads own the columns p = tid + c * WG (c < CPT): result to every thread
+template <int WG, int CPT>
+__device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *slot, const double (&lkAB)[CPT], int64_t nPos, bool jc) {
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+        if (p < nPos) stage[p] = lkAB[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lk = 1.0, loglk = 0.0;
+        vft_lk_chain(stage, nPos, jc, lk, loglk);
+        *slot = vft_lk_finish(lk, loglk);
+    }
+    __syncthreads();
+    return *slot;
+}
+
 // pairLogLk (NJ.tcc:1192-1447).  One workgroup per pair, threads over columns.  Each thread keeps the
 // reference's running product with underflow rescaling for its own columns; the per-thread log-products are
 // then summed (wave shuffles + LDS).  Only the order of that final sum differs from the reference.
@@ -139,6 +182,29 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
     }
     __syncthreads();
     double lk = 1.0, loglk = 0.0;
+    if constexpr (sizeof(REAL) == 4) if (!jc) {
+        // float-precision matrix model: the reference's ordered total (vft_lk_chain), VFT_ML_STAGE columns at a time
+        __shared__ double stage[VFT_ML_STAGE];
+        for (int64_t p0 = 0; p0 < A.d.nPos; p0 += VFT_ML_STAGE) {
+            const int64_t cnt = A.d.nPos - p0 < VFT_ML_STAGE ? A.d.nPos - p0 : VFT_ML_STAGE;
+            for (int64_t q = threadIdx.x; q < cnt; q += blockDim.x) {
+                const int64_t p = p0 + q;
+                Col<REAL, NC> c1, c2;
+                vft_load_col_ml<REAL, NC>(A, a, p, c1);
+                vft_load_col_ml<REAL, NC>(A, b, p, c2);
+                const int r = A.ratecat[p];
+                double lkAB;
+                const bool has = vft_pair_lk_col<REAL, NC>(A, c1, c2, jc, pS[r], pD[r], expeig + r * NC, lkAB);
+                if (siteLk) siteLk[k * A.d.nPos + p] = has ? lkAB : 1.0;
+                stage[q] = has ? lkAB : VFT_LK_SKIP;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) vft_lk_chain(stage, cnt, jc, lk, loglk);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loglkOut[k] = vft_lk_finish(lk, loglk);
+        return;
+    }
     for (int64_t p = threadIdx.x; p < A.d.nPos; p += blockDim.x) {
         Col<REAL, NC> c1, c2;
         vft_load_col_ml<REAL, NC>(A, a, p, c1);
@@ -503,6 +569,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
+    __shared__ double stage[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];   // ordered total of float matrix models
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
@@ -559,6 +626,21 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
                 vft_exp_eigen_rates<REAL, NC>(A, x, minRel, ee1);
             }
             __syncthreads();
+            if constexpr (sizeof(REAL) == 4) if (!jc) {   // float-precision matrix model: the reference's ordered total
+                double col[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; c++) {
+                    const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+                    col[c] = VFT_LK_SKIP;
+                    if (p < nPos) {
+                        const int r = rc[c];
+                        double lkAB;
+                        if (vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB)) col[c] = lkAB;
+                    }
+                }
+                nEval++;
+                return -vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, red, col, nPos, jc);
+            }
             double lk = 1.0, loglk = 0.0;
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
@@ -649,6 +731,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
+    __shared__ double stage[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];   // ordered total of float matrix models
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
@@ -681,6 +764,24 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
         if (lead) __syncthreads();
         table(0, len, false);
         __syncthreads();
+        if constexpr (sizeof(REAL) == 4) if (!jc) {   // float-precision matrix model: the reference's ordered total
+            double col[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; c++) {
+                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+                col[c] = VFT_LK_SKIP;
+                if (p < nPos) {
+                    const int r = rc[c];
+                    double lkAB;
+                    if (vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB)) {
+                        col[c] = lkAB;
+                        if (site) site[c] *= lkAB;
+                    }
+                }
+            }
+            nEval++;
+            return vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, red, col, nPos, jc);
+        }
         double lk = 1.0, loglk = 0.0;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
@@ -716,7 +817,8 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
-            if (p < nPos) siteOut[(k * 3 + topo) * nPos + p] = log(site[c]);   // SHSupport takes the logs, NJ.tcc:1134-1137
+            if (p < nPos)   // SHSupport takes the logs, NJ.tcc:1134-1137 (glibc's log where the totals are the reference's)
+                siteOut[(k * 3 + topo) * nPos + p] = (sizeof(REAL) == 4 && !jc && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
         }
     };
     const int64_t nA = ids[4 * k], nB = ids[4 * k + 1], nC = ids[4 * k + 2], nD = ids[4 * k + 3];

@@ -178,6 +178,14 @@ typedef unsigned int __attribute__((ext_vector_type(2))) vft_u2_t;
 typedef const __attribute__((address_space(4))) vft_u4_t *vft_smask_t;   // ColMask {vec lo, vec hi, w lo, w hi}
 typedef const __attribute__((address_space(4))) vft_u2_t *vft_soff_t;    // ColOff {vec, w}
 
+// Kernel ablation switches (tools/ablate_sweep.py) exist only in builds made with -DVFT_ABLATE; in the product build
+// the bits are a compile-time zero and every ablation branch folds away.
+#ifdef VFT_ABLATE
+#define VFT_ABLATE_BITS(s) ((s).pad)
+#else
+#define VFT_ABLATE_BITS(s) 0
+#endif
+
 // codes: the target's 16 codes of this chunk (loaded one chunk ahead so that the defaults below do not wait on it)
 // wT / fT: the tile's explicit-weight / vector streams (vft_layout.h)
 template <typename REAL, bool QLEAF>
@@ -432,8 +440,8 @@ __device__ __forceinline__ void vft_leaf_table_wg(const Arena<REAL> &A, const Qu
         top[bt] = 0;
         denom[bt] = 0;
     }
-    if (s.pad & 32) return;     // (ablation: compaction only)
-    if (!(s.pad & 16)) switch (nBatch) {   // (ablation 16: no column walk)
+    if (VFT_ABLATE_BITS(s) & 32) return;     // (ablation: compaction only)
+    if (!(VFT_ABLATE_BITS(s) & 16)) switch (nBatch) {   // (ablation 16: no column walk)
     case 1: vft_leaf_table_walk<REAL, 1>(A, Q, tab, tj, top, denom); break;
     case 2: vft_leaf_table_walk<REAL, 2>(A, Q, tab, tj, top, denom); break;
     case 3: vft_leaf_table_walk<REAL, 3>(A, Q, tab, tj, top, denom); break;
@@ -508,9 +516,9 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
                     uint4 nxt;
 #pragma unroll
                     for (int sub = 0; sub < VFT_CHUNK / VFT_SUB; sub++) {
-                        vft_int_chunk_load<REAL, QLEAF>(ca, c, sub, cur, wT, mM, mO, fT, Q, s.pad);
+                        vft_int_chunk_load<REAL, QLEAF>(ca, c, sub, cur, wT, mM, mO, fT, Q, VFT_ABLATE_BITS(s));
                         if (sub == 0) nxt = cT[(int64_t) (c + 1 < nChunk ? c + 1 : c) * VFT_TILE + lane];
-                        vft_int_chunk_consume<REAL, QLEAF>(ca, c, sub, Q, top, denom, s.pad);
+                        vft_int_chunk_consume<REAL, QLEAF>(ca, c, sub, Q, top, denom, VFT_ABLATE_BITS(s));
                     }
                     cur = nxt;
                 }
@@ -1255,38 +1263,59 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
 // answer with one stream synchronisation and no DMA copy (a 32 KB hipMemcpy D2H goes through SDMA here and costs
 // hundreds of microseconds of latency; zero-copy stores over PCIe cost a few).
 template <typename REAL, typename HIT>
-__global__ __launch_bounds__(VFT_WG) void k_select_best(const SelSlot *slots, int32_t k) {
+__global__ __launch_bounds__(VFT_WG) void k_select_best(const SelSlot *slots, int32_t k, int64_t lo, int64_t hi) {
     const SelSlot &sl = slots[blockIdx.y];
     const SelectState *S = sl.sel;
     const HIT *hits = (const HIT *) sl.hits;
     const int64_t query = sl.query;
     SelectHeader *hdr = sl.hdr, *hostHdr = sl.hostHdr;
     HIT *hostHits = (HIT *) sl.hostHits;
+    __shared__ long long sBest;
+    __shared__ REAL sCrit;
+    __shared__ int sTruncatedTie;
     for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = hits[t];
-    if (threadIdx.x != 0) return;
-    const unsigned int n = S->nCand < (unsigned int) k ? S->nCand : (unsigned int) k;
-    long long best = -1;
-    REAL bc = (REAL) 1e20;
-    for (unsigned int t = 0; t < n; t++) {
-        const long long j = (long long) hits[t].j;
-        if (j == query || j < 0) continue;
-        const REAL c = hits[t].criterion;
-        if (best < 0) {
-            if (!(c < (REAL) 1e20)) break;
-            best = j;
-            bc = c;
-        } else if (c == bc) {
-            if (j < best) best = j;
-        } else {
-            break;
+    if (threadIdx.x == 0) {
+        const unsigned int n = S->nCand < (unsigned int) k ? S->nCand : (unsigned int) k;
+        long long best = -1;
+        REAL bc = (REAL) 1e20;
+        unsigned int t = 0;
+        for (; t < n; t++) {
+            const long long j = (long long) hits[t].j;
+            if (j == query || j < 0) continue;
+            const REAL c = hits[t].criterion;
+            if (best < 0) {
+                if (!(c < (REAL) 1e20)) break;
+                best = j;
+                bc = c;
+            } else if (c == bc) {
+                if (j < best) best = j;
+            } else {
+                break;
+            }
         }
+        sBest = best;
+        sCrit = bc;
+        // the list ended inside the run of minimal criteria and was cut at k: ids below the cut (the order is id
+        // descending within a tie) may tie as well
+        sTruncatedTie = (best >= 0 && t == n && n == (unsigned int) k) ? 1 : 0;
     }
+    __syncthreads();
+    if (sTruncatedTie) {   // rare: every listed hit ties at the minimum - scan the criteria themselves
+        const REAL *crit = (const REAL *) sl.crit;
+        const REAL bc = sCrit;
+        long long mine = sBest;
+        for (int64_t j = lo + threadIdx.x; j < hi; j += VFT_WG)
+            if (j != query && crit[j] == bc && j < mine) mine = j;
+        atomicMin((unsigned long long *) &sBest, (unsigned long long) mine);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     SelectHeader h;
     h.nCand = S->nCand;
     h.overflow = S->overflow;
     h.shift = S->level;
     h.pad = 0;
-    h.bestJ = best;
+    h.bestJ = sBest;
     h.pad2 = 0;
     *hdr = h;
     *hostHdr = h;

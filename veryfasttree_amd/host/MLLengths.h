@@ -191,10 +191,11 @@ namespace veryfasttree {
         double treeLogLk(int64_t nPos, int64_t nLeafGaps) {
             std::vector<REAL> bl((size_t) nNodes);
             getLengths(bl.data());
+            /* one pairLogLk per internal node, summed in the reference's post-order (traversePostorder, the root last):
+               the total is then the reference's double sum, addend for addend */
             std::vector<int64_t> a, b;
             std::vector<double> len;
-            for (int64_t v = nSeqs; v < nNodes; v++) {
-                if (child[3 * v] < 0) continue;
+            for (int64_t v: order) {
                 a.push_back(child[3 * v]);
                 b.push_back(child[3 * v + 1]);
                 const REAL sum = bl[(size_t) a.back()] + bl[(size_t) b.back()];   /* numeric_t sum, NJ.tcc:5124 */
@@ -202,8 +203,6 @@ namespace veryfasttree {
             }
             std::vector<double> ll(a.size());
             chk(vft_pair_loglk(ctx, (int64_t) a.size(), a.data(), b.data(), len.data(), ll.data(), nullptr));
-            double total = 0;
-            for (double x: ll) total += x;
             /* the third branch of the root against the posterior of the first two (NJ.tcc:5138-5151); the root's own
                slot holds that temporary */
             const int64_t r0 = child[3 * root], r1 = child[3 * root + 1], r2 = child[3 * root + 2];
@@ -211,8 +210,18 @@ namespace veryfasttree {
             chk(vft_posterior_profiles_blen(ctx, 1, &root, &r0, &r1, &r0, &r1));   /* lengths from the device: the same values */
             double ll3 = 0;
             chk(vft_pair_loglk(ctx, 1, &root, &r2, &l2, &ll3, nullptr));
-            total += ll3;
-            if (nLeafGaps >= 0) total += (double) (nLeafGaps - nPos) * std::log(4.0);
+            double total = 0;
+            for (size_t t = 0; t < order.size(); t++) {
+                double atNode = 0;
+                atNode += ll[t];
+                if (order[t] == root) atNode += ll3;   /* traverseTreeLogLk adds both of the root's terms before returning */
+                total += atNode;
+            }
+            if (nLeafGaps >= 0) {   /* NJ.tcc:5236-5256 */
+                const double logNCodes = std::log(4.0);
+                total -= (double) nPos * logNCodes;
+                total += (double) nLeafGaps * logNCodes;
+            }
             return total;
         }
 

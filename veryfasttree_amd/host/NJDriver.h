@@ -1386,12 +1386,38 @@ namespace veryfasttree {
         /* setBestHit (NJ.tcc:3571-3646): the best join partner of `node` (lowest criterion, lowest id on ties, never
            itself); all: every active node's hit against `node`, indexed by id (besthitNew) */
         Besthit bestHitOf(int64_t node, int64_t nActive, std::vector<Besthit> *all) {
-            const int32_t k = (int32_t) std::min<int64_t>(maxnode, 8192);
-            std::vector<Besthit> hits = sweep(node, nActive, k);
             Besthit best;
             best.i = node;
             best.j = -1;
             if (all) all->assign((size_t) maxnodes, Besthit());
+            if (maxnode > 8192) {
+                /* more nodes than the device's sorted-hit buffer holds (only reachable with top hits switched off on a
+                   large input): the sweep without a selection, then the full per-target arrays - allhits[] itself */
+                chkT("vft_sweep", [&]() { return vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, 0, nullptr, nullptr, nullptr); });
+                std::vector<REAL> d((size_t) maxnode), w((size_t) maxnode), c((size_t) maxnode);
+                chkT("vft_sweep_results", [&]() { return vft_sweep_results(ctx, 0, maxnode, d.data(), w.data(), c.data()); });
+                pending = false;
+                for (int64_t j = 0; j < maxnode; j++) {
+                    if (parent[(size_t) j] >= 0) continue;
+                    Besthit h;
+                    h.i = node;
+                    h.j = j;
+                    h.dist = d[(size_t) j];
+                    h.weight = w[(size_t) j];
+                    h.criterion = c[(size_t) j];
+                    if (all) (*all)[(size_t) j] = h;
+                    if (j == node) continue;
+                    if (best.j < 0 || h.criterion < best.criterion) {   /* ascending j: the lowest id wins ties */
+                        best.j = j;
+                        best.dist = h.dist;
+                        best.weight = h.weight;
+                        best.criterion = h.criterion;
+                    }
+                }
+                return best;
+            }
+            const int32_t k = (int32_t) maxnode;
+            std::vector<Besthit> hits = sweep(node, nActive, k);
             for (const Besthit &h: hits) {
                 if (h.j < 0) continue;
                 if (all) (*all)[(size_t) h.j] = h;
