@@ -54,6 +54,8 @@ def main():
         a = args[i]
         if a == "--aa":
             aa = True
+        elif a == "--noref":
+            opt["noref"] = True
         elif a in ("--mu", "--gap", "--seed", "--threads", "--out"):
             opt[a[2:]] = args[i + 1]
             i += 1
@@ -77,6 +79,8 @@ def main():
     tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m), codes, names, **kw)
     t_gpu = time.perf_counter() - t0
     say("this backend, 1 x MI355X: %.1f s; TreeLogLk %s" % (t_gpu, " ".join("%.4f" % x for x in loglk)))
+    if opt.get("noref"):
+        return
     with tempfile.TemporaryDirectory() as tmp:
         fa, log = os.path.join(tmp, "a.fa"), os.path.join(tmp, "a.log")
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if aa else synth.ALPHABET_NT)

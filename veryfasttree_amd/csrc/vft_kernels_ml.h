@@ -143,22 +143,171 @@ __device__ __forceinline__ double vft_lk_finish(double lk, double loglk) {
     return loglk + (lk > 0.0 && lk < 1.0e300 ? vft_glibc_log(lk) : log(lk));
 }
 
-// the ordered total for kernels whose threads own the columns p = tid + c * WG (c < CPT): result to every thread
+// The ordered total for the line-search kernels (threads own the columns p = tid + c * WG, c < CPT), result to every
+// thread.  A chain of nPos dependent multiply / compare / rescale steps on one lane costs ~36 cycles per column; here the
+// rescaling decisions are taken off the chain:
+//   1. every thread stages its columns' likelihoods a_i (1.0 where the reference skips a column: multiplying by 1.0 is
+//      exact) and log2 a_i;
+//   2. wavefront 0 decides every rescaling from prefix sums of the logs.  With s_i = log2 of the product of a_0..a_i and
+//      T = log2(1e4), the reference's two while loops keep log2(lk) = s_i + n_i T inside [-T, T] by the smallest change
+//      of the net rescaling count: n_i = clamp(n_(i-1), lo_i, hi_i), lo_i = ceil((-T - s_i) / T), hi_i = floor((T - s_i) / T)
+//      (under a matrix model a column's likelihood can exceed 1 - profiles are scaled by 1 / stat - so both loops fire).
+//      Clamps compose into clamps, so all n_i come out of one wave scan.  A prefix sum closer than 1e-9 (in units of T)
+//      to a threshold, a non-positive or non-finite value, or a list overflow sends the call to the plain chain;
+//   3. the multiplier list - every a_i followed by one 1e4 (or 1e-4) per rescaling it triggers - is laid out in LDS and
+//      ONE lane multiplies it through in order: the reference's sequence of roundings at ~7 cycles per element; a lane
+//      of another wavefront applies -/+ LogLkUnderflow once per rescaling in the same order (also a chain of roundings).
+struct LkOrderedShared {
+    double prod, loglk;
+    int irregular, nList, nEvents, pad;
+};
+
+// the clamp interval [l, h] of a column whose prefix log-sum is sI; odd: too close to a threshold to decide here
+__device__ __forceinline__ void vft_lk_interval(double sI, int &l, int &h, bool &odd) {
+    if (sI == 0.0) {   // nothing but exact ones so far: lk is exactly 1, and -T, 0, T are all inside the closed window
+        l = -1;
+        h = 1;
+        return;
+    }
+    const double x = sI * (1.0 / 13.287712379549449), fl = floor(x);   // s_i / log2(1e4)
+    if (x - fl < 1.0e-9 || fl + 1.0 - x < 1.0e-9 || !(fabs(x) < 1.0e6)) odd = true;
+    l = -(int) fl - 1;
+    h = l + 1;
+}
+
+__device__ __forceinline__ int vft_clampi(int v, int l, int h) { return v < l ? l : (v > h ? h : v); }
+
 template <int WG, int CPT>
-__device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *slot, const double (&lkAB)[CPT], int64_t nPos, bool jc) {
+__device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *stageLog, double *list, signed char *events,
+                                                       LkOrderedShared *sh, const double (&lkAB)[CPT], int64_t nPos64, bool jc) {
+    constexpr int COLS = CPT * WG;              // capacity of stage / stageLog
+    constexpr int LCAP = COLS + COLS / 2;       // capacity of list
+    constexpr int ECAP = COLS / 2;              // capacity of events
+    constexpr int C = COLS / 64;                // columns per lane of wavefront 0
+    const int tid = threadIdx.x, lane = tid & 63, nPos = (int) nPos64;
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-        if (p < nPos) stage[p] = lkAB[c];
+        const int p = tid + c * WG;
+        if (p < nPos) {
+            const double a = lkAB[c] == VFT_LK_SKIP ? 1.0 : lkAB[c];
+            stage[p] = a;
+            stageLog[p] = log2(a);
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double lk = 1.0, loglk = 0.0;
-        vft_lk_chain(stage, nPos, jc, lk, loglk);
-        *slot = vft_lk_finish(lk, loglk);
+    if (tid < 64) {
+        const int BIG = 1 << 28;
+        bool odd = false;
+        const int q0 = lane * C, q1 = q0 + C < nPos ? q0 + C : nPos;   // this lane's run of columns [q0, q1)
+        // pass A: prefix sums of the logs (lane-local runs, then a wave scan); every later pass re-accumulates the run in
+        // the same order, which reproduces the same sums without keeping them in registers
+        double lsum = 0;
+        for (int q = q0; q < q1; q++) {
+            const double l = stageLog[q];
+            if (!(fabs(l) < 1.0e4)) odd = true;   // a <= 0, inf, nan
+            lsum += l;
+        }
+        double incl = lsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const double excl = incl - lsum;
+        // pass B: the run as one clamp (cl, ch), then an inclusive scan of the clamps (earlier runs first)
+        int cl = -BIG, ch = BIG;
+        double run = 0;
+        for (int q = q0; q < q1; q++) {
+            run += stageLog[q];
+            int l, h;
+            vft_lk_interval(excl + run, l, h, odd);
+            cl = vft_clampi(cl, l, h);
+            ch = vft_clampi(ch, l, h);
+        }
+        int il = cl, ih = ch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int tl = __shfl_up(il, off, 64), th = __shfl_up(ih, off, 64);
+            if (lane >= off) {   // (tl, th) covers the columns before those of (il, ih): push its bounds through
+                const int nl = vft_clampi(tl, il, ih), nh = vft_clampi(th, il, ih);
+                il = nl;
+                ih = nh;
+            }
+        }
+        const int pl = __shfl_up(il, 1, 64), ph = __shfl_up(ih, 1, 64);
+        const int nIn = lane == 0 ? 0 : vft_clampi(0, pl, ph);   // the count entering this run (lk starts at 1: n = 0)
+        // pass C: rescaling events of the run, exclusive scan of their counts
+        int n = nIn, ev = 0;
+        run = 0;
+        for (int q = q0; q < q1; q++) {
+            run += stageLog[q];
+            int l, h;
+            vft_lk_interval(excl + run, l, h, odd);
+            const int n2 = vft_clampi(n, l, h);
+            ev += n2 > n ? n2 - n : n - n2;
+            n = n2;
+        }
+        int einc = ev;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(einc, off, 64);
+            if (lane >= off) einc += t;
+        }
+        const int eTotal = __shfl(einc, 63, 64);
+        if (eTotal > ECAP || nPos + eTotal > LCAP) odd = true;
+        const bool anyOdd = __ballot(odd) != 0ull;
+        if (!anyOdd) {
+            // pass D: the multiplier list and the event list
+            int e = einc - ev;
+            n = nIn;
+            run = 0;
+            for (int q = q0; q < q1; q++) {
+                run += stageLog[q];
+                int l, h;
+                bool dummy = false;
+                vft_lk_interval(excl + run, l, h, dummy);
+                const int n2 = vft_clampi(n, l, h);
+                list[q + e] = stage[q];
+                const int d = n2 - n, cnt = d > 0 ? d : -d;
+                for (int r = 0; r < cnt; r++) {
+                    list[q + e + 1 + r] = d > 0 ? VFT_LK_UNDERFLOW_INV : VFT_LK_UNDERFLOW;
+                    events[e + r] = d > 0 ? 1 : -1;
+                }
+                e += cnt;
+                n = n2;
+            }
+        }
+        if (lane == 0) {
+            sh->irregular = anyOdd ? 1 : 0;
+            sh->nList = nPos + eTotal;
+            sh->nEvents = eTotal;
+        }
     }
     __syncthreads();
-    return *slot;
+    if (sh->irregular) {   // uniform: the plain chain, decisions and all
+        if (tid == 0) {
+            double lk = 1.0, loglk = 0.0;
+            vft_lk_chain(stage, nPos, jc, lk, loglk);
+            sh->prod = lk;
+            sh->loglk = loglk;
+        }
+    } else if (tid == 0) {
+        const int K = sh->nList;
+        double lk = 1.0;
+#pragma unroll 16
+        for (int k = 0; k < K; k++) lk *= list[k];
+        sh->prod = lk;
+    } else if (tid == 64) {
+        const int nE = sh->nEvents;
+        double loglk = 0.0;
+        for (int r = 0; r < nE; r++) {
+            if (events[r] > 0) loglk -= VFT_LOG_LK_UNDERFLOW;
+            else loglk += VFT_LOG_LK_UNDERFLOW;
+        }
+        sh->loglk = loglk;
+    }
+    __syncthreads();
+    return vft_lk_finish(sh->prod, sh->loglk);
 }
 
 // pairLogLk (NJ.tcc:1192-1447).  One workgroup per pair, threads over columns.  Each thread keeps the
@@ -570,6 +719,10 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
     __shared__ double stage[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];   // ordered total of float matrix models
+    __shared__ double stageLog[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];
+    __shared__ double stageList[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG * 3 / 2 : 1];
+    __shared__ signed char stageEvents[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG / 2 : 1];
+    __shared__ LkOrderedShared ordSh;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
@@ -639,7 +792,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
                     }
                 }
                 nEval++;
-                return -vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, red, col, nPos, jc);
+                return -vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
             }
             double lk = 1.0, loglk = 0.0;
 #pragma unroll
@@ -732,6 +885,10 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
     __shared__ double stage[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];   // ordered total of float matrix models
+    __shared__ double stageLog[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];
+    __shared__ double stageList[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG * 3 / 2 : 1];
+    __shared__ signed char stageEvents[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG / 2 : 1];
+    __shared__ LkOrderedShared ordSh;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
@@ -780,7 +937,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
                 }
             }
             nEval++;
-            return vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, red, col, nPos, jc);
+            return vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
         }
         double lk = 1.0, loglk = 0.0;
 #pragma unroll
