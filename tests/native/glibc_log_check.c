@@ -32,5 +32,23 @@ int main(int argc, char **argv) {
         }
     }
     printf("%ld mismatches in %ld\n", bad, n);
-    return bad != 0;
+    /* exp: the arguments of the P(t) tables (eigenvalue * rate * length <= 0, down to the underflow range), tiny
+       arguments, and a band of positive ones */
+    long ebad = 0;
+    for (long t = 0; t < n; t++) {
+        double x;
+        switch (t & 3) {
+            case 0: x = -30.0 * unit(); break;
+            case 1: x = -760.0 * unit(); break;
+            case 2: x = -exp(-45.0 * unit()); break;                  /* -1 ... -3e-20 */
+            default: x = 720.0 * unit() - 10.0; break;
+        }
+        const double a = vft_glibc_exp(x), b = exp(x);
+        if (memcmp(&a, &b, 8) != 0) {
+            if (ebad < 5) printf("EXP MISMATCH x=%a mine=%a libm=%a\n", x, a, b);
+            ebad++;
+        }
+    }
+    printf("%ld exp mismatches in %ld\n", ebad, n);
+    return bad != 0 || ebad != 0;
 }

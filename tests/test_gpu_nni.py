@@ -83,8 +83,8 @@ def test_gtr_model_fitted_like_the_reference(name, dt, full):
     model).  ml_*: `-nome -mllen`; full_*: the complete default pipeline.
     float32: the ML kernels compute the reference's ordered likelihood total with glibc's log (vft_kernels_ml.h,
     vft_lk_total_ordered), every per-site likelihood is bit-identical, and the output is the reference's byte for byte
-    (round 1 allowed 4 % of the splits to differ here).  double: the device's exp differs from glibc's in the last place
-    of the P(t) tables, lengths agree to the search tolerance."""
+    (round 1 allowed 4 % of the splits to differ here).  double: the P(t) tables come from glibc's exp restated on the
+    device (vft_glibc_exp), so the same holds."""
     from veryfasttree_amd import HipProfileOps
     from veryfasttree_amd.backend import nj_newick
     d = G.load(name)
@@ -106,10 +106,9 @@ def test_gtr_model_fitted_like_the_reference(name, dt, full):
     got_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", tree)])
     ref_len = np.array([float(x) for x in re.findall(r":([0-9.eE+-]+)", ref)])
     print(name, "printed lengths differing:", int((got_len != ref_len).sum()), "of", len(ref_len), "max abs", np.abs(got_len - ref_len).max())
-    if dt == np.float32:
-        assert tree == ref            # byte-identical
-    else:
-        assert np.allclose(got_len, ref_len, rtol=0.1, atol=1e-6)
+    assert tree == ref            # byte-identical, float32 and double
+    boot = nj_newick(make, codes_all, names, dtype=dt, me_lengths=True, gtr=True, n_bootstrap=1000, **kw)
+    assert boot == bytes(d["newick_support"]).decode().strip()   # SH-like supports included
 
 
 def _splits(newick):

@@ -26,10 +26,14 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 static __constant__ double vft_glog_tab_dev[256] = {VFT_GLOG_TABLE};
+static __constant__ uint64_t vft_gexp_tab_dev[256] = {VFT_GEXP_TABLE};
 #define VFT_GLOG_TAB vft_glog_tab_dev
+#define VFT_GEXP_TAB vft_gexp_tab_dev
 #else
 static const double vft_glog_tab_host[256] = {VFT_GLOG_TABLE};
+static const uint64_t vft_gexp_tab_host[256] = {VFT_GEXP_TABLE};
 #define VFT_GLOG_TAB vft_glog_tab_host
+#define VFT_GEXP_TAB vft_gexp_tab_host
 #endif
 
 VFT_GLOG_FN double vft_glibc_log(double x) {
@@ -81,6 +85,65 @@ VFT_GLOG_FN double vft_glibc_log(double x) {
     p = fma(q, r2, p);
     const double y = fma(r * r2, p, t);
     return y + hi;
+}
+
+// exp() of the same library (its FMA build, __exp_fma): x = k ln2 / 128 + r, 2^(k/128) from a 128-entry table carrying
+// a correction term, a degree-5 polynomial in r.  The matrix models' P(t) tables are exp(eigenvalue * rate * length)
+// narrowed to numeric_t (expEigenRates, NJ.tcc:2020-2038 with fastexp level 0): in double precision the device's own exp
+// differs from this in the last place of some arguments, enough to move a few optimised lengths in the ninth decimal and
+// a handful of SH-like supports; with this one the tables are the reference's bit for bit.
+VFT_GLOG_FN double vft_glibc_exp(double x) {
+    uint64_t ix;
+    memcpy(&ix, &x, 8);
+    uint32_t abstop = (uint32_t) (ix >> 52) & 0x7ff;
+    if (abstop - 0x3c9u >= 0x3fu) {
+        if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;              // |x| < 2^-54
+        if (abstop >= 0x409u) {                                          // |x| >= 1024, inf, nan
+            if (ix == 0xfff0000000000000ull) return 0.0;
+            if (abstop >= 0x7ffu) return 1.0 + x;
+            return (ix >> 63) ? 0.0 : INFINITY;
+        }
+        abstop = 0;                                                      // 512 <= |x| < 1024: scaled carefully below
+    }
+    const double kd0 = fma(x, VFT_GEXP_INVLN2N, VFT_GEXP_SHIFT);
+    uint64_t ki;
+    memcpy(&ki, &kd0, 8);
+    const double kd = kd0 - VFT_GEXP_SHIFT;
+    double r = fma(kd, VFT_GEXP_NEGLN2HIN, x);
+    r = fma(kd, VFT_GEXP_NEGLN2LON, r);
+    const unsigned idx = 2u * (unsigned) (ki & 127u);
+    const uint64_t top = ki << 45;
+    const uint64_t tbits = VFT_GEXP_TAB[idx];
+    double tail;
+    memcpy(&tail, &tbits, 8);
+    uint64_t sbits = VFT_GEXP_TAB[idx + 1] + top;
+    const double r2 = r * r;
+    double p = fma(r, VFT_GEXP_C3, VFT_GEXP_C2);
+    const double q = fma(r, VFT_GEXP_C5, VFT_GEXP_C4);
+    p = fma(p, r2, r + tail);
+    const double tmp = fma(r2 * r2, q, p);
+    double scale;
+    if (abstop == 0) {
+        if ((ki & 0x80000000ull) == 0) {   // k > 0: the result may overflow
+            sbits -= 1009ull << 52;
+            memcpy(&scale, &sbits, 8);
+            return 0x1p1009 * fma(scale, tmp, scale);
+        }
+        sbits += 1022ull << 52;            // k < 0: the result may be subnormal
+        memcpy(&scale, &sbits, 8);
+        const double st = scale * tmp;
+        double y = scale + st;
+        if (y < 1.0) {
+            double lo = (scale - y) + st;
+            const double hi = 1.0 + y;
+            lo = ((1.0 - hi) + y) + lo;
+            y = (hi + lo) - 1.0;
+            if (y == 0.0) y = 0.0;
+        }
+        return 0x1p-1022 * y;
+    }
+    memcpy(&scale, &sbits, 8);
+    return fma(scale, tmp, scale);
 }
 
 #endif

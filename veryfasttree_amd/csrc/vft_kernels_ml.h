@@ -25,7 +25,7 @@ __device__ __forceinline__ void vft_exp_eigen_rates(const Arena<REAL> &A, double
         if (relLen < minRel) relLen = minRel;
         const REAL rl = (REAL) relLen;           // vector_multiply_by takes numeric_t
         const REAL x = A.tmEigenval[j] * rl;
-        out[t] = (REAL) exp((double) x);
+        out[t] = (REAL) vft_glibc_exp((double) x);   // fastexp level 0 = libm's exp, bit for bit (vft_glibc_log.h)
     }
 }
 
@@ -122,11 +122,12 @@ __device__ __forceinline__ void vft_lk_accumulate(double lkAB, bool jc, double &
 
 // The reference's total in the reference's order (NJ.tcc:1198-1201, :1257-1262 / :1314-1321, :1444): ONE running
 // product over all columns in column order with the underflow rescaling, one final log - glibc's log, bit for bit
-// (vft_glibc_log.h).  Float-precision matrix models need it: their likelihood is rough at the 1e-10 level, Brent's
-// searches use the values arithmetically, and a total that differs in the last place sends a search to another point
-// (the cause of the float32 -gtr topology drift of round 1).  The per-thread running products of
-// the fast path reorder the multiplications; they stay for Jukes-Cantor and for double precision, where the function
-// is smooth at that scale.
+// (vft_glibc_log.h).  Matrix models need it: Brent's searches use the values arithmetically, in float precision the
+// likelihood is rough at the 1e-10 level, and a total that differs in the last place sends a search to another point
+// (the cause of the float32 -gtr topology drift of round 1); in double precision the same
+// mechanism moved a few lengths in the ninth decimal and a handful of supports.  The per-thread running products of
+// the fast path reorder the multiplications; they stay for Jukes-Cantor, where every column is double arithmetic, the
+// function is smooth at that scale, and whole runs up to 100 000 taxa have come out byte-identical.
 //   stage[0..n): the columns' likelihoods in column order, VFT_LK_SKIP for columns the reference skips (gap against gap
 //   under a matrix model); written by all threads, a barrier, then this - called by ONE thread - walks them.
 #define VFT_LK_SKIP (-2.0)
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
     }
     __syncthreads();
     double lk = 1.0, loglk = 0.0;
-    if constexpr (sizeof(REAL) == 4) if (!jc) {
-        // float-precision matrix model: the reference's ordered total (vft_lk_chain), VFT_ML_STAGE columns at a time
+    if (!jc) {
+        // matrix model: the reference's ordered total (vft_lk_chain), VFT_ML_STAGE columns at a time
         __shared__ double stage[VFT_ML_STAGE];
         for (int64_t p0 = 0; p0 < A.d.nPos; p0 += VFT_ML_STAGE) {
             const int64_t cnt = A.d.nPos - p0 < VFT_ML_STAGE ? A.d.nPos - p0 : VFT_ML_STAGE;
@@ -718,10 +719,10 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
-    __shared__ double stage[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];   // ordered total of float matrix models
-    __shared__ double stageLog[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];
-    __shared__ double stageList[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG * 3 / 2 : 1];
-    __shared__ signed char stageEvents[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG / 2 : 1];
+    __shared__ double stage[CPT * VFT_MLOPT_WG];   // ordered total of matrix models (vft_lk_total_ordered)
+    __shared__ double stageLog[CPT * VFT_MLOPT_WG];
+    __shared__ double stageList[CPT * VFT_MLOPT_WG * 3 / 2];
+    __shared__ signed char stageEvents[CPT * VFT_MLOPT_WG / 2];
     __shared__ LkOrderedShared ordSh;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
                 vft_exp_eigen_rates<REAL, NC>(A, x, minRel, ee1);
             }
             __syncthreads();
-            if constexpr (sizeof(REAL) == 4) if (!jc) {   // float-precision matrix model: the reference's ordered total
+            if (!jc) {   // matrix model: the reference's ordered total
                 double col[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; c++) {
@@ -884,10 +885,10 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
     __shared__ double red[VFT_MLOPT_WG / 64];
-    __shared__ double stage[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];   // ordered total of float matrix models
-    __shared__ double stageLog[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG : 1];
-    __shared__ double stageList[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG * 3 / 2 : 1];
-    __shared__ signed char stageEvents[sizeof(REAL) == 4 ? CPT * VFT_MLOPT_WG / 2 : 1];
+    __shared__ double stage[CPT * VFT_MLOPT_WG];   // ordered total of matrix models (vft_lk_total_ordered)
+    __shared__ double stageLog[CPT * VFT_MLOPT_WG];
+    __shared__ double stageList[CPT * VFT_MLOPT_WG * 3 / 2];
+    __shared__ signed char stageEvents[CPT * VFT_MLOPT_WG / 2];
     __shared__ LkOrderedShared ordSh;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
         if (lead) __syncthreads();
         table(0, len, false);
         __syncthreads();
-        if constexpr (sizeof(REAL) == 4) if (!jc) {   // float-precision matrix model: the reference's ordered total
+        if (!jc) {   // matrix model: the reference's ordered total
             double col[CPT];
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
         for (int c = 0; c < CPT; c++) {
             const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
             if (p < nPos)   // SHSupport takes the logs, NJ.tcc:1134-1137 (glibc's log where the totals are the reference's)
-                siteOut[(k * 3 + topo) * nPos + p] = (sizeof(REAL) == 4 && !jc && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
+                siteOut[(k * 3 + topo) * nPos + p] = (!jc && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
         }
     };
     const int64_t nA = ids[4 * k], nB = ids[4 * k + 1], nC = ids[4 * k + 2], nD = ids[4 * k + 3];
