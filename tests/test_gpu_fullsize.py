@@ -8,19 +8,28 @@ from oracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-def _state(n, L, seed, mu=0.03, gap=0.01):
+def _state(n, L, seed, mu=0.03, gap=0.01, nc=4, dt=np.float32):
     from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import distance_tables
     from veryfasttree_amd.workload import TopHitsState
-    codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
-    ops = HipProfileOps(n, L, 4, np.float32)
-    return codes, ops, TopHitsState(ops, codes, n // 4)
+    codes = synth.random_descent_codes(n, L, nc, mu, gap, seed=seed)
+    ops = HipProfileOps(n, L, nc, dt)
+    tables = None
+    if nc == 20:   # proteins: the BLOSUM45-derived distance matrix (host/AAModels.h), as the driver installs it
+        tables = {k: v.astype(dt) for k, v in distance_tables(None, dt).items()}
+        ops.set_distance_matrix(tables["distances"], tables["codefreq"], tables["eigenval"], tables["eigentot"])
+    return codes, ops, TopHitsState(ops, codes, n // 4), tables
 
 
-@pytest.mark.parametrize("n,L,seed", [(100000, 500, 3), (1000000, 200, 4)])   # BASELINE configs C3 and C4
-def test_sweep_properties_at_full_size(n, L, seed):
+# BASELINE configs C3 and C4 (nucleotides, float32) and C5 (50k proteins x 300, double precision, distance matrix)
+@pytest.mark.parametrize("n,L,seed,nc,dt,mu,gap", [(100000, 500, 3, 4, np.float32, 0.03, 0.01), (1000000, 200, 4, 4, np.float32, 0.03, 0.01),
+                                                   (50000, 300, 5, 20, np.float64, 0.08, 0.02)])
+def test_sweep_properties_at_full_size(n, L, seed, nc, dt, mu, gap):
     from veryfasttree_amd.workload import merge_hits, shard_range
-    codes, ops, st = _state(n, L, seed)
-    orc = Oracle(np.float32)
+    codes, ops, st, tables = _state(n, L, seed, mu, gap, nc, dt)
+    orc = Oracle(dt)
+    dm = orc.dmat(tables["distances"], tables["codefreq"], tables["eigenval"], tables["eigentot"]) if tables else None
+    big = dt(1e20)
     m = int(0.5 + np.sqrt(n))
     k = 2 * m
     rng = np.random.default_rng(seed)
@@ -31,7 +40,7 @@ def test_sweep_properties_at_full_size(n, L, seed):
         dist, weight, crit = ops.sweep_results(0, st.maxnode)
         # 1. inactive targets carry the sentinel, active ones do not
         inactive = st.parent < 0
-        assert np.all(crit[~inactive] == np.float32(1e20)) and np.all(crit[inactive] < np.float32(1e20))
+        assert np.all(crit[~inactive] == big) and np.all(crit[inactive] < big)
         # 2. the k hits are exactly the k smallest under (criterion asc, id desc), in that order
         ids = np.nonzero(inactive)[0]
         order = ids[np.lexsort((-ids, crit[ids]))][:k]
@@ -54,10 +63,10 @@ def test_sweep_properties_at_full_size(n, L, seed):
         for j in sample[:64]:
             j = int(j)
             if q < n and j < n:
-                od, ow = orc.seqdist(codes[q], codes[j], 4)
+                od, ow = orc.seqdist(codes[q], codes[j], nc, tables["distances"] if tables else None)
             else:
-                od, ow = orc.profiledist(pq, ops.profile_download(j))
-                od = np.float32(od - np.float32(diam[q] + diam[j]))
+                od, ow = orc.profiledist(pq, ops.profile_download(j), dm=dm)
+                od = dt(od - dt(diam[q] + diam[j]))
             assert od == dist[j] and ow == weight[j], (q, j)
         # 7. sharding: per-shard top-k merged == unsharded top-k (what the multi-GPU path relies on)
         parts = []
@@ -77,7 +86,7 @@ def test_sweep_properties_at_full_size(n, L, seed):
     # 8. self distance of a leaf is 0 with weight = ungapped columns
     some = st.active[st.active < n][:256]
     d, w, _ = ops.setDistCriterion(some, some, st.n_active, st.n_diff_allow, st.totdiam)
-    assert np.all(d == 0) and np.array_equal(w, (codes[some] != 127).sum(1).astype(np.float32))
+    assert np.all(d == 0) and np.array_equal(w, (codes[some] != 127).sum(1).astype(dt))
     ops.close()
 
 
@@ -85,7 +94,7 @@ def test_join_then_sweep_round_trip_at_c3_size():
     """averageProfile -> out-profile update -> sweep from the new node: idempotent under re-evaluation, and the
     joined children disappear from the hit list."""
     n, L = 100000, 500
-    codes, ops, st = _state(n, L, 33)
+    codes, ops, st, _ = _state(n, L, 33)
     a, b = int(st.active[10]), int(st.active[11])
     new = st.maxnode
     ops.set_max_node(new + 1)

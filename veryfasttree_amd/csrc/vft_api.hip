@@ -17,6 +17,7 @@
 
 VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_nj.h"
+#include "vft_kernels_aa.h"
 #include "vft_kernels_profile.h"
 
 struct vft_ctx {
@@ -44,6 +45,8 @@ struct vft_ctx {
     uint8_t *qC[2] = {nullptr, nullptr};
     uint4 *qEnc[2] = {nullptr, nullptr};
     double2 *qTab[2] = {nullptr, nullptr};
+    void *qPT[2] = {nullptr, nullptr};   // amino acids: per-(column, target code) piece table of the query (vft_kernels_aa.h)
+    size_t aaLds = 0;                    // dynamic LDS of k_sweep_aa, 0 = alignment too long for it (generic kernels)
     // sweep outputs
     void *swDist = nullptr, *swWeight = nullptr, *swCrit = nullptr;
     void *partMin = nullptr, *partMax = nullptr;
@@ -369,6 +372,22 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
         CR(dalloc(&c->qC[q], (size_t) nPosPad));
         CR(dalloc(&c->qEnc[q], (size_t) d.nChunk));
         CR(dalloc(&c->qTab[q], (size_t) nPosPad * 5));
+        CR(dallocb(&c->qPT[q], d.nCodes == 20 ? (size_t) nPosPad * 20 * rs : 1));
+    }
+    if (d.nCodes == 20) {
+        const size_t need = (((size_t) nPosPad * 20 * rs + 15) & ~(size_t) 15) + (size_t) nPosPad * 8 + (size_t) 2 * VFT_CHUNK * VFT_TILE * 16;
+        if (need <= (160u << 10) - 1024) {
+            c->aaLds = need;
+            if (need > (48u << 10)) {
+                if (rs == 4) {
+                    CR(hipFuncSetAttribute((const void *) k_sweep_aa<float, MODE_CRIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) need));
+                    CR(hipFuncSetAttribute((const void *) k_sweep_aa<float, MODE_OUTDIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) need));
+                } else {
+                    CR(hipFuncSetAttribute((const void *) k_sweep_aa<double, MODE_CRIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) need));
+                    CR(hipFuncSetAttribute((const void *) k_sweep_aa<double, MODE_OUTDIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) need));
+                }
+            }
+        }
     }
     c->nPart = (int) cdiv(N, VFT_WG);
     CR(dallocb(&c->partMin, (size_t) c->nPart * 8));
@@ -456,7 +475,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
     void *ptrs[] = {c->tileMask, c->colMask, c->colOff, c->leafT, c->profC, c->profW, c->profF, c->parent, c->nOutActive, c->diameter, c->selfweight,
                     c->selfdist, c->outDist, c->outW, c->outF, c->outCD, c->qW[0], c->qW[1], c->qF[0], c->qF[1],
-                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->qTab[0], c->qTab[1], c->swDist, c->swWeight, c->swCrit,
+                    c->qC[0], c->qC[1], c->qEnc[0], c->qEnc[1], c->qTab[0], c->qTab[1], c->qPT[0], c->qPT[1], c->swDist, c->swWeight, c->swCrit,
                     c->partMin, c->partMax, c->sel, c->slices, c->candKey, c->candId, c->dRes, c->dm[0],
                     c->dm[1], c->dm[2], c->dm[3], c->tm[0], c->tm[1], c->tm[2], c->tm[3], c->tm[4], c->tm[5],
                     c->rates, c->ratecat, c->scratch};
@@ -1176,6 +1195,31 @@ static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, int w
     if (timed) kernel_event(c);
 }
 
+// amino acids with a distance matrix: query tables + the tile kernels of vft_kernels_aa.h over [s.lo, s.hi).
+// Returns the number of workgroups (= min / max partials of a MODE_CRIT launch).
+template <typename REAL, int MODE>
+static unsigned launch_sweep_aa(vft_ctx *c, const SweepArgs &s, int whichQuery, int slot) {
+    const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+    REAL *wq = (REAL *) c->qW[whichQuery], *qvec = (REAL *) c->qF[whichQuery], *ptab = (REAL *) c->qPT[whichQuery];
+    launch((k_aa_query_prep<REAL>), dim3(cdiv(nPosPad * 20, 256)), dim3(256), 0, c->stream, arena<REAL>(c), s.query, wq, qvec, ptab);
+    const int64_t leafEnd = c->d.nSeqs < s.hi ? c->d.nSeqs : s.hi;
+    const int64_t leafTile0 = s.lo / VFT_TILE;
+    const int64_t nLeafTiles = leafEnd > s.lo ? (leafEnd + VFT_TILE - 1) / VFT_TILE - leafTile0 : 0;
+    const int32_t nLeafWG = (int32_t) ((nLeafTiles + VFT_AA_WG / 64 - 1) / (VFT_AA_WG / 64));
+    const int64_t intTile0 = leafTile0 > c->d.firstProfTile ? leafTile0 : c->d.firstProfTile;
+    const int64_t intTileEnd = (s.hi + VFT_TILE - 1) / VFT_TILE;
+    const int64_t nIntTiles = (s.hi > c->d.nSeqs && intTileEnd > intTile0) ? intTileEnd - intTile0 : 0;
+    const unsigned grid = (unsigned) nLeafWG + (unsigned) nIntTiles;
+    if (grid == 0) return 0;
+    AaQuery<REAL> Q;
+    Q.wq = wq;
+    Q.qvec = qvec;
+    Q.ptab = ptab;
+    launch((k_sweep_aa<REAL, MODE>), dim3(grid), dim3(VFT_AA_WG), c->aaLds, c->stream, arena<REAL>(c), Q, s, sweepout<REAL>(c, slot),
+           leafTile0, nLeafWG, intTile0);
+    return grid;
+}
+
 // launches the out-distance refresh over [lo,hi) (ids == nullptr) or over a device id list
 static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int64_t nActive, int64_t nDiffAllow,
                                 double totdiam, bool force) {
@@ -1214,6 +1258,9 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
                                arena<double>(c), qbuf<double>(c, 1));
             launch_sweep_nt<double, MODE_OUTDIST>(c, s, grid, 1, false);
         }
+    } else if (c->cfg.n_codes == 20 && c->hasDm && c->aaLds) {
+        if (c->cfg.precision == 4) launch_sweep_aa<float, MODE_OUTDIST>(c, s, 1, 0);
+        else launch_sweep_aa<double, MODE_OUTDIST>(c, s, 1, 0);
     } else {
         VFT_DISPATCH(c, (launch((k_out_distances<REAL, NC>), dim3(cdiv(span, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), (const int64_t *) nullptr, span, s)));
@@ -1398,7 +1445,11 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
         // latencies whatever the target count (~0.9 ms), wave-per-target ~50 us per 2048 targets: the crossover is
         // at ~32k targets.  (Neither is tuned: the aa arena wants its own kernel)
         kernel_event(c);
-        if (span <= 32768) {
+        if (c->cfg.n_codes == 20 && c->hasDm && c->aaLds && span > 0) {
+            const unsigned g = c->cfg.precision == 4 ? launch_sweep_aa<float, MODE_CRIT>(c, s, 0, slot) : launch_sweep_aa<double, MODE_CRIT>(c, s, 0, slot);
+            c->nPart = (int) g;
+            c->slots[(size_t) slot].nPart = (int) g;
+        } else if (span <= 32768) {
             const unsigned wgrid = (unsigned) std::min<int64_t>(cdiv(span > 0 ? span : 1, c->pwWaves), 256 * 16);
             c->nPart = (int) wgrid;
             c->slots[(size_t) slot].nPart = (int) wgrid;

@@ -66,6 +66,18 @@ struct Col {
     REAL f[NC];    // valid only when vec
 };
 
+// Element k of the vector with rank `rank` among the nvec vectors a tile holds at one column, whose block starts at
+// vector slot offVec of the tile's stream (vft_layout.h).  4-state alphabets: the vectors back to back (16 / 32 bytes
+// each - one load per lane).  20-state alphabets: the block is transposed in 16-byte pieces - piece e of all nvec
+// vectors, then piece e + 1 ... - so that the lanes of a wavefront, which own consecutive ranks, read consecutive
+// 16 bytes: a 160-byte vector per lane would otherwise touch 64 different cache lines per load instruction.
+template <typename REAL, int NC>
+__device__ __forceinline__ int64_t vft_fidx(uint32_t offVec, int nvec, int rank, int k) {
+    if (NC == 4) return ((int64_t) offVec + rank) * NC + k;
+    constexpr int E = 16 / (int) sizeof(REAL);   // elements per piece
+    return (int64_t) offVec * NC + ((int64_t) (k / E) * nvec + rank) * E + (k % E);
+}
+
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node, int64_t p, Col<REAL, NC> &c) {
     const int lane = (int) (node & (VFT_TILE - 1));
@@ -88,9 +100,10 @@ __device__ __forceinline__ void vft_load_col(const Arena<REAL> &A, int64_t node,
         else c.w = vft_implicit_weight<REAL>(c.code, hv);
         c.vec = c.w > 0 && c.code == VFT_NOCODE_;   // == hv (k_tile_commit)
         if (c.vec) {
-            const REAL *src = A.profF + vft_fstream_base(A.d, pt) + (int64_t) (o.vec + __popcll(m.vec & below)) * NC;
+            const REAL *src = A.profF + vft_fstream_base(A.d, pt);
+            const int nvec = __popcll(m.vec), rank = __popcll(m.vec & below);
 #pragma unroll
-            for (int k = 0; k < NC; k++) c.f[k] = src[k];
+            for (int k = 0; k < NC; k++) c.f[k] = src[vft_fidx<REAL, NC>(o.vec, nvec, rank, k)];
         }
     }
 }

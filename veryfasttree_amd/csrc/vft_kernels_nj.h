@@ -111,9 +111,9 @@ struct SweepOut {
 };
 
 // per-workgroup (min,max) of the criteria produced by this launch; every thread of the workgroup must call it
-template <typename REAL>
-__device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *partMin, REAL *partMax, int part) {
-    __shared__ REAL smin[VFT_WG / 64], smax[VFT_WG / 64];
+template <typename REAL, int NWAVES>
+__device__ __forceinline__ void vft_block_minmax_n(REAL cmin, REAL cmax, REAL *partMin, REAL *partMax, int part) {
+    __shared__ REAL smin[NWAVES], smax[NWAVES];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const REAL a = __shfl_xor(cmin, off, 64), b = __shfl_xor(cmax, off, 64);
@@ -127,13 +127,17 @@ __device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *par
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int w = 1; w < VFT_WG / 64; w++) {
+        for (int w = 1; w < NWAVES; w++) {
             cmin = smin[w] < cmin ? smin[w] : cmin;
             cmax = smax[w] > cmax ? smax[w] : cmax;
         }
         partMin[part] = cmin;
         partMax[part] = cmax;
     }
+}
+template <typename REAL>
+__device__ __forceinline__ void vft_block_minmax(REAL cmin, REAL cmax, REAL *partMin, REAL *partMax, int part) {
+    vft_block_minmax_n<REAL, VFT_WG / 64>(cmin, cmax, partMin, partMax, part);
 }
 
 // MODE_CRIT_LEAFQ is MODE_CRIT with the knowledge that the query is a leaf (every seed of setAllLeafTopHits): its

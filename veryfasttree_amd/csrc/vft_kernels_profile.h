@@ -156,14 +156,19 @@ __global__ __launch_bounds__(VFT_COMMIT_WG) void k_tile_commit(Arena<REAL> A, co
             const ColMask m = nm[p], old = A.colMask[mi0 + p];
             const ColOff oo = A.colOff[mi0 + p], on = no[p];
             if ((m.vec >> L) & 1ull) {
-                const REAL *src = mine ? stash + (stashRow + p) * (NC + 1)
-                                       : A.profF + fBase + (int64_t) (oo.vec + __popcll(old.vec & below)) * NC;
-                REAL *dst = fS + (int64_t) (on.vec + __popcll(m.vec & below)) * NC;
+                const int nOld = __popcll(old.vec), rOld = __popcll(old.vec & below);
+                const int nNew = __popcll(m.vec), rNew = __popcll(m.vec & below);
                 REAL v[NC];
+                if (mine) {
+                    const REAL *src = stash + (stashRow + p) * (NC + 1);
 #pragma unroll
-                for (int k = 0; k < NC; k++) v[k] = src[k];
+                    for (int k = 0; k < NC; k++) v[k] = src[k];
+                } else {
 #pragma unroll
-                for (int k = 0; k < NC; k++) dst[k] = v[k];
+                    for (int k = 0; k < NC; k++) v[k] = A.profF[fBase + vft_fidx<REAL, NC>(oo.vec, nOld, rOld, k)];
+                }
+#pragma unroll
+                for (int k = 0; k < NC; k++) fS[vft_fidx<REAL, NC>(on.vec, nNew, rNew, k)] = v[k];
             }
             if ((m.w >> L) & 1ull)
                 wS[on.w + __popcll(m.w & below)] = mine ? stash[(stashRow + p) * (NC + 1) + NC]

@@ -59,6 +59,8 @@ VFT_HD uint8_t vft_encode(uint8_t code, int nCodes) {
 //   REAL  profF[ptile][slot][nCodes]     the tile's vectors as ONE contiguous stream in (column, lane) order: the
 //                                        vector of lane l at column p sits in slot
 //                                              colOff[p].vec + popcount(colMask[p].vec & ((1<<l)-1))
+//                                        (20-state alphabets: inside a column's block of slots the vectors are
+//                                        transposed in 16-byte pieces, vft_fidx in vft_device.h)
 //   REAL  profW[ptile][slot]             the tile's explicit weights, same scheme with the .w members
 // A wavefront walking the columns of its tile therefore reads exactly the vectors that exist (the reference's
 // sparse profiles, NJ.h:126-141) as one ascending, hole-free address stream.  Streams are rebuilt per tile by
