@@ -40,41 +40,138 @@ def parse():
     ap.add_argument("--n-seqs", type=int, default=1000000)
     ap.add_argument("--n-pos", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end C3 tree (wall-clock half of the metric)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the phi ~ 1 roofline of the sweep kernel")
     return ap.parse_args()
 
 
-def cpu_baseline(state, codes, ops, budget_s=15.0):
-    """The oracle (oracle/vft_oracle.c, a scalar C port pinned to the reference) timed on one host core over a
-    bounded sample of the same workload: one internal-node seed against 4000 active leaves + 2000 internal
-    profiles, repeated until ~budget_s of CPU time."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(state, codes, ops, budget_s=8.0):
+    """SURVEY.md 8d "CPU baseline beside it": this repo's AVX2 + OpenMP restatement of the one-vs-all sweep
+    (oracle/vft_oracle_avx2.c: -O3 -mavx2 -mfma -fopenmp, bit-identical to the scalar oracle that is pinned to the
+    reference) timed on the GPU box's host cores over a bounded sample of the same workload - the benchmark's seeds
+    against 40 000 active leaves + 20 000 internal profiles of the same alignment - first on every core, then on one
+    thread, ~budget_s seconds each.  `value` is the all-core rate."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import Oracle
+    from oracle import Oracle, avx2_max_threads
     orc = Oracle(ops.dt)
-    n_leaf, n_int = 4000, 2000
     n = state.n_seqs
-    leaf_ids = state.active[state.active < n][:n_leaf]
-    int_ids = state.active[state.active >= n][:n_int]
-    profs = [orc.leaf_profile(codes[i], ops.n_codes) for i in leaf_ids]
-    profs += [ops.profile_download(int(v)) for v in int_ids]
-    W = np.stack([p[0] for p in profs]); Cc = np.stack([p[1] for p in profs]); F = np.stack([p[2] for p in profs])
-    m = len(profs)
+    leaf_ids = state.active[state.active < n][:40000]
+    int_ids = state.active[state.active >= n][:20000]
+    L = codes.shape[1]
+    m = len(leaf_ids) + len(int_ids)
+    W = np.zeros((m, L), ops.dt)
+    Cc = np.full((m, L), 127, np.uint8)
+    F = np.zeros((m, L, 4), ops.dt)
+    Cc[:len(leaf_ids)] = codes[leaf_ids]
+    W[:len(leaf_ids)] = (codes[leaf_ids] != 127)
+    for t, v in enumerate(int_ids):
+        w, c, f = ops.profile_download(int(v))
+        W[len(leaf_ids) + t], Cc[len(leaf_ids) + t], F[len(leaf_ids) + t] = w, c, f
     outp, _ = ops.out_profile_download()
     z = np.zeros(m, ops.dt)
     st = orc.state(len(leaf_ids), W, Cc, F, np.full(m, -1), z, W.sum(1).astype(ops.dt), z, state.totdiam, outp)
     od = np.zeros(m, ops.dt)
     na = np.full(m, state.n_active)
+    cores = avx2_max_threads()
+    rates = {}
+    for threads in (cores, 1):
+        orc.avx2_sweep(st, 0, state.n_active, od, na, threads=threads)   # warm-up (page in, spin up the team)
+        t0 = time.perf_counter()
+        done, q = 0, 0
+        while time.perf_counter() - t0 < budget_s:
+            query = (len(leaf_ids) + q // 2) if q % 2 == 0 else q // 2   # alternate internal / leaf seeds like the GPU step
+            orc.avx2_sweep(st, query % m, state.n_active, od, na, threads=threads)
+            done += m
+            q += 1
+        rates[threads] = (done / (time.perf_counter() - t0), q)
+    return dict(value=rates[cores][0], unit="profile-ops/s", cores=cores, kind="port", cpu=cpu_model(),
+                value_1_thread=rates[1][0],
+                sample="%d + %d sweeps (all cores / 1 thread) of one seed vs %d active leaves + %d internal profiles of the "
+                       "same alignment; AVX2 + OpenMP restatement (oracle/vft_oracle_avx2.c), %d threads"
+                       % (rates[cores][1], rates[1][1], len(leaf_ids), len(int_ids), cores))
+
+
+def dense_profile_roofline(ops, state, n, L, groups=32768):
+    """roofline of k_sweep_nt at vector density phi ~ 1 (SURVEY 8d asks for phi in {0, 0.25, 1}; the headline state has
+    0.28): `groups` internal profiles that each average 8 unrelated leaves, built in the free id space above the
+    benchmark state and swept alone (target range = those nodes).  Returns a dict or None when the ids do not fit."""
+    base = ((state.maxnode + 63) // 64) * 64
+    if base + 7 * groups > ops.max_nodes:
+        return None
+    rng = np.random.default_rng(99)
+    leaves = rng.permutation(n)[:8 * groups].astype(np.int64)
+    ops.set_max_node(base + 7 * groups)
+    # three levels of averages; the final `groups` nodes start at a tile boundary
+    l1 = base + 3 * groups + np.arange(4 * groups, dtype=np.int64)
+    l2 = base + groups + np.arange(2 * groups, dtype=np.int64)
+    l3 = base + np.arange(groups, dtype=np.int64)
+    step = 1 << 15
+    for out, a, b in ((l1, leaves[0::2], leaves[1::2]), (l2, l1[0::2], l1[1::2]), (l3, l2[0::2], l2[1::2])):
+        for k0 in range(0, len(out), step):
+            ops.averageProfile(out[k0:k0 + step], a[k0:k0 + step], b[k0:k0 + step])
+    par = np.full(7 * groups, 1, np.int64)     # only the dense nodes are active targets
+    par[:groups] = -1
+    ops.set_parents(base, par)
+    ops.set_out_distances(base, np.zeros(7 * groups, ops.dt), np.full(7 * groups, state.n_active, np.int64))
+    nvec = ops.profile_nvectors(base, groups)
+    S = ops.dt.itemsize
+    alg = groups * (L * (S + 1) + 2 * S + S + 8) + int(nvec.sum()) * 4 * S
+    pad = ((L + 15) // 16) * 16
+    moved = groups * (pad + (24 * pad) // 64 + 4 + S + 4 + S + 3 * S) + int(nvec.sum()) * 4 * S
+    ops.set_shard(base, base + groups)
+    q = int(l3[5])
+    for _ in range(3):
+        ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, 0, want_best=False, want_hits=False)
+    ops.synchronize()
+    ops.timer_start()
+    for _ in range(10):
+        ops.setBestHit(q, state.n_active, state.n_diff_allow, state.totdiam, 0, want_best=False, want_hits=False)
+    ops.timer_stop_ms()
+    ms, launches = ops.sweep_kernel_ms()
+    ops.set_parents(base, np.full(7 * groups, 1, np.int64))   # retire them again
+    ops.set_max_node(state.maxnode)
+    if ms <= 0:
+        return None
+    ach, mov = alg / (ms * 1e-3) / 1e9, moved / (ms * 1e-3) / 1e9
+    return dict(kernel="k_sweep_nt<float,MODE_CRIT>", phi=float(nvec.mean()) / L, targets=groups, launches=int(launches),
+                avg_launch_ms=ms, algorithmic_bytes_per_launch=int(alg), moved_bytes_per_launch=int(moved),
+                achieved=ach, frac=ach / HBM_PEAK_GBS, achieved_moved_gbs=mov, frac_moved=mov / HBM_PEAK_GBS)
+
+
+def end_to_end_c3(device):
+    """Wall-clock to a tree at BASELINE config C3's shape: 100 000 nt x 500, `-nt -fastest` NJ phase (top hits with the
+    second-level lists, as the reference runs it at one thread), root, minimum-evolution branch lengths, Newick - what
+    `VeryFastTree -nt -fastest -noml -nome -nosupport` prints.  newick_crc is compared with the reference's own output
+    for the same alignment (tests/golden/bb_c3_crc.npz, from oracle/_ref/VeryFastTree)."""
+    import zlib
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick
+    n, L = 100000, 500
+    codes = synth.random_descent_codes(n, L, 4, 0.03, 0.01, seed=3)
+    names = ["s%d" % k for k in range(n)]
     t0 = time.perf_counter()
-    done = 0
-    q = 0
-    while time.perf_counter() - t0 < budget_s:
-        query = (len(leaf_ids) + q) if q % 2 == 0 else q   # alternate internal / leaf seeds like the GPU step
-        orc.set_best_hit(st, query % m, state.n_active, state.n_diff_allow, od, na)
-        done += m
-        q += 1
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="profile-ops/s", cores=1, kind="port",
-                sample="%d sweeps of one seed vs %d leaves + %d internal profiles (same alignment), oracle C port, "
-                       "1 thread" % (q, len(leaf_ids), len(int_ids)))
+    tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m, device=device), codes, names,
+                     fastest=True, me_lengths=True)
+    wall = time.perf_counter() - t0
+    crc = zlib.crc32(tree.encode())
+    out = dict(workload="c3_100k_x500_nt_fastest_nj_tree", wall_s=round(wall, 2), unique_seqs=int(len(np.unique(codes, axis=0))),
+               newick_bytes=len(tree), newick_crc=crc)
+    ref = os.path.join(ROOT, "tests", "golden", "bb_c3_crc.npz")
+    if os.path.exists(ref):
+        want = int(np.load(ref)["newick_crc"])
+        out["reference_newick_crc"] = want
+        out["identical_to_reference"] = bool(want == crc)
+    return out
 
 
 def main():
@@ -199,6 +296,7 @@ def main():
                     avg_launch_ms=kern_ms, algorithmic_bytes_per_launch=int(alg_main),
                     moved_bytes_per_launch=int(moved_main),
                     achieved_moved_gbs=moved_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
+                    frac_moved=moved_main / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0,
                     phi=ab["phi"],
                     table_kernel=dict(kernel="k_sweep_nt_table<float,MODE_CRIT>", avg_ms_per_sweep=tab_ms,
                                       algorithmic_bytes_per_sweep=int(alg_tab), bound="lds",
@@ -219,6 +317,10 @@ def main():
         line["cpu_baseline"] = cpu_baseline(state, codes, ops)
     elif rank == 0:
         line["cpu_baseline"] = None
+    if world == 1 and not args.no_dense and (n, L) == (1000000, 200):
+        ops.set_shard(0, state.maxnode)
+        line["roofline"]["dense_profiles"] = dense_profile_roofline(ops, state, n, L)
+        ops.set_shard(lo, hi)
     # size-independent sanity of the last step: sorted order and no duplicate ids
     h = last[0]
     hv = h[h["j"] >= 0]
@@ -231,6 +333,11 @@ def main():
         crc = zlib.crc32(np.ascontiguousarray(hits["j"]).tobytes(), crc)
         crc = zlib.crc32(np.ascontiguousarray(hits["criterion"]).tobytes(), crc)
     line["hits_crc"] = crc
+    if world == 1 and not args.no_e2e and (n, L) == (1000000, 200):
+        # the other half of BASELINE's metric: wall-clock to a tree (one GPU; the NJ driver does not shard yet)
+        ops.close()
+        del state
+        line["e2e"] = end_to_end_c3(local_rank)
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

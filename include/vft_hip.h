@@ -167,6 +167,14 @@ int vft_sweep_results(vft_ctx *ctx, int64_t first, int64_t count, void *dist, vo
    (NJ.tcc:4580-4613, 4786-4833, 4267-4298).  Outputs are host arrays of the context precision. */
 int vft_pair_distances(vft_ctx *ctx, int64_t n, const int64_t *i, const int64_t *j, int64_t n_active,
                        int64_t n_diff_allow, double totdiam, void *dist, void *weight, void *criterion);
+/* setDistCriterion for the cross product of two lists of LEAVES (every id below n_seqs; nucleotides without a distance
+   matrix): out[x * n_b + y] belongs to the pair (a[x], b[y]).  The close-neighbour transfers of setAllLeafTopHits
+   (NJ.tcc:3957-3992 -> transferBestHits :4580-4613) are such blocks - up to m close neighbours x the seed's 2m best hits -
+   and a pair list is the wrong shape for millions of integer seqDist counts (k_leaf_block, vft_kernels_nj.h).  Negative
+   ids in b are allowed and give (1e20, 0, 1e20).  Out-distances staler than n_diff_allow are refreshed first, as in
+   vft_pair_distances.  Outputs: host arrays of the context precision, n_a * n_b each. */
+int vft_leaf_block_distances(vft_ctx *ctx, int64_t n_a, const int64_t *a, int64_t n_b, const int64_t *b, int64_t n_active,
+                             int64_t n_diff_allow, double totdiam, void *dist, void *weight, void *criterion);
 /* profileDist / seqDist itself (NJ.tcc:1167-1190, 1601-1624) for n pairs: the raw distance and weight, without the
    diameter correction and criterion of setDistCriterion.  The three distances that root the tree at the end of fastNJ
    (NJ.tcc:3110-3120) and every ME-phase distance are this call. */

@@ -340,6 +340,26 @@ def gen_aa(tmp):
                                                                     " ".join("%.3f" % x for x in ll[-2:]), os.path.getsize(dst) / 1024.0))
 
 
+def gen_c3(tmp):
+    """BASELINE config C3 at full size (100 000 x 500 nt, `-nt -fastest` at one thread, i.e. with the second-level top
+    hits): only the CRC-32 and length of the reference's `-noml -nome -nosupport` tree are kept (the tree is 2.5 MB).
+    Takes ~11 minutes of one core."""
+    import zlib
+    codes = synth.random_descent_codes(100000, 500, 4, 0.03, 0.01, seed=3)
+    fa = os.path.join(tmp, "c3.fa")
+    synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+    flags = ["-nt", "-fastest", "-noml", "-nome", "-nosupport", "-threads", "1", "-seed", "1"]
+    import time
+    t0 = time.time()
+    res = subprocess.run([REFBIN] + flags + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    tree = res.stdout.decode().strip()
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c3_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())),
+                        newick_bytes=np.int64(len(tree)), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(b"random_descent_codes(100000, 500, 4, 0.03, 0.01, seed=3)", dtype=np.uint8),
+                        reference_wall_s=np.float64(time.time() - t0))
+    print("bb_c3_crc: %d bytes of Newick, crc %d" % (len(tree), zlib.crc32(tree.encode())))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa"]
@@ -362,6 +382,8 @@ def main():
             gen_mlnni(tmp)
         if "aa" in which:
             gen_aa(tmp)
+        if "c3" in which:   # not part of the default set: ~11 minutes
+            gen_c3(tmp)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,23 @@ def _load():
 
 
 _lib = _load()
+_avx2_lib = None
+
+
+def _avx2():
+    """oracle/libvft_oracle_avx2.so: the CPU baseline of bench.py (AVX2 + OpenMP), built by `make -C oracle port`."""
+    global _avx2_lib
+    if _avx2_lib is None:
+        path = os.path.join(ORACLE_DIR, "libvft_oracle_avx2.so")
+        src = os.path.join(ORACLE_DIR, "vft_oracle_avx2.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build()
+        _avx2_lib = C.CDLL(path)
+    return _avx2_lib
+
+
+def avx2_max_threads():
+    return int(_avx2().vfto_avx2_max_threads())
 P = C.c_void_p
 I64 = C.c_int64
 
@@ -167,6 +184,20 @@ class Oracle:
         self.fn("vfto_set_best_hit")(C.byref(st), I64(node), I64(n_active), I64(n_diff_allow), _ptr(od), _ptr(na),
                                      _ptr(hi), _ptr(hj), _ptr(hw), _ptr(hd), _ptr(hc), C.byref(best))
         return dict(i=hi, j=hj, weight=hw, dist=hd, crit=hc, best_j=best.value, outdist=od, noutactive=na)
+
+    def avx2_sweep(self, st, node, n_active, out_dist, n_out_active, threads=0, repeat=1):
+        """The AVX2 + OpenMP restatement of the sweep (oracle/vft_oracle_avx2.c; nucleotides, no matrix, float32,
+        out-distances taken as fresh): dict of weight / dist / crit per target.  threads <= 0: every core."""
+        assert self.dt == np.float32
+        n = st.maxnode
+        od = self.arr(out_dist)
+        na = np.ascontiguousarray(n_out_active, np.int64)
+        hw, hd, hc = np.zeros(n, self.dt), np.zeros(n, self.dt), np.zeros(n, self.dt)
+        fn = _avx2().vfto_avx2_sweep_f32
+        fn.restype = None
+        for _ in range(repeat):
+            fn(C.byref(st), I64(node), I64(n_active), _ptr(od), _ptr(na), _ptr(hw), _ptr(hd), _ptr(hc), C.c_int(threads))
+        return dict(weight=hw, dist=hd, crit=hc)
 
     def sort_hits(self, crit):
         crit = self.arr(crit)

@@ -133,3 +133,21 @@ def test_bench_two_ranks_on_one_device_agree_with_one_rank():
     assert a["config"]["active_nodes"] == b["config"]["active_nodes"] and a["config"]["top_k"] == b["config"]["top_k"]
     assert b["value"] > 0
     assert a["hits_crc"] == b["hits_crc"]   # the merged lists of the two shards are the single-rank lists
+
+
+def test_c3_tree_equals_the_reference_tree():
+    """BASELINE config C3 end to end at full size and with its exact flags: 100 000 nt x 500, `-nt -fastest` (top hits
+    WITH the second-level lists, as the reference runs -fastest at one thread), NJ phase, root, minimum-evolution lengths,
+    Newick - the 2.5 MB tree must be the reference's byte for byte (CRC-32 and length of the reference's own output,
+    tests/golden/bb_c3_crc.npz; the reference needs 640 s of one core for it).  This is what bench.py reports as `e2e`."""
+    import zlib
+    import golden_util as G
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick
+    ref = G.load("bb_c3_crc")
+    n, L = 100000, 500
+    codes = synth.random_descent_codes(n, L, 4, 0.03, 0.01, seed=3)
+    names = ["s%d" % k for k in range(n)]
+    tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m), codes, names, fastest=True, me_lengths=True)
+    assert len(tree) == int(ref["newick_bytes"])
+    assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])

@@ -213,3 +213,32 @@ def test_sweep_batch_equals_single_sweeps(n_codes, dt):
 def G_load(name):
     import golden_util as G
     return G.load(name)
+
+
+def test_leaf_block_distances_equal_the_pair_list():
+    """vft_leaf_block_distances (k_leaf_block: the close-neighbour transfers of setAllLeafTopHits as one cross-product
+    call) against vft_pair_distances on the same pairs, bit for bit - f32 and f64, list lengths that do not fill the
+    kernel's 64 x 64 tiles, negative ids in the candidate list, a stale out-distance in play."""
+    from veryfasttree_amd import HipProfileOps, synth
+    n, L = 3000, 333
+    codes = synth.random_descent_codes(n, L, 4, 0.05, 0.08, seed=91)
+    for dt in (np.float32, np.float64):
+        ops = HipProfileOps(n, L, 4, dt)
+        ops.upload_leaves(codes)
+        ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
+        ops.outProfile(np.arange(n))
+        stamps = np.full(n, n, np.int64)
+        stamps[[5, 77, 1500]] = n + 200          # staler than allowed: refreshed inside the call
+        rng = np.random.default_rng(4)
+        ops.set_out_distances(0, rng.uniform(0, 50, n).astype(dt), stamps)
+        a = rng.choice(n, 83, replace=False)
+        b = rng.choice(n, 150, replace=False).astype(np.int64)
+        b[[3, 40]] = -1
+        b[10] = a[7]                                # a pair of a leaf with itself
+        d, w, c = ops.leafBlockDistances(a, b, n, 30, 12.5)
+        ok = b >= 0
+        pi, pj = np.repeat(a, ok.sum()), np.tile(b[ok], len(a))
+        d2, w2, c2 = ops.setDistCriterion(pi, pj, n, 30, 12.5)
+        assert np.array_equal(d[:, ok].ravel(), d2) and np.array_equal(w[:, ok].ravel(), w2) and np.array_equal(c[:, ok].ravel(), c2)
+        assert np.all(d[:, ~ok] == dt(1e20)) and np.all(w[:, ~ok] == 0)
+        ops.close()

@@ -274,3 +274,34 @@ def test_quartet_likelihoods_of_split_tests(fx):
             assert np.allclose(loglk, d[key + ".loglk"], rtol=1e-9, atol=0), (model, k, loglk, d[key + ".loglk"])
             assert np.allclose(l_ac, d[key + ".lenAC"], rtol=1e-6, atol=1e-12), (model, k)
             assert np.allclose(l_ad, d[key + ".lenAD"], rtol=1e-6, atol=1e-12), (model, k)
+
+
+@pytest.mark.parametrize("name", ["wb_nt_f32", "wb_nt_f32_gappy"])
+def test_avx2_sweep_equals_scalar_oracle(name):
+    """bench.py's CPU baseline (oracle/vft_oracle_avx2.c: AVX2 + OpenMP restatement of the one-vs-all sweep) against the
+    scalar oracle - which is pinned to the reference's own sweeps above - on the initial state (leaf x leaf) and on three
+    mid-run states (leaf and internal seeds, internal targets with vectors), bit for bit, at 1 and at 4 threads."""
+    d = G.load(name)
+    orc = Oracle(np.float32)
+    n_seqs = int(d["nSeqs"])
+    profs = G.build_nj_profiles(d, orc)
+    rng = np.random.default_rng(3)
+    for mid in ("mid0", "mid1", "mid2"):
+        J, n_active = int(d[mid + ".J"]), int(d[mid + ".nActive"])
+        lim = n_seqs + J
+        parent = G.mid_parent(d, J)
+        active = np.nonzero(parent < 0)[0]
+        W, Cc, F = G.pack(profs[:lim], orc.dt)
+        outp, _ = orc.out_profile(W[active], Cc[active], F[active], None, 1e-10)
+        st = orc.state(n_seqs, W, Cc, F, parent, d["nj.diameter"][:lim], d["nj.selfweight"][:lim], d["nj.selfdist"][:lim],
+                       float(d[mid + ".totdiam"]), outp)
+        od = d[mid + ".outdist_fresh"][:lim].astype(np.float32)
+        na = np.full(lim, n_active, np.int64)
+        na[rng.integers(0, lim, 5)] = n_active + 3          # a few stale stamps: the rescaled criterion of NJ.tcc:1099-1107
+        queries = [int(q) for q in d[mid + ".queries"]] + [int(active[0]), int(active[-1])]
+        for q in queries:
+            want = orc.set_best_hit(st, q, n_active, 10 ** 9, od, na)    # nDiffAllow huge: no lazy refresh on either side
+            for threads in (1, 4):
+                got = orc.avx2_sweep(st, q, n_active, od, na, threads=threads)
+                for key in ("dist", "weight", "crit"):
+                    assert np.array_equal(got[key], want[key]), (name, mid, q, key, threads)

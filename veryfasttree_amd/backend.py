@@ -26,7 +26,7 @@ EXPORTS = [
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
-    "vft_debug_log",
+    "vft_debug_log", "vft_leaf_block_distances",
 ]
 
 
@@ -464,6 +464,15 @@ class HipProfileOps:
         d, w, c = (np.zeros(n, self.dt) for _ in range(3))
         self._chk(self.lib.vft_pair_distances(self.ctx, I64(n), _ptr(i), _ptr(j), I64(n_active), I64(n_diff_allow),
                                               C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
+        return d, w, c
+
+    def leafBlockDistances(self, a, b, n_active, n_diff_allow, totdiam):
+        """setDistCriterion for the cross product of two leaf lists (vft_leaf_block_distances): three [len(a), len(b)]
+        arrays (dist, weight, criterion)."""
+        a, b = _i64(a), _i64(b)
+        d, w, c = (np.zeros((len(a), len(b)), self.dt) for _ in range(3))
+        self._chk(self.lib.vft_leaf_block_distances(self.ctx, I64(len(a)), _ptr(a), I64(len(b)), _ptr(b), I64(n_active),
+                                                    I64(n_diff_allow), C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
         return d, w, c
 
     def profileDist(self, i, j):

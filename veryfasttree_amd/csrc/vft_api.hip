@@ -1676,6 +1676,68 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     return VFT_OK;
 }
 
+extern "C" int vft_leaf_block_distances(vft_ctx *c, int64_t nA, const int64_t *a, int64_t nB, const int64_t *b, int64_t nActive,
+                                        int64_t nDiffAllow, double totdiam, void *dist, void *weight, void *crit) {
+    if (!c || nA < 0 || nB < 0 || !a || !b || !dist || !weight || !crit) return VFT_ERR_INVALID;
+    if (nA == 0 || nB == 0) return VFT_OK;
+    if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_leaf_block_distances before vft_upload_leaves");
+    if (c->cfg.n_codes != 4 || c->hasDm) return fail(c, VFT_ERR_STATE, "vft_leaf_block_distances: nucleotides without a distance matrix only");
+    for (int64_t t = 0; t < nA; t++)
+        if (a[t] < 0 || a[t] >= c->d.nSeqs) return fail(c, VFT_ERR_INVALID, "vft_leaf_block_distances: a[%lld] is not a leaf", (long long) t);
+    for (int64_t t = 0; t < nB; t++)
+        if (b[t] >= c->d.nSeqs) return fail(c, VFT_ERR_INVALID, "vft_leaf_block_distances: b[%lld] is not a leaf", (long long) t);
+    const size_t rs = c->rs, idB = (((size_t) (nA + nB) * 8) + 255) & ~(size_t) 255;
+    const size_t oB = (((size_t) nA * (size_t) nB * rs) + 255) & ~(size_t) 255;
+    if (int r = ensure_scratch(c, idB + 3 * oB + 256)) return r;
+    char *s = (char *) c->scratch;
+    int64_t *dA = (int64_t *) s, *dB = dA + nA;
+    HIPCHK(c, hipMemcpyAsync(dA, a, (size_t) nA * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dB, b, (size_t) nB * 8, hipMemcpyHostToDevice, c->stream));
+    // lazy refresh of whatever is stale (the host-mapped stamp mirror can only lag towards "staler")
+    bool anyStale = false;
+    for (int64_t t = 0; t < nA && !anyStale; t++) anyStale = (int64_t) c->hNOut[a[t]] - nActive > nDiffAllow;
+    for (int64_t t = 0; t < nB && !anyStale; t++) anyStale = b[t] >= 0 && (int64_t) c->hNOut[b[t]] - nActive > nDiffAllow;
+    if (anyStale) {
+        std::vector<int64_t> ids;
+        for (int64_t t = 0; t < nA; t++) ids.push_back(a[t]);
+        for (int64_t t = 0; t < nB; t++)
+            if (b[t] >= 0) ids.push_back(b[t]);
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        int64_t *dIds = (int64_t *) (s + idB + 3 * oB);
+        if (int r = ensure_scratch(c, idB + 3 * oB + 256 + ids.size() * 8)) return r;
+        s = (char *) c->scratch;   // (ensure_scratch may have moved it: re-derive everything)
+        dA = (int64_t *) s;
+        dB = dA + nA;
+        dIds = (int64_t *) (s + idB + 3 * oB);
+        HIPCHK(c, hipMemcpyAsync(dA, a, (size_t) nA * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dB, b, (size_t) nB * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dIds, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, c->stream));
+        if (nActive > c->maxStamp) c->maxStamp = nActive;
+        if (int r = launch_out_distances(c, dIds, (int64_t) ids.size(), nActive, nDiffAllow, totdiam, false)) return r;
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // ids is a local
+    }
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = nDiffAllow;
+    sa.totdiam = totdiam;
+    char *o = s + idB;
+    const dim3 grid(cdiv(nB, 64), cdiv(nA, 64));
+    if (c->cfg.precision == 4)
+        launch((k_leaf_block<float>), grid, dim3(VFT_WG), 0, c->stream, arena<float>(c), (const int64_t *) dA, nA, (const int64_t *) dB, nB, sa,
+               (float *) o, (float *) (o + oB), (float *) (o + 2 * oB));
+    else
+        launch((k_leaf_block<double>), grid, dim3(VFT_WG), 0, c->stream, arena<double>(c), (const int64_t *) dA, nA, (const int64_t *) dB, nB, sa,
+               (double *) o, (double *) (o + oB), (double *) (o + 2 * oB));
+    LAUNCHCHK(c);
+    const size_t bytes = (size_t) nA * (size_t) nB * rs;
+    HIPCHK(c, hipMemcpyAsync(dist, o, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(weight, o + oB, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(crit, o + 2 * oB, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- likelihood
 extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int64_t *b, const double *length,
                               double *loglk, double *siteLk) {

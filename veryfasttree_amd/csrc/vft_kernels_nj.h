@@ -950,6 +950,70 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh(Arena<REAL> A, const i
     __hip_atomic_store(&A.nOutActive[v], (int32_t) s.nActive, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------ leaf blocks
+// setDistCriterion for the cross product of two LEAF lists, nucleotides without a distance matrix: the close-neighbour
+// transfers of setAllLeafTopHits (NJ.tcc:3957-3992 -> transferBestHits :4580-4613) evaluate every close neighbour of a
+// seed against the seed's 2m best hits - up to m x 2m leaf pairs per seed, 2 x 10^9 over a million-sequence run, all of
+// them seqDist (NJ.tcc:1601-1612): integer counts of "both present" / "equal", order-free.  A pair list (one wavefront
+// per pair) is the wrong shape for that; here a lane owns a leaf of list B and keeps 2 x 16 counters for 16 leaves of
+// list A, whose encoded chunks arrive wave-uniformly (scalar loads): 16 bytes of B per lane and chunk serve 16 pairs.
+// Grid: (ceil(nB / 64), ceil(nA / 64)); workgroup = 4 wavefronts x 16 leaves of A.  out[a * nB + b].
+// Entries whose id is negative (or the pair of a leaf with itself) still get numbers; the caller masks them.
+#define VFT_LB_A 16
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_leaf_block(Arena<REAL> A, const int64_t *idsA, int64_t nA, const int64_t *idsB,
+                                                       int64_t nB, SweepArgs s, REAL *dist, REAL *weight, REAL *crit) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int64_t tb = (int64_t) blockIdx.x * 64 + lane;
+    const int64_t a0 = (int64_t) blockIdx.y * 64 + (int64_t) wave * VFT_LB_A;
+    if (a0 >= nA) return;   // wave-uniform
+    const int64_t b = tb < nB ? idsB[tb] : -1;
+    const bool bOk = b >= 0 && b < A.d.nSeqs;
+    const uint4 *bT = A.leafT + vft_leaf_idx(A.d, bOk ? b >> 6 : 0, 0, (int) (bOk ? b & 63 : 0));
+    int64_t aId[VFT_LB_A];
+    const uint4 *aT[VFT_LB_A];
+#pragma unroll
+    for (int u = 0; u < VFT_LB_A; u++) {
+        int64_t a = a0 + u < nA ? idsA[a0 + u] : -1;   // wave-uniform
+        if (a < 0 || a >= A.d.nSeqs) a = -1;
+        aId[u] = a;
+        aT[u] = A.leafT + vft_leaf_idx(A.d, a >= 0 ? a >> 6 : 0, 0, (int) (a >= 0 ? a & 63 : 0));
+    }
+    int nUse[VFT_LB_A], nSame[VFT_LB_A];
+#pragma unroll
+    for (int u = 0; u < VFT_LB_A; u++) nUse[u] = nSame[u] = 0;
+    const int nChunk = A.d.nChunk;
+    for (int c = 0; c < nChunk; c++) {
+        const uint4 vb = bT[(int64_t) c * VFT_TILE];
+#pragma unroll
+        for (int u = 0; u < VFT_LB_A; u++) {
+            typedef const __attribute__((address_space(4))) vft_u4_t *sp_t;
+            const vft_u4_t q = *(sp_t) (aT[u] + (int64_t) c * VFT_TILE);   // wave-uniform address: scalar load
+            uint4 va;
+            va.x = q.x; va.y = q.y; va.z = q.z; va.w = q.w;
+            vft_seq_counts(va, vb, nUse[u], nSame[u]);
+        }
+    }
+    if (tb >= nB) return;
+    const REAL outB = bOk ? A.outDist[b] : (REAL) 0;
+    const int64_t nOutB = bOk ? A.nOutActive[b] : s.nActive;
+#pragma unroll
+    for (int u = 0; u < VFT_LB_A; u++) {
+        if (a0 + u >= nA) break;
+        const int64_t a = aId[u];
+        REAL d = (REAL) 1e20, w = 0, cr = (REAL) 1e20;
+        if (a >= 0 && bOk) {   // seqDist, NJ.tcc:1621-1623, and the criterion of NJ.tcc:1099-1107
+            w = (REAL) (double) nUse[u];
+            d = (REAL) (nUse[u] > 0 ? (double) (nUse[u] - nSame[u]) / (double) nUse[u] : 1.0);
+            cr = vft_criterion<REAL>(d, A.outDist[a], A.nOutActive[a], outB, nOutB, s.nActive);
+        }
+        const int64_t o = (a0 + u) * nB + tb;
+        dist[o] = d;
+        weight[o] = w;
+        crit[o] = cr;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ top-k select
 // The reference sorts all N hits of a sweep and keeps the first 2m (NJ.tcc:3810, 4541).  Here the k best are
 // selected without sorting N records: criteria are mapped monotonically onto a 50-bit fixed-point value

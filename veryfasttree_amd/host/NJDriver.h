@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <cstdint>
 #include <stdexcept>
@@ -654,6 +655,8 @@ namespace veryfasttree {
         std::vector<int64_t> age, topvisible, hitSource;
         std::vector<Hit> visible;
         std::vector<int64_t> inTopScratch;   /* resetTopVisible: all -1 between calls */
+        std::vector<uint8_t> seenScratch;    /* resetTopVisible: all 0 between calls */
+        bool leafBlocks = true;              /* setAllLeafTopHits: vft_leaf_block_distances applies (nucleotides, no matrix) */
 
         void chk(int rc) {
             if (rc != VFT_OK) throw std::invalid_argument(std::string("NJDriver: ") + vft_last_error(ctx));
@@ -859,30 +862,69 @@ namespace veryfasttree {
             return node;
         }
 
-        /* ---- sorting with the reference's tie rule: ascending key, ties by DESCENDING position */
-        static void sortByCriterion(std::vector<Besthit> &v) {
-            std::vector<int64_t> order(v.size());
-            for (size_t t = 0; t < v.size(); t++) order[t] = (int64_t) t;
-            std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-                if (v[a].criterion != v[b].criterion) return v[a].criterion < v[b].criterion;
-                return a > b;
-            });
+        /* ---- sorting with the reference's tie rule: ascending key, ties by DESCENDING position.
+           The lists a join sorts have ~2m entries (2000 at a million sequences) and a comparison sort through 40-byte
+           records was most of a join's host time; keys are packed into integers and sorted by a stable LSD radix sort
+           that starts from the positions in descending order - stability then IS the tie rule - and skips the bytes all
+           keys share. */
+        static uint64_t orderedKey(float x) {
+            if (x == 0) x = 0;   /* -0.0 and +0.0 compare equal in the reference's comparator */
+            uint32_t u;
+            memcpy(&u, &x, 4);
+            return (uint64_t) ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+        }
+
+        static uint64_t orderedKey(double x) {
+            if (x == 0) x = 0;
+            uint64_t u;
+            memcpy(&u, &x, 8);
+            return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+        }
+
+        /* order = the permutation that sorts keys ascending, equal keys by descending position */
+        static void radixOrder(const std::vector<uint64_t> &keys, std::vector<uint32_t> &order) {
+            const size_t n = keys.size();
+            order.resize(n);
+            for (size_t t = 0; t < n; t++) order[t] = (uint32_t) (n - 1 - t);
+            if (n < 2) return;
+            uint64_t orAll = 0, andAll = ~0ull;
+            for (uint64_t k: keys) {
+                orAll |= k;
+                andAll &= k;
+            }
+            const uint64_t differ = orAll ^ andAll;
+            std::vector<uint32_t> tmp(n);
+            for (int b = 0; b < 8; b++) {
+                if (((differ >> (8 * b)) & 0xFFu) == 0) continue;
+                uint32_t count[257] = {0};
+                for (size_t t = 0; t < n; t++) count[((keys[order[t]] >> (8 * b)) & 0xFFu) + 1]++;
+                for (int c = 0; c < 256; c++) count[c + 1] += count[c];
+                for (size_t t = 0; t < n; t++) tmp[count[(keys[order[t]] >> (8 * b)) & 0xFFu]++] = order[t];
+                order.swap(tmp);
+            }
+        }
+
+        static void permute(std::vector<Besthit> &v, const std::vector<uint32_t> &order) {
             std::vector<Besthit> out(v.size());
             for (size_t t = 0; t < v.size(); t++) out[t] = v[order[t]];
             v.swap(out);
         }
 
+        static void sortByCriterion(std::vector<Besthit> &v) {
+            std::vector<uint64_t> keys(v.size());
+            for (size_t t = 0; t < v.size(); t++) keys[t] = orderedKey(v[t].criterion);
+            std::vector<uint32_t> order;
+            radixOrder(keys, order);
+            permute(v, order);
+        }
+
         static void sortByIJ(std::vector<Besthit> &v) {
-            std::vector<int64_t> order(v.size());
-            for (size_t t = 0; t < v.size(); t++) order[t] = (int64_t) t;
-            std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-                if (v[a].i != v[b].i) return v[a].i < v[b].i;
-                if (v[a].j != v[b].j) return v[a].j < v[b].j;
-                return a > b;
-            });
-            std::vector<Besthit> out(v.size());
-            for (size_t t = 0; t < v.size(); t++) out[t] = v[order[t]];
-            v.swap(out);
+            /* node ids are below 2^31 and -1 marks an empty record: (i + 1, j + 1) packs into 64 bits in order */
+            std::vector<uint64_t> keys(v.size());
+            for (size_t t = 0; t < v.size(); t++) keys[t] = ((uint64_t) (uint32_t) (v[t].i + 1) << 32) | (uint64_t) (uint32_t) (v[t].j + 1);
+            std::vector<uint32_t> order;
+            radixOrder(keys, order);
+            permute(v, order);
         }
 
         /* ---- top-hits structures */
@@ -1100,41 +1142,61 @@ namespace veryfasttree {
             Section sec(this, "[host] resetTopVisible (incl. device)");
             /* the reference sorts a value-initialised array of nActive records of which only nVisible are filled:
                the zero records take part in the sort and only the first nVisible sorted positions are considered */
-            std::vector<Besthit> vis((size_t) nActive);
-            for (Besthit &b: vis) {
-                b.i = b.j = 0;
-                b.weight = b.dist = b.criterion = 0;
-            }
-            int64_t nVisible = 0;
-            {
-                std::vector<int64_t> nodes;
-                for (int64_t node = 0; node < maxnode; node++)
-                    if (parent[node] < 0) nodes.push_back(node);
-                prefetchVisible(nActive, nodes);
-            }
             drain();
+            /* 1. getVisible of every active node touches setCriterion: refresh the out-distances that are staler than
+                  allowed, all in one device call (what prefetchVisible does, without the intermediate pair lists) */
+            const int64_t allow = nDiffAllow(nActive);
+            if (seenScratch.size() != (size_t) maxnodes) seenScratch.assign((size_t) maxnodes, 0);
+            std::vector<int64_t> stale, vi;
+            vi.reserve((size_t) nActive);
             for (int64_t node = 0; node < maxnode; node++) {
                 if (parent[node] >= 0) continue;
-                const Hit &hv = visible[node];
-                if (hv.j < 0 || parent[hv.j] >= 0) continue;   /* getVisible fails, NJ.tcc:550-552 */
-                Besthit &v = vis[nVisible++];
-                v.i = node;
-                v.j = hv.j;
-                v.dist = hv.dist;
-                v.weight = -1;
-                v.criterion = (REAL) 1e20;
+                const int64_t j = visible[node].j;
+                if (j < 0 || parent[j] >= 0) continue;   /* getVisible fails, NJ.tcc:550-552 */
+                vi.push_back(node);
+                if (mN[node] - nActive > allow && !seenScratch[(size_t) node]) {
+                    seenScratch[(size_t) node] = 1;
+                    stale.push_back(node);
+                }
+                if (mN[j] - nActive > allow && !seenScratch[(size_t) j]) {
+                    seenScratch[(size_t) j] = 1;
+                    stale.push_back(j);
+                }
             }
-#pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
-            for (int64_t t = 0; t < nVisible; t++) criterionFresh(nActive, vis[t]);
-            /* Only a prefix of the sorted array is ever looked at (until the top-visible list is full), and the order
-               (criterion ascending, ties by descending position) is total: select + sort that prefix, doubling it
-               in the rare case it does not suffice, instead of sorting nActive records every m/2 joins. */
-            std::vector<int64_t> order((size_t) nActive);
-            for (int64_t t = 0; t < nActive; t++) order[(size_t) t] = t;
-            auto before = [&](int64_t a, int64_t b) {
-                if (vis[a].criterion != vis[b].criterion) return vis[a].criterion < vis[b].criterion;
-                return a > b;
+            for (int64_t v: stale) seenScratch[(size_t) v] = 0;
+            if (!stale.empty()) {
+                std::sort(stale.begin(), stale.end());
+                const int64_t n = (int64_t) stale.size();
+                chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, n, stale.data(), nActive, totdiam); });
+                pending = true;
+                drain();
+            }
+            /* 2. criteria of the nVisible real records; the remaining nActive - nVisible records are zeros */
+            const int64_t nVisible = (int64_t) vi.size();
+            struct Key {
+                uint64_t key;
+                uint32_t negPos;   /* ~position: ascending (key, negPos) = criterion ascending, ties by descending position */
             };
+            std::vector<Key> keys((size_t) nActive);
+#pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
+            for (int64_t t = 0; t < nActive; t++) {
+                REAL crit = 0;
+                if (t < nVisible) {
+                    Besthit b;
+                    b.i = vi[(size_t) t];
+                    b.j = visible[(size_t) b.i].j;
+                    b.dist = visible[(size_t) b.i].dist;
+                    b.criterion = (REAL) 1e20;
+                    criterionFresh(nActive, b);
+                    crit = b.criterion;
+                }
+                keys[(size_t) t].key = orderedKey(crit);
+                keys[(size_t) t].negPos = ~(uint32_t) t;
+            }
+            /* Only a prefix of the sorted array is ever looked at (until the top-visible list is full), and the order
+               is total: select + sort that prefix, doubling it in the rare case it does not suffice, instead of sorting
+               nActive records every m/2 joins. */
+            auto before = [](const Key &a, const Key &b) { return a.key != b.key ? a.key < b.key : a.negPos < b.negPos; };
             if (inTopScratch.size() != (size_t) maxnodes) inTopScratch.assign((size_t) maxnodes, -1);
             std::vector<int64_t> &inTop = inTopScratch;
             std::vector<int64_t> touched;
@@ -1143,17 +1205,19 @@ namespace veryfasttree {
             while (t < nVisible && save < topvisible.size()) {
                 if (t == sorted) {
                     const int64_t upto = std::min<int64_t>(nActive, std::max<int64_t>(2 * sorted, 4 * (int64_t) topvisible.size() + 64));
-                    if (upto < nActive) std::nth_element(order.begin() + sorted, order.begin() + upto, order.end(), before);
-                    std::sort(order.begin() + sorted, order.begin() + upto, before);
+                    if (upto < nActive) std::nth_element(keys.begin() + sorted, keys.begin() + upto, keys.end(), before);
+                    std::sort(keys.begin() + sorted, keys.begin() + upto, before);
                     sorted = upto;
                 }
-                const Besthit &v = vis[(size_t) order[(size_t) t++]];
-                if (inTop[v.i] != v.j) {
-                    topvisible[save++] = v.i;
-                    inTop[v.i] = v.j;
-                    inTop[v.j] = v.i;
-                    touched.push_back(v.i);
-                    touched.push_back(v.j);
+                const int64_t pos = (int64_t) (uint32_t) ~keys[(size_t) t++].negPos;
+                const int64_t vI = pos < nVisible ? vi[(size_t) pos] : 0;
+                const int64_t vJ = pos < nVisible ? visible[(size_t) vI].j : 0;
+                if (inTop[(size_t) vI] != vJ) {
+                    topvisible[save++] = vI;
+                    inTop[(size_t) vI] = vJ;
+                    inTop[(size_t) vJ] = vI;
+                    touched.push_back(vI);
+                    touched.push_back(vJ);
                 }
             }
             for (int64_t v: touched) inTop[(size_t) v] = -1;
@@ -1232,34 +1296,62 @@ namespace veryfasttree {
                         }
                     }
                     const int64_t K = 2 * m, nNb = (int64_t) cns.size();
+                    if (nNb == 0) continue;
+                    /* nucleotides with %-different distances: every pair is an integer seqDist - one block call
+                       (k_leaf_block); the device refuses it for other alphabets / a distance matrix, once */
+                    bool block = leafBlocks;
                     std::vector<int64_t> pi, pj, first((size_t) nNb + 1, 0);
-                    pi.reserve((size_t) (nNb * K));
-                    pj.reserve((size_t) (nNb * K));
-                    for (int64_t a = 0; a < nNb; a++) {
-                        for (int64_t t = 0; t < K; t++) {
-                            const int64_t j = best[t].j;
-                            if (j < 0 || j == cns[a]) continue;
-                            pi.push_back(cns[a]);
-                            pj.push_back(j);
+                    std::vector<REAL> pd, pw, pc;
+                    if (block) {
+                        std::vector<int64_t> cand((size_t) K);
+                        for (int64_t t = 0; t < K; t++) cand[(size_t) t] = best[t].j;
+                        pd.resize((size_t) (nNb * K));
+                        pw.resize((size_t) (nNb * K));
+                        pc.resize((size_t) (nNb * K));
+                        /* rows of at most ~4M pairs per call keep the result block (3 arrays) within a few tens of MB */
+                        const int64_t rows = std::max<int64_t>(1, (int64_t) (4000000 / K));
+                        for (int64_t a0 = 0; a0 < nNb && block; a0 += rows) {
+                            const int64_t cnt = std::min<int64_t>(rows, nNb - a0);
+                            int rc = VFT_OK;
+                            chkT("vft_leaf_block_distances", [&]() {
+                                rc = vft_leaf_block_distances(ctx, cnt, cns.data() + a0, K, cand.data(), n, nDiffAllow(n), totdiam,
+                                                              pd.data() + a0 * K, pw.data() + a0 * K, pc.data() + a0 * K);
+                                return rc == VFT_ERR_STATE ? VFT_OK : rc;
+                            });
+                            if (rc == VFT_ERR_STATE) block = leafBlocks = false;
                         }
-                        first[(size_t) a + 1] = (int64_t) pi.size();
                     }
-                    const int64_t nPairs = (int64_t) pi.size();
-                    std::vector<REAL> pd((size_t) nPairs), pw((size_t) nPairs), pc((size_t) nPairs);
-                    const int64_t maxCall = 1 << 22;
-                    for (int64_t p0 = 0; p0 < nPairs; p0 += maxCall) {
-                        const int64_t cnt = std::min<int64_t>(maxCall, nPairs - p0);
-                        chkT("vft_pair_distances", [&]() {
-                            return vft_pair_distances(ctx, cnt, pi.data() + p0, pj.data() + p0, n, nDiffAllow(n), totdiam,
-                                                      pd.data() + p0, pw.data() + p0, pc.data() + p0);
-                        });
+                    if (!block) {
+                        pi.reserve((size_t) (nNb * K));
+                        pj.reserve((size_t) (nNb * K));
+                        for (int64_t a = 0; a < nNb; a++) {
+                            for (int64_t t = 0; t < K; t++) {
+                                const int64_t j = best[t].j;
+                                if (j < 0 || j == cns[a]) continue;
+                                pi.push_back(cns[a]);
+                                pj.push_back(j);
+                            }
+                            first[(size_t) a + 1] = (int64_t) pi.size();
+                        }
+                        const int64_t nPairs = (int64_t) pi.size();
+                        pd.resize((size_t) nPairs);
+                        pw.resize((size_t) nPairs);
+                        pc.resize((size_t) nPairs);
+                        const int64_t maxCall = 1 << 22;
+                        for (int64_t p0 = 0; p0 < nPairs; p0 += maxCall) {
+                            const int64_t cnt = std::min<int64_t>(maxCall, nPairs - p0);
+                            chkT("vft_pair_distances", [&]() {
+                                return vft_pair_distances(ctx, cnt, pi.data() + p0, pj.data() + p0, n, nDiffAllow(n), totdiam,
+                                                          pd.data() + p0, pw.data() + p0, pc.data() + p0);
+                            });
+                        }
                     }
                     pending = false;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(opt.hostThreads)
                     for (int64_t a = 0; a < nNb; a++) {
                         const int64_t cn = cns[(size_t) a];
                         std::vector<Besthit> nb((size_t) K);
-                        int64_t u = first[(size_t) a];
+                        int64_t u = block ? a * K : first[(size_t) a];
                         for (int64_t t = 0; t < K; t++) {
                             Besthit &h = nb[(size_t) t];
                             h.i = cn;
@@ -1268,6 +1360,7 @@ namespace veryfasttree {
                                 h.weight = 0;
                                 h.dist = (REAL) -1e20;
                                 h.criterion = (REAL) 1e20;
+                                if (block) u++;
                             } else {
                                 h.dist = pd[(size_t) u];
                                 h.weight = pw[(size_t) u];
