@@ -918,9 +918,17 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
         crit[t] = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], s.nActive);
     }
     if (flag) {
+        // The results above went to host-mapped memory; they must have LEFT the chip before the counter moves and,
+        // for the last item, before the flag does.  The explicit s_waitcnt is not redundant: ROCm 7.2 on gfx950 can drop
+        // the wait that belongs to the fence's write-back when a returned atomic follows (MI355X_MICROARCH.md, "Compiler
+        // hazard") - observed here as a host that now and then read the previous call's numbers from the ring
+        // (one 100 000-taxon tree in two came out different).
         __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(doneCtr, 1u) == (unsigned int) (n - 1)) {
             *doneCtr = 0;   // launches on this stream are ordered: the next list starts from zero
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
