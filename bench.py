@@ -148,7 +148,7 @@ def dense_profile_roofline(ops, state, n, L, groups=32768):
                 achieved=ach, frac=ach / HBM_PEAK_GBS, achieved_moved_gbs=mov, frac_moved=mov / HBM_PEAK_GBS)
 
 
-def end_to_end_c3(device):
+def end_to_end_c3(device, comm=None):
     """Wall-clock to a tree at BASELINE config C3's shape: 100 000 nt x 500, `-nt -fastest` NJ phase (top hits with the
     second-level lists, as the reference runs it at one thread), root, minimum-evolution branch lengths, Newick - what
     `VeryFastTree -nt -fastest -noml -nome -nosupport` prints.  newick_crc is compared with the reference's own output
@@ -161,11 +161,14 @@ def end_to_end_c3(device):
     names = ["s%d" % k for k in range(n)]
     t0 = time.perf_counter()
     tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m, device=device), codes, names,
-                     fastest=True, me_lengths=True)
+                     fastest=True, me_lengths=True, comm=comm)
     wall = time.perf_counter() - t0
     crc = zlib.crc32(tree.encode())
     out = dict(workload="c3_100k_x500_nt_fastest_nj_tree", wall_s=round(wall, 2), unique_seqs=int(len(np.unique(codes, axis=0))),
                newick_bytes=len(tree), newick_crc=crc)
+    if comm is not None:   # what was actually split over the ranks: sweeps + leaf blocks (the join loop itself is replicated)
+        out["allgathers"] = int(comm.calls)
+        out["allgather_bytes"] = int(comm.bytes)
     ref = os.path.join(ROOT, "tests", "golden", "bb_c3_crc.npz")
     if os.path.exists(ref):
         want = int(np.load(ref)["newick_crc"])
@@ -333,11 +336,22 @@ def main():
         crc = zlib.crc32(np.ascontiguousarray(hits["j"]).tobytes(), crc)
         crc = zlib.crc32(np.ascontiguousarray(hits["criterion"]).tobytes(), crc)
     line["hits_crc"] = crc
-    if world == 1 and not args.no_e2e and (n, L) == (1000000, 200):
-        # the other half of BASELINE's metric: wall-clock to a tree (one GPU; the NJ driver does not shard yet)
+    if not args.no_e2e and (n, L) == (1000000, 200):
+        # the other half of BASELINE's metric: wall-clock to a tree.  With several ranks the C++ driver runs on every rank
+        # (replicated join decisions) and splits its sweeps and leaf blocks over them (include/vft_host.h, vft_comm)
         ops.close()
         del state
-        line["e2e"] = end_to_end_c3(local_rank)
+        comm = None
+        if use_dist:
+            from veryfasttree_amd.backend import TorchComm
+            comm = TorchComm(dist, local_rank)
+            barrier()
+        e2e = end_to_end_c3(local_rank, comm)
+        if use_dist:
+            t = torch.tensor([e2e["wall_s"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2e["wall_s"] = round(float(t.item()), 2)
+        line["e2e"] = e2e
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

@@ -150,6 +150,11 @@ int vft_sweep_batch(vft_ctx *ctx, int32_t n_seeds, const int64_t *queries, int64
 /* Restrict sweeps/out-distance passes to node ids [lo, hi): the shard a rank owns in a multi-GPU run
    (default [0, max_nodes)).  Hits keep global ids. */
 int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);
+/* refresh_all != 0: the lazy out-distance refresh that precedes a sweep covers every node below maxnode instead of the
+   shard.  A multi-GPU run that keeps the whole NJ state on every rank (host/NJDriver.h) needs that: out-distances are
+   state, and every rank must refresh the same nodes at the same moments for the ranks to stay bit-identical; only the
+   distances of the sweep itself are split.  With it vft_set_shard no longer forgets what it knows about staleness. */
+int vft_set_shard_mode(vft_ctx *ctx, int32_t refresh_all);
 /* Multi-GPU merge: d_all holds n_lists sorted lists of k records each (every rank's vft_sweep d_hits, all-gathered,
    DEVICE memory).  Produces the k best records under the same (criterion asc, id desc) order into hits (host, may be
    NULL) and d_out (device, may be NULL) — the result a single-rank sweep over the union of the shards would give. */

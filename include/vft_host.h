@@ -11,6 +11,27 @@
 extern "C" {
 #endif
 
+/* Multi-GPU runs of the NJ driver: one process per GPU, every rank runs the SAME driver on the same input and keeps the
+   whole NJ state (profiles, out-distances, top-hit lists) - join decisions are replicated and bit-identical - while the
+   two bulk distance computations are split over the ranks and exchanged:
+     - the one-vs-all sweeps (setBestHit, NJ.tcc:3571-3646): rank r sweeps its share of the target ids and selects its
+       local top-2m, one all-gather of the k-record lists (device memory: RCCL over xGMI), every rank merges them under the
+       reference's (criterion asc, id desc) order (vft_merge_hits);
+     - the close-neighbour blocks of setAllLeafTopHits (vft_leaf_block_distances): rows split over the ranks, host arrays
+       all-gathered.
+   The driver is transport-agnostic: the caller supplies the buffers and one collective.  allgather(user, bytes, device)
+   must gather `bytes` bytes from every rank's send buffer into every rank's recv buffer in rank order - d_send / d_recv
+   (device memory, capacity d_cap / world * d_cap) when device != 0, h_send / h_recv (host) otherwise - and return 0. */
+typedef struct vft_comm {
+    int32_t rank, world;
+    int (*allgather)(void *user, int64_t bytes, int32_t device);
+    void *user;
+    void *d_send, *d_recv;
+    int64_t d_cap;
+    void *h_send, *h_recv;
+    int64_t h_cap;
+} vft_comm;
+
 typedef struct {
     int32_t fastest;            /* -fastest (main.cpp:339-343): also sets tophits_refresh = 0.5 in the caller */
     int32_t use_tophits_2nd;    /* Options::useTopHits2nd: on with -fastest at one thread (VeryFastTree.cpp:87-91) */
@@ -48,6 +69,7 @@ typedef struct {
                                    with scoredist log-correction, and before the ML stage re-averages every profile in
                                    the model's eigen-basis (transMatToDistanceMat + recomputeProfiles,
                                    VeryFastTreeImpl.tcc:253-256, 517-542) and installs the transition matrix */
+    const vft_comm *comm;       /* NULL = one GPU; otherwise see vft_comm above (top-hits NJ phase only) */
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

@@ -151,3 +151,28 @@ def test_c3_tree_equals_the_reference_tree():
     tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m), codes, names, fastest=True, me_lengths=True)
     assert len(tree) == int(ref["newick_bytes"])
     assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
+
+
+@pytest.mark.parametrize("mode", [[], ["fastest"], ["fastest", "second"]])
+def test_nj_driver_join_order_is_rank_count_independent(mode):
+    """The C++ NJ driver with its sweeps and leaf blocks split over two ranks (vft_comm over torch.distributed; both ranks
+    on this box's one GPU, gloo): every rank must produce the join order of the single-rank run - the whole NJ state is
+    replicated, only distance computations are divided, and merged top-k lists equal unsharded ones."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "run_nj_ranks.py")
+    args = ["3000", "150"] + mode
+    one = subprocess.run([sys.executable, script] + args, check=True, stdout=subprocess.PIPE, timeout=600).stdout.decode()
+    env = dict(os.environ, VFT_SAME_DEVICE="1", VFT_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29541", script] + args, check=True, stdout=subprocess.PIPE, env=env,
+                         timeout=900).stdout.decode()
+    want = re.search(r"rank 0 crc (\d+) joins (\d+)", one).groups()
+    got = re.findall(r"rank (\d) crc (\d+) joins (\d+) allgathers (\d+)", two)
+    assert len(got) == 2
+    for r, crc, nj, calls in got:
+        assert (crc, nj) == want, (r, crc, nj, want)
+        assert int(calls) > 10          # the exchange really ran

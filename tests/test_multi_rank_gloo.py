@@ -128,3 +128,73 @@ def test_batched_exchange_of_several_seeds(tmp_path):
         want = want[crit[want] < np.float32(1e20)][:k]
         assert np.array_equal(merged[s]["j"][:len(want)], want), key
         assert np.array_equal(merged[s]["criterion"][:len(want)], crit[want]), key
+
+
+class _ShardedOps:
+    """OracleOps whose one-vs-all sweep is split over the gloo ranks exactly the way the C++ driver splits it over GPUs
+    (host/NJDriver.h::sweep): this rank's tiles of the target ids, its local top-k, one all-gather, the merge in the
+    reference's order.  Everything else - the lazy out-distance refreshes included - is replicated."""
+
+    def __init__(self, ops, rank, world):
+        self._ops, self._rank, self._world = ops, rank, world
+        self.exchanges = 0
+
+    def __getattr__(self, name):
+        return getattr(self._ops, name)
+
+    def setBestHit(self, query, n_active, n_diff_allow, totdiam, k, want_best=True, d_hits=None, want_hits=True):
+        ops = self._ops
+        n = ops.maxnode
+        # replicated: every rank evaluates (and lazily refreshes) like a single rank would ...
+        crit = np.full(n, 1e20, ops.dt)
+        dd = np.full(n, 1e20, ops.dt)
+        ww = np.zeros(n, ops.dt)
+        for j in range(n):
+            if ops.parent[j] >= 0:
+                continue
+            dd[j], ww[j], crit[j] = ops._dist_crit(query, j, n_active, n_diff_allow, totdiam)
+        # ... but only its own tiles of the result enter its list
+        tiles = (n + 63) // 64
+        per = (tiles + self._world - 1) // self._world
+        lo, hi = min(n, self._rank * per * 64), min(n, (self._rank + 1) * per * 64)
+        mine = _local_topk(crit, dd, ww, lo, hi, k)
+        t_mine = torch.from_numpy(mine.view(np.uint8).copy())
+        t_all = torch.zeros(self._world * t_mine.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(t_all, t_mine)
+        self.exchanges += 1
+        allh = t_all.numpy().view(HIT_F32).reshape(self._world, k)
+        return merge_hits(list(allh), k), -1
+
+
+def _driver_worker(rank, world, port, name, fastest, second, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle_ops import OracleOps
+    from test_nj_driver_cpu import unique_codes
+    from veryfasttree_amd.nj_driver import NJDriver
+    d = G.load(name)
+    codes = unique_codes(d["codes"])
+    ops = _ShardedOps(OracleOps(codes.shape[0], codes.shape[1], 4, np.float32), rank, world)
+    drv = NJDriver(ops, codes, fastest=fastest, use_tophits_2nd=second)
+    if fastest:
+        drv.tophits_refresh = 0.5
+    joins = drv.run()
+    got = np.array([(a, b, c) for a, b, c, _ in joins], dtype=np.int64)
+    np.save(out % rank, got)
+    assert ops.exchanges > 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nj_driver_join_order_does_not_depend_on_the_rank_count(tmp_path):
+    """The NJ driver (Python prototype of host/NJDriver.h on the CPU oracle) with its sweeps split over two gloo ranks:
+    both ranks reproduce the reference's join order, i.e. what one rank produces."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "joins_%d.npy")
+    mp.spawn(_driver_worker, args=(2, port, "bb_nt_200", False, False, out), nprocs=2, join=True)
+    want = G.load("bb_nt_200")["joins"]
+    for r in range(2):
+        assert np.array_equal(np.load(out % r), want)

@@ -1,4 +1,5 @@
-"""The C3 tree (100k x 500, -nt -fastest, NJ + ME lengths) twice in one process: length and CRC-32 of the Newick must be\n2539208 / 1604271881 (the reference's, tests/golden/bb_c3_crc.npz) every time.  c3_repeat.py [plain|torch] [sdma0]"""
+"""The C3 tree (100k x 500, -nt -fastest, NJ + ME lengths) twice in one process: length and CRC-32 of the Newick must be
+2539208 / 1604271881 (the reference's, tests/golden/bb_c3_crc.npz) every time.  c3_repeat.py [plain|torch] [sdma0]"""
 import sys, zlib, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "torch":

@@ -6,6 +6,7 @@ like calls into the reference.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -26,7 +27,7 @@ EXPORTS = [
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
-    "vft_debug_log", "vft_leaf_block_distances",
+    "vft_debug_log", "vft_leaf_block_distances", "vft_set_shard_mode",
 ]
 
 
@@ -51,7 +52,7 @@ class _NJOptions(C.Structure):
     _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
                 ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
-                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32)]
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P)]
 
 
 _lib = None
@@ -71,9 +72,67 @@ def load_host_library():
 
 AA_MODELS = {None: 0, "": 0, "jtt": 1, "wag": 2, "lg": 3}
 
+_ALLGATHER = C.CFUNCTYPE(C.c_int, P, I64, I32)
+
+
+class _Comm(C.Structure):
+    _fields_ = [("rank", I32), ("world", I32), ("allgather", _ALLGATHER), ("user", P), ("d_send", P), ("d_recv", P),
+                ("d_cap", I64), ("h_send", P), ("h_recv", P), ("h_cap", I64)]
+
+
+class TorchComm:
+    """vft_comm (include/vft_host.h) over torch.distributed: exchange buffers as torch tensors (device + pinned host) and
+    ONE collective, all_gather_into_tensor - RCCL over xGMI with the nccl backend; with gloo (CPU tests, two ranks on one
+    GPU) the device buffers travel through the host.  `dist` must be initialised; device = this rank's GPU ordinal."""
+
+    def __init__(self, dist, device, d_cap=1 << 20, h_cap=64 << 20):
+        import torch
+        self.dist, self.torch = dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.gloo = dist.get_backend() != "nccl"
+        dev = torch.device("cuda", device)
+        self.d_send = torch.zeros(d_cap, dtype=torch.uint8, device=dev)
+        self.d_recv = torch.zeros(self.world * d_cap, dtype=torch.uint8, device=dev)
+        self.h_send = torch.zeros(h_cap, dtype=torch.uint8)
+        self.h_recv = torch.zeros(self.world * h_cap, dtype=torch.uint8)
+        self.calls = 0
+        self.bytes = 0
+
+        def allgather(_user, nbytes, device_side):
+            try:
+                self.calls += 1
+                self.bytes += int(nbytes) * self.world
+                if device_side:
+                    if self.gloo:
+                        out = torch.zeros(self.world * nbytes, dtype=torch.uint8)
+                        dist.all_gather_into_tensor(out, self.d_send[:nbytes].cpu())
+                        self.d_recv[:self.world * nbytes].copy_(out)
+                        torch.cuda.synchronize(dev)
+                    else:
+                        torch.cuda.synchronize(dev)   # the driver's stream is not torch's
+                        dist.all_gather_into_tensor(self.d_recv[:self.world * nbytes], self.d_send[:nbytes])
+                        torch.cuda.synchronize(dev)
+                elif self.gloo:
+                    dist.all_gather_into_tensor(self.h_recv[:self.world * nbytes], self.h_send[:nbytes])
+                else:
+                    out = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
+                    dist.all_gather_into_tensor(out, self.h_send[:nbytes].to(dev))
+                    self.h_recv[:self.world * nbytes].copy_(out.cpu())
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                sys.stderr.write("TorchComm.allgather failed: %r\n" % (e,))
+                return 1
+
+        self._cb = _ALLGATHER(allgather)
+        self.struct = _Comm(self.rank, self.world, self._cb, None, self.d_send.data_ptr(), self.d_recv.data_ptr(), d_cap,
+                            self.h_send.data_ptr(), self.h_recv.data_ptr(), h_cap)
+
+    def pointer(self):
+        return C.cast(C.pointer(self.struct), P)
+
 
 def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False, aa_model=None,
-           tophits_mult=1.0):
+           tophits_mult=1.0, comm=None):
     """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n]).
     second_level defaults to `fastest`, as in the reference at one thread (-fastest turns -2nd on)."""
     lib = load_host_library()
@@ -83,7 +142,8 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, float(tophits_mult), -1.0,
                      tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
-                     200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0, AA_MODELS[aa_model])
+                     200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0, AA_MODELS[aa_model],
+                     comm.pointer() if comm is not None else None)
     joins = np.zeros((max(n - 3, 1), 3), np.int64)
     crit = np.zeros(max(n - 3, 1), np.float64)
     nj = I64(0)
@@ -176,7 +236,7 @@ def uniquify(codes):
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
               unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False,
-              aa_model=None):
+              aa_model=None, comm=None):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -194,7 +254,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0,
-                     AA_MODELS[aa_model])
+                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None)
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)

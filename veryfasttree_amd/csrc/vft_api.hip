@@ -27,6 +27,7 @@ struct vft_ctx {
     char err[512] = {0};
     size_t rs = 4;   // sizeof(real)
     int64_t maxnode = 0, shardLo = 0, shardHi = 0;
+    bool refreshAll = false;   // vft_set_shard_mode: lazy refreshes ignore the shard
     int64_t nProfTiles = 0, nLeafTiles = 0;
     bool leavesUp = false;
 
@@ -758,7 +759,14 @@ extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
         return fail(c, VFT_ERR_INVALID, "vft_set_shard: need 0 <= lo <= hi <= max_nodes and lo %% 64 == 0");
     c->shardLo = lo;
     c->shardHi = hi;
-    c->maxStamp = (int64_t) 1 << 62;   // the bound was about the previous range
+    if (!c->refreshAll) c->maxStamp = (int64_t) 1 << 62;   // the bound was about the previous range
+    return VFT_OK;
+}
+
+extern "C" int vft_set_shard_mode(vft_ctx *c, int32_t refreshAll) {
+    if (!c) return VFT_ERR_INVALID;
+    c->refreshAll = refreshAll != 0;
+    c->maxStamp = (int64_t) 1 << 62;
     return VFT_OK;
 }
 
@@ -1225,8 +1233,8 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
                                 double totdiam, bool force) {
     SweepArgs s{};
     s.query = -1;
-    s.lo = c->shardLo;
-    s.hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
+    s.lo = (c->refreshAll && !dIds) ? 0 : c->shardLo;
+    s.hi = (c->refreshAll && !dIds) ? c->maxnode : (c->shardHi < c->maxnode ? c->shardHi : c->maxnode);
     s.nActive = nActive;
     s.nDiffAllow = nDiffAllow;
     s.totdiam = totdiam;

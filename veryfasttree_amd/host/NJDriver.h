@@ -30,7 +30,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/vft_hip.h"
+#include "../../include/vft_host.h"
 #include "MLLengths.h"
 #include "KnuthRng.h"
 #include "AAModels.h"
@@ -55,6 +55,8 @@ namespace veryfasttree {
         /* amino acids: 0 = matrices are the caller's business, else AAModel (JTT / WAG / LG): BLOSUM45-derived distances in
            the NJ / ME phase, the model's transition matrix in the ML phase (VeryFastTreeImpl.tcc:96-108, 253-256) */
         int aaModel = 0;
+        /* multi-GPU (include/vft_host.h, vft_comm): sweeps and leaf blocks are split over the ranks */
+        const vft_comm *comm = nullptr;
     };
 
     template<typename REAL>
@@ -84,6 +86,11 @@ namespace veryfasttree {
                 selfweightLeaf[i] = (REAL) c;
             }
             if (opt.aaModel) installBlosum45();
+            if (opt.comm && opt.comm->world > 1) {
+                if (!opt.comm->allgather || !opt.comm->d_send || !opt.comm->d_recv || !opt.comm->h_send || !opt.comm->h_recv)
+                    throw std::invalid_argument("NJDriver: incomplete vft_comm");
+                chkT("vft_set_shard_mode", [&]() { return vft_set_shard_mode(ctx, 1); });
+            }
             /* NJ constructor, NJ.tcc:233-260 */
             chkT("vft_upload_leaves", [&]() { return vft_upload_leaves(ctx, codes); });
             std::vector<REAL> z(nSeqs, 0);
@@ -1225,10 +1232,36 @@ namespace veryfasttree {
             topvisibleAge = 0;
         }
 
-        /* one-vs-all sweep -> the first k records of the reference's sorted besthits array */
+        /* one-vs-all sweep -> the first k records of the reference's sorted besthits array.  With several ranks: this
+           rank's share of the target ids (whole tiles of 64), its local top-k into the exchange buffer, one all-gather, the
+           merge under the reference's order on every rank - the same k records a single sweep selects. */
         std::vector<Besthit> sweep(int64_t node, int64_t nActive, int32_t k) {
             std::vector<DevHit> dev((size_t) k);
-            chkT("vft_sweep", [&]() { return vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, k, dev.data(), nullptr, nullptr); });
+            const vft_comm *cm = opt.comm;
+            if (cm && cm->world > 1) {
+                const int64_t bytes = (int64_t) k * (int64_t) sizeof(DevHit);
+                if (bytes > cm->d_cap) throw std::invalid_argument("NJDriver: vft_comm device buffers too small for a sweep");
+                const int64_t tiles = (maxnode + 63) / 64, per = (tiles + cm->world - 1) / cm->world;
+                const int64_t tlo = std::min<int64_t>(tiles, cm->rank * per), thi = std::min<int64_t>(tiles, (cm->rank + 1) * per);
+                if (thi > tlo) {
+                    const int64_t lo = tlo * 64, hi = std::min<int64_t>(maxnode, thi * 64);
+                    chkT("vft_set_shard", [&]() { return vft_set_shard(ctx, lo, hi); });
+                    chkT("vft_sweep", [&]() { return vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, k, nullptr, cm->d_send, nullptr); });
+                    chkT("vft_synchronize", [&]() { return vft_synchronize(ctx); });
+                } else {   /* more ranks than tiles: this rank contributes an empty list */
+                    for (int32_t t = 0; t < k; t++) {
+                        dev[t].j = -1;
+                        dev[t].dist = dev[t].criterion = (decltype(dev[t].dist)) 1e20;
+                        dev[t].weight = 0;
+                    }
+                    chkT("vft_device_upload", [&]() { return vft_device_upload(ctx, cm->d_send, dev.data(), bytes); });
+                }
+                if (cm->allgather(cm->user, bytes, 1) != 0) throw std::runtime_error("NJDriver: all-gather of the sweep lists failed");
+                chkT("vft_merge_hits", [&]() { return vft_merge_hits(ctx, cm->d_recv, cm->world, k, dev.data(), nullptr); });
+                chkT("vft_set_shard", [&]() { return vft_set_shard(ctx, 0, maxnodes); });
+            } else {
+                chkT("vft_sweep", [&]() { return vft_sweep(ctx, node, nActive, nDiffAllow(nActive), totdiam, k, dev.data(), nullptr, nullptr); });
+            }
             pending = false;
             std::vector<Besthit> out((size_t) k);
             for (int32_t t = 0; t < k; t++) {
@@ -1239,6 +1272,41 @@ namespace veryfasttree {
                 out[t].criterion = (REAL) dev[t].criterion;
             }
             return out;
+        }
+
+        /* vft_leaf_block_distances for nA x nB pairs; with several ranks the rows are split and the three result arrays
+           all-gathered through the host buffers (whole rows, padded to equal shares).  Returns the device's code. */
+        int leafBlock(int64_t nA, const int64_t *a, int64_t nB, const int64_t *b, int64_t n, REAL *pd, REAL *pw, REAL *pc) {
+            const vft_comm *cm = opt.comm;
+            if (!cm || cm->world <= 1) return vft_leaf_block_distances(ctx, nA, a, nB, b, n, nDiffAllow(n), totdiam, pd, pw, pc);
+            const int64_t W = cm->world, per = (nA + W - 1) / W;
+            const int64_t share = per * nB * (int64_t) sizeof(REAL);   /* bytes of ONE array of one rank */
+            if (3 * share > cm->h_cap) return -1;                       /* the caller takes fewer rows at a time */
+            /* Out-distances are replicated state: a lazy refresh inside a rank's share would happen on that rank only.
+               The one caller (setAllLeafTopHits) runs before the first join, when every stamp equals n. */
+            for (int64_t t = 0; t < nA; t++)
+                if (mN[a[t]] - n > nDiffAllow(n)) throw std::logic_error("NJDriver::leafBlock: stale out-distance in a sharded block");
+            const int64_t r0 = std::min(nA, cm->rank * per), r1 = std::min(nA, (cm->rank + 1) * per);
+            REAL *mine = (REAL *) cm->h_send;
+            std::fill(mine, mine + 3 * per * nB, (REAL) 0);
+            {   /* a rank without rows still asks the device for one (discarded) row: every rank must learn the same way
+                   whether the block kernel applies to this context at all, or some would skip the collective below */
+                const bool has = r1 > r0;
+                const int rc = vft_leaf_block_distances(ctx, has ? r1 - r0 : 1, a + (has ? r0 : 0), nB, b, n, nDiffAllow(n), totdiam, mine,
+                                                        mine + per * nB, mine + 2 * per * nB);
+                if (rc != VFT_OK) return rc;
+            }
+            if (cm->allgather(cm->user, 3 * share, 0) != 0) throw std::runtime_error("NJDriver: all-gather of a leaf block failed");
+            const REAL *all = (const REAL *) cm->h_recv;
+            for (int64_t r = 0; r < W; r++) {
+                const int64_t q0 = std::min(nA, r * per), q1 = std::min(nA, (r + 1) * per);
+                if (q1 <= q0) continue;
+                const REAL *src = all + r * 3 * per * nB;
+                std::copy(src, src + (q1 - q0) * nB, pd + q0 * nB);
+                std::copy(src + per * nB, src + per * nB + (q1 - q0) * nB, pw + q0 * nB);
+                std::copy(src + 2 * per * nB, src + 2 * per * nB + (q1 - q0) * nB, pc + q0 * nB);
+            }
+            return VFT_OK;
         }
 
         void setAllLeafTopHits() { /* NJ.tcc:3746-4119, threads == 1 branch, first-level lists */
@@ -1309,16 +1377,18 @@ namespace veryfasttree {
                         pw.resize((size_t) (nNb * K));
                         pc.resize((size_t) (nNb * K));
                         /* rows of at most ~4M pairs per call keep the result block (3 arrays) within a few tens of MB */
-                        const int64_t rows = std::max<int64_t>(1, (int64_t) (4000000 / K));
+                        int64_t rows = std::max<int64_t>(1, (int64_t) (4000000 / K));
+                        if (opt.comm && opt.comm->world > 1)   /* the shares of all ranks must fit the host exchange buffer */
+                            rows = std::max<int64_t>(opt.comm->world, std::min<int64_t>(rows, opt.comm->h_cap / (3 * K * (int64_t) sizeof(REAL)) - opt.comm->world));
                         for (int64_t a0 = 0; a0 < nNb && block; a0 += rows) {
                             const int64_t cnt = std::min<int64_t>(rows, nNb - a0);
                             int rc = VFT_OK;
                             chkT("vft_leaf_block_distances", [&]() {
-                                rc = vft_leaf_block_distances(ctx, cnt, cns.data() + a0, K, cand.data(), n, nDiffAllow(n), totdiam,
-                                                              pd.data() + a0 * K, pw.data() + a0 * K, pc.data() + a0 * K);
+                                rc = leafBlock(cnt, cns.data() + a0, K, cand.data(), n, pd.data() + a0 * K, pw.data() + a0 * K, pc.data() + a0 * K);
                                 return rc == VFT_ERR_STATE ? VFT_OK : rc;
                             });
                             if (rc == VFT_ERR_STATE) block = leafBlocks = false;
+                            else if (rc == -1) throw std::invalid_argument("NJDriver: vft_comm host buffers too small for a leaf block");
                         }
                     }
                     if (!block) {

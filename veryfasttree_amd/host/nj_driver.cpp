@@ -31,6 +31,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.tophits2Refresh = o->tophits2_refresh;
         opt.scoredist = o->scoredist != 0 || o->aa_model != 0;
         opt.aaModel = o->aa_model;
+        opt.comm = o->comm;
     }
     return opt;
 }
