@@ -110,6 +110,14 @@ int vft_set_max_node(vft_ctx *ctx, int64_t maxnode);           /* NJ.h: maxnode,
    vft_set_node_scalars + vft_set_out_distances for that node. */
 int vft_join_nodes(vft_ctx *ctx, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t stale_stamp);
 
+/* One join of the NJ loop in one launch (k_join_fused): vft_join_nodes + vft_average_profiles(1, newnode, i, j, unweighted)
+   + the new node's self distance + - when update_out_profile != 0 - vft_out_profile_update(i, j, newnode, n_active_old)
+   (NJ.tcc:2904-2909, 3003-3008, 3039-3042, 3034).  The new profile lives in the node's plain row until the tile streams
+   are rebuilt - lazily, for all joined nodes since the last rebuild at once, before the next call that reads tile streams
+   (sweeps, full out-profile, ...); results are those of the separate calls.  Stream-ordered. */
+int vft_join_fused(vft_ctx *ctx, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t stale_stamp,
+                   int64_t n_active_old, int32_t update_out_profile);
+
 /* ---- profiles */
 int vft_profile_upload(vft_ctx *ctx, int64_t node, const void *w, const uint8_t *codes, const void *f);
 int vft_profile_download(vft_ctx *ctx, int64_t node, void *w, uint8_t *codes, void *f);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""NJ phase on the GPU only (no reference run): nj_gpu_only.py N L [fastest] [second]"""
+"""NJ phase on the GPU only (no reference run): nj_gpu_only.py N L [fastest] [second] [mu=0.03] [gap=0.01] [seed=3]
+BASELINE config C4: nj_gpu_only.py 1000000 200 mu=0.02 gap=0.01 seed=4   (default -nt: top hits without -fastest)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,9 +8,10 @@ sys.path.insert(0, ROOT)
 from veryfasttree_amd import HipProfileOps, synth
 from veryfasttree_amd.backend import nj_run
 n, L = int(sys.argv[1]), int(sys.argv[2])
-fastest = len(sys.argv) > 3 and sys.argv[3] == "fastest"
-second = len(sys.argv) > 4 and sys.argv[4] == "second"
-codes = synth.random_descent_codes(n, L, 4, 0.03, 0.01, seed=3)
+fastest = "fastest" in sys.argv[3:]
+second = "second" in sys.argv[3:]
+kv = dict(a.split("=") for a in sys.argv[3:] if "=" in a)
+codes = synth.random_descent_codes(n, L, 4, float(kv.get("mu", 0.03)), float(kv.get("gap", 0.01)), seed=int(kv.get("seed", 3)))
 _, first = np.unique(codes, axis=0, return_index=True)
 codes = codes[np.sort(first)]
 ops = HipProfileOps(codes.shape[0], L, 4, np.float32)

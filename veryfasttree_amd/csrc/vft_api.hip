@@ -28,6 +28,10 @@ struct vft_ctx {
     size_t rs = 4;   // sizeof(real)
     int64_t maxnode = 0, shardLo = 0, shardHi = 0;
     bool refreshAll = false;   // vft_set_shard_mode: lazy refreshes ignore the shard
+    // vft_join_fused: joined nodes whose tile streams have not been rebuilt yet (their rows and stash slots are valid)
+    std::vector<int64_t> pend;
+    char *pendBase = nullptr;        // [stash of 64 nodes | meta | commit scratch], commit_plan(c, 64)
+    int64_t *pendIdsDev = nullptr;   // device copy of pend[], written by the kernel
     int64_t nProfTiles = 0, nLeafTiles = 0;
     bool leavesUp = false;
 
@@ -459,6 +463,8 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->blen) hipFree(c->blen);
+    if (c->pendBase) hipFree(c->pendBase);
+    if (c->pendIdsDev) hipFree(c->pendIdsDev);
     if (c->mlIs) hipFree(c->mlIs);
     if (c->mlC) hipFree(c->mlC);
     if (c->mlW) hipFree(c->mlW);
@@ -754,6 +760,10 @@ extern "C" int vft_join_nodes(vft_ctx *c, int64_t i, int64_t j, int64_t newnode,
     return VFT_OK;
 }
 
+static int ensure_ml_rows(vft_ctx *c);
+static int flush_pending(vft_ctx *c);
+struct CommitPlan;
+
 extern "C" int vft_set_shard(vft_ctx *c, int64_t lo, int64_t hi) {
     if (!c || lo < 0 || hi < lo || hi > c->d.maxNodes || (lo % VFT_TILE) != 0)
         return fail(c, VFT_ERR_INVALID, "vft_set_shard: need 0 <= lo <= hi <= max_nodes and lo %% 64 == 0");
@@ -857,6 +867,17 @@ static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNode
     return VFT_OK;
 }
 
+#define VFT_PEND_MAX 64
+// rebuilds the tile streams of the nodes joined by vft_join_fused since the last rebuild (their stash slots are intact)
+static int flush_pending(vft_ctx *c) {
+    if (c->pend.empty()) return VFT_OK;
+    CommitPlan plan = commit_plan(c, VFT_PEND_MAX);
+    const int64_t cnt = (int64_t) c->pend.size();
+    int r = commit_nodes(c, plan, c->pend.data(), c->pendIdsDev, cnt, c->pendBase);
+    c->pend.clear();
+    return r;
+}
+
 static int internal_ok(vft_ctx *c, int64_t node) {
     if (node < c->d.nSeqs || node >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "node %lld is not an internal node", (long long) node);
     return VFT_OK;
@@ -924,6 +945,7 @@ extern "C" int vft_profile_nvectors(vft_ctx *c, int64_t first, int64_t count, in
     if (!c || !nvec) return VFT_ERR_INVALID;
     if (first < 0 || count < 0 || first + count > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "node range out of bounds");
     if (count == 0) return VFT_OK;
+    if (int r = flush_pending(c)) return r;
     if (int r = ensure_scratch(c, (size_t) count * 8)) return r;
     VFT_DISPATCH(c, launch((k_nvectors<REAL, NC>), dim3(cdiv(count, 64)), dim3(64), 0, c->stream, arena<REAL>(c), first, count,
                            (int64_t *) c->scratch));
@@ -1085,11 +1107,47 @@ extern "C" int vft_average_chain(vft_ctx *c, int32_t n, const int64_t *out, cons
     return VFT_OK;
 }
 
+extern "C" int vft_join_fused(vft_ctx *c, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t staleStamp,
+                              int64_t nActiveOld, int32_t updateOutProfile) {
+    if (!c) return VFT_ERR_INVALID;
+    if (i < 0 || j < 0 || i == j || i >= c->maxnode || j >= c->maxnode || newnode < c->d.nSeqs || newnode >= c->d.maxNodes || nActiveOld < 2)
+        return fail(c, VFT_ERR_INVALID, "vft_join_fused: bad arguments (%lld, %lld -> %lld)", (long long) i, (long long) j, (long long) newnode);
+    if (c->rowMode) return fail(c, VFT_ERR_STATE, "vft_join_fused belongs to the NJ phase (before vft_set_profile_rows)");
+    if (int r = ensure_ml_rows(c)) return r;
+    if (!c->pendBase) {
+        const CommitPlan plan = commit_plan(c, VFT_PEND_MAX);
+        HIPCHK(c, hipMalloc((void **) &c->pendBase, plan.totalB + 512));
+        HIPCHK(c, hipMalloc((void **) &c->pendIdsDev, VFT_PEND_MAX * sizeof(int64_t)));
+    }
+    if ((int64_t) c->pend.size() == VFT_PEND_MAX)
+        if (int r = flush_pending(c)) return r;
+    // host-side bookkeeping of vft_join_nodes
+    if (newnode >= c->maxnode) c->maxnode = newnode + 1;
+    c->hParent[(size_t) i] = c->hParent[(size_t) j] = (int32_t) newnode;
+    const int32_t stamp = clamp_i32(staleStamp);
+    if ((int64_t) stamp > c->maxStamp) c->maxStamp = stamp;
+    if (c->rs == 4) ((float *) c->hOutDist)[newnode] = 0.f;
+    else ((double *) c->hOutDist)[newnode] = 0.0;
+    c->hNOut[newnode] = stamp;
+    const int32_t slot = (int32_t) c->pend.size();
+    c->pend.push_back(newnode);
+    const size_t lds = (size_t) 2 * c->d.nPosPad * sizeof(double);
+    VFT_DISPATCH(c, {
+        if (lds > (48u << 10))
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_join_fused<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        launch((k_join_fused<REAL, NC>), dim3(1), dim3(VFT_WG_PROF), lds, c->stream, arena<REAL>(c), i, j, newnode, (REAL) diameter, stamp,
+               nActiveOld, updateOutProfile, c->fpostTol, (REAL *) c->pendBase, c->pendIdsDev, slot);
+    });
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
 // After the NJ phase nothing sweeps the internal profiles any more: vft_average_profiles then writes plain rows (the
 // layout of the ML phase, vft_layout.h) instead of re-packing a tile per node, and skips the self distances only the
 // out-distances of the NJ phase need.  Pair distances, split supports and the ML kernels read either layout.
 extern "C" int vft_set_profile_rows(vft_ctx *c, int32_t on) {
     if (!c) return VFT_ERR_INVALID;
+    if (int r = flush_pending(c)) return r;
     c->rowMode = on != 0;
     c->allRows = false;
     if (!on) return VFT_OK;
@@ -1111,6 +1169,7 @@ extern "C" int vft_set_profile_rows(vft_ctx *c, int32_t on) {
 // ---------------------------------------------------------------------------------------------- out-profile
 extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
     if (!c || n < 1 || !ids) return VFT_ERR_INVALID;
+    if (int r = flush_pending(c)) return r;
     // fast path: nucleotide, no matrix, and the list is exactly the active nodes below maxnode in ascending order
     // (what the join loop passes, NJ.tcc:3017-3031)
     bool tiled = c->cfg.n_codes == 4 && !c->hasDm;
@@ -1247,6 +1306,7 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
         return VFT_OK;
     }
     if (s.hi <= s.lo) return VFT_OK;
+    if (int r = flush_pending(c)) return r;   // the sweep kernels read tile streams
     // after this pass every active node of the shard carries a stamp of at most nActive (forced) / nActive + nDiffAllow
     {
         const int64_t bound = force ? nActive : nActive + nDiffAllow;
@@ -1402,6 +1462,7 @@ static int run_select(vft_ctx *c, int K, const int64_t *queries, int64_t lo, int
 
 // the lazy refresh, query staging and sweep kernels of ONE seed; its results go to the buffers of `slot`
 static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam) {
+    if (int r = flush_pending(c)) return r;
     const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
     // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098) - skipped when the
     //    host's bookkeeping proves that nothing can be stale (seed after seed of setAllLeafTopHits, for instance)

@@ -393,9 +393,9 @@ __global__ void k_outprofile_update(Arena<REAL> A, int64_t old1, int64_t old2, i
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
     Col<REAL, NC> c1, c2, cn;
-    vft_load_col<REAL, NC>(A, old1, p, c1);
-    vft_load_col<REAL, NC>(A, old2, p, c2);
-    vft_load_col<REAL, NC>(A, newn, p, cn);
+    vft_load_col_ml<REAL, NC>(A, old1, p, c1);   // (rows of nodes joined by vft_join_fused whose tiles are not rebuilt yet)
+    vft_load_col_ml<REAL, NC>(A, old2, p, c2);
+    vft_load_col_ml<REAL, NC>(A, newn, p, cn);
     REAL f[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) f[k] = A.outF[p * NC + k];
@@ -420,6 +420,99 @@ __global__ void k_outprofile_update(Arena<REAL> A, int64_t old1, int64_t old2, i
 #pragma unroll
     for (int k = 0; k < NC; k++) A.outF[p * NC + k] = f[k];
     vft_out_codedist<REAL, NC>(A, p, f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One join of the NJ loop in ONE launch (NJ.tcc:2904-2909 + 3003-3008 + 3012-3042): the state change of k_join_nodes,
+// averageProfile of the two children, profileDist(new, new) (self distance / self weight) and - unless a full recompute
+// follows - updateOutProfile.  All four walk the same columns of the same two children; as separate launches they were
+// five dependent kernels of 3-35 us each, most of it launch latency and the tile re-pack.
+// The new profile goes to the node's plain row (vft_layout.h) AND into slot `slot` of the pending stash with its codes
+// in profC: the tile streams are rebuilt lazily, for up to 64 joined nodes at once, right before something that reads
+// tile streams runs (a sweep, a full out-profile; vft_api.hip: flush_pending).  Pair lists, single out-distances and
+// the next joins read the row.  One workgroup; dynamic LDS: 2 * nPosPad doubles.
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG_PROF) void k_join_fused(Arena<REAL> A, int64_t i, int64_t j, int64_t newn, REAL diameter,
+                                                           int32_t staleStamp, int64_t nActiveOld, int32_t updateOut, double tol,
+                                                           REAL *stash, int64_t *pendIds, int32_t slot) {
+    extern __shared__ __attribute__((aligned(16))) double jfLds[];
+    __shared__ double res[2];
+    double *sW = jfLds, *sT = jfLds + A.d.nPosPad;
+    const int64_t nPos = A.d.nPos;
+    if (threadIdx.x == 0) {
+        A.parent[i] = (int32_t) newn;
+        A.parent[j] = (int32_t) newn;
+        A.diameter[newn] = diameter;
+        A.outDist[newn] = 0;
+        A.nOutActive[newn] = staleStamp;
+        pendIds[slot] = newn;
+        A.mlIs[newn - A.d.nSeqs] = 1;
+    }
+    for (int64_t p = threadIdx.x; p < nPos; p += VFT_WG_PROF) {
+        Col<REAL, NC> c1, c2, cn;
+        vft_load_col_ml<REAL, NC>(A, i, p, c1);
+        vft_load_col_ml<REAL, NC>(A, j, p, c2);
+        vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, cn.w, cn.code, cn.f);
+        cn.vec = cn.w > 0 && cn.code == VFT_NOCODE_;
+        vft_store_col_ml<REAL, NC>(A, newn, p, cn.w, cn.code, cn.f);
+        vft_stash_col<REAL, NC>(A, newn, p, cn.w, cn.code, cn.f, stash + ((int64_t) slot * nPos + p) * (NC + 1));
+        // profileDist(new, new): the addends of this column (NJ.tcc:1175-1182), summed in column order below
+        double wgt = 0.0, term = 0.0;
+        if (cn.w > 0) {
+            const REAL ww = cn.w * cn.w;
+            wgt = (double) ww;
+            term = wgt * vft_piece<REAL, NC>(A, cn, cn, nullptr);
+        }
+        sW[p] = wgt;
+        sT[p] = term;
+        if (updateOut) {   // updateOutProfile, NJ.tcc:951-996 (as k_outprofile_update)
+            REAL f[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) f[k] = A.outF[p * NC + k];
+            const REAL om = A.outW[p] * (REAL) nActiveOld;
+            const double originalMult = (double) om;
+            const double newMult = originalMult + (double) cn.w - (double) c1.w - (double) c2.w;
+            REAL wo = (REAL) (newMult / (double) (nActiveOld - 1));
+            if (wo <= 0) wo = (REAL) 1e-20;
+#pragma unroll
+            for (int k = 0; k < NC; k++) f[k] = (REAL) ((double) f[k] * originalMult);
+            if (c1.w > 0) {
+                const REAL neg = -c1.w;
+                vft_add_to_freq<REAL, NC>(A, f, (double) neg, c1);
+            }
+            if (c2.w > 0) {
+                const REAL neg = -c2.w;
+                vft_add_to_freq<REAL, NC>(A, f, (double) neg, c2);
+            }
+            if (cn.w > 0) vft_add_to_freq<REAL, NC>(A, f, (double) cn.w, cn);
+            vft_normalize_freq<REAL, NC>(A, f, tol);
+            A.outW[p] = wo;
+#pragma unroll
+            for (int k = 0; k < NC; k++) A.outF[p * NC + k] = f[k];
+            vft_out_codedist<REAL, NC>(A, p, f);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {   // thread 0: top, thread 1: denom - two chains, each in column order (as vft_pair_block)
+        const double *src = threadIdx.x == 0 ? sT : sW;
+        double acc = 0;
+        int64_t p = 0;
+        for (; p + 8 <= nPos; p += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[p + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; p < nPos; p++) acc += src[p];
+        res[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double top = res[0], denom = res[1];
+        A.selfweight[newn] = (REAL) (denom > 0 ? denom : 0.01);
+        A.selfdist[newn] = (REAL) (denom > 0 ? top / denom : 1.0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

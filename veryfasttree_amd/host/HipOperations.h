@@ -227,6 +227,12 @@ namespace veryfasttree {
         }
 
         /* averageProfile + the new node's self distance (NJ.tcc:3008, 3039-3042) */
+        /* joinNodes + averageProfiles(new, i, j) + its self-distance + updateOutProfile in one launch (vft_join_fused) */
+        void joinFused(int64_t i, int64_t j, int64_t newnode, numeric_t diameter, int64_t staleStamp, int64_t nActiveOld,
+                       bool updateOutProfile) {
+            chk(vft_join_fused(ctx, i, j, newnode, (double) diameter, staleStamp, nActiveOld, updateOutProfile ? 1 : 0));
+        }
+
         void averageProfiles(int64_t n, const int64_t *out, const int64_t *a, const int64_t *b, const double *bionjWeight) {
             chk(vft_average_profiles(ctx, n, out, a, b, bionjWeight));
         }

@@ -145,10 +145,15 @@ namespace veryfasttree {
                 const double bw = 0.5;
                 const REAL bi = branchlength[i] + diameter[i], bj = branchlength[j] + diameter[j];
                 diameter[newnode] = (REAL) (bw * bi + (1 - bw) * bj);
-                chkT("vft_join_nodes", [&]() { return vft_join_nodes(ctx, i, j, newnode, (double) diameter[newnode], 10 * nSeqs); });   /* NJ.tcc:254: "unreasonably high" */
-                chkT("vft_average_profiles", [&]() { return vft_average_profiles(ctx, 1, &newnode, &i, &j, nullptr); });
+                /* one launch per join: tree arrays, the average, its self-distance and the incremental out-profile
+                   (vft_join_fused; the tile streams are rebuilt lazily, 64 joins at a time, before the next sweep) */
                 const int64_t changed = nActiveReset - (nActive - 1);
-                if (changed >= opt.nResetOutProfile && changed >= opt.fResetOutProfile * nActiveReset) {
+                const bool fullOut = changed >= opt.nResetOutProfile && changed >= opt.fResetOutProfile * nActiveReset;
+                chkT("vft_join_fused", [&]() {
+                    return vft_join_fused(ctx, i, j, newnode, (double) diameter[newnode], 10 * nSeqs /* NJ.tcc:254: "unreasonably high" */,
+                                          nActive, fullOut ? 0 : 1);
+                });
+                if (fullOut) {
                     std::vector<int64_t> active;
                     double tot = 0;
                     for (int64_t v = 0; v < maxnode; v++)
@@ -160,7 +165,6 @@ namespace veryfasttree {
                     chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, (int64_t) active.size(), active.data()); });
                     nActiveReset = nActive - 1;
                 } else {
-                    chkT("vft_out_profile_update", [&]() { return vft_out_profile_update(ctx, i, j, newnode, nActive); });
                     const REAL dd = diameter[newnode] - diameter[i] - diameter[j];
                     totdiam += dd;
                 }
