@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <utility>
 #include <vector>
+#include <chrono>
 
 #include "../../include/vft_hip.h"
 #include "vft_kernels_ml.h"
@@ -29,6 +30,9 @@ struct vft_ctx {
     int64_t maxnode = 0, shardLo = 0, shardHi = 0;
     bool refreshAll = false;   // vft_set_shard_mode: lazy refreshes ignore the shard
     // vft_join_fused: joined nodes whose tile streams have not been rebuilt yet (their rows and stash slots are valid)
+    std::vector<int64_t> staleIds;             // pair lists: the distinct stale nodes of the current list
+    std::vector<uint32_t> staleMark;
+    uint32_t staleEpoch = 0;
     std::vector<int64_t> pend;
     char *pendBase = nullptr;        // [stash of 64 nodes | meta | commit scratch], commit_plan(c, 64)
     int64_t *pendIdsDev = nullptr;   // device copy of pend[], written by the kernel
@@ -825,7 +829,7 @@ __global__ void k_clear_ml_rows(uint8_t *mlIs, const int64_t *nodes, int64_t n, 
 // hNodes/dNodes: the cnt node ids of this launch (host copy / device copy, batch order); base: device memory laid
 // out as [stash | meta | commit scratch] according to `plan`.
 static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNodes, const int64_t *dNodes, int64_t cnt,
-                        char *base) {
+                        char *base, bool keepRows = false) {
     std::vector<std::pair<int64_t, int32_t>> tk((size_t) cnt);
     for (int64_t k = 0; k < cnt; k++) tk[(size_t) k] = std::make_pair(hNodes[k] >> 6, (int32_t) k);
     std::stable_sort(tk.begin(), tk.end(),
@@ -853,7 +857,7 @@ static int commit_nodes(vft_ctx *c, const CommitPlan &plan, const int64_t *hNode
     }
     const int32_t *dOrder = (const int32_t *) dMeta, *dSeg = dOrder + cnt;
     char *cs = base + plan.stashB + plan.metaB;
-    if (c->mlIs) {
+    if (c->mlIs && !keepRows) {
         launch(k_clear_ml_rows, dim3(cdiv(cnt, 256)), dim3(256), 0, c->stream, c->mlIs, dNodes, cnt, c->d.nSeqs);
         c->allRows = false;
     }
@@ -873,7 +877,9 @@ static int flush_pending(vft_ctx *c) {
     if (c->pend.empty()) return VFT_OK;
     CommitPlan plan = commit_plan(c, VFT_PEND_MAX);
     const int64_t cnt = (int64_t) c->pend.size();
-    int r = commit_nodes(c, plan, c->pend.data(), c->pendIdsDev, cnt, c->pendBase);
+    // the rows k_join_fused wrote stay valid (NJ-phase profiles never change): pair lists keep reading them - one
+    // coalesced stage per column instead of the tile streams' dependent mask -> offset -> stream gathers
+    int r = commit_nodes(c, plan, c->pend.data(), c->pendIdsDev, cnt, c->pendBase, true);
     c->pend.clear();
     return r;
 }
@@ -994,8 +1000,8 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
     VFT_DISPATCH(c, {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_refresh_list<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_refresh_list<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distance_one<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_selfdist<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
@@ -1683,47 +1689,74 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     for (int64_t t = 0; t < n; t++)
         if (pi[t] < 0 || pi[t] >= c->maxnode || pj[t] < 0 || pj[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "pair %lld out of range", (long long) t);
     const size_t rs = c->rs, idB = (((size_t) n * 8) + 255) & ~(size_t) 255, oB = (((size_t) n * rs) + 255) & ~(size_t) 255;
-    const bool small = 2 * idB + 3 * oB <= VFT_SMALL_BYTES;
+    // setCriterion's lazy refresh (NJ.tcc:1092-1098) for the nodes the list names: the DISTINCT stale ones, found on the
+    // host-mapped stamp mirror (it can only lag towards "staler": kernels in flight make nodes fresher, host-side sets
+    // update it at once; the kernel looks at the real stamp again).  A node is typically named by hundreds of pairs
+    // (the new node of a join by all of its candidates): one workgroup / wave per NAME recomputed the same value that
+    // many times - 0.85 ms of a 0.94 ms call at 60 000 pairs.
+    std::vector<int64_t> &stale = c->staleIds;
+    stale.clear();
+    if (!raw) {
+        if (c->staleMark.size() != (size_t) c->d.maxNodes) c->staleMark.assign((size_t) c->d.maxNodes, 0u);
+        if (++c->staleEpoch == 0u) {
+            std::fill(c->staleMark.begin(), c->staleMark.end(), 0u);
+            c->staleEpoch = 1u;
+        }
+        const uint32_t ep = c->staleEpoch;
+        uint32_t *mark = c->staleMark.data();
+        for (int64_t t = 0; t < n; t++) {
+            const int64_t a = pi[t], b = pj[t];
+            if ((int64_t) c->hNOut[a] - nActive > nDiffAllow && mark[a] != ep) {
+                mark[a] = ep;
+                stale.push_back(a);
+            }
+            if ((int64_t) c->hNOut[b] - nActive > nDiffAllow && mark[b] != ep) {
+                mark[b] = ep;
+                stale.push_back(b);
+            }
+        }
+    }
+    const int64_t nStale = (int64_t) stale.size();
+    const size_t sB = (((size_t) nStale * 8) + 255) & ~(size_t) 255;
+    const bool small = 2 * idB + 3 * oB + sB <= VFT_SMALL_BYTES;
     char *hBase = nullptr, *dBase = nullptr;
     if (small) {
-        if (int r = io_alloc(c, 2 * idB + 3 * oB, &hBase, &dBase)) return r;
+        if (int r = io_alloc(c, 2 * idB + 3 * oB + sB, &hBase, &dBase)) return r;
         memcpy(hBase, pi, (size_t) n * 8);
         memcpy(hBase + idB, pj, (size_t) n * 8);
+        if (nStale) memcpy(hBase + 2 * idB + 3 * oB, stale.data(), (size_t) nStale * 8);
     } else {
-        if (int r = ensure_scratch(c, 2 * idB + 3 * oB + 64)) return r;
+        if (int r = ensure_scratch(c, 2 * idB + 3 * oB + sB + 64)) return r;
         dBase = (char *) c->scratch;
         HIPCHK(c, hipMemcpyAsync(dBase, pi, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dBase + idB, pj, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        if (nStale)
+            HIPCHK(c, hipMemcpyAsync(dBase + 2 * idB + 3 * oB, stale.data(), (size_t) nStale * 8, hipMemcpyHostToDevice, c->stream));
     }
     int64_t *dI = (int64_t *) dBase, *dJ = (int64_t *) (dBase + idB);
+    const int64_t *dStale = (const int64_t *) (dBase + 2 * idB + 3 * oB);
     char *o = dBase + 2 * idB;
     SweepArgs sa{};
     sa.nActive = nActive;
     sa.nDiffAllow = nDiffAllow;
     sa.totdiam = totdiam;
     sa.force = raw ? 1 : 0;
-    // two launches: lazy refresh of the named nodes, then distances + criteria + the completion flag (lists that fit
+    // two launches: lazy refresh of the stale nodes, then distances + criteria + the completion flag (lists that fit
     // the mapped ring)
     const unsigned long long seq = small ? ++c->signalSeq : 0ull;
+    if (nStale && nActive > c->maxStamp) c->maxStamp = nActive;   // refreshed nodes are stamped with nActive
     if (n <= 2048) {   // short list: a workgroup per pair (all of them resident at once)
         const size_t lds = pw_lds_bytes(c) / c->pwWaves;
-        // The host-mapped stamp mirror can only lag towards "staler" (kernels in flight make nodes fresher, host-side
-        // sets update it at once): if it shows no stale node there is none, and the refresh launch is skipped.
-        bool anyStale = false;
-        for (int64_t t = 0; t < n && !anyStale && !raw; t++)
-            anyStale = (int64_t) c->hNOut[pi[t]] - nActive > nDiffAllow || (int64_t) c->hNOut[pj[t]] - nActive > nDiffAllow;
-        if (anyStale && nActive > c->maxStamp) c->maxStamp = nActive;   // refreshed nodes are stamped with nActive
-        if (anyStale)
-            VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, true>), dim3((unsigned) (2 * n)), dim3(VFT_WG), lds, c->stream,
-                                    arena<REAL>(c), dI, dJ, n, sa)));
+        if (nStale)
+            VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, true>), dim3((unsigned) nStale), dim3(VFT_WG), lds, c->stream,
+                                    arena<REAL>(c), dStale, nStale, sa)));
         VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, true>), dim3((unsigned) n), dim3(VFT_WG), lds, c->stream,
                                 arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB),
                                 c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     } else {
-        if (!raw && nActive > c->maxStamp) c->maxStamp = nActive;
-        if (!raw)
-            VFT_DISPATCH(c, (launch((k_pairs_refresh<REAL, NC, false>), dim3(cdiv(2 * n, c->pwWaves)), dim3(64 * c->pwWaves),
-                                    pw_lds_bytes(c), c->stream, arena<REAL>(c), dI, dJ, n, sa)));
+        if (nStale)
+            VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves),
+                                    pw_lds_bytes(c), c->stream, arena<REAL>(c), dStale, nStale, sa)));
         VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB),
                                 (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
@@ -1738,10 +1771,28 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
         if (crit) memcpy(crit, ho + 2 * oB, (size_t) n * rs);
         return VFT_OK;
     }
+    static const bool stageTimes = getenv("VFT_API_PROFILE") != nullptr;   // tools only: where a long list's time goes
+    static double tKernel = 0, tCopy = 0;
+    static int64_t nCalls = 0, nPairs = 0;
+    std::chrono::steady_clock::time_point t0;
+    if (stageTimes) {
+        t0 = std::chrono::steady_clock::now();
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        tKernel += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        t0 = std::chrono::steady_clock::now();
+    }
     if (dist) HIPCHK(c, hipMemcpyAsync(dist, o, (size_t) n * rs, hipMemcpyDeviceToHost, c->stream));
     if (weight) HIPCHK(c, hipMemcpyAsync(weight, o + oB, (size_t) n * rs, hipMemcpyDeviceToHost, c->stream));
     if (crit) HIPCHK(c, hipMemcpyAsync(crit, o + 2 * oB, (size_t) n * rs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stageTimes) {
+        tCopy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        nCalls++;
+        nPairs += n;
+        if ((nCalls & 255) == 0)
+            fprintf(stderr, "[vft api] long pair lists: %lld calls, %lld pairs, H2D + kernels %.3f s, D2H %.3f s\n", (long long) nCalls,
+                    (long long) nPairs, tKernel, tCopy);
+    }
     return VFT_OK;
 }
 

@@ -887,7 +887,7 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_wave(Arena<REAL> A, SweepArgs 
     vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
 }
 
-// setDistCriterion over an explicit pair list whose out-distances k_pairs_refresh has brought up to date: distance and
+// setDistCriterion over an explicit pair list whose out-distances k_refresh_list has brought up to date: distance and
 // criterion per pair, results straight into (mapped) memory; the last wave to finish publishes `seq` to the host's
 // flag, which replaces a trailing signal kernel (the small lists of the join loop are latency-bound: every launch
 // saved is ~6 us of a ~50 us call).
@@ -934,19 +934,16 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     }
 }
 
-// Lazy out-distance refresh of every node named in a pair list (setCriterion, NJ.tcc:1092-1098).  A node may be
-// named many times: the refresh is idempotent and all writers store the same value.
+// Lazy out-distance refresh (setCriterion, NJ.tcc:1092-1098) of the DISTINCT stale nodes of a pair list; the host
+// builds the list from its stamp mirror (vft_api.hip: pair_distances), the kernel looks at the real stamp again.
+// WGPAIR: a workgroup per node (short lists), otherwise a wave.
 template <typename REAL, int NC, bool WGPAIR>
-__global__ __launch_bounds__(VFT_WG) void k_pairs_refresh(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
-                                                          SweepArgs s) {
+__global__ __launch_bounds__(VFT_WG) void k_refresh_list(Arena<REAL> A, const int64_t *ids, int64_t n, SweepArgs s) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
     const int64_t t = WGPAIR ? (int64_t) blockIdx.x : (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
-    if (t >= 2 * n) return;
-    const int64_t v = t < n ? pi[t] : pj[t - n];
-    // value first, staleness stamp after a release fence; a wave that already sees the stamp skips the work, one that
-    // still sees "stale" recomputes the identical value (it depends only on the node and the out-profile)
-    const int32_t nOut = __hip_atomic_load(&A.nOutActive[v], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if (!((int64_t) nOut - s.nActive > s.nDiffAllow)) return;   // uniform over the wave / workgroup
+    if (t >= n) return;
+    const int64_t v = ids[t];
+    if (!((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;   // uniform over the wave / workgroup
     REAL d, w;
     if (WGPAIR) vft_pair_block<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
     else vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
@@ -955,7 +952,7 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh(Arena<REAL> A, const i
     A.outDist[v] = od;
     A.mOutDist[v] = od;
     A.mNOut[v] = (int32_t) s.nActive;
-    __hip_atomic_store(&A.nOutActive[v], (int32_t) s.nActive, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    A.nOutActive[v] = (int32_t) s.nActive;
 }
 
 // ------------------------------------------------------------------------------------------------ leaf blocks

@@ -29,6 +29,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <memory>
 
 #include "../../include/vft_host.h"
 #include "MLLengths.h"
@@ -1782,7 +1783,12 @@ namespace veryfasttree {
                 chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, 0, nullptr, nActive, totdiam); });
                 pending = true;
             }
-            std::vector<Besthit> all = sweep(newnode, nActive, (int32_t) (2 * m));
+            Section secR(this, "[host]   topHitJoin: refresh (incl. device)");
+            std::vector<Besthit> all;
+            {
+                Section s2(this, "[host]     refresh: sweep (incl. device)");
+                all = sweep(newnode, nActive, (int32_t) (2 * m));
+            }
             std::vector<Besthit> copy(all);
             sortSaveBestHits(newnode, copy, (int64_t) copy.size(), m, false);
             /* NJ.tcc:4477-4515 — the reference runs this loop as an OpenMP parallel for: iterations only touch their
@@ -1807,12 +1813,14 @@ namespace veryfasttree {
             }
             const int64_t nW = (int64_t) work.size();
             {   /* setCriterion on every old hit (NJ.tcc:4491-4494): refresh what is stale, once, for all nodes */
+                Section s2(this, "[host]     refresh: stale old hits (incl. device)");
                 std::vector<std::pair<int64_t, int64_t> > pairs;
                 for (const Work &w: work)
                     for (const Hit &h: hits[w.node]) pairs.push_back(std::make_pair(w.node, h.j));
                 prefetchStale(nActive, pairs);
                 drain();
             }
+            std::unique_ptr<Section> sHost(new Section(this, "[host]     refresh: transfer + unique (host threads)"));
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
                 Work &w = work[t];
@@ -1855,7 +1863,9 @@ namespace veryfasttree {
                 w.isTodo.assign(w.out.size(), 0);
                 for (size_t u = 0; u < w.out.size(); u++) w.isTodo[u] = w.out[u].dist < 0.0 ? 1 : 0;
             }
+            sHost.reset();
             {   /* uniqueBestHits, device part (NJ.tcc:4822-4831): one pair list, one id list */
+                Section s2(this, "[host]     refresh: recomputed distances (incl. device)");
                 std::vector<Besthit *> todo;
                 std::vector<std::pair<int64_t, int64_t> > rest;
                 for (Work &w: work)
@@ -1863,10 +1873,12 @@ namespace veryfasttree {
                         if (w.isTodo[u]) todo.push_back(&w.out[u]);
                         else rest.push_back(std::make_pair(w.out[u].i, w.out[u].j));
                     }
+                if (profiling) acc["[count]    refresh: pairs recomputed"].calls += (int64_t) todo.size();
                 setDistCriterionBatch(nActive, todo);
                 prefetchStale(nActive, rest);
                 drain();
             }
+            std::unique_ptr<Section> sSave(new Section(this, "[host]     refresh: criteria + sort + save (host threads)"));
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
                 Work &w = work[t];
@@ -1875,6 +1887,7 @@ namespace veryfasttree {
                 sortSaveBestHits(w.node, w.out, (int64_t) w.out.size(), w.nNew);
                 visible[w.node] = hits[w.node][0];
             }
+            sSave.reset();
             resetTopVisible(nActive);
         }
     };
