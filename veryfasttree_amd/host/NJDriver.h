@@ -30,6 +30,9 @@
 #include <utility>
 #include <vector>
 #include <memory>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../../include/vft_host.h"
 #include "MLLengths.h"
@@ -49,7 +52,7 @@ namespace veryfasttree {
         int tophits2Safety = 3;
         /* OpenMP threads for the host-only parts of a top-hits refresh (the reference parallelises the same loop,
            NJ.tcc:4476); results do not depend on it */
-        int hostThreads = 16;
+        int hostThreads = 0;   /* 0: $VFT_HOST_THREADS, else as many as OpenMP offers, at most 16 */
         /* logCorrect of the minimum-evolution lengths: scoredist-like instead of Jukes-Cantor (amino acids / matrix) */
         bool meNNI = false;
         bool scoredist = false;
@@ -70,6 +73,14 @@ namespace veryfasttree {
 
         NJDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int64_t nPos, const NJOptions &opt)
                 : ctx(ctx), opt(opt), nSeqs(nSeqs), nPos(nPos), maxnodes(2 * nSeqs), maxnode(nSeqs), totdiam(0.0) {
+            if (this->opt.hostThreads <= 0) {
+#ifdef _OPENMP
+                const char *env = std::getenv("VFT_HOST_THREADS");
+                this->opt.hostThreads = env ? std::max(1, atoi(env)) : std::max(1, std::min(omp_get_max_threads(), 16));
+#else
+                this->opt.hostThreads = 1;
+#endif
+            }
             parent.assign(maxnodes, -1);
             child0.assign(maxnodes, -1);
             child1.assign(maxnodes, -1);
@@ -130,8 +141,22 @@ namespace veryfasttree {
                 /* setOutDistance(i), setOutDistance(j), setDistCriterion(join) (NJ.tcc:2897-2901) as ONE pair list of
                    length 1 with nDiffAllow = 0: the lazy refresh then fires for every stamp != nActive, i.e. it is the
                    unconditional setOutDistance, and the pair kernel follows in the same call */
-                std::vector<Besthit *> one(1, &join);
-                setDistCriterionBatch(nActive, one, 0);
+                if (!noTop && stamp(join.i) == nActive && stamp(join.j) == nActive && !checkJoins) {
+                    /* both out-distances are current (the hill climbing of topHitNJSearch forced them) and join.dist is
+                       the distance of exactly this pair of unchanged profiles: only the criterion's arithmetic is left */
+                    criterionFresh(nActive, join);
+                } else {
+                    std::vector<Besthit *> one(1, &join);
+                    Besthit before = join;
+                    setDistCriterionBatch(nActive, one, 0);
+                    if (checkJoins && !noTop && before.dist != join.dist)
+                        throw std::runtime_error("NJDriver: the stored distance of a join differs from its recomputation");
+                    if (checkJoins && !noTop) {
+                        criterionFresh(nActive, before);
+                        if (before.criterion != join.criterion)
+                            throw std::runtime_error("NJDriver: host and device criterion of a join differ");
+                    }
+                }
                 const int64_t newnode = maxnode++;
                 const int64_t i = join.i, j = join.j;
                 parent[i] = parent[j] = newnode;
@@ -724,6 +749,7 @@ namespace veryfasttree {
         };
         std::map<std::string, Acc> acc;
         bool profiling = std::getenv("VFT_NJ_PROFILE") != nullptr;
+        bool checkJoins = std::getenv("VFT_NJ_CHECK") != nullptr;   /* tools: cross-check the shortcuts against the device */
 
         /* inclusive wall-clock of a host section (VFT_NJ_PROFILE=1); device calls made inside are also listed on
            their own lines */
@@ -793,20 +819,41 @@ namespace veryfasttree {
            node depends only on the node, nActive, the out-profile and totdiam, none of which change inside such a
            loop, so refreshing the stale ones up front in one device call is the same computation. */
         void prefetchStale(int64_t nActive, const std::vector<std::pair<int64_t, int64_t> > &pairs) {
+            staleBegin(nActive);
+            for (const auto &pr: pairs) staleAdd(pr.first, pr.second);
+            staleFlush();
+        }
+
+        /* the same without the intermediate pair list: staleBegin, staleAdd for every pair, staleFlush */
+        std::vector<int64_t> staleIds;
+        int64_t staleActive = 0, staleAllow = 0;
+
+        void staleBegin(int64_t nActive) {
             drain();
-            const int64_t allow = nDiffAllow(nActive);
-            std::vector<int64_t> ids;
-            for (const auto &pr: pairs) {
-                const int64_t i = pr.first, j = pr.second;
-                if (i < 0 || j < 0 || parent[i] >= 0 || parent[j] >= 0) continue;
-                if (mN[i] - nActive > allow) ids.push_back(i);
-                if (mN[j] - nActive > allow) ids.push_back(j);
+            staleActive = nActive;
+            staleAllow = nDiffAllow(nActive);
+            staleIds.clear();
+            if (seenScratch.size() != (size_t) maxnodes) seenScratch.assign((size_t) maxnodes, 0);
+        }
+
+        void staleAdd(int64_t i, int64_t j) {
+            if (i < 0 || j < 0 || parent[i] >= 0 || parent[j] >= 0) return;
+            if (mN[i] - staleActive > staleAllow && !seenScratch[(size_t) i]) {
+                seenScratch[(size_t) i] = 1;
+                staleIds.push_back(i);
             }
-            if (ids.empty()) return;
-            std::sort(ids.begin(), ids.end());
-            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-            const int64_t n = (int64_t) ids.size();
-            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, n, ids.data(), nActive, totdiam); });
+            if (mN[j] - staleActive > staleAllow && !seenScratch[(size_t) j]) {
+                seenScratch[(size_t) j] = 1;
+                staleIds.push_back(j);
+            }
+        }
+
+        void staleFlush() {
+            if (staleIds.empty()) return;
+            for (int64_t v: staleIds) seenScratch[(size_t) v] = 0;
+            std::sort(staleIds.begin(), staleIds.end());
+            const int64_t n = (int64_t) staleIds.size(), nActive = staleActive;
+            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, n, staleIds.data(), nActive, totdiam); });
             pending = true;
         }
 
@@ -1814,10 +1861,10 @@ namespace veryfasttree {
             const int64_t nW = (int64_t) work.size();
             {   /* setCriterion on every old hit (NJ.tcc:4491-4494): refresh what is stale, once, for all nodes */
                 Section s2(this, "[host]     refresh: stale old hits (incl. device)");
-                std::vector<std::pair<int64_t, int64_t> > pairs;
+                staleBegin(nActive);
                 for (const Work &w: work)
-                    for (const Hit &h: hits[w.node]) pairs.push_back(std::make_pair(w.node, h.j));
-                prefetchStale(nActive, pairs);
+                    for (const Hit &h: hits[w.node]) staleAdd(w.node, h.j);
+                staleFlush();
                 drain();
             }
             std::unique_ptr<Section> sHost(new Section(this, "[host]     refresh: transfer + unique (host threads)"));
@@ -1867,15 +1914,16 @@ namespace veryfasttree {
             {   /* uniqueBestHits, device part (NJ.tcc:4822-4831): one pair list, one id list */
                 Section s2(this, "[host]     refresh: recomputed distances (incl. device)");
                 std::vector<Besthit *> todo;
-                std::vector<std::pair<int64_t, int64_t> > rest;
                 for (Work &w: work)
-                    for (size_t u = 0; u < w.out.size(); u++) {
+                    for (size_t u = 0; u < w.out.size(); u++)
                         if (w.isTodo[u]) todo.push_back(&w.out[u]);
-                        else rest.push_back(std::make_pair(w.out[u].i, w.out[u].j));
-                    }
                 if (profiling) acc["[count]    refresh: pairs recomputed"].calls += (int64_t) todo.size();
                 setDistCriterionBatch(nActive, todo);
-                prefetchStale(nActive, rest);
+                staleBegin(nActive);
+                for (Work &w: work)
+                    for (size_t u = 0; u < w.out.size(); u++)
+                        if (!w.isTodo[u]) staleAdd(w.out[u].i, w.out[u].j);
+                staleFlush();
                 drain();
             }
             std::unique_ptr<Section> sSave(new Section(this, "[host]     refresh: criteria + sort + save (host threads)"));
