@@ -242,3 +242,64 @@ def test_leaf_block_distances_equal_the_pair_list():
         assert np.array_equal(d[:, ok].ravel(), d2) and np.array_equal(w[:, ok].ravel(), w2) and np.array_equal(c[:, ok].ravel(), c2)
         assert np.all(d[:, ~ok] == dt(1e20)) and np.all(w[:, ~ok] == 0)
         ops.close()
+
+
+@pytest.mark.parametrize("ncodes", [4, 20])
+def test_fused_join_and_block_distances_equal_the_separate_calls(ncodes):
+    """vft_join_fused (tree arrays + average + self-distance + out-profile update in one launch, tile streams rebuilt
+    lazily) against vft_join_nodes + vft_average_profiles + vft_out_profile_update on a second context: profiles, node
+    scalars, out-profile and a sweep over the joined tree, bit for bit.  Then vft_block_distances over a mix of leaves and
+    internal nodes (negative ids, a pair of a node with itself, stale out-distances) against vft_pair_distances."""
+    from veryfasttree_amd import HipProfileOps, synth
+    n, L, nj = 300, 211, 150
+    codes = synth.random_descent_codes(n, L, ncodes, 0.05, 0.08, seed=17)
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        both = []
+        for fused in (False, True):
+            ops = HipProfileOps(n, L, ncodes, dt, max_nodes=2 * n)
+            ops.upload_leaves(codes)
+            ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
+            ops.outProfile(np.arange(n))
+            active = list(range(n))
+            order = np.random.default_rng(5)
+            for k in range(nj):
+                i, j = (int(x) for x in order.choice(len(active), 2, replace=False))
+                i, j = active[i], active[j]
+                new, diam = n + k, 0.01 * (k % 7)
+                if fused:
+                    ops.join_fused(i, j, new, diam, 10 * n, len(active), True)
+                else:
+                    ops.join_nodes(i, j, new, diam, 10 * n)
+                    ops.averageProfile([new], [i], [j])
+                    ops.updateOutProfile(i, j, new, len(active))
+                active = [v for v in active if v not in (i, j)] + [new]
+            both.append((ops, active))
+        (o1, act), (o2, _) = both
+        for v in range(n, n + nj):
+            p1, p2 = o1.profile_download(v), o2.profile_download(v)
+            assert all(np.array_equal(x, y) for x, y in zip(p1, p2)), v
+        s1, s2 = o1.get_node_scalars(n, nj), o2.get_node_scalars(n, nj)
+        assert all(np.array_equal(x, y) for x, y in zip(s1, s2))
+        assert all(np.array_equal(x, y) for x, y in zip(o1.out_profile_download()[0], o2.out_profile_download()[0]))
+        nact = len(act)
+        h1 = o1.setBestHit(act[-1], nact, 5, 3.0, 40)
+        h2 = o2.setBestHit(act[-1], nact, 5, 3.0, 40)     # flushes the pending tile rebuild first
+        assert np.array_equal(h1[0], h2[0]) and h1[1] == h2[1]
+        a = np.array(rng.choice(act, 37, replace=False), np.int64)
+        b = np.array(rng.choice(act, 90, replace=False), np.int64)
+        b[[2, 11]] = -1
+        b[5] = a[3]
+        d = o2.blockDistances(a, b, nact, 5, 3.0)
+        ok = np.ones((len(a), len(b)), bool)
+        ok[:, b < 0] = False
+        ok &= a[:, None] != b[None, :]          # (b[5] == a[3] for sure; the random draws may share more nodes)
+        assert not ok[3, 5]
+        pi, pj = np.repeat(a, len(b)).reshape(len(a), -1)[ok], np.tile(b, len(a)).reshape(len(a), -1)[ok]
+        d2, w2, c2 = o1.setDistCriterion(pi, pj, nact, 5, 3.0)
+        assert np.array_equal(d[ok], d2)
+        assert np.all(np.isnan(d[~ok]))
+        # both calls refreshed the same stale out-distances
+        assert all(np.array_equal(x, y) for x, y in zip(o1.get_out_distances(0, n + nj), o2.get_out_distances(0, n + nj)))
+        o1.close()
+        o2.close()

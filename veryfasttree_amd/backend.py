@@ -27,7 +27,7 @@ EXPORTS = [
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
-    "vft_debug_log", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused",
+    "vft_debug_log", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances",
 ]
 
 
@@ -402,6 +402,11 @@ class HipProfileOps:
         """The state change of one join in one launch (NJ.tcc:2904-2909, 3003-3007, 254)."""
         self._chk(self.lib.vft_join_nodes(self.ctx, I64(i), I64(j), I64(newnode), C.c_double(diameter), I64(stale_stamp)))
 
+    def join_fused(self, i, j, newnode, diameter, stale_stamp, n_active_old, update_out_profile=True):
+        """joinNodes + averageProfile(newnode, i, j) + its self-distance + updateOutProfile in one launch (vft_join_fused)."""
+        self._chk(self.lib.vft_join_fused(self.ctx, I64(i), I64(j), I64(newnode), C.c_double(diameter), I64(stale_stamp),
+                                          I64(n_active_old), C.c_int32(1 if update_out_profile else 0)))
+
     def get_out_distances(self, first, count):
         od = np.zeros(count, self.dt)
         na = np.zeros(count, np.int64)
@@ -534,6 +539,15 @@ class HipProfileOps:
         self._chk(self.lib.vft_leaf_block_distances(self.ctx, I64(len(a)), _ptr(a), I64(len(b)), _ptr(b), I64(n_active),
                                                     I64(n_diff_allow), C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
         return d, w, c
+
+    def blockDistances(self, a, b, n_active, n_diff_allow, totdiam):
+        """Join distances of the cross product of two node lists (vft_block_distances), lazy out-distance refresh of
+        every listed node included: a [len(a), len(b)] array; slots of negative ids / i == j hold NaN."""
+        a, b = _i64(a), _i64(b)
+        d = np.full((len(a), len(b)), np.nan, self.dt)
+        self._chk(self.lib.vft_block_distances(self.ctx, I64(len(a)), _ptr(a), I64(len(b)), _ptr(b), I64(n_active),
+                                               I64(n_diff_allow), C.c_double(totdiam), _ptr(d)))
+        return d
 
     def profileDist(self, i, j):
         """NJ.tcc:1167 / 1601 over a pair list: raw (dist, weight), no diameter correction, no criterion."""

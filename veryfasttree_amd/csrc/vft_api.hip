@@ -1000,6 +1000,7 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
     VFT_DISPATCH(c, {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_block<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_refresh_list<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_refresh_list<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
@@ -1793,6 +1794,72 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
             fprintf(stderr, "[vft api] long pair lists: %lld calls, %lld pairs, H2D + kernels %.3f s, D2H %.3f s\n", (long long) nCalls,
                     (long long) nPairs, tKernel, tCopy);
     }
+    return VFT_OK;
+}
+
+extern "C" int vft_block_distances(vft_ctx *c, int64_t nA, const int64_t *a, int64_t nB, const int64_t *b, int64_t nActive,
+                                   int64_t nDiffAllow, double totdiam, void *dist) {
+    if (!c || nA < 0 || nB < 0 || !a || !b || !dist) return VFT_ERR_INVALID;
+    if (nA == 0 || nB == 0) return VFT_OK;
+    if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_block_distances before vft_upload_leaves");
+    for (int64_t t = 0; t < nA; t++)
+        if (a[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_block_distances: a[%lld] out of range", (long long) t);
+    for (int64_t t = 0; t < nB; t++)
+        if (b[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_block_distances: b[%lld] out of range", (long long) t);
+    // the distinct stale nodes among both lists (as in pair_distances)
+    std::vector<int64_t> &stale = c->staleIds;
+    stale.clear();
+    if (c->staleMark.size() != (size_t) c->d.maxNodes) c->staleMark.assign((size_t) c->d.maxNodes, 0u);
+    if (++c->staleEpoch == 0u) {
+        std::fill(c->staleMark.begin(), c->staleMark.end(), 0u);
+        c->staleEpoch = 1u;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        const int64_t *ids = pass ? b : a, cnt = pass ? nB : nA;
+        for (int64_t t = 0; t < cnt; t++) {
+            const int64_t v = ids[t];
+            if (v >= 0 && (int64_t) c->hNOut[v] - nActive > nDiffAllow && c->staleMark[(size_t) v] != c->staleEpoch) {
+                c->staleMark[(size_t) v] = c->staleEpoch;
+                stale.push_back(v);
+            }
+        }
+    }
+    const int64_t nStale = (int64_t) stale.size();
+    const size_t rs = c->rs, idB = (((size_t) (nA + nB + nStale) * 8) + 255) & ~(size_t) 255;
+    const size_t oB = (((size_t) nA * (size_t) nB * rs) + 255) & ~(size_t) 255;
+    if (int r = ensure_scratch(c, idB + oB + 256)) return r;
+    char *sBase = (char *) c->scratch;
+    int64_t *dA = (int64_t *) sBase, *dB = dA + nA, *dStale = dB + nB;
+    // ids through the mapped ring when they fit (no staging copy), otherwise plain copies
+    if (idB <= VFT_SMALL_BYTES) {
+        char *h, *d;
+        if (int r = io_alloc(c, idB, &h, &d)) return r;
+        memcpy(h, a, (size_t) nA * 8);
+        memcpy(h + (size_t) nA * 8, b, (size_t) nB * 8);
+        if (nStale) memcpy(h + (size_t) (nA + nB) * 8, stale.data(), (size_t) nStale * 8);
+        dA = (int64_t *) d;
+        dB = dA + nA;
+        dStale = dB + nB;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(dA, a, (size_t) nA * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dB, b, (size_t) nB * 8, hipMemcpyHostToDevice, c->stream));
+        if (nStale) HIPCHK(c, hipMemcpyAsync(dStale, stale.data(), (size_t) nStale * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = nDiffAllow;
+    sa.totdiam = totdiam;
+    if (nStale) {
+        if (nActive > c->maxStamp) c->maxStamp = nActive;
+        VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
+                                c->stream, arena<REAL>(c), (const int64_t *) dStale, nStale, sa)));
+    }
+    char *o = sBase + idB;
+    VFT_DISPATCH(c, (launch((k_pairs_block<REAL, NC>), dim3(cdiv(nA * nB, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
+                            arena<REAL>(c), (const int64_t *) dA, nA, (const int64_t *) dB, nB, (REAL *) o)));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(dist, o, (size_t) nA * (size_t) nB * rs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }
 

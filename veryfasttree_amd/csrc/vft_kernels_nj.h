@@ -934,6 +934,30 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     }
 }
 
+// The cross product of two node lists (any mix of leaves and internal nodes): dist[a * nB + b] = the join distance of
+// (idsA[a], idsB[b]), i.e. profileDist / seqDist minus the two diameters (setDistCriterion without the criterion, which is
+// host arithmetic once the out-distances are current).  What a top-hits refresh recomputes (NJ.tcc:4477-4515:
+// transferBestHits of the new node's 2m best hits to each of its m closest nodes, every transferred pair needing a new
+// distance) is exactly such a block, and as a block it needs 3m ids in and m x 2m distances out instead of a list of
+// 2m^2 pairs in and three arrays out.  Entries with a negative id or i == j are skipped (their slot is not written).
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_pairs_block(Arena<REAL> A, const int64_t *idsA, int64_t nA, const int64_t *idsB,
+                                                        int64_t nB, REAL *dist) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t t = (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
+    if (t >= nA * nB) return;
+    const int64_t i = idsA[t / nB], j = idsB[t % nB];
+    if (i < 0 || j < 0 || i == j) return;   // wave-uniform
+    REAL d, w;
+    vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if ((threadIdx.x & 63) != 0) return;
+    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+        const REAL dd = A.diameter[i] + A.diameter[j];
+        d = d - dd;
+    }
+    dist[t] = d;
+}
+
 // Lazy out-distance refresh (setCriterion, NJ.tcc:1092-1098) of the DISTINCT stale nodes of a pair list; the host
 // builds the list from its stamp mirror (vft_api.hip: pair_distances), the kernel looks at the real stamp again.
 // WGPAIR: a workgroup per node (short lists), otherwise a wave.

@@ -670,6 +670,7 @@ namespace veryfasttree {
         struct Besthit {
             int64_t i = -1, j = -1;
             REAL weight = 0, dist = (REAL) 1e20, criterion = (REAL) 1e20;
+            int32_t src = -1;   /* top-hits refresh: column of the distance block this record's distance comes from */
         };
         struct Hit {
             int64_t j;
@@ -1868,6 +1869,9 @@ namespace veryfasttree {
                 drain();
             }
             std::unique_ptr<Section> sHost(new Section(this, "[host]     refresh: transfer + unique (host threads)"));
+            /* the transferred hits' partners, re-targeted to their active ancestors: the same for every node */
+            std::vector<int64_t> target(all.size());
+            for (size_t u = 0; u < all.size(); u++) target[u] = all[u].i < 0 ? -1 : activeAncestor(all[u].j);
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
                 Work &w = work[t];
@@ -1879,7 +1883,7 @@ namespace veryfasttree {
                     const Besthit &o = all[u];
                     Besthit h;
                     h.i = w.node;
-                    h.j = activeAncestor(o.j);
+                    h.j = target[(size_t) u];   /* activeAncestor(o.j) */
                     h.dist = o.dist;
                     h.weight = o.weight;
                     h.criterion = o.criterion;
@@ -1890,6 +1894,7 @@ namespace veryfasttree {
                     } else if (h.i != o.i || h.j != o.j) {
                         h.dist = (REAL) -1e20;
                         h.criterion = (REAL) 1e20;
+                        h.src = (int32_t) u;   /* the pair (w.node, target[u]) is entry (t, u) of the distance block */
                     } else {
                         h.criterion = (REAL) 1e20;
                     }
@@ -1911,13 +1916,33 @@ namespace veryfasttree {
                 for (size_t u = 0; u < w.out.size(); u++) w.isTodo[u] = w.out[u].dist < 0.0 ? 1 : 0;
             }
             sHost.reset();
-            {   /* uniqueBestHits, device part (NJ.tcc:4822-4831): one pair list, one id list */
+            std::vector<REAL> block;
+            int64_t nB = 0;
+            {   /* uniqueBestHits, device part (NJ.tcc:4822-4831).  Every transferred record needs the distance of
+                   (its node, target[u]): together they are the cross product work x target, which goes to the device as
+                   two id lists and comes back as one block of distances (vft_block_distances) - at a million sequences
+                   2m^2 = 2 000 000 pairs per refresh, 18 000 refreshes.  The few old hits whose partner was joined in
+                   the meantime still go as a pair list.  Both calls refresh the stale out-distances of the nodes they
+                   name; records whose distance is known name theirs through the stale set. */
                 Section s2(this, "[host]     refresh: recomputed distances (incl. device)");
+                for (const Work &w: work) nB = std::max<int64_t>(nB, 2 * w.nNew);
+                nB = std::min<int64_t>(nB, (int64_t) target.size());
+                std::vector<int64_t> nodesA((size_t) nW);
+                for (int64_t t = 0; t < nW; t++) nodesA[(size_t) t] = work[(size_t) t].node;
                 std::vector<Besthit *> todo;
                 for (Work &w: work)
                     for (size_t u = 0; u < w.out.size(); u++)
-                        if (w.isTodo[u]) todo.push_back(&w.out[u]);
-                if (profiling) acc["[count]    refresh: pairs recomputed"].calls += (int64_t) todo.size();
+                        if (w.isTodo[u] && w.out[u].src < 0) todo.push_back(&w.out[u]);
+                if (profiling) acc["[count]    refresh: pairs recomputed as a list"].calls += (int64_t) todo.size();
+                if (profiling) acc["[count]    refresh: pairs recomputed as a block"].calls += nW * nB;
+                if (nW > 0 && nB > 0) {
+                    block.resize((size_t) (nW * nB));
+                    const int64_t allow = nDiffAllow(nActive);
+                    chkT("vft_block_distances", [&]() {
+                        return vft_block_distances(ctx, nW, nodesA.data(), nB, target.data(), nActive, allow, totdiam, block.data());
+                    });
+                    pending = false;
+                }
                 setDistCriterionBatch(nActive, todo);
                 staleBegin(nActive);
                 for (Work &w: work)
@@ -1930,8 +1955,15 @@ namespace veryfasttree {
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
                 Work &w = work[t];
-                for (size_t u = 0; u < w.out.size(); u++)
-                    if (!w.isTodo[u]) criterionFresh(nActive, w.out[u]);
+                for (size_t u = 0; u < w.out.size(); u++) {
+                    Besthit &h = w.out[u];
+                    if (w.isTodo[u] && h.src >= 0) {
+                        h.dist = block[(size_t) (t * nB + h.src)];
+                        criterionFresh(nActive, h);
+                    } else if (!w.isTodo[u]) {
+                        criterionFresh(nActive, h);
+                    }
+                }
                 sortSaveBestHits(w.node, w.out, (int64_t) w.out.size(), w.nNew);
                 visible[w.node] = hits[w.node][0];
             }
