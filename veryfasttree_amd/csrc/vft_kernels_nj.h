@@ -939,7 +939,7 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
 // host arithmetic once the out-distances are current).  What a top-hits refresh recomputes (NJ.tcc:4477-4515:
 // transferBestHits of the new node's 2m best hits to each of its m closest nodes, every transferred pair needing a new
 // distance) is exactly such a block, and as a block it needs 3m ids in and m x 2m distances out instead of a list of
-// 2m^2 pairs in and three arrays out.  Entries with a negative id or i == j are skipped (their slot is not written).
+// 2m^2 pairs in and three arrays out.  Entries with a negative id or i == j are skipped (their slot is not written; the host gets whatever the scratch held).
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WG) void k_pairs_block(Arena<REAL> A, const int64_t *idsA, int64_t nA, const int64_t *idsB,
                                                         int64_t nB, REAL *dist) {

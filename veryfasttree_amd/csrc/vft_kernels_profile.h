@@ -3,6 +3,7 @@
 // thread per alignment column; only the out-profile's accumulation over profiles is order-sensitive and is kept
 // sequential per column, in list order, like the reference at one thread (NJ.tcc:738-784).
 #pragma once
+#include "vft_iterate_add.h"
 #include "vft_device.h"
 
 #define VFT_WG_PROF 256
@@ -516,13 +517,7 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_join_fused(Arena<REAL> A, int64
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// outProfile over ALL active nodes in ascending id order (what the join loop passes, NJ.tcc:3017-3031), nucleotide,
-// no distance matrix.  The accumulation over profiles is order-sensitive (float sums, NJ.tcc:738-784), so each
-// (column, chain) — chain 0 the weight, chains 1..4 the four frequencies — is one thread walking the nodes in order;
-// what is parallel is the 16 columns x 5 chains of a workgroup and the cooperative, coalesced staging of every tile
-// (64 nodes x 16 columns: weights, codes, vector mask, packed vectors) through LDS, prefetched one tile ahead.
-// k_outprofile_full does the same through per-thread gathers and is ~8x slower; it remains for arbitrary id lists and
-// for the matrix / amino-acid case.
+// bit l of tileMask[t]: node 64 t + l is active (the out-profile kernels below walk all active nodes in ascending order)
 static __global__ void k_tile_active_masks(const int32_t *parent, int64_t maxnode, unsigned long long *tileMask, int64_t nTiles) {
     const int64_t t = (int64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (t >= nTiles) return;
@@ -532,140 +527,170 @@ static __global__ void k_tile_active_masks(const int32_t *parent, int64_t maxnod
     if ((threadIdx.x & 63) == 0) tileMask[t] = m;
 }
 
-template <typename REAL>
-struct OutTileRegs {
-    REAL w[4];
-    uint4 codes;
-    unsigned long long mask, wmask;
-    REAL f[4][4];
-};
+// ---------------------------------------------------------------------------------------------------------------
+// outProfile over all active nodes (round 1 walked 64-node tiles with ~100 instructions per chain step on 13
+// workgroups: 170 ms at 750 000 active nodes).  The accumulation is order-sensitive only where the
+// addends differ, so it is split:
+//   * nucleotide LEAVES without a distance matrix (ids below nSeqs come first in the ascending order): a leaf adds
+//     exactly 1.0 to the frequency of its code and the constant 1/nActive to the weight.  The frequency sums are counts
+//     (exact in numeric_t up to 2^24, where float addition of 1.0 saturates - reproduced), gathered by k_leaf_hist with
+//     wave ballots over all leaf tiles in parallel; the weight chain is vft_iterate_add (closed form per binade).
+//   * everything else (internal nodes; leaves when a matrix is set or the alphabet has 20 letters) runs the chain, but a
+//     chain step is one LDS read and one add: per stage the whole workgroup expands VFT_OP_TILES tiles of 64 nodes x
+//     COLS columns into dense addend rows in LDS (lane = node, coalesced tile-stream loads, inactive nodes compacted away
+//     with the tile's active mask), prefetching the next stage's columns into registers while the (NC + 1) x COLS chain
+//     threads consume the current one.  Adding the addends of a skipped record (+0.0) would also be exact, compaction
+//     just saves the steps.
+// Grid: nPosPad / COLS workgroups of 64 * COLS threads.
+#define VFT_OP_TILES 4
+template <int NC> struct OpCols { static const int value = NC == 4 ? 8 : 2; };
 
-template <typename REAL>
-__device__ __forceinline__ void vft_outtile_load(const Arena<REAL> &A, int64_t tile, int chunk, OutTileRegs<REAL> &r) {
-    const int tid = threadIdx.x;
-    const int64_t p0 = (int64_t) chunk * VFT_CHUNK;
-    r.mask = 0;
-    // lanes below nSeqs are leaves (codes from leafT); the tile that straddles nSeqs has both kinds
-    if (tid < 64 && tile * 64 + tid < A.d.nSeqs) r.codes = A.leafT[vft_leaf_idx(A.d, tile, chunk, tid)];
-    if (tile * 64 + 63 < A.d.nSeqs) return;   // pure leaf tile
-    const int64_t pt = tile - A.d.firstProfTile;
-    if (tid < 64 && tile * 64 + tid >= A.d.nSeqs) r.codes = A.profC[vft_c_idx(A.d, pt, chunk, tid)];
-    // 16 threads per column fetch that column's run of the tile's streams: slot s of the run -> thread (s & 15)
-    const int col = tid >> 4;
-    const int64_t mi = vft_meta_idx(A.d, pt, p0 + col);
-    const ColMask m = A.colMask[mi];
-    const ColOff o = A.colOff[mi];
-    r.mask = m.vec;
-    r.wmask = m.w;
-    const int cnt = __popcll(m.vec), cntW = __popcll(m.w);
-    const REAL *fS = A.profF + vft_fstream_base(A.d, pt) + (int64_t) o.vec * 4;
-    const REAL *wS = A.profW + vft_wstream_base(A.d, pt) + o.w;
+// per-(column, code) counts of the active leaves; hist[p * 4 + k]; grid (waves over tiles, nChunk), block 256
+static __global__ __launch_bounds__(256) void k_leaf_hist(const uint4 *leafT, VftDims d, const unsigned long long *tileMask,
+                                                          int64_t nLeafTiles, unsigned int *hist) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6), nWaves = (int64_t) gridDim.x * 4;
+    const int chunk = blockIdx.y;
+    unsigned int cnt[64];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int slot = (tid & 15) + 16 * u;
-        if (slot < cntW) r.w[u] = wS[slot];
-        if (slot < cnt) {
+    for (int u = 0; u < 64; u++) cnt[u] = 0;
+    for (int64_t t = wave; t < nLeafTiles; t += nWaves) {
+        unsigned long long m = tileMask[t];
+        if (t * 64 + 63 >= d.nSeqs) m &= (1ull << (d.nSeqs - t * 64)) - 1ull;   // the tile that straddles nSeqs
+        if (m == 0) continue;
+        uint4 v = make_uint4(0, 0, 0, 0);   // gaps: no bits
+        if ((m >> lane) & 1ull) v = leafT[vft_leaf_idx(d, t, chunk, lane)];
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) r.f[u][k] = fS[slot * 4 + k];
+        for (int b = 0; b < 16; b++) {
+            const uint32_t byte = (wv[b >> 2] >> (8 * (b & 3))) & 0xFFu;   // 0x10 | 1 << code, or 0 (vft_encode)
+#pragma unroll
+            for (int k = 0; k < 4; k++) cnt[b * 4 + k] += (unsigned int) __popcll(__ballot((byte >> k) & 1u));
         }
     }
+    unsigned int mine = 0;
+#pragma unroll
+    for (int u = 0; u < 64; u++) mine = lane == u ? cnt[u] : mine;
+    if (mine) atomicAdd(&hist[((int64_t) chunk * 16 + (lane >> 2)) * 4 + (lane & 3)], mine);
 }
 
-template <typename REAL>
-__global__ __launch_bounds__(VFT_WG_PROF) void k_outprofile_full_tiled(Arena<REAL> A, const unsigned long long *tileMask,
-                                                                       int64_t nTiles, int64_t nActive, double tol) {
-    __shared__ REAL sW[VFT_CHUNK][64];
-    __shared__ uint4 sCodes[64];
-    __shared__ unsigned long long sMask[VFT_CHUNK], sWMask[VFT_CHUNK];
-    __shared__ REAL sF[VFT_CHUNK][64][4];
-    __shared__ REAL sRes[VFT_CHUNK][5];
-    const int tid = threadIdx.x;
-    const int chunk = blockIdx.x;
-    const int64_t p0 = (int64_t) chunk * VFT_CHUNK;
+template <typename REAL, int NC>
+__global__ __launch_bounds__(64 * OpCols<NC>::value) void k_outprofile_chain(Arena<REAL> A, const unsigned long long *tileMask,
+                                                                             int64_t firstTile, int64_t nTiles, int64_t nActive,
+                                                                             double tol, const unsigned int *hist) {
+    constexpr int COLS = OpCols<NC>::value, NCH = NC + 1, CAP = VFT_OP_TILES * 64, STRIDE = CAP + 4;
+    __shared__ __attribute__((aligned(16))) REAL sAdd[COLS * NCH][STRIDE];
+    __shared__ REAL sRes[COLS][NCH];
+    const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
+    const int64_t p0 = (int64_t) blockIdx.x * COLS, p = p0 + c;
+    const bool colOk = p < A.d.nPos;
     const double inweight = 1.0 / (double) nActive;
-    const int col = tid / 5, chain = tid % 5;   // threads 0..79 run the chains
+    const bool chainThread = tid < COLS * NCH;
+    const int chCol = tid / NCH, chK = tid % NCH;   // chain threads: column of the group, component (NC = the weight)
     REAL acc = 0;
-    // first non-empty tile
-    int64_t t = 0;
-    while (t < nTiles && tileMask[t] == 0) t++;
-    OutTileRegs<REAL> regs;
-    if (t < nTiles) vft_outtile_load<REAL>(A, t, chunk, regs);
-    while (t < nTiles) {
-        const unsigned long long active = tileMask[t];
-        const bool leafTile = t * 64 + 63 < A.d.nSeqs;
-        __syncthreads();   // previous tile's chains are done with the LDS buffers
-        if (leafTile) {
-            if (tid < 64) sCodes[tid] = regs.codes;
+    if (hist && chainThread && p0 + chCol < A.d.nPos) {   // the leaves' contribution (see above)
+        const unsigned int *h = hist + (p0 + chCol) * 4;
+        if (chK < NC) {
+            const unsigned int n = h[chK];
+            acc = sizeof(REAL) == 4 ? (REAL) (n < (1u << 24) ? n : (1u << 24)) : (REAL) n;
         } else {
-            if (tid < 64) sCodes[tid] = regs.codes;
-            if ((tid & 15) == 0) {
-                sMask[tid >> 4] = regs.mask;
-                sWMask[tid >> 4] = regs.wmask;
+            acc = vft_iterate_add<REAL>(inweight, (uint64_t) h[0] + h[1] + h[2] + h[3]);
+        }
+    }
+    // stage = up to VFT_OP_TILES non-empty tiles
+    int64_t tNext = firstTile;
+    unsigned long long mk[VFT_OP_TILES];
+    Col<REAL, NC> col[VFT_OP_TILES];
+    auto fetch = [&]() {   // masks of the next stage's tiles (uniform) and this thread's columns of them
+#pragma unroll
+        for (int s = 0; s < VFT_OP_TILES; s++) {
+            unsigned long long m = 0;
+            int64_t t = tNext;
+            while (t < nTiles) {
+                m = tileMask[t];
+                if (hist && t * 64 < A.d.nSeqs) m &= ~((1ull << (A.d.nSeqs - t * 64)) - 1ull);   // leaves are in the histogram
+                if (m) break;
+                t++;
             }
-            const int cnt = __popcll(regs.mask), cntW = __popcll(regs.wmask);
+            tNext = t + 1;
+            mk[s] = t < nTiles ? m : 0ull;
+            if (((mk[s] >> lane) & 1ull) && colOk) vft_load_col<REAL, NC>(A, t * 64 + lane, p, col[s]);
+        }
+    };
+    fetch();
+    for (;;) {
+        int total = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int slot = (tid & 15) + 16 * u;
-                if (slot < cntW) sW[tid >> 4][slot] = regs.w[u];
-                if (slot < cnt) {
+        for (int s = 0; s < VFT_OP_TILES; s++) total += __popcll(mk[s]);
+        if (total == 0) break;   // uniform
+        __syncthreads();   // the chains are done with the previous stage
+        {
+            int base = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) sF[tid >> 4][slot][k] = regs.f[u][k];
+            for (int s = 0; s < VFT_OP_TILES; s++) {
+                if ((mk[s] >> lane) & 1ull) {
+                    const int n = base + __popcll(mk[s] & ((1ull << lane) - 1ull));
+                    const Col<REAL, NC> &cc = col[s];
+                    const REAL w = colOk ? cc.w : (REAL) 0;
+                    sAdd[c * NCH + NC][n] = w;
+#pragma unroll
+                    for (int k = 0; k < NC; k++) {
+                        REAL a = 0;
+                        if (w > 0) {
+                            if (cc.vec) a = cc.f[k] * w;                                        // vector_add_mult, NJ.tcc:825
+                            else if (A.dmDist) a = A.dmCodeFreq[cc.code * NC + k] * w;          // NJ.tcc:828
+                            else a = k == cc.code ? w : (REAL) 0;                               // NJ.tcc:831
+                        }
+                        sAdd[c * NCH + k][n] = a;
+                    }
                 }
+                base += __popcll(mk[s]);
             }
         }
         __syncthreads();
-        // prefetch the next non-empty tile into registers while the chains run
-        int64_t tn = t + 1;
-        while (tn < nTiles && tileMask[tn] == 0) tn++;
-        if (tn < nTiles) vft_outtile_load<REAL>(A, tn, chunk, regs);
-        if (tid < VFT_CHUNK * 5 && p0 + col < A.d.nPos) {
-            unsigned long long m = active;
-            while (m) {
-                const int l = __ffsll((long long) m) - 1;
-                m &= m - 1;
-                REAL w;
-                int code;
-                if (leafTile || t * 64 + l < A.d.nSeqs) {
-                    const uint32_t enc = vft_byte(sCodes[l], col);
-                    code = vft_decode<4>(enc);
-                    w = code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
-                } else {
-                    code = (int) vft_byte(sCodes[l], col);
-                    const unsigned long long below = (1ull << l) - 1ull, wm = sWMask[col];
-                    w = ((wm >> l) & 1ull) ? sW[col][__popcll(wm & below)]
-                                           : vft_implicit_weight<REAL>(code, (sMask[col] >> l) & 1ull);
+        fetch();   // next stage's loads are in flight while the chains run
+        if (chainThread) {
+            const REAL *src = sAdd[chCol * NCH + chK];
+            int n = 0;
+            if (chK < NC) {
+                for (; n + 4 <= total; n += 4) {
+                    const REAL a0 = src[n], a1 = src[n + 1], a2 = src[n + 2], a3 = src[n + 3];
+                    acc = acc + a0;
+                    acc = acc + a1;
+                    acc = acc + a2;
+                    acc = acc + a3;
                 }
-                if (chain == 0) {
-                    acc = (REAL) ((double) acc + (double) w * inweight);               // NJ.tcc:741
-                } else if (w > 0) {
-                    const int k = chain - 1;
-                    if (code != VFT_NOCODE_) {
-                        if (code == k) acc = (REAL) ((double) acc + (double) w);       // addToFreq, NJ.tcc:831
-                    } else {
-                        const int slot = __popcll(sMask[col] & ((1ull << l) - 1ull));
-                        const REAL pr = sF[col][slot][k] * w;                          // vector_add_mult, NJ.tcc:825
-                        acc = acc + pr;
-                    }
+                for (; n < total; n++) acc = acc + src[n];
+            } else {
+                for (; n + 4 <= total; n += 4) {
+                    const double a0 = (double) src[n] * inweight, a1 = (double) src[n + 1] * inweight,
+                                 a2 = (double) src[n + 2] * inweight, a3 = (double) src[n + 3] * inweight;
+                    acc = (REAL) ((double) acc + a0);                                           // NJ.tcc:741
+                    acc = (REAL) ((double) acc + a1);
+                    acc = (REAL) ((double) acc + a2);
+                    acc = (REAL) ((double) acc + a3);
                 }
+                for (; n < total; n++) acc = (REAL) ((double) acc + (double) src[n] * inweight);
             }
         }
-        t = tn;
     }
     __syncthreads();
-    if (tid < VFT_CHUNK * 5) sRes[col][chain] = acc;
+    if (chainThread) sRes[chCol][chK] = acc;
     __syncthreads();
-    if (tid < VFT_CHUNK && p0 + tid < A.d.nPos) {
-        const int64_t p = p0 + tid;
-        REAL wo = sRes[tid][0];
+    if (tid < COLS && p0 + tid < A.d.nPos) {
+        const int64_t pp = p0 + tid;
+        REAL wo = sRes[tid][NC];
         if (wo <= 0) wo = (REAL) 1e-20;
-        REAL f[4] = {sRes[tid][1], sRes[tid][2], sRes[tid][3], sRes[tid][4]};
-        vft_normalize_freq<REAL, 4>(A, f, tol);
-        A.outW[p] = wo;
+        REAL f[NC];
 #pragma unroll
-        for (int k = 0; k < 4; k++) A.outF[p * 4 + k] = f[k];
+        for (int k = 0; k < NC; k++) f[k] = sRes[tid][k];
+        vft_normalize_freq<REAL, NC>(A, f, tol);
+        A.outW[pp] = wo;
+#pragma unroll
+        for (int k = 0; k < NC; k++) A.outF[pp * NC + k] = f[k];
+        vft_out_codedist<REAL, NC>(A, pp, f);
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Local-bootstrap support of the split (A,B)|(C,D) around an internal node (splitSupport, NJ.tcc:607-702): the six

@@ -849,6 +849,22 @@ namespace veryfasttree {
             }
         }
 
+        /* the same from inside an OpenMP region: collect candidates per thread (duplicates allowed), then staleMerge */
+        void staleCandidates(int64_t nActive, int64_t allow, int64_t i, int64_t j, std::vector<int64_t> &out) const {
+            if (i < 0 || j < 0 || parent[i] >= 0 || parent[j] >= 0) return;
+            if (mN[i] - nActive > allow) out.push_back(i);
+            if (mN[j] - nActive > allow) out.push_back(j);
+        }
+
+        void staleMerge(int64_t nActive, std::vector<int64_t> &ids) {
+            if (ids.empty()) return;
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            const int64_t n = (int64_t) ids.size();
+            chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, n, ids.data(), nActive, totdiam); });
+            pending = true;
+        }
+
         void staleFlush() {
             if (staleIds.empty()) return;
             for (int64_t v: staleIds) seenScratch[(size_t) v] = 0;
@@ -1206,26 +1222,32 @@ namespace veryfasttree {
             /* 1. getVisible of every active node touches setCriterion: refresh the out-distances that are staler than
                   allowed, all in one device call (what prefetchVisible does, without the intermediate pair lists) */
             const int64_t allow = nDiffAllow(nActive);
-            if (seenScratch.size() != (size_t) maxnodes) seenScratch.assign((size_t) maxnodes, 0);
             std::vector<int64_t> stale, vi;
-            vi.reserve((size_t) nActive);
-            for (int64_t node = 0; node < maxnode; node++) {
-                if (parent[node] >= 0) continue;
-                const int64_t j = visible[node].j;
-                if (j < 0 || parent[j] >= 0) continue;   /* getVisible fails, NJ.tcc:550-552 */
-                vi.push_back(node);
-                if (mN[node] - nActive > allow && !seenScratch[(size_t) node]) {
-                    seenScratch[(size_t) node] = 1;
-                    stale.push_back(node);
+            {   /* node ranges in parallel; concatenated in range order, vi stays ascending */
+                const int nT = opt.hostThreads;
+                std::vector<std::vector<int64_t> > viPart((size_t) nT), stalePart((size_t) nT);
+#pragma omp parallel for schedule(static, 1) num_threads(opt.hostThreads)
+                for (int part = 0; part < nT; part++) {
+                    const int64_t lo = maxnode * part / nT, hi = maxnode * (part + 1) / nT;
+                    std::vector<int64_t> &v = viPart[(size_t) part], &st = stalePart[(size_t) part];
+                    for (int64_t node = lo; node < hi; node++) {
+                        if (parent[node] >= 0) continue;
+                        const int64_t j = visible[node].j;
+                        if (j < 0 || parent[j] >= 0) continue;   /* getVisible fails, NJ.tcc:550-552 */
+                        v.push_back(node);
+                        if (mN[node] - nActive > allow) st.push_back(node);
+                        if (mN[j] - nActive > allow) st.push_back(j);
+                    }
                 }
-                if (mN[j] - nActive > allow && !seenScratch[(size_t) j]) {
-                    seenScratch[(size_t) j] = 1;
-                    stale.push_back(j);
-                }
+                size_t total = 0;
+                for (auto &v: viPart) total += v.size();
+                vi.reserve(total);
+                for (auto &v: viPart) vi.insert(vi.end(), v.begin(), v.end());
+                for (auto &v: stalePart) stale.insert(stale.end(), v.begin(), v.end());
             }
-            for (int64_t v: stale) seenScratch[(size_t) v] = 0;
             if (!stale.empty()) {
                 std::sort(stale.begin(), stale.end());
+                stale.erase(std::unique(stale.begin(), stale.end()), stale.end());
                 const int64_t n = (int64_t) stale.size();
                 chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, n, stale.data(), nActive, totdiam); });
                 pending = true;
@@ -1237,7 +1259,8 @@ namespace veryfasttree {
                 uint64_t key;
                 uint32_t negPos;   /* ~position: ascending (key, negPos) = criterion ascending, ties by descending position */
             };
-            std::vector<Key> keys((size_t) nActive);
+            std::unique_ptr<Key[]> keysBuf(new Key[(size_t) nActive]);   /* (no value-initialisation: 16 MB at a million nodes) */
+            Key *keys = keysBuf.get();
 #pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nActive; t++) {
                 REAL crit = 0;
@@ -1262,14 +1285,37 @@ namespace veryfasttree {
             std::vector<int64_t> touched;
             size_t save = 0;
             int64_t sorted = 0, t = 0;
-            while (t < nVisible && save < topvisible.size()) {
-                if (t == sorted) {
-                    const int64_t upto = std::min<int64_t>(nActive, std::max<int64_t>(2 * sorted, 4 * (int64_t) topvisible.size() + 64));
-                    if (upto < nActive) std::nth_element(keys.begin() + sorted, keys.begin() + upto, keys.end(), before);
-                    std::sort(keys.begin() + sorted, keys.begin() + upto, before);
+            std::vector<Key> cand;
+            const Key *order = keys;
+            {   /* the first `upto` records of the order: every part of the array contributes its own `upto` smallest
+                   (selected in parallel); the answer is among those */
+                const int64_t upto = std::min<int64_t>(nActive, 4 * (int64_t) topvisible.size() + 64);
+                const int nT = opt.hostThreads;
+                if ((int64_t) nT * upto * 2 < nActive) {
+                    cand.resize((size_t) nT * (size_t) upto);
+#pragma omp parallel for schedule(static, 1) num_threads(opt.hostThreads)
+                    for (int part = 0; part < nT; part++) {
+                        const int64_t lo = nActive * part / nT, hi = nActive * (part + 1) / nT;   /* hi - lo > upto */
+                        std::nth_element(keys + lo, keys + lo + upto, keys + hi, before);
+                        std::copy(keys + lo, keys + lo + upto, cand.begin() + (size_t) part * (size_t) upto);
+                    }
+                    std::nth_element(cand.begin(), cand.begin() + upto, cand.end(), before);
+                    std::sort(cand.begin(), cand.begin() + upto, before);
+                    order = cand.data();
                     sorted = upto;
                 }
-                const int64_t pos = (int64_t) (uint32_t) ~keys[(size_t) t++].negPos;
+            }
+            while (t < nVisible && save < topvisible.size()) {
+                if (t == sorted) {   /* (after the parallel selection: rare; the order is total, so starting over on the whole
+                                        array reproduces the prefix already consumed) */
+                    const int64_t upto = std::min<int64_t>(nActive, std::max<int64_t>(2 * sorted, 4 * (int64_t) topvisible.size() + 64));
+                    const int64_t from = order == keys ? sorted : 0;
+                    if (upto < nActive) std::nth_element(keys + from, keys + upto, (keys + nActive), before);
+                    std::sort(keys + from, keys + upto, before);
+                    order = keys;
+                    sorted = upto;
+                }
+                const int64_t pos = (int64_t) (uint32_t) ~order[(size_t) t++].negPos;
                 const int64_t vI = pos < nVisible ? vi[(size_t) pos] : 0;
                 const int64_t vJ = pos < nVisible ? visible[(size_t) vI].j : 0;
                 if (inTop[(size_t) vI] != vJ) {
@@ -1389,7 +1435,11 @@ namespace veryfasttree {
                 const int64_t seed = seeds[s];
                 if (visited[seed]) continue;
                 visited[seed] = 1;
-                std::vector<Besthit> best = sweep(seed, n, (int32_t) (2 * m));
+                std::vector<Besthit> best;
+                {
+                    Section s2(this, "[host]   setAllLeafTopHits: seed sweep (incl. device)");
+                    best = sweep(seed, n, (int32_t) (2 * m));
+                }
                 std::vector<Besthit> copy(best);
                 sortSaveBestHits(seed, copy, (int64_t) copy.size(), m, false);
                 const double neardist = best[2 * m - 1].dist * close;
@@ -1421,6 +1471,7 @@ namespace veryfasttree {
                     /* nucleotides with %-different distances: every pair is an integer seqDist - one block call
                        (k_leaf_block); the device refuses it for other alphabets / a distance matrix, once */
                     bool block = leafBlocks;
+                    std::unique_ptr<Section> sDev(new Section(this, "[host]   setAllLeafTopHits: neighbour distances (incl. device)"));
                     std::vector<int64_t> pi, pj, first((size_t) nNb + 1, 0);
                     std::vector<REAL> pd, pw, pc;
                     if (block) {
@@ -1470,6 +1521,8 @@ namespace veryfasttree {
                         }
                     }
                     pending = false;
+                    sDev.reset();
+                    Section sSort(this, "[host]   setAllLeafTopHits: neighbour sort + save (host threads)");
 #pragma omp parallel for schedule(dynamic, 4) num_threads(opt.hostThreads)
                     for (int64_t a = 0; a < nNb; a++) {
                         const int64_t cn = cns[(size_t) a];
@@ -1529,8 +1582,59 @@ namespace veryfasttree {
             for (int64_t node = 0; node < n; node++) visible[node] = hits[node][0];
             /* checking phase, NJ.tcc:4052-4119 */
             const int64_t nCheck = q > 0 ? q : (int64_t) (0.5 + 2.0 * std::sqrt((double) m));
+            /* The loop below is sequential in the reference (an iteration may rewrite ANOTHER node's list), but almost
+               every iteration ends at one of its two early exits, which only read.  Those verdicts are computed for all
+               (node, hit) in parallel first; the sequential pass trusts a verdict as long as neither list involved has
+               been rewritten since (dirty), and does the full work otherwise.  n * nCheck = 63 million iterations of
+               cache misses at a million sequences. */
+            Section sCheck(this, "[host]   setAllLeafTopHits: checking phase");
+            drain();
+            bool allFresh = true;
+            for (int64_t v = 0; v < n && allFresh; v++) allFresh = mN[v] == n;
+            std::vector<uint8_t> verdict, dirty;
+            if (allFresh && n * nCheck < ((int64_t) 1 << 31)) {
+                verdict.assign((size_t) (n * nCheck), 0);
+                dirty.assign((size_t) n, 0);
+#pragma omp parallel for schedule(dynamic, 256) num_threads(opt.hostThreads)
+                for (int64_t node = 0; node < n; node++) {
+                    for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
+                        Besthit bh;
+                        bh.i = node;
+                        bh.j = hits[node][iHit].j;
+                        bh.dist = hits[node][iHit].dist;
+                        criterionFresh(n, bh);
+                        const std::vector<Hit> &lT = hits[bh.j];
+                        if ((int64_t) lT.size() < nCheck) continue;   /* (the sequential pass handles it like the reference) */
+                        Besthit chk2;
+                        chk2.i = bh.j;
+                        chk2.j = lT[nCheck - 1].j;
+                        chk2.dist = lT[nCheck - 1].dist;
+                        criterionFresh(n, chk2);
+                        bool skip = chk2.criterion < bh.criterion;
+                        for (size_t t = 0; t < lT.size() && !skip; t++) skip = lT[t].j == node;
+                        if (!skip) {   /* the scan for the worst hit of the other list: a no-op too unless it is worse than this one */
+                            double dWorst = -1e20;
+                            for (size_t t = 0; t < lT.size(); t++) {
+                                Besthit b2;
+                                b2.i = bh.j;
+                                b2.j = lT[t].j;
+                                b2.dist = lT[t].dist;
+                                criterionFresh(n, b2);
+                                if (b2.criterion > dWorst) dWorst = b2.criterion;
+                            }
+                            skip = !(dWorst > bh.criterion);
+                        }
+                        verdict[(size_t) (node * nCheck + iHit)] = skip ? 1 : 0;
+                    }
+                }
+            }
+            int64_t nFullChecks = 0;
             for (int64_t node = 0; node < n; node++) {
                 for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
+                    if (!verdict.empty() && verdict[(size_t) (node * nCheck + iHit)] && !dirty[(size_t) node] &&
+                        !dirty[(size_t) hits[node][iHit].j])
+                        continue;
+                    nFullChecks++;
                     Besthit bh;
                     bh.i = node;
                     bh.j = hits[node][iHit].j;
@@ -1563,6 +1667,7 @@ namespace veryfasttree {
                         }
                     }
                     if (dWorst > bh.criterion) {
+                        if (!dirty.empty()) dirty[(size_t) bh.j] = 1;
                         lT[iWorst].j = node;
                         lT[iWorst].dist = bh.dist;
                         Besthit v;
@@ -1570,6 +1675,10 @@ namespace veryfasttree {
                         if (bh.criterion < v.criterion) visible[bh.j] = lT[iWorst];
                     }
                 }
+            }
+            if (profiling) {
+                acc["[count]  checking phase: iterations done in full"].calls += nFullChecks;
+                acc["[count]  checking phase: verdicts precomputed"].calls += (int64_t) verdict.size();
             }
         }
 
@@ -1704,6 +1813,7 @@ namespace veryfasttree {
                 int64_t nCand = 0;
                 bestNode = -1;
                 double bestCrit = 1e20;
+                Section sScan(this, "[host]   topHitNJSearch: top-visible scan (incl. device)");
                 prefetchVisible(nActive, topvisible);
                 for (int64_t node: topvisible) {
                     Besthit v;
@@ -1747,6 +1857,7 @@ namespace veryfasttree {
             if (opt.fastest) return join;
             Besthit join2 = join;
             bool changed;
+            Section sClimb(this, "[host]   topHitNJSearch: hill climbing (incl. device)");
             do {
                 changed = false;
                 Besthit best = getBestFromTopHits(join2.i, nActive);
@@ -1846,6 +1957,8 @@ namespace veryfasttree {
                 int64_t node, nNew;
                 std::vector<Besthit> both, out;
                 std::vector<uint8_t> isTodo;
+                std::vector<int32_t> listTodo;      /* records whose distance goes to the device as a pair list */
+                std::vector<int64_t> staleCand;     /* ends of the records whose distance is known, if stale */
             };
             std::vector<Work> work;
             for (int64_t iHit = 0; iHit < m && iHit < (int64_t) all.size(); iHit++) {
@@ -1862,16 +1975,29 @@ namespace veryfasttree {
             const int64_t nW = (int64_t) work.size();
             {   /* setCriterion on every old hit (NJ.tcc:4491-4494): refresh what is stale, once, for all nodes */
                 Section s2(this, "[host]     refresh: stale old hits (incl. device)");
-                staleBegin(nActive);
-                for (const Work &w: work)
-                    for (const Hit &h: hits[w.node]) staleAdd(w.node, h.j);
-                staleFlush();
+                drain();
+                const int64_t allow = nDiffAllow(nActive);
+                std::vector<std::vector<int64_t> > cand((size_t) opt.hostThreads);
+#pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
+                for (int64_t t = 0; t < nW; t++) {
+#ifdef _OPENMP
+                    std::vector<int64_t> &mine = cand[(size_t) omp_get_thread_num()];
+#else
+                    std::vector<int64_t> &mine = cand[0];
+#endif
+                    const int64_t node = work[(size_t) t].node;
+                    for (const Hit &h: hits[node]) staleCandidates(nActive, allow, node, h.j, mine);
+                }
+                std::vector<int64_t> ids;
+                for (auto &v: cand) ids.insert(ids.end(), v.begin(), v.end());
+                staleMerge(nActive, ids);
                 drain();
             }
             std::unique_ptr<Section> sHost(new Section(this, "[host]     refresh: transfer + unique (host threads)"));
             /* the transferred hits' partners, re-targeted to their active ancestors: the same for every node */
             std::vector<int64_t> target(all.size());
             for (size_t u = 0; u < all.size(); u++) target[u] = all[u].i < 0 ? -1 : activeAncestor(all[u].j);
+            const int64_t allowR = nDiffAllow(nActive);
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
                 Work &w = work[t];
@@ -1913,7 +2039,15 @@ namespace veryfasttree {
                     last = (int64_t) u;
                 }
                 w.isTodo.assign(w.out.size(), 0);
-                for (size_t u = 0; u < w.out.size(); u++) w.isTodo[u] = w.out[u].dist < 0.0 ? 1 : 0;
+                for (size_t u = 0; u < w.out.size(); u++) {
+                    const Besthit &h = w.out[u];
+                    w.isTodo[u] = h.dist < 0.0 ? 1 : 0;
+                    if (w.isTodo[u]) {
+                        if (h.src < 0) w.listTodo.push_back((int32_t) u);
+                    } else {
+                        staleCandidates(nActive, allowR, h.i, h.j, w.staleCand);
+                    }
+                }
             }
             sHost.reset();
             std::vector<REAL> block;
@@ -1931,8 +2065,7 @@ namespace veryfasttree {
                 for (int64_t t = 0; t < nW; t++) nodesA[(size_t) t] = work[(size_t) t].node;
                 std::vector<Besthit *> todo;
                 for (Work &w: work)
-                    for (size_t u = 0; u < w.out.size(); u++)
-                        if (w.isTodo[u] && w.out[u].src < 0) todo.push_back(&w.out[u]);
+                    for (int32_t u: w.listTodo) todo.push_back(&w.out[(size_t) u]);
                 if (profiling) acc["[count]    refresh: pairs recomputed as a list"].calls += (int64_t) todo.size();
                 if (profiling) acc["[count]    refresh: pairs recomputed as a block"].calls += nW * nB;
                 if (nW > 0 && nB > 0) {
@@ -1944,11 +2077,11 @@ namespace veryfasttree {
                     pending = false;
                 }
                 setDistCriterionBatch(nActive, todo);
-                staleBegin(nActive);
-                for (Work &w: work)
-                    for (size_t u = 0; u < w.out.size(); u++)
-                        if (!w.isTodo[u]) staleAdd(w.out[u].i, w.out[u].j);
-                staleFlush();
+                {   /* (candidates were collected before the two calls above: what those refreshed is skipped on the device) */
+                    std::vector<int64_t> ids;
+                    for (Work &w: work) ids.insert(ids.end(), w.staleCand.begin(), w.staleCand.end());
+                    staleMerge(nActive, ids);
+                }
                 drain();
             }
             std::unique_ptr<Section> sSave(new Section(this, "[host]     refresh: criteria + sort + save (host threads)"));
