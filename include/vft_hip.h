@@ -189,6 +189,12 @@ int vft_sweep_results(vft_ctx *ctx, int64_t first, int64_t count, void *dist, vo
    (NJ.tcc:4580-4613, 4786-4833, 4267-4298).  Outputs are host arrays of the context precision. */
 int vft_pair_distances(vft_ctx *ctx, int64_t n, const int64_t *i, const int64_t *j, int64_t n_active,
                        int64_t n_diff_allow, double totdiam, void *dist, void *weight, void *criterion);
+/* The same with n_force nodes whose out-distance is recomputed first unless it carries the stamp n_active (setOutDistance,
+   NJ.tcc:1012-1015) - getBestFromTopHits' own node (NJ.tcc:4270) and the stale ends of the hits whose distance is known,
+   which would otherwise be a vft_out_distances call and a second wait per list.  n == 0: vft_out_distances(force_ids). */
+int vft_pair_distances_refresh(vft_ctx *ctx, int64_t n, const int64_t *i, const int64_t *j, int64_t n_force,
+                               const int64_t *force_ids, int64_t n_active, int64_t n_diff_allow, double totdiam, void *dist,
+                               void *weight, void *criterion);
 /* setDistCriterion for the cross product of two lists of LEAVES (every id below n_seqs; nucleotides without a distance
    matrix): out[x * n_b + y] belongs to the pair (a[x], b[y]).  The close-neighbour transfers of setAllLeafTopHits
    (NJ.tcc:3957-3992 -> transferBestHits :4580-4613) are such blocks - up to m close neighbours x the seed's 2m best hits -

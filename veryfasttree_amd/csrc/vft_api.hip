@@ -1684,18 +1684,27 @@ extern "C" int vft_sweep_results(vft_ctx *c, int64_t first, int64_t count, void 
 }
 
 static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive, int64_t nDiffAllow,
-                          double totdiam, void *dist, void *weight, void *crit, bool raw);
+                          double totdiam, void *dist, void *weight, void *crit, bool raw, int64_t nForce, const int64_t *forceIds);
 extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive,
                                   int64_t nDiffAllow, double totdiam, void *dist, void *weight, void *crit) {
-    return pair_distances(c, n, pi, pj, nActive, nDiffAllow, totdiam, dist, weight, crit, false);
+    return pair_distances(c, n, pi, pj, nActive, nDiffAllow, totdiam, dist, weight, crit, false, 0, nullptr);
+}
+extern "C" int vft_pair_distances_refresh(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nForce,
+                                          const int64_t *forceIds, int64_t nActive, int64_t nDiffAllow, double totdiam,
+                                          void *dist, void *weight, void *crit) {
+    if (nForce < 0 || (nForce > 0 && !forceIds)) return VFT_ERR_INVALID;
+    if (n == 0 && nForce > 0) return vft_out_distances(c, nForce, forceIds, nActive, totdiam);
+    return pair_distances(c, n, pi, pj, nActive, nDiffAllow, totdiam, dist, weight, crit, false, nForce, forceIds);
 }
 extern "C" int vft_profile_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, void *dist, void *weight) {
-    return pair_distances(c, n, pi, pj, 3, 0, 0.0, dist, weight, nullptr, true);
+    return pair_distances(c, n, pi, pj, 3, 0, 0.0, dist, weight, nullptr, true, 0, nullptr);
 }
 static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive, int64_t nDiffAllow,
-                          double totdiam, void *dist, void *weight, void *crit, bool raw) {
+                          double totdiam, void *dist, void *weight, void *crit, bool raw, int64_t nForce, const int64_t *forceIds) {
     if (!c || n < 0 || !pi || !pj) return VFT_ERR_INVALID;
     if (n == 0) return VFT_OK;
+    for (int64_t t = 0; t < nForce; t++)
+        if (forceIds[t] < 0 || forceIds[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "forced node %lld out of range", (long long) t);
     if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_pair_distances before vft_upload_leaves");
     for (int64_t t = 0; t < n; t++)
         if (pi[t] < 0 || pi[t] >= c->maxnode || pj[t] < 0 || pj[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "pair %lld out of range", (long long) t);
@@ -1707,6 +1716,7 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     // many times - 0.85 ms of a 0.94 ms call at 60 000 pairs.
     std::vector<int64_t> &stale = c->staleIds;
     stale.clear();
+    int64_t nForced = 0;
     if (!raw) {
         if (c->staleMark.size() != (size_t) c->d.maxNodes) c->staleMark.assign((size_t) c->d.maxNodes, 0u);
         if (++c->staleEpoch == 0u) {
@@ -1715,6 +1725,16 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
         }
         const uint32_t ep = c->staleEpoch;
         uint32_t *mark = c->staleMark.data();
+        // forced refreshes first (setOutDistance, NJ.tcc:1012-1015: recomputed unless the stamp IS n_active); the kernel
+        // applies that rule to the first nForced entries of the list and the lazy one to the rest
+        for (int64_t t = 0; t < nForce; t++) {
+            const int64_t v = forceIds[t];
+            if ((int64_t) c->hNOut[v] != nActive && mark[v] != ep) {
+                mark[v] = ep;
+                stale.push_back(v);
+            }
+        }
+        nForced = (int64_t) stale.size();
         for (int64_t t = 0; t < n; t++) {
             const int64_t a = pi[t], b = pj[t];
             if ((int64_t) c->hNOut[a] - nActive > nDiffAllow && mark[a] != ep) {
@@ -1760,14 +1780,14 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
         const size_t lds = pw_lds_bytes(c) / c->pwWaves;
         if (nStale)
             VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, true>), dim3((unsigned) nStale), dim3(VFT_WG), lds, c->stream,
-                                    arena<REAL>(c), dStale, nStale, sa)));
+                                    arena<REAL>(c), dStale, nStale, nForced, sa)));
         VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, true>), dim3((unsigned) n), dim3(VFT_WG), lds, c->stream,
                                 arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB),
                                 c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
     } else {
         if (nStale)
             VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves),
-                                    pw_lds_bytes(c), c->stream, arena<REAL>(c), dStale, nStale, sa)));
+                                    pw_lds_bytes(c), c->stream, arena<REAL>(c), dStale, nStale, nForced, sa)));
         VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB),
                                 (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
@@ -1862,7 +1882,7 @@ extern "C" int vft_block_distances(vft_ctx *c, int64_t nA, const int64_t *a, int
     if (nStale) {
         if (nActive > c->maxStamp) c->maxStamp = nActive;
         VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
-                                c->stream, arena<REAL>(c), (const int64_t *) dStale, nStale, sa)));
+                                c->stream, arena<REAL>(c), (const int64_t *) dStale, nStale, (int64_t) 0, sa)));
     }
     char *o = sBase + idB;
     VFT_DISPATCH(c, (launch((k_pairs_block<REAL, NC>), dim3(cdiv(nA * nB, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,

@@ -960,14 +960,17 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_block(Arena<REAL> A, const int
 
 // Lazy out-distance refresh (setCriterion, NJ.tcc:1092-1098) of the DISTINCT stale nodes of a pair list; the host
 // builds the list from its stamp mirror (vft_api.hip: pair_distances), the kernel looks at the real stamp again.
+// Entries below nForced are unconditional refreshes that travel with the list (vft_pair_distances_refresh).
 // WGPAIR: a workgroup per node (short lists), otherwise a wave.
 template <typename REAL, int NC, bool WGPAIR>
-__global__ __launch_bounds__(VFT_WG) void k_refresh_list(Arena<REAL> A, const int64_t *ids, int64_t n, SweepArgs s) {
+__global__ __launch_bounds__(VFT_WG) void k_refresh_list(Arena<REAL> A, const int64_t *ids, int64_t n, int64_t nForced, SweepArgs s) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
     const int64_t t = WGPAIR ? (int64_t) blockIdx.x : (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;
     const int64_t v = ids[t];
-    if (!((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;   // uniform over the wave / workgroup
+    // the first nForced entries: setOutDistance itself (recomputed unless the stamp IS nActive, NJ.tcc:1012-1015); the
+    // rest: setCriterion's lazy rule.  Uniform over the wave / workgroup.
+    if (t < nForced ? (int64_t) A.nOutActive[v] == s.nActive : !((int64_t) A.nOutActive[v] - s.nActive > s.nDiffAllow)) return;
     REAL d, w;
     if (WGPAIR) vft_pair_block<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
     else vft_pair_wave<REAL, NC>(A, v, -1, true, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);

@@ -912,8 +912,18 @@ namespace veryfasttree {
             hit.criterion = (REAL) (hit.dist - (outI + outJ) / (double) (nActive - 2));
         }
 
-        void setDistCriterionBatch(int64_t nActive, std::vector<Besthit *> &list, int64_t allow = -1) { /* NJ.tcc:1115-1124 */
-            if (list.empty()) return;
+        /* forced: nodes whose out-distance is recomputed in the same call unless it carries the stamp nActive
+           (vft_pair_distances_refresh) - one wait instead of two when a list comes with refreshes of its own */
+        void setDistCriterionBatch(int64_t nActive, std::vector<Besthit *> &list, int64_t allow = -1,
+                                   const std::vector<int64_t> *forced = nullptr) { /* NJ.tcc:1115-1124 */
+            const int64_t nF = forced ? (int64_t) forced->size() : 0;
+            if (list.empty()) {
+                if (nF > 0) {
+                    chkT("vft_out_distances", [&]() { return vft_out_distances(ctx, nF, forced->data(), nActive, totdiam); });
+                    pending = true;
+                }
+                return;
+            }
             if (allow < 0) allow = nDiffAllow(nActive);
             const int64_t n = (int64_t) list.size();
             std::vector<int64_t> pi(n), pj(n);
@@ -922,8 +932,10 @@ namespace veryfasttree {
                 pi[t] = list[t]->i;
                 pj[t] = list[t]->j;
             }
-            chkT("vft_pair_distances", [&]() { return vft_pair_distances(ctx, n, pi.data(), pj.data(), nActive, allow, totdiam, d.data(), w.data(),
-                                   c.data()); });
+            chkT("vft_pair_distances", [&]() {
+                return vft_pair_distances_refresh(ctx, n, pi.data(), pj.data(), nF, nF ? forced->data() : nullptr, nActive, allow, totdiam,
+                                                  d.data(), w.data(), c.data());
+            });
             pending = false;   /* the call returned data: the stream has drained */
             for (int64_t t = 0; t < n; t++) {
                 list[t]->dist = d[t];
@@ -1130,12 +1142,15 @@ namespace veryfasttree {
                     todo.push_back(&out[t]);
                     isTodo[t] = 1;
                 }
-            setDistCriterionBatch(nActive, todo);
-            {
-                std::vector<std::pair<int64_t, int64_t> > pairs;
+            {   /* the lazy refreshes of the hits whose distance is known travel with the pair list */
+                drain();
+                const int64_t allow = nDiffAllow(nActive);
+                std::vector<int64_t> forced;
                 for (size_t t = 0; t < out.size(); t++)
-                    if (!isTodo[t]) pairs.push_back(std::make_pair(out[t].i, out[t].j));
-                prefetchStale(nActive, pairs);
+                    if (!isTodo[t]) staleCandidates(nActive, allow, out[t].i, out[t].j, forced);
+                std::sort(forced.begin(), forced.end());
+                forced.erase(std::unique(forced.begin(), forced.end()), forced.end());
+                setDistCriterionBatch(nActive, todo, -1, &forced);
             }
             for (size_t t = 0; t < out.size(); t++)
                 if (!isTodo[t]) setCriterion(nActive, out[t]);
@@ -1683,20 +1698,28 @@ namespace veryfasttree {
         }
 
         Besthit getBestFromTopHits(int64_t node, int64_t nActive) { /* NJ.tcc:4267-4298 */
-            if (!opt.fastest) setOutDistance(node, nActive);
+            /* setOutDistance(node) (unless -fastest), the recomputed distances of re-targeted hits and the lazy refreshes
+               of setCriterion on every hit all belong to the same window: one device call, one wait */
+            drain();
+            std::vector<int64_t> forced;
+            if (!opt.fastest && mN[node] != nActive) forced.push_back(node);
             Besthit best;
             best.i = best.j = -1;
             std::vector<Besthit> cand = hitsToBestHits(hits[node], node);
             std::vector<uint8_t> ok(cand.size(), 0);
             std::vector<Besthit *> todo;
             for (size_t t = 0; t < cand.size(); t++) ok[t] = updateBestHit(cand[t], true, &todo) ? 1 : 0;
-            setDistCriterionBatch(nActive, todo);
             {
-                std::vector<std::pair<int64_t, int64_t> > pairs;
+                const int64_t allow = nDiffAllow(nActive);
+                const size_t first = forced.size();
                 for (size_t t = 0; t < cand.size(); t++)
-                    if (ok[t]) pairs.push_back(std::make_pair(cand[t].i, cand[t].j));
-                prefetchStale(nActive, pairs);
+                    if (ok[t]) staleCandidates(nActive, allow, cand[t].i, cand[t].j, forced);
+                if (forced.size() > first + 1) {
+                    std::sort(forced.begin() + first, forced.end());
+                    forced.erase(std::unique(forced.begin() + first, forced.end()), forced.end());
+                }
             }
+            setDistCriterionBatch(nActive, todo, -1, &forced);
             for (size_t t = 0; t < cand.size(); t++) {
                 if (!ok[t]) continue;
                 setCriterion(nActive, cand[t]);
