@@ -1423,6 +1423,20 @@ namespace veryfasttree {
             return VFT_OK;
         }
 
+        /* criteria of the hits of one top-hits list when every out-distance involved is current (host arithmetic only) */
+        void fillCriteria(int64_t nActive, int64_t x, std::vector<REAL> &out) const {
+            const std::vector<Hit> &l = hits[(size_t) x];
+            out.resize(l.size());
+            for (size_t t = 0; t < l.size(); t++) {
+                Besthit b2;
+                b2.i = x;
+                b2.j = l[t].j;
+                b2.dist = l[t].dist;
+                criterionFresh(nActive, b2);
+                out[t] = b2.criterion;
+            }
+        }
+
         void setAllLeafTopHits() { /* NJ.tcc:3746-4119, threads == 1 branch, first-level lists */
             Section sec(this, "[host] setAllLeafTopHits (incl. device)");
             const int64_t n = nSeqs;
@@ -1597,19 +1611,38 @@ namespace veryfasttree {
             for (int64_t node = 0; node < n; node++) visible[node] = hits[node][0];
             /* checking phase, NJ.tcc:4052-4119 */
             const int64_t nCheck = q > 0 ? q : (int64_t) (0.5 + 2.0 * std::sqrt((double) m));
-            /* The loop below is sequential in the reference (an iteration may rewrite ANOTHER node's list), but almost
-               every iteration ends at one of its two early exits, which only read.  Those verdicts are computed for all
-               (node, hit) in parallel first; the sequential pass trusts a verdict as long as neither list involved has
-               been rewritten since (dirty), and does the full work otherwise.  n * nCheck = 63 million iterations of
-               cache misses at a million sequences. */
+            /* The loop below is sequential in the reference (an iteration may rewrite one entry of ANOTHER node's list),
+               but almost every iteration is a no-op that only reads: (a) the other list's nCheck-th hit already beats
+               this one, (b) the other list already holds this node, (c) its worst hit is not worse than this one.  The
+               verdicts are computed for all (node, hit) in parallel first.  A later rewrite replaces the WORST entry of a
+               list by a better one, so (a) and (c) can only become "more true" (criteria are constants here: every
+               out-distance carries the stamp n); a verdict is withdrawn only where the rewrite touches what it read -
+               the rewritten entry itself, and (b)-verdicts of the node that was pushed out.  The sequential pass then does
+               the full work for the withdrawn and the undecided ones.  n * nCheck = 63 million iterations of cache misses
+               at a million sequences. */
             Section sCheck(this, "[host]   setAllLeafTopHits: checking phase");
             drain();
             bool allFresh = true;
             for (int64_t v = 0; v < n && allFresh; v++) allFresh = mN[v] == n;
-            std::vector<uint8_t> verdict, dirty;
-            if (allFresh && n * nCheck < ((int64_t) 1 << 31)) {
+            std::vector<uint8_t> verdict;
+            if (allFresh && n * nCheck < ((int64_t) 1 << 32)) {
                 verdict.assign((size_t) (n * nCheck), 0);
-                dirty.assign((size_t) n, 0);
+                /* (c) asks for the worst criterion of the OTHER list: a property of that list, computed once per list
+                   instead of once per (node, hit) - the lists are 16 GB at a million sequences */
+                std::vector<double> worstOf((size_t) n, -1e20);
+#pragma omp parallel for schedule(dynamic, 256) num_threads(opt.hostThreads)
+                for (int64_t x = 0; x < n; x++) {
+                    double dWorst = -1e20;
+                    for (const Hit &h: hits[x]) {
+                        Besthit b2;
+                        b2.i = x;
+                        b2.j = h.j;
+                        b2.dist = h.dist;
+                        criterionFresh(n, b2);
+                        if (b2.criterion > dWorst) dWorst = b2.criterion;
+                    }
+                    worstOf[(size_t) x] = dWorst;
+                }
 #pragma omp parallel for schedule(dynamic, 256) num_threads(opt.hostThreads)
                 for (int64_t node = 0; node < n; node++) {
                     for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
@@ -1625,30 +1658,29 @@ namespace veryfasttree {
                         chk2.j = lT[nCheck - 1].j;
                         chk2.dist = lT[nCheck - 1].dist;
                         criterionFresh(n, chk2);
-                        bool skip = chk2.criterion < bh.criterion;
-                        for (size_t t = 0; t < lT.size() && !skip; t++) skip = lT[t].j == node;
-                        if (!skip) {   /* the scan for the worst hit of the other list: a no-op too unless it is worse than this one */
-                            double dWorst = -1e20;
-                            for (size_t t = 0; t < lT.size(); t++) {
-                                Besthit b2;
-                                b2.i = bh.j;
-                                b2.j = lT[t].j;
-                                b2.dist = lT[t].dist;
-                                criterionFresh(n, b2);
-                                if (b2.criterion > dWorst) dWorst = b2.criterion;
-                            }
-                            skip = !(dWorst > bh.criterion);
-                        }
-                        verdict[(size_t) (node * nCheck + iHit)] = skip ? 1 : 0;
+                        uint8_t why = chk2.criterion < bh.criterion ? 1 : 0;
+                        for (size_t t = 0; t < lT.size() && !why; t++)
+                            if (lT[t].j == node) why = 2;
+                        if (!why && !(worstOf[(size_t) bh.j] > bh.criterion)) why = 3;
+                        verdict[(size_t) (node * nCheck + iHit)] = why;
                     }
                 }
+            }
+            std::vector<std::vector<REAL> > critOf;
+            if (!verdict.empty()) {
+                critOf.resize((size_t) n);
+                std::vector<uint8_t> need((size_t) n, 0);
+                for (int64_t node = 0; node < n; node++)
+                    for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++)
+                        if (!verdict[(size_t) (node * nCheck + iHit)]) need[(size_t) hits[node][iHit].j] = 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(opt.hostThreads)
+                for (int64_t x = 0; x < n; x++)
+                    if (need[(size_t) x]) fillCriteria(n, x, critOf[(size_t) x]);
             }
             int64_t nFullChecks = 0;
             for (int64_t node = 0; node < n; node++) {
                 for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
-                    if (!verdict.empty() && verdict[(size_t) (node * nCheck + iHit)] && !dirty[(size_t) node] &&
-                        !dirty[(size_t) hits[node][iHit].j])
-                        continue;
+                    if (!verdict.empty() && verdict[(size_t) (node * nCheck + iHit)]) continue;
                     nFullChecks++;
                     Besthit bh;
                     bh.i = node;
@@ -1669,20 +1701,40 @@ namespace veryfasttree {
                     if (found) continue;
                     int64_t iWorst = -1;
                     double dWorst = -1e20;
-                    for (size_t t = 0; t < lT.size(); t++) {
-                        Besthit b2;
-                        b2.i = bh.j;
-                        b2.j = lT[t].j;
-                        b2.dist = lT[t].dist;
-                        b2.weight = -1;
-                        setCriterion(n, b2);
-                        if (b2.criterion > dWorst) {
-                            iWorst = (int64_t) t;
-                            dWorst = b2.criterion;
+                    if (!verdict.empty()) {
+                        /* every out-distance is current, so the criteria of a list's hits are constants: computed once per
+                           list that is ever scanned (in parallel above for the lists known to need it), updated when an
+                           entry is replaced - a scan is then m contiguous numbers instead of m x (two random reads) */
+                        std::vector<REAL> &cr = critOf[(size_t) bh.j];
+                        if (cr.size() != lT.size()) fillCriteria(n, bh.j, cr);
+                        for (size_t t = 0; t < cr.size(); t++)
+                            if (cr[t] > dWorst) {
+                                iWorst = (int64_t) t;
+                                dWorst = cr[t];
+                            }
+                    } else {
+                        for (size_t t = 0; t < lT.size(); t++) {
+                            Besthit b2;
+                            b2.i = bh.j;
+                            b2.j = lT[t].j;
+                            b2.dist = lT[t].dist;
+                            b2.weight = -1;
+                            setCriterion(n, b2);
+                            if (b2.criterion > dWorst) {
+                                iWorst = (int64_t) t;
+                                dWorst = b2.criterion;
+                            }
                         }
                     }
                     if (dWorst > bh.criterion) {
-                        if (!dirty.empty()) dirty[(size_t) bh.j] = 1;
+                        if (!verdict.empty()) critOf[(size_t) bh.j][(size_t) iWorst] = bh.criterion;   /* (x, node) = (node, x) */
+                        if (!verdict.empty()) {   /* withdraw what read the entry that is about to change */
+                            if (iWorst < nCheck) verdict[(size_t) (bh.j * nCheck + iWorst)] = 0;
+                            const int64_t gone = lT[iWorst].j;
+                            if (gone >= 0 && gone < n)
+                                for (int64_t ih = 0; ih < nCheck && ih < (int64_t) hits[gone].size(); ih++)
+                                    if (hits[gone][ih].j == bh.j) verdict[(size_t) (gone * nCheck + ih)] = 0;
+                        }
                         lT[iWorst].j = node;
                         lT[iWorst].dist = bh.dist;
                         Besthit v;
