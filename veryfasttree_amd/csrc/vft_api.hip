@@ -1207,7 +1207,7 @@ extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
         }
         const int64_t firstTile = leafHist ? c->d.firstProfTile : 0;
         VFT_DISPATCH(c, (launch((k_outprofile_chain<REAL, NC>), dim3((unsigned) (c->d.nPosPad / OpCols<NC>::value)),
-                                dim3(64 * OpCols<NC>::value), 0, c->stream, arena<REAL>(c), (const unsigned long long *) c->tileMask,
+                                dim3(OpThreads<NC>::value), 0, c->stream, arena<REAL>(c), (const unsigned long long *) c->tileMask,
                                 firstTile, nTiles, n, c->fpostTol, leafHist ? (const unsigned int *) c->opHist : (const unsigned int *) nullptr)));
         LAUNCHCHK(c);
         return VFT_OK;

@@ -574,65 +574,63 @@ static __global__ __launch_bounds__(256) void k_leaf_hist(const uint4 *leafT, Vf
     if (mine) atomicAdd(&hist[((int64_t) chunk * 16 + (lane >> 2)) * 4 + (lane & 3)], mine);
 }
 
+// workgroup: COLS loader waves (wave c = column c of the group, lane = node of the tile) + one wave of frequency chains
+// + one wave of weight chains; the two kinds of chain have different step costs (a float add against convert - double
+// add - convert) and would serialise inside one wave.
+template <typename REAL> struct OpTiles { static const int value = sizeof(REAL) == 4 ? VFT_OP_TILES : VFT_OP_TILES / 2; };
+template <int NC> struct OpThreads { static const int value = 64 * (OpCols<NC>::value + 2); };
+
 template <typename REAL, int NC>
-__global__ __launch_bounds__(64 * OpCols<NC>::value) void k_outprofile_chain(Arena<REAL> A, const unsigned long long *tileMask,
-                                                                             int64_t firstTile, int64_t nTiles, int64_t nActive,
-                                                                             double tol, const unsigned int *hist) {
-    constexpr int COLS = OpCols<NC>::value, NCH = NC + 1, CAP = VFT_OP_TILES * 64, STRIDE = CAP + 4;
-    __shared__ __attribute__((aligned(16))) REAL sAdd[COLS * NCH][STRIDE];
+__global__ __launch_bounds__(OpThreads<NC>::value) void k_outprofile_chain(Arena<REAL> A, const unsigned long long *tileMask,
+                                                                          int64_t firstTile, int64_t nTiles, int64_t nActive,
+                                                                          double tol, const unsigned int *hist) {
+    constexpr int COLS = OpCols<NC>::value, NCH = NC + 1, TILES = OpTiles<REAL>::value, CAP = TILES * 64, STRIDE = CAP + 4;
+    // two addend buffers: the loaders expand stage s + 1 while the chains consume stage s (one barrier per stage)
+    __shared__ __attribute__((aligned(16))) REAL sAdd[2][COLS * NCH][STRIDE];
+    __shared__ int sTotal[2];
     __shared__ REAL sRes[COLS][NCH];
-    const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
-    const int64_t p0 = (int64_t) blockIdx.x * COLS, p = p0 + c;
-    const bool colOk = p < A.d.nPos;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t p0 = (int64_t) blockIdx.x * COLS;
     const double inweight = 1.0 / (double) nActive;
-    const bool chainThread = tid < COLS * NCH;
-    const int chCol = tid / NCH, chK = tid % NCH;   // chain threads: column of the group, component (NC = the weight)
-    REAL acc = 0;
-    if (hist && chainThread && p0 + chCol < A.d.nPos) {   // the leaves' contribution (see above)
-        const unsigned int *h = hist + (p0 + chCol) * 4;
-        if (chK < NC) {
-            const unsigned int n = h[chK];
-            acc = sizeof(REAL) == 4 ? (REAL) (n < (1u << 24) ? n : (1u << 24)) : (REAL) n;
-        } else {
-            acc = vft_iterate_add<REAL>(inweight, (uint64_t) h[0] + h[1] + h[2] + h[3]);
-        }
-    }
-    // stage = up to VFT_OP_TILES non-empty tiles
-    int64_t tNext = firstTile;
-    unsigned long long mk[VFT_OP_TILES];
-    Col<REAL, NC> col[VFT_OP_TILES];
-    auto fetch = [&]() {   // masks of the next stage's tiles (uniform) and this thread's columns of them
+    if (wv < COLS) {
+        // ------------------------------------------------------------------------------------------ loaders
+        const int c = wv;
+        const int64_t p = p0 + c;
+        const bool colOk = p < A.d.nPos;
+        int64_t tNext = firstTile;
+        unsigned long long mkA[TILES], mkB[TILES];
+        Col<REAL, NC> colA[TILES], colB[TILES];
+        auto fetch = [&](unsigned long long (&mk)[TILES], Col<REAL, NC> (&col)[TILES]) {
 #pragma unroll
-        for (int s = 0; s < VFT_OP_TILES; s++) {
-            unsigned long long m = 0;
-            int64_t t = tNext;
-            while (t < nTiles) {
-                m = tileMask[t];
-                if (hist && t * 64 < A.d.nSeqs) m &= ~((1ull << (A.d.nSeqs - t * 64)) - 1ull);   // leaves are in the histogram
-                if (m) break;
-                t++;
+            for (int s = 0; s < TILES; s++) {
+                unsigned long long m = 0;
+                int64_t t = tNext;
+                while (t < nTiles) {
+                    m = tileMask[t];
+                    if (hist && t * 64 < A.d.nSeqs) m &= ~((1ull << (A.d.nSeqs - t * 64)) - 1ull);   // leaves are in the histogram
+                    if (m) break;
+                    t++;
+                }
+                tNext = t + 1;
+                mk[s] = t < nTiles ? m : 0ull;
+                if (((mk[s] >> lane) & 1ull) && colOk) vft_load_col<REAL, NC>(A, t * 64 + lane, p, col[s]);
             }
-            tNext = t + 1;
-            mk[s] = t < nTiles ? m : 0ull;
-            if (((mk[s] >> lane) & 1ull) && colOk) vft_load_col<REAL, NC>(A, t * 64 + lane, p, col[s]);
-        }
-    };
-    fetch();
-    for (;;) {
-        int total = 0;
+        };
+        // expands one stage into buf, publishes its size; false when the stage is empty (the end)
+        auto expand = [&](unsigned long long (&mk)[TILES], Col<REAL, NC> (&col)[TILES], int buf) -> bool {
+            int total = 0;
 #pragma unroll
-        for (int s = 0; s < VFT_OP_TILES; s++) total += __popcll(mk[s]);
-        if (total == 0) break;   // uniform
-        __syncthreads();   // the chains are done with the previous stage
-        {
+            for (int s = 0; s < TILES; s++) total += __popcll(mk[s]);
+            if (tid == 0) sTotal[buf] = total;
+            if (total == 0) return false;   // uniform
             int base = 0;
 #pragma unroll
-            for (int s = 0; s < VFT_OP_TILES; s++) {
+            for (int s = 0; s < TILES; s++) {
                 if ((mk[s] >> lane) & 1ull) {
                     const int n = base + __popcll(mk[s] & ((1ull << lane) - 1ull));
                     const Col<REAL, NC> &cc = col[s];
                     const REAL w = colOk ? cc.w : (REAL) 0;
-                    sAdd[c * NCH + NC][n] = w;
+                    sAdd[buf][c * NCH + NC][n] = w;
 #pragma unroll
                     for (int k = 0; k < NC; k++) {
                         REAL a = 0;
@@ -641,41 +639,110 @@ __global__ __launch_bounds__(64 * OpCols<NC>::value) void k_outprofile_chain(Are
                             else if (A.dmDist) a = A.dmCodeFreq[cc.code * NC + k] * w;          // NJ.tcc:828
                             else a = k == cc.code ? w : (REAL) 0;                               // NJ.tcc:831
                         }
-                        sAdd[c * NCH + k][n] = a;
+                        sAdd[buf][c * NCH + k][n] = a;
                     }
                 }
                 base += __popcll(mk[s]);
             }
+            return true;
+        };
+        fetch(mkA, colA);
+        fetch(mkB, colB);
+        for (int st = 0;; st += 2) {
+            bool more = expand(mkA, colA, 0);
+            if (more) fetch(mkA, colA);   // the stage after the next
+            __syncthreads();
+            if (!more) break;
+            more = expand(mkB, colB, 1);
+            if (more) fetch(mkB, colB);
+            __syncthreads();
+            if (!more) break;
         }
-        __syncthreads();
-        fetch();   // next stage's loads are in flight while the chains run
-        if (chainThread) {
-            const REAL *src = sAdd[chCol * NCH + chK];
-            int n = 0;
-            if (chK < NC) {
-                for (; n + 4 <= total; n += 4) {
-                    const REAL a0 = src[n], a1 = src[n + 1], a2 = src[n + 2], a3 = src[n + 3];
-                    acc = acc + a0;
-                    acc = acc + a1;
-                    acc = acc + a2;
-                    acc = acc + a3;
-                }
-                for (; n < total; n++) acc = acc + src[n];
+    } else {
+        // ------------------------------------------------------------------------------------------ chains
+        const bool weightWave = wv == COLS + 1;
+        const int nChains = weightWave ? COLS : COLS * NC;
+        const bool mine = lane < nChains;
+        const int chCol = weightWave ? lane : lane / NC, chK = weightWave ? NC : lane % NC;
+        REAL acc = 0;
+        if (hist && mine && p0 + chCol < A.d.nPos) {   // the leaves' contribution (see above)
+            const unsigned int *h = hist + (p0 + chCol) * 4;
+            if (!weightWave) {
+                const unsigned int n = h[chK];
+                acc = sizeof(REAL) == 4 ? (REAL) (n < (1u << 24) ? n : (1u << 24)) : (REAL) n;
             } else {
-                for (; n + 4 <= total; n += 4) {
-                    const double a0 = (double) src[n] * inweight, a1 = (double) src[n + 1] * inweight,
-                                 a2 = (double) src[n + 2] * inweight, a3 = (double) src[n + 3] * inweight;
-                    acc = (REAL) ((double) acc + a0);                                           // NJ.tcc:741
-                    acc = (REAL) ((double) acc + a1);
-                    acc = (REAL) ((double) acc + a2);
-                    acc = (REAL) ((double) acc + a3);
-                }
-                for (; n < total; n++) acc = (REAL) ((double) acc + (double) src[n] * inweight);
+                acc = vft_iterate_add<REAL>(inweight, (uint64_t) h[0] + h[1] + h[2] + h[3]);
             }
         }
+        __syncthreads();   // stage 0 is in buffer 0
+        for (int buf = 0;; buf ^= 1) {
+            const int total = sTotal[buf];
+            if (total == 0) break;   // uniform
+            if (mine) {
+                const REAL *src = sAdd[buf][chCol * NCH + chK];
+                int n = 0;
+                if (!weightWave) {
+                    // reads run one group ahead of the adds (the adds are the dependent chain, the LDS latency is not)
+                    REAL a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    if (total >= 4) {
+                        a0 = src[0];
+                        a1 = src[1];
+                        a2 = src[2];
+                        a3 = src[3];
+                    }
+                    for (; n + 8 <= total; n += 4) {
+                        const REAL b0 = src[n + 4], b1 = src[n + 5], b2 = src[n + 6], b3 = src[n + 7];
+                        acc = acc + a0;
+                        acc = acc + a1;
+                        acc = acc + a2;
+                        acc = acc + a3;
+                        a0 = b0;
+                        a1 = b1;
+                        a2 = b2;
+                        a3 = b3;
+                    }
+                    if (n + 4 <= total) {
+                        acc = acc + a0;
+                        acc = acc + a1;
+                        acc = acc + a2;
+                        acc = acc + a3;
+                        n += 4;
+                    }
+                    for (; n < total; n++) acc = acc + src[n];
+                } else {
+                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    if (total >= 4) {
+                        a0 = (double) src[0] * inweight;
+                        a1 = (double) src[1] * inweight;
+                        a2 = (double) src[2] * inweight;
+                        a3 = (double) src[3] * inweight;
+                    }
+                    for (; n + 8 <= total; n += 4) {
+                        const double b0 = (double) src[n + 4] * inweight, b1 = (double) src[n + 5] * inweight,
+                                     b2 = (double) src[n + 6] * inweight, b3 = (double) src[n + 7] * inweight;
+                        acc = (REAL) ((double) acc + a0);                                       // NJ.tcc:741
+                        acc = (REAL) ((double) acc + a1);
+                        acc = (REAL) ((double) acc + a2);
+                        acc = (REAL) ((double) acc + a3);
+                        a0 = b0;
+                        a1 = b1;
+                        a2 = b2;
+                        a3 = b3;
+                    }
+                    if (n + 4 <= total) {
+                        acc = (REAL) ((double) acc + a0);
+                        acc = (REAL) ((double) acc + a1);
+                        acc = (REAL) ((double) acc + a2);
+                        acc = (REAL) ((double) acc + a3);
+                        n += 4;
+                    }
+                    for (; n < total; n++) acc = (REAL) ((double) acc + (double) src[n] * inweight);
+                }
+            }
+            __syncthreads();   // the loaders have the next stage in the other buffer (or its size 0)
+        }
+        if (mine) sRes[chCol][chK] = acc;
     }
-    __syncthreads();
-    if (chainThread) sRes[chCol][chK] = acc;
     __syncthreads();
     if (tid < COLS && p0 + tid < A.d.nPos) {
         const int64_t pp = p0 + tid;
