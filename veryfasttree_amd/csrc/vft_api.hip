@@ -32,6 +32,8 @@ struct vft_ctx {
     // vft_join_fused: joined nodes whose tile streams have not been rebuilt yet (their rows and stash slots are valid)
     std::vector<int64_t> staleIds;             // pair lists: the distinct stale nodes of the current list
     std::vector<uint32_t> staleMark;
+    std::vector<int32_t> staleIdx;
+    unsigned int *refDone = nullptr;           // k_pairs_refresh_fused: completion tags of the refresh workgroups
     uint32_t staleEpoch = 0;
     std::vector<int64_t> pend;
     char *pendBase = nullptr;        // [stash of 64 nodes | meta | commit scratch], commit_plan(c, 64)
@@ -46,6 +48,7 @@ struct vft_ctx {
     ColOff *colOff = nullptr;
     std::vector<int32_t> hParent;          // host copy of parent[], to recognise "all active nodes, ascending" lists
     unsigned long long *tileMask = nullptr;
+    bool noFusedRefresh = getenv("VFT_NO_FUSED_REFRESH") != nullptr;   // tools: A/B the single-launch pair lists
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -469,6 +472,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
     if (c->blen) hipFree(c->blen);
     if (c->opHist) hipFree(c->opHist);
+    if (c->refDone) hipFree(c->refDone);
     if (c->pendBase) hipFree(c->pendBase);
     if (c->pendIdsDev) hipFree(c->pendIdsDev);
     if (c->mlIs) hipFree(c->mlIs);
@@ -1003,6 +1007,7 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_fused<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_block<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_refresh_fused<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_refresh_list<REAL, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_refresh_list<REAL, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *) k_out_distances<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
@@ -1727,10 +1732,13 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
         uint32_t *mark = c->staleMark.data();
         // forced refreshes first (setOutDistance, NJ.tcc:1012-1015: recomputed unless the stamp IS n_active); the kernel
         // applies that rule to the first nForced entries of the list and the lazy one to the rest
+        if (c->staleIdx.size() != (size_t) c->d.maxNodes) c->staleIdx.assign((size_t) c->d.maxNodes, -1);
+        int32_t *sidx = c->staleIdx.data();   // position in the list, valid where mark == ep
         for (int64_t t = 0; t < nForce; t++) {
             const int64_t v = forceIds[t];
             if ((int64_t) c->hNOut[v] != nActive && mark[v] != ep) {
                 mark[v] = ep;
+                sidx[v] = (int32_t) stale.size();
                 stale.push_back(v);
             }
         }
@@ -1739,23 +1747,41 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
             const int64_t a = pi[t], b = pj[t];
             if ((int64_t) c->hNOut[a] - nActive > nDiffAllow && mark[a] != ep) {
                 mark[a] = ep;
+                sidx[a] = (int32_t) stale.size();
                 stale.push_back(a);
             }
             if ((int64_t) c->hNOut[b] - nActive > nDiffAllow && mark[b] != ep) {
                 mark[b] = ep;
+                sidx[b] = (int32_t) stale.size();
                 stale.push_back(b);
             }
         }
     }
     const int64_t nStale = (int64_t) stale.size();
     const size_t sB = (((size_t) nStale * 8) + 255) & ~(size_t) 255;
-    const bool small = 2 * idB + 3 * oB + sB <= VFT_SMALL_BYTES;
+    const size_t wB = (((size_t) n * 8) + 255) & ~(size_t) 255;   // per-pair wait indices of the single-launch variant
+    const bool small = 2 * idB + 3 * oB + sB + wB <= VFT_SMALL_BYTES;
+    bool fusedRefresh = small && nStale > 0 && n <= 2048 && n + nStale <= 4096 && !c->noFusedRefresh;
+    if (fusedRefresh && !c->refDone) {
+        HIPCHK(c, hipMalloc((void **) &c->refDone, 4096 * sizeof(unsigned int)));
+        HIPCHK(c, hipMemsetAsync(c->refDone, 0, 4096 * sizeof(unsigned int), c->stream));
+    }
     char *hBase = nullptr, *dBase = nullptr;
     if (small) {
-        if (int r = io_alloc(c, 2 * idB + 3 * oB + sB, &hBase, &dBase)) return r;
+        if (int r = io_alloc(c, 2 * idB + 3 * oB + sB + wB, &hBase, &dBase)) return r;
         memcpy(hBase, pi, (size_t) n * 8);
         memcpy(hBase + idB, pj, (size_t) n * 8);
         if (nStale) memcpy(hBase + 2 * idB + 3 * oB, stale.data(), (size_t) nStale * 8);
+        if (fusedRefresh) {   // which refresh workgroup each end of a pair has to wait for (-1: none)
+            int32_t *wt = (int32_t *) (hBase + 2 * idB + 3 * oB + sB);
+            const uint32_t ep = c->staleEpoch;
+            const uint32_t *mark = c->staleMark.data();
+            const int32_t *sidx = c->staleIdx.data();
+            for (int64_t t = 0; t < n; t++) {
+                wt[2 * t] = mark[pi[t]] == ep ? sidx[pi[t]] : -1;
+                wt[2 * t + 1] = mark[pj[t]] == ep ? sidx[pj[t]] : -1;
+            }
+        }
     } else {
         if (int r = ensure_scratch(c, 2 * idB + 3 * oB + sB + 64)) return r;
         dBase = (char *) c->scratch;
@@ -1776,7 +1802,13 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     // the mapped ring)
     const unsigned long long seq = small ? ++c->signalSeq : 0ull;
     if (nStale && nActive > c->maxStamp) c->maxStamp = nActive;   // refreshed nodes are stamped with nActive
-    if (n <= 2048) {   // short list: a workgroup per pair (all of them resident at once)
+    if (fusedRefresh) {   // short list that needs refreshes: one launch, pair workgroups wait on the stamps of flagged ends
+        const size_t lds = pw_lds_bytes(c) / c->pwWaves;
+        VFT_DISPATCH(c, (launch((k_pairs_refresh_fused<REAL, NC>), dim3((unsigned) (nStale + n)), dim3(VFT_WG), lds, c->stream,
+                                arena<REAL>(c), dStale, nStale, nForced, (const int64_t *) dI, (const int64_t *) dJ,
+                                (const int32_t *) (dBase + 2 * idB + 3 * oB + sB), n, sa, (REAL *) o, (REAL *) (o + oB),
+                                (REAL *) (o + 2 * oB), c->refDone, c->doneCtr, c->dFlag, seq)));
+    } else if (n <= 2048) {   // short list: a workgroup per pair (all of them resident at once)
         const size_t lds = pw_lds_bytes(c) / c->pwWaves;
         if (nStale)
             VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, true>), dim3((unsigned) nStale), dim3(VFT_WG), lds, c->stream,

@@ -934,6 +934,78 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     }
 }
 
+// A short pair list and the out-distance refreshes it needs in ONE launch (the join loop makes three such calls per join
+// and each is a host round trip: a second, dependent launch is ~8 us of a ~33 us call).  Workgroups [0, nStale) refresh
+// the listed nodes exactly like k_refresh_list (the host put the distinct stale / forced nodes there) and then publish
+// refDone[b] = seq, whether they recomputed or found the node fresh; workgroups [nStale, nStale + n) are k_pairs_fused's,
+// one pair each.  A pair's distance does not depend on out-distances, only its criterion does: the pair workgroup computes
+// the distance first and then - thread 0 - waits for the refresh workgroups of its two ends (wait[2 t], wait[2 t + 1]:
+// their positions in the refresh list, or -1).  Refresh workgroups have the lowest block ids, are dispatched first and
+// never wait, so the waiting ones always make progress; the host uses this kernel only while the whole grid fits the chip
+// a few times over (n + nStale <= 4096).
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, const int64_t *ids, int64_t nStale, int64_t nForced,
+                                                                const int64_t *pi, const int64_t *pj, const int32_t *wait, int64_t n,
+                                                                SweepArgs s, REAL *dist, REAL *weight, REAL *crit,
+                                                                unsigned int *refDone, unsigned int *doneCtr,
+                                                                unsigned long long *flag, unsigned long long seq) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    const int64_t b = blockIdx.x;
+    const unsigned int tag = (unsigned int) seq;
+    if (b < nStale) {
+        const int64_t v = ids[b];
+        const int64_t st = A.nOutActive[v];
+        const bool skip = b < nForced ? st == s.nActive : !(st - s.nActive > s.nDiffAllow);   // workgroup-uniform
+        if (!skip) {
+            REAL d, w;
+            vft_pair_block<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
+            if (threadIdx.x == 0) {
+                const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+                A.outDist[v] = od;
+                A.nOutActive[v] = (int32_t) s.nActive;
+                A.mOutDist[v] = od;
+                A.mNOut[v] = (int32_t) s.nActive;
+                __threadfence_system();   // the host-mapped mirrors must be out before any pair result that used them is
+            }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&refDone[b], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int64_t t = b - nStale;
+    if (t >= n) return;
+    const int64_t i = pi[t], j = pj[t];
+    REAL d, w;
+    vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, w);
+    if (threadIdx.x != 0) return;
+    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+        const REAL dd = A.diameter[i] + A.diameter[j];
+        d = d - dd;
+    }
+    dist[t] = d;
+    weight[t] = w;
+    const int32_t wi = wait[2 * t], wj = wait[2 * t + 1];
+    if (wi >= 0)
+        while (__hip_atomic_load(&refDone[wi], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+    if (wj >= 0)
+        while (__hip_atomic_load(&refDone[wj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+    // (out-distances of ends nobody refreshes in this launch were written by earlier launches)
+    const REAL oi = __hip_atomic_load(&A.outDist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const REAL oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t si = __hip_atomic_load(&A.nOutActive[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    crit[t] = vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
+    if (flag) {   // as in k_pairs_fused (the explicit s_waitcnt is not redundant, see there)
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(doneCtr, 1u) == (unsigned int) (n - 1)) {
+            *doneCtr = 0;
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // The cross product of two node lists (any mix of leaves and internal nodes): dist[a * nB + b] = the join distance of
 // (idsA[a], idsB[b]), i.e. profileDist / seqDist minus the two diameters (setDistCriterion without the criterion, which is
 // host arithmetic once the out-distances are current).  What a top-hits refresh recomputes (NJ.tcc:4477-4515:

@@ -1152,8 +1152,9 @@ namespace veryfasttree {
                 forced.erase(std::unique(forced.begin(), forced.end()), forced.end());
                 setDistCriterionBatch(nActive, todo, -1, &forced);
             }
+            drain();   /* (as in getBestFromTopHits: nothing these hits name is stale any more) */
             for (size_t t = 0; t < out.size(); t++)
-                if (!isTodo[t]) setCriterion(nActive, out[t]);
+                if (!isTodo[t]) criterionFresh(nActive, out[t]);
             return out;
         }
 
@@ -1167,6 +1168,21 @@ namespace veryfasttree {
             out.criterion = (REAL) 1e20;
             out.weight = -1;
             setCriterion(nActive, out);
+            return true;
+        }
+
+        /* getVisible when the out-distances of the node and its visible partner are known to be fresh enough
+           (prefetchVisible + drain done): host arithmetic only */
+        bool getVisibleFresh(int64_t nActive, int64_t node, Besthit &out) const {
+            if (node < 0 || parent[node] >= 0) return false;
+            const Hit &v = visible[node];
+            if (v.j < 0 || parent[v.j] >= 0) return false;
+            out.i = node;
+            out.j = v.j;
+            out.dist = v.dist;
+            out.criterion = (REAL) 1e20;
+            out.weight = -1;
+            criterionFresh(nActive, out);
             return true;
         }
 
@@ -1214,12 +1230,13 @@ namespace veryfasttree {
                 for (int64_t t = 0; t < count; t++)
                     if (list[t].i >= 0) nodes.push_back(list[t].j);
                 prefetchVisible(nActive, nodes);
+                drain();
             }
             for (int64_t t = 0; t < count; t++) {
                 const Besthit &hit = list[t];
                 if (hit.i < 0) continue;
                 Besthit vis;
-                const bool ok = getVisible(nActive, hit.j, vis);
+                const bool ok = getVisibleFresh(nActive, hit.j, vis);
                 if (!ok || hit.criterion < vis.criterion) {
                     Hit &v = visible[hit.j];
                     v.j = hit.i;
@@ -1772,9 +1789,10 @@ namespace veryfasttree {
                 }
             }
             setDistCriterionBatch(nActive, todo, -1, &forced);
+            drain();   /* every out-distance these hits name is fresh enough now: setCriterion is its arithmetic */
             for (size_t t = 0; t < cand.size(); t++) {
                 if (!ok[t]) continue;
-                setCriterion(nActive, cand[t]);
+                criterionFresh(nActive, cand[t]);
                 if (cand[t].criterion < best.criterion) best = cand[t];
             }
             return best;
@@ -1890,9 +1908,10 @@ namespace veryfasttree {
                 double bestCrit = 1e20;
                 Section sScan(this, "[host]   topHitNJSearch: top-visible scan (incl. device)");
                 prefetchVisible(nActive, topvisible);
+                drain();
                 for (int64_t node: topvisible) {
                     Besthit v;
-                    if (getVisible(nActive, node, v)) {
+                    if (getVisibleFresh(nActive, node, v)) {
                         nCand++;
                         if (bestNode < 0 || v.criterion < bestCrit) {
                             bestNode = node;
