@@ -101,12 +101,14 @@ def cpu_baseline(state, codes, ops, budget_s=8.0):
                        % (rates[cores][1], rates[1][1], len(leaf_ids), len(int_ids), cores))
 
 
-def dense_profile_roofline(ops, state, n, L, groups=32768):
+def dense_profile_roofline(ops, state, n, L, groups=None):
     """roofline of k_sweep_nt at vector density phi ~ 1 (SURVEY 8d asks for phi in {0, 0.25, 1}; the headline state has
     0.28): `groups` internal profiles that each average 8 unrelated leaves, built in the free id space above the
     benchmark state and swept alone (target range = those nodes).  Returns a dict or None when the ids do not fit."""
     base = ((state.maxnode + 63) // 64) * 64
-    if base + 7 * groups > ops.max_nodes:
+    if groups is None:   # as many as the free id space holds (a sweep needs >> 1024 tiles of 64 targets to fill 256 CUs)
+        groups = min(131072, ((ops.max_nodes - base) // 7) // 8192 * 8192)
+    if groups < 8192 or base + 7 * groups > ops.max_nodes or 8 * groups > n:
         return None
     rng = np.random.default_rng(99)
     leaves = rng.permutation(n)[:8 * groups].astype(np.int64)
