@@ -2183,12 +2183,14 @@ extern "C" int vft_posterior_chain_blen(vft_ctx *c, int32_t n, const int64_t *ou
     return VFT_OK;
 }
 
+static inline int mlopt_wg(const vft_ctx *c) { return c->d.nCodes == 20 ? MlOptWG<20>::value : MlOptWG<4>::value; }
+
 template <typename REAL, int NC>
 static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
                               double ftol, double atol) {
 #define VFT_MLOPT_CASE(CPT)                                                                                             \
     case CPT:                                                                                                           \
-        launch((k_ml_node_lengths<REAL, NC, CPT>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream, arena<REAL>(c), \
+        launch((k_ml_node_lengths<REAL, NC, CPT>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream, arena<REAL>(c), \
                dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);                  \
         break;
     switch (cpt == 2 ? 4 : cpt) {
@@ -2196,7 +2198,7 @@ static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dId
         VFT_MLOPT_CASE(4)
         default:
             if (NC == 4 && cpt == 8) {
-                launch((k_ml_node_lengths<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n), dim3(VFT_MLOPT_WG), 0, c->stream,
+                launch((k_ml_node_lengths<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream,
                        arena<REAL>(c), dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);
                 break;
             }
@@ -2230,7 +2232,7 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
     if (int r = ensure_ml_rows(c)) return r;
-    const int64_t per = cdiv(c->d.nPos, VFT_MLOPT_WG);
+    const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
     const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
     const size_t idB = (size_t) n * 8;
     if (7 * idB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: too many splits per call");
@@ -2253,7 +2255,7 @@ static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds
                              QuartetNNIResult *dNni, QuartetNNIState *dState = nullptr) {
 #define VFT_MLQ_CASE(CPT)                                                                                               \
     case CPT:                                                                                                           \
-        launch((k_ml_quartet<REAL, NC, CPT>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(VFT_MLOPT_WG), 0, c->stream,  \
+        launch((k_ml_quartet<REAL, NC, CPT>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlOptWG<NC>::value), 0, c->stream,  \
                arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, \
                dLoglk, dSite, dLen, dNni, dState, c->mlEvals);                                                           \
         break;
@@ -2289,7 +2291,7 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
-    const int64_t per = cdiv(c->d.nPos, VFT_MLOPT_WG);
+    const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
     const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
     const size_t idB = (size_t) n * 8, resB = (size_t) n * sizeof(QuartetNNIResult);
     static_assert(sizeof(QuartetNNIResult) == sizeof(vft_quartet_nni), "result record layout");
@@ -2343,7 +2345,7 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
     const int64_t nPos = c->d.nPos;
-    const int64_t per = cdiv(nPos, VFT_MLOPT_WG);
+    const int64_t per = cdiv(nPos, mlopt_wg(c));
     const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
     if (nBoot > 0 && (nPos > 65535 || (size_t) 3 * nPos * sizeof(double) > 60000)) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the SH resampling kernel");
     // chunks of splits: per split 3 x nPos site log-likelihoods

@@ -618,6 +618,13 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior_chain(Arena<REAL> A, co
 // launches on the stream.  Afterwards the node's own posterior from its two children and their new lengths
 // (recomputeProfile, NJ.tcc:3436-3473, useML) is written to its dense ML row.
 #define VFT_MLOPT_WG 256
+// Threads per workgroup of the two line-search kernels.  20-state alphabets: 512, so that alignments up to 512 columns
+// run with ONE column per thread - a thread keeps its columns of the three / four profiles in registers, 160 VGPRs per
+// column for proteins in double, and the four-columns-per-thread instance spills 2.8 KB per lane to scratch
+// (k_ml_quartet<double, 20, 4>: 1.2 ms per quartet round at 300 columns).  The column -> thread mapping is free to
+// change there: matrix models take their totals in column order (vft_lk_total_ordered).  Nucleotides keep 256: the
+// Jukes-Cantor totals are per-thread products summed in thread order, and that order is pinned by the fixtures.
+template <int NC> struct MlOptWG { static const int value = NC == 20 ? 512 : VFT_MLOPT_WG; };
 #define VFT_MLOPT_MAXLEN 6.0
 
 // Brent's minimiser with the reference's bracketing (onedimenmin): all threads run it in lockstep on uniform values;
@@ -712,17 +719,18 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
 }
 
 template <typename REAL, int NC, int CPT>
-__global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
+__global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
                                                                   const int64_t *recN, REAL *blen, double minLen,
                                                                   double minRel, double ftol, double atol,
                                                                   unsigned int *evalCount) {
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
-    __shared__ double red[VFT_MLOPT_WG / 64];
-    __shared__ double stage[CPT * VFT_MLOPT_WG];   // ordered total of matrix models (vft_lk_total_ordered)
-    __shared__ double stageLog[CPT * VFT_MLOPT_WG];
-    __shared__ double stageList[CPT * VFT_MLOPT_WG * 3 / 2];
-    __shared__ signed char stageEvents[CPT * VFT_MLOPT_WG / 2];
+    constexpr int WG = MlOptWG<NC>::value;
+    __shared__ double red[WG / 64];
+    __shared__ double stage[CPT * WG];   // ordered total of matrix models (vft_lk_total_ordered)
+    __shared__ double stageLog[CPT * WG];
+    __shared__ double stageList[CPT * WG * 3 / 2];
+    __shared__ signed char stageEvents[CPT * WG / 2];
     __shared__ LkOrderedShared ordSh;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
     int rc[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
         rc[c] = p < nPos ? A.ratecat[p] : 0;
     }
     // tables of the two branch lengths of a posterior, into LDS (the caller synchronises)
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
         if (l1 < minLen) l1 = minLen;   // NJ.tcc:2150-2155
         if (l2 < minLen) l2 = minLen;
         if (jc) {
-            for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) {
+            for (int r = threadIdx.x; r < A.nRates; r += WG) {
                 vft_psame_pdiff(l1, (double) A.rates[r], pS1[r], pD1[r]);
                 vft_psame_pdiff(l2, (double) A.rates[r], pS2[r], pD2[r]);
             }
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
         Col<REAL, NC> pA[CPT], pB[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
             if (p < nPos) {
                 Col<REAL, NC> c1, c2;
                 vft_load_col_ml<REAL, NC>(A, n1, p, c1);
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
         __syncthreads();
         auto negLogLk = [&](double x) -> double {
             if (jc) {
-                for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r]);
+                for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r]);
             } else {
                 vft_exp_eigen_rates<REAL, NC>(A, x, minRel, ee1);
             }
@@ -784,7 +792,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
                 double col[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; c++) {
-                    const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+                    const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
                     col[c] = VFT_LK_SKIP;
                     if (p < nPos) {
                         const int r = rc[c];
@@ -793,12 +801,12 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
                     }
                 }
                 nEval++;
-                return -vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
+                return -vft_lk_total_ordered<WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
             }
             double lk = 1.0, loglk = 0.0;
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
-                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
                 if (p < nPos) {
                     const int r = rc[c];
                     double lkAB;
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
             __syncthreads();
             double tot = 0;
 #pragma unroll
-            for (int w = 0; w < VFT_MLOPT_WG / 64; w++) tot += red[w];
+            for (int w = 0; w < WG / 64; w++) tot += red[w];
             nEval++;
             return -tot;
         };
@@ -831,7 +839,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_node_lengths(Arena<REAL> A,
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
         if (p < nPos) {
             Col<REAL, NC> c1, c2;
             vft_load_col_ml<REAL, NC>(A, ids[3 * k], p, c1);
@@ -877,18 +885,19 @@ struct QuartetNNIState {
 };
 
 template <typename REAL, int NC, int CPT>
-__global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
+__global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
                                                              double minLen, double minRel, double ftol, double atol,
                                                              double closeLimit, int mlAccuracy, int mode, double *loglkOut,
                                                              double *siteOut, double *lenOut, QuartetNNIResult *nniOut,
                                                              QuartetNNIState *nniState, unsigned int *evalCount) {
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
-    __shared__ double red[VFT_MLOPT_WG / 64];
-    __shared__ double stage[CPT * VFT_MLOPT_WG];   // ordered total of matrix models (vft_lk_total_ordered)
-    __shared__ double stageLog[CPT * VFT_MLOPT_WG];
-    __shared__ double stageList[CPT * VFT_MLOPT_WG * 3 / 2];
-    __shared__ signed char stageEvents[CPT * VFT_MLOPT_WG / 2];
+    constexpr int WG = MlOptWG<NC>::value;
+    __shared__ double red[WG / 64];
+    __shared__ double stage[CPT * WG];   // ordered total of matrix models (vft_lk_total_ordered)
+    __shared__ double stageLog[CPT * WG];
+    __shared__ double stageList[CPT * WG * 3 / 2];
+    __shared__ signed char stageEvents[CPT * WG / 2];
     __shared__ LkOrderedShared ordSh;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     int rc[CPT];   // rate category of the thread's columns; -1 beyond the alignment (such columns hold no data at all)
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
         rc[c] = p < nPos ? A.ratecat[p] : -1;
     }
     unsigned int nEval = 0;
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
     auto table = [&](int s, double len, bool clamp) {
         if (clamp && len < minLen) len = minLen;
         if (jc) {
-            for (int r = threadIdx.x; r < A.nRates; r += VFT_MLOPT_WG) vft_psame_pdiff(len, (double) A.rates[r], pS[s][r], pD[s][r]);
+            for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(len, (double) A.rates[r], pS[s][r], pD[s][r]);
         } else {
             vft_exp_eigen_rates<REAL, NC>(A, len, minRel, ee[s]);
         }
@@ -926,7 +935,7 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
             double col[CPT];
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
-                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
                 col[c] = VFT_LK_SKIP;
                 if (p < nPos) {
                     const int r = rc[c];
@@ -938,12 +947,12 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
                 }
             }
             nEval++;
-            return vft_lk_total_ordered<VFT_MLOPT_WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
+            return vft_lk_total_ordered<WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
         }
         double lk = 1.0, loglk = 0.0;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
             if (p < nPos) {
                 const int r = rc[c];
                 double lkAB;
@@ -960,21 +969,21 @@ __global__ __launch_bounds__(VFT_MLOPT_WG) void k_ml_quartet(Arena<REAL> A, cons
         __syncthreads();
         double tot = 0;
 #pragma unroll
-        for (int w = 0; w < VFT_MLOPT_WG / 64; w++) tot += red[w];
+        for (int w = 0; w < WG / 64; w++) tot += red[w];
         nEval++;
         return tot;
     };
     auto loadCols = [&](int64_t node, Col<REAL, NC> *dst) {
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
             if (p < nPos) vft_load_col_ml<REAL, NC>(A, node, p, dst[c]);
         }
     };
     auto storeSite = [&](int topo, const double *site) {
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * VFT_MLOPT_WG;
+            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
             if (p < nPos)   // SHSupport takes the logs, NJ.tcc:1134-1137 (glibc's log where the totals are the reference's)
                 siteOut[(k * 3 + topo) * nPos + p] = (!jc && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
         }
