@@ -257,12 +257,17 @@ MLNNI_CASES = [
     ("full_nt_250_double", ["-nt", "-double-precision"], 250, 150, 0.10, 0.04, 54),
     ("full_nt_200_gtr", ["-nt", "-gtr"], 200, 120, 0.05, 0.02, 21),                 # BASELINE C2's model: GTR + CAT
     ("full_nt_250_double_gtr", ["-nt", "-gtr", "-double-precision"], 250, 150, 0.10, 0.04, 54),
+    # 16S-like length: more than 1024 columns (eight columns per thread in the quartet kernels)
+    ("full_nt_40_x1500", ["-nt"], 40, 1500, 0.05, 0.02, 71),
+    ("full_nt_30_x1300_gtr_double", ["-nt", "-gtr", "-double-precision"], 30, 1300, 0.06, 0.02, 72),
 ]
 
 
-def gen_mlnni(tmp):
+def gen_mlnni(tmp, only=None):
     """Black box: TreeLogLk after every ML NNI round and after the final length pass, NNI counts, final trees."""
     for name, flags, n, L, mu, gap, seed in MLNNI_CASES:
+        if only and name not in only:
+            continue
         codes = synth.random_descent_codes(n, L, 4, mu, gap, seed)
         fa = os.path.join(tmp, name + ".fa")
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
@@ -380,6 +385,8 @@ def main():
             gen_menni(tmp)
         if "mlnni" in which:
             gen_mlnni(tmp)
+        if any(w.startswith("mlnni:") for w in which):
+            gen_mlnni(tmp, [w[6:] for w in which if w.startswith("mlnni:")])
         if "aa" in which:
             gen_aa(tmp)
         if "c3" in which:   # not part of the default set: ~11 minutes

@@ -40,7 +40,8 @@ def test_min_evolution_nnis_match_the_reference_run(name, dt, spr):
                                                  ("mlnni_nt_300_spr0", np.float32, 20, True, 0),
                                                  ("full_nt_200", np.float32, 20, True, 2),
                                                  ("full_nt_300", np.float32, 20, True, 2),
-                                                 ("full_nt_250_double", np.float64, 20, True, 2)])
+                                                 ("full_nt_250_double", np.float64, 20, True, 2),
+                                                 ("full_nt_40_x1500", np.float32, 20, True, 2)])   # > 1024 columns: 8 per thread
 def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me, spr):
     """`VeryFastTree -nt [-nome | -spr 0] [-nocat] [-nosupport]` and plain `VeryFastTree -nt` (full_*: the complete
     default pipeline - NJ, ME NNIs + SPRs, ML NNIs, CAT rates, SH-like supports): ML NNI rounds (DoNNI with MLQuartetNNI per node on the
@@ -76,7 +77,8 @@ def test_max_likelihood_nnis_match_the_reference_run(name, dt, ncat, me, spr):
 
 
 @pytest.mark.parametrize("name,dt,full", [("ml_nt_200_gtr", np.float32, False), ("ml_nt_150_double_gtr", np.float64, False),
-                                          ("full_nt_200_gtr", np.float32, True), ("full_nt_250_double_gtr", np.float64, True)])
+                                          ("full_nt_200_gtr", np.float32, True), ("full_nt_250_double_gtr", np.float64, True),
+                                          ("full_nt_30_x1300_gtr_double", np.float64, True)])   # > 1024 columns
 def test_gtr_model_fitted_like_the_reference(name, dt, full):
     """`-gtr`: Jukes-Cantor for the first ML round, then setMLGtr (NJ.tcc:6436-6500) fits base frequencies and the six
     rates by line searches over the whole tree's likelihood and the run continues under GTR + CAT (BASELINE config C2's

@@ -2263,6 +2263,12 @@ static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds
         VFT_MLQ_CASE(1)
         VFT_MLQ_CASE(4)
         default:
+            if (NC == 4 && cpt == 8) {   // nucleotides up to 2048 columns (16S-length alignments); proteins: 4 x 512
+                launch((k_ml_quartet<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlOptWG<NC>::value), 0,
+                       c->stream, arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy,
+                       mode, dLoglk, dSite, dLen, dNni, dState, c->mlEvals);
+                break;
+            }
             return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");
     }
 #undef VFT_MLQ_CASE
@@ -2292,7 +2298,7 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
     const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
-    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
+    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
     const size_t idB = (size_t) n * 8, resB = (size_t) n * sizeof(QuartetNNIResult);
     static_assert(sizeof(QuartetNNIResult) == sizeof(vft_quartet_nni), "result record layout");
     const size_t stB = ((size_t) n * sizeof(QuartetNNIState) + 255) & ~(size_t) 255;
@@ -2346,7 +2352,7 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
     }
     const int64_t nPos = c->d.nPos;
     const int64_t per = cdiv(nPos, mlopt_wg(c));
-    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 0;
+    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
     if (nBoot > 0 && (nPos > 65535 || (size_t) 3 * nPos * sizeof(double) > 60000)) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the SH resampling kernel");
     // chunks of splits: per split 3 x nPos site log-likelihoods
     int64_t chunk = (int64_t) ((512u << 20) / ((size_t) 3 * nPos * sizeof(double)));

@@ -1340,11 +1340,13 @@ static __global__ __launch_bounds__(256) void k_sh_support(const double *siteLog
 #define VFT_ML_QUARTET_INSTANCES_F32(PFX)                 \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 1)             \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 4)             \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 8)             \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 1)            \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4)
 #define VFT_ML_QUARTET_INSTANCES_F64(PFX)                 \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 1)            \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 4)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 8)            \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 1)           \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4)
 #define VFT_ML_HEAVY_INSTANCES(PFX)        \
