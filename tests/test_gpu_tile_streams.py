@@ -352,3 +352,55 @@ def test_out_profile_chain_kernel_equals_the_column_walk(ncodes, matrix):
                 assert all(np.array_equal(x, y) for x, y in zip(got[0], ref[0])), (k, dt)
                 assert got[1] is None or np.array_equal(got[1], ref[1])
         ops.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_pair_list_with_refreshes_in_one_call(fused, monkeypatch):
+    """vft_pair_distances_refresh (forced + lazy out-distance refreshes travelling with the pair list; with `fused` the
+    single-launch kernel whose pair workgroups wait for the refresh workgroups, otherwise two launches) against the
+    separate calls on a second context: vft_out_distances(forced ids), then vft_pair_distances - distances, criteria and
+    every out-distance / stamp afterwards, bit for bit; leaves and internal nodes, nodes named many times, a forced node
+    that is also a pair end, a forced node whose stamp is already current."""
+    from veryfasttree_amd import HipProfileOps, synth
+    if not fused:
+        monkeypatch.setenv("VFT_NO_FUSED_REFRESH", "1")
+    n, L, nj = 400, 190, 200
+    codes = synth.random_descent_codes(n, L, 4, 0.05, 0.05, seed=31)
+    for dt in (np.float32, np.float64):
+        ctxs = []
+        for _ in range(2):
+            rng = np.random.default_rng(12)       # the same draws for both contexts
+            ops = HipProfileOps(n, L, 4, dt, max_nodes=2 * n)
+            ops.upload_leaves(codes)
+            ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
+            ops.outProfile(np.arange(n))
+            active = list(range(n))
+            order = np.random.default_rng(6)
+            for k in range(nj):
+                i, j = (int(x) for x in order.choice(len(active), 2, replace=False))
+                i, j = active[i], active[j]
+                ops.join_fused(i, j, n + k, 0.02 * (k % 5), 10 * n, len(active), True)
+                active = [v for v in active if v != i and v != j] + [n + k]
+            nact = len(active)
+            stamps = np.full(n + nj, nact, np.int64)
+            stale = rng.choice(active, 60, replace=False)
+            stamps[stale] = nact + 50             # staler than allowed
+            stamps[active[3]] = nact + 2          # fresh enough for the lazy rule, not for a forced refresh
+            ops.set_out_distances(0, np.random.default_rng(2).uniform(0, 30, n + nj).astype(dt), stamps)
+            ctxs.append((ops, active, nact, stale))
+        (o1, active, nact, stale), (o2, _, _, _) = ctxs
+        rng = np.random.default_rng(13)
+        hub = active[-1]                           # the newest node against many partners, as after a join
+        partners = np.array([v for v in rng.choice(active, 150, replace=False) if v != hub], np.int64)
+        pi = np.concatenate([np.full(len(partners), hub, np.int64), rng.choice(active, 40)])
+        pj = np.concatenate([partners, rng.choice(active, 40)])
+        keep = pi != pj
+        pi, pj = pi[keep], pj[keep]
+        forced = np.array([hub, active[3], active[5], int(stale[0])], np.int64)   # active[5]: stamp already current
+        d1, w1, c1 = o1.setDistCriterionRefresh(pi, pj, forced, nact, 5, 2.5)
+        o2.setOutDistance(forced, nact, 2.5)
+        d2, w2, c2 = o2.setDistCriterion(pi, pj, nact, 5, 2.5)
+        assert np.array_equal(d1, d2) and np.array_equal(w1, w2) and np.array_equal(c1, c2)
+        assert all(np.array_equal(x, y) for x, y in zip(o1.get_out_distances(0, n + nj), o2.get_out_distances(0, n + nj)))
+        o1.close()
+        o2.close()

@@ -531,6 +531,15 @@ class HipProfileOps:
                                               C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
         return d, w, c
 
+    def setDistCriterionRefresh(self, i, j, force_ids, n_active, n_diff_allow, totdiam):
+        """vft_pair_distances_refresh: the pair list plus nodes whose out-distance is recomputed first unless it carries
+        the stamp n_active (setOutDistance).  (dist, weight, criterion)."""
+        i, j, f = _i64(i), _i64(j), _i64(force_ids)
+        d, w, c = (np.zeros(len(i), self.dt) for _ in range(3))
+        self._chk(self.lib.vft_pair_distances_refresh(self.ctx, I64(len(i)), _ptr(i), _ptr(j), I64(len(f)), _ptr(f), I64(n_active),
+                                                      I64(n_diff_allow), C.c_double(totdiam), _ptr(d), _ptr(w), _ptr(c)))
+        return d, w, c
+
     def leafBlockDistances(self, a, b, n_active, n_diff_allow, totdiam):
         """setDistCriterion for the cross product of two leaf lists (vft_leaf_block_distances): three [len(a), len(b)]
         arrays (dist, weight, criterion)."""
