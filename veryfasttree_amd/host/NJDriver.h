@@ -672,8 +672,9 @@ namespace veryfasttree {
             REAL weight = 0, dist = (REAL) 1e20, criterion = (REAL) 1e20;
             int32_t src = -1;   /* top-hits refresh: column of the distance block this record's distance comes from */
         };
-        struct Hit {
-            int64_t j;
+        struct Hit {        /* one entry of a top-hits list: 8 bytes in float precision (node ids are below 2^31) - the lists of a
+                               million-sequence run are 10^9 entries and several host loops stream them */
+            int32_t j;
             REAL dist;
         };
         typedef typename std::conditional<sizeof(REAL) == 4, vft_hit_f32, vft_hit_f64>::type DevHit;
@@ -1023,7 +1024,7 @@ namespace veryfasttree {
             hitSource.assign(maxnodes, -1);
             hits.assign(maxnodes, std::vector<Hit>());
             age.assign(maxnodes, 0);
-            visible.assign(maxnodes, Hit{-1, (REAL) 1e20});
+            visible.assign(maxnodes, Hit{(int32_t) -1, (REAL) 1e20});
             topvisible.assign((size_t) (0.5 + opt.topvisibleMult * m), -1);
             topvisibleAge = 0;
         }
@@ -1059,7 +1060,7 @@ namespace veryfasttree {
             for (int64_t t = 0; t < nIn && (int64_t) l.size() < nSave; t++) {
                 const int64_t j = bh[t].j;
                 if (j != node && j != jLast && j >= 0) {
-                    l.push_back(Hit{j, bh[t].dist});
+                    l.push_back(Hit{(int32_t) j, bh[t].dist});
                     jLast = j;
                 }
             }
