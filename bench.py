@@ -318,7 +318,7 @@ def main():
                             seeds_per_step=len(seeds), top_k=k, sharding="target-range x%d" % world,
                             setup_s=round(setup_s, 1)),
                 roofline=roofline)
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the other ranks would wait for it)
         line["cpu_baseline"] = cpu_baseline(state, codes, ops)
     elif rank == 0:
         line["cpu_baseline"] = None
