@@ -695,6 +695,9 @@ namespace veryfasttree {
         std::vector<Hit> visible;
         std::vector<int64_t> inTopScratch;   /* resetTopVisible: all -1 between calls */
         std::vector<uint8_t> seenScratch;    /* resetTopVisible: all 0 between calls */
+        std::vector<int64_t> gbForced, gbJ;   /* getBestFromTopHits: scratch that keeps its capacity */
+        std::vector<Besthit> gbTodo;
+        std::vector<Besthit *> gbTodoPtr;
         bool leafBlocks = true;              /* setAllLeafTopHits: vft_leaf_block_distances applies (nucleotides, no matrix) */
 
         void chk(int rc) {
@@ -1769,32 +1772,63 @@ namespace veryfasttree {
 
         Besthit getBestFromTopHits(int64_t node, int64_t nActive) { /* NJ.tcc:4267-4298 */
             /* setOutDistance(node) (unless -fastest), the recomputed distances of re-targeted hits and the lazy refreshes
-               of setCriterion on every hit all belong to the same window: one device call, one wait */
+               of setCriterion on every hit all belong to the same window: one device call, one wait.  The list (1 000 hits
+               at a million sequences, twice per join) is walked in place: records are built only for the hits whose
+               partner was joined since and needs a new distance. */
             drain();
-            std::vector<int64_t> forced;
+            std::vector<int64_t> &forced = gbForced;
+            forced.clear();
             if (!opt.fastest && mN[node] != nActive) forced.push_back(node);
+            const std::vector<Hit> &l = hits[(size_t) node];
+            const size_t n = l.size();
+            const int64_t iA = activeAncestor(node), allow = nDiffAllow(nActive);
+            gbJ.resize(n);
+            gbTodo.clear();
+            const size_t first = forced.size();
+            for (size_t t = 0; t < n; t++) {   /* updateBestHit(hit, true, todo), NJ.tcc:1626-1648 */
+                const int64_t j = activeAncestor(l[t].j);
+                if (iA < 0 || j < 0 || iA == j) {
+                    gbJ[t] = -1;
+                    continue;
+                }
+                gbJ[t] = j;
+                if (iA != node || j != l[t].j) {
+                    Besthit h;
+                    h.i = iA;
+                    h.j = j;
+                    h.dist = l[t].dist;
+                    h.weight = -1;
+                    h.src = (int32_t) t;
+                    gbTodo.push_back(h);
+                }
+                staleCandidates(nActive, allow, iA, j, forced);
+            }
+            if (forced.size() > first + 1) {
+                std::sort(forced.begin() + first, forced.end());
+                forced.erase(std::unique(forced.begin() + first, forced.end()), forced.end());
+            }
+            gbTodoPtr.clear();
+            for (Besthit &h: gbTodo) gbTodoPtr.push_back(&h);
+            setDistCriterionBatch(nActive, gbTodoPtr, -1, &forced);
+            drain();   /* every out-distance these hits name is fresh enough now: setCriterion is its arithmetic */
             Besthit best;
             best.i = best.j = -1;
-            std::vector<Besthit> cand = hitsToBestHits(hits[node], node);
-            std::vector<uint8_t> ok(cand.size(), 0);
-            std::vector<Besthit *> todo;
-            for (size_t t = 0; t < cand.size(); t++) ok[t] = updateBestHit(cand[t], true, &todo) ? 1 : 0;
-            {
-                const int64_t allow = nDiffAllow(nActive);
-                const size_t first = forced.size();
-                for (size_t t = 0; t < cand.size(); t++)
-                    if (ok[t]) staleCandidates(nActive, allow, cand[t].i, cand[t].j, forced);
-                if (forced.size() > first + 1) {
-                    std::sort(forced.begin() + first, forced.end());
-                    forced.erase(std::unique(forced.begin() + first, forced.end()), forced.end());
+            size_t u = 0;
+            for (size_t t = 0; t < n; t++) {
+                if (gbJ[t] < 0) continue;
+                Besthit h;
+                if (u < gbTodo.size() && gbTodo[u].src == (int32_t) t) {
+                    h = gbTodo[u++];
+                    h.src = -1;
+                } else {
+                    h.i = iA;
+                    h.j = gbJ[t];
+                    h.dist = l[t].dist;
+                    h.weight = -1;
                 }
-            }
-            setDistCriterionBatch(nActive, todo, -1, &forced);
-            drain();   /* every out-distance these hits name is fresh enough now: setCriterion is its arithmetic */
-            for (size_t t = 0; t < cand.size(); t++) {
-                if (!ok[t]) continue;
-                criterionFresh(nActive, cand[t]);
-                if (cand[t].criterion < best.criterion) best = cand[t];
+                h.criterion = (REAL) 1e20;
+                criterionFresh(nActive, h);
+                if (h.criterion < best.criterion) best = h;
             }
             return best;
         }
