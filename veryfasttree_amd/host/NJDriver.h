@@ -696,6 +696,7 @@ namespace veryfasttree {
         std::vector<int64_t> inTopScratch;   /* resetTopVisible: all -1 between calls */
         std::vector<uint8_t> seenScratch;    /* resetTopVisible: all 0 between calls */
         std::vector<int64_t> gbForced, gbJ;   /* getBestFromTopHits: scratch that keeps its capacity */
+        std::vector<int32_t> ujScratch, ujTmp;
         std::vector<Besthit> gbTodo;
         std::vector<Besthit *> gbTodoPtr;
         bool leafBlocks = true;              /* setAllLeafTopHits: vft_leaf_block_distances applies (nucleotides, no matrix) */
@@ -1159,6 +1160,50 @@ namespace veryfasttree {
             drain();   /* (as in getBestFromTopHits: nothing these hits name is stale any more) */
             for (size_t t = 0; t < out.size(); t++)
                 if (!isTodo[t]) criterionFresh(nActive, out[t]);
+            return out;
+        }
+
+        /* uniqueBestHits(combined lists of the two children of a fresh join), NJ.tcc:4325-4330 + 4786-4833.  Every record
+           of the children's lists changes its first node (c0 / c1 -> newnode), so updateBestHit invalidates every distance:
+           what is left after the sort by (i, j) and the removal of duplicates is the ascending list of the distinct active
+           ancestors of the partners, all of them to be measured against the new node - built here from the ids alone. */
+        std::vector<Besthit> uniqueOfJoin(int64_t nActive, int64_t newnode, int64_t c0, int64_t c1) {
+            std::vector<int32_t> &js = ujScratch;
+            js.clear();
+            for (int side = 0; side < 2; side++)
+                for (const Hit &h: hits[(size_t) (side ? c1 : c0)]) {
+                    const int64_t j = activeAncestor(h.j);
+                    if (j >= 0 && j != newnode) js.push_back((int32_t) j);
+                }
+            {   /* ascending ids: LSD radix sort over the bytes that differ (std::sort costs more than the rest of this function) */
+                uint32_t orAll = 0, andAll = ~0u;
+                for (int32_t v: js) {
+                    orAll |= (uint32_t) v;
+                    andAll &= (uint32_t) v;
+                }
+                std::vector<int32_t> &tmp = ujTmp;
+                tmp.resize(js.size());
+                for (int b = 0; b < 4; b++) {
+                    if ((((orAll ^ andAll) >> (8 * b)) & 0xFFu) == 0) continue;
+                    uint32_t count[257] = {0};
+                    for (int32_t v: js) count[(((uint32_t) v >> (8 * b)) & 0xFFu) + 1]++;
+                    for (int c = 0; c < 256; c++) count[c + 1] += count[c];
+                    for (int32_t v: js) tmp[count[((uint32_t) v >> (8 * b)) & 0xFFu]++] = v;
+                    js.swap(tmp);
+                }
+            }
+            js.erase(std::unique(js.begin(), js.end()), js.end());
+            std::vector<Besthit> out(js.size());
+            std::vector<Besthit *> todo(js.size());
+            for (size_t t = 0; t < js.size(); t++) {
+                out[t].i = newnode;
+                out[t].j = js[t];
+                out[t].dist = (REAL) -1e20;
+                out[t].weight = -1;
+                out[t].criterion = (REAL) 1e20;
+                todo[t] = &out[t];
+            }
+            setDistCriterionBatch(nActive, todo);
             return out;
         }
 
@@ -2007,13 +2052,10 @@ namespace veryfasttree {
         void topHitJoin(int64_t newnode, int64_t nActive) { /* NJ.tcc:4306-4533, first-level lists */
             Section sec(this, "[host] topHitJoin (incl. device)");
             const int64_t c0 = child0[newnode], c1 = child1[newnode];
-            std::vector<Besthit> combined = hitsToBestHits(hits[c0], c0);
-            std::vector<Besthit> fromC1 = hitsToBestHits(hits[c1], c1);
-            combined.insert(combined.end(), fromC1.begin(), fromC1.end());
             std::vector<Besthit> unique;
             {
                 Section s2(this, "[host]   topHitJoin: uniqueBestHits (incl. device)");
-                unique = uniqueBestHits(nActive, combined);
+                unique = uniqueOfJoin(nActive, newnode, c0, c1);
             }
             const int64_t nUnique = (int64_t) unique.size();
             hits[c0].clear();
