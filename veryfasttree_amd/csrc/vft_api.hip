@@ -14,6 +14,8 @@
 #include <chrono>
 
 #include "../../include/vft_hip.h"
+#define VFT_PAIR_STAGE_CAP 2048   // = the longest list the workgroup-per-pair kernels take
+#define VFT_SMALL_BYTES_ (256u << 10)   // = VFT_SMALL_BYTES below: what goes through the host-mapped ring
 #include "vft_kernels_ml.h"
 
 VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
@@ -49,6 +51,7 @@ struct vft_ctx {
     std::vector<int32_t> hParent;          // host copy of parent[], to recognise "all active nodes, ascending" lists
     unsigned long long *tileMask = nullptr;
     bool noFusedRefresh = getenv("VFT_NO_FUSED_REFRESH") != nullptr;   // tools: A/B the single-launch pair lists
+    int pairWG = getenv("VFT_PAIR_WG") ? atoi(getenv("VFT_PAIR_WG")) : 0;   // tools: threads per pair of the short-list kernels
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -112,6 +115,9 @@ struct vft_ctx {
     size_t ioCap = 8u << 20, ioHead = 0;
     unsigned long long *hFlag = nullptr, *dFlag = nullptr, signalSeq = 0;
     unsigned int *doneCtr = nullptr;   // completion counter of k_pairs_fused
+    void *pairIn = nullptr;            // device copy of the ids of a short pair list (k_copy16x2)
+    bool noPairStaging = getenv("VFT_NO_PAIR_STAGING") != nullptr;   // tools: A/B
+    void *pairStage = nullptr;         // device staging of the results of lists of up to VFT_PAIR_STAGE_CAP pairs
     // Upper bound of nOutActive over the nodes of the shard (host bookkeeping; VFT_STAMP_UNKNOWN = no bound): lets
     // vft_sweep skip its lazy out-distance pre-pass when provably no target can be stale.
     int64_t maxStamp = (int64_t) 1 << 62;
@@ -433,8 +439,10 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipHostMalloc((void **) &c->hFlag, 64, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dFlag, c->hFlag, 0));
     *c->hFlag = 0;
-    CR(dalloc(&c->doneCtr, 1));
-    CR(hipMemset(c->doneCtr, 0, 4));
+    CR(dalloc(&c->doneCtr, 65));   // [0]: top level / single-level users, [1..64]: slots of vft_publish_staged
+    CR(hipMalloc(&c->pairStage, 3 * VFT_PAIR_STAGE_CAP * sizeof(double)));   // staging of short pair lists' results (vft_publish_staged)
+    CR(hipMalloc(&c->pairIn, VFT_SMALL_BYTES_));   // device copy of a short list's inputs
+    CR(hipMemset(c->doneCtr, 0, 65 * 4));
     CR(hipHostMalloc((void **) &c->hIO, c->ioCap, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dIO, c->hIO, 0));
     CR(hipHostMalloc(&c->hOutDist, (size_t) N * rs, hipHostMallocMapped));
@@ -502,6 +510,8 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hIO) hipHostFree(c->hIO);
     if (c->hFlag) hipHostFree(c->hFlag);
     if (c->doneCtr) hipFree(c->doneCtr);
+    if (c->pairStage) hipFree(c->pairStage);
+    if (c->pairIn) hipFree(c->pairIn);
     if (c->hOutDist) hipHostFree(c->hOutDist);
     if (c->hNOut) hipHostFree(c->hNOut);
     for (hipEvent_t e : c->kev) hipEventDestroy(e);
@@ -1688,6 +1698,13 @@ extern "C" int vft_sweep_results(vft_ctx *c, int64_t first, int64_t count, void 
     return VFT_OK;
 }
 
+// two ranges of 16-byte pieces in one launch (host-mapped memory -> device memory)
+static __global__ void k_copy16x2(uint4 *dstA, const uint4 *srcA, int64_t nA, uint4 *dstB, const uint4 *srcB, int64_t nB) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nA) dstA[t] = srcA[t];
+    else if (t < nA + nB) dstB[t - nA] = srcB[t - nA];
+}
+
 static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive, int64_t nDiffAllow,
                           double totdiam, void *dist, void *weight, void *crit, bool raw, int64_t nForce, const int64_t *forceIds);
 extern "C" int vft_pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_t *pj, int64_t nActive,
@@ -1708,6 +1725,11 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
                           double totdiam, void *dist, void *weight, void *crit, bool raw, int64_t nForce, const int64_t *forceIds) {
     if (!c || n < 0 || !pi || !pj) return VFT_ERR_INVALID;
     if (n == 0) return VFT_OK;
+    static const bool smallTimes = getenv("VFT_API_PROFILE") != nullptr;   // tools only: where a short list's time goes
+    static double tsPrep = 0, tsLaunch = 0, tsWait = 0, tsOut = 0;
+    static int64_t tsCalls = 0, tsPairs = 0;
+    std::chrono::steady_clock::time_point ts0, ts1, ts2, ts3;
+    if (smallTimes) ts0 = std::chrono::steady_clock::now();
     for (int64_t t = 0; t < nForce; t++)
         if (forceIds[t] < 0 || forceIds[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "forced node %lld out of range", (long long) t);
     if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_pair_distances before vft_upload_leaves");
@@ -1790,9 +1812,24 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
         if (nStale)
             HIPCHK(c, hipMemcpyAsync(dBase + 2 * idB + 3 * oB, stale.data(), (size_t) nStale * 8, hipMemcpyHostToDevice, c->stream));
     }
+    if (smallTimes) ts1 = std::chrono::steady_clock::now();
     int64_t *dI = (int64_t *) dBase, *dJ = (int64_t *) (dBase + idB);
     const int64_t *dStale = (const int64_t *) (dBase + 2 * idB + 3 * oB);
+    const int32_t *dWait = (const int32_t *) (dBase + 2 * idB + 3 * oB + sB);
     char *o = dBase + 2 * idB;
+    if (small && n >= 128 && !c->noPairStaging) {
+        // One workgroup per pair reading ITS ids from the host-mapped ring is two 8-byte PCIe reads per pair - 4 000 tiny
+        // non-posted reads at 2 000 pairs, ~35 ns per pair of a call that otherwise takes ~25 us.  A copy kernel fetches the
+        // inputs with 16-byte-per-lane loads first; the pair kernels then read device memory.
+        char *in = (char *) c->pairIn;
+        const size_t nA = 2 * idB / 16, nB = (sB + wB) / 16;
+        launch(k_copy16x2, dim3(cdiv((int64_t) (nA + nB), 256)), dim3(256), 0, c->stream, (uint4 *) in, (const uint4 *) dBase, (int64_t) nA,
+               (uint4 *) (in + 2 * idB), (const uint4 *) (dBase + 2 * idB + 3 * oB), (int64_t) nB);
+        dI = (int64_t *) in;
+        dJ = (int64_t *) (in + idB);
+        dStale = (const int64_t *) (in + 2 * idB);
+        dWait = (const int32_t *) (in + 2 * idB + sB);
+    }
     SweepArgs sa{};
     sa.nActive = nActive;
     sa.nDiffAllow = nDiffAllow;
@@ -1802,36 +1839,54 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     // the mapped ring)
     const unsigned long long seq = small ? ++c->signalSeq : 0ull;
     if (nStale && nActive > c->maxStamp) c->maxStamp = nActive;   // refreshed nodes are stamped with nActive
+    // threads per pair of the workgroup-per-pair kernels: one column per thread for short lists (lowest latency); from 1024
+    // pairs on the list fills the chip and half the wavefronts per pair finish sooner
+    const unsigned pairThreads = c->pairWG > 0 ? (unsigned) c->pairWG : (n > 1024 && c->d.nPos <= 1024 ? 128u : (unsigned) VFT_WG);
     if (fusedRefresh) {   // short list that needs refreshes: one launch, pair workgroups wait on the stamps of flagged ends
         const size_t lds = pw_lds_bytes(c) / c->pwWaves;
-        VFT_DISPATCH(c, (launch((k_pairs_refresh_fused<REAL, NC>), dim3((unsigned) (nStale + n)), dim3(VFT_WG), lds, c->stream,
+        VFT_DISPATCH(c, (launch((k_pairs_refresh_fused<REAL, NC>), dim3((unsigned) (nStale + n)), dim3(pairThreads), lds, c->stream,
                                 arena<REAL>(c), dStale, nStale, nForced, (const int64_t *) dI, (const int64_t *) dJ,
-                                (const int32_t *) (dBase + 2 * idB + 3 * oB + sB), n, sa, (REAL *) o, (REAL *) (o + oB),
-                                (REAL *) (o + 2 * oB), c->refDone, c->doneCtr, c->dFlag, seq)));
+                                dWait, n, sa, (REAL *) o, (REAL *) (o + oB),
+                                (REAL *) (o + 2 * oB), c->refDone, c->doneCtr, c->dFlag, seq, (REAL *) c->pairStage, (int64_t) VFT_PAIR_STAGE_CAP)));
     } else if (n <= 2048) {   // short list: a workgroup per pair (all of them resident at once)
         const size_t lds = pw_lds_bytes(c) / c->pwWaves;
         if (nStale)
             VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, true>), dim3((unsigned) nStale), dim3(VFT_WG), lds, c->stream,
                                     arena<REAL>(c), dStale, nStale, nForced, sa)));
-        VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, true>), dim3((unsigned) n), dim3(VFT_WG), lds, c->stream,
+        VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, true>), dim3((unsigned) n), dim3(pairThreads), lds, c->stream,
                                 arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB), (REAL *) (o + 2 * oB),
-                                c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
+                                c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq, (REAL *) c->pairStage,
+                                (int64_t) VFT_PAIR_STAGE_CAP)));
     } else {
         if (nStale)
             VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves),
                                     pw_lds_bytes(c), c->stream, arena<REAL>(c), dStale, nStale, nForced, sa)));
         VFT_DISPATCH(c, (launch((k_pairs_fused<REAL, NC, false>), dim3(cdiv(n, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
                                 c->stream, arena<REAL>(c), dI, dJ, n, sa, (REAL *) o, (REAL *) (o + oB),
-                                (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq)));
+                                (REAL *) (o + 2 * oB), c->doneCtr, small ? c->dFlag : (unsigned long long *) nullptr, seq,
+                                (REAL *) nullptr, (int64_t) 0)));
     }
     LAUNCHCHK(c);
     if (small) {
         // results were written straight into mapped host memory; the kernel's last wave raises the flag
+        if (smallTimes) ts2 = std::chrono::steady_clock::now();
         if (int r = wait_flag(c, seq)) return r;
+        if (smallTimes) ts3 = std::chrono::steady_clock::now();
         const char *ho = hBase + 2 * idB;
         if (dist) memcpy(dist, ho, (size_t) n * rs);
         if (weight) memcpy(weight, ho + oB, (size_t) n * rs);
         if (crit) memcpy(crit, ho + 2 * oB, (size_t) n * rs);
+        if (smallTimes && n >= 1000) {
+            const auto ts4 = std::chrono::steady_clock::now();
+            tsPrep += std::chrono::duration<double>(ts1 - ts0).count();
+            tsLaunch += std::chrono::duration<double>(ts2 - ts1).count();
+            tsWait += std::chrono::duration<double>(ts3 - ts2).count();
+            tsOut += std::chrono::duration<double>(ts4 - ts3).count();
+            tsPairs += n;
+            if ((++tsCalls & 127) == 0)
+                fprintf(stderr, "[vft api] short pair lists (n >= 1000): %lld calls, %.0f pairs avg; per call: prep %.1f us, launch %.1f us, wait %.1f us, copy-out %.1f us\n",
+                        (long long) tsCalls, (double) tsPairs / tsCalls, 1e6 * tsPrep / tsCalls, 1e6 * tsLaunch / tsCalls, 1e6 * tsWait / tsCalls, 1e6 * tsOut / tsCalls);
+        }
         return VFT_OK;
     }
     static const bool stageTimes = getenv("VFT_API_PROFILE") != nullptr;   // tools only: where a long list's time goes

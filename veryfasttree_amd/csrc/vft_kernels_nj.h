@@ -887,6 +887,62 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_wave(Arena<REAL> A, SweepArgs 
     vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
 }
 
+// Publication of a short list's results to host-mapped memory.  One pair per workgroup writing its three numbers
+// straight over PCIe is 3 x n tiny posted writes and n system-scope fences: 35 ns per pair, 70 us of a 96 us call at 2 000
+// pairs.  Instead every workgroup stores into a DEVICE staging buffer (stage[0..cap) dist, [cap..2 cap) weight,
+// [2 cap..3 cap) criterion), and the last one to arrive - all of its threads - copies the three arrays to the host in
+// coalesced wavefront-wide stores, fences once and raises the flag.  Every thread of every workgroup must call.
+template <typename REAL>
+__device__ __forceinline__ void vft_stage_store(REAL *stage, int64_t cap, int64_t t, REAL d, REAL w, REAL cr) {
+    __hip_atomic_store(&stage[t], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&stage[cap + t], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&stage[2 * cap + t], cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename REAL>
+__device__ __forceinline__ void vft_publish_staged(const REAL *stage, int64_t cap, int64_t n, REAL *dist, REAL *weight, REAL *crit,
+                                                   unsigned int *doneCtr, unsigned long long *flag, unsigned long long seq) {
+    __shared__ int isLast;
+    if (threadIdx.x == 0) {
+        // The staged results were written by THIS thread with agent-scope atomic stores (vft_stage_store): they go to the
+        // memory side of this 8-XCD part, and once they are acknowledged (vmcnt 0) the counter may move.  A release fence
+        // here would be an L2 write-back per workgroup - 2 000 of them serialise into ~50 us, which was the whole per-pair
+        // cost of a long list.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // two-level completion count: 2 000 read-modify-writes of ONE address serialise at the memory side (~20 ns each);
+        // workgroup t counts in slot 1 + (t & 63), the workgroup that completes a slot counts in slot 0
+        const int64_t t = blockIdx.x >= (unsigned int) (gridDim.x - n) ? (int64_t) blockIdx.x - ((int64_t) gridDim.x - n) : 0;
+        const unsigned int sub = (unsigned int) (t & 63);
+        const unsigned int inSub = (unsigned int) ((n - sub + 63) / 64), nSubs = (unsigned int) (n < 64 ? n : 64);
+        int last = 0;
+        if (__hip_atomic_fetch_add(&doneCtr[1 + sub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == inSub - 1) {
+            __hip_atomic_store(&doneCtr[1 + sub], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(&doneCtr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nSubs - 1;
+        }
+        isLast = last;
+    }
+    __syncthreads();
+    if (!isLast) return;
+    __threadfence();       // (one fence, in the one workgroup that goes on)
+    for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
+        dist[t] = __hip_atomic_load(&stage[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        weight[t] = __hip_atomic_load(&stage[cap + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (crit) crit[t] = __hip_atomic_load(&stage[2 * cap + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The results must have LEFT the chip before the flag moves.  The explicit s_waitcnt is not redundant: ROCm 7.2 on
+    // gfx950 can drop the wait that belongs to the fence's write-back when a returned atomic follows (MI355X_MICROARCH.md,
+    // "Compiler hazard").
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *doneCtr = 0;   // launches on this stream are ordered: the next list starts from zero
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // setDistCriterion over an explicit pair list whose out-distances k_refresh_list has brought up to date: distance and
 // criterion per pair, results straight into (mapped) memory; the last wave to finish publishes `seq` to the host's
 // flag, which replaces a trailing signal kernel (the small lists of the join loop are latency-bound: every launch
@@ -896,7 +952,7 @@ template <typename REAL, int NC, bool WGPAIR>
 __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int64_t *pi, const int64_t *pj, int64_t n,
                                                         SweepArgs s, REAL *dist, REAL *weight, REAL *crit,
                                                         unsigned int *doneCtr, unsigned long long *flag,
-                                                        unsigned long long seq) {
+                                                        unsigned long long seq, REAL *stage, int64_t stageCap) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
     const int64_t t = WGPAIR ? (int64_t) blockIdx.x : (int64_t) blockIdx.x * VFT_PW_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;
@@ -904,6 +960,21 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     REAL d, w;
     if (WGPAIR) vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, w);
     else vft_pair_wave<REAL, NC>(A, i, j, false, vft_pw_lds(pwLds, A.d.nPosPad, 0), vft_pw_lds(pwLds, A.d.nPosPad, 1), d, w);
+    if (WGPAIR && flag && stage) {   // results through the device staging buffer (vft_publish_staged)
+        if (threadIdx.x == 0) {
+            REAL cr = 0;
+            if (!s.force) {
+                if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+                    const REAL dd = A.diameter[i] + A.diameter[j];
+                    d = d - dd;
+                }
+                cr = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], s.nActive);
+            }
+            vft_stage_store<REAL>(stage, stageCap, t, d, w, cr);
+        }
+        vft_publish_staged<REAL>(stage, stageCap, n, dist, weight, s.force ? (REAL *) nullptr : crit, doneCtr, flag, seq);
+        return;
+    }
     if ((WGPAIR ? threadIdx.x : (threadIdx.x & 63)) != 0) return;
     if (s.force) {   // raw profileDist / seqDist (vft_profile_distances): no diameter correction, no criterion
         dist[t] = d;
@@ -948,7 +1019,8 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, c
                                                                 const int64_t *pi, const int64_t *pj, const int32_t *wait, int64_t n,
                                                                 SweepArgs s, REAL *dist, REAL *weight, REAL *crit,
                                                                 unsigned int *refDone, unsigned int *doneCtr,
-                                                                unsigned long long *flag, unsigned long long seq) {
+                                                                unsigned long long *flag, unsigned long long seq, REAL *stage,
+                                                                int64_t stageCap) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
     const int64_t b = blockIdx.x;
     const unsigned int tag = (unsigned int) seq;
@@ -976,34 +1048,24 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, c
     const int64_t i = pi[t], j = pj[t];
     REAL d, w;
     vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, w);
-    if (threadIdx.x != 0) return;
-    if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
-        const REAL dd = A.diameter[i] + A.diameter[j];
-        d = d - dd;
-    }
-    dist[t] = d;
-    weight[t] = w;
-    const int32_t wi = wait[2 * t], wj = wait[2 * t + 1];
-    if (wi >= 0)
-        while (__hip_atomic_load(&refDone[wi], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
-    if (wj >= 0)
-        while (__hip_atomic_load(&refDone[wj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
-    // (out-distances of ends nobody refreshes in this launch were written by earlier launches)
-    const REAL oi = __hip_atomic_load(&A.outDist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const REAL oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int32_t si = __hip_atomic_load(&A.nOutActive[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int32_t sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    crit[t] = vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
-    if (flag) {   // as in k_pairs_fused (the explicit s_waitcnt is not redundant, see there)
-        __threadfence_system();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(doneCtr, 1u) == (unsigned int) (n - 1)) {
-            *doneCtr = 0;
-            __threadfence_system();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
+            const REAL dd = A.diameter[i] + A.diameter[j];
+            d = d - dd;
         }
+        const int32_t wi = wait[2 * t], wj = wait[2 * t + 1];
+        if (wi >= 0)
+            while (__hip_atomic_load(&refDone[wi], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+        if (wj >= 0)
+            while (__hip_atomic_load(&refDone[wj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+        // (out-distances of ends nobody refreshes in this launch were written by earlier launches)
+        const REAL oi = __hip_atomic_load(&A.outDist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const REAL oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t si = __hip_atomic_load(&A.nOutActive[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vft_stage_store<REAL>(stage, stageCap, t, d, w, vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive));
     }
+    vft_publish_staged<REAL>(stage, stageCap, n, dist, weight, crit, doneCtr, flag, seq);
 }
 
 // The cross product of two node lists (any mix of leaves and internal nodes): dist[a * nB + b] = the join distance of
