@@ -27,3 +27,13 @@ for cnt in (1, 64, 512, 1024, 2000):
         for _ in range(reps):
             ops.setDistCriterion(pi, pj, st.n_active, st.n_diff_allow, st.totdiam)
         print("%5d pairs, hub vs %-8s  %7.1f us / call (VFT_PAIR_WG=%s)" % (cnt, mix, (time.perf_counter() - t0) / reps * 1e6, os.environ.get("VFT_PAIR_WG", "default")))
+        if cnt >= 512 and mix == "internal":   # the hub needs a refresh in every call (as right after a join): the single-launch variant
+            od, na = ops.get_out_distances(hub, 1)
+            t0 = time.perf_counter()
+            tset = 0.0
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                ops.set_out_distances(hub, od, np.array([10 * n], np.int64))
+                tset += time.perf_counter() - t1
+                ops.setDistCriterion(pi, pj, st.n_active, st.n_diff_allow, st.totdiam)
+            print("%5d pairs, stale hub          %7.1f us / call" % (cnt, (time.perf_counter() - t0 - tset) / reps * 1e6))

@@ -1054,10 +1054,13 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, c
             d = d - dd;
         }
         const int32_t wi = wait[2 * t], wj = wait[2 * t + 1];
+        // (relaxed polls: what is read afterwards is read with agent-scope atomic loads, which go to the memory side where the
+        //  refresh workgroup's fenced stores already are when its tag appears; an acquire per pair workgroup would be a cache
+        //  invalidation per pair of a list in which every pair names the freshly joined node)
         if (wi >= 0)
-            while (__hip_atomic_load(&refDone[wi], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(&refDone[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
         if (wj >= 0)
-            while (__hip_atomic_load(&refDone[wj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(&refDone[wj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
         // (out-distances of ends nobody refreshes in this launch were written by earlier launches)
         const REAL oi = __hip_atomic_load(&A.outDist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const REAL oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
