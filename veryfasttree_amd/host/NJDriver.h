@@ -1763,7 +1763,7 @@ namespace veryfasttree {
                     setCriterion(n, chk2);
                     if (chk2.criterion < bh.criterion) continue;
                     bool found = false;
-                    for (const Hit &h: lT) found = found || h.j == node;
+                    for (size_t t = 0; t < lT.size() && !found; t++) found = lT[t].j == node;
                     if (found) continue;
                     int64_t iWorst = -1;
                     double dWorst = -1e20;
