@@ -26,7 +26,7 @@ def build_host(force=False):
     """The C++ host driver: plain g++, links against the HIP library next to it."""
     if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in HOST_DEPS + [LIB]):
         return HOST_LIB
-    subprocess.run(["g++", "-O2", "-std=c++11", "-fopenmp", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB] + HOST_SOURCES +
+    subprocess.run(["g++", "-O3", "-mavx2", "-ffp-contract=off", "-std=c++11", "-fopenmp", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB] + HOST_SOURCES +
                    ["-L" + os.path.dirname(LIB), "-lvft_hip", "-Wl,-rpath,$ORIGIN"], check=True)
     return HOST_LIB
 

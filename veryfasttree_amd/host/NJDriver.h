@@ -1696,6 +1696,7 @@ namespace veryfasttree {
                 /* (c) asks for the worst criterion of the OTHER list: a property of that list, computed once per list
                    instead of once per (node, hit) - the lists are 16 GB at a million sequences */
                 std::vector<double> worstOf((size_t) n, -1e20);
+                std::unique_ptr<Section> sW(new Section(this, "[host]     checking: worst criterion per list (host threads)"));
 #pragma omp parallel for schedule(dynamic, 256) num_threads(opt.hostThreads)
                 for (int64_t x = 0; x < n; x++) {
                     double dWorst = -1e20;
@@ -1709,6 +1710,7 @@ namespace veryfasttree {
                     }
                     worstOf[(size_t) x] = dWorst;
                 }
+                sW.reset(new Section(this, "[host]     checking: verdicts (host threads)"));
 #pragma omp parallel for schedule(dynamic, 256) num_threads(opt.hostThreads)
                 for (int64_t node = 0; node < n; node++) {
                     for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
@@ -1733,7 +1735,9 @@ namespace veryfasttree {
                 }
             }
             std::vector<std::vector<REAL> > critOf;
+            std::unique_ptr<Section> sSeq;
             if (!verdict.empty()) {
+                Section sC(this, "[host]     checking: criteria of the lists that will be scanned (host threads)");
                 critOf.resize((size_t) n);
                 std::vector<uint8_t> need((size_t) n, 0);
                 for (int64_t node = 0; node < n; node++)
@@ -1743,6 +1747,7 @@ namespace veryfasttree {
                 for (int64_t x = 0; x < n; x++)
                     if (need[(size_t) x]) fillCriteria(n, x, critOf[(size_t) x]);
             }
+            sSeq.reset(new Section(this, "[host]     checking: sequential pass"));
             int64_t nFullChecks = 0;
             for (int64_t node = 0; node < n; node++) {
                 for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
@@ -1809,6 +1814,7 @@ namespace veryfasttree {
                     }
                 }
             }
+            sSeq.reset();
             if (profiling) {
                 acc["[count]  checking phase: iterations done in full"].calls += nFullChecks;
                 acc["[count]  checking phase: verdicts precomputed"].calls += (int64_t) verdict.size();
