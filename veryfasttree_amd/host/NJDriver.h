@@ -2130,10 +2130,16 @@ namespace veryfasttree {
             /* NJ.tcc:4477-4515 — the reference runs this loop as an OpenMP parallel for: iterations only touch their
                own node's list.  Here: the host parts run in parallel per node, every distance that must be recomputed,
                for ALL nodes, goes to the device as ONE pair list, and every lazy out-distance refresh as one id list. */
+            /* one record of a node's merged list: 16 bytes instead of a 32-byte Besthit (a refresh at a million sequences
+               handles 3 000 of them for each of 1 000 nodes) */
+            struct Ent {
+                int32_t j;
+                int32_t src;     /* >= 0: column of the distance block; -1: the distance is known; -2: recomputed as a list pair */
+                REAL dist, crit;
+            };
             struct Work {
                 int64_t node, nNew;
-                std::vector<Besthit> both, out;
-                std::vector<uint8_t> isTodo;
+                std::vector<Ent> out;
                 std::vector<int32_t> listTodo;      /* records whose distance goes to the device as a pair list */
                 std::vector<int64_t> staleCand;     /* ends of the records whose distance is known, if stale */
             };
@@ -2177,53 +2183,52 @@ namespace veryfasttree {
             const int64_t allowR = nDiffAllow(nActive);
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
+                /* transferBestHits(..., updateDistances = false) + uniqueBestHits' host part (NJ.tcc:4580-4613, 4786-4817) on
+                   compact records.  The node's own hits come first, the transferred ones after them; every record is
+                   re-targeted to the active ancestor of its partner (updateBestHit); records without a partner or whose
+                   partner is the node itself drop out; the sort by partner id keeps, among equal ids, the record that came
+                   LAST (the tie rule of the reference's sort: ascending key, descending position) - a transferred record
+                   over an old one.  Old hits whose partner changed, and - as in the reference, whose test is dist < 0 -
+                   old hits with a negative distance, are recomputed as list pairs. */
                 Work &w = work[t];
-                const int64_t nOld = (int64_t) hits[w.node].size();
-                w.both = hitsToBestHits(hits[w.node], w.node);
-                for (Besthit &b: w.both) criterionFresh(nActive, b);
-                /* transferBestHits(..., updateDistances = false), NJ.tcc:4580-4613: host only */
-                for (int64_t u = 0; u < 2 * w.nNew; u++) {
-                    const Besthit &o = all[u];
-                    Besthit h;
-                    h.i = w.node;
-                    h.j = target[(size_t) u];   /* activeAncestor(o.j) */
-                    h.dist = o.dist;
-                    h.weight = o.weight;
-                    h.criterion = o.criterion;
-                    if (h.j < 0 || h.j == w.node) {
-                        h.weight = 0;
-                        h.dist = (REAL) -1e20;
-                        h.criterion = (REAL) 1e20;
-                    } else if (h.i != o.i || h.j != o.j) {
-                        h.dist = (REAL) -1e20;
-                        h.criterion = (REAL) 1e20;
-                        h.src = (int32_t) u;   /* the pair (w.node, target[u]) is entry (t, u) of the distance block */
-                    } else {
-                        h.criterion = (REAL) 1e20;
-                    }
-                    w.both.push_back(h);
+                const int64_t node = w.node;
+                const std::vector<Hit> &l = hits[(size_t) node];
+                std::vector<Ent> ents;
+                ents.reserve(l.size() + (size_t) (2 * w.nNew));
+                for (const Hit &h: l) {
+                    const int64_t j = activeAncestor(h.j);
+                    if (j < 0 || j == node) continue;
+                    Ent e;
+                    e.j = (int32_t) j;
+                    e.src = (j == h.j && !(h.dist < 0.0)) ? -1 : -2;
+                    e.dist = h.dist;
+                    e.crit = (REAL) 1e20;
+                    ents.push_back(e);
                 }
-                w.both.resize((size_t) (nOld + 2 * w.nNew));
-                /* uniqueBestHits, host part (NJ.tcc:4786-4817) */
-                for (Besthit &h: w.both) updateBestHit(h, false, nullptr);
-                sortByIJ(w.both);
-                int64_t last = -1;
-                for (size_t u = 0; u < w.both.size(); u++) {
-                    const Besthit &h = w.both[u];
-                    if (h.i < 0 || h.j < 0) continue;
-                    if (last >= 0 && w.both[last].i == h.i && w.both[last].j == h.j) continue;
-                    w.out.push_back(h);
-                    last = (int64_t) u;
+                for (int64_t u = 0; u < 2 * w.nNew && u < (int64_t) target.size(); u++) {
+                    const int64_t j = target[(size_t) u];
+                    if (j < 0 || j == node) continue;
+                    Ent e;
+                    e.j = (int32_t) j;
+                    e.src = (int32_t) u;   /* the pair (node, target[u]) is entry (t, u) of the distance block */
+                    e.dist = (REAL) -1e20;
+                    e.crit = (REAL) 1e20;
+                    ents.push_back(e);
                 }
-                w.isTodo.assign(w.out.size(), 0);
+                std::vector<uint64_t> keys(ents.size());
+                for (size_t k = 0; k < ents.size(); k++) keys[k] = (uint64_t) (uint32_t) ents[k].j;
+                std::vector<uint32_t> order;
+                radixOrder(keys, order);
+                w.out.reserve(ents.size());
+                for (size_t k = 0; k < order.size(); k++) {
+                    const Ent &e = ents[order[k]];
+                    if (!w.out.empty() && w.out.back().j == e.j) continue;
+                    w.out.push_back(e);
+                }
                 for (size_t u = 0; u < w.out.size(); u++) {
-                    const Besthit &h = w.out[u];
-                    w.isTodo[u] = h.dist < 0.0 ? 1 : 0;
-                    if (w.isTodo[u]) {
-                        if (h.src < 0) w.listTodo.push_back((int32_t) u);
-                    } else {
-                        staleCandidates(nActive, allowR, h.i, h.j, w.staleCand);
-                    }
+                    const Ent &e = w.out[u];
+                    if (e.src == -2) w.listTodo.push_back((int32_t) u);
+                    else if (e.src == -1) staleCandidates(nActive, allowR, node, e.j, w.staleCand);
                 }
             }
             sHost.reset();
@@ -2240,9 +2245,18 @@ namespace veryfasttree {
                 nB = std::min<int64_t>(nB, (int64_t) target.size());
                 std::vector<int64_t> nodesA((size_t) nW);
                 for (int64_t t = 0; t < nW; t++) nodesA[(size_t) t] = work[(size_t) t].node;
-                std::vector<Besthit *> todo;
-                for (Work &w: work)
-                    for (int32_t u: w.listTodo) todo.push_back(&w.out[(size_t) u]);
+                std::vector<Besthit> listRecs;
+                std::vector<std::pair<int32_t, int32_t> > listRef;   /* (work index, record index) of every list pair */
+                for (int64_t t = 0; t < nW; t++)
+                    for (int32_t u: work[(size_t) t].listTodo) {
+                        Besthit h;
+                        h.i = work[(size_t) t].node;
+                        h.j = work[(size_t) t].out[(size_t) u].j;
+                        listRecs.push_back(h);
+                        listRef.push_back(std::make_pair((int32_t) t, u));
+                    }
+                std::vector<Besthit *> todo(listRecs.size());
+                for (size_t k = 0; k < listRecs.size(); k++) todo[k] = &listRecs[k];
                 if (profiling) acc["[count]    refresh: pairs recomputed as a list"].calls += (int64_t) todo.size();
                 if (profiling) acc["[count]    refresh: pairs recomputed as a block"].calls += nW * nB;
                 if (nW > 0 && nB > 0) {
@@ -2254,6 +2268,11 @@ namespace veryfasttree {
                     pending = false;
                 }
                 setDistCriterionBatch(nActive, todo);
+                for (size_t k = 0; k < listRecs.size(); k++) {
+                    Ent &e = work[(size_t) listRef[k].first].out[(size_t) listRef[k].second];
+                    e.dist = listRecs[k].dist;
+                    e.crit = listRecs[k].criterion;
+                }
                 {   /* (candidates were collected before the two calls above: what those refreshed is skipped on the device) */
                     std::vector<int64_t> ids;
                     for (Work &w: work) ids.insert(ids.end(), w.staleCand.begin(), w.staleCand.end());
@@ -2264,18 +2283,34 @@ namespace veryfasttree {
             std::unique_ptr<Section> sSave(new Section(this, "[host]     refresh: criteria + sort + save (host threads)"));
 #pragma omp parallel for schedule(dynamic, 8) num_threads(opt.hostThreads)
             for (int64_t t = 0; t < nW; t++) {
+                /* criteria of the merged list (setCriterion's arithmetic: every out-distance involved is fresh enough now),
+                   then sortSaveBestHits (NJ.tcc:4535-4578): ascending criterion, ties by descending position, the first nNew */
                 Work &w = work[t];
+                const int64_t node = w.node;
+                std::vector<uint64_t> keys(w.out.size());
                 for (size_t u = 0; u < w.out.size(); u++) {
-                    Besthit &h = w.out[u];
-                    if (w.isTodo[u] && h.src >= 0) {
-                        h.dist = block[(size_t) (t * nB + h.src)];
+                    Ent &e = w.out[u];
+                    if (e.src >= 0) e.dist = block[(size_t) (t * nB + e.src)];
+                    if (e.src != -2) {
+                        Besthit h;
+                        h.i = node;
+                        h.j = e.j;
+                        h.dist = e.dist;
+                        h.criterion = (REAL) 1e20;
                         criterionFresh(nActive, h);
-                    } else if (!w.isTodo[u]) {
-                        criterionFresh(nActive, h);
+                        e.crit = h.criterion;
                     }
+                    keys[u] = orderedKey(e.crit);
                 }
-                sortSaveBestHits(w.node, w.out, (int64_t) w.out.size(), w.nNew);
-                visible[w.node] = hits[w.node][0];
+                std::vector<uint32_t> order;
+                radixOrder(keys, order);
+                std::vector<Hit> &l = hits[(size_t) node];
+                l.clear();
+                for (size_t k = 0; k < order.size() && (int64_t) l.size() < w.nNew; k++) {
+                    const Ent &e = w.out[order[k]];
+                    l.push_back(Hit{e.j, e.dist});
+                }
+                visible[(size_t) node] = l[0];
             }
             sSave.reset();
             resetTopVisible(nActive);
