@@ -756,6 +756,7 @@ namespace veryfasttree {
         std::map<std::string, Acc> acc;
         bool profiling = std::getenv("VFT_NJ_PROFILE") != nullptr;
         bool checkJoins = std::getenv("VFT_NJ_CHECK") != nullptr;   /* tools: cross-check the shortcuts against the device */
+        int64_t checkFailures = 0;
 
         /* inclusive wall-clock of a host section (VFT_NJ_PROFILE=1); device calls made inside are also listed on
            their own lines */
@@ -2213,6 +2214,11 @@ namespace veryfasttree {
                     e.src = (int32_t) u;   /* the pair (node, target[u]) is entry (t, u) of the distance block */
                     e.dist = (REAL) -1e20;
                     e.crit = (REAL) 1e20;
+                    if (node == all[(size_t) u].i && j == all[(size_t) u].j) {   /* the swept node's own record (the sweep lists the
+                                                                                   node itself among its hits): distance known */
+                        e.dist = all[(size_t) u].dist;
+                        e.src = e.dist < 0.0 ? -2 : -1;
+                    }
                     ents.push_back(e);
                 }
                 std::vector<uint64_t> keys(ents.size());
@@ -2230,7 +2236,55 @@ namespace veryfasttree {
                     if (e.src == -2) w.listTodo.push_back((int32_t) u);
                     else if (e.src == -1) staleCandidates(nActive, allowR, node, e.j, w.staleCand);
                 }
+                if (checkJoins) {   /* tools (VFT_NJ_CHECK): the same merge on the reference's records, step by step */
+                    std::vector<Besthit> both = hitsToBestHits(hits[(size_t) node], node);
+                    for (int64_t u = 0; u < 2 * w.nNew; u++) {
+                        const Besthit &o = all[(size_t) u];
+                        Besthit h;
+                        h.i = node;
+                        h.j = target[(size_t) u];
+                        h.dist = o.dist;
+                        if (h.j < 0 || h.j == node) h.dist = (REAL) -1e20;
+                        else if (h.i != o.i || h.j != o.j) {
+                            h.dist = (REAL) -1e20;
+                            h.src = (int32_t) u;
+                        }
+                        both.push_back(h);
+                    }
+                    for (Besthit &h: both) updateBestHit(h, false, nullptr);
+                    const std::vector<Besthit> unsorted(both);
+                    sortByIJ(both);
+                    std::vector<Besthit> ref;
+                    int64_t last = -1;
+                    for (size_t u = 0; u < both.size(); u++) {
+                        const Besthit &h = both[u];
+                        if (h.i < 0 || h.j < 0) continue;
+                        if (last >= 0 && both[(size_t) last].i == h.i && both[(size_t) last].j == h.j) continue;
+                        ref.push_back(h);
+                        last = (int64_t) u;
+                    }
+                    bool same = ref.size() == w.out.size();
+                    for (size_t u = 0; same && u < ref.size(); u++) {
+                        const Ent &e = w.out[u];
+                        const int cls = ref[u].dist < 0.0 ? (ref[u].src >= 0 ? 1 : 2) : 0, mine = e.src >= 0 ? 1 : e.src == -2 ? 2 : 0;
+                        same = ref[u].j == e.j && cls == mine && (cls != 1 || ref[u].src == e.src) && (cls != 0 || ref[u].dist == e.dist);
+                        if (!same) {
+                            for (size_t q2 = 0; q2 < unsorted.size(); q2++)
+                                if (unsorted[q2].j == ref[u].j)
+                                    fprintf(stderr, "[check]   record at position %zu of %zu (nOld %zu): i %lld j %lld dist %g src %d\n", q2, unsorted.size(),
+                                            hits[(size_t) node].size(), (long long) unsorted[q2].i, (long long) unsorted[q2].j, (double) unsorted[q2].dist, unsorted[q2].src);
+                        }
+                        if (!same)
+                            fprintf(stderr, "[check] refresh merge of node %lld differs at %zu: j %lld / %d, class %d / %d, src %d / %d, dist %g / %g\n",
+                                    (long long) node, u, (long long) ref[u].j, e.j, cls, mine, ref[u].src, e.src, (double) ref[u].dist, (double) e.dist);
+                    }
+                    if (!same) {
+#pragma omp critical
+                        checkFailures++;
+                    }
+                }
             }
+            if (checkJoins && checkFailures) throw std::runtime_error("NJDriver: the compact refresh merge differs from the record-by-record one");
             sHost.reset();
             std::vector<REAL> block;
             int64_t nB = 0;
