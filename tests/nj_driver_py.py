@@ -1,14 +1,12 @@
-"""Host driver of the neighbour-joining phase on top of the batched profile operations.
+"""TEST INFRASTRUCTURE: a Python restatement of the neighbour-joining driver (the product's driver is C++:
+veryfasttree_amd/host/NJDriver.h, entry point vft_nj_run).
 
-This is the CALLER of the hot path: the top-hits bookkeeping of fastNJ (NJ.tcc:2796-3155, 3746-4833) restated
-against the backend interface (`HipProfileOps` on the GPU, an oracle-backed stand-in in the CPU tests), so that the
-join order can be checked against the reference's `Join` lines.  All profile arithmetic happens behind `ops`; what
-lives here is control flow and the handful of scalar formulas the reference evaluates on the host (criterion,
-branch lengths, diameters), with the reference's float/double mix reproduced through numpy scalars.
-
-Prototype status: Python, deterministic single-thread semantics, default options and `-fastest -no2nd`
-(no second-level top hits, no constraints, no BIONJ weighting).  The C++ port behind HipOperations.h is the next
-step; the logic below is what it must do.
+The top-hits bookkeeping of fastNJ (NJ.tcc:2796-3155, 3746-4833) against the backend interface (`HipProfileOps` on the
+GPU, the oracle-backed stand-in of tests/oracle_ops.py on the CPU), so that the reference's `Join` lines can be checked
+without a GPU and the multi-rank exchange with gloo.  All profile arithmetic happens behind `ops`; what lives here is
+control flow and the handful of scalar formulas the reference evaluates on the host (criterion, branch lengths,
+diameters), with the reference's float/double mix reproduced through numpy scalars.  Deterministic single-thread
+semantics, default options and `-fastest -no2nd` (no second-level top hits, no constraints, no BIONJ weighting).
 """
 import math
 

@@ -5,7 +5,7 @@ import pytest
 
 import golden_util as G
 from test_nj_driver_cpu import unique_codes
-from veryfasttree_amd.nj_driver import NJDriver
+from nj_driver_py import NJDriver
 
 pytestmark = pytest.mark.gpu
 

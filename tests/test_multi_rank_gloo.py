@@ -172,7 +172,7 @@ def _driver_worker(rank, world, port, name, fastest, second, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle_ops import OracleOps
     from test_nj_driver_cpu import unique_codes
-    from veryfasttree_amd.nj_driver import NJDriver
+    from nj_driver_py import NJDriver
     d = G.load(name)
     codes = unique_codes(d["codes"])
     ops = _ShardedOps(OracleOps(codes.shape[0], codes.shape[1], 4, np.float32), rank, world)

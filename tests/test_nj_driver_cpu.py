@@ -6,7 +6,7 @@ import pytest
 
 import golden_util as G
 from oracle_ops import OracleOps
-from veryfasttree_amd.nj_driver import NJDriver
+from nj_driver_py import NJDriver
 from veryfasttree_amd.synth import NOCODE
 
 
