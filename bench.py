@@ -25,9 +25,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# small device->host copies (merged hit lists in the multi-GPU path) go through blit kernels instead of the SDMA
-# engines, whose fixed latency is hundreds of microseconds on this platform; must be set before HIP initialises
-os.environ.setdefault("HSA_ENABLE_SDMA", "0")
+# Multi-GPU runs only: small device->host copies (the merged hit lists of a step) go through blit kernels instead of the
+# SDMA engines, whose fixed latency is hundreds of microseconds on this platform; must be set before HIP initialises.
+# The single-GPU path returns its small results through host-mapped memory and does not need it (measured: no change).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("HSA_ENABLE_SDMA", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 

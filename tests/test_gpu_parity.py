@@ -82,6 +82,10 @@ def test_pair_distances(fx):
     ok = ~(both_leaves & (d["pdist.weight"] == ops.dt.type(0.01)))   # seqDist reports weight 0 there, see NJ.tcc:1621
     assert np.array_equal(dist[ok], d["pdist.dist"][ok])
     assert np.array_equal(weight[ok], d["pdist.weight"][ok])
+    # the excluded pairs are two leaves without a common column: the fixture's numbers come from profileDist (weight 0.01,
+    # NJ.tcc:1186-1188), the path under test goes through seqDist like the reference's own callers (NJ.tcc:1601-1624),
+    # whose answer for them is distance 1, weight 0
+    assert np.all(weight[~ok] == 0) and np.all(dist[~ok] == 1)
     # leaf x leaf through seqDist
     dist, weight, _ = ops.setDistCriterion(d["seqdist.a"], d["seqdist.b"], 5, 10 ** 6, 0.0)
     assert np.array_equal(dist, d["seqdist.dist"])
