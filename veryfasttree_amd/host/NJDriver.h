@@ -1291,6 +1291,7 @@ namespace veryfasttree {
                     Hit &v = visible[hit.j];
                     v.j = hit.i;
                     v.dist = hit.dist;
+                    Section s3(this, "[host]     updateVisible: updateTopVisible");
                     updateTopVisible(nActive, hit.j, v);
                 }
             }
