@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--n-seqs", type=int, default=1000000)
     ap.add_argument("--n-pos", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end C3 tree (wall-clock half of the metric)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end trees (wall-clock half of the metric)")
+    ap.add_argument("--no-e2e-c4", action="store_true", help="skip the 1M x 200 end-to-end tree (minutes), keep C3's")
     ap.add_argument("--no-dense", action="store_true", help="skip the phi ~ 1 roofline of the sweep kernel")
     return ap.parse_args()
 
@@ -57,18 +58,20 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(state, codes, ops, budget_s=8.0):
+def cpu_baseline(state, codes, ops, budget_s=6.0):
     """SURVEY.md 8d "CPU baseline beside it": this repo's AVX2 + OpenMP restatement of the one-vs-all sweep
     (oracle/vft_oracle_avx2.c: -O3 -mavx2 -mfma -fopenmp, bit-identical to the scalar oracle that is pinned to the
     reference) timed on the GPU box's host cores over a bounded sample of the same workload - the benchmark's seeds
-    against 40 000 active leaves + 20 000 internal profiles of the same alignment - first on every core, then on one
-    thread, ~budget_s seconds each.  `value` is the all-core rate."""
+    against 170 000 active leaves + 80 000 internal profiles of the same alignment (1 GB in the oracle's dense layout).
+    The timed leg allocates and first-touches its own copy of the sample inside the OpenMP team, static blocks of 64
+    targets per thread, so that every thread streams memory of its own NUMA node; run on every core, on half of them
+    (one socket's worth) and on one thread, ~budget_s seconds each.  `value` is the all-core rate."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import Oracle, avx2_max_threads
     orc = Oracle(ops.dt)
     n = state.n_seqs
-    leaf_ids = state.active[state.active < n][:40000]
-    int_ids = state.active[state.active >= n][:20000]
+    leaf_ids = state.active[state.active < n][:170000]
+    int_ids = state.active[state.active >= n][:80000]
     L = codes.shape[1]
     m = len(leaf_ids) + len(int_ids)
     W = np.zeros((m, L), ops.dt)
@@ -85,22 +88,20 @@ def cpu_baseline(state, codes, ops, budget_s=8.0):
     od = np.zeros(m, ops.dt)
     na = np.full(m, state.n_active)
     cores = avx2_max_threads()
+    # alternate internal / leaf seeds like the GPU step
+    queries = np.array([(len(leaf_ids) + q // 2) % m if q % 2 == 0 else q // 2 for q in range(16)], np.int64)
     rates = {}
-    for threads in (cores, 1):
-        orc.avx2_sweep(st, 0, state.n_active, od, na, threads=threads)   # warm-up (page in, spin up the team)
-        t0 = time.perf_counter()
-        done, q = 0, 0
-        while time.perf_counter() - t0 < budget_s:
-            query = (len(leaf_ids) + q // 2) if q % 2 == 0 else q // 2   # alternate internal / leaf seeds like the GPU step
-            orc.avx2_sweep(st, query % m, state.n_active, od, na, threads=threads)
-            done += m
-            q += 1
-        rates[threads] = (done / (time.perf_counter() - t0), q)
+    for threads in sorted({cores, max(1, cores // 2), 1}, reverse=True):
+        secs, done, _ = orc.avx2_sweep_bench(st, queries, state.n_active, od, na, threads=threads,
+                                             budget=budget_s if threads > 1 else min(budget_s, 4.0))
+        rates[threads] = (done * m / secs, done)
     return dict(value=rates[cores][0], unit="profile-ops/s", cores=cores, kind="port", cpu=cpu_model(),
-                value_1_thread=rates[1][0],
-                sample="%d + %d sweeps (all cores / 1 thread) of one seed vs %d active leaves + %d internal profiles of the "
-                       "same alignment; AVX2 + OpenMP restatement (oracle/vft_oracle_avx2.c), %d threads"
-                       % (rates[cores][1], rates[1][1], len(leaf_ids), len(int_ids), cores))
+                value_1_thread=rates[1][0], value_half_cores=rates[max(1, cores // 2)][0],
+                scaling_all_cores_vs_1_thread=rates[cores][0] / rates[1][0],
+                sample="%d sweeps on %d threads, %d on %d, %d on 1 thread, each of one seed vs %d active leaves + %d internal "
+                       "profiles of the same alignment (team-allocated, first-touched copy; static blocks of 64 targets); "
+                       "AVX2 + OpenMP restatement (oracle/vft_oracle_avx2.c)"
+                       % (rates[cores][1], cores, rates[max(1, cores // 2)][1], max(1, cores // 2), rates[1][1], len(leaf_ids), len(int_ids)))
 
 
 def dense_profile_roofline(ops, state, n, L, groups=None):
@@ -152,39 +153,87 @@ def dense_profile_roofline(ops, state, n, L, groups=None):
                 achieved=ach, frac=ach / HBM_PEAK_GBS, achieved_moved_gbs=mov, frac_moved=mov / HBM_PEAK_GBS)
 
 
-def end_to_end_c3(device, comm=None):
-    """Wall-clock to a tree at BASELINE config C3's shape: 100 000 nt x 500, `-nt -fastest` NJ phase (top hits with the
-    second-level lists, as the reference runs it at one thread), root, minimum-evolution branch lengths, Newick - what
-    `VeryFastTree -nt -fastest -noml -nome -nosupport` prints.  newick_crc is compared with the reference's own output
-    for the same alignment (tests/golden/bb_c3_crc.npz, from oracle/_ref/VeryFastTree)."""
+E2E = {
+    # name: (n, L, mu, gap, seed, fastest, golden file, the reference's flags)
+    "c3": (100000, 500, 0.03, 0.01, 3, True, "bb_c3_crc.npz", "-nt -fastest -noml -nome -nosupport"),
+    "c4": (1000000, 200, 0.02, 0.01, 4, False, "bb_c4_crc.npz", "-nt -noml -nome -nosupport"),
+}
+
+
+def end_to_end(which, device, comm=None):
+    """Wall-clock to a tree for BASELINE config C3 (100 000 nt x 500, `-nt -fastest`: top hits with the second-level lists,
+    as the reference runs it at one thread) or C4 (1 000 000 nt x 200, `-nt`: the headline alignment): NJ phase, root,
+    minimum-evolution branch lengths, Newick - what `VeryFastTree <flags> -noml -nome -nosupport` prints.  newick_crc is
+    compared with the reference's own output for the same alignment (tests/golden/bb_c{3,4}_crc.npz, from
+    oracle/_ref/VeryFastTree at one thread)."""
     import zlib
     from veryfasttree_amd import HipProfileOps, synth
     from veryfasttree_amd.backend import nj_newick
-    n, L = 100000, 500
-    codes = synth.random_descent_codes(n, L, 4, 0.03, 0.01, seed=3)
+    n, L, mu, gap, seed, fastest, golden, flags = E2E[which]
+    codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
     names = ["s%d" % k for k in range(n)]
     t0 = time.perf_counter()
     tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m, device=device), codes, names,
-                     fastest=True, me_lengths=True, comm=comm)
+                     fastest=fastest, me_lengths=True, comm=comm)
     wall = time.perf_counter() - t0
     crc = zlib.crc32(tree.encode())
-    out = dict(workload="c3_100k_x500_nt_fastest_nj_tree", wall_s=round(wall, 2), unique_seqs=int(len(np.unique(codes, axis=0))),
-               newick_bytes=len(tree), newick_crc=crc)
+    out = dict(workload="%s_%dk_x%d_nt_%snj_tree" % (which, n // 1000, L, "fastest_" if fastest else ""), reference_flags=flags,
+               wall_s=round(wall, 2), unique_seqs=int(len(np.unique(codes, axis=0))), newick_bytes=len(tree), newick_crc=crc)
     if comm is not None:   # what was actually split over the ranks: sweeps + leaf blocks (the join loop itself is replicated)
         out["allgathers"] = int(comm.calls)
         out["allgather_bytes"] = int(comm.bytes)
-    ref = os.path.join(ROOT, "tests", "golden", "bb_c3_crc.npz")
+    ref = os.path.join(ROOT, "tests", "golden", golden)
     if os.path.exists(ref):
-        want = int(np.load(ref)["newick_crc"])
+        g = np.load(ref)
+        want = int(g["newick_crc"])
         out["reference_newick_crc"] = want
         out["identical_to_reference"] = bool(want == crc)
+        if "reference_wall_s" in g:
+            out["reference_wall_s_1_thread"] = round(float(g["reference_wall_s"]), 1)
     return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes (torch.distributed.run,
+    one per GPU, rendezvous on 127.0.0.1) before anything in this process touches the GPU, relay what they print and exit
+    with their code.  Never exec: this process may hold profiler / runtime state."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run(cmd, env=env)
+    sys.exit(res.returncode)
+
+
+def launch_only(args, world, rank):
+    """test hook (VFT_BENCH_LAUNCH_ONLY=1, CPU): the launcher, the rendezvous and one collective, no GPU work"""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("VFT_BENCH_BACKEND", "gloo"))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    assert dist.get_world_size() == args.gpus == world
+    if rank == 0:
+        print(json.dumps(dict(metric="profile-ops/sec", n_gpus=world, world=dist.get_world_size(), launch_only=True,
+                              rank_sum=float(t.item()))))
+    dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not os.environ.get("VFT_BENCH_SAME_DEVICE"):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("VFT_BENCH_LAUNCH_ONLY"):
+        return launch_only(args, world, int(os.environ.get("RANK", "0")))
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -340,6 +389,14 @@ def main():
         crc = zlib.crc32(np.ascontiguousarray(hits["j"]).tobytes(), crc)
         crc = zlib.crc32(np.ascontiguousarray(hits["criterion"]).tobytes(), crc)
     line["hits_crc"] = crc
+    line["world"] = world
+    if use_dist:   # what each rank swept (target ids [lo, hi) of every sweep) and what the exchange moved per step
+        sh = torch.tensor([float(lo), float(hi)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        allsh = [torch.zeros_like(sh) for _ in range(world)]
+        dist.all_gather(allsh, sh)
+        line["shards"] = [[int(x[0].item()), int(x[1].item())] for x in allsh]
+        line["allgathers_per_step"] = 1
+        line["allgather_bytes_per_step"] = int(world * rec)
     if not args.no_e2e and (n, L) == (1000000, 200):
         # the other half of BASELINE's metric: wall-clock to a tree.  With several ranks the C++ driver runs on every rank
         # (replicated join decisions) and splits its sweeps and leaf blocks over them (include/vft_host.h, vft_comm)
@@ -350,15 +407,30 @@ def main():
             from veryfasttree_amd.backend import TorchComm
             comm = TorchComm(dist, local_rank)
             barrier()
-        try:
-            e2e = end_to_end_c3(local_rank, comm)
+        for which, key in (("c3", "e2e"), ("c4", "e2e_c4")):
+            if which == "c4" and args.no_e2e_c4:
+                continue
+            e2e, ok = None, 1.0
+            try:
+                e2e = end_to_end(which, local_rank, comm)
+            except Exception as exc:   # the headline line must still be printed
+                e2e, ok = {"workload": which, "error": repr(exc)}, 0.0
             if use_dist:
-                t = torch.tensor([e2e["wall_s"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                e2e["wall_s"] = round(float(t.item()), 2)
-        except Exception as exc:   # the headline line must still be printed (the failure is symmetric over the ranks)
-            e2e = {"workload": "c3_100k_x500_nt_fastest_nj_tree", "error": repr(exc)}
-        line["e2e"] = e2e
+                # every rank takes part in both collectives whatever happened on it: first whether all succeeded, then the
+                # slowest rank's wall-clock (a failure on one rank must not leave the others waiting in an all-reduce)
+                gdev = "cuda" if backend == "nccl" else "cpu"
+                t = torch.tensor([ok], dtype=torch.float64, device=gdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                w = torch.tensor([float(e2e.get("wall_s", 0.0))], dtype=torch.float64, device=gdev)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                c = torch.tensor([float(e2e.get("newick_crc", -1)), -float(e2e.get("newick_crc", -1))], dtype=torch.float64, device=gdev)
+                dist.all_reduce(c, op=dist.ReduceOp.MAX)
+                if float(t.item()) < 1.0 and ok:
+                    e2e = {"workload": which, "error": "another rank failed"}
+                elif ok:
+                    e2e["wall_s"] = round(float(w.item()), 2)
+                    e2e["same_crc_on_all_ranks"] = bool(c[0].item() == -c[1].item())
+            line[key] = e2e
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

@@ -291,6 +291,13 @@ int vft_split_supports(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t 
    float-precision matrix-model pairLogLk - glibc 2.35's algorithm (csrc/vft_glibc_log.h), not the device math library.
    x, out: host arrays of n doubles (positive, normal). */
 int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
+/* Test / tool hooks: which of two equivalent kernel variants a context uses (results are identical; the tests compare
+   them).  No environment variable selects kernels in this library. */
+#define VFT_DEBUG_NO_FUSED_REFRESH 1   /* value != 0: pair lists with refreshes as two launches instead of one */
+#define VFT_DEBUG_PAIR_THREADS 2       /* threads per pair of the short-list kernels (0 = the built-in choice) */
+#define VFT_DEBUG_NO_PAIR_STAGING 3    /* value != 0: short pair lists read their ids from the mapped ring directly */
+#define VFT_DEBUG_GENERIC_OUTPROFILE 4 /* value != 0: vft_out_profile_full always takes the one-thread-per-column kernel */
+int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */
 int vft_timer_start(vft_ctx *ctx);

@@ -365,6 +365,47 @@ def gen_c3(tmp):
     print("bb_c3_crc: %d bytes of Newick, crc %d" % (len(tree), zlib.crc32(tree.encode())))
 
 
+def gen_c4(tmp):
+    """BASELINE config C4 at full size (1 000 000 x 200 nt, `-nt` at one thread): CRC-32 and length of the reference's
+    `-noml -nome -nosupport` tree, plus the join order as one CRC-32 per 10 000 `Join` lines (`i j new`, NJ.tcc:2993-3001)
+    so that a divergence can be located.  The complete join list stays in oracle/_ref/c4_joins.npy (git-ignored).
+    Takes hours of one core and tens of GB of memory."""
+    import time
+    import zlib
+    codes = synth.random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)
+    fa = os.path.join(tmp, "c4.fa")
+    synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+    del codes
+    flags = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "1", "-seed", "1"]
+    joins_txt = os.path.join(HERE, "_ref", "c4_joins.txt")
+    tree_path = os.path.join(HERE, "_ref", "c4_nj.tree")
+    t0 = time.time()
+    with open(tree_path, "wb") as out:
+        ref = subprocess.Popen([REFBIN] + flags + ["-verbose", "3", fa], stdout=out, stderr=subprocess.PIPE)
+        with open(joins_txt, "wb") as jt:
+            flt = subprocess.Popen(["grep", "^Join"], stdin=ref.stderr, stdout=jt)
+            ref.stderr.close()
+            rc = ref.wait()
+            flt.wait()
+    wall = time.time() - t0
+    assert rc == 0, "reference exited with %d" % rc
+    tree = open(tree_path, "rb").read().decode().strip()
+    joins = []
+    for line in open(joins_txt):
+        f = line.split("\t")
+        joins.append((int(f[1]), int(f[2]), int(f[10])))
+    ja = np.array(joins, dtype=np.int64)
+    np.save(os.path.join(HERE, "_ref", "c4_joins.npy"), ja.astype(np.int32))
+    chunk = 10000
+    crcs = np.array([zlib.crc32(ja[k:k + chunk].astype("<i4").tobytes()) for k in range(0, len(ja), chunk)], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c4_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())),
+                        newick_bytes=np.int64(len(tree)), n_joins=np.int64(len(ja)), join_chunk=np.int64(chunk),
+                        join_chunk_crc=crcs, flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8),
+                        reference_wall_s=np.float64(wall))
+    print("bb_c4_crc: %d bytes of Newick, crc %d, %d joins, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ja), wall))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa"]
@@ -391,6 +432,8 @@ def main():
             gen_aa(tmp)
         if "c3" in which:   # not part of the default set: ~11 minutes
             gen_c3(tmp)
+        if "c4" in which:   # not part of the default set: hours
+            gen_c4(tmp)
 
 
 if __name__ == "__main__":

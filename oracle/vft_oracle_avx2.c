@@ -50,95 +50,161 @@ static inline void seq_counts(const unsigned char *a, const unsigned char *b, in
     *nDiff = diff;
 }
 
-/* One sweep of `node` against every node below maxnode; inactive targets get the reference's sentinel.  nt, no matrix,
-   float.  nThreads <= 0: OpenMP's default. */
-void vfto_avx2_sweep_f32(const vfto_state_f32 *st, int64_t node, int64_t nActive, const float *outDist, const int64_t *nOutActive,
-                         float *hit_weight, float *hit_dist, float *hit_crit, int nThreads) {
+/* the per-(column, code) addends of a leaf target against a profile query: code c -> (wgt * (1 - fq[c]), wgt), or
+   (wgt * (cq == c ? 0 : 1), wgt) when the query holds a code; nothing for gaps on either side.  NULL for a leaf query. */
+static double *query_table(const vfto_state_f32 *st, int64_t node) {
+    const int64_t nPos = st->nPos;
+    if (node < st->nSeqs) return NULL;
+    const float *wq = st->W + node * nPos, *fq = st->F + node * nPos * 4;
+    const unsigned char *cq = st->C + node * nPos;
+    double *tab = (double *) malloc((size_t) nPos * 8 * sizeof(double));
+    for (int64_t p = 0; p < nPos; p++) {
+        const int qvec = wq[p] > 0 && cq[p] == VFTO_NOCODE;
+        for (int c = 0; c < 4; c++) {
+            double term = 0, wgt = 0;
+            if (wq[p] > 0 && (qvec || cq[p] != VFTO_NOCODE)) {
+                const float ww = wq[p] * 1.0f;
+                wgt = (double) ww;
+                const double piece = qvec ? 1.0 - (double) fq[p * 4 + c] : (cq[p] == c ? 0.0 : 1.0);
+                term = wgt * piece;
+            }
+            tab[p * 8 + c] = term;
+            tab[p * 8 + 4 + c] = wgt;
+        }
+    }
+    return tab;
+}
+
+/* one target of a sweep: seqDist / profileDist + the criterion; inactive targets get the reference's sentinel */
+static inline void sweep_target(const vfto_state_f32 *st, const double *tab, int64_t node, int64_t j, int64_t nActive,
+                                const float *outDist, const int64_t *nOutActive, float *hit_weight, float *hit_dist, float *hit_crit) {
     const int64_t nPos = st->nPos, nSeqs = st->nSeqs;
     const float *wq = st->W + node * nPos, *fq = st->F + node * nPos * 4;
     const unsigned char *cq = st->C + node * nPos;
     const int qLeaf = node < nSeqs;
-    /* per-(column, code) addends of a leaf target against a profile query: code c -> (wgt * (1 - fq[c]), wgt), or
-       (wgt * (cq == c ? 0 : 1), wgt) when the query holds a code; nothing for gaps on either side */
-    double *tab = NULL;
-    if (!qLeaf) {
-        tab = (double *) malloc((size_t) nPos * 8 * sizeof(double));
-        for (int64_t p = 0; p < nPos; p++) {
-            const int qvec = wq[p] > 0 && cq[p] == VFTO_NOCODE;
-            for (int c = 0; c < 4; c++) {
-                double term = 0, wgt = 0;
-                if (wq[p] > 0 && (qvec || cq[p] != VFTO_NOCODE)) {
-                    const float ww = wq[p] * 1.0f;
-                    wgt = (double) ww;
-                    const double piece = qvec ? 1.0 - (double) fq[p * 4 + c] : (cq[p] == c ? 0.0 : 1.0);
-                    term = wgt * piece;
+    if (st->parent[j] >= 0) {
+        hit_weight[j] = 0;
+        hit_crit[j] = hit_dist[j] = 1e20f;
+        return;
+    }
+    float d, w;
+    if (qLeaf && j < nSeqs) {
+        int64_t nUse, nDiff;
+        seq_counts(cq, st->C + j * nPos, nPos, &nUse, &nDiff);
+        w = (float) (double) nUse;
+        d = (float) (nUse > 0 ? (double) nDiff / (double) nUse : 1.0);
+    } else {
+        double top = 0, denom = 0;
+        const unsigned char *ct = st->C + j * nPos;
+        if (!qLeaf && j < nSeqs) {
+            for (int64_t p = 0; p < nPos; p++) {
+                const unsigned c = ct[p];
+                if (c < 4) {
+                    denom += tab[p * 8 + 4 + c];
+                    top += tab[p * 8 + c];
                 }
-                tab[p * 8 + c] = term;
-                tab[p * 8 + 4 + c] = wgt;
+            }
+        } else {
+            const float *wt = st->W + j * nPos, *ft = st->F + j * nPos * 4;
+            for (int64_t p = 0; p < nPos; p++) {
+                if (!(wq[p] > 0 && wt[p] > 0)) continue;
+                const float ww = wq[p] * wt[p];
+                const double wgt = (double) ww;
+                denom += wgt;
+                const int c1 = cq[p], c2 = ct[p];
+                double piece;
+                if (c1 != VFTO_NOCODE) {
+                    if (c2 != VFTO_NOCODE) piece = c1 == c2 ? 0.0 : 1.0;
+                    else piece = 1.0 - (double) ft[p * 4 + c1];
+                } else if (c2 != VFTO_NOCODE) {
+                    piece = 1.0 - (double) fq[p * 4 + c2];
+                } else {
+                    float pr[4];
+                    _mm_storeu_ps(pr, _mm_mul_ps(_mm_loadu_ps(fq + p * 4), _mm_loadu_ps(ft + p * 4)));
+                    piece = 1.0;
+                    piece -= (double) pr[0];
+                    piece -= (double) pr[1];
+                    piece -= (double) pr[2];
+                    piece -= (double) pr[3];
+                }
+                top += wgt * piece;
             }
         }
+        w = (float) (denom > 0 ? denom : 0.01);
+        d = (float) (denom > 0 ? top / denom : 1.0);
+        const float dd = st->diameter[node] + st->diameter[j];
+        d = d - dd;
     }
+    hit_dist[j] = d;
+    hit_weight[j] = w;
+    hit_crit[j] = criterion_f32(d, outDist[node], nOutActive[node], outDist[j], nOutActive[j], nActive);
+}
+
+/* One sweep of `node` against every node below maxnode; inactive targets get the reference's sentinel.  nt, no matrix,
+   float.  nThreads <= 0: OpenMP's default. */
+void vfto_avx2_sweep_f32(const vfto_state_f32 *st, int64_t node, int64_t nActive, const float *outDist, const int64_t *nOutActive,
+                         float *hit_weight, float *hit_dist, float *hit_crit, int nThreads) {
+    double *tab = query_table(st, node);
     if (nThreads <= 0) nThreads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nThreads)
-    for (int64_t j = 0; j < st->maxnode; j++) {
-        if (st->parent[j] >= 0) {
-            hit_weight[j] = 0;
-            hit_crit[j] = hit_dist[j] = 1e20f;
-            continue;
-        }
-        float d, w;
-        if (qLeaf && j < nSeqs) {
-            int64_t nUse, nDiff;
-            seq_counts(cq, st->C + j * nPos, nPos, &nUse, &nDiff);
-            w = (float) (double) nUse;
-            d = (float) (nUse > 0 ? (double) nDiff / (double) nUse : 1.0);
-        } else {
-            double top = 0, denom = 0;
-            const unsigned char *ct = st->C + j * nPos;
-            if (!qLeaf && j < nSeqs) {
-                for (int64_t p = 0; p < nPos; p++) {
-                    const unsigned c = ct[p];
-                    if (c < 4) {
-                        denom += tab[p * 8 + 4 + c];
-                        top += tab[p * 8 + c];
-                    }
-                }
-            } else {
-                const float *wt = st->W + j * nPos, *ft = st->F + j * nPos * 4;
-                for (int64_t p = 0; p < nPos; p++) {
-                    if (!(wq[p] > 0 && wt[p] > 0)) continue;
-                    const float ww = wq[p] * wt[p];
-                    const double wgt = (double) ww;
-                    denom += wgt;
-                    const int c1 = cq[p], c2 = ct[p];
-                    double piece;
-                    if (c1 != VFTO_NOCODE) {
-                        if (c2 != VFTO_NOCODE) piece = c1 == c2 ? 0.0 : 1.0;
-                        else piece = 1.0 - (double) ft[p * 4 + c1];
-                    } else if (c2 != VFTO_NOCODE) {
-                        piece = 1.0 - (double) fq[p * 4 + c2];
-                    } else {
-                        float pr[4];
-                        _mm_storeu_ps(pr, _mm_mul_ps(_mm_loadu_ps(fq + p * 4), _mm_loadu_ps(ft + p * 4)));
-                        piece = 1.0;
-                        piece -= (double) pr[0];
-                        piece -= (double) pr[1];
-                        piece -= (double) pr[2];
-                        piece -= (double) pr[3];
-                    }
-                    top += wgt * piece;
-                }
-            }
-            w = (float) (denom > 0 ? denom : 0.01);
-            d = (float) (denom > 0 ? top / denom : 1.0);
-            const float dd = st->diameter[node] + st->diameter[j];
-            d = d - dd;
-        }
-        hit_dist[j] = d;
-        hit_weight[j] = w;
-        hit_crit[j] = criterion_f32(d, outDist[node], nOutActive[node], outDist[j], nOutActive[j], nActive);
-    }
+    for (int64_t j = 0; j < st->maxnode; j++)
+        sweep_target(st, tab, node, j, nActive, outDist, nOutActive, hit_weight, hit_dist, hit_crit);
     free(tab);
+}
+
+/* The timed leg of bench.py's cpu_baseline: the same sweeps over a copy of the state that the OpenMP team itself
+   allocates and FIRST-TOUCHES - targets are dealt to the threads in blocks of VFTO_BENCH_BLOCK (schedule(static, block)),
+   the same thread initialises and later sweeps a block, so every thread streams memory of its own NUMA node (a numpy
+   array is first-touched by one thread: 128 cores then share one node's bandwidth).  Sweeps the queries round-robin
+   until `budget` seconds have passed (at least once each); returns the seconds spent inside the sweeps and the number
+   of sweeps in *nDone.  The last sweep's results come back in hit_* (maxnode floats each) for the bit-identity check. */
+#define VFTO_BENCH_BLOCK 64
+double vfto_avx2_sweep_bench_f32(const vfto_state_f32 *st, const int64_t *queries, int64_t nQueries, int64_t nActive,
+                                 const float *outDist, const int64_t *nOutActive, int nThreads, double budget,
+                                 float *hit_weight, float *hit_dist, float *hit_crit, int64_t *nDone) {
+    const int64_t n = st->maxnode, nPos = st->nPos;
+    if (nThreads <= 0) nThreads = omp_get_max_threads();
+    vfto_state_f32 loc = *st;
+    float *W = (float *) malloc((size_t) n * nPos * sizeof(float)), *F = (float *) malloc((size_t) n * nPos * 4 * sizeof(float));
+    unsigned char *Cc = (unsigned char *) malloc((size_t) n * nPos);
+    int64_t *par = (int64_t *) malloc((size_t) n * sizeof(int64_t)), *nOut = (int64_t *) malloc((size_t) n * sizeof(int64_t));
+    float *diam = (float *) malloc((size_t) n * sizeof(float)), *od = (float *) malloc((size_t) n * sizeof(float));
+    float *hw = (float *) malloc((size_t) n * sizeof(float)), *hd = (float *) malloc((size_t) n * sizeof(float)),
+          *hc = (float *) malloc((size_t) n * sizeof(float));
+#pragma omp parallel for schedule(static, VFTO_BENCH_BLOCK) num_threads(nThreads)
+    for (int64_t j = 0; j < n; j++) {
+        memcpy(W + j * nPos, st->W + j * nPos, (size_t) nPos * sizeof(float));
+        memcpy(F + j * nPos * 4, st->F + j * nPos * 4, (size_t) nPos * 4 * sizeof(float));
+        memcpy(Cc + j * nPos, st->C + j * nPos, (size_t) nPos);
+        par[j] = st->parent[j];
+        diam[j] = st->diameter[j];
+        od[j] = outDist[j];
+        nOut[j] = nOutActive[j];
+        hw[j] = hd[j] = hc[j] = 0;
+    }
+    loc.W = W;
+    loc.F = F;
+    loc.C = Cc;
+    loc.parent = par;
+    loc.diameter = diam;
+    int64_t done = 0;
+    double spent = 0;
+    while (done < nQueries || spent < budget) {
+        const int64_t node = queries[done % nQueries];
+        double *tab = query_table(&loc, node);
+        const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static, VFTO_BENCH_BLOCK) num_threads(nThreads)
+        for (int64_t j = 0; j < n; j++) sweep_target(&loc, tab, node, j, nActive, od, nOut, hw, hd, hc);
+        spent += omp_get_wtime() - t0;
+        free(tab);
+        done++;
+    }
+    if (hit_weight) memcpy(hit_weight, hw, (size_t) n * sizeof(float));
+    if (hit_dist) memcpy(hit_dist, hd, (size_t) n * sizeof(float));
+    if (hit_crit) memcpy(hit_crit, hc, (size_t) n * sizeof(float));
+    *nDone = done;
+    free(W); free(F); free(Cc); free(par); free(nOut); free(diam); free(od); free(hw); free(hd); free(hc);
+    return spent;
 }
 
 int vfto_avx2_max_threads(void) { return omp_get_max_threads(); }

@@ -199,6 +199,23 @@ class Oracle:
             fn(C.byref(st), I64(node), I64(n_active), _ptr(od), _ptr(na), _ptr(hw), _ptr(hd), _ptr(hc), C.c_int(threads))
         return dict(weight=hw, dist=hd, crit=hc)
 
+    def avx2_sweep_bench(self, st, queries, n_active, out_dist, n_out_active, threads=0, budget=5.0):
+        """bench.py's timed CPU leg (vfto_avx2_sweep_bench_f32): the sweeps of `queries`, round-robin for `budget` seconds,
+        over a copy of the state that the OpenMP team allocates and first-touches itself.  Returns (seconds inside the
+        sweeps, sweeps done, dict of the last sweep's weight / dist / crit)."""
+        assert self.dt == np.float32
+        n = st.maxnode
+        od = self.arr(out_dist)
+        na = np.ascontiguousarray(n_out_active, np.int64)
+        q = np.ascontiguousarray(queries, np.int64)
+        hw, hd, hc = np.zeros(n, self.dt), np.zeros(n, self.dt), np.zeros(n, self.dt)
+        done = I64(0)
+        fn = _avx2().vfto_avx2_sweep_bench_f32
+        fn.restype = C.c_double
+        secs = fn(C.byref(st), _ptr(q), I64(len(q)), I64(n_active), _ptr(od), _ptr(na), C.c_int(threads), C.c_double(budget),
+                  _ptr(hw), _ptr(hd), _ptr(hc), C.byref(done))
+        return float(secs), int(done.value), dict(weight=hw, dist=hd, crit=hc)
+
     def sort_hits(self, crit):
         crit = self.arr(crit)
         order = np.zeros(len(crit), np.int64)

@@ -1,0 +1,42 @@
+"""bench.py --gpus N starts its N ranks by itself (child processes through torch.distributed.run, rendezvous on
+127.0.0.1) when no launcher is around it - the form the round driver uses.  CPU test: the launch-only hook runs the
+launcher, the rendezvous (gloo) and one collective, and prints a line with n_gpus = N; no GPU work."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_gpus_n_spawns_n_ranks(n):
+    env = dict(os.environ, VFT_BENCH_LAUNCH_ONLY="1", VFT_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout.decode()
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["world"] == n
+    assert line["rank_sum"] == n * (n + 1) / 2      # every rank took part in the collective
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, VFT_BENCH_LAUNCH_ONLY="1", WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode != 0 and b"WORLD_SIZE" in res.stderr
+
+
+def test_a_failing_rank_fails_the_launcher():
+    env = dict(os.environ, VFT_BENCH_LAUNCH_ONLY="1", VFT_BENCH_BACKEND="no-such-backend")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode != 0

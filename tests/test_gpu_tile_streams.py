@@ -308,7 +308,7 @@ def test_fused_join_and_block_distances_equal_the_separate_calls(ncodes):
 def test_out_profile_chain_kernel_equals_the_column_walk(ncodes, matrix):
     """vft_out_profile_full over all active nodes (k_leaf_hist + vft_iterate_add for matrix-free nucleotide leaves,
     k_outprofile_chain with LDS-staged addends for the rest) against the one-thread-per-column walk over the same list
-    (k_outprofile_full, forced through VFT_DEBUG_GENERIC_OUTPROFILE), bit for bit: 5000 leaves with gaps, 3000 joins,
+    (k_outprofile_full, forced through vft_debug_option), bit for bit: 5000 leaves with gaps, 3000 joins,
     f32 and f64, with and without a distance matrix."""
     import os
     from veryfasttree_amd import HipProfileOps, synth
@@ -324,12 +324,12 @@ def test_out_profile_chain_kernel_equals_the_column_walk(ncodes, matrix):
         ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
         ops.outProfile(np.arange(n))
         first = ops.out_profile_download(matrix)
-        os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"] = "1"
+        ops.debug_option(4, 1)
         try:
             ops.outProfile(np.arange(n))
             ref = ops.out_profile_download(matrix)
         finally:
-            del os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"]
+            ops.debug_option(4, 0)
         assert all(np.array_equal(x, y) for x, y in zip(first[0], ref[0]))
         assert first[1] is None or np.array_equal(first[1], ref[1])
         active = list(range(n))
@@ -343,12 +343,12 @@ def test_out_profile_chain_kernel_equals_the_column_walk(ncodes, matrix):
                 ids = np.array(sorted(active))
                 ops.outProfile(ids)
                 got = ops.out_profile_download(matrix)
-                os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"] = "1"
+                ops.debug_option(4, 1)
                 try:
                     ops.outProfile(ids)
                     ref = ops.out_profile_download(matrix)
                 finally:
-                    del os.environ["VFT_DEBUG_GENERIC_OUTPROFILE"]
+                    ops.debug_option(4, 0)
                 assert all(np.array_equal(x, y) for x, y in zip(got[0], ref[0])), (k, dt)
                 assert got[1] is None or np.array_equal(got[1], ref[1])
         ops.close()
@@ -362,8 +362,6 @@ def test_pair_list_with_refreshes_in_one_call(fused, monkeypatch):
     every out-distance / stamp afterwards, bit for bit; leaves and internal nodes, nodes named many times, a forced node
     that is also a pair end, a forced node whose stamp is already current."""
     from veryfasttree_amd import HipProfileOps, synth
-    if not fused:
-        monkeypatch.setenv("VFT_NO_FUSED_REFRESH", "1")
     n, L, nj = 400, 190, 200
     codes = synth.random_descent_codes(n, L, 4, 0.05, 0.05, seed=31)
     for dt in (np.float32, np.float64):
@@ -371,6 +369,8 @@ def test_pair_list_with_refreshes_in_one_call(fused, monkeypatch):
         for _ in range(2):
             rng = np.random.default_rng(12)       # the same draws for both contexts
             ops = HipProfileOps(n, L, 4, dt, max_nodes=2 * n)
+            if not fused:
+                ops.debug_option(1, 1)   # VFT_DEBUG_NO_FUSED_REFRESH
             ops.upload_leaves(codes)
             ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
             ops.outProfile(np.arange(n))
@@ -402,5 +402,16 @@ def test_pair_list_with_refreshes_in_one_call(fused, monkeypatch):
         d2, w2, c2 = o2.setDistCriterion(pi, pj, nact, 5, 2.5)
         assert np.array_equal(d1, d2) and np.array_equal(w1, w2) and np.array_equal(c1, c2)
         assert all(np.array_equal(x, y) for x, y in zip(o1.get_out_distances(0, n + nj), o2.get_out_distances(0, n + nj)))
+        # one pair and many forced nodes that are no end of it: nobody waits for those refresh workgroups but the publishing
+        # one; the host-mapped mirrors must hold every forced refresh the moment the call returns (no synchronisation here)
+        for rep in range(20):
+            far = np.array([v for v in active if v not in (active[0], active[1])][rep:rep + 120], np.int64)
+            o1.set_out_distances(0, np.zeros(n + nj, dt), np.full(n + nj, nact + 7, np.int64))
+            o1.setDistCriterionRefresh(np.array([active[0]], np.int64), np.array([active[1]], np.int64), far, nact, 50, 2.5)
+            mo, mn = o1.out_distance_mirror()
+            assert np.all(mn[far] == nact), rep
+            o2.set_out_distances(0, np.zeros(n + nj, dt), np.full(n + nj, nact + 7, np.int64))
+            o2.setOutDistance(far, nact, 2.5)
+            assert np.array_equal(mo[far], o2.get_out_distances(0, n + nj)[0][far]), rep
         o1.close()
         o2.close()

@@ -305,3 +305,10 @@ def test_avx2_sweep_equals_scalar_oracle(name):
                 got = orc.avx2_sweep(st, q, n_active, od, na, threads=threads)
                 for key in ("dist", "weight", "crit"):
                     assert np.array_equal(got[key], want[key]), (name, mid, q, key, threads)
+        # the timed leg of bench.py (its own first-touched copy of the state, static blocks): same bits; the last sweep it
+        # returns is the last query's
+        secs, done, got = orc.avx2_sweep_bench(st, queries, n_active, od, na, threads=3, budget=0.0)
+        assert done == len(queries) and secs > 0
+        want = orc.set_best_hit(st, queries[-1], n_active, 10 ** 9, od, na)
+        for key in ("dist", "weight", "crit"):
+            assert np.array_equal(got[key], want[key]), (name, mid, key, "bench leg")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of one pair-list call (vft_pair_distances: a hub node against n partners, as after a join) on the 1M x 200
-benchmark state, by list length.  VFT_PAIR_WG=64|128|256 overrides the threads per pair.  usage: microbench_pairlist.py"""
+benchmark state, by list length.  usage: microbench_pairlist.py [threads per pair: 64|128|256]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,8 @@ from veryfasttree_amd.workload import TopHitsState
 n, L = 1000000, 200
 codes = synth.random_descent_codes(n, L, 4, 0.02, 0.01, seed=4)
 ops = HipProfileOps(n, L, 4, np.float32)
+pair_threads = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ops.debug_option(2, pair_threads)   # VFT_DEBUG_PAIR_THREADS (0 = the library's own choice)
 st = TopHitsState(ops, codes, n // 4)
 rng = np.random.default_rng(1)
 act = np.array(st.active)
@@ -26,7 +28,7 @@ for cnt in (1, 64, 512, 1024, 2000):
         reps = 200
         for _ in range(reps):
             ops.setDistCriterion(pi, pj, st.n_active, st.n_diff_allow, st.totdiam)
-        print("%5d pairs, hub vs %-8s  %7.1f us / call (VFT_PAIR_WG=%s)" % (cnt, mix, (time.perf_counter() - t0) / reps * 1e6, os.environ.get("VFT_PAIR_WG", "default")))
+        print("%5d pairs, hub vs %-8s  %7.1f us / call (threads per pair: %s)" % (cnt, mix, (time.perf_counter() - t0) / reps * 1e6, pair_threads or "default"))
         if cnt >= 512 and mix == "internal":   # the hub needs a refresh in every call (as right after a join): the single-launch variant
             od, na = ops.get_out_distances(hub, 1)
             t0 = time.perf_counter()

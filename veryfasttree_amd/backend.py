@@ -27,7 +27,7 @@ EXPORTS = [
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
-    "vft_debug_log", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
+    "vft_debug_log", "vft_debug_option", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
 ]
 
 
@@ -407,6 +407,15 @@ class HipProfileOps:
         self._chk(self.lib.vft_join_fused(self.ctx, I64(i), I64(j), I64(newnode), C.c_double(diameter), I64(stale_stamp),
                                           I64(n_active_old), C.c_int32(1 if update_out_profile else 0)))
 
+    def out_distance_mirror(self):
+        """numpy views of the host-mapped mirrors of outDistances[] / nOutDistActive[] (vft_out_distance_mirror): what the
+        host driver reads without a device call; valid while the context lives."""
+        po, pn = C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.vft_out_distance_mirror(self.ctx, C.byref(po), C.byref(pn)))
+        od = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_float if self.dt == np.float32 else C.c_double)), shape=(self.max_nodes,))
+        na = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_int32)), shape=(self.max_nodes,))
+        return od, na
+
     def get_out_distances(self, first, count):
         od = np.zeros(count, self.dt)
         na = np.zeros(count, np.int64)
@@ -623,6 +632,10 @@ class HipProfileOps:
         l2 = np.ascontiguousarray(len2, np.float64)
         self._chk(self.lib.vft_posterior_profiles(self.ctx, I64(len(out)), _ptr(out), _ptr(a), _ptr(b), _ptr(l1),
                                                   _ptr(l2)))
+
+    def debug_option(self, option, value):
+        """test hook (include/vft_hip.h VFT_DEBUG_*): 1 no fused refresh, 2 threads per pair, 3 no pair staging, 4 generic out-profile"""
+        self._chk(self.lib.vft_debug_option(self.ctx, C.c_int32(option), I64(value)))
 
     def debug_log(self, x):
         """log(x) as the ML kernels evaluate it on the device (glibc's algorithm): diagnostics."""

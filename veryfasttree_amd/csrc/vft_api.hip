@@ -50,8 +50,11 @@ struct vft_ctx {
     ColOff *colOff = nullptr;
     std::vector<int32_t> hParent;          // host copy of parent[], to recognise "all active nodes, ascending" lists
     unsigned long long *tileMask = nullptr;
-    bool noFusedRefresh = getenv("VFT_NO_FUSED_REFRESH") != nullptr;   // tools: A/B the single-launch pair lists
-    int pairWG = getenv("VFT_PAIR_WG") ? atoi(getenv("VFT_PAIR_WG")) : 0;   // tools: threads per pair of the short-list kernels
+    // test / tool hooks, set through vft_debug_option only (no environment variable changes which kernels run)
+    bool noFusedRefresh = false;   // VFT_DEBUG_NO_FUSED_REFRESH: pair lists with refreshes as two launches
+    int pairWG = 0;                // VFT_DEBUG_PAIR_THREADS: threads per pair of the short-list kernels
+    bool genericOutProfile = false;   // VFT_DEBUG_GENERIC_OUTPROFILE: the one-thread-per-column out-profile kernel
+    int fusedLimit = 2048;         // workgroups of k_pairs_refresh_fused that are resident at once (set by vft_create)
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -116,7 +119,7 @@ struct vft_ctx {
     unsigned long long *hFlag = nullptr, *dFlag = nullptr, signalSeq = 0;
     unsigned int *doneCtr = nullptr;   // completion counter of k_pairs_fused
     void *pairIn = nullptr;            // device copy of the ids of a short pair list (k_copy16x2)
-    bool noPairStaging = getenv("VFT_NO_PAIR_STAGING") != nullptr;   // tools: A/B
+    bool noPairStaging = false;        // VFT_DEBUG_NO_PAIR_STAGING
     void *pairStage = nullptr;         // device staging of the results of lists of up to VFT_PAIR_STAGE_CAP pairs
     // Upper bound of nOutActive over the nodes of the shard (host bookkeeping; VFT_STAMP_UNKNOWN = no bound): lets
     // vft_sweep skip its lazy out-distance pre-pass when provably no target can be stale.
@@ -1011,6 +1014,16 @@ static int raise_pair_kernel_lds(vft_ctx *c) {
     c->pwWaves = 4;
     while (c->pwWaves > 1 && pw_lds_bytes(c) > (160u << 10)) c->pwWaves >>= 1;
     const size_t bytes = pw_lds_bytes(c);
+    {   // how many workgroups of the single-launch pair list are resident at once (its pair workgroups wait for refresh
+        // workgroups of the same grid, so the host only uses it while the whole grid fits)
+        int dev = 0, cus = 0, perCU = 0;
+        HIPCHK(c, hipGetDevice(&dev));
+        HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const size_t lds = bytes / c->pwWaves;
+        hipError_t e = hipErrorUnknown;
+        VFT_DISPATCH(c, (e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *) k_pairs_refresh_fused<REAL, NC>, VFT_WG, lds)));
+        c->fusedLimit = (e == hipSuccess && perCU > 0 && cus > 0) ? std::min(4096, perCU * cus) : 256;
+    }
     if (bytes <= (48u << 10)) return VFT_OK;
     if (bytes > (160u << 10)) return fail(c, VFT_ERR_INVALID, "alignment too long for the pair kernels' LDS staging (%lld columns, limit 10240)", (long long) c->d.nPos);
     VFT_DISPATCH(c, {
@@ -1196,7 +1209,7 @@ extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
     if (int r = flush_pending(c)) return r;
     // fast path: the list is exactly the active nodes below maxnode in ascending order (what the join loop passes,
     // NJ.tcc:3017-3031): k_outprofile_chain, with the leaves of a matrix-free nucleotide alignment folded into a histogram
-    bool tiled = getenv("VFT_DEBUG_GENERIC_OUTPROFILE") == nullptr;   // tests: the one-thread-per-column kernel as the reference
+    bool tiled = !c->genericOutProfile;   // tests (vft_debug_option): the one-thread-per-column kernel as the reference
     if (tiled) {
         int64_t k = 0;
         for (int64_t v = 0; v < c->maxnode && tiled; v++) {
@@ -1783,7 +1796,9 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     const size_t sB = (((size_t) nStale * 8) + 255) & ~(size_t) 255;
     const size_t wB = (((size_t) n * 8) + 255) & ~(size_t) 255;   // per-pair wait indices of the single-launch variant
     const bool small = 2 * idB + 3 * oB + sB + wB <= VFT_SMALL_BYTES;
-    bool fusedRefresh = small && nStale > 0 && n <= 2048 && n + nStale <= 4096 && !c->noFusedRefresh;
+    // (the pair workgroups of the single-launch variant spin on tags of refresh workgroups of the same grid: only while the
+    //  whole grid is resident at once, whatever order the dispatcher picks)
+    bool fusedRefresh = small && nStale > 0 && n <= 2048 && n + nStale <= c->fusedLimit && !c->noFusedRefresh;
     if (fusedRefresh && !c->refDone) {
         HIPCHK(c, hipMalloc((void **) &c->refDone, 4096 * sizeof(unsigned int)));
         HIPCHK(c, hipMemsetAsync(c->refDone, 0, 4096 * sizeof(unsigned int), c->stream));
@@ -2555,6 +2570,18 @@ extern "C" int vft_split_supports(vft_ctx *c, int64_t n, const int64_t *a, const
 __global__ void k_debug_log(const double *x, double *out, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = vft_glibc_log(x[i]);
+}
+
+extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
+    if (!c) return VFT_ERR_INVALID;
+    switch (option) {
+        case VFT_DEBUG_NO_FUSED_REFRESH: c->noFusedRefresh = value != 0; break;
+        case VFT_DEBUG_PAIR_THREADS: c->pairWG = (int) value; break;
+        case VFT_DEBUG_NO_PAIR_STAGING: c->noPairStaging = value != 0; break;
+        case VFT_DEBUG_GENERIC_OUTPROFILE: c->genericOutProfile = value != 0; break;
+        default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
+    }
+    return VFT_OK;
 }
 
 extern "C" int vft_debug_log(vft_ctx *c, int64_t n, const double *x, double *out) {

@@ -899,9 +899,13 @@ __device__ __forceinline__ void vft_stage_store(REAL *stage, int64_t cap, int64_
     __hip_atomic_store(&stage[2 * cap + t], cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// refDone / nRef: completion tags of refresh workgroups of the SAME launch (k_pairs_refresh_fused) that the publishing
+// workgroup has to see before the host may: a forced refresh that is not an end of any listed pair is awaited by no pair
+// workgroup, and the host reads its mirrors as soon as the flag moves.
 template <typename REAL>
 __device__ __forceinline__ void vft_publish_staged(const REAL *stage, int64_t cap, int64_t n, REAL *dist, REAL *weight, REAL *crit,
-                                                   unsigned int *doneCtr, unsigned long long *flag, unsigned long long seq) {
+                                                   unsigned int *doneCtr, unsigned long long *flag, unsigned long long seq,
+                                                   const unsigned int *refDone = nullptr, int64_t nRef = 0) {
     __shared__ int isLast;
     if (threadIdx.x == 0) {
         // The staged results were written by THIS thread with agent-scope atomic stores (vft_stage_store): they go to the
@@ -923,6 +927,10 @@ __device__ __forceinline__ void vft_publish_staged(const REAL *stage, int64_t ca
     }
     __syncthreads();
     if (!isLast) return;
+    for (int64_t b = threadIdx.x; b < nRef; b += blockDim.x)   // every refresh workgroup of this launch has published
+        while (__hip_atomic_load(&refDone[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned int) seq) __builtin_amdgcn_s_sleep(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     __threadfence();       // (one fence, in the one workgroup that goes on)
     for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
         dist[t] = __hip_atomic_load(&stage[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1033,11 +1041,13 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, c
             vft_pair_block<REAL, NC>(A, v, -1, true, pwLds, pwLds + A.d.nPosPad, d, w);
             if (threadIdx.x == 0) {
                 const REAL od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
-                A.outDist[v] = od;
-                A.nOutActive[v] = (int32_t) s.nActive;
+                // agent-scope atomic stores: they pair with the pair workgroups' agent-scope atomic loads below
+                __hip_atomic_store(&A.outDist[v], od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.nOutActive[v], (int32_t) s.nActive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 A.mOutDist[v] = od;
                 A.mNOut[v] = (int32_t) s.nActive;
                 __threadfence_system();   // the host-mapped mirrors must be out before any pair result that used them is
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         if (threadIdx.x == 0) __hip_atomic_store(&refDone[b], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1061,6 +1071,9 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, c
             while (__hip_atomic_load(&refDone[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
         if (wj >= 0)
             while (__hip_atomic_load(&refDone[wj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+        // nothing below may be issued before the polls have returned (compiler and hardware): the loads that follow go to
+        // different addresses and are relaxed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (out-distances of ends nobody refreshes in this launch were written by earlier launches)
         const REAL oi = __hip_atomic_load(&A.outDist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const REAL oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1068,7 +1081,7 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_refresh_fused(Arena<REAL> A, c
         const int32_t sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         vft_stage_store<REAL>(stage, stageCap, t, d, w, vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive));
     }
-    vft_publish_staged<REAL>(stage, stageCap, n, dist, weight, crit, doneCtr, flag, seq);
+    vft_publish_staged<REAL>(stage, stageCap, n, dist, weight, crit, doneCtr, flag, seq, refDone, nStale);
 }
 
 // The cross product of two node lists (any mix of leaves and internal nodes): dist[a * nB + b] = the join distance of

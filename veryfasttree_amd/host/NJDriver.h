@@ -4,8 +4,8 @@
 // profile operation goes through a batched device call, while the control flow and the scalar formulas the
 // reference evaluates on the host (criterion :1099-1107, branch lengths :2911-2916, diameters :3003) stay here, with
 // the reference's float/double mix.  Join order is pinned against the reference's `Join` lines
-// (tests/golden/bb_*.npz; tests/test_gpu_nj_driver.py).  The same logic exists as a Python prototype
-// (veryfasttree_amd/nj_driver.py) that also runs on the CPU oracle for debugging.
+// (tests/golden/bb_*.npz; tests/test_gpu_nj_driver.py).  The same logic exists as a Python restatement among the
+// tests (tests/nj_driver_py.py) that also runs on the CPU oracle for debugging.
 //
 // Scope: deterministic single-thread semantics, default options, `-fastest` (with its second-level top-hit lists) and
 // `-fastest -no2nd`; no constraints, no BIONJ weighting, top-hits on (m >= 4 and 2m < nSeqs).
