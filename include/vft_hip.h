@@ -118,6 +118,47 @@ int vft_join_nodes(vft_ctx *ctx, int64_t i, int64_t j, int64_t newnode, double d
 int vft_join_fused(vft_ctx *ctx, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t stale_stamp,
                    int64_t n_active_old, int32_t update_out_profile);
 
+/* ---- top-hit lists on the device (TopHits / TopHitsList / Hit, NJ.h:206-248)
+ * The lists of fastNJ's top-hits heuristic live in HBM: `m` entries of {int32 j; numeric_t dist} (vft_tophit_f32 /
+ * vft_tophit_f64) for each of the first n_lists node ids.  The three list walks of a join are one launch each and return
+ * only their result (veryfasttree_amd/csrc/vft_kernels_tophits.h). */
+typedef struct { int32_t j; float dist; } vft_tophit_f32;
+typedef struct { int32_t j; int32_t pad; double dist; } vft_tophit_f64;   /* = struct {int32_t j; double dist;} */
+typedef struct { int32_t j, pos; double dist, criterion; } vft_tophits_best_t;
+typedef struct { int32_t n_unique, use_unique, n_save, pad; } vft_tophits_join_t;
+int vft_tophits_create(vft_ctx *ctx, int32_t m, int64_t n_lists);
+/* lists of `count` nodes in one piece: packed = count x m entries (list t at packed[t * m]), lens[t] of them valid */
+int vft_tophits_upload(vft_ctx *ctx, int64_t count, const int64_t *nodes, const int32_t *lens, const void *packed);
+int vft_tophits_download(vft_ctx *ctx, int64_t node, int32_t *len, void *hits /* m entries */);
+/* getBestFromTopHits (NJ.tcc:4267-4298) over the first `len` entries of node's list: every entry re-targeted to the active
+   ancestor of its partner (updateBestHit :1626-1648; new distance where the partner changed), lazy out-distance refreshes
+   (setCriterion :1092-1098), criterion; the first strict minimum in list order.  force_node != 0: setOutDistance(node) first
+   (:4273-4279).  The list itself is not changed.  out->j < 0: no usable entry. */
+int vft_tophits_best(vft_ctx *ctx, int64_t node, int32_t len, int64_t n_active, int64_t n_diff_allow, double totdiam,
+                     int32_t force_node, vft_tophits_best_t *out);
+/* The merge of the lists of the two children c0 (n0 entries) and c1 (n1) of the freshly joined `newnode`
+   (topHitJoin NJ.tcc:4319-4362 -> uniqueBestHits :4786-4833 -> sortSaveBestHits :4535-4578): one candidate per distinct
+   active ancestor of a listed partner, its distance against newnode, lazy refreshes, criteria; sorted by (criterion
+   ascending, partner id descending); used - i.e. its first min(n_unique, n_save_max) entries saved as newnode's list - when
+   n_unique == n_active - 1 or (age_ok and n_unique >= need).  info: counts and the decision; j / dist / criterion: the
+   n_unique sorted candidates (host arrays of n0 + n1 entries; dist / criterion in the context's precision).
+   n_active: the count after the join. */
+int vft_tophits_join(vft_ctx *ctx, int64_t newnode, int64_t c0, int32_t n0, int64_t c1, int32_t n1, int64_t n_active,
+                     int64_t n_diff_allow, double totdiam, int32_t n_save_max, int32_t need, int32_t age_ok,
+                     vft_tophits_join_t *info, int32_t *j, void *dist, void *criterion);
+
+/* The top-hits refresh of a join (topHitJoin's else-branch, NJ.tcc:4440-4517) once `newnode` has been swept (vft_sweep):
+   hit_j / hit_dist = the first n_hits (2m) records of its sorted hits (negative j: empty record); own_list = newnode's own
+   new list (n_own entries, what sortSaveBestHits keeps of the sweep); work = the active nodes among its first m hits, each
+   to receive the first 2 * n_new[t] swept hits: merged with the node's own re-targeted hits, one record per partner,
+   distances recomputed where the reference recomputes them, sorted, the first n_new[t] saved (uniqueBestHits :4786-4833,
+   sortSaveBestHits :4535-4578) - one workgroup per node, the m x 2m distances as one block.  lens[t] / first[t]: new length
+   and first entry (vft_tophit_*) of every list.  Every out-distance must be fresh enough already (:4451-4464).
+   VFT_ERR_STATE: lists too long for the merge kernel's LDS (the caller merges on the host). */
+int vft_tophits_refresh(vft_ctx *ctx, int64_t newnode, int32_t n_hits, const int64_t *hit_j, const void *hit_dist, int32_t n_own,
+                        const void *own_list, int64_t n_work, const int64_t *work, const int32_t *n_new, int64_t n_active,
+                        int64_t n_diff_allow, double totdiam, int32_t *lens, void *first);
+
 /* ---- profiles */
 int vft_profile_upload(vft_ctx *ctx, int64_t node, const void *w, const uint8_t *codes, const void *f);
 int vft_profile_download(vft_ctx *ctx, int64_t node, void *w, uint8_t *codes, void *f);

@@ -27,7 +27,7 @@ EXPORTS = [
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
     "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
-    "vft_debug_log", "vft_debug_option", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
+    "vft_debug_log", "vft_debug_option", "vft_tophits_create", "vft_tophits_upload", "vft_tophits_download", "vft_tophits_best", "vft_tophits_join", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
 ]
 
 
@@ -632,6 +632,50 @@ class HipProfileOps:
         l2 = np.ascontiguousarray(len2, np.float64)
         self._chk(self.lib.vft_posterior_profiles(self.ctx, I64(len(out)), _ptr(out), _ptr(a), _ptr(b), _ptr(l1),
                                                   _ptr(l2)))
+
+    # ---- top-hit lists on the device (include/vft_hip.h, vft_tophits_*)
+    @property
+    def tophit_dtype(self):
+        return np.dtype([("j", np.int32), ("dist", np.float32)]) if self.dt == np.float32 else \
+            np.dtype([("j", np.int32), ("pad", np.int32), ("dist", np.float64)])
+
+    def tophits_create(self, m, n_lists=None):
+        self.th_m = int(m)
+        self._chk(self.lib.vft_tophits_create(self.ctx, C.c_int32(m), I64(self.max_nodes if n_lists is None else n_lists)))
+
+    def tophits_upload(self, nodes, lists):
+        """lists: one (j[], dist[]) pair per node"""
+        nodes = _i64(nodes)
+        packed = np.zeros((len(nodes), self.th_m), self.tophit_dtype)
+        lens = np.zeros(len(nodes), np.int32)
+        for t, (j, d) in enumerate(lists):
+            lens[t] = len(j)
+            packed["j"][t, :len(j)] = j
+            packed["dist"][t, :len(j)] = d
+        self._chk(self.lib.vft_tophits_upload(self.ctx, I64(len(nodes)), _ptr(nodes), _ptr(lens), _ptr(packed)))
+
+    def tophits_download(self, node):
+        buf = np.zeros(self.th_m, self.tophit_dtype)
+        n = C.c_int32(0)
+        self._chk(self.lib.vft_tophits_download(self.ctx, I64(node), C.byref(n), _ptr(buf)))
+        return buf["j"][:n.value].copy(), buf["dist"][:n.value].copy()
+
+    def tophits_best(self, node, length, n_active, n_diff_allow, totdiam, force_node=True):
+        out = np.zeros(1, np.dtype([("j", np.int32), ("pos", np.int32), ("dist", np.float64), ("criterion", np.float64)]))
+        self._chk(self.lib.vft_tophits_best(self.ctx, I64(node), C.c_int32(length), I64(n_active), I64(n_diff_allow), C.c_double(totdiam),
+                                            C.c_int32(1 if force_node else 0), _ptr(out)))
+        return int(out["j"][0]), int(out["pos"][0]), self.dt.type(out["dist"][0]), self.dt.type(out["criterion"][0])
+
+    def tophits_join(self, newnode, c0, n0, c1, n1, n_active, n_diff_allow, totdiam, n_save_max, need, age_ok):
+        info = np.zeros(4, np.int32)
+        j = np.zeros(n0 + n1 + 1, np.int32)
+        d = np.zeros(n0 + n1 + 1, self.dt)
+        cr = np.zeros(n0 + n1 + 1, self.dt)
+        self._chk(self.lib.vft_tophits_join(self.ctx, I64(newnode), I64(c0), C.c_int32(n0), I64(c1), C.c_int32(n1), I64(n_active),
+                                            I64(n_diff_allow), C.c_double(totdiam), C.c_int32(n_save_max), C.c_int32(need),
+                                            C.c_int32(1 if age_ok else 0), _ptr(info), _ptr(j), _ptr(d), _ptr(cr)))
+        nu = int(info[0])
+        return dict(n_unique=nu, use_unique=bool(info[1]), n_save=int(info[2]), j=j[:nu], dist=d[:nu], criterion=cr[:nu])
 
     def debug_option(self, option, value):
         """test hook (include/vft_hip.h VFT_DEBUG_*): 1 no fused refresh, 2 threads per pair, 3 no pair staging, 4 generic out-profile"""

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvft_hip.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("vft_api.hip", "vft_ml_kernels_lengths.hip", "vft_ml_kernels_quartet32.hip",
                                              "vft_ml_kernels_quartet64.hip")]
-HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_aa.h", "vft_kernels_profile.h", "vft_kernels_ml.h", "vft_iterate_add.h", "vft_glibc_log.h",
+HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_aa.h", "vft_kernels_profile.h", "vft_kernels_tophits.h", "vft_kernels_ml.h", "vft_iterate_add.h", "vft_glibc_log.h",
            "vft_glibc_log_data.h"]   # deps of every unit
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"] + \
     os.environ.get("VFT_EXTRA_HIPCC_FLAGS", "").split()   # tools only, e.g. -DVFT_ABLATE (tools/ablate_sweep.py)
@@ -31,6 +31,25 @@ def build_host(force=False):
     return HOST_LIB
 
 
+ML_HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_profile.h", "vft_iterate_add.h", "vft_kernels_ml.h", "vft_glibc_log.h", "vft_glibc_log_data.h"]   # deps of the vft_ml_kernels_*.hip units
+OBJ_DIR = os.path.join(HERE, "..", "build", "obj")   # git-ignored; objects are kept so that a header change recompiles only its units
+
+
+def unit_deps(src):
+    if os.path.basename(src) != "vft_api.hip":   # the explicit-instantiation units see the ML kernels only
+        return [src] + [os.path.join(CSRC, h) for h in ML_HEADERS]
+    return [src] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "vft_hip.h")]
+
+
+def stale_units(force=False):
+    out = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in unit_deps(src)):
+            out.append((src, obj))
+    return out
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -42,17 +61,19 @@ def needs_build():
 def build(force=False):
     if force or needs_build():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        os.makedirs(OBJ_DIR, exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        # one hipcc per translation unit, in parallel (the line-search kernels of vft_ml_kernels.hip take as long as
-        # everything else together), then the link
-        objs = [os.path.join(os.path.dirname(LIB), os.path.basename(src) + ".o") for src in SOURCES]
-        jobs = [subprocess.Popen([hipcc] + FLAGS + ["-c", "-o", obj, src]) for src, obj in zip(SOURCES, objs)]
-        for src, job in zip(SOURCES, jobs):
+        # one hipcc per translation unit whose sources changed, in parallel (the line-search kernels of the
+        # vft_ml_kernels_*.hip units take as long as everything else together), then the link
+        todo = stale_units(force or bool(os.environ.get("VFT_EXTRA_HIPCC_FLAGS")))
+        jobs = [subprocess.Popen([hipcc] + FLAGS + ["-c", "-o", obj, src]) for src, obj in todo]
+        for (src, obj), job in zip(todo, jobs):
             if job.wait() != 0:
+                if os.path.exists(obj):
+                    os.remove(obj)
                 raise subprocess.CalledProcessError(job.returncode, "hipcc -c " + src)
+        objs = [os.path.join(OBJ_DIR, os.path.basename(src) + ".o") for src in SOURCES]
         subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs, check=True)
-        for obj in objs:
-            os.remove(obj)
     build_host(force)
     return LIB
 

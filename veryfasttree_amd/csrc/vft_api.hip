@@ -22,6 +22,7 @@ VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_nj.h"
 #include "vft_kernels_aa.h"
 #include "vft_kernels_profile.h"
+#include "vft_kernels_tophits.h"
 
 struct vft_ctx {
     vft_config cfg;
@@ -129,6 +130,15 @@ struct vft_ctx {
     // host-mapped mirrors of outDist / nOutActive, written by the kernels that refresh them
     void *hOutDist = nullptr, *dOutDistM = nullptr;
     int32_t *hNOut = nullptr, *dNOutM = nullptr;
+    // top-hit lists on the device (vft_kernels_tophits.h)
+    void *thHits = nullptr, *thStD = nullptr, *thStC = nullptr;
+    int32_t *thLen = nullptr, *thStJ = nullptr;
+    unsigned int *thMark = nullptr, *thDone = nullptr;
+    int32_t thM = 0, thCap = 0;
+    int64_t thLists = 0;
+    unsigned int thTag = 0;
+    size_t thLds = 0;                  // dynamic LDS of k_th_best / k_th_join
+    size_t thRefreshLds = 0;           // the largest dynamic LDS k_th_refresh has been configured for
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
@@ -513,6 +523,8 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hIO) hipHostFree(c->hIO);
     if (c->hFlag) hipHostFree(c->hFlag);
     if (c->doneCtr) hipFree(c->doneCtr);
+    for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone})
+        if (p) hipFree(p);
     if (c->pairStage) hipFree(c->pairStage);
     if (c->pairIn) hipFree(c->pairIn);
     if (c->hOutDist) hipHostFree(c->hOutDist);
@@ -2054,6 +2066,271 @@ extern "C" int vft_leaf_block_distances(vft_ctx *c, int64_t nA, const int64_t *a
     HIPCHK(c, hipMemcpyAsync(weight, o + oB, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(crit, o + 2 * oB, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- top-hit lists
+template <typename REAL>
+static TopHits<REAL> tophits(const vft_ctx *c) {
+    TopHits<REAL> T;
+    T.hits = (ThHit<REAL> *) c->thHits;
+    T.len = c->thLen;
+    T.m = c->thM;
+    T.cap = c->thCap;
+    T.nLists = c->thLists;
+    T.stJ = c->thStJ;
+    T.stD = (REAL *) c->thStD;
+    T.stC = (REAL *) c->thStC;
+    T.mark = c->thMark;
+    T.doneCtr = c->thDone;
+    return T;
+}
+
+extern "C" int vft_tophits_create(vft_ctx *c, int32_t m, int64_t nLists) {
+    if (!c || m < 1 || nLists < 1 || nLists > c->d.maxNodes) return VFT_ERR_INVALID;
+    if (c->thHits) return fail(c, VFT_ERR_STATE, "vft_tophits_create: lists exist already");
+    const size_t hitB = c->rs == 4 ? sizeof(ThHit<float>) : sizeof(ThHit<double>);
+    int P = 1;
+    while (P < 2 * m) P <<= 1;
+    c->thLds = std::max(pw_lds_bytes(c) / c->pwWaves, (size_t) P * sizeof(ThKey));
+    if (c->thLds > (160u << 10) - 8192) return fail(c, VFT_ERR_INVALID, "vft_tophits_create: lists of %d entries do not fit the LDS of the merge kernel", (int) m);
+    c->thM = m;
+    c->thCap = 2 * m + 64;
+    c->thLists = nLists;
+    HIPCHK(c, hipMalloc(&c->thHits, (size_t) nLists * (size_t) m * hitB));
+    HIPCHK(c, hipMalloc((void **) &c->thLen, (size_t) nLists * 4));
+    HIPCHK(c, hipMemsetAsync(c->thLen, 0, (size_t) nLists * 4, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->thStJ, (size_t) c->thCap * 4));
+    HIPCHK(c, hipMalloc(&c->thStD, (size_t) c->thCap * c->rs));
+    HIPCHK(c, hipMalloc(&c->thStC, (size_t) c->thCap * c->rs));
+    HIPCHK(c, hipMalloc((void **) &c->thMark, (size_t) c->d.maxNodes * 4));
+    HIPCHK(c, hipMemsetAsync(c->thMark, 0, (size_t) c->d.maxNodes * 4, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->thDone, 65 * 4));
+    HIPCHK(c, hipMemsetAsync(c->thDone, 0, 65 * 4, c->stream));
+    c->thTag = 0;
+    if (c->thLds > (48u << 10))
+        VFT_DISPATCH(c, {
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_th_best<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->thLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_th_join<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->thLds));
+        });
+    return VFT_OK;
+}
+
+extern "C" int vft_tophits_upload(vft_ctx *c, int64_t count, const int64_t *nodes, const int32_t *lens, const void *packed) {
+    if (!c || count < 0 || !nodes || !lens || !packed) return VFT_ERR_INVALID;
+    if (!c->thHits) return fail(c, VFT_ERR_STATE, "vft_tophits_upload before vft_tophits_create");
+    if (count == 0) return VFT_OK;
+    for (int64_t t = 0; t < count; t++)
+        if (nodes[t] < 0 || nodes[t] >= c->thLists || lens[t] < 0 || lens[t] > c->thM) return fail(c, VFT_ERR_INVALID, "vft_tophits_upload: list %lld out of range", (long long) t);
+    const size_t hitB = c->rs == 4 ? sizeof(ThHit<float>) : sizeof(ThHit<double>);
+    const size_t idB = (((size_t) count * 8) + 255) & ~(size_t) 255, lenB = (((size_t) count * 4) + 255) & ~(size_t) 255;
+    const size_t pkB = (size_t) count * (size_t) c->thM * hitB;
+    if (int r = ensure_scratch(c, idB + lenB + pkB + 256)) return r;
+    char *sb = (char *) c->scratch;
+    HIPCHK(c, hipMemcpyAsync(sb, nodes, (size_t) count * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sb + idB, lens, (size_t) count * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sb + idB + lenB, packed, pkB, hipMemcpyHostToDevice, c->stream));
+    if (c->rs == 4)
+        launch((k_th_scatter<float>), dim3((unsigned) count), dim3(256), 0, c->stream, tophits<float>(c), (const int64_t *) sb,
+               (const int32_t *) (sb + idB), (const ThHit<float> *) (sb + idB + lenB));
+    else
+        launch((k_th_scatter<double>), dim3((unsigned) count), dim3(256), 0, c->stream, tophits<double>(c), (const int64_t *) sb,
+               (const int32_t *) (sb + idB), (const ThHit<double> *) (sb + idB + lenB));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller's buffers are pageable: the copies may still be reading them
+    return VFT_OK;
+}
+
+extern "C" int vft_tophits_download(vft_ctx *c, int64_t node, int32_t *len, void *hits) {
+    if (!c || !len || !hits) return VFT_ERR_INVALID;
+    if (!c->thHits || node < 0 || node >= c->thLists) return fail(c, VFT_ERR_INVALID, "vft_tophits_download: no such list");
+    const size_t hitB = c->rs == 4 ? sizeof(ThHit<float>) : sizeof(ThHit<double>);
+    HIPCHK(c, hipMemcpyAsync(len, c->thLen + node, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hits, (char *) c->thHits + (size_t) node * (size_t) c->thM * hitB, (size_t) c->thM * hitB, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// setOutDistance(node) in front of a list walk: forced (recomputed unless the stamp IS n_active) or the lazy rule; skipped
+// when the host-mapped stamp mirror shows that nothing would happen (it can only lag towards "staler")
+static void tophits_refresh_own(vft_ctx *c, int64_t node, const SweepArgs &sa, bool force) {
+    const int64_t st = (int64_t) c->hNOut[node];
+    if (force ? st == sa.nActive : !(st - sa.nActive > sa.nDiffAllow)) return;
+    SweepArgs s1 = sa;
+    s1.force = force ? 1 : 0;
+    if (sa.nActive > c->maxStamp) c->maxStamp = sa.nActive;
+    VFT_DISPATCH(c, (launch((k_out_distance_one<REAL, NC>), dim3(1), dim3(VFT_WG), pw_lds_bytes(c) / c->pwWaves, c->stream,
+                            arena<REAL>(c), node, s1)));
+}
+
+extern "C" int vft_tophits_best(vft_ctx *c, int64_t node, int32_t len, int64_t nActive, int64_t nDiffAllow, double totdiam,
+                                int32_t forceNode, vft_tophits_best_t *out) {
+    if (!c || !out) return VFT_ERR_INVALID;
+    if (!c->thHits || node < 0 || node >= c->thLists || node >= c->maxnode || len < 0 || len > c->thM)
+        return fail(c, VFT_ERR_INVALID, "vft_tophits_best: bad list");
+    if (len == 0) {
+        out->j = out->pos = -1;
+        out->dist = out->criterion = 1e20;
+        return VFT_OK;
+    }
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = nDiffAllow;
+    sa.totdiam = totdiam;
+    tophits_refresh_own(c, node, sa, forceNode != 0);
+    if (nActive > c->maxStamp) c->maxStamp = nActive;   // the walk may refresh partners
+    char *h, *d;
+    if (int r = io_alloc(c, sizeof(ThBestOut), &h, &d)) return r;
+    const unsigned long long seq = ++c->signalSeq;
+    VFT_DISPATCH(c, (launch((k_th_best<REAL, NC>), dim3((unsigned) len), dim3(VFT_WG), c->thLds, c->stream, arena<REAL>(c),
+                            tophits<REAL>(c), node, sa, (ThBestOut *) d, c->dFlag, seq)));
+    LAUNCHCHK(c);
+    if (int r = wait_flag(c, seq)) return r;
+    const ThBestOut *o = (const ThBestOut *) h;
+    out->j = o->j;
+    out->pos = o->pos;
+    out->dist = o->dist;
+    out->criterion = o->crit;
+    return VFT_OK;
+}
+
+extern "C" int vft_tophits_join(vft_ctx *c, int64_t newnode, int64_t c0, int32_t n0, int64_t c1, int32_t n1, int64_t nActive,
+                                int64_t nDiffAllow, double totdiam, int32_t nSaveMax, int32_t need, int32_t ageOK,
+                                vft_tophits_join_t *info, int32_t *j, void *dist, void *crit) {
+    if (!c || !info || !j || !dist || !crit) return VFT_ERR_INVALID;
+    if (!c->thHits || newnode < 0 || newnode >= c->thLists || newnode >= c->maxnode || c0 < 0 || c0 >= c->thLists || c1 < 0 ||
+        c1 >= c->thLists || n0 < 0 || n0 > c->thM || n1 < 0 || n1 > c->thM || nSaveMax < 0 || nSaveMax > c->thM)
+        return fail(c, VFT_ERR_INVALID, "vft_tophits_join: bad lists");
+    const int32_t n = n0 + n1;
+    if (n == 0) {
+        info->n_unique = info->n_save = info->pad = 0;
+        info->use_unique = (nActive - 1 == 0 || (ageOK && 0 >= need)) ? 1 : 0;
+        return VFT_OK;
+    }
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = nDiffAllow;
+    sa.totdiam = totdiam;
+    tophits_refresh_own(c, newnode, sa, false);   // the new node's stamp is "unreasonably high" (NJ.tcc:254): the lazy rule fires
+    if (nActive > c->maxStamp) c->maxStamp = nActive;
+    const size_t rs = c->rs, aB = (((size_t) n * 8) + 255) & ~(size_t) 255;
+    char *h, *d;
+    if (int r = io_alloc(c, 256 + 3 * aB, &h, &d)) return r;
+    const unsigned long long seq = ++c->signalSeq;
+    if (++c->thTag == 0u) {   // (2^32 joins on one context: start the marks over)
+        HIPCHK(c, hipMemsetAsync(c->thMark, 0, (size_t) c->d.maxNodes * 4, c->stream));
+        c->thTag = 1u;
+    }
+    VFT_DISPATCH(c, (launch((k_th_join<REAL, NC>), dim3((unsigned) n), dim3(VFT_WG), c->thLds, c->stream, arena<REAL>(c),
+                            tophits<REAL>(c), newnode, c0, n0, c1, sa, c->thTag, nSaveMax, need, ageOK, (ThJoinInfo *) d,
+                            (int32_t *) (d + 256), (REAL *) (d + 256 + aB), (REAL *) (d + 256 + 2 * aB), c->dFlag, seq)));
+    LAUNCHCHK(c);
+    if (int r = wait_flag(c, seq)) return r;
+    const ThJoinInfo *o = (const ThJoinInfo *) h;
+    info->n_unique = o->nUnique;
+    info->use_unique = o->useUnique;
+    info->n_save = o->nSave;
+    info->pad = 0;
+    memcpy(j, h + 256, (size_t) o->nUnique * 4);
+    memcpy(dist, h + 256 + aB, (size_t) o->nUnique * rs);
+    memcpy(crit, h + 256 + 2 * aB, (size_t) o->nUnique * rs);
+    return VFT_OK;
+}
+
+extern "C" int vft_tophits_refresh(vft_ctx *c, int64_t newnode, int32_t nHits, const int64_t *hitJ, const void *hitDist, int32_t nOwn,
+                                   const void *ownList, int64_t nWork, const int64_t *work, const int32_t *nNew, int64_t nActive,
+                                   int64_t nDiffAllow, double totdiam, int32_t *lens, void *first) {
+    if (!c || nHits < 0 || !hitJ || !hitDist || nOwn < 0 || (nOwn > 0 && !ownList) || nWork < 0 || (nWork > 0 && (!work || !nNew || !lens || !first)))
+        return VFT_ERR_INVALID;
+    if (!c->thHits || newnode < 0 || newnode >= c->thLists || newnode >= c->maxnode || nOwn > c->thM)
+        return fail(c, VFT_ERR_INVALID, "vft_tophits_refresh: bad list");
+    int32_t maxNew = 0;
+    for (int64_t t = 0; t < nWork; t++) {
+        if (work[t] < 0 || work[t] >= c->thLists || work[t] >= c->maxnode || nNew[t] < 1 || nNew[t] > c->thM)
+            return fail(c, VFT_ERR_INVALID, "vft_tophits_refresh: work node %lld out of range", (long long) t);
+        maxNew = std::max(maxNew, nNew[t]);
+    }
+    for (int32_t u = 0; u < nHits; u++)
+        if (hitJ[u] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_tophits_refresh: hit %d out of range", (int) u);
+    const size_t rs = c->rs, hitB = rs == 4 ? sizeof(ThHit<float>) : sizeof(ThHit<double>);
+    const int32_t nB = std::min<int32_t>(nHits, 2 * maxNew);
+    const int32_t E = ((c->thM + nB + 3) / 4) * 4;
+    int32_t P = 2;
+    while (P < E) P <<= 1;
+    const size_t lds = pw_lds_bytes(c) / c->pwWaves + (size_t) P * sizeof(ThKey) + (size_t) E * 16 + (size_t) E * rs;
+    if (lds > (160u << 10) - 1024) return fail(c, VFT_ERR_STATE, "vft_tophits_refresh: %zu bytes of LDS per node", lds);
+    // input block: targets | distances | work | nNew | own list   (host-mapped ring, then one copy to device memory)
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+    const size_t oT = 0, oD = oT + pad((size_t) nB * 8), oW = oD + pad((size_t) nB * rs), oN = oW + pad((size_t) nWork * 8),
+                 oO = oN + pad((size_t) nWork * 4), inB = oO + pad((size_t) nOwn * hitB);
+    const size_t oLen = 0, oFirst = pad((size_t) nWork * 4), outB = oFirst + pad((size_t) nWork * hitB);
+    char *h, *d;
+    if (int r = io_alloc(c, inB + outB, &h, &d)) return r;
+    memcpy(h + oT, hitJ, (size_t) nB * 8);
+    memcpy(h + oD, hitDist, (size_t) nB * rs);
+    if (nWork) memcpy(h + oW, work, (size_t) nWork * 8);
+    if (nWork) memcpy(h + oN, nNew, (size_t) nWork * 4);
+    if (nOwn) memcpy(h + oO, ownList, (size_t) nOwn * hitB);
+    const size_t blockB = pad((size_t) nWork * (size_t) nB * rs);
+    if (int r = ensure_scratch(c, inB + blockB + 256)) return r;
+    char *sIn = (char *) c->scratch, *sBlock = sIn + inB;
+    launch(k_copy16x2, dim3(cdiv((int64_t) (inB / 16), 256)), dim3(256), 0, c->stream, (uint4 *) sIn, (const uint4 *) d, (int64_t) (inB / 16),
+           (uint4 *) nullptr, (const uint4 *) nullptr, (int64_t) 0);
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = nDiffAllow;
+    sa.totdiam = totdiam;
+    if (c->rs == 4) launch((k_th_store<float>), dim3(1), dim3(256), 0, c->stream, tophits<float>(c), newnode, (const ThHit<float> *) (sIn + oO), nOwn);
+    else launch((k_th_store<double>), dim3(1), dim3(256), 0, c->stream, tophits<double>(c), newnode, (const ThHit<double> *) (sIn + oO), nOwn);
+    if (nWork == 0) {
+        LAUNCHCHK(c);
+        return VFT_OK;   // (stream-ordered: the next walk sees the list)
+    }
+    // setCriterion's lazy refresh for every node the block names (none after NJ.tcc:4451-4464; kept for callers that skip it)
+    {
+        std::vector<int64_t> &stale = c->staleIds;
+        stale.clear();
+        if (c->staleMark.size() != (size_t) c->d.maxNodes) c->staleMark.assign((size_t) c->d.maxNodes, 0u);
+        if (++c->staleEpoch == 0u) {
+            std::fill(c->staleMark.begin(), c->staleMark.end(), 0u);
+            c->staleEpoch = 1u;
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            const int64_t *ids = pass ? hitJ : work, cnt = pass ? nB : nWork;
+            for (int64_t t = 0; t < cnt; t++) {
+                const int64_t v = ids[t];
+                if (v >= 0 && (int64_t) c->hNOut[v] - nActive > nDiffAllow && c->staleMark[(size_t) v] != c->staleEpoch) {
+                    c->staleMark[(size_t) v] = c->staleEpoch;
+                    stale.push_back(v);
+                }
+            }
+        }
+        if (!stale.empty()) {
+            const int64_t nStale = (int64_t) stale.size();
+            char *hs, *ds;
+            if (int r = io_alloc(c, (size_t) nStale * 8, &hs, &ds)) return r;
+            memcpy(hs, stale.data(), (size_t) nStale * 8);
+            if (nActive > c->maxStamp) c->maxStamp = nActive;
+            VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c),
+                                    c->stream, arena<REAL>(c), (const int64_t *) ds, nStale, (int64_t) 0, sa)));
+        }
+    }
+    VFT_DISPATCH(c, (launch((k_pairs_block<REAL, NC>), dim3(cdiv(nWork * nB, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
+                            arena<REAL>(c), (const int64_t *) (sIn + oW), nWork, (const int64_t *) (sIn + oT), (int64_t) nB, (REAL *) sBlock)));
+    if (lds > c->thRefreshLds) {
+        VFT_DISPATCH(c, HIPCHK(c, hipFuncSetAttribute((const void *) k_th_refresh<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)));
+        c->thRefreshLds = lds;
+    }
+    const unsigned long long seq = ++c->signalSeq;
+    char *dOut = d + inB;
+    VFT_DISPATCH(c, (launch((k_th_refresh<REAL, NC>), dim3((unsigned) nWork), dim3(VFT_WG), lds, c->stream, arena<REAL>(c), tophits<REAL>(c),
+                            newnode, (const int64_t *) (sIn + oW), (const int32_t *) (sIn + oN), (const int64_t *) (sIn + oT),
+                            (const REAL *) (sIn + oD), nB, (const REAL *) sBlock, sa, P, E, (int32_t *) (dOut + oLen),
+                            (ThHit<REAL> *) (dOut + oFirst), c->dFlag, seq)));
+    LAUNCHCHK(c);
+    if (int r = wait_flag(c, seq)) return r;
+    memcpy(lens, h + inB + oLen, (size_t) nWork * 4);
+    memcpy(first, h + inB + oFirst, (size_t) nWork * hitB);
     return VFT_OK;
 }
 

@@ -432,11 +432,12 @@ __global__ void k_outprofile_update(Arena<REAL> A, int64_t old1, int64_t old2, i
 // in profC: the tile streams are rebuilt lazily, for up to 64 joined nodes at once, right before something that reads
 // tile streams runs (a sweep, a full out-profile; vft_api.hip: flush_pending).  Pair lists, single out-distances and
 // the next joins read the row.  One workgroup; dynamic LDS: 2 * nPosPad doubles.
+// the body of one join, shared by k_join_fused (arguments from the host) and the join engine's k_nj_join (arguments from the
+// device-resident state, vft_kernels_njengine.h); every thread of the workgroup calls, blockDim.x = VFT_WG_PROF
 template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_WG_PROF) void k_join_fused(Arena<REAL> A, int64_t i, int64_t j, int64_t newn, REAL diameter,
-                                                           int32_t staleStamp, int64_t nActiveOld, int32_t updateOut, double tol,
-                                                           REAL *stash, int64_t *pendIds, int32_t slot) {
-    extern __shared__ __attribute__((aligned(16))) double jfLds[];
+__device__ __forceinline__ void vft_join_body(const Arena<REAL> &A, int64_t i, int64_t j, int64_t newn, REAL diameter,
+                                              int32_t staleStamp, int64_t nActiveOld, int32_t updateOut, double tol,
+                                              REAL *stash, int64_t *pendIds, int32_t slot, double *jfLds) {
     __shared__ double res[2];
     double *sW = jfLds, *sT = jfLds + A.d.nPosPad;
     const int64_t nPos = A.d.nPos;
@@ -514,6 +515,14 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_join_fused(Arena<REAL> A, int64
         A.selfweight[newn] = (REAL) (denom > 0 ? denom : 0.01);
         A.selfdist[newn] = (REAL) (denom > 0 ? top / denom : 1.0);
     }
+}
+
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG_PROF) void k_join_fused(Arena<REAL> A, int64_t i, int64_t j, int64_t newn, REAL diameter,
+                                                           int32_t staleStamp, int64_t nActiveOld, int32_t updateOut, double tol,
+                                                           REAL *stash, int64_t *pendIds, int32_t slot) {
+    extern __shared__ __attribute__((aligned(16))) double jfLds[];
+    vft_join_body<REAL, NC>(A, i, j, newn, diameter, staleStamp, nActiveOld, updateOut, tol, stash, pendIds, slot, jfLds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

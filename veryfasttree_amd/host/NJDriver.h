@@ -61,6 +61,9 @@ namespace veryfasttree {
         int aaModel = 0;
         /* multi-GPU (include/vft_host.h, vft_comm): sweeps and leaf blocks are split over the ranks */
         const vft_comm *comm = nullptr;
+        /* top-hit lists on the device (vft_tophits_*): the list walks of a join are one launch each; false = the host walks
+           of round 2 (kept as the cross-check of VFT_NJ_CHECK and for tools) */
+        bool deviceLists = true;
     };
 
     template<typename REAL>
@@ -700,6 +703,13 @@ namespace veryfasttree {
         std::vector<Besthit> gbTodo;
         std::vector<Besthit *> gbTodoPtr;
         bool leafBlocks = true;              /* setAllLeafTopHits: vft_leaf_block_distances applies (nucleotides, no matrix) */
+        bool devLists = false;               /* the lists have a device copy (vft_tophits_create succeeded) */
+        bool refreshOnDevice = true;         /* the per-node merges of a top-hits refresh run on the device (k_th_refresh) */
+        bool hostLists = true;               /* the host holds the lists as well: no device lists, second-level lists (their
+                                                transfers and the 2nd -> 1st level switch are host code), or VFT_NJ_CHECK */
+        std::vector<int32_t> listLen;        /* devLists: length of every node's list */
+        std::vector<int32_t> thJ;            /* vft_tophits_join results: scratch that keeps its capacity */
+        std::vector<REAL> thD, thC;
 
         void chk(int rc) {
             if (rc != VFT_OK) throw std::invalid_argument(std::string("NJDriver: ") + vft_last_error(ctx));
@@ -1032,6 +1042,35 @@ namespace veryfasttree {
             visible.assign(maxnodes, Hit{(int32_t) -1, (REAL) 1e20});
             topvisible.assign((size_t) (0.5 + opt.topvisibleMult * m), -1);
             topvisibleAge = 0;
+            devLists = false;
+            if (opt.deviceLists && std::getenv("VFT_NJ_HOST_LISTS") == nullptr)   /* (tools: the host walks of round 2) */
+                devLists = vft_tophits_create(ctx, (int32_t) m, maxnodes) == VFT_OK;
+            hostLists = !devLists || q > 0 || checkJoins;
+            if (devLists) listLen.assign((size_t) maxnodes, 0);
+        }
+
+        int32_t lenOf(int64_t node) const { return devLists ? listLen[(size_t) node] : (int32_t) hits[(size_t) node].size(); }
+
+        /* device copies of host-side lists (stage 1: the refresh and setAllLeafTopHits still build lists on the host) */
+        void uploadLists(const std::vector<int64_t> &nodes) {
+            if (!devLists || nodes.empty()) return;
+            Section sec(this, "[host] list upload (incl. device)");
+            const size_t chunk = 2048;
+            std::vector<Hit> packed;
+            std::vector<int32_t> lens;
+            for (size_t a0 = 0; a0 < nodes.size(); a0 += chunk) {
+                const size_t cnt = std::min(chunk, nodes.size() - a0);
+                packed.resize(cnt * (size_t) m);
+                lens.resize(cnt);
+#pragma omp parallel for schedule(static) num_threads(opt.hostThreads)
+                for (int64_t t = 0; t < (int64_t) cnt; t++) {
+                    const std::vector<Hit> &l = hits[(size_t) nodes[a0 + (size_t) t]];
+                    lens[(size_t) t] = (int32_t) l.size();
+                    listLen[(size_t) nodes[a0 + (size_t) t]] = (int32_t) l.size();
+                    if (!l.empty()) memcpy(&packed[(size_t) t * (size_t) m], l.data(), l.size() * sizeof(Hit));
+                }
+                chkT("vft_tophits_upload", [&]() { return vft_tophits_upload(ctx, (int64_t) cnt, nodes.data() + a0, lens.data(), packed.data()); });
+            }
         }
 
         std::vector<Besthit> hitsToBestHits(const std::vector<Hit> &l, int64_t node) const {
@@ -1828,6 +1867,13 @@ namespace veryfasttree {
                 }
             }
             sSeq.reset();
+            if (devLists) {
+                std::vector<int64_t> all((size_t) n);
+                for (int64_t v = 0; v < n; v++) all[(size_t) v] = v;
+                uploadLists(all);
+                if (!hostLists)   /* from here on the lists live on the device only (8 GB at a million sequences) */
+                    for (auto &l: hits) std::vector<Hit>().swap(l);
+            }
             if (profiling) {
                 acc["[count]  checking phase: iterations done in full"].calls += nFullChecks;
                 acc["[count]  checking phase: verdicts precomputed"].calls += (int64_t) verdict.size();
@@ -1835,6 +1881,36 @@ namespace veryfasttree {
         }
 
         Besthit getBestFromTopHits(int64_t node, int64_t nActive) { /* NJ.tcc:4267-4298 */
+            if (!devLists) return getBestFromTopHitsHost(node, nActive);
+            /* one launch over the device copy of the list; only the best hit comes back */
+            drain();
+            vft_tophits_best_t r;
+            chkT("vft_tophits_best", [&]() {
+                return vft_tophits_best(ctx, node, lenOf(node), nActive, nDiffAllow(nActive), totdiam, opt.fastest ? 0 : 1, &r);
+            });
+            pending = false;
+            Besthit best;
+            best.i = best.j = -1;
+            if (r.j >= 0) {
+                best.i = node;
+                best.j = r.j;
+                best.dist = (REAL) r.dist;
+                best.criterion = (REAL) r.criterion;
+                best.weight = -1;
+            }
+            if (checkJoins) {
+                const Besthit h = getBestFromTopHitsHost(node, nActive);
+                if (h.i != best.i || h.j != best.j || h.dist != best.dist || h.criterion != best.criterion) {
+                    fprintf(stderr, "[check] getBestFromTopHits(%lld) at nActive %lld: device (%lld, %lld, %.9g, %.9g) host (%lld, %lld, %.9g, %.9g)\n",
+                            (long long) node, (long long) nActive, (long long) best.i, (long long) best.j, (double) best.dist, (double) best.criterion,
+                            (long long) h.i, (long long) h.j, (double) h.dist, (double) h.criterion);
+                    throw std::runtime_error("NJDriver: device and host getBestFromTopHits differ");
+                }
+            }
+            return best;
+        }
+
+        Besthit getBestFromTopHitsHost(int64_t node, int64_t nActive) {
             /* setOutDistance(node) (unless -fastest), the recomputed distances of re-targeted hits and the lazy refreshes
                of setCriterion on every hit all belong to the same window: one device call, one wait.  The list (1 000 hits
                at a million sequences, twice per join) is walked in place: records are built only for the hits whose
@@ -2072,18 +2148,68 @@ namespace veryfasttree {
             Section sec(this, "[host] topHitJoin (incl. device)");
             const int64_t c0 = child0[newnode], c1 = child1[newnode];
             std::vector<Besthit> unique;
-            {
+            age[newnode] = (age[c0] + age[c1] + 1) / 2 + 1;
+            const int64_t ageLimit = std::max<int64_t>(1, (int64_t) (0.5 + std::log((double) m) / std::log(2.0)));
+            bool second = hitSource[c0] >= 0 && hitSource[c1] >= 0;
+            const int64_t need = second ? (int64_t) (0.5 + opt.tophits2Refresh * q) : (int64_t) (0.5 + m * opt.tophitsRefresh);
+            bool devSorted = false;   /* `unique` is the device's sorted candidate list and hits[newnode] is saved there */
+            if (devLists) {
+                /* one launch: candidates, distances, criteria, the sort, the decision and the new list (k_th_join) */
+                Section s2(this, "[host]   topHitJoin: uniqueBestHits (incl. device)");
+                drain();
+                const int32_t n0 = lenOf(c0), n1 = lenOf(c1);
+                thJ.resize((size_t) (n0 + n1) + 1);
+                thD.resize((size_t) (n0 + n1) + 1);
+                thC.resize((size_t) (n0 + n1) + 1);
+                vft_tophits_join_t info;
+                chkT("vft_tophits_join", [&]() {
+                    return vft_tophits_join(ctx, newnode, c0, n0, c1, n1, nActive, nDiffAllow(nActive), totdiam, (int32_t) (second ? q : m),
+                                            (int32_t) need, age[newnode] <= ageLimit ? 1 : 0, &info, thJ.data(), thD.data(), thC.data());
+                });
+                pending = false;
+                unique.resize((size_t) info.n_unique);
+                for (size_t t = 0; t < unique.size(); t++) {
+                    Besthit &h = unique[t];
+                    h.i = newnode;
+                    h.j = thJ[t];
+                    h.dist = thD[t];
+                    h.criterion = thC[t];
+                    h.weight = -1;
+                }
+                devSorted = info.use_unique != 0;
+                if (checkJoins) {
+                    std::vector<Besthit> ref = uniqueOfJoin(nActive, newnode, c0, c1);
+                    bool same = ref.size() == unique.size();
+                    if (same) {
+                        sortByCriterion(ref);
+                        for (size_t t = 0; same && t < ref.size(); t++)
+                            same = ref[t].j == unique[t].j && ref[t].dist == unique[t].dist && ref[t].criterion == unique[t].criterion;
+                    }
+                    if (!same) {
+                        fprintf(stderr, "[check] merge for node %lld at nActive %lld: device %zu candidates, host %zu\n", (long long) newnode,
+                                (long long) nActive, unique.size(), ref.size());
+                        for (size_t t = 0; t < std::min(ref.size(), unique.size()); t++)
+                            if (ref[t].j != unique[t].j || ref[t].dist != unique[t].dist || ref[t].criterion != unique[t].criterion) {
+                                fprintf(stderr, "[check]   first difference at %zu: device (%lld, %.9g, %.9g) host (%lld, %.9g, %.9g)\n", t,
+                                        (long long) unique[t].j, (double) unique[t].dist, (double) unique[t].criterion, (long long) ref[t].j,
+                                        (double) ref[t].dist, (double) ref[t].criterion);
+                                break;
+                            }
+                        throw std::runtime_error("NJDriver: device and host merge of a join differ");
+                    }
+                }
+                if (!devSorted) {   /* the paths below expect the candidates in ascending id order, as uniqueBestHits leaves them */
+                    std::sort(unique.begin(), unique.end(), [](const Besthit &a, const Besthit &b) { return a.j < b.j; });
+                }
+            } else {
                 Section s2(this, "[host]   topHitJoin: uniqueBestHits (incl. device)");
                 unique = uniqueOfJoin(nActive, newnode, c0, c1);
             }
             const int64_t nUnique = (int64_t) unique.size();
             hits[c0].clear();
             hits[c1].clear();
-            age[newnode] = (age[c0] + age[c1] + 1) / 2 + 1;
-            const int64_t ageLimit = std::max<int64_t>(1, (int64_t) (0.5 + std::log((double) m) / std::log(2.0)));
-            bool second = hitSource[c0] >= 0 && hitSource[c1] >= 0;
-            const int64_t need = second ? (int64_t) (0.5 + opt.tophits2Refresh * q) : (int64_t) (0.5 + m * opt.tophitsRefresh);
             bool useUnique = nUnique == nActive - 1 || (age[newnode] <= ageLimit && nUnique >= need);
+            if (devLists && useUnique != devSorted) throw std::runtime_error("NJDriver: host and device disagree on the merged list");
             if (!useUnique && second && age[newnode] <= ageLimit) {
                 /* switch from 2nd-level to 1st-level top hits, NJ.tcc:4364-4410 */
                 int64_t source = activeAncestor(hitSource[c0]);
@@ -2108,11 +2234,20 @@ namespace veryfasttree {
             if (useUnique) {
                 if (second) hitSource[newnode] = hitSource[c0];
                 const int64_t nSave = std::min(nUnique, second ? q : m);
-                {
+                if (devSorted) {
+                    /* sorted and saved by k_th_join */
+                    listLen[(size_t) newnode] = (int32_t) nSave;
+                    if (hostLists) {
+                        std::vector<Hit> &l = hits[(size_t) newnode];
+                        l.resize((size_t) nSave);
+                        for (int64_t t = 0; t < nSave; t++) l[(size_t) t] = Hit{(int32_t) unique[(size_t) t].j, unique[(size_t) t].dist};
+                    }
+                } else {
                     Section s2(this, "[host]   topHitJoin: sortSaveBestHits");
                     sortSaveBestHits(newnode, unique, nUnique, nSave);
+                    uploadLists(std::vector<int64_t>(1, newnode));
                 }
-                visible[newnode] = hits[newnode][0];
+                visible[newnode] = devSorted ? Hit{(int32_t) unique[0].j, unique[0].dist} : hits[newnode][0];
                 {
                     Section s2(this, "[host]   topHitJoin: updateTopVisible");
                     updateTopVisible(nActive, newnode, visible[newnode]);
@@ -2138,8 +2273,66 @@ namespace veryfasttree {
                 Section s2(this, "[host]     refresh: sweep (incl. device)");
                 all = sweep(newnode, nActive, (int32_t) (2 * m));
             }
-            std::vector<Besthit> copy(all);
-            sortSaveBestHits(newnode, copy, (int64_t) copy.size(), m, false);
+            std::vector<Hit> ownList;   /* sortSaveBestHits(newnode, allhits, ..., m), NJ.tcc:4473: the first m usable records */
+            {
+                int64_t jLast = -1;
+                for (size_t t = 0; t < all.size() && (int64_t) ownList.size() < m; t++) {
+                    if (all[t].i < 0) continue;
+                    const int64_t j = all[t].j;
+                    if (j != newnode && j != jLast && j >= 0) {
+                        ownList.push_back(Hit{(int32_t) j, all[t].dist});
+                        jLast = j;
+                    }
+                }
+            }
+            const bool devRefresh = devLists && q == 0 && refreshOnDevice;
+            std::vector<int32_t> devLens;
+            std::vector<Hit> devFirst;
+            std::vector<int64_t> devWork;
+            if (devRefresh) {
+                /* one workgroup per node merges on the device (k_th_refresh); the host receives lengths and first hits */
+                Section s2(this, "[host]     refresh: device merge (incl. device)");
+                std::vector<int64_t> hj(all.size());
+                std::vector<REAL> hd(all.size());
+                for (size_t u = 0; u < all.size(); u++) {
+                    hj[u] = all[u].i < 0 ? -1 : all[u].j;
+                    hd[u] = all[u].dist;
+                }
+                for (int64_t iHit = 0; iHit < m && iHit < (int64_t) all.size(); iHit++) {
+                    if (all[iHit].i < 0) continue;
+                    const int64_t node = all[iHit].j;
+                    if (parent[node] >= 0) continue;
+                    devWork.push_back(node);
+                }
+                std::vector<int32_t> nNew(devWork.size(), (int32_t) m);
+                devLens.resize(devWork.size());
+                devFirst.resize(devWork.size());
+                int rc = VFT_OK;
+                chkT("vft_tophits_refresh", [&]() {
+                    rc = vft_tophits_refresh(ctx, newnode, (int32_t) all.size(), hj.data(), hd.data(), (int32_t) ownList.size(), ownList.data(),
+                                             (int64_t) devWork.size(), devWork.data(), nNew.data(), nActive, nDiffAllow(nActive), totdiam,
+                                             devLens.data(), devFirst.data());
+                    return rc == VFT_ERR_STATE ? VFT_OK : rc;
+                });
+                if (rc == VFT_ERR_STATE) {   /* lists too long for the merge kernel: the host merges from now on */
+                    refreshOnDevice = false;
+                    throw std::runtime_error("NJDriver: top-hit lists too long for the device merge (host lists were released)");
+                }
+                pending = false;
+                listLen[(size_t) newnode] = (int32_t) ownList.size();
+                for (size_t t = 0; t < devWork.size(); t++) {
+                    const int64_t node = devWork[t];
+                    age[(size_t) node] = 0;
+                    listLen[(size_t) node] = devLens[t];
+                    visible[(size_t) node] = devFirst[t];
+                }
+                if (!hostLists) {
+                    resetTopVisible(nActive);
+                    return;
+                }
+                /* VFT_NJ_CHECK: the host merge below runs as well and every list is compared */
+            }
+            hits[(size_t) newnode] = ownList;
             /* NJ.tcc:4477-4515 — the reference runs this loop as an OpenMP parallel for: iterations only touch their
                own node's list.  Here: the host parts run in parallel per node, every distance that must be recomputed,
                for ALL nodes, goes to the device as ONE pair list, and every lazy out-distance refresh as one id list. */
@@ -2379,6 +2572,27 @@ namespace veryfasttree {
                 visible[(size_t) node] = l[0];
             }
             sSave.reset();
+            if (devRefresh) {   /* VFT_NJ_CHECK: the device's lists against the host merge */
+                bool same = (int64_t) devWork.size() == nW;
+                std::vector<Hit> got((size_t) m);
+                for (int64_t t = 0; same && t <= nW; t++) {
+                    const int64_t node = t < nW ? work[(size_t) t].node : newnode;
+                    if (t < nW) same = devWork[(size_t) t] == node;
+                    int32_t len = 0;
+                    chk(vft_tophits_download(ctx, node, &len, got.data()));
+                    const std::vector<Hit> &want = hits[(size_t) node];
+                    same = same && len == (int32_t) want.size();
+                    for (size_t u = 0; same && u < want.size(); u++) same = got[u].j == want[u].j && got[u].dist == want[u].dist;
+                    if (!same) fprintf(stderr, "[check] refresh of node %lld (new node %lld, nActive %lld): the device list differs from the host merge (%d / %zu entries)\n",
+                                       (long long) node, (long long) newnode, (long long) nActive, (int) len, want.size());
+                }
+                if (!same) throw std::runtime_error("NJDriver: device and host top-hits refresh differ");
+            } else if (devLists) {
+                std::vector<int64_t> changed((size_t) nW + 1);
+                for (int64_t t = 0; t < nW; t++) changed[(size_t) t] = work[(size_t) t].node;
+                changed[(size_t) nW] = newnode;
+                uploadLists(changed);
+            }
             resetTopVisible(nActive);
         }
     };
