@@ -159,6 +159,64 @@ int vft_tophits_refresh(vft_ctx *ctx, int64_t newnode, int32_t n_hits, const int
                         const void *own_list, int64_t n_work, const int64_t *work, const int32_t *n_new, int64_t n_active,
                         int64_t n_diff_allow, double totdiam, int32_t *lens, void *first);
 
+/* ---- the join loop on the device (veryfasttree_amd/csrc/vft_kernels_njengine.h)
+ * fastNJ's loop over joins with top hits (NJ.tcc:2857-3047) as a stream of kernels whose arguments live in a device-resident
+ * state block (nActive, maxnode, totdiam, the candidate join, the visible set, list ages): the caller enqueues the launches
+ * of many joins without waiting, reads the join records from a host-mapped log, and handles the events a kernel flags by
+ * raising `halt` (every later kernel then does nothing until vft_nj_engine_resume).  First-level top-hit lists only
+ * (vft_tophits_create must have been called; lists, out-distances, profiles are the context's). */
+typedef struct { int32_t i, j, newnode, pad; double dist, criterion, bl_i, bl_j, diameter; } vft_nj_join_t;
+typedef struct {
+    int32_t m, n_top;          /* list length, size of the top-visible list (NJ.tcc:2827-2839, 197-208) */
+    int32_t need;              /* a merged list is used when it holds at least this many hits... (m * tophitsRefresh, NJ.tcc:4352) */
+    int32_t age_limit;         /* ...and is at most this old (NJ.tcc:4342-4351) */
+    int32_t fastest;           /* -fastest: no hill climbing (NJ.tcc:4218-4220) */
+    int32_t pad;
+    int64_t stale_stamp;       /* nOutDistActive of a new node ("unreasonably high", NJ.tcc:254) */
+    double stale_out_limit;    /* Options.h:38 */
+} vft_nj_engine_config;
+#define VFT_NJ_HALT_NONE 0
+#define VFT_NJ_HALT_RESET 1     /* topHitNJSearch of join halt_join wants resetTopVisible (NJ.tcc:4156-4206); the join has not happened */
+#define VFT_NJ_HALT_REFRESH 2   /* topHitJoin of join halt_join wants a top-hits refresh of the new node (NJ.tcc:4440-4517); the join is logged */
+#define VFT_NJ_HALT_CLIMB 3     /* the hill climbing of join halt_join changed the candidate in its last enqueued round */
+#define VFT_NJ_PHASE_SEARCH 1   /* top-visible scan of join_index + one hill-climbing round (up to its last comparison) */
+#define VFT_NJ_PHASE_CLIMB 2    /* one more hill-climbing round */
+#define VFT_NJ_PHASE_JOIN 4     /* the round's last comparison; the join (record, tree arrays, profile, out-profile, out-distance) */
+#define VFT_NJ_PHASE_MERGE 8    /* the new node's list from the children's, the visible-set updates */
+#define VFT_NJ_PHASE_NEXT 16    /* with PHASE_MERGE: the same kernels go on with PHASE_SEARCH of join_index + 1 */
+int vft_nj_engine_create(vft_ctx *ctx, const vft_nj_engine_config *cfg);
+/* scalars of the loop (stream-ordered stores); a negative / NaN argument leaves the value alone */
+int vft_nj_engine_set_state(vft_ctx *ctx, int64_t n_active, int64_t maxnode, double totdiam, int32_t top_visible_age);
+/* waits for the stream; any pointer may be NULL */
+int vft_nj_engine_get_state(vft_ctx *ctx, int64_t *n_active, int64_t *maxnode, double *totdiam, int32_t *top_visible_age,
+                            int64_t *joins_done, int32_t *halt, int32_t *halt_join, int32_t *n_unique);
+/* visible[first .. first + count) (j int32, dist numeric_t) */
+int vft_nj_engine_visible_set(vft_ctx *ctx, int64_t first, int64_t count, const int32_t *j, const void *dist);
+int vft_nj_engine_visible_get(vft_ctx *ctx, int64_t first, int64_t count, int32_t *j, void *dist);
+/* visible[nodes[t]] = (j[t], dist[t]) and age[nodes[t]] = age for t < n (j == NULL: ages only) */
+int vft_nj_engine_nodes_set(vft_ctx *ctx, int64_t n, const int64_t *nodes, const int32_t *j, const void *dist, int32_t age);
+int vft_nj_engine_topvisible_set(vft_ctx *ctx, const int32_t *nodes /* n_top */);
+int vft_nj_engine_topvisible_get(vft_ctx *ctx, int32_t *nodes /* n_top */);   /* waits for the stream */
+/* the kernels of the given phases of join number join_index (0-based), no waiting.  update_out (PHASE_JOIN): the incremental
+   out-profile update (NJ.tcc:3034-3035); 0 when the caller recomputes the out-profile after the join (then it also sets
+   totdiam, and passes 0 with PHASE_MERGE as well: the new node's out-distance is then computed first).  A candidate that
+   the enqueued hill-climbing round changed raises HALT_CLIMB. */
+int vft_nj_engine_enqueue(vft_ctx *ctx, int64_t join_index, int32_t phases, int32_t update_out);
+/* resetTopVisible (NJ.tcc:4728-4784), device part: the lazy out-distance refreshes of getVisible for every active node with
+   a usable visible hit, its criterion, and the first k such nodes under (criterion ascending, node id descending) - the order
+   the reference sorts by (positions are ascending node ids).  hits: k records vft_hit_* in host memory with j = the node,
+   weight = its visible partner, dist = the visible hit's distance, criterion (j = -1: fewer than k); n_visible: how many
+   nodes have a usable visible hit.  k <= 8192.  Waits for the stream. */
+int vft_nj_engine_reset_candidates(vft_ctx *ctx, int64_t n_active, double totdiam, int32_t k, void *hits, int64_t *n_visible);
+/* host-mapped status words, no synchronisation: joins completed (merge done or refresh requested), halt reason, its join */
+int vft_nj_engine_poll(vft_ctx *ctx, int64_t *joins_done, int32_t *halt, int32_t *halt_join);
+/* clears the halt; next_join = the first join the caller enqueues next (joins enqueued behind the event have not run) */
+int vft_nj_engine_resume(vft_ctx *ctx, int64_t next_join);
+/* the host-mapped join log (record k is valid once join k has run: joins_done > k, or halt_join == k after a REFRESH halt)
+   and the host bookkeeping of the joins [from, to): parent mirror, node count */
+int vft_nj_engine_log(vft_ctx *ctx, const vft_nj_join_t **log);
+int vft_nj_engine_adopt(vft_ctx *ctx, int64_t from, int64_t to);
+
 /* ---- profiles */
 int vft_profile_upload(vft_ctx *ctx, int64_t node, const void *w, const uint8_t *codes, const void *f);
 int vft_profile_download(vft_ctx *ctx, int64_t node, void *w, uint8_t *codes, void *f);

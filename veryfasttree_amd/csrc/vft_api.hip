@@ -23,6 +23,7 @@ VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_aa.h"
 #include "vft_kernels_profile.h"
 #include "vft_kernels_tophits.h"
+#include "vft_kernels_njengine.h"
 
 struct vft_ctx {
     vft_config cfg;
@@ -139,6 +140,14 @@ struct vft_ctx {
     unsigned int thTag = 0;
     size_t thLds = 0;                  // dynamic LDS of k_th_best / k_th_join
     size_t thRefreshLds = 0;           // the largest dynamic LDS k_th_refresh has been configured for
+    // the join loop on the device (vft_kernels_njengine.h)
+    void *njState = nullptr, *njVisD = nullptr;
+    int32_t *njVisJ = nullptr, *njTop = nullptr, *njAge = nullptr;
+    NjJoinRec *njLogDev = nullptr, *njLogHost = nullptr, *njLogHostDev = nullptr;
+    long long *njStatusHost = nullptr, *njStatusDev = nullptr;
+    vft_nj_engine_config njCfg{};
+    size_t njScanLds = 0, njTailLds = 0;
+    int njP = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
@@ -523,8 +532,11 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hIO) hipHostFree(c->hIO);
     if (c->hFlag) hipHostFree(c->hFlag);
     if (c->doneCtr) hipFree(c->doneCtr);
-    for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone})
+    for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone,
+                    c->njState, c->njVisD, (void *) c->njVisJ, (void *) c->njTop, (void *) c->njAge, (void *) c->njLogDev})
         if (p) hipFree(p);
+    if (c->njLogHost) hipHostFree(c->njLogHost);
+    if (c->njStatusHost) hipHostFree(c->njStatusHost);
     if (c->pairStage) hipFree(c->pairStage);
     if (c->pairIn) hipFree(c->pairIn);
     if (c->hOutDist) hipHostFree(c->hOutDist);
@@ -2331,6 +2343,374 @@ extern "C" int vft_tophits_refresh(vft_ctx *c, int64_t newnode, int32_t nHits, c
     if (int r = wait_flag(c, seq)) return r;
     memcpy(lens, h + inB + oLen, (size_t) nWork * 4);
     memcpy(first, h + inB + oFirst, (size_t) nWork * hitB);
+    return VFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- join engine
+template <typename REAL>
+static NjEngine<REAL> njengine(const vft_ctx *c) {
+    NjEngine<REAL> E;
+    E.st = (NjState<REAL> *) c->njState;
+    E.visJ = c->njVisJ;
+    E.visD = (REAL *) c->njVisD;
+    E.topvis = c->njTop;
+    E.age = c->njAge;
+    E.logDev = c->njLogDev;
+    E.logHost = c->njLogHostDev;
+    E.hostStatus = c->njStatusDev;
+    E.m = c->njCfg.m;
+    E.nTop = c->njCfg.n_top;
+    E.need = c->njCfg.need;
+    E.ageLimit = c->njCfg.age_limit;
+    E.fastest = c->njCfg.fastest;
+    E.staleStamp = clamp_i32(c->njCfg.stale_stamp);
+    E.staleOutLimit = c->njCfg.stale_out_limit;
+    E.tol = c->fpostTol;
+    E.stash = (REAL *) c->pendBase;
+    E.pendIds = c->pendIdsDev;
+    return E;
+}
+
+template <typename REAL>
+static __global__ void k_nj_set_state(NjState<REAL> *st, long long nActive, long long maxnode, double totdiam, int32_t tvAge, int32_t clearHalt,
+                                      volatile long long *hostStatus) {
+    if (nActive >= 0) st->nActive = nActive;
+    if (maxnode >= 0) st->maxnode = maxnode;
+    if (totdiam == totdiam) st->totdiam = totdiam;
+    if (tvAge >= 0) st->tvAge = tvAge;
+    if (clearHalt) {
+        st->halt = 0;
+        hostStatus[1] = 0;
+        __threadfence_system();
+    }
+}
+
+template <typename REAL>
+static __global__ void k_nj_nodes_set(NjEngine<REAL> E, const int64_t *nodes, const int32_t *j, const REAL *dist, int64_t n, int32_t age) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t v = nodes[t];
+    if (j) {
+        E.visJ[v] = j[t];
+        E.visD[v] = dist[t];
+    }
+    if (age >= 0) E.age[v] = age;
+}
+
+static __global__ void k_copy_i32(int32_t *dst, const int32_t *src, int64_t n) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+
+extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg) {
+    if (!c || !cfg || cfg->m < 1 || cfg->n_top < 1) return VFT_ERR_INVALID;
+    if (!c->thHits || cfg->m != c->thM) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: vft_tophits_create(m) first");
+    if (c->njState) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: the engine exists already");
+    if (c->rowMode) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create belongs to the NJ phase");
+    c->njCfg = *cfg;
+    const size_t rs = c->rs, stB = c->rs == 4 ? sizeof(NjState<float>) : sizeof(NjState<double>);
+    const size_t pairLds = pw_lds_bytes(c) / c->pwWaves;
+    int P = 2;
+    while (P < 2 * cfg->m) P <<= 1;
+    c->njP = P;
+    c->njScanLds = 0;
+    // k_nj_glue_scan: pair staging | keys | slot criteria | distances by staging index | slot cache | stale list | pass list
+    c->njTailLds = pairLds + (size_t) P * sizeof(ThKey) + (size_t) cfg->n_top * 8 + (size_t) P * rs + (size_t) cfg->n_top * rs +
+                   (size_t) cfg->n_top * 12 + (size_t) (2 * cfg->n_top + 2 * P + 2) * 4 + (size_t) P * 4 + 64;
+    if (c->njTailLds > (160u << 10) - (16u << 10)) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists too long for the merge kernel's LDS");
+    if (int r = ensure_ml_rows(c)) return r;
+    if (!c->pendBase) {
+        const CommitPlan plan = commit_plan(c, VFT_PEND_MAX);
+        HIPCHK(c, hipMalloc((void **) &c->pendBase, plan.totalB + 512));
+        HIPCHK(c, hipMalloc((void **) &c->pendIdsDev, VFT_PEND_MAX * sizeof(int64_t)));
+    }
+    const size_t nodes = (size_t) c->d.maxNodes, joins = (size_t) c->d.nSeqs;
+    HIPCHK(c, hipMalloc(&c->njState, stB));
+    HIPCHK(c, hipMemsetAsync(c->njState, 0, stB, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->njVisJ, nodes * 4));
+    HIPCHK(c, hipMemsetAsync(c->njVisJ, 0xFF, nodes * 4, c->stream));
+    HIPCHK(c, hipMalloc(&c->njVisD, nodes * rs));
+    HIPCHK(c, hipMemsetAsync(c->njVisD, 0, nodes * rs, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->njTop, (size_t) cfg->n_top * 4));
+    HIPCHK(c, hipMemsetAsync(c->njTop, 0xFF, (size_t) cfg->n_top * 4, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->njAge, nodes * 4));
+    HIPCHK(c, hipMemsetAsync(c->njAge, 0, nodes * 4, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->njLogDev, joins * sizeof(NjJoinRec)));
+    HIPCHK(c, hipHostMalloc((void **) &c->njLogHost, joins * sizeof(NjJoinRec), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **) &c->njLogHostDev, c->njLogHost, 0));
+    HIPCHK(c, hipHostMalloc((void **) &c->njStatusHost, 64, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **) &c->njStatusDev, c->njStatusHost, 0));
+    memset(c->njStatusHost, 0, 64);
+    VFT_DISPATCH(c, {
+        if (c->njTailLds > (48u << 10))
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_scan<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->njTailLds));
+        if (pairLds > (48u << 10)) {
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_best<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_best_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_join<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_refresh_new<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_merge_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+        }
+    });
+    return VFT_OK;
+}
+
+#define NJ_ENGINE_OK(c) do { if (!(c)) return VFT_ERR_INVALID; if (!(c)->njState) return fail((c), VFT_ERR_STATE, "no join engine (vft_nj_engine_create)"); } while (0)
+
+extern "C" int vft_nj_engine_set_state(vft_ctx *c, int64_t nActive, int64_t maxnode, double totdiam, int32_t tvAge) {
+    NJ_ENGINE_OK(c);
+    if (c->rs == 4) launch((k_nj_set_state<float>), dim3(1), dim3(1), 0, c->stream, (NjState<float> *) c->njState, (long long) nActive, (long long) maxnode, totdiam, tvAge, 0, c->njStatusDev);
+    else launch((k_nj_set_state<double>), dim3(1), dim3(1), 0, c->stream, (NjState<double> *) c->njState, (long long) nActive, (long long) maxnode, totdiam, tvAge, 0, c->njStatusDev);
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+template <typename REAL>
+static int nj_get_state(vft_ctx *c, int64_t *nActive, int64_t *maxnode, double *totdiam, int32_t *tvAge, int64_t *joinsDone, int32_t *halt,
+                        int32_t *haltJoin, int32_t *nUnique) {
+    NjState<REAL> st;
+    HIPCHK(c, hipMemcpyAsync(&st, c->njState, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nActive) *nActive = st.nActive;
+    if (maxnode) *maxnode = st.maxnode;
+    if (totdiam) *totdiam = st.totdiam;
+    if (tvAge) *tvAge = st.tvAge;
+    if (joinsDone) *joinsDone = st.joinsDone;
+    if (halt) *halt = st.halt;
+    if (haltJoin) *haltJoin = st.haltJoin;
+    if (nUnique) *nUnique = st.nUnique;
+    return VFT_OK;
+}
+extern "C" int vft_nj_engine_get_state(vft_ctx *c, int64_t *nActive, int64_t *maxnode, double *totdiam, int32_t *tvAge, int64_t *joinsDone,
+                                       int32_t *halt, int32_t *haltJoin, int32_t *nUnique) {
+    NJ_ENGINE_OK(c);
+    return c->rs == 4 ? nj_get_state<float>(c, nActive, maxnode, totdiam, tvAge, joinsDone, halt, haltJoin, nUnique)
+                      : nj_get_state<double>(c, nActive, maxnode, totdiam, tvAge, joinsDone, halt, haltJoin, nUnique);
+}
+
+extern "C" int vft_nj_engine_visible_set(vft_ctx *c, int64_t first, int64_t count, const int32_t *j, const void *dist) {
+    NJ_ENGINE_OK(c);
+    if (first < 0 || count < 0 || first + count > c->d.maxNodes || !j || !dist) return VFT_ERR_INVALID;
+    HIPCHK(c, hipMemcpyAsync(c->njVisJ + first, j, (size_t) count * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char *) c->njVisD + (size_t) first * c->rs, dist, (size_t) count * c->rs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_visible_get(vft_ctx *c, int64_t first, int64_t count, int32_t *j, void *dist) {
+    NJ_ENGINE_OK(c);
+    if (first < 0 || count < 0 || first + count > c->d.maxNodes || !j || !dist) return VFT_ERR_INVALID;
+    HIPCHK(c, hipMemcpyAsync(j, c->njVisJ + first, (size_t) count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist, (char *) c->njVisD + (size_t) first * c->rs, (size_t) count * c->rs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_nodes_set(vft_ctx *c, int64_t n, const int64_t *nodes, const int32_t *j, const void *dist, int32_t age) {
+    NJ_ENGINE_OK(c);
+    if (n < 0 || (n > 0 && !nodes) || (j && !dist)) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    for (int64_t t = 0; t < n; t++)
+        if (nodes[t] < 0 || nodes[t] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_nj_engine_nodes_set: node %lld out of range", (long long) t);
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+    const size_t oN = 0, oJ = pad((size_t) n * 8), oD = oJ + pad((size_t) n * 4), tot = oD + pad((size_t) n * c->rs);
+    char *h, *d;
+    if (tot <= VFT_SMALL_BYTES) {
+        if (int r = io_alloc(c, tot, &h, &d)) return r;
+        memcpy(h + oN, nodes, (size_t) n * 8);
+        if (j) memcpy(h + oJ, j, (size_t) n * 4);
+        if (j) memcpy(h + oD, dist, (size_t) n * c->rs);
+    } else {
+        if (int r = ensure_scratch(c, tot + 256)) return r;
+        d = (char *) c->scratch;
+        HIPCHK(c, hipMemcpyAsync(d + oN, nodes, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+        if (j) HIPCHK(c, hipMemcpyAsync(d + oJ, j, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+        if (j) HIPCHK(c, hipMemcpyAsync(d + oD, dist, (size_t) n * c->rs, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->rs == 4)
+        launch((k_nj_nodes_set<float>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, njengine<float>(c), (const int64_t *) (d + oN),
+               j ? (const int32_t *) (d + oJ) : (const int32_t *) nullptr, (const float *) (d + oD), n, age);
+    else
+        launch((k_nj_nodes_set<double>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, njengine<double>(c), (const int64_t *) (d + oN),
+               j ? (const int32_t *) (d + oJ) : (const int32_t *) nullptr, (const double *) (d + oD), n, age);
+    LAUNCHCHK(c);
+    if (tot > VFT_SMALL_BYTES) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_topvisible_set(vft_ctx *c, const int32_t *nodes) {
+    NJ_ENGINE_OK(c);
+    if (!nodes) return VFT_ERR_INVALID;
+    const size_t bytes = (size_t) c->njCfg.n_top * 4;
+    char *h, *d;
+    if (int r = io_alloc(c, bytes, &h, &d)) return r;
+    memcpy(h, nodes, bytes);
+    launch(k_copy_i32, dim3(cdiv(c->njCfg.n_top, 256)), dim3(256), 0, c->stream, c->njTop, (const int32_t *) d, (int64_t) c->njCfg.n_top);
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_topvisible_get(vft_ctx *c, int32_t *nodes) {
+    NJ_ENGINE_OK(c);
+    if (!nodes) return VFT_ERR_INVALID;
+    HIPCHK(c, hipMemcpyAsync(nodes, c->njTop, (size_t) c->njCfg.n_top * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_reset_candidates(vft_ctx *c, int64_t nActive, double totdiam, int32_t k, void *hits, int64_t *nVisible) {
+    NJ_ENGINE_OK(c);
+    if (!hits || !nVisible || k < 1 || k > c->hitsCap || nActive < 1) return VFT_ERR_INVALID;
+    const int64_t maxnode = c->maxnode;
+    if (int r = ensure_scratch(c, (size_t) maxnode * 8 + 512)) return r;
+    unsigned int *dCnt = (unsigned int *) c->scratch;            // [0] stale nodes, [1] nodes with a usable visible hit
+    int64_t *dList = (int64_t *) ((char *) c->scratch + 256);
+    char *h, *d;
+    if (int r = io_alloc(c, 256, &h, &d)) return r;
+    SweepArgs sa{};
+    sa.nActive = nActive;
+    sa.nDiffAllow = (int64_t) ((double) nActive * c->njCfg.stale_out_limit);
+    sa.totdiam = totdiam;
+    HIPCHK(c, hipMemsetAsync(dCnt, 0, 8, c->stream));
+    if (++c->thTag == 0u) {
+        HIPCHK(c, hipMemsetAsync(c->thMark, 0, (size_t) c->d.maxNodes * 4, c->stream));
+        c->thTag = 1u;
+    }
+    const unsigned grid = cdiv(maxnode, VFT_WG);
+    // 1. the lazy refreshes (setCriterion inside getVisible, NJ.tcc:1092-1098) of exactly the nodes the reference touches
+    if (c->rs == 4) launch((k_nj_reset_stale<float>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<float>(c), njengine<float>(c), sa, maxnode, c->thMark, c->thTag, dList, dCnt);
+    else launch((k_nj_reset_stale<double>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<double>(c), njengine<double>(c), sa, maxnode, c->thMark, c->thTag, dList, dCnt);
+    launch(k_nj_publish_u32, dim3(1), dim3(64), 0, c->stream, (const unsigned int *) dCnt, (unsigned int *) d, 1);
+    LAUNCHCHK(c);
+    if (int r = wait_stream(c)) return r;
+    const int64_t nStale = (int64_t) *(volatile unsigned int *) h;
+    if (nStale > 0) {
+        if (nActive > c->maxStamp) c->maxStamp = nActive;
+        VFT_DISPATCH(c, (launch((k_refresh_list<REAL, NC, false>), dim3(cdiv(nStale, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
+                                arena<REAL>(c), (const int64_t *) dList, nStale, (int64_t) 0, sa)));
+    }
+    // 2. criteria as a sweep-shaped result in slot 0, 3. the selection of the sweeps
+    if (int r = ensure_slots(c, 1)) return r;
+    c->nPart = (int) grid;
+    c->slots[0].nPart = (int) grid;
+    if (c->rs == 4) launch((k_nj_reset_crit<float>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<float>(c), njengine<float>(c), sa, maxnode, sweepout<float>(c, 0), dCnt + 1);
+    else launch((k_nj_reset_crit<double>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<double>(c), njengine<double>(c), sa, maxnode, sweepout<double>(c, 0), dCnt + 1);
+    launch(k_nj_publish_u32, dim3(1), dim3(64), 0, c->stream, (const unsigned int *) dCnt, (unsigned int *) d, 2);
+    LAUNCHCHK(c);
+    const int64_t query = -1;
+    int r;
+    if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, 1, &query, 0, maxnode, k);
+    else r = run_select<double, vft_hit_f64>(c, 1, &query, 0, maxnode, k);
+    if (r) return r;
+    *nVisible = (int64_t) ((volatile unsigned int *) h)[1];
+    memcpy(hits, c->hRes + sizeof(SelectHeader), (size_t) k * (c->cfg.precision == 4 ? sizeof(vft_hit_f32) : sizeof(vft_hit_f64)));
+    return VFT_OK;
+}
+
+template <typename REAL, int NC>
+static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t updateOut) {
+    const Arena<REAL> A = arena<REAL>(c);
+    NjEngine<REAL> E = njengine<REAL>(c);
+    const TopHits<REAL> T = tophits<REAL>(c);
+    const size_t pairLds = pw_lds_bytes(c) / c->pwWaves;
+    const long long ji = (long long) joinIndex;
+    const int64_t newnode = c->d.nSeqs + joinIndex;   // (ids are handed out in join order)
+    if (phases & VFT_NJ_PHASE_JOIN) {
+        if (newnode >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_nj_engine_enqueue: join %lld out of range", (long long) joinIndex);
+        // Room in the pending stash BEFORE anything is launched (a refused call must not have enqueued half a join).  Every
+        // pending node must really exist before its tile is rebuilt: the joins enqueued so far have run - or an event has
+        // stopped them, which the caller handles first.
+        if ((c->pend.empty() || c->pend.back() != newnode) && (int64_t) c->pend.size() == VFT_PEND_MAX) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if ((__atomic_load_n(&c->njStatusHost[1], __ATOMIC_ACQUIRE) >> 32) != 0)
+                return fail(c, VFT_ERR_STATE, "vft_nj_engine_enqueue: the engine has halted (handle the event first)");
+            if (int r = flush_pending(c)) return r;
+            E = njengine<REAL>(c);
+        }
+    }
+    // one hill-climbing round up to its last comparison, which k_nj_glue_join makes
+    auto round = [&]() {
+        launch((k_nj_best_pairs<REAL, NC>), dim3((unsigned) c->thM), dim3(VFT_WG), pairLds, c->stream, A, E, T, 0);
+        launch((k_nj_glue_best<REAL, NC>), dim3(1), dim3(VFT_WG), pairLds, c->stream, A, E, T);
+        launch((k_nj_best_pairs<REAL, NC>), dim3((unsigned) c->thM), dim3(VFT_WG), pairLds, c->stream, A, E, T, 1);
+    };
+    if (phases & VFT_NJ_PHASE_SEARCH) {
+        launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, -1ll, ji, c->njP);
+        if (!c->njCfg.fastest) round();
+    }
+    if (phases & VFT_NJ_PHASE_CLIMB) round();
+    if (phases & VFT_NJ_PHASE_JOIN) {
+        // host-side bookkeeping of vft_join_fused (a join that is enqueued again after a halt keeps its slot)
+        if (c->pend.empty() || c->pend.back() != newnode) c->pend.push_back(newnode);
+        if (newnode >= c->maxnode) c->maxnode = newnode + 1;
+        if ((int64_t) E.staleStamp > c->maxStamp) c->maxStamp = E.staleStamp;
+        const int32_t slot = (int32_t) c->pend.size() - 1;
+        launch((k_nj_glue_join<REAL, NC>), dim3(1), dim3(VFT_WG_PROF), pairLds, c->stream, arena<REAL>(c), E, T, ji, updateOut, slot, 1);
+    }
+    if (phases & VFT_NJ_PHASE_MERGE) {
+        if (++c->thTag == 0u) {
+            HIPCHK(c, hipMemsetAsync(c->thMark, 0, (size_t) c->d.maxNodes * 4, c->stream));
+            c->thTag = 1u;
+        }
+        // (the join kernel computes the new node's out-distance itself unless the caller recomputes the out-profile in between)
+        if (!updateOut) launch((k_nj_refresh_new<REAL, NC>), dim3(1), dim3(VFT_WG), pairLds, c->stream, A, E);
+        launch((k_nj_merge_pairs<REAL, NC>), dim3((unsigned) (2 * c->thM)), dim3(VFT_WG), pairLds, c->stream, A, E, T, ji, c->thTag);
+        const bool chain = (phases & VFT_NJ_PHASE_NEXT) != 0;
+        launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, ji, chain ? ji + 1 : -1ll, c->njP);
+        if (chain && !c->njCfg.fastest) round();
+    }
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t updateOut) {
+    NJ_ENGINE_OK(c);
+    if (joinIndex < 0 || joinIndex >= c->d.nSeqs) return VFT_ERR_INVALID;
+    int r = VFT_OK;
+    VFT_DISPATCH(c, (r = nj_enqueue<REAL, NC>(c, joinIndex, phases, updateOut)));
+    return r;
+}
+
+extern "C" int vft_nj_engine_poll(vft_ctx *c, int64_t *joinsDone, int32_t *halt, int32_t *haltJoin) {
+    NJ_ENGINE_OK(c);
+    volatile long long *s = c->njStatusHost;
+    const long long h = __atomic_load_n(&s[1], __ATOMIC_ACQUIRE);   // (halt << 32) | join, written in one piece
+    if (joinsDone) *joinsDone = __atomic_load_n(&s[0], __ATOMIC_ACQUIRE);
+    if (halt) *halt = (int32_t) (h >> 32);
+    if (haltJoin) *haltJoin = (int32_t) (h & 0xFFFFFFFFll);
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_resume(vft_ctx *c, int64_t nextJoin) {
+    NJ_ENGINE_OK(c);
+    // joins enqueued behind the event have not run: their pending slots and node ids are handed out again
+    const int64_t firstFree = c->d.nSeqs + nextJoin;
+    while (!c->pend.empty() && c->pend.back() >= firstFree) c->pend.pop_back();
+    if (c->maxnode > firstFree) c->maxnode = firstFree;
+    c->njStatusHost[1] = 0;
+    if (c->rs == 4) launch((k_nj_set_state<float>), dim3(1), dim3(1), 0, c->stream, (NjState<float> *) c->njState, -1ll, -1ll, (double) NAN, -1, 1, c->njStatusDev);
+    else launch((k_nj_set_state<double>), dim3(1), dim3(1), 0, c->stream, (NjState<double> *) c->njState, -1ll, -1ll, (double) NAN, -1, 1, c->njStatusDev);
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_log(vft_ctx *c, const vft_nj_join_t **log) {
+    NJ_ENGINE_OK(c);
+    if (!log) return VFT_ERR_INVALID;
+    *log = (const vft_nj_join_t *) c->njLogHost;
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_engine_adopt(vft_ctx *c, int64_t from, int64_t to) {
+    NJ_ENGINE_OK(c);
+    if (from < 0 || to > c->d.nSeqs || from > to) return VFT_ERR_INVALID;
+    for (int64_t k = from; k < to; k++) {
+        const NjJoinRec &r = c->njLogHost[k];
+        if (r.i < 0 || r.j < 0 || r.i >= c->d.maxNodes || r.j >= c->d.maxNodes || r.newnode != (int32_t) (c->d.nSeqs + k))
+            return fail(c, VFT_ERR_STATE, "vft_nj_engine_adopt: join %lld has not been logged", (long long) k);
+        c->hParent[(size_t) r.i] = c->hParent[(size_t) r.j] = r.newnode;
+        if ((int64_t) r.newnode >= c->maxnode) c->maxnode = (int64_t) r.newnode + 1;
+    }
     return VFT_OK;
 }
 

@@ -7,10 +7,17 @@
 // in between: 377 us per join at a million sequences.  Here the visible set (visible[] / topvisible[], NJ.h:236-246), the
 // ages of the lists and the scalars of the loop (nActive, maxnode, totdiam, the candidate join) live next to the lists
 // (vft_kernels_tophits.h) and a join is the launch sequence
-//     k_nj_scan                                   top-visible scan, candidate join, reset test           (:4137-4209)
-//     k_nj_refresh_cur, k_nj_best_pairs, k_nj_best_tail   x2: getBestFromTopHits for both ends       (:4226-4261, 4267-4298)
-//     k_nj_refresh_cur x2, k_nj_join              criterion on fresh out-distances, the join itself      (:2897-3042)
-//     k_nj_refresh_new, k_nj_merge_pairs, k_nj_merge_tail   the new node's list, visible-set updates   (:4306-4438, 4633-4726)
+//     k_nj_best_pairs(i)     getBestFromTopHits for the first end: one workgroup per list entry       (:4267-4298)
+//     k_nj_glue_best         its result against the candidate; setOutDistance of the (new) second end   (:4226-4240)
+//     k_nj_best_pairs(j)     getBestFromTopHits for the second end
+//     k_nj_glue_join         its result against the candidate (:4243-4260); the join itself: criterion on fresh
+//                            out-distances, tree arrays, branch lengths, profile, out-profile (:2897-3042); the new node's
+//                            out-distance
+//     k_nj_merge_pairs       uniqueBestHits of the children's lists: one workgroup per entry           (:4319-4330, 4786-4833)
+//     k_nj_glue_scan         the rest of topHitJoin (:4342-4438: decision, sortSaveBestHits, visible-set updates :4633-4726)
+//                            AND topHitNJSearch of the next join up to the hill climbing (:4137-4223), setOutDistance of
+//                            its first end
+// - three wide kernels and three single-workgroup "glue" kernels per join (-fastest: no hill climbing, three kernels).
 // Every kernel starts by looking at state->halt and does nothing when an earlier kernel has raised it; the host resumes
 // after it has dealt with the event.  Results are bit-identical to the host-driven loop (same formulas, same order of every
 // floating-point operation; -ffp-contract=off).
@@ -37,7 +44,7 @@ struct NjState {
     int32_t halt, haltJoin, changed, tvAge;
     int32_t curI, curJ;
     REAL curDist, curCrit;
-    int32_t nUnique, pad;
+    int32_t nUnique, runRound;   // runRound: the hill-climbing round whose kernels come next executes (NJ.tcc:4226-4262: "while (changed)")
 };
 
 template <typename REAL>
@@ -48,7 +55,7 @@ struct NjEngine {
     int32_t *topvis;        // topvisible[nTop] (NJ.h:242-246)
     int32_t *age;           // TopHitsList::age
     NjJoinRec *logDev, *logHost;
-    volatile long long *hostStatus;   // host-mapped: [0] joinsDone, [1] halt, [2] haltJoin
+    volatile long long *hostStatus;   // host-mapped: [0] joinsDone, [1] (halt << 32) | haltJoin
     int32_t m, nTop, need, ageLimit, fastest, staleStamp;
     double staleOutLimit, tol;
     REAL *stash;            // vft_join_fused's pending stash
@@ -67,6 +74,13 @@ __device__ __forceinline__ SweepArgs vft_nj_args(const NjEngine<REAL> &E, long l
     s.nDiffAllow = vft_nj_allow(E, nActive);
     s.totdiam = totdiam;
     return s;
+}
+
+// Loads of state that a thread of the SAME workgroup may have rewritten earlier in the kernel (out-distances refreshed by
+// thread 0, visible[] entries): served by the L2, never by a vector-L1 line cached before the write.
+template <typename T>
+__device__ __forceinline__ T vft_nj_ld(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // setOutDistance(v) by the whole workgroup (NJ.tcc:1012-1053); every thread calls
@@ -89,9 +103,13 @@ __device__ __forceinline__ void vft_nj_out_distance(const Arena<REAL> &A, const 
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_nj_refresh_listed(const Arena<REAL> &A, const SweepArgs &s, const int32_t *list, int n,
                                                       double *sW, double *sT) {
+    __shared__ int njGo;
     for (int k = 0; k < n; k++) {
         const int32_t v = list[k];
-        if (!((long long) A.nOutActive[v] - s.nActive > s.nDiffAllow)) continue;   // (uniform: every thread reads the same word)
+        __syncthreads();
+        if (threadIdx.x == 0) njGo = (long long) vft_nj_ld(&A.nOutActive[v]) - s.nActive > s.nDiffAllow;   // one verdict for the workgroup
+        __syncthreads();
+        if (!njGo) continue;
         vft_nj_out_distance<REAL, NC>(A, s, v, sW, sT);
     }
 }
@@ -101,118 +119,457 @@ template <typename REAL>
 __device__ __forceinline__ bool vft_nj_visible_ok(const Arena<REAL> &A, const NjEngine<REAL> &E, int32_t node, int32_t &vj) {
     vj = -1;
     if (node < 0 || A.parent[node] >= 0) return false;
-    vj = E.visJ[node];
+    vj = vft_nj_ld(&E.visJ[node]);
     return vj >= 0 && A.parent[vj] < 0;
 }
 
 template <typename REAL>
 __device__ __forceinline__ REAL vft_nj_crit(const Arena<REAL> &A, REAL dist, int32_t i, int32_t j, long long nActive) {
-    return vft_criterion<REAL>(dist, A.outDist[i], A.nOutActive[i], A.outDist[j], A.nOutActive[j], nActive);
+    return vft_criterion<REAL>(dist, vft_nj_ld(&A.outDist[i]), vft_nj_ld(&A.nOutActive[i]), vft_nj_ld(&A.outDist[j]),
+                               vft_nj_ld(&A.nOutActive[j]), nActive);
+}
+
+template <typename REAL>
+__device__ __forceinline__ bool vft_nj_stale(const Arena<REAL> &A, const SweepArgs &s, int32_t v) {
+    return (long long) vft_nj_ld(&A.nOutActive[v]) - s.nActive > s.nDiffAllow;
 }
 
 template <typename REAL>
 __device__ __forceinline__ void vft_nj_publish(const NjEngine<REAL> &E, const NjState<REAL> *st) {
+    // two 8-byte words, each written in one piece: [0] joins completed, [1] (halt reason << 32) | join it belongs to
     E.hostStatus[0] = st->joinsDone;
-    E.hostStatus[1] = st->halt;
-    E.hostStatus[2] = st->haltJoin;
+    __threadfence_system();
+    E.hostStatus[1] = ((long long) st->halt << 32) | (long long) (uint32_t) st->haltJoin;
     __threadfence_system();
 }
 
+// (criterion, slot) reduction over the workgroup: the first minimum in slot order (MAXLAST = false; no candidate: slot
+// 0x7FFFFFFF) or the last maximum (MAXLAST = true; no candidate: slot -1).  Wave shuffles, then one LDS exchange: three barriers
+// instead of log2(threads).  Every thread calls; every thread gets the result.  redC / redT: blockDim.x / 64 entries.
+template <bool MAXLAST>
+__device__ __forceinline__ void vft_nj_arg_reduce(double &c, int &t, double *redC, int *redT) {
+    constexpr int inv = MAXLAST ? -1 : 0x7FFFFFFF;
+    auto take = [&](double c2, int t2) {
+        const bool better = t2 != inv && (t == inv || (MAXLAST ? (c2 > c || (c2 == c && t2 > t)) : (c2 < c || (c2 == c && t2 < t))));
+        if (better) {
+            c = c2;
+            t = t2;
+        }
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double c2 = __shfl_xor(c, off, 64);
+        const int t2 = __shfl_xor(t, off, 64);
+        take(c2, t2);
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        redC[wave] = c;
+        redT[wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        c = (int) threadIdx.x < nw ? redC[threadIdx.x] : 0.0;
+        t = (int) threadIdx.x < nw ? redT[threadIdx.x] : inv;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double c2 = __shfl_xor(c, off, 64);
+            const int t2 = __shfl_xor(t, off, 64);
+            take(c2, t2);
+        }
+        if (threadIdx.x == 0) {
+            redC[0] = c;
+            redT[0] = t;
+        }
+    }
+    __syncthreads();
+    c = redC[0];
+    t = redT[0];
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// topHitNJSearch up to the hill climbing (NJ.tcc:4137-4223).  One workgroup of VFT_NJ_TAIL threads.
-// Dynamic LDS: 2 * nPosPad doubles | nTop x (int32 stale list x 2)
+// The top-visible list in LDS with everything getVisible computes for its slots, so that updateTopVisible and the scan of the
+// next join run without touching global memory: flags bits 0-1 = 0 empty / dead node, 1 active node without a usable visible
+// hit, 2 usable (node and partner active); bit 2 / 3: the node's / the partner's out-distance is staler than allowed (a
+// getVisible would refresh it first).  Any refresh inside the kernel reloads the whole cache.
+template <typename REAL>
+struct NjSlots {
+    int32_t *node, *vj, *flags;
+    REAL *dist;
+    double *crit;
+    int *anyStale;   // some slot carries a stale flag (set when the cache is loaded)
+};
+
+template <typename REAL>
+__device__ __forceinline__ void vft_nj_slot_load(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s, const NjSlots<REAL> &S, int t) {
+    const int32_t node = S.node[t];
+    int32_t f = 0, vj = -1;
+    REAL d = 0;
+    double cr = 0;
+    if (node >= 0 && A.parent[node] < 0) {
+        vj = vft_nj_ld(&E.visJ[node]);
+        if (vj >= 0 && A.parent[vj] < 0) {
+            f = 2;
+            d = vft_nj_ld(&E.visD[node]);
+            const REAL oi = vft_nj_ld(&A.outDist[node]), oj = vft_nj_ld(&A.outDist[vj]);
+            const int32_t si = vft_nj_ld(&A.nOutActive[node]), sj = vft_nj_ld(&A.nOutActive[vj]);
+            cr = (double) vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
+            if ((long long) si - s.nActive > s.nDiffAllow) f |= 4;
+            if ((long long) sj - s.nActive > s.nDiffAllow) f |= 8;
+        } else {
+            f = 1;
+        }
+    }
+    S.vj[t] = vj;
+    S.flags[t] = f;
+    S.dist[t] = d;
+    S.crit[t] = cr;
+    if (f & 12) *S.anyStale = 1;   // (benign race: every writer stores 1)
+}
+
+// every thread calls; ends with a barrier
+template <typename REAL>
+__device__ __forceinline__ void vft_nj_slots_load(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s, const NjSlots<REAL> &S) {
+    __syncthreads();
+    if (threadIdx.x == 0) *S.anyStale = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) vft_nj_slot_load(A, E, s, S, t);
+    __syncthreads();
+}
+
+// The lazy refreshes the getVisible calls of slots [0, reach) would make (plus `extra` nodes, -1 = none), then the cache again.
+// Every thread calls.  Returns (to every thread) whether anything was refreshed.
 template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_scan(Arena<REAL> A, NjEngine<REAL> E, long long joinIndex) {
+__device__ __forceinline__ bool vft_nj_slots_refresh(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s, const NjSlots<REAL> &S,
+                                                     int reach, int32_t extra0, int32_t extra1, int32_t *staleList, double *sW, double *sT) {
+    __shared__ int njStaleN;
+    if (extra0 < 0 && extra1 < 0 && *S.anyStale == 0) return false;   // (uniform; the common case)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        if (extra0 >= 0 && vft_nj_stale(A, s, extra0)) staleList[n++] = extra0;
+        if (extra1 >= 0 && vft_nj_stale(A, s, extra1)) staleList[n++] = extra1;
+        njStaleN = n;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < reach; t += blockDim.x) {
+        const int32_t f = S.flags[t];
+        if ((f & 3) != 2) continue;
+        if (f & 4) staleList[atomicAdd(&njStaleN, 1)] = S.node[t];
+        if (f & 8) staleList[atomicAdd(&njStaleN, 1)] = S.vj[t];
+    }
+    __syncthreads();
+    const int n = njStaleN;
+    if (n == 0) return false;
+    vft_nj_refresh_listed<REAL, NC>(A, s, staleList, n, sW, sT);
+    __syncthreads();
+    vft_nj_slots_load(A, E, s, S);
+    return true;
+}
+
+// updateTopVisible(iIn, hit) (NJ.tcc:4660-4726) on the cached list, by the whole workgroup:
+//   1. the first slot that holds iIn already or a dead / empty node takes (iIn, hit);
+//   2. otherwise getVisible of every slot in order until one fails (iIn takes that slot) or shows the same pair from the other
+//      side (done); the lazy refreshes of those getVisible calls only happen for the slots the reference's loop reaches;
+//   3. otherwise the slot with the worst criterion (the last one among equals) is replaced if the new hit is better.
+// hitCrit: the criterion of (iIn, hit.j) as the merge computed it - valid while *nRefreshes (refreshes made by this kernel so
+// far) is zero, recomputed otherwise.
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s,
+                                                          const NjSlots<REAL> &S, int32_t iIn, int32_t hitJ, REAL hitDist, REAL hitCrit,
+                                                          int *nRefreshes, double *sW, double *sT, int32_t *staleList, double *redC, int *redT) {
+    __shared__ int first1, stop2;
+    if (threadIdx.x == 0) {
+        first1 = 0x7FFFFFFF;
+        stop2 = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
+        if (S.node[t] == iIn) {
+            // visible[iIn] has just become `hit`: every slot that holds iIn shows it from now on (the list may hold a node more
+            // than once: step 1 takes a dead slot in front of the node's own)
+            S.vj[t] = hitJ;
+            S.dist[t] = hitDist;
+            S.crit[t] = (double) (*nRefreshes == 0 ? hitCrit : vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, s.nActive));
+            S.flags[t] = 2;
+        }
+        if (S.node[t] == iIn || (S.flags[t] & 3) == 0) atomicMin(&first1, t);
+    }
+    __syncthreads();
+    const int f1 = first1;
+    auto takeSlot = [&](int t) {   // thread 0: slot t now shows (iIn -> hit.j); its criterion from current out-distances
+        S.node[t] = iIn;
+        S.vj[t] = hitJ;
+        S.dist[t] = hitDist;
+        S.crit[t] = (double) (*nRefreshes == 0 ? hitCrit : vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, s.nActive));
+        // (neither end can be staler than allowed: the merge of this join has just evaluated setCriterion on this very pair)
+        S.flags[t] = 2;
+    };
+    if (f1 != 0x7FFFFFFF) {
+        if (threadIdx.x == 0) takeSlot(f1);   // (a slot that held iIn already shows its new visible hit from now on)
+        __syncthreads();
+        return;
+    }
+    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x)
+        if ((S.flags[t] & 3) != 2 || (S.node[t] == hitJ && S.vj[t] == iIn)) atomicMin(&stop2, t);
+    __syncthreads();
+    const int stop = stop2;
+    const bool stopOk = stop != 0x7FFFFFFF && (S.flags[stop] & 3) == 2;   // the same pair from the other side
+    const int reach = stop == 0x7FFFFFFF ? E.nTop : (stopOk ? stop + 1 : stop);
+    // (the final setCriterion(iIn, hit.j), made when the scan did not stop, cannot refresh anything: the merge of this join has
+    //  just evaluated setCriterion on this very pair)
+    if (vft_nj_slots_refresh<REAL, NC>(A, E, s, S, reach, -1, -1, staleList, sW, sT)) {
+        if (threadIdx.x == 0) (*nRefreshes)++;
+        __syncthreads();
+    }
+    if (stop != 0x7FFFFFFF) {
+        if (!stopOk && threadIdx.x == 0) takeSlot(stop);
+        __syncthreads();
+        return;
+    }
+    // the worst slot: "vis.criterion >= critWorst" in slot order = the largest criterion, the last one among equals
+    double wc = -1e20;
+    int wt = -1;
+    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
+        const double c = S.crit[t];
+        if (c >= wc) {
+            wc = c;
+            wt = t;
+        }
+    }
+    vft_nj_arg_reduce<true>(wc, wt, redC, redT);
+    if (threadIdx.x == 0 && wt >= 0) {
+        const REAL b = *nRefreshes == 0 ? hitCrit : vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, s.nActive);
+        if ((double) b < wc) takeSlot(wt);
+    }
+    __syncthreads();
+}
+
+// setOutDistance(v) unless its stamp is nActive (NJ.tcc:1012-1015); every thread calls, v uniform
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_nj_force_out_distance(const Arena<REAL> &A, const SweepArgs &s, int64_t v, double *sW, double *sT) {
+    __shared__ int njForce;
+    __syncthreads();
+    if (threadIdx.x == 0) njForce = (long long) vft_nj_ld(&A.nOutActive[v]) != s.nActive;
+    __syncthreads();
+    if (njForce) vft_nj_out_distance<REAL, NC>(A, s, v, sW, sT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_nj_glue_scan: [the rest of topHitJoin for join `doneJoin` (>= 0): NJ.tcc:4342-4438 - the age of the new list, the decision,
+// sortSaveBestHits, the new node's visible hit, updateTopVisible for it, updateVisible over the saved hits] + [topHitNJSearch
+// of join `nextJoin` (>= 0) up to the hill climbing, NJ.tcc:4137-4223: the lazy refreshes of the scan, the best visible hit,
+// the reset test; then setOutDistance of the candidate's first end (both ends with -fastest, which does not climb)].
+// One workgroup of VFT_NJ_TAIL threads.  Dynamic LDS: pair staging | ThKey[P] | REAL[P] | slot cache (3 int32 + REAL +
+// double per slot) | int32[2 nTop + 2 P + 2] stale list | int32[P] pass list.
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long doneJoin,
+                                                              long long nextJoin, int P) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     NjState<REAL> *st = E.st;
     if (st->halt) return;
     double *sW = njLds, *sT = njLds + A.d.nPosPad;
-    int32_t *staleList = (int32_t *) (njLds + 2 * A.d.nPosPad);
-    __shared__ int nStale, nCand;
+    ThKey *keys = (ThKey *) (njLds + 2 * A.d.nPosPad);
+    double *critS = (double *) (keys + P);
+    REAL *distL = (REAL *) (critS + E.nTop);
+    NjSlots<REAL> S;
+    S.crit = critS;
+    S.dist = distL + P;
+    S.node = (int32_t *) (S.dist + E.nTop);
+    S.vj = S.node + E.nTop;
+    S.flags = S.vj + E.nTop;
+    int32_t *staleList = S.flags + E.nTop;
+    int32_t *passList = staleList + 2 * E.nTop + 2 * P + 2;
+    __shared__ int thCount, nPass, nRefreshes, nCand, slotsStale;
+    S.anyStale = &slotsStale;
     __shared__ double redC[VFT_NJ_TAIL];
     __shared__ int redT[VFT_NJ_TAIL];
     const long long nActive = st->nActive;
     const SweepArgs s = vft_nj_args(E, nActive, st->totdiam);
-    if (threadIdx.x == 0) nStale = nCand = 0;
+    if (threadIdx.x == 0) thCount = nPass = nRefreshes = nCand = 0;
+    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) S.node[t] = E.topvis[t];
     __syncthreads();
-    // prefetchVisible(topvisible): the lazy refreshes of every getVisible of the scan
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        int32_t vj;
-        const int32_t node = E.topvis[t];
-        if (!vft_nj_visible_ok(A, E, node, vj)) continue;
-        if ((long long) A.nOutActive[node] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale, 1)] = node;
-        if ((long long) A.nOutActive[vj] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale, 1)] = vj;
+    vft_nj_slots_load(A, E, s, S);
+    if (doneJoin >= 0) {
+        const NjJoinRec rec = E.logDev[doneJoin];
+        const int32_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
+        const int n = T.len[c0] + T.len[c1];
+        for (int u = threadIdx.x; u < n; u += blockDim.x) {
+            const int32_t ju = T.stJ[u];
+            if (ju < 0) continue;
+            ThKey k;
+            k.key = vft_th_order(T.stC[u]);
+            k.nj = ~(uint32_t) ju;
+            k.src = u;
+            keys[atomicAdd(&thCount, 1)] = k;
+            distL[u] = T.stD[u];
+        }
+        __syncthreads();
+        const int nU = thCount;
+        int P1 = 2;
+        while (P1 < nU) P1 <<= 1;
+        for (int u = nU + threadIdx.x; u < P1; u += blockDim.x) {
+            ThKey k;
+            k.key = ~0ull;
+            k.nj = ~0u;
+            k.src = -1;
+            keys[u] = k;
+        }
+        vft_th_bitonic(keys, P1);   // (a counting sort by the whole workgroup was measured slower: 4 M key comparisons on one CU)
+        // NJ.tcc:4342-4362
+        const int32_t ageNew = (E.age[c0] + E.age[c1] + 1) / 2 + 1;
+        const bool useUnique = (long long) nU == nActive - 1 || (ageNew <= E.ageLimit && nU >= E.need);
+        if (!useUnique) {
+            if (threadIdx.x == 0) {
+                E.age[newnode] = ageNew;
+                st->nUnique = nU;
+                st->joinsDone = doneJoin + 1;
+                st->halt = VFT_NJ_HALT_REFRESH;
+                st->haltJoin = (int32_t) doneJoin;
+                vft_nj_publish(E, st);
+            }
+            return;
+        }
+        const int nSave = nU < E.m ? nU : E.m;
+        for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
+            ThHit<REAL> e;
+            e.j = (int32_t) ~keys[r].nj;
+            e.dist = distL[keys[r].src];
+            T.hits[(int64_t) newnode * T.m + r] = e;
+        }
+        const int32_t firstJ = (int32_t) ~keys[0].nj;
+        const REAL firstD = distL[keys[0].src], firstC = T.stC[keys[0].src];
+        if (threadIdx.x == 0) {
+            E.age[newnode] = ageNew;
+            T.len[newnode] = nSave;
+            E.visJ[newnode] = firstJ;            // visible[newnode] = hits[newnode][0]
+            E.visD[newnode] = firstD;
+        }
+        __syncthreads();
+        vft_nj_update_top_visible<REAL, NC>(A, E, s, S, newnode, firstJ, firstD, firstC, &nRefreshes, sW, sT, staleList, redC, redT);
+        // updateVisible (NJ.tcc:4633-4657) over the saved hits in order.  The getVisible of hit t looks at hit.j's own visible
+        // hit, which only iteration t changes: the lazy refreshes of all of them first, then all tests, then the few hits that
+        // pass update visible[] and the top-visible list one after the other.
+        {
+            // one pass in the common case: getVisible of every hit's partner (its visible hit, both out-distances) and the test;
+            // only when one of those out-distances is staler than allowed (rare) are they refreshed and the pass repeated
+            __shared__ int nStaleV;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                if (threadIdx.x == 0) nStaleV = nPass = 0;
+                __syncthreads();
+                for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
+                    const int32_t node = (int32_t) ~keys[r].nj;
+                    // the hit's criterion as updateVisible sees it: the merge's (hits are not re-evaluated, NJ.tcc:4640-4650)
+                    const REAL hitCrit = T.stC[keys[r].src];
+                    const int32_t vj = vft_nj_ld(&E.visJ[node]);
+                    bool pass = true;
+                    if (vj >= 0 && A.parent[vj] < 0) {   // (node itself is active: it is a candidate of this merge)
+                        const REAL vd = vft_nj_ld(&E.visD[node]);
+                        const REAL oi = vft_nj_ld(&A.outDist[node]), oj = vft_nj_ld(&A.outDist[vj]);
+                        const int32_t si = vft_nj_ld(&A.nOutActive[node]), sj = vft_nj_ld(&A.nOutActive[vj]);
+                        const bool staleI = (long long) si - nActive > s.nDiffAllow, staleJ = (long long) sj - nActive > s.nDiffAllow;
+                        if (staleI || staleJ) {
+                            if (attempt == 0) {
+                                if (staleI) staleList[atomicAdd(&nStaleV, 1)] = node;
+                                if (staleJ) staleList[atomicAdd(&nStaleV, 1)] = vj;
+                            }
+                        }
+                        pass = hitCrit < vft_criterion<REAL>(vd, oi, si, oj, sj, nActive);
+                    }
+                    if (pass) passList[atomicAdd(&nPass, 1)] = r;
+                }
+                __syncthreads();
+                if (nStaleV == 0) break;   // (uniform)
+                vft_nj_refresh_listed<REAL, NC>(A, s, staleList, nStaleV, sW, sT);
+                __syncthreads();
+                vft_nj_slots_load(A, E, s, S);
+                if (threadIdx.x == 0) nRefreshes++;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        const int np = nPass;
+        if (threadIdx.x == 0)   // (in list order: a selection sort over the few entries)
+            for (int a = 0; a < np; a++)
+                for (int b = a + 1; b < np; b++)
+                    if (passList[b] < passList[a]) {
+                        const int32_t x = passList[a];
+                        passList[a] = passList[b];
+                        passList[b] = x;
+                    }
+        __syncthreads();
+        for (int a = 0; a < np; a++) {
+            const int r = passList[a];
+            const int32_t node = (int32_t) ~keys[r].nj;
+            const REAL d = distL[keys[r].src], cr = T.stC[keys[r].src];
+            if (threadIdx.x == 0) {
+                E.visJ[node] = newnode;
+                E.visD[node] = d;
+            }
+            __syncthreads();
+            vft_nj_update_top_visible<REAL, NC>(A, E, s, S, node, newnode, d, cr, &nRefreshes, sW, sT, staleList, redC, redT);
+        }
+        for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) E.topvis[t] = S.node[t];
+        if (threadIdx.x == 0) {
+            st->nUnique = nU;
+            st->joinsDone = doneJoin + 1;
+            if (nextJoin < 0) vft_nj_publish(E, st);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    vft_nj_refresh_listed<REAL, NC>(A, s, staleList, nStale, sW, sT);
-    __syncthreads();
-    // the first minimum in array order ("bestNode < 0 || v.criterion < bestCrit")
+    if (nextJoin < 0) return;
+    // ---- topHitNJSearch(nextJoin): prefetchVisible(topvisible), the first minimum in slot order, the reset test
+    vft_nj_slots_refresh<REAL, NC>(A, E, s, S, E.nTop, -1, -1, staleList, sW, sT);
     double bc = 0;
     int bt = 0x7FFFFFFF, mine = 0;
     for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        int32_t vj;
-        const int32_t node = E.topvis[t];
-        if (!vft_nj_visible_ok(A, E, node, vj)) continue;
+        if ((S.flags[t] & 3) != 2) continue;
         mine++;
-        const double c = (double) vft_nj_crit<REAL>(A, E.visD[node], node, vj, nActive);
+        const double c = S.crit[t];
         if (bt == 0x7FFFFFFF || c < bc) {
             bc = c;
             bt = t;
         }
     }
     if (mine) atomicAdd(&nCand, mine);
-    redC[threadIdx.x] = bc;
-    redT[threadIdx.x] = bt;
-    __syncthreads();
-    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if ((int) threadIdx.x < off) {
-            const double c2 = redC[threadIdx.x + off];
-            const int t2 = redT[threadIdx.x + off];
-            if (t2 != 0x7FFFFFFF && (redT[threadIdx.x] == 0x7FFFFFFF || c2 < redC[threadIdx.x] || (c2 == redC[threadIdx.x] && t2 < redT[threadIdx.x]))) {
-                redC[threadIdx.x] = c2;
-                redT[threadIdx.x] = t2;
-            }
-        }
-        __syncthreads();
-    }
+    vft_nj_arg_reduce<false>(bc, bt, redC, redT);
+    __shared__ int scanHalt, scanI, scanJ;
     if (threadIdx.x == 0) {
         const int age = ++st->tvAge;
         const long long cand = nCand;
-        if (2ll * age > E.m || (3 * cand < E.nTop && 3 * cand < nActive) || redT[0] == 0x7FFFFFFF) {
+        scanHalt = 0;
+        scanI = scanJ = -1;
+        if (2ll * age > E.m || (3 * cand < E.nTop && 3 * cand < nActive) || bt == 0x7FFFFFFF) {
             st->halt = VFT_NJ_HALT_RESET;
-            st->haltJoin = (int32_t) joinIndex;
-            vft_nj_publish(E, st);
+            st->haltJoin = (int32_t) nextJoin;
+            scanHalt = 1;
         } else {
-            const int32_t node = E.topvis[redT[0]];
-            st->curI = node;
-            st->curJ = E.visJ[node];
-            st->curDist = E.visD[node];
-            st->curCrit = (REAL) redC[0];
+            const int b = bt;
+            st->curI = scanI = S.node[b];
+            st->curJ = scanJ = S.vj[b];
+            st->curDist = S.dist[b];
+            st->curCrit = (REAL) S.crit[b];
             st->changed = 0;
+            st->runRound = 1;
         }
+        vft_nj_publish(E, st);
     }
-}
-
-// setOutDistance for one end of the candidate join (which: 0 = i, 1 = j): getBestFromTopHits' own node (NJ.tcc:4273-4279)
-// and the two ends before the join (:2897-2898).  Recomputed unless the stamp is nActive.  One workgroup of VFT_WG threads.
-template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_WG) void k_nj_refresh_cur(Arena<REAL> A, NjEngine<REAL> E, int which, int onlyIfChanged) {
-    extern __shared__ __attribute__((aligned(16))) double njLds[];
-    const NjState<REAL> *st = E.st;
-    if (st->halt || (onlyIfChanged && !st->changed)) return;
-    const int64_t v = which ? st->curJ : st->curI;
-    if ((long long) A.nOutActive[v] == st->nActive) return;
-    const SweepArgs s = vft_nj_args(E, st->nActive, st->totdiam);
-    vft_nj_out_distance<REAL, NC>(A, s, v, njLds, njLds + A.d.nPosPad);
+    __syncthreads();
+    if (scanHalt) return;
+    // getBestFromTopHits' setOutDistance(join.i) (NJ.tcc:4273-4279); with -fastest the two ends before the join (:2897-2898)
+    vft_nj_force_out_distance<REAL, NC>(A, s, scanI, sW, sT);
+    if (E.fastest) vft_nj_force_out_distance<REAL, NC>(A, s, scanJ, sW, sT);
 }
 
 // getBestFromTopHits for one end of the candidate (NJ.tcc:4267-4298): one workgroup per list entry (grid = m; workgroups
-// beyond the list's length leave), results into the staging arrays; k_nj_best_tail picks.
+// beyond the list's length leave), results into the staging arrays; the glue kernel that follows picks.
 template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_WG) void k_nj_best_pairs(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, int which, int onlyIfChanged) {
+__global__ __launch_bounds__(VFT_WG) void k_nj_best_pairs(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, int which) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     const NjState<REAL> *st = E.st;
-    if (st->halt || (onlyIfChanged && !st->changed)) return;
+    if (st->halt || !st->runRound) return;
     const int64_t node = which ? st->curJ : st->curI;
     const int t = (int) blockIdx.x;
     if (t >= T.len[node]) return;
@@ -233,15 +590,11 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_best_pairs(Arena<REAL> A, NjEngin
 }
 
 // the end of getBestFromTopHits and the comparison of the hill climbing (NJ.tcc:4226-4260): the first strict minimum in list
-// order; "if (best.j != join.<other end> && best.criterion < join.criterion) join = best".  which == 1 closes a round: when
-// the candidate changed in it and `lastRound` is set, the host has to enqueue another round.  One workgroup of VFT_WG.
+// order; "if (best.j != join.<other end> && best.criterion < join.criterion) join = best".  Every thread calls; thread 0 updates
+// the state.  which == 0 opens a round ("changed = false").
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_nj_best_tail(NjEngine<REAL> E, TopHits<REAL> T, int which, int onlyIfChanged, int lastRound,
-                                                         long long joinIndex) {
+__device__ __forceinline__ void vft_nj_best_pick(const NjEngine<REAL> &E, const TopHits<REAL> &T, int which, double *redC, int *redT, int *out) {
     NjState<REAL> *st = E.st;
-    if (st->halt || (onlyIfChanged && !st->changed)) return;
-    __shared__ double redC[VFT_WG];
-    __shared__ int redT[VFT_WG];
     const int64_t node = which ? st->curJ : st->curI;
     const int n = T.len[node];
     double bc = 1e20;
@@ -254,60 +607,92 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_best_tail(NjEngine<REAL> E, TopHi
             bt = u;
         }
     }
-    redC[threadIdx.x] = bc;
-    redT[threadIdx.x] = bt;
-    __syncthreads();
-    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if ((int) threadIdx.x < off) {
-            const double c2 = redC[threadIdx.x + off];
-            const int t2 = redT[threadIdx.x + off];
-            if (t2 != 0x7FFFFFFF && (redT[threadIdx.x] == 0x7FFFFFFF || c2 < redC[threadIdx.x] || (c2 == redC[threadIdx.x] && t2 < redT[threadIdx.x]))) {
-                redC[threadIdx.x] = c2;
-                redT[threadIdx.x] = t2;
+    vft_nj_arg_reduce<false>(bc, bt, redC, redT);
+    if (threadIdx.x == 0) {
+        int changed = which == 0 ? 0 : st->changed;
+        int32_t ci = st->curI, cj = st->curJ;
+        const int b = bt;
+        if (b != 0x7FFFFFFF) {
+            const int32_t bj = T.stJ[b];
+            const REAL bcr = T.stC[b];
+            const int32_t other = which ? ci : cj;
+            if (bj != other && bcr < st->curCrit) {
+                changed = 1;
+                ci = (int32_t) node;
+                cj = bj;
+                st->curI = ci;
+                st->curJ = cj;
+                st->curDist = T.stD[b];
+                st->curCrit = bcr;
             }
         }
-        __syncthreads();
+        st->changed = changed;
+        out[0] = changed;   // (to the other threads through LDS: they may hold the state's cache line from the kernel's start)
+        out[1] = ci;
+        out[2] = cj;
     }
-    if (threadIdx.x != 0) return;
-    if (which == 0 && !onlyIfChanged) st->changed = 0;     // (a round starts: "changed = false")
-    else if (which == 0) st->changed = 0;
-    const int b = redT[0];
-    if (b != 0x7FFFFFFF) {
-        const int32_t bj = T.stJ[b];
-        const REAL bcr = T.stC[b];
-        const int32_t other = which ? st->curI : st->curJ;
-        if (bj != other && bcr < st->curCrit) {
-            st->changed = 1;
-            st->curI = (int32_t) node;
-            st->curJ = bj;
-            st->curDist = T.stD[b];
-            st->curCrit = bcr;
-        }
-    }
-    if (which == 1 && lastRound && st->changed) {
-        st->halt = VFT_NJ_HALT_CLIMB;
-        st->haltJoin = (int32_t) joinIndex;
-        vft_nj_publish(E, st);
-    }
+    __syncthreads();
 }
 
-// The join itself (NJ.tcc:2897-3042): criterion on the fresh out-distances of both ends (k_nj_refresh_cur ran for both),
-// tree arrays, branch lengths, diameter, the new profile, its self distance, the incremental out-profile (vft_join_body),
-// totdiam, the counters.  One workgroup of VFT_WG_PROF threads; dynamic LDS: 2 * nPosPad doubles.
+// k_nj_glue_best: the first half of a hill-climbing round is over (k_nj_best_pairs(0)): its result against the candidate, then
+// getBestFromTopHits' setOutDistance for the - possibly new - second end.  One workgroup of VFT_WG threads.
 template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_WG_PROF) void k_nj_join(Arena<REAL> A, NjEngine<REAL> E, long long joinIndex, int32_t updateOut, int32_t slot) {
+__global__ __launch_bounds__(VFT_WG) void k_nj_glue_best(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T) {
+    extern __shared__ __attribute__((aligned(16))) double njLds[];
+    NjState<REAL> *st = E.st;
+    if (st->halt || !st->runRound) return;
+    __shared__ double redC[VFT_WG];
+    __shared__ int redT[VFT_WG];
+    __shared__ int picked[3];
+    const SweepArgs s = vft_nj_args(E, st->nActive, st->totdiam);
+    vft_nj_best_pick<REAL>(E, T, 0, redC, redT, picked);
+    vft_nj_force_out_distance<REAL, NC>(A, s, picked[2], njLds, njLds + A.d.nPosPad);
+}
+
+// k_nj_glue_join: the second half of the round (k_nj_best_pairs(1)) against the candidate; when the round changed it, another
+// round follows (its first setOutDistance here; raised as an event when no further round has been enqueued: lastRound).
+// Otherwise the join itself (NJ.tcc:2897-3042): criterion on the fresh out-distances of both ends, tree arrays, branch
+// lengths, diameter, the new profile, its self distance, the incremental out-profile (vft_join_body), totdiam, the counters;
+// and - unless the caller recomputes the out-profile first (updateOut == 0) - the new node's out-distance, which the first
+// setCriterion of topHitJoin would compute.  One workgroup of VFT_WG_PROF threads; dynamic LDS: 2 * nPosPad doubles.
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex,
+                                                              int32_t updateOut, int32_t slot, int32_t lastRound) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     NjState<REAL> *st = E.st;
     if (st->halt) return;
+    __shared__ double redC[VFT_WG_PROF];
+    __shared__ int redT[VFT_WG_PROF];
     __shared__ REAL sDiam;
     const long long nActive = st->nActive;
-    const int64_t i = st->curI, j = st->curJ, newn = st->maxnode;
+    const SweepArgs s = vft_nj_args(E, nActive, st->totdiam);
+    __shared__ int picked[3];
+    int64_t i = st->curI, j = st->curJ;
+    if (!E.fastest && st->runRound) {
+        vft_nj_best_pick<REAL>(E, T, 1, redC, redT, picked);
+        i = picked[1];
+        j = picked[2];
+        if (picked[0]) {
+            vft_nj_force_out_distance<REAL, NC>(A, s, i, njLds, njLds + A.d.nPosPad);
+            if (threadIdx.x == 0 && lastRound) {
+                st->halt = VFT_NJ_HALT_CLIMB;
+                st->haltJoin = (int32_t) joinIndex;
+                vft_nj_publish(E, st);
+            }
+            return;   // runRound stays set: the next round's kernels execute
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) st->runRound = 0;
+    }
+    const int64_t newn = st->maxnode;
+    vft_nj_force_out_distance<REAL, NC>(A, s, i, njLds, njLds + A.d.nPosPad);   // (fresh already unless the caller skipped the search kernels)
+    vft_nj_force_out_distance<REAL, NC>(A, s, j, njLds, njLds + A.d.nPosPad);
     if (threadIdx.x == 0) {
         const REAL dist = st->curDist;
         const REAL crit = vft_nj_crit<REAL>(A, dist, (int32_t) i, (int32_t) j, nActive);   // criterionFresh / setDistCriterion(join)
         // NJ.tcc:2911-2916, 3003-3007 (BIONJ off: weight 1/2)
         const double distIJ = (double) dist;
-        const REAL od = A.outDist[i] - A.outDist[j];
+        const REAL od = vft_nj_ld(&A.outDist[i]) - vft_nj_ld(&A.outDist[j]);
         const double deltaDist = (double) od / (double) (nActive - 2);
         const REAL blI = (REAL) ((distIJ + deltaDist) / 2), blJ = (REAL) ((distIJ - deltaDist) / 2);
         const double bw = 0.5;
@@ -335,13 +720,20 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_join(Arena<REAL> A, NjEngine
     }
     __syncthreads();
     vft_join_body<REAL, NC>(A, i, j, newn, sDiam, E.staleStamp, nActive, updateOut, E.tol, E.stash, E.pendIds, slot, njLds);
+    __syncthreads();
     if (threadIdx.x == 0) {
         st->maxnode = newn + 1;
         st->nActive = nActive - 1;
     }
+    if (updateOut) {
+        __syncthreads();
+        const SweepArgs s2 = vft_nj_args(E, nActive - 1, st->totdiam);
+        vft_nj_out_distance<REAL, NC>(A, s2, newn, njLds, njLds + A.d.nPosPad);
+    }
 }
 
-// the new node's out-distance (the first setCriterion of topHitJoin refreshes it: its stamp is "unreasonably high")
+// the new node's out-distance after the caller has recomputed the out-profile (the first setCriterion of topHitJoin refreshes
+// it: its stamp is "unreasonably high")
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WG) void k_nj_refresh_new(Arena<REAL> A, NjEngine<REAL> E) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
@@ -353,7 +745,7 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_refresh_new(Arena<REAL> A, NjEngi
 
 // uniqueBestHits of the two children's lists (k_th_join's first half; grid = 2 m, workgroups beyond the lists leave)
 template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_WG) void k_nj_merge_pairs(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex) {
+__global__ __launch_bounds__(VFT_WG) void k_nj_merge_pairs(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex, unsigned int tag) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     const NjState<REAL> *st = E.st;
     if (st->halt) return;
@@ -365,7 +757,6 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_pairs(Arena<REAL> A, NjEngi
     const SweepArgs s = vft_nj_args(E, st->nActive, st->totdiam);
     const ThHit<REAL> h = t < n0 ? T.hits[c0 * T.m + t] : T.hits[c1 * T.m + (t - n0)];
     const int32_t j = vft_active_ancestor(A.parent, h.j);
-    const unsigned int tag = (unsigned int) (joinIndex + 1);
     if (threadIdx.x == 0)
         thOwner = j >= 0 && j != (int32_t) newnode && __hip_atomic_exchange(&T.mark[j], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag;
     __syncthreads();
@@ -383,222 +774,52 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_pairs(Arena<REAL> A, NjEngi
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The rest of topHitJoin for a merged list (NJ.tcc:4342-4438): the age of the new list, the decision, sortSaveBestHits, the
-// new node's visible hit, updateTopVisible for it, updateVisible over the saved hits.  One workgroup of VFT_NJ_TAIL threads.
-//
-// updateTopVisible(iIn, hit) (NJ.tcc:4660-4726), by the whole workgroup on the LDS copy of topvisible[]:
-//   1. the first slot that holds iIn already (done) or a dead / empty node (it takes the slot);
-//   2. otherwise getVisible of every slot in order until one fails (iIn takes that slot) or shows the same pair from the other
-//      side (done); the lazy refreshes of those getVisible calls only happen for the slots the reference's loop reaches;
-//   3. otherwise the slot with the worst criterion (the last one among equals) is replaced if the new hit is better.
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s,
-                                                          int32_t *tv, int32_t iIn, int32_t hitJ, REAL hitDist, double *sW, double *sT,
-                                                          int32_t *staleList, double *redC, int *redT) {
-    __shared__ int first1, stop2, nStale2;
-    const long long nActive = s.nActive;
-    if (threadIdx.x == 0) {
-        first1 = 0x7FFFFFFF;
-        stop2 = 0x7FFFFFFF;
-        nStale2 = 0;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        const int32_t node = tv[t];
-        if (node == iIn || node < 0 || A.parent[node] >= 0) atomicMin(&first1, t);
-    }
-    __syncthreads();
-    if (first1 != 0x7FFFFFFF) {
-        if (threadIdx.x == 0 && tv[first1] != iIn) tv[first1] = iIn;
-        __syncthreads();
-        return;
-    }
-    // no free slot: every slot holds an active node.  Where does the reference's scan stop?
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        int32_t vj;
-        const int32_t node = tv[t];
-        const bool ok = vft_nj_visible_ok(A, E, node, vj);
-        if (!ok || (node == hitJ && vj == iIn)) atomicMin(&stop2, t);
-    }
-    __syncthreads();
-    const int stop = stop2;
-    const bool stopOk = stop != 0x7FFFFFFF && ({ int32_t vj; vft_nj_visible_ok(A, E, tv[stop], vj); });   // the same pair from the other side
-    // lazy refreshes of the getVisible calls the scan makes: slots before the stop, and the stopping slot if its getVisible succeeded
-    const int reach = stop == 0x7FFFFFFF ? E.nTop : (stopOk ? stop + 1 : stop);
-    for (int t = threadIdx.x; t < reach; t += blockDim.x) {
-        int32_t vj;
-        const int32_t node = tv[t];
-        vft_nj_visible_ok(A, E, node, vj);
-        if ((long long) A.nOutActive[node] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale2, 1)] = node;
-        if ((long long) A.nOutActive[vj] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale2, 1)] = vj;
-    }
-    if (stop == 0x7FFFFFFF && threadIdx.x == 0) {   // the final setCriterion(iIn, hit.j)
-        if ((long long) A.nOutActive[iIn] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale2, 1)] = iIn;
-        if ((long long) A.nOutActive[hitJ] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale2, 1)] = hitJ;
-    }
-    __syncthreads();
-    vft_nj_refresh_listed<REAL, NC>(A, s, staleList, nStale2, sW, sT);
-    __syncthreads();
-    if (stop != 0x7FFFFFFF) {
-        if (!stopOk && threadIdx.x == 0) tv[stop] = iIn;
-        __syncthreads();
-        return;
-    }
-    // the worst slot: "vis.criterion >= critWorst" in slot order = the largest criterion, the last one among equals
-    double wc = -1e20;
-    int wt = -1;
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        const int32_t node = tv[t];
-        const double c = (double) vft_nj_crit<REAL>(A, E.visD[node], node, E.visJ[node], nActive);
-        if (c >= wc) {
-            wc = c;
-            wt = t;
-        }
-    }
-    redC[threadIdx.x] = wc;
-    redT[threadIdx.x] = wt;
-    __syncthreads();
-    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if ((int) threadIdx.x < off) {
-            const double c2 = redC[threadIdx.x + off];
-            const int t2 = redT[threadIdx.x + off];
-            if (t2 >= 0 && (redT[threadIdx.x] < 0 || c2 > redC[threadIdx.x] || (c2 == redC[threadIdx.x] && t2 > redT[threadIdx.x]))) {
-                redC[threadIdx.x] = c2;
-                redT[threadIdx.x] = t2;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && redT[0] >= 0) {
-        const REAL b = vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, nActive);
-        if ((double) b < redC[0]) tv[redT[0]] = iIn;
-    }
-    __syncthreads();
+// resetTopVisible (NJ.tcc:4728-4784), device part: the criterion of (node, visible[node]) for every active node with a usable
+// visible hit, after the lazy refreshes the reference's getVisible calls make, as a sweep-shaped result (dist = the visible
+// hit's distance, weight = its partner, criterion) from which the top-k selection of the sweeps (k_select_*) takes the best
+// k under the same order the reference sorts by: criterion ascending, ties by descending position = descending node id.
+// The host walks those k records (a few thousand) to fill the list.
+
+// the distinct nodes a getVisible would refresh; grid over [0, maxnode)
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_nj_reset_stale(Arena<REAL> A, NjEngine<REAL> E, SweepArgs s, int64_t maxnode, unsigned int *mark,
+                                                           unsigned int tag, int64_t *list, unsigned int *counter) {
+    const int64_t v = (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    if (v >= maxnode || A.parent[v] >= 0) return;
+    const int32_t vj = E.visJ[v];
+    if (vj < 0 || A.parent[vj] >= 0) return;
+    if ((long long) A.nOutActive[v] - s.nActive > s.nDiffAllow && atomicExch(&mark[v], tag) != tag) list[atomicAdd(counter, 1u)] = v;
+    if ((long long) A.nOutActive[vj] - s.nActive > s.nDiffAllow && atomicExch(&mark[vj], tag) != tag) list[atomicAdd(counter, 1u)] = vj;
 }
 
-// Dynamic LDS: max(2 * nPosPad doubles | P keys | P distances, ...) laid out as: pair staging | ThKey[P] | REAL[P] (distances by
-// staging index) | int32[nTop] topvisible | int32[2 * nTop + 2 * P] stale lists / pass list
-template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_merge_tail(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex, int P) {
-    extern __shared__ __attribute__((aligned(16))) double njLds[];
-    NjState<REAL> *st = E.st;
-    if (st->halt) return;
-    double *sW = njLds, *sT = njLds + A.d.nPosPad;
-    ThKey *keys = (ThKey *) (njLds + 2 * A.d.nPosPad);
-    REAL *distL = (REAL *) (keys + P);
-    int32_t *tv = (int32_t *) (distL + P);
-    int32_t *staleList = tv + E.nTop;             // 2 * nTop + 2 entries (updateTopVisible), 2 * P (updateVisible)
-    int32_t *passList = staleList + 2 * E.nTop + 2 * P + 2;   // P entries
-    __shared__ int thCount, nStale, nPass;
-    __shared__ double redC[VFT_NJ_TAIL];
-    __shared__ int redT[VFT_NJ_TAIL];
-    const NjJoinRec rec = E.logDev[joinIndex];
-    const int32_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
-    const int n = T.len[c0] + T.len[c1];
-    const long long nActive = st->nActive;
-    const SweepArgs s = vft_nj_args(E, nActive, st->totdiam);
-    if (threadIdx.x == 0) thCount = nStale = nPass = 0;
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) tv[t] = E.topvis[t];
-    __syncthreads();
-    for (int u = threadIdx.x; u < n; u += blockDim.x) {
-        const int32_t ju = T.stJ[u];
-        if (ju < 0) continue;
-        ThKey k;
-        k.key = vft_th_order(T.stC[u]);
-        k.nj = ~(uint32_t) ju;
-        k.src = u;
-        keys[atomicAdd(&thCount, 1)] = k;
-        distL[u] = T.stD[u];
-    }
-    __syncthreads();
-    const int nU = thCount;
-    int P1 = 2;
-    while (P1 < nU) P1 <<= 1;
-    for (int u = nU + threadIdx.x; u < P1; u += blockDim.x) {
-        ThKey k;
-        k.key = ~0ull;
-        k.nj = ~0u;
-        k.src = -1;
-        keys[u] = k;
-    }
-    vft_th_bitonic(keys, P1);
-    // NJ.tcc:4342-4362
-    const int32_t ageNew = (E.age[c0] + E.age[c1] + 1) / 2 + 1;
-    const bool useUnique = (long long) nU == nActive - 1 || (ageNew <= E.ageLimit && nU >= E.need);
-    if (!useUnique) {
-        if (threadIdx.x == 0) {
-            E.age[newnode] = ageNew;
-            st->nUnique = nU;
-            st->joinsDone = joinIndex + 1;
-            st->halt = VFT_NJ_HALT_REFRESH;
-            st->haltJoin = (int32_t) joinIndex;
-            vft_nj_publish(E, st);
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_nj_reset_crit(Arena<REAL> A, NjEngine<REAL> E, SweepArgs s, int64_t maxnode, SweepOut<REAL> O,
+                                                          unsigned int *nVisible) {
+    const int64_t v = (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
+    bool ok = false;
+    if (v < maxnode) {
+        REAL d = (REAL) 1e20, w = 0, cr = (REAL) 1e20;
+        if (A.parent[v] < 0) {
+            const int32_t vj = E.visJ[v];
+            if (vj >= 0 && A.parent[vj] < 0) {
+                ok = true;
+                d = E.visD[v];
+                w = (REAL) vj;
+                cr = vft_criterion<REAL>(d, A.outDist[v], A.nOutActive[v], A.outDist[vj], A.nOutActive[vj], s.nActive);
+                cmin = cmax = cr;
+            }
         }
-        return;
+        O.dist[v] = d;
+        O.weight[v] = w;
+        O.crit[v] = cr;
     }
-    const int nSave = nU < E.m ? nU : E.m;
-    for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
-        ThHit<REAL> e;
-        e.j = (int32_t) ~keys[r].nj;
-        e.dist = distL[keys[r].src];
-        T.hits[(int64_t) newnode * T.m + r] = e;
-    }
-    if (threadIdx.x == 0) {
-        E.age[newnode] = ageNew;
-        T.len[newnode] = nSave;
-        E.visJ[newnode] = (int32_t) ~keys[0].nj;            // visible[newnode] = hits[newnode][0]
-        E.visD[newnode] = distL[keys[0].src];
-    }
-    __syncthreads();
-    vft_nj_update_top_visible<REAL, NC>(A, E, s, tv, newnode, (int32_t) ~keys[0].nj, distL[keys[0].src], sW, sT, staleList, redC, redT);
-    // updateVisible (NJ.tcc:4633-4657) over the saved hits in order.  The getVisible of hit t looks at hit.j's own visible hit,
-    // which only iteration t changes: all tests are made first (with their lazy refreshes), then the few hits that pass update
-    // visible[] and the top-visible list one after the other.
-    for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
-        int32_t vj;
-        const int32_t node = (int32_t) ~keys[r].nj;
-        if (!vft_nj_visible_ok(A, E, node, vj)) continue;
-        if ((long long) A.nOutActive[node] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale, 1)] = node;
-        if ((long long) A.nOutActive[vj] - nActive > s.nDiffAllow) staleList[atomicAdd(&nStale, 1)] = vj;
-    }
-    __syncthreads();
-    vft_nj_refresh_listed<REAL, NC>(A, s, staleList, nStale, sW, sT);
-    __syncthreads();
-    for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
-        int32_t vj;
-        const int32_t node = (int32_t) ~keys[r].nj;
-        const REAL hitCrit = T.stC[keys[r].src];
-        bool pass = true;
-        if (vft_nj_visible_ok(A, E, node, vj)) pass = hitCrit < vft_nj_crit<REAL>(A, E.visD[node], node, vj, nActive);
-        if (pass) passList[atomicAdd(&nPass, 1)] = r;
-    }
-    __syncthreads();
-    const int np = nPass;
-    // (in list order: a selection sort over the few entries by thread 0)
-    if (threadIdx.x == 0)
-        for (int a = 0; a < np; a++)
-            for (int b = a + 1; b < np; b++)
-                if (passList[b] < passList[a]) {
-                    const int32_t x = passList[a];
-                    passList[a] = passList[b];
-                    passList[b] = x;
-                }
-    __syncthreads();
-    for (int a = 0; a < np; a++) {
-        const int r = passList[a];
-        const int32_t node = (int32_t) ~keys[r].nj;
-        const REAL d = distL[keys[r].src];
-        if (threadIdx.x == 0) {
-            E.visJ[node] = newnode;
-            E.visD[node] = d;
-        }
-        __syncthreads();
-        vft_nj_update_top_visible<REAL, NC>(A, E, s, tv, node, newnode, d, sW, sT, staleList, redC, redT);
-    }
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) E.topvis[t] = tv[t];
-    if (threadIdx.x == 0) {
-        st->nUnique = nU;
-        st->joinsDone = joinIndex + 1;
-        vft_nj_publish(E, st);
-    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nVisible, (unsigned int) __popcll(m));
+    vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
+}
+
+static __global__ void k_nj_publish_u32(const unsigned int *src, unsigned int *hostDst, int n) {
+    for (int t = threadIdx.x; t < n; t += blockDim.x) hostDst[t] = src[t];
+    __threadfence_system();
 }

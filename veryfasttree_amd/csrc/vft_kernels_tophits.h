@@ -90,6 +90,15 @@ template <typename REAL, int NC>
 __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArgs &s, int64_t i, int64_t j, bool recompute,
                                             double *sW, double *sT, REAL &d, REAL &crit) {
     __shared__ int thStale;
+    // thread 0 issues everything the criterion needs up front: the loads complete while the workgroup computes the distance
+    int32_t sj = 0, si = 0;
+    REAL oj = 0, oi = 0;
+    if (threadIdx.x == 0) {
+        sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        si = A.nOutActive[i];
+        oi = A.outDist[i];
+    }
     if (recompute) {
         REAL w;
         vft_pair_block<REAL, NC>(A, i, j, false, sW, sT, d, w);
@@ -98,14 +107,9 @@ __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArg
             d = d - dd;
         }
     }
-    int32_t sj = 0;
-    if (threadIdx.x == 0) {
-        sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        thStale = (int64_t) sj - s.nActive > s.nDiffAllow;
-    }
+    if (threadIdx.x == 0) thStale = (int64_t) sj - s.nActive > s.nDiffAllow;
     __syncthreads();
     const bool stale = thStale != 0;
-    REAL oj = 0;
     if (stale) {
         REAL dd, ww;
         vft_pair_block<REAL, NC>(A, j, -1, true, sW, sT, dd, ww);
@@ -122,11 +126,13 @@ __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArg
             __threadfence_system();   // the host-mapped mirrors are out before this workgroup counts itself
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    } else if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stamp has been read before the value is
+    } else if (threadIdx.x == 0 && (int64_t) sj == s.nActive) {
+        // a stamp of this very step may have been written a moment ago by another workgroup of this launch (the same
+        // partner listed twice): its value is read again, now certainly after the stamp
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) crit = vft_criterion<REAL>(d, A.outDist[i], A.nOutActive[i], oj, sj, s.nActive);
+    if (threadIdx.x == 0) crit = vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
 }
 
 template <typename REAL>

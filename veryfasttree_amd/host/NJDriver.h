@@ -64,6 +64,9 @@ namespace veryfasttree {
         /* top-hit lists on the device (vft_tophits_*): the list walks of a join are one launch each; false = the host walks
            of round 2 (kept as the cross-check of VFT_NJ_CHECK and for tools) */
         bool deviceLists = true;
+        /* the join loop itself on the device (vft_nj_engine_*): the host enqueues the kernels of many joins ahead, reads the
+           join records from a log and handles top-visible resets and top-hits refreshes; needs deviceLists, first-level lists */
+        bool deviceJoins = true;
     };
 
     template<typename REAL>
@@ -136,10 +139,15 @@ namespace veryfasttree {
                 initTopHits(m);
                 setAllLeafTopHits();
                 resetTopVisible(nSeqs);
+                if (devLists && !hostLists && opt.deviceJoins && maxJoins < 0 && std::getenv("VFT_NJ_HOST_JOINS") == nullptr && runEngine()) return joins;
             }
             int64_t nActiveReset = nSeqs;
             for (int64_t nActive = nSeqs; nActive > 3; nActive--) {
                 if (maxJoins >= 0 && (int64_t) joins.size() >= maxJoins) break;
+                if (!noTop && dumpJoin >= 0 && (int64_t) joins.size() == dumpJoin) {
+                    drain();
+                    dumpVisibleState("host", dumpJoin, nActive);
+                }
                 Besthit join = noTop ? fastNJSearch(nActive) : topHitNJSearch(nActive);
                 /* setOutDistance(i), setOutDistance(j), setDistCriterion(join) (NJ.tcc:2897-2901) as ONE pair list of
                    length 1 with nDiffAllow = 0: the lazy refresh then fires for every stamp != nActive, i.e. it is the
@@ -201,6 +209,274 @@ namespace veryfasttree {
                 else topHitJoin(newnode, nActive - 1);
             }
             return joins;
+        }
+
+        /* ---- the join loop on the device (include/vft_hip.h, vft_nj_engine_*) */
+        int64_t engineConsumed = 0;
+        int64_t dumpJoin = std::getenv("VFT_NJ_DUMP_JOIN") ? atoll(std::getenv("VFT_NJ_DUMP_JOIN")) : -1;
+        bool traceEvents = std::getenv("VFT_NJ_TRACE_EVENTS") != nullptr;   /* debugging: resets / refreshes with their join index */
+
+        /* tree arrays, branch lengths, diameters and the Join records of the joins [engineConsumed, upTo) from the device's log */
+        void consumeLog(const vft_nj_join_t *log, int64_t upTo) {
+            if (upTo <= engineConsumed) return;
+            chkT("vft_nj_engine_adopt", [&]() { return vft_nj_engine_adopt(ctx, engineConsumed, upTo); });
+            for (int64_t k = engineConsumed; k < upTo; k++) {
+                const vft_nj_join_t &r = log[k];
+                const int64_t i = r.i, j = r.j, newnode = r.newnode;
+                if (newnode != maxnode) throw std::runtime_error("NJDriver: join log out of order");
+                maxnode++;
+                parent[i] = parent[j] = newnode;
+                child0[newnode] = std::min(i, j);
+                child1[newnode] = std::max(i, j);
+                joins.push_back(Join{std::min(i, j), std::max(i, j), newnode, (REAL) r.criterion});
+                branchlength[i] = (REAL) r.bl_i;
+                branchlength[j] = (REAL) r.bl_j;
+                diameter[newnode] = (REAL) r.diameter;
+            }
+            engineConsumed = upTo;
+        }
+
+        void engineDownloadVisible() {
+            std::vector<int32_t> vj((size_t) maxnode);
+            std::vector<REAL> vd((size_t) maxnode);
+            chkT("vft_nj_engine_visible_get", [&]() { return vft_nj_engine_visible_get(ctx, 0, maxnode, vj.data(), vd.data()); });
+            for (int64_t v = 0; v < maxnode; v++) visible[(size_t) v] = Hit{vj[(size_t) v], vd[(size_t) v]};
+        }
+
+        void engineUploadNodes(const std::vector<int64_t> &nodes, int32_t newAge) {
+            if (nodes.empty()) return;
+            std::vector<int32_t> vj(nodes.size());
+            std::vector<REAL> vd(nodes.size());
+            for (size_t t = 0; t < nodes.size(); t++) {
+                vj[t] = visible[(size_t) nodes[t]].j;
+                vd[t] = visible[(size_t) nodes[t]].dist;
+            }
+            chkT("vft_nj_engine_nodes_set", [&]() { return vft_nj_engine_nodes_set(ctx, (int64_t) nodes.size(), nodes.data(), vj.data(), vd.data(), newAge); });
+        }
+
+        void engineUploadTopVisible() {
+            std::vector<int32_t> tv(topvisible.size());
+            for (size_t t = 0; t < tv.size(); t++) tv[t] = (int32_t) topvisible[t];
+            chkT("vft_nj_engine_topvisible_set", [&]() { return vft_nj_engine_topvisible_set(ctx, tv.data()); });
+            chkT("vft_nj_engine_set_state", [&]() { return vft_nj_engine_set_state(ctx, -1, -1, std::nan(""), (int32_t) topvisibleAge); });
+        }
+
+        /* debugging (VFT_NJ_DUMP_JOIN=k): the visible set as join k's search finds it */
+        void dumpVisibleState(const char *who, int64_t k, int64_t nActive) const {
+            fprintf(stderr, "[dump %s] join %lld nActive %lld topvisibleAge %lld\n", who, (long long) k, (long long) nActive, (long long) topvisibleAge);
+            for (size_t t = 0; t < topvisible.size(); t++) {
+                const int64_t node = topvisible[t];
+                if (node < 0) {
+                    fprintf(stderr, "[dump %s] slot %zu: -1\n", who, t);
+                    continue;
+                }
+                const int64_t j = visible[(size_t) node].j;
+                fprintf(stderr, "[dump %s] slot %zu: node %lld parent %lld vis (%lld, %.9g) out %.9g stamp %d | partner parent %lld out %.9g stamp %d\n", who, t,
+                        (long long) node, (long long) parent[(size_t) node], (long long) j, (double) visible[(size_t) node].dist, (double) mOut[node], (int) mN[node],
+                        (long long) (j >= 0 ? parent[(size_t) j] : -9), (double) (j >= 0 ? mOut[j] : 0), (int) (j >= 0 ? mN[j] : 0));
+            }
+        }
+
+        /* false: the engine cannot be used on this context (the caller runs the host-driven loop) */
+        bool runEngine() {
+            vft_nj_engine_config cfg;
+            memset(&cfg, 0, sizeof(cfg));
+            cfg.m = (int32_t) m;
+            cfg.n_top = (int32_t) topvisible.size();
+            cfg.need = (int32_t) (int64_t) (0.5 + m * opt.tophitsRefresh);
+            cfg.age_limit = (int32_t) std::max<int64_t>(1, (int64_t) (0.5 + std::log((double) m) / std::log(2.0)));
+            cfg.fastest = opt.fastest ? 1 : 0;
+            cfg.stale_stamp = 10 * nSeqs;
+            cfg.stale_out_limit = opt.tophitsMult > 0 ? opt.staleOutLimit : 0.0;
+            if (vft_nj_engine_create(ctx, &cfg) != VFT_OK) return false;
+            engineActive = true;
+            Section sec(this, "[host] join engine (incl. device)");
+            drain();
+            const vft_nj_join_t *log = nullptr;
+            chk(vft_nj_engine_log(ctx, &log));
+            {
+                std::vector<int32_t> vj((size_t) nSeqs);
+                std::vector<REAL> vd((size_t) nSeqs);
+                for (int64_t v = 0; v < nSeqs; v++) {
+                    vj[(size_t) v] = visible[(size_t) v].j;
+                    vd[(size_t) v] = visible[(size_t) v].dist;
+                }
+                chkT("vft_nj_engine_visible_set", [&]() { return vft_nj_engine_visible_set(ctx, 0, nSeqs, vj.data(), vd.data()); });
+            }
+            chkT("vft_nj_engine_set_state", [&]() { return vft_nj_engine_set_state(ctx, nSeqs, nSeqs, totdiam, 0); });
+            engineUploadTopVisible();
+            const int64_t nTotal = nSeqs - 3;
+            const int64_t window = std::getenv("VFT_NJ_ENGINE_WINDOW") ? std::max(1, atoi(std::getenv("VFT_NJ_ENGINE_WINDOW"))) : 16;   /* (debugging) */
+            int64_t enq = 0, nActiveReset = nSeqs;
+            bool climbPending = false, needSearch = true;   /* needSearch: the search of join `enq` has not been enqueued behind the previous merge */
+            auto isFullOut = [&](int64_t k) {
+                const int64_t nActive = nSeqs - k, changed = nActiveReset - (nActive - 1);
+                return changed >= opt.nResetOutProfile && changed >= opt.fResetOutProfile * nActiveReset;
+            };
+            /* the events the kernels raise; afterwards the loop goes on enqueueing from `enq` */
+            auto handleHalt = [&](int32_t reason, int64_t h) {
+                int64_t devActive = 0, devMax = 0, done = 0;
+                int32_t tvAge = 0;
+                double devTot = 0;
+                chkT("vft_nj_engine_get_state", [&]() { return vft_nj_engine_get_state(ctx, &devActive, &devMax, &devTot, &tvAge, &done, nullptr, nullptr, nullptr); });
+                totdiam = devTot;
+                if (traceEvents) {
+                    int32_t nU = 0;
+                    chk(vft_nj_engine_get_state(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &nU));
+                    fprintf(stderr, "[event engine] %s at join %lld (nActive %lld) tvAge %d nUnique %d\n", reason == VFT_NJ_HALT_RESET ? "reset" : reason == VFT_NJ_HALT_REFRESH ? "refresh" : "climb",
+                            (long long) h, (long long) devActive, (int) tvAge, (int) nU);
+                }
+                if (reason == VFT_NJ_HALT_CLIMB) {
+                    consumeLog(log, h);
+                    chkT("vft_nj_engine_resume", [&]() { return vft_nj_engine_resume(ctx, h); });
+                    climbPending = true;
+                    needSearch = false;
+                    enq = h;
+                    if (profiling) acc["[count]  engine: extra hill-climbing rounds"].calls++;
+                    return;
+                }
+                if (reason == VFT_NJ_HALT_RESET) {
+                    Section s2(this, "[host]   engine: top-visible reset (incl. device)");
+                    consumeLog(log, h);
+                    chkT("vft_nj_engine_resume", [&]() { return vft_nj_engine_resume(ctx, h); });
+                    const int64_t nActive = nSeqs - h;
+                    if (devActive != nActive || devMax != maxnode) throw std::runtime_error("NJDriver: engine state out of step at a reset");
+                    topvisibleAge = tvAge;
+                    if (topvisibleAge <= 2) {   /* NJ.tcc:4166-4195: visible hits whose partner was joined are re-targeted first */
+                        engineDownloadVisible();
+                        std::vector<int64_t> changedNodes;
+                        for (int64_t node = 0; node < maxnode; node++) {
+                            if (parent[node] >= 0) continue;
+                            Hit &v = visible[node];
+                            int64_t newj = activeAncestor(v.j);
+                            if (newj >= 0 && newj != v.j) {
+                                if (newj == node) {
+                                    newj = 0;
+                                    while (parent[newj] >= 0 || newj == node) newj++;
+                                }
+                                Besthit bh;
+                                bh.i = node;
+                                bh.j = newj;
+                                std::vector<Besthit *> one(1, &bh);
+                                setDistCriterionBatch(nActive, one);
+                                v.j = (int32_t) newj;
+                                v.dist = bh.dist;
+                                changedNodes.push_back(node);
+                            }
+                        }
+                        engineUploadNodes(changedNodes, -1);
+                    }
+                    resetTopVisible(nActive);
+                    engineUploadTopVisible();
+                    enq = h;
+                    needSearch = true;
+                    climbPending = false;
+                    return;
+                }
+                if (reason == VFT_NJ_HALT_REFRESH) {
+                    Section s2(this, "[host]   engine: top-hits refresh (incl. device)");
+                    consumeLog(log, h + 1);
+                    chkT("vft_nj_engine_resume", [&]() { return vft_nj_engine_resume(ctx, h + 1); });
+                    const int64_t nActive = nSeqs - h - 1, newnode = log[h].newnode;
+                    if (devActive != nActive || devMax != maxnode) throw std::runtime_error("NJDriver: engine state out of step at a refresh");
+                    refreshTopHits(newnode, nActive);   /* (device merge; uploads the new first hits; ends with resetTopVisible) */
+                    engineUploadTopVisible();
+                    enq = h + 1;
+                    needSearch = true;
+                    climbPending = false;
+                    return;
+                }
+                throw std::runtime_error("NJDriver: the join engine stopped with an error");
+            };
+            int64_t lastDone = -1;
+            auto lastProgress = std::chrono::steady_clock::now();
+            while (engineConsumed < nTotal) {
+                int64_t done = 0;
+                int32_t halt = 0, haltJoin = 0;
+                chk(vft_nj_engine_poll(ctx, &done, &halt, &haltJoin));
+                if (halt) {
+                    handleHalt(halt, haltJoin);
+                    lastProgress = std::chrono::steady_clock::now();
+                    continue;
+                }
+                consumeLog(log, std::min(done, nTotal));
+                if (dumpJoin >= 0 && done == dumpJoin && enq == done) {   /* (window 1: nothing of join dumpJoin has been enqueued) */
+                    chkT("vft_synchronize", [&]() { return vft_synchronize(ctx); });
+                    engineDownloadVisible();
+                    std::vector<int32_t> tv(topvisible.size());
+                    chk(vft_nj_engine_topvisible_get(ctx, tv.data()));
+                    for (size_t t = 0; t < tv.size(); t++) topvisible[t] = tv[t];
+                    int32_t tvAge = 0;
+                    chk(vft_nj_engine_get_state(ctx, nullptr, nullptr, nullptr, &tvAge, nullptr, nullptr, nullptr, nullptr));
+                    topvisibleAge = tvAge;
+                    dumpVisibleState("engine", dumpJoin, nSeqs - dumpJoin);
+                    dumpJoin = -1;
+                }
+                if (done != lastDone) {
+                    lastDone = done;
+                    lastProgress = std::chrono::steady_clock::now();
+                }
+                if (enq >= nTotal || enq >= done + window) {
+                    for (int spin = 0; spin < 64; spin++) __builtin_ia32_pause();
+                    /* a stream that makes no progress for 30 s is broken: surface its error instead of spinning on */
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - lastProgress).count() > 30.0) {
+                        chkT("vft_synchronize", [&]() { return vft_synchronize(ctx); });
+                        chk(vft_nj_engine_poll(ctx, &done, &halt, &haltJoin));
+                        if (!halt && done == lastDone)
+                            throw std::runtime_error("NJDriver: the join engine makes no progress (join " + std::to_string((long long) done) + ")");
+                        lastProgress = std::chrono::steady_clock::now();
+                    }
+                    continue;
+                }
+                const int32_t first = (climbPending ? VFT_NJ_PHASE_CLIMB : 0) | (needSearch ? VFT_NJ_PHASE_SEARCH : 0);
+                const int32_t next = enq + 1 < nTotal ? VFT_NJ_PHASE_NEXT : 0;   /* the merge kernels go on with the next join's search */
+                int rc;
+                if (!isFullOut(enq)) {
+                    rc = vft_nj_engine_enqueue(ctx, enq, first | VFT_NJ_PHASE_JOIN | VFT_NJ_PHASE_MERGE | next, 1);
+                    if (rc == VFT_ERR_STATE) continue;   /* halted meanwhile: the next poll sees it */
+                    chk(rc);
+                    climbPending = false;
+                    needSearch = next == 0;
+                    enq++;
+                    continue;
+                }
+                /* a join after which the out-profile is recomputed from scratch (NJ.tcc:3012-3033): the merge needs the new
+                   out-profile and totdiam, so the host waits for the join in between */
+                rc = vft_nj_engine_enqueue(ctx, enq, first | VFT_NJ_PHASE_JOIN, 0);
+                if (rc == VFT_ERR_STATE) continue;
+                chk(rc);
+                climbPending = false;
+                needSearch = false;   /* (of THIS join: a halt below sets it again) */
+                int64_t devActive = 0;
+                chkT("vft_nj_engine_get_state", [&]() { return vft_nj_engine_get_state(ctx, &devActive, nullptr, nullptr, nullptr, nullptr, &halt, &haltJoin, nullptr); });
+                if (halt) {
+                    handleHalt(halt, haltJoin);
+                    continue;
+                }
+                if (devActive != nSeqs - enq - 1) throw std::runtime_error("NJDriver: engine state out of step at an out-profile reset");
+                consumeLog(log, enq + 1);
+                {
+                    std::vector<int64_t> active;
+                    double tot = 0;
+                    for (int64_t v = 0; v < maxnode; v++)
+                        if (parent[v] < 0) {
+                            active.push_back(v);
+                            tot += diameter[v];
+                        }
+                    totdiam = tot;
+                    chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, (int64_t) active.size(), active.data()); });
+                    chkT("vft_nj_engine_set_state", [&]() { return vft_nj_engine_set_state(ctx, -1, -1, totdiam, -1); });
+                    nActiveReset = nSeqs - enq - 1;
+                }
+                chk(vft_nj_engine_enqueue(ctx, enq, VFT_NJ_PHASE_MERGE | next, 0));
+                needSearch = next == 0;
+                enq++;
+            }
+            /* the loop state of the host-driven code, for what follows (finishRoot, branch lengths) */
+            chkT("vft_nj_engine_get_state", [&]() { return vft_nj_engine_get_state(ctx, nullptr, nullptr, &totdiam, nullptr, nullptr, nullptr, nullptr, nullptr); });
+            pending = false;
+            engineActive = false;
+            return true;
         }
 
         std::vector<Join> joins;
@@ -1347,7 +1623,65 @@ namespace veryfasttree {
             }
         }
 
+        /* resetTopVisible with the join engine: criteria, lazy refreshes and the selection of the best candidates on the device
+           (vft_nj_engine_reset_candidates); the host walks the few thousand sorted records.  false: not enough candidates (the
+           caller takes the host path). */
+        bool resetTopVisibleEngine(int64_t nActive) {
+            Section sec(this, "[host] resetTopVisible, device candidates (incl. device)");
+            const int64_t nTop = (int64_t) topvisible.size();
+            const int64_t K = std::min<int64_t>(nActive, 4 * nTop + 64);
+            if (K > 8192 || K < 1) return false;
+            std::vector<DevHit> recs((size_t) K);
+            int64_t nVisible = 0;
+            chkT("vft_nj_engine_reset_candidates", [&]() { return vft_nj_engine_reset_candidates(ctx, nActive, totdiam, (int32_t) K, recs.data(), &nVisible); });
+            pending = false;
+            int64_t nReal = 0;   /* records the selection returned (all of them when K >= nVisible) */
+            while (nReal < K && recs[(size_t) nReal].j >= 0) nReal++;
+            if (nReal < std::min(K, nVisible)) return false;
+            /* The reference sorts nActive records of which only the first nVisible are real (NJ.tcc:4729-4744): the others are
+               zeros - criterion 0, positions above every real record, i.e. in front of the real records with criterion 0 - and
+               every one of them reads as the pair (0, 0). */
+            if (inTopScratch.size() != (size_t) maxnodes) inTopScratch.assign((size_t) maxnodes, -1);
+            std::vector<int64_t> &inTop = inTopScratch;
+            std::vector<int64_t> touched, out;
+            int64_t zerosLeft = nActive - nVisible, r = 0, t = 0;
+            bool complete = true;
+            while (t < nVisible && (int64_t) out.size() < nTop) {
+                int64_t vI, vJ;
+                if (zerosLeft > 0 && (r == nVisible || (r < nReal && !(recs[(size_t) r].criterion < 0)))) {
+                    vI = vJ = 0;
+                    zerosLeft--;
+                } else if (r < nReal) {
+                    vI = recs[(size_t) r].j;
+                    vJ = (int64_t) recs[(size_t) r].weight;
+                    r++;
+                } else {
+                    complete = false;   /* more candidates needed than were selected */
+                    break;
+                }
+                t++;
+                if (inTop[(size_t) vI] != vJ) {
+                    out.push_back(vI);
+                    inTop[(size_t) vI] = vJ;
+                    inTop[(size_t) vJ] = vI;
+                    touched.push_back(vI);
+                    touched.push_back(vJ);
+                }
+            }
+            for (int64_t v: touched) inTop[(size_t) v] = -1;
+            if (!complete) return false;
+            for (size_t k = 0; k < topvisible.size(); k++) topvisible[k] = k < out.size() ? out[k] : -1;
+            topvisibleAge = 0;
+            return true;
+        }
+
+        bool engineActive = false;   /* the visible set lives on the device (runEngine) */
+
         void resetTopVisible(int64_t nActive) { /* NJ.tcc:4728-4784 */
+            if (engineActive) {
+                if (std::getenv("VFT_NJ_HOST_RESET") == nullptr && resetTopVisibleEngine(nActive)) return;   /* (debugging knob) */
+                engineDownloadVisible();
+            }
             Section sec(this, "[host] resetTopVisible (incl. device)");
             /* the reference sorts a value-initialised array of nActive records of which only nVisible are filled:
                the zero records take part in the sort and only the first nVisible sorted positions are considered */
@@ -2116,6 +2450,7 @@ namespace veryfasttree {
                             }
                         }
                     }
+                    if (traceEvents) fprintf(stderr, "[event host] reset at join %zu (nActive %lld) tvAge %lld nCand %lld\n", joins.size(), (long long) nActive, (long long) topvisibleAge, (long long) nCand);
                     resetTopVisible(nActive);
                     continue;
                 }
@@ -2258,8 +2593,16 @@ namespace veryfasttree {
                 }
                 return;
             }
-            /* refresh */
+            refreshTopHits(newnode, nActive);
+        }
+
+        /* the else-branch of topHitJoin (NJ.tcc:4440-4517): new top hits for the new node from a sweep, and for its m closest
+           nodes from theirs + its own; then resetTopVisible */
+        std::vector<int64_t> lastRefreshWork;   /* the nodes whose lists (and visible hits) the last refresh rewrote */
+        void refreshTopHits(int64_t newnode, int64_t nActive) {
+            if (traceEvents) fprintf(stderr, "[event %s] refresh for node %lld (nActive %lld)\n", engineConsumed > 0 ? "engine-host" : "host", (long long) newnode, (long long) nActive);
             age[newnode] = 0;
+            lastRefreshWork.clear();
             if (opt.fastest) {
                 /* NJ.tcc:4454-4459 touches every active node with setCriterion, i.e. refreshes exactly the out-distances
                    that are staler than allowed: that is the lazy pre-pass vft_sweep runs before the sweep below */
@@ -2325,6 +2668,11 @@ namespace veryfasttree {
                     age[(size_t) node] = 0;
                     listLen[(size_t) node] = devLens[t];
                     visible[(size_t) node] = devFirst[t];
+                }
+                lastRefreshWork = devWork;
+                if (engineActive) {   /* the visible set lives on the device: the rewritten lists' first hits and ages go there first */
+                    engineUploadNodes(devWork, 0);
+                    chkT("vft_nj_engine_nodes_set", [&]() { return vft_nj_engine_nodes_set(ctx, 1, &newnode, nullptr, nullptr, 0); });
                 }
                 if (!hostLists) {
                     resetTopVisible(nActive);
