@@ -34,6 +34,7 @@ extern "C" {
 #define VFT_ERR_INVALID 1   /* bad argument */
 #define VFT_ERR_HIP 2       /* a HIP runtime call failed */
 #define VFT_ERR_STATE 3     /* call sequence error (e.g. sweep before leaves were uploaded) */
+#define VFT_ERR_TIMEOUT 4   /* a kernel did not raise its completion flag (the wait is bounded; the context is unusable afterwards) */
 #define VFT_NOCODE 127
 
 typedef struct vft_ctx vft_ctx;
@@ -396,6 +397,8 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_PAIR_THREADS 2       /* threads per pair of the short-list kernels (0 = the built-in choice) */
 #define VFT_DEBUG_NO_PAIR_STAGING 3    /* value != 0: short pair lists read their ids from the mapped ring directly */
 #define VFT_DEBUG_GENERIC_OUTPROFILE 4 /* value != 0: vft_out_profile_full always takes the one-thread-per-column kernel */
+#define VFT_DEBUG_FAULT_NO_FLAG 5      /* value != 0: fault injection - the next wait for a completion flag waits for a value no kernel publishes */
+#define VFT_DEBUG_WAIT_LIMIT_MS 6      /* the longest a wait for a completion flag may last while the stream is busy (default 120 000) */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */

@@ -1,0 +1,103 @@
+"""Repetition tests of the hand-rolled cross-workgroup / host synchronisation (one real race was found in round 2;
+a single run per suite guards nothing): the single-launch pair list with refreshes against the two-launch path over 200 random
+lists of 1 ... 2 048 pairs, whole NJ runs repeated (the join engine's flag protocol, the staged publication of the list
+kernels), and the bounded wait: a completion flag that never comes is an error code, not a hang."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _contexts(dt, n=3000, L=200, nj=1500, seed=41):
+    from veryfasttree_amd import HipProfileOps, synth
+    codes = synth.random_descent_codes(n, L, 4, 0.05, 0.03, seed=seed)
+    out = []
+    for k in range(2):
+        ops = HipProfileOps(n, L, 4, dt, max_nodes=2 * n)
+        if k == 1:
+            ops.debug_option(1, 1)   # VFT_DEBUG_NO_FUSED_REFRESH: refreshes and pairs as two launches
+        ops.upload_leaves(codes)
+        ops.set_node_scalars(0, np.zeros(n, dt), (codes != 127).sum(1).astype(dt), np.zeros(n, dt))
+        ops.outProfile(np.arange(n))
+        active = list(range(n))
+        order = np.random.default_rng(6)
+        for t in range(nj):
+            i, j = (int(x) for x in order.choice(len(active), 2, replace=False))
+            i, j = active[i], active[j]
+            ops.join_fused(i, j, n + t, 0.02 * (t % 5), 10 * n, len(active), True)
+            active = [v for v in active if v != i and v != j] + [n + t]
+        out.append(ops)
+    return out, np.array(active, np.int64), n + nj
+
+
+def test_fused_pair_lists_equal_the_two_launch_path_200_times():
+    (o1, o2), active, nn = _contexts(np.float32)
+    nact = len(active)
+    rng = np.random.default_rng(99)
+    sizes = [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 2048] + [int(x) for x in rng.integers(1, 2049, 186)]
+    for rep, cnt in enumerate(sizes):
+        stamps = np.full(nn, nact, np.int64)
+        stale = rng.choice(active, int(rng.integers(1, 400)), replace=False)
+        stamps[stale] = nact + 50                      # staler than allowed
+        od = rng.uniform(0, 30, nn).astype(np.float32)
+        for o in (o1, o2):
+            o.set_out_distances(0, od, stamps)
+        hub = int(active[rng.integers(len(active))])   # one node against many partners, as after a join
+        pj = rng.choice(active, cnt, replace=cnt > len(active)).astype(np.int64)
+        pi = np.where(rng.random(cnt) < 0.8, hub, rng.choice(active, cnt)).astype(np.int64)
+        keep = pi != pj
+        pi, pj = pi[keep], pj[keep]
+        if len(pi) == 0:
+            continue
+        forced = rng.choice(active, int(rng.integers(0, 60)), replace=False).astype(np.int64)   # mostly NOT ends of a listed pair
+        r1 = o1.setDistCriterionRefresh(pi, pj, forced, nact, 5, 2.5)
+        mo, mn = o1.out_distance_mirror()
+        assert np.all(mn[forced] == nact), rep         # every forced refresh has landed when the call returns
+        r2 = o2.setDistCriterionRefresh(pi, pj, forced, nact, 5, 2.5)
+        for a, b in zip(r1, r2):
+            assert np.array_equal(a, b), (rep, cnt)
+        g1, g2 = o1.get_out_distances(0, nn), o2.get_out_distances(0, nn)
+        assert np.array_equal(g1[0], g2[0]) and np.array_equal(g1[1], g2[1]), (rep, cnt)
+    o1.close()
+    o2.close()
+
+
+def test_a_flag_that_never_comes_is_an_error_not_a_hang():
+    from veryfasttree_amd.backend import VftError
+    (o1, o2), active, nn = _contexts(np.float32, n=400, nj=100)
+    o2.close()
+    nact = len(active)
+    o1.set_out_distances(0, np.zeros(nn, np.float32), np.full(nn, nact, np.int64))
+    pi, pj = active[:50].copy(), active[50:100].copy()
+    o1.setDistCriterion(pi, pj, nact, 5, 1.0)                 # (works)
+    o1.debug_option(5, 1)                                      # VFT_DEBUG_FAULT_NO_FLAG: the next wait never sees its flag
+    t0 = time.perf_counter()
+    with pytest.raises(VftError, match="completion flag"):
+        o1.setDistCriterion(pi, pj, nact, 5, 1.0)
+    assert time.perf_counter() - t0 < 2.0
+    o1.setDistCriterion(pi, pj, nact, 5, 1.0)                 # the hook is one-shot: the context goes on
+    o1.close()
+
+
+def test_nj_runs_are_reproducible():
+    """20 000 x 200 through the join engine five times and once through the host-driven loop: 19 9xx joins each, identical.
+    (The kernels of a join and the host's enqueue-ahead window overlap differently in every run.)"""
+    import os
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_run
+    codes = synth.random_descent_codes(20000, 200, 4, 0.03, 0.01, seed=3)
+    codes = codes[np.sort(np.unique(codes, axis=0, return_index=True)[1])]
+    runs = []
+    for rep in range(6):
+        if rep == 5:
+            os.environ["VFT_NJ_HOST_JOINS"] = "1"
+        try:
+            ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+            runs.append(nj_run(ops, codes))
+            ops.close()
+        finally:
+            os.environ.pop("VFT_NJ_HOST_JOINS", None)
+    for rep in range(1, 6):
+        assert np.array_equal(runs[0][0], runs[rep][0]) and np.array_equal(runs[0][1], runs[rep][1]), rep

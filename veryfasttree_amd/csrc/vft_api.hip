@@ -57,6 +57,8 @@ struct vft_ctx {
     int pairWG = 0;                // VFT_DEBUG_PAIR_THREADS: threads per pair of the short-list kernels
     bool genericOutProfile = false;   // VFT_DEBUG_GENERIC_OUTPROFILE: the one-thread-per-column out-profile kernel
     int fusedLimit = 2048;         // workgroups of k_pairs_refresh_fused that are resident at once (set by vft_create)
+    bool faultNoFlag = false;      // VFT_DEBUG_FAULT_NO_FLAG: the next wait for a completion flag waits for one that never comes
+    double waitLimitS = 120.0;     // how long a wait for a completion flag may last while the stream is busy
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -135,6 +137,7 @@ struct vft_ctx {
     void *thHits = nullptr, *thStD = nullptr, *thStC = nullptr;
     int32_t *thLen = nullptr, *thStJ = nullptr;
     unsigned int *thMark = nullptr, *thDone = nullptr;
+    int32_t *thSorted = nullptr;
     int32_t thM = 0, thCap = 0;
     int64_t thLists = 0;
     unsigned int thTag = 0;
@@ -299,13 +302,29 @@ static int wait_stream(vft_ctx *c) {
     return wait_flag(c, seq);
 }
 // spins on the host-mapped flag until the stream has published `seq`
+// The spin is bounded: a flag that a kernel never raises (a bug in one of the hand-written completion protocols, a faulted
+// kernel) comes back as VFT_ERR_TIMEOUT instead of hanging the caller - at once when the stream has drained without the flag
+// moving, after waitLimitS seconds (vft_debug_option(VFT_DEBUG_WAIT_LIMIT_MS)) when it is still busy.
 static int wait_flag(vft_ctx *c, unsigned long long seq) {
     volatile unsigned long long *f = c->hFlag;
+    if (c->faultNoFlag) {   // test hook: wait for a value nobody will ever publish
+        seq += 1ull << 40;
+        c->faultNoFlag = false;
+    }
+    std::chrono::steady_clock::time_point t0;
     for (long spins = 0;; spins++) {
         if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= seq) return VFT_OK;
-        if (spins > 2000000) {   // ~ a second: fall back to the runtime (also surfaces asynchronous errors)
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            return VFT_OK;
+        if (spins == 200000) t0 = std::chrono::steady_clock::now();   // (~ 0.1 s of spinning: start looking at the stream)
+        if (spins >= 200000 && (spins & 0xFFFF) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {   // everything enqueued has run: the flag is as high as it will ever get
+                if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= seq) return VFT_OK;
+                return fail(c, VFT_ERR_TIMEOUT, "the stream has drained but the completion flag stands at %llu, not %llu",
+                            (unsigned long long) *f, seq);
+            }
+            if (e != hipErrorNotReady) return fail(c, VFT_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(e));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->waitLimitS)
+                return fail(c, VFT_ERR_TIMEOUT, "no completion flag after %.0f s (the stream is still busy)", c->waitLimitS);
         }
         __builtin_ia32_pause();
     }
@@ -532,7 +551,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hIO) hipHostFree(c->hIO);
     if (c->hFlag) hipHostFree(c->hFlag);
     if (c->doneCtr) hipFree(c->doneCtr);
-    for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone,
+    for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone, (void *) c->thSorted,
                     c->njState, c->njVisD, (void *) c->njVisJ, (void *) c->njTop, (void *) c->njAge, (void *) c->njLogDev})
         if (p) hipFree(p);
     if (c->njLogHost) hipHostFree(c->njLogHost);
@@ -2095,6 +2114,7 @@ static TopHits<REAL> tophits(const vft_ctx *c) {
     T.stC = (REAL *) c->thStC;
     T.mark = c->thMark;
     T.doneCtr = c->thDone;
+    T.sorted = c->thSorted;
     return T;
 }
 
@@ -2117,6 +2137,7 @@ extern "C" int vft_tophits_create(vft_ctx *c, int32_t m, int64_t nLists) {
     HIPCHK(c, hipMalloc(&c->thStC, (size_t) c->thCap * c->rs));
     HIPCHK(c, hipMalloc((void **) &c->thMark, (size_t) c->d.maxNodes * 4));
     HIPCHK(c, hipMemsetAsync(c->thMark, 0, (size_t) c->d.maxNodes * 4, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->thSorted, (size_t) (c->thCap + 1) * 4));
     HIPCHK(c, hipMalloc((void **) &c->thDone, 65 * 4));
     HIPCHK(c, hipMemsetAsync(c->thDone, 0, 65 * 4, c->stream));
     c->thTag = 0;
@@ -2380,8 +2401,7 @@ static __global__ void k_nj_set_state(NjState<REAL> *st, long long nActive, long
     if (tvAge >= 0) st->tvAge = tvAge;
     if (clearHalt) {
         st->halt = 0;
-        hostStatus[1] = 0;
-        __threadfence_system();
+        hostStatus[0] = (long long) ((unsigned long long) st->joinsDone & 0x7FFFFFFFull);
     }
 }
 
@@ -2416,8 +2436,9 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     c->njScanLds = 0;
     // k_nj_glue_scan: pair staging | keys | slot criteria | distances by staging index | slot cache | stale list | pass list
     c->njTailLds = pairLds + (size_t) P * sizeof(ThKey) + (size_t) cfg->n_top * 8 + (size_t) P * rs + (size_t) cfg->n_top * rs +
-                   (size_t) cfg->n_top * 12 + (size_t) (2 * cfg->n_top + 2 * P + 2) * 4 + (size_t) P * 4 + 64;
-    if (c->njTailLds > (160u << 10) - (16u << 10)) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists too long for the merge kernel's LDS");
+                   (size_t) cfg->n_top * 12 + (size_t) (2 * cfg->n_top + 2 * P + 2) * 4 + (size_t) P * 4 + (size_t) P * rs + 64;
+    if (c->njTailLds > (160u << 10) - (16u << 10) || 2 * pairLds > (160u << 10) - (16u << 10))
+        return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists or alignment too long for the glue kernels' LDS");
     if (int r = ensure_ml_rows(c)) return r;
     if (!c->pendBase) {
         const CommitPlan plan = commit_plan(c, VFT_PEND_MAX);
@@ -2444,10 +2465,12 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     VFT_DISPATCH(c, {
         if (c->njTailLds > (48u << 10))
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_scan<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->njTailLds));
-        if (pairLds > (48u << 10)) {
+        if ((size_t) P * sizeof(ThKey) > (48u << 10))
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_merge_rank<REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ((size_t) P * sizeof(ThKey))));
+        if (2 * pairLds > (48u << 10)) {
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_best<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_best_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
-            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_join<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_join<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (2 * pairLds)));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_refresh_new<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_merge_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
         }
@@ -2622,7 +2645,7 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         // stopped them, which the caller handles first.
         if ((c->pend.empty() || c->pend.back() != newnode) && (int64_t) c->pend.size() == VFT_PEND_MAX) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if ((__atomic_load_n(&c->njStatusHost[1], __ATOMIC_ACQUIRE) >> 32) != 0)
+            if ((((unsigned long long) __atomic_load_n(&c->njStatusHost[0], __ATOMIC_ACQUIRE) >> 31) & 7ull) != 0)
                 return fail(c, VFT_ERR_STATE, "vft_nj_engine_enqueue: the engine has halted (handle the event first)");
             if (int r = flush_pending(c)) return r;
             E = njengine<REAL>(c);
@@ -2645,7 +2668,7 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         if (newnode >= c->maxnode) c->maxnode = newnode + 1;
         if ((int64_t) E.staleStamp > c->maxStamp) c->maxStamp = E.staleStamp;
         const int32_t slot = (int32_t) c->pend.size() - 1;
-        launch((k_nj_glue_join<REAL, NC>), dim3(1), dim3(VFT_WG_PROF), pairLds, c->stream, arena<REAL>(c), E, T, ji, updateOut, slot, 1);
+        launch((k_nj_glue_join<REAL, NC>), dim3(1), dim3(VFT_WG_PROF), 2 * pairLds, c->stream, arena<REAL>(c), E, T, ji, updateOut, slot, 1);
     }
     if (phases & VFT_NJ_PHASE_MERGE) {
         if (++c->thTag == 0u) {
@@ -2655,6 +2678,7 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         // (the join kernel computes the new node's out-distance itself unless the caller recomputes the out-profile in between)
         if (!updateOut) launch((k_nj_refresh_new<REAL, NC>), dim3(1), dim3(VFT_WG), pairLds, c->stream, A, E);
         launch((k_nj_merge_pairs<REAL, NC>), dim3((unsigned) (2 * c->thM)), dim3(VFT_WG), pairLds, c->stream, A, E, T, ji, c->thTag);
+        launch((k_nj_merge_rank<REAL>), dim3(cdiv(2 * c->thM, VFT_NJ_RANK_PER_WG)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, E, T, ji);
         const bool chain = (phases & VFT_NJ_PHASE_NEXT) != 0;
         launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, ji, chain ? ji + 1 : -1ll, c->njP);
         if (chain && !c->njCfg.fastest) round();
@@ -2674,10 +2698,10 @@ extern "C" int vft_nj_engine_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phas
 extern "C" int vft_nj_engine_poll(vft_ctx *c, int64_t *joinsDone, int32_t *halt, int32_t *haltJoin) {
     NJ_ENGINE_OK(c);
     volatile long long *s = c->njStatusHost;
-    const long long h = __atomic_load_n(&s[1], __ATOMIC_ACQUIRE);   // (halt << 32) | join, written in one piece
-    if (joinsDone) *joinsDone = __atomic_load_n(&s[0], __ATOMIC_ACQUIRE);
-    if (halt) *halt = (int32_t) (h >> 32);
-    if (haltJoin) *haltJoin = (int32_t) (h & 0xFFFFFFFFll);
+    const unsigned long long w = (unsigned long long) __atomic_load_n(&s[0], __ATOMIC_ACQUIRE);   // vft_nj_publish: one word
+    if (joinsDone) *joinsDone = (int64_t) (w & 0x7FFFFFFFull);
+    if (halt) *halt = (int32_t) ((w >> 31) & 7ull);
+    if (haltJoin) *haltJoin = (int32_t) (w >> 34);
     return VFT_OK;
 }
 
@@ -2687,12 +2711,19 @@ extern "C" int vft_nj_engine_resume(vft_ctx *c, int64_t nextJoin) {
     const int64_t firstFree = c->d.nSeqs + nextJoin;
     while (!c->pend.empty() && c->pend.back() >= firstFree) c->pend.pop_back();
     if (c->maxnode > firstFree) c->maxnode = firstFree;
-    c->njStatusHost[1] = 0;
+    c->njStatusHost[0] &= 0x7FFFFFFFll;   // (the halt bits; the device clears them again when the stream gets there)
     if (c->rs == 4) launch((k_nj_set_state<float>), dim3(1), dim3(1), 0, c->stream, (NjState<float> *) c->njState, -1ll, -1ll, (double) NAN, -1, 1, c->njStatusDev);
     else launch((k_nj_set_state<double>), dim3(1), dim3(1), 0, c->stream, (NjState<double> *) c->njState, -1ll, -1ll, (double) NAN, -1, 1, c->njStatusDev);
     LAUNCHCHK(c);
     return VFT_OK;
 }
+
+#ifdef VFT_NJ_TIMING
+extern "C" int vft_nj_engine_ticks(vft_ctx *c, unsigned long long *ticks /* 16 */) {   // tools-only build
+    hipStreamSynchronize(c->stream);
+    return hipMemcpyFromSymbol(ticks, HIP_SYMBOL(vftNjTicks), 16 * sizeof(unsigned long long)) == hipSuccess ? VFT_OK : VFT_ERR_HIP;
+}
+#endif
 
 extern "C" int vft_nj_engine_log(vft_ctx *c, const vft_nj_join_t **log) {
     NJ_ENGINE_OK(c);
@@ -3236,6 +3267,8 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_PAIR_THREADS: c->pairWG = (int) value; break;
         case VFT_DEBUG_NO_PAIR_STAGING: c->noPairStaging = value != 0; break;
         case VFT_DEBUG_GENERIC_OUTPROFILE: c->genericOutProfile = value != 0; break;
+        case VFT_DEBUG_FAULT_NO_FLAG: c->faultNoFlag = value != 0; break;
+        case VFT_DEBUG_WAIT_LIMIT_MS: c->waitLimitS = value > 0 ? (double) value / 1000.0 : 120.0; break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }
     return VFT_OK;

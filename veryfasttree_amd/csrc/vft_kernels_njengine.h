@@ -24,7 +24,22 @@
 #pragma once
 #include "vft_kernels_tophits.h"
 
-#define VFT_NJ_TAIL 1024   // threads of the single-workgroup kernels (scan, merge tail)
+// tools-only build (-DVFT_NJ_TIMING): thread 0 of k_nj_glue_scan accumulates the clock ticks between its phases
+#ifdef VFT_NJ_TIMING
+__device__ unsigned long long vftNjTicks[16];
+#define VFT_NJ_TICK(k)                                                                  \
+    do {                                                                                \
+        if (threadIdx.x == 0) {                                                         \
+            const unsigned long long now_ = wall_clock64();                             \
+            atomicAdd(&vftNjTicks[k], now_ - tick_);                                    \
+            tick_ = now_;                                                               \
+        }                                                                               \
+    } while (0)
+#else
+#define VFT_NJ_TICK(k) do { } while (0)
+#endif
+#define VFT_NJ_TAIL 256    // threads of k_nj_glue_scan: its cost is barriers and dependent loads, not arithmetic - four wavefronts
+                           // synchronise several times faster than sixteen (measured: 1024 threads 47 us per call at 20 000 taxa)
 
 // halt reasons
 #define VFT_NJ_HALT_RESET 1     // topHitNJSearch wants resetTopVisible (NJ.tcc:4156-4206); nothing of the join has happened
@@ -55,7 +70,7 @@ struct NjEngine {
     int32_t *topvis;        // topvisible[nTop] (NJ.h:242-246)
     int32_t *age;           // TopHitsList::age
     NjJoinRec *logDev, *logHost;
-    volatile long long *hostStatus;   // host-mapped: [0] joinsDone, [1] (halt << 32) | haltJoin
+    volatile long long *hostStatus;   // host-mapped status word (vft_nj_publish)
     int32_t m, nTop, need, ageLimit, fastest, staleStamp;
     double staleOutLimit, tol;
     REAL *stash;            // vft_join_fused's pending stash
@@ -136,11 +151,12 @@ __device__ __forceinline__ bool vft_nj_stale(const Arena<REAL> &A, const SweepAr
 
 template <typename REAL>
 __device__ __forceinline__ void vft_nj_publish(const NjEngine<REAL> &E, const NjState<REAL> *st) {
-    // two 8-byte words, each written in one piece: [0] joins completed, [1] (halt reason << 32) | join it belongs to
-    E.hostStatus[0] = st->joinsDone;
-    __threadfence_system();
-    E.hostStatus[1] = ((long long) st->halt << 32) | (long long) (uint32_t) st->haltJoin;
-    __threadfence_system();
+    // ONE 8-byte word, written in one piece (the host polls it): bits 0-30 joins completed, 31-33 halt reason, 34-63 its join.
+    // No fence: the store drains by itself within the kernel's lifetime, and what the host reads once it has seen the word
+    // (the join log) was written by earlier kernels.  (Two system fences here were 6 us of every join.)
+    const unsigned long long w = ((unsigned long long) st->joinsDone & 0x7FFFFFFFull) | ((unsigned long long) (st->halt & 7) << 31) |
+                                 ((unsigned long long) (uint32_t) st->haltJoin << 34);
+    E.hostStatus[0] = (long long) w;
 }
 
 // (criterion, slot) reduction over the workgroup: the first minimum in slot order (MAXLAST = false; no candidate: slot
@@ -208,18 +224,28 @@ __device__ __forceinline__ void vft_nj_slot_load(const Arena<REAL> &A, const NjE
     int32_t f = 0, vj = -1;
     REAL d = 0;
     double cr = 0;
-    if (node >= 0 && A.parent[node] < 0) {
-        vj = vft_nj_ld(&E.visJ[node]);
-        if (vj >= 0 && A.parent[vj] < 0) {
-            f = 2;
-            d = vft_nj_ld(&E.visD[node]);
-            const REAL oi = vft_nj_ld(&A.outDist[node]), oj = vft_nj_ld(&A.outDist[vj]);
-            const int32_t si = vft_nj_ld(&A.nOutActive[node]), sj = vft_nj_ld(&A.nOutActive[vj]);
-            cr = (double) vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
-            if ((long long) si - s.nActive > s.nDiffAllow) f |= 4;
-            if ((long long) sj - s.nActive > s.nDiffAllow) f |= 8;
-        } else {
+    if (node >= 0) {
+        // two dependent rounds of loads: everything that hangs on the node, then everything that hangs on its partner
+        const int32_t pn = A.parent[node];
+        const int32_t vj0 = vft_nj_ld(&E.visJ[node]);
+        const REAL d0 = vft_nj_ld(&E.visD[node]);
+        const REAL oi = vft_nj_ld(&A.outDist[node]);
+        const int32_t si = vft_nj_ld(&A.nOutActive[node]);
+        if (pn < 0) {
+            vj = vj0;
             f = 1;
+            if (vj >= 0) {
+                const int32_t pj = A.parent[vj];
+                const REAL oj = vft_nj_ld(&A.outDist[vj]);
+                const int32_t sj = vft_nj_ld(&A.nOutActive[vj]);
+                if (pj < 0) {
+                    f = 2;
+                    d = d0;
+                    cr = (double) vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
+                    if ((long long) si - s.nActive > s.nDiffAllow) f |= 4;
+                    if ((long long) sj - s.nActive > s.nDiffAllow) f |= 8;
+                }
+            }
         }
     }
     S.vj[t] = vj;
@@ -358,6 +384,58 @@ __device__ __forceinline__ void vft_nj_force_out_distance(const Arena<REAL> &A, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The candidates of a merge (k_nj_merge_pairs' staging arrays) in sortSaveBestHits' order: criterion ascending, ties by
+// descending partner id (NJ.tcc:4535-4578 on a list in ascending partner order).  Sorting 2 m keys inside the
+// single-workgroup glue kernel was the largest part of it (bitonic network: 23 us at 300 000 taxa); ranking by counting is
+// 4 m^2 comparisons that spread over the chip: every workgroup holds all keys in LDS and ranks VFT_NJ_RANK_PER_WG of them, four
+// lanes per key.  T.sorted[r] = staging index of the candidate of rank r, T.sorted[T.cap] = number of candidates.
+// Dynamic LDS: P keys.
+#define VFT_NJ_RANK_PER_WG (VFT_WG / 4)
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex) {
+    extern __shared__ __attribute__((aligned(16))) double njLds[];
+    if (E.st->halt) return;
+    ThKey *keys = (ThKey *) njLds;
+    __shared__ int nValid;
+    const NjJoinRec rec = E.logDev[joinIndex];
+    const int n = T.len[rec.i] + T.len[rec.j];
+    if ((int) (blockIdx.x * VFT_NJ_RANK_PER_WG) >= n) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) T.sorted[T.cap] = 0;   // (two empty lists)
+        return;
+    }
+    if (threadIdx.x == 0) nValid = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int u = threadIdx.x; u < n; u += blockDim.x) {
+        const int32_t ju = T.stJ[u];
+        const REAL cu = T.stC[u];
+        ThKey k;
+        k.key = ju < 0 ? ~0ull : vft_th_order(cu);
+        k.nj = ju < 0 ? ~0u : ~(uint32_t) ju;
+        k.src = ju < 0 ? -1 : u;
+        keys[u] = k;
+        mine += ju >= 0;
+    }
+    if (mine) atomicAdd(&nValid, mine);
+    __syncthreads();
+    const int e = (int) (blockIdx.x * VFT_NJ_RANK_PER_WG) + (int) (threadIdx.x >> 2), part = threadIdx.x & 3;
+    int rank = 0;
+    ThKey ke;
+    ke.key = ~0ull;
+    ke.nj = ~0u;
+    ke.src = -1;
+    if (e < n) ke = keys[e];
+    if (ke.src >= 0) {
+#pragma unroll 8
+        for (int u = part; u < n; u += 4) rank += vft_th_before(keys[u], ke) ? 1 : 0;
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    if (part == 0 && ke.src >= 0) T.sorted[rank] = e;
+    if (blockIdx.x == 0 && threadIdx.x == 0) T.sorted[T.cap] = nValid;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_nj_glue_scan: [the rest of topHitJoin for join `doneJoin` (>= 0): NJ.tcc:4342-4438 - the age of the new list, the decision,
 // sortSaveBestHits, the new node's visible hit, updateTopVisible for it, updateVisible over the saved hits] + [topHitNJSearch
 // of join `nextJoin` (>= 0) up to the hill climbing, NJ.tcc:4137-4223: the lazy refreshes of the scan, the best visible hit,
@@ -373,10 +451,10 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
     double *sW = njLds, *sT = njLds + A.d.nPosPad;
     ThKey *keys = (ThKey *) (njLds + 2 * A.d.nPosPad);
     double *critS = (double *) (keys + P);
-    REAL *distL = (REAL *) (critS + E.nTop);
+    REAL *distL = (REAL *) (critS + E.nTop), *critL = distL + P;   // by rank: distance and criterion of the sorted candidates
     NjSlots<REAL> S;
     S.crit = critS;
-    S.dist = distL + P;
+    S.dist = critL + P;
     S.node = (int32_t *) (S.dist + E.nTop);
     S.vj = S.node + E.nTop;
     S.flags = S.vj + E.nTop;
@@ -388,36 +466,34 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
     __shared__ int redT[VFT_NJ_TAIL];
     const long long nActive = st->nActive;
     const SweepArgs s = vft_nj_args(E, nActive, st->totdiam);
+#ifdef VFT_NJ_TIMING
+    unsigned long long tick_ = wall_clock64();
+#endif
     if (threadIdx.x == 0) thCount = nPass = nRefreshes = nCand = 0;
     for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) S.node[t] = E.topvis[t];
     __syncthreads();
     vft_nj_slots_load(A, E, s, S);
+    VFT_NJ_TICK(0);
     if (doneJoin >= 0) {
         const NjJoinRec rec = E.logDev[doneJoin];
         const int32_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
         const int n = T.len[c0] + T.len[c1];
-        for (int u = threadIdx.x; u < n; u += blockDim.x) {
-            const int32_t ju = T.stJ[u];
-            if (ju < 0) continue;
+        (void) n;
+        // the candidates in sorted order (k_nj_merge_rank): rank r -> staging index -> (partner, distance, criterion)
+        const int nU = T.sorted[T.cap];
+        for (int r = threadIdx.x; r < nU; r += blockDim.x) {
+            const int src = T.sorted[r];
             ThKey k;
-            k.key = vft_th_order(T.stC[u]);
-            k.nj = ~(uint32_t) ju;
-            k.src = u;
-            keys[atomicAdd(&thCount, 1)] = k;
-            distL[u] = T.stD[u];
+            k.key = 0;
+            k.nj = ~(uint32_t) T.stJ[src];
+            k.src = r;
+            keys[r] = k;
+            distL[r] = T.stD[src];
+            critL[r] = T.stC[src];
         }
         __syncthreads();
-        const int nU = thCount;
-        int P1 = 2;
-        while (P1 < nU) P1 <<= 1;
-        for (int u = nU + threadIdx.x; u < P1; u += blockDim.x) {
-            ThKey k;
-            k.key = ~0ull;
-            k.nj = ~0u;
-            k.src = -1;
-            keys[u] = k;
-        }
-        vft_th_bitonic(keys, P1);   // (a counting sort by the whole workgroup was measured slower: 4 M key comparisons on one CU)
+        VFT_NJ_TICK(1);
+        VFT_NJ_TICK(2);
         // NJ.tcc:4342-4362
         const int32_t ageNew = (E.age[c0] + E.age[c1] + 1) / 2 + 1;
         const bool useUnique = (long long) nU == nActive - 1 || (ageNew <= E.ageLimit && nU >= E.need);
@@ -436,11 +512,11 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
         for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
             ThHit<REAL> e;
             e.j = (int32_t) ~keys[r].nj;
-            e.dist = distL[keys[r].src];
+            e.dist = distL[r];
             T.hits[(int64_t) newnode * T.m + r] = e;
         }
         const int32_t firstJ = (int32_t) ~keys[0].nj;
-        const REAL firstD = distL[keys[0].src], firstC = T.stC[keys[0].src];
+        const REAL firstD = distL[0], firstC = critL[0];
         if (threadIdx.x == 0) {
             E.age[newnode] = ageNew;
             T.len[newnode] = nSave;
@@ -448,7 +524,9 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             E.visD[newnode] = firstD;
         }
         __syncthreads();
+        VFT_NJ_TICK(3);
         vft_nj_update_top_visible<REAL, NC>(A, E, s, S, newnode, firstJ, firstD, firstC, &nRefreshes, sW, sT, staleList, redC, redT);
+        VFT_NJ_TICK(4);
         // updateVisible (NJ.tcc:4633-4657) over the saved hits in order.  The getVisible of hit t looks at hit.j's own visible
         // hit, which only iteration t changes: the lazy refreshes of all of them first, then all tests, then the few hits that
         // pass update visible[] and the top-visible list one after the other.
@@ -462,13 +540,20 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
                 for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
                     const int32_t node = (int32_t) ~keys[r].nj;
                     // the hit's criterion as updateVisible sees it: the merge's (hits are not re-evaluated, NJ.tcc:4640-4650)
-                    const REAL hitCrit = T.stC[keys[r].src];
+                    const REAL hitCrit = critL[r];
                     const int32_t vj = vft_nj_ld(&E.visJ[node]);
+                    const REAL vd = vft_nj_ld(&E.visD[node]);
+                    const REAL oi = vft_nj_ld(&A.outDist[node]);
+                    const int32_t si = vft_nj_ld(&A.nOutActive[node]);
                     bool pass = true;
-                    if (vj >= 0 && A.parent[vj] < 0) {   // (node itself is active: it is a candidate of this merge)
-                        const REAL vd = vft_nj_ld(&E.visD[node]);
-                        const REAL oi = vft_nj_ld(&A.outDist[node]), oj = vft_nj_ld(&A.outDist[vj]);
-                        const int32_t si = vft_nj_ld(&A.nOutActive[node]), sj = vft_nj_ld(&A.nOutActive[vj]);
+                    int32_t pj = 0, sj = 0;
+                    REAL oj = 0;
+                    if (vj >= 0) {
+                        pj = A.parent[vj];
+                        oj = vft_nj_ld(&A.outDist[vj]);
+                        sj = vft_nj_ld(&A.nOutActive[vj]);
+                    }
+                    if (vj >= 0 && pj < 0) {   // (node itself is active: it is a candidate of this merge)
                         const bool staleI = (long long) si - nActive > s.nDiffAllow, staleJ = (long long) sj - nActive > s.nDiffAllow;
                         if (staleI || staleJ) {
                             if (attempt == 0) {
@@ -490,6 +575,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             }
         }
         __syncthreads();
+        VFT_NJ_TICK(5);
         const int np = nPass;
         if (threadIdx.x == 0)   // (in list order: a selection sort over the few entries)
             for (int a = 0; a < np; a++)
@@ -503,7 +589,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
         for (int a = 0; a < np; a++) {
             const int r = passList[a];
             const int32_t node = (int32_t) ~keys[r].nj;
-            const REAL d = distL[keys[r].src], cr = T.stC[keys[r].src];
+            const REAL d = distL[r], cr = critL[r];
             if (threadIdx.x == 0) {
                 E.visJ[node] = newnode;
                 E.visD[node] = d;
@@ -511,6 +597,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             __syncthreads();
             vft_nj_update_top_visible<REAL, NC>(A, E, s, S, node, newnode, d, cr, &nRefreshes, sW, sT, staleList, redC, redT);
         }
+        VFT_NJ_TICK(6);
         for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) E.topvis[t] = S.node[t];
         if (threadIdx.x == 0) {
             st->nUnique = nU;
@@ -519,6 +606,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
         }
         __syncthreads();
     }
+    VFT_NJ_TICK(7);
     if (nextJoin < 0) return;
     // ---- topHitNJSearch(nextJoin): prefetchVisible(topvisible), the first minimum in slot order, the reset test
     vft_nj_slots_refresh<REAL, NC>(A, E, s, S, E.nTop, -1, -1, staleList, sW, sT);
@@ -557,10 +645,12 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
         vft_nj_publish(E, st);
     }
     __syncthreads();
+    VFT_NJ_TICK(8);
     if (scanHalt) return;
     // getBestFromTopHits' setOutDistance(join.i) (NJ.tcc:4273-4279); with -fastest the two ends before the join (:2897-2898)
     vft_nj_force_out_distance<REAL, NC>(A, s, scanI, sW, sT);
     if (E.fastest) vft_nj_force_out_distance<REAL, NC>(A, s, scanJ, sW, sT);
+    VFT_NJ_TICK(9);
 }
 
 // getBestFromTopHits for one end of the candidate (NJ.tcc:4267-4298): one workgroup per list entry (grid = m; workgroups
@@ -600,8 +690,9 @@ __device__ __forceinline__ void vft_nj_best_pick(const NjEngine<REAL> &E, const 
     double bc = 1e20;
     int bt = 0x7FFFFFFF;
     for (int u = threadIdx.x; u < n; u += blockDim.x) {
-        if (T.stJ[u] < 0) continue;
-        const REAL cu = T.stC[u];
+        const int32_t ju = T.stJ[u];
+        const REAL cu = T.stC[u];   // (loaded with the partner, not after it; meaningless where ju < 0)
+        if (ju < 0) continue;
         if ((bt == 0x7FFFFFFF && cu < (REAL) 1e20) || (bt != 0x7FFFFFFF && (double) cu < bc)) {
             bc = (double) cu;
             bt = u;
@@ -654,7 +745,7 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_glue_best(Arena<REAL> A, NjEngine
 // Otherwise the join itself (NJ.tcc:2897-3042): criterion on the fresh out-distances of both ends, tree arrays, branch
 // lengths, diameter, the new profile, its self distance, the incremental out-profile (vft_join_body), totdiam, the counters;
 // and - unless the caller recomputes the out-profile first (updateOut == 0) - the new node's out-distance, which the first
-// setCriterion of topHitJoin would compute.  One workgroup of VFT_WG_PROF threads; dynamic LDS: 2 * nPosPad doubles.
+// setCriterion of topHitJoin would compute.  One workgroup of VFT_WG_PROF threads; dynamic LDS: 4 * nPosPad doubles.
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex,
                                                               int32_t updateOut, int32_t slot, int32_t lastRound) {
@@ -685,14 +776,15 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
         if (threadIdx.x == 0) st->runRound = 0;
     }
     const int64_t newn = st->maxnode;
-    vft_nj_force_out_distance<REAL, NC>(A, s, i, njLds, njLds + A.d.nPosPad);   // (fresh already unless the caller skipped the search kernels)
-    vft_nj_force_out_distance<REAL, NC>(A, s, j, njLds, njLds + A.d.nPosPad);
+    // setOutDistance(i), setOutDistance(j) (NJ.tcc:2897-2898) have happened: the search forces the first end (k_nj_glue_scan, or
+    // this kernel when a round changed the candidate) and the second (k_nj_glue_best; with -fastest k_nj_glue_scan forces both)
     if (threadIdx.x == 0) {
         const REAL dist = st->curDist;
-        const REAL crit = vft_nj_crit<REAL>(A, dist, (int32_t) i, (int32_t) j, nActive);   // criterionFresh / setDistCriterion(join)
+        const REAL outI = A.outDist[i], outJ = A.outDist[j];
+        const REAL crit = vft_criterion<REAL>(dist, outI, A.nOutActive[i], outJ, A.nOutActive[j], nActive);   // criterionFresh / setDistCriterion(join)
         // NJ.tcc:2911-2916, 3003-3007 (BIONJ off: weight 1/2)
         const double distIJ = (double) dist;
-        const REAL od = vft_nj_ld(&A.outDist[i]) - vft_nj_ld(&A.outDist[j]);
+        const REAL od = outI - outJ;
         const double deltaDist = (double) od / (double) (nActive - 2);
         const REAL blI = (REAL) ((distIJ + deltaDist) / 2), blJ = (REAL) ((distIJ - deltaDist) / 2);
         const double bw = 0.5;
@@ -719,16 +811,24 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
         A.mNOut[newn] = E.staleStamp;
     }
     __syncthreads();
-    vft_join_body<REAL, NC>(A, i, j, newn, sDiam, E.staleStamp, nActive, updateOut, E.tol, E.stash, E.pendIds, slot, njLds);
+    __shared__ double newOut[2];
+    vft_join_body<REAL, NC>(A, i, j, newn, sDiam, E.staleStamp, nActive, updateOut, E.tol, E.stash, E.pendIds, slot, njLds,
+                            updateOut ? newOut : (double *) nullptr);
     __syncthreads();
     if (threadIdx.x == 0) {
         st->maxnode = newn + 1;
         st->nActive = nActive - 1;
-    }
-    if (updateOut) {
-        __syncthreads();
-        const SweepArgs s2 = vft_nj_args(E, nActive - 1, st->totdiam);
-        vft_nj_out_distance<REAL, NC>(A, s2, newn, njLds, njLds + A.d.nPosPad);
+        if (updateOut) {
+            // setOutDistance(new node) (NJ.tcc:1012-1053) from profileDist(new node, updated out-profile), whose column sums the
+            // join body has just formed
+            const double top = newOut[0], denom = newOut[1];
+            const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
+            const REAL od = vft_out_distance<REAL>(d, w, nActive - 1, A.selfweight[newn], A.selfdist[newn], sDiam, st->totdiam);
+            A.outDist[newn] = od;
+            A.nOutActive[newn] = (int32_t) (nActive - 1);
+            A.mOutDist[newn] = od;
+            A.mNOut[newn] = (int32_t) (nActive - 1);
+        }
     }
 }
 

@@ -437,9 +437,13 @@ __global__ void k_outprofile_update(Arena<REAL> A, int64_t old1, int64_t old2, i
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_join_body(const Arena<REAL> &A, int64_t i, int64_t j, int64_t newn, REAL diameter,
                                               int32_t staleStamp, int64_t nActiveOld, int32_t updateOut, double tol,
-                                              REAL *stash, int64_t *pendIds, int32_t slot, double *jfLds) {
-    __shared__ double res[2];
+                                              REAL *stash, int64_t *pendIds, int32_t slot, double *jfLds, double *newOut = nullptr) {
+    // newOut != nullptr (with updateOut): also profileDist(new node, UPDATED out-profile) - what setOutDistance(new node) needs
+    // right after the join (NJ.tcc:1020) - from the columns this workgroup holds anyway: newOut[0] = top, newOut[1] = denom of
+    // NJ.tcc:1168-1183 (LDS: two more arrays of nPosPad doubles behind the first two)
+    __shared__ double res[4];
     double *sW = jfLds, *sT = jfLds + A.d.nPosPad;
+    double *sW2 = jfLds + 2 * A.d.nPosPad, *sT2 = jfLds + 3 * A.d.nPosPad;
     const int64_t nPos = A.d.nPos;
     if (threadIdx.x == 0) {
         A.parent[i] = (int32_t) newn;
@@ -492,11 +496,27 @@ __device__ __forceinline__ void vft_join_body(const Arena<REAL> &A, int64_t i, i
 #pragma unroll
             for (int k = 0; k < NC; k++) A.outF[p * NC + k] = f[k];
             vft_out_codedist<REAL, NC>(A, p, f);
+            if (newOut) {   // the addends of (new node, out-profile) at this column, as vft_pair_block would form them
+                Col<REAL, NC> co;
+                co.w = wo;
+                co.code = VFT_NOCODE_;
+                co.vec = wo > 0;
+#pragma unroll
+                for (int k = 0; k < NC; k++) co.f[k] = f[k];
+                double wgt2 = 0.0, term2 = 0.0;
+                if (cn.w > 0 && co.w > 0) {
+                    const REAL ww = cn.w * co.w;
+                    wgt2 = (double) ww;
+                    term2 = wgt2 * vft_piece<REAL, NC>(A, cn, co, A.outCD ? A.outCD + p * NC : nullptr);
+                }
+                sW2[p] = wgt2;
+                sT2[p] = term2;
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {   // thread 0: top, thread 1: denom - two chains, each in column order (as vft_pair_block)
-        const double *src = threadIdx.x == 0 ? sT : sW;
+    if (threadIdx.x < (newOut ? 4 : 2)) {   // thread 0: top, thread 1: denom - chains in column order (as vft_pair_block); 2, 3: the same for newOut
+        const double *src = threadIdx.x == 0 ? sT : threadIdx.x == 1 ? sW : threadIdx.x == 2 ? sT2 : sW2;
         double acc = 0;
         int64_t p = 0;
         for (; p + 8 <= nPos; p += 8) {
@@ -514,6 +534,10 @@ __device__ __forceinline__ void vft_join_body(const Arena<REAL> &A, int64_t i, i
         const double top = res[0], denom = res[1];
         A.selfweight[newn] = (REAL) (denom > 0 ? denom : 0.01);
         A.selfdist[newn] = (REAL) (denom > 0 ? top / denom : 1.0);
+        if (newOut) {
+            newOut[0] = res[2];
+            newOut[1] = res[3];
+        }
     }
 }
 

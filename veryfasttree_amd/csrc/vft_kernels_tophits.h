@@ -42,6 +42,7 @@ struct TopHits {
     REAL *stD, *stC;
     unsigned int *mark;     // [maxNodes]: tag of the last k_th_join call that claimed the node as a candidate
     unsigned int *doneCtr;  // [65] two-level completion count
+    int32_t *sorted;        // [cap + 1] join engine: staging indices of the candidates in sorted order; [cap] = how many
 };
 
 struct ThBestOut {      // what getBestFromTopHits returns (host-mapped)

@@ -1319,7 +1319,9 @@ namespace veryfasttree {
             topvisible.assign((size_t) (0.5 + opt.topvisibleMult * m), -1);
             topvisibleAge = 0;
             devLists = false;
-            if (opt.deviceLists && std::getenv("VFT_NJ_HOST_LISTS") == nullptr)   /* (tools: the host walks of round 2) */
+            /* (second-level lists keep the host walks of round 2: their transfers and the 2nd -> 1st level switch are host code,
+                and the device walks only pay off when the host holds no lists at all; VFT_NJ_HOST_LISTS: tools) */
+            if (opt.deviceLists && q == 0 && std::getenv("VFT_NJ_HOST_LISTS") == nullptr)
                 devLists = vft_tophits_create(ctx, (int32_t) m, maxnodes) == VFT_OK;
             hostLists = !devLists || q > 0 || checkJoins;
             if (devLists) listLen.assign((size_t) maxnodes, 0);
@@ -2135,10 +2137,34 @@ namespace veryfasttree {
             }
             sSeq.reset(new Section(this, "[host]     checking: sequential pass"));
             int64_t nFullChecks = 0;
+            /* the lists are 8 GB at a million sequences and every full iteration walks one of them from cold memory: the
+               target list of the NEXT undecided iteration is requested while this one is worked on (a hint only) */
+            int64_t ahead = 0;
+            auto prefetchNext = [&](int64_t from) {
+                if (verdict.empty()) return;
+                if (ahead < from) ahead = from;
+                const int64_t end = n * nCheck;
+                while (ahead < end && verdict[(size_t) ahead]) ahead++;
+                if (ahead >= end) return;
+                const int64_t nd = ahead / nCheck, ih = ahead % nCheck;
+                ahead++;
+                if (ih >= (int64_t) hits[(size_t) nd].size()) return;
+                const int64_t x = hits[(size_t) nd][(size_t) ih].j;
+                if (x < 0 || x >= n) return;
+                const char *p0 = (const char *) hits[(size_t) x].data();
+                const size_t b0 = hits[(size_t) x].size() * sizeof(Hit);
+                for (size_t o = 0; o < b0; o += 64) __builtin_prefetch(p0 + o, 0, 1);
+                if ((size_t) x < critOf.size() && !critOf[(size_t) x].empty()) {
+                    const char *p1 = (const char *) critOf[(size_t) x].data();
+                    const size_t b1 = critOf[(size_t) x].size() * sizeof(REAL);
+                    for (size_t o = 0; o < b1; o += 64) __builtin_prefetch(p1 + o, 0, 1);
+                }
+            };
             for (int64_t node = 0; node < n; node++) {
                 for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[node].size(); iHit++) {
                     if (!verdict.empty() && verdict[(size_t) (node * nCheck + iHit)]) continue;
                     nFullChecks++;
+                    prefetchNext(node * nCheck + iHit + 1);
                     Besthit bh;
                     bh.i = node;
                     bh.j = hits[node][iHit].j;
