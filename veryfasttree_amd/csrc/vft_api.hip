@@ -143,6 +143,7 @@ struct vft_ctx {
     unsigned int thTag = 0;
     size_t thLds = 0;                  // dynamic LDS of k_th_best / k_th_join
     size_t thRefreshLds = 0;           // the largest dynamic LDS k_th_refresh has been configured for
+    size_t pbLdsSet = 0;               // ... and k_pairs_block_tiled
     // the join loop on the device (vft_kernels_njengine.h)
     void *njState = nullptr, *njVisD = nullptr;
     int32_t *njVisJ = nullptr, *njTop = nullptr, *njAge = nullptr;
@@ -1972,6 +1973,27 @@ static int pair_distances(vft_ctx *c, int64_t n, const int64_t *pi, const int64_
     return VFT_OK;
 }
 
+// the cross product of two id lists in device memory -> dist[nA][nB] (device): lane per pair for 4-state alphabets without a
+// distance matrix (k_pairs_block_tiled), a wavefront per pair otherwise
+static int launch_pairs_block(vft_ctx *c, const int64_t *dA, int64_t nA, const int64_t *dB, int64_t nB, void *dOut) {
+    const size_t tiledLds = (size_t) VFT_PB_A * (size_t) c->d.nPos * (5 * c->rs + 4) + 64;   // [A][nPos] x (4 frequencies + weight + code)
+    if (c->cfg.n_codes == 4 && !c->hasDm && tiledLds <= (144u << 10)) {
+        if (tiledLds > (48u << 10) && tiledLds > c->pbLdsSet) {
+            if (c->rs == 4) HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_block_tiled<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) tiledLds));
+            else HIPCHK(c, hipFuncSetAttribute((const void *) k_pairs_block_tiled<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) tiledLds));
+            c->pbLdsSet = tiledLds;
+        }
+        const dim3 grid(cdiv(nB, VFT_WG), cdiv(nA, VFT_PB_A));
+        if (c->rs == 4) launch((k_pairs_block_tiled<float, 4>), grid, dim3(VFT_WG), tiledLds, c->stream, arena<float>(c), dA, nA, dB, nB, (float *) dOut);
+        else launch((k_pairs_block_tiled<double, 4>), grid, dim3(VFT_WG), tiledLds, c->stream, arena<double>(c), dA, nA, dB, nB, (double *) dOut);
+    } else {
+        VFT_DISPATCH(c, (launch((k_pairs_block<REAL, NC>), dim3(cdiv(nA * nB, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
+                                arena<REAL>(c), dA, nA, dB, nB, (REAL *) dOut)));
+    }
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
 extern "C" int vft_block_distances(vft_ctx *c, int64_t nA, const int64_t *a, int64_t nB, const int64_t *b, int64_t nActive,
                                    int64_t nDiffAllow, double totdiam, void *dist) {
     if (!c || nA < 0 || nB < 0 || !a || !b || !dist) return VFT_ERR_INVALID;
@@ -2030,9 +2052,7 @@ extern "C" int vft_block_distances(vft_ctx *c, int64_t nA, const int64_t *a, int
                                 c->stream, arena<REAL>(c), (const int64_t *) dStale, nStale, (int64_t) 0, sa)));
     }
     char *o = sBase + idB;
-    VFT_DISPATCH(c, (launch((k_pairs_block<REAL, NC>), dim3(cdiv(nA * nB, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
-                            arena<REAL>(c), (const int64_t *) dA, nA, (const int64_t *) dB, nB, (REAL *) o)));
-    LAUNCHCHK(c);
+    if (int r = launch_pairs_block(c, (const int64_t *) dA, nA, (const int64_t *) dB, nB, o)) return r;
     HIPCHK(c, hipMemcpyAsync(dist, o, (size_t) nA * (size_t) nB * rs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
@@ -2348,8 +2368,7 @@ extern "C" int vft_tophits_refresh(vft_ctx *c, int64_t newnode, int32_t nHits, c
                                     c->stream, arena<REAL>(c), (const int64_t *) ds, nStale, (int64_t) 0, sa)));
         }
     }
-    VFT_DISPATCH(c, (launch((k_pairs_block<REAL, NC>), dim3(cdiv(nWork * nB, c->pwWaves)), dim3(64 * c->pwWaves), pw_lds_bytes(c), c->stream,
-                            arena<REAL>(c), (const int64_t *) (sIn + oW), nWork, (const int64_t *) (sIn + oT), (int64_t) nB, (REAL *) sBlock)));
+    if (int r = launch_pairs_block(c, (const int64_t *) (sIn + oW), nWork, (const int64_t *) (sIn + oT), (int64_t) nB, sBlock)) return r;
     if (lds > c->thRefreshLds) {
         VFT_DISPATCH(c, HIPCHK(c, hipFuncSetAttribute((const void *) k_th_refresh<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)));
         c->thRefreshLds = lds;

@@ -1108,6 +1108,81 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_block(Arena<REAL> A, const int
     dist[t] = d;
 }
 
+// The same block for 4-state alphabets, lane per pair: a lane owns one node of list B and VFT_PB_A nodes of list A at a time and
+// walks the columns in order with VFT_PB_A pairs of double accumulators (top, denom: the reference's own sequence of additions,
+// NJ.tcc:1168-1183, one lane per pair as in the sweeps) - B's column is loaded once per VFT_PB_A pairs, A's columns are staged
+// in LDS by the workgroup.  The wave-per-pair kernel above re-reads both profiles for every pair and spends 64 lanes on 200
+// columns: 2.9 ms for the 1 000 x 2 000 block of a top-hits refresh at a million sequences, 1.45 ns per pair; this one is
+// bound by its arithmetic.  Leaf x leaf pairs come out as seqDist does: top = the number of differing columns, denom = the
+// number of shared ones, both exact in double, and the same division.  Grid (ceil(nB / VFT_WG), ceil(nA / VFT_PB_A)).
+// Dynamic LDS: VFT_PB_A * nPos * ((NC + 1) REALs + 1 int).
+#define VFT_PB_A 8
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_pairs_block_tiled(Arena<REAL> A, const int64_t *idsA, int64_t nA, const int64_t *idsB,
+                                                              int64_t nB, REAL *dist) {
+    extern __shared__ __attribute__((aligned(16))) double pbLds[];
+    const int64_t nPos = A.d.nPos;
+    REAL *sF = (REAL *) pbLds;                                   // [VFT_PB_A][nPos][NC]
+    REAL *sWt = sF + (int64_t) VFT_PB_A * nPos * NC;             // [VFT_PB_A][nPos]
+    int32_t *sCode = (int32_t *) (sWt + (int64_t) VFT_PB_A * nPos);   // [VFT_PB_A][nPos]; bit 8: the column holds a vector
+    const int64_t a0 = (int64_t) blockIdx.y * VFT_PB_A;
+    for (int64_t e = threadIdx.x; e < (int64_t) VFT_PB_A * nPos; e += VFT_WG) {
+        const int64_t a = e / nPos, p = e % nPos;
+        const int64_t id = a0 + a < nA ? idsA[a0 + a] : -1;
+        Col<REAL, NC> c;
+        c.w = 0;
+        c.code = VFT_NOCODE_;
+        c.vec = false;
+#pragma unroll
+        for (int k = 0; k < NC; k++) c.f[k] = 0;
+        if (id >= 0) vft_load_col_ml<REAL, NC>(A, id, p, c);
+        sWt[e] = c.w;
+        sCode[e] = c.code | (c.vec ? 256 : 0);
+#pragma unroll
+        for (int k = 0; k < NC; k++) sF[e * NC + k] = c.vec ? c.f[k] : (REAL) 0;
+    }
+    __syncthreads();
+    const int64_t b = (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
+    const int64_t jb = b < nB ? idsB[b] : -1;
+    if (jb < 0) return;
+    double top[VFT_PB_A], den[VFT_PB_A];
+#pragma unroll
+    for (int a = 0; a < VFT_PB_A; a++) top[a] = den[a] = 0.0;
+    for (int64_t p = 0; p < nPos; p++) {
+        Col<REAL, NC> cb;
+        vft_load_col_ml<REAL, NC>(A, jb, p, cb);
+        if (!(cb.w > 0)) continue;
+#pragma unroll
+        for (int a = 0; a < VFT_PB_A; a++) {
+            const int64_t e = (int64_t) a * nPos + p;
+            Col<REAL, NC> ca;
+            ca.w = sWt[e];
+            if (!(ca.w > 0)) continue;
+            const int32_t cc = sCode[e];
+            ca.code = cc & 255;
+            ca.vec = (cc & 256) != 0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) ca.f[k] = sF[e * NC + k];
+            const REAL ww = ca.w * cb.w;
+            const double wgt = (double) ww;
+            den[a] += wgt;
+            top[a] += wgt * vft_piece<REAL, NC>(A, ca, cb, nullptr);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < VFT_PB_A; a++) {
+        if (a0 + a >= nA) break;
+        const int64_t i = idsA[a0 + a];
+        if (i < 0 || i == jb) continue;
+        REAL d = (REAL) (den[a] > 0 ? top[a] / den[a] : 1.0);
+        if (!(i < A.d.nSeqs && jb < A.d.nSeqs)) {
+            const REAL dd = A.diameter[i] + A.diameter[jb];
+            d = d - dd;
+        }
+        dist[(a0 + a) * nB + b] = d;
+    }
+}
+
 // Lazy out-distance refresh (setCriterion, NJ.tcc:1092-1098) of the DISTINCT stale nodes of a pair list; the host
 // builds the list from its stamp mirror (vft_api.hip: pair_distances), the kernel looks at the real stamp again.
 // Entries below nForced are unconditional refreshes that travel with the list (vft_pair_distances_refresh).

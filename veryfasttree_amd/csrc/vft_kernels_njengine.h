@@ -218,50 +218,70 @@ struct NjSlots {
     int *anyStale;   // some slot carries a stale flag (set when the cache is loaded)
 };
 
-template <typename REAL>
-__device__ __forceinline__ void vft_nj_slot_load(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s, const NjSlots<REAL> &S, int t) {
-    const int32_t node = S.node[t];
-    int32_t f = 0, vj = -1;
-    REAL d = 0;
-    double cr = 0;
-    if (node >= 0) {
-        // two dependent rounds of loads: everything that hangs on the node, then everything that hangs on its partner
-        const int32_t pn = A.parent[node];
-        const int32_t vj0 = vft_nj_ld(&E.visJ[node]);
-        const REAL d0 = vft_nj_ld(&E.visD[node]);
-        const REAL oi = vft_nj_ld(&A.outDist[node]);
-        const int32_t si = vft_nj_ld(&A.nOutActive[node]);
-        if (pn < 0) {
-            vj = vj0;
-            f = 1;
-            if (vj >= 0) {
-                const int32_t pj = A.parent[vj];
-                const REAL oj = vft_nj_ld(&A.outDist[vj]);
-                const int32_t sj = vft_nj_ld(&A.nOutActive[vj]);
-                if (pj < 0) {
-                    f = 2;
-                    d = d0;
-                    cr = (double) vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
-                    if ((long long) si - s.nActive > s.nDiffAllow) f |= 4;
-                    if ((long long) sj - s.nActive > s.nDiffAllow) f |= 8;
-                }
-            }
-        }
-    }
-    S.vj[t] = vj;
-    S.flags[t] = f;
-    S.dist[t] = d;
-    S.crit[t] = cr;
-    if (f & 12) *S.anyStale = 1;   // (benign race: every writer stores 1)
-}
-
-// every thread calls; ends with a barrier
+// The cache for all slots.  A thread owns several slots (1 500 slots on 256 threads at a million sequences) and every slot is
+// two dependent rounds of loads - everything that hangs on the node, then everything that hangs on its partner: the loads of
+// VFT_NJ_BATCH slots are issued together, round by round, instead of slot after slot.  Every thread calls; ends with a barrier.
+#define VFT_NJ_BATCH 8
 template <typename REAL>
 __device__ __forceinline__ void vft_nj_slots_load(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s, const NjSlots<REAL> &S) {
     __syncthreads();
     if (threadIdx.x == 0) *S.anyStale = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) vft_nj_slot_load(A, E, s, S, t);
+    for (int base = 0; base < E.nTop; base += VFT_NJ_BATCH * (int) blockDim.x) {
+        int32_t node[VFT_NJ_BATCH], pn[VFT_NJ_BATCH], vj[VFT_NJ_BATCH], si[VFT_NJ_BATCH], pj[VFT_NJ_BATCH], sj[VFT_NJ_BATCH];
+        REAL d0[VFT_NJ_BATCH], oi[VFT_NJ_BATCH], oj[VFT_NJ_BATCH];
+#pragma unroll
+        for (int k = 0; k < VFT_NJ_BATCH; k++) {
+            const int t = base + k * (int) blockDim.x + (int) threadIdx.x;
+            node[k] = t < E.nTop ? S.node[t] : -1;
+            pn[k] = 0;
+            vj[k] = -1;
+            si[k] = 0;
+            d0[k] = oi[k] = 0;
+            if (node[k] >= 0) {
+                pn[k] = A.parent[node[k]];
+                vj[k] = vft_nj_ld(&E.visJ[node[k]]);
+                d0[k] = vft_nj_ld(&E.visD[node[k]]);
+                oi[k] = vft_nj_ld(&A.outDist[node[k]]);
+                si[k] = vft_nj_ld(&A.nOutActive[node[k]]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VFT_NJ_BATCH; k++) {
+            pj[k] = 0;
+            sj[k] = 0;
+            oj[k] = 0;
+            if (node[k] >= 0 && pn[k] < 0 && vj[k] >= 0) {
+                pj[k] = A.parent[vj[k]];
+                oj[k] = vft_nj_ld(&A.outDist[vj[k]]);
+                sj[k] = vft_nj_ld(&A.nOutActive[vj[k]]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VFT_NJ_BATCH; k++) {
+            const int t = base + k * (int) blockDim.x + (int) threadIdx.x;
+            if (t >= E.nTop) continue;
+            int32_t f = 0, v = -1;
+            REAL d = 0;
+            double cr = 0;
+            if (node[k] >= 0 && pn[k] < 0) {
+                v = vj[k];
+                f = 1;
+                if (v >= 0 && pj[k] < 0) {
+                    f = 2;
+                    d = d0[k];
+                    cr = (double) vft_criterion<REAL>(d, oi[k], si[k], oj[k], sj[k], s.nActive);
+                    if ((long long) si[k] - s.nActive > s.nDiffAllow) f |= 4;
+                    if ((long long) sj[k] - s.nActive > s.nDiffAllow) f |= 8;
+                }
+            }
+            S.vj[t] = v;
+            S.flags[t] = f;
+            S.dist[t] = d;
+            S.crit[t] = cr;
+            if (f & 12) *S.anyStale = 1;   // (benign race: every writer stores 1)
+        }
+    }
     __syncthreads();
 }
 
@@ -481,15 +501,37 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
         (void) n;
         // the candidates in sorted order (k_nj_merge_rank): rank r -> staging index -> (partner, distance, criterion)
         const int nU = T.sorted[T.cap];
-        for (int r = threadIdx.x; r < nU; r += blockDim.x) {
-            const int src = T.sorted[r];
-            ThKey k;
-            k.key = 0;
-            k.nj = ~(uint32_t) T.stJ[src];
-            k.src = r;
-            keys[r] = k;
-            distL[r] = T.stD[src];
-            critL[r] = T.stC[src];
+        for (int base = 0; base < nU; base += VFT_NJ_BATCH * (int) blockDim.x) {
+            int src[VFT_NJ_BATCH];
+#pragma unroll
+            for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
+                src[k] = r < nU ? T.sorted[r] : -1;
+            }
+            int32_t jj[VFT_NJ_BATCH];
+            REAL dd[VFT_NJ_BATCH], cc[VFT_NJ_BATCH];
+#pragma unroll
+            for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                jj[k] = 0;
+                dd[k] = cc[k] = 0;
+                if (src[k] >= 0) {
+                    jj[k] = T.stJ[src[k]];
+                    dd[k] = T.stD[src[k]];
+                    cc[k] = T.stC[src[k]];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
+                if (r >= nU) continue;
+                ThKey kk;
+                kk.key = 0;
+                kk.nj = ~(uint32_t) jj[k];
+                kk.src = r;
+                keys[r] = kk;
+                distL[r] = dd[k];
+                critL[r] = cc[k];
+            }
         }
         __syncthreads();
         VFT_NJ_TICK(1);
@@ -537,33 +579,51 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             for (int attempt = 0; attempt < 2; attempt++) {
                 if (threadIdx.x == 0) nStaleV = nPass = 0;
                 __syncthreads();
-                for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
-                    const int32_t node = (int32_t) ~keys[r].nj;
-                    // the hit's criterion as updateVisible sees it: the merge's (hits are not re-evaluated, NJ.tcc:4640-4650)
-                    const REAL hitCrit = critL[r];
-                    const int32_t vj = vft_nj_ld(&E.visJ[node]);
-                    const REAL vd = vft_nj_ld(&E.visD[node]);
-                    const REAL oi = vft_nj_ld(&A.outDist[node]);
-                    const int32_t si = vft_nj_ld(&A.nOutActive[node]);
-                    bool pass = true;
-                    int32_t pj = 0, sj = 0;
-                    REAL oj = 0;
-                    if (vj >= 0) {
-                        pj = A.parent[vj];
-                        oj = vft_nj_ld(&A.outDist[vj]);
-                        sj = vft_nj_ld(&A.nOutActive[vj]);
-                    }
-                    if (vj >= 0 && pj < 0) {   // (node itself is active: it is a candidate of this merge)
-                        const bool staleI = (long long) si - nActive > s.nDiffAllow, staleJ = (long long) sj - nActive > s.nDiffAllow;
-                        if (staleI || staleJ) {
-                            if (attempt == 0) {
-                                if (staleI) staleList[atomicAdd(&nStaleV, 1)] = node;
-                                if (staleJ) staleList[atomicAdd(&nStaleV, 1)] = vj;
-                            }
+                for (int base = 0; base < nSave; base += VFT_NJ_BATCH * (int) blockDim.x) {
+                    int32_t node[VFT_NJ_BATCH], vj[VFT_NJ_BATCH], si[VFT_NJ_BATCH], pj[VFT_NJ_BATCH], sj[VFT_NJ_BATCH];
+                    REAL vd[VFT_NJ_BATCH], oi[VFT_NJ_BATCH], oj[VFT_NJ_BATCH];
+#pragma unroll
+                    for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                        const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
+                        node[k] = r < nSave ? (int32_t) ~keys[r].nj : -1;
+                        vj[k] = -1;
+                        si[k] = 0;
+                        vd[k] = oi[k] = 0;
+                        if (node[k] >= 0) {
+                            vj[k] = vft_nj_ld(&E.visJ[node[k]]);
+                            vd[k] = vft_nj_ld(&E.visD[node[k]]);
+                            oi[k] = vft_nj_ld(&A.outDist[node[k]]);
+                            si[k] = vft_nj_ld(&A.nOutActive[node[k]]);
                         }
-                        pass = hitCrit < vft_criterion<REAL>(vd, oi, si, oj, sj, nActive);
                     }
-                    if (pass) passList[atomicAdd(&nPass, 1)] = r;
+#pragma unroll
+                    for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                        pj[k] = 0;
+                        sj[k] = 0;
+                        oj[k] = 0;
+                        if (vj[k] >= 0) {
+                            pj[k] = A.parent[vj[k]];
+                            oj[k] = vft_nj_ld(&A.outDist[vj[k]]);
+                            sj[k] = vft_nj_ld(&A.nOutActive[vj[k]]);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                        const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
+                        if (r >= nSave) continue;
+                        // the hit's criterion as updateVisible sees it: the merge's (hits are not re-evaluated, NJ.tcc:4640-4650)
+                        const REAL hitCrit = critL[r];
+                        bool pass = true;
+                        if (vj[k] >= 0 && pj[k] < 0) {   // (node itself is active: it is a candidate of this merge)
+                            const bool staleI = (long long) si[k] - nActive > s.nDiffAllow, staleJ = (long long) sj[k] - nActive > s.nDiffAllow;
+                            if (attempt == 0) {
+                                if (staleI) staleList[atomicAdd(&nStaleV, 1)] = node[k];
+                                if (staleJ) staleList[atomicAdd(&nStaleV, 1)] = vj[k];
+                            }
+                            pass = hitCrit < vft_criterion<REAL>(vd[k], oi[k], si[k], oj[k], sj[k], nActive);
+                        }
+                        if (pass) passList[atomicAdd(&nPass, 1)] = r;
+                    }
                 }
                 __syncthreads();
                 if (nStaleV == 0) break;   // (uniform)

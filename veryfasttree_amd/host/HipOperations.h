@@ -233,6 +233,40 @@ namespace veryfasttree {
             chk(vft_join_fused(ctx, i, j, newnode, (double) diameter, staleStamp, nActiveOld, updateOutProfile ? 1 : 0));
         }
 
+        /* TopHits on the device (NJ.h:206-248): the lists, and the three list walks of a join as one launch each */
+        void topHitsCreate(int32_t m, int64_t nLists) { chk(vft_tophits_create(ctx, m, nLists)); }
+
+        void topHitsUpload(int64_t count, const int64_t *nodes, const int32_t *lens, const void *packed) {
+            chk(vft_tophits_upload(ctx, count, nodes, lens, packed));
+        }
+
+        /* getBestFromTopHits (NJ.tcc:4267-4298) */
+        void topHitsBest(int64_t node, int32_t len, int64_t nActive, int64_t nDiffAllow, double totdiam, bool forceNode, vft_tophits_best_t &out) {
+            chk(vft_tophits_best(ctx, node, len, nActive, nDiffAllow, totdiam, forceNode ? 1 : 0, &out));
+        }
+
+        /* topHitJoin's merge (NJ.tcc:4319-4362, 4786-4833, 4535-4578) */
+        void topHitsJoin(int64_t newnode, int64_t c0, int32_t n0, int64_t c1, int32_t n1, int64_t nActive, int64_t nDiffAllow, double totdiam,
+                         int32_t nSaveMax, int32_t need, bool ageOk, vft_tophits_join_t &info, int32_t *j, numeric_t *dist, numeric_t *criterion) {
+            chk(vft_tophits_join(ctx, newnode, c0, n0, c1, n1, nActive, nDiffAllow, totdiam, nSaveMax, need, ageOk ? 1 : 0, &info, j, dist, criterion));
+        }
+
+        /* topHitJoin's refresh (NJ.tcc:4440-4517) after the sweep of the new node */
+        void topHitsRefresh(int64_t newnode, int32_t nHits, const int64_t *hitJ, const numeric_t *hitDist, int32_t nOwn, const void *ownList,
+                            int64_t nWork, const int64_t *work, const int32_t *nNew, int64_t nActive, int64_t nDiffAllow, double totdiam,
+                            int32_t *lens, void *first) {
+            chk(vft_tophits_refresh(ctx, newnode, nHits, hitJ, hitDist, nOwn, ownList, nWork, work, nNew, nActive, nDiffAllow, totdiam, lens, first));
+        }
+
+        /* the join loop itself on the device (NJ.tcc:2857-3047; vft_nj_engine_*, driven by NJDriver::runEngine) */
+        void njEngineCreate(const vft_nj_engine_config &cfg) { chk(vft_nj_engine_create(ctx, &cfg)); }
+
+        void njEngineEnqueue(int64_t joinIndex, int32_t phases, bool updateOutProfile) {
+            chk(vft_nj_engine_enqueue(ctx, joinIndex, phases, updateOutProfile ? 1 : 0));
+        }
+
+        void njEnginePoll(int64_t &joinsDone, int32_t &halt, int32_t &haltJoin) { chk(vft_nj_engine_poll(ctx, &joinsDone, &halt, &haltJoin)); }
+
         void averageProfiles(int64_t n, const int64_t *out, const int64_t *a, const int64_t *b, const double *bionjWeight) {
             chk(vft_average_profiles(ctx, n, out, a, b, bionjWeight));
         }

@@ -2135,8 +2135,161 @@ namespace veryfasttree {
                 for (int64_t x = 0; x < n; x++)
                     if (need[(size_t) x]) fillCriteria(n, x, critOf[(size_t) x]);
             }
-            sSeq.reset(new Section(this, "[host]     checking: sequential pass"));
             int64_t nFullChecks = 0;
+            bool checkedInParallel = false;
+            if (!verdict.empty() && opt.hostThreads > 1) {
+                /* The undecided iterations, grouped by the list they may rewrite.  An iteration (node, iHit) reads its own
+                   entry hits[node][iHit] - one of the first nCheck of node's list - and reads / rewrites the list of its
+                   target x = that entry's partner: the worst entry of x's list, critOf[x], visible[x], and the verdicts of
+                   entries that point at x.  Lists are sorted when this phase starts, a rewrite puts a BETTER hit in the place of
+                   the worst one, so the worst entry stays behind the first nCheck entries unless a list is rewritten almost
+                   completely or ties reach into its head: iterations with different targets then touch disjoint data (apart
+                   from the immutable heads), and the reference's order only matters among iterations with the same target.  One
+                   thread takes a target and runs its iterations in the reference's order, including those a rewrite re-opens
+                   (the verdicts of the pushed-out partner).  Should a rewrite ever reach into a head (checked), everything is
+                   rolled back from a log and the sequential pass below does the work. */
+                Section sPar(this, "[host]     checking: undecided iterations by target (host threads)");
+                const int nT = opt.hostThreads;
+                const int64_t total = n * nCheck;
+                std::vector<std::vector<std::pair<int32_t, int64_t> > > part((size_t) nT);   /* (target, linear index), index ascending */
+#pragma omp parallel for schedule(static, 1) num_threads(opt.hostThreads)
+                for (int pt = 0; pt < nT; pt++) {
+                    const int64_t lo = n * pt / nT, hi = n * (pt + 1) / nT;
+                    std::vector<std::pair<int32_t, int64_t> > &mine = part[(size_t) pt];
+                    for (int64_t node = lo; node < hi; node++)
+                        for (int64_t iHit = 0; iHit < nCheck && iHit < (int64_t) hits[(size_t) node].size(); iHit++)
+                            if (!verdict[(size_t) (node * nCheck + iHit)]) mine.push_back(std::make_pair(hits[(size_t) node][(size_t) iHit].j, node * nCheck + iHit));
+                }
+                std::vector<int64_t> first((size_t) n + 1, 0);
+                for (auto &v: part)
+                    for (auto &pr: v) first[(size_t) pr.first + 1]++;
+                for (int64_t x = 0; x < n; x++) first[(size_t) x + 1] += first[(size_t) x];
+                std::vector<int64_t> byTarget((size_t) first[(size_t) n]), fill(first.begin(), first.end() - 1);
+                for (auto &v: part)   /* (parts in node order: every target's indices end up ascending) */
+                    for (auto &pr: v) byTarget[(size_t) fill[(size_t) pr.first]++] = pr.second;
+                std::vector<int32_t> targets;
+                for (int64_t x = 0; x < n; x++)
+                    if (first[(size_t) x + 1] > first[(size_t) x]) targets.push_back((int32_t) x);
+                struct Undo {
+                    int32_t x, pos;
+                    Hit oldHit, oldVisible;
+                    REAL oldCrit;
+                    bool visibleChanged;
+                };
+                std::vector<std::vector<Undo> > undo((size_t) nT);
+                std::vector<std::vector<int64_t> > reopened((size_t) nT);   /* verdicts set to 0 on the way (restored on a rollback) */
+                std::vector<std::vector<uint8_t> > reopenedOld((size_t) nT);
+                bool hazard = false;
+                int64_t done = 0;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(opt.hostThreads) reduction(+: done)
+                for (int64_t tI = 0; tI < (int64_t) targets.size(); tI++) {
+#ifdef _OPENMP
+                    const int me = omp_get_thread_num();
+#else
+                    const int me = 0;
+#endif
+                    const int64_t x = targets[(size_t) tI];
+                    std::vector<Hit> &lT = hits[(size_t) x];
+                    std::vector<REAL> &cr = critOf[(size_t) x];
+                    if (cr.size() != lT.size()) fillCriteria(n, x, cr);
+                    int64_t pos = first[(size_t) x];
+                    const int64_t end = first[(size_t) x + 1];
+                    std::vector<int64_t> extra;   /* re-opened iterations, kept as a min-heap */
+                    int64_t lastIdx = -1;
+                    for (;;) {
+                        int64_t idx;
+                        const bool haveBase = pos < end, haveExtra = !extra.empty();
+                        if (!haveBase && !haveExtra) break;
+                        if (haveExtra && (!haveBase || extra.front() < byTarget[(size_t) pos])) {
+                            std::pop_heap(extra.begin(), extra.end(), std::greater<int64_t>());
+                            idx = extra.back();
+                            extra.pop_back();
+                        } else {
+                            idx = byTarget[(size_t) pos++];
+                        }
+                        if (idx == lastIdx) continue;
+                        lastIdx = idx;
+                        done++;
+                        const int64_t node = idx / nCheck, iHit = idx % nCheck;
+                        Besthit bh;
+                        bh.i = node;
+                        bh.j = x;
+                        bh.dist = hits[(size_t) node][(size_t) iHit].dist;
+                        criterionFresh(n, bh);
+                        Besthit chk2;
+                        chk2.i = x;
+                        chk2.j = lT[(size_t) (nCheck - 1)].j;
+                        chk2.dist = lT[(size_t) (nCheck - 1)].dist;
+                        criterionFresh(n, chk2);
+                        if (chk2.criterion < bh.criterion) continue;
+                        bool found = false;
+                        for (size_t t = 0; t < lT.size() && !found; t++) found = lT[t].j == node;
+                        if (found) continue;
+                        int64_t iWorst = -1;
+                        double dWorst = -1e20;
+                        for (size_t t = 0; t < cr.size(); t++)
+                            if (cr[t] > dWorst) {
+                                iWorst = (int64_t) t;
+                                dWorst = cr[t];
+                            }
+                        if (!(dWorst > bh.criterion)) continue;
+                        if (iWorst < nCheck) {   /* would change the head of a list: not covered by the grouping */
+#pragma omp atomic write
+                            hazard = true;
+                            break;
+                        }
+                        Undo u;
+                        u.x = (int32_t) x;
+                        u.pos = (int32_t) iWorst;
+                        u.oldHit = lT[(size_t) iWorst];
+                        u.oldCrit = cr[(size_t) iWorst];
+                        u.oldVisible = visible[(size_t) x];
+                        u.visibleChanged = false;
+                        cr[(size_t) iWorst] = bh.criterion;
+                        const int64_t gone = lT[(size_t) iWorst].j;
+                        if (gone >= 0 && gone < n)
+                            for (int64_t ih = 0; ih < nCheck && ih < (int64_t) hits[(size_t) gone].size(); ih++)
+                                if (hits[(size_t) gone][(size_t) ih].j == x) {
+                                    const int64_t g = gone * nCheck + ih;
+                                    reopened[(size_t) me].push_back(g);
+                                    reopenedOld[(size_t) me].push_back(verdict[(size_t) g]);
+                                    verdict[(size_t) g] = 0;
+                                    if (g > idx) {   /* the reference's loop has not been there yet: it will look at it */
+                                        extra.push_back(g);
+                                        std::push_heap(extra.begin(), extra.end(), std::greater<int64_t>());
+                                    }
+                                }
+                        lT[(size_t) iWorst].j = (int32_t) node;
+                        lT[(size_t) iWorst].dist = bh.dist;
+                        Besthit v;
+                        getVisibleFresh(n, x, v);
+                        if (bh.criterion < v.criterion) {
+                            visible[(size_t) x] = lT[(size_t) iWorst];
+                            u.visibleChanged = true;
+                        }
+                        undo[(size_t) me].push_back(u);
+                    }
+                }
+                if (!hazard) {
+                    checkedInParallel = true;
+                    nFullChecks = done;
+                } else {
+                    for (int pt = 0; pt < nT; pt++) {
+                        for (size_t k = undo[(size_t) pt].size(); k-- > 0;) {
+                            const Undo &u = undo[(size_t) pt][k];
+                            hits[(size_t) u.x][(size_t) u.pos] = u.oldHit;
+                            critOf[(size_t) u.x][(size_t) u.pos] = u.oldCrit;
+                            if (u.visibleChanged) visible[(size_t) u.x] = u.oldVisible;
+                        }
+                        for (size_t k = reopened[(size_t) pt].size(); k-- > 0;) verdict[(size_t) reopened[(size_t) pt][k]] = reopenedOld[(size_t) pt][k];
+                    }
+                    if (profiling) acc["[count]  checking phase: parallel pass rolled back"].calls++;
+                }
+                (void) total;
+            }
+            sSeq.reset(new Section(this, "[host]     checking: sequential pass"));
+            if (checkedInParallel) goto checkingDone;
+            {
             /* the lists are 8 GB at a million sequences and every full iteration walks one of them from cold memory: the
                target list of the NEXT undecided iteration is requested while this one is worked on (a hint only) */
             int64_t ahead = 0;
@@ -2226,6 +2379,8 @@ namespace veryfasttree {
                     }
                 }
             }
+            }
+            checkingDone:
             sSeq.reset();
             if (devLists) {
                 std::vector<int64_t> all((size_t) n);
