@@ -406,6 +406,27 @@ def gen_c4(tmp):
     print("bb_c4_crc: %d bytes of Newick, crc %d, %d joins, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ja), wall))
 
 
+def gen_c4_prefix(tmp):
+    """The part of gen_c4's run that exists so far (oracle/_ref/c4_joins.txt grows while the reference works: the 1M-taxa NJ
+    phase takes it more than half a day at one thread): CRC-32 per 10 000 complete `Join` lines.  Pins the join order of
+    config C4 up to the join the reference had reached when this was written."""
+    import zlib
+    joins = []
+    for line in open(os.path.join(HERE, "_ref", "c4_joins.txt")):
+        f = line.rstrip("\n").split("\t")
+        if len(f) < 11 or not line.endswith("\n"):
+            break
+        joins.append((int(f[1]), int(f[2]), int(f[10])))
+    chunk = 10000
+    ja = np.array(joins[:len(joins) // chunk * chunk], dtype=np.int64)
+    crcs = np.array([zlib.crc32(ja[k:k + chunk].astype("<i4").tobytes()) for k in range(0, len(ja), chunk)], dtype=np.int64)
+    flags = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "1", "-seed", "1"]
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c4_prefix.npz"), n_joins=np.int64(len(ja)), join_chunk=np.int64(chunk), join_chunk_crc=crcs,
+                        flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8))
+    print("bb_c4_prefix: %d joins in %d chunks" % (len(ja), len(crcs)))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa"]
@@ -434,6 +455,8 @@ def main():
             gen_c3(tmp)
         if "c4" in which:   # not part of the default set: hours
             gen_c4(tmp)
+        if "c4_prefix" in which:   # from the Join lines a running gen_c4 has produced so far
+            gen_c4_prefix(tmp)
 
 
 if __name__ == "__main__":

@@ -18,5 +18,7 @@ ops = HipProfileOps(codes.shape[0], L, 4, np.float32)
 t0 = time.perf_counter()
 joins, crit = nj_run(ops, codes, fastest=fastest, second_level=second)
 import zlib
+if "save" in kv:   # the join order as int32 [n, 3] (i, j, new node), e.g. save=gpurun_out/joins.npy
+    np.save(kv["save"], np.ascontiguousarray(joins, np.int64).astype(np.int32))
 print("GPU NJ phase: %.2f s for %d joins (%d unique seqs, L=%d, fastest=%s, 2nd=%s)  join-order crc %d" % (
     time.perf_counter() - t0, len(joins), codes.shape[0], L, fastest, second, zlib.crc32(np.ascontiguousarray(joins, np.int64).astype("<i4").tobytes())))

@@ -152,6 +152,9 @@ struct vft_ctx {
     vft_nj_engine_config njCfg{};
     size_t njScanLds = 0, njTailLds = 0;
     int njP = 0;
+    unsigned int *njClaim = nullptr, njClaimTag = 0;   // speculative double walks: one writer per refreshed node
+    int32_t *njLogNode = nullptr, *njLogStamp = nullptr;
+    void *njLogOut = nullptr;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
@@ -553,7 +556,8 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hFlag) hipHostFree(c->hFlag);
     if (c->doneCtr) hipFree(c->doneCtr);
     for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone, (void *) c->thSorted,
-                    c->njState, c->njVisD, (void *) c->njVisJ, (void *) c->njTop, (void *) c->njAge, (void *) c->njLogDev})
+                    c->njState, c->njVisD, (void *) c->njVisJ, (void *) c->njTop, (void *) c->njAge, (void *) c->njLogDev, (void *) c->njClaim,
+                    (void *) c->njLogNode, (void *) c->njLogStamp, c->njLogOut})
         if (p) hipFree(p);
     if (c->njLogHost) hipHostFree(c->njLogHost);
     if (c->njStatusHost) hipHostFree(c->njStatusHost);
@@ -2408,6 +2412,10 @@ static NjEngine<REAL> njengine(const vft_ctx *c) {
     E.tol = c->fpostTol;
     E.stash = (REAL *) c->pendBase;
     E.pendIds = c->pendIdsDev;
+    E.refClaim = c->njClaim;
+    E.logNode = c->njLogNode;
+    E.logStamp = c->njLogStamp;
+    E.logOut = (REAL *) c->njLogOut;
     return E;
 }
 
@@ -2476,6 +2484,11 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     HIPCHK(c, hipMalloc((void **) &c->njAge, nodes * 4));
     HIPCHK(c, hipMemsetAsync(c->njAge, 0, nodes * 4, c->stream));
     HIPCHK(c, hipMalloc((void **) &c->njLogDev, joins * sizeof(NjJoinRec)));
+    HIPCHK(c, hipMalloc((void **) &c->njClaim, nodes * 4));
+    HIPCHK(c, hipMemsetAsync(c->njClaim, 0, nodes * 4, c->stream));
+    HIPCHK(c, hipMalloc((void **) &c->njLogNode, (size_t) (cfg->m + 64) * 4));
+    HIPCHK(c, hipMalloc((void **) &c->njLogStamp, (size_t) (cfg->m + 64) * 4));
+    HIPCHK(c, hipMalloc(&c->njLogOut, (size_t) (cfg->m + 64) * rs));
     HIPCHK(c, hipHostMalloc((void **) &c->njLogHost, joins * sizeof(NjJoinRec), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void **) &c->njLogHostDev, c->njLogHost, 0));
     HIPCHK(c, hipHostMalloc((void **) &c->njStatusHost, 64, hipHostMallocMapped));
@@ -2489,6 +2502,7 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
         if (2 * pairLds > (48u << 10)) {
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_best<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_best_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_best_pairs2<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_join<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (2 * pairLds)));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_refresh_new<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_merge_pairs<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pairLds));
@@ -2676,9 +2690,17 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         launch((k_nj_glue_best<REAL, NC>), dim3(1), dim3(VFT_WG), pairLds, c->stream, A, E, T);
         launch((k_nj_best_pairs<REAL, NC>), dim3((unsigned) c->thM), dim3(VFT_WG), pairLds, c->stream, A, E, T, 1);
     };
+    // ... and both walks of a round in one launch, the second one speculatively (k_nj_best_pairs2): what follows a search
+    auto roundSpec = [&]() {
+        if (++c->njClaimTag == 0u) {
+            hipMemsetAsync(c->njClaim, 0, (size_t) c->d.maxNodes * 4, c->stream);
+            c->njClaimTag = 1u;
+        }
+        launch((k_nj_best_pairs2<REAL, NC>), dim3((unsigned) (2 * c->thM)), dim3(VFT_WG), pairLds, c->stream, A, E, T, c->njClaimTag);
+    };
     if (phases & VFT_NJ_PHASE_SEARCH) {
         launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, -1ll, ji, c->njP);
-        if (!c->njCfg.fastest) round();
+        if (!c->njCfg.fastest) roundSpec();
     }
     if (phases & VFT_NJ_PHASE_CLIMB) round();
     if (phases & VFT_NJ_PHASE_JOIN) {
@@ -2687,7 +2709,9 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         if (newnode >= c->maxnode) c->maxnode = newnode + 1;
         if ((int64_t) E.staleStamp > c->maxStamp) c->maxStamp = E.staleStamp;
         const int32_t slot = (int32_t) c->pend.size() - 1;
-        launch((k_nj_glue_join<REAL, NC>), dim3(1), dim3(VFT_WG_PROF), 2 * pairLds, c->stream, arena<REAL>(c), E, T, ji, updateOut, slot, 1);
+        // (the round in front of this join was a speculative double walk unless the caller asked for a classic round)
+        launch((k_nj_glue_join<REAL, NC>), dim3(1), dim3(VFT_WG_PROF), 2 * pairLds, c->stream, arena<REAL>(c), E, T, ji, updateOut, slot, 1,
+               (phases & VFT_NJ_PHASE_CLIMB) ? 0 : 1);
     }
     if (phases & VFT_NJ_PHASE_MERGE) {
         if (++c->thTag == 0u) {
@@ -2700,7 +2724,7 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         launch((k_nj_merge_rank<REAL>), dim3(cdiv(2 * c->thM, VFT_NJ_RANK_PER_WG)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, E, T, ji);
         const bool chain = (phases & VFT_NJ_PHASE_NEXT) != 0;
         launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, ji, chain ? ji + 1 : -1ll, c->njP);
-        if (chain && !c->njCfg.fastest) round();
+        if (chain && !c->njCfg.fastest) roundSpec();
     }
     LAUNCHCHK(c);
     return VFT_OK;

@@ -60,6 +60,9 @@ struct NjState {
     int32_t curI, curJ;
     REAL curDist, curCrit;
     int32_t nUnique, runRound;   // runRound: the hill-climbing round whose kernels come next executes (NJ.tcc:4226-4262: "while (changed)")
+    // the speculative double walk (k_nj_best_pairs2): setOutDistance(join.j) computed ahead but not stored yet
+    REAL specOut;
+    int32_t specStamp, specValid, logCount;
 };
 
 template <typename REAL>
@@ -75,6 +78,9 @@ struct NjEngine {
     double staleOutLimit, tol;
     REAL *stash;            // vft_join_fused's pending stash
     int64_t *pendIds;
+    unsigned int *refClaim; // [maxNodes] one writer per refreshed node in a speculative double walk
+    int32_t *logNode, *logStamp;   // [m] what the walk of the second end refreshed (undone when the first walk changes the candidate)
+    REAL *logOut;
 };
 
 template <typename REAL>
@@ -111,6 +117,17 @@ __device__ __forceinline__ void vft_nj_out_distance(const Arena<REAL> &A, const 
         A.mNOut[v] = (int32_t) s.nActive;
     }
     __syncthreads();
+}
+
+// the same value without storing it (thread 0 gets it); every thread calls
+template <typename REAL, int NC>
+__device__ __forceinline__ REAL vft_nj_out_value(const Arena<REAL> &A, const SweepArgs &s, int64_t v, double *sW, double *sT) {
+    REAL d, w;
+    vft_pair_block<REAL, NC>(A, v, -1, true, sW, sT, d, w);
+    REAL od = 0;
+    if (threadIdx.x == 0) od = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v], A.selfdist[v], A.diameter[v], s.totdiam);
+    __syncthreads();
+    return od;
 }
 
 // the lazy refreshes of a batch of setCriterion calls, single-workgroup kernels: `list` (LDS, n entries, duplicates allowed)
@@ -426,15 +443,26 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     if (threadIdx.x == 0) nValid = 0;
     __syncthreads();
     int mine = 0;
-    for (int u = threadIdx.x; u < n; u += blockDim.x) {
-        const int32_t ju = T.stJ[u];
-        const REAL cu = T.stC[u];
-        ThKey k;
-        k.key = ju < 0 ? ~0ull : vft_th_order(cu);
-        k.nj = ju < 0 ? ~0u : ~(uint32_t) ju;
-        k.src = ju < 0 ? -1 : u;
-        keys[u] = k;
-        mine += ju >= 0;
+    for (int base = 0; base < n; base += VFT_NJ_BATCH * (int) blockDim.x) {   // (all loads of a batch in flight together)
+        int32_t ju[VFT_NJ_BATCH];
+        REAL cu[VFT_NJ_BATCH];
+#pragma unroll
+        for (int q = 0; q < VFT_NJ_BATCH; q++) {
+            const int u = base + q * (int) blockDim.x + (int) threadIdx.x;
+            ju[q] = u < n ? T.stJ[u] : -1;
+            cu[q] = u < n ? T.stC[u] : (REAL) 0;
+        }
+#pragma unroll
+        for (int q = 0; q < VFT_NJ_BATCH; q++) {
+            const int u = base + q * (int) blockDim.x + (int) threadIdx.x;
+            if (u >= n) continue;
+            ThKey k;
+            k.key = ju[q] < 0 ? ~0ull : vft_th_order(cu[q]);
+            k.nj = ju[q] < 0 ? ~0u : ~(uint32_t) ju[q];
+            k.src = ju[q] < 0 ? -1 : u;
+            keys[u] = k;
+            mine += ju[q] >= 0;
+        }
     }
     if (mine) atomicAdd(&nValid, mine);
     __syncthreads();
@@ -446,8 +474,15 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     ke.src = -1;
     if (e < n) ke = keys[e];
     if (ke.src >= 0) {
-#pragma unroll 8
-        for (int u = part; u < n; u += 4) rank += vft_th_before(keys[u], ke) ? 1 : 0;
+        int u = part;
+        for (; u + 28 < n; u += 32) {   // eight keys of this lane's quarter per trip: the LDS reads go out together
+            ThKey kk[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) kk[q] = keys[u + 4 * q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) rank += vft_th_before(kk[q], ke) ? 1 : 0;
+        }
+        for (; u < n; u += 4) rank += vft_th_before(keys[u], ke) ? 1 : 0;
     }
     rank += __shfl_xor(rank, 1, 64);
     rank += __shfl_xor(rank, 2, 64);
@@ -709,7 +744,25 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
     if (scanHalt) return;
     // getBestFromTopHits' setOutDistance(join.i) (NJ.tcc:4273-4279); with -fastest the two ends before the join (:2897-2898)
     vft_nj_force_out_distance<REAL, NC>(A, s, scanI, sW, sT);
-    if (E.fastest) vft_nj_force_out_distance<REAL, NC>(A, s, scanJ, sW, sT);
+    if (E.fastest) {
+        vft_nj_force_out_distance<REAL, NC>(A, s, scanJ, sW, sT);
+    } else {
+        // The hill climbing walks both ends' lists in ONE launch (k_nj_best_pairs2), i.e. the second walk starts before the
+        // first one has had its say.  The reference's second walk begins with setOutDistance(join.j) - which the first walk must
+        // not see (its own hit (i, j) is evaluated with j's out-distance as it was): computed here, kept in the state block,
+        // stored by k_nj_glue_join once the first walk has confirmed the candidate.
+        __shared__ int needJ;
+        if (threadIdx.x == 0) needJ = (long long) vft_nj_ld(&A.nOutActive[scanJ]) != nActive;
+        __syncthreads();
+        REAL od = 0;
+        if (needJ) od = vft_nj_out_value<REAL, NC>(A, s, scanJ, sW, sT);
+        if (threadIdx.x == 0) {
+            st->specValid = needJ;
+            st->specOut = od;
+            st->specStamp = (int32_t) nActive;
+            st->logCount = 0;
+        }
+    }
     VFT_NJ_TICK(9);
 }
 
@@ -739,23 +792,75 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_best_pairs(Arena<REAL> A, NjEngin
     }
 }
 
+// Both walks of a hill-climbing round in one launch: workgroups [0, m) are getBestFromTopHits(join.i), [m, 2 m) are
+// getBestFromTopHits(join.j) for the candidate as k_nj_glue_scan left it - speculating that the first walk will not change it
+// (it does in 0.6 % of the joins).  What the second walk may not do before the first one is over is kept apart: join.j's
+// forced out-distance comes from the state block (specOut), and every out-distance the second walk refreshes is logged so that
+// k_nj_glue_join can undo the walk.  One writer per refreshed node (claims): the log then holds consistent (value, stamp)
+// pairs.  Staging: entries [0, m) and [m, 2 m).
+template <typename REAL, int NC>
+__global__ __launch_bounds__(VFT_WG) void k_nj_best_pairs2(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, unsigned int tag) {
+    extern __shared__ __attribute__((aligned(16))) double njLds[];
+    NjState<REAL> *st = E.st;
+    if (st->halt || !st->runRound) return;
+    const int side = (int) blockIdx.x >= T.m ? 1 : 0, t = (int) blockIdx.x - side * T.m;
+    const int64_t node = side ? st->curJ : st->curI;
+    if (t >= T.len[node]) return;
+    const SweepArgs s = vft_nj_args(E, st->nActive, st->totdiam);
+    const ThHit<REAL> h = T.hits[node * T.m + t];
+    const int32_t j = vft_active_ancestor(A.parent, h.j);
+    const int slot = side * T.m + t;
+    if (j < 0 || j == (int32_t) node) {
+        if (threadIdx.x == 0) T.stJ[slot] = -1;
+        return;
+    }
+    ThPairSpec<REAL> spec;
+    spec.ovOut = side && st->specValid ? &st->specOut : nullptr;
+    spec.ovStamp = side && st->specValid ? &st->specStamp : nullptr;
+    spec.claim = E.refClaim;
+    spec.tag = tag;
+    spec.logNode = side ? E.logNode : nullptr;
+    spec.logOut = side ? E.logOut : nullptr;
+    spec.logStamp = side ? E.logStamp : nullptr;
+    spec.logCount = side ? &st->logCount : nullptr;
+    REAL d = h.dist, cr = (REAL) 1e20;
+    vft_th_pair<REAL, NC>(A, s, node, j, j != h.j, njLds, njLds + A.d.nPosPad, d, cr, &spec);
+    if (threadIdx.x == 0) {
+        T.stJ[slot] = j;
+        T.stD[slot] = d;
+        T.stC[slot] = cr;
+    }
+}
+
 // the end of getBestFromTopHits and the comparison of the hill climbing (NJ.tcc:4226-4260): the first strict minimum in list
 // order; "if (best.j != join.<other end> && best.criterion < join.criterion) join = best".  Every thread calls; thread 0 updates
 // the state.  which == 0 opens a round ("changed = false").
 template <typename REAL>
-__device__ __forceinline__ void vft_nj_best_pick(const NjEngine<REAL> &E, const TopHits<REAL> &T, int which, double *redC, int *redT, int *out) {
+__device__ __forceinline__ void vft_nj_best_pick(const NjEngine<REAL> &E, const TopHits<REAL> &T, int which, double *redC, int *redT, int *out,
+                                                 int base = 0, bool dry = false) {
+    // base: where this walk's staging entries start; dry: only report whether the walk would change the candidate (out[0])
     NjState<REAL> *st = E.st;
     const int64_t node = which ? st->curJ : st->curI;
     const int n = T.len[node];
     double bc = 1e20;
     int bt = 0x7FFFFFFF;
-    for (int u = threadIdx.x; u < n; u += blockDim.x) {
-        const int32_t ju = T.stJ[u];
-        const REAL cu = T.stC[u];   // (loaded with the partner, not after it; meaningless where ju < 0)
-        if (ju < 0) continue;
-        if ((bt == 0x7FFFFFFF && cu < (REAL) 1e20) || (bt != 0x7FFFFFFF && (double) cu < bc)) {
-            bc = (double) cu;
-            bt = u;
+    for (int b0 = 0; b0 < n; b0 += VFT_NJ_BATCH * (int) blockDim.x) {   // (the loads of a batch are in flight together)
+        int32_t jb[VFT_NJ_BATCH];
+        REAL cb[VFT_NJ_BATCH];
+#pragma unroll
+        for (int q = 0; q < VFT_NJ_BATCH; q++) {
+            const int u0 = b0 + q * (int) blockDim.x + (int) threadIdx.x;
+            jb[q] = u0 < n ? T.stJ[base + u0] : -1;
+            cb[q] = u0 < n ? T.stC[base + u0] : (REAL) 0;   // (meaningless where the partner is < 0)
+        }
+#pragma unroll
+        for (int q = 0; q < VFT_NJ_BATCH; q++) {   // ascending list positions: the first strict minimum
+            const int u = base + b0 + q * (int) blockDim.x + (int) threadIdx.x;
+            if (jb[q] < 0) continue;
+            if ((bt == 0x7FFFFFFF && cb[q] < (REAL) 1e20) || (bt != 0x7FFFFFFF && (double) cb[q] < bc)) {
+                bc = (double) cb[q];
+                bt = u;
+            }
         }
     }
     vft_nj_arg_reduce<false>(bc, bt, redC, redT);
@@ -769,15 +874,17 @@ __device__ __forceinline__ void vft_nj_best_pick(const NjEngine<REAL> &E, const 
             const int32_t other = which ? ci : cj;
             if (bj != other && bcr < st->curCrit) {
                 changed = 1;
-                ci = (int32_t) node;
-                cj = bj;
-                st->curI = ci;
-                st->curJ = cj;
-                st->curDist = T.stD[b];
-                st->curCrit = bcr;
+                if (!dry) {
+                    ci = (int32_t) node;
+                    cj = bj;
+                    st->curI = ci;
+                    st->curJ = cj;
+                    st->curDist = T.stD[b];
+                    st->curCrit = bcr;
+                }
             }
         }
-        st->changed = changed;
+        if (!dry) st->changed = changed;
         out[0] = changed;   // (to the other threads through LDS: they may hold the state's cache line from the kernel's start)
         out[1] = ci;
         out[2] = cj;
@@ -808,7 +915,7 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_glue_best(Arena<REAL> A, NjEngine
 // setCriterion of topHitJoin would compute.  One workgroup of VFT_WG_PROF threads; dynamic LDS: 4 * nPosPad doubles.
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex,
-                                                              int32_t updateOut, int32_t slot, int32_t lastRound) {
+                                                              int32_t updateOut, int32_t slot, int32_t lastRound, int32_t speculative) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     NjState<REAL> *st = E.st;
     if (st->halt) return;
@@ -820,7 +927,43 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
     __shared__ int picked[3];
     int64_t i = st->curI, j = st->curJ;
     if (!E.fastest && st->runRound) {
-        vft_nj_best_pick<REAL>(E, T, 1, redC, redT, picked);
+        if (speculative) {
+            // k_nj_best_pairs2 walked both lists at once.  Did the first walk leave the candidate alone?
+            vft_nj_best_pick<REAL>(E, T, 0, redC, redT, picked, 0, true);
+            if (picked[0]) {
+                // No: the second walk was for the wrong node.  Every out-distance it refreshed goes back to what it was (the
+                // first walk's refreshes are the reference's own), the candidate stays as the scan left it, and the host enqueues
+                // the round again as two separate walks.
+                const int nLog = st->logCount;
+                for (int k = threadIdx.x; k < nLog; k += blockDim.x) {
+                    const int32_t v = E.logNode[k];
+                    A.outDist[v] = E.logOut[k];
+                    A.nOutActive[v] = E.logStamp[k];
+                    A.mOutDist[v] = E.logOut[k];
+                    A.mNOut[v] = E.logStamp[k];
+                }
+                if (threadIdx.x == 0) {
+                    st->halt = VFT_NJ_HALT_CLIMB;
+                    st->haltJoin = (int32_t) joinIndex;
+                    vft_nj_publish(E, st);
+                }
+                return;
+            }
+            if (threadIdx.x == 0) {   // confirmed: setOutDistance(join.j) as k_nj_glue_scan computed it
+                if (st->specValid) {
+                    const int32_t v = st->curJ;
+                    A.outDist[v] = st->specOut;
+                    A.nOutActive[v] = st->specStamp;
+                    A.mOutDist[v] = st->specOut;
+                    A.mNOut[v] = st->specStamp;
+                }
+                st->changed = 0;
+            }
+            __syncthreads();
+            vft_nj_best_pick<REAL>(E, T, 1, redC, redT, picked, T.m, false);
+        } else {
+            vft_nj_best_pick<REAL>(E, T, 1, redC, redT, picked);
+        }
         i = picked[1];
         j = picked[2];
         if (picked[0]) {

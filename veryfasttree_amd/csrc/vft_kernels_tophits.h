@@ -87,9 +87,24 @@ __device__ __forceinline__ bool vft_th_arrive(unsigned int *doneCtr) {
 // has brought up to date: optionally the distance (recompute), the lazy refresh of j (setCriterion's rule: recomputed when
 // staler than nDiffAllow; several workgroups may refresh the same node - they store identical values, value before stamp),
 // the criterion.  Every thread calls; the results are valid in thread 0.
+// Optional behaviour of vft_th_pair for the speculative double walk of the join engine (k_nj_best_pairs2):
+//   ovOut / ovStamp  the out-distance and stamp of node i to use instead of the arrays' (a forced refresh that is not committed yet);
+//   claim / tag      one writer per refreshed node and launch: the workgroup that wins atomicExch(claim[j], tag) stores the
+//                    refresh, the others compute the same value for themselves and store nothing;
+//   log*             the winner records (node, old out-distance, old stamp) so that the launch can be undone.
+template <typename REAL>
+struct ThPairSpec {
+    const REAL *ovOut;
+    const int32_t *ovStamp;
+    unsigned int *claim;
+    unsigned int tag;
+    int32_t *logNode, *logStamp, *logCount;
+    REAL *logOut;
+};
+
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArgs &s, int64_t i, int64_t j, bool recompute,
-                                            double *sW, double *sT, REAL &d, REAL &crit) {
+                                            double *sW, double *sT, REAL &d, REAL &crit, const ThPairSpec<REAL> *spec = nullptr) {
     __shared__ int thStale;
     // thread 0 issues everything the criterion needs up front: the loads complete while the workgroup computes the distance
     int32_t sj = 0, si = 0;
@@ -97,8 +112,8 @@ __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArg
     if (threadIdx.x == 0) {
         sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        si = A.nOutActive[i];
-        oi = A.outDist[i];
+        si = spec && spec->ovStamp ? *spec->ovStamp : A.nOutActive[i];
+        oi = spec && spec->ovOut ? *spec->ovOut : A.outDist[i];
     }
     if (recompute) {
         REAL w;
@@ -115,17 +130,29 @@ __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArg
         REAL dd, ww;
         vft_pair_block<REAL, NC>(A, j, -1, true, sW, sT, dd, ww);
         if (threadIdx.x == 0) {
+            const REAL oldOut = oj;
+            const int32_t oldStamp = sj;
             oj = vft_out_distance<REAL>(dd, ww, s.nActive, A.selfweight[j], A.selfdist[j], A.diameter[j], s.totdiam);
             sj = (int32_t) s.nActive;
-            // value first, stamp after it has been acknowledged: a reader that sees the new stamp sees the new value
-            __hip_atomic_store(&A.outDist[j], oj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.mOutDist[j] = oj;
-            __threadfence_system();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&A.nOutActive[j], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.mNOut[j] = sj;
-            __threadfence_system();   // the host-mapped mirrors are out before this workgroup counts itself
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // with claims: one writer (whoever gets there first); without: every workgroup that found the node stale stores
+            // the same value - value first, stamp after it has been acknowledged: a reader that sees the new stamp sees the value
+            const bool store = !(spec && spec->claim) || __hip_atomic_exchange(&spec->claim[j], spec->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != spec->tag;
+            if (store) {
+                if (spec && spec->logCount) {   // (oldOut belongs to oldStamp: nobody else writes this node in this launch)
+                    const int k = atomicAdd(spec->logCount, 1);
+                    spec->logNode[k] = (int32_t) j;
+                    spec->logOut[k] = oldOut;
+                    spec->logStamp[k] = oldStamp;
+                }
+                __hip_atomic_store(&A.outDist[j], oj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                A.mOutDist[j] = oj;
+                __threadfence_system();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&A.nOutActive[j], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                A.mNOut[j] = sj;
+                __threadfence_system();   // the host-mapped mirrors are out before this workgroup counts itself
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
     } else if (threadIdx.x == 0 && (int64_t) sj == s.nActive) {
         // a stamp of this very step may have been written a moment ago by another workgroup of this launch (the same
