@@ -151,7 +151,7 @@ struct vft_ctx {
     long long *njStatusHost = nullptr, *njStatusDev = nullptr;
     vft_nj_engine_config njCfg{};
     size_t njScanLds = 0, njTailLds = 0;
-    int njP = 0;
+    int njP = 0, njTailThreads = 0;
     unsigned int *njClaim = nullptr, njClaimTag = 0;   // speculative double walks: one writer per refreshed node
     int32_t *njLogNode = nullptr, *njLogStamp = nullptr;
     void *njLogOut = nullptr;
@@ -2461,11 +2461,14 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     while (P < 2 * cfg->m) P <<= 1;
     c->njP = P;
     c->njScanLds = 0;
-    // k_nj_glue_scan: pair staging | keys | slot criteria | distances by staging index | slot cache | stale list | pass list
-    c->njTailLds = pairLds + (size_t) P * sizeof(ThKey) + (size_t) cfg->n_top * 8 + (size_t) P * rs + (size_t) cfg->n_top * rs +
+    // k_nj_glue_scan: 2 x pair staging | keys | slot criteria | distances by staging index | slot cache | stale list | pass list
+    c->njTailLds = 2 * pairLds + (size_t) P * sizeof(ThKey) + (size_t) cfg->n_top * 8 + (size_t) P * rs + (size_t) cfg->n_top * rs +
                    (size_t) cfg->n_top * 12 + (size_t) (2 * cfg->n_top + 2 * P + 2) * 4 + (size_t) P * 4 + (size_t) P * rs + 64;
     if (c->njTailLds > (160u << 10) - (16u << 10) || 2 * pairLds > (160u << 10) - (16u << 10))
         return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists or alignment too long for the glue kernels' LDS");
+    // a thread of k_nj_glue_scan holds VFT_NJ_BATCH slots of the top-visible list and as many ranks of the merge
+    c->njTailThreads = std::max(cfg->n_top, P) <= VFT_NJ_BATCH * VFT_NJ_TAIL ? VFT_NJ_TAIL : 1024;
+    if (std::max(cfg->n_top, P) > VFT_NJ_BATCH * 1024) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists too long for the glue kernel");
     if (int r = ensure_ml_rows(c)) return r;
     if (!c->pendBase) {
         const CommitPlan plan = commit_plan(c, VFT_PEND_MAX);
@@ -2495,8 +2498,10 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     HIPCHK(c, hipHostGetDevicePointer((void **) &c->njStatusDev, c->njStatusHost, 0));
     memset(c->njStatusHost, 0, 64);
     VFT_DISPATCH(c, {
-        if (c->njTailLds > (48u << 10))
-            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_scan<REAL, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->njTailLds));
+        if (c->njTailLds > (48u << 10)) {
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_scan<REAL, NC, VFT_NJ_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->njTailLds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_glue_scan<REAL, NC, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->njTailLds));
+        }
         if ((size_t) P * sizeof(ThKey) > (48u << 10))
             HIPCHK(c, hipFuncSetAttribute((const void *) k_nj_merge_rank<REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ((size_t) P * sizeof(ThKey))));
         if (2 * pairLds > (48u << 10)) {
@@ -2698,8 +2703,13 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         }
         launch((k_nj_best_pairs2<REAL, NC>), dim3((unsigned) (2 * c->thM)), dim3(VFT_WG), pairLds, c->stream, A, E, T, c->njClaimTag);
     };
+    auto glueScan = [&](long long done, long long next) {
+        if (c->njTailThreads == VFT_NJ_TAIL)
+            launch((k_nj_glue_scan<REAL, NC, VFT_NJ_TAIL>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, done, next, c->njP);
+        else launch((k_nj_glue_scan<REAL, NC, 1024>), dim3(1), dim3(1024), c->njTailLds, c->stream, A, E, T, done, next, c->njP);
+    };
     if (phases & VFT_NJ_PHASE_SEARCH) {
-        launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, -1ll, ji, c->njP);
+        glueScan(-1ll, ji);
         if (!c->njCfg.fastest) roundSpec();
     }
     if (phases & VFT_NJ_PHASE_CLIMB) round();
@@ -2721,9 +2731,9 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         // (the join kernel computes the new node's out-distance itself unless the caller recomputes the out-profile in between)
         if (!updateOut) launch((k_nj_refresh_new<REAL, NC>), dim3(1), dim3(VFT_WG), pairLds, c->stream, A, E);
         launch((k_nj_merge_pairs<REAL, NC>), dim3((unsigned) (2 * c->thM)), dim3(VFT_WG), pairLds, c->stream, A, E, T, ji, c->thTag);
-        launch((k_nj_merge_rank<REAL>), dim3(cdiv(2 * c->thM, VFT_NJ_RANK_PER_WG)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, E, T, ji);
+        launch((k_nj_merge_rank<REAL>), dim3(cdiv(2 * c->thM, VFT_NJ_RANK_PER_WG)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, E, T);
         const bool chain = (phases & VFT_NJ_PHASE_NEXT) != 0;
-        launch((k_nj_glue_scan<REAL, NC>), dim3(1), dim3(VFT_NJ_TAIL), c->njTailLds, c->stream, A, E, T, ji, chain ? ji + 1 : -1ll, c->njP);
+        glueScan(ji, chain ? ji + 1 : -1ll);
         if (chain && !c->njCfg.fastest) roundSpec();
     }
     LAUNCHCHK(c);

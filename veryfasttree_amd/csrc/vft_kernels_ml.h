@@ -16,6 +16,21 @@
 #define VFT_LK_UNDERFLOW_INV 1.0e4           /* Constants.h:14 */
 #define VFT_LOG_LK_UNDERFLOW 9.21034037197618 /* Constants.h:15 */
 
+// tools-only build (-DVFT_ML_TIMING): thread 0 of workgroup 0 of k_ml_quartet accumulates the clock ticks (100 MHz) of its phases
+#ifdef VFT_ML_TIMING
+static __device__ unsigned long long vftMlTicks[16];
+#define VFT_ML_TICK(k)                                                                  \
+    do {                                                                                \
+        if (threadIdx.x == 0) {                                                         \
+            const unsigned long long now_ = wall_clock64();                             \
+            atomicAdd(&vftMlTicks[k], now_ - mlTick_);                                  \
+            mlTick_ = now_;                                                             \
+        }                                                                               \
+    } while (0)
+#else
+#define VFT_ML_TICK(k) do { } while (0)
+#endif
+
 // expEigenRates (NJ.tcc:2020-2038, NDEBUG branch with fastexp level 0) into LDS: out[r*NC + j]
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_exp_eigen_rates(const Arena<REAL> &A, double length, double minRel, REAL *out) {
@@ -909,6 +924,9 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
         rc[c] = p < nPos ? A.ratecat[p] : -1;
     }
     unsigned int nEval = 0;
+#ifdef VFT_ML_TIMING
+    unsigned long long mlTick_ = wall_clock64();
+#endif
     // P(t) tables of one branch length into slot s (callers synchronise); posteriorProfile clamps its lengths
     auto table = [&](int s, double len, bool clamp) {
         if (clamp && len < minLen) len = minLen;
@@ -929,8 +947,10 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
     //  barrier already came after every wave's last table read)
     auto pairTotal = [&](const Col<REAL, NC> *X, const Col<REAL, NC> *Y, double len, double *site, bool lead = true) -> double {
         if (lead) __syncthreads();
+        VFT_ML_TICK(0);   // whatever came before this evaluation
         table(0, len, false);
         __syncthreads();
+        VFT_ML_TICK(1);   // tables
         if (!jc) {   // matrix model: the reference's ordered total
             double col[CPT];
 #pragma unroll
@@ -947,7 +967,10 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
                 }
             }
             nEval++;
-            return vft_lk_total_ordered<WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
+            VFT_ML_TICK(2);   // column likelihoods
+            const double total_ = vft_lk_total_ordered<WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
+            VFT_ML_TICK(3);   // ordered total
+            return total_;
         }
         double lk = 1.0, loglk = 0.0;
 #pragma unroll
@@ -1120,6 +1143,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
                 loadCols(step == 3 ? qc : qd, X);                                   // pair1 = C / D
             }
             __syncthreads();   // the posteriors above are done with the tables
+            VFT_ML_TICK(4);   // a step's tables, loads and posteriors
             auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr, false); };
             const int slot = step == 0 ? 4 : step - 1;
             L[slot] = vft_min_branch_length(negLogLk, minLen, L[slot], VFT_MLOPT_MAXLEN, ftol, atol, negll);
@@ -1163,6 +1187,11 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
         if (sitep) storeSite(t, site);
     }
     if (threadIdx.x != 0) return;
+#ifdef VFT_ML_TIMING
+    VFT_ML_TICK(0);
+    atomicAdd(&vftMlTicks[8], (unsigned long long) nEval);
+    atomicAdd(&vftMlTicks[9], 1ull);
+#endif
     if (evalCount) atomicAdd(evalCount, nEval);
     if (mode == 2) {
         QuartetNNIState &st = nniState[k];

@@ -63,6 +63,8 @@ struct NjState {
     // the speculative double walk (k_nj_best_pairs2): setOutDistance(join.j) computed ahead but not stored yet
     REAL specOut;
     int32_t specStamp, specValid, logCount;
+    // the merge that follows a join (written by k_nj_glue_join): the new node, its children in id order, their lists' lengths
+    int32_t mergeNew, mergeC0, mergeC1, mergeN0, mergeN1;
 };
 
 template <typename REAL>
@@ -222,6 +224,40 @@ __device__ __forceinline__ void vft_nj_arg_reduce(double &c, int &t, double *red
     __syncthreads();
 }
 
+// two first-minimum reductions at once (the two walks of a speculative hill-climbing round): redC / redT hold 2 x waves entries
+__device__ __forceinline__ void vft_nj_arg_reduce2(double &c0, int &t0, double &c1, int &t1, double *redC, int *redT) {
+    constexpr int inv = 0x7FFFFFFF;
+    auto take = [](double &c, int &t, double c2, int t2) {
+        if (t2 != inv && (t == inv || c2 < c || (c2 == c && t2 < t))) {
+            c = c2;
+            t = t2;
+        }
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double a = __shfl_xor(c0, off, 64), b = __shfl_xor(c1, off, 64);
+        const int ta = __shfl_xor(t0, off, 64), tb = __shfl_xor(t1, off, 64);
+        take(c0, t0, a, ta);
+        take(c1, t1, b, tb);
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        redC[2 * wave] = c0;
+        redT[2 * wave] = t0;
+        redC[2 * wave + 1] = c1;
+        redT[2 * wave + 1] = t1;
+    }
+    __syncthreads();
+    c0 = c1 = 0.0;
+    t0 = t1 = inv;
+    for (int w = 0; w < nw; w++) {   // (a handful of waves: every thread folds them in order)
+        take(c0, t0, redC[2 * w], redT[2 * w]);
+        take(c1, t1, redC[2 * w + 1], redT[2 * w + 1]);
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The top-visible list in LDS with everything getVisible computes for its slots, so that updateTopVisible and the scan of the
 // next join run without touching global memory: flags bits 0-1 = 0 empty / dead node, 1 active node without a usable visible
@@ -343,14 +379,20 @@ template <typename REAL, int NC>
 __device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, const NjEngine<REAL> &E, const SweepArgs &s,
                                                           const NjSlots<REAL> &S, int32_t iIn, int32_t hitJ, REAL hitDist, REAL hitCrit,
                                                           int *nRefreshes, double *sW, double *sT, int32_t *staleList, double *redC, int *redT) {
+    // ONE pass over the cached list collects what all three steps ask for - the first slot of step 1, the slot where step 2's scan
+    // stops, step 3's worst slot - and one reduction delivers them (the steps as three passes were eight barriers per call,
+    // 2.6 calls per join); only a refresh inside step 2 (rare) makes step 3 look again.
     __shared__ int first1, stop2;
     if (threadIdx.x == 0) {
         first1 = 0x7FFFFFFF;
         stop2 = 0x7FFFFFFF;
     }
     __syncthreads();
+    int f1 = 0x7FFFFFFF, s2 = 0x7FFFFFFF, wt = -1;
+    double wc = -1e20;
     for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        if (S.node[t] == iIn) {
+        const int32_t node = S.node[t], fl = S.flags[t] & 3;
+        if (node == iIn) {
             // visible[iIn] has just become `hit`: every slot that holds iIn shows it from now on (the list may hold a node more
             // than once: step 1 takes a dead slot in front of the node's own)
             S.vj[t] = hitJ;
@@ -358,10 +400,19 @@ __device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, 
             S.crit[t] = (double) (*nRefreshes == 0 ? hitCrit : vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, s.nActive));
             S.flags[t] = 2;
         }
-        if (S.node[t] == iIn || (S.flags[t] & 3) == 0) atomicMin(&first1, t);
+        if ((node == iIn || fl == 0) && t < f1) f1 = t;
+        if ((fl != 2 || (node == hitJ && S.vj[t] == iIn)) && t < s2) s2 = t;   // (meaningless when some slot holds iIn: step 1 ends the call)
+        // "vis.criterion >= critWorst" in slot order = the largest criterion, the last one among equals
+        const double c = S.crit[t];
+        if (c >= wc) {
+            wc = c;
+            wt = t;
+        }
     }
-    __syncthreads();
-    const int f1 = first1;
+    if (f1 != 0x7FFFFFFF) atomicMin(&first1, f1);
+    if (s2 != 0x7FFFFFFF) atomicMin(&stop2, s2);
+    vft_nj_arg_reduce<true>(wc, wt, redC, redT);   // (its barriers also publish first1 and stop2)
+    const int fFirst = first1;
     auto takeSlot = [&](int t) {   // thread 0: slot t now shows (iIn -> hit.j); its criterion from current out-distances
         S.node[t] = iIn;
         S.vj[t] = hitJ;
@@ -370,20 +421,18 @@ __device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, 
         // (neither end can be staler than allowed: the merge of this join has just evaluated setCriterion on this very pair)
         S.flags[t] = 2;
     };
-    if (f1 != 0x7FFFFFFF) {
-        if (threadIdx.x == 0) takeSlot(f1);   // (a slot that held iIn already shows its new visible hit from now on)
+    if (fFirst != 0x7FFFFFFF) {
+        if (threadIdx.x == 0) takeSlot(fFirst);   // (a slot that held iIn already shows its new visible hit from now on)
         __syncthreads();
         return;
     }
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x)
-        if ((S.flags[t] & 3) != 2 || (S.node[t] == hitJ && S.vj[t] == iIn)) atomicMin(&stop2, t);
-    __syncthreads();
     const int stop = stop2;
     const bool stopOk = stop != 0x7FFFFFFF && (S.flags[stop] & 3) == 2;   // the same pair from the other side
     const int reach = stop == 0x7FFFFFFF ? E.nTop : (stopOk ? stop + 1 : stop);
     // (the final setCriterion(iIn, hit.j), made when the scan did not stop, cannot refresh anything: the merge of this join has
     //  just evaluated setCriterion on this very pair)
-    if (vft_nj_slots_refresh<REAL, NC>(A, E, s, S, reach, -1, -1, staleList, sW, sT)) {
+    const bool refreshed = vft_nj_slots_refresh<REAL, NC>(A, E, s, S, reach, -1, -1, staleList, sW, sT);
+    if (refreshed) {
         if (threadIdx.x == 0) (*nRefreshes)++;
         __syncthreads();
     }
@@ -392,17 +441,18 @@ __device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, 
         __syncthreads();
         return;
     }
-    // the worst slot: "vis.criterion >= critWorst" in slot order = the largest criterion, the last one among equals
-    double wc = -1e20;
-    int wt = -1;
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
-        const double c = S.crit[t];
-        if (c >= wc) {
-            wc = c;
-            wt = t;
+    if (refreshed) {   // the criteria have changed: the worst slot again
+        wc = -1e20;
+        wt = -1;
+        for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
+            const double c = S.crit[t];
+            if (c >= wc) {
+                wc = c;
+                wt = t;
+            }
         }
+        vft_nj_arg_reduce<true>(wc, wt, redC, redT);
     }
-    vft_nj_arg_reduce<true>(wc, wt, redC, redT);
     if (threadIdx.x == 0 && wt >= 0) {
         const REAL b = *nRefreshes == 0 ? hitCrit : vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, s.nActive);
         if ((double) b < wc) takeSlot(wt);
@@ -424,18 +474,29 @@ __device__ __forceinline__ void vft_nj_force_out_distance(const Arena<REAL> &A, 
 // The candidates of a merge (k_nj_merge_pairs' staging arrays) in sortSaveBestHits' order: criterion ascending, ties by
 // descending partner id (NJ.tcc:4535-4578 on a list in ascending partner order).  Sorting 2 m keys inside the
 // single-workgroup glue kernel was the largest part of it (bitonic network: 23 us at 300 000 taxa); ranking by counting is
-// 4 m^2 comparisons that spread over the chip: every workgroup holds all keys in LDS and ranks VFT_NJ_RANK_PER_WG of them, four
-// lanes per key.  T.sorted[r] = staging index of the candidate of rank r, T.sorted[T.cap] = number of candidates.
+// 4 m^2 comparisons that spread over the chip: every workgroup holds all keys in LDS and ranks VFT_NJ_RANK_PER_WG of them,
+// VFT_NJ_RANK_LANES lanes per key.  T.sorted[r] = staging index of the candidate of rank r, T.sorted[T.cap] = number of candidates.
 // Dynamic LDS: P keys.
-#define VFT_NJ_RANK_PER_WG (VFT_WG / 4)
+#define VFT_NJ_RANK_LANES 16
+#define VFT_NJ_RANK_PER_WG (VFT_WG / VFT_NJ_RANK_LANES)
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex) {
+__global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopHits<REAL> T) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
-    if (E.st->halt) return;
+    const NjState<REAL> *st = E.st;
+    const int32_t halt = st->halt;
+    const int n = st->mergeN0 + st->mergeN1;
+    // (all loads of the staging arrays in flight together: the kernel is two memory round trips and some LDS work)
+    int32_t ju[VFT_NJ_BATCH];
+    REAL cu[VFT_NJ_BATCH];
+#pragma unroll
+    for (int q = 0; q < VFT_NJ_BATCH; q++) {
+        const int u = q * (int) blockDim.x + (int) threadIdx.x;
+        ju[q] = u < T.cap ? T.stJ[u] : -1;
+        cu[q] = u < T.cap ? T.stC[u] : (REAL) 0;
+    }
+    if (halt) return;
     ThKey *keys = (ThKey *) njLds;
     __shared__ int nValid;
-    const NjJoinRec rec = E.logDev[joinIndex];
-    const int n = T.len[rec.i] + T.len[rec.j];
     if ((int) (blockIdx.x * VFT_NJ_RANK_PER_WG) >= n) {
         if (blockIdx.x == 0 && threadIdx.x == 0) T.sorted[T.cap] = 0;   // (two empty lists)
         return;
@@ -443,30 +504,29 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     if (threadIdx.x == 0) nValid = 0;
     __syncthreads();
     int mine = 0;
-    for (int base = 0; base < n; base += VFT_NJ_BATCH * (int) blockDim.x) {   // (all loads of a batch in flight together)
-        int32_t ju[VFT_NJ_BATCH];
-        REAL cu[VFT_NJ_BATCH];
 #pragma unroll
-        for (int q = 0; q < VFT_NJ_BATCH; q++) {
-            const int u = base + q * (int) blockDim.x + (int) threadIdx.x;
-            ju[q] = u < n ? T.stJ[u] : -1;
-            cu[q] = u < n ? T.stC[u] : (REAL) 0;
-        }
-#pragma unroll
-        for (int q = 0; q < VFT_NJ_BATCH; q++) {
-            const int u = base + q * (int) blockDim.x + (int) threadIdx.x;
-            if (u >= n) continue;
-            ThKey k;
-            k.key = ju[q] < 0 ? ~0ull : vft_th_order(cu[q]);
-            k.nj = ju[q] < 0 ? ~0u : ~(uint32_t) ju[q];
-            k.src = ju[q] < 0 ? -1 : u;
-            keys[u] = k;
-            mine += ju[q] >= 0;
-        }
+    for (int q = 0; q < VFT_NJ_BATCH; q++) {
+        const int u = q * (int) blockDim.x + (int) threadIdx.x;
+        if (u >= n) continue;
+        ThKey k;
+        k.key = ju[q] < 0 ? ~0ull : vft_th_order(cu[q]);
+        k.nj = ju[q] < 0 ? ~0u : ~(uint32_t) ju[q];
+        k.src = ju[q] < 0 ? -1 : u;
+        keys[u] = k;
+        mine += ju[q] >= 0;
+    }
+    for (int u = VFT_NJ_BATCH * (int) blockDim.x + (int) threadIdx.x; u < n; u += blockDim.x) {   // (lists beyond 2 048 candidates)
+        const int32_t j = T.stJ[u];
+        ThKey k;
+        k.key = j < 0 ? ~0ull : vft_th_order(T.stC[u]);
+        k.nj = j < 0 ? ~0u : ~(uint32_t) j;
+        k.src = j < 0 ? -1 : u;
+        keys[u] = k;
+        mine += j >= 0;
     }
     if (mine) atomicAdd(&nValid, mine);
     __syncthreads();
-    const int e = (int) (blockIdx.x * VFT_NJ_RANK_PER_WG) + (int) (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const int e = (int) (blockIdx.x * VFT_NJ_RANK_PER_WG) + (int) (threadIdx.x / VFT_NJ_RANK_LANES), part = threadIdx.x % VFT_NJ_RANK_LANES;
     int rank = 0;
     ThKey ke;
     ke.key = ~0ull;
@@ -475,19 +535,69 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     if (e < n) ke = keys[e];
     if (ke.src >= 0) {
         int u = part;
-        for (; u + 28 < n; u += 32) {   // eight keys of this lane's quarter per trip: the LDS reads go out together
+        for (; u + 7 * VFT_NJ_RANK_LANES < n; u += 8 * VFT_NJ_RANK_LANES) {   // eight keys of this lane's share per trip: the LDS reads go out together
             ThKey kk[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) kk[q] = keys[u + 4 * q];
+            for (int q = 0; q < 8; q++) kk[q] = keys[u + VFT_NJ_RANK_LANES * q];
 #pragma unroll
             for (int q = 0; q < 8; q++) rank += vft_th_before(kk[q], ke) ? 1 : 0;
         }
-        for (; u < n; u += 4) rank += vft_th_before(keys[u], ke) ? 1 : 0;
+        for (; u < n; u += VFT_NJ_RANK_LANES) rank += vft_th_before(keys[u], ke) ? 1 : 0;
     }
-    rank += __shfl_xor(rank, 1, 64);
-    rank += __shfl_xor(rank, 2, 64);
+#pragma unroll
+    for (int off = 1; off < VFT_NJ_RANK_LANES; off <<= 1) rank += __shfl_xor(rank, off, 64);
     if (part == 0 && ke.src >= 0) T.sorted[rank] = e;
     if (blockIdx.x == 0 && threadIdx.x == 0) T.sorted[T.cap] = nValid;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// setOutDistance's value for two nodes at once (either may be skipped): the columns of both against the out-profile are loaded
+// together and four threads add the four column-ordered chains (vft_pair_block twice costs two rounds of dependent loads).
+// Every thread calls; thread 0 gets the values.  LDS: sW / sT for v0, sW2 / sT2 for v1 (nPos doubles each).
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_nj_out_values2(const Arena<REAL> &A, const SweepArgs &s, int64_t v0, bool need0, int64_t v1, bool need1,
+                                                   double *sW, double *sT, double *sW2, double *sT2, REAL &od0, REAL &od1) {
+    __shared__ double res2[4];
+    od0 = od1 = 0;
+    if (!need0 && !need1) return;   // (uniform)
+    const int64_t nPos = A.d.nPos;
+    const bool row0 = need0 && vft_is_row<REAL>(A, v0), row1 = need1 && vft_is_row<REAL>(A, v1);
+    for (int64_t p = threadIdx.x; p < nPos; p += blockDim.x) {
+        Col<REAL, NC> a1, a2, b1, b2;
+        if (need0) vft_pair_load<REAL, NC>(A, v0, -1, true, p, a1, a2, row0, false);
+        if (need1) vft_pair_load<REAL, NC>(A, v1, -1, true, p, b1, b2, row1, false);
+        if (need0) vft_pair_addends<REAL, NC>(A, false, true, p, a1, a2, sW, sT);
+        if (need1) vft_pair_addends<REAL, NC>(A, false, true, p, b1, b2, sW2, sT2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && (threadIdx.x < 2 ? need0 : need1)) {   // top and denom of v0, top and denom of v1: each in column order
+        const double *src = threadIdx.x == 0 ? sT : threadIdx.x == 1 ? sW : threadIdx.x == 2 ? sT2 : sW2;
+        double acc = 0;
+        int64_t p = 0;
+        for (; p + 8 <= nPos; p += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[p + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; p < nPos; p++) acc += src[p];
+        res2[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (need0) {
+            const double top = res2[0], denom = res2[1];
+            const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
+            od0 = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v0], A.selfdist[v0], A.diameter[v0], s.totdiam);
+        }
+        if (need1) {
+            const double top = res2[2], denom = res2[3];
+            const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
+            od1 = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v1], A.selfdist[v1], A.diameter[v1], s.totdiam);
+        }
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -495,16 +605,21 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
 // sortSaveBestHits, the new node's visible hit, updateTopVisible for it, updateVisible over the saved hits] + [topHitNJSearch
 // of join `nextJoin` (>= 0) up to the hill climbing, NJ.tcc:4137-4223: the lazy refreshes of the scan, the best visible hit,
 // the reset test; then setOutDistance of the candidate's first end (both ends with -fastest, which does not climb)].
-// One workgroup of VFT_NJ_TAIL threads.  Dynamic LDS: pair staging | ThKey[P] | REAL[P] | slot cache (3 int32 + REAL +
-// double per slot) | int32[2 nTop + 2 P + 2] stale list | int32[P] pass list.
-template <typename REAL, int NC>
-__global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long doneJoin,
-                                                              long long nextJoin, int P) {
+// One workgroup of THREADS threads; a single-workgroup kernel is a chain of dependent memory round trips (2-3 us each at a
+// million sequences, where the node arrays do not fit the L2), so everything the kernel will want is loaded in FOUR rounds up
+// front: (0) state, the join's record, the top-visible list, the ranks; (1) what hangs on a slot's node, the candidates behind
+// the ranks, the children's ages; (2) what hangs on a slot's partner, getVisible of the hits that will be saved; (3) their
+// partners.  A thread holds VFT_NJ_BATCH slots and ranks: nTop, P <= VFT_NJ_BATCH * THREADS (the host picks THREADS).
+// Dynamic LDS: 2 x pair staging | ThKey[P] | REAL[P] | slot cache (3 int32 + REAL + double per slot) | int32[2 nTop + 2 P + 2]
+// stale list | int32[P] pass list.
+template <typename REAL, int NC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long doneJoin,
+                                                          long long nextJoin, int P) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
+    constexpr int B = VFT_NJ_BATCH, TB = VFT_NJ_BATCH / 2;   // (saved hits: at most m <= P / 2 ranks)
     NjState<REAL> *st = E.st;
-    if (st->halt) return;
-    double *sW = njLds, *sT = njLds + A.d.nPosPad;
-    ThKey *keys = (ThKey *) (njLds + 2 * A.d.nPosPad);
+    double *sW = njLds, *sT = njLds + A.d.nPosPad, *sW2 = njLds + 2 * A.d.nPosPad, *sT2 = njLds + 3 * A.d.nPosPad;
+    ThKey *keys = (ThKey *) (njLds + 4 * A.d.nPosPad);
     double *critS = (double *) (keys + P);
     REAL *distL = (REAL *) (critS + E.nTop), *critL = distL + P;   // by rank: distance and criterion of the sorted candidates
     NjSlots<REAL> S;
@@ -517,65 +632,154 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
     int32_t *passList = staleList + 2 * E.nTop + 2 * P + 2;
     __shared__ int thCount, nPass, nRefreshes, nCand, slotsStale;
     S.anyStale = &slotsStale;
-    __shared__ double redC[VFT_NJ_TAIL];
-    __shared__ int redT[VFT_NJ_TAIL];
+    __shared__ double redC[THREADS];
+    __shared__ int redT[THREADS];
+    const int tid = (int) threadIdx.x;
+    const bool merge = doneJoin >= 0;
+    // ---- round 0
+    const int32_t halt = st->halt;
     const long long nActive = st->nActive;
-    const SweepArgs s = vft_nj_args(E, nActive, st->totdiam);
+    const double totdiam = st->totdiam;
+    const int32_t tvAge0 = st->tvAge;
+    NjJoinRec rec{};
+    int nU = 0;
+    if (merge) {
+        rec = E.logDev[doneJoin];
+        nU = T.sorted[T.cap];
+    }
+    int32_t sNode[B];
+    int rSrc[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        const int t = k * THREADS + tid;
+        sNode[k] = t < E.nTop ? E.topvis[t] : -1;
+        rSrc[k] = merge && t < T.cap ? T.sorted[t] : -1;   // (ranks beyond the number of candidates hold older entries: unused)
+    }
+    if (halt) return;
+    const SweepArgs s = vft_nj_args(E, nActive, totdiam);
 #ifdef VFT_NJ_TIMING
     unsigned long long tick_ = wall_clock64();
 #endif
-    if (threadIdx.x == 0) thCount = nPass = nRefreshes = nCand = 0;
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) S.node[t] = E.topvis[t];
+    if (tid == 0) thCount = nPass = nRefreshes = nCand = slotsStale = 0;
+    const int32_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
+    const int nSave = nU < E.m ? nU : E.m;
+    // ---- round 1
+    int32_t sPn[B], sVj[B], sSi[B], rJ[B], ageA = 0, ageB = 0;
+    REAL sD[B], sOi[B], rD[B], rC[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        sPn[k] = 0;
+        sVj[k] = -1;
+        sSi[k] = 0;
+        sD[k] = sOi[k] = 0;
+        if (sNode[k] >= 0) {
+            sPn[k] = A.parent[sNode[k]];
+            sVj[k] = vft_nj_ld(&E.visJ[sNode[k]]);
+            sD[k] = vft_nj_ld(&E.visD[sNode[k]]);
+            sOi[k] = vft_nj_ld(&A.outDist[sNode[k]]);
+            sSi[k] = vft_nj_ld(&A.nOutActive[sNode[k]]);
+        }
+        const int r = k * THREADS + tid;
+        rJ[k] = -1;
+        rD[k] = rC[k] = 0;
+        if (r < nU) {
+            rJ[k] = T.stJ[rSrc[k]];
+            rD[k] = T.stD[rSrc[k]];
+            rC[k] = T.stC[rSrc[k]];
+        }
+    }
+    if (merge) {
+        ageA = E.age[c0];
+        ageB = E.age[c1];
+    }
+    // ---- round 2
+    int32_t sPj[B], sSj[B], tVj[TB], tSi[TB];
+    REAL sOj[B], tVd[TB], tOi[TB];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        sPj[k] = 0;
+        sSj[k] = 0;
+        sOj[k] = 0;
+        if (sNode[k] >= 0 && sPn[k] < 0 && sVj[k] >= 0) {
+            sPj[k] = A.parent[sVj[k]];
+            sOj[k] = vft_nj_ld(&A.outDist[sVj[k]]);
+            sSj[k] = vft_nj_ld(&A.nOutActive[sVj[k]]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TB; k++) {
+        const int r = k * THREADS + tid;
+        tVj[k] = -1;
+        tSi[k] = 0;
+        tVd[k] = tOi[k] = 0;
+        if (r < nSave) {
+            tVj[k] = vft_nj_ld(&E.visJ[rJ[k]]);
+            tVd[k] = vft_nj_ld(&E.visD[rJ[k]]);
+            tOi[k] = vft_nj_ld(&A.outDist[rJ[k]]);
+            tSi[k] = vft_nj_ld(&A.nOutActive[rJ[k]]);
+        }
+    }
+    // ---- round 3
+    int32_t tPj[TB], tSj[TB];
+    REAL tOj[TB];
+#pragma unroll
+    for (int k = 0; k < TB; k++) {
+        tPj[k] = 0;
+        tSj[k] = 0;
+        tOj[k] = 0;
+        if (tVj[k] >= 0) {
+            tPj[k] = A.parent[tVj[k]];
+            tOj[k] = vft_nj_ld(&A.outDist[tVj[k]]);
+            tSj[k] = vft_nj_ld(&A.nOutActive[tVj[k]]);
+        }
+    }
+    // ---- the slot cache (as vft_nj_slots_load leaves it) and the candidates by rank, into LDS
     __syncthreads();
-    vft_nj_slots_load(A, E, s, S);
-    VFT_NJ_TICK(0);
-    if (doneJoin >= 0) {
-        const NjJoinRec rec = E.logDev[doneJoin];
-        const int32_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
-        const int n = T.len[c0] + T.len[c1];
-        (void) n;
-        // the candidates in sorted order (k_nj_merge_rank): rank r -> staging index -> (partner, distance, criterion)
-        const int nU = T.sorted[T.cap];
-        for (int base = 0; base < nU; base += VFT_NJ_BATCH * (int) blockDim.x) {
-            int src[VFT_NJ_BATCH];
 #pragma unroll
-            for (int k = 0; k < VFT_NJ_BATCH; k++) {
-                const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
-                src[k] = r < nU ? T.sorted[r] : -1;
-            }
-            int32_t jj[VFT_NJ_BATCH];
-            REAL dd[VFT_NJ_BATCH], cc[VFT_NJ_BATCH];
-#pragma unroll
-            for (int k = 0; k < VFT_NJ_BATCH; k++) {
-                jj[k] = 0;
-                dd[k] = cc[k] = 0;
-                if (src[k] >= 0) {
-                    jj[k] = T.stJ[src[k]];
-                    dd[k] = T.stD[src[k]];
-                    cc[k] = T.stC[src[k]];
+    for (int k = 0; k < B; k++) {
+        const int t = k * THREADS + tid;
+        if (t < E.nTop) {
+            int32_t f = 0, v = -1;
+            REAL d = 0;
+            double cr = 0;
+            if (sNode[k] >= 0 && sPn[k] < 0) {
+                v = sVj[k];
+                f = 1;
+                if (v >= 0 && sPj[k] < 0) {
+                    f = 2;
+                    d = sD[k];
+                    cr = (double) vft_criterion<REAL>(d, sOi[k], sSi[k], sOj[k], sSj[k], nActive);
+                    if ((long long) sSi[k] - nActive > s.nDiffAllow) f |= 4;
+                    if ((long long) sSj[k] - nActive > s.nDiffAllow) f |= 8;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < VFT_NJ_BATCH; k++) {
-                const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
-                if (r >= nU) continue;
-                ThKey kk;
-                kk.key = 0;
-                kk.nj = ~(uint32_t) jj[k];
-                kk.src = r;
-                keys[r] = kk;
-                distL[r] = dd[k];
-                critL[r] = cc[k];
-            }
+            S.node[t] = sNode[k];
+            S.vj[t] = v;
+            S.flags[t] = f;
+            S.dist[t] = d;
+            S.crit[t] = cr;
+            if (f & 12) slotsStale = 1;   // (benign race: every writer stores 1)
         }
-        __syncthreads();
+        if (t < nU) {
+            ThKey kk;
+            kk.key = 0;
+            kk.nj = ~(uint32_t) rJ[k];
+            kk.src = t;
+            keys[t] = kk;
+            distL[t] = rD[k];
+            critL[t] = rC[k];
+        }
+    }
+    __syncthreads();
+    VFT_NJ_TICK(0);
+    if (merge) {
         VFT_NJ_TICK(1);
         VFT_NJ_TICK(2);
         // NJ.tcc:4342-4362
-        const int32_t ageNew = (E.age[c0] + E.age[c1] + 1) / 2 + 1;
+        const int32_t ageNew = (ageA + ageB + 1) / 2 + 1;
         const bool useUnique = (long long) nU == nActive - 1 || (ageNew <= E.ageLimit && nU >= E.need);
         if (!useUnique) {
-            if (threadIdx.x == 0) {
+            if (tid == 0) {
                 E.age[newnode] = ageNew;
                 st->nUnique = nU;
                 st->joinsDone = doneJoin + 1;
@@ -585,16 +789,19 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             }
             return;
         }
-        const int nSave = nU < E.m ? nU : E.m;
-        for (int r = threadIdx.x; r < nSave; r += blockDim.x) {
-            ThHit<REAL> e;
-            e.j = (int32_t) ~keys[r].nj;
-            e.dist = distL[r];
-            T.hits[(int64_t) newnode * T.m + r] = e;
+#pragma unroll
+        for (int k = 0; k < TB; k++) {
+            const int r = k * THREADS + tid;
+            if (r < nSave) {
+                ThHit<REAL> e;
+                e.j = rJ[k];
+                e.dist = rD[k];
+                T.hits[(int64_t) newnode * T.m + r] = e;
+            }
         }
         const int32_t firstJ = (int32_t) ~keys[0].nj;
         const REAL firstD = distL[0], firstC = critL[0];
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             E.age[newnode] = ageNew;
             T.len[newnode] = nSave;
             E.visJ[newnode] = firstJ;            // visible[newnode] = hits[newnode][0]
@@ -608,18 +815,40 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
         // hit, which only iteration t changes: the lazy refreshes of all of them first, then all tests, then the few hits that
         // pass update visible[] and the top-visible list one after the other.
         {
-            // one pass in the common case: getVisible of every hit's partner (its visible hit, both out-distances) and the test;
-            // only when one of those out-distances is staler than allowed (rare) are they refreshed and the pass repeated
+            // one pass in the common case: getVisible of every hit's partner (its visible hit, both out-distances) and the test -
+            // on what rounds 2 and 3 loaded unless something has been refreshed since; only when one of those out-distances is
+            // staler than allowed (rare) are they refreshed and the pass repeated
             __shared__ int nStaleV;
+            // the hit's criterion as updateVisible sees it: the merge's (hits are not re-evaluated, NJ.tcc:4640-4650)
+            auto test = [&](int r, int32_t node, int32_t vj, REAL vd, REAL oi, int32_t si, int32_t pj, REAL oj, int32_t sj, bool collect) {
+                bool pass = true;
+                if (vj >= 0 && pj < 0) {   // (node itself is active: it is a candidate of this merge)
+                    const bool staleI = (long long) si - nActive > s.nDiffAllow, staleJ = (long long) sj - nActive > s.nDiffAllow;
+                    if (collect) {
+                        if (staleI) staleList[atomicAdd(&nStaleV, 1)] = node;
+                        if (staleJ) staleList[atomicAdd(&nStaleV, 1)] = vj;
+                    }
+                    pass = critL[r] < vft_criterion<REAL>(vd, oi, si, oj, sj, nActive);
+                }
+                if (pass) passList[atomicAdd(&nPass, 1)] = r;
+            };
+            const bool preloaded = nRefreshes == 0;   // (uniform: written before the last barrier)
             for (int attempt = 0; attempt < 2; attempt++) {
-                if (threadIdx.x == 0) nStaleV = nPass = 0;
                 __syncthreads();
-                for (int base = 0; base < nSave; base += VFT_NJ_BATCH * (int) blockDim.x) {
-                    int32_t node[VFT_NJ_BATCH], vj[VFT_NJ_BATCH], si[VFT_NJ_BATCH], pj[VFT_NJ_BATCH], sj[VFT_NJ_BATCH];
-                    REAL vd[VFT_NJ_BATCH], oi[VFT_NJ_BATCH], oj[VFT_NJ_BATCH];
+                if (tid == 0) nStaleV = nPass = 0;
+                __syncthreads();
+                if (attempt == 0 && preloaded) {
 #pragma unroll
-                    for (int k = 0; k < VFT_NJ_BATCH; k++) {
-                        const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
+                    for (int k = 0; k < TB; k++) {
+                        const int r = k * THREADS + tid;
+                        if (r < nSave) test(r, rJ[k], tVj[k], tVd[k], tOi[k], tSi[k], tPj[k], tOj[k], tSj[k], true);
+                    }
+                } else {
+                    int32_t node[TB], vj[TB], si[TB], pj[TB], sj[TB];
+                    REAL vd[TB], oi[TB], oj[TB];
+#pragma unroll
+                    for (int k = 0; k < TB; k++) {
+                        const int r = k * THREADS + tid;
                         node[k] = r < nSave ? (int32_t) ~keys[r].nj : -1;
                         vj[k] = -1;
                         si[k] = 0;
@@ -632,7 +861,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < VFT_NJ_BATCH; k++) {
+                    for (int k = 0; k < TB; k++) {
                         pj[k] = 0;
                         sj[k] = 0;
                         oj[k] = 0;
@@ -643,36 +872,24 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < VFT_NJ_BATCH; k++) {
-                        const int r = base + k * (int) blockDim.x + (int) threadIdx.x;
-                        if (r >= nSave) continue;
-                        // the hit's criterion as updateVisible sees it: the merge's (hits are not re-evaluated, NJ.tcc:4640-4650)
-                        const REAL hitCrit = critL[r];
-                        bool pass = true;
-                        if (vj[k] >= 0 && pj[k] < 0) {   // (node itself is active: it is a candidate of this merge)
-                            const bool staleI = (long long) si[k] - nActive > s.nDiffAllow, staleJ = (long long) sj[k] - nActive > s.nDiffAllow;
-                            if (attempt == 0) {
-                                if (staleI) staleList[atomicAdd(&nStaleV, 1)] = node[k];
-                                if (staleJ) staleList[atomicAdd(&nStaleV, 1)] = vj[k];
-                            }
-                            pass = hitCrit < vft_criterion<REAL>(vd[k], oi[k], si[k], oj[k], sj[k], nActive);
-                        }
-                        if (pass) passList[atomicAdd(&nPass, 1)] = r;
+                    for (int k = 0; k < TB; k++) {
+                        const int r = k * THREADS + tid;
+                        if (r < nSave) test(r, node[k], vj[k], vd[k], oi[k], si[k], pj[k], oj[k], sj[k], attempt == 0);
                     }
                 }
                 __syncthreads();
-                if (nStaleV == 0) break;   // (uniform)
+                if (attempt == 1 || nStaleV == 0) break;   // (uniform)
                 vft_nj_refresh_listed<REAL, NC>(A, s, staleList, nStaleV, sW, sT);
                 __syncthreads();
                 vft_nj_slots_load(A, E, s, S);
-                if (threadIdx.x == 0) nRefreshes++;
+                if (tid == 0) nRefreshes++;
                 __syncthreads();
             }
         }
         __syncthreads();
         VFT_NJ_TICK(5);
         const int np = nPass;
-        if (threadIdx.x == 0)   // (in list order: a selection sort over the few entries)
+        if (tid == 0)   // (in list order: a selection sort over the few entries)
             for (int a = 0; a < np; a++)
                 for (int b = a + 1; b < np; b++)
                     if (passList[b] < passList[a]) {
@@ -685,7 +902,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             const int r = passList[a];
             const int32_t node = (int32_t) ~keys[r].nj;
             const REAL d = distL[r], cr = critL[r];
-            if (threadIdx.x == 0) {
+            if (tid == 0) {
                 E.visJ[node] = newnode;
                 E.visD[node] = d;
             }
@@ -693,8 +910,8 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             vft_nj_update_top_visible<REAL, NC>(A, E, s, S, node, newnode, d, cr, &nRefreshes, sW, sT, staleList, redC, redT);
         }
         VFT_NJ_TICK(6);
-        for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) E.topvis[t] = S.node[t];
-        if (threadIdx.x == 0) {
+        for (int t = tid; t < E.nTop; t += THREADS) E.topvis[t] = S.node[t];
+        if (tid == 0) {
             st->nUnique = nU;
             st->joinsDone = doneJoin + 1;
             if (nextJoin < 0) vft_nj_publish(E, st);
@@ -707,7 +924,7 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
     vft_nj_slots_refresh<REAL, NC>(A, E, s, S, E.nTop, -1, -1, staleList, sW, sT);
     double bc = 0;
     int bt = 0x7FFFFFFF, mine = 0;
-    for (int t = threadIdx.x; t < E.nTop; t += blockDim.x) {
+    for (int t = tid; t < E.nTop; t += THREADS) {
         if ((S.flags[t] & 3) != 2) continue;
         mine++;
         const double c = S.crit[t];
@@ -718,9 +935,10 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
     }
     if (mine) atomicAdd(&nCand, mine);
     vft_nj_arg_reduce<false>(bc, bt, redC, redT);
-    __shared__ int scanHalt, scanI, scanJ;
-    if (threadIdx.x == 0) {
-        const int age = ++st->tvAge;
+    __shared__ int scanHalt, scanI, scanJ, needI, needJ;
+    if (tid == 0) {
+        const int age = tvAge0 + 1;
+        st->tvAge = age;
         const long long cand = nCand;
         scanHalt = 0;
         scanI = scanJ = -1;
@@ -736,29 +954,39 @@ __global__ __launch_bounds__(VFT_NJ_TAIL) void k_nj_glue_scan(Arena<REAL> A, NjE
             st->curCrit = (REAL) S.crit[b];
             st->changed = 0;
             st->runRound = 1;
+            needI = (long long) vft_nj_ld(&A.nOutActive[scanI]) != nActive;
+            needJ = (long long) vft_nj_ld(&A.nOutActive[scanJ]) != nActive;
         }
         vft_nj_publish(E, st);
     }
     __syncthreads();
     VFT_NJ_TICK(8);
     if (scanHalt) return;
-    // getBestFromTopHits' setOutDistance(join.i) (NJ.tcc:4273-4279); with -fastest the two ends before the join (:2897-2898)
-    vft_nj_force_out_distance<REAL, NC>(A, s, scanI, sW, sT);
-    if (E.fastest) {
-        vft_nj_force_out_distance<REAL, NC>(A, s, scanJ, sW, sT);
-    } else {
-        // The hill climbing walks both ends' lists in ONE launch (k_nj_best_pairs2), i.e. the second walk starts before the
-        // first one has had its say.  The reference's second walk begins with setOutDistance(join.j) - which the first walk must
-        // not see (its own hit (i, j) is evaluated with j's out-distance as it was): computed here, kept in the state block,
-        // stored by k_nj_glue_join once the first walk has confirmed the candidate.
-        __shared__ int needJ;
-        if (threadIdx.x == 0) needJ = (long long) vft_nj_ld(&A.nOutActive[scanJ]) != nActive;
-        __syncthreads();
-        REAL od = 0;
-        if (needJ) od = vft_nj_out_value<REAL, NC>(A, s, scanJ, sW, sT);
-        if (threadIdx.x == 0) {
+    // getBestFromTopHits' setOutDistance(join.i) (NJ.tcc:4273-4279); with -fastest the two ends before the join (:2897-2898).
+    // Without -fastest the hill climbing walks both ends' lists in ONE launch (k_nj_best_pairs2), i.e. the second walk starts
+    // before the first one has had its say.  The reference's second walk begins with setOutDistance(join.j) - which the first
+    // walk must not see (its own hit (i, j) is evaluated with j's out-distance as it was): computed here, kept in the state
+    // block, stored by k_nj_glue_join once the first walk has confirmed the candidate.
+    REAL odI, odJ;
+    const int64_t vI = scanI, vJ = scanJ;
+    vft_nj_out_values2<REAL, NC>(A, s, vI, needI != 0, vJ, needJ != 0, sW, sT, sW2, sT2, odI, odJ);
+    if (tid == 0) {
+        if (needI) {
+            A.outDist[vI] = odI;
+            A.nOutActive[vI] = (int32_t) nActive;
+            A.mOutDist[vI] = odI;
+            A.mNOut[vI] = (int32_t) nActive;
+        }
+        if (E.fastest) {
+            if (needJ) {
+                A.outDist[vJ] = odJ;
+                A.nOutActive[vJ] = (int32_t) nActive;
+                A.mOutDist[vJ] = odJ;
+                A.mNOut[vJ] = (int32_t) nActive;
+            }
+        } else {
             st->specValid = needJ;
-            st->specOut = od;
+            st->specOut = odJ;
             st->specStamp = (int32_t) nActive;
             st->logCount = 0;
         }
@@ -918,23 +1146,105 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
                                                               int32_t updateOut, int32_t slot, int32_t lastRound, int32_t speculative) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     NjState<REAL> *st = E.st;
-    if (st->halt) return;
+    // (the state block in one round of loads)
+    const int32_t halt = st->halt, runRound = st->runRound;
+    const long long nActive = st->nActive;
+    const double totdiam0 = st->totdiam;
+    const int64_t newn = st->maxnode;
+    const REAL curDist0 = st->curDist;
+    int64_t i = st->curI, j = st->curJ;
+    if (halt) return;
     __shared__ double redC[VFT_WG_PROF];
     __shared__ int redT[VFT_WG_PROF];
     __shared__ REAL sDiam;
-    const long long nActive = st->nActive;
-    const SweepArgs s = vft_nj_args(E, nActive, st->totdiam);
+    const SweepArgs s = vft_nj_args(E, nActive, totdiam0);
     __shared__ int picked[3];
-    int64_t i = st->curI, j = st->curJ;
-    if (!E.fastest && st->runRound) {
+    if (!E.fastest && runRound) {
+        bool roundChanged;
         if (speculative) {
-            // k_nj_best_pairs2 walked both lists at once.  Did the first walk leave the candidate alone?
-            vft_nj_best_pick<REAL>(E, T, 0, redC, redT, picked, 0, true);
-            if (picked[0]) {
-                // No: the second walk was for the wrong node.  Every out-distance it refreshed goes back to what it was (the
-                // first walk's refreshes are the reference's own), the candidate stays as the scan left it, and the host enqueues
-                // the round again as two separate walks.
-                const int nLog = st->logCount;
+            // k_nj_best_pairs2 walked both lists at once: both walks' first minima in one pass over the staging arrays (loads of
+            // both sides in flight together, one reduction for the two), then thread 0 takes the reference's decisions in the
+            // reference's order: did the first walk leave the candidate alone?  If so, does the second?
+            __shared__ int pickLen[2], pickBest[2];
+            if (threadIdx.x < 2) pickLen[threadIdx.x] = T.len[threadIdx.x ? j : i];
+            __syncthreads();
+            const int n0 = pickLen[0], n1 = pickLen[1];
+            double bc0 = 1e20, bc1 = 1e20;
+            int bt0 = 0x7FFFFFFF, bt1 = 0x7FFFFFFF;
+            for (int b0 = 0; b0 < (n0 > n1 ? n0 : n1); b0 += (VFT_NJ_BATCH / 2) * (int) blockDim.x) {
+                int32_t ja[VFT_NJ_BATCH / 2], jb[VFT_NJ_BATCH / 2];
+                REAL ca[VFT_NJ_BATCH / 2], cb[VFT_NJ_BATCH / 2];
+#pragma unroll
+                for (int q = 0; q < VFT_NJ_BATCH / 2; q++) {
+                    const int u = b0 + q * (int) blockDim.x + (int) threadIdx.x;
+                    ja[q] = u < n0 ? T.stJ[u] : -1;
+                    ca[q] = u < n0 ? T.stC[u] : (REAL) 0;
+                    jb[q] = u < n1 ? T.stJ[T.m + u] : -1;
+                    cb[q] = u < n1 ? T.stC[T.m + u] : (REAL) 0;
+                }
+#pragma unroll
+                for (int q = 0; q < VFT_NJ_BATCH / 2; q++) {   // ascending list positions: the first strict minimum of each walk
+                    const int u = b0 + q * (int) blockDim.x + (int) threadIdx.x;
+                    if (ja[q] >= 0 && ((bt0 == 0x7FFFFFFF && ca[q] < (REAL) 1e20) || (bt0 != 0x7FFFFFFF && (double) ca[q] < bc0))) {
+                        bc0 = (double) ca[q];
+                        bt0 = u;
+                    }
+                    if (jb[q] >= 0 && ((bt1 == 0x7FFFFFFF && cb[q] < (REAL) 1e20) || (bt1 != 0x7FFFFFFF && (double) cb[q] < bc1))) {
+                        bc1 = (double) cb[q];
+                        bt1 = T.m + u;
+                    }
+                }
+            }
+            vft_nj_arg_reduce2(bc0, bt0, bc1, bt1, redC, redT);
+            if (threadIdx.x == 0) {
+                const REAL curCrit = st->curCrit;
+                // (everything thread 0 may need, asked for together)
+                int32_t bj0 = -1, bj1 = -1;
+                REAL cr0 = 0, cr1 = 0, d1 = 0;
+                if (bt0 != 0x7FFFFFFF) {
+                    bj0 = T.stJ[bt0];
+                    cr0 = T.stC[bt0];
+                }
+                if (bt1 != 0x7FFFFFFF) {
+                    bj1 = T.stJ[bt1];
+                    cr1 = T.stC[bt1];
+                    d1 = T.stD[bt1];
+                }
+                const int32_t specValid = st->specValid, specStamp = st->specStamp, nLog = st->logCount;
+                const REAL specOut = st->specOut;
+                int verdict = 0;   // 0 join, 1 the first walk changed the candidate (undo the second), 2 the second walk changed it
+                if (bt0 != 0x7FFFFFFF && bj0 != (int32_t) j && cr0 < curCrit) {
+                    verdict = 1;
+                } else {
+                    if (specValid) {   // confirmed: setOutDistance(join.j) as k_nj_glue_scan computed it
+                        A.outDist[j] = specOut;
+                        A.nOutActive[j] = specStamp;
+                        A.mOutDist[j] = specOut;
+                        A.mNOut[j] = specStamp;
+                    }
+                    int changed = 0;
+                    if (bt1 != 0x7FFFFFFF && bj1 != (int32_t) i && cr1 < curCrit) {
+                        changed = 1;
+                        verdict = 2;
+                        st->curI = (int32_t) j;
+                        st->curJ = bj1;
+                        st->curDist = d1;
+                        st->curCrit = cr1;
+                        picked[1] = (int32_t) j;
+                        picked[2] = bj1;
+                    }
+                    st->changed = changed;
+                }
+                picked[0] = verdict;
+                pickBest[0] = nLog;
+            }
+            __syncthreads();
+            const int verdict = picked[0];
+            if (verdict == 1) {
+                // The second walk was for the wrong node.  Every out-distance it refreshed goes back to what it was (the first
+                // walk's refreshes are the reference's own), the candidate stays as the scan left it, and the host enqueues the
+                // round again as two separate walks.
+                const int nLog = pickBest[0];
                 for (int k = threadIdx.x; k < nLog; k += blockDim.x) {
                     const int32_t v = E.logNode[k];
                     A.outDist[v] = E.logOut[k];
@@ -949,24 +1259,18 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
                 }
                 return;
             }
-            if (threadIdx.x == 0) {   // confirmed: setOutDistance(join.j) as k_nj_glue_scan computed it
-                if (st->specValid) {
-                    const int32_t v = st->curJ;
-                    A.outDist[v] = st->specOut;
-                    A.nOutActive[v] = st->specStamp;
-                    A.mOutDist[v] = st->specOut;
-                    A.mNOut[v] = st->specStamp;
-                }
-                st->changed = 0;
+            if (verdict == 2) {
+                i = picked[1];
+                j = picked[2];
             }
-            __syncthreads();
-            vft_nj_best_pick<REAL>(E, T, 1, redC, redT, picked, T.m, false);
+            roundChanged = verdict == 2;
         } else {
             vft_nj_best_pick<REAL>(E, T, 1, redC, redT, picked);
+            i = picked[1];
+            j = picked[2];
+            roundChanged = picked[0] != 0;
         }
-        i = picked[1];
-        j = picked[2];
-        if (picked[0]) {
+        if (roundChanged) {
             vft_nj_force_out_distance<REAL, NC>(A, s, i, njLds, njLds + A.d.nPosPad);
             if (threadIdx.x == 0 && lastRound) {
                 st->halt = VFT_NJ_HALT_CLIMB;
@@ -978,20 +1282,27 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
         __syncthreads();
         if (threadIdx.x == 0) st->runRound = 0;
     }
-    const int64_t newn = st->maxnode;
+    double totdiamNew = totdiam0;
     // setOutDistance(i), setOutDistance(j) (NJ.tcc:2897-2898) have happened: the search forces the first end (k_nj_glue_scan, or
     // this kernel when a round changed the candidate) and the second (k_nj_glue_best; with -fastest k_nj_glue_scan forces both)
     if (threadIdx.x == 0) {
-        const REAL dist = st->curDist;
-        const REAL outI = A.outDist[i], outJ = A.outDist[j];
-        const REAL crit = vft_criterion<REAL>(dist, outI, A.nOutActive[i], outJ, A.nOutActive[j], nActive);   // criterionFresh / setDistCriterion(join)
+        // (one round of loads: the ends' out-distances, stamps and diameters, their lists' lengths for the merge)
+        const REAL dist = curDist0;
+        const REAL outI = A.outDist[i], outJ = A.outDist[j], diaI = A.diameter[i], diaJ = A.diameter[j];
+        const int32_t stampI = A.nOutActive[i], stampJ = A.nOutActive[j], lenI = T.len[i], lenJ = T.len[j];
+        st->mergeNew = (int32_t) newn;
+        st->mergeC0 = (int32_t) (i < j ? i : j);
+        st->mergeC1 = (int32_t) (i < j ? j : i);
+        st->mergeN0 = i < j ? lenI : lenJ;
+        st->mergeN1 = i < j ? lenJ : lenI;
+        const REAL crit = vft_criterion<REAL>(dist, outI, stampI, outJ, stampJ, nActive);   // criterionFresh / setDistCriterion(join)
         // NJ.tcc:2911-2916, 3003-3007 (BIONJ off: weight 1/2)
         const double distIJ = (double) dist;
         const REAL od = outI - outJ;
         const double deltaDist = (double) od / (double) (nActive - 2);
         const REAL blI = (REAL) ((distIJ + deltaDist) / 2), blJ = (REAL) ((distIJ - deltaDist) / 2);
         const double bw = 0.5;
-        const REAL bi = blI + A.diameter[i], bj = blJ + A.diameter[j];
+        const REAL bi = blI + diaI, bj = blJ + diaJ;
         const REAL diam = (REAL) (bw * (double) bi + (1 - bw) * (double) bj);
         sDiam = diam;
         NjJoinRec r;
@@ -1007,8 +1318,9 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
         E.logDev[joinIndex] = r;
         E.logHost[joinIndex] = r;
         if (updateOut) {   // (a full out-profile follows otherwise, and the host sets totdiam from the diameters)
-            const REAL dd = diam - A.diameter[i] - A.diameter[j];
-            st->totdiam += (double) dd;
+            const REAL dd = diam - diaI - diaJ;
+            totdiamNew = totdiam0 + (double) dd;
+            st->totdiam = totdiamNew;
         }
         A.mOutDist[newn] = 0;
         A.mNOut[newn] = E.staleStamp;
@@ -1026,7 +1338,7 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
             // join body has just formed
             const double top = newOut[0], denom = newOut[1];
             const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
-            const REAL od = vft_out_distance<REAL>(d, w, nActive - 1, A.selfweight[newn], A.selfdist[newn], sDiam, st->totdiam);
+            const REAL od = vft_out_distance<REAL>(d, w, nActive - 1, A.selfweight[newn], A.selfdist[newn], sDiam, totdiamNew);
             A.outDist[newn] = od;
             A.nOutActive[newn] = (int32_t) (nActive - 1);
             A.mOutDist[newn] = od;
@@ -1053,9 +1365,9 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_pairs(Arena<REAL> A, NjEngi
     const NjState<REAL> *st = E.st;
     if (st->halt) return;
     __shared__ int thOwner;
-    const NjJoinRec rec = E.logDev[joinIndex];
-    const int64_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
-    const int n0 = T.len[c0], n1 = T.len[c1], t = (int) blockIdx.x;
+    // (the join's record as k_nj_glue_join left it in the state block: no chain log -> lengths -> hits)
+    const int64_t newnode = st->mergeNew, c0 = st->mergeC0, c1 = st->mergeC1;
+    const int n0 = st->mergeN0, n1 = st->mergeN1, t = (int) blockIdx.x;
     if (t >= n0 + n1) return;
     const SweepArgs s = vft_nj_args(E, st->nActive, st->totdiam);
     const ThHit<REAL> h = t < n0 ? T.hits[c0 * T.m + t] : T.hits[c1 * T.m + (t - n0)];

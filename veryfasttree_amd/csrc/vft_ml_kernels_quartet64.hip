@@ -10,3 +10,9 @@
 #include "vft_kernels_ml.h"
 
 VFT_ML_QUARTET_INSTANCES_F64()
+
+#ifdef VFT_ML_TIMING
+extern "C" int vft_ml_ticks(unsigned long long *out) {
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(vftMlTicks), 16 * sizeof(unsigned long long));
+}
+#endif
