@@ -2996,26 +2996,37 @@ extern "C" int vft_posterior_chain_blen(vft_ctx *c, int32_t n, const int64_t *ou
 
 static inline int mlopt_wg(const vft_ctx *c) { return c->d.nCodes == 20 ? MlOptWG<20>::value : MlOptWG<4>::value; }
 
-template <typename REAL, int NC>
-static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
-                              double ftol, double atol) {
-#define VFT_MLOPT_CASE(CPT)                                                                                             \
-    case CPT:                                                                                                           \
-        launch((k_ml_node_lengths<REAL, NC, CPT>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream, arena<REAL>(c), \
-               dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);                  \
-        break;
-    switch (cpt == 2 ? 4 : cpt) {
-        VFT_MLOPT_CASE(1)
-        VFT_MLOPT_CASE(4)
-        default:
-            if (NC == 4 && cpt == 8) {
-                launch((k_ml_node_lengths<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream,
-                       arena<REAL>(c), dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals);
-                break;
-            }
-            return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: alignment too long for the in-kernel optimiser");
+// Columns per thread of the two line-search kernels (0: the alignment is too long for them).  Proteins under a matrix model up
+// to 512 columns: a quad of lanes per column (`quad`; one or four passes of 128 columns); otherwise whole columns per thread.
+static inline int mlopt_cpt(const vft_ctx *c, bool &quad) {
+    quad = false;
+    if (c->d.nCodes == 20 && c->hasTm && c->d.nPos <= MlOptWG<20>::value) {
+        quad = true;
+        return c->d.nPos <= MlOptWG<20>::value / 4 ? 1 : 4;
     }
-#undef VFT_MLOPT_CASE
+    const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
+    if (c->d.nCodes == 20) return per <= 4 ? 4 : 0;
+    return per <= 1 ? 1 : per <= 4 ? 4 : per <= 8 ? 8 : 0;   // (two columns per thread run the four-column kernel: fewer instantiations)
+}
+
+template <typename REAL, int NC>
+static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, bool quad, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
+                              double ftol, double atol) {
+#define VFT_MLOPT_GO(CPT, QUAD)                                                                                         \
+    launch((k_ml_node_lengths<REAL, NC, CPT, QUAD>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream, arena<REAL>(c), \
+           dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals)
+    if constexpr (NC == 20) {
+        if (quad && cpt == 1) VFT_MLOPT_GO(1, true);
+        else if (quad && cpt == 4) VFT_MLOPT_GO(4, true);
+        else if (!quad && cpt == 4) VFT_MLOPT_GO(4, false);
+        else return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: alignment too long for the in-kernel optimiser");
+    } else {
+        if (cpt == 1) VFT_MLOPT_GO(1, false);
+        else if (cpt == 4) VFT_MLOPT_GO(4, false);
+        else if (cpt == 8) VFT_MLOPT_GO(8, false);
+        else return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: alignment too long for the in-kernel optimiser");
+    }
+#undef VFT_MLOPT_GO
     return VFT_OK;
 }
 
@@ -3043,8 +3054,8 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
     if (int r = ensure_ml_rows(c)) return r;
-    const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
-    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
+    bool quad;
+    const int cpt = mlopt_cpt(c, quad);
     const size_t idB = (size_t) n * 8;
     if (7 * idB > VFT_SMALL_BYTES) return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: too many splits per call");
     char *h, *s;
@@ -3053,7 +3064,7 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
     memcpy(h + 3 * idB, lenIdx, 3 * idB);
     memcpy(h + 6 * idB, recompute, idB);
     int r = VFT_OK;
-    VFT_DISPATCH(c, (r = ml_optimize_launch<REAL, NC>(c, n, cpt, (const int64_t *) s, (const int64_t *) (s + 3 * idB),
+    VFT_DISPATCH(c, (r = ml_optimize_launch<REAL, NC>(c, n, cpt, quad, (const int64_t *) s, (const int64_t *) (s + 3 * idB),
                                                       (const int64_t *) (s + 6 * idB), ftol, atol)));
     if (r) return r;
     LAUNCHCHK(c);
@@ -3061,28 +3072,25 @@ extern "C" int vft_ml_optimize_splits(vft_ctx *c, int64_t n, const int64_t *ids,
 }
 
 template <typename REAL, int NC>
-static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
+static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, bool quad, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
                              double closeLimit, int mlAccuracy, int mode, double *dLoglk, double *dSite, double *dLen,
                              QuartetNNIResult *dNni, QuartetNNIState *dState = nullptr) {
-#define VFT_MLQ_CASE(CPT)                                                                                               \
-    case CPT:                                                                                                           \
-        launch((k_ml_quartet<REAL, NC, CPT>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlOptWG<NC>::value), 0, c->stream,  \
-               arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, \
-               dLoglk, dSite, dLen, dNni, dState, c->mlEvals);                                                           \
-        break;
-    switch (cpt == 2 ? 4 : cpt) {   // two columns per thread run the four-column kernel (fewer instantiations to build)
-        VFT_MLQ_CASE(1)
-        VFT_MLQ_CASE(4)
-        default:
-            if (NC == 4 && cpt == 8) {   // nucleotides up to 2048 columns (16S-length alignments); proteins: 4 x 512
-                launch((k_ml_quartet<REAL, NC, (NC == 4 ? 8 : 4)>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlOptWG<NC>::value), 0,
-                       c->stream, arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy,
-                       mode, dLoglk, dSite, dLen, dNni, dState, c->mlEvals);
-                break;
-            }
-            return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");
+#define VFT_MLQ_GO(CPT, QUAD)                                                                                           \
+    launch((k_ml_quartet<REAL, NC, CPT, QUAD>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlOptWG<NC>::value), 0, c->stream, \
+           arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode,  \
+           dLoglk, dSite, dLen, dNni, dState, c->mlEvals)
+    if constexpr (NC == 20) {
+        if (quad && cpt == 1) VFT_MLQ_GO(1, true);
+        else if (quad && cpt == 4) VFT_MLQ_GO(4, true);
+        else if (!quad && cpt == 4) VFT_MLQ_GO(4, false);
+        else return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");
+    } else {
+        if (cpt == 1) VFT_MLQ_GO(1, false);
+        else if (cpt == 4) VFT_MLQ_GO(4, false);
+        else if (cpt == 8) VFT_MLQ_GO(8, false);   // nucleotides up to 2048 columns (16S-length alignments)
+        else return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");
     }
-#undef VFT_MLQ_CASE
+#undef VFT_MLQ_GO
     return VFT_OK;
 }
 
@@ -3108,8 +3116,8 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMalloc((void **) &c->mlEvals, sizeof(unsigned int)));
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
-    const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
-    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
+    bool quad;
+    const int cpt = mlopt_cpt(c, quad);
     const size_t idB = (size_t) n * 8, resB = (size_t) n * sizeof(QuartetNNIResult);
     static_assert(sizeof(QuartetNNIResult) == sizeof(vft_quartet_nni), "result record layout");
     const size_t stB = ((size_t) n * sizeof(QuartetNNIState) + 255) & ~(size_t) 255;
@@ -3129,7 +3137,7 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
     else launch((k_ml_nni_init<double>), g1, b1, 0, c->stream, dLi, (const double *) c->blen, dState, n);
     for (int round = 0; round < nRounds; round++) {
         int r = VFT_OK;
-        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, dIds, dLi, ftol, atol, closeLimit, mlAccuracy, 2, nullptr, nullptr,
+        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, quad, dIds, dLi, ftol, atol, closeLimit, mlAccuracy, 2, nullptr, nullptr,
                                                          nullptr, nullptr, dState)));
         if (r) return r;
         launch(k_ml_nni_decide, g1, b1, 0, c->stream, dState, n, c->minLen, closeLimit, (int) mlAccuracy, round == nRounds - 1 ? 1 : 0);
@@ -3162,8 +3170,8 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMemsetAsync(c->mlEvals, 0, sizeof(unsigned int), c->stream));
     }
     const int64_t nPos = c->d.nPos;
-    const int64_t per = cdiv(nPos, mlopt_wg(c));
-    const int cpt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 0;
+    bool quad;
+    const int cpt = mlopt_cpt(c, quad);
     if (nBoot > 0 && (nPos > 65535 || (size_t) 3 * nPos * sizeof(double) > 60000)) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the SH resampling kernel");
     // chunks of splits: per split 3 x nPos site log-likelihoods
     int64_t chunk = (int64_t) ((512u << 20) / ((size_t) 3 * nPos * sizeof(double)));
@@ -3196,7 +3204,7 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
         HIPCHK(c, hipMemcpyAsync(dIds, ids + 4 * k0, 4 * cB, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dLi, lenIdx + 5 * k0, 5 * cB, hipMemcpyHostToDevice, c->stream));
         int r = VFT_OK;
-        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, cnt, cpt, dIds, dLi, ftol, atol, closeLimit, alwaysSecondPass ? 2 : 1, 0,
+        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, cnt, cpt, quad, dIds, dLi, ftol, atol, closeLimit, alwaysSecondPass ? 2 : 1, 0,
                                                          dLoglk, dSite, dLen, nullptr)));
         if (r) return r;
         LAUNCHCHK(c);

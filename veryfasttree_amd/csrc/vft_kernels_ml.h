@@ -8,6 +8,7 @@
 #include "vft_device.h"
 #include "vft_kernels_profile.h"
 #include "vft_glibc_log.h"
+#include <type_traits>
 
 #define VFT_ML_WG 128
 #define VFT_ML_STAGE 2048   /* columns staged in LDS per pass of the ordered likelihood total */
@@ -159,23 +160,27 @@ __device__ __forceinline__ double vft_lk_finish(double lk, double loglk) {
     return loglk + (lk > 0.0 && lk < 1.0e300 ? vft_glibc_log(lk) : log(lk));
 }
 
-// The ordered total for the line-search kernels (threads own the columns p = tid + c * WG, c < CPT), result to every
-// thread.  A chain of nPos dependent multiply / compare / rescale steps on one lane costs ~36 cycles per column; here the
-// rescaling decisions are taken off the chain:
+// The ordered total for the line-search kernels, result to every thread.  A chain of nPos dependent multiply / compare /
+// rescale steps on one lane costs ~36 cycles per column; here the rescaling decisions are taken off the chain:
 //   1. every thread stages its columns' likelihoods a_i (1.0 where the reference skips a column: multiplying by 1.0 is
-//      exact) and log2 a_i;
-//   2. wavefront 0 decides every rescaling from prefix sums of the logs.  With s_i = log2 of the product of a_0..a_i and
+//      exact) and log2 a_i (vft_lk_stage);
+//   2. the workgroup decides every rescaling from prefix sums of the logs.  With s_i = log2 of the product of a_0..a_i and
 //      T = log2(1e4), the reference's two while loops keep log2(lk) = s_i + n_i T inside [-T, T] by the smallest change
 //      of the net rescaling count: n_i = clamp(n_(i-1), lo_i, hi_i), lo_i = ceil((-T - s_i) / T), hi_i = floor((T - s_i) / T)
 //      (under a matrix model a column's likelihood can exceed 1 - profiles are scaled by 1 / stat - so both loops fire).
-//      Clamps compose into clamps, so all n_i come out of one wave scan.  A prefix sum closer than 1e-9 (in units of T)
-//      to a threshold, a non-positive or non-finite value, or a list overflow sends the call to the plain chain;
+//      Clamps compose into clamps, so all n_i come out of scans: a thread owns a run of C consecutive columns; the prefix
+//      sums, the composed clamps and the event counts are each one wave scan plus one exchange through LDS (round 2 had
+//      wavefront 0 walk runs of COLS / 64 columns four times: 9.6 us of a 15 us evaluation at 300 protein columns).  A
+//      prefix sum closer than 1e-9 (in units of T) to a threshold, a non-positive or non-finite value, or a list overflow
+//      sends the call to the plain chain;
 //   3. the multiplier list - every a_i followed by one 1e4 (or 1e-4) per rescaling it triggers - is laid out in LDS and
 //      ONE lane multiplies it through in order: the reference's sequence of roundings at ~7 cycles per element; a lane
 //      of another wavefront applies -/+ LogLkUnderflow once per rescaling in the same order (also a chain of roundings).
 struct LkOrderedShared {
     double prod, loglk;
     int irregular, nList, nEvents, pad;
+    double waveSum[16];
+    int waveLo[16], waveHi[16], waveEv[16];
 };
 
 // the clamp interval [l, h] of a column whose prefix log-sum is sI; odd: too close to a threshold to decide here
@@ -193,114 +198,137 @@ __device__ __forceinline__ void vft_lk_interval(double sI, int &l, int &h, bool 
 
 __device__ __forceinline__ int vft_clampi(int v, int l, int h) { return v < l ? l : (v > h ? h : v); }
 
-template <int WG, int CPT>
-__device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *stageLog, double *list, signed char *events,
-                                                       LkOrderedShared *sh, const double (&lkAB)[CPT], int64_t nPos64, bool jc) {
-    constexpr int COLS = CPT * WG;              // capacity of stage / stageLog
+// step 1 for one column (every thread, for each of its columns; the total starts with a barrier)
+__device__ __forceinline__ void vft_lk_stage(double *stage, double *stageLog, int p, double lkAB) {
+    const double a = lkAB == VFT_LK_SKIP ? 1.0 : lkAB;
+    stage[p] = a;
+    stageLog[p] = log2(a);
+}
+
+// steps 2 and 3 over stage[0, nPos) / stageLog[0, nPos); COLS: capacity of the staging arrays (list: COLS * 3 / 2, events: COLS / 2)
+template <int WG, int COLS>
+__device__ __forceinline__ double vft_lk_total_staged(double *stage, double *stageLog, double *list, signed char *events,
+                                                      LkOrderedShared *sh, int nPos, bool jc) {
     constexpr int LCAP = COLS + COLS / 2;       // capacity of list
     constexpr int ECAP = COLS / 2;              // capacity of events
-    constexpr int C = COLS / 64;                // columns per lane of wavefront 0
-    const int tid = threadIdx.x, lane = tid & 63, nPos = (int) nPos64;
-#pragma unroll
-    for (int c = 0; c < CPT; c++) {
-        const int p = tid + c * WG;
-        if (p < nPos) {
-            const double a = lkAB[c] == VFT_LK_SKIP ? 1.0 : lkAB[c];
-            stage[p] = a;
-            stageLog[p] = log2(a);
-        }
-    }
+    constexpr int C = (COLS + WG - 1) / WG;     // columns per thread
+    constexpr int NW = WG / 64;
+    constexpr int BIG = 1 << 28;
+    static_assert(NW <= 16, "LkOrderedShared holds 16 wavefronts");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sh->irregular = 0;
     __syncthreads();
-    if (tid < 64) {
-        const int BIG = 1 << 28;
-        bool odd = false;
-        const int q0 = lane * C, q1 = q0 + C < nPos ? q0 + C : nPos;   // this lane's run of columns [q0, q1)
-        // pass A: prefix sums of the logs (lane-local runs, then a wave scan); every later pass re-accumulates the run in
-        // the same order, which reproduces the same sums without keeping them in registers
-        double lsum = 0;
-        for (int q = q0; q < q1; q++) {
-            const double l = stageLog[q];
-            if (!(fabs(l) < 1.0e4)) odd = true;   // a <= 0, inf, nan
-            lsum += l;
-        }
-        double incl = lsum;
+    bool odd = false;
+    const int q0 = tid * C < nPos ? tid * C : nPos, q1 = q0 + C < nPos ? q0 + C : nPos;   // this thread's run of columns [q0, q1)
+    // prefix sums of the logs: the run, a wave scan, the earlier wavefronts' totals
+    double lg[C], lsum = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        const double excl = incl - lsum;
-        // pass B: the run as one clamp (cl, ch), then an inclusive scan of the clamps (earlier runs first)
-        int cl = -BIG, ch = BIG;
+    for (int k = 0; k < C; k++) {
+        lg[k] = q0 + k < q1 ? stageLog[q0 + k] : 0.0;
+        if (!(fabs(lg[k]) < 1.0e4)) odd = true;   // a <= 0, inf, nan
+        lsum += lg[k];
+    }
+    double incl = lsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) sh->waveSum[wave] = incl;
+    __syncthreads();
+    double excl = 0;
+    for (int w = 0; w < wave; w++) excl += sh->waveSum[w];
+    excl += incl - lsum;
+    // every column's interval, the run as one clamp (cl, ch), an inclusive scan of the clamps (earlier runs first)
+    int L[C], H[C], cl = -BIG, ch = BIG;
+    {
         double run = 0;
-        for (int q = q0; q < q1; q++) {
-            run += stageLog[q];
-            int l, h;
-            vft_lk_interval(excl + run, l, h, odd);
-            cl = vft_clampi(cl, l, h);
-            ch = vft_clampi(ch, l, h);
-        }
-        int il = cl, ih = ch;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int tl = __shfl_up(il, off, 64), th = __shfl_up(ih, off, 64);
-            if (lane >= off) {   // (tl, th) covers the columns before those of (il, ih): push its bounds through
-                const int nl = vft_clampi(tl, il, ih), nh = vft_clampi(th, il, ih);
-                il = nl;
-                ih = nh;
+        for (int k = 0; k < C; k++) {
+            L[k] = -BIG;
+            H[k] = BIG;
+            if (q0 + k < q1) {
+                run += lg[k];
+                vft_lk_interval(excl + run, L[k], H[k], odd);
+                cl = vft_clampi(cl, L[k], H[k]);
+                ch = vft_clampi(ch, L[k], H[k]);
             }
         }
-        const int pl = __shfl_up(il, 1, 64), ph = __shfl_up(ih, 1, 64);
-        const int nIn = lane == 0 ? 0 : vft_clampi(0, pl, ph);   // the count entering this run (lk starts at 1: n = 0)
-        // pass C: rescaling events of the run, exclusive scan of their counts
-        int n = nIn, ev = 0;
-        run = 0;
-        for (int q = q0; q < q1; q++) {
-            run += stageLog[q];
-            int l, h;
-            vft_lk_interval(excl + run, l, h, odd);
-            const int n2 = vft_clampi(n, l, h);
+    }
+    int il = cl, ih = ch;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int tl = __shfl_up(il, off, 64), th = __shfl_up(ih, off, 64);
+        if (lane >= off) {   // (tl, th) covers the columns before those of (il, ih): push its bounds through
+            const int nl = vft_clampi(tl, il, ih), nh = vft_clampi(th, il, ih);
+            il = nl;
+            ih = nh;
+        }
+    }
+    if (lane == 63) {
+        sh->waveLo[wave] = il;
+        sh->waveHi[wave] = ih;
+    }
+    int pl = __shfl_up(il, 1, 64), ph = __shfl_up(ih, 1, 64);   // the lanes in front of this one (this wavefront)
+    if (lane == 0) {
+        pl = -BIG;
+        ph = BIG;
+    }
+    __syncthreads();
+    int nIn = 0;   // the count entering this run (lk starts at 1: n = 0): through the earlier wavefronts, then the earlier lanes
+    for (int w = 0; w < wave; w++) nIn = vft_clampi(nIn, sh->waveLo[w], sh->waveHi[w]);
+    nIn = vft_clampi(nIn, pl, ph);
+    // rescaling events of the run, exclusive scan of their counts
+    int ev = 0;
+    if (!odd) {
+        int n = nIn;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const int n2 = vft_clampi(n, L[k], H[k]);
             ev += n2 > n ? n2 - n : n - n2;
             n = n2;
         }
-        int einc = ev;
+        if (ev > ECAP) {
+            ev = 0;
+            odd = true;
+        }
+    }
+    int einc = ev;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(einc, off, 64);
-            if (lane >= off) einc += t;
-        }
-        const int eTotal = __shfl(einc, 63, 64);
-        if (eTotal > ECAP || nPos + eTotal > LCAP) odd = true;
-        const bool anyOdd = __ballot(odd) != 0ull;
-        if (!anyOdd) {
-            // pass D: the multiplier list and the event list
-            int e = einc - ev;
-            n = nIn;
-            run = 0;
-            for (int q = q0; q < q1; q++) {
-                run += stageLog[q];
-                int l, h;
-                bool dummy = false;
-                vft_lk_interval(excl + run, l, h, dummy);
-                const int n2 = vft_clampi(n, l, h);
-                list[q + e] = stage[q];
-                const int d = n2 - n, cnt = d > 0 ? d : -d;
-                for (int r = 0; r < cnt; r++) {
-                    list[q + e + 1 + r] = d > 0 ? VFT_LK_UNDERFLOW_INV : VFT_LK_UNDERFLOW;
-                    events[e + r] = d > 0 ? 1 : -1;
-                }
-                e += cnt;
-                n = n2;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(einc, off, 64);
+        if (lane >= off) einc += t;
+    }
+    if (lane == 63) sh->waveEv[wave] = einc;
+    if (odd) sh->irregular = 1;   // (every writer stores 1)
+    __syncthreads();
+    int eBase = 0, eTotal = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int v = sh->waveEv[w];
+        if (w < wave) eBase += v;
+        eTotal += v;
+    }
+    const bool irregular = sh->irregular != 0 || eTotal > ECAP || nPos + eTotal > LCAP;   // (uniform)
+    if (!irregular) {
+        // the multiplier list and the event list
+        int e = eBase + einc - ev, n = nIn;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            if (q0 + k >= q1) continue;
+            const int q = q0 + k, n2 = vft_clampi(n, L[k], H[k]);
+            list[q + e] = stage[q];
+            const int d = n2 - n, cnt = d > 0 ? d : -d;
+            for (int r = 0; r < cnt; r++) {
+                list[q + e + 1 + r] = d > 0 ? VFT_LK_UNDERFLOW_INV : VFT_LK_UNDERFLOW;
+                events[e + r] = d > 0 ? 1 : -1;
             }
-        }
-        if (lane == 0) {
-            sh->irregular = anyOdd ? 1 : 0;
-            sh->nList = nPos + eTotal;
-            sh->nEvents = eTotal;
+            e += cnt;
+            n = n2;
         }
     }
     __syncthreads();
-    if (sh->irregular) {   // uniform: the plain chain, decisions and all
+    if (irregular) {   // uniform: the plain chain, decisions and all
         if (tid == 0) {
             double lk = 1.0, loglk = 0.0;
             vft_lk_chain(stage, nPos, jc, lk, loglk);
@@ -308,15 +336,14 @@ __device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *st
             sh->loglk = loglk;
         }
     } else if (tid == 0) {
-        const int K = sh->nList;
+        const int K = nPos + eTotal;
         double lk = 1.0;
 #pragma unroll 16
         for (int k = 0; k < K; k++) lk *= list[k];
         sh->prod = lk;
     } else if (tid == 64) {
-        const int nE = sh->nEvents;
         double loglk = 0.0;
-        for (int r = 0; r < nE; r++) {
+        for (int r = 0; r < eTotal; r++) {
             if (events[r] > 0) loglk -= VFT_LOG_LK_UNDERFLOW;
             else loglk += VFT_LOG_LK_UNDERFLOW;
         }
@@ -324,6 +351,19 @@ __device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *st
     }
     __syncthreads();
     return vft_lk_finish(sh->prod, sh->loglk);
+}
+
+// the same for threads that own the columns p = tid + c * WG, c < CPT
+template <int WG, int CPT>
+__device__ __forceinline__ double vft_lk_total_ordered(double *stage, double *stageLog, double *list, signed char *events,
+                                                       LkOrderedShared *sh, const double (&lkAB)[CPT], int64_t nPos64, bool jc) {
+    const int nPos = (int) nPos64;
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int p = (int) threadIdx.x + c * WG;
+        if (p < nPos) vft_lk_stage(stage, stageLog, p, lkAB[c]);
+    }
+    return vft_lk_total_staged<WG, CPT * WG>(stage, stageLog, list, events, sh, nPos, jc);
 }
 
 // pairLogLk (NJ.tcc:1192-1447).  One workgroup per pair, threads over columns.  Each thread keeps the
@@ -632,6 +672,228 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior_chain(Arena<REAL> A, co
 // array (numeric_t, like the reference's branchlength[]), so consecutive splits of a traversal are just consecutive
 // launches on the stream.  Afterwards the node's own posterior from its two children and their new lengths
 // (recomputeProfile, NJ.tcc:3436-3473, useML) is written to its dense ML row.
+// ------------------------------------------------------------------------------------------------------------------
+// 20-state columns spread over FOUR lanes (the line-search kernels for proteins).  The reference's SSE / AVX kernels keep four
+// strided accumulators over the 20 states - s[l] += x[l + 4 i] - and finish with (s0 + s1) + (s2 + s3) (vft_red4_*): lane l of
+// a quad owns the states l, l + 4, ..., l + 16 of its column, i.e. accumulator l, and two quad exchanges finish the sum in the
+// reference's order on all four lanes.  A thread that owns whole columns needs 20 values per profile and column - 240 VGPRs
+// for the six profiles of a quartet step in double precision: round 2's kernels spilled 300 - 5 365 registers to scratch.
+// A quad holds 5.
+template <int CTRL>
+__device__ __forceinline__ float vft_quad_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double vft_quad_perm(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long) hi << 32) | (long long) (unsigned int) lo);
+}
+// accumulator l on lane l -> (s0 + s1) + (s2 + s3) on all four lanes (additions commute: every lane forms the same two sums)
+template <typename REAL>
+__device__ __forceinline__ REAL vft_quad_red4(REAL s) {
+    const REAL a = s + vft_quad_perm<0xB1>(s);   // lanes 1 0 3 2
+    return a + vft_quad_perm<0x4E>(a);           // lanes 2 3 0 1
+}
+
+#define VFT_QS 5   /* states per lane */
+
+// the model's tables in LDS for the quad kernels (global loads of them were a memory round trip per use)
+template <typename REAL>
+struct MlQuadTables {
+    REAL codeFreq[21 * 20], eigenInv[20 * 20], statInv[20], eigenval[20], rates[VFT_MAXRATES];
+};
+template <typename REAL>
+__device__ __forceinline__ void vft_quad_tables_load(const Arena<REAL> &A, MlQuadTables<REAL> *Q) {
+    for (int t = threadIdx.x; t < 21 * 20; t += blockDim.x) Q->codeFreq[t] = A.tmCodeFreq[t];
+    for (int t = threadIdx.x; t < 20 * 20; t += blockDim.x) Q->eigenInv[t] = A.tmEigenInv[t];
+    for (int t = threadIdx.x; t < 20; t += blockDim.x) {
+        Q->statInv[t] = A.tmStatInv[t];
+        Q->eigenval[t] = A.tmEigenval[t];
+    }
+    for (int t = threadIdx.x; t < A.nRates && t < VFT_MAXRATES; t += blockDim.x) Q->rates[t] = A.rates[t];
+}
+
+// expEigenRates from the LDS copies (vft_exp_eigen_rates)
+template <typename REAL>
+__device__ __forceinline__ void vft_quad_exp_eigen_rates(const MlQuadTables<REAL> *Q, int nRates, double length, double minRel, REAL *out) {
+    for (int t = threadIdx.x; t < nRates * 20; t += blockDim.x) {
+        const int r = t / 20, j = t % 20;
+        double relLen = length * (double) Q->rates[r];
+        if (relLen < minRel) relLen = minRel;
+        const REAL rl = (REAL) relLen;           // vector_multiply_by takes numeric_t
+        const REAL x = Q->eigenval[j] * rl;
+        out[t] = (REAL) vft_glibc_exp((double) x);
+    }
+}
+
+// lane l's states of one column (vft_load_col_ml)
+template <typename REAL>
+__device__ __forceinline__ void vft_quad_load_col_ml(const Arena<REAL> &A, int64_t node, int64_t p, int l, Col<REAL, VFT_QS> &c) {
+    if (node >= A.d.nSeqs && A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs]) {
+        const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
+        c.w = A.mlW[idx];
+        c.code = (int) A.mlC[idx];
+        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+        if (c.vec) {
+            const REAL *src = A.mlF + idx * 20;
+#pragma unroll
+            for (int i = 0; i < VFT_QS; i++) c.f[i] = src[l + 4 * i];
+        }
+        return;
+    }
+    const int lane = (int) (node & (VFT_TILE - 1));
+    const int64_t tile = node >> 6;
+    if (node < A.d.nSeqs) {
+        const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, (int) (p >> 4), lane)];
+        c.code = vft_decode<20>(vft_byte(t, (int) (p & 15)));
+        c.w = c.code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
+        c.vec = false;
+        return;
+    }
+    const int64_t pt = tile - A.d.firstProfTile;
+    const int64_t mi = vft_meta_idx(A.d, pt, p);
+    const ColMask m = A.colMask[mi];
+    const ColOff o = A.colOff[mi];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint4 t = A.profC[vft_c_idx(A.d, pt, (int) (p >> 4), lane)];
+    c.code = (int) vft_byte(t, (int) (p & 15));
+    const bool hv = (m.vec >> lane) & 1ull;
+    if ((m.w >> lane) & 1ull) c.w = A.profW[vft_wstream_base(A.d, pt) + o.w + __popcll(m.w & below)];
+    else c.w = vft_implicit_weight<REAL>(c.code, hv);
+    c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+    if (c.vec) {
+        const REAL *src = A.profF + vft_fstream_base(A.d, pt);
+        const int nvec = __popcll(m.vec), rank = __popcll(m.vec & below);
+#pragma unroll
+        for (int i = 0; i < VFT_QS; i++) c.f[i] = src[vft_fidx<REAL, 20>(o.vec, nvec, rank, l + 4 * i)];
+    }
+}
+
+// lane l's part of vft_store_col_ml
+template <typename REAL>
+__device__ __forceinline__ void vft_quad_store_col_ml(const Arena<REAL> &A, int64_t node, int64_t p, int l, REAL w, int code, const REAL *f) {
+    const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
+    if (l == 0) {
+        A.mlW[idx] = w;
+        A.mlC[idx] = (uint8_t) code;
+    }
+    if (w > 0 && code == VFT_NOCODE_) {
+        REAL *dst = A.mlF + idx * 20;
+#pragma unroll
+        for (int i = 0; i < VFT_QS; i++) dst[l + 4 * i] = f[i];
+    }
+}
+
+// lane l's states of vft_model_freq
+template <typename REAL>
+__device__ __forceinline__ void vft_quad_model_freq(const MlQuadTables<REAL> *Q, const Col<REAL, VFT_QS> &c, bool mixAlways, int l, REAL *f) {
+    const double w = (double) c.w;
+    if (c.vec) {
+#pragma unroll
+        for (int i = 0; i < VFT_QS; i++) f[i] = c.f[i];
+        if (!mixAlways) return;   // posteriorProfile mixes only code columns (NJ.tcc:2283-2292)
+    } else {
+        const int row = c.code == VFT_NOCODE_ ? 20 : c.code;
+#pragma unroll
+        for (int i = 0; i < VFT_QS; i++) f[i] = Q->codeFreq[row * 20 + l + 4 * i];
+    }
+    if (w > 0.0 && w < 1.0) {
+#pragma unroll
+        for (int i = 0; i < VFT_QS; i++) f[i] = (REAL) (w * (double) f[i] + (1.0 - w) * (double) Q->codeFreq[20 * 20 + l + 4 * i]);
+    }
+}
+
+// vft_pair_lk_col under a matrix model (NJ.tcc:1267-1439), result on all four lanes; ee: the column's rate category's row
+template <typename REAL>
+__device__ __forceinline__ bool vft_quad_pair_lk_col(const MlQuadTables<REAL> *Q, const Col<REAL, VFT_QS> &c1, const Col<REAL, VFT_QS> &c2,
+                                                     const REAL *ee, int l, double &lkAB) {
+    lkAB = 0;
+    if (c1.w == 0 && c2.w == 0 && c1.code == VFT_NOCODE_ && c2.code == VFT_NOCODE_) return false;
+    REAL fA[VFT_QS], fB[VFT_QS];
+    vft_quad_model_freq<REAL>(Q, c1, true, l, fA);
+    vft_quad_model_freq<REAL>(Q, c2, true, l, fB);
+    REAL s = 0;
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) {
+        REAL pr = ee[l + 4 * i] * fA[i];   // vft_red4_mul3(e, fA, fB), NJ.tcc:1359
+        pr = pr * fB[i];
+        s = pr + s;
+    }
+    lkAB = (double) vft_quad_red4<REAL>(s);
+    return true;
+}
+
+// vft_posterior_col under a matrix model with 20 states (NJ.tcc:2267-2447), lane l's states of the result
+template <typename REAL>
+__device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> *Q, const Col<REAL, VFT_QS> &c1, const Col<REAL, VFT_QS> &c2,
+                                                       const REAL *e1, const REAL *e2, int l, Col<REAL, VFT_QS> &o) {
+    o.w = (REAL) 1.0;
+    o.code = VFT_NOCODE_;
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) o.f[i] = 0;
+    if (c1.code == VFT_NOCODE_ && c2.code == VFT_NOCODE_ && c1.w == 0 && c2.w == 0) {
+        o.w = 0;   // gap with gap (NJ.tcc:2267-2272)
+        o.vec = false;
+        return;
+    }
+    REAL fM1[VFT_QS], fM2[VFT_QS], fPost[VFT_QS];
+    vft_quad_model_freq<REAL>(Q, c1, false, l, fM1);
+    vft_quad_model_freq<REAL>(Q, c2, false, l, fM2);
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) {
+        fM1[i] = fM1[i] * e1[l + 4 * i];
+        fM2[i] = fM2[i] * e2[l + 4 * i];
+        fPost[i] = 0;
+    }
+#pragma unroll
+    for (int jq = 0; jq < VFT_QS; jq++) {
+#pragma unroll
+        for (int jl = 0; jl < 4; jl++) {
+            const int j = jl + 4 * jq;
+            const REAL *cf = Q->codeFreq + j * 20;
+            REAL s1 = 0, s2 = 0;
+#pragma unroll
+            for (int i = 0; i < VFT_QS; i++) {   // vft_red4_mul(fM1, cf), vft_red4_mul(fM2, cf): accumulator l
+                const REAL c = cf[l + 4 * i];
+                const REAL p1 = fM1[i] * c, p2 = fM2[i] * c;
+                s1 = p1 + s1;
+                s2 = p2 + s2;
+            }
+            const REAL d1 = vft_quad_red4<REAL>(s1), d2 = vft_quad_red4<REAL>(s2);
+            REAL value = d1 * d2;
+            value = value * Q->statInv[j];
+            value = value >= 0 ? value : (REAL) 0;
+            if (jl == l) fPost[jq] = value;   // state j belongs to lane j % 4
+        }
+    }
+    REAL st = 0;
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) st = fPost[i] + st;   // vft_red4_sum
+    const double tot = (double) vft_quad_red4<REAL>(st);
+    const REAL invr = (REAL) (1.0 / tot);
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) fPost[i] = fPost[i] * invr;
+#pragma unroll
+    for (int jq = 0; jq < VFT_QS; jq++) {
+#pragma unroll
+        for (int jl = 0; jl < 4; jl++) {
+            const int j = jl + 4 * jq;
+            const REAL *ei = Q->eigenInv + j * 20;
+            REAL sv = 0;
+#pragma unroll
+            for (int i = 0; i < VFT_QS; i++) {   // vft_red4_mul(fPost, eigeninv row j)
+                const REAL pr = fPost[i] * ei[l + 4 * i];
+                sv = pr + sv;
+            }
+            const REAL v = vft_quad_red4<REAL>(sv);
+            if (jl == l) o.f[jq] = v;
+        }
+    }
+    o.vec = true;   // code == NOCODE, w == 1
+}
+
 #define VFT_MLOPT_WG 256
 // Threads per workgroup of the two line-search kernels.  20-state alphabets: 512, so that alignments up to 512 columns
 // run with ONE column per thread - a thread keeps its columns of the three / four profiles in registers, 160 VGPRs per
@@ -733,29 +995,39 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
     return x;
 }
 
-template <typename REAL, int NC, int CPT>
+template <typename REAL, int NC, int CPT, bool QUAD>
 __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
                                                                   const int64_t *recN, REAL *blen, double minLen,
                                                                   double minRel, double ftol, double atol,
                                                                   unsigned int *evalCount) {
+    static_assert(!QUAD || NC == 20, "quads of lanes hold 20-state columns");
+    constexpr int WG = MlOptWG<NC>::value;
+    constexpr int LPC = QUAD ? 4 : 1, NS = NC / LPC, CW = WG / LPC, COLS = CPT * CW;   // lanes per column, states per lane, columns per pass
+    typedef Col<REAL, NS> ColT;
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
-    constexpr int WG = MlOptWG<NC>::value;
     __shared__ double red[WG / 64];
-    __shared__ double stage[CPT * WG];   // ordered total of matrix models (vft_lk_total_ordered)
-    __shared__ double stageLog[CPT * WG];
-    __shared__ double stageList[CPT * WG * 3 / 2];
-    __shared__ signed char stageEvents[CPT * WG / 2];
+    __shared__ double stage[COLS];   // ordered total of matrix models (vft_lk_total_staged)
+    __shared__ double stageLog[COLS];
+    __shared__ double stageList[COLS * 3 / 2];
+    __shared__ signed char stageEvents[COLS / 2];
     __shared__ LkOrderedShared ordSh;
+    __shared__ typename std::conditional<QUAD, MlQuadTables<REAL>, int>::type quadTab;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
+    const int ql = QUAD ? (int) (threadIdx.x & 3) : 0, qc = (int) threadIdx.x / LPC;
+    if constexpr (QUAD) vft_quad_tables_load<REAL>(A, &quadTab);
     int rc[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+        const int64_t p = (int64_t) qc + (int64_t) c * CW;
         rc[c] = p < nPos ? A.ratecat[p] : 0;
     }
+    auto eigenTable = [&](double len, REAL *out) {
+        if constexpr (QUAD) vft_quad_exp_eigen_rates<REAL>(&quadTab, A.nRates, len, minRel, out);
+        else vft_exp_eigen_rates<REAL, NC>(A, len, minRel, out);
+    };
     // tables of the two branch lengths of a posterior, into LDS (the caller synchronises)
     auto tables2 = [&](double l1, double l2) {
         if (l1 < minLen) l1 = minLen;   // NJ.tcc:2150-2155
@@ -766,8 +1038,21 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<RE
                 vft_psame_pdiff(l2, (double) A.rates[r], pS2[r], pD2[r]);
             }
         } else {
-            vft_exp_eigen_rates<REAL, NC>(A, l1, minRel, ee1);
-            vft_exp_eigen_rates<REAL, NC>(A, l2, minRel, ee2);
+            eigenTable(l1, ee1);
+            eigenTable(l2, ee2);
+        }
+    };
+    auto loadCol = [&](int64_t node, int64_t p, ColT &c) {
+        if constexpr (QUAD) vft_quad_load_col_ml<REAL>(A, node, p, ql, c);
+        else vft_load_col_ml<REAL, NC>(A, node, p, c);
+    };
+    // posteriorProfile of one column from the tables in ee1 / ee2 (pS1.. under Jukes-Cantor)
+    auto post = [&](const ColT &c1, const ColT &c2, int r, ColT &o) {
+        if constexpr (QUAD) {
+            vft_quad_posterior_col<REAL>(&quadTab, c1, c2, ee1 + r * NC, ee2 + r * NC, ql, o);
+        } else {
+            vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, o.w, o.code, o.f);
+            o.vec = o.code == VFT_NOCODE_ && o.w > (REAL) 0;
         }
     };
     unsigned int nEval = 0;
@@ -778,19 +1063,16 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<RE
         __syncthreads();   // the previous round's writes to blen[] and reads of the tables are done
         tables2((double) blen[lenIdx[3 * k + b1]], (double) blen[lenIdx[3 * k + b2]]);
         __syncthreads();
-        Col<REAL, NC> pA[CPT], pB[CPT];
+        ColT pA[CPT], pB[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+            const int64_t p = (int64_t) qc + (int64_t) c * CW;
             if (p < nPos) {
-                Col<REAL, NC> c1, c2;
-                vft_load_col_ml<REAL, NC>(A, n1, p, c1);
-                vft_load_col_ml<REAL, NC>(A, n2, p, c2);
-                const int r = rc[c];
-                vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC,
-                                            pB[c].w, pB[c].code, pB[c].f);
-                pB[c].vec = pB[c].code == VFT_NOCODE_ && pB[c].w > (REAL) 0;
-                vft_load_col_ml<REAL, NC>(A, nI, p, pA[c]);
+                ColT c1, c2;
+                loadCol(n1, p, c1);
+                loadCol(n2, p, c2);
+                post(c1, c2, rc[c], pB[c]);
+                loadCol(nI, p, pA[c]);
             }
         }
         // -pairLogLk(P_i, posterior, x), collectively.  No barrier in front: the previous evaluation ended with one after
@@ -800,43 +1082,46 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<RE
             if (jc) {
                 for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r]);
             } else {
-                vft_exp_eigen_rates<REAL, NC>(A, x, minRel, ee1);
+                eigenTable(x, ee1);
             }
             __syncthreads();
             if (!jc) {   // matrix model: the reference's ordered total
-                double col[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; c++) {
-                    const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-                    col[c] = VFT_LK_SKIP;
+                    const int64_t p = (int64_t) qc + (int64_t) c * CW;
                     if (p < nPos) {
                         const int r = rc[c];
                         double lkAB;
-                        if (vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB)) col[c] = lkAB;
+                        bool ok;
+                        if constexpr (QUAD) ok = vft_quad_pair_lk_col<REAL>(&quadTab, pA[c], pB[c], ee1 + r * NC, ql, lkAB);
+                        else ok = vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB);
+                        if (ql == 0) vft_lk_stage(stage, stageLog, (int) p, ok ? lkAB : VFT_LK_SKIP);
                     }
                 }
                 nEval++;
-                return -vft_lk_total_ordered<WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
+                return -vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc);
             }
-            double lk = 1.0, loglk = 0.0;
-#pragma unroll
-            for (int c = 0; c < CPT; c++) {
-                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-                if (p < nPos) {
-                    const int r = rc[c];
-                    double lkAB;
-                    if (vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB))
-                        vft_lk_accumulate(lkAB, jc, lk, loglk);
-                }
-            }
-            double part = loglk + log(lk);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-            __syncthreads();
             double tot = 0;
+            if constexpr (!QUAD) {
+                double lk = 1.0, loglk = 0.0;
 #pragma unroll
-            for (int w = 0; w < WG / 64; w++) tot += red[w];
+                for (int c = 0; c < CPT; c++) {
+                    const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+                    if (p < nPos) {
+                        const int r = rc[c];
+                        double lkAB;
+                        if (vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB))
+                            vft_lk_accumulate(lkAB, jc, lk, loglk);
+                    }
+                }
+                double part = loglk + log(lk);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < WG / 64; w++) tot += red[w];
+            }
             nEval++;
             return -tot;
         };
@@ -854,16 +1139,14 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<RE
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+        const int64_t p = (int64_t) qc + (int64_t) c * CW;
         if (p < nPos) {
-            Col<REAL, NC> c1, c2;
-            vft_load_col_ml<REAL, NC>(A, ids[3 * k], p, c1);
-            vft_load_col_ml<REAL, NC>(A, ids[3 * k + 1], p, c2);
-            const int r = rc[c];
-            REAL wo, f[NC];
-            int co;
-            vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS1[r], pD1[r], pS2[r], pD2[r], ee1 + r * NC, ee2 + r * NC, wo, co, f);
-            vft_store_col_ml<REAL, NC>(A, rec, p, wo, co, f);
+            ColT c1, c2, o;
+            loadCol(ids[3 * k], p, c1);
+            loadCol(ids[3 * k + 1], p, c2);
+            post(c1, c2, rc[c], o);
+            if constexpr (QUAD) vft_quad_store_col_ml<REAL>(A, rec, p, ql, o.w, o.code, o.f);
+            else vft_store_col_ml<REAL, NC>(A, rec, p, o.w, o.code, o.f);
         }
     }
     if (threadIdx.x == 0) A.mlIs[rec - A.d.nSeqs] = 1;
@@ -899,28 +1182,34 @@ struct QuartetNNIState {
     int32_t consider1, consider2, done, star;
 };
 
-template <typename REAL, int NC, int CPT>
+template <typename REAL, int NC, int CPT, bool QUAD>
 __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
                                                              double minLen, double minRel, double ftol, double atol,
                                                              double closeLimit, int mlAccuracy, int mode, double *loglkOut,
                                                              double *siteOut, double *lenOut, QuartetNNIResult *nniOut,
                                                              QuartetNNIState *nniState, unsigned int *evalCount) {
+    static_assert(!QUAD || NC == 20, "quads of lanes hold 20-state columns");
+    constexpr int WG = MlOptWG<NC>::value;
+    constexpr int LPC = QUAD ? 4 : 1, NS = NC / LPC, CW = WG / LPC, COLS = CPT * CW;   // lanes per column, states per lane, columns per pass
+    typedef Col<REAL, NS> ColT;
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
     __shared__ double pS[4][VFT_MAXRATES], pD[4][VFT_MAXRATES];
-    constexpr int WG = MlOptWG<NC>::value;
     __shared__ double red[WG / 64];
-    __shared__ double stage[CPT * WG];   // ordered total of matrix models (vft_lk_total_ordered)
-    __shared__ double stageLog[CPT * WG];
-    __shared__ double stageList[CPT * WG * 3 / 2];
-    __shared__ signed char stageEvents[CPT * WG / 2];
+    __shared__ double stage[COLS];   // ordered total of matrix models (vft_lk_total_staged)
+    __shared__ double stageLog[COLS];
+    __shared__ double stageList[COLS * 3 / 2];
+    __shared__ signed char stageEvents[COLS / 2];
     __shared__ LkOrderedShared ordSh;
+    __shared__ typename std::conditional<QUAD, MlQuadTables<REAL>, int>::type quadTab;
     const int64_t k = blockIdx.x;
     const bool jc = A.tmStat == nullptr;
     const int64_t nPos = A.d.nPos;
+    const int ql = QUAD ? (int) (threadIdx.x & 3) : 0, qc = (int) threadIdx.x / LPC;
+    if constexpr (QUAD) vft_quad_tables_load<REAL>(A, &quadTab);
     int rc[CPT];   // rate category of the thread's columns; -1 beyond the alignment (such columns hold no data at all)
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
-        const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+        const int64_t p = (int64_t) qc + (int64_t) c * CW;
         rc[c] = p < nPos ? A.ratecat[p] : -1;
     }
     unsigned int nEval = 0;
@@ -933,81 +1222,90 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
         if (jc) {
             for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(len, (double) A.rates[r], pS[s][r], pD[s][r]);
         } else {
-            vft_exp_eigen_rates<REAL, NC>(A, len, minRel, ee[s]);
+            if constexpr (QUAD) vft_quad_exp_eigen_rates<REAL>(&quadTab, A.nRates, len, minRel, ee[s]);
+            else vft_exp_eigen_rates<REAL, NC>(A, len, minRel, ee[s]);
         }
     };
-    auto post = [&](const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, int s1, int s2, int r, Col<REAL, NC> &o) {
+    auto post = [&](const ColT &c1, const ColT &c2, int s1, int s2, int r, ColT &o) {
         if (r < 0) return;
-        vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS[s1][r], pD[s1][r], pS[s2][r], pD[s2][r], ee[s1] + r * NC, ee[s2] + r * NC,
-                                    o.w, o.code, o.f);
-        o.vec = o.code == VFT_NOCODE_ && o.w > (REAL) 0;
+        if constexpr (QUAD) {
+            vft_quad_posterior_col<REAL>(&quadTab, c1, c2, ee[s1] + r * NC, ee[s2] + r * NC, ql, o);
+        } else {
+            vft_posterior_col<REAL, NC>(A, c1, c2, jc, pS[s1][r], pD[s1][r], pS[s2][r], pD[s2][r], ee[s1] + r * NC, ee[s2] + r * NC,
+                                        o.w, o.code, o.f);
+            o.vec = o.code == VFT_NOCODE_ && o.w > (REAL) 0;
+        }
     };
     // pairLogLk(X, Y, len) over the workgroup (table slot 0); site != nullptr: multiply the per-site likelihoods in
     // (lead: barrier in front - needed unless the previous thing the workgroup did was another pairTotal, whose final
     //  barrier already came after every wave's last table read)
-    auto pairTotal = [&](const Col<REAL, NC> *X, const Col<REAL, NC> *Y, double len, double *site, bool lead = true) -> double {
+    auto pairTotal = [&](const ColT *X, const ColT *Y, double len, double *site, bool lead = true) -> double {
         if (lead) __syncthreads();
         VFT_ML_TICK(0);   // whatever came before this evaluation
         table(0, len, false);
         __syncthreads();
         VFT_ML_TICK(1);   // tables
         if (!jc) {   // matrix model: the reference's ordered total
-            double col[CPT];
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
-                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-                col[c] = VFT_LK_SKIP;
+                const int64_t p = (int64_t) qc + (int64_t) c * CW;
                 if (p < nPos) {
                     const int r = rc[c];
                     double lkAB;
-                    if (vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB)) {
-                        col[c] = lkAB;
-                        if (site) site[c] *= lkAB;
-                    }
+                    bool ok;
+                    if constexpr (QUAD) ok = vft_quad_pair_lk_col<REAL>(&quadTab, X[c], Y[c], ee[0] + r * NC, ql, lkAB);
+                    else ok = vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB);
+                    if (ok && site) site[c] *= lkAB;
+                    if (ql == 0) vft_lk_stage(stage, stageLog, (int) p, ok ? lkAB : VFT_LK_SKIP);
                 }
             }
             nEval++;
             VFT_ML_TICK(2);   // column likelihoods
-            const double total_ = vft_lk_total_ordered<WG, CPT>(stage, stageLog, stageList, stageEvents, &ordSh, col, nPos, jc);
+            const double total_ = vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc);
             VFT_ML_TICK(3);   // ordered total
             return total_;
         }
-        double lk = 1.0, loglk = 0.0;
+        double tot = 0;
+        if constexpr (!QUAD) {
+            double lk = 1.0, loglk = 0.0;
 #pragma unroll
-        for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-            if (p < nPos) {
-                const int r = rc[c];
-                double lkAB;
-                if (vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB)) {
-                    vft_lk_accumulate(lkAB, jc, lk, loglk);
-                    if (site) site[c] *= lkAB;
+            for (int c = 0; c < CPT; c++) {
+                const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
+                if (p < nPos) {
+                    const int r = rc[c];
+                    double lkAB;
+                    if (vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB)) {
+                        vft_lk_accumulate(lkAB, jc, lk, loglk);
+                        if (site) site[c] *= lkAB;
+                    }
                 }
             }
+            double part = loglk + log(lk);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < WG / 64; w++) tot += red[w];
         }
-        double part = loglk + log(lk);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-        __syncthreads();
-        double tot = 0;
-#pragma unroll
-        for (int w = 0; w < WG / 64; w++) tot += red[w];
         nEval++;
         return tot;
     };
-    auto loadCols = [&](int64_t node, Col<REAL, NC> *dst) {
+    auto loadCols = [&](int64_t node, ColT *dst) {
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-            if (p < nPos) vft_load_col_ml<REAL, NC>(A, node, p, dst[c]);
+            const int64_t p = (int64_t) qc + (int64_t) c * CW;
+            if (p < nPos) {
+                if constexpr (QUAD) vft_quad_load_col_ml<REAL>(A, node, p, ql, dst[c]);
+                else vft_load_col_ml<REAL, NC>(A, node, p, dst[c]);
+            }
         }
     };
     auto storeSite = [&](int topo, const double *site) {
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t p = (int64_t) threadIdx.x + (int64_t) c * WG;
-            if (p < nPos)   // SHSupport takes the logs, NJ.tcc:1134-1137 (glibc's log where the totals are the reference's)
+            const int64_t p = (int64_t) qc + (int64_t) c * CW;
+            if (p < nPos && ql == 0)   // SHSupport takes the logs, NJ.tcc:1134-1137 (glibc's log where the totals are the reference's)
                 siteOut[(k * 3 + topo) * nPos + p] = (!jc && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
         }
     };
@@ -1016,7 +1314,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
 #pragma unroll
     for (int t = 0; t < 5; t++) base[t] = (double) blen[lenIdx[5 * k + t]];
     double crit[3] = {0, 0, 0};
-    Col<REAL, NC> X[CPT], Y[CPT], T[CPT];
+    ColT X[CPT], Y[CPT], T[CPT];
     double site[CPT];
 
     if (mode == 0) {
@@ -1041,7 +1339,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            Col<REAL, NC> cd;
+            ColT cd;
             post(X[c], Y[c], 1, 2, rc[c], cd);
             Y[c] = cd;                                                        // CD
         }
@@ -1126,7 +1424,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
                 loadCols(qb, Y);
 #pragma unroll
                 for (int c = 0; c < CPT; c++) {
-                    Col<REAL, NC> ab;
+                    ColT ab;
                     post(X[c], Y[c], 3, 0, rc[c], ab);
                     X[c] = ab;      // pair1 = AB
                     Y[c] = T[c];    // pair2 = CD
@@ -1348,36 +1646,42 @@ static __global__ __launch_bounds__(256) void k_sh_support(const double *siteLog
 // The two line-search kernels are by far the largest pieces of device code.  They are instantiated in their own
 // translation units (vft_ml_kernels_*.hip) so that the library builds as parallel hipcc jobs; vft_api.hip only
 // declares the instances (`extern template`).
-#define VFT_ML_NODE_LENGTHS_INSTANCE(PFX, REAL, NC, CPT)                                                                  \
-    PFX template __global__ void k_ml_node_lengths<REAL, NC, CPT>(Arena<REAL>, const int64_t *, const int64_t *, const int64_t *, \
-                                                                 REAL *, double, double, double, double, unsigned int *);
-#define VFT_ML_QUARTET_INSTANCE(PFX, REAL, NC, CPT)                                                                        \
-    PFX template __global__ void k_ml_quartet<REAL, NC, CPT>(Arena<REAL>, const int64_t *, const int64_t *, REAL *, double, double, \
-                                                            double, double, double, int, int, double *, double *, double *,  \
-                                                            QuartetNNIResult *, QuartetNNIState *, unsigned int *);
-#define VFT_ML_NODE_LENGTHS_INSTANCES(PFX)                \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 1)        \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 4)        \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 8)        \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 1)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 4)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 1)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 4)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 8)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 1)      \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 4)
-#define VFT_ML_QUARTET_INSTANCES_F32(PFX)                 \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 1)             \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 4)             \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 8)             \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 1)            \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4)
-#define VFT_ML_QUARTET_INSTANCES_F64(PFX)                 \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 1)            \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 4)            \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 8)            \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 1)           \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4)
+#define VFT_ML_NODE_LENGTHS_INSTANCE(PFX, REAL, NC, CPT, QUAD)                                                            \
+    PFX template __global__ void k_ml_node_lengths<REAL, NC, CPT, QUAD>(Arena<REAL>, const int64_t *, const int64_t *, const int64_t *, \
+                                                                       REAL *, double, double, double, double, unsigned int *);
+#define VFT_ML_QUARTET_INSTANCE(PFX, REAL, NC, CPT, QUAD)                                                                  \
+    PFX template __global__ void k_ml_quartet<REAL, NC, CPT, QUAD>(Arena<REAL>, const int64_t *, const int64_t *, REAL *, double, double, \
+                                                                  double, double, double, int, int, double *, double *, double *,  \
+                                                                  QuartetNNIResult *, QuartetNNIState *, unsigned int *);
+// 20 states: quads of lanes per column for alignments up to 512 columns under a matrix model (one or four passes of 128 columns),
+// whole columns per thread (four passes of 512) beyond that and under Jukes-Cantor
+#define VFT_ML_NODE_LENGTHS_INSTANCES(PFX)                      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 1, false)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 4, false)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 8, false)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 1, true)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 4, true)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 4, false)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 1, false)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 4, false)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 8, false)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 1, true)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 4, true)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 4, false)
+#define VFT_ML_QUARTET_INSTANCES_F32(PFX)                       \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 1, false)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 4, false)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 8, false)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 1, true)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4, true)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4, false)
+#define VFT_ML_QUARTET_INSTANCES_F64(PFX)                       \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 1, false)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 4, false)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 8, false)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 1, true)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4, true)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4, false)
 #define VFT_ML_HEAVY_INSTANCES(PFX)        \
     VFT_ML_NODE_LENGTHS_INSTANCES(PFX)     \
     VFT_ML_QUARTET_INSTANCES_F32(PFX)      \
