@@ -190,6 +190,16 @@ def end_to_end(which, device, comm=None):
         out["identical_to_reference"] = bool(want == crc)
         if "reference_wall_s" in g:
             out["reference_wall_s_1_thread"] = round(float(g["reference_wall_s"]), 1)
+    # the join order against the reference's `Join` trace as far as the reference got (C4: the one-thread reference needs more than
+    # half a day for the million-sequence NJ phase; tests/golden/bb_c4_prefix.npz holds CRC-32s per 10 000 joins of what it wrote)
+    pre = os.path.join(ROOT, "tests", "golden", "bb_%s_prefix.npz" % which)
+    if os.path.exists(pre):
+        from veryfasttree_amd.backend import last_join_crcs
+        g = np.load(pre)
+        chunk, n_joins, crcs = last_join_crcs()
+        k = min(len(crcs), len(g["join_chunk_crc"])) if chunk == int(g["join_chunk"]) else 0
+        out["reference_joins_compared"] = int(k * chunk)
+        out["join_order_identical_to_reference_prefix"] = bool(k > 0 and np.array_equal(crcs[:k].astype(np.int64), g["join_chunk_crc"][:k]))
     return out
 
 

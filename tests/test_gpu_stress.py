@@ -101,3 +101,11 @@ def test_nj_runs_are_reproducible():
             os.environ.pop("VFT_NJ_HOST_JOINS", None)
     for rep in range(1, 6):
         assert np.array_equal(runs[0][0], runs[rep][0]) and np.array_equal(runs[0][1], runs[rep][1]), rep
+    # the join-order checksums a tree-only caller can ask for afterwards (vft_nj_last_join_crcs): zlib's CRC-32 per 10 000 joins
+    import zlib
+    from veryfasttree_amd.backend import last_join_crcs
+    chunk, n_joins, crcs = last_join_crcs()
+    joins = runs[5][0]
+    assert chunk == 10000 and n_joins == len(joins) and len(crcs) == len(joins) // chunk >= 1
+    for k in range(len(crcs)):
+        assert int(crcs[k]) == zlib.crc32(joins[k * chunk:(k + 1) * chunk].astype("<i4").tobytes()), k

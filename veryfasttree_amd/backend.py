@@ -44,7 +44,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(HERE, "lib", "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
                 "vft_aa_model_tables", "vft_blosum45_tables", "vft_aa_model_as_distance_tables"]
 
 
@@ -279,6 +279,16 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     if return_loglk:
         return out.value.decode(), loglk[:n_rounds.value]
     return out.value.decode()
+
+
+def last_join_crcs():
+    """(chunk, n_joins, crcs): CRC-32 per complete chunk of joins of the last NJ run of this process (vft_nj_last_join_crcs)"""
+    lib = load_host_library()
+    chunk, nj, nc = I64(0), I64(0), I64(0)
+    lib.vft_nj_last_join_crcs(C.byref(chunk), C.byref(nj), None, I64(0), C.byref(nc))
+    crcs = np.zeros(max(nc.value, 1), np.uint32)
+    lib.vft_nj_last_join_crcs(None, None, _ptr(crcs), I64(nc.value), None)
+    return chunk.value, nj.value, crcs[:nc.value]
 
 
 def load_library():

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <type_traits>
@@ -13,6 +14,54 @@
 #include "MLLengths.h"
 #include "GtrModel.h"
 #include "AAModels.h"
+
+// CRC-32 (the zlib polynomial) of the last join order this process produced, per chunk of joins: lets a caller that only asked
+// for the tree (vft_nj_newick at a million sequences) compare the join order with a prefix of the reference's `Join` lines
+static std::mutex gJoinCrcMutex;
+static std::vector<uint32_t> gJoinCrc;
+static int64_t gJoinCrcChunk = 10000, gJoinCrcJoins = 0;
+
+static uint32_t crc32Bytes(const unsigned char *p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+template<typename JOINS>
+static void recordJoinCrc(const JOINS &js) {
+    std::lock_guard<std::mutex> lock(gJoinCrcMutex);
+    gJoinCrc.clear();
+    gJoinCrcJoins = (int64_t) js.size();
+    std::vector<int32_t> buf((size_t) gJoinCrcChunk * 3);
+    for (size_t k0 = 0; k0 + (size_t) gJoinCrcChunk <= js.size(); k0 += (size_t) gJoinCrcChunk) {
+        for (size_t k = 0; k < (size_t) gJoinCrcChunk; k++) {
+            buf[3 * k] = (int32_t) js[k0 + k].i;
+            buf[3 * k + 1] = (int32_t) js[k0 + k].j;
+            buf[3 * k + 2] = (int32_t) js[k0 + k].newnode;
+        }
+        gJoinCrc.push_back(crc32Bytes((const unsigned char *) buf.data(), buf.size() * 4));
+    }
+}
+
+extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *crcs, int64_t cap, int64_t *nCrcs) {
+    std::lock_guard<std::mutex> lock(gJoinCrcMutex);
+    if (chunk) *chunk = gJoinCrcChunk;
+    if (nJoins) *nJoins = gJoinCrcJoins;
+    if (nCrcs) *nCrcs = (int64_t) gJoinCrc.size();
+    if (crcs)
+        for (int64_t k = 0; k < cap && k < (int64_t) gJoinCrc.size(); k++) crcs[k] = gJoinCrc[(size_t) k];
+    return VFT_OK;
+}
 
 static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
@@ -42,7 +91,7 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
                            int64_t nAll, const char *names, std::vector<double> &loglk, std::vector<double> &rates,
                            std::vector<int64_t> &ratecat, double *gtrOut) {
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
-    drv.run(-1);
+    recordJoinCrc(drv.run(-1));
     drv.finishRoot();
     if (o && o->me_nni) drv.meNNIRounds(o->spr);
     if (meLengths) drv.updateBranchLengths();
@@ -122,6 +171,7 @@ static int64_t runDriver(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, int6
     const veryfasttree::NJOptions opt = toOptions(o);
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, opt);
     const auto &js = drv.run(maxJoins);
+    recordJoinCrc(js);
     drv.report();
     for (size_t k = 0; k < js.size(); k++) {
         joins[3 * k] = js[k].i;
