@@ -3000,9 +3000,10 @@ static inline int mlopt_wg(const vft_ctx *c) { return c->d.nCodes == 20 ? MlOptW
 // to 512 columns: a quad of lanes per column (`quad`; one or four passes of 128 columns); otherwise whole columns per thread.
 static inline int mlopt_cpt(const vft_ctx *c, bool &quad) {
     quad = false;
-    if (c->d.nCodes == 20 && c->hasTm && c->d.nPos <= MlOptWG<20>::value) {
+    if (c->d.nCodes == 20 && c->hasTm && c->d.nPos <= 8 * (MlLineWG<20, true>::value / 4)) {
         quad = true;
-        return c->d.nPos <= MlOptWG<20>::value / 4 ? 1 : 4;
+        const int64_t per = cdiv(c->d.nPos, MlLineWG<20, true>::value / 4);
+        return per <= 2 ? 2 : per <= 5 ? 5 : 8;
     }
     const int64_t per = cdiv(c->d.nPos, mlopt_wg(c));
     if (c->d.nCodes == 20) return per <= 4 ? 4 : 0;
@@ -3013,11 +3014,12 @@ template <typename REAL, int NC>
 static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, bool quad, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
                               double ftol, double atol) {
 #define VFT_MLOPT_GO(CPT, QUAD)                                                                                         \
-    launch((k_ml_node_lengths<REAL, NC, CPT, QUAD>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream, arena<REAL>(c), \
+    launch((k_ml_node_lengths<REAL, NC, CPT, QUAD>), dim3((unsigned) n), dim3(MlLineWG<NC, QUAD>::value), 0, c->stream, arena<REAL>(c), \
            dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals)
     if constexpr (NC == 20) {
-        if (quad && cpt == 1) VFT_MLOPT_GO(1, true);
-        else if (quad && cpt == 4) VFT_MLOPT_GO(4, true);
+        if (quad && cpt == 2) VFT_MLOPT_GO(2, true);
+        else if (quad && cpt == 5) VFT_MLOPT_GO(5, true);
+        else if (quad && cpt == 8) VFT_MLOPT_GO(8, true);
         else if (!quad && cpt == 4) VFT_MLOPT_GO(4, false);
         else return fail(c, VFT_ERR_INVALID, "vft_ml_optimize_splits: alignment too long for the in-kernel optimiser");
     } else {
@@ -3076,12 +3078,13 @@ static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, bool quad, const in
                              double closeLimit, int mlAccuracy, int mode, double *dLoglk, double *dSite, double *dLen,
                              QuartetNNIResult *dNni, QuartetNNIState *dState = nullptr) {
 #define VFT_MLQ_GO(CPT, QUAD)                                                                                           \
-    launch((k_ml_quartet<REAL, NC, CPT, QUAD>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlOptWG<NC>::value), 0, c->stream, \
+    launch((k_ml_quartet<REAL, NC, CPT, QUAD>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlLineWG<NC, QUAD>::value), 0, c->stream, \
            arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode,  \
            dLoglk, dSite, dLen, dNni, dState, c->mlEvals)
     if constexpr (NC == 20) {
-        if (quad && cpt == 1) VFT_MLQ_GO(1, true);
-        else if (quad && cpt == 4) VFT_MLQ_GO(4, true);
+        if (quad && cpt == 2) VFT_MLQ_GO(2, true);
+        else if (quad && cpt == 5) VFT_MLQ_GO(5, true);
+        else if (quad && cpt == 8) VFT_MLQ_GO(8, true);
         else if (!quad && cpt == 4) VFT_MLQ_GO(4, false);
         else return fail(c, VFT_ERR_INVALID, "alignment too long for the in-kernel quartet optimiser");
     } else {

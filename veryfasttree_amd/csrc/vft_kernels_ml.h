@@ -205,6 +205,29 @@ __device__ __forceinline__ void vft_lk_stage(double *stage, double *stageLog, in
     stageLog[p] = log2(a);
 }
 
+// step 1 for the CPT columns p = qc + c * CW of a group of LPC lanes that all hold the columns' likelihoods (LPC = 4: lane l takes
+// the columns c = l, l + 4, ... - the logarithm is most of the staging, one lane doing all of them left three idle)
+template <int CPT, int LPC>
+__device__ __forceinline__ void vft_lk_stage_cols(double *stage, double *stageLog, const double (&lk)[CPT], int qc, int ql, int CW, int nPos) {
+    if (LPC == 1) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int p = qc + c * CW;
+            if (p < nPos) vft_lk_stage(stage, stageLog, p, lk[c]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < (CPT + LPC - 1) / LPC; g++) {
+        double v = VFT_LK_SKIP;
+#pragma unroll
+        for (int l = 0; l < LPC; l++)
+            if (g * LPC + l < CPT && ql == l) v = lk[g * LPC + l];
+        const int c = g * LPC + ql, p = qc + c * CW;
+        if (c < CPT && p < nPos) vft_lk_stage(stage, stageLog, p, v);
+    }
+}
+
 // steps 2 and 3 over stage[0, nPos) / stageLog[0, nPos); COLS: capacity of the staging arrays (list: COLS * 3 / 2, events: COLS / 2)
 template <int WG, int COLS>
 __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *stageLog, double *list, signed char *events,
@@ -847,8 +870,11 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
         fM2[i] = fM2[i] * e2[l + 4 * i];
         fPost[i] = 0;
     }
-#pragma unroll
+    // (the loops over the 20 states run as loops of five trips: unrolled, one posterior was 12 KB of straight-line code - per
+    //  column and per place it is used - and the kernels executed from a cold instruction cache)
+#pragma unroll 1
     for (int jq = 0; jq < VFT_QS; jq++) {
+        REAL mine = 0;
 #pragma unroll
         for (int jl = 0; jl < 4; jl++) {
             const int j = jl + 4 * jq;
@@ -865,8 +891,10 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
             REAL value = d1 * d2;
             value = value * Q->statInv[j];
             value = value >= 0 ? value : (REAL) 0;
-            if (jl == l) fPost[jq] = value;   // state j belongs to lane j % 4
+            if (jl == l) mine = value;   // state j belongs to lane j % 4
         }
+#pragma unroll
+        for (int q = 0; q < VFT_QS; q++) fPost[q] = q == jq ? mine : fPost[q];
     }
     REAL st = 0;
 #pragma unroll
@@ -875,8 +903,9 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
     const REAL invr = (REAL) (1.0 / tot);
 #pragma unroll
     for (int i = 0; i < VFT_QS; i++) fPost[i] = fPost[i] * invr;
-#pragma unroll
+#pragma unroll 1
     for (int jq = 0; jq < VFT_QS; jq++) {
+        REAL mine = 0;
 #pragma unroll
         for (int jl = 0; jl < 4; jl++) {
             const int j = jl + 4 * jq;
@@ -888,8 +917,10 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
                 sv = pr + sv;
             }
             const REAL v = vft_quad_red4<REAL>(sv);
-            if (jl == l) o.f[jq] = v;
+            if (jl == l) mine = v;
         }
+#pragma unroll
+        for (int q = 0; q < VFT_QS; q++) o.f[q] = q == jq ? mine : o.f[q];
     }
     o.vec = true;   // code == NOCODE, w == 1
 }
@@ -902,10 +933,18 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
 // change there: matrix models take their totals in column order (vft_lk_total_ordered).  Nucleotides keep 256: the
 // Jukes-Cantor totals are per-thread products summed in thread order, and that order is pinned by the fixtures.
 template <int NC> struct MlOptWG { static const int value = NC == 20 ? 512 : VFT_MLOPT_WG; };
+// ... and with a quad of lanes per column (proteins under a matrix model, up to 512 columns): 256 threads = 64 columns per pass.
+// One wavefront per SIMD may use all 512 VGPRs: the kernels' scalar state (Brent's variables, three pairings' lengths) takes ~250
+// of them, five columns of three profiles ~210; at 512 threads (256 VGPRs per lane) the columns went to scratch, 6 us per evaluation.
+template <int NC, bool QUAD> struct MlLineWG { static const int value = QUAD ? 256 : MlOptWG<NC>::value; };
 #define VFT_MLOPT_MAXLEN 6.0
 
 // Brent's minimiser with the reference's bracketing (onedimenmin): all threads run it in lockstep on uniform values;
-// `eval` is a workgroup-collective call.
+// `eval` is a workgroup-collective call.  Written as ONE loop around ONE call of eval - the bracket's three points, the two
+// widening loops and Brent's iterations are states of it: `eval` is the whole likelihood evaluation, inlined, and six copies of
+// it per search (times the searches of a kernel) made kernels of 0.2 - 1 MB whose every evaluation ran from a cold instruction
+// cache (round 2: everything in these kernels took 3 - 4 times what its instructions cost).  Same evaluations in the same
+// order, same arithmetic.
 template <typename EVAL>
 __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin, double xguess, double xmax, double ftol,
                                                         double atol, double &fBest) {
@@ -926,29 +965,74 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
     }
     if (hi > xmax) hi = xmax;
     if (mid >= hi) mid = 0.5 * (lo + hi);
-    double fLo = eval(lo), fMid = eval(mid), fHi = eval(hi);
-    // widen towards the limits while the minimum is not inside
-    while (fLo < fMid && lo > xmin) {
-        lo = (lo + xmin) / 2.0;
-        if (lo < 2.0 * xmin) lo = xmin;
-        fLo = eval(lo);
-    }
-    while (fHi < fMid && hi < xmax) {
-        hi = (hi + xmax) / 2.0;
-        if (hi > xmax * 0.95) hi = xmax;
-        fHi = eval(hi);
-    }
-    // Brent: x = best point, w = second best, v = previous w; [a, b] brackets the minimum
     const double golden = 0.3819660, zeps = 1.0e-10;
-    double a = lo < hi ? lo : hi, b = lo > hi ? lo : hi;
-    double x = mid, fx = fMid, w, fw, v, fv;
-    if (fLo < fHi) {
-        w = lo; fw = fLo; v = hi; fv = fHi;
-    } else {
-        w = hi; fw = fHi; v = lo; fv = fLo;
-    }
-    double step = 0.0, prevStep = 0.0;
-    for (int it = 0; it < 100; it++) {
+    double fLo = 0, fMid = 0, fHi = 0;
+    // Brent: x = best point, w = second best, v = previous w; [a, b] brackets the minimum
+    double a = 0, b = 0, x = mid, fx = 0, w = 0, fw = 0, v = 0, fv = 0, step = 0.0, prevStep = 0.0, u = 0;
+    // state: 0, 1, 2 = f(lo), f(mid), f(hi) of the bracket; 3 / 4 = a step of the first / second widening loop; 5 = Brent
+    int state = 0, it = 0;
+    double xe = lo;
+#pragma unroll 1
+    for (;;) {
+        const double f = eval(xe);
+        if (state == 0) {
+            fLo = f;
+            xe = mid;
+            state = 1;
+            continue;
+        }
+        if (state == 1) {
+            fMid = f;
+            xe = hi;
+            state = 2;
+            continue;
+        }
+        if (state == 2 || state == 4) fHi = f;
+        else if (state == 3) fLo = f;
+        if (state <= 3 && fLo < fMid && lo > xmin) {   // widen towards the lower limit while the minimum is not inside
+            lo = (lo + xmin) / 2.0;
+            if (lo < 2.0 * xmin) lo = xmin;
+            xe = lo;
+            state = 3;
+            continue;
+        }
+        if (state <= 4) {
+            if (fHi < fMid && hi < xmax) {   // ... and towards the upper one
+                hi = (hi + xmax) / 2.0;
+                if (hi > xmax * 0.95) hi = xmax;
+                xe = hi;
+                state = 4;
+                continue;
+            }
+            a = lo < hi ? lo : hi;
+            b = lo > hi ? lo : hi;
+            x = mid;
+            fx = fMid;
+            if (fLo < fHi) {
+                w = lo; fw = fLo; v = hi; fv = fHi;
+            } else {
+                w = hi; fw = fHi; v = lo; fv = fLo;
+            }
+            state = 5;
+        } else {   // f = f(u) of a Brent step
+            const double fu = f;
+            if (fu <= fx) {
+                if (u >= x) a = x; else b = x;
+                v = w; w = x; x = u;
+                fv = fw; fw = fx; fx = fu;
+            } else {
+                if (u < x) a = u; else b = u;
+                if (fu <= fw || w == x) {
+                    v = w; w = u;
+                    fv = fw; fw = fu;
+                } else if (fu <= fv || v == x || v == w) {
+                    v = u;
+                    fv = fu;
+                }
+            }
+        }
+        // the next Brent step, or the end
+        if (it == 100) break;
         const double xm = 0.5 * (a + b);
         const double tol1 = ftol * fabs(x), tol2 = 2.0 * (tol1 + zeps);
         if (fabs(x - xm) <= (tol2 - 0.5 * (b - a)) || fabs(a - b) < atol) break;
@@ -965,8 +1049,8 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
             prevStep = step;
             if (!(fabs(p) >= fabs(0.5 * q * before) || p <= q * (a - x) || p >= q * (b - x))) {
                 step = p / q;
-                const double u = x + step;
-                if (u - a < tol2 || b - u < tol2) step = (xm - x) >= 0.0 ? fabs(tol1) : -fabs(tol1);
+                const double uu = x + step;
+                if (uu - a < tol2 || b - uu < tol2) step = (xm - x) >= 0.0 ? fabs(tol1) : -fabs(tol1);
                 goldenStep = false;
             }
         }
@@ -974,34 +1058,21 @@ __device__ __forceinline__ double vft_min_branch_length(EVAL &&eval, double xmin
             prevStep = x >= xm ? a - x : b - x;
             step = golden * prevStep;
         }
-        const double u = fabs(step) >= tol1 ? x + step : x + (step >= 0.0 ? fabs(tol1) : -fabs(tol1));
-        const double fu = eval(u);
-        if (fu <= fx) {
-            if (u >= x) a = x; else b = x;
-            v = w; w = x; x = u;
-            fv = fw; fw = fx; fx = fu;
-        } else {
-            if (u < x) a = u; else b = u;
-            if (fu <= fw || w == x) {
-                v = w; w = u;
-                fv = fw; fw = fu;
-            } else if (fu <= fv || v == x || v == w) {
-                v = u;
-                fv = fu;
-            }
-        }
+        u = fabs(step) >= tol1 ? x + step : x + (step >= 0.0 ? fabs(tol1) : -fabs(tol1));
+        xe = u;
+        it++;
     }
     fBest = fx;
     return x;
 }
 
 template <typename REAL, int NC, int CPT, bool QUAD>
-__global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
+__global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_node_lengths(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx,
                                                                   const int64_t *recN, REAL *blen, double minLen,
                                                                   double minRel, double ftol, double atol,
                                                                   unsigned int *evalCount) {
     static_assert(!QUAD || NC == 20, "quads of lanes hold 20-state columns");
-    constexpr int WG = MlOptWG<NC>::value;
+    constexpr int WG = MlLineWG<NC, QUAD>::value;
     constexpr int LPC = QUAD ? 4 : 1, NS = NC / LPC, CW = WG / LPC, COLS = CPT * CW;   // lanes per column, states per lane, columns per pass
     typedef Col<REAL, NS> ColT;
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
@@ -1047,7 +1118,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<RE
         else vft_load_col_ml<REAL, NC>(A, node, p, c);
     };
     // posteriorProfile of one column from the tables in ee1 / ee2 (pS1.. under Jukes-Cantor)
-    auto post = [&](const ColT &c1, const ColT &c2, int r, ColT &o) {
+    auto post = [&](const ColT &c1, const ColT &c2, int r, ColT &o) __attribute__((always_inline)) {
         if constexpr (QUAD) {
             vft_quad_posterior_col<REAL>(&quadTab, c1, c2, ee1 + r * NC, ee2 + r * NC, ql, o);
         } else {
@@ -1086,18 +1157,21 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_node_lengths(Arena<RE
             }
             __syncthreads();
             if (!jc) {   // matrix model: the reference's ordered total
+                double col[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; c++) {
                     const int64_t p = (int64_t) qc + (int64_t) c * CW;
+                    col[c] = VFT_LK_SKIP;
                     if (p < nPos) {
                         const int r = rc[c];
                         double lkAB;
                         bool ok;
                         if constexpr (QUAD) ok = vft_quad_pair_lk_col<REAL>(&quadTab, pA[c], pB[c], ee1 + r * NC, ql, lkAB);
                         else ok = vft_pair_lk_col<REAL, NC>(A, pA[c], pB[c], jc, pS1[r], pD1[r], ee1 + r * NC, lkAB);
-                        if (ql == 0) vft_lk_stage(stage, stageLog, (int) p, ok ? lkAB : VFT_LK_SKIP);
+                        if (ok) col[c] = lkAB;
                     }
                 }
+                vft_lk_stage_cols<CPT, LPC>(stage, stageLog, col, qc, ql, CW, (int) nPos);
                 nEval++;
                 return -vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc);
             }
@@ -1183,13 +1257,13 @@ struct QuartetNNIState {
 };
 
 template <typename REAL, int NC, int CPT, bool QUAD>
-__global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
+__global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Arena<REAL> A, const int64_t *ids, const int64_t *lenIdx, REAL *blen,
                                                              double minLen, double minRel, double ftol, double atol,
                                                              double closeLimit, int mlAccuracy, int mode, double *loglkOut,
                                                              double *siteOut, double *lenOut, QuartetNNIResult *nniOut,
                                                              QuartetNNIState *nniState, unsigned int *evalCount) {
     static_assert(!QUAD || NC == 20, "quads of lanes hold 20-state columns");
-    constexpr int WG = MlOptWG<NC>::value;
+    constexpr int WG = MlLineWG<NC, QUAD>::value;
     constexpr int LPC = QUAD ? 4 : 1, NS = NC / LPC, CW = WG / LPC, COLS = CPT * CW;   // lanes per column, states per lane, columns per pass
     typedef Col<REAL, NS> ColT;
     __shared__ REAL ee[4][VFT_MAXRATES * NC];
@@ -1226,7 +1300,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
             else vft_exp_eigen_rates<REAL, NC>(A, len, minRel, ee[s]);
         }
     };
-    auto post = [&](const ColT &c1, const ColT &c2, int s1, int s2, int r, ColT &o) {
+    auto post = [&](const ColT &c1, const ColT &c2, int s1, int s2, int r, ColT &o) __attribute__((always_inline)) {
         if (r < 0) return;
         if constexpr (QUAD) {
             vft_quad_posterior_col<REAL>(&quadTab, c1, c2, ee[s1] + r * NC, ee[s2] + r * NC, ql, o);
@@ -1239,26 +1313,31 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
     // pairLogLk(X, Y, len) over the workgroup (table slot 0); site != nullptr: multiply the per-site likelihoods in
     // (lead: barrier in front - needed unless the previous thing the workgroup did was another pairTotal, whose final
     //  barrier already came after every wave's last table read)
-    auto pairTotal = [&](const ColT *X, const ColT *Y, double len, double *site, bool lead = true) -> double {
+    auto pairTotal = [&](const ColT *X, const ColT *Y, double len, double *site, bool lead = true) __attribute__((always_inline)) -> double {
         if (lead) __syncthreads();
         VFT_ML_TICK(0);   // whatever came before this evaluation
         table(0, len, false);
         __syncthreads();
         VFT_ML_TICK(1);   // tables
         if (!jc) {   // matrix model: the reference's ordered total
+            double col[CPT];
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
                 const int64_t p = (int64_t) qc + (int64_t) c * CW;
+                col[c] = VFT_LK_SKIP;
                 if (p < nPos) {
                     const int r = rc[c];
                     double lkAB;
                     bool ok;
                     if constexpr (QUAD) ok = vft_quad_pair_lk_col<REAL>(&quadTab, X[c], Y[c], ee[0] + r * NC, ql, lkAB);
                     else ok = vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB);
-                    if (ok && site) site[c] *= lkAB;
-                    if (ql == 0) vft_lk_stage(stage, stageLog, (int) p, ok ? lkAB : VFT_LK_SKIP);
+                    if (ok) {
+                        col[c] = lkAB;
+                        if (site) site[c] *= lkAB;
+                    }
                 }
             }
+            vft_lk_stage_cols<CPT, LPC>(stage, stageLog, col, qc, ql, CW, (int) nPos);
             nEval++;
             VFT_ML_TICK(2);   // column likelihoods
             const double total_ = vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc);
@@ -1291,7 +1370,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
         nEval++;
         return tot;
     };
-    auto loadCols = [&](int64_t node, ColT *dst) {
+    auto loadCols = [&](int64_t node, ColT *dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             const int64_t p = (int64_t) qc + (int64_t) c * CW;
@@ -1301,7 +1380,7 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
             }
         }
     };
-    auto storeSite = [&](int topo, const double *site) {
+    auto storeSite = [&](int topo, const double *site) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             const int64_t p = (int64_t) qc + (int64_t) c * CW;
@@ -1321,27 +1400,23 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
         // ---- AB|CD with the lengths as they are: pairLogLk(A,B) + pairLogLk(C,D) + pairLogLk(AB,CD)
 #pragma unroll
         for (int c = 0; c < CPT; c++) site[c] = 1.0;
-        loadCols(nA, X);
-        loadCols(nB, Y);
-        double tot = pairTotal(X, Y, base[0] + base[1], site);
-        __syncthreads();
-        table(1, base[0], true);
-        table(2, base[1], true);
-        __syncthreads();
+        double tot = 0;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {   // (A, B) -> T = AB, then (C, D) -> Y = CD: one piece of code for both
+            loadCols(half ? nC : nA, X);
+            loadCols(half ? nD : nB, Y);
+            tot += pairTotal(X, Y, base[2 * half] + base[2 * half + 1], site);
+            __syncthreads();
+            table(1, base[2 * half], true);
+            table(2, base[2 * half + 1], true);
+            __syncthreads();
 #pragma unroll
-        for (int c = 0; c < CPT; c++) post(X[c], Y[c], 1, 2, rc[c], T[c]);   // AB
-        loadCols(nC, X);
-        loadCols(nD, Y);
-        tot += pairTotal(X, Y, base[2] + base[3], site);
-        __syncthreads();
-        table(1, base[2], true);
-        table(2, base[3], true);
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CPT; c++) {
-            ColT cd;
-            post(X[c], Y[c], 1, 2, rc[c], cd);
-            Y[c] = cd;                                                        // CD
+            for (int c = 0; c < CPT; c++) {
+                ColT r;
+                post(X[c], Y[c], 1, 2, rc[c], r);
+                if (half == 0) T[c] = r;
+                else Y[c] = r;
+            }
         }
         tot += pairTotal(T, Y, base[4], site);
         crit[0] = tot;
@@ -1419,27 +1494,22 @@ __global__ __launch_bounds__(MlOptWG<NC>::value) void k_ml_quartet(Arena<REAL> A
             loadCols(step <= 2 ? qd : qb, Y);
 #pragma unroll
             for (int c = 0; c < CPT; c++) post(X[c], Y[c], 1, 2, rc[c], T[c]);   // CD (steps 0-2) or AB (steps 3, 4)
-            if (step == 0) {
-                loadCols(qa, X);
-                loadCols(qb, Y);
+            // the outer posterior, one piece of code for the five steps: (A, B) -> pair1 = AB, pair2 = CD | (B, CD) resp. (A, CD)
+            // -> pair2 = BCD / ACD, pair1 = A / B | (AB, D) resp. (AB, C) -> pair2 = ABD / ABC, pair1 = C / D
+            loadCols(step == 0 ? qa : step == 1 ? qb : step == 2 ? qa : step == 3 ? qd : qc, X);
+            if (step == 0) loadCols(qb, Y);
 #pragma unroll
-                for (int c = 0; c < CPT; c++) {
-                    ColT ab;
-                    post(X[c], Y[c], 3, 0, rc[c], ab);
-                    X[c] = ab;      // pair1 = AB
-                    Y[c] = T[c];    // pair2 = CD
+            for (int c = 0; c < CPT; c++) {
+                ColT r;
+                post(step >= 3 ? T[c] : X[c], step == 0 ? Y[c] : step <= 2 ? T[c] : X[c], 3, 0, rc[c], r);
+                if (step == 0) {
+                    X[c] = r;
+                    Y[c] = T[c];
+                } else {
+                    Y[c] = r;
                 }
-            } else if (step <= 2) {
-                loadCols(step == 1 ? qb : qa, X);
-#pragma unroll
-                for (int c = 0; c < CPT; c++) post(X[c], T[c], 3, 0, rc[c], Y[c]);   // BCD / ACD
-                loadCols(step == 1 ? qa : qb, X);                                   // pair1 = A / B
-            } else {
-                loadCols(step == 3 ? qd : qc, X);
-#pragma unroll
-                for (int c = 0; c < CPT; c++) post(T[c], X[c], 3, 0, rc[c], Y[c]);   // ABD / ABC
-                loadCols(step == 3 ? qc : qd, X);                                   // pair1 = C / D
             }
+            if (step != 0) loadCols(step == 1 ? qa : step == 2 ? qb : step == 3 ? qc : qd, X);
             __syncthreads();   // the posteriors above are done with the tables
             VFT_ML_TICK(4);   // a step's tables, loads and posteriors
             auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr, false); };
@@ -1653,34 +1723,38 @@ static __global__ __launch_bounds__(256) void k_sh_support(const double *siteLog
     PFX template __global__ void k_ml_quartet<REAL, NC, CPT, QUAD>(Arena<REAL>, const int64_t *, const int64_t *, REAL *, double, double, \
                                                                   double, double, double, int, int, double *, double *, double *,  \
                                                                   QuartetNNIResult *, QuartetNNIState *, unsigned int *);
-// 20 states: quads of lanes per column for alignments up to 512 columns under a matrix model (one or four passes of 128 columns),
-// whole columns per thread (four passes of 512) beyond that and under Jukes-Cantor
+// 20 states: quads of lanes per column for alignments up to 512 columns under a matrix model (two, five or eight passes of 64
+// columns), whole columns per thread (four passes of 512) beyond that and under Jukes-Cantor
 #define VFT_ML_NODE_LENGTHS_INSTANCES(PFX)                      \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 1, false)       \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 4, false)       \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 4, 8, false)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 1, true)       \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 4, true)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 2, true)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 5, true)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 8, true)       \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, float, 20, 4, false)      \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 1, false)      \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 4, false)      \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 4, 8, false)      \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 1, true)      \
-    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 4, true)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 2, true)      \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 5, true)       \
+    VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 8, true)      \
     VFT_ML_NODE_LENGTHS_INSTANCE(PFX, double, 20, 4, false)
 #define VFT_ML_QUARTET_INSTANCES_F32(PFX)                       \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 1, false)            \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 4, false)            \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 4, 8, false)            \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 1, true)            \
-    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4, true)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 2, true)            \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 5, true)       \
+    VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 8, true)            \
     VFT_ML_QUARTET_INSTANCE(PFX, float, 20, 4, false)
 #define VFT_ML_QUARTET_INSTANCES_F64(PFX)                       \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 1, false)           \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 4, false)           \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 4, 8, false)           \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 1, true)           \
-    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4, true)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 2, true)           \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 5, true)       \
+    VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 8, true)           \
     VFT_ML_QUARTET_INSTANCE(PFX, double, 20, 4, false)
 #define VFT_ML_HEAVY_INSTANCES(PFX)        \
     VFT_ML_NODE_LENGTHS_INSTANCES(PFX)     \
