@@ -228,7 +228,7 @@ __device__ __forceinline__ void vft_lk_stage_cols(double *stage, double *stageLo
     }
 }
 
-// steps 2 and 3 over stage[0, nPos) / stageLog[0, nPos); COLS: capacity of the staging arrays (list: COLS * 3 / 2, events: COLS / 2)
+// steps 2 and 3 over stage[0, nPos) / stageLog[0, nPos); COLS: capacity of the staging arrays (list: COLS * 3 / 2 + 32, events: COLS / 2)
 template <int WG, int COLS>
 __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *stageLog, double *list, signed char *events,
                                                       LkOrderedShared *sh, int nPos, bool jc) {
@@ -239,8 +239,22 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
     constexpr int BIG = 1 << 28;
     static_assert(NW <= 16, "LkOrderedShared holds 16 wavefronts");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VFT_ML_TIMING
+    unsigned long long subTick_ = wall_clock64();
+#define VFT_ML_SUBTICK(k)                                                   \
+    do {                                                                    \
+        if (threadIdx.x == 0) {                                             \
+            const unsigned long long now_ = wall_clock64();                 \
+            atomicAdd(&vftMlTicks[k], now_ - subTick_);                     \
+            subTick_ = now_;                                                \
+        }                                                                   \
+    } while (0)
+#else
+#define VFT_ML_SUBTICK(k) do { } while (0)
+#endif
     if (tid == 0) sh->irregular = 0;
     __syncthreads();
+    VFT_ML_SUBTICK(10);
     bool odd = false;
     const int q0 = tid * C < nPos ? tid * C : nPos, q1 = q0 + C < nPos ? q0 + C : nPos;   // this thread's run of columns [q0, q1)
     // prefix sums of the logs: the run, a wave scan, the earlier wavefronts' totals
@@ -259,6 +273,7 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
     }
     if (lane == 63) sh->waveSum[wave] = incl;
     __syncthreads();
+    VFT_ML_SUBTICK(11);
     double excl = 0;
     for (int w = 0; w < wave; w++) excl += sh->waveSum[w];
     excl += incl - lsum;
@@ -298,6 +313,7 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
         ph = BIG;
     }
     __syncthreads();
+    VFT_ML_SUBTICK(12);
     int nIn = 0;   // the count entering this run (lk starts at 1: n = 0): through the earlier wavefronts, then the earlier lanes
     for (int w = 0; w < wave; w++) nIn = vft_clampi(nIn, sh->waveLo[w], sh->waveHi[w]);
     nIn = vft_clampi(nIn, pl, ph);
@@ -325,6 +341,7 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
     if (lane == 63) sh->waveEv[wave] = einc;
     if (odd) sh->irregular = 1;   // (every writer stores 1)
     __syncthreads();
+    VFT_ML_SUBTICK(13);
     int eBase = 0, eTotal = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
@@ -349,8 +366,10 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
             e += cnt;
             n = n2;
         }
+        if (tid < 32) list[nPos + eTotal + tid] = 1.0;   // (multiplying by one is exact: the chain runs in whole groups of sixteen)
     }
     __syncthreads();
+    VFT_ML_SUBTICK(14);
     if (irregular) {   // uniform: the plain chain, decisions and all
         if (tid == 0) {
             double lk = 1.0, loglk = 0.0;
@@ -359,10 +378,27 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
             sh->loglk = loglk;
         }
     } else if (tid == 0) {
+        // (sixteen multipliers per trip, the next sixteen already on their way from LDS; the list ends with 32 ones)
         const int K = nPos + eTotal;
         double lk = 1.0;
+#ifdef VFT_TEST_PLAIN_CHAIN
 #pragma unroll 16
         for (int k = 0; k < K; k++) lk *= list[k];
+#else
+        double cur[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) cur[u] = list[u];
+#pragma unroll 1
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            double nxt[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) nxt[u] = list[k0 + 16 + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) lk *= cur[u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) cur[u] = nxt[u];
+        }
+#endif
         sh->prod = lk;
     } else if (tid == 64) {
         double loglk = 0.0;
@@ -373,6 +409,7 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
         sh->loglk = loglk;
     }
     __syncthreads();
+    VFT_ML_SUBTICK(15);
     return vft_lk_finish(sh->prod, sh->loglk);
 }
 
@@ -925,6 +962,20 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
     o.vec = true;   // code == NOCODE, w == 1
 }
 
+// element idx of a small array that must stay in registers (a runtime index would send it to scratch memory)
+template <typename T, int N>
+__device__ __forceinline__ T vft_sel_get(const T (&a)[N], int idx) {
+    T v = a[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) v = i == idx ? a[i] : v;
+    return v;
+}
+template <typename T, int N>
+__device__ __forceinline__ void vft_sel_set(T (&a)[N], int idx, T v) {
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i] = i == idx ? v : a[i];
+}
+
 #define VFT_MLOPT_WG 256
 // Threads per workgroup of the two line-search kernels.  20-state alphabets: 512, so that alignments up to 512 columns
 // run with ONE column per thread - a thread keeps its columns of the three / four profiles in registers, 160 VGPRs per
@@ -1080,7 +1131,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_node_lengths
     __shared__ double red[WG / 64];
     __shared__ double stage[COLS];   // ordered total of matrix models (vft_lk_total_staged)
     __shared__ double stageLog[COLS];
-    __shared__ double stageList[COLS * 3 / 2];
+    __shared__ double stageList[COLS * 3 / 2 + 32];
     __shared__ signed char stageEvents[COLS / 2];
     __shared__ LkOrderedShared ordSh;
     __shared__ typename std::conditional<QUAD, MlQuadTables<REAL>, int>::type quadTab;
@@ -1271,7 +1322,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
     __shared__ double red[WG / 64];
     __shared__ double stage[COLS];   // ordered total of matrix models (vft_lk_total_staged)
     __shared__ double stageLog[COLS];
-    __shared__ double stageList[COLS * 3 / 2];
+    __shared__ double stageList[COLS * 3 / 2 + 32];
     __shared__ signed char stageEvents[COLS / 2];
     __shared__ LkOrderedShared ordSh;
     __shared__ typename std::conditional<QUAD, MlQuadTables<REAL>, int>::type quadTab;
@@ -1313,7 +1364,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
     // pairLogLk(X, Y, len) over the workgroup (table slot 0); site != nullptr: multiply the per-site likelihoods in
     // (lead: barrier in front - needed unless the previous thing the workgroup did was another pairTotal, whose final
     //  barrier already came after every wave's last table read)
-    auto pairTotal = [&](const ColT *X, const ColT *Y, double len, double *site, bool lead = true) __attribute__((always_inline)) -> double {
+    auto pairTotal = [&](const ColT *X, const ColT *Y, double len, double *site, bool useSite, bool lead = true) __attribute__((always_inline)) -> double {
         if (lead) __syncthreads();
         VFT_ML_TICK(0);   // whatever came before this evaluation
         table(0, len, false);
@@ -1333,7 +1384,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
                     else ok = vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB);
                     if (ok) {
                         col[c] = lkAB;
-                        if (site) site[c] *= lkAB;
+                        if (useSite) site[c] *= lkAB;
                     }
                 }
             }
@@ -1355,7 +1406,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
                     double lkAB;
                     if (vft_pair_lk_col<REAL, NC>(A, X[c], Y[c], jc, pS[0][r], pD[0][r], ee[0] + r * NC, lkAB)) {
                         vft_lk_accumulate(lkAB, jc, lk, loglk);
-                        if (site) site[c] *= lkAB;
+                        if (useSite) site[c] *= lkAB;
                     }
                 }
             }
@@ -1405,7 +1456,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
         for (int half = 0; half < 2; half++) {   // (A, B) -> T = AB, then (C, D) -> Y = CD: one piece of code for both
             loadCols(half ? nC : nA, X);
             loadCols(half ? nD : nB, Y);
-            tot += pairTotal(X, Y, base[2 * half] + base[2 * half + 1], site);
+            tot += pairTotal(X, Y, base[2 * half] + base[2 * half + 1], site, true);
             __syncthreads();
             table(1, base[2 * half], true);
             table(2, base[2 * half + 1], true);
@@ -1418,7 +1469,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
                 else Y[c] = r;
             }
         }
-        tot += pairTotal(T, Y, base[4], site);
+        tot += pairTotal(T, Y, base[4], site, true);
         crit[0] = tot;
         storeSite(0, site);
     }
@@ -1435,7 +1486,12 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
         const int t = (int) blockIdx.y;
         if (st.done || (t == 1 && !st.consider1) || (t == 2 && !st.consider2)) return;
 #pragma unroll
-        for (int j = 0; j < 5; j++) len[t][j] = st.len[t][j];
+        for (int j = 0; j < 5; j++) {
+            const double v = st.len[t][j];
+#pragma unroll
+            for (int tt = 0; tt < 3; tt++)
+                if (tt == t) len[tt][j] = v;
+        }
     }
     for (int guard = 0; guard < 64; guard++) {
         int t;
@@ -1447,7 +1503,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
             else if (guard == 1) t = 2;
             else if (guard == 2) {
                 t = crit[1] > crit[2] ? 1 : 2;
-                if (!(mlAccuracy > 1 || crit[t] > crit[0] - closeLimit)) break;
+                if (!(mlAccuracy > 1 || (t == 1 ? crit[1] : crit[2]) > crit[0] - closeLimit)) break;
             } else break;
         } else {
             if (phase == 3) {   // end of a round (NJ.tcc:4961-4983)
@@ -1465,10 +1521,20 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
             if ((t == 1 && !consider1) || (t == 2 && !consider2)) continue;
         }
         const int64_t qa = nA, qb = t == 0 ? nB : t == 1 ? nC : nD, qc = t == 1 ? nB : nC, qd = t == 2 ? nB : nD;
-        double *L = len[t];
+        double L[5];   // len[t] (a copy: runtime indices would send the arrays to scratch memory; written back below)
 #pragma unroll
-        for (int j = 0; j < 5; j++)
+        for (int j = 0; j < 5; j++) {
+            L[j] = t == 0 ? len[0][j] : t == 1 ? len[1][j] : len[2][j];
             if (L[j] < minLen) L[j] = minLen;
+        }
+#define VFT_STORE_L()                                   \
+    do {                                                \
+        _Pragma("unroll") for (int j = 0; j < 5; j++) { \
+            if (t == 0) len[0][j] = L[j];               \
+            else if (t == 1) len[1][j] = L[j];          \
+            else len[2][j] = L[j];                      \
+        }                                               \
+    } while (0)
         double negll = 0;
         bool starHere = false;
         for (int step = 0; step < 5; step++) {
@@ -1500,8 +1566,11 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
             if (step == 0) loadCols(qb, Y);
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
-                ColT r;
-                post(step >= 3 ? T[c] : X[c], step == 0 ? Y[c] : step <= 2 ? T[c] : X[c], 3, 0, rc[c], r);
+                ColT r, u = X[c], v = X[c];   // (operands by value: selected field by field, the arrays stay in registers)
+                if (step >= 3) u = T[c];
+                if (step == 0) v = Y[c];
+                else if (step <= 2) v = T[c];
+                post(u, v, 3, 0, rc[c], r);
                 if (step == 0) {
                     X[c] = r;
                     Y[c] = T[c];
@@ -1512,9 +1581,12 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
             if (step != 0) loadCols(step == 1 ? qa : step == 2 ? qb : step == 3 ? qc : qd, X);
             __syncthreads();   // the posteriors above are done with the tables
             VFT_ML_TICK(4);   // a step's tables, loads and posteriors
-            auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, nullptr, false); };
+            auto negLogLk = [&](double x) -> double { return -pairTotal(X, Y, x, site, false, false); };
             const int slot = step == 0 ? 4 : step - 1;
-            L[slot] = vft_min_branch_length(negLogLk, minLen, L[slot], VFT_MLOPT_MAXLEN, ftol, atol, negll);
+            {
+                const double found = vft_min_branch_length(negLogLk, minLen, vft_sel_get<double, 5>(L, slot), VFT_MLOPT_MAXLEN, ftol, atol, negll);
+                vft_sel_set<double, 5>(L, slot, found);
+            }
             if (step == 0 && mode != 0 && t == 0) {
                 // star topology test (NJ.tcc:1691-1700): is the internal branch worth more than closeLogLkLimit?
                 const double loglkStar = -negLogLk(minLen);
@@ -1528,32 +1600,35 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
             // -negloglk + pairLogLk(A, B, lA + lB) + pairLogLk(C, D, lC + lD)
             loadCols(qa, X);
             loadCols(qb, Y);
-            double tot = -negll + pairTotal(X, Y, L[0] + L[1], nullptr);
+            double tot = -negll + pairTotal(X, Y, L[0] + L[1], site, false);
             loadCols(qc, X);
             loadCols(qd, Y);
-            tot += pairTotal(X, Y, L[2] + L[3], nullptr);
+            tot += pairTotal(X, Y, L[2] + L[3], site, false);
             crit[0] = tot;
             crit[1] = crit[2] = -1e20;
             star = true;
+            VFT_STORE_L();
             break;
         }
         // total: pairLogLk(ABC, D) (= the last search's optimum) + pairLogLk(AB, C, lI + lC) + pairLogLk(A, B, lA + lB);
         // X = D, Y = ABC, T = AB here
-        double *sitep = mode == 0 ? site : nullptr;
+        const bool sitep = mode == 0;
         if (sitep) {
 #pragma unroll
             for (int c = 0; c < CPT; c++) site[c] = 1.0;
-            pairTotal(Y, X, L[3], sitep);
+            pairTotal(Y, X, L[3], site, true);
         }
         double tot = -negll;
         loadCols(qc, X);
-        tot += pairTotal(T, X, L[4] + L[2], sitep);
+        tot += pairTotal(T, X, L[4] + L[2], site, sitep);
         loadCols(qa, X);
         loadCols(qb, Y);
-        tot += pairTotal(X, Y, L[0] + L[1], sitep);
-        crit[t] = tot;
+        tot += pairTotal(X, Y, L[0] + L[1], site, sitep);
+        vft_sel_set<double, 3>(crit, t, tot);
         if (sitep) storeSite(t, site);
+        VFT_STORE_L();
     }
+#undef VFT_STORE_L
     if (threadIdx.x != 0) return;
 #ifdef VFT_ML_TIMING
     VFT_ML_TICK(0);
@@ -1564,16 +1639,21 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
     if (mode == 2) {
         QuartetNNIState &st = nniState[k];
         const int t = (int) blockIdx.y;
-        st.crit[t] = crit[t];
-        for (int j = 0; j < 5; j++) st.len[t][j] = len[t][j];
+        st.crit[t] = vft_sel_get<double, 3>(crit, t);
+#pragma unroll
+        for (int j = 0; j < 5; j++) st.len[t][j] = t == 0 ? len[0][j] : t == 1 ? len[1][j] : len[2][j];
         if (t == 0) st.star = star ? 1 : 0;
         return;
     }
     if (mode == 0) {
+#pragma unroll
         for (int t = 0; t < 3; t++) loglkOut[3 * k + t] = crit[t];
-        if (lenOut)
+        if (lenOut) {
+#pragma unroll
             for (int t = 0; t < 2; t++)
+#pragma unroll
                 for (int j = 0; j < 5; j++) lenOut[(2 * k + t) * 5 + j] = len[1 + t][j];
+        }
         return;
     }
     // MLQuartetNNI's verdict (NJ.tcc:4989-5003) and DoNNI's branch-length update (NJ.tcc:5889-5915)
@@ -1586,7 +1666,9 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
     if (star) {
         blen[li[4]] = (REAL) len[0][4];
     } else {
-        const double *L = len[choice];
+        double L[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) L[j] = choice == 0 ? len[0][j] : choice == 1 ? len[1][j] : len[2][j];
         blen[li[0]] = (REAL) L[0];                                   // A
         blen[li[1]] = (REAL) (choice == 0 ? L[1] : choice == 1 ? L[2] : L[3]);   // B
         blen[li[2]] = (REAL) (choice == 0 ? L[2] : choice == 1 ? L[1] : L[2]);   // C
