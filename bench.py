@@ -153,6 +153,17 @@ def dense_profile_roofline(ops, state, n, L, groups=None):
                 achieved=ach, frac=ach / HBM_PEAK_GBS, achieved_moved_gbs=mov, frac_moved=mov / HBM_PEAK_GBS)
 
 
+def sweep_kernel_hash():
+    """SHA-256 over the sources of the sweep kernels and of the layout they read: profiles/traffic.json (HBM bytes per launch
+    from rocprofv3 PMC passes, tools/profile_collect.py) carries the hash it was measured at, and `roofline.traffic` is
+    printed only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("vft_kernels_nj.h", "vft_layout.h", "vft_device.h"):
+        h.update(open(os.path.join(ROOT, "veryfasttree_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 E2E = {
     # name: (n, L, mu, gap, seed, fastest, golden file, the reference's flags)
     "c3": (100000, 500, 0.03, 0.01, 3, True, "bb_c3_crc.npz", "-nt -fastest -noml -nome -nosupport"),
@@ -355,7 +366,9 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (n, L, world) == (1000000, 200, 1):
-        traffic = json.load(open(tpath)).get("k_sweep_nt<float,MODE_CRIT>", {}).get("bytes_per_launch")
+        t = json.load(open(tpath))
+        if t.get("kernel_sources_sha256") == sweep_kernel_hash():   # (counters read from other kernel sources say nothing: null)
+            traffic = t.get("k_sweep_nt<float,MODE_CRIT>", {}).get("bytes_per_launch")
     both_ms = kern_ms + tab_ms
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, kernel="k_sweep_nt<float,MODE_CRIT>", launches=int(launches),

@@ -79,5 +79,9 @@ if tb:
     wk = sum(v["WRITE_SIZE"] for v in tb.values()) / len(tb)
     traffic["k_sweep_nt_table<float,MODE_CRIT>"] = {"fetch_size_kb": round(fk, 1), "write_size_kb": round(wk, 1),
                                                      "bytes_per_launch": int((2 * fk + wk) * 1024), "algorithmic_bytes_per_launch": 110000000}
+# the figure belongs to the sweep kernels as they were when the counters were read: bench.py prints it only while these files are unchanged
+sys.path.insert(0, ROOT)
+from bench import sweep_kernel_hash
+traffic["kernel_sources_sha256"] = sweep_kernel_hash()
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=2)
 print(json.dumps(traffic, indent=1))

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): the bench line, the rocprofv3 kernel statistics of the same command, the two PMC passes the
 # HBM-traffic figure comes from (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md), and the per-operator
 # tables.  Everything lands in gpurun_out/$1/; tools/profile_collect.py turns it into profiles/$1_* afterwards.
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box: the wall-clock measurements of a round (NJ phase at several sizes, whole-pipeline comparisons with the
-# compiled reference at config C2's size and on proteins).  Output: gpurun_out/$1/.
-tag=${1:-r02w}
+# Runs on the GPU box: the wall-clock measurements of a round (NJ phase at several sizes, the join engine's kernel statistics at
+# a million sequences, whole-pipeline comparisons with the compiled reference at config C2's size and on proteins, the tick
+# counters of the quartet kernel when a timing build is present).  Output: gpurun_out/$1/.
+tag=${1:-r03w}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
@@ -16,3 +17,15 @@ timeout 900 python3 tests/compare_with_reference_run.py 10000 1000 -gtr --out $o
 tail -8 $out/compare_c2.txt
 timeout 900 python3 tests/compare_with_reference_run.py 3000 300 --aa -lg -double-precision --out $out/compare_aa_3000.txt > /dev/null 2>&1
 tail -8 $out/compare_aa_3000.txt
+if [ -f build/timing/libvft_hip_mltiming.so ]; then
+  cp veryfasttree_amd/lib/libvft_hip.so /tmp/libvft_hip_orig.so
+  cp build/timing/libvft_hip_mltiming.so veryfasttree_amd/lib/libvft_hip.so
+  timeout 600 python3 tools/ml_ticks.py 1500 300 > $out/ml_ticks_aa_1500.txt 2>&1
+  cp /tmp/libvft_hip_orig.so veryfasttree_amd/lib/libvft_hip.so
+fi
+cd /tmp && export TMPDIR=/tmp
+timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e1m -o e1m -- python3 $GRAFT_REPO_ROOT/tools/nj_gpu_only.py 1000000 200 mu=0.02 gap=0.01 seed=4 > $out/nj_1M_under_rocprof.log 2>&1
+cp /tmp/prof_e1m/*kernel_stats.csv $out/engine_1M_kernel_stats.csv 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_aa -o aa -- python3 $GRAFT_REPO_ROOT/tools/full_pipeline_aa_once.py 3000 300 > $out/aa_3000_under_rocprof.log 2>&1
+cp /tmp/prof_aa/*kernel_stats.csv $out/aa_3000_kernel_stats.csv 2>/dev/null
+ls -la $out
