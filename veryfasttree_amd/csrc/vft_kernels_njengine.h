@@ -489,10 +489,10 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     int32_t ju[VFT_NJ_BATCH];
     REAL cu[VFT_NJ_BATCH];
 #pragma unroll
-    for (int q = 0; q < VFT_NJ_BATCH; q++) {
-        const int u = q * (int) blockDim.x + (int) threadIdx.x;
-        ju[q] = u < T.cap ? T.stJ[u] : -1;
-        cu[q] = u < T.cap ? T.stC[u] : (REAL) 0;
+    for (int q = 0; q < VFT_NJ_BATCH; q++) {   // (unconditional loads from clamped indices: see k_nj_glue_scan)
+        const int u = q * (int) blockDim.x + (int) threadIdx.x, uc = u < T.cap ? u : T.cap - 1;
+        ju[q] = T.stJ[uc];
+        cu[q] = T.stC[uc];
     }
     if (halt) return;
     ThKey *keys = (ThKey *) njLds;
@@ -641,19 +641,27 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     const long long nActive = st->nActive;
     const double totdiam = st->totdiam;
     const int32_t tvAge0 = st->tvAge;
-    NjJoinRec rec{};
-    int nU = 0;
-    if (merge) {
-        rec = E.logDev[doneJoin];
-        nU = T.sorted[T.cap];
+    NjJoinRec rec = E.logDev[merge ? doneJoin : 0];
+    int nU = T.sorted[T.cap];
+    if (!merge) {
+        rec = NjJoinRec{};
+        nU = 0;
     }
+    // (every load of a round is UNCONDITIONAL, from a clamped index, and masked afterwards: a load inside a divergent branch
+    //  makes the compiler wait for it before the next one is issued, which serialised the eight slots of a thread)
     int32_t sNode[B];
     int rSrc[B];
 #pragma unroll
     for (int k = 0; k < B; k++) {
         const int t = k * THREADS + tid;
-        sNode[k] = t < E.nTop ? E.topvis[t] : -1;
-        rSrc[k] = merge && t < T.cap ? T.sorted[t] : -1;   // (ranks beyond the number of candidates hold older entries: unused)
+        sNode[k] = E.topvis[t < E.nTop ? t : E.nTop - 1];
+        rSrc[k] = T.sorted[t < T.cap ? t : T.cap - 1];   // (ranks beyond the number of candidates hold older entries: unused)
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        const int t = k * THREADS + tid;
+        if (t >= E.nTop) sNode[k] = -1;
+        if (!merge || t >= T.cap) rSrc[k] = -1;
     }
     if (halt) return;
     const SweepArgs s = vft_nj_args(E, nActive, totdiam);
@@ -668,55 +676,67 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     REAL sD[B], sOi[B], rD[B], rC[B];
 #pragma unroll
     for (int k = 0; k < B; k++) {
-        sPn[k] = 0;
-        sVj[k] = -1;
-        sSi[k] = 0;
-        sD[k] = sOi[k] = 0;
-        if (sNode[k] >= 0) {
-            sPn[k] = A.parent[sNode[k]];
-            sVj[k] = vft_nj_ld(&E.visJ[sNode[k]]);
-            sD[k] = vft_nj_ld(&E.visD[sNode[k]]);
-            sOi[k] = vft_nj_ld(&A.outDist[sNode[k]]);
-            sSi[k] = vft_nj_ld(&A.nOutActive[sNode[k]]);
-        }
+        const int32_t nd = sNode[k] >= 0 ? sNode[k] : 0;
+        sPn[k] = A.parent[nd];
+        sVj[k] = vft_nj_ld(&E.visJ[nd]);
+        sD[k] = vft_nj_ld(&E.visD[nd]);
+        sOi[k] = vft_nj_ld(&A.outDist[nd]);
+        sSi[k] = vft_nj_ld(&A.nOutActive[nd]);
         const int r = k * THREADS + tid;
-        rJ[k] = -1;
-        rD[k] = rC[k] = 0;
-        if (r < nU) {
-            rJ[k] = T.stJ[rSrc[k]];
-            rD[k] = T.stD[rSrc[k]];
-            rC[k] = T.stC[rSrc[k]];
-        }
+        const int src = r < nU ? rSrc[k] : 0;
+        rJ[k] = T.stJ[src];
+        rD[k] = T.stD[src];
+        rC[k] = T.stC[src];
     }
-    if (merge) {
-        ageA = E.age[c0];
-        ageB = E.age[c1];
+    ageA = E.age[merge ? c0 : 0];
+    ageB = E.age[merge ? c1 : 0];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        if (sNode[k] < 0) {
+            sPn[k] = 0;
+            sVj[k] = -1;
+            sSi[k] = 0;
+            sD[k] = sOi[k] = 0;
+        }
+        if (k * THREADS + tid >= nU) {
+            rJ[k] = -1;
+            rD[k] = rC[k] = 0;
+        }
     }
     // ---- round 2
     int32_t sPj[B], sSj[B], tVj[TB], tSi[TB];
     REAL sOj[B], tVd[TB], tOi[TB];
 #pragma unroll
     for (int k = 0; k < B; k++) {
-        sPj[k] = 0;
-        sSj[k] = 0;
-        sOj[k] = 0;
-        if (sNode[k] >= 0 && sPn[k] < 0 && sVj[k] >= 0) {
-            sPj[k] = A.parent[sVj[k]];
-            sOj[k] = vft_nj_ld(&A.outDist[sVj[k]]);
-            sSj[k] = vft_nj_ld(&A.nOutActive[sVj[k]]);
-        }
+        const bool ok = sNode[k] >= 0 && sPn[k] < 0 && sVj[k] >= 0;
+        const int32_t vj = ok ? sVj[k] : 0;
+        sPj[k] = A.parent[vj];
+        sOj[k] = vft_nj_ld(&A.outDist[vj]);
+        sSj[k] = vft_nj_ld(&A.nOutActive[vj]);
     }
 #pragma unroll
     for (int k = 0; k < TB; k++) {
         const int r = k * THREADS + tid;
-        tVj[k] = -1;
-        tSi[k] = 0;
-        tVd[k] = tOi[k] = 0;
-        if (r < nSave) {
-            tVj[k] = vft_nj_ld(&E.visJ[rJ[k]]);
-            tVd[k] = vft_nj_ld(&E.visD[rJ[k]]);
-            tOi[k] = vft_nj_ld(&A.outDist[rJ[k]]);
-            tSi[k] = vft_nj_ld(&A.nOutActive[rJ[k]]);
+        const int32_t nd = r < nSave ? rJ[k] : 0;
+        tVj[k] = vft_nj_ld(&E.visJ[nd]);
+        tVd[k] = vft_nj_ld(&E.visD[nd]);
+        tOi[k] = vft_nj_ld(&A.outDist[nd]);
+        tSi[k] = vft_nj_ld(&A.nOutActive[nd]);
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        if (!(sNode[k] >= 0 && sPn[k] < 0 && sVj[k] >= 0)) {
+            sPj[k] = 0;
+            sSj[k] = 0;
+            sOj[k] = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TB; k++) {
+        if (k * THREADS + tid >= nSave) {
+            tVj[k] = -1;
+            tSi[k] = 0;
+            tVd[k] = tOi[k] = 0;
         }
     }
     // ---- round 3
@@ -724,13 +744,17 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     REAL tOj[TB];
 #pragma unroll
     for (int k = 0; k < TB; k++) {
-        tPj[k] = 0;
-        tSj[k] = 0;
-        tOj[k] = 0;
-        if (tVj[k] >= 0) {
-            tPj[k] = A.parent[tVj[k]];
-            tOj[k] = vft_nj_ld(&A.outDist[tVj[k]]);
-            tSj[k] = vft_nj_ld(&A.nOutActive[tVj[k]]);
+        const int32_t vj = tVj[k] >= 0 ? tVj[k] : 0;
+        tPj[k] = A.parent[vj];
+        tOj[k] = vft_nj_ld(&A.outDist[vj]);
+        tSj[k] = vft_nj_ld(&A.nOutActive[vj]);
+    }
+#pragma unroll
+    for (int k = 0; k < TB; k++) {
+        if (tVj[k] < 0) {
+            tPj[k] = 0;
+            tSj[k] = 0;
+            tOj[k] = 0;
         }
     }
     // ---- the slot cache (as vft_nj_slots_load leaves it) and the candidates by rank, into LDS
@@ -1175,12 +1199,19 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
                 int32_t ja[VFT_NJ_BATCH / 2], jb[VFT_NJ_BATCH / 2];
                 REAL ca[VFT_NJ_BATCH / 2], cb[VFT_NJ_BATCH / 2];
 #pragma unroll
+                for (int q = 0; q < VFT_NJ_BATCH / 2; q++) {   // (unconditional loads from clamped indices: see k_nj_glue_scan)
+                    const int u = b0 + q * (int) blockDim.x + (int) threadIdx.x;
+                    const int ua = u < n0 ? u : 0, ub = u < n1 ? u : 0;
+                    ja[q] = T.stJ[ua];
+                    ca[q] = T.stC[ua];
+                    jb[q] = T.stJ[T.m + ub];
+                    cb[q] = T.stC[T.m + ub];
+                }
+#pragma unroll
                 for (int q = 0; q < VFT_NJ_BATCH / 2; q++) {
                     const int u = b0 + q * (int) blockDim.x + (int) threadIdx.x;
-                    ja[q] = u < n0 ? T.stJ[u] : -1;
-                    ca[q] = u < n0 ? T.stC[u] : (REAL) 0;
-                    jb[q] = u < n1 ? T.stJ[T.m + u] : -1;
-                    cb[q] = u < n1 ? T.stC[T.m + u] : (REAL) 0;
+                    if (u >= n0) ja[q] = -1;
+                    if (u >= n1) jb[q] = -1;
                 }
 #pragma unroll
                 for (int q = 0; q < VFT_NJ_BATCH / 2; q++) {   // ascending list positions: the first strict minimum of each walk

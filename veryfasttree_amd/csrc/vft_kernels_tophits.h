@@ -459,17 +459,70 @@ __global__ __launch_bounds__(VFT_WG) void k_th_refresh(Arena<REAL> A, TopHits<RE
     }
     __syncthreads();
     const int n2 = nKept, nRe = nTodo;
-    for (int k = 0; k < nRe; k++) {   // setDistCriterion for the old hits whose partner changed
-        const int slot = todo[k];
-        const int64_t j = entJ[slot];
-        REAL d, w;
-        vft_pair_block<REAL, NC>(A, x, j, false, sW, sT, d, w);
-        if (threadIdx.x == 0) {
+    // setDistCriterion for the old hits whose partner changed (dozens to hundreds per list late in a run).  One workgroup-wide
+    // pair evaluation after the other was most of this kernel (1.9 ms per refresh at a million sequences); all of them have x
+    // on one side: x's columns go to LDS once - the sort keys' space is free here - and a LANE walks the columns of one pair in
+    // order with its own double accumulators, as k_pairs_block_tiled does (the reference's sequence of additions, NJ.tcc:1168-1183).
+    const int64_t nPos = A.d.nPos;
+    if (nRe > 1 && (size_t) nPos * ((NC + 1) * sizeof(REAL) + 4) <= (size_t) P * sizeof(ThKey)) {
+        REAL *sF = (REAL *) keys;                         // [nPos][NC]
+        REAL *sWt = sF + nPos * NC;                       // [nPos]
+        int32_t *sCode = (int32_t *) (sWt + nPos);        // [nPos]; bit 8: the column holds a vector
+        for (int64_t p = threadIdx.x; p < nPos; p += blockDim.x) {
+            Col<REAL, NC> c;
+            c.w = 0;
+            c.code = VFT_NOCODE_;
+            c.vec = false;
+#pragma unroll
+            for (int k = 0; k < NC; k++) c.f[k] = 0;
+            vft_load_col_ml<REAL, NC>(A, x, p, c);
+            sWt[p] = c.w;
+            sCode[p] = c.code | (c.vec ? 256 : 0);
+#pragma unroll
+            for (int k = 0; k < NC; k++) sF[p * NC + k] = c.vec ? c.f[k] : (REAL) 0;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < nRe; k += blockDim.x) {
+            const int slot = todo[k];
+            const int64_t j = entJ[slot];
+            double top = 0.0, den = 0.0;
+            for (int64_t p = 0; p < nPos; p++) {
+                Col<REAL, NC> cb;
+                vft_load_col_ml<REAL, NC>(A, j, p, cb);
+                if (!(cb.w > 0)) continue;
+                Col<REAL, NC> ca;
+                ca.w = sWt[p];
+                if (!(ca.w > 0)) continue;
+                const int32_t cc = sCode[p];
+                ca.code = cc & 255;
+                ca.vec = (cc & 256) != 0;
+#pragma unroll
+                for (int q = 0; q < NC; q++) ca.f[q] = sF[p * NC + q];
+                const REAL ww = ca.w * cb.w;
+                const double wgt = (double) ww;
+                den += wgt;
+                top += wgt * vft_piece<REAL, NC>(A, ca, cb, nullptr);
+            }
+            REAL d = (REAL) (den > 0 ? top / den : 1.0);
             if (!(x < A.d.nSeqs && j < A.d.nSeqs)) {
                 const REAL dd = A.diameter[x] + A.diameter[j];
                 d = d - dd;
             }
             entD[slot] = d;
+        }
+    } else {
+        for (int k = 0; k < nRe; k++) {
+            const int slot = todo[k];
+            const int64_t j = entJ[slot];
+            REAL d, w;
+            vft_pair_block<REAL, NC>(A, x, j, false, sW, sT, d, w);
+            if (threadIdx.x == 0) {
+                if (!(x < A.d.nSeqs && j < A.d.nSeqs)) {
+                    const REAL dd = A.diameter[x] + A.diameter[j];
+                    d = d - dd;
+                }
+                entD[slot] = d;
+            }
         }
     }
     __syncthreads();
