@@ -155,6 +155,9 @@ struct vft_ctx {
     unsigned int *njClaim = nullptr, njClaimTag = 0;   // speculative double walks: one writer per refreshed node
     int32_t *njLogNode = nullptr, *njLogStamp = nullptr;
     void *njLogOut = nullptr;
+    int32_t *njSlotI = nullptr, *njCandI = nullptr;
+    void *njSlotR = nullptr, *njCandR = nullptr;
+    int njTopPad = 0, njCapPad = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
@@ -557,7 +560,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->doneCtr) hipFree(c->doneCtr);
     for (void *p : {c->thHits, c->thStD, c->thStC, (void *) c->thLen, (void *) c->thStJ, (void *) c->thMark, (void *) c->thDone, (void *) c->thSorted,
                     c->njState, c->njVisD, (void *) c->njVisJ, (void *) c->njTop, (void *) c->njAge, (void *) c->njLogDev, (void *) c->njClaim,
-                    (void *) c->njLogNode, (void *) c->njLogStamp, c->njLogOut})
+                    (void *) c->njLogNode, (void *) c->njLogStamp, c->njLogOut, (void *) c->njSlotI, c->njSlotR, (void *) c->njCandI, c->njCandR})
         if (p) hipFree(p);
     if (c->njLogHost) hipHostFree(c->njLogHost);
     if (c->njStatusHost) hipHostFree(c->njStatusHost);
@@ -2416,6 +2419,12 @@ static NjEngine<REAL> njengine(const vft_ctx *c) {
     E.logNode = c->njLogNode;
     E.logStamp = c->njLogStamp;
     E.logOut = (REAL *) c->njLogOut;
+    E.slotI = c->njSlotI;
+    E.slotR = (REAL *) c->njSlotR;
+    E.candI = c->njCandI;
+    E.candR = (REAL *) c->njCandR;
+    E.nTopPad = c->njTopPad;
+    E.capPad = c->njCapPad;
     return E;
 }
 
@@ -2492,6 +2501,16 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     HIPCHK(c, hipMalloc((void **) &c->njLogNode, (size_t) (cfg->m + 64) * 4));
     HIPCHK(c, hipMalloc((void **) &c->njLogStamp, (size_t) (cfg->m + 64) * 4));
     HIPCHK(c, hipMalloc(&c->njLogOut, (size_t) (cfg->m + 64) * rs));
+    c->njTopPad = (cfg->n_top + 63) & ~63;
+    c->njCapPad = (c->thCap + 63) & ~63;
+    HIPCHK(c, hipMalloc((void **) &c->njSlotI, (size_t) 6 * c->njTopPad * 4));
+    HIPCHK(c, hipMalloc(&c->njSlotR, (size_t) 3 * c->njTopPad * rs));
+    HIPCHK(c, hipMalloc((void **) &c->njCandI, (size_t) 5 * c->njCapPad * 4));
+    HIPCHK(c, hipMalloc(&c->njCandR, (size_t) 5 * c->njCapPad * rs));
+    HIPCHK(c, hipMemsetAsync(c->njSlotI, 0, (size_t) 6 * c->njTopPad * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->njSlotR, 0, (size_t) 3 * c->njTopPad * rs, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->njCandI, 0, (size_t) 5 * c->njCapPad * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->njCandR, 0, (size_t) 5 * c->njCapPad * rs, c->stream));
     HIPCHK(c, hipHostMalloc((void **) &c->njLogHost, joins * sizeof(NjJoinRec), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void **) &c->njLogHostDev, c->njLogHost, 0));
     HIPCHK(c, hipHostMalloc((void **) &c->njStatusHost, 64, hipHostMallocMapped));
@@ -2709,6 +2728,8 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         else launch((k_nj_glue_scan<REAL, NC, 1024>), dim3(1), dim3(1024), c->njTailLds, c->stream, A, E, T, done, next, c->njP);
     };
     if (phases & VFT_NJ_PHASE_SEARCH) {
+        // (the slot records of the top-visible list: k_nj_merge_rank's second half alone)
+        launch((k_nj_merge_rank<REAL>), dim3((unsigned) cdiv(c->njCfg.n_top, VFT_WG)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, A, E, T, 0);
         glueScan(-1ll, ji);
         if (!c->njCfg.fastest) roundSpec();
     }
@@ -2731,7 +2752,10 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         // (the join kernel computes the new node's out-distance itself unless the caller recomputes the out-profile in between)
         if (!updateOut) launch((k_nj_refresh_new<REAL, NC>), dim3(1), dim3(VFT_WG), pairLds, c->stream, A, E);
         launch((k_nj_merge_pairs<REAL, NC>), dim3((unsigned) (2 * c->thM)), dim3(VFT_WG), pairLds, c->stream, A, E, T, ji, c->thTag);
-        launch((k_nj_merge_rank<REAL>), dim3(cdiv(2 * c->thM, VFT_NJ_RANK_PER_WG)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, E, T);
+        {
+            const int rankBlocks = (int) cdiv(2 * c->thM, VFT_NJ_RANK_PER_WG), prepBlocks = (int) cdiv(c->njCfg.n_top, VFT_WG);
+            launch((k_nj_merge_rank<REAL>), dim3((unsigned) (rankBlocks + prepBlocks)), dim3(VFT_WG), (size_t) c->njP * sizeof(ThKey), c->stream, A, E, T, rankBlocks);
+        }
         const bool chain = (phases & VFT_NJ_PHASE_NEXT) != 0;
         glueScan(ji, chain ? ji + 1 : -1ll);
         if (chain && !c->njCfg.fastest) roundSpec();

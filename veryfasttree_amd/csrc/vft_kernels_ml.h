@@ -907,57 +907,75 @@ __device__ __forceinline__ void vft_quad_posterior_col(const MlQuadTables<REAL> 
         fM2[i] = fM2[i] * e2[l + 4 * i];
         fPost[i] = 0;
     }
-    // (the loops over the 20 states run as loops of five trips: unrolled, one posterior was 12 KB of straight-line code - per
-    //  column and per place it is used - and the kernels executed from a cold instruction cache)
+    // Every lane of the quad fetches all 20 entries of both vectors (quad broadcasts) and forms the dot products of ITS five
+    // states j = l, l + 4, ... whole - four strided accumulators and (s0 + s1) + (s2 + s3), vft_red4_mul as the reference has
+    // it - instead of every lane adding a quarter of all 20 dot products and two exchanges per product finishing them: no
+    // cross-lane step inside the sums, eight independent chains per state.  (The loops over a lane's states stay loops: unrolled,
+    // one posterior was 12 KB of straight-line code per column and per place it is used.)
+    REAL g1[20], g2[20];
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) {
+        g1[4 * i] = vft_quad_perm<0x00>(fM1[i]);
+        g1[4 * i + 1] = vft_quad_perm<0x55>(fM1[i]);
+        g1[4 * i + 2] = vft_quad_perm<0xAA>(fM1[i]);
+        g1[4 * i + 3] = vft_quad_perm<0xFF>(fM1[i]);
+        g2[4 * i] = vft_quad_perm<0x00>(fM2[i]);
+        g2[4 * i + 1] = vft_quad_perm<0x55>(fM2[i]);
+        g2[4 * i + 2] = vft_quad_perm<0xAA>(fM2[i]);
+        g2[4 * i + 3] = vft_quad_perm<0xFF>(fM2[i]);
+    }
 #pragma unroll 1
     for (int jq = 0; jq < VFT_QS; jq++) {
-        REAL mine = 0;
+        const int j = l + 4 * jq;
+        const REAL *cf = Q->codeFreq + j * 20;
+        REAL s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int jl = 0; jl < 4; jl++) {
-            const int j = jl + 4 * jq;
-            const REAL *cf = Q->codeFreq + j * 20;
-            REAL s1 = 0, s2 = 0;
+        for (int i = 0; i < 20; i += 4)
 #pragma unroll
-            for (int i = 0; i < VFT_QS; i++) {   // vft_red4_mul(fM1, cf), vft_red4_mul(fM2, cf): accumulator l
-                const REAL c = cf[l + 4 * i];
-                const REAL p1 = fM1[i] * c, p2 = fM2[i] * c;
-                s1 = p1 + s1;
-                s2 = p2 + s2;
+            for (int a = 0; a < 4; a++) {   // vft_red4_mul(fM1, cf), vft_red4_mul(fM2, cf)
+                const REAL c = cf[i + a];
+                const REAL p1 = g1[i + a] * c, p2 = g2[i + a] * c;
+                s1[a] = p1 + s1[a];
+                s2[a] = p2 + s2[a];
             }
-            const REAL d1 = vft_quad_red4<REAL>(s1), d2 = vft_quad_red4<REAL>(s2);
-            REAL value = d1 * d2;
-            value = value * Q->statInv[j];
-            value = value >= 0 ? value : (REAL) 0;
-            if (jl == l) mine = value;   // state j belongs to lane j % 4
-        }
+        const REAL lo1 = s1[0] + s1[1], hi1 = s1[2] + s1[3], lo2 = s2[0] + s2[1], hi2 = s2[2] + s2[3];
+        const REAL d1 = lo1 + hi1, d2 = lo2 + hi2;
+        REAL value = d1 * d2;
+        value = value * Q->statInv[j];
+        value = value >= 0 ? value : (REAL) 0;
 #pragma unroll
-        for (int q = 0; q < VFT_QS; q++) fPost[q] = q == jq ? mine : fPost[q];
+        for (int q = 0; q < VFT_QS; q++) fPost[q] = q == jq ? value : fPost[q];
     }
     REAL st = 0;
 #pragma unroll
-    for (int i = 0; i < VFT_QS; i++) st = fPost[i] + st;   // vft_red4_sum
+    for (int i = 0; i < VFT_QS; i++) st = fPost[i] + st;   // vft_red4_sum: lane l is accumulator l
     const double tot = (double) vft_quad_red4<REAL>(st);
     const REAL invr = (REAL) (1.0 / tot);
 #pragma unroll
     for (int i = 0; i < VFT_QS; i++) fPost[i] = fPost[i] * invr;
+#pragma unroll
+    for (int i = 0; i < VFT_QS; i++) {
+        g1[4 * i] = vft_quad_perm<0x00>(fPost[i]);
+        g1[4 * i + 1] = vft_quad_perm<0x55>(fPost[i]);
+        g1[4 * i + 2] = vft_quad_perm<0xAA>(fPost[i]);
+        g1[4 * i + 3] = vft_quad_perm<0xFF>(fPost[i]);
+    }
 #pragma unroll 1
     for (int jq = 0; jq < VFT_QS; jq++) {
-        REAL mine = 0;
+        const int j = l + 4 * jq;
+        const REAL *ei = Q->eigenInv + j * 20;
+        REAL sv[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int jl = 0; jl < 4; jl++) {
-            const int j = jl + 4 * jq;
-            const REAL *ei = Q->eigenInv + j * 20;
-            REAL sv = 0;
+        for (int i = 0; i < 20; i += 4)
 #pragma unroll
-            for (int i = 0; i < VFT_QS; i++) {   // vft_red4_mul(fPost, eigeninv row j)
-                const REAL pr = fPost[i] * ei[l + 4 * i];
-                sv = pr + sv;
+            for (int a = 0; a < 4; a++) {   // vft_red4_mul(fPost, eigeninv row j)
+                const REAL pr = g1[i + a] * ei[i + a];
+                sv[a] = pr + sv[a];
             }
-            const REAL v = vft_quad_red4<REAL>(sv);
-            if (jl == l) mine = v;
-        }
+        const REAL lo = sv[0] + sv[1], hi = sv[2] + sv[3];
+        const REAL v = lo + hi;
 #pragma unroll
-        for (int q = 0; q < VFT_QS; q++) o.f[q] = q == jq ? mine : o.f[q];
+        for (int q = 0; q < VFT_QS; q++) o.f[q] = q == jq ? v : o.f[q];
     }
     o.vec = true;   // code == NOCODE, w == 1
 }

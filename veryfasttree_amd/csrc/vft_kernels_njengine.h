@@ -64,7 +64,7 @@ struct NjState {
     REAL specOut;
     int32_t specStamp, specValid, logCount;
     // the merge that follows a join (written by k_nj_glue_join): the new node, its children in id order, their lists' lengths
-    int32_t mergeNew, mergeC0, mergeC1, mergeN0, mergeN1;
+    int32_t mergeNew, mergeC0, mergeC1, mergeN0, mergeN1, mergeAge;   // mergeAge: (age[c0] + age[c1] + 1) / 2 + 1, NJ.tcc:4342-4345
 };
 
 template <typename REAL>
@@ -83,6 +83,13 @@ struct NjEngine {
     unsigned int *refClaim; // [maxNodes] one writer per refreshed node in a speculative double walk
     int32_t *logNode, *logStamp;   // [m] what the walk of the second end refreshed (undone when the first walk changes the candidate)
     REAL *logOut;
+    // what k_nj_glue_scan wants to know about the slots of the top-visible list and about the merge's candidates, gathered by
+    // the wide kernel in front of it (k_nj_merge_rank): slot t resp. rank r at [field * stride + index]
+    int32_t *slotI;         // [6][nTopPad]: node, parent[node], visible[node].j, stamp(node), parent[partner], stamp(partner)
+    REAL *slotR;            // [3][nTopPad]: visible[node].dist, outDist[node], outDist[partner]
+    int32_t *candI;         // [5][capPad]: partner j of the candidate of rank r; for r < m: visible[j].j, stamp(j), parent[v], stamp(v)
+    REAL *candR;            // [5][capPad]: distance, criterion; for r < m: visible[j].dist, outDist[j], outDist[v]
+    int32_t nTopPad, capPad;
 };
 
 template <typename REAL>
@@ -411,7 +418,7 @@ __device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, 
     }
     if (f1 != 0x7FFFFFFF) atomicMin(&first1, f1);
     if (s2 != 0x7FFFFFFF) atomicMin(&stop2, s2);
-    vft_nj_arg_reduce<true>(wc, wt, redC, redT);   // (its barriers also publish first1 and stop2)
+    __syncthreads();
     const int fFirst = first1;
     auto takeSlot = [&](int t) {   // thread 0: slot t now shows (iIn -> hit.j); its criterion from current out-distances
         S.node[t] = iIn;
@@ -451,8 +458,8 @@ __device__ __forceinline__ void vft_nj_update_top_visible(const Arena<REAL> &A, 
                 wt = t;
             }
         }
-        vft_nj_arg_reduce<true>(wc, wt, redC, redT);
     }
+    vft_nj_arg_reduce<true>(wc, wt, redC, redT);   // (only step 3 needs the reduction: the two dead slots of a join end most calls in step 1)
     if (threadIdx.x == 0 && wt >= 0) {
         const REAL b = *nRefreshes == 0 ? hitCrit : vft_nj_crit<REAL>(A, hitDist, iIn, hitJ, s.nActive);
         if ((double) b < wc) takeSlot(wt);
@@ -479,11 +486,48 @@ __device__ __forceinline__ void vft_nj_force_out_distance(const Arena<REAL> &A, 
 // Dynamic LDS: P keys.
 #define VFT_NJ_RANK_LANES 16
 #define VFT_NJ_RANK_PER_WG (VFT_WG / VFT_NJ_RANK_LANES)
+// Workgroups [0, rankBlocks) rank; workgroups beyond them gather, for k_nj_glue_scan, what it needs per slot of the top-visible
+// list (a single workgroup gathering 1 500 slots x 8 words from 8 MB arrays is bound by its CU's one cache line per cycle: 20 us
+// of that kernel); the lane that ranks a candidate also gathers the getVisible record updateVisible will test it against.
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopHits<REAL> T) {
+__global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, int rankBlocks) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     const NjState<REAL> *st = E.st;
     const int32_t halt = st->halt;
+    if ((int) blockIdx.x >= rankBlocks) {   // ---- slot records
+        const int t = ((int) blockIdx.x - rankBlocks) * (int) blockDim.x + (int) threadIdx.x;
+        const int32_t node = E.topvis[t < E.nTop ? t : E.nTop - 1];
+        if (halt || t >= E.nTop) return;
+        const int32_t nd = node >= 0 ? node : 0;
+        int32_t pn = A.parent[nd], vj = E.visJ[nd], si = A.nOutActive[nd];
+        REAL d0 = E.visD[nd], oi = A.outDist[nd];
+        if (node < 0) {
+            pn = 0;
+            vj = -1;
+            si = 0;
+            d0 = oi = 0;
+        }
+        const bool ok = node >= 0 && pn < 0 && vj >= 0;
+        const int32_t v = ok ? vj : 0;
+        int32_t pj = A.parent[v], sj = A.nOutActive[v];
+        REAL oj = A.outDist[v];
+        if (!ok) {
+            pj = 0;
+            sj = 0;
+            oj = 0;
+        }
+        const int S = E.nTopPad;
+        E.slotI[t] = node;
+        E.slotI[S + t] = pn;
+        E.slotI[2 * S + t] = vj;
+        E.slotI[3 * S + t] = si;
+        E.slotI[4 * S + t] = pj;
+        E.slotI[5 * S + t] = sj;
+        E.slotR[t] = d0;
+        E.slotR[S + t] = oi;
+        E.slotR[2 * S + t] = oj;
+        return;
+    }
     const int n = st->mergeN0 + st->mergeN1;
     // (all loads of the staging arrays in flight together: the kernel is two memory round trips and some LDS work)
     int32_t ju[VFT_NJ_BATCH];
@@ -533,6 +577,18 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     ke.nj = ~0u;
     ke.src = -1;
     if (e < n) ke = keys[e];
+    // (this candidate's distance, criterion and the getVisible record of its partner: asked for now, used after the ranking)
+    const int32_t cj = ke.src >= 0 ? (int32_t) ~ke.nj : 0;
+    REAL cD = 0, cC = 0, vd = 0, oi = 0;
+    int32_t vj = -1, si = 0;
+    if (part == 0 && ke.src >= 0) {
+        cD = T.stD[e];
+        cC = T.stC[e];
+        vj = E.visJ[cj];
+        vd = E.visD[cj];
+        oi = A.outDist[cj];
+        si = A.nOutActive[cj];
+    }
     if (ke.src >= 0) {
         int u = part;
         for (; u + 7 * VFT_NJ_RANK_LANES < n; u += 8 * VFT_NJ_RANK_LANES) {   // eight keys of this lane's share per trip: the LDS reads go out together
@@ -546,7 +602,30 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
     }
 #pragma unroll
     for (int off = 1; off < VFT_NJ_RANK_LANES; off <<= 1) rank += __shfl_xor(rank, off, 64);
-    if (part == 0 && ke.src >= 0) T.sorted[rank] = e;
+    if (part == 0 && ke.src >= 0) {
+        T.sorted[rank] = e;
+        const int S = E.capPad;
+        E.candI[rank] = cj;
+        E.candR[rank] = cD;
+        E.candR[S + rank] = cC;
+        if (rank < T.m) {
+            const int32_t v = vj >= 0 ? vj : 0;
+            int32_t pj = A.parent[v], sj = A.nOutActive[v];
+            REAL oj = A.outDist[v];
+            if (vj < 0) {
+                pj = 0;
+                sj = 0;
+                oj = 0;
+            }
+            E.candI[S + rank] = vj;
+            E.candI[2 * S + rank] = si;
+            E.candI[3 * S + rank] = pj;
+            E.candI[4 * S + rank] = sj;
+            E.candR[2 * S + rank] = vd;
+            E.candR[3 * S + rank] = oi;
+            E.candR[4 * S + rank] = oj;
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) T.sorted[T.cap] = nValid;
 }
 
@@ -555,23 +634,32 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_merge_rank(NjEngine<REAL> E, TopH
 // together and four threads add the four column-ordered chains (vft_pair_block twice costs two rounds of dependent loads).
 // Every thread calls; thread 0 gets the values.  LDS: sW / sT for v0, sW2 / sT2 for v1 (nPos doubles each).
 template <typename REAL, int NC>
-__device__ __forceinline__ void vft_nj_out_values2(const Arena<REAL> &A, const SweepArgs &s, int64_t v0, bool need0, int64_t v1, bool need1,
-                                                   double *sW, double *sT, double *sW2, double *sT2, REAL &od0, REAL &od1) {
+__device__ __forceinline__ void vft_nj_out_values2(const Arena<REAL> &A, const SweepArgs &s, int64_t v0, int64_t v1,
+                                                   double *sW, double *sT, double *sW2, double *sT2, REAL &od0, REAL &od1, bool &need0, bool &need1) {
+    // setOutDistance recomputes unless the stamp IS nActive (NJ.tcc:1012-1015) - which it almost never is here, so the columns are
+    // loaded without waiting for the stamps; threads 0 / 1 fetch the stamps and the scalars of the closed form meanwhile
     __shared__ double res2[4];
-    od0 = od1 = 0;
-    if (!need0 && !need1) return;   // (uniform)
+    __shared__ int needS[2];
     const int64_t nPos = A.d.nPos;
-    const bool row0 = need0 && vft_is_row<REAL>(A, v0), row1 = need1 && vft_is_row<REAL>(A, v1);
+    REAL selfW = 0, selfD = 0, dia = 0;
+    if (threadIdx.x < 2) {
+        const int64_t v = threadIdx.x ? v1 : v0;
+        needS[threadIdx.x] = (long long) vft_nj_ld(&A.nOutActive[v]) != s.nActive;
+        selfW = A.selfweight[v];
+        selfD = A.selfdist[v];
+        dia = A.diameter[v];
+    }
+    const bool row0 = vft_is_row<REAL>(A, v0), row1 = vft_is_row<REAL>(A, v1);
     for (int64_t p = threadIdx.x; p < nPos; p += blockDim.x) {
         Col<REAL, NC> a1, a2, b1, b2;
-        if (need0) vft_pair_load<REAL, NC>(A, v0, -1, true, p, a1, a2, row0, false);
-        if (need1) vft_pair_load<REAL, NC>(A, v1, -1, true, p, b1, b2, row1, false);
-        if (need0) vft_pair_addends<REAL, NC>(A, false, true, p, a1, a2, sW, sT);
-        if (need1) vft_pair_addends<REAL, NC>(A, false, true, p, b1, b2, sW2, sT2);
+        vft_pair_load<REAL, NC>(A, v0, -1, true, p, a1, a2, row0, false);
+        vft_pair_load<REAL, NC>(A, v1, -1, true, p, b1, b2, row1, false);
+        vft_pair_addends<REAL, NC>(A, false, true, p, a1, a2, sW, sT);
+        vft_pair_addends<REAL, NC>(A, false, true, p, b1, b2, sW2, sT2);
     }
     __syncthreads();
-    if (threadIdx.x < 4 && (threadIdx.x < 2 ? need0 : need1)) {   // top and denom of v0, top and denom of v1: each in column order
-        const double *src = threadIdx.x == 0 ? sT : threadIdx.x == 1 ? sW : threadIdx.x == 2 ? sT2 : sW2;
+    if (threadIdx.x < 4) {   // top and denom of v0, top and denom of v1: each in column order
+        const double *src = threadIdx.x == 0 ? sT : threadIdx.x == 1 ? sT2 : threadIdx.x == 2 ? sW : sW2;
         double acc = 0;
         int64_t p = 0;
         for (; p + 8 <= nPos; p += 8) {
@@ -582,21 +670,19 @@ __device__ __forceinline__ void vft_nj_out_values2(const Arena<REAL> &A, const S
             for (int u = 0; u < 8; u++) acc += v[u];
         }
         for (; p < nPos; p++) acc += src[p];
-        res2[threadIdx.x] = acc;
+        res2[threadIdx.x] = acc;   // [0] top(v0) [1] top(v1) [2] denom(v0) [3] denom(v1)
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (need0) {
-            const double top = res2[0], denom = res2[1];
-            const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
-            od0 = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v0], A.selfdist[v0], A.diameter[v0], s.totdiam);
-        }
-        if (need1) {
-            const double top = res2[2], denom = res2[3];
-            const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
-            od1 = vft_out_distance<REAL>(d, w, s.nActive, A.selfweight[v1], A.selfdist[v1], A.diameter[v1], s.totdiam);
-        }
+    REAL od = 0;
+    if (threadIdx.x < 2) {
+        const double top = res2[threadIdx.x], denom = res2[2 + threadIdx.x];
+        const REAL w = (REAL) (denom > 0 ? denom : 0.01), d = (REAL) (denom > 0 ? top / denom : 1.0);
+        od = vft_out_distance<REAL>(d, w, s.nActive, selfW, selfD, dia, s.totdiam);
     }
+    od0 = od;                              // (thread 0's value is v0's)
+    od1 = __shfl(od, 1, 64);               // (thread 0 gets thread 1's)
+    need0 = needS[0] != 0;
+    need1 = needS[1] != 0;
     __syncthreads();
 }
 
@@ -636,32 +722,50 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     __shared__ int redT[THREADS];
     const int tid = (int) threadIdx.x;
     const bool merge = doneJoin >= 0;
-    // ---- round 0
+    // ---- the one round of loads: the state block, the join's record, and the slot / candidate records k_nj_merge_rank gathered
+    // (all UNCONDITIONAL, from clamped indices, masked afterwards: a load inside a divergent branch makes the compiler wait for
+    //  it before the next one is issued)
     const int32_t halt = st->halt;
     const long long nActive = st->nActive;
     const double totdiam = st->totdiam;
-    const int32_t tvAge0 = st->tvAge;
+    const int32_t tvAge0 = st->tvAge, ageNew0 = st->mergeAge;
     NjJoinRec rec = E.logDev[merge ? doneJoin : 0];
     int nU = T.sorted[T.cap];
     if (!merge) {
         rec = NjJoinRec{};
         nU = 0;
     }
-    // (every load of a round is UNCONDITIONAL, from a clamped index, and masked afterwards: a load inside a divergent branch
-    //  makes the compiler wait for it before the next one is issued, which serialised the eight slots of a thread)
-    int32_t sNode[B];
-    int rSrc[B];
+    int32_t sNode[B], sPn[B], sVj[B], sSi[B], sPj[B], sSj[B], rJ[B], tVj[TB], tSi[TB], tPj[TB], tSj[TB];
+    REAL sD[B], sOi[B], sOj[B], rD[B], rC[B], tVd[TB], tOi[TB], tOj[TB];
+    {
+        const int S = E.nTopPad, C = E.capPad;
 #pragma unroll
-    for (int k = 0; k < B; k++) {
-        const int t = k * THREADS + tid;
-        sNode[k] = E.topvis[t < E.nTop ? t : E.nTop - 1];
-        rSrc[k] = T.sorted[t < T.cap ? t : T.cap - 1];   // (ranks beyond the number of candidates hold older entries: unused)
-    }
+        for (int k = 0; k < B; k++) {
+            const int t = k * THREADS + tid, ts = t < E.nTop ? t : E.nTop - 1, rs = t < T.cap ? t : T.cap - 1;
+            sNode[k] = E.slotI[ts];
+            sPn[k] = E.slotI[S + ts];
+            sVj[k] = E.slotI[2 * S + ts];
+            sSi[k] = E.slotI[3 * S + ts];
+            sPj[k] = E.slotI[4 * S + ts];
+            sSj[k] = E.slotI[5 * S + ts];
+            sD[k] = E.slotR[ts];
+            sOi[k] = E.slotR[S + ts];
+            sOj[k] = E.slotR[2 * S + ts];
+            rJ[k] = E.candI[rs];
+            rD[k] = E.candR[rs];
+            rC[k] = E.candR[C + rs];
+        }
 #pragma unroll
-    for (int k = 0; k < B; k++) {
-        const int t = k * THREADS + tid;
-        if (t >= E.nTop) sNode[k] = -1;
-        if (!merge || t >= T.cap) rSrc[k] = -1;
+        for (int k = 0; k < TB; k++) {
+            const int t = k * THREADS + tid, rs = t < T.m ? t : T.m - 1;
+            tVj[k] = E.candI[C + rs];
+            tSi[k] = E.candI[2 * C + rs];
+            tPj[k] = E.candI[3 * C + rs];
+            tSj[k] = E.candI[4 * C + rs];
+            tVd[k] = E.candR[2 * C + rs];
+            tOi[k] = E.candR[3 * C + rs];
+            tOj[k] = E.candR[4 * C + rs];
+        }
     }
     if (halt) return;
     const SweepArgs s = vft_nj_args(E, nActive, totdiam);
@@ -669,92 +773,29 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     unsigned long long tick_ = wall_clock64();
 #endif
     if (tid == 0) thCount = nPass = nRefreshes = nCand = slotsStale = 0;
-    const int32_t newnode = rec.newnode, c0 = rec.i < rec.j ? rec.i : rec.j, c1 = rec.i < rec.j ? rec.j : rec.i;
+    const int32_t newnode = rec.newnode;
     const int nSave = nU < E.m ? nU : E.m;
-    // ---- round 1
-    int32_t sPn[B], sVj[B], sSi[B], rJ[B], ageA = 0, ageB = 0;
-    REAL sD[B], sOi[B], rD[B], rC[B];
 #pragma unroll
     for (int k = 0; k < B; k++) {
-        const int32_t nd = sNode[k] >= 0 ? sNode[k] : 0;
-        sPn[k] = A.parent[nd];
-        sVj[k] = vft_nj_ld(&E.visJ[nd]);
-        sD[k] = vft_nj_ld(&E.visD[nd]);
-        sOi[k] = vft_nj_ld(&A.outDist[nd]);
-        sSi[k] = vft_nj_ld(&A.nOutActive[nd]);
-        const int r = k * THREADS + tid;
-        const int src = r < nU ? rSrc[k] : 0;
-        rJ[k] = T.stJ[src];
-        rD[k] = T.stD[src];
-        rC[k] = T.stC[src];
-    }
-    ageA = E.age[merge ? c0 : 0];
-    ageB = E.age[merge ? c1 : 0];
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-        if (sNode[k] < 0) {
+        const int t = k * THREADS + tid;
+        if (t >= E.nTop) {
+            sNode[k] = -1;
             sPn[k] = 0;
             sVj[k] = -1;
-            sSi[k] = 0;
-            sD[k] = sOi[k] = 0;
+            sSi[k] = sPj[k] = sSj[k] = 0;
+            sD[k] = sOi[k] = sOj[k] = 0;
         }
-        if (k * THREADS + tid >= nU) {
+        if (t >= nU) {
             rJ[k] = -1;
             rD[k] = rC[k] = 0;
-        }
-    }
-    // ---- round 2
-    int32_t sPj[B], sSj[B], tVj[TB], tSi[TB];
-    REAL sOj[B], tVd[TB], tOi[TB];
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-        const bool ok = sNode[k] >= 0 && sPn[k] < 0 && sVj[k] >= 0;
-        const int32_t vj = ok ? sVj[k] : 0;
-        sPj[k] = A.parent[vj];
-        sOj[k] = vft_nj_ld(&A.outDist[vj]);
-        sSj[k] = vft_nj_ld(&A.nOutActive[vj]);
-    }
-#pragma unroll
-    for (int k = 0; k < TB; k++) {
-        const int r = k * THREADS + tid;
-        const int32_t nd = r < nSave ? rJ[k] : 0;
-        tVj[k] = vft_nj_ld(&E.visJ[nd]);
-        tVd[k] = vft_nj_ld(&E.visD[nd]);
-        tOi[k] = vft_nj_ld(&A.outDist[nd]);
-        tSi[k] = vft_nj_ld(&A.nOutActive[nd]);
-    }
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-        if (!(sNode[k] >= 0 && sPn[k] < 0 && sVj[k] >= 0)) {
-            sPj[k] = 0;
-            sSj[k] = 0;
-            sOj[k] = 0;
         }
     }
 #pragma unroll
     for (int k = 0; k < TB; k++) {
         if (k * THREADS + tid >= nSave) {
             tVj[k] = -1;
-            tSi[k] = 0;
-            tVd[k] = tOi[k] = 0;
-        }
-    }
-    // ---- round 3
-    int32_t tPj[TB], tSj[TB];
-    REAL tOj[TB];
-#pragma unroll
-    for (int k = 0; k < TB; k++) {
-        const int32_t vj = tVj[k] >= 0 ? tVj[k] : 0;
-        tPj[k] = A.parent[vj];
-        tOj[k] = vft_nj_ld(&A.outDist[vj]);
-        tSj[k] = vft_nj_ld(&A.nOutActive[vj]);
-    }
-#pragma unroll
-    for (int k = 0; k < TB; k++) {
-        if (tVj[k] < 0) {
-            tPj[k] = 0;
-            tSj[k] = 0;
-            tOj[k] = 0;
+            tSi[k] = tPj[k] = tSj[k] = 0;
+            tVd[k] = tOi[k] = tOj[k] = 0;
         }
     }
     // ---- the slot cache (as vft_nj_slots_load leaves it) and the candidates by rank, into LDS
@@ -799,8 +840,8 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     if (merge) {
         VFT_NJ_TICK(1);
         VFT_NJ_TICK(2);
-        // NJ.tcc:4342-4362
-        const int32_t ageNew = (ageA + ageB + 1) / 2 + 1;
+        // NJ.tcc:4342-4362 (the new list's age: k_nj_glue_join formed it from the children's)
+        const int32_t ageNew = ageNew0;
         const bool useUnique = (long long) nU == nActive - 1 || (ageNew <= E.ageLimit && nU >= E.need);
         if (!useUnique) {
             if (tid == 0) {
@@ -959,7 +1000,7 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     }
     if (mine) atomicAdd(&nCand, mine);
     vft_nj_arg_reduce<false>(bc, bt, redC, redT);
-    __shared__ int scanHalt, scanI, scanJ, needI, needJ;
+    __shared__ int scanHalt, scanI, scanJ;
     if (tid == 0) {
         const int age = tvAge0 + 1;
         st->tvAge = age;
@@ -978,8 +1019,6 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
             st->curCrit = (REAL) S.crit[b];
             st->changed = 0;
             st->runRound = 1;
-            needI = (long long) vft_nj_ld(&A.nOutActive[scanI]) != nActive;
-            needJ = (long long) vft_nj_ld(&A.nOutActive[scanJ]) != nActive;
         }
         vft_nj_publish(E, st);
     }
@@ -992,8 +1031,9 @@ __global__ __launch_bounds__(THREADS) void k_nj_glue_scan(Arena<REAL> A, NjEngin
     // walk must not see (its own hit (i, j) is evaluated with j's out-distance as it was): computed here, kept in the state
     // block, stored by k_nj_glue_join once the first walk has confirmed the candidate.
     REAL odI, odJ;
+    bool needI, needJ;
     const int64_t vI = scanI, vJ = scanJ;
-    vft_nj_out_values2<REAL, NC>(A, s, vI, needI != 0, vJ, needJ != 0, sW, sT, sW2, sT2, odI, odJ);
+    vft_nj_out_values2<REAL, NC>(A, s, vI, vJ, sW, sT, sW2, sT2, odI, odJ, needI, needJ);
     if (tid == 0) {
         if (needI) {
             A.outDist[vI] = odI;
@@ -1320,7 +1360,8 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
         // (one round of loads: the ends' out-distances, stamps and diameters, their lists' lengths for the merge)
         const REAL dist = curDist0;
         const REAL outI = A.outDist[i], outJ = A.outDist[j], diaI = A.diameter[i], diaJ = A.diameter[j];
-        const int32_t stampI = A.nOutActive[i], stampJ = A.nOutActive[j], lenI = T.len[i], lenJ = T.len[j];
+        const int32_t stampI = A.nOutActive[i], stampJ = A.nOutActive[j], lenI = T.len[i], lenJ = T.len[j], ageI = E.age[i], ageJ = E.age[j];
+        st->mergeAge = (ageI + ageJ + 1) / 2 + 1;
         st->mergeNew = (int32_t) newn;
         st->mergeC0 = (int32_t) (i < j ? i : j);
         st->mergeC1 = (int32_t) (i < j ? j : i);
