@@ -99,7 +99,7 @@ def cpu_baseline(state, codes, ops, budget_s=6.0):
                 value_1_thread=rates[1][0], value_half_cores=rates[max(1, cores // 2)][0],
                 scaling_all_cores_vs_1_thread=rates[cores][0] / rates[1][0],
                 sample="%d sweeps on %d threads, %d on %d, %d on 1 thread, each of one seed vs %d active leaves + %d internal "
-                       "profiles of the same alignment (team-allocated, first-touched copy; static blocks of 64 targets); "
+                       "profiles of the same alignment (team-allocated, first-touched copy; static blocks of 64 targets; all repetitions inside one parallel region); "
                        "AVX2 + OpenMP restatement (oracle/vft_oracle_avx2.c)"
                        % (rates[cores][1], cores, rates[max(1, cores // 2)][1], max(1, cores // 2), rates[1][1], len(leaf_ids), len(int_ids)))
 

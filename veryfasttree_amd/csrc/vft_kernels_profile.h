@@ -316,17 +316,43 @@ __global__ void k_average_chain(Arena<REAL> A, const int64_t *outN, const int64_
                                 int32_t n, double tol) {
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
+    // Every op was three dependent memory rounds (its ids, its two columns, and - for an input that is the previous op's output -
+    // a store that has to land before it can be read back): 5 us per op, 124 000 launches in a 3 000-taxon protein run.  The
+    // next op's ids are fetched while the current one computes, and the previous op's column is handed over in registers.
+    int64_t prevOut = -1, aNext = aN[0], bNext = bN[0], oNext = outN[0];
+    uint8_t dNext = direct[0];
+    Col<REAL, NC> prev;
+    prev.w = 0;
+    prev.code = VFT_NOCODE_;
+    prev.vec = false;
+#pragma unroll
+    for (int q = 0; q < NC; q++) prev.f[q] = 0;
     for (int32_t k = 0; k < n; k++) {
+        const int64_t a = aNext, b = bNext, o = oNext;
+        const uint8_t d = dNext;
+        if (k + 1 < n) {
+            aNext = aN[k + 1];
+            bNext = bN[k + 1];
+            oNext = outN[k + 1];
+            dNext = direct[k + 1];
+        }
         Col<REAL, NC> c1, c2;
-        const uint8_t d = direct[k];
-        if (d & 1) vft_load_row<REAL, NC>(A, aN[k], p, c1);
-        else vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
-        if (d & 2) vft_load_row<REAL, NC>(A, bN[k], p, c2);
-        else vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
+        if (a == prevOut) c1 = prev;
+        else if (d & 1) vft_load_row<REAL, NC>(A, a, p, c1);
+        else vft_load_col_ml<REAL, NC>(A, a, p, c1);
+        if (b == prevOut) c2 = prev;
+        else if (d & 2) vft_load_row<REAL, NC>(A, b, p, c2);
+        else vft_load_col_ml<REAL, NC>(A, b, p, c2);
         REAL wo, f[NC];
         int co;
         vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
-        vft_store_col_ml<REAL, NC>(A, outN[k], p, wo, co, f);
+        vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
+        prevOut = o;
+        prev.w = wo;
+        prev.code = co;
+        prev.vec = wo > 0 && co == VFT_NOCODE_;   // what vft_load_row would find
+#pragma unroll
+        for (int q = 0; q < NC; q++) prev.f[q] = f[q];
     }
     // (the row flags are raised by k_mark_rows afterwards: raising them here would race with workgroups that are still
     //  on an earlier op and read the same node through its flag)
