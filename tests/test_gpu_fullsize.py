@@ -177,3 +177,28 @@ def test_nj_driver_join_order_is_rank_count_independent(mode):
     for r, crc, nj, calls in got:
         assert (crc, nj) == want, (r, crc, nj, want)
         assert int(calls) > 10          # the exchange really ran
+
+
+@pytest.mark.gpu
+def test_c4_join_order_equals_the_reference_trace():
+    """Config C4 (1 000 000 x 200 nt, default settings): the first joins of the NJ phase against the reference's own `Join` trace
+    (`-verbose 3`), as far as the one-thread reference got while the fixture was made (tests/golden/bb_c4_prefix.npz: CRC-32 of
+    every 10 000 joins, oracle/gen_fixtures.py c4 / c4_prefix).  The top-hit lists, setAllLeafTopHits over 10^6 leaves, the
+    join engine with m = 1 000 and the top-hits refreshes all run at their full size here."""
+    import os, zlib
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_run
+    path = os.path.join(os.path.dirname(__file__), "golden", "bb_c4_prefix.npz")
+    g = np.load(path)
+    chunk, want = int(g["join_chunk"]), g["join_chunk_crc"]
+    spec = bytes(g["alignment"]).decode()
+    assert spec == "random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)"
+    codes = synth.random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)
+    codes = codes[np.sort(np.unique(codes, axis=0, return_index=True)[1])]
+    n_check = min(len(want), 3) * chunk   # (the early joins are the expensive ones: 30 000 of them keep the test under a minute)
+    ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+    joins, _ = nj_run(ops, codes, max_joins=n_check)
+    ops.close()
+    assert len(joins) == n_check
+    for k in range(n_check // chunk):
+        assert zlib.crc32(joins[k * chunk:(k + 1) * chunk].astype("<i4").tobytes()) == int(want[k]), "joins %d..%d differ from the reference's" % (k * chunk, (k + 1) * chunk)

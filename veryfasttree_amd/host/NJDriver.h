@@ -139,7 +139,7 @@ namespace veryfasttree {
                 initTopHits(m);
                 setAllLeafTopHits();
                 resetTopVisible(nSeqs);
-                if (devLists && !hostLists && opt.deviceJoins && maxJoins < 0 && std::getenv("VFT_NJ_HOST_JOINS") == nullptr && runEngine()) return joins;
+                if (devLists && !hostLists && opt.deviceJoins && std::getenv("VFT_NJ_HOST_JOINS") == nullptr && runEngine(maxJoins)) return joins;
             }
             int64_t nActiveReset = nSeqs;
             for (int64_t nActive = nSeqs; nActive > 3; nActive--) {
@@ -278,7 +278,7 @@ namespace veryfasttree {
         }
 
         /* false: the engine cannot be used on this context (the caller runs the host-driven loop) */
-        bool runEngine() {
+        bool runEngine(int64_t maxJoins = -1) {
             vft_nj_engine_config cfg;
             memset(&cfg, 0, sizeof(cfg));
             cfg.m = (int32_t) m;
@@ -305,7 +305,7 @@ namespace veryfasttree {
             }
             chkT("vft_nj_engine_set_state", [&]() { return vft_nj_engine_set_state(ctx, nSeqs, nSeqs, totdiam, 0); });
             engineUploadTopVisible();
-            const int64_t nTotal = nSeqs - 3;
+            const int64_t nTotal = maxJoins >= 0 ? std::min(maxJoins, nSeqs - 3) : nSeqs - 3;   /* (a truncated run: tests) */
             const int64_t window = std::getenv("VFT_NJ_ENGINE_WINDOW") ? std::max(1, atoi(std::getenv("VFT_NJ_ENGINE_WINDOW"))) : 16;   /* (debugging) */
             int64_t enq = 0, nActiveReset = nSeqs;
             bool climbPending = false, needSearch = true;   /* needSearch: the search of join `enq` has not been enqueued behind the previous merge */
