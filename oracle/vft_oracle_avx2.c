@@ -1,3 +1,4 @@
+#define _GNU_SOURCE   /* sched_setaffinity: the timed leg pins its threads */
 /* TEST INFRASTRUCTURE - the CPU baseline of SURVEY.md section 8d: an AVX2 + OpenMP restatement of the batched
  * one-vs-all sweep (setBestHit, NJ.tcc:3571-3646, over seqDist NJ.tcc:1601-1624 / profileDist NJ.tcc:1167-1190 with the
  * no-matrix branch of profileDistPiece NJ.tcc:919-940 and the criterion of NJ.tcc:1099-1107) for the nucleotide
@@ -15,6 +16,7 @@
  * Out-distances are taken as given (no lazy refresh): the caller passes fresh ones. */
 #include <immintrin.h>
 #include <omp.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -171,7 +173,27 @@ double vfto_avx2_sweep_bench_f32(const vfto_state_f32 *st, const int64_t *querie
     float *diam = (float *) malloc((size_t) n * sizeof(float)), *od = (float *) malloc((size_t) n * sizeof(float));
     float *hw = (float *) malloc((size_t) n * sizeof(float)), *hd = (float *) malloc((size_t) n * sizeof(float)),
           *hc = (float *) malloc((size_t) n * sizeof(float));
-#pragma omp parallel for schedule(static, VFTO_BENCH_BLOCK) num_threads(nThreads)
+    /* The threads of the first-touch and of the timed regions are pinned, evenly spread over the CPUs this process may use (and
+       released afterwards): unpinned, a 64-thread team ran its first 8 sweeps at 41x the one-thread rate and the next 5 000 at
+       9x - the scheduler moves threads away from the memory they first touched (no numactl on the box). */
+    cpu_set_t allowed;
+    int cpus[4096], nCpu = 0;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE && nCpu < 4096; c++)
+            if (CPU_ISSET(c, &allowed)) cpus[nCpu++] = c;
+#define VFTO_PIN()                                                                                                 \
+    cpu_set_t before, mine;                                                                                        \
+    const int pinned = nCpu >= omp_get_num_threads() && sched_getaffinity(0, sizeof(before), &before) == 0;        \
+    if (pinned) {                                                                                                  \
+        CPU_ZERO(&mine);                                                                                           \
+        CPU_SET(cpus[(int64_t) omp_get_thread_num() * nCpu / omp_get_num_threads()], &mine);                       \
+        sched_setaffinity(0, sizeof(mine), &mine);                                                                 \
+    }
+#define VFTO_UNPIN() if (pinned) sched_setaffinity(0, sizeof(before), &before)
+#pragma omp parallel num_threads(nThreads)
+    {
+    VFTO_PIN()
+#pragma omp for schedule(static, VFTO_BENCH_BLOCK)
     for (int64_t j = 0; j < n; j++) {
         memcpy(W + j * nPos, st->W + j * nPos, (size_t) nPos * sizeof(float));
         memcpy(F + j * nPos * 4, st->F + j * nPos * 4, (size_t) nPos * 4 * sizeof(float));
@@ -181,6 +203,8 @@ double vfto_avx2_sweep_bench_f32(const vfto_state_f32 *st, const int64_t *querie
         od[j] = outDist[j];
         nOut[j] = nOutActive[j];
         hw[j] = hd[j] = hc[j] = 0;
+    }
+    VFTO_UNPIN();
     }
     loc.W = W;
     loc.F = F;
@@ -208,11 +232,13 @@ double vfto_avx2_sweep_bench_f32(const vfto_state_f32 *st, const int64_t *querie
         const double t0 = omp_get_wtime();
 #pragma omp parallel num_threads(nThreads)
         {
+            VFTO_PIN()
             for (int64_t r = 0; r < reps; r++) {
                 const int64_t q = r % nQueries;
 #pragma omp for schedule(static, VFTO_BENCH_BLOCK)
                 for (int64_t j = 0; j < n; j++) sweep_target(&loc, tabs[q], queries[q], j, nActive, od, nOut, hw, hd, hc);
             }
+            VFTO_UNPIN();
         }
         const double dt = omp_get_wtime() - t0;
         if (round == 1 || dt >= budget) {
