@@ -58,6 +58,34 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) and the
+    CPUs its affinity mask allows: a pod that gets a slice of the box cannot scale beyond its quota whatever the thread count."""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = None
+    load = None
+    try:
+        load = float(open("/proc/loadavg").read().split()[0])
+    except (OSError, ValueError):
+        pass
+    return dict(cgroup_quota_cpus=quota, affinity_cpus=allowed, loadavg_1min_before=load)
+
+
 def cpu_baseline(state, codes, ops, budget_s=6.0):
     """SURVEY.md 8d "CPU baseline beside it": this repo's AVX2 + OpenMP restatement of the one-vs-all sweep
     (oracle/vft_oracle_avx2.c: -O3 -mavx2 -mfma -fopenmp, bit-identical to the scalar oracle that is pinned to the
@@ -65,7 +93,8 @@ def cpu_baseline(state, codes, ops, budget_s=6.0):
     against 170 000 active leaves + 80 000 internal profiles of the same alignment (1 GB in the oracle's dense layout).
     The timed leg allocates and first-touches its own copy of the sample inside the OpenMP team, static blocks of 64
     targets per thread, so that every thread streams memory of its own NUMA node; run on every core, on half of them
-    (one socket's worth) and on one thread, ~budget_s seconds each.  `value` is the all-core rate."""
+    (one socket's worth) and on one thread, ~budget_s seconds each.  `value` is the rate on all the cores the container may use
+    (its cgroup CPU quota and affinity mask, reported in `host`: the pool's GPU pods get 16 CPUs' worth of a 256-thread box)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import Oracle, avx2_max_threads
     orc = Oracle(ops.dt)
@@ -90,6 +119,13 @@ def cpu_baseline(state, codes, ops, budget_s=6.0):
     cores = avx2_max_threads()
     # alternate internal / leaf seeds like the GPU step
     queries = np.array([(len(leaf_ids) + q // 2) % m if q % 2 == 0 else q // 2 for q in range(16)], np.int64)
+    host = cpu_quota_cores()
+    # a container with a CPU quota (the pool's GPU pods: 16 CPUs' worth of a 256-thread box) cannot use more cores than that:
+    # a team of 128 threads only fights over the quota's time slices (measured: 128 threads slower than 64, 5-9x one thread)
+    if host["cgroup_quota_cpus"]:
+        cores = max(1, min(cores, int(host["cgroup_quota_cpus"] + 0.5)))
+    if host["affinity_cpus"]:
+        cores = max(1, min(cores, host["affinity_cpus"]))
     rates = {}
     for threads in sorted({cores, max(1, cores // 2), 1}, reverse=True):
         secs, done, _ = orc.avx2_sweep_bench(st, queries, state.n_active, od, na, threads=threads,
@@ -97,7 +133,7 @@ def cpu_baseline(state, codes, ops, budget_s=6.0):
         rates[threads] = (done * m / secs, done)
     return dict(value=rates[cores][0], unit="profile-ops/s", cores=cores, kind="port", cpu=cpu_model(),
                 value_1_thread=rates[1][0], value_half_cores=rates[max(1, cores // 2)][0],
-                scaling_all_cores_vs_1_thread=rates[cores][0] / rates[1][0],
+                scaling_all_cores_vs_1_thread=rates[cores][0] / rates[1][0], host=host,
                 sample="%d sweeps on %d threads, %d on %d, %d on 1 thread, each of one seed vs %d active leaves + %d internal "
                        "profiles of the same alignment (team-allocated, first-touched copy; static blocks of 64 targets; all repetitions inside one parallel region); "
                        "AVX2 + OpenMP restatement (oracle/vft_oracle_avx2.c)"

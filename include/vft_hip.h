@@ -399,6 +399,7 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_GENERIC_OUTPROFILE 4 /* value != 0: vft_out_profile_full always takes the one-thread-per-column kernel */
 #define VFT_DEBUG_FAULT_NO_FLAG 5      /* value != 0: fault injection - the next wait for a completion flag waits for a value no kernel publishes */
 #define VFT_DEBUG_WAIT_LIMIT_MS 6      /* the longest a wait for a completion flag may last while the stream is busy (default 120 000) */
+#define VFT_DEBUG_WIDE_GLUE 7          /* value != 0: vft_nj_engine_create takes the 1 024-thread glue kernel (lists beyond 1 024 hits) at any size */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */

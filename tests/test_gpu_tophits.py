@@ -159,12 +159,13 @@ def test_driver_cross_checks_every_device_walk_against_the_host_walk(name, faste
     ops.close()
 
 
-@pytest.mark.parametrize("fastest", [False, True])
-def test_join_engine_equals_the_host_driven_loop(fastest, monkeypatch):
+@pytest.mark.parametrize("fastest,wide", [(False, False), (True, False), (False, True)])
+def test_join_engine_equals_the_host_driven_loop(fastest, wide, monkeypatch):
     """The join loop on the device (vft_nj_engine_*: kernels that take their arguments from a device-resident state block,
     the host only handling resets and refreshes) against the host-driven loop of the same driver on a 6 000 x 150 alignment:
     every join (i, j, new node) and every criterion, bit for bit.  (The fixtures of test_gpu_nj_driver.py pin both to the
-    reference.)"""
+    reference.)  wide: the 1 024-thread instance of the glue kernel, which lists of more than 1 024 hits (beyond a million
+    sequences) select, forced at this size (VFT_DEBUG_WIDE_GLUE)."""
     from veryfasttree_amd import HipProfileOps, synth
     from veryfasttree_amd.backend import nj_run
     codes = synth.random_descent_codes(6000, 150, 4, 0.04, 0.02, seed=77)
@@ -174,6 +175,8 @@ def test_join_engine_equals_the_host_driven_loop(fastest, monkeypatch):
         if host:
             monkeypatch.setenv("VFT_NJ_HOST_JOINS", "1")
         ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+        if wide and not host:
+            ops.debug_option(7, 1)
         runs.append(nj_run(ops, codes, fastest=fastest, second_level=False))
         ops.close()
     assert np.array_equal(runs[0][0], runs[1][0])

@@ -59,6 +59,7 @@ struct vft_ctx {
     int fusedLimit = 2048;         // workgroups of k_pairs_refresh_fused that are resident at once (set by vft_create)
     bool faultNoFlag = false;      // VFT_DEBUG_FAULT_NO_FLAG: the next wait for a completion flag waits for one that never comes
     double waitLimitS = 120.0;     // how long a wait for a completion flag may last while the stream is busy
+    bool wideGlue = false;         // test hook: the 1 024-thread instance of k_nj_glue_scan at any size
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -2476,7 +2477,7 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     if (c->njTailLds > (160u << 10) - (16u << 10) || 2 * pairLds > (160u << 10) - (16u << 10))
         return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists or alignment too long for the glue kernels' LDS");
     // a thread of k_nj_glue_scan holds VFT_NJ_BATCH slots of the top-visible list and as many ranks of the merge
-    c->njTailThreads = std::max(cfg->n_top, P) <= VFT_NJ_BATCH * VFT_NJ_TAIL ? VFT_NJ_TAIL : 1024;
+    c->njTailThreads = std::max(cfg->n_top, P) <= VFT_NJ_BATCH * VFT_NJ_TAIL && !c->wideGlue ? VFT_NJ_TAIL : 1024;
     if (std::max(cfg->n_top, P) > VFT_NJ_BATCH * 1024) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: lists too long for the glue kernel");
     if (int r = ensure_ml_rows(c)) return r;
     if (!c->pendBase) {
@@ -3357,6 +3358,7 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_GENERIC_OUTPROFILE: c->genericOutProfile = value != 0; break;
         case VFT_DEBUG_FAULT_NO_FLAG: c->faultNoFlag = value != 0; break;
         case VFT_DEBUG_WAIT_LIMIT_MS: c->waitLimitS = value > 0 ? (double) value / 1000.0 : 120.0; break;
+        case VFT_DEBUG_WIDE_GLUE: c->wideGlue = value != 0; break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }
     return VFT_OK;

@@ -709,12 +709,14 @@ __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, i
 // workgroup must call; sW / sT: nPosPad doubles each; the results are broadcast.
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
-                                               double *sT, REAL &dist, REAL &weight) {
+                                               double *sT, REAL &dist, REAL &weight, bool rowsById = false) {
     __shared__ double res[2];
     const int64_t nPos = A.d.nPos;
     const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
     // two columns per thread and trip, loads of both issued before the first is consumed (as in vft_pair_wave)
-    const bool iRow = vft_is_row<REAL>(A, i), jRow = !jIsOut && vft_is_row<REAL>(A, j);
+    // (rowsById: the caller knows that every internal node has its row - the join engine, whose joins write rows - and spares
+    //  the flag's memory round trip in front of the column loads)
+    const bool iRow = rowsById ? i >= A.d.nSeqs : vft_is_row<REAL>(A, i), jRow = !jIsOut && (rowsById ? j >= A.d.nSeqs : vft_is_row<REAL>(A, j));
     for (int64_t p = threadIdx.x; p < nPos; p += 2 * (int64_t) blockDim.x) {
         const int64_t pb = p + blockDim.x;
         const bool hasB = pb < nPos;

@@ -100,6 +100,7 @@ struct ThPairSpec {
     unsigned int tag;
     int32_t *logNode, *logStamp, *logCount;
     REAL *logOut;
+    bool rowsById = false;   // every internal node has its row (the join engine): no flag lookup in front of the column loads
 };
 
 template <typename REAL, int NC>
@@ -116,11 +117,15 @@ __device__ __forceinline__ void vft_th_pair(const Arena<REAL> &A, const SweepArg
         oi = spec && spec->ovOut ? *spec->ovOut : A.outDist[i];
     }
     if (recompute) {
-        REAL w;
-        vft_pair_block<REAL, NC>(A, i, j, false, sW, sT, d, w);
+        REAL w, diaI = 0, diaJ = 0;
+        if (threadIdx.x == 0) {   // (asked for before the distance, not after it)
+            diaI = A.diameter[i];
+            diaJ = A.diameter[j];
+        }
+        vft_pair_block<REAL, NC>(A, i, j, false, sW, sT, d, w, spec && spec->rowsById);
         if (!(i < A.d.nSeqs && j < A.d.nSeqs)) {
-            const REAL dd = A.diameter[i] + A.diameter[j];
-            d = d - dd;
+            const REAL dd = diaI + diaJ;
+            d = d - dd;   // (thread 0's value is the one used: the criterion and the staging store are thread 0's)
         }
     }
     if (threadIdx.x == 0) thStale = (int64_t) sj - s.nActive > s.nDiffAllow;
