@@ -23,6 +23,26 @@ __global__ void clocks(unsigned long long *out, int n, float a, float b) {
     }
     if (x == 12345.678f) out[2] = (unsigned long long) x;
 }
+// dependent double-precision chains, 64 operations per trip: plain multiply, multiply written as fma(x, a, 0), add
+template <int OP>
+__global__ void clocks64(unsigned long long *out, int n, double a) {
+    double x = 1.0 + (double) threadIdx.x * 1e-9;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int u = 0; u < 64; u++) {
+            if (OP == 0) x = x * a;
+            else if (OP == 1) x = __builtin_fma(x, a, 0.0);
+            else x = x + a;
+        }
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+    }
+    if (x == 12345.678) out[2] = (unsigned long long) x;
+}
 __global__ void chain64(double *out, int n, double a, double b) {
     double x = (double) threadIdx.x;
     for (int i = 0; i < n; i++) x = x * a + b;
@@ -83,6 +103,15 @@ int main() {
         hipDeviceSynchronize();
         printf("grid %5d: %llu shader-clock ticks, %llu ticks of 100 MHz for %d x 64 dependent FMAs: s_memtime runs at %.1f MHz; %.2f ns, %.2f s_memtime ticks per FMA\n",
                grid, ck[0], ck[1], m, (double) ck[0] / ((double) ck[1] / 100.0), (double) ck[1] * 10.0 / (64.0 * m), (double) ck[0] / (64.0 * m));
+    }
+    const char *names[3] = {"v_mul_f64", "v_fma_f64 (x * a + 0)", "v_add_f64"};
+    for (int op = 0; op < 3; op++) {
+        const int m = 50000;
+        if (op == 0) hipLaunchKernelGGL(clocks64<0>, dim3(1), dim3(64), 0, s, ck, m, 1.0000001);
+        else if (op == 1) hipLaunchKernelGGL(clocks64<1>, dim3(1), dim3(64), 0, s, ck, m, 1.0000001);
+        else hipLaunchKernelGGL(clocks64<2>, dim3(1), dim3(64), 0, s, ck, m, 1.0000001);
+        hipDeviceSynchronize();
+        printf("dependent %-24s %.2f ns = %.2f shader clocks per operation\n", names[op], (double) ck[1] * 10.0 / (64.0 * m), (double) ck[0] / (64.0 * m));
     }
     return 0;
 }

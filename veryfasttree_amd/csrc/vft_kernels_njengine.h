@@ -1463,92 +1463,34 @@ __global__ __launch_bounds__(VFT_WG) void k_nj_refresh_new(Arena<REAL> A, NjEngi
     vft_nj_out_distance<REAL, NC>(A, s, st->maxnode - 1, njLds, njLds + A.d.nPosPad);
 }
 
-// uniqueBestHits of the two children's lists (k_th_join's first half; grid = 2 m, workgroups beyond the lists leave).
-// A workgroup's work is a chain of memory round trips - the list entry, is its partner still active, who owns the partner, row
-// flags, the two profiles, stamps and diameters - so everything that hangs on the list entry is asked for AT ONCE on the guess
-// that the partner is still active (it was joined since the list was made in a few per cent of the entries): the ownership claim
-// on the guessed partner is harmless when the guess is wrong (nobody's active ancestor is an inactive node), and the distance is
-// simply computed again for the real partner.
+// uniqueBestHits of the two children's lists (k_th_join's first half; grid = 2 m, workgroups beyond the lists leave)
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WG) void k_nj_merge_pairs(Arena<REAL> A, NjEngine<REAL> E, TopHits<REAL> T, long long joinIndex, unsigned int tag) {
     extern __shared__ __attribute__((aligned(16))) double njLds[];
     const NjState<REAL> *st = E.st;
     if (st->halt) return;
-    __shared__ int thOwner, thJ, thAgain, thStale;
+    __shared__ int thOwner;
     // (the join's record as k_nj_glue_join left it in the state block: no chain log -> lengths -> hits)
     const int64_t newnode = st->mergeNew, c0 = st->mergeC0, c1 = st->mergeC1;
     const int n0 = st->mergeN0, n1 = st->mergeN1, t = (int) blockIdx.x;
     if (t >= n0 + n1) return;
     const SweepArgs s = vft_nj_args(E, st->nActive, st->totdiam);
     const ThHit<REAL> h = t < n0 ? T.hits[c0 * T.m + t] : T.hits[c1 * T.m + (t - n0)];
-    const int32_t jg = h.j;   // the guess
-    int32_t pj = 0, sj = 0, si = 0;
-    unsigned int old = 0;
-    REAL oj = 0, oi = 0, diaI = 0, diaJ = 0;
-    if (threadIdx.x == 0) {
-        pj = A.parent[jg];
-        old = __hip_atomic_exchange(&T.mark[jg], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sj = __hip_atomic_load(&A.nOutActive[jg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        oj = __hip_atomic_load(&A.outDist[jg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        si = A.nOutActive[newnode];
-        oi = A.outDist[newnode];
-        diaI = A.diameter[newnode];
-        diaJ = A.diameter[jg];
-    }
-    REAL d = 0, w = 0, cr = (REAL) 1e20;
-    vft_pair_block<REAL, NC>(A, newnode, jg, false, njLds, njLds + A.d.nPosPad, d, w, true);   // (ends with a barrier)
-    if (threadIdx.x == 0) {
-        int32_t j = jg;
-        int owner, again = 0;
-        if (pj < 0) {
-            owner = jg != (int32_t) newnode && old != tag;
-        } else {
-            // joined since: its active ancestor (possibly the new node itself).  The launch lasts as long as its slowest workgroup,
-            // and some entry of 2 000 is always of this kind: the same trick one level up - claim, stamps and diameter of the
-            // parent together with the question whether IT is active
-            j = pj;
-            for (;;) {
-                const int32_t pp = A.parent[j];
-                old = __hip_atomic_exchange(&T.mark[j], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sj = __hip_atomic_load(&A.nOutActive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                diaJ = A.diameter[j];
-                if (pp < 0) break;
-                j = pp;   // (a claim on an inactive node is harmless: nobody's active ancestor is that node)
-            }
-            owner = j != (int32_t) newnode && old != tag;
-            again = owner;
-        }
-        thOwner = owner;
-        thJ = j;
-        thAgain = again;
-        thStale = owner && (int64_t) sj - s.nActive > s.nDiffAllow;
-    }
+    const int32_t j = vft_active_ancestor(A.parent, h.j);
+    if (threadIdx.x == 0)
+        thOwner = j >= 0 && j != (int32_t) newnode && __hip_atomic_exchange(&T.mark[j], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag;
     __syncthreads();
     if (!thOwner) {
         if (threadIdx.x == 0) T.stJ[t] = -1;
         return;
     }
-    const int32_t j = thJ;
-    if (thStale) {   // (rare: the plain path with the lazy refresh of the partner's out-distance)
-        d = 0;
-        vft_th_pair<REAL, NC>(A, s, newnode, j, true, njLds, njLds + A.d.nPosPad, d, cr);
-    } else {
-        if (thAgain) vft_pair_block<REAL, NC>(A, newnode, j, false, njLds, njLds + A.d.nPosPad, d, w, true);
-        if (threadIdx.x == 0) {
-            if (!(newnode < A.d.nSeqs && j < A.d.nSeqs)) {
-                const REAL dd = diaI + diaJ;
-                d = d - dd;
-            }
-            if ((int64_t) sj == s.nActive) {
-                // a stamp of this very step may have been written a moment ago by another workgroup of this launch: its value is
-                // read again, now certainly after the stamp (vft_th_pair)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                oj = __hip_atomic_load(&A.outDist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            cr = vft_criterion<REAL>(d, oi, si, oj, sj, s.nActive);
-        }
-    }
+    // (asking for everything that hangs on the list entry at once, on the guess that the partner is still active, was tried: every
+    //  workgroup then pays for a distance, owners or not, and the launch - which lasts as long as its slowest workgroup - took
+    //  19.3 us instead of 15.4)
+    ThPairSpec<REAL> spec{};
+    spec.rowsById = true;   // (every internal node of the engine's run has its row: no flag lookup in front of the column loads)
+    REAL d = 0, cr = (REAL) 1e20;
+    vft_th_pair<REAL, NC>(A, s, newnode, j, true, njLds, njLds + A.d.nPosPad, d, cr, &spec);
     if (threadIdx.x == 0) {
         T.stJ[t] = j;
         T.stD[t] = d;
