@@ -24,5 +24,6 @@ tot = sum(t[:5])
 print("workgroups %d, evaluations %d (%.1f per workgroup), %.1f us per workgroup" % (t[9], t[8], t[8] / wgs, tot / 100.0 / wgs))
 for k, nm in enumerate(names):
     print("%-44s %8.2f us per workgroup  %5.1f %%   %6.2f us per evaluation" % (nm, t[k] / 100.0 / wgs, 100.0 * t[k] / max(tot, 1), t[k] / 100.0 / evals))
+print("ordered totals that fell back to the plain chain: %d of %d; rescaling events per evaluation: %.1f" % (t[7], t[8], t[6] / evals))
 print("inside the ordered total (us per evaluation): " + "  ".join("%s %.2f" % (nm, t[10 + k] / 100.0 / evals) for k, nm in enumerate(
     ["entry barrier", "log sums + scan", "intervals + clamp scan", "events + scan", "lists", "chain"])))

@@ -228,7 +228,194 @@ __device__ __forceinline__ void vft_lk_stage_cols(double *stage, double *stageLo
     }
 }
 
+// (round 3's first form, kept verbatim for the whole-column protein instances: hipcc 7.2 fails on them - "Illegal instruction
+// detected: Operand has incorrect register class" - with any variation of this function that was tried)
 // steps 2 and 3 over stage[0, nPos) / stageLog[0, nPos); COLS: capacity of the staging arrays (list: COLS * 3 / 2 + 32, events: COLS / 2)
+template <int WG, int COLS>
+__device__ __forceinline__ double vft_lk_total_staged_v1(double *stage, double *stageLog, double *list, signed char *events,
+                                                      LkOrderedShared *sh, int nPos, bool jc) {
+    constexpr int LCAP = COLS + COLS / 2;       // capacity of list
+    constexpr int ECAP = COLS / 2;              // capacity of events
+    constexpr int C = (COLS + WG - 1) / WG;     // columns per thread
+    constexpr int NW = WG / 64;
+    constexpr int BIG = 1 << 28;
+    static_assert(NW <= 16, "LkOrderedShared holds 16 wavefronts");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VFT_ML_TIMING
+    unsigned long long subTick_ = wall_clock64();
+#define VFT_ML_SUBTICK1(k)                                                   \
+    do {                                                                    \
+        if (threadIdx.x == 0) {                                             \
+            const unsigned long long now_ = wall_clock64();                 \
+            atomicAdd(&vftMlTicks[k], now_ - subTick_);                     \
+            subTick_ = now_;                                                \
+        }                                                                   \
+    } while (0)
+#else
+#define VFT_ML_SUBTICK1(k) do { } while (0)
+#endif
+    if (tid == 0) sh->irregular = 0;
+    __syncthreads();
+    VFT_ML_SUBTICK1(10);
+    bool odd = false;
+    const int q0 = tid * C < nPos ? tid * C : nPos, q1 = q0 + C < nPos ? q0 + C : nPos;   // this thread's run of columns [q0, q1)
+    // prefix sums of the logs: the run, a wave scan, the earlier wavefronts' totals
+    double lg[C], lsum = 0;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        lg[k] = q0 + k < q1 ? stageLog[q0 + k] : 0.0;
+        if (!(fabs(lg[k]) < 1.0e4)) odd = true;   // a <= 0, inf, nan
+        lsum += lg[k];
+    }
+    double incl = lsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) sh->waveSum[wave] = incl;
+    __syncthreads();
+    VFT_ML_SUBTICK1(11);
+    double excl = 0;
+    for (int w = 0; w < wave; w++) excl += sh->waveSum[w];
+    excl += incl - lsum;
+    // every column's interval, the run as one clamp (cl, ch), an inclusive scan of the clamps (earlier runs first)
+    int L[C], H[C], cl = -BIG, ch = BIG;
+    {
+        double run = 0;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            L[k] = -BIG;
+            H[k] = BIG;
+            if (q0 + k < q1) {
+                run += lg[k];
+                vft_lk_interval(excl + run, L[k], H[k], odd);
+                cl = vft_clampi(cl, L[k], H[k]);
+                ch = vft_clampi(ch, L[k], H[k]);
+            }
+        }
+    }
+    int il = cl, ih = ch;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int tl = __shfl_up(il, off, 64), th = __shfl_up(ih, off, 64);
+        if (lane >= off) {   // (tl, th) covers the columns before those of (il, ih): push its bounds through
+            const int nl = vft_clampi(tl, il, ih), nh = vft_clampi(th, il, ih);
+            il = nl;
+            ih = nh;
+        }
+    }
+    if (lane == 63) {
+        sh->waveLo[wave] = il;
+        sh->waveHi[wave] = ih;
+    }
+    int pl = __shfl_up(il, 1, 64), ph = __shfl_up(ih, 1, 64);   // the lanes in front of this one (this wavefront)
+    if (lane == 0) {
+        pl = -BIG;
+        ph = BIG;
+    }
+    __syncthreads();
+    VFT_ML_SUBTICK1(12);
+    int nIn = 0;   // the count entering this run (lk starts at 1: n = 0): through the earlier wavefronts, then the earlier lanes
+    for (int w = 0; w < wave; w++) nIn = vft_clampi(nIn, sh->waveLo[w], sh->waveHi[w]);
+    nIn = vft_clampi(nIn, pl, ph);
+    // rescaling events of the run, exclusive scan of their counts
+    int ev = 0;
+    if (!odd) {
+        int n = nIn;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const int n2 = vft_clampi(n, L[k], H[k]);
+            ev += n2 > n ? n2 - n : n - n2;
+            n = n2;
+        }
+        if (ev > ECAP) {
+            ev = 0;
+            odd = true;
+        }
+    }
+    int einc = ev;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(einc, off, 64);
+        if (lane >= off) einc += t;
+    }
+    if (lane == 63) sh->waveEv[wave] = einc;
+    if (odd) sh->irregular = 1;   // (every writer stores 1)
+    __syncthreads();
+    VFT_ML_SUBTICK1(13);
+    int eBase = 0, eTotal = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int v = sh->waveEv[w];
+        if (w < wave) eBase += v;
+        eTotal += v;
+    }
+    const bool irregular = sh->irregular != 0 || eTotal > ECAP || nPos + eTotal > LCAP;   // (uniform)
+    if (!irregular) {
+        // the multiplier list and the event list
+        int e = eBase + einc - ev, n = nIn;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            if (q0 + k >= q1) continue;
+            const int q = q0 + k, n2 = vft_clampi(n, L[k], H[k]);
+            list[q + e] = stage[q];
+            const int d = n2 - n, cnt = d > 0 ? d : -d;
+            for (int r = 0; r < cnt; r++) {
+                list[q + e + 1 + r] = d > 0 ? VFT_LK_UNDERFLOW_INV : VFT_LK_UNDERFLOW;
+                events[e + r] = d > 0 ? 1 : -1;
+            }
+            e += cnt;
+            n = n2;
+        }
+        if (tid < 32) list[nPos + eTotal + tid] = 1.0;   // (multiplying by one is exact: the chain runs in whole groups of sixteen)
+    }
+    __syncthreads();
+    VFT_ML_SUBTICK1(14);
+    if (irregular) {   // uniform: the plain chain, decisions and all
+        if (tid == 0) {
+            double lk = 1.0, loglk = 0.0;
+            vft_lk_chain(stage, nPos, jc, lk, loglk);
+            sh->prod = lk;
+            sh->loglk = loglk;
+        }
+    } else if (tid == 0) {
+        // (sixteen multipliers per trip, the next sixteen already on their way from LDS; the list ends with 32 ones)
+        const int K = nPos + eTotal;
+        double lk = 1.0;
+#ifdef VFT_TEST_PLAIN_CHAIN
+#pragma unroll 16
+        for (int k = 0; k < K; k++) lk *= list[k];
+#else
+        double cur[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) cur[u] = list[u];
+#pragma unroll 1
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            double nxt[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) nxt[u] = list[k0 + 16 + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) lk *= cur[u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) cur[u] = nxt[u];
+        }
+#endif
+        sh->prod = lk;
+    } else if (tid == 64) {
+        double loglk = 0.0;
+        for (int r = 0; r < eTotal; r++) {
+            if (events[r] > 0) loglk -= VFT_LOG_LK_UNDERFLOW;
+            else loglk += VFT_LOG_LK_UNDERFLOW;
+        }
+        sh->loglk = loglk;
+    }
+    __syncthreads();
+    VFT_ML_SUBTICK1(15);
+    return vft_lk_finish(sh->prod, sh->loglk);
+}
+
+// steps 2 and 3 over stage[0, nPos) / stageLog[0, nPos); COLS: capacity of the staging arrays (list: COLS * 3 / 2 + 64, events: COLS / 2 + 16)
 template <int WG, int COLS>
 __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *stageLog, double *list, signed char *events,
                                                       LkOrderedShared *sh, int nPos, bool jc) {
@@ -366,10 +553,16 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
             e += cnt;
             n = n2;
         }
-        if (tid < 32) list[nPos + eTotal + tid] = 1.0;   // (multiplying by one is exact: the chain runs in whole groups of sixteen)
+        if (tid < 64) list[nPos + eTotal + tid] = 1.0;   // (multiplying by one is exact: the chain runs in whole groups of sixteen)
     }
     __syncthreads();
     VFT_ML_SUBTICK(14);
+#ifdef VFT_ML_TIMING
+    if (tid == 0) {
+        atomicAdd(&vftMlTicks[7], irregular ? 1ull : 0ull);
+        atomicAdd(&vftMlTicks[6], (unsigned long long) eTotal);
+    }
+#endif
     if (irregular) {   // uniform: the plain chain, decisions and all
         if (tid == 0) {
             double lk = 1.0, loglk = 0.0;
@@ -378,33 +571,49 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
             sh->loglk = loglk;
         }
     } else if (tid == 0) {
-        // (sixteen multipliers per trip, the next sixteen already on their way from LDS; the list ends with 32 ones)
+        // Sixteen multipliers per step from two register buffers in turn: the loads of one are issued before the other is
+        // multiplied through, and the scheduling barriers keep it that way (left to itself the compiler loads sixteen values,
+        // waits for them and multiplies - an LDS latency per sixteen 5.6-cycle multiplications).  The list ends with 64 ones.
         const int K = nPos + eTotal;
         double lk = 1.0;
-#ifdef VFT_TEST_PLAIN_CHAIN
-#pragma unroll 16
-        for (int k = 0; k < K; k++) lk *= list[k];
-#else
-        double cur[16];
+        {
+            double bufA[16], bufB[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) cur[u] = list[u];
+            for (int u = 0; u < 16; u++) bufA[u] = list[u];
 #pragma unroll 1
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            double nxt[16];
+            for (int k0 = 0; k0 < K; k0 += 32) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) nxt[u] = list[k0 + 16 + u];
+                for (int u = 0; u < 16; u++) bufB[u] = list[k0 + 16 + u];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 16; u++) lk *= cur[u];
+                for (int u = 0; u < 16; u++) lk *= bufA[u];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 16; u++) cur[u] = nxt[u];
+                for (int u = 0; u < 16; u++) bufA[u] = list[k0 + 32 + u];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; u++) lk *= bufB[u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-#endif
         sh->prod = lk;
     } else if (tid == 64) {
+        // (sixteen events per LDS read: one read per event made this the longer of the two chains - 100 events x an LDS latency)
         double loglk = 0.0;
-        for (int r = 0; r < eTotal; r++) {
-            if (events[r] > 0) loglk -= VFT_LOG_LK_UNDERFLOW;
-            else loglk += VFT_LOG_LK_UNDERFLOW;
+        {
+#pragma unroll 1
+            for (int r0 = 0; r0 < eTotal; r0 += 16) {
+                signed char e16[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) e16[u] = events[r0 + u];   // (sixteen reads in flight: the array has 16 spare bytes)
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (r0 + u < eTotal) {
+                        if (e16[u] > 0) loglk -= VFT_LOG_LK_UNDERFLOW;
+                        else loglk += VFT_LOG_LK_UNDERFLOW;
+                    }
+                }
+            }
         }
         sh->loglk = loglk;
     }
@@ -1149,8 +1358,9 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_node_lengths
     __shared__ double red[WG / 64];
     __shared__ double stage[COLS];   // ordered total of matrix models (vft_lk_total_staged)
     __shared__ double stageLog[COLS];
-    __shared__ double stageList[COLS * 3 / 2 + 32];
-    __shared__ signed char stageEvents[COLS / 2];
+    constexpr bool V1 = NC == 20 && !QUAD;   // (vft_lk_total_staged_v1)
+    __shared__ double stageList[COLS * 3 / 2 + (V1 ? 32 : 64)];
+    __shared__ signed char stageEvents[COLS / 2 + (V1 ? 0 : 16)];
     __shared__ LkOrderedShared ordSh;
     __shared__ typename std::conditional<QUAD, MlQuadTables<REAL>, int>::type quadTab;
     const int64_t k = blockIdx.x;
@@ -1242,7 +1452,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_node_lengths
                 }
                 vft_lk_stage_cols<CPT, LPC>(stage, stageLog, col, qc, ql, CW, (int) nPos);
                 nEval++;
-                return -vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc);
+                return -(V1 ? vft_lk_total_staged_v1<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc) : vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc));
             }
             double tot = 0;
             if constexpr (!QUAD) {
@@ -1340,8 +1550,9 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
     __shared__ double red[WG / 64];
     __shared__ double stage[COLS];   // ordered total of matrix models (vft_lk_total_staged)
     __shared__ double stageLog[COLS];
-    __shared__ double stageList[COLS * 3 / 2 + 32];
-    __shared__ signed char stageEvents[COLS / 2];
+    constexpr bool V1 = NC == 20 && !QUAD;   // (vft_lk_total_staged_v1)
+    __shared__ double stageList[COLS * 3 / 2 + (V1 ? 32 : 64)];
+    __shared__ signed char stageEvents[COLS / 2 + (V1 ? 0 : 16)];
     __shared__ LkOrderedShared ordSh;
     __shared__ typename std::conditional<QUAD, MlQuadTables<REAL>, int>::type quadTab;
     const int64_t k = blockIdx.x;
@@ -1409,7 +1620,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
             vft_lk_stage_cols<CPT, LPC>(stage, stageLog, col, qc, ql, CW, (int) nPos);
             nEval++;
             VFT_ML_TICK(2);   // column likelihoods
-            const double total_ = vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc);
+            const double total_ = (V1 ? vft_lk_total_staged_v1<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc) : vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, jc));
             VFT_ML_TICK(3);   // ordered total
             return total_;
         }
