@@ -554,6 +554,7 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
             n = n2;
         }
         if (tid < 64) list[nPos + eTotal + tid] = 1.0;   // (multiplying by one is exact: the chain runs in whole groups of sixteen)
+        if (tid >= 64 && tid < 80) events[eTotal + tid - 64] = 0;
     }
     __syncthreads();
     VFT_ML_SUBTICK(14);
@@ -601,18 +602,16 @@ __device__ __forceinline__ double vft_lk_total_staged(double *stage, double *sta
         // (sixteen events per LDS read: one read per event made this the longer of the two chains - 100 events x an LDS latency)
         double loglk = 0.0;
         {
+            // (no branches: an event is +1 / -1, the sixteen bytes behind the last one are 0, and -e * LogLkUnderflow is exactly
+            //  -/+ LogLkUnderflow or a zero that changes nothing - as compares and branches on these uniform values the loop was
+            //  three taken branches per event, the longer of the two chains by far)
 #pragma unroll 1
             for (int r0 = 0; r0 < eTotal; r0 += 16) {
                 signed char e16[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) e16[u] = events[r0 + u];   // (sixteen reads in flight: the array has 16 spare bytes)
+                for (int u = 0; u < 16; u++) e16[u] = events[r0 + u];
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    if (r0 + u < eTotal) {
-                        if (e16[u] > 0) loglk -= VFT_LOG_LK_UNDERFLOW;
-                        else loglk += VFT_LOG_LK_UNDERFLOW;
-                    }
-                }
+                for (int u = 0; u < 16; u++) loglk += (double) (-(int) e16[u]) * VFT_LOG_LK_UNDERFLOW;
             }
         }
         sh->loglk = loglk;
