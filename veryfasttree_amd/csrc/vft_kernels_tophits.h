@@ -491,22 +491,37 @@ __global__ __launch_bounds__(VFT_WG) void k_th_refresh(Arena<REAL> A, TopHits<RE
             const int slot = todo[k];
             const int64_t j = entJ[slot];
             double top = 0.0, den = 0.0;
-            for (int64_t p = 0; p < nPos; p++) {
-                Col<REAL, NC> cb;
-                vft_load_col_ml<REAL, NC>(A, j, p, cb);
-                if (!(cb.w > 0)) continue;
-                Col<REAL, NC> ca;
-                ca.w = sWt[p];
-                if (!(ca.w > 0)) continue;
-                const int32_t cc = sCode[p];
-                ca.code = cc & 255;
-                ca.vec = (cc & 256) != 0;
+            // (four columns of the partner per trip, their loads issued together: one column at a time this loop was a memory
+            //  latency per column - 200 of them per pair)
+            constexpr int U = 4;
+            const bool jRow = vft_is_row<REAL>(A, j);
+            for (int64_t p0 = 0; p0 < nPos; p0 += U) {
+                Col<REAL, NC> cbs[U];
 #pragma unroll
-                for (int q = 0; q < NC; q++) ca.f[q] = sF[p * NC + q];
-                const REAL ww = ca.w * cb.w;
-                const double wgt = (double) ww;
-                den += wgt;
-                top += wgt * vft_piece<REAL, NC>(A, ca, cb, nullptr);
+                for (int u = 0; u < U; u++) {
+                    const int64_t p = p0 + u < nPos ? p0 + u : nPos - 1;   // (clamped: unconditional loads)
+                    if (jRow) vft_load_row<REAL, NC>(A, j, p, cbs[u]);
+                    else vft_load_col<REAL, NC>(A, j, p, cbs[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t p = p0 + u;
+                    if (p >= nPos) break;
+                    const Col<REAL, NC> &cb = cbs[u];
+                    if (!(cb.w > 0)) continue;
+                    Col<REAL, NC> ca;
+                    ca.w = sWt[p];
+                    if (!(ca.w > 0)) continue;
+                    const int32_t cc = sCode[p];
+                    ca.code = cc & 255;
+                    ca.vec = (cc & 256) != 0;
+#pragma unroll
+                    for (int q = 0; q < NC; q++) ca.f[q] = sF[p * NC + q];
+                    const REAL ww = ca.w * cb.w;
+                    const double wgt = (double) ww;
+                    den += wgt;
+                    top += wgt * vft_piece<REAL, NC>(A, ca, cb, nullptr);
+                }
             }
             REAL d = (REAL) (den > 0 ? top / den : 1.0);
             if (!(x < A.d.nSeqs && j < A.d.nSeqs)) {
