@@ -331,6 +331,13 @@ int vft_set_profile_rows(vft_ctx *ctx, int32_t on);
    vft_set_profile_rows(ctx, 1); n <= 256.  Stream-ordered. */
 int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b);
 
+/* n_chains independent chains of averages in ONE launch: chain k = ops [chain_off[k], chain_off[k + 1]) of out / a / b
+   (chain_off[0] = 0; a chain holds at most 256 ops, a call at most 4096).  Chains must not read what another chain of the
+   same call writes.  The subtree schedule of the refinement stages (MLLengths::doNNIThreaded - the reference's
+   `-threads T` traversal, NJ.tcc:6108-6160) queues one chain per subtree and step.  Stream-ordered. */
+int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
+                       const int64_t *b);
+
 /* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */
 int vft_branch_lengths_set(vft_ctx *ctx, int64_t first, int64_t count, const void *values);
@@ -343,6 +350,9 @@ int vft_posterior_profiles_blen(vft_ctx *ctx, int64_t n, const int64_t *out, con
 /* n vft_posterior_profiles_blen calls executed in order in ONE launch, later ones may read earlier outputs (n <= 256). */
 int vft_posterior_chain_blen(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b,
                              const int64_t *len_idx_a, const int64_t *len_idx_b);
+/* The same for n_chains independent chains in one launch (see vft_average_chains). */
+int vft_posterior_chains_blen(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
+                              const int64_t *b, const int64_t *len_idx_a, const int64_t *len_idx_b);
 /* The body of traverseOptimizeAllBranchLengths' loop (NJ.tcc:5025-5064) for n independent splits, one workgroup each:
    ids[3k..3k+2] = the three profiles around split k (children 0 and 1 + the up-profile, or the root's three children),
    len_idx[3k..3k+2] = the branchlength[] slots they own.  Two passes over the three branches; branch i gets
@@ -378,6 +388,12 @@ typedef struct vft_quartet_nni {
 } vft_quartet_nni;
 int vft_ml_quartet_nni(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, double ftol, double atol,
                        double close_limit, int32_t ml_accuracy, vft_quartet_nni *results);
+/* vft_ml_quartet_nni with flags.  VFT_QUARTET_NO_STAR_TEST: AB|CD is optimised without the star-topology test - what the
+   reference does when MLQuartetNNI runs outside a parallel region in a run with threads > 1 (the `omp sections` variant,
+   NJ.tcc:4925-4931, passes no bStarTest): the serial part of a threaded NNI round. */
+#define VFT_QUARTET_NO_STAR_TEST 1
+int vft_ml_quartet_nni_flags(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, double ftol, double atol,
+                             double close_limit, int32_t ml_accuracy, int32_t flags, vft_quartet_nni *results);
 /* likelihood evaluations (pairLogLk calls of the reference) made by vft_ml_optimize_splits since the last query */
 int vft_ml_eval_count(vft_ctx *ctx, int64_t *evals);
 

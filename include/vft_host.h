@@ -70,6 +70,16 @@ typedef struct {
                                    the model's eigen-basis (transMatToDistanceMat + recomputeProfiles,
                                    VeryFastTreeImpl.tcc:253-256, 517-542) and installs the transition matrix */
     const vft_comm *comm;       /* NULL = one GPU; otherwise see vft_comm above (top-hits NJ phase only) */
+    int32_t threads;            /* the reference's `-threads T` at its default -threads-level 3: 0 / 1 = the one-thread order
+                                   (everything above); T > 1 = the refinement stages follow the schedule of a T-thread run -
+                                   NNI rounds and ML length rounds over the subtrees of treePartitioning (NJ.tcc:5540-5750,
+                                   :6108-6160, :5083-5112), whose walks this backend advances in lockstep as batches of
+                                   quartets / splits (host/MLLengths.h "the subtree schedule"), and no star-topology test in
+                                   the serial part of an ML NNI round (NJ.tcc:4902-4948).  The tree is byte-identical to
+                                   `VeryFastTree -threads T` whenever the NJ phase of that run joins in the one-thread
+                                   order (its tree does not depend on the thread count).  The caller keeps
+                                   use_tophits_2nd = 0 with T > 1, as the reference does (VeryFastTree.cpp:87-91). */
+    int32_t reserved;
 } vft_nj_options;
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

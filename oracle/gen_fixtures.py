@@ -345,6 +345,67 @@ def gen_aa(tmp):
                                                                     " ".join("%.3f" % x for x in ll[-2:]), os.path.getsize(dst) / 1024.0))
 
 
+THREADS_CASES = [
+    # name, alphabet, flags, n_seq, n_pos, mu, gap, seed, threads.  The reference with `-threads T` (default -threads-level 3,
+    # deterministic mode): NNI rounds and ML length rounds over the subtrees of treePartitioning, no star test in the serial
+    # part of an ML NNI round - a different (still deterministic) schedule than one thread, a function of T.
+    ("thr_menni_nt_400_t4", 4, ["-nt", "-noml"], 400, 150, 0.06, 0.02, 81, 4),             # ME NNIs + 2 SPR rounds
+    ("thr_mllen_nt_300_t4", 4, ["-nt", "-nome", "-mllen"], 300, 120, 0.06, 0.02, 82, 4),   # ML lengths + CAT on the NJ topology
+    ("thr_full_nt_400_t4", 4, ["-nt"], 400, 150, 0.06, 0.02, 81, 4),
+    ("thr_full_nt_600_t8", 4, ["-nt"], 600, 120, 0.05, 0.02, 83, 8),
+    ("thr_full_nt_300_double_t3", 4, ["-nt", "-double-precision"], 300, 150, 0.08, 0.03, 84, 3),
+    # (`-gtr` with threads > 1 cannot be pinned: two runs of the reference fit different GTR rates - 0.9348 vs 0.9397 for ac on
+    #  500 x 200 at -threads 4 - a race in its threaded setMLGtr path; Jukes-Cantor and the protein models are deterministic)
+    ("thr_full_nt_500_t16", 4, ["-nt"], 500, 200, 0.05, 0.02, 85, 16),
+    ("thr_full_nt_1500_t32", 4, ["-nt"], 1500, 100, 0.04, 0.01, 86, 32),
+    # Matrix models (GTR, JTT / WAG / LG) with threads > 1: the reference is NOT reproducible - two runs of the same command give
+    # different trees (observed at every -threads-level, 0 included; TreeLogLk differs by ~2e-5 relative after the first ML NNI
+    # round: a race in its threaded likelihood code).  These fixtures keep the TreeLogLk lines of three runs; the test asks for
+    # the north star's 1e-4 against them, and for this backend's own two runs to be identical.
+    ("thrx_full_aa_300_lg_double_t8", 20, ["-lg", "-double-precision"], 300, 100, 0.10, 0.03, 87, 8),   # BASELINE C5's flags
+    ("thrx_full_nt_500_gtr_t16", 4, ["-nt", "-gtr"], 500, 200, 0.05, 0.02, 85, 16),                     # BASELINE C2's flags
+]
+
+
+def gen_threads(tmp, only=None):
+    """Black box, `-threads T`: every TreeLogLk line, the final tree without and with supports."""
+    env = dict(os.environ, OMP_WAIT_POLICY="passive")
+    for name, nc, flags, n, L, mu, gap, seed, threads in THREADS_CASES:
+        if only and name not in only:
+            continue
+        codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT if nc == 4 else synth.ALPHABET_AA)
+        log = os.path.join(tmp, name + ".log")
+        base = [REFBIN] + flags + ["-threads", str(threads), "-seed", "1"]
+        res = subprocess.run(base + ["-nosupport", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        text = open(log).read()
+        ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", text, re.M)]
+        if name.startswith("thrx_"):
+            runs = [ll]
+            trees = {res.stdout}
+            for _ in range(2):
+                r = subprocess.run(base + ["-nosupport", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                runs.append([float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", open(log).read(), re.M)])
+                trees.add(r.stdout)
+            n_lines = min(len(r) for r in runs)
+            np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), codes=codes, threads=np.int64(threads),
+                                loglk_runs=np.array([r[:n_lines] for r in runs]), n_lines=np.array([len(r) for r in runs]),
+                                distinct_trees=np.int64(len(trees)), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+            print("%-30s T=%2d  3 runs of the reference: %d distinct trees, final TreeLogLk %s" % (name, threads, len(trees), [r[-1] for r in runs]))
+            continue
+        res2 = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        again = subprocess.run(base + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert again.stdout == res2.stdout, name + ": two runs of the reference differ"
+        one = subprocess.run([REFBIN] + flags + ["-threads", "1", "-seed", "1", fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), codes=codes, threads=np.int64(threads), loglk=np.array(ll),
+                            newick=np.frombuffer(res.stdout, dtype=np.uint8), newick_support=np.frombuffer(res2.stdout, dtype=np.uint8),
+                            differs_from_one_thread=np.int64(one.stdout != res2.stdout),
+                            flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        print("%-30s T=%2d  %2d TreeLogLk lines, final %.4f, %s the one-thread tree" % (name, threads, len(ll), ll[-1] if ll else 0.0,
+                                                                                      "differs from" if one.stdout != res2.stdout else "EQUALS"))
+
+
 def gen_c3(tmp):
     """BASELINE config C3 at full size (100 000 x 500 nt, `-nt -fastest` at one thread, i.e. with the second-level top
     hits): only the CRC-32 and length of the reference's `-noml -nome -nosupport` tree are kept (the tree is 2.5 MB).
@@ -429,7 +490,7 @@ def gen_c4_prefix(tmp):
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa", "threads"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -451,6 +512,10 @@ def main():
             gen_mlnni(tmp, [w[6:] for w in which if w.startswith("mlnni:")])
         if "aa" in which:
             gen_aa(tmp)
+        if "threads" in which:
+            gen_threads(tmp)
+        if any(w.startswith("threads:") for w in which):
+            gen_threads(tmp, [w[8:] for w in which if w.startswith("threads:")])
         if "c3" in which:   # not part of the default set: ~11 minutes
             gen_c3(tmp)
         if "c4" in which:   # not part of the default set: hours

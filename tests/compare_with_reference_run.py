@@ -70,7 +70,10 @@ def main():
     say = lambda s: (lines.append(s), print(s, flush=True))
     say("alignment %d x %d %s, mu %g gap %g seed %d; flags %s; %s" % (n, L, "aa" if aa else "nt", mu, gap, seed, " ".join(flags) or "(default)",
                                                                       "float64" if dt == np.float64 else "float32"))
-    kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True, fastest="-fastest" in flags)
+    # --threads T: both sides run the T-thread schedule (the reference with -threads T, this backend with threads = T: the
+    # lanes of treePartitioning in lockstep); T = 1 is the one-thread order
+    kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True, fastest="-fastest" in flags,
+              threads=threads, second_level="-fastest" in flags and threads == 1)
     if aa:
         kw["aa_model"] = "lg" if "-lg" in flags else "wag" if "-wag" in flags else "jtt"
     elif "-gtr" in flags:
@@ -78,7 +81,7 @@ def main():
     t0 = time.perf_counter()
     tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m), codes, names, **kw)
     t_gpu = time.perf_counter() - t0
-    say("this backend, 1 x MI355X: %.1f s; TreeLogLk %s" % (t_gpu, " ".join("%.4f" % x for x in loglk)))
+    say("this backend, 1 x MI355X, schedule of %d thread(s): %.1f s; TreeLogLk %s" % (threads, t_gpu, " ".join("%.4f" % x for x in loglk)))
     if opt.get("noref"):
         return
     with tempfile.TemporaryDirectory() as tmp:
@@ -86,7 +89,7 @@ def main():
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA if aa else synth.ALPHABET_NT)
         cmd = [REFBIN] + ([] if aa else ["-nt"]) + flags + ["-threads", str(threads), "-seed", "1", "-log", log, fa]
         t0 = time.perf_counter()
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
         t_ref = time.perf_counter() - t0
         text = open(log).read()
     ref = res.stdout.decode().strip()

@@ -1,0 +1,96 @@
+"""The subtree schedule (veryfasttree_amd/host/MLLengths.h: doNNIThreaded, optimizeRoundThreaded) against whole runs of the
+reference with `-threads T` (oracle/gen_fixtures.py threads): the reference partitions the tree (treePartitioning,
+NJ.tcc:5540-5750) and lets T OpenMP threads walk the subtrees; this backend advances all the walks in lockstep as batches of
+quartets / splits on one GPU.  Same schedule, same arithmetic: the trees must come out byte for byte."""
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+AA = {"-lg": "lg", "-wag": "wag"}
+
+
+def run_case(name, n_bootstrap=0):
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load(name)
+    flags = bytes(d["flags"]).decode().split()
+    codes_all = d["codes"]
+    nt = "-nt" in flags
+    dt = np.float64 if "-double-precision" in flags else np.float32
+    names = ["s%d" % k for k in range(len(codes_all))]
+    make = lambda n, L: HipProfileOps(n, L, 4 if nt else 20, dt, max_nodes=3 * n)
+    kw = dict(dtype=dt, me_lengths=True, threads=int(d["threads"]), n_bootstrap=n_bootstrap, return_loglk=True)
+    if not nt:
+        kw["aa_model"] = next((AA[f] for f in flags if f in AA), "jtt")
+    if "-noml" in flags:
+        kw.update(me_nni=True, spr=2)
+    elif "-mllen" in flags:
+        kw.update(mllen=20)
+    else:
+        kw.update(me_nni="-nome" not in flags, spr=0 if "-nome" in flags else 2, ml_nni=20, gtr="-gtr" in flags)
+    if "-noml" in flags:
+        kw.pop("return_loglk")
+        return d, nj_newick(make, codes_all, names, **kw), []
+    tree, loglk = nj_newick(make, codes_all, names, **kw)
+    return d, tree, loglk
+
+
+@pytest.mark.parametrize("name", ["thr_menni_nt_400_t4", "thr_mllen_nt_300_t4", "thr_full_nt_400_t4", "thr_full_nt_600_t8",
+                                  "thr_full_nt_300_double_t3", "thr_full_nt_500_t16", "thr_full_nt_1500_t32"])
+def test_trees_match_the_reference_at_T_threads(name):
+    """`VeryFastTree [-nt] [flags] -threads T -nosupport`: TreeLogLk after every stage within the north star's 1e-4 relative
+    (observed: to the printed digit), topology identical, the printed tree byte-identical."""
+    d, tree, loglk = run_case(name)
+    want = d["loglk"]
+    ref = bytes(d["newick"]).decode().strip()
+    print(name, "T =", int(d["threads"]), "TreeLogLk", list(loglk), "reference", list(want),
+          "(the reference's tree at T threads", "differs from" if int(d["differs_from_one_thread"]) else "equals", "its one-thread tree)")
+    if len(want):
+        assert len(loglk) == len(want)
+        assert np.allclose(loglk, want, rtol=1e-4, atol=0)
+    strip = lambda t: re.sub(r":[0-9.eE+-]+", ":", t)
+    assert strip(tree) == strip(ref), "topology differs"
+    assert tree == ref
+
+
+@pytest.mark.parametrize("name", ["thr_full_nt_400_t4", "thr_full_nt_600_t8"])
+def test_supports_match_the_reference_at_T_threads(name):
+    """the same runs with the default 1000 resamples: SH-like supports included, byte for byte"""
+    d, tree, _ = run_case(name, n_bootstrap=1000)
+    assert tree == bytes(d["newick_support"]).decode().strip()
+
+
+@pytest.mark.parametrize("name", ["thrx_full_aa_300_lg_double_t8", "thrx_full_nt_500_gtr_t16"])
+def test_matrix_models_stay_within_the_references_own_spread(name):
+    """Matrix models with threads > 1: the reference itself is not reproducible (oracle/gen_fixtures.py THREADS_CASES - three runs,
+    three trees), so there is no tree to pin.  The schedule is pinned by the Jukes-Cantor cases above, the matrix arithmetic by the
+    one-thread fixtures (test_gpu_nni.py, test_gpu_aa.py); here: the first two and the last TreeLogLk within the north star's 1e-4
+    relative of the span of the reference's three runs, and two runs of this backend identical."""
+    d, tree, loglk = run_case(name)
+    runs = d["loglk_runs"]
+    print(name, "T =", int(d["threads"]), "TreeLogLk", list(loglk), "reference runs (final)", list(runs[:, -1]), "distinct reference trees", int(d["distinct_trees"]))
+    n = min(len(loglk), runs.shape[1])
+    assert n >= 2
+    # (the three GTR runs of the reference end 1.8e-4 apart: the envelope of its runs, widened by the bar)
+    for k in (0, 1, -1):
+        lo, hi = runs[:, k].min(), runs[:, k].max()
+        assert lo - 1e-4 * abs(lo) <= loglk[k] <= hi + 1e-4 * abs(hi), (k, loglk[k], lo, hi)
+    _, again, _ = run_case(name)
+    assert again == tree
+
+
+def test_one_thread_is_untouched_by_the_option():
+    """threads = 1 is the one-thread order: the fixture of the sequential walk, through the same entry point"""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load("full_nt_200")
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    make = lambda n, L: HipProfileOps(n, L, 4, np.float32, max_nodes=3 * n)
+    tree = nj_newick(make, codes_all, names, me_lengths=True, me_nni=True, spr=2, ml_nni=20, threads=1)
+    assert tree == bytes(d["newick"]).decode().strip()

@@ -17,12 +17,13 @@ timeout 900 python3 tests/compare_with_reference_run.py 10000 1000 -gtr --out $o
 tail -8 $out/compare_c2.txt
 timeout 900 python3 tests/compare_with_reference_run.py 3000 300 --aa -lg -double-precision --out $out/compare_aa_3000.txt > /dev/null 2>&1
 tail -8 $out/compare_aa_3000.txt
-if [ -f build/timing/libvft_hip_mltiming.so ]; then
-  cp veryfasttree_amd/lib/libvft_hip.so /tmp/libvft_hip_orig.so
-  cp build/timing/libvft_hip_mltiming.so veryfasttree_amd/lib/libvft_hip.so
-  timeout 600 python3 tools/ml_ticks.py 1500 300 > $out/ml_ticks_aa_1500.txt 2>&1
-  cp /tmp/libvft_hip_orig.so veryfasttree_amd/lib/libvft_hip.so
-fi
+# the tick counters need a variant build (VFT_EXTRA_HIPCC_FLAGS=-DVFT_ML_TIMING python -m veryfasttree_amd.build): loaded by path,
+# the installed library is never touched
+for v in build/variants/*/; do
+  if grep -q VFT_ML_TIMING $v/FLAGS 2>/dev/null; then
+    VFT_LIB_DIR=$GRAFT_REPO_ROOT/$v timeout 600 python3 tools/ml_ticks.py 1500 300 > $out/ml_ticks_aa_1500.txt 2>&1
+  fi
+done
 cd /tmp && export TMPDIR=/tmp
 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e1m -o e1m -- python3 $GRAFT_REPO_ROOT/tools/nj_gpu_only.py 1000000 200 mu=0.02 gap=0.01 seed=4 > $out/nj_1M_under_rocprof.log 2>&1
 cp /tmp/prof_e1m/*kernel_stats.csv $out/engine_1M_kernel_stats.csv 2>/dev/null

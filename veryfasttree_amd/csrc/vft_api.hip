@@ -1163,37 +1163,63 @@ extern "C" int vft_average_profiles(vft_ctx *c, int64_t n, const int64_t *out, c
 }
 
 // n unweighted averages in order, later ones may read earlier results (k_average_chain); profile-rows mode only.
-extern "C" int vft_average_chain(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b) {
-    if (!c || n < 0 || !out || !a || !b) return VFT_ERR_INVALID;
+// nChains independent chains go down as one launch (blockIdx.y): chainOff[nChains + 1] splits the n ops (NULL: one chain).
+static int average_chains(vft_ctx *c, int32_t nChains, const int32_t *chainOff, int32_t n, const int64_t *out, const int64_t *a,
+                          const int64_t *b, const char *who) {
     if (n == 0) return VFT_OK;
-    if (!c->rowMode) return fail(c, VFT_ERR_STATE, "vft_average_chain needs vft_set_profile_rows(ctx, 1)");
-    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_average_chain: at most 256 averages per call");
+    if (!c->rowMode) return fail(c, VFT_ERR_STATE, "%s needs vft_set_profile_rows(ctx, 1)", who);
     for (int32_t k = 0; k < n; k++) {
         if (int r = internal_ok(c, out[k])) return r;
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "bad child id");
     }
     if (int r = ensure_ml_rows(c)) return r;
-    const size_t idB = (size_t) n * 8;
+    const size_t idB = (size_t) n * 8, dB = ((size_t) n + 7) & ~(size_t) 7, offB = chainOff ? (size_t) (nChains + 1) * 4 : 0;
     char *h, *s;
-    if (int r = io_alloc(c, 3 * idB + (size_t) n, &h, &s)) return r;
+    if (int r = io_alloc(c, 3 * idB + dB + offB, &h, &s)) return r;
     memcpy(h, out, idB);
     memcpy(h + idB, a, idB);
     memcpy(h + 2 * idB, b, idB);
     uint8_t *direct = (uint8_t *) (h + 3 * idB);
-    for (int32_t k = 0; k < n; k++) {
-        uint8_t d = 0;
-        for (int32_t j = 0; j < k; j++) {
-            if (out[j] == a[k]) d |= 1;
-            if (out[j] == b[k]) d |= 2;
+    for (int32_t ch = 0; ch < nChains; ch++) {
+        const int32_t k0 = chainOff ? chainOff[ch] : 0, k1 = chainOff ? chainOff[ch + 1] : n;
+        for (int32_t k = k0; k < k1; k++) {
+            uint8_t d = 0;
+            for (int32_t j = k0; j < k; j++) {
+                if (out[j] == a[k]) d |= 1;
+                if (out[j] == b[k]) d |= 2;
+            }
+            direct[k] = d;
         }
-        direct[k] = d;
     }
-    VFT_DISPATCH(c, launch((k_average_chain<REAL, NC>), dim3(cdiv(c->d.nPos, 128)), dim3(128), 0, c->stream, arena<REAL>(c),
+    if (chainOff) memcpy(h + 3 * idB + dB, chainOff, offB);
+    VFT_DISPATCH(c, launch((k_average_chain<REAL, NC>), dim3(cdiv(c->d.nPos, 128), (unsigned) nChains), dim3(128), 0, c->stream, arena<REAL>(c),
                            (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
-                           (const uint8_t *) (s + 3 * idB), n, c->fpostTol));
+                           (const uint8_t *) (s + 3 * idB), n, c->fpostTol, chainOff ? (const int32_t *) (s + 3 * idB + dB) : nullptr));
     if (!c->allRows) launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
     LAUNCHCHK(c);
     return VFT_OK;
+}
+
+static int chains_ok(vft_ctx *c, int32_t nChains, const int32_t *chainOff, const char *who) {
+    if (nChains < 1 || nChains > 65535 || chainOff[0] != 0) return fail(c, VFT_ERR_INVALID, "%s: bad chain table", who);
+    for (int32_t ch = 0; ch < nChains; ch++)
+        if (chainOff[ch + 1] < chainOff[ch] || chainOff[ch + 1] - chainOff[ch] > 256)
+            return fail(c, VFT_ERR_INVALID, "%s: a chain holds 0..256 ops", who);
+    if (chainOff[nChains] > 4096) return fail(c, VFT_ERR_INVALID, "%s: at most 4096 ops per call", who);
+    return VFT_OK;
+}
+
+extern "C" int vft_average_chain(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b) {
+    if (!c || n < 0 || !out || !a || !b) return VFT_ERR_INVALID;
+    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_average_chain: at most 256 averages per call");
+    return average_chains(c, 1, nullptr, n, out, a, b, "vft_average_chain");
+}
+
+extern "C" int vft_average_chains(vft_ctx *c, int32_t nChains, const int32_t *chainOff, const int64_t *out, const int64_t *a,
+                                  const int64_t *b) {
+    if (!c || !chainOff || !out || !a || !b) return VFT_ERR_INVALID;
+    if (int r = chains_ok(c, nChains, chainOff, "vft_average_chains")) return r;
+    return average_chains(c, nChains, chainOff, chainOff[nChains], out, a, b, "vft_average_chains");
 }
 
 extern "C" int vft_join_fused(vft_ctx *c, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t staleStamp,
@@ -2978,45 +3004,62 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
     return VFT_OK;
 }
 
-// n posteriorProfile calls in order in one launch (k_posterior_chain), lengths from the device's branchlength[]
-extern "C" int vft_posterior_chain_blen(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b,
-                                        const int64_t *lenIdxA, const int64_t *lenIdxB) {
-    if (!c || n < 0 || !out || !a || !b || !lenIdxA || !lenIdxB) return VFT_ERR_INVALID;
+// n posteriorProfile calls in order in one launch (k_posterior_chain), lengths from the device's branchlength[];
+// nChains independent chains as one launch (blockIdx.y), split by chainOff[nChains + 1] (NULL: one chain)
+static int posterior_chains(vft_ctx *c, int32_t nChains, const int32_t *chainOff, int32_t n, const int64_t *out, const int64_t *a,
+                            const int64_t *b, const int64_t *lenIdxA, const int64_t *lenIdxB, const char *who) {
     if (n == 0) return VFT_OK;
-    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_posterior_chain_blen: at most 256 posteriors per call");
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid posteriors need vft_set_transition_matrix");
     for (int32_t k = 0; k < n; k++) {
         if (int r = internal_ok(c, out[k])) return r;
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes || lenIdxA[k] < 0 || lenIdxA[k] >= c->d.maxNodes ||
             lenIdxB[k] < 0 || lenIdxB[k] >= c->d.maxNodes)
-            return fail(c, VFT_ERR_INVALID, "vft_posterior_chain_blen: index out of range");
+            return fail(c, VFT_ERR_INVALID, "%s: index out of range", who);
     }
     if (int r = ensure_blen(c)) return r;
     if (int r = ensure_ml_rows(c)) return r;
-    const size_t idB = (size_t) n * 8;
+    const size_t idB = (size_t) n * 8, dB = ((size_t) n + 7) & ~(size_t) 7, offB = chainOff ? (size_t) (nChains + 1) * 4 : 0;
     char *h, *s;
-    if (int r = io_alloc(c, 5 * idB + (size_t) n, &h, &s)) return r;
+    if (int r = io_alloc(c, 5 * idB + dB + offB, &h, &s)) return r;
     memcpy(h, out, idB);
     memcpy(h + idB, a, idB);
     memcpy(h + 2 * idB, b, idB);
     memcpy(h + 3 * idB, lenIdxA, idB);
     memcpy(h + 4 * idB, lenIdxB, idB);
     uint8_t *direct = (uint8_t *) (h + 5 * idB);
-    for (int32_t k = 0; k < n; k++) {
-        uint8_t d = 0;
-        for (int32_t j = 0; j < k; j++) {
-            if (out[j] == a[k]) d |= 1;
-            if (out[j] == b[k]) d |= 2;
+    for (int32_t ch = 0; ch < nChains; ch++) {
+        const int32_t k0 = chainOff ? chainOff[ch] : 0, k1 = chainOff ? chainOff[ch + 1] : n;
+        for (int32_t k = k0; k < k1; k++) {
+            uint8_t d = 0;
+            for (int32_t j = k0; j < k; j++) {
+                if (out[j] == a[k]) d |= 1;
+                if (out[j] == b[k]) d |= 2;
+            }
+            direct[k] = d;
         }
-        direct[k] = d;
     }
-    VFT_DISPATCH(c, launch((k_posterior_chain<REAL, NC>), dim3(cdiv(c->d.nPos, VFT_ML_WG)), dim3(VFT_ML_WG), 0, c->stream,
+    if (chainOff) memcpy(h + 5 * idB + dB, chainOff, offB);
+    VFT_DISPATCH(c, launch((k_posterior_chain<REAL, NC>), dim3(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) nChains), dim3(VFT_ML_WG), 0, c->stream,
                            arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB), (const int64_t *) (s + 2 * idB),
                            (const int64_t *) (s + 3 * idB), (const int64_t *) (s + 4 * idB), (const uint8_t *) (s + 5 * idB), n,
-                           (const REAL *) c->blen, c->minLen, c->minRel));
+                           (const REAL *) c->blen, c->minLen, c->minRel, chainOff ? (const int32_t *) (s + 5 * idB + dB) : nullptr));
     if (!c->allRows) launch(k_mark_rows, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->mlIs, (const int64_t *) s, n, c->d.nSeqs);
     LAUNCHCHK(c);
     return VFT_OK;
+}
+
+extern "C" int vft_posterior_chain_blen(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b,
+                                        const int64_t *lenIdxA, const int64_t *lenIdxB) {
+    if (!c || n < 0 || !out || !a || !b || !lenIdxA || !lenIdxB) return VFT_ERR_INVALID;
+    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_posterior_chain_blen: at most 256 posteriors per call");
+    return posterior_chains(c, 1, nullptr, n, out, a, b, lenIdxA, lenIdxB, "vft_posterior_chain_blen");
+}
+
+extern "C" int vft_posterior_chains_blen(vft_ctx *c, int32_t nChains, const int32_t *chainOff, const int64_t *out, const int64_t *a,
+                                         const int64_t *b, const int64_t *lenIdxA, const int64_t *lenIdxB) {
+    if (!c || !chainOff || !out || !a || !b || !lenIdxA || !lenIdxB) return VFT_ERR_INVALID;
+    if (int r = chains_ok(c, nChains, chainOff, "vft_posterior_chains_blen")) return r;
+    return posterior_chains(c, nChains, chainOff, chainOff[nChains], out, a, b, lenIdxA, lenIdxB, "vft_posterior_chains_blen");
 }
 
 static inline int mlopt_wg(const vft_ctx *c) { return c->d.nCodes == 20 ? MlOptWG<20>::value : MlOptWG<4>::value; }
@@ -3134,8 +3177,8 @@ static int quartet_args_ok(vft_ctx *c, int64_t n, const int64_t *ids, const int6
 
 // MLQuartetNNI (NJ.tcc:4885-5004) for n independent quartets (DoNNI evaluates one at a time: n = 1): results come back
 // through mapped host memory; the chosen pairing's branch lengths are written to the device's branchlength[].
-extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, double ftol, double atol,
-                                  double closeLimit, int32_t mlAccuracy, vft_quartet_nni *results) {
+static int ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, double ftol, double atol,
+                          double closeLimit, int32_t mlAccuracy, int32_t flags, vft_quartet_nni *results) {
     if (!c || n < 1 || !ids || !lenIdx || !results) return VFT_ERR_INVALID;
     if (!c->hasTm && c->d.nCodes != 4) return fail(c, VFT_ERR_STATE, "amino-acid likelihoods need vft_set_transition_matrix");
     if (int r = quartet_args_ok(c, n, ids, lenIdx, "vft_ml_quartet_nni")) return r;
@@ -3160,12 +3203,16 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
     const int64_t *dIds = (const int64_t *) s, *dLi = (const int64_t *) (s + 4 * idB);
     // init -> {round (a workgroup per pairing) -> decide} x rounds -> verdict, all queued; one wait at the end
     const int nRounds = mlAccuracy < 2 ? 2 : mlAccuracy;
+    // In mode 2 the quartet kernel uses its close_limit for the star-topology test alone ("is the internal branch worth more
+    // than close_limit?", NJ.tcc:1691-1700; the alternatives are weighed by k_ml_nni_decide): a limit no likelihood
+    // difference reaches switches the test off without another kernel instance.
+    const double starLimit = (flags & VFT_QUARTET_NO_STAR_TEST) ? 1.0e300 : closeLimit;
     const dim3 g1(cdiv(n, 64)), b1(64);
     if (c->cfg.precision == 4) launch((k_ml_nni_init<float>), g1, b1, 0, c->stream, dLi, (const float *) c->blen, dState, n);
     else launch((k_ml_nni_init<double>), g1, b1, 0, c->stream, dLi, (const double *) c->blen, dState, n);
     for (int round = 0; round < nRounds; round++) {
         int r = VFT_OK;
-        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, quad, dIds, dLi, ftol, atol, closeLimit, mlAccuracy, 2, nullptr, nullptr,
+        VFT_DISPATCH(c, (r = ml_quartet_launch<REAL, NC>(c, n, cpt, quad, dIds, dLi, ftol, atol, starLimit, mlAccuracy, 2, nullptr, nullptr,
                                                          nullptr, nullptr, dState)));
         if (r) return r;
         launch(k_ml_nni_decide, g1, b1, 0, c->stream, dState, n, c->minLen, closeLimit, (int) mlAccuracy, round == nRounds - 1 ? 1 : 0);
@@ -3178,6 +3225,16 @@ extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, con
     if (int w = wait_stream(c)) return w;
     memcpy(results, h + off, resB);
     return VFT_OK;
+}
+
+extern "C" int vft_ml_quartet_nni(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, double ftol, double atol,
+                                  double closeLimit, int32_t mlAccuracy, vft_quartet_nni *results) {
+    return ml_quartet_nni(c, n, ids, lenIdx, ftol, atol, closeLimit, mlAccuracy, 0, results);
+}
+
+extern "C" int vft_ml_quartet_nni_flags(vft_ctx *c, int64_t n, const int64_t *ids, const int64_t *lenIdx, double ftol, double atol,
+                                        double closeLimit, int32_t mlAccuracy, int32_t flags, vft_quartet_nni *results) {
+    return ml_quartet_nni(c, n, ids, lenIdx, ftol, atol, closeLimit, mlAccuracy, flags, results);
 }
 
 // testSplitsML (NJ.tcc:6800-6999) for n independent splits: ids[4k..] = A, B (children), C, D (sibling side / up-profile)

@@ -893,14 +893,16 @@ template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_ML_WG) void k_posterior_chain(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
                                                                const int64_t *bN, const int64_t *liA, const int64_t *liB,
                                                                const uint8_t *direct, int32_t n, const REAL *blen,
-                                                               double minLen, double minRel) {
+                                                               double minLen, double minRel, const int32_t *chainOff) {
     __shared__ REAL ee1[VFT_MAXRATES * NC], ee2[VFT_MAXRATES * NC];
     __shared__ double pS1[VFT_MAXRATES], pD1[VFT_MAXRATES], pS2[VFT_MAXRATES], pD2[VFT_MAXRATES];
     const bool jc = A.tmStat == nullptr;
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < A.d.nPos;
     const int r = live ? A.ratecat[p] : 0;
-    for (int32_t k = 0; k < n; k++) {
+    // several independent chains in one launch (blockIdx.y; the lanes of a subtree schedule): ops [chainOff[y], chainOff[y + 1])
+    const int32_t k0 = chainOff ? chainOff[blockIdx.y] : 0, k1 = chainOff ? chainOff[blockIdx.y + 1] : n;
+    for (int32_t k = k0; k < k1; k++) {
         double len1 = (double) blen[liA[k]], len2 = (double) blen[liB[k]];
         if (len1 < minLen) len1 = minLen;
         if (len2 < minLen) len2 = minLen;

@@ -313,9 +313,19 @@ __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN,
 // visible to other workgroups yet, so it is read as a row unconditionally).
 template <typename REAL, int NC>
 __global__ void k_average_chain(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN, const uint8_t *direct,
-                                int32_t n, double tol) {
+                                int32_t n, double tol, const int32_t *chainOff) {
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.d.nPos) return;
+    // several independent chains in one launch (blockIdx.y; the lanes of a subtree schedule): ops [chainOff[y], chainOff[y + 1])
+    if (chainOff) {
+        const int32_t k0 = chainOff[blockIdx.y];
+        n = chainOff[blockIdx.y + 1] - k0;
+        if (n <= 0) return;
+        outN += k0;
+        aN += k0;
+        bN += k0;
+        direct += k0;
+    }
     // Every op was three dependent memory rounds (its ids, its two columns, and - for an input that is the previous op's output -
     // a store that has to land before it can be read back): 5 us per op, 124 000 launches in a 3 000-taxon protein run.  The
     // next op's ids are fetched while the current one computes, and the previous op's column is handed over in registers.

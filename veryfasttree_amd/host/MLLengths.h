@@ -103,9 +103,15 @@ namespace veryfasttree {
 
         /* one call of optimizeAllBranchLengths */
         void optimizeRound(double ftol, double atol) {
-            std::vector<char> upHave((size_t) nNodes, 0);
+            std::vector<char> upHave((size_t) nNodes, 0), done((size_t) nNodes, 0);
+            optimizeRoundFrom(ftol, atol, upHave, done);
+        }
+
+        /* the walk itself; done[v]: handled by a lane of optimizeRoundThreaded, upHave as the lanes left it */
+        void optimizeRoundFrom(double ftol, double atol, std::vector<char> &upHave, const std::vector<char> &done) {
             std::vector<int64_t> path;
             for (int64_t v: order) {
+                if (done[(size_t) v]) continue;
                 int64_t ids[3], li[3], rec;
                 if (v == root) {
                     for (int k = 0; k < 3; k++) ids[k] = li[k] = child[3 * v + k];
@@ -418,6 +424,24 @@ namespace veryfasttree {
            vft_ml_quartet_nni call; useML = true) - rearranges the tree on the spot and keeps the profiles around the node
            current.  The tree changes under the walk, so the device work of a node is queued when the walk gets there
            and the host waits for each verdict. */
+        /* ---- lanes (see "the subtree schedule" above) */
+        struct Lane {
+            int64_t R = -1;                  /* root of the subtree; -1: the serial walk from the tree's root */
+            int j = 0, k = 0;                /* NNIs: next branch = child k of child j of R (read when the walk gets there) */
+            int64_t node = -1, branchRoot = -1;
+            bool inBranch = false, finished = false, hasRequest = false;
+            int64_t qnode = -1, q[4] = {-1, -1, -1, -1}, idD = -1;   /* the quartet waiting for its verdict */
+            std::vector<int64_t> roots;      /* branch roots walked so far */
+            std::vector<int64_t> nodes;      /* lengths: the internal nodes of the lane in post-order */
+            size_t pos = 0;
+            std::vector<int64_t> out, a, b, la, lb;   /* profile ops queued since the last step, in order */
+        };
+        struct SharedOp {
+            int64_t depth, out, a, b, la, lb;
+        };
+        Lane *cur = nullptr;
+        std::vector<SharedOp> sharedOps;
+
         struct NNIStats {
             int64_t age, subtreeAge;
             double delta, support;
@@ -531,6 +555,181 @@ namespace veryfasttree {
             return nNNIThisRound;
         }
 
+        /* traverseNNI (NJ.tcc:5797-5990) for a set of independent walks in lockstep: every lane advances to its next
+           quartet, the queued profile work of all lanes goes down as one launch, all quartets are judged in one batch, every
+           lane applies its verdict - the statements are doNNI's, the evaluation is deferred */
+        void runNNILanes(std::vector<Lane> &lanes, const NNIParams &prm, std::vector<NNIStats> &stats, std::vector<char> &traversal,
+                         std::vector<char> &upHave, bool starTest, int64_t &nNNIThisRound, double &dMaxDelta) {
+            const double supportThreshold = prm.useML ? 0.1 /* treeLogLkDelta */ : prm.minDelta;
+            std::vector<Lane *> asking;
+            std::vector<int64_t> ids, li, pi, pj;
+            std::vector<vft_quartet_nni> res;
+            std::vector<REAL> d, w;
+            for (;;) {
+                for (Lane &ln: lanes)
+                    if (!ln.finished && !ln.hasRequest) advanceNNILane(ln, prm, traversal, upHave);
+                runShared(prm.useML);
+                runChains(lanes, prm.useML);
+                asking.clear();
+                for (Lane &ln: lanes)
+                    if (ln.hasRequest) asking.push_back(&ln);
+                if (asking.empty()) break;
+                const size_t K = asking.size();
+                laneSteps++;
+                laneWork += (int64_t) K;
+                if (prm.useML) {
+                    ids.resize(4 * K);
+                    li.resize(5 * K);
+                    res.resize(K);
+                    for (size_t t = 0; t < K; t++) {
+                        const Lane &ln = *asking[t];
+                        const int64_t q4[4] = {ln.q[0], ln.q[1], ln.q[2], ln.idD}, l5[5] = {ln.q[0], ln.q[1], ln.q[2], ln.q[3], ln.qnode};
+                        std::copy(q4, q4 + 4, ids.begin() + (long) (4 * t));
+                        std::copy(l5, l5 + 5, li.begin() + (long) (5 * t));
+                    }
+                    const size_t maxBatch = 512;
+                    for (size_t k0 = 0; k0 < K; k0 += maxBatch) {
+                        const size_t cnt = std::min(maxBatch, K - k0);
+                        chk(vft_ml_quartet_nni_flags(ctx, (int64_t) cnt, ids.data() + 4 * k0, li.data() + 5 * k0, prm.ftol, prm.atol, /*closeLogLkLimit*/5.0,
+                                                     prm.mlAccuracy, starTest ? 0 : VFT_QUARTET_NO_STAR_TEST, res.data() + k0));
+                    }
+                } else {
+                    pi.resize(6 * K);
+                    pj.resize(6 * K);
+                    d.resize(6 * K);
+                    w.resize(6 * K);
+                    for (size_t t = 0; t < K; t++) {
+                        const Lane &ln = *asking[t];
+                        const int64_t a[6] = {ln.q[0], ln.q[0], ln.q[0], ln.q[1], ln.q[1], ln.q[2]}, b[6] = {ln.q[1], ln.q[2], ln.idD, ln.q[2], ln.idD, ln.idD};
+                        std::copy(a, a + 6, pi.begin() + (long) (6 * t));
+                        std::copy(b, b + 6, pj.begin() + (long) (6 * t));
+                    }
+                    chk(vft_profile_distances(ctx, (int64_t) (6 * K), pi.data(), pj.data(), d.data(), w.data()));
+                }
+                for (size_t t = 0; t < K; t++) {
+                    Lane &ln = *asking[t];
+                    int choice = 0;
+                    double criteria[3];
+                    if (prm.useML) {
+                        choice = res[t].choice;
+                        for (int i = 0; i < 3; i++) criteria[i] = res[t].criteria[i];
+                        if (res[t].star) nStarTests++;
+                    } else {
+                        double c[6];
+                        for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[6 * t + (size_t) i], prm.scoredist);
+                        criteria[0] = c[0] + c[5];
+                        criteria[1] = c[1] + c[4];
+                        criteria[2] = c[2] + c[3];
+                        if (criteria[1] < criteria[0] && criteria[1] <= criteria[2]) choice = 1;
+                        else if (criteria[2] < criteria[0] && criteria[2] <= criteria[1]) choice = 2;
+                        for (int i = 0; i < 3; i++) criteria[i] = -criteria[i];
+                    }
+                    cur = &ln;
+                    applyNNIVerdict(ln.qnode, ln.q, choice, criteria, prm.useML, supportThreshold, stats, upHave, nNNIThisRound, dMaxDelta);
+                    cur = nullptr;
+                    ln.hasRequest = false;
+                }
+            }
+        }
+
+        /* the walk of one lane up to its next quartet */
+        void advanceNNILane(Lane &ln, const NNIParams &prm, std::vector<char> &traversal, std::vector<char> &upHave) {
+            cur = &ln;
+            for (;;) {
+                if (!ln.inBranch) {
+                    if (ln.R < 0) {   /* the serial walk has the whole tree as its one branch */
+                        ln.finished = true;
+                        break;
+                    }
+                    /* the branches of a subtree: the children of its root's children, read when the walk gets there - an NNI
+                       of an earlier branch may have put a different node in the slot (NJ.tcc:6139-6147) */
+                    bool found = false;
+                    while (ln.j < 2 && child[3 * ln.R + ln.j] >= 0) {
+                        const int64_t dc = child[3 * ln.R + ln.j];
+                        if (ln.k < 2 && child[3 * dc + ln.k] >= 0) {
+                            ln.node = ln.branchRoot = child[3 * dc + ln.k];
+                            ln.k++;
+                            ln.roots.push_back(ln.branchRoot);
+                            ln.inBranch = found = true;
+                            break;
+                        }
+                        ln.j++;
+                        ln.k = 0;
+                    }
+                    if (!found) {
+                        ln.finished = true;
+                        break;
+                    }
+                }
+                bool bUp = false;
+                const int64_t node = nextPostorder(ln.node, traversal, &bUp, ln.branchRoot);
+                if (node < 0) {
+                    ln.inBranch = false;
+                    continue;
+                }
+                ln.node = node;
+                if (node < nSeqs || node == root) continue;
+                if (bUp) {   /* NJ.tcc:5809-5820 */
+                    for (int k = 0; k < 2; k++) upHave[(size_t) child[3 * node + k]] = 0;
+                    upHave[(size_t) node] = 0;
+                    recomputeProfile(node, prm.useML);
+                    continue;
+                }
+                quartetNodes(node, ln.q);
+                const int64_t par = parent[(size_t) node];
+                ln.idD = ln.q[3];
+                if (par != root) {
+                    ensureUpProfile(par, prm.useML, upHave);
+                    ln.idD = par + nSeqs;
+                }
+                ln.qnode = node;
+                ln.hasRequest = true;
+                break;
+            }
+            cur = nullptr;
+        }
+
+        /* what traverseNNI does with a verdict (NJ.tcc:5880-5980): rearrange, statistics, profiles */
+        void applyNNIVerdict(int64_t node, const int64_t q[4], int choice, const double criteria[3], bool useML, double supportThreshold,
+                             std::vector<NNIStats> &stats, std::vector<char> &upHave, int64_t &nNNIThisRound, double &dMaxDelta) {
+            const int64_t nodeA = q[0], nodeB = q[1], nodeC = q[2], nodeD = q[3], par = parent[(size_t) node];
+            if (choice == 1) {          /* swap B and C */
+                replaceChild(node, nodeB, nodeC);
+                replaceChild(par, nodeC, nodeB);
+            } else if (choice == 2) {   /* swap A and C */
+                replaceChild(node, nodeA, nodeC);
+                replaceChild(par, nodeC, nodeA);
+            }
+            NNIStats &st = stats[(size_t) node];
+            if (choice == 0) {
+                st.age++;
+            } else {
+                nNNIThisRound++;
+                st.age = 0;
+                stats[(size_t) nodeA].age = stats[(size_t) nodeB].age = stats[(size_t) nodeC].age = stats[(size_t) nodeD].age = 0;
+            }
+            st.delta = criteria[choice] - criteria[0];
+            if (st.delta > dMaxDelta) dMaxDelta = st.delta;
+            st.support = 1e20;
+            for (int i = 0; i < 3; i++)
+                if (choice != i && criteria[choice] - criteria[i] < st.support) st.support = criteria[choice] - criteria[i];
+            if (st.delta > supportThreshold) {
+                st.subtreeAge = 0;
+            } else {
+                st.subtreeAge++;
+                for (int i = 0; i < 2; i++) {
+                    const int64_t ch = child[3 * node + i];
+                    if (st.subtreeAge > stats[(size_t) ch].subtreeAge) st.subtreeAge = stats[(size_t) ch].subtreeAge;
+                }
+            }
+            if (choice == 0) {
+                upHave[(size_t) nodeA] = upHave[(size_t) nodeB] = upHave[(size_t) nodeC] = 0;
+                recomputeProfile(node, useML);
+            } else {
+                updateForNNI(node, useML, upHave);
+            }
+        }
+
         /* SPR (NJ.tcc:6185-6404, one thread, fast flavour): every node in post-order is moved along chains of up to
            maxSPRLength minimum-evolution NNIs around its parent and its sibling (findSPRSteps, NJ.tcc:1805-1859; the
            first step forced to AC or AD), keeping the prefix of the chain with the best total length change and
@@ -611,6 +810,243 @@ namespace veryfasttree {
             return nSPR;
         }
 
+        /* ---------------------------------------------------------------------------------------------- the subtree schedule
+           What the reference does with `-threads T` (T > 1, the default -threads-level 3): treePartitioning
+           (NJ.tcc:5540-5750) picks an antichain of subtrees, every OpenMP thread walks its subtrees with a private up-profile
+           cache, then one thread walks what is left from the root.  The result does not depend on the thread timing: inside
+           the parallel phase a walk reads nothing outside its subtree that another walk writes (the subtree roots and, for
+           NNIs, their children are never the centre of a step, NJ.tcc:6135-6147, :5092-5096), so the up-profiles at and
+           above a subtree root are the same whoever builds them.  It DOES depend on T (the partition) and differs from the
+           one-thread order.  Here every subtree is a LANE; all lanes advance in lockstep, one step = one launch of their
+           up-profile / recompute chains (vft_*_chains) and one batch of their quartets / splits - the independent work the
+           GPU needs.  Output is byte-identical to `VeryFastTree -threads T` (tests/test_gpu_threads.py, fixtures from
+           oracle/gen_fixtures.py threads). */
+
+        /* treePartitioning: roots of the subtrees, in the order the reference hands them to its threads */
+        std::vector<int64_t> treePartitioning(int penalty, int threads, int window = 50) {
+            const size_t N = (size_t) nNodes;
+            std::vector<int64_t> size(N, 1), depth(N, 0);
+            for (int64_t v: order) {   /* children before parents */
+                int64_t w = 1;
+                for (int k = 0; k < 3 && child[3 * v + k] >= 0; k++) w += size[(size_t) child[3 * v + k]];
+                size[(size_t) v] = w;
+            }
+            int64_t deepest = 0;
+            for (size_t t = order.size(); t-- > 0;) {   /* parents before children */
+                const int64_t v = order[t];
+                for (int k = 0; k < 3 && child[3 * v + k] >= 0; k++) {
+                    const int64_t c = child[3 * v + k];
+                    depth[(size_t) c] = depth[(size_t) v] + 1;
+                    if (depth[(size_t) c] > deepest) deepest = depth[(size_t) c];
+                }
+            }
+            /* the weight of a candidate: the nodes `penalty` levels below it and deeper (what a walk may touch), 0 for
+               candidates too close to the deepest level */
+            std::vector<int64_t> weight(N, 0), frontier, next;
+            for (size_t i = 0; i < N; i++) {
+                if (deepest - depth[i] < penalty) continue;
+                frontier.assign(1, (int64_t) i);
+                for (int lv = 0; lv < penalty; lv++) {
+                    next.clear();
+                    for (int64_t v: frontier)
+                        for (int k = 0; k < 3 && child[3 * v + k] >= 0; k++) next.push_back(child[3 * v + k]);
+                    frontier.swap(next);
+                }
+                int64_t w = 0;
+                for (int64_t v: frontier) w += size[(size_t) v];
+                weight[i] = w;
+            }
+            const size_t T = (size_t) threads;
+            auto speedup = [&](const std::vector<int64_t> &sol) -> double {
+                int64_t denom;
+                if (sol.empty()) {
+                    denom = nNodes;
+                } else if (sol.size() <= T) {
+                    int64_t inside = 0;
+                    for (int64_t v: sol) inside += weight[(size_t) v];
+                    denom = nNodes - inside + weight[(size_t) sol.back()];
+                } else {   /* greedy: every subtree to the least loaded thread; loads kept in descending order */
+                    std::vector<int64_t> load(T, 0);
+                    int64_t inside = 0;
+                    for (int64_t v: sol) {
+                        int64_t least = load.back();
+                        load.pop_back();
+                        inside += weight[(size_t) v];
+                        least += weight[(size_t) v];
+                        load.insert(std::lower_bound(load.begin(), load.end(), least, [](int64_t a, int64_t b) { return b < a; }), least);
+                    }
+                    denom = nNodes - inside + load[0];
+                }
+                return (double) nNodes / (double) denom;
+            };
+            std::vector<int64_t> sol, best;   /* ascending weight; a newcomer goes in front of its equals */
+            auto lighter = [&](int64_t x, int64_t y) { return weight[(size_t) x] < weight[(size_t) y]; };
+            auto put = [&](int64_t v) {
+                if (weight[(size_t) v] > 0) sol.insert(std::lower_bound(sol.begin(), sol.end(), v, lighter), v);
+            };
+            for (int k = 0; k < 3; k++) put(child[3 * root + k]);
+            best = sol;
+            double cur = speedup(sol), bestSpeedup = cur;
+            std::vector<double> recent;   /* the last `window` + 1 speed-ups: stop once they trend downwards */
+            for (;;) {
+                if (sol.empty()) break;
+                recent.push_back(cur);
+                if (sol.size() >= T && recent.size() > (size_t) window) {
+                    int64_t balance = 0;
+                    for (size_t a = 0; a < recent.size(); a++)
+                        for (size_t b = a; b < recent.size(); b++) balance += recent[a] <= recent[b] ? 1 : -1;
+                    recent.erase(recent.begin());
+                    if (balance < 0) break;
+                }
+                const int64_t v = sol.back();   /* split the heaviest */
+                sol.pop_back();
+                if (child[3 * v] < 0) continue;
+                put(child[3 * v]);
+                put(child[3 * v + 1]);
+                cur = speedup(sol);
+                if (cur > bestSpeedup) {
+                    best = sol;
+                    bestSpeedup = cur;
+                }
+            }
+            /* the hand-out: lightest first, each to the least loaded thread (ties: the thread that was touched longest ago,
+               initially the last); the list is read thread-major per round, which is the order returned */
+            std::vector<std::vector<int64_t>> mine(T);
+            std::vector<std::pair<int64_t, int64_t>> load(T);   /* (thread, load), descending load */
+            for (size_t i = 0; i < T; i++) load[i] = std::make_pair((int64_t) (T - i - 1), (int64_t) 0);
+            for (int64_t v: best) {
+                std::pair<int64_t, int64_t> least = load.back();
+                load.pop_back();
+                least.second += weight[(size_t) v];
+                mine[(size_t) least.first].push_back(v);
+                load.insert(std::lower_bound(load.begin(), load.end(), least,
+                                             [](const std::pair<int64_t, int64_t> &a, const std::pair<int64_t, int64_t> &b) { return b.second < a.second; }),
+                            least);
+            }
+            std::vector<int64_t> out;
+            for (size_t lv = 0;; lv++) {
+                bool any = false;
+                for (size_t t = 0; t < T; t++)
+                    if (mine[t].size() > lv) {
+                        out.push_back(mine[t][lv]);
+                        any = true;
+                    }
+                if (!any) break;
+            }
+            partitionSpeedup = bestSpeedup;
+            return out;
+        }
+
+        /* DoNNI with threads > 1 (NJ.tcc:6108-6160 + the serial traverseNNI that follows): the lanes of treePartitioning(2)
+           in lockstep, then the rest of the tree from the root.  Maximum likelihood: the lanes test the star topology, the
+           serial walk does not (MLQuartetNNI's `omp sections` branch, NJ.tcc:4902-4948). */
+        int64_t doNNIThreaded(const NNIParams &prm, std::vector<NNIStats> &stats, double &dMaxDelta, int threads) {
+            const double supportThreshold = prm.useML ? 0.1 : prm.minDelta;
+            int64_t nNNIThisRound = 0;
+            dMaxDelta = 0.0;
+            if (nSeqs <= 3) return 0;
+            std::vector<char> traversal((size_t) nNodes, 0), upHave((size_t) nNodes, 0);
+            for (int64_t node = nSeqs; node < nNodes; node++) {   /* quiet subtrees are not entered (NJ.tcc:6047-6075) */
+                const NNIStats &st = stats[(size_t) node];
+                if (node != root && st.age >= 2 && st.subtreeAge >= 2 && st.support > supportThreshold) {
+                    int64_t q[4];
+                    quartetNodes(node, q);
+                    int i;
+                    for (i = 0; i < 4; i++)
+                        if (stats[(size_t) q[i]].age == 0 && stats[(size_t) q[i]].support > supportThreshold) break;
+                    if (i == 4) traversal[(size_t) node] = 1;
+                }
+            }
+            const std::vector<int64_t> subtrees = treePartitioning(2, threads);
+            std::vector<Lane> lanes(subtrees.size());
+            for (size_t i = 0; i < subtrees.size(); i++) lanes[i].R = subtrees[i];
+            runNNILanes(lanes, prm, stats, traversal, upHave, /*starTest*/true, nNNIThisRound, dMaxDelta);
+            /* the threads' private caches end with the parallel region: what survives (moveUpProfile from every branch root,
+               NJ.tcc:5766-5779, :6150-6155) are the entries on the way from each branch root up to the root of the tree - every
+               other entry below the subtree's root is gone */
+            std::vector<char> keep((size_t) nNodes, 0);
+            std::vector<int64_t> stack;
+            for (const Lane &ln: lanes) {
+                for (int64_t g: ln.roots)
+                    for (int64_t x = g; x != ln.R && x >= 0; x = parent[(size_t) x]) keep[(size_t) x] = 1;
+                stack.assign(1, ln.R);
+                while (!stack.empty()) {
+                    const int64_t v = stack.back();
+                    stack.pop_back();
+                    for (int k = 0; k < 2 && child[3 * v + k] >= 0; k++) {
+                        const int64_t c = child[3 * v + k];
+                        if (!keep[(size_t) c]) upHave[(size_t) c] = 0;
+                        stack.push_back(c);
+                    }
+                }
+            }
+            std::vector<Lane> rest(1);
+            rest[0].node = rest[0].branchRoot = root;
+            rest[0].inBranch = true;
+            runNNILanes(rest, prm, stats, traversal, upHave, /*starTest*/false, nNNIThisRound, dMaxDelta);
+            rebuildOrder();
+            return nNNIThisRound;
+        }
+
+        /* optimizeAllBranchLengths with threads > 1 and -threads-level 3 (NJ.tcc:5083-5112): the lanes of treePartitioning(1)
+           - both branches below every subtree root, the root's children included - then the rest of the tree */
+        void optimizeRoundThreaded(double ftol, double atol, int threads) {
+            std::vector<char> upHave((size_t) nNodes, 0), done((size_t) nNodes, 0);
+            const std::vector<int64_t> subtrees = treePartitioning(1, threads);
+            std::vector<Lane> lanes(subtrees.size());
+            std::vector<std::pair<int64_t, int>> stack;
+            size_t longest = 0;
+            for (size_t i = 0; i < subtrees.size(); i++) {
+                Lane &ln = lanes[i];
+                ln.R = subtrees[i];
+                for (int b = 0; b < 2 && child[3 * ln.R + b] >= 0; b++) {   /* post-order of each branch, internal nodes only */
+                    stack.assign(1, std::make_pair(child[3 * ln.R + b], 0));
+                    while (!stack.empty()) {
+                        const int64_t v = stack.back().first;
+                        const int k = stack.back().second;
+                        if (k < 2 && child[3 * v + k] >= 0) {
+                            stack.back().second++;
+                            stack.push_back(std::make_pair(child[3 * v + k], 0));
+                        } else {
+                            stack.pop_back();
+                            if (child[3 * v] >= 0) ln.nodes.push_back(v);
+                        }
+                    }
+                }
+                longest = std::max(longest, ln.nodes.size());
+            }
+            std::vector<int64_t> ids, li, rec;
+            for (size_t step = 0; step < longest; step++) {
+                ids.clear(); li.clear(); rec.clear();
+                for (Lane &ln: lanes) {
+                    if (ln.pos >= ln.nodes.size()) continue;
+                    const int64_t v = ln.nodes[ln.pos++];
+                    cur = &ln;
+                    ensureUpProfile(v, true, upHave);
+                    cur = nullptr;
+                    const int64_t q[3] = {child[3 * v], child[3 * v + 1], v + nSeqs}, l[3] = {child[3 * v], child[3 * v + 1], v};
+                    ids.insert(ids.end(), q, q + 3);
+                    li.insert(li.end(), l, l + 3);
+                    rec.push_back(v);
+                    upHave[(size_t) v] = 0;   /* NJ.tcc:5062 */
+                    done[(size_t) v] = 1;
+                }
+                runShared(true);
+                runChains(lanes, true);
+                const size_t maxBatch = 2048;
+                for (size_t k0 = 0; k0 < rec.size(); k0 += maxBatch) {
+                    const size_t cnt = std::min(maxBatch, rec.size() - k0);
+                    chk(vft_ml_optimize_splits(ctx, (int64_t) cnt, ids.data() + 3 * k0, li.data() + 3 * k0, rec.data() + k0, ftol, atol));
+                }
+                laneSteps++;
+                laneWork += (int64_t) rec.size();
+            }
+            optimizeRoundFrom(ftol, atol, upHave, done);
+        }
+
+        double partitionSpeedup = 0;           /* the reference's "theoretical speedup" of the last partition */
+        int64_t laneSteps = 0, laneWork = 0;   /* lockstep steps / quartets or splits evaluated in them (all rounds so far) */
+
         int64_t nStarTests = 0;
 
         const std::vector<int64_t> &children() const { return child; }
@@ -626,7 +1062,7 @@ namespace veryfasttree {
             double rates[6], freq[4];
         };
 
-        GtrFit setMLGtr(const int64_t leafCodeCounts[4], int64_t nPos, int32_t mlAccuracy, double ftol, double atol) {
+        GtrFit setMLGtr(const int64_t leafCodeCounts[4], int64_t nPos, int32_t mlAccuracy, double ftol, double atol, int threads = 1) {
             GtrFit g;
             int64_t n[4], sum = 0;
             for (int i = 0; i < 4; i++) {
@@ -653,7 +1089,8 @@ namespace veryfasttree {
             g.rates[5] = 1.0;
             installGTR(g.rates, g.freq);
             recomputeMLProfiles();
-            optimizeRound(ftol, atol);
+            if (threads > 1) optimizeRoundThreaded(ftol, atol, threads);
+            else optimizeRound(ftol, atol);
             return g;
         }
 
@@ -892,16 +1329,83 @@ namespace veryfasttree {
             if (upHave[(size_t) node]) return;
             std::vector<int64_t> path;
             for (int64_t x = node; x != root; x = parent[(size_t) x]) path.push_back(x);
+            /* a lane: the up-profiles of its subtree root and above do not change during the parallel phase and belong to
+               every lane below them - they are built once, level by level, before the lanes' chains (runShared) */
+            size_t tR = path.size();
+            if (cur && cur->R >= 0)
+                for (size_t t = 0; t < path.size(); t++)
+                    if (path[t] == cur->R) tR = t;
             for (size_t t = path.size(); t-- > 0;) {
                 const int64_t x = path[t];
                 if (upHave[(size_t) x]) continue;
                 int64_t cd[2], lcd[2];
                 quartetCD(x, cd, lcd);
                 const int64_t out = x + nSeqs;
-                if (useML) queuePosterior(out, cd[0], cd[1], lcd[0], lcd[1]);
+                if (t >= tR) {
+                    SharedOp op = {(int64_t) (path.size() - t), out, cd[0], cd[1], lcd[0], lcd[1]};
+                    sharedOps.push_back(op);
+                } else if (useML) queuePosterior(out, cd[0], cd[1], lcd[0], lcd[1]);
                 else queueAverage(out, cd[0], cd[1]);
                 upHave[(size_t) x] = 1;
             }
+        }
+
+        void runShared(bool useML) {
+            if (sharedOps.empty()) return;
+            std::stable_sort(sharedOps.begin(), sharedOps.end(), [](const SharedOp &x, const SharedOp &y) { return x.depth < y.depth; });
+            std::vector<int64_t> o, a, b, la, lb;
+            for (size_t i = 0; i < sharedOps.size();) {
+                size_t e = i;
+                o.clear(); a.clear(); b.clear(); la.clear(); lb.clear();
+                for (; e < sharedOps.size() && sharedOps[e].depth == sharedOps[i].depth; e++) {
+                    o.push_back(sharedOps[e].out);
+                    a.push_back(sharedOps[e].a);
+                    b.push_back(sharedOps[e].b);
+                    la.push_back(sharedOps[e].la);
+                    lb.push_back(sharedOps[e].lb);
+                }
+                if (useML) chk(vft_posterior_profiles_blen(ctx, (int64_t) o.size(), o.data(), a.data(), b.data(), la.data(), lb.data()));
+                else chk(vft_average_profiles(ctx, (int64_t) o.size(), o.data(), a.data(), b.data(), nullptr));
+                i = e;
+            }
+            sharedOps.clear();
+        }
+
+        /* the chains of all lanes as one launch (several when there are more than 4096 ops); a lane with more than 256 ops -
+           a deep first descent - sends the head of its chain ahead on its own */
+        void runChains(std::vector<Lane> &lanes, bool useML) {
+            std::vector<int64_t> o, a, b, la, lb;
+            std::vector<int32_t> off(1, 0);
+            auto flush = [&]() {
+                if (off.size() > 1) {
+                    if (useML) chk(vft_posterior_chains_blen(ctx, (int32_t) off.size() - 1, off.data(), o.data(), a.data(), b.data(), la.data(), lb.data()));
+                    else chk(vft_average_chains(ctx, (int32_t) off.size() - 1, off.data(), o.data(), a.data(), b.data()));
+                }
+                o.clear(); a.clear(); b.clear(); la.clear(); lb.clear();
+                off.assign(1, 0);
+            };
+            for (Lane &ln: lanes) {
+                size_t first = 0;
+                const size_t n = ln.out.size();
+                while (n - first > 256) {
+                    if (useML) chk(vft_posterior_chain_blen(ctx, 256, &ln.out[first], &ln.a[first], &ln.b[first], &ln.la[first], &ln.lb[first]));
+                    else chk(vft_average_chain(ctx, 256, &ln.out[first], &ln.a[first], &ln.b[first]));
+                    first += 256;
+                }
+                if (n == first) {
+                    if (n) { ln.out.clear(); ln.a.clear(); ln.b.clear(); ln.la.clear(); ln.lb.clear(); }
+                    continue;
+                }
+                if (o.size() + (n - first) > 4096 || off.size() > 60000) flush();
+                o.insert(o.end(), ln.out.begin() + (long) first, ln.out.end());
+                a.insert(a.end(), ln.a.begin() + (long) first, ln.a.end());
+                b.insert(b.end(), ln.b.begin() + (long) first, ln.b.end());
+                la.insert(la.end(), ln.la.begin() + (long) first, ln.la.end());
+                lb.insert(lb.end(), ln.lb.begin() + (long) first, ln.lb.end());
+                off.push_back((int32_t) o.size());
+                ln.out.clear(); ln.a.clear(); ln.b.clear(); ln.la.clear(); ln.lb.clear();
+            }
+            flush();
         }
 
         /* recomputeProfile (NJ.tcc:3436-3473) without BIONJ weighting */
@@ -915,6 +1419,14 @@ namespace veryfasttree {
         /* the same for the posteriors of the ML walk (vft_posterior_chain_blen); the branch lengths are read on the
            device when the chain runs, i.e. after the verdict kernels queued before it */
         void queuePosterior(int64_t out, int64_t a, int64_t b, int64_t la, int64_t lb) {
+            if (cur) {   /* a lane of the subtree schedule: its own chain, launched with the other lanes' */
+                cur->out.push_back(out);
+                cur->a.push_back(a);
+                cur->b.push_back(b);
+                cur->la.push_back(la);
+                cur->lb.push_back(lb);
+                return;
+            }
             pOut.push_back(out);
             pA.push_back(a);
             pB.push_back(b);
@@ -938,6 +1450,14 @@ namespace veryfasttree {
         /* Minimum-evolution averages are queued and go down as one chain launch (vft_average_chain) right before
            something reads profiles: a step of an NNI / SPR walk is then two launches (chain, distances) and one wait */
         void queueAverage(int64_t out, int64_t a, int64_t b) {
+            if (cur) {
+                cur->out.push_back(out);
+                cur->a.push_back(a);
+                cur->b.push_back(b);
+                cur->la.push_back(a);
+                cur->lb.push_back(b);
+                return;
+            }
             qOut.push_back(out);
             qA.push_back(a);
             qB.push_back(b);

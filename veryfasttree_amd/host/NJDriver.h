@@ -61,6 +61,8 @@ namespace veryfasttree {
         int aaModel = 0;
         /* multi-GPU (include/vft_host.h, vft_comm): sweeps and leaf blocks are split over the ranks */
         const vft_comm *comm = nullptr;
+        /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
+        int threads = 1;
         /* top-hit lists on the device (vft_tophits_*): the list walks of a join are one launch each; false = the host walks
            of round 2 (kept as the cross-check of VFT_NJ_CHECK and for tools) */
         bool deviceLists = true;
@@ -722,7 +724,7 @@ namespace veryfasttree {
             for (int64_t i = 0; i < nniToDo; i++) {
                 if (!bConverged) {
                     double maxDelta;
-                    const int64_t nChange = tree.doNNI(prm, stats, maxDelta);
+                    const int64_t nChange = opt.threads > 1 ? tree.doNNIThreaded(prm, stats, maxDelta, opt.threads) : tree.doNNI(prm, stats, maxDelta);
                     meNNIRoundsDone++;
                     total += nChange;
                     if (nChange == 0) bConverged = true;
@@ -796,6 +798,7 @@ namespace veryfasttree {
                 /* VFT_ML_PARALLEL_LENGTHS=1 (measurements only): the level-parallel rounds of MLLengths.h, which do not
                    follow the one-thread order of the reference */
                 if (parallelLengths) ml.optimizeRoundParallel(ftol, atol);
+                else if (opt.threads > 1) ml.optimizeRoundThreaded(ftol, atol, opt.threads);
                 else ml.optimizeRound(ftol, atol);
                 ml.getLengths(branchlength.data());
                 double dMaxChange = 0;
@@ -816,7 +819,8 @@ namespace veryfasttree {
                    the best NNI stops improving by 0.1, NNI statistics reset for the last one), the rate categories
                    fitted after the first round, and a final pass over all lengths */
                 const int64_t MLnniToDo = (int64_t) (0.5 + 2.0 * std::log((double) nSeqs) / std::log(2.0));
-                ml.optimizeRound(ftol, atol);
+                if (opt.threads > 1) ml.optimizeRoundThreaded(ftol, atol, opt.threads);
+                else ml.optimizeRound(ftol, atol);
                 typename MLLengths<REAL>::NNIParams prm;
                 prm.useML = true;
                 prm.ftol = ftol;
@@ -828,7 +832,7 @@ namespace veryfasttree {
                 mlNNIs = 0;
                 for (int64_t iMLnni = 0; iMLnni < MLnniToDo; iMLnni++) {
                     double maxDelta;
-                    mlNNIs += ml.doNNI(prm, stats, maxDelta);
+                    mlNNIs += opt.threads > 1 ? ml.doNNIThreaded(prm, stats, maxDelta, opt.threads) : ml.doNNI(prm, stats, maxDelta);
                     const double ll = ml.treeLogLk(nPos, nLeafGaps);
                     loglk.push_back(ll);
                     const bool bConvergedHere = iMLnni > 0 && (ll < lastloglk + 0.1 || maxDelta < 0.1);
@@ -842,7 +846,8 @@ namespace veryfasttree {
                         ratesSet = nRateCats > 1;
                     }
                 }
-                ml.optimizeRound(ftol, atol);
+                if (opt.threads > 1) ml.optimizeRoundThreaded(ftol, atol, opt.threads);
+                else ml.optimizeRound(ftol, atol);
                 loglk.push_back(ml.treeLogLk(nPos, nLeafGaps));   /* "TreeLogLk ML_Lengths2" */
                 ml.getLengths(branchlength.data());
                 adoptTree(ml.parents(), ml.children());
@@ -866,11 +871,13 @@ namespace veryfasttree {
                 mlWorstDelta = st.worstDelta;
             }
             mlEvaluations = ml.evaluations();
+            mlLaneSteps = ml.laneSteps;
+            mlLaneWork = ml.laneWork;
             return loglk;
         }
 
         void fitGtr(MLLengths<REAL> &ml, int64_t &nLeafGaps, double ftol, double atol) {
-            const typename MLLengths<REAL>::GtrFit g = ml.setMLGtr(leafCodeCounts, nPos, /*mlAccuracy*/1, ftol, atol);
+            const typename MLLengths<REAL>::GtrFit g = ml.setMLGtr(leafCodeCounts, nPos, /*mlAccuracy*/1, ftol, atol, opt.threads);
             for (int i = 0; i < 6; i++) gtrRates[i] = g.rates[i];
             for (int i = 0; i < 4; i++) gtrFreq[i] = g.freq[i];
             gtrFitted = true;
@@ -878,6 +885,7 @@ namespace veryfasttree {
         }
 
         int64_t mlNNIs = 0;
+        int64_t mlLaneSteps = 0, mlLaneWork = 0;   /* lockstep steps of the subtree schedule and the quartets / splits judged in them */
         int64_t leafCodeCounts[4];                /* occurrences of codes 0..3 in the unique sequences (setMLGtr) */
         bool gtrFitted = false;
         double gtrRates[6] = {1, 1, 1, 1, 1, 1}, gtrFreq[4] = {0.25, 0.25, 0.25, 0.25};   /* "GTR rates" / "GTR Frequencies" */

@@ -81,6 +81,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.scoredist = o->scoredist != 0 || o->aa_model != 0;
         opt.aaModel = o->aa_model;
         opt.comm = o->comm;
+        opt.threads = o->threads > 1 ? o->threads : 1;
     }
     return opt;
 }
