@@ -254,13 +254,11 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes (torch.distributed.run,
     one per GPU, rendezvous on 127.0.0.1) before anything in this process touches the GPU, relay what they print and exit
     with their code.  Never exec: this process may hold profiler / runtime state."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the rendezvous store listens on a port the launcher itself picks and holds (binding a socket here, closing it
+    # and passing the number on can lose the port to another launch on the same box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     res = subprocess.run(cmd, env=env)
@@ -474,6 +472,12 @@ def main():
                 e2e = end_to_end(which, local_rank, comm)
             except Exception as exc:   # the headline line must still be printed
                 e2e, ok = {"workload": which, "error": repr(exc)}, 0.0
+                if use_dist and comm is not None:
+                    # The other ranks are inside the C++ driver's all-gathers for this tree: joining the all-reduces below from
+                    # here would pair them with collectives of another kind and hang the job until the backend's timeout.  Say
+                    # what happened and leave with an error code - the launcher (torch.distributed.run) then ends the job.
+                    print("bench.py: rank %d failed in the sharded end-to-end run (%r); ending the job" % (rank, exc), file=sys.stderr, flush=True)
+                    os._exit(17)
             if use_dist:
                 # every rank takes part in both collectives whatever happened on it: first whether all succeeded, then the
                 # slowest rank's wall-clock (a failure on one rank must not leave the others waiting in an all-reduce)

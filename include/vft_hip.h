@@ -35,6 +35,7 @@ extern "C" {
 #define VFT_ERR_HIP 2       /* a HIP runtime call failed */
 #define VFT_ERR_STATE 3     /* call sequence error (e.g. sweep before leaves were uploaded) */
 #define VFT_ERR_TIMEOUT 4   /* a kernel did not raise its completion flag (the wait is bounded; the context is unusable afterwards) */
+#define VFT_ERR_HALTED 5    /* vft_nj_engine_enqueue: the join engine has stopped at an event the caller handles first (poll, resume) */
 #define VFT_NOCODE 127
 
 typedef struct vft_ctx vft_ctx;
@@ -337,6 +338,18 @@ int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t
    `-threads T` traversal, NJ.tcc:6108-6160) queues one chain per subtree and step.  Stream-ordered. */
 int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
                        const int64_t *b);
+
+/* One round of subtree-prune-regraft moves (SPR, NJ.tcc:6185-6404, one thread, fast flavour; findSPRSteps :1805-1859,
+   unwindSPRStep :1861-1879) entirely on the device: node_list[n_list] is the walk (the reference fixes it before anything
+   moves: every node in post-order), parent[n_nodes] (-1 at the root) / child[n_nodes][3] (-1 = none) the tree, rearranged in
+   place; chains of up to max_len (<= 16; the reference's default is 10) forced minimum-evolution NNIs per node, criteria =
+   log-corrected profile distances (scoredist: NJ.tcc:322-330).  Profiles and up-profiles (slot node + n_seqs) are kept
+   current exactly as the host walk keeps them (recomputeProfile after every step, all ancestors after an accepted move).
+   Needs vft_set_profile_rows(ctx, 1) and max_nodes >= n_nodes + n_seqs; alignments up to ~1 700 columns (the six distances
+   of a step are staged in LDS).  out[8]: accepted moves, chain steps evaluated, averages computed, cache epochs, device clock
+   ticks (100 MHz) inside average commands / distance commands / in total, 0.  Waits. */
+int vft_spr_round(vft_ctx *ctx, int64_t n_nodes, int64_t *parent, int64_t *child, int64_t root, int64_t n_list,
+                  const int64_t *node_list, int32_t scoredist, int32_t max_len, int64_t *out);
 
 /* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */

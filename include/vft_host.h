@@ -79,8 +79,19 @@ typedef struct {
                                    `VeryFastTree -threads T` whenever the NJ phase of that run joins in the one-thread
                                    order (its tree does not depend on the thread count).  The caller keeps
                                    use_tophits_2nd = 0 with T > 1, as the reference does (VeryFastTree.cpp:87-91). */
-    int32_t reserved;
+    int32_t debug_flags;        /* tests and tools only - which of two equivalent loops runs (no environment variable selects one):
+                                   VFT_NJ_DEBUG_HOST_JOINS 1  the host-driven join loop instead of the join engine
+                                   VFT_NJ_DEBUG_HOST_LISTS 2  top-hit lists on the host (round 2's walks)
+                                   VFT_NJ_DEBUG_HOST_RESET 4  resetTopVisible entirely on the host
+                                   VFT_NJ_DEBUG_HOST_SPR   8  the host-driven SPR walk instead of vft_spr_round
+                                   VFT_NJ_DEBUG_LEVEL_LENGTHS 16  ML length rounds as one batch per tree height - NOT the reference's
+                                                              order in any of its modes (measurements only) */
 } vft_nj_options;
+#define VFT_NJ_DEBUG_HOST_JOINS 1
+#define VFT_NJ_DEBUG_HOST_LISTS 2
+#define VFT_NJ_DEBUG_HOST_RESET 4
+#define VFT_NJ_DEBUG_HOST_SPR 8
+#define VFT_NJ_DEBUG_LEVEL_LENGTHS 16
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
    joins: up to n_seqs-3 rows of (i, j, newnode) with i < j, in join order; criterion[k] = the join's criterion.
@@ -122,6 +133,12 @@ int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t
    trace lines (-verbose 3, NJ.tcc:2925) reduced the same way pin the join order of a run whose tree is all the caller asked
    for (tests/golden/bb_c4_prefix.npz).  crcs[cap] may be NULL. */
 int vft_nj_last_join_crcs(int64_t *chunk, int64_t *n_joins, uint32_t *crcs, int64_t cap, int64_t *n_crcs);
+
+/* Where the wall-clock of the last vft_nj_newick / vft_nj_ml_newick of this process went.  seconds[8]: the NJ phase with its root;
+   the minimum-evolution NNI + SPR rounds, of which the SPR rounds; ME branch lengths + local supports; the whole ML stage, of which
+   the ML NNI rounds, the SH-like supports, the model fits (CAT rates, GTR).  counts[4]: lockstep steps of the subtree schedule
+   (opt.threads > 1) and the quartets / splits judged in them, SPR chain steps evaluated, SPR moves made.  Either may be NULL. */
+int vft_nj_last_stage_seconds(double *seconds, int64_t *counts);
 
 /* The first n values of the random stream the bootstrap columns are drawn from (Knuth's ran_array at its default
    seed, as the reference uses it, Knuth.cpp:95-111): exported so that tests can pin the host generator. */

@@ -90,15 +90,11 @@ def test_nj_runs_are_reproducible():
     codes = synth.random_descent_codes(20000, 200, 4, 0.03, 0.01, seed=3)
     codes = codes[np.sort(np.unique(codes, axis=0, return_index=True)[1])]
     runs = []
+    from veryfasttree_amd.backend import DEBUG_HOST_JOINS
     for rep in range(6):
-        if rep == 5:
-            os.environ["VFT_NJ_HOST_JOINS"] = "1"
-        try:
-            ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
-            runs.append(nj_run(ops, codes))
-            ops.close()
-        finally:
-            os.environ.pop("VFT_NJ_HOST_JOINS", None)
+        ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+        runs.append(nj_run(ops, codes, debug_flags=DEBUG_HOST_JOINS if rep == 5 else 0))
+        ops.close()
     for rep in range(1, 6):
         assert np.array_equal(runs[0][0], runs[rep][0]) and np.array_equal(runs[0][1], runs[rep][1]), rep
     # the join-order checksums a tree-only caller can ask for afterwards (vft_nj_last_join_crcs): zlib's CRC-32 per 10 000 joins

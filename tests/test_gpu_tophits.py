@@ -171,13 +171,12 @@ def test_join_engine_equals_the_host_driven_loop(fastest, wide, monkeypatch):
     codes = synth.random_descent_codes(6000, 150, 4, 0.04, 0.02, seed=77)
     codes = codes[np.sort(np.unique(codes, axis=0, return_index=True)[1])]
     runs = []
+    from veryfasttree_amd.backend import DEBUG_HOST_JOINS
     for host in (False, True):
-        if host:
-            monkeypatch.setenv("VFT_NJ_HOST_JOINS", "1")
         ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
         if wide and not host:
             ops.debug_option(7, 1)
-        runs.append(nj_run(ops, codes, fastest=fastest, second_level=False))
+        runs.append(nj_run(ops, codes, fastest=fastest, second_level=False, debug_flags=DEBUG_HOST_JOINS if host else 0))
         ops.close()
     assert np.array_equal(runs[0][0], runs[1][0])
     assert np.array_equal(runs[0][1], runs[1][1])

@@ -16,6 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("VFT_LIB_DIR") or os.path.join(HERE, "lib")
 LIB_PATH = os.environ.get("VFT_HIP_LIB") or os.path.join(LIB_DIR, "libvft_hip.so")
 NOCODE = 127
+# vft_nj_options.debug_flags (include/vft_host.h): tests and tools choose between equivalent loops explicitly
+DEBUG_HOST_JOINS, DEBUG_HOST_LISTS, DEBUG_HOST_RESET, DEBUG_HOST_SPR, DEBUG_LEVEL_LENGTHS = 1, 2, 4, 8, 16
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -27,7 +29,7 @@ EXPORTS = [
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
+    "vft_sweep_batch", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_spr_round", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms",
     "vft_debug_log", "vft_debug_option", "vft_tophits_create", "vft_tophits_upload", "vft_tophits_download", "vft_tophits_best", "vft_tophits_join", "vft_tophits_refresh", "vft_nj_engine_create", "vft_nj_engine_set_state", "vft_nj_engine_get_state", "vft_nj_engine_visible_set", "vft_nj_engine_visible_get", "vft_nj_engine_nodes_set", "vft_nj_engine_topvisible_set", "vft_nj_engine_topvisible_get", "vft_nj_engine_reset_candidates", "vft_nj_engine_enqueue", "vft_nj_engine_poll", "vft_nj_engine_resume", "vft_nj_engine_log", "vft_nj_engine_adopt", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
 ]
@@ -46,7 +48,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
                 "vft_aa_model_tables", "vft_blosum45_tables", "vft_aa_model_as_distance_tables"]
 
 
@@ -54,7 +56,7 @@ class _NJOptions(C.Structure):
     _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
                 ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
-                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P), ("threads", I32), ("reserved", I32)]
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P), ("threads", I32), ("debug_flags", I32)]
 
 
 _lib = None
@@ -134,7 +136,7 @@ class TorchComm:
 
 
 def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False, aa_model=None,
-           tophits_mult=1.0, comm=None):
+           tophits_mult=1.0, comm=None, debug_flags=0):
     """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n]).
     second_level defaults to `fastest`, as in the reference at one thread (-fastest turns -2nd on)."""
     lib = load_host_library()
@@ -145,7 +147,7 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, float(tophits_mult), -1.0,
                      tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0, AA_MODELS[aa_model],
-                     comm.pointer() if comm is not None else None, 1, 0)
+                     comm.pointer() if comm is not None else None, 1, int(debug_flags))
     joins = np.zeros((max(n - 3, 1), 3), np.int64)
     crit = np.zeros(max(n - 3, 1), np.float64)
     nj = I64(0)
@@ -238,7 +240,7 @@ def uniquify(codes):
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
               unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False,
-              aa_model=None, comm=None, threads=1):
+              aa_model=None, comm=None, threads=1, debug_flags=0):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -256,7 +258,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0,
-                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None, int(threads), 0)
+                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None, int(threads), int(debug_flags))
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)
@@ -281,6 +283,20 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
     if return_loglk:
         return out.value.decode(), loglk[:n_rounds.value]
     return out.value.decode()
+
+
+STAGES = ("nj", "me_nni_spr", "of_which_spr", "me_lengths_supports", "ml_stage", "of_which_ml_nni", "of_which_sh_supports", "of_which_model_fits")
+
+
+def last_stage_seconds():
+    """dict: wall-clock per stage of the last nj_newick of this process + the lane / SPR counters (vft_nj_last_stage_seconds)"""
+    lib = load_host_library()
+    sec = np.zeros(8, np.float64)
+    cnt = np.zeros(4, np.int64)
+    lib.vft_nj_last_stage_seconds(_ptr(sec), _ptr(cnt))
+    out = {k: round(float(v), 2) for k, v in zip(STAGES, sec)}
+    out.update(lane_steps=int(cnt[0]), lane_work=int(cnt[1]), spr_steps=int(cnt[2]), spr_moves=int(cnt[3]))
+    return out
 
 
 def last_join_crcs():

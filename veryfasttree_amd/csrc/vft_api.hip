@@ -24,6 +24,7 @@ VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_profile.h"
 #include "vft_kernels_tophits.h"
 #include "vft_kernels_njengine.h"
+#include "vft_kernels_spr.h"
 
 struct vft_ctx {
     vft_config cfg;
@@ -1220,6 +1221,74 @@ extern "C" int vft_average_chains(vft_ctx *c, int32_t nChains, const int32_t *ch
     if (!c || !chainOff || !out || !a || !b) return VFT_ERR_INVALID;
     if (int r = chains_ok(c, nChains, chainOff, "vft_average_chains")) return r;
     return average_chains(c, nChains, chainOff, chainOff[nChains], out, a, b, "vft_average_chains");
+}
+
+// One round of SPR moves (NJ.tcc:6185-6404) as a persistent workgroup (k_spr_walk, vft_kernels_spr.h): the tree arrays go
+// to the device, wave 0 of the workgroup walks node_list, the arrays come back rearranged.  Waits for the kernel.
+extern "C" int vft_spr_round(vft_ctx *c, int64_t nNodes, int64_t *parent, int64_t *child, int64_t root, int64_t nList,
+                             const int64_t *nodeList, int32_t scoredist, int32_t maxLen, int64_t *out) {
+    if (!c || !parent || !child || !nodeList || !out || nNodes < 4 || nList < 0) return VFT_ERR_INVALID;
+    if (!c->rowMode) return fail(c, VFT_ERR_STATE, "vft_spr_round needs vft_set_profile_rows(ctx, 1)");
+    if (maxLen < 1 || maxLen > VFT_SPR_MAXLEN) return fail(c, VFT_ERR_INVALID, "vft_spr_round: chain length 1..%d", VFT_SPR_MAXLEN);
+    if (nNodes + c->d.nSeqs > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: the up-profiles need max_nodes >= n_nodes + n_seqs");
+    if (root < c->d.nSeqs || root >= nNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad root");
+    const size_t lds = (size_t) 12 * (size_t) c->d.nPosPad * sizeof(double);
+    if (lds + sizeof(SprCmd) + 256 > 160u * 1024u) return fail(c, VFT_ERR_INVALID, "vft_spr_round: alignment too long for the in-kernel walk");
+    if (int r = ensure_ml_rows(c)) return r;
+    const size_t N = (size_t) nNodes;
+    if (nNodes + c->d.nSeqs >= (1ll << 31)) return fail(c, VFT_ERR_INVALID, "vft_spr_round: too many nodes");
+    std::vector<SprNode> hn(N);
+    for (size_t v = 0; v < N; v++) {
+        for (int k = 0; k < 3; k++)
+            if (child[3 * v + k] >= nNodes || child[3 * v + k] < -1) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad child of node %zu", v);
+        if (parent[v] >= nNodes || parent[v] < -1) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad parent of node %zu", v);
+        hn[v].parent = (int32_t) parent[v];
+        hn[v].c0 = (int32_t) child[3 * v];
+        hn[v].c1 = (int32_t) child[3 * v + 1];
+        hn[v].c2 = (int32_t) child[3 * v + 2];
+    }
+    std::vector<int32_t> hl((size_t) nList);
+    for (int64_t t = 0; t < nList; t++) {
+        if (nodeList[t] < 0 || nodeList[t] >= nNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad node list");
+        hl[(size_t) t] = (int32_t) nodeList[t];
+    }
+    const size_t offList = N * sizeof(SprNode), offPath = offList + (((size_t) nList * 4 + 255) & ~(size_t) 255), offEpoch = offPath + ((N * 4 + 255) & ~(size_t) 255),
+                 offOut = offEpoch + ((N * 4 + 255) & ~(size_t) 255), total = offOut + 64;
+    if (int r = ensure_scratch(c, total + 512)) return r;
+    char *base = (char *) c->scratch;
+    HIPCHK(c, hipMemcpyAsync(base, hn.data(), N * sizeof(SprNode), hipMemcpyHostToDevice, c->stream));
+    if (nList) HIPCHK(c, hipMemcpyAsync(base + offList, hl.data(), (size_t) nList * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(base + offEpoch, 0, N * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(base + offOut, 0, 64, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are pageable)
+    SprState S;
+    S.nodes = (SprNode *) base;
+    S.nodeList = (const int32_t *) (base + offList);
+    S.path = (int32_t *) (base + offPath);
+    S.upEpoch = (uint32_t *) (base + offEpoch);
+    S.out = (int64_t *) (base + offOut);
+    S.nList = nList;
+    S.nNodes = nNodes;
+    S.root = root;
+    S.scoredist = scoredist;
+    S.maxLen = maxLen;
+    S.rowsById = c->allRows ? 1 : 0;
+    S.pad = 0;
+    S.tol = c->fpostTol;
+    // (set on every call: the attribute belongs to the function, and contexts with other alignment lengths share it)
+    VFT_DISPATCH(c, HIPCHK(c, hipFuncSetAttribute((const void *) (k_spr_walk<REAL, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)));
+    VFT_DISPATCH(c, launch((k_spr_walk<REAL, NC>), dim3(1), dim3(VFT_SPR_WG), lds, c->stream, arena<REAL>(c), S));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(hn.data(), base, N * sizeof(SprNode), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, base + offOut, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t v = 0; v < N; v++) {
+        parent[v] = hn[v].parent;
+        child[3 * v] = hn[v].c0;
+        child[3 * v + 1] = hn[v].c1;
+        child[3 * v + 2] = hn[v].c2;
+    }
+    return VFT_OK;
 }
 
 extern "C" int vft_join_fused(vft_ctx *c, int64_t i, int64_t j, int64_t newnode, double diameter, int64_t staleStamp,
@@ -2485,7 +2554,7 @@ static __global__ void k_copy_i32(int32_t *dst, const int32_t *src, int64_t n) {
     if (t < n) dst[t] = src[t];
 }
 
-extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg) {
+static int nj_engine_create_impl(vft_ctx *c, const vft_nj_engine_config *cfg) {
     if (!c || !cfg || cfg->m < 1 || cfg->n_top < 1) return VFT_ERR_INVALID;
     if (!c->thHits || cfg->m != c->thM) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: vft_tophits_create(m) first");
     if (c->njState) return fail(c, VFT_ERR_STATE, "vft_nj_engine_create: the engine exists already");
@@ -2540,6 +2609,7 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
     HIPCHK(c, hipMemsetAsync(c->njCandR, 0, (size_t) 5 * c->njCapPad * rs, c->stream));
     HIPCHK(c, hipHostMalloc((void **) &c->njLogHost, joins * sizeof(NjJoinRec), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void **) &c->njLogHostDev, c->njLogHost, 0));
+    memset(c->njLogHost, 0xFF, joins * sizeof(NjJoinRec));   // an unwritten record fails vft_nj_engine_adopt's check (newnode = -1)
     HIPCHK(c, hipHostMalloc((void **) &c->njStatusHost, 64, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void **) &c->njStatusDev, c->njStatusHost, 0));
     memset(c->njStatusHost, 0, 64);
@@ -2560,6 +2630,31 @@ extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg)
         }
     });
     return VFT_OK;
+}
+
+// every buffer of the engine, released: after a failed creation the context must not look as if it had one
+static void nj_engine_free(vft_ctx *c) {
+    void **dev[] = {&c->njState, &c->njVisD, (void **) &c->njVisJ, (void **) &c->njTop, (void **) &c->njAge, (void **) &c->njLogDev, (void **) &c->njClaim,
+                    (void **) &c->njLogNode, (void **) &c->njLogStamp, &c->njLogOut, (void **) &c->njSlotI, &c->njSlotR, (void **) &c->njCandI, &c->njCandR};
+    for (void **p: dev)
+        if (*p) {
+            hipFree(*p);
+            *p = nullptr;
+        }
+    if (c->njLogHost) hipHostFree(c->njLogHost);
+    if (c->njStatusHost) hipHostFree(c->njStatusHost);
+    c->njLogHost = c->njLogHostDev = nullptr;
+    c->njStatusHost = c->njStatusDev = nullptr;
+}
+
+extern "C" int vft_nj_engine_create(vft_ctx *c, const vft_nj_engine_config *cfg) {
+    const bool had = c && c->njState;   // ("the engine exists already" must leave that engine alone)
+    const int r = nj_engine_create_impl(c, cfg);
+    if (r != VFT_OK && c && !had && c->njState) {
+        hipStreamSynchronize(c->stream);
+        nj_engine_free(c);
+    }
+    return r;
 }
 
 #define NJ_ENGINE_OK(c) do { if (!(c)) return VFT_ERR_INVALID; if (!(c)->njState) return fail((c), VFT_ERR_STATE, "no join engine (vft_nj_engine_create)"); } while (0)
@@ -2730,7 +2825,7 @@ static int nj_enqueue(vft_ctx *c, int64_t joinIndex, int32_t phases, int32_t upd
         if ((c->pend.empty() || c->pend.back() != newnode) && (int64_t) c->pend.size() == VFT_PEND_MAX) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if ((((unsigned long long) __atomic_load_n(&c->njStatusHost[0], __ATOMIC_ACQUIRE) >> 31) & 7ull) != 0)
-                return fail(c, VFT_ERR_STATE, "vft_nj_engine_enqueue: the engine has halted (handle the event first)");
+                return fail(c, VFT_ERR_HALTED, "vft_nj_engine_enqueue: the engine has halted (handle the event first)");
             if (int r = flush_pending(c)) return r;
             E = njengine<REAL>(c);
         }

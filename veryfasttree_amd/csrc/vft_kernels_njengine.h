@@ -1422,6 +1422,11 @@ __global__ __launch_bounds__(VFT_WG_PROF) void k_nj_glue_join(Arena<REAL> A, NjE
         r.diameter = (double) diam;
         E.logDev[joinIndex] = r;
         E.logHost[joinIndex] = r;
+        // The host reads this record as soon as it sees the join counted in the status word, which a LATER kernel of the stream
+        // publishes with a plain store: the record must have left the chip before this kernel ends.  One system-scope fence on
+        // the record (thread 0 of the one workgroup), not on the status word of every scan.
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (updateOut) {   // (a full out-profile follows otherwise, and the host sets totdiam from the diameters)
             const REAL dd = diam - diaI - diaJ;
             totdiamNew = totdiam0 + (double) dd;

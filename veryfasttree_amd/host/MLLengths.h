@@ -13,6 +13,8 @@
 #define VFT_ML_LENGTHS_H
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -743,6 +745,21 @@ namespace veryfasttree {
                 bool up;
                 while ((node = nextPostorder(node, traversal, &up, root, /*reportUp*/false)) >= 0) nodeList.push_back(node);
             }
+            /* the walk itself runs on the device (k_spr_walk, csrc/vft_kernels_spr.h: the statements below, wave 0 of one
+               persistent workgroup executing them, no host round trip per step) whenever the alignment fits its staging;
+               the host walk that follows is the same algorithm for longer alignments and chains */
+            if (sprOnDevice && maxSPRLength <= 16 && (size_t) sprPosPad * 96 + 2048 <= 160u * 1024u) {
+                flushAverages();
+                int64_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                chk(vft_spr_round(ctx, nNodes, parent.data(), child.data(), root, (int64_t) nodeList.size(), nodeList.data(), scoredist ? 1 : 0,
+                                  maxSPRLength, out));
+                sprSteps += out[1];
+                if (std::getenv("VFT_SPR_REPORT"))   /* tools: where the kernel's time goes */
+                    fprintf(stderr, "SPR round on the device: %lld moves, %lld steps, %lld averages; %.3f s in all, %.3f s in average commands, %.3f s in distance commands\n",
+                            (long long) out[0], (long long) out[1], (long long) out[2], 1e-8 * (double) out[6], 1e-8 * (double) out[4], 1e-8 * (double) out[5]);
+                rebuildOrder();
+                return out[0];
+            }
             struct Step {
                 int64_t nodes[2];
                 double deltaLength;
@@ -1048,6 +1065,10 @@ namespace veryfasttree {
         int64_t laneSteps = 0, laneWork = 0;   /* lockstep steps / quartets or splits evaluated in them (all rounds so far) */
 
         int64_t nStarTests = 0;
+        bool sprOnDevice = true;    /* false: the host-driven SPR walk (tests compare the two) */
+        int64_t sprPosPad = 1 << 30;   /* the context's padded column count (setSprPosPad); unknown: host walk */
+        int64_t sprSteps = 0;
+        void setSprPosPad(int64_t nPos) { sprPosPad = (nPos + 15) / 16 * 16; }
 
         const std::vector<int64_t> &children() const { return child; }
         const std::vector<int64_t> &parents() const { return parent; }

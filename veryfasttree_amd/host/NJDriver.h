@@ -61,6 +61,8 @@ namespace veryfasttree {
         int aaModel = 0;
         /* multi-GPU (include/vft_host.h, vft_comm): sweeps and leaf blocks are split over the ranks */
         const vft_comm *comm = nullptr;
+        /* the SPR rounds as one persistent kernel per round (vft_spr_round); false = the host-driven walk (tools) */
+        bool deviceSPR = true;
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
         /* top-hit lists on the device (vft_tophits_*): the list walks of a join are one launch each; false = the host walks
@@ -69,6 +71,13 @@ namespace veryfasttree {
         /* the join loop itself on the device (vft_nj_engine_*): the host enqueues the kernels of many joins ahead, reads the
            join records from a log and handles top-visible resets and top-hits refreshes; needs deviceLists, first-level lists */
         bool deviceJoins = true;
+        /* resetTopVisible through the engine's kernels; false = entirely on the host (tools) */
+        bool deviceReset = true;
+        /* joins the engine is asked to run ahead of the host */
+        int engineWindow = 16;
+        /* measurements only: ML length rounds as one batch per tree height (MLLengths::optimizeRoundParallel) - not the
+           reference's order in any of its modes */
+        bool parallelLengths = false;
     };
 
     template<typename REAL>
@@ -141,7 +150,7 @@ namespace veryfasttree {
                 initTopHits(m);
                 setAllLeafTopHits();
                 resetTopVisible(nSeqs);
-                if (devLists && !hostLists && opt.deviceJoins && std::getenv("VFT_NJ_HOST_JOINS") == nullptr && runEngine(maxJoins)) return joins;
+                if (devLists && !hostLists && opt.deviceJoins && runEngine(maxJoins)) return joins;
             }
             int64_t nActiveReset = nSeqs;
             for (int64_t nActive = nSeqs; nActive > 3; nActive--) {
@@ -308,7 +317,7 @@ namespace veryfasttree {
             chkT("vft_nj_engine_set_state", [&]() { return vft_nj_engine_set_state(ctx, nSeqs, nSeqs, totdiam, 0); });
             engineUploadTopVisible();
             const int64_t nTotal = maxJoins >= 0 ? std::min(maxJoins, nSeqs - 3) : nSeqs - 3;   /* (a truncated run: tests) */
-            const int64_t window = std::getenv("VFT_NJ_ENGINE_WINDOW") ? std::max(1, atoi(std::getenv("VFT_NJ_ENGINE_WINDOW"))) : 16;   /* (debugging) */
+            const int64_t window = std::max(1, opt.engineWindow);
             int64_t enq = 0, nActiveReset = nSeqs;
             bool climbPending = false, needSearch = true;   /* needSearch: the search of join `enq` has not been enqueued behind the previous merge */
             auto isFullOut = [&](int64_t k) {
@@ -435,7 +444,7 @@ namespace veryfasttree {
                 int rc;
                 if (!isFullOut(enq)) {
                     rc = vft_nj_engine_enqueue(ctx, enq, first | VFT_NJ_PHASE_JOIN | VFT_NJ_PHASE_MERGE | next, 1);
-                    if (rc == VFT_ERR_STATE) continue;   /* halted meanwhile: the next poll sees it */
+                    if (rc == VFT_ERR_HALTED) continue;   /* halted meanwhile: the next poll sees it (any other error is thrown) */
                     chk(rc);
                     climbPending = false;
                     needSearch = next == 0;
@@ -445,7 +454,7 @@ namespace veryfasttree {
                 /* a join after which the out-profile is recomputed from scratch (NJ.tcc:3012-3033): the merge needs the new
                    out-profile and totdiam, so the host waits for the join in between */
                 rc = vft_nj_engine_enqueue(ctx, enq, first | VFT_NJ_PHASE_JOIN, 0);
-                if (rc == VFT_ERR_STATE) continue;
+                if (rc == VFT_ERR_HALTED) continue;
                 chk(rc);
                 climbPending = false;
                 needSearch = false;   /* (of THIS join: a halt below sets it again) */
@@ -711,6 +720,8 @@ namespace veryfasttree {
             std::vector<int64_t> par, ch;
             treeArrays(par, ch);
             MLLengths<REAL> tree(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
+            tree.setSprPosPad(nPos);
+            tree.sprOnDevice = opt.deviceSPR;
             typename MLLengths<REAL>::NNIParams prm;
             prm.useML = false;
             prm.scoredist = opt.scoredist;
@@ -720,6 +731,7 @@ namespace veryfasttree {
             int64_t total = 0, sprRemaining = spr;
             meNNIRoundsDone = 0;
             meSPRs = 0;
+            meSPRSeconds = 0;
             bool bConverged = false;
             for (int64_t i = 0; i < nniToDo; i++) {
                 if (!bConverged) {
@@ -731,7 +743,11 @@ namespace veryfasttree {
                 }
                 /* SPR rounds sit between thirds of the NNI rounds (VeryFastTreeImpl.tcc:187-198) */
                 if (sprRemaining > 0 && nniToDo / (spr + 1) > 0 && ((i + 1) % (nniToDo / (spr + 1))) == 0) {
-                    meSPRs += tree.doSPR(opt.scoredist);
+                    {
+                        const std::chrono::steady_clock::time_point ts = std::chrono::steady_clock::now();
+                        meSPRs += tree.doSPR(opt.scoredist);
+                        meSPRSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+                    }
                     sprRemaining--;
                     bConverged = false;
                     tree.initNNIStats(stats);
@@ -739,14 +755,18 @@ namespace veryfasttree {
                 if (bConverged && sprRemaining == 0) break;
             }
             while (sprRemaining > 0) {
+                const std::chrono::steady_clock::time_point ts = std::chrono::steady_clock::now();
                 meSPRs += tree.doSPR(opt.scoredist);
+                meSPRSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
                 sprRemaining--;
             }
+            meSPRSteps = tree.sprSteps;
             adoptTree(tree.parents(), tree.children());
             return total;
         }
 
-        int64_t meSPRs = 0;
+        int64_t meSPRs = 0, meSPRSteps = 0;
+        double meSPRSeconds = 0, mlNNISeconds = 0, mlSupportSeconds = 0, mlModelSeconds = 0;   /* stage timers (vft_nj_last_stage_seconds) */
         int64_t meNNIRoundsDone = 0;
 
         /* `-mllen -nocat` under Jukes-Cantor (VeryFastTreeImpl.tcc:249-311): rounds of optimizeAllBranchLengths +
@@ -776,6 +796,7 @@ namespace veryfasttree {
             } else {
                 chkT("vft_set_transition_matrix", [&]() { return vft_set_transition_matrix(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); });
             }
+            mlNNISeconds = mlSupportSeconds = mlModelSeconds = 0;
             MLLengths<REAL> ml(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             upReady = false;   /* the up-profile slots now hold ML up-profiles */
             ml.setLengths(branchlength.data());
@@ -788,14 +809,13 @@ namespace veryfasttree {
                 ml.recomputeAverageProfiles();
             } else if (reaverage) ml.recomputeAverageProfiles();
             std::vector<double> loglk;
-            const char *pl = std::getenv("VFT_ML_PARALLEL_LENGTHS");
-            const bool parallelLengths = pl && pl[0] == '1';
+            const bool parallelLengths = opt.parallelLengths;
             const int64_t maxRound = mllen ? (int64_t) (0.5 + std::log((double) nSeqs) / std::log(2.0)) : 0;
             std::vector<REAL> old((size_t) maxnode);
             bool ratesSet = false;
             for (int64_t iRound = 1; iRound <= maxRound; iRound++) {
                 for (int64_t v = 0; v < maxnode; v++) old[(size_t) v] = branchlength[(size_t) v];
-                /* VFT_ML_PARALLEL_LENGTHS=1 (measurements only): the level-parallel rounds of MLLengths.h, which do not
+                /* opt.parallelLengths (measurements only): the level-parallel rounds of MLLengths.h, which do not
                    follow the one-thread order of the reference */
                 if (parallelLengths) ml.optimizeRoundParallel(ftol, atol);
                 else if (opt.threads > 1) ml.optimizeRoundThreaded(ftol, atol, opt.threads);
@@ -832,7 +852,11 @@ namespace veryfasttree {
                 mlNNIs = 0;
                 for (int64_t iMLnni = 0; iMLnni < MLnniToDo; iMLnni++) {
                     double maxDelta;
-                    mlNNIs += opt.threads > 1 ? ml.doNNIThreaded(prm, stats, maxDelta, opt.threads) : ml.doNNI(prm, stats, maxDelta);
+                    {
+                        const std::chrono::steady_clock::time_point ts = std::chrono::steady_clock::now();
+                        mlNNIs += opt.threads > 1 ? ml.doNNIThreaded(prm, stats, maxDelta, opt.threads) : ml.doNNI(prm, stats, maxDelta);
+                        mlNNISeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+                    }
                     const double ll = ml.treeLogLk(nPos, nLeafGaps);
                     loglk.push_back(ll);
                     const bool bConvergedHere = iMLnni > 0 && (ll < lastloglk + 0.1 || maxDelta < 0.1);
@@ -841,9 +865,11 @@ namespace veryfasttree {
                     if (bConverged || iMLnni == MLnniToDo - 2) ml.initNNIStats(stats);
                     lastloglk = ll;
                     if (iMLnni == 0 && !ratesSet) {
+                        const std::chrono::steady_clock::time_point ts = std::chrono::steady_clock::now();
                         if (gtr && !gtrFitted) fitGtr(ml, nLeafGaps, ftol, atol);
                         ml.setMLRates(nRateCats, nPos, mlRates, mlRateCat);
                         ratesSet = nRateCats > 1;
+                        mlModelSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
                     }
                 }
                 if (opt.threads > 1) ml.optimizeRoundThreaded(ftol, atol, opt.threads);
@@ -864,7 +890,9 @@ namespace veryfasttree {
                     else if (pos == nPos) pos = nPos - 1;
                     col[t] = (int32_t) pos;
                 }
+                const std::chrono::steady_clock::time_point ts = std::chrono::steady_clock::now();
                 const typename MLLengths<REAL>::SplitTests st = ml.testSplits(ftol, atol, nBootstrap, col.data());
+                mlSupportSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
                 support = st.support;
                 mlBadSplits = st.nBadSplits;
                 mlSplits = st.nSplits;
@@ -1329,7 +1357,7 @@ namespace veryfasttree {
             devLists = false;
             /* (second-level lists keep the host walks of round 2: their transfers and the 2nd -> 1st level switch are host code,
                 and the device walks only pay off when the host holds no lists at all; VFT_NJ_HOST_LISTS: tools) */
-            if (opt.deviceLists && q == 0 && std::getenv("VFT_NJ_HOST_LISTS") == nullptr)
+            if (opt.deviceLists && q == 0)
                 devLists = vft_tophits_create(ctx, (int32_t) m, maxnodes) == VFT_OK;
             hostLists = !devLists || q > 0 || checkJoins;
             if (devLists) listLen.assign((size_t) maxnodes, 0);
@@ -1689,7 +1717,7 @@ namespace veryfasttree {
 
         void resetTopVisible(int64_t nActive) { /* NJ.tcc:4728-4784 */
             if (engineActive) {
-                if (std::getenv("VFT_NJ_HOST_RESET") == nullptr && resetTopVisibleEngine(nActive)) return;   /* (debugging knob) */
+                if (opt.deviceReset && resetTopVisibleEngine(nActive)) return;
                 engineDownloadVisible();
             }
             Section sec(this, "[host] resetTopVisible (incl. device)");

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -63,6 +64,18 @@ extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *
     return VFT_OK;
 }
 
+/* wall-clock of the stages of the last vft_nj_newick / vft_nj_ml_newick of this process (vft_nj_last_stage_seconds) */
+static double gStage[8];
+static int64_t gLanes[4];
+
+extern "C" int vft_nj_last_stage_seconds(double *seconds, int64_t *counts) {
+    if (seconds)
+        for (int i = 0; i < 8; i++) seconds[i] = gStage[i];
+    if (counts)
+        for (int i = 0; i < 4; i++) counts[i] = gLanes[i];
+    return VFT_OK;
+}
+
 static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
     veryfasttree::NJOptions opt;
     if (o) {
@@ -82,6 +95,11 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.aaModel = o->aa_model;
         opt.comm = o->comm;
         opt.threads = o->threads > 1 ? o->threads : 1;
+        if (o->debug_flags & VFT_NJ_DEBUG_HOST_JOINS) opt.deviceJoins = false;
+        if (o->debug_flags & VFT_NJ_DEBUG_HOST_LISTS) opt.deviceLists = false;
+        if (o->debug_flags & VFT_NJ_DEBUG_HOST_RESET) opt.deviceReset = false;
+        if (o->debug_flags & VFT_NJ_DEBUG_HOST_SPR) opt.deviceSPR = false;
+        if (o->debug_flags & VFT_NJ_DEBUG_LEVEL_LENGTHS) opt.parallelLengths = true;
     }
     return opt;
 }
@@ -92,12 +110,23 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
                            int64_t nAll, const char *names, std::vector<double> &loglk, std::vector<double> &rates,
                            std::vector<int64_t> &ratecat, double *gtrOut) {
     veryfasttree::NJDriver<REAL> drv(ctx, codes, nSeqs, nPos, toOptions(o));
+    for (double &x: gStage) x = 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+    std::chrono::steady_clock::time_point t0 = now();
     recordJoinCrc(drv.run(-1));
     drv.finishRoot();
+    gStage[0] = since(t0);
+    t0 = now();
     if (o && o->me_nni) drv.meNNIRounds(o->spr);
+    gStage[1] = since(t0);
+    gStage[2] = drv.meSPRSeconds;
+    t0 = now();
     if (meLengths) drv.updateBranchLengths();
     const bool ml = o && (o->mllen || o->ml_nni);
     if (nBootstrap > 0 && !ml) drv.computeSupports(nBootstrap);
+    gStage[3] = since(t0);
+    t0 = now();
     if (ml) {
         if (!meLengths) throw std::invalid_argument("vft_nj_ml_newick: the ML stage needs me_lengths (updateBranchLengths runs first)");
         /* with supports: SH-like (testSplitsML) instead of the local bootstrap */
@@ -110,6 +139,14 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
         rates.assign(drv.mlRates.begin(), drv.mlRates.end());
         ratecat = drv.mlRateCat;
     }
+    gStage[4] = since(t0);
+    gStage[5] = drv.mlNNISeconds;
+    gStage[6] = drv.mlSupportSeconds;
+    gStage[7] = drv.mlModelSeconds;
+    gLanes[0] = drv.mlLaneSteps;
+    gLanes[1] = drv.mlLaneWork;
+    gLanes[2] = drv.meSPRSteps;
+    gLanes[3] = drv.meSPRs;
     drv.report();
     std::vector<std::string> nm;
     const char *p = names;
