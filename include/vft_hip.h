@@ -345,9 +345,9 @@ int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off,
    place; chains of up to max_len (<= 16; the reference's default is 10) forced minimum-evolution NNIs per node, criteria =
    log-corrected profile distances (scoredist: NJ.tcc:322-330).  Profiles and up-profiles (slot node + n_seqs) are kept
    current exactly as the host walk keeps them (recomputeProfile after every step, all ancestors after an accepted move).
-   Needs vft_set_profile_rows(ctx, 1) and max_nodes >= n_nodes + n_seqs; alignments up to ~1 700 columns (the six distances
-   of a step are staged in LDS).  out[8]: accepted moves, chain steps evaluated, averages computed, cache epochs, device clock
-   ticks (100 MHz) inside average commands / distance commands / in total, 0.  Waits. */
+   Needs vft_set_profile_rows(ctx, 1) and max_nodes >= n_nodes + n_seqs; alignments up to ~1 300 columns (the six distances
+   of a step are staged in LDS).  out[16]: accepted moves, chain steps evaluated, averages computed, cache epochs, device clock
+   ticks (100 MHz) inside commands / in total, commands issued, thread 0's ticks in the four phases of a command, 0...  Waits. */
 int vft_spr_round(vft_ctx *ctx, int64_t n_nodes, int64_t *parent, int64_t *child, int64_t root, int64_t n_list,
                   const int64_t *node_list, int32_t scoredist, int32_t max_len, int64_t *out);
 

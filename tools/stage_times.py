@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64]"""
+"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [devspr]
+(devspr: the SPR rounds as persistent kernels, vft_nj_options.debug_flags bit 8; VFT_SPR_REPORT=1 prints their tick counters)"""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +14,7 @@ T = max([int(a) for a in rest if a.isdigit()] or [1])
 dt = np.float64 if "f64" in rest else np.float32
 codes = synth.random_descent_codes(n, L, 20 if aa else 4, 0.03, 0.01, seed=2)
 names = ["s%d" % k for k in range(n)]
-kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, threads=T, return_loglk=True)
+kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, threads=T, return_loglk=True, debug_flags=8 if "devspr" in rest else 0)
 if aa:
     kw["aa_model"] = "lg" if "lg" in rest else "jtt"
 elif "gtr" in rest:

@@ -17,7 +17,7 @@ LIB_DIR = os.environ.get("VFT_LIB_DIR") or os.path.join(HERE, "lib")
 LIB_PATH = os.environ.get("VFT_HIP_LIB") or os.path.join(LIB_DIR, "libvft_hip.so")
 NOCODE = 127
 # vft_nj_options.debug_flags (include/vft_host.h): tests and tools choose between equivalent loops explicitly
-DEBUG_HOST_JOINS, DEBUG_HOST_LISTS, DEBUG_HOST_RESET, DEBUG_HOST_SPR, DEBUG_LEVEL_LENGTHS = 1, 2, 4, 8, 16
+DEBUG_HOST_JOINS, DEBUG_HOST_LISTS, DEBUG_HOST_RESET, DEBUG_DEVICE_SPR, DEBUG_LEVEL_LENGTHS = 1, 2, 4, 8, 16
 
 P = C.c_void_p
 I64 = C.c_int64

@@ -1233,8 +1233,10 @@ extern "C" int vft_spr_round(vft_ctx *c, int64_t nNodes, int64_t *parent, int64_
     if (nNodes + c->d.nSeqs > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: the up-profiles need max_nodes >= n_nodes + n_seqs");
     if (root < c->d.nSeqs || root >= nNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad root");
     const size_t lds = (size_t) 12 * (size_t) c->d.nPosPad * sizeof(double);
-    if (lds + sizeof(SprCmd) + 256 > 160u * 1024u) return fail(c, VFT_ERR_INVALID, "vft_spr_round: alignment too long for the in-kernel walk");
+    if (lds + sizeof(SprCmd) + sizeof(SprState) + 512 + (size_t) VFT_SPR_NCACHE * 28 + 1024 > 160u * 1024u)
+        return fail(c, VFT_ERR_INVALID, "vft_spr_round: alignment too long for the in-kernel walk");
     if (int r = ensure_ml_rows(c)) return r;
+    if (!c->allRows) return fail(c, VFT_ERR_STATE, "vft_spr_round: some internal profile has no row (written through the tile streams since vft_set_profile_rows)");
     const size_t N = (size_t) nNodes;
     if (nNodes + c->d.nSeqs >= (1ll << 31)) return fail(c, VFT_ERR_INVALID, "vft_spr_round: too many nodes");
     std::vector<SprNode> hn(N);
@@ -1253,13 +1255,13 @@ extern "C" int vft_spr_round(vft_ctx *c, int64_t nNodes, int64_t *parent, int64_
         hl[(size_t) t] = (int32_t) nodeList[t];
     }
     const size_t offList = N * sizeof(SprNode), offPath = offList + (((size_t) nList * 4 + 255) & ~(size_t) 255), offEpoch = offPath + ((N * 4 + 255) & ~(size_t) 255),
-                 offOut = offEpoch + ((N * 4 + 255) & ~(size_t) 255), total = offOut + 64;
+                 offOut = offEpoch + ((N * 4 + 255) & ~(size_t) 255), total = offOut + 128;
     if (int r = ensure_scratch(c, total + 512)) return r;
     char *base = (char *) c->scratch;
     HIPCHK(c, hipMemcpyAsync(base, hn.data(), N * sizeof(SprNode), hipMemcpyHostToDevice, c->stream));
     if (nList) HIPCHK(c, hipMemcpyAsync(base + offList, hl.data(), (size_t) nList * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(base + offEpoch, 0, N * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(base + offOut, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(base + offOut, 0, 128, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are pageable)
     SprState S;
     S.nodes = (SprNode *) base;
@@ -1280,7 +1282,7 @@ extern "C" int vft_spr_round(vft_ctx *c, int64_t nNodes, int64_t *parent, int64_
     VFT_DISPATCH(c, launch((k_spr_walk<REAL, NC>), dim3(1), dim3(VFT_SPR_WG), lds, c->stream, arena<REAL>(c), S));
     LAUNCHCHK(c);
     HIPCHK(c, hipMemcpyAsync(hn.data(), base, N * sizeof(SprNode), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, base + offOut, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, base + offOut, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (size_t v = 0; v < N; v++) {
         parent[v] = hn[v].parent;

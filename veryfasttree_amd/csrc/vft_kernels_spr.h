@@ -7,7 +7,8 @@
 // walk (MLLengths::doSPR) was one host<->device round trip per step: ~47 us each, 300 000 steps for two rounds on 10 000 taxa,
 // three quarters of the whole pipeline once the NNI rounds ran as lanes.  Here the tree (parent / child arrays, the up-profile
 // cache flags) lives in device memory and wave 0 of the workgroup IS the walk: it runs the reference's control flow, and hands the
-// column work to the whole workgroup as commands through LDS -
+// column work to the whole workgroup as commands through LDS (one command = the averages queued since the last one + the six
+// distances of the quartet they lead up to) -
 //     AVERAGES  a chain of unweighted averageProfile calls (recomputeProfile, up-profiles): column-parallel, a thread takes its
 //               columns through the whole chain (as k_average_chain);
 //     DISTANCES the six profile distances of a quartet: every thread forms the addends of its columns for all six pairs, twelve
@@ -19,8 +20,10 @@
 #define VFT_KERNELS_SPR_H
 
 #define VFT_SPR_WG 512            // 8 wavefronts: wave 0 walks, all of them work on the commands
-#define VFT_SPR_CHAIN 48          // averages queued per command
+#define VFT_SPR_CHAIN 16          // averages per command
 #define VFT_SPR_MAXLEN 16         // chain length the kernel is built for (the reference's default maxSPRLength is 10)
+#define VFT_SPR_NCACHE 1024       // entries of wave 0's node-record and cache-flag caches in LDS (direct mapped)
+#define VFT_SPR_MISS 64           // missing up-profiles remembered per walk to the root
 
 struct SprNode {                  // one 16-byte load tells everything about a node
     int32_t parent, c0, c1, c2;   // -1 = none (c2: the root's third child)
@@ -35,158 +38,289 @@ struct SprState {
     int32_t scoredist, maxLen, rowsById, pad;
     double tol;
     int64_t *out;                 // [0] accepted moves, [1] chain steps evaluated, [2] average ops, [3] last epoch,
-                                  // [4] / [5] / [6] clock ticks (100 MHz) in average commands / distance commands / in all
+                                  // [4] / [5] clock ticks (100 MHz) inside commands / in all, [6] commands
 };
 
 struct SprCmd {
-    int32_t type, n;              // 0: stop, 1: averages (n ops), 2: distances
+    int32_t type;                 // 0: stop, 1: work
+    int32_t n;                    // averages, in order
+    int32_t hasDist, pad;
     int32_t out[VFT_SPR_CHAIN], a[VFT_SPR_CHAIN], b[VFT_SPR_CHAIN];
-    int32_t q[4];
+    // where an input comes from: 0 memory, untouched by this command (requested ahead of the chain); 1 the previous op's output
+    // (handed over in registers); 2 an earlier op's output (read back after that op's store - by the thread that stored it)
+    uint8_t ka[VFT_SPR_CHAIN], kb[VFT_SPR_CHAIN];
+    int32_t q[4];                 // A, B, C, D of the distances
+    uint8_t kq[4];                // 0: untouched by this command's averages, 2: written by them
     double dist[6];
     double sum[12];
     // wave 0's chain bookkeeping (LDS instead of scratch: the arrays are indexed at run time)
     int32_t stepA[VFT_SPR_MAXLEN], stepB[VFT_SPR_MAXLEN];
     double stepDelta[VFT_SPR_MAXLEN];
+    int32_t miss[VFT_SPR_MISS];
+    long long tick[6];            // thread 0's clock ticks per phase of a command (diagnostics): columns, barrier, sums, barrier, end
 };
 
-// One column of a node for the SPR walk.  byId: every internal id (>= nSeqs: nodes and up-profile slots) is a plain row - true
-// in the refinement phase once vft_set_profile_rows has copied the tree over - so neither the row flag nor the "is this a
-// vector?" test stands between the thread and its loads: weight, code and vector are requested together (one memory round
-// instead of three; the vector is simply ignored under a code).
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_spr_load(const Arena<REAL> &A, int64_t node, int64_t p, bool byId, Col<REAL, NC> &c) {
-    if (node >= A.d.nSeqs && (byId || (A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs]))) {
-        const int64_t idx = (node - A.d.nSeqs) * A.d.nPos + p;
-        const REAL *src = A.mlF + idx * NC;
-        REAL f[NC];
-#pragma unroll
-        for (int k = 0; k < NC; k++) f[k] = src[k];
-        c.w = A.mlW[idx];
-        c.code = (int) A.mlC[idx];
-        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
-#pragma unroll
-        for (int k = 0; k < NC; k++) c.f[k] = f[k];
-        return;
+// One column of a node for the SPR walk: a leaf's code or an internal id's plain row.  Every internal id (>= nSeqs: nodes and
+// up-profile slots) IS a row in the refinement phase once vft_set_profile_rows has copied the tree over (the host checks), so
+// neither the row flag nor the "is this a vector?" test stands between the thread and its loads: weight, code and vector are
+// requested together (one memory round instead of three; the vector is simply ignored under a code).  Deliberately small: the
+// generic loader with its tile-stream decoding, inlined at every use, made the command loop 47 KB of code - more than the
+// instruction cache two CUs share - and every command streamed it from L2 again.
+#define VFT_GLOBAL __attribute__((address_space(1)))
+#define VFT_LDS __attribute__((address_space(3)))
+// the four arrays a column comes from, as GLOBAL pointers: inside a real function the arena's pointers are plain (flat) pointers,
+// and a flat load counts on the LDS counter as well - every wait for an LDS read (the command's ids) then waits for all the
+// memory loads in flight before it
+typedef unsigned int vft_u32x4 __attribute__((ext_vector_type(4)));
+template <typename REAL>
+struct SprRows {
+    const VFT_GLOBAL vft_u32x4 *leafT;
+    __device__ __forceinline__ uint4 leaf(int64_t i) const {
+        const vft_u32x4 v = leafT[i];
+        return make_uint4(v.x, v.y, v.z, v.w);
     }
-    vft_load_col<REAL, NC>(A, node, p, c);
+    VFT_GLOBAL REAL *mlW, *mlF;
+    VFT_GLOBAL uint8_t *mlC;
+    VftDims d;
+};
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_spr_load(const SprRows<REAL> &R, int64_t node, int64_t p, Col<REAL, NC> &c) {
+    if (node >= R.d.nSeqs) {
+        const int64_t idx = (node - R.d.nSeqs) * R.d.nPos + p;
+        const VFT_GLOBAL REAL *src = R.mlF + idx * NC;
+#pragma unroll
+        for (int k = 0; k < NC; k++) c.f[k] = src[k];
+        c.w = R.mlW[idx];
+        c.code = (int) R.mlC[idx];
+        c.vec = c.w > 0 && c.code == VFT_NOCODE_;
+    } else {
+        const uint4 t = R.leaf(vft_leaf_idx(R.d, node >> 6, (int) (p >> 4), (int) (node & (VFT_TILE - 1))));
+        c.code = vft_decode<NC>(vft_byte(t, (int) (p & 15)));
+        c.w = c.code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
+        c.vec = false;
+    }
+}
+
+// vft_pair_addends (vft_kernels_nj.h) with the two staging arrays typed as LDS: the addends of one pair at one column
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_spr_addends(const Arena<REAL> &A, bool leaves, int64_t p, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2,
+                                                VFT_LDS double *sW, VFT_LDS double *sT) {
+    double wgt = 0.0, term = 0.0;
+    if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
+        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
+            wgt = 1.0;
+            term = A.dmDist ? (double) A.dmDist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
+        }
+    } else if (c1.w > 0 && c2.w > 0) {
+        const REAL ww = c1.w * c2.w;
+        wgt = (double) ww;
+        term = wgt * vft_piece<REAL, NC>(A, c1, c2, nullptr);
+    }
+    sW[p] = wgt;
+    sT[p] = term;
+}
+
+// the column-ordered sum of n doubles in LDS (n a multiple of 16; the tail beyond the alignment holds +0.0): the adds are one
+// dependent chain, so the reads of the next sixteen are in flight while the current sixteen are added
+__device__ __forceinline__ double vft_spr_chain_sum(const VFT_LDS double *src, int64_t n) {
+    double acc = 0, b0[16], b1[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) b0[u] = src[u];
+    int64_t p = 16;
+    for (; p + 16 <= n; p += 32) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) b1[u] = src[p + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += b0[u];
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 32 <= n) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) b0[u] = src[p + 16 + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += b1[u];
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 32 > n) return acc;   // (b0 was not refilled: everything is added)
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += b0[u];   // the last sixteen when n / 16 is odd (or n == 16)
+    return acc;
 }
 
 // the data half of a command, executed by every thread of the workgroup (one copy in the binary: the walk calls it from
-// many places)
+// several places)
+// Its arguments are LDS objects and say so in their types: handed over as plain pointers they become FLAT accesses - every
+// cmd.a[k] in front of a load, every addend parked for the sums, every double the twelve summing lanes read went through the
+// vector-memory path instead of a ds_read (the in-order sum of 1 000 doubles took 13-20 us instead of 3).
 template <typename REAL, int NC>
-__device__ __noinline__ void vft_spr_exec(const Arena<REAL> &A, const SprState &S, SprCmd &cmd, double *pwLds) {
-    const bool byId = S.rowsById != 0;
-    if (cmd.type == 1) {
-        const int n = cmd.n;
-        for (int64_t p = threadIdx.x; p < A.d.nPos; p += VFT_SPR_WG) {
-            int64_t prevOut = -1;
-            Col<REAL, NC> prev;
-            prev.w = 0;
-            prev.code = VFT_NOCODE_;
-            prev.vec = false;
+__device__ __noinline__ void vft_spr_exec(const VFT_LDS Arena<REAL> *Ap, const VFT_LDS SprState *Sp, VFT_LDS SprCmd *cmdp, VFT_LDS double *pwp) {
+    const Arena<REAL> A = *(const Arena<REAL> *) Ap;   // (fields in registers; the casts are resolved back to LDS reads)
+    const double tolS = ((const SprState *) Sp)->tol;
+    VFT_LDS double *pwLds = pwp;
+    SprRows<REAL> R;
+    R.leafT = (const VFT_GLOBAL vft_u32x4 *) A.leafT;
+    R.mlW = (VFT_GLOBAL REAL *) A.mlW;
+    R.mlF = (VFT_GLOBAL REAL *) A.mlF;
+    R.mlC = (VFT_GLOBAL uint8_t *) A.mlC;
+    R.d = A.d;
+    constexpr int PF = NC == 4 ? 2 : 1;   // ops whose memory inputs are requested together
+    const int n = cmdp->n;
+    const bool hasDist = cmdp->hasDist != 0;
+    const int64_t nPos = A.d.nPos, nPosPad = A.d.nPosPad;
+    int64_t id[4];
+    bool leaf[4];
 #pragma unroll
-            for (int q = 0; q < NC; q++) prev.f[q] = 0;
-            for (int k = 0; k < n; k++) {
-                const int64_t a = cmd.a[k], b = cmd.b[k], o = cmd.out[k];
-                Col<REAL, NC> c1, c2;
-                if (a == prevOut) c1 = prev;
-                else vft_spr_load<REAL, NC>(A, a, p, byId, c1);
-                if (b == prevOut) c2 = prev;
-                else vft_spr_load<REAL, NC>(A, b, p, byId, c2);
-                REAL wo, f[NC];
-                int co;
-                vft_average_col<REAL, NC>(A, c1, c2, 0.5, S.tol, wo, co, f);
-                {   // the row's vector slot is written whatever the column holds: the loads above never test before they read
-                    const int64_t idx = (o - A.d.nSeqs) * A.d.nPos + p;
-                    A.mlW[idx] = wo;
-                    A.mlC[idx] = (uint8_t) co;
-                    REAL *dst = A.mlF + idx * NC;
+    for (int x = 0; x < 4; x++) {
+        id[x] = hasDist ? cmdp->q[x] : 0;
+        leaf[x] = id[x] < A.d.nSeqs;
+    }
+    const bool counts = !A.dmDist && NC == 4;   // leaf pairs by integer counts (seqDist, any order)
+    long long tk0 = wall_clock64();
+    for (int64_t p = threadIdx.x; p < nPos; p += VFT_SPR_WG) {
+        // the quartet's columns that this command does not write: on their way before the averages start
+        // (4-state columns only: four 20-state columns next to the averages' operands do not fit the registers)
+        constexpr int NQ = NC == 4 ? 4 : 1;
+        Col<REAL, NC> cq[NQ];
+        if constexpr (NC == 4) {
+            if (hasDist) {
 #pragma unroll
-                    for (int q = 0; q < NC; q++) dst[q] = f[q];
-                }
-                prevOut = o;
-                prev.w = wo;
-                prev.code = co;
-                prev.vec = wo > 0 && co == VFT_NOCODE_;
-#pragma unroll
-                for (int q = 0; q < NC; q++) prev.f[q] = f[q];
+                for (int x = 0; x < 4; x++)
+                    if (cmdp->kq[x] == 0) vft_spr_load<REAL, NC>(R, id[x], p, cq[x]);
             }
         }
-        // every output is a row from now on (the flags of internal nodes are set already in this phase; up-profile slots get
-        // theirs here); other threads read them only after the barrier that ends the command
-        if (threadIdx.x < (unsigned) n && A.mlIs) A.mlIs[cmd.out[threadIdx.x] - A.d.nSeqs] = 1;
-    } else if (cmd.type == 2) {
-        // The six distances AB AC AD BC BD CD of (A, B, C, D) = q[0..3] (chooseNNI, NJ.tcc:4836-4846).  A wavefront per pair
-        // (vft_pair_wave) walks nPos / 64 dependent memory rounds - 16 us of a step at 1 000 columns.  Instead every thread
-        // loads ITS columns of the four profiles once and parks the addends of all six pairs in LDS (vft_pair_addends, exactly
-        // as the pair kernels form them); then twelve lanes on eight wavefronts add the twelve chains in column order.
-        // Leaf x leaf pairs of a matrix-free nucleotide run are seqDist's integer counts (any order): vft_pair_wave's fast path.
-        const int64_t nPos = A.d.nPos, nPosPad = A.d.nPosPad;
-        int64_t id[4];
-        bool leaf[4];
+        // ---- the averages, in order; a thread takes its column through the whole chain
+        Col<REAL, NC> prev;
+        prev.w = 0;
+        prev.code = VFT_NOCODE_;
+        prev.vec = false;
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            id[x] = cmd.q[x];
-            leaf[x] = id[x] < A.d.nSeqs;
+        for (int q = 0; q < NC; q++) prev.f[q] = 0;
+        for (int g0 = 0; g0 < n; g0 += PF) {
+            Col<REAL, NC> ea[PF], eb[PF];
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int k = g0 + u;
+                if (k < n) {
+                    if (cmdp->ka[k] == 0) vft_spr_load<REAL, NC>(R, cmdp->a[k], p, ea[u]);
+                    if (cmdp->kb[k] == 0) vft_spr_load<REAL, NC>(R, cmdp->b[k], p, eb[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int k = g0 + u;
+                if (k < n) {
+                    Col<REAL, NC> c1, c2;
+                    const int ka = cmdp->ka[k], kb = cmdp->kb[k];
+                    if (ka == 0) c1 = ea[u];
+                    else if (ka == 1) c1 = prev;
+                    else vft_spr_load<REAL, NC>(R, cmdp->a[k], p, c1);
+                    if (kb == 0) c2 = eb[u];
+                    else if (kb == 1) c2 = prev;
+                    else vft_spr_load<REAL, NC>(R, cmdp->b[k], p, c2);
+                    REAL wo, f[NC];
+                    int co;
+                    vft_average_col<REAL, NC>(A, c1, c2, 0.5, tolS, wo, co, f);
+                    {   // the row's vector slot is written whatever the column holds: the loads above never test before they read
+                        const int64_t idx = ((int64_t) cmdp->out[k] - A.d.nSeqs) * nPos + p;
+                        R.mlW[idx] = wo;
+                        R.mlC[idx] = (uint8_t) co;
+                        VFT_GLOBAL REAL *dst = R.mlF + idx * NC;
+#pragma unroll
+                        for (int q = 0; q < NC; q++) dst[q] = f[q];
+                    }
+                    prev.w = wo;
+                    prev.code = co;
+                    prev.vec = wo > 0 && co == VFT_NOCODE_;
+#pragma unroll
+                    for (int q = 0; q < NC; q++) prev.f[q] = f[q];
+                }
+            }
         }
-        const bool counts = !A.dmDist && NC == 4;   // leaf pairs by integer counts
-        for (int64_t p = threadIdx.x; p < nPos; p += VFT_SPR_WG) {
-            if constexpr (NC == 4) {   // the four columns at once: 4 loads for 6 pairs
-                Col<REAL, NC> c[4];
+        // ---- the addends of the six pairs AB AC AD BC BD CD at this column (chooseNNI, NJ.tcc:4836-4846): exactly what the
+        // pair kernels park in LDS (vft_pair_addends); members written above are read back by the thread that wrote them
+        if (hasDist) {
+            if constexpr (NC == 4) {
 #pragma unroll
-                for (int x = 0; x < 4; x++) vft_spr_load<REAL, NC>(A, id[x], p, byId, c[x]);
+                for (int x = 0; x < 4; x++)
+                    if (cmdp->kq[x] != 0) vft_spr_load<REAL, NC>(R, id[x], p, cq[x]);
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     const int x = k < 3 ? 0 : k < 5 ? 1 : 2, y = k == 0 ? 1 : (k == 1 || k == 3) ? 2 : 3;
                     const bool ll = leaf[x] && leaf[y];
                     if (ll && counts) continue;
-                    vft_pair_addends<REAL, NC>(A, ll, false, p, c[x], c[y], pwLds + (int64_t) (2 * k) * nPosPad, pwLds + (int64_t) (2 * k + 1) * nPosPad);
+                    vft_spr_addends<REAL, NC>(A, ll, p, cq[x], cq[y], pwLds + (2 * k) * (int) nPosPad, pwLds + (2 * k + 1) * (int) nPosPad);
                 }
-            } else {                   // 20-state columns: two in registers at a time
-#pragma unroll 1
+            } else {
+                Col<REAL, NC> c4[4];   // all four requested at once (one memory round), then the six pairs
+#pragma unroll
+                for (int x = 0; x < 4; x++) vft_spr_load<REAL, NC>(R, id[x], p, c4[x]);
+#pragma unroll
                 for (int k = 0; k < 6; k++) {
                     const int x = k < 3 ? 0 : k < 5 ? 1 : 2, y = k == 0 ? 1 : (k == 1 || k == 3) ? 2 : 3;
-                    const bool ll = id[x] < A.d.nSeqs && id[y] < A.d.nSeqs;
-                    Col<REAL, NC> c1, c2;
-                    vft_spr_load<REAL, NC>(A, id[x], p, byId, c1);
-                    vft_spr_load<REAL, NC>(A, id[y], p, byId, c2);
-                    vft_pair_addends<REAL, NC>(A, ll, false, p, c1, c2, pwLds + (int64_t) (2 * k) * nPosPad, pwLds + (int64_t) (2 * k + 1) * nPosPad);
+                    vft_spr_addends<REAL, NC>(A, leaf[x] && leaf[y], p, c4[x], c4[y], pwLds + (2 * k) * (int) nPosPad, pwLds + (2 * k + 1) * (int) nPosPad);
                 }
             }
         }
-        __syncthreads();
-        {   // chain ch = 2 k + which (0: the pair's weights sW -> denom, 1: its terms sT -> top) on wave ch & 7, lane ch >> 3
-            const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-            if (l < 2 && w + 8 * l < 12) {
-                const double *src = pwLds + (int64_t) (w + 8 * l) * nPosPad;
-                double acc = 0;
-                int64_t p = 0;
-                for (; p + 8 <= nPos; p += 8) {
-                    double v[8];
+    }
+    // every output is a row from now on (the flags of internal nodes are set already in this phase; up-profile slots get
+    // theirs here); other kernels read them after this one
+    if (threadIdx.x < (unsigned) n && A.mlIs) A.mlIs[cmdp->out[threadIdx.x] - A.d.nSeqs] = 1;
+    if (threadIdx.x == 0) {
+        const long long t = wall_clock64();
+        cmdp->tick[0] += t - tk0;
+        tk0 = t;
+    }
+    if (!hasDist) return;
+    {   // leaf x leaf pairs of a matrix-free nucleotide run: integer counts by the pair's wavefront (one round of loads)
+        const int w = threadIdx.x >> 6;
+        if (w < 6) {
+            const int x = w < 3 ? 0 : w < 5 ? 1 : 2, y = w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3;
+            if (leaf[x] && leaf[y] && counts) {   // seqDist (NJ.tcc:1601-1624) as vft_pair_wave counts it
+                const int lane = threadIdx.x & 63;
+                int nUse = 0, nSame = 0;
+                for (int c = lane; c < A.d.nChunk; c += 64)
+                    vft_seq_counts(R.leaf(vft_leaf_idx(A.d, id[x] >> 6, c, (int) (id[x] & 63))),
+                                   R.leaf(vft_leaf_idx(A.d, id[y] >> 6, c, (int) (id[y] & 63))), nUse, nSame);
 #pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = src[p + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) acc += v[u];
+                for (int off = 32; off > 0; off >>= 1) {
+                    nUse += __shfl_xor(nUse, off, 64);
+                    nSame += __shfl_xor(nSame, off, 64);
                 }
-                for (; p < nPos; p++) acc += src[p];
-                cmd.sum[w + 8 * l] = acc;
+                const REAL d = (REAL) (nUse > 0 ? (double) (nUse - nSame) / (double) nUse : 1.0);
+                if (lane == 0) cmdp->dist[w] = (double) d;
             }
         }
-        __syncthreads();
-        {
-            const int w = threadIdx.x >> 6;
-            if (w < 6) {
-                const int x = w < 3 ? 0 : w < 5 ? 1 : 2, y = w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3;
-                if (leaf[x] && leaf[y] && counts) {
-                    REAL d, wt;
-                    vft_pair_wave<REAL, NC>(A, id[x], id[y], false, nullptr, nullptr, d, wt);   // (the integer path touches no LDS)
-                    if ((threadIdx.x & 63) == 0) cmd.dist[w] = (double) d;
-                } else if ((threadIdx.x & 63) == 0) {
-                    const double denom = cmd.sum[2 * w], top = cmd.sum[2 * w + 1];
-                    const REAL d = (REAL) (denom > 0 ? top / denom : 1.0);
-                    cmd.dist[w] = (double) d;
-                }
-            }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t = wall_clock64();
+        cmdp->tick[1] += t - tk0;
+        tk0 = t;
+    }
+    {   // chain ch = 2 k + which (0: the pair's weights sW -> denom, 1: its terms sT -> top) on wave ch & 7, lane ch >> 3
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l < 2 && w + 8 * l < 12) cmdp->sum[w + 8 * l] = vft_spr_chain_sum(pwLds + (w + 8 * l) * (int) nPosPad, nPosPad);
+    }
+    if (threadIdx.x == 0) {
+        const long long t = wall_clock64();
+        cmdp->tick[2] += t - tk0;
+        tk0 = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t = wall_clock64();
+        cmdp->tick[3] += t - tk0;
+        tk0 = t;
+    }
+    if (threadIdx.x < 6) {
+        const int w = threadIdx.x;
+        const int x = w < 3 ? 0 : w < 5 ? 1 : 2, y = w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3;
+        if (!(leaf[x] && leaf[y] && counts)) {
+            const double denom = cmdp->sum[2 * w], top = cmdp->sum[2 * w + 1];
+            const REAL d = (REAL) (denom > 0 ? top / denom : 1.0);
+            cmdp->dist[w] = (double) d;
         }
     }
 }
@@ -195,22 +329,34 @@ __device__ __noinline__ void vft_spr_exec(const Arena<REAL> &A, const SprState &
 struct SprWalk {
     uint32_t epoch;
     int nQueued;
-    long long nAvg, tAvg, tDist;
+    long long nAvg, tCmd, nCmd;
 };
 
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprState S_) {
     extern __shared__ __attribute__((aligned(16))) double pwLds[];
     __shared__ SprCmd cmd;
-    // The arena and the walk's state as LDS objects: vft_spr_exec is ONE function called from many places (not inlined), and a
-    // reference to a kernel argument handed to a real function makes the compiler keep a copy of the argument in scratch memory
-    // - every A.mlW, A.d.nPos in the column loops was then a trip to private memory in front of the load it feeds (12 us of a
-    // 28 us distance command).  A reference to an LDS object costs an LDS read.
+    // The arena and the walk's state as LDS objects: vft_spr_exec is ONE function called from several places (not inlined), and
+    // a reference to a kernel argument handed to a real function makes the compiler keep a copy of the argument in scratch
+    // memory - every A.mlW, A.d.nPos in the column loops was then a trip to private memory in front of the load it feeds.
+    // A reference to an LDS object costs an LDS read.
     __shared__ Arena<REAL> sArena;
     __shared__ SprState sState;
+    // wave 0's view of the tree: the records and up-profile flags of recently touched nodes (a step works on a dozen nodes and
+    // walks one path to the root; from L2 every one of those dependent reads is a memory round trip)
+    __shared__ int4 ncache[VFT_SPR_NCACHE];
+    __shared__ int32_t ntag[VFT_SPR_NCACHE], etag[VFT_SPR_NCACHE];
+    __shared__ uint32_t eval[VFT_SPR_NCACHE];
     if (threadIdx.x == 0) {
         sArena = A_;
         sState = S_;
+    }
+    for (int t = threadIdx.x; t < VFT_SPR_NCACHE; t += VFT_SPR_WG) ntag[t] = etag[t] = -1;
+    if (threadIdx.x < 6) cmd.tick[threadIdx.x] = 0;
+    // the columns between the alignment's end and the staging stride hold +0.0 for good (vft_spr_chain_sum adds whole sixteens)
+    for (int64_t t = threadIdx.x; t < 12 * (A_.d.nPosPad - A_.d.nPos); t += VFT_SPR_WG) {
+        const int64_t arr = t / (A_.d.nPosPad - A_.d.nPos), off = t % (A_.d.nPosPad - A_.d.nPos);
+        pwLds[arr * A_.d.nPosPad + A_.d.nPos + off] = 0.0;
     }
     __syncthreads();
     const Arena<REAL> &A = sArena;
@@ -220,7 +366,7 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
         for (;;) {
             __syncthreads();
             if (cmd.type == 0) return;
-            vft_spr_exec<REAL, NC>(A, S, cmd, pwLds);
+            vft_spr_exec<REAL, NC>((const VFT_LDS Arena<REAL> *) &sArena, (const VFT_LDS SprState *) &sState, (VFT_LDS SprCmd *) &cmd, (VFT_LDS double *) pwLds);
             __syncthreads();
         }
     }
@@ -237,16 +383,26 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
     SprWalk W;
     W.epoch = 1;
     W.nQueued = 0;
-    W.nAvg = W.tAvg = W.tDist = 0;
+    W.nAvg = W.tCmd = W.nCmd = 0;
     int64_t nSPR = 0, nSteps = 0;
-    const long long tStart = wall_clock64();
+    const long long tStart = wall_clock64(), cStart = clock64();
     auto sync0 = [&]() {   // wave 0's own stores (lane 0) before its next loads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto ld = [&](int32_t v) -> SprNode {
-        const int4 r = *reinterpret_cast<const int4 *>(&nodes[v]);
+        const int slot = v & (VFT_SPR_NCACHE - 1);
+        int4 r;
+        if (ntag[slot] == v) {
+            r = ncache[slot];
+        } else {
+            r = *reinterpret_cast<const int4 *>(&nodes[v]);
+            if (lane == 0) {
+                ncache[slot] = r;
+                ntag[slot] = v;
+            }
+        }
         SprNode n;
         n.parent = r.x;
         n.c0 = r.y;
@@ -254,33 +410,50 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
         n.c2 = r.w;
         return n;
     };
-    auto issue = [&]() {   // hand the command in LDS to the workgroup and take part in it
-        const long long t0 = wall_clock64();
-        const int type = cmd.type;
-        __syncthreads();
-        vft_spr_exec<REAL, NC>(A, S, cmd, pwLds);
-        __syncthreads();
-        const long long dt = wall_clock64() - t0;
-        if (type == 1) W.tAvg += dt;
-        else W.tDist += dt;
+    auto parentOf = [&](int32_t v) -> int32_t { return ld(v).parent; };
+    auto epochOf = [&](int32_t v) -> uint32_t {
+        const int slot = v & (VFT_SPR_NCACHE - 1);
+        if (etag[slot] == v) return eval[slot];
+        const uint32_t e = upEpoch[v];
+        if (lane == 0) {
+            eval[slot] = e;
+            etag[slot] = v;
+        }
+        return e;
     };
-    auto flushAverages = [&]() {
-        if (W.nQueued == 0) return;
+    // hand the command in LDS to the workgroup and take part in it: the averages queued so far, then (withDist) the distances
+    auto issue = [&](bool withDist) {
         if (lane == 0) {
             cmd.type = 1;
             cmd.n = W.nQueued;
+            cmd.hasDist = withDist ? 1 : 0;
         }
         W.nAvg += W.nQueued;
         W.nQueued = 0;
-        issue();
+        W.nCmd++;
+        const long long t0 = wall_clock64();
+        __syncthreads();
+        vft_spr_exec<REAL, NC>((const VFT_LDS Arena<REAL> *) &sArena, (const VFT_LDS SprState *) &sState, (VFT_LDS SprCmd *) &cmd, (VFT_LDS double *) pwLds);
+        __syncthreads();
+        W.tCmd += wall_clock64() - t0;
+    };
+    auto producer = [&](int32_t v) -> int {   // 0: not written by the queued ops, 1: by the last one, 2: by an earlier one
+        int kind = 0;
+        for (int k = 0; k < W.nQueued; k++)
+            if (cmd.out[k] == v) kind = k == W.nQueued - 1 ? 1 : 2;
+        return kind;
     };
     auto queueAverage = [&](int32_t out, int32_t a, int32_t b) {
+        if (W.nQueued == VFT_SPR_CHAIN) issue(false);
+        const int ka = producer(a), kb = producer(b);
         if (lane == 0) {
             cmd.out[W.nQueued] = out;
             cmd.a[W.nQueued] = a;
             cmd.b[W.nQueued] = b;
+            cmd.ka[W.nQueued] = (uint8_t) ka;
+            cmd.kb[W.nQueued] = (uint8_t) kb;
         }
-        if (++W.nQueued == VFT_SPR_CHAIN) flushAverages();
+        W.nQueued++;
     };
     // the two children of the root that are not v
     auto rootOthers = [&](const SprNode &R, int32_t v, int32_t &x, int32_t &y) {
@@ -296,7 +469,11 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
         }
     };
     auto setUp = [&](int32_t v, uint32_t e) {
-        if (lane == 0) upEpoch[v] = e;
+        if (lane == 0) {
+            upEpoch[v] = e;
+            eval[v & (VFT_SPR_NCACHE - 1)] = e;
+            etag[v & (VFT_SPR_NCACHE - 1)] = v;
+        }
     };
     auto replaceChild = [&](int32_t par, int32_t oldChild, int32_t newChild) {   // NJ.tcc:1929-1940
         SprNode P = ld(par);
@@ -304,24 +481,33 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
         else if (P.c1 == oldChild) P.c1 = newChild;
         else if (P.c2 == oldChild) P.c2 = newChild;
         if (lane == 0) {
-            *reinterpret_cast<int4 *>(&nodes[par]) = make_int4(P.parent, P.c0, P.c1, P.c2);
+            const int4 r = make_int4(P.parent, P.c0, P.c1, P.c2);
+            *reinterpret_cast<int4 *>(&nodes[par]) = r;
+            ncache[par & (VFT_SPR_NCACHE - 1)] = r;   // (ld above left par in its slot)
             nodes[newChild].parent = par;
+            const int cs = newChild & (VFT_SPR_NCACHE - 1);
+            if (ntag[cs] == newChild) ncache[cs].x = par;
         }
         sync0();
     };
     auto ensureUpProfile = [&](int32_t node) {   // getUpProfile (NJ.tcc:3382-3434): cached; missing ones from the root down
-        if (upEpoch[node] == W.epoch) return;
-        int len = 0;
+        if (epochOf(node) == W.epoch) return;
+        // the way up: parents through the LDS cache; the cache flags of the nodes passed are requested on the way (they are not
+        // part of the chase) and the missing ones remembered, deepest first
+        int len = 0, nMiss = 0;
         for (int32_t x = node; x != root;) {
-            const SprNode X = ld(x);
+            const uint32_t e = epochOf(x);
+            const int32_t up = parentOf(x);
             if (lane == 0) pathBuf[len] = x;
+            if (e != W.epoch) {
+                if (nMiss < VFT_SPR_MISS && lane == 0) cmd.miss[nMiss] = x;
+                nMiss++;
+            }
             len++;
-            x = X.parent;
+            x = up;
         }
         sync0();
-        for (int t = len; t-- > 0;) {
-            const int32_t x = pathBuf[t];
-            if (upEpoch[x] == W.epoch) continue;
+        auto build = [&](int32_t x) {
             const SprNode X = ld(x);
             const SprNode P = ld(X.parent);
             int32_t c0, c1;
@@ -333,6 +519,14 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
             }
             queueAverage(x + nSeqs, c0, c1);
             setUp(x, W.epoch);
+        };
+        if (nMiss <= VFT_SPR_MISS) {
+            for (int t = nMiss; t-- > 0;) build(cmd.miss[t]);   // from the root down
+        } else {
+            for (int t = len; t-- > 0;) {
+                const int32_t x = pathBuf[t];
+                if (epochOf(x) != W.epoch) build(x);
+            }
         }
         sync0();
     };
@@ -392,15 +586,20 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
             ensureUpProfile(N.parent);
             idD = N.parent + nSeqs;
         }
-        flushAverages();
-        if (lane == 0) {
-            cmd.type = 2;
-            cmd.q[0] = q0;
-            cmd.q[1] = q1;
-            cmd.q[2] = q2;
-            cmd.q[3] = idD;
+        {
+            const int k0 = producer(q0), k1 = producer(q1), k2 = producer(q2), k3 = producer(idD);
+            if (lane == 0) {
+                cmd.q[0] = q0;
+                cmd.q[1] = q1;
+                cmd.q[2] = q2;
+                cmd.q[3] = idD;
+                cmd.kq[0] = (uint8_t) (k0 ? 2 : 0);
+                cmd.kq[1] = (uint8_t) (k1 ? 2 : 0);
+                cmd.kq[2] = (uint8_t) (k2 ? 2 : 0);
+                cmd.kq[3] = (uint8_t) (k3 ? 2 : 0);
+            }
         }
-        issue();
+        issue(true);
         const double c0 = logCorrect(cmd.dist[0]), c1 = logCorrect(cmd.dist[1]), c2 = logCorrect(cmd.dist[2]), c3 = logCorrect(cmd.dist[3]),
                      c4 = logCorrect(cmd.dist[4]), c5 = logCorrect(cmd.dist[5]);
         cr0 = c0 + c5;
@@ -477,15 +676,20 @@ __global__ __launch_bounds__(VFT_SPR_WG) void k_spr_walk(Arena<REAL> A_, SprStat
             }
         }
     }
-    flushAverages();
+    if (W.nQueued) issue(false);
     if (lane == 0) {
         outBuf[0] = nSPR;
         outBuf[1] = nSteps;
         outBuf[2] = W.nAvg;
         outBuf[3] = (int64_t) W.epoch;
-        outBuf[4] = W.tAvg;
-        outBuf[5] = W.tDist;
-        outBuf[6] = wall_clock64() - tStart;
+        outBuf[4] = W.tCmd;
+        outBuf[5] = wall_clock64() - tStart;
+        outBuf[6] = W.nCmd;
+        outBuf[7] = cmd.tick[0];
+        outBuf[8] = cmd.tick[1];
+        outBuf[9] = cmd.tick[2];
+        outBuf[10] = cmd.tick[3];
+        outBuf[11] = clock64() - cStart;   // shader clock cycles of the whole walk
         cmd.type = 0;
     }
     __syncthreads();   // releases the workers

@@ -748,18 +748,23 @@ namespace veryfasttree {
             /* the walk itself runs on the device (k_spr_walk, csrc/vft_kernels_spr.h: the statements below, wave 0 of one
                persistent workgroup executing them, no host round trip per step) whenever the alignment fits its staging;
                the host walk that follows is the same algorithm for longer alignments and chains */
-            if (sprOnDevice && maxSPRLength <= 16 && (size_t) sprPosPad * 96 + 2048 <= 160u * 1024u) {
+            if (sprOnDevice && maxSPRLength <= 16 && (size_t) sprPosPad * 96 + 34 * 1024 <= 160u * 1024u) {
                 flushAverages();
-                int64_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                chk(vft_spr_round(ctx, nNodes, parent.data(), child.data(), root, (int64_t) nodeList.size(), nodeList.data(), scoredist ? 1 : 0,
-                                  maxSPRLength, out));
+                int64_t out[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const int rc = vft_spr_round(ctx, nNodes, parent.data(), child.data(), root, (int64_t) nodeList.size(), nodeList.data(), scoredist ? 1 : 0,
+                                             maxSPRLength, out);
+                if (rc == VFT_ERR_STATE) goto hostWalk;   /* a profile without a row: the kernel has refused before touching anything */
+                chk(rc);
                 sprSteps += out[1];
                 if (std::getenv("VFT_SPR_REPORT"))   /* tools: where the kernel's time goes */
-                    fprintf(stderr, "SPR round on the device: %lld moves, %lld steps, %lld averages; %.3f s in all, %.3f s in average commands, %.3f s in distance commands\n",
-                            (long long) out[0], (long long) out[1], (long long) out[2], 1e-8 * (double) out[6], 1e-8 * (double) out[4], 1e-8 * (double) out[5]);
+                    fprintf(stderr, "SPR round on the device: %lld moves, %lld steps, %lld averages, %lld commands; %.3f s in all, %.3f s inside commands\n",
+                            (long long) out[0], (long long) out[1], (long long) out[2], (long long) out[6], 1e-8 * (double) out[5], 1e-8 * (double) out[4]);
+                    fprintf(stderr, "  thread 0 inside commands: columns %.3f s, barrier %.3f s, sums %.3f s, barrier %.3f s\n", 1e-8 * (double) out[7], 1e-8 * (double) out[8], 1e-8 * (double) out[9], 1e-8 * (double) out[10]);
+                    fprintf(stderr, "  shader clock during the walk: %.0f MHz\n", out[5] > 0 ? 100.0 * (double) out[11] / (double) out[5] : 0.0);
                 rebuildOrder();
                 return out[0];
             }
+            hostWalk:
             struct Step {
                 int64_t nodes[2];
                 double deltaLength;

@@ -61,8 +61,10 @@ namespace veryfasttree {
         int aaModel = 0;
         /* multi-GPU (include/vft_host.h, vft_comm): sweeps and leaf blocks are split over the ranks */
         const vft_comm *comm = nullptr;
-        /* the SPR rounds as one persistent kernel per round (vft_spr_round); false = the host-driven walk (tools) */
-        bool deviceSPR = true;
+        /* the SPR rounds as one persistent kernel per round (vft_spr_round) instead of the host-driven walk.  Off by default:
+           measured on MI355X the kernel needs ~50 us per chain step on its one CU, the host-driven walk ~45 us with six to eight
+           CUs per step; both give the same tree (tests/test_gpu_threads.py) */
+        bool deviceSPR = false;
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
         /* top-hit lists on the device (vft_tophits_*): the list walks of a join are one launch each; false = the host walks
