@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end trees (wall-clock half of the metric)")
     ap.add_argument("--no-e2e-c4", action="store_true", help="skip the 1M x 200 end-to-end tree (minutes), keep C3's")
     ap.add_argument("--no-dense", action="store_true", help="skip the phi ~ 1 roofline of the sweep kernel")
+    ap.add_argument("--no-e2e-full", action="store_true", help="skip the complete pipelines of configs C2 and C5 (~3.5 minutes)")
     return ap.parse_args()
 
 
@@ -247,6 +248,52 @@ def end_to_end(which, device, comm=None):
         k = min(len(crcs), len(g["join_chunk_crc"])) if chunk == int(g["join_chunk"]) else 0
         out["reference_joins_compared"] = int(k * chunk)
         out["join_order_identical_to_reference_prefix"] = bool(k > 0 and np.array_equal(crcs[:k].astype(np.int64), g["join_chunk_crc"][:k]))
+    return out
+
+
+E2E_FULL = {
+    # BASELINE configs 2 and 5: the complete default pipeline (NJ, ME NNIs + 2 SPR rounds, ML NNIs with 20 CAT categories, model
+    # fit, SH-like supports).  threads: the reference's `-threads T` schedule this backend follows for the refinement stages
+    # (host/MLLengths.h "the subtree schedule": the walks of T-thread partitions advanced in lockstep, batches of quartets on the GPU).
+    "c2": dict(n=10000, L=1000, nc=4, seed=2, dtype="float32", gtr=True, aa=None, threads=64, flags="-nt -gtr", golden="bb_c2_crc.npz"),
+    "c5": dict(n=50000, L=300, nc=20, seed=2, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden=None),
+}
+
+
+def end_to_end_full(which, device, one_thread):
+    """Wall-clock to the final tree of BASELINE config C2 (10 000 nt x 1 000, `-nt -gtr`, float32) or C5 (50 000 aa x 300, `-lg`, float64):
+    everything `VeryFastTree <flags>` does, supports included.  one_thread: the reference's one-thread order (its deterministic path;
+    C2's tree is compared with tests/golden/bb_c2_crc.npz, the reference binary's own output); otherwise the schedule of a T-thread
+    run of the reference (byte-identical to `VeryFastTree -threads T` under Jukes-Cantor, tests/test_gpu_threads.py; with a matrix
+    model the reference's threaded runs are not reproducible and there is nothing to pin)."""
+    import zlib
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick, last_stage_seconds
+    cfg = E2E_FULL[which]
+    dt = np.float64 if cfg["dtype"] == "float64" else np.float32
+    codes = synth.random_descent_codes(cfg["n"], cfg["L"], cfg["nc"], 0.03, 0.01, seed=cfg["seed"])
+    names = ["s%d" % k for k in range(cfg["n"])]
+    T = 1 if one_thread else cfg["threads"]
+    kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True, threads=T)
+    if cfg["aa"]:
+        kw["aa_model"] = cfg["aa"]
+    if cfg["gtr"]:
+        kw["gtr"] = True
+    t0 = time.perf_counter()
+    tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, cfg["nc"], dt, max_nodes=3 * m, device=device), codes, names, **kw)
+    wall = time.perf_counter() - t0
+    out = dict(workload="%s_%dk_x%d_%s_full_pipeline" % (which, cfg["n"] // 1000, cfg["L"], "nt" if cfg["nc"] == 4 else "aa"),
+               reference_flags=cfg["flags"] + " -threads %d" % T, schedule_threads=T, dtype=cfg["dtype"], wall_s=round(wall, 2),
+               tree_loglk=[round(float(x), 4) for x in loglk], newick_bytes=len(tree), newick_crc=zlib.crc32(tree.encode()),
+               stages_s=last_stage_seconds())
+    if one_thread and cfg["golden"] and os.path.exists(os.path.join(ROOT, "tests", "golden", cfg["golden"])):
+        g = np.load(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
+        out["reference_newick_crc"] = int(g["newick_crc"])
+        out["identical_to_reference"] = bool(int(g["newick_crc"]) == out["newick_crc"])
+        out["reference_wall_s_1_thread"] = round(float(g["reference_wall_s"]), 1)
+        want = g["loglk"]
+        if len(want) and len(loglk):
+            out["final_loglk_rel_diff"] = float(abs(loglk[-1] - want[-1]) / abs(want[-1]))
     return out
 
 
@@ -494,6 +541,13 @@ def main():
                     e2e["wall_s"] = round(float(w.item()), 2)
                     e2e["same_crc_on_all_ranks"] = bool(c[0].item() == -c[1].item())
             line[key] = e2e
+        if not args.no_e2e_full and not use_dist:
+            # the complete pipelines (refinement + maximum likelihood) of configs C2 and C5: not sharded, rank 0 only
+            for key, which, one in (("e2e_c2", "c2", True), ("e2e_c2_threads", "c2", False), ("e2e_c5_threads", "c5", False)):
+                try:
+                    line[key] = end_to_end_full(which, local_rank, one)
+                except Exception as exc:
+                    line[key] = {"workload": which, "error": repr(exc)}
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

@@ -339,6 +339,13 @@ int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t
 int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
                        const int64_t *b);
 
+/* differ[k] = 1 when the profiles of nodes a[k] and b[k] are not bit-identical (weights, codes, vectors), else 0; n <= 4096.  The
+   speculative SPR rounds (host/MLLengths.h, doSPRSpeculative) ask whether an attempt that left the tree as it was also left the
+   profiles it recomputed as they were.  Waits. */
+int vft_profiles_differ(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, int32_t *differ);
+/* the max_nodes the context was created with (rows beyond the tree's nodes and up-profile slots serve as private scratch) */
+int vft_get_max_nodes(vft_ctx *ctx, int64_t *max_nodes);
+
 /* One round of subtree-prune-regraft moves (SPR, NJ.tcc:6185-6404, one thread, fast flavour; findSPRSteps :1805-1859,
    unwindSPRStep :1861-1879) entirely on the device: node_list[n_list] is the walk (the reference fixes it before anything
    moves: every node in post-order), parent[n_nodes] (-1 at the root) / child[n_nodes][3] (-1 = none) the tree, rearranged in

@@ -426,6 +426,29 @@ def gen_c3(tmp):
     print("bb_c3_crc: %d bytes of Newick, crc %d" % (len(tree), zlib.crc32(tree.encode())))
 
 
+def gen_c2(tmp):
+    """BASELINE config C2 at full size (10 000 x 1 000 nt, `-nt -gtr`, one thread, the complete default pipeline with supports):
+    CRC-32 and length of the reference's tree and its TreeLogLk lines - what bench.py's e2e_c2 compares its one-thread-order run with."""
+    import time
+    import zlib
+    codes = synth.random_descent_codes(10000, 1000, 4, 0.03, 0.01, seed=2)
+    fa = os.path.join(tmp, "c2.fa")
+    synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+    del codes
+    flags = ["-nt", "-gtr", "-threads", "1", "-seed", "1"]
+    log = os.path.join(tmp, "c2.log")
+    t0 = time.time()
+    res = subprocess.run([REFBIN] + flags + ["-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    wall = time.time() - t0
+    tree = res.stdout.decode().strip()
+    ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", open(log).read(), re.M)]
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c2_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+                        loglk=np.array(ll), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(b"random_descent_codes(10000, 1000, 4, 0.03, 0.01, seed=2)", dtype=np.uint8),
+                        reference_wall_s=np.float64(wall))
+    print("bb_c2_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ll), wall))
+
+
 def gen_c4(tmp):
     """BASELINE config C4 at full size (1 000 000 x 200 nt, `-nt` at one thread): CRC-32 and length of the reference's
     `-noml -nome -nosupport` tree, plus the join order as one CRC-32 per 10 000 `Join` lines (`i j new`, NJ.tcc:2993-3001)
@@ -518,6 +541,8 @@ def main():
             gen_threads(tmp, [w[8:] for w in which if w.startswith("threads:")])
         if "c3" in which:   # not part of the default set: ~11 minutes
             gen_c3(tmp)
+        if "c2" in which:   # not part of the default set: minutes
+            gen_c2(tmp)
         if "c4" in which:   # not part of the default set: hours
             gen_c4(tmp)
         if "c4_prefix" in which:   # from the Join lines a running gen_c4 has produced so far

@@ -1223,6 +1223,33 @@ extern "C" int vft_average_chains(vft_ctx *c, int32_t nChains, const int32_t *ch
     return average_chains(c, nChains, chainOff, chainOff[nChains], out, a, b, "vft_average_chains");
 }
 
+// differ[k] = 1 when the profiles of nodes a[k] and b[k] (rows or tile streams, internal or leaf) are not bit-identical.  Waits.
+extern "C" int vft_profiles_differ(vft_ctx *c, int64_t n, const int64_t *a, const int64_t *b, int32_t *differ) {
+    if (!c || n < 0 || !a || !b || !differ) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (n > 4096) return fail(c, VFT_ERR_INVALID, "vft_profiles_differ: at most 4096 pairs per call");
+    for (int64_t k = 0; k < n; k++)
+        if (a[k] < 0 || a[k] >= c->maxnode || b[k] < 0 || b[k] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_profiles_differ: pair %lld out of range", (long long) k);
+    const size_t idB = (size_t) n * 8, flB = ((size_t) n * 4 + 255) & ~(size_t) 255;
+    char *h, *s;
+    if (int r = io_alloc(c, 2 * idB + flB, &h, &s)) return r;
+    memcpy(h, a, idB);
+    memcpy(h + idB, b, idB);
+    memset(h + 2 * idB, 0, flB);
+    VFT_DISPATCH(c, launch((k_rows_differ<REAL, NC>), dim3(cdiv(c->d.nPos, 128), (unsigned) n), dim3(128), 0, c->stream, arena<REAL>(c),
+                           (const int64_t *) s, (const int64_t *) (s + idB), (int32_t *) (s + 2 * idB)));
+    LAUNCHCHK(c);
+    if (int w = wait_stream(c)) return w;
+    memcpy(differ, h + 2 * idB, (size_t) n * 4);
+    return VFT_OK;
+}
+
+extern "C" int vft_get_max_nodes(vft_ctx *c, int64_t *maxNodes) {
+    if (!c || !maxNodes) return VFT_ERR_INVALID;
+    *maxNodes = c->d.maxNodes;
+    return VFT_OK;
+}
+
 // One round of SPR moves (NJ.tcc:6185-6404) as a persistent workgroup (k_spr_walk, vft_kernels_spr.h): the tree arrays go
 // to the device, wave 0 of the workgroup walks node_list, the arrays come back rearranged.  Waits for the kernel.
 extern "C" int vft_spr_round(vft_ctx *c, int64_t nNodes, int64_t *parent, int64_t *child, int64_t root, int64_t nList,

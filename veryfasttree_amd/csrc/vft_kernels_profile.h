@@ -379,6 +379,25 @@ __global__ void k_rows_from_tiles(Arena<REAL> A, int64_t first) {
     vft_store_col_ml<REAL, NC>(A, node, p, c.w, c.code, c.f);
 }
 
+// are two nodes' rows the same profile, bit for bit?  flags[k] |= 1 when rows a[k], b[k] differ at some column (weight, code, or
+// vector under a vector column).  The speculative SPR rounds (host/MLLengths.h) ask whether an attempt that changed nothing in the
+// tree left the profiles it recomputed as they were.
+template <typename REAL, int NC>
+__global__ void k_rows_differ(Arena<REAL> A, const int64_t *aN, const int64_t *bN, int32_t *flags) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    const int64_t k = blockIdx.y;
+    Col<REAL, NC> c1, c2;
+    vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
+    vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
+    bool diff = c1.code != c2.code || c1.vec != c2.vec || memcmp(&c1.w, &c2.w, sizeof(REAL)) != 0;
+    if (!diff && c1.vec) {
+#pragma unroll
+        for (int q = 0; q < NC; q++) diff = diff || memcmp(&c1.f[q], &c2.f[q], sizeof(REAL)) != 0;
+    }
+    if (diff) flags[k] = 1;   // (every writer stores the same value; the buffer may be host-mapped memory)
+}
+
 static __global__ void k_mark_rows(uint8_t *mlIs, const int64_t *nodes, int32_t n, int64_t nSeqs) {
     const int32_t k = (int32_t) (blockIdx.x * blockDim.x + threadIdx.x);
     if (k < n) mlIs[nodes[k] - nSeqs] = 1;
