@@ -379,6 +379,9 @@ __global__ void k_rows_from_tiles(Arena<REAL> A, int64_t first) {
     vft_store_col_ml<REAL, NC>(A, node, p, c.w, c.code, c.f);
 }
 
+__device__ __forceinline__ bool vft_same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+__device__ __forceinline__ bool vft_same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
 // are two nodes' rows the same profile, bit for bit?  flags[k] |= 1 when rows a[k], b[k] differ at some column (weight, code, or
 // vector under a vector column).  The speculative SPR rounds (host/MLLengths.h) ask whether an attempt that changed nothing in the
 // tree left the profiles it recomputed as they were.
@@ -390,10 +393,10 @@ __global__ void k_rows_differ(Arena<REAL> A, const int64_t *aN, const int64_t *b
     Col<REAL, NC> c1, c2;
     vft_load_col_ml<REAL, NC>(A, aN[k], p, c1);
     vft_load_col_ml<REAL, NC>(A, bN[k], p, c2);
-    bool diff = c1.code != c2.code || c1.vec != c2.vec || memcmp(&c1.w, &c2.w, sizeof(REAL)) != 0;
+    bool diff = c1.code != c2.code || c1.vec != c2.vec || !vft_same_bits(c1.w, c2.w);
     if (!diff && c1.vec) {
 #pragma unroll
-        for (int q = 0; q < NC; q++) diff = diff || memcmp(&c1.f[q], &c2.f[q], sizeof(REAL)) != 0;
+        for (int q = 0; q < NC; q++) diff = diff || !vft_same_bits(c1.f[q], c2.f[q]);
     }
     if (diff) flags[k] = 1;   // (every writer stores the same value; the buffer may be host-mapped memory)
 }

@@ -732,6 +732,72 @@ namespace veryfasttree {
             }
         }
 
+        /* one node of traverseSPR (NJ.tcc:6213-6300): its up to four chains of forced minimum-evolution NNIs, best prefix kept, rest
+           unwound; true when the tree changed */
+        bool sprAttempt(int64_t node, bool scoredist, int maxSPRLength, std::vector<char> &upHave) {
+            if (node == root) return false;
+            struct Step {
+                int64_t nodes[2];
+                double deltaLength;
+            };
+            Step steps[64];
+            if (maxSPRLength > 64) throw std::invalid_argument("MLLengths::sprAttempt: chains of at most 64 steps");
+            int64_t nodeAround[2];
+            movePivots(node, nodeAround);
+            bool bChanged = false;
+            for (int iAround = 0; iAround < 2 && !bChanged; iAround++) {
+                for (int acFirst = 0; acFirst < 2 && !bChanged; acFirst++) {
+                    /* findSPRSteps */
+                    int64_t around = nodeAround[iAround], chainLength = 0;
+                    for (; chainLength < maxSPRLength; chainLength++) {
+                        if (around < nSeqs || around == root) break;   /* nChild != 2 */
+                        int64_t q[4];
+                        double criteria[3];
+                        meCriteria(around, scoredist, upHave, q, criteria);
+                        sprSteps++;
+                        Step &st = steps[(size_t) chainLength];
+                        if (chainLength == 0 ? acFirst != 0 : criteria[1] < criteria[2]) {
+                            st.deltaLength = criteria[1] - criteria[0];   /* swap B and C: AC together */
+                            st.nodes[0] = q[1];
+                            st.nodes[1] = q[2];
+                        } else {
+                            st.deltaLength = criteria[2] - criteria[0];   /* swap A and C: AD together */
+                            st.nodes[0] = q[0];
+                            st.nodes[1] = q[2];
+                        }
+                        replaceChild(around, st.nodes[0], st.nodes[1]);
+                        replaceChild(parent[(size_t) around], st.nodes[1], st.nodes[0]);
+                        updateForNNI(around, false, upHave);
+                        int64_t next[2];
+                        movePivots(node, next);
+                        around = next[next[0] == around ? 1 : 0];
+                    }
+                    double dMinDelta = 0.0, dTotDelta = 0.0;
+                    int64_t iCBest = -1;
+                    for (int64_t iC = 0; iC < chainLength; iC++) {
+                        dTotDelta += steps[(size_t) iC].deltaLength;
+                        if (dTotDelta < dMinDelta) {
+                            dMinDelta = dTotDelta;
+                            iCBest = iC;
+                        }
+                    }
+                    for (int64_t iC = chainLength - 1; iC > iCBest; iC--) {   /* unwindSPRStep */
+                        const Step &st = steps[(size_t) iC];
+                        const int64_t p0 = parent[(size_t) st.nodes[0]], p1 = parent[(size_t) st.nodes[1]];
+                        replaceChild(p0, st.nodes[0], st.nodes[1]);
+                        replaceChild(p1, st.nodes[1], st.nodes[0]);
+                        updateForNNI(parent[(size_t) p0] == p1 ? p0 : p1, false, upHave);
+                    }
+                    if (iCBest >= 0) bChanged = true;
+                }
+            }
+            if (bChanged) {
+                std::fill(upHave.begin(), upHave.end(), 0);
+                for (int64_t anc = parent[(size_t) node]; anc >= 0; anc = parent[(size_t) anc]) recomputeProfile(anc, false);
+            }
+            return bChanged;
+        }
+
         /* SPR (NJ.tcc:6185-6404, one thread, fast flavour): every node in post-order is moved along chains of up to
            maxSPRLength minimum-evolution NNIs around its parent and its sibling (findSPRSteps, NJ.tcc:1805-1859; the
            first step forced to AC or AD), keeping the prefix of the chain with the best total length change and
@@ -765,68 +831,9 @@ namespace veryfasttree {
                 return out[0];
             }
             hostWalk:
-            struct Step {
-                int64_t nodes[2];
-                double deltaLength;
-            };
-            std::vector<Step> steps((size_t) maxSPRLength);
             int64_t nSPR = 0;
-            for (int64_t node: nodeList) {
-                if (node == root) continue;
-                int64_t nodeAround[2];
-                movePivots(node, nodeAround);
-                bool bChanged = false;
-                for (int iAround = 0; iAround < 2 && !bChanged; iAround++) {
-                    for (int acFirst = 0; acFirst < 2 && !bChanged; acFirst++) {
-                        /* findSPRSteps */
-                        int64_t around = nodeAround[iAround], chainLength = 0;
-                        for (; chainLength < maxSPRLength; chainLength++) {
-                            if (around < nSeqs || around == root) break;   /* nChild != 2 */
-                            int64_t q[4];
-                            double criteria[3];
-                            meCriteria(around, scoredist, upHave, q, criteria);
-                            Step &st = steps[(size_t) chainLength];
-                            if (chainLength == 0 ? acFirst != 0 : criteria[1] < criteria[2]) {
-                                st.deltaLength = criteria[1] - criteria[0];   /* swap B and C: AC together */
-                                st.nodes[0] = q[1];
-                                st.nodes[1] = q[2];
-                            } else {
-                                st.deltaLength = criteria[2] - criteria[0];   /* swap A and C: AD together */
-                                st.nodes[0] = q[0];
-                                st.nodes[1] = q[2];
-                            }
-                            replaceChild(around, st.nodes[0], st.nodes[1]);
-                            replaceChild(parent[(size_t) around], st.nodes[1], st.nodes[0]);
-                            updateForNNI(around, false, upHave);
-                            int64_t next[2];
-                            movePivots(node, next);
-                            around = next[next[0] == around ? 1 : 0];
-                        }
-                        double dMinDelta = 0.0, dTotDelta = 0.0;
-                        int64_t iCBest = -1;
-                        for (int64_t iC = 0; iC < chainLength; iC++) {
-                            dTotDelta += steps[(size_t) iC].deltaLength;
-                            if (dTotDelta < dMinDelta) {
-                                dMinDelta = dTotDelta;
-                                iCBest = iC;
-                            }
-                        }
-                        for (int64_t iC = chainLength - 1; iC > iCBest; iC--) {   /* unwindSPRStep */
-                            const Step &st = steps[(size_t) iC];
-                            const int64_t p0 = parent[(size_t) st.nodes[0]], p1 = parent[(size_t) st.nodes[1]];
-                            replaceChild(p0, st.nodes[0], st.nodes[1]);
-                            replaceChild(p1, st.nodes[1], st.nodes[0]);
-                            updateForNNI(parent[(size_t) p0] == p1 ? p0 : p1, false, upHave);
-                        }
-                        if (iCBest >= 0) bChanged = true;
-                    }
-                }
-                if (bChanged) {
-                    nSPR++;
-                    std::fill(upHave.begin(), upHave.end(), 0);
-                    for (int64_t anc = parent[(size_t) node]; anc >= 0; anc = parent[(size_t) anc]) recomputeProfile(anc, false);
-                }
-            }
+            for (int64_t node: nodeList)
+                if (sprAttempt(node, scoredist, maxSPRLength, upHave)) nSPR++;
             flushAverages();
             rebuildOrder();
             return nSPR;
