@@ -220,6 +220,8 @@ def end_to_end(which, device, comm=None):
     n, L, mu, gap, seed, fastest, golden, flags = E2E[which]
     codes = synth.random_descent_codes(n, L, 4, mu, gap, seed=seed)
     names = ["s%d" % k for k in range(n)]
+    if comm is not None:   # count this tree's collectives
+        comm.calls = comm.bytes = comm.device_calls = comm.device_bytes = 0
     t0 = time.perf_counter()
     tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m, device=device), codes, names,
                      fastest=fastest, me_lengths=True, comm=comm)
@@ -230,6 +232,7 @@ def end_to_end(which, device, comm=None):
     if comm is not None:   # what was actually split over the ranks: sweeps + leaf blocks (the join loop itself is replicated)
         out["allgathers"] = int(comm.calls)
         out["allgather_bytes"] = int(comm.bytes)
+        out["allgather_bytes_by_phase"] = {"sweep_lists_device": int(comm.device_bytes), "leaf_blocks_host": int(comm.bytes - comm.device_bytes)}
     ref = os.path.join(ROOT, "tests", "golden", golden)
     if os.path.exists(ref):
         g = np.load(ref)

@@ -339,6 +339,13 @@ int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t
 int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
                        const int64_t *b);
 
+/* One step of a host-driven refinement walk (an SPR chain step, a minimum-evolution NNI of the one-thread order) as ONE launch and
+   one wait: the n unweighted averages queued since the last step, in order (as vft_average_chain; n <= 256, may be 0), then the six
+   raw profile distances AB AC AD BC BD CD of the quartet q[0..3] = A, B, C, D (as vft_profile_distances; chooseNNI, NJ.tcc:4836-4846)
+   into dist[6] (numeric_t).  Results are bit-identical to the two calls.  Needs vft_set_profile_rows(ctx, 1) with every internal
+   profile a plain row - VFT_ERR_STATE otherwise (the caller falls back to the two calls). */
+int vft_walk_step(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, void *dist);
+
 /* differ[k] = 1 when the profiles of nodes a[k] and b[k] are not bit-identical (weights, codes, vectors), else 0; n <= 4096.  The
    speculative SPR rounds (host/MLLengths.h, doSPRSpeculative) ask whether an attempt that left the tree as it was also left the
    profiles it recomputed as they were.  Waits. */

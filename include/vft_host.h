@@ -17,8 +17,10 @@ extern "C" {
      - the one-vs-all sweeps (setBestHit, NJ.tcc:3571-3646): rank r sweeps its share of the target ids and selects its
        local top-2m, one all-gather of the k-record lists (device memory: RCCL over xGMI), every rank merges them under the
        reference's (criterion asc, id desc) order (vft_merge_hits);
-     - the close-neighbour blocks of setAllLeafTopHits (vft_leaf_block_distances): rows split over the ranks, host arrays
-       all-gathered.
+     - the close-neighbour blocks of setAllLeafTopHits (vft_leaf_block_distances): computed whole on every rank.  They are
+       integer seqDist counts, ~5 s of a million-sequence run on one GPU; split by rows (vft_nj_options.debug_flags &
+       VFT_NJ_SHARD_LEAF_BLOCKS, round 3's behaviour) their results are 25 GB of host-buffer all-gathers at that size - more
+       than the split saves.
    The driver is transport-agnostic: the caller supplies the buffers and one collective.  allgather(user, bytes, device)
    must gather `bytes` bytes from every rank's send buffer into every rank's recv buffer in rank order - d_send / d_recv
    (device memory, capacity d_cap / world * d_cap) when device != 0, h_send / h_recv (host) otherwise - and return 0. */
@@ -93,6 +95,7 @@ typedef struct {
 #define VFT_NJ_DEBUG_HOST_RESET 4
 #define VFT_NJ_DEBUG_DEVICE_SPR 8
 #define VFT_NJ_DEBUG_LEVEL_LENGTHS 16
+#define VFT_NJ_SHARD_LEAF_BLOCKS 64   /* with comm: split the close-neighbour blocks by rows and all-gather the results (see vft_comm) */
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
    joins: up to n_seqs-3 rows of (i, j, newnode) with i < j, in join order; criterion[k] = the join's criterion.

@@ -146,6 +146,7 @@ struct vft_ctx {
     size_t thLds = 0;                  // dynamic LDS of k_th_best / k_th_join
     size_t thRefreshLds = 0;           // the largest dynamic LDS k_th_refresh has been configured for
     size_t pbLdsSet = 0;               // ... and k_pairs_block_tiled
+    bool walkLdsSet = false;           // k_walk_step's dynamic LDS limit has been raised
     // the join loop on the device (vft_kernels_njengine.h)
     void *njState = nullptr, *njVisD = nullptr;
     int32_t *njVisJ = nullptr, *njTop = nullptr, *njAge = nullptr;
@@ -1221,6 +1222,57 @@ extern "C" int vft_average_chains(vft_ctx *c, int32_t nChains, const int32_t *ch
     if (!c || !chainOff || !out || !a || !b) return VFT_ERR_INVALID;
     if (int r = chains_ok(c, nChains, chainOff, "vft_average_chains")) return r;
     return average_chains(c, nChains, chainOff, chainOff[nChains], out, a, b, "vft_average_chains");
+}
+
+// One step of a host-driven refinement walk as one launch (k_walk_step): n queued averages in order, then the six raw profile
+// distances of the quartet q[0..3].  VFT_ERR_STATE when some internal profile is not a plain row (the caller then takes the
+// two-call path: vft_average_chain + vft_profile_distances).
+extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, void *dist) {
+    if (!c || n < 0 || (n > 0 && (!out || !a || !b)) || !q || !dist) return VFT_ERR_INVALID;
+    if (!c->rowMode || !c->allRows) return fail(c, VFT_ERR_STATE, "vft_walk_step: every internal profile must be a plain row (vft_set_profile_rows)");
+    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_walk_step: at most 256 averages per step");
+    for (int32_t k = 0; k < n; k++) {
+        if (int r = internal_ok(c, out[k])) return r;
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_walk_step: bad child id");
+    }
+    for (int t = 0; t < 4; t++)
+        if (q[t] < 0 || q[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_walk_step: quartet member out of range");
+    const size_t lds = (size_t) 2 * c->d.nPosPad * sizeof(double);
+    if (lds > (160u << 10) - 1024) return fail(c, VFT_ERR_STATE, "vft_walk_step: alignment too long for one workgroup per pair");
+    const size_t rs = c->rs, idB = ((size_t) (n > 0 ? n : 1) * 8 + 255) & ~(size_t) 255;
+    char *h, *s;
+    if (int r = io_alloc(c, 3 * idB + 256 + 256, &h, &s)) return r;
+    if (n > 0) {
+        memcpy(h, out, (size_t) n * 8);
+        memcpy(h + idB, a, (size_t) n * 8);
+        memcpy(h + 2 * idB, b, (size_t) n * 8);
+    }
+    memcpy(h + 3 * idB, q, 32);
+    // a column per thread where the registers allow it: 1 024 threads for 4-state columns, 512 for 20-state ones
+    const int wg = c->d.nPos <= 256 ? 256 : (c->d.nPos <= 512 || c->d.nCodes == 20) ? 512 : 1024;
+    if (!c->walkLdsSet && lds > (48u << 10)) {
+        VFT_DISPATCH(c, {
+            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            if constexpr (NC == 4) HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        });
+        c->walkLdsSet = true;
+    }
+    const unsigned long long seq = ++c->signalSeq;
+#define VFT_WALK_GO(WGN)                                                                                                                      \
+    launch((k_walk_step<REAL, NC, WGN>), dim3(6), dim3(WGN), lds, c->stream, arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB),  \
+           (const int64_t *) (s + 2 * idB), n, c->fpostTol, (const int64_t *) (s + 3 * idB), (REAL *) (s + 3 * idB + 256), c->doneCtr, c->dFlag, \
+           seq, (REAL *) c->pairStage, (int64_t) VFT_PAIR_STAGE_CAP)
+    VFT_DISPATCH(c, {
+        if (wg == 256) VFT_WALK_GO(256);
+        else if (wg == 512) VFT_WALK_GO(512);
+        else if constexpr (NC == 4) VFT_WALK_GO(1024);
+    });
+#undef VFT_WALK_GO
+    LAUNCHCHK(c);
+    if (int r = wait_flag(c, seq)) return r;
+    memcpy(dist, h + 3 * idB + 256, 6 * rs);
+    return VFT_OK;
 }
 
 // differ[k] = 1 when the profiles of nodes a[k] and b[k] (rows or tile streams, internal or leaf) are not bit-identical.  Waits.

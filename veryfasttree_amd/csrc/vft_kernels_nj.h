@@ -1015,6 +1015,59 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     }
 }
 
+// One step of a host-driven refinement walk in ONE launch (SPR chains, minimum-evolution NNIs of the one-thread order): the unweighted
+// averages queued since the last step (recomputeProfile, up-profiles down a path: a chain, later ones may read earlier outputs) and
+// then the six raw profile distances AB AC AD BC BD CD of the quartet q[0..3] they lead up to (chooseNNI, NJ.tcc:4836-4846).  Two
+// launches and a wait per step before (k_average_chain, then k_pairs_fused over six pairs); the averages are column-wise and cheap, so
+// each of the six pair workgroups simply runs the whole chain itself for all columns (every workgroup stores the outputs - the same
+// bits six times - and reads back only what it wrote itself), then forms its pair's addends and adds them in column order
+// (vft_pair_block: bit-identical to every other pair kernel).  No workgroup waits for another; the last one publishes the six
+// distances.  Rows only: every internal id must be a plain row (the refinement phase after vft_set_profile_rows).
+template <typename REAL, int NC, int WG>
+__global__ __launch_bounds__(WG) void k_walk_step(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN, int32_t n, double tol,
+                                                      const int64_t *q, REAL *dist, unsigned int *doneCtr, unsigned long long *flag,
+                                                      unsigned long long seq, REAL *stage, int64_t stageCap) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+    // (WG threads: a column per thread up to 1 024 columns - the chain is a sequence of dependent memory rounds per column)
+    for (int64_t p = threadIdx.x; p < A.d.nPos; p += WG) {
+        int64_t prevOut = -1;
+        Col<REAL, NC> prev;
+        prev.w = 0;
+        prev.code = VFT_NOCODE_;
+        prev.vec = false;
+#pragma unroll
+        for (int k = 0; k < NC; k++) prev.f[k] = 0;
+        for (int32_t k = 0; k < n; k++) {
+            const int64_t a = aN[k], b = bN[k], o = outN[k];
+            Col<REAL, NC> c1, c2;
+            if (a == prevOut) c1 = prev;
+            else if (a >= A.d.nSeqs) vft_load_row<REAL, NC>(A, a, p, c1);
+            else vft_load_col<REAL, NC>(A, a, p, c1);
+            if (b == prevOut) c2 = prev;
+            else if (b >= A.d.nSeqs) vft_load_row<REAL, NC>(A, b, p, c2);
+            else vft_load_col<REAL, NC>(A, b, p, c2);
+            REAL wo, f[NC];
+            int co;
+            vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
+            vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
+            prevOut = o;
+            prev.w = wo;
+            prev.code = co;
+            prev.vec = wo > 0 && co == VFT_NOCODE_;
+#pragma unroll
+            for (int k2 = 0; k2 < NC; k2++) prev.f[k2] = f[k2];
+        }
+    }
+    // the pair of this workgroup; its columns come from memory: what this thread stored above, or rows nobody touched
+    // (vft_pair_block with the same column -> thread mapping as the loop above: p = threadIdx.x + i * blockDim.x)
+    const int w = (int) blockIdx.x;
+    const int64_t i = q[w < 3 ? 0 : w < 5 ? 1 : 2], j = q[w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3];
+    REAL d, wt;
+    vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
+    if (threadIdx.x == 0) vft_stage_store<REAL>(stage, stageCap, w, d, wt, (REAL) 0);
+    vft_publish_staged<REAL>(stage, stageCap, 6, dist, dist + 6, (REAL *) nullptr, doneCtr, flag, seq);
+}
+
 // A short pair list and the out-distance refreshes it needs in ONE launch (the join loop makes three such calls per join
 // and each is a host round trip: a second, dependent launch is ~8 us of a ~33 us call).  Workgroups [0, nStale) refresh
 // the listed nodes exactly like k_refresh_list (the host put the distinct stale / forced nodes there) and then publish

@@ -1077,6 +1077,7 @@ namespace veryfasttree {
         int64_t laneSteps = 0, laneWork = 0;   /* lockstep steps / quartets or splits evaluated in them (all rounds so far) */
 
         int64_t nStarTests = 0;
+        bool walkStepFused = true;   /* meCriteria: averages + distances as one launch (false: two calls; tests compare) */
         bool sprOnDevice = true;    /* false: the host-driven SPR walk (tests compare the two) */
         int64_t sprPosPad = 1 << 30;   /* the context's padded column count (setSprPosPad); unknown: host walk */
         int64_t sprSteps = 0;
@@ -1321,8 +1322,26 @@ namespace veryfasttree {
             }
             const int64_t pi[6] = {q[0], q[0], q[0], q[1], q[1], q[2]}, pj[6] = {q[1], q[2], idD, q[2], idD, idD};
             REAL d[6], w[6];
-            flushAverages();
-            chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
+            /* the queued averages and the six distances as one launch (vft_walk_step) while every profile is a plain row */
+            bool fused = false;
+            if (walkStepFused) {
+                const int64_t q4[4] = {q[0], q[1], q[2], idD};
+                const int rc = vft_walk_step(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data(), q4, d);
+                if (rc == VFT_OK) {
+                    fused = true;
+                    qOut.clear();
+                    qA.clear();
+                    qB.clear();
+                } else if (rc == VFT_ERR_STATE) {
+                    walkStepFused = false;   /* (some profile lives in the tile streams: the two calls from here on) */
+                } else {
+                    chk(rc);
+                }
+            }
+            if (!fused) {
+                flushAverages();
+                chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
+            }
             double c[6];
             for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[i], scoredist);
             criteria[0] = c[0] + c[5];

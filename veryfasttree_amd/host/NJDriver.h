@@ -61,6 +61,9 @@ namespace veryfasttree {
         int aaModel = 0;
         /* multi-GPU (include/vft_host.h, vft_comm): sweeps and leaf blocks are split over the ranks */
         const vft_comm *comm = nullptr;
+        /* with comm: split the close-neighbour blocks of setAllLeafTopHits by rows and all-gather the results (round 3); off: every
+           rank computes them whole - 25 GB of gathers at a million sequences cost more than the ~5 s of integer counts they split */
+        bool shardLeafBlocks = false;
         /* the SPR rounds as one persistent kernel per round (vft_spr_round) instead of the host-driven walk.  Off by default:
            measured on MI355X the kernel needs ~50 us per chain step on its one CU, the host-driven walk ~45 us with six to eight
            CUs per step; both give the same tree (tests/test_gpu_threads.py) */
@@ -1884,7 +1887,7 @@ namespace veryfasttree {
            all-gathered through the host buffers (whole rows, padded to equal shares).  Returns the device's code. */
         int leafBlock(int64_t nA, const int64_t *a, int64_t nB, const int64_t *b, int64_t n, REAL *pd, REAL *pw, REAL *pc) {
             const vft_comm *cm = opt.comm;
-            if (!cm || cm->world <= 1) return vft_leaf_block_distances(ctx, nA, a, nB, b, n, nDiffAllow(n), totdiam, pd, pw, pc);
+            if (!cm || cm->world <= 1 || !opt.shardLeafBlocks) return vft_leaf_block_distances(ctx, nA, a, nB, b, n, nDiffAllow(n), totdiam, pd, pw, pc);
             const int64_t W = cm->world, per = (nA + W - 1) / W;
             const int64_t share = per * nB * (int64_t) sizeof(REAL);   /* bytes of ONE array of one rank */
             if (3 * share > cm->h_cap) return -1;                       /* the caller takes fewer rows at a time */
@@ -2003,7 +2006,7 @@ namespace veryfasttree {
                         pc.resize((size_t) (nNb * K));
                         /* rows of at most ~4M pairs per call keep the result block (3 arrays) within a few tens of MB */
                         int64_t rows = std::max<int64_t>(1, (int64_t) (4000000 / K));
-                        if (opt.comm && opt.comm->world > 1)   /* the shares of all ranks must fit the host exchange buffer */
+                        if (opt.comm && opt.comm->world > 1 && opt.shardLeafBlocks)   /* the shares of all ranks must fit the host exchange buffer */
                             rows = std::max<int64_t>(opt.comm->world, std::min<int64_t>(rows, opt.comm->h_cap / (3 * K * (int64_t) sizeof(REAL)) - opt.comm->world));
                         for (int64_t a0 = 0; a0 < nNb && block; a0 += rows) {
                             const int64_t cnt = std::min<int64_t>(rows, nNb - a0);
