@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [devspr]
+"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [devspr] [mu=M] [seed=S]
 (devspr: the SPR rounds as persistent kernels, vft_nj_options.debug_flags bit 8; VFT_SPR_REPORT=1 prints their tick counters)"""
 import os, sys, time, json
 import numpy as np
@@ -12,7 +12,8 @@ rest = sys.argv[3:]
 aa = "aa" in rest
 T = max([int(a) for a in rest if a.isdigit()] or [1])
 dt = np.float64 if "f64" in rest else np.float32
-codes = synth.random_descent_codes(n, L, 20 if aa else 4, 0.03, 0.01, seed=2)
+kv = dict(a.split("=") for a in rest if "=" in a)   # mu=0.02 seed=4: config C4's alignment
+codes = synth.random_descent_codes(n, L, 20 if aa else 4, float(kv.get("mu", 0.03)), 0.01, seed=int(kv.get("seed", 2)))
 names = ["s%d" % k for k in range(n)]
 kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, threads=T, return_loglk=True, debug_flags=8 if "devspr" in rest else 0)
 if aa:
@@ -22,4 +23,5 @@ elif "gtr" in rest:
 t0 = time.perf_counter()
 tree, ll = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m), codes, names, **kw)
 print("%d x %d %s %s threads=%d: %.1f s, TreeLogLk %.4f" % (n, L, "aa" if aa else "nt", " ".join(r for r in rest if not r.isdigit()), T, time.perf_counter() - t0, ll[-1]))
-print(json.dumps(last_stage_seconds()))
+import zlib
+print(json.dumps(dict(last_stage_seconds(), newick_bytes=len(tree), newick_crc=zlib.crc32(tree.encode()), tree_loglk=[round(float(x), 4) for x in ll])))

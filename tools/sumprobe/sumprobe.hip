@@ -54,6 +54,21 @@ __global__ __launch_bounds__(512) void probe(unsigned long long *out, int n, dou
                 }
             }
         }
+        else if (MODE == 4) {   // a rotating window of eight 16-byte reads: every pair of adds waits for the OLDEST read only
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2 *src = (const d2 *) lds;
+            d2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6], v7 = src[7];
+            const int n2 = n / 2;
+            int p = 0;
+            for (; p + 16 <= n2; p += 8) {
+#define STEP(V, K) acc += V.x; acc += V.y; V = src[p + 8 + K]; __builtin_amdgcn_sched_barrier(0);
+                STEP(v0, 0) STEP(v1, 1) STEP(v2, 2) STEP(v3, 3) STEP(v4, 4) STEP(v5, 5) STEP(v6, 6) STEP(v7, 7)
+#undef STEP
+            }
+            acc += v0.x; acc += v0.y; acc += v1.x; acc += v1.y; acc += v2.x; acc += v2.y; acc += v3.x; acc += v3.y;
+            acc += v4.x; acc += v4.y; acc += v5.x; acc += v5.y; acc += v6.x; acc += v6.y; acc += v7.x; acc += v7.y;
+            for (p = (p + 8) * 2; p < n; p++) acc += lds[p];
+        }
         c1 = clock64();
     }
     __syncthreads();
@@ -75,7 +90,7 @@ int main() {
     hipLaunchKernelGGL(probe<M>, dim3(1), dim3(block), 2 * n * sizeof(double), 0, d, n, 0.5);              \
     hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);                                                            \
     printf("  mode %d: %6llu cycles (%.1f per term)", M, h[0], (double) h[0] / n);
-            RUN(0) RUN(1) RUN(2) RUN(3)
+            RUN(0) RUN(1) RUN(3) RUN(4)
             printf("\n");
         }
     return 0;
