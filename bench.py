@@ -239,6 +239,8 @@ def end_to_end(which, device, comm=None):
         want = int(g["newick_crc"])
         out["reference_newick_crc"] = want
         out["identical_to_reference"] = bool(want == crc)
+        if "flags" in g:
+            out["reference_tree_flags"] = bytes(g["flags"]).decode()
         if "reference_wall_s" in g:
             out["reference_wall_s_1_thread"] = round(float(g["reference_wall_s"]), 1)
     # the join order against the reference's `Join` trace as far as the reference got (C4: the one-thread reference needs more than

@@ -490,6 +490,35 @@ def gen_c4(tmp):
     print("bb_c4_crc: %d bytes of Newick, crc %d, %d joins, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ja), wall))
 
 
+def gen_c4_tree(tmp):
+    """bb_c4_crc.npz from what the reference runs of config C4 have left under oracle/_ref/:
+      c4_nj_t6.tree        the tree of `VeryFastTree -nt -noml -nome -nosupport -threads 6 -seed 1` (the reference binary itself, quiet: the
+                           one-thread run with `Join` lines needs ~17 h; the NJ-only tree does not depend on the thread count - SURVEY.md
+                           section 0, checked again this round at 20 000 and 60 000 sequences: one tree for -threads 1 and 4)
+      c4_joins_t1_r03.txt  the `Join` lines of the one-thread run as far as it got in round 3 (594 643 of 999 014)
+    newick_crc pins the complete 26 MB tree (topology and branch lengths of all 999 017 unique sequences), join_chunk_crc the join
+    order over the traced prefix."""
+    import zlib
+    tree = open(os.path.join(HERE, "_ref", "c4_nj_t6.tree"), "rb").read().decode().strip()
+    assert tree.endswith(";") and tree.count(",") > 900000, "the reference has not finished"
+    joins = []
+    for line in open(os.path.join(HERE, "_ref", "c4_joins_t1_r03.txt")):
+        f = line.rstrip("\n").split("\t")
+        if len(f) < 11 or not line.endswith("\n"):
+            break
+        joins.append((int(f[1]), int(f[2]), int(f[10])))
+    chunk = 10000
+    ja = np.array(joins[:len(joins) // chunk * chunk], dtype=np.int64)
+    crcs = np.array([zlib.crc32(ja[k:k + chunk].astype("<i4").tobytes()) for k in range(0, len(ja), chunk)], dtype=np.int64)
+    flags = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "6", "-seed", "1"]
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c4_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+                        n_joins=np.int64(len(ja)), join_chunk=np.int64(chunk), join_chunk_crc=crcs,
+                        flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        join_trace_flags=np.frombuffer(b"-nt -noml -nome -nosupport -threads 1 -seed 1 -verbose 3", dtype=np.uint8),
+                        alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8))
+    print("bb_c4_crc: %d bytes of Newick, crc %d; join order over %d joins" % (len(tree), zlib.crc32(tree.encode()), len(ja)))
+
+
 def gen_c4_prefix(tmp):
     """The part of gen_c4's run that exists so far (oracle/_ref/c4_joins.txt grows while the reference works: the 1M-taxa NJ
     phase takes it more than half a day at one thread): CRC-32 per 10 000 complete `Join` lines.  Pins the join order of
@@ -545,6 +574,8 @@ def main():
             gen_c2(tmp)
         if "c4" in which:   # not part of the default set: hours
             gen_c4(tmp)
+        if "c4_tree" in which:   # from the files a finished reference run left under oracle/_ref/
+            gen_c4_tree(tmp)
         if "c4_prefix" in which:   # from the Join lines a running gen_c4 has produced so far
             gen_c4_prefix(tmp)
 

@@ -202,3 +202,46 @@ def test_c4_join_order_equals_the_reference_trace():
     assert len(joins) == n_check
     for k in range(n_check // chunk):
         assert zlib.crc32(joins[k * chunk:(k + 1) * chunk].astype("<i4").tobytes()) == int(want[k]), "joins %d..%d differ from the reference's" % (k * chunk, (k + 1) * chunk)
+
+
+def _c2_alignment():
+    from veryfasttree_amd import synth
+    return synth.random_descent_codes(10000, 1000, 4, 0.03, 0.01, seed=2)
+
+
+def test_c2_tree_equals_the_reference_tree():
+    """BASELINE config C2 at full size with its exact flags (10 000 nt x 1 000, `-nt -gtr`, float32, one-thread order): the complete
+    default pipeline - NJ, ME NNIs + SPRs, ML NNIs with CAT and the fitted GTR model, SH-like supports - must print the reference's
+    289 KB tree byte for byte (CRC-32 and length of the reference binary's own output, tests/golden/bb_c2_crc.npz, oracle/gen_fixtures.py
+    c2; 221 s of one core there).  This is bench.py's `e2e_c2`."""
+    import zlib
+    import golden_util as G
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick
+    ref = G.load("bb_c2_crc")
+    codes = _c2_alignment()
+    names = ["s%d" % k for k in range(len(codes))]
+    tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m), codes, names, me_lengths=True, me_nni=True,
+                            spr=2, ml_nni=20, gtr=True, n_bootstrap=1000, return_loglk=True)
+    assert abs(loglk[-1] - ref["loglk"][-1]) <= 1e-4 * abs(ref["loglk"][-1])   # the north star's bar
+    assert len(tree) == int(ref["newick_bytes"])
+    assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
+
+
+def test_c2_shape_on_the_64_thread_schedule_equals_the_reference_run():
+    """10 000 nt x 1 000 under Jukes-Cantor (config C2's shape; `-gtr` is not reproducible in the reference at T > 1) on the schedule of
+    a 64-thread run: this backend (threads = 64: the walks of the reference's tree partitions in lockstep, host/MLLengths.h) against
+    the compiled reference run HERE with `-threads 64` - the printed trees, SH supports included, byte for byte.  Needs oracle/_ref
+    (travels with the snapshot) and a box with a few dozen cores; about 1.5 minutes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "VeryFastTree")):
+        pytest.skip("the compiled reference is not on this box")
+    if (os.cpu_count() or 1) < 16:
+        pytest.skip("too few cores for a 64-thread run of the reference")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "compare_with_reference_run.py"), "10000", "1000", "--threads", "64"],
+                         check=True, stdout=subprocess.PIPE, timeout=1200).stdout.decode()
+    print(out)
+    assert "byte-identical output: YES" in out
