@@ -138,6 +138,13 @@ int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t
    for (tests/golden/bb_c4_prefix.npz).  crcs[cap] may be NULL. */
 int vft_nj_last_join_crcs(int64_t *chunk, int64_t *n_joins, uint32_t *crcs, int64_t cap, int64_t *n_crcs);
 
+/* The reference's treePartitioning(penalty) (NJ.tcc:5540-5750) for `threads` threads on a tree given as child[n_nodes][3] (-1 = none;
+   the root has three children): the roots of the subtrees its threads walk, in its hand-out order (round-robin over the threads'
+   lists), window = -threads-ptw (0: the default 50).  Pure host code - what MLLengths::doNNIThreaded / optimizeRoundThreaded make
+   their lanes from (penalty 2 / 1).  out[cap] may be NULL to query *n_out. */
+int vft_tree_partitioning(int64_t n_nodes, const int64_t *child, int64_t root, int32_t penalty, int32_t threads, int32_t window,
+                          int64_t *out, int64_t cap, int64_t *n_out, double *speedup);
+
 /* Where the wall-clock of the last vft_nj_newick / vft_nj_ml_newick of this process went.  seconds[8]: the NJ phase with its root;
    the minimum-evolution NNI + SPR rounds, of which the SPR rounds; ME branch lengths + local supports; the whole ML stage, of which
    the ML NNI rounds, the SH-like supports, the model fits (CAT rates, GTR).  counts[4]: lockstep steps of the subtree schedule

@@ -76,6 +76,26 @@ def gen_whitebox(tmp):
         print("%-20s %4d arrays  %7.1f KiB" % (name, len(d), os.path.getsize(dst) / 1024.0))
 
 
+PARTITION_CASES = [("wb_partition_40", 40, 60, 0.10, 91), ("wb_partition_300", 300, 100, 0.06, 92), ("wb_partition_2000", 2000, 60, 0.04, 93)]
+
+
+def gen_partition(tmp):
+    """White box: the reference's own treePartitioning(penalty) (NJ.tcc:5540-5750, a private member called through oracle/whitebox.cpp)
+    on the NJ tree of three alignments, penalty 1 and 2, for 2 ... 64 threads - what vft_tree_partitioning has to return."""
+    for name, n, L, mu, seed in PARTITION_CASES:
+        codes = synth.random_descent_codes(n, L, 4, mu, 0.01, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+        vfx = os.path.join(tmp, name + ".vfx")
+        subprocess.run([WHITEBOX, "nt_f32:partition", fa, vfx, str(seed)], check=True)
+        d = read_vfx(vfx)
+        keep = {k: v for k, v in d.items() if k.startswith("part.") or k in ("nj.child", "nj.parent", "nj.root", "nj.nchild", "nSeqs")}
+        dst = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(dst, **keep)
+        print("%-20s %4d arrays  %7.1f KiB; subtrees at 8 threads, penalty 2: %d" % (name, len(keep), os.path.getsize(dst) / 1024.0,
+                                                                                     int((keep["part.T8.p2"] >= 0).sum())))
+
+
 def gen_knuth(tmp):
     """5000 values of the reference's knuth_rand() stream (Knuth.cpp; never re-seeded by the pipeline)."""
     vfx = os.path.join(tmp, "knuth.vfx")
@@ -542,7 +562,7 @@ def gen_c4_prefix(tmp):
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa", "threads"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa", "threads", "partition"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -550,6 +570,8 @@ def main():
             gen_blackbox(tmp)
         if any(w.startswith("bb_") for w in which):
             gen_blackbox(tmp, [w for w in which if w.startswith("bb_")])
+        if "partition" in which:
+            gen_partition(tmp)
         if "knuth" in which:
             gen_knuth(tmp)
         if "tables" in which:

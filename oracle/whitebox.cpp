@@ -479,7 +479,7 @@ struct Harness {
 };
 
 template<typename P, template<class> class Op>
-static int run(Options &options, const std::string &fasta, const std::string &outPath, uint64_t seed, bool aa) {
+static int run(Options &options, const std::string &fasta, const std::string &outPath, uint64_t seed, bool aa, bool partitionOnly = false) {
     typedef Op<P> op_t;
     std::ostringstream logbuf;
     std::ostream &log = logbuf;
@@ -578,6 +578,19 @@ static int run(Options &options, const std::string &fasta, const std::string &ou
     /* ---- the reference builds its NJ tree; every internal profile is then a real averageProfile output */
     nj.fastNJ();
     h.dumpNodeArrays("nj");
+    if (partitionOnly) {
+        /* treePartitioning (NJ.tcc:5540-5750, private) as the reference's threaded NNI / length rounds call it: penalty 2 and 1, for
+           several thread counts - the partitions the subtree schedule of the backend has to reproduce */
+        const int Ts[] = {2, 3, 4, 8, 16, 64};
+        for (int T: Ts)
+            for (int penalty = 1; penalty <= 2; penalty++) {
+                options.threads = T;
+                std::vector<int64_t> part = nj.treePartitioning(penalty);
+                out.vec("part.T" + std::to_string(T) + ".p" + std::to_string(penalty), part);
+            }
+        options.threads = 1;
+        return 0;
+    }
     h.dumpAllProfileHashes("nj.profiles", nj.maxnode - 1);
     {
         /* a handful of complete internal profiles: early, middle and late joins */
@@ -742,7 +755,7 @@ int main(int argc, char **argv) {
     options.nBootstrap = 0;
     options.extension = "whitebox";
     bool aa = mode.substr(0, 2) == "aa";
-    bool dbl = mode.substr(3) == "f64";
+    bool dbl = mode.substr(3, 3) == "f64";
     options.nCodes = aa ? 20 : 4;
     options.doublePrecision = dbl;
     options.bUseLg = aa;
@@ -764,6 +777,7 @@ int main(int argc, char **argv) {
     }
     /* backends exactly as the dispatcher picks them (VeryFastTree.cpp:46-66): nt float -> SSE3,
        everything else with AVX available -> AVX2 */
+    if (mode == "nt_f32:partition") return run<float, SSE128Operations>(options, argv[2], argv[3], seed, false, true);
     if (mode == "nt_f32") return run<float, SSE128Operations>(options, argv[2], argv[3], seed, false);
     if (mode == "nt_f64") return run<double, AVX256Operations>(options, argv[2], argv[3], seed, false);
     if (mode == "aa_f32") return run<float, SSE128Operations>(options, argv[2], argv[3], seed, true);

@@ -822,11 +822,12 @@ namespace veryfasttree {
                 if (rc == VFT_ERR_STATE) goto hostWalk;   /* a profile without a row: the kernel has refused before touching anything */
                 chk(rc);
                 sprSteps += out[1];
-                if (std::getenv("VFT_SPR_REPORT"))   /* tools: where the kernel's time goes */
+                if (std::getenv("VFT_SPR_REPORT")) {   /* tools: where the kernel's time goes */
                     fprintf(stderr, "SPR round on the device: %lld moves, %lld steps, %lld averages, %lld commands; %.3f s in all, %.3f s inside commands\n",
                             (long long) out[0], (long long) out[1], (long long) out[2], (long long) out[6], 1e-8 * (double) out[5], 1e-8 * (double) out[4]);
                     fprintf(stderr, "  thread 0 inside commands: columns %.3f s, barrier %.3f s, sums %.3f s, barrier %.3f s\n", 1e-8 * (double) out[7], 1e-8 * (double) out[8], 1e-8 * (double) out[9], 1e-8 * (double) out[10]);
                     fprintf(stderr, "  shader clock during the walk: %.0f MHz\n", out[5] > 0 ? 100.0 * (double) out[11] / (double) out[5] : 0.0);
+                }
                 rebuildOrder();
                 return out[0];
             }
@@ -853,6 +854,13 @@ namespace veryfasttree {
 
         /* treePartitioning: roots of the subtrees, in the order the reference hands them to its threads */
         std::vector<int64_t> treePartitioning(int penalty, int threads, int window = 50) {
+            return partitionTree(nNodes, child, root, order, penalty, threads, window, &partitionSpeedup);
+        }
+
+        /* the algorithm itself, on plain arrays (exported as vft_tree_partitioning for the CPU test that pins it to the reference's
+           own partitions, tests/test_abi_cpu.py): child[nNodes][3], order = internal nodes in post-order, the root last */
+        static std::vector<int64_t> partitionTree(int64_t nNodes, const std::vector<int64_t> &child, int64_t root, const std::vector<int64_t> &order,
+                                                  int penalty, int threads, int window, double *speedupOut) {
             const size_t N = (size_t) nNodes;
             std::vector<int64_t> size(N, 1), depth(N, 0);
             for (int64_t v: order) {   /* children before parents */
@@ -962,7 +970,7 @@ namespace veryfasttree {
                     }
                 if (!any) break;
             }
-            partitionSpeedup = bestSpeedup;
+            if (speedupOut) *speedupOut = bestSpeedup;
             return out;
         }
 

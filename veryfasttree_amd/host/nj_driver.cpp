@@ -68,6 +68,32 @@ extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *
 static double gStage[8];
 static int64_t gLanes[4];
 
+/* treePartitioning (NJ.tcc:5540-5750) on a tree given as arrays: pure host code, no context (tests pin it to the reference's own
+   partitions).  out[cap] receives the subtree roots in the reference's hand-out order. */
+extern "C" int vft_tree_partitioning(int64_t nNodes, const int64_t *childIn, int64_t root, int32_t penalty, int32_t threads, int32_t window,
+                                     int64_t *out, int64_t cap, int64_t *nOut, double *speedup) {
+    if (nNodes < 4 || !childIn || root < 0 || root >= nNodes || penalty < 0 || threads < 1 || !nOut) return VFT_ERR_INVALID;
+    std::vector<int64_t> child(childIn, childIn + 3 * nNodes), order;
+    std::vector<std::pair<int64_t, int>> stack(1, std::make_pair(root, 0));
+    while (!stack.empty()) {   /* post-order of the internal nodes, children in stored order */
+        const int64_t v = stack.back().first;
+        const int k = stack.back().second;
+        if (k < 3 && child[3 * v + k] >= 0) {
+            stack.back().second++;
+            stack.push_back(std::make_pair(child[3 * v + k], 0));
+        } else {
+            stack.pop_back();
+            if (child[3 * v] >= 0) order.push_back(v);
+        }
+    }
+    double sp = 0;
+    const std::vector<int64_t> res = veryfasttree::MLLengths<float>::partitionTree(nNodes, child, root, order, penalty, threads, window > 0 ? window : 50, &sp);
+    *nOut = (int64_t) res.size();
+    if (speedup) *speedup = sp;
+    for (int64_t k = 0; out && k < cap && k < (int64_t) res.size(); k++) out[k] = res[(size_t) k];
+    return VFT_OK;
+}
+
 extern "C" int vft_nj_last_stage_seconds(double *seconds, int64_t *counts) {
     if (seconds)
         for (int i = 0; i < 8; i++) seconds[i] = gStage[i];
