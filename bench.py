@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-e2e-c4", action="store_true", help="skip the 1M x 200 end-to-end tree (minutes), keep C3's")
     ap.add_argument("--no-dense", action="store_true", help="skip the phi ~ 1 roofline of the sweep kernel")
     ap.add_argument("--no-e2e-full", action="store_true", help="skip the complete pipelines of configs C2 and C5 (~3.5 minutes)")
+    ap.add_argument("--e2e-c4-full", action="store_true", help="also the complete -nt pipeline of config C4 (1M x 200; ~18 minutes on one GPU)")
     return ap.parse_args()
 
 
@@ -262,6 +263,8 @@ E2E_FULL = {
     # (host/MLLengths.h "the subtree schedule": the walks of T-thread partitions advanced in lockstep, batches of quartets on the GPU).
     "c2": dict(n=10000, L=1000, nc=4, seed=2, dtype="float32", gtr=True, aa=None, threads=64, flags="-nt -gtr", golden="bb_c2_crc.npz"),
     "c5": dict(n=50000, L=300, nc=20, seed=2, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden=None),
+    # config C4 with its real flags (--e2e-c4-full: 18 minutes; profiles/r04_c4_full_flags.txt holds a run)
+    "c4": dict(n=1000000, L=200, nc=4, seed=4, mu=0.02, dtype="float32", gtr=False, aa=None, threads=1024, flags="-nt", golden=None),
 }
 
 
@@ -276,7 +279,7 @@ def end_to_end_full(which, device, one_thread):
     from veryfasttree_amd.backend import nj_newick, last_stage_seconds
     cfg = E2E_FULL[which]
     dt = np.float64 if cfg["dtype"] == "float64" else np.float32
-    codes = synth.random_descent_codes(cfg["n"], cfg["L"], cfg["nc"], 0.03, 0.01, seed=cfg["seed"])
+    codes = synth.random_descent_codes(cfg["n"], cfg["L"], cfg["nc"], cfg.get("mu", 0.03), 0.01, seed=cfg["seed"])
     names = ["s%d" % k for k in range(cfg["n"])]
     T = 1 if one_thread else cfg["threads"]
     kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True, threads=T)
@@ -548,7 +551,10 @@ def main():
             line[key] = e2e
         if not args.no_e2e_full and not use_dist:
             # the complete pipelines (refinement + maximum likelihood) of configs C2 and C5: not sharded, rank 0 only
-            for key, which, one in (("e2e_c2", "c2", True), ("e2e_c2_threads", "c2", False), ("e2e_c5_threads", "c5", False)):
+            legs = [("e2e_c2", "c2", True), ("e2e_c2_threads", "c2", False), ("e2e_c5_threads", "c5", False)]
+            if args.e2e_c4_full:
+                legs.append(("e2e_c4_full_threads", "c4", False))
+            for key, which, one in legs:
                 try:
                     line[key] = end_to_end_full(which, local_rank, one)
                 except Exception as exc:
