@@ -244,6 +244,11 @@ def end_to_end(which, device, comm=None):
             out["reference_tree_flags"] = bytes(g["flags"]).decode()
         if "reference_wall_s" in g:
             out["reference_wall_s_1_thread"] = round(float(g["reference_wall_s"]), 1)
+    t6 = os.path.join(ROOT, "tests", "golden", "bb_%s_t6.npz" % which)
+    if os.path.exists(t6):   # C4: the reference at six threads - a different tree than its own one-thread run (oracle/gen_fixtures.py c4_tree)
+        g = np.load(t6)
+        out["reference_tree_at_6_threads"] = dict(newick_crc=int(g["newick_crc"]), identical=bool(int(g["newick_crc"]) == crc),
+                                                  one_thread_traced_joins_not_in_it=int(len(g["one_thread_traced_joins_not_in_this_tree"])))
     # the join order against the reference's `Join` trace as far as the reference got (C4: the one-thread reference needs more than
     # half a day for the million-sequence NJ phase; tests/golden/bb_c4_prefix.npz holds CRC-32s per 10 000 joins of what it wrote)
     pre = os.path.join(ROOT, "tests", "golden", "bb_%s_prefix.npz" % which)

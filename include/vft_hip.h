@@ -443,6 +443,7 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_FAULT_NO_FLAG 5      /* value != 0: fault injection - the next wait for a completion flag waits for a value no kernel publishes */
 #define VFT_DEBUG_WAIT_LIMIT_MS 6      /* the longest a wait for a completion flag may last while the stream is busy (default 120 000) */
 #define VFT_DEBUG_WIDE_GLUE 7          /* value != 0: vft_nj_engine_create takes the 1 024-thread glue kernel (lists beyond 1 024 hits) at any size */
+#define VFT_DEBUG_WALK_IDS_IN_RING 8  /* value != 0: vft_walk_step reads its ids from the mapped ring and publishes through the staging buffer at any step length (the path of steps with more than 16 averages) */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */

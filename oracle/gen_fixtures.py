@@ -511,13 +511,13 @@ def gen_c4(tmp):
 
 
 def gen_c4_tree(tmp):
-    """bb_c4_crc.npz from what the reference runs of config C4 have left under oracle/_ref/:
-      c4_nj_t6.tree        the tree of `VeryFastTree -nt -noml -nome -nosupport -threads 6 -seed 1` (the reference binary itself, quiet: the
-                           one-thread run with `Join` lines needs ~17 h; the NJ-only tree does not depend on the thread count - SURVEY.md
-                           section 0, checked again this round at 20 000 and 60 000 sequences: one tree for -threads 1 and 4)
-      c4_joins_t1_r03.txt  the `Join` lines of the one-thread run as far as it got in round 3 (594 643 of 999 014)
-    newick_crc pins the complete 26 MB tree (topology and branch lengths of all 999 017 unique sequences), join_chunk_crc the join
-    order over the traced prefix."""
+    """bb_c4_t6.npz: the tree of `VeryFastTree -nt -noml -nome -nosupport -threads 6 -seed 1` for config C4's alignment (the reference
+    binary itself, 12 200 s on six cores; oracle/_ref/c4_nj_t6.tree).  NOT a pin of the one-thread order: at a million sequences the
+    reference's NJ phase depends on the thread count - 14 of the 594 643 joins its own one-thread run traced in round 3
+    (oracle/_ref/c4_joins_t1_r03.txt) are not clades of this tree, the first one join 293 793 (tools/c4_clades.py,
+    profiles/r04_c4_pin.txt; at 200 000 sequences the two thread counts still give the same splits and lengths, see gen_c4_scaled).
+    Kept as a record: CRC and length of the 26 MB tree, and the per-10 000 CRCs of the one-thread `Join` trace (the same numbers as
+    bb_c4_prefix.npz, from the finished file)."""
     import zlib
     tree = open(os.path.join(HERE, "_ref", "c4_nj_t6.tree"), "rb").read().decode().strip()
     assert tree.endswith(";") and tree.count(",") > 900000, "the reference has not finished"
@@ -531,12 +531,50 @@ def gen_c4_tree(tmp):
     ja = np.array(joins[:len(joins) // chunk * chunk], dtype=np.int64)
     crcs = np.array([zlib.crc32(ja[k:k + chunk].astype("<i4").tobytes()) for k in range(0, len(ja), chunk)], dtype=np.int64)
     flags = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "6", "-seed", "1"]
-    np.savez_compressed(os.path.join(GOLDEN, "bb_c4_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c4_t6.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
                         n_joins=np.int64(len(ja)), join_chunk=np.int64(chunk), join_chunk_crc=crcs,
+                        one_thread_traced_joins_not_in_this_tree=np.array([293793, 299441, 323356, 335439, 367072, 383275, 386516, 391329,
+                                                                           401229, 428835, 439930, 487421, 527439, 545714], dtype=np.int64),
                         flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
                         join_trace_flags=np.frombuffer(b"-nt -noml -nome -nosupport -threads 1 -seed 1 -verbose 3", dtype=np.uint8),
                         alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8))
-    print("bb_c4_crc: %d bytes of Newick, crc %d; join order over %d joins" % (len(tree), zlib.crc32(tree.encode()), len(ja)))
+    print("bb_c4_t6: %d bytes of Newick, crc %d; join order over %d joins" % (len(tree), zlib.crc32(tree.encode()), len(ja)))
+
+
+def gen_c4_scaled(tmp, sizes=(200000, 400000)):
+    """Config C4's generator and flags at sizes the one-thread reference finishes in an hour or two (200 000: 2 080 s; 400 000:
+    see reference_wall_s): `VeryFastTree -nt -noml -nome -nosupport -threads 1 -seed 1`, CRC and length of the tree
+    (bb_c4_200k_crc.npz, bb_c4_400k_crc.npz).  A finished tree under oracle/_ref/c4_<n>k_t1.tree is reused (its wall-clock then comes
+    from the log line next to it, or 0)."""
+    import time
+    import zlib
+    for n in sizes:
+        keep = os.path.join(HERE, "_ref", "c4_%dk_t1.tree" % (n // 1000))
+        flags = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "1", "-seed", "1"]
+        wall = 0.0
+        if os.path.exists(keep) and os.path.getsize(keep) > 0:
+            tree = open(keep).read().strip()
+            if os.path.exists(keep + ".wall"):
+                wall = float(open(keep + ".wall").read())
+        else:
+            if n > 200000 and "c4_scaled_all" not in sys.argv:
+                print("c4 at %d sequences: no finished tree under oracle/_ref (add c4_scaled_all to run the reference: more than an hour)" % n)
+                continue
+            codes = synth.random_descent_codes(n, 200, 4, 0.02, 0.01, seed=4)
+            fa = os.path.join(tmp, "c4s.fa")
+            synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+            t0 = time.time()
+            res = subprocess.run([REFBIN] + flags + [fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.time() - t0
+            tree = res.stdout.decode().strip()
+            open(keep, "w").write(tree + "\n")
+            open(keep + ".wall", "w").write("%.1f" % wall)
+        assert tree.endswith(";")
+        np.savez_compressed(os.path.join(GOLDEN, "bb_c4_%dk_crc.npz" % (n // 1000)), newick_crc=np.int64(zlib.crc32(tree.encode())),
+                            newick_bytes=np.int64(len(tree)), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                            alignment=np.frombuffer(("random_descent_codes(%d, 200, 4, 0.02, 0.01, seed=4)" % n).encode(), dtype=np.uint8),
+                            reference_wall_s=np.float64(wall))
+        print("bb_c4_%dk_crc: %d bytes of Newick, crc %d" % (n // 1000, len(tree), zlib.crc32(tree.encode())))
 
 
 def gen_c4_prefix(tmp):
@@ -598,6 +636,8 @@ def main():
             gen_c4(tmp)
         if "c4_tree" in which:   # from the files a finished reference run left under oracle/_ref/
             gen_c4_tree(tmp)
+        if "c4_scaled" in which or "c4_scaled_all" in which:   # 35 minutes of one core (200 000), more with c4_scaled_all
+            gen_c4_scaled(tmp)
         if "c4_prefix" in which:   # from the Join lines a running gen_c4 has produced so far
             gen_c4_prefix(tmp)
 

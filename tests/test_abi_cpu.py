@@ -36,7 +36,7 @@ def test_host_driver_library_exports_its_header(lib):
     host = backend.load_host_library()
     text = open(os.path.join(ROOT, "include", "vft_host.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth|ml|gtr|aa|blosum45)_[a-z0-9_]+)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b(vft_(?:nj|knuth|ml|gtr|aa|blosum45|tree)_[a-z0-9_]+)\s*\(", text)))
     assert names == sorted(backend.HOST_EXPORTS)
     assert all(hasattr(host, n) for n in names)
 

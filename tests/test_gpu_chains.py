@@ -87,12 +87,16 @@ def test_average_chains_equal_single_chains(dt, nc):
     ops.close()
 
 
+@pytest.mark.parametrize("ring", [0, 1])
 @pytest.mark.parametrize("dt,nc", [(np.float32, 4), (np.float64, 4), (np.float32, 20), (np.float64, 20)])
-def test_walk_step_equals_chain_plus_distances(dt, nc):
+def test_walk_step_equals_chain_plus_distances(dt, nc, ring):
+    """steps of up to 16 averages travel in the kernel arguments (k_walk_step_args), longer ones through the mapped ring (k_walk_step;
+    ring = 1: every step that way)"""
     ops, rng, free = make_state(dt, nc)
-    for trial in range(6):
-        n = [0, 1, 2, 5, 9, 3][trial]
-        base1, base2 = free + 20 * trial, free + 120 + 20 * trial
+    assert ops.lib.vft_debug_option(ops.ctx, I32(8), I64(ring)) == 0
+    for trial in range(7):
+        n = [0, 1, 2, 5, 9, 3, 19][trial]
+        base1, base2 = free + 20 * trial, free + 140 + 20 * trial
         a = rng.integers(0, free, n).astype(np.int64)
         b = rng.integers(0, free, n).astype(np.int64)
 

@@ -154,6 +154,28 @@ def test_c3_tree_equals_the_reference_tree():
     assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
 
 
+@pytest.mark.parametrize("n", [200000, 400000])
+def test_c4_generator_tree_equals_the_reference_tree(n):
+    """Config C4's alignment generator and flags (`-nt`, default top hits) at the sizes the one-thread reference finishes in an hour
+    or two: NJ phase, root, minimum-evolution lengths, Newick - byte for byte the reference's tree (CRC-32 and length of
+    oracle/_ref/VeryFastTree's own output, oracle/gen_fixtures.py c4_scaled).  The million-sequence run itself is pinned by its join
+    order as far as the one-thread reference got (bench.py e2e_c4, bb_c4_prefix.npz)."""
+    import os
+    import zlib
+    import golden_util as G
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick
+    name = "bb_c4_%dk_crc" % (n // 1000)
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")):
+        pytest.skip("no fixture at this size")
+    ref = G.load(name)
+    codes = synth.random_descent_codes(n, 200, 4, 0.02, 0.01, seed=4)
+    names = ["s%d" % k for k in range(n)]
+    tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m), codes, names, fastest=False, me_lengths=True)
+    assert len(tree) == int(ref["newick_bytes"])
+    assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
+
+
 @pytest.mark.parametrize("mode", [[], ["fastest"], ["fastest", "second"]])
 def test_nj_driver_join_order_is_rank_count_independent(mode):
     """The C++ NJ driver with its sweeps and leaf blocks split over two ranks (vft_comm over torch.distributed; both ranks

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [devspr] [mu=M] [seed=S]
+"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [devspr] [ring] [mu=M] [seed=S]
 (devspr: the SPR rounds as persistent kernels, vft_nj_options.debug_flags bit 8; VFT_SPR_REPORT=1 prints their tick counters)"""
 import os, sys, time, json
 import numpy as np
@@ -21,7 +21,13 @@ if aa:
 elif "gtr" in rest:
     kw["gtr"] = True
 t0 = time.perf_counter()
-tree, ll = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m), codes, names, **kw)
+def make(m, Lp):
+    ops = HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m)
+    if "ring" in rest:   # VFT_DEBUG_WALK_IDS_IN_RING: every walk step through the long-step kernel
+        import ctypes
+        assert ops.lib.vft_debug_option(ops.ctx, ctypes.c_int32(8), ctypes.c_int64(1)) == 0
+    return ops
+tree, ll = nj_newick(make, codes, names, **kw)
 print("%d x %d %s %s threads=%d: %.1f s, TreeLogLk %.4f" % (n, L, "aa" if aa else "nt", " ".join(r for r in rest if not r.isdigit()), T, time.perf_counter() - t0, ll[-1]))
 import zlib
 print(json.dumps(dict(last_stage_seconds(), newick_bytes=len(tree), newick_crc=zlib.crc32(tree.encode()), tree_loglk=[round(float(x), 4) for x in ll])))

@@ -61,6 +61,7 @@ struct vft_ctx {
     bool faultNoFlag = false;      // VFT_DEBUG_FAULT_NO_FLAG: the next wait for a completion flag waits for one that never comes
     double waitLimitS = 120.0;     // how long a wait for a completion flag may last while the stream is busy
     bool wideGlue = false;         // test hook: the 1 024-thread instance of k_nj_glue_scan at any size
+    bool walkIdsInRing = false;    // VFT_DEBUG_WALK_IDS_IN_RING: vft_walk_step takes the kernel of its long steps (k_walk_step) for every step
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -304,7 +305,7 @@ __global__ void k_signal(unsigned long long *flag, unsigned long long seq) {
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-static int wait_flag(vft_ctx *c, unsigned long long seq);
+static int wait_flag(vft_ctx *c, unsigned long long seq, int first = 0, int count = 1);
 static int wait_stream(vft_ctx *c) {
     const unsigned long long seq = ++c->signalSeq;
     launch(k_signal, dim3(1), dim3(1), 0, c->stream, c->dFlag, seq);
@@ -315,20 +316,26 @@ static int wait_stream(vft_ctx *c) {
 // The spin is bounded: a flag that a kernel never raises (a bug in one of the hand-written completion protocols, a faulted
 // kernel) comes back as VFT_ERR_TIMEOUT instead of hanging the caller - at once when the stream has drained without the flag
 // moving, after waitLimitS seconds (vft_debug_option(VFT_DEBUG_WAIT_LIMIT_MS)) when it is still busy.
-static int wait_flag(vft_ctx *c, unsigned long long seq) {
-    volatile unsigned long long *f = c->hFlag;
+// (first, count: the words of the flag block that have to reach seq - the stream's own flag, or the six of k_walk_step_args)
+static int wait_flag(vft_ctx *c, unsigned long long seq, int first, int count) {
+    volatile unsigned long long *f = c->hFlag + first;
     if (c->faultNoFlag) {   // test hook: wait for a value nobody will ever publish
         seq += 1ull << 40;
         c->faultNoFlag = false;
     }
+    auto raised = [&]() {
+        for (int k = 0; k < count; k++)
+            if (__atomic_load_n(f + k, __ATOMIC_ACQUIRE) < seq) return false;
+        return true;
+    };
     std::chrono::steady_clock::time_point t0;
     for (long spins = 0;; spins++) {
-        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= seq) return VFT_OK;
+        if (raised()) return VFT_OK;
         if (spins == 200000) t0 = std::chrono::steady_clock::now();   // (~ 0.1 s of spinning: start looking at the stream)
         if (spins >= 200000 && (spins & 0xFFFF) == 0) {
             const hipError_t e = hipStreamQuery(c->stream);
             if (e == hipSuccess) {   // everything enqueued has run: the flag is as high as it will ever get
-                if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= seq) return VFT_OK;
+                if (raised()) return VFT_OK;
                 return fail(c, VFT_ERR_TIMEOUT, "the stream has drained but the completion flag stands at %llu, not %llu",
                             (unsigned long long) *f, seq);
             }
@@ -487,9 +494,10 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
         s0.hResDev = c->hResDev;
         c->slots.assign(1, s0);
     }
-    CR(hipHostMalloc((void **) &c->hFlag, 64, hipHostMallocMapped));
+    // [0]: the stream's completion flag; [8..13]: the six workgroup flags of k_walk_step_args; [16..27]: its six {distance, weight}
+    CR(hipHostMalloc((void **) &c->hFlag, 512, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dFlag, c->hFlag, 0));
-    *c->hFlag = 0;
+    memset(c->hFlag, 0, 512);
     CR(dalloc(&c->doneCtr, 65));   // [0]: top level / single-level users, [1..64]: slots of vft_publish_staged
     CR(hipMalloc(&c->pairStage, 3 * VFT_PAIR_STAGE_CAP * sizeof(double)));   // staging of short pair lists' results (vft_publish_staged)
     CR(hipMalloc(&c->pairIn, VFT_SMALL_BYTES_));   // device copy of a short list's inputs
@@ -1239,7 +1247,75 @@ extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const in
         if (q[t] < 0 || q[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_walk_step: quartet member out of range");
     const size_t lds = (size_t) 2 * c->d.nPosPad * sizeof(double);
     if (lds > (160u << 10) - 1024) return fail(c, VFT_ERR_STATE, "vft_walk_step: alignment too long for one workgroup per pair");
-    const size_t rs = c->rs, idB = ((size_t) (n > 0 ? n : 1) * 8 + 255) & ~(size_t) 255;
+    // The six workgroups of the step kernels each run the whole chain and store every output - the same bits six times, at six
+    // different moments.  That is only sound while no node is written after it has been read or written earlier in the step (a
+    // workgroup that is ahead would hand a later value to one that is behind; three steps in ten of an SPR round are like that):
+    // such a step runs its chain in ONE workgroup and its six pairs in a second launch.
+    bool rewrites = false;
+    for (int32_t k2 = 1; k2 < n && !rewrites; k2++)
+        for (int32_t k = 0; k < k2; k++)
+            if (out[k2] == a[k] || out[k2] == b[k] || out[k2] == out[k]) {
+                rewrites = true;
+                break;
+            }
+    // a column per thread where the registers allow it: 1 024 threads for 4-state columns, 512 for 20-state ones
+    const int wg = c->d.nPos <= 256 ? 256 : (c->d.nPos <= 512 || c->d.nCodes == 20) ? 512 : 1024;
+    if (!c->walkLdsSet && lds > (48u << 10)) {
+        VFT_DISPATCH(c, {
+            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step_args<REAL, NC, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step_args<REAL, NC, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            if constexpr (NC == 4) {
+                HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step_args<REAL, NC, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            }
+        });
+        c->walkLdsSet = true;
+    }
+    const size_t rs = c->rs;
+    if (n <= VFT_WALK_ARGS && !c->walkIdsInRing) {   // the usual step: ids in the kernel arguments, one flag per workgroup (k_walk_step_args)
+        const unsigned long long seq = ++c->signalSeq;
+        // nOps averages and then (chainOnly: nothing else, one workgroup; otherwise) the six pairs, one workgroup each
+        auto go = [&](int32_t nOps, bool chainOnly) -> int {
+            WalkIds W{};
+            W.n = nOps;
+            W.chainOnly = chainOnly ? 1 : 0;
+            for (int32_t k = 0; k < nOps; k++) {
+                W.out[k] = (int32_t) out[k];
+                W.a[k] = (int32_t) a[k];
+                W.b[k] = (int32_t) b[k];
+            }
+            for (int t = 0; t < 4; t++) W.q[t] = (int32_t) q[t];
+#define VFT_WALK_GO(WGN)                                                                                                                     \
+    launch((k_walk_step_args<REAL, NC, WGN>), dim3(chainOnly ? 1 : 6), dim3(WGN), lds, c->stream, arena<REAL>(c), W, c->fpostTol,               \
+           (REAL *) (c->dFlag + 16), c->dFlag + 8, seq)
+            VFT_DISPATCH(c, {
+                if (wg == 256) VFT_WALK_GO(256);
+                else if (wg == 512) VFT_WALK_GO(512);
+                else if constexpr (NC == 4) VFT_WALK_GO(1024);
+            });
+#undef VFT_WALK_GO
+            LAUNCHCHK(c);
+            return VFT_OK;
+        };
+        if (rewrites) {
+            if (int r = go(n, true)) return r;
+            if (int r = go(0, false)) return r;
+        } else {
+            if (int r = go(n, false)) return r;
+        }
+        if (int r = wait_flag(c, seq, 8, 6)) return r;
+        for (int w = 0; w < 6; w++) memcpy((char *) dist + (size_t) w * rs, (const char *) (c->hFlag + 16) + (size_t) 2 * w * rs, rs);
+        return VFT_OK;
+    }
+    if (rewrites) {   // (a long step: the two plain calls)
+        if (int r = vft_average_chain(c, n, out, a, b)) return r;
+        const int64_t pi[6] = {q[0], q[0], q[0], q[1], q[1], q[2]}, pj[6] = {q[1], q[2], q[3], q[2], q[3], q[3]};
+        double wt[6];
+        return vft_profile_distances(c, 6, pi, pj, dist, wt);
+    }
+    const size_t idB = ((size_t) n * 8 + 255) & ~(size_t) 255;
     char *h, *s;
     if (int r = io_alloc(c, 3 * idB + 256 + 256, &h, &s)) return r;
     if (n > 0) {
@@ -1248,16 +1324,6 @@ extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const in
         memcpy(h + 2 * idB, b, (size_t) n * 8);
     }
     memcpy(h + 3 * idB, q, 32);
-    // a column per thread where the registers allow it: 1 024 threads for 4-state columns, 512 for 20-state ones
-    const int wg = c->d.nPos <= 256 ? 256 : (c->d.nPos <= 512 || c->d.nCodes == 20) ? 512 : 1024;
-    if (!c->walkLdsSet && lds > (48u << 10)) {
-        VFT_DISPATCH(c, {
-            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            if constexpr (NC == 4) HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        });
-        c->walkLdsSet = true;
-    }
     const unsigned long long seq = ++c->signalSeq;
 #define VFT_WALK_GO(WGN)                                                                                                                      \
     launch((k_walk_step<REAL, NC, WGN>), dim3(6), dim3(WGN), lds, c->stream, arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB),  \
@@ -1274,6 +1340,12 @@ extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const in
     memcpy(dist, h + 3 * idB + 256, 6 * rs);
     return VFT_OK;
 }
+
+#ifdef VFT_WALK_TIMING   // tools-only build (tools/walk_ticks.py): never in the product library
+extern "C" int vft_walk_ticks(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vftWalkTicks), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // differ[k] = 1 when the profiles of nodes a[k] and b[k] (rows or tile streams, internal or leaf) are not bit-identical.  Waits.
 extern "C" int vft_profiles_differ(vft_ctx *c, int64_t n, const int64_t *a, const int64_t *b, int32_t *differ) {
@@ -3592,6 +3664,7 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_FAULT_NO_FLAG: c->faultNoFlag = value != 0; break;
         case VFT_DEBUG_WAIT_LIMIT_MS: c->waitLimitS = value > 0 ? (double) value / 1000.0 : 120.0; break;
         case VFT_DEBUG_WIDE_GLUE: c->wideGlue = value != 0; break;
+        case VFT_DEBUG_WALK_IDS_IN_RING: c->walkIdsInRing = value != 0; break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }
     return VFT_OK;

@@ -704,28 +704,10 @@ __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, i
     }
 }
 
-// The same for ONE pair handled by a whole workgroup (single out-distances and self distances of the join loop: the
-// wave version spends ~nPos/64 dependent memory round trips on them, this one nPos/blockDim.x).  Every thread of the
-// workgroup must call; sW / sT: nPosPad doubles each; the results are broadcast.
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
-                                               double *sT, REAL &dist, REAL &weight, bool rowsById = false) {
+// The second half of vft_pair_block: the addends of all columns are in sW / sT; every thread of the workgroup must call.
+template <typename REAL>
+__device__ __forceinline__ void vft_pair_block_sum(int64_t nPos, bool leaves, const double *sW, const double *sT, REAL &dist, REAL &weight) {
     __shared__ double res[2];
-    const int64_t nPos = A.d.nPos;
-    const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
-    // two columns per thread and trip, loads of both issued before the first is consumed (as in vft_pair_wave)
-    // (rowsById: the caller knows that every internal node has its row - the join engine, whose joins write rows - and spares
-    //  the flag's memory round trip in front of the column loads)
-    const bool iRow = rowsById ? i >= A.d.nSeqs : vft_is_row<REAL>(A, i), jRow = !jIsOut && (rowsById ? j >= A.d.nSeqs : vft_is_row<REAL>(A, j));
-    for (int64_t p = threadIdx.x; p < nPos; p += 2 * (int64_t) blockDim.x) {
-        const int64_t pb = p + blockDim.x;
-        const bool hasB = pb < nPos;
-        Col<REAL, NC> a1, a2, b1, b2;
-        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2, iRow, jRow);
-        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2, iRow, jRow);
-        vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
-        if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
-    }
     __syncthreads();
     if (threadIdx.x < 2) {   // thread 0: `top`, thread 1: `denom`, each in column order
         const double *src = threadIdx.x == 0 ? sT : sW;
@@ -750,6 +732,30 @@ __device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, 
         weight = (REAL) (denom > 0 ? denom : 0.01);
         dist = (REAL) (denom > 0 ? top / denom : 1.0);
     }
+}
+
+// The same for ONE pair handled by a whole workgroup (single out-distances and self distances of the join loop: the
+// wave version spends ~nPos/64 dependent memory round trips on them, this one nPos/blockDim.x).  Every thread of the
+// workgroup must call; sW / sT: nPosPad doubles each; the results are broadcast.
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
+                                               double *sT, REAL &dist, REAL &weight, bool rowsById = false) {
+    const int64_t nPos = A.d.nPos;
+    const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
+    // two columns per thread and trip, loads of both issued before the first is consumed (as in vft_pair_wave)
+    // (rowsById: the caller knows that every internal node has its row - the join engine, whose joins write rows - and spares
+    //  the flag's memory round trip in front of the column loads)
+    const bool iRow = rowsById ? i >= A.d.nSeqs : vft_is_row<REAL>(A, i), jRow = !jIsOut && (rowsById ? j >= A.d.nSeqs : vft_is_row<REAL>(A, j));
+    for (int64_t p = threadIdx.x; p < nPos; p += 2 * (int64_t) blockDim.x) {
+        const int64_t pb = p + blockDim.x;
+        const bool hasB = pb < nPos;
+        Col<REAL, NC> a1, a2, b1, b2;
+        vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2, iRow, jRow);
+        if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2, iRow, jRow);
+        vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
+        if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
+    }
+    vft_pair_block_sum<REAL>(nPos, leaves, sW, sT, dist, weight);
 }
 
 // wave-per-item kernels: a workgroup holds blockDim.x / 64 items (4 by default; the host launches fewer waves per
@@ -1066,6 +1072,100 @@ __global__ __launch_bounds__(WG) void k_walk_step(Arena<REAL> A, const int64_t *
     vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
     if (threadIdx.x == 0) vft_stage_store<REAL>(stage, stageCap, w, d, wt, (REAL) 0);
     vft_publish_staged<REAL>(stage, stageCap, 6, dist, dist + 6, (REAL *) nullptr, doneCtr, flag, seq);
+}
+
+// The same step with everything the host hands over in the kernel ARGUMENTS (up to VFT_WALK_ARGS averages - the usual step has
+// five) and every workgroup publishing its own distance: the ids of k_walk_step live in the mapped ring, so each trip of its loop
+// starts with a read over PCIe that the stores of the trip before keep the compiler from hoisting, and its six results go through a
+// staging buffer, two counters and the last workgroup.  Here the ids come with the dispatch packet (scalar loads from the constant
+// kernel-argument segment), and workgroup w writes {distance, weight} to res[2 w], res[2 w + 1] and then `seq` to flags[w] (both
+// host-mapped; the host waits for all six words, which share a cache line).  Same arithmetic, same order.
+// Measured against this on one box and slower: the chain's outside inputs loaded ahead of the chain into registers (with
+// and without a loop free of loads), rows loaded in one round with the vector fetched unconditionally.
+#ifndef VFT_WALK_ARGS
+#define VFT_WALK_ARGS 48
+#endif
+// tools-only build (-DVFT_WALK_TIMING, tools/walk_ticks.py): thread 0 of every workgroup of k_walk_step_args adds the clock ticks
+// (100 MHz) of its phases - [0] the averages, [1] the pair's columns and ordered sum, [2] publication - and [3] counts workgroups
+#ifdef VFT_WALK_TIMING
+static __device__ unsigned long long vftWalkTicks[8];
+#define VFT_WALK_TICK(k)                                       \
+    do {                                                       \
+        if (threadIdx.x == 0) {                                \
+            const unsigned long long now_ = wall_clock64();    \
+            atomicAdd(&vftWalkTicks[k], now_ - walkTick_);     \
+            walkTick_ = now_;                                  \
+        }                                                      \
+    } while (0)
+#else
+#define VFT_WALK_TICK(k) do { } while (0)
+#endif
+struct WalkIds {
+    int32_t out[VFT_WALK_ARGS], a[VFT_WALK_ARGS], b[VFT_WALK_ARGS];
+    int32_t q[4];
+    int32_t n;
+    int32_t chainOnly;   // the launch is ONE workgroup that runs the averages and nothing else (see vft_walk_step: steps that
+                         // write a node twice, or after reading it, must not run their chain six times side by side)
+};
+
+template <typename REAL, int NC, int WG>
+__global__ __launch_bounds__(WG) void k_walk_step_args(Arena<REAL> A, const WalkIds W, double tol, REAL *res, unsigned long long *flags,
+                                                           unsigned long long seq) {
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];
+#ifdef VFT_WALK_TIMING
+    unsigned long long walkTick_ = wall_clock64();
+#endif
+    for (int64_t p = threadIdx.x; p < A.d.nPos; p += WG) {
+        int64_t prevOut = -1;
+        Col<REAL, NC> prev;
+        prev.w = 0;
+        prev.code = VFT_NOCODE_;
+        prev.vec = false;
+#pragma unroll
+        for (int k = 0; k < NC; k++) prev.f[k] = 0;
+        for (int32_t k = 0; k < W.n; k++) {
+            const int64_t a = W.a[k], b = W.b[k], o = W.out[k];
+            Col<REAL, NC> c1, c2;
+            if (a == prevOut) c1 = prev;
+            else if (a >= A.d.nSeqs) vft_load_row<REAL, NC>(A, a, p, c1);
+            else vft_load_col<REAL, NC>(A, a, p, c1);
+            if (b == prevOut) c2 = prev;
+            else if (b >= A.d.nSeqs) vft_load_row<REAL, NC>(A, b, p, c2);
+            else vft_load_col<REAL, NC>(A, b, p, c2);
+            REAL wo, f[NC];
+            int co;
+            vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
+            vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
+            prevOut = o;
+            prev.w = wo;
+            prev.code = co;
+            prev.vec = wo > 0 && co == VFT_NOCODE_;
+#pragma unroll
+            for (int k2 = 0; k2 < NC; k2++) prev.f[k2] = f[k2];
+        }
+    }
+    VFT_WALK_TICK(0);
+    if (W.chainOnly) return;
+    const int w = (int) blockIdx.x;
+    const int64_t i = W.q[w < 3 ? 0 : w < 5 ? 1 : 2], j = W.q[w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3];
+    REAL d, wt;
+    vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
+    VFT_WALK_TICK(1);
+    if (threadIdx.x == 0) {
+        res[2 * w] = d;
+        res[2 * w + 1] = wt;
+        // the two numbers must have LEFT the chip before the flag moves (the explicit wait: see vft_publish_staged)
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&flags[w], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    VFT_WALK_TICK(2);
+#ifdef VFT_WALK_TIMING
+    if (threadIdx.x == 0) {
+        atomicAdd(&vftWalkTicks[3], 1ull);
+        atomicAdd(&vftWalkTicks[4], (unsigned long long) W.n);
+    }
+#endif
 }
 
 // A short pair list and the out-distance refreshes it needs in ONE launch (the join loop makes three such calls per join
