@@ -192,19 +192,32 @@ __device__ __forceinline__ REAL vft_red4_sum(const REAL *a) {
     return lo + hi;
 }
 
+// Where a kernel reads the distance-matrix tables from: the arena (global memory, the default of every function below), or a copy
+// a latency-bound kernel made in LDS (k_walk_step_args: a table read from global memory inside a loop that also stores is a wait for
+// the stores).  The tables: distances [NC][NC], codeFreq [NC][NC], eigenval [NC], eigentot [NC].
+template <typename REAL>
+struct DmGlobal {
+    const REAL *dist, *codeFreq, *eigenval, *eigentot;
+    __device__ __forceinline__ explicit DmGlobal(const Arena<REAL> &A) : dist(A.dmDist), codeFreq(A.dmCodeFreq), eigenval(A.dmEigenval), eigentot(A.dmEigentot) {}
+};
+template <typename REAL>
+struct DmLds {
+    const __attribute__((address_space(3))) REAL *dist, *codeFreq, *eigenval, *eigentot;
+};
+
 // profileDistPiece (NJ.tcc:900-941).  cd2 = codeDist row of profile 2 for this column, or nullptr.
-template <typename REAL, int NC>
+template <typename REAL, int NC, typename DM>
 __device__ __forceinline__ double vft_piece(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2,
-                                            const REAL *cd2) {
+                                            const REAL *cd2, const DM &T) {
     if (A.dmDist) {
-        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) return (double) A.dmDist[c1.code * NC + c2.code];
+        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) return (double) T.dist[c1.code * NC + c2.code];
         if (cd2 != nullptr && c1.code != VFT_NOCODE_) return (double) cd2[c1.code];
         REAL f1[NC], f2[NC], ev[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) {
-            f1[k] = c1.vec ? c1.f[k] : A.dmCodeFreq[(c1.code == VFT_NOCODE_ ? 0 : c1.code) * NC + k];
-            f2[k] = c2.vec ? c2.f[k] : A.dmCodeFreq[(c2.code == VFT_NOCODE_ ? 0 : c2.code) * NC + k];
-            ev[k] = A.dmEigenval[k];
+            f1[k] = c1.vec ? c1.f[k] : T.codeFreq[(c1.code == VFT_NOCODE_ ? 0 : c1.code) * NC + k];
+            f2[k] = c2.vec ? c2.f[k] : T.codeFreq[(c2.code == VFT_NOCODE_ ? 0 : c2.code) * NC + k];
+            ev[k] = T.eigenval[k];
         }
         if ((!c1.vec && c1.code == VFT_NOCODE_) || (!c2.vec && c2.code == VFT_NOCODE_)) return 10.0;
         return (double) vft_red4_mul3<REAL, NC>(f1, f2, ev);
@@ -226,6 +239,11 @@ __device__ __forceinline__ double vft_piece(const Arena<REAL> &A, const Col<REAL
         piece -= (double) p;
     }
     return piece;
+}
+
+template <typename REAL, int NC>
+__device__ __forceinline__ double vft_piece(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, const REAL *cd2) {
+    return vft_piece<REAL, NC, DmGlobal<REAL>>(A, c1, c2, cd2, DmGlobal<REAL>(A));
 }
 
 // setOutDistance's closed form (NJ.tcc:1046-1053): numeric_t products, one double division.

@@ -625,22 +625,27 @@ __device__ __forceinline__ bool vft_is_row(const Arena<REAL> &A, int64_t node) {
     return node >= A.d.nSeqs && A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs] != 0;
 }
 // its addends to (denom, top), parked in LDS for the in-order sum
-template <typename REAL, int NC>
+template <typename REAL, int NC, typename DM>
 __device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
-                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT) {
+                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT, const DM &T) {
     double wgt = 0.0, term = 0.0;
     if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
         if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
             wgt = 1.0;
-            term = A.dmDist ? (double) A.dmDist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
+            term = A.dmDist ? (double) T.dist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
         }
     } else if (c1.w > 0 && c2.w > 0) {
         const REAL ww = c1.w * c2.w;
         wgt = (double) ww;
-        term = wgt * vft_piece<REAL, NC>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr);
+        term = wgt * vft_piece<REAL, NC, DM>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr, T);
     }
     sW[p] = wgt;
     sT[p] = term;
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
+                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT) {
+    vft_pair_addends<REAL, NC, DmGlobal<REAL>>(A, leaves, jIsOut, p, c1, c2, sW, sT, DmGlobal<REAL>(A));
 }
 
 template <typename REAL, int NC>
@@ -737,9 +742,9 @@ __device__ __forceinline__ void vft_pair_block_sum(int64_t nPos, bool leaves, co
 // The same for ONE pair handled by a whole workgroup (single out-distances and self distances of the join loop: the
 // wave version spends ~nPos/64 dependent memory round trips on them, this one nPos/blockDim.x).  Every thread of the
 // workgroup must call; sW / sT: nPosPad doubles each; the results are broadcast.
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
-                                               double *sT, REAL &dist, REAL &weight, bool rowsById = false) {
+template <typename REAL, int NC, typename DM>
+__device__ __forceinline__ void vft_pair_block_t(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
+                                               double *sT, REAL &dist, REAL &weight, bool rowsById, const DM &T) {
     const int64_t nPos = A.d.nPos;
     const bool leaves = !jIsOut && i < A.d.nSeqs && j < A.d.nSeqs;
     // two columns per thread and trip, loads of both issued before the first is consumed (as in vft_pair_wave)
@@ -752,10 +757,15 @@ __device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, 
         Col<REAL, NC> a1, a2, b1, b2;
         vft_pair_load<REAL, NC>(A, i, j, jIsOut, p, a1, a2, iRow, jRow);
         if (hasB) vft_pair_load<REAL, NC>(A, i, j, jIsOut, pb, b1, b2, iRow, jRow);
-        vft_pair_addends<REAL, NC>(A, leaves, jIsOut, p, a1, a2, sW, sT);
-        if (hasB) vft_pair_addends<REAL, NC>(A, leaves, jIsOut, pb, b1, b2, sW, sT);
+        vft_pair_addends<REAL, NC, DM>(A, leaves, jIsOut, p, a1, a2, sW, sT, T);
+        if (hasB) vft_pair_addends<REAL, NC, DM>(A, leaves, jIsOut, pb, b1, b2, sW, sT, T);
     }
     vft_pair_block_sum<REAL>(nPos, leaves, sW, sT, dist, weight);
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_block(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
+                                               double *sT, REAL &dist, REAL &weight, bool rowsById = false) {
+    vft_pair_block_t<REAL, NC, DmGlobal<REAL>>(A, i, j, jIsOut, sW, sT, dist, weight, rowsById, DmGlobal<REAL>(A));
 }
 
 // wave-per-item kernels: a workgroup holds blockDim.x / 64 items (4 by default; the host launches fewer waves per
@@ -1115,6 +1125,23 @@ __global__ __launch_bounds__(WG) void k_walk_step_args(Arena<REAL> A, const Walk
 #ifdef VFT_WALK_TIMING
     unsigned long long walkTick_ = wall_clock64();
 #endif
+    // Amino acids: the distance-matrix tables (distances, codeFreq, eigenval, eigentot: 840 numbers) come to LDS first.  An average
+    // reads codeFreq rows and eigentot, a pair codeFreq rows and eigenval; from global memory each of those reads sits behind the
+    // stores of the average before (loads and stores share one counter), ~1 us apiece.
+    constexpr int NT = NC == 20 ? 2 * NC * NC + 2 * NC : 1;
+    __shared__ REAL sDm[NT];
+    typedef const __attribute__((address_space(3))) REAL *lds_t;
+    DmLds<REAL> T;
+    T.dist = (lds_t) sDm;
+    T.codeFreq = (lds_t) sDm + (NC == 20 ? NC * NC : 0);
+    T.eigenval = (lds_t) sDm + (NC == 20 ? 2 * NC * NC : 0);
+    T.eigentot = (lds_t) sDm + (NC == 20 ? 2 * NC * NC + NC : 0);
+    const bool ldsTables = NC == 20 && A.dmDist != nullptr;
+    if (ldsTables) {
+        for (int t = threadIdx.x; t < NT; t += WG)
+            sDm[t] = t < NC * NC ? A.dmDist[t] : t < 2 * NC * NC ? A.dmCodeFreq[t - NC * NC] : t < 2 * NC * NC + NC ? A.dmEigenval[t - 2 * NC * NC] : A.dmEigentot[t - 2 * NC * NC - NC];
+        __syncthreads();
+    }
     for (int64_t p = threadIdx.x; p < A.d.nPos; p += WG) {
         int64_t prevOut = -1;
         Col<REAL, NC> prev;
@@ -1134,7 +1161,8 @@ __global__ __launch_bounds__(WG) void k_walk_step_args(Arena<REAL> A, const Walk
             else vft_load_col<REAL, NC>(A, b, p, c2);
             REAL wo, f[NC];
             int co;
-            vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
+            if (ldsTables) vft_average_col<REAL, NC, DmLds<REAL>>(A, c1, c2, 0.5, tol, wo, co, f, T);
+            else vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
             vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
             prevOut = o;
             prev.w = wo;
@@ -1149,7 +1177,8 @@ __global__ __launch_bounds__(WG) void k_walk_step_args(Arena<REAL> A, const Walk
     const int w = (int) blockIdx.x;
     const int64_t i = W.q[w < 3 ? 0 : w < 5 ? 1 : 2], j = W.q[w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3];
     REAL d, wt;
-    vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
+    if (ldsTables) vft_pair_block_t<REAL, NC, DmLds<REAL>>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true, T);
+    else vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
     VFT_WALK_TICK(1);
     if (threadIdx.x == 0) {
         res[2 * w] = d;

@@ -215,8 +215,8 @@ __global__ void k_profile_gather(Arena<REAL> A, int64_t node, REAL *w, uint8_t *
 }
 
 // addToFreq (NJ.tcc:821-833)
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_add_to_freq(const Arena<REAL> &A, REAL *fOut, double weight, const Col<REAL, NC> &in) {
+template <typename REAL, int NC, typename DM>
+__device__ __forceinline__ void vft_add_to_freq(const Arena<REAL> &A, REAL *fOut, double weight, const Col<REAL, NC> &in, const DM &T) {
     if (in.vec) {
         const REAL wr = (REAL) weight;
 #pragma unroll
@@ -228,7 +228,7 @@ __device__ __forceinline__ void vft_add_to_freq(const Arena<REAL> &A, REAL *fOut
         const REAL wr = (REAL) weight;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
-            const REAL pr = A.dmCodeFreq[in.code * NC + k] * wr;
+            const REAL pr = T.codeFreq[in.code * NC + k] * wr;
             fOut[k] = fOut[k] + pr;
         }
     } else {
@@ -239,13 +239,13 @@ __device__ __forceinline__ void vft_add_to_freq(const Arena<REAL> &A, REAL *fOut
 }
 
 // normalizeFreq (NJ.tcc:843-871)
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *freq, double tol) {
+template <typename REAL, int NC, typename DM>
+__device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *freq, double tol, const DM &T) {
     double total = 0;
     if (A.dmDist) {
         REAL et[NC];
 #pragma unroll
-        for (int k = 0; k < NC; k++) et[k] = A.dmEigentot[k];
+        for (int k = 0; k < NC; k++) et[k] = T.eigentot[k];
         total = (double) vft_red4_mul<REAL, NC>(freq, et);
     } else {
 #pragma unroll
@@ -260,14 +260,23 @@ __device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *f
         for (int k = 0; k < NC; k++) freq[k] = (REAL) (1.0 / NC);
     } else {
 #pragma unroll
-        for (int k = 0; k < NC; k++) freq[k] = A.dmCodeFreq[k];
+        for (int k = 0; k < NC; k++) freq[k] = T.codeFreq[k];
     }
 }
 
 // averageProfile (NJ.tcc:2067-2135) of one column
 template <typename REAL, int NC>
+__device__ __forceinline__ void vft_add_to_freq(const Arena<REAL> &A, REAL *fOut, double weight, const Col<REAL, NC> &in) {
+    vft_add_to_freq<REAL, NC, DmGlobal<REAL>>(A, fOut, weight, in, DmGlobal<REAL>(A));
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_normalize_freq(const Arena<REAL> &A, REAL *freq, double tol) {
+    vft_normalize_freq<REAL, NC, DmGlobal<REAL>>(A, freq, tol, DmGlobal<REAL>(A));
+}
+
+template <typename REAL, int NC, typename DM>
 __device__ __forceinline__ void vft_average_col(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double bw,
-                                                double tol, REAL &wo, int &co, REAL *f) {
+                                                double tol, REAL &wo, int &co, REAL *f, const DM &T) {
     wo = (REAL) (bw * (double) c1.w + (1 - bw) * (double) c2.w);
     co = VFT_NOCODE_;
 #pragma unroll
@@ -276,11 +285,16 @@ __device__ __forceinline__ void vft_average_col(const Arena<REAL> &A, const Col<
         if (c1.w > 0 && c1.code != VFT_NOCODE_ && (c2.w <= 0 || c1.code == c2.code)) co = c1.code;
         else if (c1.w <= 0 && c2.w > 0 && c2.code != VFT_NOCODE_) co = c2.code;
         if (co == VFT_NOCODE_) {
-            if (c1.w > 0) vft_add_to_freq<REAL, NC>(A, f, (double) c1.w * bw, c1);
-            if (c2.w > 0) vft_add_to_freq<REAL, NC>(A, f, (double) c2.w * (1.0 - bw), c2);
-            vft_normalize_freq<REAL, NC>(A, f, tol);
+            if (c1.w > 0) vft_add_to_freq<REAL, NC, DM>(A, f, (double) c1.w * bw, c1, T);
+            if (c2.w > 0) vft_add_to_freq<REAL, NC, DM>(A, f, (double) c2.w * (1.0 - bw), c2, T);
+            vft_normalize_freq<REAL, NC, DM>(A, f, tol, T);
         }
     }
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_average_col(const Arena<REAL> &A, const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double bw,
+                                                double tol, REAL &wo, int &co, REAL *f) {
+    vft_average_col<REAL, NC, DmGlobal<REAL>>(A, c1, c2, bw, tol, wo, co, f, DmGlobal<REAL>(A));
 }
 
 // averageProfile: grid.y = join index, threads over columns
