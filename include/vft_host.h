@@ -89,6 +89,10 @@ typedef struct {
                                                               host-driven walk (same tree; slower on MI355X today)
                                    VFT_NJ_DEBUG_LEVEL_LENGTHS 16  ML length rounds as one batch per tree height - NOT the reference's
                                                               order in any of its modes (measurements only) */
+    int32_t gamma;              /* `-gamma` (VeryFastTreeImpl.tcc:391-394, NJ.tcc:297-308, :5261-5357): after the CAT tree and its supports
+                                   are final, fit the shape of a discretised Gamma over the ml_nni / mllen rate categories and a
+                                   multiplier of the rates to the per-site likelihoods, and multiply every branch length by
+                                   1 / multiplier; vft_nj_last_gamma returns the "Gamma(20) LogLk" line's three numbers */
 } vft_nj_options;
 #define VFT_NJ_DEBUG_HOST_JOINS 1
 #define VFT_NJ_DEBUG_HOST_LISTS 2
@@ -150,6 +154,10 @@ int vft_tree_partitioning(int64_t n_nodes, const int64_t *child, int64_t root, i
    the ML NNI rounds, the SH-like supports, the model fits (CAT rates, GTR).  counts[4]: lockstep steps of the subtree schedule
    (opt.threads > 1) and the quartets / splits judged in them, SPR chain steps evaluated, SPR moves made.  Either may be NULL. */
 int vft_nj_last_stage_seconds(double *seconds, int64_t *counts);
+
+/* out[3]: what `-gamma` (vft_nj_options.gamma) found for the last tree of this process - the Gamma(nCat) log-likelihood, the shape
+   alpha, the factor every branch length was multiplied by (the reference's "Gamma(20) LogLk = .. alpha = .. rescaling lengths by ..") */
+int vft_nj_last_gamma(double *out);
 
 /* The first n values of the random stream the bootstrap columns are drawn from (Knuth's ran_array at its default
    seed, as the reference uses it, Knuth.cpp:95-111): exported so that tests can pin the host generator. */

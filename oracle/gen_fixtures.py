@@ -426,6 +426,34 @@ def gen_threads(tmp, only=None):
                                                                                       "differs from" if one.stdout != res2.stdout else "EQUALS"))
 
 
+GAMMA_CASES = [
+    # name, alphabet size, flags, n, L, mu, gap, seed
+    ("gamma_nt_200", 4, ["-nt", "-gamma"], 200, 120, 0.05, 0.02, 21),
+    ("gamma_nt_300_gtr", 4, ["-nt", "-gtr", "-gamma"], 300, 200, 0.05, 0.02, 22),
+    ("gamma_aa_150_lg_double", 20, ["-lg", "-gamma", "-double-precision"], 150, 120, 0.08, 0.02, 23),
+]
+
+
+def gen_gamma(tmp):
+    """Black box, `-gamma` at one thread: the complete default pipeline, then the Gamma(20) fit and the rescaled lengths
+    (branchlengthScale, NJ.tcc:297-308).  Kept: the final tree with supports, every TreeLogLk line, the three numbers of the
+    "Gamma(20) LogLk = .. alpha = .. rescaling lengths by .." line."""
+    for name, nc, flags, n, L, mu, gap, seed in GAMMA_CASES:
+        codes = synth.random_descent_codes(n, L, nc, mu, gap, seed)
+        fa = os.path.join(tmp, name + ".fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT if nc == 4 else synth.ALPHABET_AA)
+        log = os.path.join(tmp, name + ".log")
+        res = subprocess.run([REFBIN] + flags + ["-threads", "1", "-seed", "1", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        text = open(log).read() + res.stderr.decode(errors="replace")
+        ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", text, re.M)]
+        m = re.search(r"Gamma\(20\) LogLk = (\S+) alpha = (\S+) rescaling lengths by (\S+)", text)
+        assert m, name + ": no Gamma(20) line"
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), codes=codes, loglk=np.array(ll), newick=np.frombuffer(res.stdout, dtype=np.uint8),
+                            gamma=np.array([float(m.group(1)), float(m.group(2)), float(m.group(3))]),
+                            flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8))
+        print("%-26s %d TreeLogLk lines, Gamma(20) LogLk %s alpha %s rescale %s" % (name, len(ll), m.group(1), m.group(2), m.group(3)))
+
+
 def gen_c3(tmp):
     """BASELINE config C3 at full size (100 000 x 500 nt, `-nt -fastest` at one thread, i.e. with the second-level top
     hits): only the CRC-32 and length of the reference's `-noml -nome -nosupport` tree are kept (the tree is 2.5 MB).
@@ -600,7 +628,7 @@ def gen_c4_prefix(tmp):
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa", "threads", "partition"]
+    which = sys.argv[1:] or ["whitebox", "blackbox", "knuth", "tables", "mllen", "menni", "mlnni", "aa", "threads", "partition", "gamma"]
     with tempfile.TemporaryDirectory() as tmp:
         if "whitebox" in which:
             gen_whitebox(tmp)
@@ -628,6 +656,8 @@ def main():
             gen_threads(tmp)
         if any(w.startswith("threads:") for w in which):
             gen_threads(tmp, [w[8:] for w in which if w.startswith("threads:")])
+        if "gamma" in which:
+            gen_gamma(tmp)
         if "c3" in which:   # not part of the default set: ~11 minutes
             gen_c3(tmp)
         if "c2" in which:   # not part of the default set: minutes

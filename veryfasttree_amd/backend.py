@@ -49,7 +49,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_tree_partitioning", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_nj_last_gamma", "vft_tree_partitioning", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
                 "vft_aa_model_tables", "vft_blosum45_tables", "vft_aa_model_as_distance_tables"]
 
 
@@ -57,7 +57,7 @@ class _NJOptions(C.Structure):
     _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
                 ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
-                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P), ("threads", I32), ("debug_flags", I32)]
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P), ("threads", I32), ("debug_flags", I32), ("gamma", I32)]
 
 
 _lib = None
@@ -245,7 +245,7 @@ def uniquify(codes):
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
               unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False,
-              aa_model=None, comm=None, threads=1, debug_flags=0):
+              aa_model=None, comm=None, threads=1, debug_flags=0, gamma=False):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -263,7 +263,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0,
-                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None, int(threads), int(debug_flags))
+                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None, int(threads), int(debug_flags), 1 if gamma else 0)
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)
@@ -291,6 +291,13 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
 
 
 STAGES = ("nj", "me_nni_spr", "of_which_spr", "me_lengths_supports", "ml_stage", "of_which_ml_nni", "of_which_sh_supports", "of_which_model_fits")
+
+
+def last_gamma():
+    """(Gamma(nCat) log-likelihood, alpha, length factor) of the last nj_newick(..., gamma=True): the reference's "Gamma(20) LogLk" line"""
+    out = np.zeros(3, np.float64)
+    load_host_library().vft_nj_last_gamma(_ptr(out))
+    return tuple(float(x) for x in out)
 
 
 def last_stage_seconds():

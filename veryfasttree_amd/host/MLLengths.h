@@ -327,6 +327,141 @@ namespace veryfasttree {
             recomputeMLProfiles();
         }
 
+        /* `-gamma` (branchlengthScale, NJ.tcc:297-308; rescaleGammaLogLk :5295-5357; gammaLogLk :5261-5293): after the CAT tree is
+           final, the site likelihoods at each of the nCat evenly spaced rates once more (MLSiteLikelihoodsByRate, with treeLogLk's
+           per-site Jukes-Cantor gap terms this time: gapsPerPos, or null with a transition matrix), then - host arithmetic on
+           those nCat x nPos numbers - the shape alpha of a discretised Gamma and a multiplier of the rates are fitted by
+           alternating line searches (at most 10 rounds), and every branch length is multiplied by 1 / multiplier.  Returns
+           {Gamma(nCat) log-likelihood, alpha, 1 / multiplier} - the numbers of the reference's "Gamma(20) LogLk" line. */
+        struct GammaFit {
+            double loglk, alpha, rescale;
+        };
+
+        static double lnGamma(double alpha) {   /* NJ.tcc:7192-7210 (Pike & Hill 1966, Algorithm 291) */
+            double x = alpha, f = 0;
+            if (x < 7) {
+                f = 1;
+                double z = x - 1;
+                while (++z < 7) f *= z;
+                x = z;
+                f = -std::log(f);
+            }
+            const double z = 1 / (x * x);
+            return f + (x - 0.5) * std::log(x) - x + .918938533204673
+                   + (((-.000595238095238 * z + .000793650793651) * z - .002777777777778) * z + .083333333333333) / x;
+        }
+
+        static double incompleteGamma(double x, double alpha, double lnGammaAlpha) {   /* NJ.tcc:7212-7275 (Bhattacharjee 1970, AS 32) */
+            const double accurate = 1e-8, overflow = 1e30;
+            const double p = alpha;
+            if (x == 0) return 0;
+            if (x < 0 || p <= 0) return -1;
+            const double factor = std::exp(p * std::log(x) - x - lnGammaAlpha);
+            if (!(x > 1 && x >= p)) {   /* series expansion */
+                double gin = 1, term = 1, rn = p;
+                do {
+                    rn++;
+                    term *= x / rn;
+                    gin += term;
+                } while (term > accurate);
+                return gin * (factor / p);
+            }
+            /* continued fraction */
+            double a = 1 - p, b = a + x + 1, term = 0, pn[6];
+            pn[0] = 1;
+            pn[1] = x;
+            pn[2] = x + 1;
+            pn[3] = x * b;
+            double gin = pn[2] / pn[3];
+            for (;;) {
+                a++;
+                b += 2;
+                term++;
+                const double an = a * term;
+                for (int i = 0; i < 2; i++) pn[i + 4] = b * pn[i + 2] - an * pn[i];
+                if (pn[5] != 0) {
+                    const double rn = pn[4] / pn[5], dif = std::fabs(gin - rn);
+                    if (dif <= accurate && dif <= accurate * rn) break;
+                    gin = rn;
+                }
+                for (int i = 0; i < 4; i++) pn[i] = pn[i + 2];
+                if (!(std::fabs(pn[4]) < overflow))
+                    for (int i = 0; i < 4; i++) pn[i] /= overflow;
+            }
+            return 1 - factor * gin;
+        }
+
+        static double pGamma(double x, double alpha) { return incompleteGamma(x * alpha, alpha, lnGamma(alpha)); }   /* NJ.tcc:5362-5365 */
+
+        GammaFit branchlengthScale(int32_t nCat, int64_t nPos, const std::vector<REAL> &curRates, const std::vector<int64_t> &curRatecat,
+                                   const int64_t *gapsPerPos) {
+            std::vector<REAL> rates((size_t) nCat);
+            const double logNCat = std::log((double) nCat);
+            const double logd = (logNCat + logNCat) / (double) (nCat - 1);
+            for (int32_t i = 0; i < nCat; i++) rates[(size_t) i] = (REAL) std::exp(-logNCat + logd * (double) i);
+            std::vector<double> siteLoglk((size_t) (nPos * nCat));
+            std::vector<int64_t> zero((size_t) nPos, 0);
+            const double logNCodes = std::log(4.0);
+            for (int32_t i = 0; i < nCat; i++) {
+                chk(vft_set_rates(ctx, &rates[(size_t) i], 1, zero.data()));
+                recomputeMLProfiles();
+                double *row = siteLoglk.data() + (size_t) (nPos * i);
+                siteLogLk(nPos, row);
+                if (gapsPerPos)   /* NJ.tcc:5236-5252 */
+                    for (int64_t p = 0; p < nPos; p++) {
+                        row[p] += (double) gapsPerPos[p] * logNCodes;
+                        row[p] -= logNCodes;
+                    }
+            }
+            chk(vft_set_rates(ctx, curRates.data(), (int32_t) curRates.size(), curRatecat.data()));   /* "restore original rates and profiles" */
+            recomputeMLProfiles();
+            double mult = 1.0, alpha = 1.0;
+            std::vector<double> dRate((size_t) nCat);
+            auto gammaLogLk = [&](double *sites) {
+                for (int32_t i = 0; i < nCat; i++) {
+                    const double pMin = i == 0 ? 0.0 : pGamma(mult * (double) (rates[(size_t) i - 1] + rates[(size_t) i]) / 2.0, alpha);
+                    const double pMax = i == nCat - 1 ? 1.0 : pGamma(mult * (double) (rates[(size_t) i] + rates[(size_t) i + 1]) / 2.0, alpha);
+                    dRate[(size_t) i] = pMax - pMin;
+                }
+                double loglk = 0.0;
+                for (int64_t p = 0; p < nPos; p++) {
+                    double maxloglk = -1e20;
+                    for (int32_t i = 0; i < nCat; i++) maxloglk = std::max(maxloglk, siteLoglk[(size_t) (nPos * i + p)]);
+                    double rellk = 0;
+                    for (int32_t i = 0; i < nCat; i++) rellk += std::exp(siteLoglk[(size_t) (nPos * i + p)] - maxloglk) * dRate[(size_t) i];
+                    const double s = maxloglk + std::log(rellk);
+                    loglk += s;
+                    if (sites) sites[p] = s;
+                }
+                return loglk;
+            };
+            double fx = -gammaLogLk(nullptr);
+            for (int round = 0; round < 10; round++) {
+                const double start = fx;
+                auto optAlpha = [&](double x) {
+                    alpha = x;
+                    return -gammaLogLk(nullptr);
+                };
+                alpha = hostMinimise(optAlpha, 0.01, alpha, 10.0, 0.001, 0.001);
+                auto optMult = [&](double x) {
+                    mult = x;
+                    return -gammaLogLk(nullptr);
+                };
+                mult = hostMinimise(optMult, 0.01, mult, 10.0, 0.001, 0.001);
+                fx = -gammaLogLk(nullptr);
+                if (fx > start - 0.001) break;
+            }
+            GammaFit g;
+            g.loglk = gammaLogLk(nullptr);
+            g.alpha = alpha;
+            g.rescale = 1.0 / mult;
+            std::vector<REAL> bl((size_t) nNodes);
+            getLengths(bl.data());
+            for (REAL &x: bl) x = (REAL) ((double) x * g.rescale);   /* branchlength[i] *= scale */
+            setLengths(bl.data());
+            return g;
+        }
+
         /* all up-profiles at once, breadth first from the root (getUpProfile with useML, NJ.tcc:3382-3434, on a tree
            that no longer changes): one vft_posterior_profiles_blen per depth */
         void allUpProfiles() {

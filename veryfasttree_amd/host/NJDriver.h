@@ -70,6 +70,7 @@ namespace veryfasttree {
         bool deviceSPR = false;
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
+        bool gamma = false;          /* `-gamma`: rescale the final lengths to a fitted discrete Gamma (MLLengths::branchlengthScale) */
         /* top-hit lists on the device (vft_tophits_*): the list walks of a join are one launch each; false = the host walks
            of round 2 (kept as the cross-check of VFT_NJ_CHECK and for tools) */
         bool deviceLists = true;
@@ -110,11 +111,13 @@ namespace veryfasttree {
             branchlength.assign(maxnodes, 0);
             selfweightLeaf.resize(nSeqs);
             for (int k = 0; k < 4; k++) leafCodeCounts[k] = 0;
+            gapsPerPos.assign((size_t) nPos, 0);
             for (int64_t i = 0; i < nSeqs; i++) {
                 int64_t c = 0;
                 for (int64_t p = 0; p < nPos; p++) {
                     const uint8_t code = codes[i * nPos + p];
                     c += code != VFT_NOCODE;
+                    gapsPerPos[(size_t) p] += code == VFT_NOCODE;
                     if (code < 4) leafCodeCounts[code]++;
                 }
                 selfweightLeaf[i] = (REAL) c;
@@ -903,6 +906,14 @@ namespace veryfasttree {
                 mlSplits = st.nSplits;
                 mlWorstDelta = st.worstDelta;
             }
+            if (opt.gamma && nRateCats > 1) {   /* `-gamma` (VeryFastTreeImpl.tcc:391-394): after the supports */
+                /* (Jukes-Cantor only: treeLogLk's per-site gap terms, NJ.tcc:5236-5252) */
+                const typename MLLengths<REAL>::GammaFit g = ml.branchlengthScale(nRateCats, nPos, mlRates, mlRateCat, nLeafGaps >= 0 ? gapsPerPos.data() : nullptr);
+                gammaFit[0] = g.loglk;
+                gammaFit[1] = g.alpha;
+                gammaFit[2] = g.rescale;
+                ml.getLengths(branchlength.data());
+            }
             mlEvaluations = ml.evaluations();
             mlLaneSteps = ml.laneSteps;
             mlLaneWork = ml.laneWork;
@@ -919,6 +930,8 @@ namespace veryfasttree {
 
         int64_t mlNNIs = 0;
         int64_t mlLaneSteps = 0, mlLaneWork = 0;   /* lockstep steps of the subtree schedule and the quartets / splits judged in them */
+        std::vector<int64_t> gapsPerPos;          /* gaps of the unique sequences, by column */
+        double gammaFit[3] = {0, 0, 0};           /* `-gamma`: Gamma(nCat) log-likelihood, alpha, the factor the lengths were multiplied by */
         int64_t leafCodeCounts[4];                /* occurrences of codes 0..3 in the unique sequences (setMLGtr) */
         bool gtrFitted = false;
         double gtrRates[6] = {1, 1, 1, 1, 1, 1}, gtrFreq[4] = {0.25, 0.25, 0.25, 0.25};   /* "GTR rates" / "GTR Frequencies" */

@@ -67,6 +67,7 @@ extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *
 /* wall-clock of the stages of the last vft_nj_newick / vft_nj_ml_newick of this process (vft_nj_last_stage_seconds) */
 static double gStage[8];
 static int64_t gLanes[4];
+static double gGamma[3];   /* `-gamma` of the last tree: Gamma(nCat) log-likelihood, alpha, length factor (vft_nj_last_gamma) */
 
 /* treePartitioning (NJ.tcc:5540-5750) on a tree given as arrays: pure host code, no context (tests pin it to the reference's own
    partitions).  out[cap] receives the subtree roots in the reference's hand-out order. */
@@ -91,6 +92,12 @@ extern "C" int vft_tree_partitioning(int64_t nNodes, const int64_t *childIn, int
     *nOut = (int64_t) res.size();
     if (speedup) *speedup = sp;
     for (int64_t k = 0; out && k < cap && k < (int64_t) res.size(); k++) out[k] = res[(size_t) k];
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_last_gamma(double *out) {
+    if (!out) return VFT_ERR_INVALID;
+    for (int i = 0; i < 3; i++) out[i] = gGamma[i];
     return VFT_OK;
 }
 
@@ -121,6 +128,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.aaModel = o->aa_model;
         opt.comm = o->comm;
         opt.threads = o->threads > 1 ? o->threads : 1;
+        opt.gamma = o->gamma != 0;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_JOINS) opt.deviceJoins = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_LISTS) opt.deviceLists = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_RESET) opt.deviceReset = false;
@@ -170,6 +178,7 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     gStage[5] = drv.mlNNISeconds;
     gStage[6] = drv.mlSupportSeconds;
     gStage[7] = drv.mlModelSeconds;
+    for (int i = 0; i < 3; i++) gGamma[i] = drv.gammaFit[i];
     gLanes[0] = drv.mlLaneSteps;
     gLanes[1] = drv.mlLaneWork;
     gLanes[2] = drv.meSPRSteps;
