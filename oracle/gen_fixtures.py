@@ -444,8 +444,9 @@ def gen_gamma(tmp):
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT if nc == 4 else synth.ALPHABET_AA)
         log = os.path.join(tmp, name + ".log")
         res = subprocess.run([REFBIN] + flags + ["-threads", "1", "-seed", "1", "-log", log, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        text = open(log).read() + res.stderr.decode(errors="replace")
+        text = open(log).read()
         ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", text, re.M)]
+        text += res.stderr.decode(errors="replace")
         m = re.search(r"Gamma\(20\) LogLk = (\S+) alpha = (\S+) rescaling lengths by (\S+)", text)
         assert m, name + ": no Gamma(20) line"
         np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), codes=codes, loglk=np.array(ll), newick=np.frombuffer(res.stdout, dtype=np.uint8),
