@@ -1251,6 +1251,32 @@ extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const in
     // different moments.  That is only sound while no node is written after it has been read or written earlier in the step (a
     // workgroup that is ahead would hand a later value to one that is behind; three steps in ten of an SPR round are like that):
     // such a step runs its chain in ONE workgroup and its six pairs in a second launch.
+#ifdef VFT_WALK_CENSUS   // tools-only build: what kind of rewrites the steps contain (printed every 200 000 steps)
+    {
+        static long steps = 0, kinds[4] = {0, 0, 0, 0}, sameInputs = 0;
+        bool war = false, dup = false, dupRead = false;
+        for (int32_t k2 = 1; k2 < n; k2++)
+            for (int32_t k = 0; k < k2; k++) {
+                if (out[k2] == out[k]) {
+                    dup = true;
+                    if (a[k2] == a[k] && b[k2] == b[k]) sameInputs++;
+                    for (int32_t m = k + 1; m < k2; m++)
+                        if (a[m] == out[k] || b[m] == out[k]) dupRead = true;
+                }
+                bool ext = true;
+                for (int32_t m = 0; m < k; m++)
+                    if (out[m] == out[k2]) ext = false;
+                if ((out[k2] == a[k] || out[k2] == b[k]) && ext) war = true;
+            }
+        kinds[0] += war;
+        kinds[1] += dup;
+        kinds[2] += dupRead;
+        kinds[3] += n;
+        if (++steps % 200000 == 0)
+            fprintf(stderr, "walk census: %ld steps, %.2f averages per step; read-then-written %ld, written twice %ld (read in between %ld), identical repeats %ld\n",
+                    steps, (double) kinds[3] / steps, kinds[0], kinds[1], kinds[2], sameInputs);
+    }
+#endif
     bool rewrites = false;
     for (int32_t k2 = 1; k2 < n && !rewrites; k2++)
         for (int32_t k = 0; k < k2; k++)
