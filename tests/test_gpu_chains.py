@@ -131,6 +131,37 @@ def test_walk_step_equals_chain_plus_distances(dt, nc, ring):
     ops.close()
 
 
+@pytest.mark.parametrize("ring", [0, 1])
+@pytest.mark.parametrize("dt,nc", [(np.float32, 4), (np.float64, 20)])
+def test_walk_step_that_rewrites_nodes(dt, nc, ring):
+    """Three steps in ten of an SPR round write a node that the step read or wrote earlier (an up-profile slot re-used, a node
+    recomputed after its old profile went into another average).  The six pair workgroups of the step kernels must not each run such
+    a chain (one that is ahead would hand a later value to one that is behind): vft_walk_step runs it once and the pairs in a second
+    launch.  Against the plain sequence on an identical state, twenty times over (the race needed a dozen runs of a pipeline to show)."""
+    a_ops, rng, free = make_state(dt, nc, seed=11)
+    b_ops, _, _ = make_state(dt, nc, seed=11)
+    assert a_ops.lib.vft_debug_option(a_ops.ctx, I32(8), I64(ring)) == 0
+    X, Y, Z = free, free + 1, free + 2
+    for trial in range(20):
+        e = [int(v) for v in rng.integers(0, free, 6)]
+        # X written, read, written again; e[2] (an old node) read and then overwritten; Y written twice without a read in between
+        out = np.array([X, Y, X, Y, Z, e[2] if e[2] >= 48 else 60, Z], np.int64)
+        a = np.array([e[0], X, Y, e[3], e[2], X, Z], np.int64)
+        b = np.array([e[1], e[2], e[4], X, Y, e[5], e[0]], np.int64)
+        q = np.array([X, Z, int(out[5]), e[1]], np.int64)
+        d1 = np.zeros(6, dt)
+        assert a_ops.lib.vft_walk_step(a_ops.ctx, I32(len(out)), ptr(out), ptr(a), ptr(b), ptr(q), ptr(d1)) == 0
+        assert b_ops.lib.vft_average_chain(b_ops.ctx, I32(len(out)), ptr(out), ptr(a), ptr(b)) == 0
+        pi = np.array([q[0], q[0], q[0], q[1], q[1], q[2]], np.int64)
+        pj = np.array([q[1], q[2], q[3], q[2], q[3], q[3]], np.int64)
+        d2, _ = b_ops.profileDist(pi, pj)
+        assert np.array_equal(np.asarray(d1).view(np.uint8), np.asarray(d2, dt).view(np.uint8)), (trial, d1, d2)
+        for x in set(int(v) for v in out):
+            assert same(a_ops.profile_download(x), b_ops.profile_download(x)), (trial, x)
+    a_ops.close()
+    b_ops.close()
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_posterior_chains_equal_single_chains(dt):
     ops, rng, free = make_state(dt, 4)
