@@ -1300,7 +1300,7 @@ extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const in
         c->walkLdsSet = true;
     }
     const size_t rs = c->rs;
-    if (n <= VFT_WALK_ARGS && !c->walkIdsInRing) {   // the usual step: ids in the kernel arguments, one flag per workgroup (k_walk_step_args)
+    if (n <= VFT_WALK_ARGS && !c->walkIdsInRing && c->d.maxNodes <= 0x7FFFFFFF) {   // (32-bit ids in the arguments)   // the usual step: ids in the kernel arguments, one flag per workgroup (k_walk_step_args)
         const unsigned long long seq = ++c->signalSeq;
         // nOps averages and then (chainOnly: nothing else, one workgroup; otherwise) the six pairs, one workgroup each
         auto go = [&](int32_t nOps, bool chainOnly) -> int {
