@@ -568,6 +568,18 @@ def gen_c4_tree(tmp):
                         join_trace_flags=np.frombuffer(b"-nt -noml -nome -nosupport -threads 1 -seed 1 -verbose 3", dtype=np.uint8),
                         alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8))
     print("bb_c4_t6: %d bytes of Newick, crc %d; join order over %d joins" % (len(tree), zlib.crc32(tree.encode()), len(ja)))
+    # The pin proper: the ONE-thread run's tree, if a run was allowed to finish (`VeryFastTree -nt -noml -nome -nosupport -threads 1
+    # -seed 1 c4.fa > oracle/_ref/c4_nj_t1.tree`, ~17 h; one was started detached at the end of round 4) -> bb_c4_crc.npz, which
+    # bench.py's e2e_c4 compares with (identical_to_reference).
+    t1 = os.path.join(HERE, "_ref", "c4_nj_t1.tree")
+    if os.path.exists(t1) and os.path.getsize(t1) > 20000000:
+        tree1 = open(t1, "rb").read().decode().strip()
+        if tree1.endswith(";"):
+            f1 = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "1", "-seed", "1"]
+            np.savez_compressed(os.path.join(GOLDEN, "bb_c4_crc.npz"), newick_crc=np.int64(zlib.crc32(tree1.encode())), newick_bytes=np.int64(len(tree1)),
+                                flags=np.frombuffer(" ".join(f1).encode(), dtype=np.uint8),
+                                alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8))
+            print("bb_c4_crc: %d bytes of Newick, crc %d (the one-thread reference)" % (len(tree1), zlib.crc32(tree1.encode())))
 
 
 def gen_c4_scaled(tmp, sizes=(200000, 400000)):
