@@ -339,7 +339,8 @@ int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t
 int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
                        const int64_t *b);
 
-/* One step of a host-driven refinement walk (an SPR chain step, a minimum-evolution NNI of the one-thread order) as ONE launch and
+/* One step of a host-driven refinement walk (an SPR chain step, a minimum-evolution NNI of the one-thread order) as ONE launch (two
+   when the step writes a node it has read or written before: the chain then runs in one workgroup, the six pairs in a second launch) and
    one wait: the n unweighted averages queued since the last step, in order (as vft_average_chain; n <= 256, may be 0), then the six
    raw profile distances AB AC AD BC BD CD of the quartet q[0..3] = A, B, C, D (as vft_profile_distances; chooseNNI, NJ.tcc:4836-4846)
    into dist[6] (numeric_t).  Results are bit-identical to the two calls.  Needs vft_set_profile_rows(ctx, 1) with every internal
