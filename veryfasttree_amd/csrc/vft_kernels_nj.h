@@ -1162,6 +1162,11 @@ __global__ __launch_bounds__(WG) void k_walk_step_args(Arena<REAL> A, const Walk
             REAL wo, f[NC];
             int co;
             if (ldsTables) vft_average_col<REAL, NC, DmLds<REAL>>(A, c1, c2, 0.5, tol, wo, co, f, T);
+#ifndef VFT_WALK_BRANCHY_AVG   // (A/B builds: the branchy average everywhere)
+            else if (NC == 4 && A.dmDist == nullptr) {   // selects instead of branches: -5 % per step at 200 columns, neutral at 1 000
+                if constexpr (NC == 4) vft_average_col_nt_select<REAL>(c1, c2, tol, wo, co, f);
+            }
+#endif
             else vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
             vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
             prevOut = o;

@@ -297,6 +297,48 @@ __device__ __forceinline__ void vft_average_col(const Arena<REAL> &A, const Col<
     vft_average_col<REAL, NC, DmGlobal<REAL>>(A, c1, c2, bw, tol, wo, co, f, DmGlobal<REAL>(A));
 }
 
+// The same for nucleotides without a distance matrix, written with selects instead of branches: the kinds of column (gap, code,
+// vector) differ from lane to lane, and a latency-bound caller with one wavefront per SIMD (k_walk_step_args) pays for every branch
+// region a wavefront walks through.  Same operations on the same operands in the same order as vft_average_col / vft_add_to_freq /
+// vft_normalize_freq above; results of the paths a lane does not take are computed and dropped.
+template <typename REAL>
+__device__ __forceinline__ void vft_average_col_nt_select(const Col<REAL, 4> &c1, const Col<REAL, 4> &c2, double tol, REAL &wo, int &co,
+                                                          REAL *f) {
+    const double bw = 0.5;
+    wo = (REAL) (bw * (double) c1.w + (1 - bw) * (double) c2.w);
+    const bool pos = wo > 0, p1 = c1.w > 0, p2 = c2.w > 0;
+    const bool k1 = p1 && c1.code != VFT_NOCODE_ && (c2.w <= 0 || c1.code == c2.code);
+    const bool k2 = !k1 && c1.w <= 0 && p2 && c2.code != VFT_NOCODE_;
+    co = pos ? (k1 ? c1.code : k2 ? c2.code : VFT_NOCODE_) : VFT_NOCODE_;
+    const bool mix = pos && co == VFT_NOCODE_;
+    const double wt1 = (double) c1.w * bw, wt2 = (double) c2.w * (1.0 - bw);
+    const REAL wr1 = (REAL) wt1, wr2 = (REAL) wt2;
+    REAL g[4];
+    double total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        REAL v = 0;
+        {
+            const REAL pr = c1.f[k] * wr1;
+            const REAL asVec = v + pr;
+            const REAL asCode = (REAL) ((double) v + wt1);
+            v = p1 ? (c1.vec ? asVec : (k == c1.code ? asCode : v)) : v;
+        }
+        {
+            const REAL pr = c2.f[k] * wr2;
+            const REAL asVec = v + pr;
+            const REAL asCode = (REAL) ((double) v + wt2);
+            v = p2 ? (c2.vec ? asVec : (k == c2.code ? asCode : v)) : v;
+        }
+        g[k] = v;
+        total += (double) v;
+    }
+    const REAL inv = (REAL) (1.0 / total);
+    const bool scale = total > tol;
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = mix ? (scale ? g[k] * inv : (REAL) (1.0 / 4)) : (REAL) 0;
+}
+
 // averageProfile: grid.y = join index, threads over columns
 template <typename REAL, int NC>
 __global__ void k_average(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN,
