@@ -347,6 +347,24 @@ int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off,
    profile a plain row - VFT_ERR_STATE otherwise (the caller falls back to the two calls). */
 int vft_walk_step(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, void *dist);
 
+/* The walk server: the same steps WITHOUT a launch each.  vft_walk_server_start leaves six workgroups resident on a stream of their own
+   (csrc/vft_kernels_walk.h); from then on vft_walk_step hands its step over through a mailbox they poll (a round trip of ~2.5 us instead
+   of ~11 for a launch and its completion wait) until vft_walk_server_stop - or any other call that launches on the context's stream,
+   which retires the server first.  The walks of host/MLLengths.h (doSPR, the one-thread minimum-evolution NNIs: traverseSPR
+   NJ.tcc:6185-6312, traverseNNI :5797-5990) start it around their loops.  vft_walk_submit / vft_walk_collect split a step in two so that a
+   caller who does not need a step's distances to build the next step (the forced first NNI of an SPR chain, NJ.tcc:1820-1830) can have
+   two steps in flight; q == NULL submits averages alone (collect with dist == NULL waits for their acknowledgement).  Results are
+   bit-identical to vft_walk_step without the server.  VFT_ERR_STATE from start: rows missing, alignment too long for the staging, or the
+   server switched off - the caller keeps the launch per step.  One server per process. */
+int vft_walk_server_start(vft_ctx *ctx);
+int vft_walk_server_stop(vft_ctx *ctx);
+int vft_walk_submit(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, uint32_t *ticket);
+int vft_walk_collect(vft_ctx *ctx, uint32_t ticket, void *dist);
+/* tools builds (-DVFT_WALK_TIMING): clock ticks (100 MHz) workgroup 0 of the server spent per phase since the context was created -
+   [0] waiting for a command, [1] averages, [2] waiting for the other workgroups' averages, [3] the pair's columns, [4] the ordered
+   sums, [5] the answer; zeros in a production build */
+int vft_walk_server_ticks(vft_ctx *ctx, int64_t *out, int32_t n);
+
 /* differ[k] = 1 when the profiles of nodes a[k] and b[k] are not bit-identical (weights, codes, vectors), else 0; n <= 4096.  The
    speculative SPR rounds (host/MLLengths.h, doSPRSpeculative) ask whether an attempt that left the tree as it was also left the
    profiles it recomputed as they were.  Waits. */
@@ -445,6 +463,9 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_WAIT_LIMIT_MS 6      /* the longest a wait for a completion flag may last while the stream is busy (default 120 000) */
 #define VFT_DEBUG_WIDE_GLUE 7          /* value != 0: vft_nj_engine_create takes the 1 024-thread glue kernel (lists beyond 1 024 hits) at any size */
 #define VFT_DEBUG_WALK_IDS_IN_RING 8  /* value != 0: vft_walk_step reads its ids from the mapped ring and publishes through the staging buffer at any step length (the path of steps with more than 16 averages) */
+#define VFT_DEBUG_NO_WALK_SERVER 9      /* value != 0: vft_walk_server_start answers VFT_ERR_STATE - the walks keep one launch per step (tests compare) */
+#define VFT_DEBUG_WALK_DEVICE_MAILBOX 10 /* value != 0: the server's mailbox in device memory written through the PCIe aperture (large-BAR boxes) instead of pinned host memory */
+#define VFT_DEBUG_WALK_SERVER_STRIDE 11 /* 1: the server's six workgroups on six XCDs instead of one (placement is for speed only; tests run both) */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */

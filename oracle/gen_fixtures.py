@@ -498,6 +498,43 @@ def gen_c2(tmp):
     print("bb_c2_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ll), wall))
 
 
+def gen_c5(tmp, n=50000):
+    """BASELINE config C5 (50 000 aa x 300, `-lg -double-precision`, one thread, the complete default pipeline with supports), or the
+    same generator at a smaller n: CRC-32 and length of the reference's tree and its TreeLogLk lines - what bench.py's e2e_c5 leg and
+    tests/test_gpu_fullsize.py compare the one-thread-order run with.  bb_c5_crc.npz for n = 50 000, bb_c5_<n/1000>k_crc.npz otherwise.
+    Hours of one core at full size; the files are written under oracle/_ref/ first so that a run that outlives this script can be
+    harvested (`c5h:<n>`)."""
+    import time
+    codes = synth.random_descent_codes(n, 300, 20, 0.03, 0.01, seed=2)
+    tag = "c5" if n == 50000 else "c5_%dk" % (n // 1000)
+    fa = os.path.join(HERE, "_ref", tag + ".fa")
+    synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA)
+    del codes
+    flags = ["-lg", "-double-precision", "-threads", "1", "-seed", "1"]
+    log = os.path.join(HERE, "_ref", tag + ".log")
+    t0 = time.time()
+    with open(os.path.join(HERE, "_ref", tag + ".tree"), "wb") as out, open(os.path.join(HERE, "_ref", tag + ".err"), "wb") as err:
+        subprocess.run([REFBIN] + flags + ["-log", log, fa], check=True, stdout=out, stderr=err)
+    open(os.path.join(HERE, "_ref", tag + ".wall"), "w").write("%.1f" % (time.time() - t0))
+    os.remove(fa)
+    harvest_c5(n)
+
+
+def harvest_c5(n):
+    import zlib
+    tag = "c5" if n == 50000 else "c5_%dk" % (n // 1000)
+    tree = open(os.path.join(HERE, "_ref", tag + ".tree"), "rb").read().decode().strip()
+    assert tree.endswith(";"), "the reference has not finished"
+    wall = float(open(os.path.join(HERE, "_ref", tag + ".wall")).read())
+    ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", open(os.path.join(HERE, "_ref", tag + ".log")).read(), re.M)]
+    flags = ["-lg", "-double-precision", "-threads", "1", "-seed", "1"]
+    np.savez_compressed(os.path.join(GOLDEN, "bb_%s_crc.npz" % tag), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+                        loglk=np.array(ll), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(("random_descent_codes(%d, 300, 20, 0.03, 0.01, seed=2)" % n).encode(), dtype=np.uint8),
+                        reference_wall_s=np.float64(wall))
+    print("bb_%s_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (tag, len(tree), zlib.crc32(tree.encode()), len(ll), wall))
+
+
 def gen_c4(tmp):
     """BASELINE config C4 at full size (1 000 000 x 200 nt, `-nt` at one thread): CRC-32 and length of the reference's
     `-noml -nome -nosupport` tree, plus the join order as one CRC-32 per 10 000 `Join` lines (`i j new`, NJ.tcc:2993-3001)
@@ -675,6 +712,11 @@ def main():
             gen_c3(tmp)
         if "c2" in which:   # not part of the default set: minutes
             gen_c2(tmp)
+        for w in which:     # `c5:<n>`: config C5's generator at n sequences (50000 = the config itself, hours); `c5h:<n>` harvests a finished run
+            if w.startswith("c5:"):
+                gen_c5(tmp, int(w[3:]))
+            if w.startswith("c5h:"):
+                harvest_c5(int(w[4:]))
         if "c4" in which:   # not part of the default set: hours
             gen_c4(tmp)
         if "c4_tree" in which:   # from the files a finished reference run left under oracle/_ref/

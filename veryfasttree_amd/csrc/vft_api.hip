@@ -25,6 +25,9 @@ VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_tophits.h"
 #include "vft_kernels_njengine.h"
 #include "vft_kernels_spr.h"
+#include "vft_kernels_walk.h"
+
+VFT_WALK_SERVER_INSTANCES(extern)   // compiled in vft_walk_kernels.hip
 
 struct vft_ctx {
     vft_config cfg;
@@ -148,6 +151,21 @@ struct vft_ctx {
     size_t thRefreshLds = 0;           // the largest dynamic LDS k_th_refresh has been configured for
     size_t pbLdsSet = 0;               // ... and k_pairs_block_tiled
     bool walkLdsSet = false;           // k_walk_step's dynamic LDS limit has been raised
+    // the walk server (vft_kernels_walk.h): six resident workgroups that take the steps of a refinement walk from a mailbox
+    struct WalkServerHost {
+        bool up = false;
+        hipStream_t stream = nullptr;
+        unsigned long long *hMail = nullptr, *dMail = nullptr;   // the mailbox as the CPU writes it / as the kernel polls it
+        bool mailOnDevice = false;                                // ... in device memory behind the PCIe aperture (sfence after writing)
+        bool wantDeviceMail = false;                              // VFT_DEBUG_WALK_DEVICE_MAILBOX
+        unsigned long long *hRes = nullptr, *dRes = nullptr;      // answers, host-mapped
+        unsigned long long *hStatus = nullptr, *dStatus = nullptr;
+        unsigned long long *dFlags = nullptr, *dTicks = nullptr;
+        uint32_t seq = 0;       // the last sequence number handed out
+        uint32_t acked = 0;     // every command up to this one has been answered by all six workgroups
+        int stride = 8;         // VFT_DEBUG_WALK_SERVER_STRIDE: 8 = the six workgroups on one XCD, 1 = on six
+        bool disabled = false;  // VFT_DEBUG_NO_WALK_SERVER
+    } ws;
     // the join loop on the device (vft_kernels_njengine.h)
     void *njState = nullptr, *njVisD = nullptr;
     int32_t *njVisJ = nullptr, *njTop = nullptr, *njAge = nullptr;
@@ -292,8 +310,13 @@ static SweepOut<REAL> sweepout(const vft_ctx *c, int slot = 0) {
     } while (0)
 
 // statement-safe launch wrapper (hipLaunchKernelGGL is a do/while macro)
+static vft_ctx *g_walkServerOwner = nullptr;   // the context whose walk server is resident (one per process)
+static int walk_server_retire(vft_ctx *c);
 template <typename... KArgs, typename... Args>
 static inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args... args) {
+    // a context whose walk server is resident owns its rows through the server: anything else launched on that context's stream
+    // first retires the server (the refinement code stops it itself; this is the safety net)
+    if (g_walkServerOwner && g_walkServerOwner->stream == s) walk_server_retire(g_walkServerOwner);
     hipLaunchKernelGGL(k, g, b, shm, s, static_cast<KArgs>(args)...);
 }
 
@@ -537,6 +560,15 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
 
 extern "C" int vft_destroy(vft_ctx *c) {
     if (!c) return VFT_OK;
+    (void) walk_server_retire(c);
+    if (c->ws.stream) {
+        hipStreamDestroy(c->ws.stream);
+        if (c->ws.mailOnDevice) hipFree(c->ws.dMail);
+        else hipHostFree(c->ws.hMail);
+        hipHostFree(c->ws.hRes);
+        hipFree(c->ws.dFlags);
+        hipFree(c->ws.dTicks);
+    }
     if (c->blen) hipFree(c->blen);
     if (c->opHist) hipFree(c->opHist);
     if (c->refDone) hipFree(c->refDone);
@@ -1235,10 +1267,215 @@ extern "C" int vft_average_chains(vft_ctx *c, int32_t nChains, const int32_t *ch
 // One step of a host-driven refinement walk as one launch (k_walk_step): n queued averages in order, then the six raw profile
 // distances of the quartet q[0..3].  VFT_ERR_STATE when some internal profile is not a plain row (the caller then takes the
 // two-call path: vft_average_chain + vft_profile_distances).
+// ---------------------------------------------------------------------------------------------- the walk server (vft_kernels_walk.h)
+// Host side: the mailbox (self-tagged 8-byte granules), the answers, start / stop.  One server per process (g_walkServerOwner).
+static inline void ws_put(vft_ctx *c, uint32_t seq, int g, uint32_t data) {
+    volatile unsigned long long *slot = c->ws.hMail + (size_t) (seq % VFT_WS_RING) * VFT_WS_GRAN;
+    slot[g] = ((unsigned long long) seq << 32) | (unsigned long long) data;
+}
+// all six workgroups have answered command `seq` (isDist: with a distance, copied to dist[6] when not null)
+static bool ws_answered(vft_ctx *c, uint32_t seq, bool wide) {
+    const volatile unsigned long long *slot = c->ws.hRes + (size_t) (seq % VFT_WS_RING) * VFT_WS_RESG;
+    for (int w = 0; w < VFT_WS_NWG; w++) {
+        if ((uint32_t) (slot[2 * w] >> 32) != seq) return false;
+        if (wide && (uint32_t) (slot[2 * w + 1] >> 32) != seq) return false;
+    }
+    return true;
+}
+static int ws_wait(vft_ctx *c, uint32_t seq, bool wide) {
+    std::chrono::steady_clock::time_point t0;
+    for (long spins = 0;; spins++) {
+        if (ws_answered(c, seq, wide)) {
+            if ((int32_t) (seq - c->ws.acked) > 0) c->ws.acked = seq;   // (the workgroups answer in order)
+            return VFT_OK;
+        }
+        if (spins == 200000) t0 = std::chrono::steady_clock::now();
+        if (spins >= 200000 && (spins & 0xFFFF) == 0) {
+            const hipError_t e = hipStreamQuery(c->ws.stream);
+            if (e == hipSuccess) {   // the server has left
+                if (ws_answered(c, seq, wide)) continue;
+                c->ws.up = false;
+                if (g_walkServerOwner == c) g_walkServerOwner = nullptr;
+                return fail(c, VFT_ERR_TIMEOUT, "the walk server has stopped (status %llu %llu %llu %llu %llu %llu) with command %u unanswered",
+                            c->ws.hStatus[0], c->ws.hStatus[1], c->ws.hStatus[2], c->ws.hStatus[3], c->ws.hStatus[4], c->ws.hStatus[5], seq);
+            }
+            if (e != hipErrorNotReady) return fail(c, VFT_ERR_HIP, "walk server stream: %s", hipGetErrorString(e));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->waitLimitS)
+                return fail(c, VFT_ERR_TIMEOUT, "no answer from the walk server to command %u after %.0f s", seq, c->waitLimitS);
+        }
+    }
+}
+// one command: nOps averages (<= VFT_WS_MAXOPS) and, with q, the six distances of the quartet; returns its sequence number
+static int ws_command(vft_ctx *c, int32_t nOps, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, uint32_t *seqOut) {
+    const uint32_t seq = ++c->ws.seq;
+    const bool wide = c->rs == 8;
+    // the slot of seq is the slot of seq - RING, and the answers share a ring of the same length: stay well inside it
+    while ((int32_t) (seq - c->ws.acked) > VFT_WS_RING / 2) {
+        // (answers of commands without distances are one granule per workgroup)
+        const volatile unsigned long long *slot = c->ws.hRes + (size_t) ((c->ws.acked + 1) % VFT_WS_RING) * VFT_WS_RESG;
+        (void) slot;
+        if (int r = ws_wait(c, c->ws.acked + 1, false)) return r;
+    }
+    const bool noWait = c->ws.acked == seq - 1;   // every earlier answer has been seen: no workgroup is still reading rows
+    for (int t = 0; t < 4; t++) ws_put(c, seq, 1 + t, q ? (uint32_t) (int32_t) q[t] : 0u);
+    for (int32_t k = 0; k < nOps; k++) {
+        ws_put(c, seq, 5 + 3 * k, (uint32_t) (int32_t) out[k]);
+        ws_put(c, seq, 6 + 3 * k, (uint32_t) (int32_t) a[k]);
+        ws_put(c, seq, 7 + 3 * k, (uint32_t) (int32_t) b[k]);
+    }
+    ws_put(c, seq, 0, VFT_WS_CMD_WORK | ((uint32_t) nOps << 8) | (q ? 1u << 16 : 0u) | (noWait ? 1u << 17 : 0u));
+    if (c->ws.mailOnDevice) __builtin_ia32_sfence();
+    *seqOut = seq;
+    return VFT_OK;
+}
+
+extern "C" int vft_walk_server_start(vft_ctx *c) {
+    if (!c) return VFT_ERR_INVALID;
+    if (c->ws.up) return VFT_OK;
+    if (c->ws.disabled) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: switched off (VFT_DEBUG_NO_WALK_SERVER)");
+    if (!c->rowMode || !c->allRows) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: every internal profile must be a plain row (vft_set_profile_rows)");
+    if (c->d.maxNodes > 0x7FFFFFFF || c->d.nPos * 20 * 8 > 0x7FFFFFFF) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: ids and row offsets are 32-bit");
+    if (g_walkServerOwner && g_walkServerOwner != c) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: another context's server is resident");
+    const size_t lds = (size_t) 2 * c->d.nPosPad * sizeof(double);
+    const size_t staticLds = (c->d.nCodes == 20 ? (size_t) 840 * c->rs : 8) + 1024;
+    if (lds + staticLds > (160u << 10)) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: alignment too long for one workgroup per pair");
+    vft_ctx::WalkServerHost &W = c->ws;
+    if (!W.stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipHostMalloc((void **) &W.hRes, (size_t) VFT_WS_RING * VFT_WS_RESG * 8 + 512, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void **) &W.dRes, W.hRes, 0));
+        memset(W.hRes, 0, (size_t) VFT_WS_RING * VFT_WS_RESG * 8 + 512);
+        W.hStatus = W.hRes + (size_t) VFT_WS_RING * VFT_WS_RESG;
+        W.dStatus = W.dRes + (size_t) VFT_WS_RING * VFT_WS_RESG;
+        HIPCHK(c, dalloc(&W.dFlags, 64));
+        HIPCHK(c, hipMemset(W.dFlags, 0, 64 * 8));
+        HIPCHK(c, dalloc(&W.dTicks, 16));
+        HIPCHK(c, hipMemset(W.dTicks, 0, 16 * 8));
+        const size_t mailBytes = (size_t) VFT_WS_RING * VFT_WS_GRAN * 8;
+        int largeBar = 0;
+        if (W.wantDeviceMail) (void) hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, c->cfg.device);
+        if (W.wantDeviceMail && largeBar) {   // device memory the CPU writes through the PCIe aperture: the polls stay on the device
+            HIPCHK(c, hipExtMallocWithFlags((void **) &W.dMail, mailBytes, hipDeviceMallocFinegrained));
+            HIPCHK(c, hipMemset(W.dMail, 0, mailBytes));
+            W.hMail = W.dMail;
+            W.mailOnDevice = true;
+        } else {
+            HIPCHK(c, hipHostMalloc((void **) &W.hMail, mailBytes, hipHostMallocMapped));
+            HIPCHK(c, hipHostGetDevicePointer((void **) &W.dMail, W.hMail, 0));
+            memset(W.hMail, 0, mailBytes);
+        }
+        HIPCHK(c, hipDeviceSynchronize());
+    }
+    if (int r = wait_stream(c)) return r;   // everything queued on the context's stream has written its rows
+    for (int w = 0; w < VFT_WS_NWG; w++) W.hStatus[w] = 0;
+    WalkServerArgs S{};
+    S.mail = W.dMail;
+    S.res = W.dRes;
+    S.flags = W.dFlags;
+    S.status = W.dStatus;
+    S.ticks = W.dTicks;
+    S.tol = c->fpostTol;
+    S.firstSeq = W.seq + 1;
+    S.stride = W.stride;
+    S.idleTicks = 3000000000ll;   // 30 s without a command: the host has gone away
+    S.flagTicks = 500000000ll;    // 5 s for another workgroup's flag
+    W.acked = W.seq;
+    VFT_DISPATCH(c, {
+        if (lds > (48u << 10)) HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_server<REAL, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL((k_walk_server<REAL, NC>), dim3((VFT_WS_NWG - 1) * W.stride + 1), dim3(VFT_WS_WG_OF(NC)), lds, W.stream, arena<REAL>(c), S);
+    });
+    LAUNCHCHK(c);
+    W.up = true;
+    g_walkServerOwner = c;
+    return VFT_OK;
+}
+
+static int walk_server_retire(vft_ctx *c) {
+    vft_ctx::WalkServerHost &W = c->ws;
+    if (!W.up) return VFT_OK;
+    W.up = false;
+    if (g_walkServerOwner == c) g_walkServerOwner = nullptr;
+    const uint32_t seq = ++W.seq;
+    ws_put(c, seq, 0, VFT_WS_CMD_STOP);
+    if (W.mailOnDevice) __builtin_ia32_sfence();
+    HIPCHK(c, hipStreamSynchronize(W.stream));
+    for (int w = 0; w < VFT_WS_NWG; w++)
+        if (W.hStatus[w] != 1) return fail(c, VFT_ERR_TIMEOUT, "walk server: workgroup %d ended with status %llu", w, W.hStatus[w]);
+    return VFT_OK;
+}
+extern "C" int vft_walk_server_stop(vft_ctx *c) {
+    if (!c) return VFT_ERR_INVALID;
+    return walk_server_retire(c);
+}
+extern "C" int vft_walk_server_ticks(vft_ctx *c, int64_t *out, int32_t n) {
+    if (!c || !out || n < 0 || n > 16) return VFT_ERR_INVALID;
+    if (c->ws.up) return fail(c, VFT_ERR_STATE, "vft_walk_server_ticks: stop the server first");
+    for (int32_t k = 0; k < n; k++) out[k] = 0;
+    if (!c->ws.dTicks) return VFT_OK;
+    unsigned long long t[16];
+    HIPCHK(c, hipMemcpy(t, c->ws.dTicks, sizeof(t), hipMemcpyDeviceToHost));
+    for (int32_t k = 0; k < n; k++) out[k] = (int64_t) t[k];
+    return VFT_OK;
+}
+
+static int walk_ids_ok(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, const char *who);
+
+// a step (or, with q == NULL, averages alone) handed to the server; *ticket answers vft_walk_collect.  Steps with more than
+// VFT_WS_MAXOPS averages go down as several commands, the distances with the last.
+extern "C" int vft_walk_submit(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, uint32_t *ticket) {
+    if (!c || n < 0 || (n > 0 && (!out || !a || !b)) || !ticket) return VFT_ERR_INVALID;
+    if (!c->ws.up) return fail(c, VFT_ERR_STATE, "vft_walk_submit: the walk server is not running (vft_walk_server_start)");
+    if (int r = walk_ids_ok(c, n, out, a, b, q, "vft_walk_submit")) return r;
+    int32_t first = 0;
+    uint32_t seq = 0;
+    do {
+        const int32_t m = n - first > VFT_WS_MAXOPS ? VFT_WS_MAXOPS : n - first;
+        const bool last = first + m == n;
+        if (int r = ws_command(c, m, out + first, a + first, b + first, last ? q : nullptr, &seq)) return r;
+        first += m;
+    } while (first < n);
+    *ticket = seq;
+    return VFT_OK;
+}
+// waits for the answer to a ticket; dist[6] (numeric_t) when the step asked for distances (NULL: an acknowledgement is waited for)
+extern "C" int vft_walk_collect(vft_ctx *c, uint32_t ticket, void *dist) {
+    if (!c) return VFT_ERR_INVALID;
+    const bool wide = c->rs == 8 && dist != nullptr;
+    if (int r = ws_wait(c, ticket, wide)) return r;
+    if (dist) {
+        const volatile unsigned long long *slot = c->ws.hRes + (size_t) (ticket % VFT_WS_RING) * VFT_WS_RESG;
+        for (int w = 0; w < VFT_WS_NWG; w++) {
+            if (c->rs == 4) {
+                const uint32_t v = (uint32_t) slot[2 * w];
+                memcpy((char *) dist + 4 * w, &v, 4);
+            } else {
+                const unsigned long long v = (slot[2 * w] & 0xFFFFFFFFull) | (slot[2 * w + 1] << 32);
+                memcpy((char *) dist + 8 * w, &v, 8);
+            }
+        }
+    }
+    return VFT_OK;
+}
+static int walk_ids_ok(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, const char *who) {
+    for (int32_t k = 0; k < n; k++) {
+        if (int r = internal_ok(c, out[k])) return r;
+        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "%s: bad child id", who);
+    }
+    if (q)
+        for (int t = 0; t < 4; t++)
+            if (q[t] < 0 || q[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "%s: quartet member out of range", who);
+    return VFT_OK;
+}
+
 extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, void *dist) {
     if (!c || n < 0 || (n > 0 && (!out || !a || !b)) || !q || !dist) return VFT_ERR_INVALID;
     if (!c->rowMode || !c->allRows) return fail(c, VFT_ERR_STATE, "vft_walk_step: every internal profile must be a plain row (vft_set_profile_rows)");
     if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_walk_step: at most 256 averages per step");
+    if (c->ws.up) {   // the resident workgroups take it: no launch
+        uint32_t ticket;
+        if (int r = vft_walk_submit(c, n, out, a, b, q, &ticket)) return r;
+        return vft_walk_collect(c, ticket, dist);
+    }
     for (int32_t k = 0; k < n; k++) {
         if (int r = internal_ok(c, out[k])) return r;
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_walk_step: bad child id");
@@ -3691,6 +3928,9 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_WAIT_LIMIT_MS: c->waitLimitS = value > 0 ? (double) value / 1000.0 : 120.0; break;
         case VFT_DEBUG_WIDE_GLUE: c->wideGlue = value != 0; break;
         case VFT_DEBUG_WALK_IDS_IN_RING: c->walkIdsInRing = value != 0; break;
+        case VFT_DEBUG_NO_WALK_SERVER: c->ws.disabled = value != 0; break;
+        case VFT_DEBUG_WALK_DEVICE_MAILBOX: c->ws.wantDeviceMail = value != 0; break;
+        case VFT_DEBUG_WALK_SERVER_STRIDE: c->ws.stride = value == 1 ? 1 : 8; break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }
     return VFT_OK;

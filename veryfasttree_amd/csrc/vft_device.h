@@ -246,6 +246,31 @@ __device__ __forceinline__ double vft_piece(const Arena<REAL> &A, const Col<REAL
     return vft_piece<REAL, NC, DmGlobal<REAL>>(A, c1, c2, cd2, DmGlobal<REAL>(A));
 }
 
+// One column's addends to (denom, top) of a profile distance (profileDist NJ.tcc:1176-1182, seqDist :1614-1620), parked in LDS for the
+// in-order sum of the pair kernels (vft_kernels_nj.h vft_pair_wave / vft_pair_block, vft_kernels_walk.h)
+template <typename REAL, int NC, typename DM>
+__device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
+                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT, const DM &T) {
+    double wgt = 0.0, term = 0.0;
+    if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
+        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
+            wgt = 1.0;
+            term = A.dmDist ? (double) T.dist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
+        }
+    } else if (c1.w > 0 && c2.w > 0) {
+        const REAL ww = c1.w * c2.w;
+        wgt = (double) ww;
+        term = wgt * vft_piece<REAL, NC, DM>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr, T);
+    }
+    sW[p] = wgt;
+    sT[p] = term;
+}
+template <typename REAL, int NC>
+__device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
+                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT) {
+    vft_pair_addends<REAL, NC, DmGlobal<REAL>>(A, leaves, jIsOut, p, c1, c2, sW, sT, DmGlobal<REAL>(A));
+}
+
 // setOutDistance's closed form (NJ.tcc:1046-1053): numeric_t products, one double division.
 template <typename REAL>
 __device__ __forceinline__ REAL vft_out_distance(REAL dist, REAL weight, int64_t nActive, REAL selfweight,

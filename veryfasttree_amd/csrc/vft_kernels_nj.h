@@ -624,30 +624,7 @@ __device__ __forceinline__ bool vft_is_row(const Arena<REAL> &A, int64_t node) {
 #endif
     return node >= A.d.nSeqs && A.mlIs != nullptr && A.mlIs[node - A.d.nSeqs] != 0;
 }
-// its addends to (denom, top), parked in LDS for the in-order sum
-template <typename REAL, int NC, typename DM>
-__device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
-                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT, const DM &T) {
-    double wgt = 0.0, term = 0.0;
-    if (leaves) {   // seqDist with a distance matrix (NJ.tcc:1614-1620): top += distances[c1][c2], in order
-        if (c1.code != VFT_NOCODE_ && c2.code != VFT_NOCODE_) {
-            wgt = 1.0;
-            term = A.dmDist ? (double) T.dist[c1.code * NC + c2.code] : (c1.code != c2.code ? 1.0 : 0.0);
-        }
-    } else if (c1.w > 0 && c2.w > 0) {
-        const REAL ww = c1.w * c2.w;
-        wgt = (double) ww;
-        term = wgt * vft_piece<REAL, NC, DM>(A, c1, c2, (jIsOut && A.outCD) ? A.outCD + p * NC : nullptr, T);
-    }
-    sW[p] = wgt;
-    sT[p] = term;
-}
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_pair_addends(const Arena<REAL> &A, bool leaves, bool jIsOut, int64_t p,
-                                                 const Col<REAL, NC> &c1, const Col<REAL, NC> &c2, double *sW, double *sT) {
-    vft_pair_addends<REAL, NC, DmGlobal<REAL>>(A, leaves, jIsOut, p, c1, c2, sW, sT, DmGlobal<REAL>(A));
-}
-
+// (vft_pair_addends - a column's addends to (denom, top), parked in LDS for the in-order sum - lives in vft_device.h: the walk server's unit uses it too)
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_pair_wave(const Arena<REAL> &A, int64_t i, int64_t j, bool jIsOut, double *sW,
                                               double *sT, REAL &dist, REAL &weight) {

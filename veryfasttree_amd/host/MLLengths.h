@@ -617,6 +617,7 @@ namespace veryfasttree {
             }
             int64_t node = root;
             bool bUp = false;
+            WalkServerGuard server(*this, !prm.useML);   /* minimum evolution: every step is a vft_walk_step */
             while ((node = nextPostorder(node, traversal, &bUp, root)) >= 0) {
                 if (node < nSeqs || node == root) continue;
                 if (bUp) {   /* back at a node whose surroundings were rearranged: refresh it (NJ.tcc:5809-5820) */
@@ -686,7 +687,7 @@ namespace veryfasttree {
                     updateForNNI(node, prm.useML, upHave);
                 }
             }
-            flushAverages();
+            server.finish();
             flushPosteriors();
             rebuildOrder();
             return nNNIThisRound;
@@ -874,6 +875,7 @@ namespace veryfasttree {
             struct Step {
                 int64_t nodes[2];
                 double deltaLength;
+                bool bc;
             };
             Step steps[64];
             if (maxSPRLength > 64) throw std::invalid_argument("MLLengths::sprAttempt: chains of at most 64 steps");
@@ -882,21 +884,40 @@ namespace veryfasttree {
             bool bChanged = false;
             for (int iAround = 0; iAround < 2 && !bChanged; iAround++) {
                 for (int acFirst = 0; acFirst < 2 && !bChanged; acFirst++) {
-                    /* findSPRSteps */
+                    /* findSPRSteps.  The first NNI of a chain is forced (AC or AD by acFirst), its criteria only price it: the
+                       second step is built and handed over before the first one's distances are waited for */
                     int64_t around = nodeAround[iAround], chainLength = 0;
+                    MeTicket first;
+                    bool firstOpen = false;
                     for (; chainLength < maxSPRLength; chainLength++) {
                         if (around < nSeqs || around == root) break;   /* nChild != 2 */
                         int64_t q[4];
                         double criteria[3];
-                        meCriteria(around, scoredist, upHave, q, criteria);
+                        MeTicket tk;
+                        meSubmit(around, upHave, q, tk);
                         sprSteps++;
                         Step &st = steps[(size_t) chainLength];
-                        if (chainLength == 0 ? acFirst != 0 : criteria[1] < criteria[2]) {
-                            st.deltaLength = criteria[1] - criteria[0];   /* swap B and C: AC together */
+                        bool swapBC;
+                        if (chainLength == 0) {
+                            swapBC = acFirst != 0;
+                            first = tk;
+                            firstOpen = true;
+                        } else {
+                            if (firstOpen) {
+                                double c0[3];
+                                meCollect(first, scoredist, c0);
+                                steps[0].deltaLength = (steps[0].bc ? c0[1] : c0[2]) - c0[0];
+                                firstOpen = false;
+                            }
+                            meCollect(tk, scoredist, criteria);
+                            swapBC = criteria[1] < criteria[2];
+                            st.deltaLength = (swapBC ? criteria[1] : criteria[2]) - criteria[0];
+                        }
+                        st.bc = swapBC;
+                        if (swapBC) {   /* swap B and C: AC together */
                             st.nodes[0] = q[1];
                             st.nodes[1] = q[2];
-                        } else {
-                            st.deltaLength = criteria[2] - criteria[0];   /* swap A and C: AD together */
+                        } else {        /* swap A and C: AD together */
                             st.nodes[0] = q[0];
                             st.nodes[1] = q[2];
                         }
@@ -906,6 +927,11 @@ namespace veryfasttree {
                         int64_t next[2];
                         movePivots(node, next);
                         around = next[next[0] == around ? 1 : 0];
+                    }
+                    if (firstOpen) {
+                        double c0[3];
+                        meCollect(first, scoredist, c0);
+                        steps[0].deltaLength = (steps[0].bc ? c0[1] : c0[2]) - c0[0];
                     }
                     double dMinDelta = 0.0, dTotDelta = 0.0;
                     int64_t iCBest = -1;
@@ -968,9 +994,10 @@ namespace veryfasttree {
             }
             hostWalk:
             int64_t nSPR = 0;
+            WalkServerGuard server(*this);
             for (int64_t node: nodeList)
                 if (sprAttempt(node, scoredist, maxSPRLength, upHave)) nSPR++;
-            flushAverages();
+            server.finish();
             rebuildOrder();
             return nSPR;
         }
@@ -1221,6 +1248,8 @@ namespace veryfasttree {
 
         int64_t nStarTests = 0;
         bool walkStepFused = true;   /* meCriteria: averages + distances as one launch (false: two calls; tests compare) */
+        bool walkServer = true;      /* the walks' steps go to resident workgroups through a mailbox (vft_walk_server_start) instead of one
+                                        launch each; false: the launch per step (tests compare) */
         bool sprOnDevice = true;    /* false: the host-driven SPR walk (tests compare the two) */
         int64_t sprPosPad = 1 << 30;   /* the context's padded column count (setSprPosPad); unknown: host walk */
         int64_t sprSteps = 0;
@@ -1454,8 +1483,16 @@ namespace veryfasttree {
         }
 
         /* setupABCD + chooseNNI's criteria (NJ.tcc:4836-4846; lower is better): log-corrected distances AB+CD, AC+BD,
-           AD+BC over the four profiles around `node` */
-        void meCriteria(int64_t node, bool scoredist, std::vector<char> &upHave, int64_t q[4], double criteria[3]) {
+           AD+BC over the four profiles around `node`.  In two halves: meSubmit queues the up-profile of the quartet and hands the
+           step - the averages queued since the last one + the six distances - to the device; meCollect waits for the distances.
+           With the walk server up a caller that does not need a step's criteria to build the next step (sprAttempt: the first
+           NNI of a chain is forced) keeps two steps in flight; otherwise meSubmit has waited already. */
+        struct MeTicket {
+            uint32_t ticket = 0;
+            bool pending = false;
+            REAL d[6];
+        };
+        void meSubmit(int64_t node, std::vector<char> &upHave, int64_t q[4], MeTicket &t) {
             quartetNodes(node, q);
             const int64_t par = parent[(size_t) node];
             int64_t idD = q[3];
@@ -1463,13 +1500,22 @@ namespace veryfasttree {
                 ensureUpProfile(par, false, upHave);
                 idD = par + nSeqs;
             }
+            const int64_t q4[4] = {q[0], q[1], q[2], idD};
+            t.pending = false;
+            if (serverUp) {
+                chk(vft_walk_submit(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data(), q4, &t.ticket));
+                qOut.clear();
+                qA.clear();
+                qB.clear();
+                t.pending = true;
+                return;
+            }
             const int64_t pi[6] = {q[0], q[0], q[0], q[1], q[1], q[2]}, pj[6] = {q[1], q[2], idD, q[2], idD, idD};
-            REAL d[6], w[6];
+            REAL w[6];
             /* the queued averages and the six distances as one launch (vft_walk_step) while every profile is a plain row */
             bool fused = false;
             if (walkStepFused) {
-                const int64_t q4[4] = {q[0], q[1], q[2], idD};
-                const int rc = vft_walk_step(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data(), q4, d);
+                const int rc = vft_walk_step(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data(), q4, t.d);
                 if (rc == VFT_OK) {
                     fused = true;
                     qOut.clear();
@@ -1483,13 +1529,24 @@ namespace veryfasttree {
             }
             if (!fused) {
                 flushAverages();
-                chk(vft_profile_distances(ctx, 6, pi, pj, d, w));
+                chk(vft_profile_distances(ctx, 6, pi, pj, t.d, w));
+            }
+        }
+        void meCollect(MeTicket &t, bool scoredist, double criteria[3]) {
+            if (t.pending) {
+                chk(vft_walk_collect(ctx, t.ticket, t.d));
+                t.pending = false;
             }
             double c[6];
-            for (int i = 0; i < 6; i++) c[i] = logCorrect((double) d[i], scoredist);
+            for (int i = 0; i < 6; i++) c[i] = logCorrect((double) t.d[i], scoredist);
             criteria[0] = c[0] + c[5];
             criteria[1] = c[1] + c[4];
             criteria[2] = c[2] + c[3];
+        }
+        void meCriteria(int64_t node, bool scoredist, std::vector<char> &upHave, int64_t q[4], double criteria[3]) {
+            MeTicket t;
+            meSubmit(node, upHave, q, t);
+            meCollect(t, scoredist, criteria);
         }
 
         /* traversePostorder (NJ.tcc:3343-3380) on the tree as it is now */
@@ -1659,8 +1716,41 @@ namespace veryfasttree {
             if (qOut.size() >= 128) flushAverages();
         }
 
+        /* The walk server around a host-driven walk (doSPR, the one-thread minimum-evolution NNIs): up for the lifetime of the
+           guard when the context can run it (every profile a row, the alignment fits its staging), otherwise the walk keeps its
+           launch per step.  finish() sends what is still queued and retires the server; the destructor only retires it (an
+           exception is on its way). */
+        struct WalkServerGuard {
+            MLLengths &t;
+            explicit WalkServerGuard(MLLengths &tree, bool enable = true) : t(tree) {
+                if (!enable || !t.walkServer || !t.walkStepFused || t.serverUp) return;
+                t.flushAverages();
+                const int rc = vft_walk_server_start(t.ctx);
+                if (rc == VFT_OK) t.serverUp = true;
+                else if (rc != VFT_ERR_STATE) t.chk(rc);
+            }
+            void finish() {
+                t.flushAverages();
+                if (t.serverUp) {
+                    t.serverUp = false;
+                    t.chk(vft_walk_server_stop(t.ctx));
+                }
+            }
+            ~WalkServerGuard() {
+                if (t.serverUp) {
+                    t.serverUp = false;
+                    (void) vft_walk_server_stop(t.ctx);
+                }
+            }
+        };
+        bool serverUp = false;
+
         void flushAverages() {
             if (qOut.empty()) return;
+            if (serverUp) {   /* the resident workgroups take them, in order with the steps before and after */
+                uint32_t ticket;
+                chk(vft_walk_submit(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data(), nullptr, &ticket));
+            } else
             chk(vft_average_chain(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data()));
             qOut.clear();
             qA.clear();

@@ -68,6 +68,7 @@ namespace veryfasttree {
            measured on MI355X the kernel needs ~50 us per chain step on its one CU, the host-driven walk ~45 us with six to eight
            CUs per step; both give the same tree (tests/test_gpu_threads.py) */
         bool deviceSPR = false;
+        bool walkServer = true;    /* refinement walks through the resident walk server (vft_walk_server_start); false: a launch per step */
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
         bool gamma = false;          /* `-gamma`: rescale the final lengths to a fitted discrete Gamma (MLLengths::branchlengthScale) */
@@ -730,6 +731,7 @@ namespace veryfasttree {
             MLLengths<REAL> tree(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             tree.setSprPosPad(nPos);
             tree.sprOnDevice = opt.deviceSPR;
+            tree.walkServer = opt.walkServer;
             typename MLLengths<REAL>::NNIParams prm;
             prm.useML = false;
             prm.scoredist = opt.scoredist;
