@@ -360,10 +360,10 @@ int vft_walk_server_start(vft_ctx *ctx);
 int vft_walk_server_stop(vft_ctx *ctx);
 int vft_walk_submit(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, uint32_t *ticket);
 int vft_walk_collect(vft_ctx *ctx, uint32_t ticket, void *dist);
-/* tools builds (-DVFT_WALK_TIMING): clock ticks (100 MHz) workgroup 0 of the server spent per phase since the context was created -
+/* tools builds (-DVFT_WALK_TIMING): clock ticks (100 MHz) workgroup 0 of the servers of this process spent per phase -
    [0] waiting for a command, [1] averages, [2] waiting for the other workgroups' averages, [3] the pair's columns, [4] the ordered
-   sums, [5] the answer; zeros in a production build */
-int vft_walk_server_ticks(vft_ctx *ctx, int64_t *out, int32_t n);
+   sums, [5] the answer, [6] steps with distances, [7] averages; zeros in a production build */
+int vft_walk_server_ticks(int64_t *out, int32_t n);
 
 /* differ[k] = 1 when the profiles of nodes a[k] and b[k] are not bit-identical (weights, codes, vectors), else 0; n <= 4096.  The
    speculative SPR rounds (host/MLLengths.h, doSPRSpeculative) ask whether an attempt that left the tree as it was also left the

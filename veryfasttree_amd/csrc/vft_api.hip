@@ -160,7 +160,7 @@ struct vft_ctx {
         bool wantDeviceMail = false;                              // VFT_DEBUG_WALK_DEVICE_MAILBOX
         unsigned long long *hRes = nullptr, *dRes = nullptr;      // answers, host-mapped
         unsigned long long *hStatus = nullptr, *dStatus = nullptr;
-        unsigned long long *dFlags = nullptr, *dTicks = nullptr;
+        unsigned long long *dFlags = nullptr;
         uint32_t seq = 0;       // the last sequence number handed out
         uint32_t acked = 0;     // every command up to this one has been answered by all six workgroups
         int stride = 8;         // VFT_DEBUG_WALK_SERVER_STRIDE: 8 = the six workgroups on one XCD, 1 = on six
@@ -311,6 +311,7 @@ static SweepOut<REAL> sweepout(const vft_ctx *c, int slot = 0) {
 
 // statement-safe launch wrapper (hipLaunchKernelGGL is a do/while macro)
 static vft_ctx *g_walkServerOwner = nullptr;   // the context whose walk server is resident (one per process)
+static unsigned long long *g_wsTicks = nullptr;   // phase clock ticks of the walk server's workgroup 0 (written by -DVFT_WALK_TIMING builds only)
 static int walk_server_retire(vft_ctx *c);
 template <typename... KArgs, typename... Args>
 static inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args... args) {
@@ -567,7 +568,6 @@ extern "C" int vft_destroy(vft_ctx *c) {
         else hipHostFree(c->ws.hMail);
         hipHostFree(c->ws.hRes);
         hipFree(c->ws.dFlags);
-        hipFree(c->ws.dTicks);
     }
     if (c->blen) hipFree(c->blen);
     if (c->opHist) hipFree(c->opHist);
@@ -1336,7 +1336,8 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
     if (!c->rowMode || !c->allRows) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: every internal profile must be a plain row (vft_set_profile_rows)");
     if (c->d.maxNodes > 0x7FFFFFFF || c->d.nPos * 20 * 8 > 0x7FFFFFFF) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: ids and row offsets are 32-bit");
     if (g_walkServerOwner && g_walkServerOwner != c) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: another context's server is resident");
-    const size_t lds = (size_t) 2 * c->d.nPosPad * sizeof(double);
+    if ((c->d.nCodes == 20) != c->hasDm) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: built for nucleotides without and proteins with a distance matrix");
+    const size_t lds = (size_t) 2 * ((c->d.nPos + 31) / 32 * 32) * sizeof(double);   // (the server's ordered sums add whole thirty-twos)
     const size_t staticLds = (c->d.nCodes == 20 ? (size_t) 840 * c->rs : 8) + 1024;
     if (lds + staticLds > (160u << 10)) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: alignment too long for one workgroup per pair");
     vft_ctx::WalkServerHost &W = c->ws;
@@ -1349,8 +1350,10 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
         W.dStatus = W.dRes + (size_t) VFT_WS_RING * VFT_WS_RESG;
         HIPCHK(c, dalloc(&W.dFlags, 64));
         HIPCHK(c, hipMemset(W.dFlags, 0, 64 * 8));
-        HIPCHK(c, dalloc(&W.dTicks, 16));
-        HIPCHK(c, hipMemset(W.dTicks, 0, 16 * 8));
+        if (!g_wsTicks) {   // (per process: tools read it after the contexts are gone)
+            HIPCHK(c, dalloc(&g_wsTicks, 16));
+            HIPCHK(c, hipMemset(g_wsTicks, 0, 16 * 8));
+        }
         const size_t mailBytes = (size_t) VFT_WS_RING * VFT_WS_GRAN * 8;
         int largeBar = 0;
         if (W.wantDeviceMail) (void) hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, c->cfg.device);
@@ -1373,7 +1376,7 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
     S.res = W.dRes;
     S.flags = W.dFlags;
     S.status = W.dStatus;
-    S.ticks = W.dTicks;
+    S.ticks = g_wsTicks;
     S.tol = c->fpostTol;
     S.firstSeq = W.seq + 1;
     S.stride = W.stride;
@@ -1407,13 +1410,12 @@ extern "C" int vft_walk_server_stop(vft_ctx *c) {
     if (!c) return VFT_ERR_INVALID;
     return walk_server_retire(c);
 }
-extern "C" int vft_walk_server_ticks(vft_ctx *c, int64_t *out, int32_t n) {
-    if (!c || !out || n < 0 || n > 16) return VFT_ERR_INVALID;
-    if (c->ws.up) return fail(c, VFT_ERR_STATE, "vft_walk_server_ticks: stop the server first");
+extern "C" int vft_walk_server_ticks(int64_t *out, int32_t n) {
+    if (!out || n < 0 || n > 16) return VFT_ERR_INVALID;
     for (int32_t k = 0; k < n; k++) out[k] = 0;
-    if (!c->ws.dTicks) return VFT_OK;
+    if (!g_wsTicks) return VFT_OK;
     unsigned long long t[16];
-    HIPCHK(c, hipMemcpy(t, c->ws.dTicks, sizeof(t), hipMemcpyDeviceToHost));
+    if (hipMemcpy(t, g_wsTicks, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return VFT_ERR_HIP;
     for (int32_t k = 0; k < n; k++) out[k] = (int64_t) t[k];
     return VFT_OK;
 }

@@ -65,9 +65,12 @@ struct WalkServerArgs {
 typedef unsigned int vft_ws_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int vft_ws_u32x2 __attribute__((ext_vector_type(2)));
 
-// One row of the refinement phase as three buffer resources (weights, codes, vectors), or a leaf's byte lane of its tile.  The node
-// id is wave-uniform, so the resources live in scalar registers and a column costs one 32-bit offset per array.  Reads beyond the
-// alignment return zeros and writes there are dropped by the bounds check: whole wavefronts run without a tail test.
+// One row of the refinement phase as three buffer resources (weights, codes, vectors).  The node id is wave-uniform, so the resources
+// live in scalar registers and a column costs one 32-bit offset per array.  Reads beyond the alignment return zeros and writes there
+// are dropped by the bounds check: whole wavefronts run without a tail test.  A LEAF looks the same to the loads: its weight and
+// vector resources are empty (every read returns zero, no memory traffic) and its code resource is the leaf's byte lane of its tile,
+// so that a column is always the same three loads with no branch around them - the compiler's s_waitcnt bookkeeping stays exact and
+// loads requested an average ahead really stay in flight (a load inside a branch makes every later wait a wait for everything).
 template <typename REAL, int NC>
 struct WsRow {
     __amdgpu_buffer_rsrc_t w, c, f;
@@ -78,37 +81,30 @@ __device__ __forceinline__ WsRow<REAL, NC> vft_ws_row(const Arena<REAL> &A, int3
     WsRow<REAL, NC> R;
     const int32_t nPos = (int32_t) A.d.nPos;
     R.leaf = node < (int32_t) A.d.nSeqs;
-    if (R.leaf) {
-        const char *base = (const char *) A.leafT + (((int64_t) (node >> 6) * A.d.nChunk) * VFT_TILE + (node & (VFT_TILE - 1))) * 16;
-        R.c = __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, A.d.nChunk * (VFT_TILE * 16), 0x00020000);
-        R.w = R.c;
-        R.f = R.c;
-    } else {
-        const int64_t idx = (int64_t) (node - (int32_t) A.d.nSeqs) * nPos;
-        R.w = __builtin_amdgcn_make_buffer_rsrc((void *) (A.mlW + idx), 0, nPos * (int) sizeof(REAL), 0x00020000);
-        R.c = __builtin_amdgcn_make_buffer_rsrc((void *) (A.mlC + idx), 0, nPos, 0x00020000);
-        R.f = __builtin_amdgcn_make_buffer_rsrc((void *) (A.mlF + idx * NC), 0, nPos * NC * (int) sizeof(REAL), 0x00020000);
-    }
+    const int64_t idx = (int64_t) (R.leaf ? 0 : node - (int32_t) A.d.nSeqs) * nPos;
+    const char *leafBase = (const char *) A.leafT + (((int64_t) ((R.leaf ? node : 0) >> 6) * A.d.nChunk) * VFT_TILE + (node & (VFT_TILE - 1))) * 16;
+    R.w = __builtin_amdgcn_make_buffer_rsrc((void *) (A.mlW + idx), 0, R.leaf ? 0 : nPos * (int) sizeof(REAL), 0x00020000);
+    R.c = __builtin_amdgcn_make_buffer_rsrc(R.leaf ? (void *) leafBase : (void *) (A.mlC + idx), 0, R.leaf ? A.d.nChunk * (VFT_TILE * 16) : nPos, 0x00020000);
+    R.f = __builtin_amdgcn_make_buffer_rsrc((void *) (A.mlF + idx * NC), 0, R.leaf ? 0 : nPos * NC * (int) sizeof(REAL), 0x00020000);
     return R;
 }
-template <typename REAL>
-__device__ __forceinline__ REAL vft_ws_ld_real(__amdgpu_buffer_rsrc_t r, int32_t off);
-template <>
-__device__ __forceinline__ float vft_ws_ld_real<float>(__amdgpu_buffer_rsrc_t r, int32_t off) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, VFT_WS_SC1));
-}
-template <>
-__device__ __forceinline__ double vft_ws_ld_real<double>(__amdgpu_buffer_rsrc_t r, int32_t off) {
-    const vft_ws_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, VFT_WS_SC1);
-    return __hiloint2double((int) v.y, (int) v.x);
+// AUX: the cache policy of the loads - VFT_WS_SC1 (past the CU's L1: rows another workgroup has written) or 0 (the chain's own columns)
+template <typename REAL, int AUX>
+__device__ __forceinline__ REAL vft_ws_ld_real(__amdgpu_buffer_rsrc_t r, int32_t off) {
+    if constexpr (sizeof(REAL) == 4) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
+    } else {
+        const vft_ws_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX);
+        return __hiloint2double((int) v.y, (int) v.x);
+    }
 }
 // the NC numbers of a vector as 16-byte loads
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_ws_ld_vec(__amdgpu_buffer_rsrc_t r, int32_t p, REAL *f) {
+template <typename REAL, int NC, int AUX>
+__device__ __forceinline__ void vft_ws_ld_vec(__amdgpu_buffer_rsrc_t r, int32_t off, REAL *f) {
     constexpr int PER = 16 / (int) sizeof(REAL), NLD = NC / PER;
 #pragma unroll
     for (int t = 0; t < NLD; t++) {
-        const vft_ws_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, p * (NC * (int) sizeof(REAL)) + 16 * t, 0, VFT_WS_SC1);
+        const vft_ws_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16 * t, 0, AUX);
         if constexpr (sizeof(REAL) == 4) {
             f[4 * t] = __uint_as_float(v.x);
             f[4 * t + 1] = __uint_as_float(v.y);
@@ -141,48 +137,52 @@ __device__ __forceinline__ void vft_ws_st_vec(__amdgpu_buffer_rsrc_t r, int32_t 
     }
 }
 
-// One column in two steps, so that the loads of BOTH inputs of an average (or both members of a pair) are in flight before the
-// first is looked at: vft_ws_request issues weight, code and - 4-state alphabets: unconditionally, in the same memory round - the
-// vector; vft_ws_finish interprets them (20-state alphabets fetch the vector there, once the column is known to hold one: five
-// times the bytes otherwise).
+// One column in two steps, so that loads can be in flight long before they are looked at (both inputs of an average, and the NEXT
+// average's inputs while the current one is computed): vft_ws_request issues weight, code and (EAGER) the vector - always the same
+// loads, leaf or row; vft_ws_finish interprets them.  !EAGER (the pair phase of 20-state alphabets, whose vectors are 160 bytes a
+// column behind loads that cannot use the L1): the vector is fetched in vft_ws_finish once the column is known to hold one.
 template <typename REAL, int NC>
 struct WsRaw {
     REAL w;
     uint32_t code;
     REAL f[NC];
 };
+// the thread's offsets into the arrays of a row / into a leaf's byte lane: fixed for a column
+struct WsOff {
+    int32_t w, c, f, leaf;
+};
 template <typename REAL, int NC>
-__device__ __forceinline__ void vft_ws_request(const WsRow<REAL, NC> &R, int32_t p, WsRaw<REAL, NC> &r) {
-    if (R.leaf) {
-        r.code = __builtin_amdgcn_raw_buffer_load_b8(R.c, (p >> 4) * (VFT_TILE * 16) + (p & 15), 0, 0);
-        return;
-    }
-    r.w = vft_ws_ld_real<REAL>(R.w, p * (int) sizeof(REAL));
-    r.code = __builtin_amdgcn_raw_buffer_load_b8(R.c, p, 0, VFT_WS_SC1);
-    if constexpr (NC == 4) vft_ws_ld_vec<REAL, NC>(R.f, p, r.f);
+__device__ __forceinline__ WsOff vft_ws_off(int32_t p) {
+    WsOff o;
+    o.w = p * (int) sizeof(REAL);
+    o.c = p;
+    o.f = p * (NC * (int) sizeof(REAL));
+    o.leaf = (p >> 4) * (VFT_TILE * 16) + (p & 15);
+    return o;
 }
-template <typename REAL, int NC>
-__device__ __forceinline__ void vft_ws_finish(const WsRow<REAL, NC> &R, int32_t p, const WsRaw<REAL, NC> &r, Col<REAL, NC> &c) {
-    if (R.leaf) {
-        c.code = vft_decode<NC>(r.code);
-        c.w = c.code != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0;
-        c.vec = false;
+template <typename REAL, int NC, int AUX, bool EAGER>
+__device__ __forceinline__ void vft_ws_request(const WsRow<REAL, NC> &R, const WsOff &o, WsRaw<REAL, NC> &r) {
+    r.w = vft_ws_ld_real<REAL, AUX>(R.w, o.w);
+    r.code = __builtin_amdgcn_raw_buffer_load_b8(R.c, R.leaf ? o.leaf : o.c, 0, AUX);
+    if constexpr (EAGER) vft_ws_ld_vec<REAL, NC, AUX>(R.f, o.f, r.f);
+}
+template <typename REAL, int NC, int AUX, bool EAGER>
+__device__ __forceinline__ void vft_ws_finish(const WsRow<REAL, NC> &R, const WsOff &o, const WsRaw<REAL, NC> &r, Col<REAL, NC> &c) {
+    const int lcode = vft_decode<NC>(r.code);
+    c.code = R.leaf ? lcode : (int) r.code;
+    c.w = R.leaf ? (lcode != VFT_NOCODE_ ? (REAL) 1 : (REAL) 0) : r.w;
+    c.vec = c.w > 0 && c.code == VFT_NOCODE_ && !R.leaf;
+    if constexpr (EAGER) {
 #pragma unroll
-        for (int k = 0; k < NC; k++) c.f[k] = 0;
-        return;
-    }
-    c.w = r.w;
-    c.code = (int) r.code;
-    c.vec = c.w > 0 && c.code == VFT_NOCODE_;
-    if constexpr (NC == 4) {
-#pragma unroll
-        for (int k = 0; k < NC; k++) c.f[k] = r.f[k];
+        for (int k = 0; k < NC; k++) c.f[k] = r.f[k];   // (zeros for a leaf: its vector resource is empty)
     } else {
 #pragma unroll
         for (int k = 0; k < NC; k++) c.f[k] = 0;
-        if (c.vec) vft_ws_ld_vec<REAL, NC>(R.f, p, c.f);
+        if (c.vec) vft_ws_ld_vec<REAL, NC, AUX>(R.f, o.f, c.f);
     }
 }
+// the row's vector slot is written whatever the column holds (zeros under a code or a gap): a store inside a branch would spoil the
+// wait bookkeeping like a load does, and readers only look at the slot of a vector column
 template <typename REAL, int NC>
 __device__ __forceinline__ void vft_ws_store(const WsRow<REAL, NC> &R, int32_t p, REAL w, int code, const REAL *f) {
     if constexpr (sizeof(REAL) == 4) {
@@ -194,7 +194,7 @@ __device__ __forceinline__ void vft_ws_store(const WsRow<REAL, NC> &R, int32_t p
         __builtin_amdgcn_raw_buffer_store_b64(v, R.w, p * 8, 0, VFT_WS_SC1);
     }
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char) code, R.c, p, 0, VFT_WS_SC1);
-    if (w > 0 && code == VFT_NOCODE_) vft_ws_st_vec<REAL, NC>(R.f, p, f);
+    vft_ws_st_vec<REAL, NC>(R.f, p, f);
 }
 
 __device__ __forceinline__ unsigned long long vft_ws_ld_sys(const unsigned long long *p) {
@@ -215,40 +215,39 @@ __device__ __forceinline__ bool vft_ws_wait6(const unsigned long long *f, unsign
     }
 }
 
-// the column-ordered sum of n doubles in LDS (n a multiple of 16; the tail beyond the alignment holds +0.0): the adds are one
-// dependent chain (~13 cycles each on gfx950, tools/sumprobe), so the reads of the next sixteen are in flight while the current
-// sixteen are added
+// the column-ordered sum of n doubles in LDS (n a multiple of 32; the tail beyond the alignment holds +0.0): the adds are one
+// dependent chain (~13 cycles each on gfx950, tools/sumprobe), so the reads of the sixteen after next are issued while sixteen
+// are added - two fixed register blocks, each refilled right after it has been consumed
 __device__ __forceinline__ double vft_ws_ordered_sum(const double *src, int32_t n) {
     double acc = 0, b0[16], b1[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) b0[u] = src[u];
-    int32_t p = 16;
-    for (; p + 16 <= n; p += 32) {
 #pragma unroll
-        for (int u = 0; u < 16; u++) b1[u] = src[p + u];
+    for (int u = 0; u < 16; u++) b1[u] = src[16 + u];
+    for (int32_t p = 0;; p += 32) {
+        const bool more = p + 32 < n;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 16; u++) acc += b0[u];
         __builtin_amdgcn_sched_barrier(0);
-        if (p + 32 <= n) {
+        if (more) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) b0[u] = src[p + 16 + u];
+            for (int u = 0; u < 16; u++) b0[u] = src[p + 32 + u];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 16; u++) acc += b1[u];
         __builtin_amdgcn_sched_barrier(0);
-        if (p + 32 > n) return acc;   // (b0 was not refilled: everything is added)
-    }
+        if (!more) return acc;
 #pragma unroll
-    for (int u = 0; u < 16; u++) acc += b0[u];   // the last sixteen when n / 16 is odd (or n == 16)
-    return acc;
+        for (int u = 0; u < 16; u++) b1[u] = src[p + 48 + u];
+    }
 }
 
 template <typename REAL, int NC>
 __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A, WalkServerArgs S) {
     constexpr int WG = VFT_WS_WG_OF(NC);
-    extern __shared__ __attribute__((aligned(16))) double pwLds[];   // addends: sW [nPosPad], sT [nPosPad]
+    extern __shared__ __attribute__((aligned(16))) double pwLds[];   // addends: sW, sT, (nPos rounded up to 32) doubles each
     if (blockIdx.x % S.stride) return;
     const int w = (int) (blockIdx.x / S.stride);
     if (w >= VFT_WS_NWG) return;
@@ -264,11 +263,11 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
     T.codeFreq = (lds_t) sDm + (NC == 20 ? NC * NC : 0);
     T.eigenval = (lds_t) sDm + (NC == 20 ? 2 * NC * NC : 0);
     T.eigentot = (lds_t) sDm + (NC == 20 ? 2 * NC * NC + NC : 0);
-    const bool ldsTables = NC == 20 && A.dmDist != nullptr;
-    if (ldsTables)
+    // (the host starts the server only for 4-state alphabets without a distance matrix and 20-state ones with one)
+    if (NC == 20)
         for (int t = threadIdx.x; t < NT; t += WG)
             sDm[t] = t < NC * NC ? A.dmDist[t] : t < 2 * NC * NC ? A.dmCodeFreq[t - NC * NC] : t < 2 * NC * NC + NC ? A.dmEigenval[t - 2 * NC * NC] : A.dmEigentot[t - 2 * NC * NC - NC];
-    const int32_t nPos = (int32_t) A.d.nPos, nPosPad = (int32_t) A.d.nPosPad;
+    const int32_t nPos = (int32_t) A.d.nPos, nPosPad = (nPos + 31) & ~31;   // (the ordered sums add whole thirty-twos)
     double *sW = pwLds, *sT = pwLds + nPosPad;
     for (int32_t t = nPos + (int32_t) threadIdx.x; t < nPosPad; t += WG) sW[t] = sT[t] = 0.0;   // +0.0 beyond the alignment, for good
     if (threadIdx.x == 0) sStop = 0;
@@ -318,6 +317,7 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
         if (n > 0) {
             for (int32_t s = w + VFT_WS_NWG * wave; s < nSlices; s += VFT_WS_NWG * (WG / 64)) {
                 const int32_t p = s * 64 + lane;
+                const WsOff off = vft_ws_off<REAL, NC>(p);
                 int32_t prevOut = -1;
                 Col<REAL, NC> prev;
                 prev.w = 0;
@@ -325,26 +325,41 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
                 prev.vec = false;
 #pragma unroll
                 for (int k = 0; k < NC; k++) prev.f[k] = 0;
+                // The inputs of average k + 1 are requested BEFORE average k is computed - always, branch-free (the last average
+                // requests its own inputs again; an input that is k's output row is requested too and never looked at: that one
+                // is handed over in registers): rows written by earlier averages of the command were stored by this very thread
+                // earlier in program order, so the only row a request can miss is k's output.  An average then costs its
+                // arithmetic, not arithmetic + a memory round.  Plain (L1) loads: these are the thread's own columns.
+                int32_t o = __builtin_amdgcn_readfirstlane((int32_t) sCmd[5]), a = __builtin_amdgcn_readfirstlane((int32_t) sCmd[6]),
+                        b = __builtin_amdgcn_readfirstlane((int32_t) sCmd[7]);
+                WsRow<REAL, NC> Ra = vft_ws_row<REAL, NC>(A, a), Rb = vft_ws_row<REAL, NC>(A, b);
+                WsRaw<REAL, NC> na, nb;
+                vft_ws_request<REAL, NC, 0, true>(Ra, off, na);
+                vft_ws_request<REAL, NC, 0, true>(Rb, off, nb);
                 for (int k = 0; k < n; k++) {
-                    const int32_t o = __builtin_amdgcn_readfirstlane((int32_t) sCmd[5 + 3 * k]), a = __builtin_amdgcn_readfirstlane((int32_t) sCmd[6 + 3 * k]),
-                                  b = __builtin_amdgcn_readfirstlane((int32_t) sCmd[7 + 3 * k]);
-                    // both inputs are requested before either is looked at (an input that is the previous output comes from the
-                    // registers; its row - this thread's own store - is not touched)
-                    const WsRow<REAL, NC> Ra = vft_ws_row<REAL, NC>(A, a), Rb = vft_ws_row<REAL, NC>(A, b);
-                    WsRaw<REAL, NC> ra, rb;
-                    if (a != prevOut) vft_ws_request<REAL, NC>(Ra, p, ra);
-                    if (b != prevOut) vft_ws_request<REAL, NC>(Rb, p, rb);
+                    const WsRaw<REAL, NC> ra = na, rb = nb;
+                    const bool leafA = Ra.leaf, leafB = Rb.leaf;
+                    const int k1 = k + 1 < n ? k + 1 : k;
+                    const int32_t o1 = __builtin_amdgcn_readfirstlane((int32_t) sCmd[5 + 3 * k1]), a1 = __builtin_amdgcn_readfirstlane((int32_t) sCmd[6 + 3 * k1]),
+                                  b1 = __builtin_amdgcn_readfirstlane((int32_t) sCmd[7 + 3 * k1]);
+                    Ra = vft_ws_row<REAL, NC>(A, a1);
+                    Rb = vft_ws_row<REAL, NC>(A, b1);
+                    vft_ws_request<REAL, NC, 0, true>(Ra, off, na);
+                    vft_ws_request<REAL, NC, 0, true>(Rb, off, nb);
                     Col<REAL, NC> c1, c2;
+                    {
+                        WsRow<REAL, NC> Rc;   // (only the leaf flag matters to an eager finish)
+                        Rc.leaf = leafA;
+                        vft_ws_finish<REAL, NC, 0, true>(Rc, off, ra, c1);
+                        Rc.leaf = leafB;
+                        vft_ws_finish<REAL, NC, 0, true>(Rc, off, rb, c2);
+                    }
                     if (a == prevOut) c1 = prev;
-                    else vft_ws_finish<REAL, NC>(Ra, p, ra, c1);
                     if (b == prevOut) c2 = prev;
-                    else vft_ws_finish<REAL, NC>(Rb, p, rb, c2);
                     REAL wo, f[NC];
                     int co;
-                    if (ldsTables) vft_average_col<REAL, NC, DmLds<REAL>>(A, c1, c2, 0.5, S.tol, wo, co, f, T);
-                    else if (NC == 4 && A.dmDist == nullptr) {
-                        if constexpr (NC == 4) vft_average_col_nt_select<REAL>(c1, c2, S.tol, wo, co, f);
-                    } else vft_average_col<REAL, NC>(A, c1, c2, 0.5, S.tol, wo, co, f);
+                    if constexpr (NC == 4) vft_average_col_nt_select<REAL>(c1, c2, S.tol, wo, co, f);
+                    else vft_average_col<REAL, NC, DmLds<REAL>>(A, c1, c2, 0.5, S.tol, wo, co, f, T);
                     vft_ws_store<REAL, NC>(vft_ws_row<REAL, NC>(A, o), p, wo, co, f);
                     prevOut = o;
                     prev.w = wo;
@@ -352,6 +367,9 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
                     prev.vec = wo > 0 && co == VFT_NOCODE_;
 #pragma unroll
                     for (int k2 = 0; k2 < NC; k2++) prev.f[k2] = f[k2];
+                    o = o1;
+                    a = a1;
+                    b = b1;
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every row byte of this wavefront has left the chip's caches
@@ -376,30 +394,32 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
             const int32_t i = (int32_t) sCmd[1 + pi], j = (int32_t) sCmd[1 + pj];
             const WsRow<REAL, NC> Ri = vft_ws_row<REAL, NC>(A, __builtin_amdgcn_readfirstlane(i)), Rj = vft_ws_row<REAL, NC>(A, __builtin_amdgcn_readfirstlane(j));
             const bool leaves = Ri.leaf && Rj.leaf;
-            // two columns per thread and trip, the loads of both issued before the first is consumed (as in vft_pair_block)
-            for (int32_t p = threadIdx.x; p < nPos; p += 2 * WG) {
+            // 4-state columns: two per thread and trip, the loads of both issued before the first is consumed (as in vft_pair_block);
+            // 20-state columns one at a time (two pairs of 20-state profiles do not fit the registers)
+            constexpr int PER = NC == 4 ? 2 : 1;
+            for (int32_t p = threadIdx.x; p < nPos; p += PER * WG) {
                 const int32_t pb = p + WG;
-                const bool hasB = pb < nPos;
+                const bool hasB = PER == 2 && pb < nPos;
+                constexpr bool EAGER = NC == 4;
+                const WsOff oa = vft_ws_off<REAL, NC>(p), ob = vft_ws_off<REAL, NC>(pb);
                 WsRaw<REAL, NC> r1, r2, r3, r4;
-                vft_ws_request<REAL, NC>(Ri, p, r1);
-                vft_ws_request<REAL, NC>(Rj, p, r2);
+                vft_ws_request<REAL, NC, VFT_WS_SC1, EAGER>(Ri, oa, r1);
+                vft_ws_request<REAL, NC, VFT_WS_SC1, EAGER>(Rj, oa, r2);
                 if (hasB) {
-                    vft_ws_request<REAL, NC>(Ri, pb, r3);
-                    vft_ws_request<REAL, NC>(Rj, pb, r4);
+                    vft_ws_request<REAL, NC, VFT_WS_SC1, EAGER>(Ri, ob, r3);
+                    vft_ws_request<REAL, NC, VFT_WS_SC1, EAGER>(Rj, ob, r4);
                 }
-                Col<REAL, NC> a1, a2, b1, b2;
-                vft_ws_finish<REAL, NC>(Ri, p, r1, a1);
-                vft_ws_finish<REAL, NC>(Rj, p, r2, a2);
+                Col<REAL, NC> a1, a2;
+                vft_ws_finish<REAL, NC, VFT_WS_SC1, EAGER>(Ri, oa, r1, a1);
+                vft_ws_finish<REAL, NC, VFT_WS_SC1, EAGER>(Rj, oa, r2, a2);
+                if constexpr (NC == 20) vft_pair_addends<REAL, NC, DmLds<REAL>>(A, leaves, false, p, a1, a2, sW, sT, T);
+                else vft_pair_addends<REAL, NC>(A, leaves, false, p, a1, a2, sW, sT);
                 if (hasB) {
-                    vft_ws_finish<REAL, NC>(Ri, pb, r3, b1);
-                    vft_ws_finish<REAL, NC>(Rj, pb, r4, b2);
-                }
-                if (ldsTables) {
-                    vft_pair_addends<REAL, NC, DmLds<REAL>>(A, leaves, false, p, a1, a2, sW, sT, T);
-                    if (hasB) vft_pair_addends<REAL, NC, DmLds<REAL>>(A, leaves, false, pb, b1, b2, sW, sT, T);
-                } else {
-                    vft_pair_addends<REAL, NC>(A, leaves, false, p, a1, a2, sW, sT);
-                    if (hasB) vft_pair_addends<REAL, NC>(A, leaves, false, pb, b1, b2, sW, sT);
+                    Col<REAL, NC> b1, b2;
+                    vft_ws_finish<REAL, NC, VFT_WS_SC1, EAGER>(Ri, ob, r3, b1);
+                    vft_ws_finish<REAL, NC, VFT_WS_SC1, EAGER>(Rj, ob, r4, b2);
+                    if constexpr (NC == 20) vft_pair_addends<REAL, NC, DmLds<REAL>>(A, leaves, false, pb, b1, b2, sW, sT, T);
+                    else vft_pair_addends<REAL, NC>(A, leaves, false, pb, b1, b2, sW, sT);
                 }
             }
         }
@@ -420,6 +440,12 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
             }
         }
         VFT_WS_TICK(5);
+#ifdef VFT_WALK_TIMING
+        if (w == 0 && threadIdx.x == 0) {
+            atomicAdd(&S.ticks[6], 1ull);
+            atomicAdd(&S.ticks[7], (unsigned long long) n);
+        }
+#endif
     }
     if (threadIdx.x == 0) __hip_atomic_store(S.status + w, (unsigned long long) sStop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
