@@ -267,7 +267,7 @@ E2E_FULL = {
     # fit, SH-like supports).  threads: the reference's `-threads T` schedule this backend follows for the refinement stages
     # (host/MLLengths.h "the subtree schedule": the walks of T-thread partitions advanced in lockstep, batches of quartets on the GPU).
     "c2": dict(n=10000, L=1000, nc=4, seed=2, dtype="float32", gtr=True, aa=None, threads=64, flags="-nt -gtr", golden="bb_c2_crc.npz"),
-    "c5": dict(n=50000, L=300, nc=20, seed=2, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden=None),
+    "c5": dict(n=50000, L=300, nc=20, seed=2, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden="bb_c5_crc.npz"),
     # config C4 with its real flags (--e2e-c4-full: 18 minutes; profiles/r04_c4_full_flags.txt holds a run)
     "c4": dict(n=1000000, L=200, nc=4, seed=4, mu=0.02, dtype="float32", gtr=False, aa=None, threads=1024, flags="-nt", golden=None),
 }

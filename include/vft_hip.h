@@ -339,12 +339,11 @@ int vft_average_chain(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t
 int vft_average_chains(vft_ctx *ctx, int32_t n_chains, const int32_t *chain_off, const int64_t *out, const int64_t *a,
                        const int64_t *b);
 
-/* One step of a host-driven refinement walk (an SPR chain step, a minimum-evolution NNI of the one-thread order) as ONE launch (two
-   when the step writes a node it has read or written before: the chain then runs in one workgroup, the six pairs in a second launch) and
-   one wait: the n unweighted averages queued since the last step, in order (as vft_average_chain; n <= 256, may be 0), then the six
-   raw profile distances AB AC AD BC BD CD of the quartet q[0..3] = A, B, C, D (as vft_profile_distances; chooseNNI, NJ.tcc:4836-4846)
-   into dist[6] (numeric_t).  Results are bit-identical to the two calls.  Needs vft_set_profile_rows(ctx, 1) with every internal
-   profile a plain row - VFT_ERR_STATE otherwise (the caller falls back to the two calls). */
+/* One step of a host-driven refinement walk (an SPR chain step, a minimum-evolution NNI of the one-thread order): the n unweighted
+   averages queued since the last step, in order (as vft_average_chain; n may be 0), then the six raw profile distances AB AC AD BC BD CD
+   of the quartet q[0..3] = A, B, C, D (as vft_profile_distances; chooseNNI, NJ.tcc:4836-4846) into dist[6] (numeric_t) - handed to the
+   walk server below (= vft_walk_submit + vft_walk_collect); VFT_ERR_STATE while no server is running: the caller makes the two plain
+   calls.  Results are bit-identical to them. */
 int vft_walk_step(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, void *dist);
 
 /* The walk server: the same steps WITHOUT a launch each.  vft_walk_server_start leaves six workgroups resident on a stream of their own
@@ -371,18 +370,6 @@ int vft_walk_server_ticks(int64_t *out, int32_t n);
 int vft_profiles_differ(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, int32_t *differ);
 /* the max_nodes the context was created with (rows beyond the tree's nodes and up-profile slots serve as private scratch) */
 int vft_get_max_nodes(vft_ctx *ctx, int64_t *max_nodes);
-
-/* One round of subtree-prune-regraft moves (SPR, NJ.tcc:6185-6404, one thread, fast flavour; findSPRSteps :1805-1859,
-   unwindSPRStep :1861-1879) entirely on the device: node_list[n_list] is the walk (the reference fixes it before anything
-   moves: every node in post-order), parent[n_nodes] (-1 at the root) / child[n_nodes][3] (-1 = none) the tree, rearranged in
-   place; chains of up to max_len (<= 16; the reference's default is 10) forced minimum-evolution NNIs per node, criteria =
-   log-corrected profile distances (scoredist: NJ.tcc:322-330).  Profiles and up-profiles (slot node + n_seqs) are kept
-   current exactly as the host walk keeps them (recomputeProfile after every step, all ancestors after an accepted move).
-   Needs vft_set_profile_rows(ctx, 1) and max_nodes >= n_nodes + n_seqs; alignments up to ~1 300 columns (the six distances
-   of a step are staged in LDS).  out[16]: accepted moves, chain steps evaluated, averages computed, cache epochs, device clock
-   ticks (100 MHz) inside commands / in total, commands issued, thread 0's ticks in the four phases of a command, 0...  Waits. */
-int vft_spr_round(vft_ctx *ctx, int64_t n_nodes, int64_t *parent, int64_t *child, int64_t root, int64_t n_list,
-                  const int64_t *node_list, int32_t scoredist, int32_t max_len, int64_t *out);
 
 /* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */
@@ -462,7 +449,6 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_FAULT_NO_FLAG 5      /* value != 0: fault injection - the next wait for a completion flag waits for a value no kernel publishes */
 #define VFT_DEBUG_WAIT_LIMIT_MS 6      /* the longest a wait for a completion flag may last while the stream is busy (default 120 000) */
 #define VFT_DEBUG_WIDE_GLUE 7          /* value != 0: vft_nj_engine_create takes the 1 024-thread glue kernel (lists beyond 1 024 hits) at any size */
-#define VFT_DEBUG_WALK_IDS_IN_RING 8  /* value != 0: vft_walk_step reads its ids from the mapped ring and publishes through the staging buffer at any step length (the path of steps with more than 16 averages) */
 #define VFT_DEBUG_NO_WALK_SERVER 9      /* value != 0: vft_walk_server_start answers VFT_ERR_STATE - the walks keep one launch per step (tests compare) */
 #define VFT_DEBUG_WALK_DEVICE_MAILBOX 10 /* value != 0: the server's mailbox in device memory written through the PCIe aperture (large-BAR boxes) instead of pinned host memory */
 #define VFT_DEBUG_WALK_SERVER_STRIDE 11 /* 1: the server's six workgroups on six XCDs instead of one (placement is for speed only; tests run both) */

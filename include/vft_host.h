@@ -85,8 +85,6 @@ typedef struct {
                                    VFT_NJ_DEBUG_HOST_JOINS 1  the host-driven join loop instead of the join engine
                                    VFT_NJ_DEBUG_HOST_LISTS 2  top-hit lists on the host (round 2's walks)
                                    VFT_NJ_DEBUG_HOST_RESET 4  resetTopVisible entirely on the host
-                                   VFT_NJ_DEBUG_DEVICE_SPR 8  the SPR rounds as one persistent kernel each (vft_spr_round) instead of the
-                                                              host-driven walk (same tree; slower on MI355X today)
                                    VFT_NJ_DEBUG_LEVEL_LENGTHS 16  ML length rounds as one batch per tree height - NOT the reference's
                                                               order in any of its modes (measurements only)
                                    VFT_NJ_DEBUG_NO_WALK_SERVER 128  the SPR / one-thread NNI walks with one launch per step
@@ -99,7 +97,6 @@ typedef struct {
 #define VFT_NJ_DEBUG_HOST_JOINS 1
 #define VFT_NJ_DEBUG_HOST_LISTS 2
 #define VFT_NJ_DEBUG_HOST_RESET 4
-#define VFT_NJ_DEBUG_DEVICE_SPR 8
 #define VFT_NJ_DEBUG_LEVEL_LENGTHS 16
 #define VFT_NJ_DEBUG_NO_WALK_SERVER 128
 #define VFT_NJ_SHARD_LEAF_BLOCKS 64   /* with comm: split the close-neighbour blocks by rows and all-gather the results (see vft_comm) */

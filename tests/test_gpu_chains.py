@@ -1,6 +1,6 @@
 """The entry points round 4 added for batched refinement steps, each against the calls it replaces - bit for bit:
 vft_average_chains / vft_posterior_chains_blen (several independent chains in one launch) against one vft_*_chain call per chain,
-vft_walk_step (queued averages + the six distances of a quartet in one launch) against vft_average_chain + vft_profile_distances,
+vft_walk_step (queued averages + the six distances of a quartet, through the walk server) against vft_average_chain + vft_profile_distances,
 vft_profiles_differ against a host comparison of the downloaded profiles."""
 import ctypes as C
 
@@ -87,13 +87,14 @@ def test_average_chains_equal_single_chains(dt, nc):
     ops.close()
 
 
-@pytest.mark.parametrize("ring", [0, 1])
 @pytest.mark.parametrize("dt,nc", [(np.float32, 4), (np.float64, 4), (np.float32, 20), (np.float64, 20)])
-def test_walk_step_equals_chain_plus_distances(dt, nc, ring):
-    """steps of up to 16 averages travel in the kernel arguments (k_walk_step_args), longer ones through the mapped ring (k_walk_step;
-    ring = 1: every step that way)"""
+def test_walk_step_equals_chain_plus_distances(dt, nc):
+    """vft_walk_step hands the step to the walk server (tests/test_gpu_walk_server.py has the long runs); without a server it answers
+    VFT_ERR_STATE and the caller makes the two calls"""
     ops, rng, free = make_state(dt, nc)
-    assert ops.lib.vft_debug_option(ops.ctx, I32(8), I64(ring)) == 0
+    o0 = np.array([free], np.int64)
+    assert ops.lib.vft_walk_step(ops.ctx, I32(1), ptr(o0), ptr(o0), ptr(o0), ptr(np.zeros(4, np.int64)), ptr(np.zeros(6, dt))) == 3
+    assert ops.lib.vft_walk_server_start(ops.ctx) == 0
     for trial in range(7):
         n = [0, 1, 2, 5, 9, 3, 19][trial]
         base1, base2 = free + 20 * trial, free + 140 + 20 * trial
@@ -119,6 +120,7 @@ def test_walk_step_equals_chain_plus_distances(dt, nc, ring):
         if trial == 5:
             q1[1] = q2[1] = int(rng.integers(0, 48))   # a leaf x leaf pair as well
         d1 = np.zeros(6, dt)
+        assert ops.lib.vft_walk_server_start(ops.ctx) == 0   # (the plain calls below retire it every time)
         assert ops.lib.vft_walk_step(ops.ctx, I32(n), ptr(o1), ptr(a1), ptr(b1), ptr(q1), ptr(d1)) == 0
         if n:
             assert ops.lib.vft_average_chain(ops.ctx, I32(n), ptr(o2), ptr(a2), ptr(b2)) == 0
@@ -131,16 +133,15 @@ def test_walk_step_equals_chain_plus_distances(dt, nc, ring):
     ops.close()
 
 
-@pytest.mark.parametrize("ring", [0, 1])
 @pytest.mark.parametrize("dt,nc", [(np.float32, 4), (np.float64, 20)])
-def test_walk_step_that_rewrites_nodes(dt, nc, ring):
+def test_walk_step_that_rewrites_nodes(dt, nc):
     """Three steps in ten of an SPR round write a node that the step read or wrote earlier (an up-profile slot re-used, a node
-    recomputed after its old profile went into another average).  The six pair workgroups of the step kernels must not each run such
-    a chain (one that is ahead would hand a later value to one that is behind): vft_walk_step runs it once and the pairs in a second
-    launch.  Against the plain sequence on an identical state, twenty times over (the race needed a dozen runs of a pipeline to show)."""
+    recomputed after its old profile went into another average).  Round 4's step kernel ran the chain in each of its six workgroups
+    and raced on such steps; in the walk server every column has one owner.  Against the plain sequence on an identical state, twenty
+    times over (the race needed a dozen runs of a pipeline to show)."""
     a_ops, rng, free = make_state(dt, nc, seed=11)
     b_ops, _, _ = make_state(dt, nc, seed=11)
-    assert a_ops.lib.vft_debug_option(a_ops.ctx, I32(8), I64(ring)) == 0
+    assert a_ops.lib.vft_walk_server_start(a_ops.ctx) == 0
     X, Y, Z = free, free + 1, free + 2
     for trial in range(20):
         e = [int(v) for v in rng.integers(0, free, 6)]
@@ -156,8 +157,9 @@ def test_walk_step_that_rewrites_nodes(dt, nc, ring):
         pj = np.array([q[1], q[2], q[3], q[2], q[3], q[3]], np.int64)
         d2, _ = b_ops.profileDist(pi, pj)
         assert np.array_equal(np.asarray(d1).view(np.uint8), np.asarray(d2, dt).view(np.uint8)), (trial, d1, d2)
-        for x in set(int(v) for v in out):
-            assert same(a_ops.profile_download(x), b_ops.profile_download(x)), (trial, x)
+    assert a_ops.lib.vft_walk_server_stop(a_ops.ctx) == 0
+    for x in (X, Y, Z):
+        assert same(a_ops.profile_download(x), b_ops.profile_download(x)), x
     a_ops.close()
     b_ops.close()
 

@@ -250,6 +250,25 @@ def test_c2_tree_equals_the_reference_tree():
     assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
 
 
+def test_c5_generator_tree_equals_the_reference_tree():
+    """BASELINE config C5's generator and flags at 20 000 sequences (amino acids x 300, `-lg -double-precision`, one-thread order - the
+    reference's deterministic path): the complete default pipeline must print the reference binary's 749 KB tree byte for byte and end at
+    its log-likelihood (tests/golden/bb_c5_20k_crc.npz, oracle/gen_fixtures.py c5:20000; 293 s of one core there).  The configuration
+    itself - 50 000 sequences, bb_c5_crc.npz, 827 s of one core - is bench.py's `e2e_c5` (6 minutes here)."""
+    import zlib
+    import golden_util as G
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick
+    ref = G.load("bb_c5_20k_crc")
+    codes = synth.random_descent_codes(20000, 300, 20, 0.03, 0.01, seed=2)
+    names = ["s%d" % k for k in range(len(codes))]
+    tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 20, np.float64, max_nodes=3 * m), codes, names, dtype=np.float64, aa_model="lg",
+                            me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True)
+    assert abs(loglk[-1] - ref["loglk"][-1]) <= 1e-4 * abs(ref["loglk"][-1])   # the north star's bar
+    assert len(tree) == int(ref["newick_bytes"])
+    assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
+
+
 def test_c2_shape_on_the_64_thread_schedule_equals_the_reference_run():
     """10 000 nt x 1 000 under Jukes-Cantor (config C2's shape; `-gtr` is not reproducible in the reference at T > 1) on the schedule of
     a 64-thread run: this backend (threads = 64: the walks of the reference's tree partitions in lockstep, host/MLLengths.h) against

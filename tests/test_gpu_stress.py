@@ -105,3 +105,23 @@ def test_nj_runs_are_reproducible():
     assert chunk == 10000 and n_joins == len(joins) and len(crcs) == len(joins) // chunk >= 1
     for k in range(len(crcs)):
         assert int(crcs[k]) == zlib.crc32(joins[k * chunk:(k + 1) * chunk].astype("<i4").tobytes()), k
+
+
+def test_protein_pipelines_are_reproducible_with_and_without_the_walk_server():
+    """The complete pipeline of 5 000 proteins x 300 on the 32-thread schedule four times through the walk server (resident workgroups
+    exchanging rows through flags, two steps in flight, averages evaluated lazily) and once with a launch per step: the same tree, the
+    same number of SPR steps and the same lane work every time.  Round 4's race in the step kernel showed as one run in twelve taking
+    173 977 steps instead of 173 972 at exactly this size; nothing at fixture size could see it."""
+    import zlib
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick, last_stage_seconds, DEBUG_NO_WALK_SERVER
+    codes = synth.random_descent_codes(5000, 300, 20, 0.02, 0.01, seed=4)
+    names = ["s%d" % k for k in range(len(codes))]
+    runs = []
+    for rep in range(5):
+        tree = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 20, np.float64, max_nodes=3 * m), codes, names, dtype=np.float64, aa_model="lg",
+                         me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, threads=32,
+                         debug_flags=DEBUG_NO_WALK_SERVER if rep == 4 else 0)
+        st = last_stage_seconds()
+        runs.append((zlib.crc32(tree.encode()), int(st["spr_steps"]), int(st["lane_work"]), int(st["spr_moves"])))
+    assert all(r == runs[0] for r in runs), runs

@@ -97,19 +97,20 @@ def test_one_thread_is_untouched_by_the_option():
 
 
 @pytest.mark.parametrize("name,dt,aa", [("spr_nt_500", np.float32, None), ("spr_nt_300_double", np.float64, None), ("nni_aa_150", np.float32, "jtt")])
-def test_spr_walk_on_the_device_gives_the_reference_tree(name, dt, aa):
-    """vft_spr_round (k_spr_walk: a whole SPR round as one persistent workgroup, csrc/vft_kernels_spr.h) instead of the host-driven walk:
-    `VeryFastTree [-nt] -noml` with the default two SPR rounds, byte for byte."""
+def test_spr_walk_without_the_walk_server_gives_the_reference_tree(name, dt, aa):
+    """The SPR / NNI walks with the resident walk server switched off (vft_nj_options.debug_flags & VFT_NJ_DEBUG_NO_WALK_SERVER): every step
+    is then the two plain calls (vft_average_chain + vft_profile_distances) - `VeryFastTree [-nt] -noml` with the default two SPR rounds,
+    byte for byte, as through the server (the default, every other test of this file)."""
     from veryfasttree_amd import HipProfileOps
-    from veryfasttree_amd.backend import nj_newick, DEBUG_DEVICE_SPR, last_stage_seconds
+    from veryfasttree_amd.backend import nj_newick, DEBUG_NO_WALK_SERVER, last_stage_seconds
     d = G.load(name)
     codes_all = d["codes"]
     names = ["s%d" % k for k in range(len(codes_all))]
     make = lambda n, L: HipProfileOps(n, L, 20 if aa else 4, dt, max_nodes=3 * n)
-    kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, debug_flags=DEBUG_DEVICE_SPR)
+    kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, debug_flags=DEBUG_NO_WALK_SERVER)
     if aa:
         kw["aa_model"] = aa
     tree = nj_newick(make, codes_all, names, **kw)
     st = last_stage_seconds()
-    assert st["spr_steps"] > 0, "the kernel did not run"
+    assert st["spr_steps"] > 0
     assert tree == bytes(d["newick"]).decode().strip()

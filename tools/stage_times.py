@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [devspr] [ring] [mu=M] [seed=S]
-(devspr: the SPR rounds as persistent kernels, vft_nj_options.debug_flags bit 8; VFT_SPR_REPORT=1 prints their tick counters)"""
+"""Where the wall-clock of one complete pipeline goes (vft_nj_last_stage_seconds): stage_times.py N L [nt|aa] [threads] [gtr|lg] [f64] [noserver] [mu=M] [seed=S]
+(noserver: the SPR / NNI walks without the resident walk server, vft_nj_options.debug_flags bit 128)"""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,18 +15,14 @@ dt = np.float64 if "f64" in rest else np.float32
 kv = dict(a.split("=") for a in rest if "=" in a)   # mu=0.02 seed=4: config C4's alignment
 codes = synth.random_descent_codes(n, L, 20 if aa else 4, float(kv.get("mu", 0.03)), 0.01, seed=int(kv.get("seed", 2)))
 names = ["s%d" % k for k in range(n)]
-kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, threads=T, return_loglk=True, debug_flags=8 if "devspr" in rest else 0)
+kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, threads=T, return_loglk=True, debug_flags=128 if "noserver" in rest else 0)
 if aa:
     kw["aa_model"] = "lg" if "lg" in rest else "jtt"
 elif "gtr" in rest:
     kw["gtr"] = True
 t0 = time.perf_counter()
 def make(m, Lp):
-    ops = HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m)
-    if "ring" in rest:   # VFT_DEBUG_WALK_IDS_IN_RING: every walk step through the long-step kernel
-        import ctypes
-        assert ops.lib.vft_debug_option(ops.ctx, ctypes.c_int32(8), ctypes.c_int64(1)) == 0
-    return ops
+    return HipProfileOps(m, Lp, 20 if aa else 4, dt, max_nodes=3 * m)
 tree, ll = nj_newick(make, codes, names, **kw)
 print("%d x %d %s %s threads=%d: %.1f s, TreeLogLk %.4f" % (n, L, "aa" if aa else "nt", " ".join(r for r in rest if not r.isdigit()), T, time.perf_counter() - t0, ll[-1]))
 import zlib

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvft_hip.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("vft_api.hip", "vft_ml_kernels_lengths.hip", "vft_ml_kernels_quartet32.hip",
                                              "vft_ml_kernels_quartet64.hip", "vft_walk_kernels.hip")]
-HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_aa.h", "vft_kernels_profile.h", "vft_kernels_tophits.h", "vft_kernels_njengine.h", "vft_kernels_spr.h", "vft_kernels_walk.h", "vft_kernels_ml.h", "vft_iterate_add.h", "vft_glibc_log.h",
+HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_aa.h", "vft_kernels_profile.h", "vft_kernels_tophits.h", "vft_kernels_njengine.h", "vft_kernels_walk.h", "vft_kernels_ml.h", "vft_iterate_add.h", "vft_glibc_log.h",
            "vft_glibc_log_data.h"]   # deps of every unit
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 # Tools only (e.g. -DVFT_ABLATE, -DVFT_ML_TIMING, -DVFT_NJ_TIMING): a VARIANT build.  Its objects and its libraries live in

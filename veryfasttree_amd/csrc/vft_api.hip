@@ -24,7 +24,6 @@ VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
 #include "vft_kernels_profile.h"
 #include "vft_kernels_tophits.h"
 #include "vft_kernels_njengine.h"
-#include "vft_kernels_spr.h"
 #include "vft_kernels_walk.h"
 
 VFT_WALK_SERVER_INSTANCES(extern)   // compiled in vft_walk_kernels.hip
@@ -64,7 +63,6 @@ struct vft_ctx {
     bool faultNoFlag = false;      // VFT_DEBUG_FAULT_NO_FLAG: the next wait for a completion flag waits for one that never comes
     double waitLimitS = 120.0;     // how long a wait for a completion flag may last while the stream is busy
     bool wideGlue = false;         // test hook: the 1 024-thread instance of k_nj_glue_scan at any size
-    bool walkIdsInRing = false;    // VFT_DEBUG_WALK_IDS_IN_RING: vft_walk_step takes the kernel of its long steps (k_walk_step) for every step
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -150,7 +148,6 @@ struct vft_ctx {
     size_t thLds = 0;                  // dynamic LDS of k_th_best / k_th_join
     size_t thRefreshLds = 0;           // the largest dynamic LDS k_th_refresh has been configured for
     size_t pbLdsSet = 0;               // ... and k_pairs_block_tiled
-    bool walkLdsSet = false;           // k_walk_step's dynamic LDS limit has been raised
     // the walk server (vft_kernels_walk.h): six resident workgroups that take the steps of a refinement walk from a mailbox
     struct WalkServerHost {
         bool up = false;
@@ -340,7 +337,7 @@ static int wait_stream(vft_ctx *c) {
 // The spin is bounded: a flag that a kernel never raises (a bug in one of the hand-written completion protocols, a faulted
 // kernel) comes back as VFT_ERR_TIMEOUT instead of hanging the caller - at once when the stream has drained without the flag
 // moving, after waitLimitS seconds (vft_debug_option(VFT_DEBUG_WAIT_LIMIT_MS)) when it is still busy.
-// (first, count: the words of the flag block that have to reach seq - the stream's own flag, or the six of k_walk_step_args)
+// (first, count: the words of the flag block that have to reach seq)
 static int wait_flag(vft_ctx *c, unsigned long long seq, int first, int count) {
     volatile unsigned long long *f = c->hFlag + first;
     if (c->faultNoFlag) {   // test hook: wait for a value nobody will ever publish
@@ -518,7 +515,7 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
         s0.hResDev = c->hResDev;
         c->slots.assign(1, s0);
     }
-    // [0]: the stream's completion flag; [8..13]: the six workgroup flags of k_walk_step_args; [16..27]: its six {distance, weight}
+    // [0]: the stream's completion flag
     CR(hipHostMalloc((void **) &c->hFlag, 512, hipHostMallocMapped));
     CR(hipHostGetDevicePointer((void **) &c->dFlag, c->hFlag, 0));
     memset(c->hFlag, 0, 512);
@@ -1264,9 +1261,6 @@ extern "C" int vft_average_chains(vft_ctx *c, int32_t nChains, const int32_t *ch
     return average_chains(c, nChains, chainOff, chainOff[nChains], out, a, b, "vft_average_chains");
 }
 
-// One step of a host-driven refinement walk as one launch (k_walk_step): n queued averages in order, then the six raw profile
-// distances of the quartet q[0..3].  VFT_ERR_STATE when some internal profile is not a plain row (the caller then takes the
-// two-call path: vft_average_chain + vft_profile_distances).
 // ---------------------------------------------------------------------------------------------- the walk server (vft_kernels_walk.h)
 // Host side: the mailbox (self-tagged 8-byte granules), the answers, start / stop.  One server per process (g_walkServerOwner).
 static inline void ws_put(vft_ctx *c, uint32_t seq, int g, uint32_t data) {
@@ -1471,139 +1465,10 @@ static int walk_ids_ok(vft_ctx *c, int32_t n, const int64_t *out, const int64_t 
 
 extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, void *dist) {
     if (!c || n < 0 || (n > 0 && (!out || !a || !b)) || !q || !dist) return VFT_ERR_INVALID;
-    if (!c->rowMode || !c->allRows) return fail(c, VFT_ERR_STATE, "vft_walk_step: every internal profile must be a plain row (vft_set_profile_rows)");
-    if (n > 256) return fail(c, VFT_ERR_INVALID, "vft_walk_step: at most 256 averages per step");
-    if (c->ws.up) {   // the resident workgroups take it: no launch
-        uint32_t ticket;
-        if (int r = vft_walk_submit(c, n, out, a, b, q, &ticket)) return r;
-        return vft_walk_collect(c, ticket, dist);
-    }
-    for (int32_t k = 0; k < n; k++) {
-        if (int r = internal_ok(c, out[k])) return r;
-        if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_walk_step: bad child id");
-    }
-    for (int t = 0; t < 4; t++)
-        if (q[t] < 0 || q[t] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_walk_step: quartet member out of range");
-    const size_t lds = (size_t) 2 * c->d.nPosPad * sizeof(double);
-    if (lds > (160u << 10) - 1024) return fail(c, VFT_ERR_STATE, "vft_walk_step: alignment too long for one workgroup per pair");
-    // The six workgroups of the step kernels each run the whole chain and store every output - the same bits six times, at six
-    // different moments.  That is only sound while no node is written after it has been read or written earlier in the step (a
-    // workgroup that is ahead would hand a later value to one that is behind; three steps in ten of an SPR round are like that):
-    // such a step runs its chain in ONE workgroup and its six pairs in a second launch.
-#ifdef VFT_WALK_CENSUS   // tools-only build: what kind of rewrites the steps contain (printed every 200 000 steps)
-    {
-        static long steps = 0, kinds[4] = {0, 0, 0, 0}, sameInputs = 0;
-        bool war = false, dup = false, dupRead = false;
-        for (int32_t k2 = 1; k2 < n; k2++)
-            for (int32_t k = 0; k < k2; k++) {
-                if (out[k2] == out[k]) {
-                    dup = true;
-                    if (a[k2] == a[k] && b[k2] == b[k]) sameInputs++;
-                    for (int32_t m = k + 1; m < k2; m++)
-                        if (a[m] == out[k] || b[m] == out[k]) dupRead = true;
-                }
-                bool ext = true;
-                for (int32_t m = 0; m < k; m++)
-                    if (out[m] == out[k2]) ext = false;
-                if ((out[k2] == a[k] || out[k2] == b[k]) && ext) war = true;
-            }
-        kinds[0] += war;
-        kinds[1] += dup;
-        kinds[2] += dupRead;
-        kinds[3] += n;
-        if (++steps % 200000 == 0)
-            fprintf(stderr, "walk census: %ld steps, %.2f averages per step; read-then-written %ld, written twice %ld (read in between %ld), identical repeats %ld\n",
-                    steps, (double) kinds[3] / steps, kinds[0], kinds[1], kinds[2], sameInputs);
-    }
-#endif
-    bool rewrites = false;
-    for (int32_t k2 = 1; k2 < n && !rewrites; k2++)
-        for (int32_t k = 0; k < k2; k++)
-            if (out[k2] == a[k] || out[k2] == b[k] || out[k2] == out[k]) {
-                rewrites = true;
-                break;
-            }
-    // a column per thread where the registers allow it: 1 024 threads for 4-state columns, 512 for 20-state ones
-    const int wg = c->d.nPos <= 256 ? 256 : (c->d.nPos <= 512 || c->d.nCodes == 20) ? 512 : 1024;
-    if (!c->walkLdsSet && lds > (48u << 10)) {
-        VFT_DISPATCH(c, {
-            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step_args<REAL, NC, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step_args<REAL, NC, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            if constexpr (NC == 4) {
-                HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step<REAL, NC, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-                HIPCHK(c, hipFuncSetAttribute((const void *) (k_walk_step_args<REAL, NC, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            }
-        });
-        c->walkLdsSet = true;
-    }
-    const size_t rs = c->rs;
-    if (n <= VFT_WALK_ARGS && !c->walkIdsInRing && c->d.maxNodes <= 0x7FFFFFFF) {   // (32-bit ids in the arguments)   // the usual step: ids in the kernel arguments, one flag per workgroup (k_walk_step_args)
-        const unsigned long long seq = ++c->signalSeq;
-        // nOps averages and then (chainOnly: nothing else, one workgroup; otherwise) the six pairs, one workgroup each
-        auto go = [&](int32_t nOps, bool chainOnly) -> int {
-            WalkIds W{};
-            W.n = nOps;
-            W.chainOnly = chainOnly ? 1 : 0;
-            for (int32_t k = 0; k < nOps; k++) {
-                W.out[k] = (int32_t) out[k];
-                W.a[k] = (int32_t) a[k];
-                W.b[k] = (int32_t) b[k];
-            }
-            for (int t = 0; t < 4; t++) W.q[t] = (int32_t) q[t];
-#define VFT_WALK_GO(WGN)                                                                                                                     \
-    launch((k_walk_step_args<REAL, NC, WGN>), dim3(chainOnly ? 1 : 6), dim3(WGN), lds, c->stream, arena<REAL>(c), W, c->fpostTol,               \
-           (REAL *) (c->dFlag + 16), c->dFlag + 8, seq)
-            VFT_DISPATCH(c, {
-                if (wg == 256) VFT_WALK_GO(256);
-                else if (wg == 512) VFT_WALK_GO(512);
-                else if constexpr (NC == 4) VFT_WALK_GO(1024);
-            });
-#undef VFT_WALK_GO
-            LAUNCHCHK(c);
-            return VFT_OK;
-        };
-        if (rewrites) {
-            if (int r = go(n, true)) return r;
-            if (int r = go(0, false)) return r;
-        } else {
-            if (int r = go(n, false)) return r;
-        }
-        if (int r = wait_flag(c, seq, 8, 6)) return r;
-        for (int w = 0; w < 6; w++) memcpy((char *) dist + (size_t) w * rs, (const char *) (c->hFlag + 16) + (size_t) 2 * w * rs, rs);
-        return VFT_OK;
-    }
-    if (rewrites) {   // (a long step: the two plain calls)
-        if (int r = vft_average_chain(c, n, out, a, b)) return r;
-        const int64_t pi[6] = {q[0], q[0], q[0], q[1], q[1], q[2]}, pj[6] = {q[1], q[2], q[3], q[2], q[3], q[3]};
-        double wt[6];
-        return vft_profile_distances(c, 6, pi, pj, dist, wt);
-    }
-    const size_t idB = ((size_t) n * 8 + 255) & ~(size_t) 255;
-    char *h, *s;
-    if (int r = io_alloc(c, 3 * idB + 256 + 256, &h, &s)) return r;
-    if (n > 0) {
-        memcpy(h, out, (size_t) n * 8);
-        memcpy(h + idB, a, (size_t) n * 8);
-        memcpy(h + 2 * idB, b, (size_t) n * 8);
-    }
-    memcpy(h + 3 * idB, q, 32);
-    const unsigned long long seq = ++c->signalSeq;
-#define VFT_WALK_GO(WGN)                                                                                                                      \
-    launch((k_walk_step<REAL, NC, WGN>), dim3(6), dim3(WGN), lds, c->stream, arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB),  \
-           (const int64_t *) (s + 2 * idB), n, c->fpostTol, (const int64_t *) (s + 3 * idB), (REAL *) (s + 3 * idB + 256), c->doneCtr, c->dFlag, \
-           seq, (REAL *) c->pairStage, (int64_t) VFT_PAIR_STAGE_CAP)
-    VFT_DISPATCH(c, {
-        if (wg == 256) VFT_WALK_GO(256);
-        else if (wg == 512) VFT_WALK_GO(512);
-        else if constexpr (NC == 4) VFT_WALK_GO(1024);
-    });
-#undef VFT_WALK_GO
-    LAUNCHCHK(c);
-    if (int r = wait_flag(c, seq)) return r;
-    memcpy(dist, h + 3 * idB + 256, 6 * rs);
-    return VFT_OK;
+    if (!c->ws.up) return fail(c, VFT_ERR_STATE, "vft_walk_step: the walk server is not running (vft_walk_server_start); the caller makes the two plain calls");
+    uint32_t ticket;
+    if (int r = vft_walk_submit(c, n, out, a, b, q, &ticket)) return r;
+    return vft_walk_collect(c, ticket, dist);
 }
 
 #ifdef VFT_WALK_TIMING   // tools-only build (tools/walk_ticks.py): never in the product library
@@ -1636,76 +1501,6 @@ extern "C" int vft_profiles_differ(vft_ctx *c, int64_t n, const int64_t *a, cons
 extern "C" int vft_get_max_nodes(vft_ctx *c, int64_t *maxNodes) {
     if (!c || !maxNodes) return VFT_ERR_INVALID;
     *maxNodes = c->d.maxNodes;
-    return VFT_OK;
-}
-
-// One round of SPR moves (NJ.tcc:6185-6404) as a persistent workgroup (k_spr_walk, vft_kernels_spr.h): the tree arrays go
-// to the device, wave 0 of the workgroup walks node_list, the arrays come back rearranged.  Waits for the kernel.
-extern "C" int vft_spr_round(vft_ctx *c, int64_t nNodes, int64_t *parent, int64_t *child, int64_t root, int64_t nList,
-                             const int64_t *nodeList, int32_t scoredist, int32_t maxLen, int64_t *out) {
-    if (!c || !parent || !child || !nodeList || !out || nNodes < 4 || nList < 0) return VFT_ERR_INVALID;
-    if (!c->rowMode) return fail(c, VFT_ERR_STATE, "vft_spr_round needs vft_set_profile_rows(ctx, 1)");
-    if (maxLen < 1 || maxLen > VFT_SPR_MAXLEN) return fail(c, VFT_ERR_INVALID, "vft_spr_round: chain length 1..%d", VFT_SPR_MAXLEN);
-    if (nNodes + c->d.nSeqs > c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: the up-profiles need max_nodes >= n_nodes + n_seqs");
-    if (root < c->d.nSeqs || root >= nNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad root");
-    const size_t lds = (size_t) 12 * (size_t) c->d.nPosPad * sizeof(double);
-    if (lds + sizeof(SprCmd) + sizeof(SprState) + 512 + (size_t) VFT_SPR_NCACHE * 28 + 1024 > 160u * 1024u)
-        return fail(c, VFT_ERR_INVALID, "vft_spr_round: alignment too long for the in-kernel walk");
-    if (int r = ensure_ml_rows(c)) return r;
-    if (!c->allRows) return fail(c, VFT_ERR_STATE, "vft_spr_round: some internal profile has no row (written through the tile streams since vft_set_profile_rows)");
-    const size_t N = (size_t) nNodes;
-    if (nNodes + c->d.nSeqs >= (1ll << 31)) return fail(c, VFT_ERR_INVALID, "vft_spr_round: too many nodes");
-    std::vector<SprNode> hn(N);
-    for (size_t v = 0; v < N; v++) {
-        for (int k = 0; k < 3; k++)
-            if (child[3 * v + k] >= nNodes || child[3 * v + k] < -1) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad child of node %zu", v);
-        if (parent[v] >= nNodes || parent[v] < -1) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad parent of node %zu", v);
-        hn[v].parent = (int32_t) parent[v];
-        hn[v].c0 = (int32_t) child[3 * v];
-        hn[v].c1 = (int32_t) child[3 * v + 1];
-        hn[v].c2 = (int32_t) child[3 * v + 2];
-    }
-    std::vector<int32_t> hl((size_t) nList);
-    for (int64_t t = 0; t < nList; t++) {
-        if (nodeList[t] < 0 || nodeList[t] >= nNodes) return fail(c, VFT_ERR_INVALID, "vft_spr_round: bad node list");
-        hl[(size_t) t] = (int32_t) nodeList[t];
-    }
-    const size_t offList = N * sizeof(SprNode), offPath = offList + (((size_t) nList * 4 + 255) & ~(size_t) 255), offEpoch = offPath + ((N * 4 + 255) & ~(size_t) 255),
-                 offOut = offEpoch + ((N * 4 + 255) & ~(size_t) 255), total = offOut + 128;
-    if (int r = ensure_scratch(c, total + 512)) return r;
-    char *base = (char *) c->scratch;
-    HIPCHK(c, hipMemcpyAsync(base, hn.data(), N * sizeof(SprNode), hipMemcpyHostToDevice, c->stream));
-    if (nList) HIPCHK(c, hipMemcpyAsync(base + offList, hl.data(), (size_t) nList * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(base + offEpoch, 0, N * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(base + offOut, 0, 128, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are pageable)
-    SprState S;
-    S.nodes = (SprNode *) base;
-    S.nodeList = (const int32_t *) (base + offList);
-    S.path = (int32_t *) (base + offPath);
-    S.upEpoch = (uint32_t *) (base + offEpoch);
-    S.out = (int64_t *) (base + offOut);
-    S.nList = nList;
-    S.nNodes = nNodes;
-    S.root = root;
-    S.scoredist = scoredist;
-    S.maxLen = maxLen;
-    S.rowsById = c->allRows ? 1 : 0;
-    S.pad = 0;
-    S.tol = c->fpostTol;
-    // (set on every call: the attribute belongs to the function, and contexts with other alignment lengths share it)
-    VFT_DISPATCH(c, HIPCHK(c, hipFuncSetAttribute((const void *) (k_spr_walk<REAL, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)));
-    VFT_DISPATCH(c, launch((k_spr_walk<REAL, NC>), dim3(1), dim3(VFT_SPR_WG), lds, c->stream, arena<REAL>(c), S));
-    LAUNCHCHK(c);
-    HIPCHK(c, hipMemcpyAsync(hn.data(), base, N * sizeof(SprNode), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, base + offOut, 128, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t v = 0; v < N; v++) {
-        parent[v] = hn[v].parent;
-        child[3 * v] = hn[v].c0;
-        child[3 * v + 1] = hn[v].c1;
-        child[3 * v + 2] = hn[v].c2;
-    }
     return VFT_OK;
 }
 
@@ -3929,7 +3724,6 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_FAULT_NO_FLAG: c->faultNoFlag = value != 0; break;
         case VFT_DEBUG_WAIT_LIMIT_MS: c->waitLimitS = value > 0 ? (double) value / 1000.0 : 120.0; break;
         case VFT_DEBUG_WIDE_GLUE: c->wideGlue = value != 0; break;
-        case VFT_DEBUG_WALK_IDS_IN_RING: c->walkIdsInRing = value != 0; break;
         case VFT_DEBUG_NO_WALK_SERVER: c->ws.disabled = value != 0; break;
         case VFT_DEBUG_WALK_DEVICE_MAILBOX: c->ws.wantDeviceMail = value != 0; break;
         case VFT_DEBUG_WALK_SERVER_STRIDE: c->ws.stride = value == 1 ? 1 : 8; break;

@@ -193,7 +193,7 @@ __device__ __forceinline__ REAL vft_red4_sum(const REAL *a) {
 }
 
 // Where a kernel reads the distance-matrix tables from: the arena (global memory, the default of every function below), or a copy
-// a latency-bound kernel made in LDS (k_walk_step_args: a table read from global memory inside a loop that also stores is a wait for
+// a latency-bound kernel made in LDS (k_walk_server: a table read from global memory inside a loop that also stores is a wait for
 // the stores).  The tables: distances [NC][NC], codeFreq [NC][NC], eigenval [NC], eigentot [NC].
 template <typename REAL>
 struct DmGlobal {

@@ -1008,176 +1008,7 @@ __global__ __launch_bounds__(VFT_WG) void k_pairs_fused(Arena<REAL> A, const int
     }
 }
 
-// One step of a host-driven refinement walk in ONE launch (SPR chains, minimum-evolution NNIs of the one-thread order): the unweighted
-// averages queued since the last step (recomputeProfile, up-profiles down a path: a chain, later ones may read earlier outputs) and
-// then the six raw profile distances AB AC AD BC BD CD of the quartet q[0..3] they lead up to (chooseNNI, NJ.tcc:4836-4846).  Two
-// launches and a wait per step before (k_average_chain, then k_pairs_fused over six pairs); the averages are column-wise and cheap, so
-// each of the six pair workgroups simply runs the whole chain itself for all columns (every workgroup stores the outputs - the same
-// bits six times - and reads back only what it wrote itself), then forms its pair's addends and adds them in column order
-// (vft_pair_block: bit-identical to every other pair kernel).  No workgroup waits for another; the last one publishes the six
-// distances.  Rows only: every internal id must be a plain row (the refinement phase after vft_set_profile_rows).
-template <typename REAL, int NC, int WG>
-__global__ __launch_bounds__(WG) void k_walk_step(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN, int32_t n, double tol,
-                                                      const int64_t *q, REAL *dist, unsigned int *doneCtr, unsigned long long *flag,
-                                                      unsigned long long seq, REAL *stage, int64_t stageCap) {
-    extern __shared__ __attribute__((aligned(16))) double pwLds[];
-    // (WG threads: a column per thread up to 1 024 columns - the chain is a sequence of dependent memory rounds per column)
-    for (int64_t p = threadIdx.x; p < A.d.nPos; p += WG) {
-        int64_t prevOut = -1;
-        Col<REAL, NC> prev;
-        prev.w = 0;
-        prev.code = VFT_NOCODE_;
-        prev.vec = false;
-#pragma unroll
-        for (int k = 0; k < NC; k++) prev.f[k] = 0;
-        for (int32_t k = 0; k < n; k++) {
-            const int64_t a = aN[k], b = bN[k], o = outN[k];
-            Col<REAL, NC> c1, c2;
-            if (a == prevOut) c1 = prev;
-            else if (a >= A.d.nSeqs) vft_load_row<REAL, NC>(A, a, p, c1);
-            else vft_load_col<REAL, NC>(A, a, p, c1);
-            if (b == prevOut) c2 = prev;
-            else if (b >= A.d.nSeqs) vft_load_row<REAL, NC>(A, b, p, c2);
-            else vft_load_col<REAL, NC>(A, b, p, c2);
-            REAL wo, f[NC];
-            int co;
-            vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
-            vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
-            prevOut = o;
-            prev.w = wo;
-            prev.code = co;
-            prev.vec = wo > 0 && co == VFT_NOCODE_;
-#pragma unroll
-            for (int k2 = 0; k2 < NC; k2++) prev.f[k2] = f[k2];
-        }
-    }
-    // the pair of this workgroup; its columns come from memory: what this thread stored above, or rows nobody touched
-    // (vft_pair_block with the same column -> thread mapping as the loop above: p = threadIdx.x + i * blockDim.x)
-    const int w = (int) blockIdx.x;
-    const int64_t i = q[w < 3 ? 0 : w < 5 ? 1 : 2], j = q[w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3];
-    REAL d, wt;
-    vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
-    if (threadIdx.x == 0) vft_stage_store<REAL>(stage, stageCap, w, d, wt, (REAL) 0);
-    vft_publish_staged<REAL>(stage, stageCap, 6, dist, dist + 6, (REAL *) nullptr, doneCtr, flag, seq);
-}
-
-// The same step with everything the host hands over in the kernel ARGUMENTS (up to VFT_WALK_ARGS averages - the usual step has
-// five) and every workgroup publishing its own distance: the ids of k_walk_step live in the mapped ring, so each trip of its loop
-// starts with a read over PCIe that the stores of the trip before keep the compiler from hoisting, and its six results go through a
-// staging buffer, two counters and the last workgroup.  Here the ids come with the dispatch packet (scalar loads from the constant
-// kernel-argument segment), and workgroup w writes {distance, weight} to res[2 w], res[2 w + 1] and then `seq` to flags[w] (both
-// host-mapped; the host waits for all six words, which share a cache line).  Same arithmetic, same order.
-// Measured against this on one box and slower: the chain's outside inputs loaded ahead of the chain into registers (with
-// and without a loop free of loads), rows loaded in one round with the vector fetched unconditionally.
-#ifndef VFT_WALK_ARGS
-#define VFT_WALK_ARGS 48
-#endif
-// tools-only build (-DVFT_WALK_TIMING, tools/walk_ticks.py): thread 0 of every workgroup of k_walk_step_args adds the clock ticks
-// (100 MHz) of its phases - [0] the averages, [1] the pair's columns and ordered sum, [2] publication - and [3] counts workgroups
-#ifdef VFT_WALK_TIMING
-static __device__ unsigned long long vftWalkTicks[8];
-#define VFT_WALK_TICK(k)                                       \
-    do {                                                       \
-        if (threadIdx.x == 0) {                                \
-            const unsigned long long now_ = wall_clock64();    \
-            atomicAdd(&vftWalkTicks[k], now_ - walkTick_);     \
-            walkTick_ = now_;                                  \
-        }                                                      \
-    } while (0)
-#else
-#define VFT_WALK_TICK(k) do { } while (0)
-#endif
-struct WalkIds {
-    int32_t out[VFT_WALK_ARGS], a[VFT_WALK_ARGS], b[VFT_WALK_ARGS];
-    int32_t q[4];
-    int32_t n;
-    int32_t chainOnly;   // the launch is ONE workgroup that runs the averages and nothing else (see vft_walk_step: steps that
-                         // write a node twice, or after reading it, must not run their chain six times side by side)
-};
-
-template <typename REAL, int NC, int WG>
-__global__ __launch_bounds__(WG) void k_walk_step_args(Arena<REAL> A, const WalkIds W, double tol, REAL *res, unsigned long long *flags,
-                                                           unsigned long long seq) {
-    extern __shared__ __attribute__((aligned(16))) double pwLds[];
-#ifdef VFT_WALK_TIMING
-    unsigned long long walkTick_ = wall_clock64();
-#endif
-    // Amino acids: the distance-matrix tables (distances, codeFreq, eigenval, eigentot: 840 numbers) come to LDS first.  An average
-    // reads codeFreq rows and eigentot, a pair codeFreq rows and eigenval; from global memory each of those reads sits behind the
-    // stores of the average before (loads and stores share one counter), ~1 us apiece.
-    constexpr int NT = NC == 20 ? 2 * NC * NC + 2 * NC : 1;
-    __shared__ REAL sDm[NT];
-    typedef const __attribute__((address_space(3))) REAL *lds_t;
-    DmLds<REAL> T;
-    T.dist = (lds_t) sDm;
-    T.codeFreq = (lds_t) sDm + (NC == 20 ? NC * NC : 0);
-    T.eigenval = (lds_t) sDm + (NC == 20 ? 2 * NC * NC : 0);
-    T.eigentot = (lds_t) sDm + (NC == 20 ? 2 * NC * NC + NC : 0);
-    const bool ldsTables = NC == 20 && A.dmDist != nullptr;
-    if (ldsTables) {
-        for (int t = threadIdx.x; t < NT; t += WG)
-            sDm[t] = t < NC * NC ? A.dmDist[t] : t < 2 * NC * NC ? A.dmCodeFreq[t - NC * NC] : t < 2 * NC * NC + NC ? A.dmEigenval[t - 2 * NC * NC] : A.dmEigentot[t - 2 * NC * NC - NC];
-        __syncthreads();
-    }
-    for (int64_t p = threadIdx.x; p < A.d.nPos; p += WG) {
-        int64_t prevOut = -1;
-        Col<REAL, NC> prev;
-        prev.w = 0;
-        prev.code = VFT_NOCODE_;
-        prev.vec = false;
-#pragma unroll
-        for (int k = 0; k < NC; k++) prev.f[k] = 0;
-        for (int32_t k = 0; k < W.n; k++) {
-            const int64_t a = W.a[k], b = W.b[k], o = W.out[k];
-            Col<REAL, NC> c1, c2;
-            if (a == prevOut) c1 = prev;
-            else if (a >= A.d.nSeqs) vft_load_row<REAL, NC>(A, a, p, c1);
-            else vft_load_col<REAL, NC>(A, a, p, c1);
-            if (b == prevOut) c2 = prev;
-            else if (b >= A.d.nSeqs) vft_load_row<REAL, NC>(A, b, p, c2);
-            else vft_load_col<REAL, NC>(A, b, p, c2);
-            REAL wo, f[NC];
-            int co;
-            if (ldsTables) vft_average_col<REAL, NC, DmLds<REAL>>(A, c1, c2, 0.5, tol, wo, co, f, T);
-#ifndef VFT_WALK_BRANCHY_AVG   // (A/B builds: the branchy average everywhere)
-            else if (NC == 4 && A.dmDist == nullptr) {   // selects instead of branches: -5 % per step at 200 columns, neutral at 1 000
-                if constexpr (NC == 4) vft_average_col_nt_select<REAL>(c1, c2, tol, wo, co, f);
-            }
-#endif
-            else vft_average_col<REAL, NC>(A, c1, c2, 0.5, tol, wo, co, f);
-            vft_store_col_ml<REAL, NC>(A, o, p, wo, co, f);
-            prevOut = o;
-            prev.w = wo;
-            prev.code = co;
-            prev.vec = wo > 0 && co == VFT_NOCODE_;
-#pragma unroll
-            for (int k2 = 0; k2 < NC; k2++) prev.f[k2] = f[k2];
-        }
-    }
-    VFT_WALK_TICK(0);
-    if (W.chainOnly) return;
-    const int w = (int) blockIdx.x;
-    const int64_t i = W.q[w < 3 ? 0 : w < 5 ? 1 : 2], j = W.q[w == 0 ? 1 : (w == 1 || w == 3) ? 2 : 3];
-    REAL d, wt;
-    if (ldsTables) vft_pair_block_t<REAL, NC, DmLds<REAL>>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true, T);
-    else vft_pair_block<REAL, NC>(A, i, j, false, pwLds, pwLds + A.d.nPosPad, d, wt, /*rowsById*/true);
-    VFT_WALK_TICK(1);
-    if (threadIdx.x == 0) {
-        res[2 * w] = d;
-        res[2 * w + 1] = wt;
-        // the two numbers must have LEFT the chip before the flag moves (the explicit wait: see vft_publish_staged)
-        __threadfence_system();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&flags[w], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    VFT_WALK_TICK(2);
-#ifdef VFT_WALK_TIMING
-    if (threadIdx.x == 0) {
-        atomicAdd(&vftWalkTicks[3], 1ull);
-        atomicAdd(&vftWalkTicks[4], (unsigned long long) W.n);
-    }
-#endif
-}
+// (a step of a host-driven refinement walk - queued averages + the six distances of a quartet - is the walk server's, vft_kernels_walk.h)
 
 // A short pair list and the out-distance refreshes it needs in ONE launch (the join loop makes three such calls per join
 // and each is a host round trip: a second, dependent launch is ~8 us of a ~33 us call).  Workgroups [0, nStale) refresh

@@ -298,7 +298,7 @@ __device__ __forceinline__ void vft_average_col(const Arena<REAL> &A, const Col<
 }
 
 // The same for nucleotides without a distance matrix, written with selects instead of branches: the kinds of column (gap, code,
-// vector) differ from lane to lane, and a latency-bound caller with one wavefront per SIMD (k_walk_step_args) pays for every branch
+// vector) differ from lane to lane, and a latency-bound caller with one wavefront per SIMD (k_walk_server) pays for every branch
 // region a wavefront walks through.  Same operations on the same operands in the same order as vft_average_col / vft_add_to_freq /
 // vft_normalize_freq above; results of the paths a lane does not take are computed and dropped.
 template <typename REAL>

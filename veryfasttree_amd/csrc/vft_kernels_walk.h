@@ -3,9 +3,9 @@
 //
 // A step = the unweighted averages queued since the last step (recomputeProfile, up-profiles down a path: a chain, later ones read
 // earlier outputs) + the six raw profile distances AB AC AD BC BD CD of the quartet they lead up to (chooseNNI, NJ.tcc:4836-4846).
-// k_walk_step_args did that in one launch: ~11 us of launch + completion wait around ~10 us of work on six workgroups that each ran
-// the whole chain, and a second launch for the 28 % of steps that rewrite a node.  Here six workgroups stay RESIDENT for a whole
-// round.  The host keeps what a CPU is good at - the tree, the cache flags, the pointer chasing of traverseSPR (a wavefront needs
+// Round 4 did that in one launch per step (k_walk_step_args, since removed): ~11 us of launch + completion wait around ~10 us of work on
+// six workgroups that each ran the whole chain, and a second launch for the 28 % of steps that rewrite a node.  Here six workgroups stay
+// RESIDENT for a whole round.  The host keeps what a CPU is good at - the tree, the cache flags, the pointer chasing of traverseSPR (a wavefront needs
 // ~12 us per step for that) - and hands every step over as a command in a mailbox the workgroups poll:
 //
 //   host      writes the command as self-tagged 8-byte granules {data, seq} into slot seq % RING of the mailbox (pinned host memory,
@@ -20,7 +20,7 @@
 //             parks the addends of all columns in LDS, raises readsDone[w] = seq (the next chain may overwrite the rows now), adds the
 //             addends in column order (two lanes: `top` and `denom`, the reference's sequence of double additions, exactly as
 //             vft_pair_block) and sends the distance to the host as one or two self-tagged granules - no fence, no flag.
-// Same operations on the same values in the same order as k_walk_step_args / k_average_chain + k_pairs_fused: the trees stay
+// Same operations on the same values in the same order as k_average_chain + k_pairs_fused: the trees stay
 // byte-identical (tests/test_gpu_walk_server.py and every SPR / NNI fixture, which run through the server by default).
 // Every spin is bounded: a workgroup that sees no command for idleTicks, or no flag for flagTicks, reports a status and exits.
 #ifndef VFT_KERNELS_WALK_H
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
     __shared__ uint32_t sCmd[VFT_WS_GRAN];
     __shared__ double sSum[2];
     __shared__ int sStop;
-    // amino acids: the distance-matrix tables (distances, codeFreq, eigenval, eigentot) in LDS, as in k_walk_step_args
+    // amino acids: the distance-matrix tables (distances, codeFreq, eigenval, eigentot) in LDS: a table read from global memory between the chain's stores is a wait for the stores
     constexpr int NT = NC == 20 ? 2 * NC * NC + 2 * NC : 1;
     __shared__ REAL sDm[NT];
     typedef const __attribute__((address_space(3))) REAL *lds_t;

@@ -972,27 +972,6 @@ namespace veryfasttree {
                 bool up;
                 while ((node = nextPostorder(node, traversal, &up, root, /*reportUp*/false)) >= 0) nodeList.push_back(node);
             }
-            /* the walk itself runs on the device (k_spr_walk, csrc/vft_kernels_spr.h: the statements below, wave 0 of one
-               persistent workgroup executing them, no host round trip per step) whenever the alignment fits its staging;
-               the host walk that follows is the same algorithm for longer alignments and chains */
-            if (sprOnDevice && maxSPRLength <= 16 && (size_t) sprPosPad * 96 + 34 * 1024 <= 160u * 1024u) {
-                flushAverages();
-                int64_t out[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                const int rc = vft_spr_round(ctx, nNodes, parent.data(), child.data(), root, (int64_t) nodeList.size(), nodeList.data(), scoredist ? 1 : 0,
-                                             maxSPRLength, out);
-                if (rc == VFT_ERR_STATE) goto hostWalk;   /* a profile without a row: the kernel has refused before touching anything */
-                chk(rc);
-                sprSteps += out[1];
-                if (std::getenv("VFT_SPR_REPORT")) {   /* tools: where the kernel's time goes */
-                    fprintf(stderr, "SPR round on the device: %lld moves, %lld steps, %lld averages, %lld commands; %.3f s in all, %.3f s inside commands\n",
-                            (long long) out[0], (long long) out[1], (long long) out[2], (long long) out[6], 1e-8 * (double) out[5], 1e-8 * (double) out[4]);
-                    fprintf(stderr, "  thread 0 inside commands: columns %.3f s, barrier %.3f s, sums %.3f s, barrier %.3f s\n", 1e-8 * (double) out[7], 1e-8 * (double) out[8], 1e-8 * (double) out[9], 1e-8 * (double) out[10]);
-                    fprintf(stderr, "  shader clock during the walk: %.0f MHz\n", out[5] > 0 ? 100.0 * (double) out[11] / (double) out[5] : 0.0);
-                }
-                rebuildOrder();
-                return out[0];
-            }
-            hostWalk:
             int64_t nSPR = 0;
             WalkServerGuard server(*this);
             for (int64_t node: nodeList)
@@ -1247,13 +1226,10 @@ namespace veryfasttree {
         int64_t laneSteps = 0, laneWork = 0;   /* lockstep steps / quartets or splits evaluated in them (all rounds so far) */
 
         int64_t nStarTests = 0;
-        bool walkStepFused = true;   /* meCriteria: averages + distances as one launch (false: two calls; tests compare) */
-        bool walkServer = true;      /* the walks' steps go to resident workgroups through a mailbox (vft_walk_server_start) instead of one
-                                        launch each; false: the launch per step (tests compare) */
-        bool sprOnDevice = true;    /* false: the host-driven SPR walk (tests compare the two) */
-        int64_t sprPosPad = 1 << 30;   /* the context's padded column count (setSprPosPad); unknown: host walk */
-        int64_t sprSteps = 0;
-        void setSprPosPad(int64_t nPos) { sprPosPad = (nPos + 15) / 16 * 16; }
+        bool walkStepFused = true;   /* meSubmit: averages + distances as one step of the walk server (false: the two plain calls) */
+        bool walkServer = true;      /* the walks' steps go to resident workgroups through a mailbox (vft_walk_server_start); false: the
+                                        two plain calls per step (tests compare) */
+        int64_t sprSteps = 0;        /* chain steps evaluated by the SPR rounds */
 
         const std::vector<int64_t> &children() const { return child; }
         const std::vector<int64_t> &parents() const { return parent; }
@@ -1523,10 +1499,10 @@ namespace veryfasttree {
                     qOut.clear();
                     qA.clear();
                     qB.clear();
-                } else if (rc == VFT_ERR_STATE) {
-                    walkStepFused = false;   /* (some profile lives in the tile streams: the two calls from here on) */
-                } else {
+                } else if (rc == VFT_ERR_TIMEOUT) {
                     chk(rc);
+                } else {
+                    walkStepFused = false;   /* (no walk server - VFT_ERR_STATE - or it cannot take this step: the two calls from here on) */
                 }
             }
             if (!fused) {

@@ -64,10 +64,6 @@ namespace veryfasttree {
         /* with comm: split the close-neighbour blocks of setAllLeafTopHits by rows and all-gather the results (round 3); off: every
            rank computes them whole - 25 GB of gathers at a million sequences cost more than the ~5 s of integer counts they split */
         bool shardLeafBlocks = false;
-        /* the SPR rounds as one persistent kernel per round (vft_spr_round) instead of the host-driven walk.  Off by default:
-           measured on MI355X the kernel needs ~50 us per chain step on its one CU, the host-driven walk ~45 us with six to eight
-           CUs per step; both give the same tree (tests/test_gpu_threads.py) */
-        bool deviceSPR = false;
         bool walkServer = true;    /* refinement walks through the resident walk server (vft_walk_server_start); false: a launch per step */
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
@@ -729,8 +725,6 @@ namespace veryfasttree {
             std::vector<int64_t> par, ch;
             treeArrays(par, ch);
             MLLengths<REAL> tree(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
-            tree.setSprPosPad(nPos);
-            tree.sprOnDevice = opt.deviceSPR;
             tree.walkServer = opt.walkServer;
             typename MLLengths<REAL>::NNIParams prm;
             prm.useML = false;

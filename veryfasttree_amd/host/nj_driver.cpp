@@ -74,11 +74,24 @@ static double gGamma[3];   /* `-gamma` of the last tree: Gamma(nCat) log-likelih
 extern "C" int vft_tree_partitioning(int64_t nNodes, const int64_t *childIn, int64_t root, int32_t penalty, int32_t threads, int32_t window,
                                      int64_t *out, int64_t cap, int64_t *nOut, double *speedup) {
     if (nNodes < 4 || !childIn || root < 0 || root >= nNodes || penalty < 0 || threads < 1 || !nOut) return VFT_ERR_INVALID;
+    if (threads > nNodes) threads = (int32_t) nNodes;   /* (more threads than nodes cannot change the partition) */
+    /* the arrays come from the caller: every child id in range and every node the child of at most one parent - a tree, so the walk
+       below ends and stays inside the arrays */
+    std::vector<char> seen((size_t) nNodes, 0);
+    for (int64_t i = 0; i < 3 * nNodes; i++) {
+        const int64_t ch = childIn[i];
+        if (ch < -1 || ch >= nNodes || ch == root) return VFT_ERR_INVALID;
+        if (ch >= 0) {
+            if (seen[(size_t) ch]) return VFT_ERR_INVALID;
+            seen[(size_t) ch] = 1;
+        }
+    }
     std::vector<int64_t> child(childIn, childIn + 3 * nNodes), order;
     std::vector<std::pair<int64_t, int>> stack(1, std::make_pair(root, 0));
     while (!stack.empty()) {   /* post-order of the internal nodes, children in stored order */
         const int64_t v = stack.back().first;
         const int k = stack.back().second;
+        if ((int64_t) stack.size() > nNodes) return VFT_ERR_INVALID;   /* (a cycle that does not pass through the root) */
         if (k < 3 && child[3 * v + k] >= 0) {
             stack.back().second++;
             stack.push_back(std::make_pair(child[3 * v + k], 0));
@@ -132,7 +145,6 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_JOINS) opt.deviceJoins = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_LISTS) opt.deviceLists = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_RESET) opt.deviceReset = false;
-        if (o->debug_flags & VFT_NJ_DEBUG_DEVICE_SPR) opt.deviceSPR = true;
         if (o->debug_flags & VFT_NJ_DEBUG_NO_WALK_SERVER) opt.walkServer = false;
         if (o->debug_flags & VFT_NJ_DEBUG_LEVEL_LENGTHS) opt.parallelLengths = true;
         if (o->debug_flags & VFT_NJ_SHARD_LEAF_BLOCKS) opt.shardLeafBlocks = true;
