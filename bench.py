@@ -32,6 +32,7 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("HSA_ENABLE_SDMA", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+T_START = time.perf_counter()
 
 
 def parse():
@@ -45,8 +46,10 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end trees (wall-clock half of the metric)")
     ap.add_argument("--no-e2e-c4", action="store_true", help="skip the 1M x 200 end-to-end tree (minutes), keep C3's")
     ap.add_argument("--no-dense", action="store_true", help="skip the phi ~ 1 roofline of the sweep kernel")
-    ap.add_argument("--no-e2e-full", action="store_true", help="skip the complete pipelines of configs C2 and C5 (~3.5 minutes)")
-    ap.add_argument("--e2e-c4-full", action="store_true", help="also the complete -nt pipeline of config C4 (1M x 200; ~18 minutes on one GPU)")
+    ap.add_argument("--no-e2e-full", action="store_true", help="skip the complete pipelines of configs C2, C5 and C4 (~17 minutes)")
+    ap.add_argument("--no-e2e-c4-full", action="store_true", help="skip the complete -nt pipeline of config C4 (1M x 200; ~9 minutes on one GPU)")
+    ap.add_argument("--no-e2e-c5-one-thread", action="store_true", help="skip config C5's complete pipeline in the reference's one-thread order (~6 minutes)")
+    ap.add_argument("--time-budget", type=float, default=1500.0, help="seconds after which the remaining complete pipelines are skipped (and reported as skipped)")
     return ap.parse_args()
 
 
@@ -268,7 +271,7 @@ E2E_FULL = {
     # (host/MLLengths.h "the subtree schedule": the walks of T-thread partitions advanced in lockstep, batches of quartets on the GPU).
     "c2": dict(n=10000, L=1000, nc=4, seed=2, dtype="float32", gtr=True, aa=None, threads=64, flags="-nt -gtr", golden="bb_c2_crc.npz"),
     "c5": dict(n=50000, L=300, nc=20, seed=2, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden="bb_c5_crc.npz"),
-    # config C4 with its real flags (--e2e-c4-full: 18 minutes; profiles/r04_c4_full_flags.txt holds a run)
+    # config C4 with its real flags (9 minutes)
     "c4": dict(n=1000000, L=200, nc=4, seed=4, mu=0.02, dtype="float32", gtr=False, aa=None, threads=1024, flags="-nt", golden=None),
 }
 
@@ -438,45 +441,53 @@ def main():
     ops_per_step = len(seeds) * state.n_active
     value = ops_per_step * args.steps / elapsed
 
-    # A sweep is two kernels (vft_kernels_nj.h): k_sweep_nt - every target of a leaf seed, the internal-profile
-    # targets of a profile seed - and k_sweep_nt_table - the leaf targets of a profile seed.  Both are timed with HIP
-    # events on their own stream over one more step; k_sweep_nt is the dominant one (roofline), the other is reported
-    # beside it, and "sweep" prices the whole sweep (both kernels) against the same peak.
-    ops.timer_start()
-    one_step()
-    ops.timer_stop_ms()
-    kern_ms, launches = ops.sweep_kernel_ms()
-    tab_ms, _ = ops.sweep_table_kernel_ms()
+    # A sweep is ONE launch over all targets (vft_kernels_nj.h): k_sweep_nt<MODE_CRIT_LEAFQ> for a leaf seed, k_sweep_nt_both for a
+    # profile seed - the profile x profile ProfileDist over the internal targets with the table walk over the leaf targets riding on
+    # the same CUs.  Timed with HIP events on the kernels' own stream over one more pass per kind of seed (events between the
+    # launches would open gaps in the timed region above); the roofline prices the average launch against its algorithmic bytes.
+    seeds_leaf = np.asarray([q for q in seeds if q < n], np.int64)
+    seeds_prof = np.asarray([q for q in seeds if q >= n], np.int64)
+
+    def timed_pass(which):
+        ops.timer_start()
+        ops.setBestHitBatch(which, state.n_active, state.n_diff_allow, state.totdiam, k)
+        ops.timer_stop_ms()
+        return ops.sweep_kernel_ms()
+
+    leaf_ms, n_leaf_launches = timed_pass(seeds_leaf) if len(seeds_leaf) and not use_dist else (0.0, 0)
+    prof_ms, n_prof_launches = timed_pass(seeds_prof) if len(seeds_prof) and not use_dist else (0.0, 0)
+    if use_dist:   # (sharded: one instrumented step as it is)
+        ops.timer_start()
+        one_step()
+        ops.timer_stop_ms()
+        kern_ms, launches = ops.sweep_kernel_ms()
+    else:
+        launches = n_leaf_launches + n_prof_launches
+        kern_ms = (leaf_ms * n_leaf_launches + prof_ms * n_prof_launches) / max(launches, 1)
     ab = state.algorithmic_bytes_per_sweep(lo, hi)
-    n_leaf_seeds = sum(1 for q in seeds if q < n)
-    n_prof_seeds = len(seeds) - n_leaf_seeds
-    # leaf seed: k_sweep_nt sees all targets; profile seed: the internal ones (+ < 1024 leaves of the range remainder)
-    alg_main = (n_leaf_seeds * (ab["leaf"] + ab["internal"]) + n_prof_seeds * ab["internal"]) / float(len(seeds))
-    moved_main = (n_leaf_seeds * (ab["moved_leaf"] + ab["moved_internal"]) + n_prof_seeds * ab["moved_internal"]) / float(len(seeds))
-    alg_tab = n_prof_seeds * ab["leaf"] / float(len(seeds))          # tab_ms is averaged over all sweeps as well
+    alg_main = float(ab["leaf"] + ab["internal"])
+    moved_main = float(ab["moved_leaf"] + ab["moved_internal"])
     achieved = alg_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    # HBM traffic of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
+    # HBM traffic of the same kernels from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
     # process): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, bytes per launch
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (n, L, world) == (1000000, 200, 1):
         t = json.load(open(tpath))
         if t.get("kernel_sources_sha256") == sweep_kernel_hash():   # (counters read from other kernel sources say nothing: null)
-            traffic = t.get("k_sweep_nt<float,MODE_CRIT>", {}).get("bytes_per_launch")
-    both_ms = kern_ms + tab_ms
+            traffic = t.get("sweep_launch_average", {}).get("bytes_per_launch")
+    per_kind = lambda ms: dict(avg_launch_ms=ms, achieved_gbs=alg_main / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                               frac=alg_main / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0)
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="k_sweep_nt<float,MODE_CRIT>", launches=int(launches),
+                    traffic=traffic, kernel="k_sweep_nt_both<float> (profile seeds) / k_sweep_nt<float,MODE_CRIT_LEAFQ> (leaf seeds)", launches=int(launches),
                     avg_launch_ms=kern_ms, algorithmic_bytes_per_launch=int(alg_main),
                     moved_bytes_per_launch=int(moved_main),
                     achieved_moved_gbs=moved_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
                     frac_moved=moved_main / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0,
                     phi=ab["phi"],
-                    table_kernel=dict(kernel="k_sweep_nt_table<float,MODE_CRIT>", avg_ms_per_sweep=tab_ms,
-                                      algorithmic_bytes_per_sweep=int(alg_tab), bound="lds",
-                                      achieved_gbs=alg_tab / (tab_ms * 1e-3) / 1e9 if tab_ms > 0 else 0.0),
-                    sweep=dict(avg_ms=both_ms, algorithmic_bytes=int(ab["leaf"] + ab["internal"]),
-                               achieved_gbs=(ab["leaf"] + ab["internal"]) / (both_ms * 1e-3) / 1e9 if both_ms > 0 else 0.0,
-                               frac=(ab["leaf"] + ab["internal"]) / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if both_ms > 0 else 0.0))
+                    profile_seed_launch=per_kind(prof_ms), leaf_seed_launch=per_kind(leaf_ms),
+                    step=dict(algorithmic_bytes=int(alg_main * len(seeds)), achieved_gbs=alg_main * len(seeds) / (elapsed / args.steps) / 1e9,
+                              frac=alg_main * len(seeds) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS))
 
     line = dict(metric="profile-ops/sec", value=value, unit="profile-ops/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
@@ -555,11 +566,18 @@ def main():
                     e2e["same_crc_on_all_ranks"] = bool(c[0].item() == -c[1].item())
             line[key] = e2e
         if not args.no_e2e_full and not use_dist:
-            # the complete pipelines (refinement + maximum likelihood) of configs C2 and C5: not sharded, rank 0 only
+            # the complete pipelines (refinement + maximum likelihood + supports): not sharded, rank 0 only.  C2 and C5 in the
+            # reference's one-thread order (its deterministic path: trees compared with the reference binary's own output) and on
+            # the schedule of a T-thread run; C4 with its real flags on the schedule of 1 024 threads.
             legs = [("e2e_c2", "c2", True), ("e2e_c2_threads", "c2", False), ("e2e_c5_threads", "c5", False)]
-            if args.e2e_c4_full:
+            if not args.no_e2e_c4_full:
                 legs.append(("e2e_c4_full_threads", "c4", False))
+            if not args.no_e2e_c5_one_thread:
+                legs.append(("e2e_c5", "c5", True))
             for key, which, one in legs:
+                if time.perf_counter() - T_START > args.time_budget:
+                    line[key] = {"workload": which, "skipped": "time budget of %.0f s used up" % args.time_budget}
+                    continue
                 try:
                     line[key] = end_to_end_full(which, local_rank, one)
                 except Exception as exc:

@@ -84,7 +84,7 @@ struct vft_ctx {
     uint64_t *candKey = nullptr;
     int32_t *candId = nullptr;
     char *dRes = nullptr;    // SelectHeader followed by the k hit records
-    char *hRes = nullptr;    // pinned, device-mapped host mirror of dRes, written by k_select_best (zero-copy)
+    char *hRes = nullptr;    // pinned, device-mapped host mirror of dRes, written by the last workgroup of k_select_rank (zero-copy)
     char *hResDev = nullptr; // device address of hRes
     // One set of sweep-result + selection buffers per seed of a batch (vft_sweep_batch); slot 0 aliases the members
     // above, further slots are allocated on first use.
@@ -96,6 +96,11 @@ struct vft_ctx {
         int32_t *candId = nullptr;
         char *dRes = nullptr, *hRes = nullptr, *hResDev = nullptr;
         int nPart = 0;
+        // the seed's staged query (nt without a distance matrix; slot 0 uses the context's qW[0] ...)
+        void *qW = nullptr, *qF = nullptr;
+        uint8_t *qC = nullptr;
+        uint4 *qEnc = nullptr;
+        double2 *qTab = nullptr;
     };
     std::vector<SweepSlotHost> slots;
     char *dMerge = nullptr, *hMerge = nullptr, *hMergeDev = nullptr;   // result blocks of vft_merge_hits_batch
@@ -277,6 +282,20 @@ static QueryBuf<REAL> qbuf(const vft_ctx *c, int which) {
     q.f = (REAL *) c->qF[which];
     q.enc = c->qEnc[which];
     q.tab = c->qTab[which];
+    return q;
+}
+
+// the staged query of a batch slot
+template <typename REAL>
+static QueryBuf<REAL> qbuf_slot(const vft_ctx *c, int slot) {
+    if (slot == 0) return qbuf<REAL>(c, 0);
+    const vft_ctx::SweepSlotHost &h = c->slots[(size_t) slot];
+    QueryBuf<REAL> q;
+    q.w = (REAL *) h.qW;
+    q.code = h.qC;
+    q.f = (REAL *) h.qF;
+    q.enc = h.qEnc;
+    q.tab = h.qTab;
     return q;
 }
 
@@ -580,7 +599,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->hMerge) hipHostFree(c->hMerge);
     for (size_t i = 1; i < c->slots.size(); i++) {   // slot 0 aliases members freed below
         vft_ctx::SweepSlotHost &h = c->slots[i];
-        void *dev[] = {h.swDist, h.swWeight, h.swCrit, h.partMin, h.partMax, h.sel, h.slices, h.candKey, h.candId, h.dRes};
+        void *dev[] = {h.swDist, h.swWeight, h.swCrit, h.partMin, h.partMax, h.sel, h.slices, h.candKey, h.candId, h.dRes, h.qW, h.qF, h.qC, h.qEnc, h.qTab};
         for (void *p: dev)
             if (p) hipFree(p);
         if (h.hRes) hipHostFree(h.hRes);
@@ -1656,14 +1675,21 @@ static unsigned sweep_nt_grid(vft_ctx *c, SweepArgs &s, bool tablePath) {
 static void kernel_event(vft_ctx *c);
 // the two launches of one nt sweep (vft_kernels_nj.h); events: before, between, after
 template <typename REAL, int MODE>
-static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, int whichQuery, bool timed, int slot = 0) {
+static void launch_sweep_nt(vft_ctx *c, const SweepArgs &s, unsigned grid, const QueryBuf<REAL> &Q, bool timed, int slot = 0) {
     const unsigned nHeavy = grid - (unsigned) s.nLeafWG;
+    if (MODE == MODE_CRIT && s.nLeafWG && nHeavy) {   // a profile seed's criteria: both kinds of workgroups in one launch
+        if (timed) kernel_event(c);
+        launch((k_sweep_nt_both<REAL>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), Q, s, sweepout<REAL>(c, slot));
+        if (timed) kernel_event(c);
+        if (timed) kernel_event(c);
+        return;
+    }
     if (timed) kernel_event(c);
     if (nHeavy) launch((k_sweep_nt<REAL, MODE>), dim3(nHeavy), dim3(VFT_WG), 0, c->stream, arena<REAL>(c),
-                       qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c, slot));
+                       Q, s, sweepout<REAL>(c, slot));
     if (timed) kernel_event(c);
     if (s.nLeafWG) launch((k_sweep_nt_table<REAL, (MODE == MODE_OUTDIST ? MODE_OUTDIST : MODE_CRIT)>), dim3((unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream,
-                          arena<REAL>(c), qbuf<REAL>(c, whichQuery), s, sweepout<REAL>(c, slot));
+                          arena<REAL>(c), Q, s, sweepout<REAL>(c, slot));
     if (timed) kernel_event(c);
 }
 
@@ -1725,11 +1751,11 @@ static int launch_out_distances(vft_ctx *c, const int64_t *dIds, int64_t n, int6
         if (c->cfg.precision == 4) {
             launch((k_outprofile_as_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<float>(c), qbuf<float>(c, 1));
-            launch_sweep_nt<float, MODE_OUTDIST>(c, s, grid, 1, false);
+            launch_sweep_nt<float, MODE_OUTDIST>(c, s, grid, qbuf<float>(c, 1), false);
         } else {
             launch((k_outprofile_as_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
                                arena<double>(c), qbuf<double>(c, 1));
-            launch_sweep_nt<double, MODE_OUTDIST>(c, s, grid, 1, false);
+            launch_sweep_nt<double, MODE_OUTDIST>(c, s, grid, qbuf<double>(c, 1), false);
         }
     } else if (c->cfg.n_codes == 20 && c->hasDm && c->aaLds) {
         if (c->cfg.precision == 4) launch_sweep_aa<float, MODE_OUTDIST>(c, s, 1, 0);
@@ -1804,9 +1830,46 @@ static int ensure_slots(vft_ctx *c, int count) {
         HIPCHK(c, hipHostMalloc((void **) &h.hRes, resB, hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer((void **) &h.hResDev, h.hRes, 0));
         memset(h.hRes, 0, sizeof(SelectHeader));
+        if (c->cfg.n_codes == 4 && !c->slots.empty()) {   // (slot 0 is made by vft_create and uses the context's staging)
+            const size_t nPosPad = (size_t) c->d.nChunk * VFT_CHUNK;
+            HIPCHK(c, hipMalloc(&h.qW, nPosPad * rs));
+            HIPCHK(c, hipMalloc(&h.qF, nPosPad * 4 * rs));
+            HIPCHK(c, hipMalloc((void **) &h.qC, nPosPad));
+            HIPCHK(c, hipMalloc((void **) &h.qEnc, (size_t) c->d.nChunk * sizeof(uint4)));
+            HIPCHK(c, hipMalloc((void **) &h.qTab, nPosPad * 5 * sizeof(double2)));
+        }
         c->slots.push_back(h);
     }
     return VFT_OK;
+}
+
+// waits until the host headers of slots [s0, s0 + count) carry `seq` (written by the last workgroup of k_select_rank); bounded like
+// wait_flag: VFT_ERR_TIMEOUT when the stream has drained without them, or after waitLimitS
+static int wait_headers(vft_ctx *c, int s0, int count, unsigned long long seq) {
+    if (c->faultNoFlag) {   // test hook: wait for a value nobody will ever publish
+        seq += 1ull << 40;
+        c->faultNoFlag = false;
+    }
+    auto raised = [&]() {
+        for (int s = s0; s < s0 + count; s++)
+            if ((unsigned long long) __atomic_load_n(&((const SelectHeader *) c->slots[(size_t) s].hRes)->pad2, __ATOMIC_ACQUIRE) != seq) return false;
+        return true;
+    };
+    std::chrono::steady_clock::time_point t0;
+    for (long spins = 0;; spins++) {
+        if (raised()) return VFT_OK;
+        if (spins == 200000) t0 = std::chrono::steady_clock::now();
+        if (spins >= 200000 && (spins & 0xFFFF) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {
+                if (raised()) return VFT_OK;
+                return fail(c, VFT_ERR_TIMEOUT, "the stream has drained but a selection never published its result");
+            }
+            if (e != hipErrorNotReady) return fail(c, VFT_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(e));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->waitLimitS)
+                return fail(c, VFT_ERR_TIMEOUT, "no selection result after %.0f s (the stream is still busy)", c->waitLimitS);
+        }
+    }
 }
 
 // Top-k selection of K seeds at once (their sweep results sit in slots 0..K-1): one set of launches, blockIdx.y =
@@ -1839,17 +1902,18 @@ static int run_select(vft_ctx *c, int K, const int64_t *queries, int64_t lo, int
     if (int r = io_alloc(c, hs.size() * sizeof(SelSlot), &hS, &dS)) return r;
     memcpy(hS, hs.data(), hs.size() * sizeof(SelSlot));
     const SelSlot *slots = (const SelSlot *) dS;
-    auto round = [&](const SelSlot *sl, unsigned ny) {
-        launch((k_select_hist<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi);
+    // hist (round one: with the key range) -> thresh -> collect -> rank; the rank sort's last workgroup of every seed finishes the
+    // selection and writes `seq` into the seed's host header - the host waits for those words, no kernel behind the rank sort
+    auto round = [&](const SelSlot *sl, unsigned ny, int first, int s0) -> int {
+        const unsigned long long seq = ++c->signalSeq;
+        launch((k_select_hist<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi, first);
         launch(k_select_thresh, dim3(1, ny), dim3(VFT_NBINS), 0, c->stream, sl, VFT_SEL_WGS, (unsigned int) k);
         launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi);
-        launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG, ny), dim3(VFT_WG), 0, c->stream, sl, k);
-        launch((k_select_best<REAL, HIT>), dim3(1, ny), dim3(VFT_WG), 0, c->stream, sl, k, lo, hi);
+        launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG, ny), dim3(VFT_WG), 0, c->stream, sl, k, lo, hi, (long long) seq);
+        LAUNCHCHK(c);
+        return wait_headers(c, s0, (int) ny, seq);
     };
-    launch((k_select_range<REAL>), dim3(1, (unsigned) K), dim3(1024), 0, c->stream, slots);
-    round(slots, (unsigned) K);
-    LAUNCHCHK(c);
-    if (int r = wait_stream(c)) return r;
+    if (int r = round(slots, (unsigned) K, 1, 0)) return r;
     for (int s = 0; s < K; s++) {
         const SelectHeader *h = (const SelectHeader *) c->slots[(size_t) s].hRes;
         // rare: the threshold bin alone has more candidates than the rank sort takes; narrow the key range to it
@@ -1857,16 +1921,14 @@ static int run_select(vft_ctx *c, int K, const int64_t *queries, int64_t lo, int
             if (level == VFT_MAX_LEVEL)
                 return fail(c, VFT_ERR_STATE, "top-k select: more than %d hits tied at the k-th criterion", VFT_CAND_CAP);
             launch(k_select_refine, dim3(1, 1), dim3(1), 0, c->stream, slots + s);
-            round(slots + s, 1u);
-            LAUNCHCHK(c);
-            if (int r = wait_stream(c)) return r;
+            if (int r = round(slots + s, 1u, 0, s)) return r;
         }
     }
     return VFT_OK;
 }
 
 // the lazy refresh, query staging and sweep kernels of ONE seed; its results go to the buffers of `slot`
-static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam) {
+static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64_t nDiffAllow, double totdiam, bool staged = false) {
     if (int r = flush_pending(c)) return r;
     const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
     // 1. lazy out-distance refresh of every stale active target and of the query (NJ.tcc:1092-1098) - skipped when the
@@ -1903,16 +1965,17 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
     c->slots[(size_t) slot].nPart = (int) grid;
     const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
     if (c->cfg.n_codes == 4 && !c->hasDm) {
+        // (staged: vft_sweep_batch has extracted the queries of all its seeds in one launch, each into its slot's buffers)
         if (c->cfg.precision == 4) {
-            launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c),
-                               query, qbuf<float>(c, 0));
-            if (s.queryIsLeaf) launch_sweep_nt<float, MODE_CRIT_LEAFQ>(c, s, grid, 0, true, slot);
-            else launch_sweep_nt<float, MODE_CRIT>(c, s, grid, 0, true, slot);
+            const QueryBuf<float> Q = staged ? qbuf_slot<float>(c, slot) : qbuf<float>(c, 0);
+            if (!staged) launch((k_extract_query<float, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<float>(c), query, Q);
+            if (s.queryIsLeaf) launch_sweep_nt<float, MODE_CRIT_LEAFQ>(c, s, grid, Q, true, slot);
+            else launch_sweep_nt<float, MODE_CRIT>(c, s, grid, Q, true, slot);
         } else {
-            launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream,
-                               arena<double>(c), query, qbuf<double>(c, 0));
-            if (s.queryIsLeaf) launch_sweep_nt<double, MODE_CRIT_LEAFQ>(c, s, grid, 0, true, slot);
-            else launch_sweep_nt<double, MODE_CRIT>(c, s, grid, 0, true, slot);
+            const QueryBuf<double> Q = staged ? qbuf_slot<double>(c, slot) : qbuf<double>(c, 0);
+            if (!staged) launch((k_extract_query<double, 4>), dim3(cdiv(nPosPad, 256)), dim3(256), 0, c->stream, arena<double>(c), query, Q);
+            if (s.queryIsLeaf) launch_sweep_nt<double, MODE_CRIT_LEAFQ>(c, s, grid, Q, true, slot);
+            else launch_sweep_nt<double, MODE_CRIT>(c, s, grid, Q, true, slot);
         }
     } else {
         // amino acids / distance matrix.  Measured on C5 (50k x 300, f64): lane-per-target costs ~nPos dependent
@@ -1979,8 +2042,35 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
     for (int s = 0; s < nSeeds; s++)
         if (int r = sweep_args_ok(c, queries[s], nActive, k)) return r;
     if (int r = ensure_slots(c, nSeeds)) return r;
+    // nucleotides without a distance matrix: the queries of all seeds are staged by ONE launch, each into its slot's buffers
+    const bool staged = c->cfg.n_codes == 4 && !c->hasDm && nSeeds > 1;
+    if (staged) {
+        if (int r = flush_pending(c)) return r;
+        const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+        char *hQ, *dQ;
+        if (c->cfg.precision == 4) {
+            if (int r = io_alloc(c, (size_t) nSeeds * sizeof(QuerySlot<float>), &hQ, &dQ)) return r;
+            for (int s = 0; s < nSeeds; s++) {
+                QuerySlot<float> qs;
+                qs.node = queries[s];
+                qs.q = qbuf_slot<float>(c, s);
+                memcpy(hQ + (size_t) s * sizeof(qs), &qs, sizeof(qs));
+            }
+            launch((k_extract_query_batch<float, 4>), dim3(cdiv(nPosPad, 256), (unsigned) nSeeds), dim3(256), 0, c->stream, arena<float>(c), (const QuerySlot<float> *) dQ);
+        } else {
+            if (int r = io_alloc(c, (size_t) nSeeds * sizeof(QuerySlot<double>), &hQ, &dQ)) return r;
+            for (int s = 0; s < nSeeds; s++) {
+                QuerySlot<double> qs;
+                qs.node = queries[s];
+                qs.q = qbuf_slot<double>(c, s);
+                memcpy(hQ + (size_t) s * sizeof(qs), &qs, sizeof(qs));
+            }
+            launch((k_extract_query_batch<double, 4>), dim3(cdiv(nPosPad, 256), (unsigned) nSeeds), dim3(256), 0, c->stream, arena<double>(c), (const QuerySlot<double> *) dQ);
+        }
+        LAUNCHCHK(c);
+    }
     for (int s = 0; s < nSeeds; s++)
-        if (int r = sweep_one(c, s, queries[s], nActive, nDiffAllow, totdiam)) return r;
+        if (int r = sweep_one(c, s, queries[s], nActive, nDiffAllow, totdiam, staged)) return r;
     const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
     int r;
     if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, nSeeds, queries, lo, hi, k);

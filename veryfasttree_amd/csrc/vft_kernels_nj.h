@@ -39,7 +39,7 @@ __device__ __forceinline__ void vft_query_tab(const QueryBuf<REAL> &q, int64_t p
 }
 
 template <typename REAL, int NC>
-__global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
+__device__ __forceinline__ void vft_extract_query(const Arena<REAL> &A, int64_t node, const QueryBuf<REAL> &q) {
     const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nPosPad = (int64_t) A.d.nChunk * VFT_CHUNK;
     if (p >= nPosPad) return;
@@ -69,6 +69,20 @@ __global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
     if (node < A.d.nSeqs && p < A.d.nChunk) {
         q.enc[p] = A.leafT[vft_leaf_idx(A.d, node >> 6, (int) p, (int) (node & 63))];
     }
+}
+template <typename REAL, int NC>
+__global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
+    vft_extract_query<REAL, NC>(A, node, q);
+}
+// the queries of a batch of seeds in ONE launch (vft_sweep_batch): blockIdx.y = seed, each into its own staging buffers
+template <typename REAL>
+struct QuerySlot {
+    int64_t node;
+    QueryBuf<REAL> q;
+};
+template <typename REAL, int NC>
+__global__ void k_extract_query_batch(Arena<REAL> A, const QuerySlot<REAL> *qs) {
+    vft_extract_query<REAL, NC>(A, qs[blockIdx.y].node, qs[blockIdx.y].q);
 }
 
 // The out-profile as a query (every column NOCODE with a vector, NJ.tcc:743-747).
@@ -107,7 +121,7 @@ template <typename REAL>
 struct SweepOut {
     REAL *dist, *weight, *crit;   // [maxNodes], indexed by target id; inactive targets hold the 1e20 sentinel
     REAL *partMin, *partMax;      // [gridDim.x] per-workgroup min / max criterion of the active targets, reduced
-                                  // by k_select_range: the sweep issues no global atomics at all
+                                  // by k_select_hist: the sweep issues no global atomics at all
 };
 
 // per-workgroup (min,max) of the criteria produced by this launch; every thread of the workgroup must call it
@@ -462,10 +476,15 @@ __device__ __forceinline__ void vft_leaf_table_wg(const Arena<REAL> &A, const Qu
     }
 }
 
-// A sweep is two launches: k_sweep_nt over every id that is not covered by a table workgroup (internal targets, all
-// targets of a leaf query, range remainders), then k_sweep_nt_table over s.nLeafWG spans of VFT_LEAF_SPAN leaves
-// (profile query only).  Separate kernels so that each gets its own register budget / occupancy: the first is
-// HBM-bound and wants loads in flight, the second LDS/VALU-bound.  part = index into the per-workgroup min/max.
+// A sweep covers its targets with two kinds of workgroups: "heavy" ones, a target per lane, over every id that is not covered by a
+// table workgroup (internal targets, all targets of a leaf query, range remainders) - HBM-bound, they want loads in flight - and
+// "table" ones over s.nLeafWG spans of VFT_LEAF_SPAN leaves (profile query only) - LDS / VALU-bound.  part = index into the
+// per-workgroup min/max: table workgroups [0, nLeafWG), heavy ones behind them.
+//   k_sweep_nt        heavy workgroups only (leaf queries; MODE_OUTDIST's first launch)
+//   k_sweep_nt_table  table workgroups only (MODE_OUTDIST's second launch)
+//   k_sweep_nt_both   a profile seed's criteria in ONE launch: every third of the first 3 * nLeafWG workgroups is a table workgroup, so
+//                     that the CUs hold both kinds side by side - the table walk (34 us on its own, bound by LDS reads) hides under
+//                     the stream of the internal targets (80 us on its own, bound by HBM) instead of following it
 template <typename REAL, int MODE>
 __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_table(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
     REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
@@ -473,14 +492,14 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_table(Arena<REAL> A, QueryB
     if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, (int) blockIdx.x);
 }
 
+// heavy workgroup number wg of a sweep (every thread of the workgroup must call)
 template <typename REAL, int MODE_>
-__global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
+__device__ __forceinline__ void vft_sweep_heavy_wg(const Arena<REAL> &A, const QueryBuf<REAL> &Q, const SweepArgs &s, const SweepOut<REAL> &O, int wg) {
     constexpr bool QLEAF = MODE_ == MODE_CRIT_LEAFQ;
     constexpr int MODE = QLEAF ? MODE_CRIT : MODE_;
     REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
     // highest ids first: the workgroups of internal targets (~10x the bytes of a leaf) start before the leaf ones,
     // which then fill the idle slots instead of running ahead of them
-    const int wg = (int) gridDim.x - 1 - (int) blockIdx.x;
     const int64_t j = s.heavyLo + (int64_t) wg * VFT_WG + threadIdx.x;
     const int lane = (int) (j & 63);
     const int64_t tile = j >> 6;
@@ -533,6 +552,31 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REA
         vft_sweep_finish<REAL, MODE>(A, s, O, j, dist, weight, s.queryIsLeaf && targetLeaf, cmin, cmax);
     }
     if (MODE == MODE_CRIT) vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, s.nLeafWG + wg);
+}
+
+template <typename REAL, int MODE_>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_nt(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
+    // highest ids first: the workgroups of internal targets (~10x the bytes of a leaf) start before the leaf ones,
+    // which then fill the idle slots instead of running ahead of them
+    vft_sweep_heavy_wg<REAL, MODE_>(A, Q, s, O, (int) gridDim.x - 1 - (int) blockIdx.x);
+}
+
+template <typename REAL>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_nt_both(Arena<REAL> A, QueryBuf<REAL> Q, SweepArgs s, SweepOut<REAL> O) {
+    const int b = (int) blockIdx.x, nT = s.nLeafWG, nHeavy = (int) gridDim.x - nT;
+    // block -> (kind, number): table workgroups at every third block while two heavy ones are there for each (else all of them first)
+    const bool spread = nHeavy >= 2 * nT;
+    const bool mixed = spread && b < 3 * nT;
+    const bool isTable = spread ? (mixed && b % 3 == 0) : b < nT;
+    if (isTable) {
+        const int t = spread ? b / 3 : b;
+        REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
+        vft_leaf_table_wg<REAL, MODE_CRIT>(A, Q, s, O, s.lo + (int64_t) t * VFT_LEAF_SPAN, cmin, cmax);
+        vft_block_minmax<REAL>(cmin, cmax, O.partMin, O.partMax, t);
+        return;
+    }
+    const int h = mixed ? b - b / 3 - 1 : b - nT;                      // heavy workgroups in launch order ...
+    vft_sweep_heavy_wg<REAL, MODE_CRIT>(A, Q, s, O, nHeavy - 1 - h);   // ... take the highest ids first, as in k_sweep_nt
 }
 
 // ------------------------------------------------------------------------------------------------ generic pair
@@ -1295,7 +1339,7 @@ struct SelectState {
     unsigned int nBelow;         // #values with a smaller digit than threshBin in this round
     unsigned int nThresh;        // #values in threshBin
     unsigned int nIn;            // #values below the prefix (already known to be among the k smallest)
-    unsigned int pad;
+    unsigned int rankDone;       // workgroups of k_select_rank that have stored their hits (the last one publishes)
 };
 
 // Everything one seed's selection works on.  The selection kernels take an array of these and pick theirs by
@@ -1324,43 +1368,6 @@ __device__ __forceinline__ unsigned int vft_level_shift(unsigned int level) {
     return (unsigned int) (VFT_VK_FRAC_BITS - VFT_DIGIT_BITS * (int) level);
 }
 
-// one workgroup: reduce the sweep's per-workgroup (min,max) criteria and set up round one
-template <typename REAL>
-__global__ __launch_bounds__(1024) void k_select_range(const SelSlot *slots) {
-    const SelSlot &sl = slots[blockIdx.y];
-    SelectState *S = sl.sel;
-    const REAL *partMin = (const REAL *) sl.partMin, *partMax = (const REAL *) sl.partMax;
-    const int nPart = sl.nPart;
-    __shared__ double smin[1024], smax[1024];
-    double cmin = 1e30, cmax = -1e30;
-    for (int t = threadIdx.x; t < nPart; t += 1024) {
-        const double a = (double) partMin[t], b = (double) partMax[t];
-        cmin = a < cmin ? a : cmin;
-        cmax = b > cmax ? b : cmax;
-    }
-    smin[threadIdx.x] = cmin;
-    smax[threadIdx.x] = cmax;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if ((int) threadIdx.x < off) {
-            if (smin[threadIdx.x + off] < smin[threadIdx.x]) smin[threadIdx.x] = smin[threadIdx.x + off];
-            if (smax[threadIdx.x + off] > smax[threadIdx.x]) smax[threadIdx.x] = smax[threadIdx.x + off];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double lo = smin[0], hi = smax[0];
-        const double span = hi > lo ? hi - lo : 1.0;
-        S->lo = lo;
-        S->scale = 1023.9990234375 * 1099511627776.0 / span;   // (1024 - 2^-10) * 2^40 / span: VK < 2^50
-        S->prefix = 0;
-        S->level = 0;
-        S->nCand = 0;
-        S->overflow = 0;
-        S->nIn = 0;
-    }
-}
-
 // refinement (rare): descend into the threshold digit
 __global__ void k_select_refine(const SelSlot *slots) {
     SelectState *S = slots[blockIdx.y].sel;
@@ -1369,21 +1376,77 @@ __global__ void k_select_refine(const SelSlot *slots) {
     S->level += 1;
     S->nCand = 0;
     S->overflow = 0;
+    S->rankDone = 0;
 }
 
-// VFT_SEL_WGS workgroups, each writes its own histogram slice (plain stores)
+// VFT_SEL_WGS workgroups, each writes its own histogram slice (plain stores).  first: round one - the key range comes from the
+// sweep's per-workgroup (min, max) criteria, which EVERY workgroup reduces for itself (min and max are exact: all of them arrive at the
+// same two numbers, a few microseconds of L2 reads side by side instead of a one-workgroup launch in front), and workgroup 0 sets the
+// selection's state up for the kernels that follow.
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_select_hist(const SelSlot *slots, int64_t lo, int64_t hi) {
+__global__ __launch_bounds__(VFT_WG) void k_select_hist(const SelSlot *slots, int64_t lo, int64_t hi, int first) {
     const SelSlot &sl = slots[blockIdx.y];
     const REAL *crit = (const REAL *) sl.crit;
-    const SelectState *S = sl.sel;
+    SelectState *S = sl.sel;
     unsigned int *slices = sl.slices;
-    __shared__ unsigned int lh[VFT_NBINS];
-    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) lh[t] = 0;
-    __syncthreads();
-    const double vlo = S->lo, scale = S->scale;
-    const unsigned long long prefix = S->prefix;
-    const unsigned int shift = vft_level_shift(S->level);
+    // four copies of the histogram, one per lane modulo 4: the criteria of a sweep crowd into a few digits, and LDS atomics of a
+    // wavefront on one address run one after the other
+    __shared__ unsigned int lh4[4][VFT_NBINS];
+    unsigned int *lh = lh4[threadIdx.x & 3];
+    __shared__ double smin[VFT_WG / 64], smax[VFT_WG / 64];
+    for (int t = threadIdx.x; t < 4 * VFT_NBINS; t += VFT_WG) lh4[0][t] = 0;
+    double vlo, scale;
+    unsigned long long prefix;
+    unsigned int level;
+    if (first) {
+        const REAL *partMin = (const REAL *) sl.partMin, *partMax = (const REAL *) sl.partMax;
+        double cmin = 1e30, cmax = -1e30;
+        for (int t = threadIdx.x; t < sl.nPart; t += VFT_WG) {
+            const double a = (double) partMin[t], b = (double) partMax[t];
+            cmin = a < cmin ? a : cmin;
+            cmax = b > cmax ? b : cmax;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double a = __shfl_xor(cmin, off, 64), b = __shfl_xor(cmax, off, 64);
+            cmin = a < cmin ? a : cmin;
+            cmax = b > cmax ? b : cmax;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            smin[threadIdx.x >> 6] = cmin;
+            smax[threadIdx.x >> 6] = cmax;
+        }
+        __syncthreads();
+        cmin = smin[0];
+        cmax = smax[0];
+#pragma unroll
+        for (int w = 1; w < VFT_WG / 64; w++) {
+            cmin = smin[w] < cmin ? smin[w] : cmin;
+            cmax = smax[w] > cmax ? smax[w] : cmax;
+        }
+        const double span = cmax > cmin ? cmax - cmin : 1.0;
+        vlo = cmin;
+        scale = 1023.9990234375 * 1099511627776.0 / span;   // (1024 - 2^-10) * 2^40 / span: VK < 2^50
+        prefix = 0;
+        level = 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            S->lo = vlo;
+            S->scale = scale;
+            S->prefix = 0;
+            S->level = 0;
+            S->nCand = 0;
+            S->overflow = 0;
+            S->nIn = 0;
+            S->rankDone = 0;
+        }
+    } else {
+        __syncthreads();
+        vlo = S->lo;
+        scale = S->scale;
+        prefix = S->prefix;
+        level = S->level;
+    }
+    const unsigned int shift = vft_level_shift(level);
     const int64_t stride = (int64_t) gridDim.x * VFT_WG;
     int64_t j = lo + (int64_t) blockIdx.x * VFT_WG + threadIdx.x;
     for (; j + 3 * stride < hi; j += 4 * stride) {   // four independent loads in flight per thread
@@ -1406,7 +1469,7 @@ __global__ __launch_bounds__(VFT_WG) void k_select_hist(const SelSlot *slots, in
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) slices[(int64_t) blockIdx.x * VFT_NBINS + t] = lh[t];
+    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) slices[(int64_t) blockIdx.x * VFT_NBINS + t] = lh4[0][t] + lh4[1][t] + lh4[2][t] + lh4[3][t];
 }
 
 // one workgroup of VFT_NBINS threads: column sums, scan, the digit that holds the need-th smallest value
@@ -1513,16 +1576,44 @@ struct SelectHeader {
     long long pad2;
 };
 
+// hit records cross workgroups inside k_select_rank: 8-byte agent-scope words (write-through stores, L1-bypassing loads)
+template <typename HIT>
+__device__ __forceinline__ void vft_hit_publish(HIT *dst, const HIT &h) {
+    static_assert(sizeof(HIT) % 8 == 0, "hit records are whole 8-byte words");
+    unsigned long long w[sizeof(HIT) / 8];
+    __builtin_memcpy(w, &h, sizeof(HIT));
+#pragma unroll
+    for (unsigned int t = 0; t < sizeof(HIT) / 8; t++)
+        __hip_atomic_store((unsigned long long *) dst + t, w[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename HIT>
+__device__ __forceinline__ HIT vft_hit_fetch(const HIT *src) {
+    unsigned long long w[sizeof(HIT) / 8];
+#pragma unroll
+    for (unsigned int t = 0; t < sizeof(HIT) / 8; t++)
+        w[t] = __hip_atomic_load((const unsigned long long *) src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    HIT h;
+    __builtin_memcpy(&h, w, sizeof(HIT));
+    return h;
+}
+
 // Rank sort of the candidates: a candidate's position in the (criterion asc, id desc) order is the number of
 // candidates that precede it.  n is a few thousand, so the n^2 comparisons are cheap when spread wide: 16 lanes
 // share one candidate (each scans 1/16 of the list, staged through LDS), partial ranks are summed with shuffles.
 // A single-workgroup bitonic sort of the same list takes ~50 us (80 barriers); this takes a few.
+// The LAST workgroup to finish (a counter in the selection's state) also finishes the selection: bestjoin
+// (NJ.tcc:3625-3637: strict '<' while scanning ids upwards => the smallest id among the minimal criteria, the query itself
+// excluded), header + hits into the host-mapped result block (the host gets its answer without a DMA copy: a 32 KB hipMemcpy
+// D2H goes through SDMA here and costs hundreds of microseconds of latency; zero-copy stores over PCIe cost a few) and the
+// completion word `seq` in the host header that vft_sweep(_batch) waits for - no kernel behind this one.  Hits travel
+// between the workgroups as write-through 8-byte words + a drained counter increment (no release fence: round 2 tried this
+// fold with fences - every workgroup's agent-scope release is an L2 write-back on this 8-XCD part - and the kernel doubled).
 #define VFT_RANK_TILE 2048
 #define VFT_RANK_LANES 16
 template <typename REAL, typename HIT>
-__global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, int32_t k) {
+__global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, int32_t k, int64_t lo, int64_t hi, long long seq) {
     const SelSlot &sl = slots[blockIdx.y];
-    const SelectState *S = sl.sel;
+    SelectState *S = sl.sel;
     const uint64_t *candKey = sl.candKey;
     const int32_t *candId = sl.candId;
     const REAL *dist = (const REAL *) sl.dist, *weight = (const REAL *) sl.weight, *crit = (const REAL *) sl.crit;
@@ -1531,7 +1622,8 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     __shared__ int32_t si[VFT_RANK_TILE];
     const unsigned int n = S->nCand < VFT_CAND_CAP ? S->nCand : VFT_CAND_CAP;
     const unsigned int perWg = VFT_WG / VFT_RANK_LANES;
-    if (blockIdx.x * perWg >= (n > (unsigned int) k ? n : (unsigned int) k)) return;   // whole workgroup idle
+    const unsigned int span = n > (unsigned int) k ? n : (unsigned int) k;
+    if (blockIdx.x * perWg >= span) return;   // whole workgroup idle (not counted below)
     const unsigned int cand = blockIdx.x * perWg + threadIdx.x / VFT_RANK_LANES;
     const unsigned int sub = threadIdx.x % VFT_RANK_LANES;
     const bool mine = cand < n;
@@ -1558,53 +1650,51 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     }
 #pragma unroll
     for (int off = VFT_RANK_LANES / 2; off > 0; off >>= 1) rank += __shfl_xor(rank, off, VFT_RANK_LANES);
-    if (sub != 0) return;
-    if (mine && rank < (unsigned int) k) {
-        HIT h;
-        h.j = myId;
-        h.dist = dist[myId];
-        h.weight = weight[myId];
-        h.criterion = crit[myId];
-        hits[rank] = h;
+    if (sub == 0) {
+        if (mine && rank < (unsigned int) k) {
+            HIT h;
+            h.j = myId;
+            h.dist = dist[myId];
+            h.weight = weight[myId];
+            h.criterion = crit[myId];
+            vft_hit_publish<HIT>(hits + rank, h);
+        }
+        if (cand >= n && cand < (unsigned int) k) {   // fewer candidates than requested: empty records
+            HIT h;
+            h.j = -1;
+            h.dist = (REAL) 1e20;
+            h.weight = 0;
+            h.criterion = (REAL) 1e20;
+            vft_hit_publish<HIT>(hits + cand, h);
+        }
     }
-    if (cand >= n && cand < (unsigned int) k) {   // fewer candidates than requested: empty records
-        HIT h;
-        h.j = -1;
-        h.dist = (REAL) 1e20;
-        h.weight = 0;
-        h.criterion = (REAL) 1e20;
-        hits[cand] = h;
+    // ---- the last workgroup to get here finishes the selection
+    __shared__ unsigned int sLast;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's records have left the chip's caches
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int active = (span + perWg - 1) / perWg;
+        sLast = __hip_atomic_fetch_add(&S->rankDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == active - 1 ? 1u : 0u;
     }
-}
-
-// (Folding bestjoin + publication + the completion flag into the last workgroup of the rank sort, and the min/max
-//  reduction into the histogram kernel, were both tried: on this multi-XCD part every workgroup's agent-scope release
-//  fence costs an L2 write-back - the rank kernel went from 15 to 31 us - while a kernel boundary does it once.)
-// bestjoin (NJ.tcc:3625-3637): strict '<' while scanning ids upwards => the smallest id among the minimal criteria,
-// the query itself excluded.  Also publishes header + hits into the host-mapped result block: the host gets its
-// answer with one stream synchronisation and no DMA copy (a 32 KB hipMemcpy D2H goes through SDMA here and costs
-// hundreds of microseconds of latency; zero-copy stores over PCIe cost a few).
-template <typename REAL, typename HIT>
-__global__ __launch_bounds__(VFT_WG) void k_select_best(const SelSlot *slots, int32_t k, int64_t lo, int64_t hi) {
-    const SelSlot &sl = slots[blockIdx.y];
-    const SelectState *S = sl.sel;
-    const HIT *hits = (const HIT *) sl.hits;
+    __syncthreads();
+    if (!sLast) return;
     const int64_t query = sl.query;
     SelectHeader *hdr = sl.hdr, *hostHdr = sl.hostHdr;
     HIT *hostHits = (HIT *) sl.hostHits;
     __shared__ long long sBest;
     __shared__ REAL sCrit;
     __shared__ int sTruncatedTie;
-    for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = hits[t];
+    for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = vft_hit_fetch<HIT>(hits + t);
     if (threadIdx.x == 0) {
-        const unsigned int n = S->nCand < (unsigned int) k ? S->nCand : (unsigned int) k;
+        const unsigned int nn = n < (unsigned int) k ? n : (unsigned int) k;
         long long best = -1;
         REAL bc = (REAL) 1e20;
         unsigned int t = 0;
-        for (; t < n; t++) {
-            const long long j = (long long) hits[t].j;
+        for (; t < nn; t++) {
+            const HIT h = vft_hit_fetch<HIT>(hits + t);
+            const long long j = (long long) h.j;
             if (j == query || j < 0) continue;
-            const REAL c = hits[t].criterion;
+            const REAL c = h.criterion;
             if (best < 0) {
                 if (!(c < (REAL) 1e20)) break;
                 best = j;
@@ -1619,18 +1709,21 @@ __global__ __launch_bounds__(VFT_WG) void k_select_best(const SelSlot *slots, in
         sCrit = bc;
         // the list ended inside the run of minimal criteria and was cut at k: ids below the cut (the order is id
         // descending within a tie) may tie as well
-        sTruncatedTie = (best >= 0 && t == n && n == (unsigned int) k) ? 1 : 0;
+        sTruncatedTie = (best >= 0 && t == nn && nn == (unsigned int) k) ? 1 : 0;
     }
     __syncthreads();
     if (sTruncatedTie) {   // rare: every listed hit ties at the minimum - scan the criteria themselves
-        const REAL *crit = (const REAL *) sl.crit;
         const REAL bc = sCrit;
-        long long mine = sBest;
+        long long mineJ = sBest;
         for (int64_t j = lo + threadIdx.x; j < hi; j += VFT_WG)
-            if (j != query && crit[j] == bc && j < mine) mine = j;
-        atomicMin((unsigned long long *) &sBest, (unsigned long long) mine);
-        __syncthreads();
+            if (j != query && crit[j] == bc && j < mineJ) mineJ = j;
+        atomicMin((unsigned long long *) &sBest, (unsigned long long) mineJ);
     }
+    // the host copies of the records must have LEFT the chip before the completion word moves (the explicit wait: see
+    // vft_publish_staged)
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x != 0) return;
     SelectHeader h;
     h.nCand = S->nCand;
@@ -1640,7 +1733,14 @@ __global__ __launch_bounds__(VFT_WG) void k_select_best(const SelSlot *slots, in
     h.bestJ = sBest;
     h.pad2 = 0;
     *hdr = h;
-    *hostHdr = h;
+    hostHdr->nCand = h.nCand;
+    hostHdr->overflow = h.overflow;
+    hostHdr->shift = h.shift;
+    hostHdr->pad = 0;
+    hostHdr->bestJ = h.bestJ;
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&hostHdr->pad2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Merge of per-shard hit lists (multi-GPU: each rank's sorted top-k, all-gathered): rank sort of the n = lists * k
