@@ -1230,6 +1230,8 @@ namespace veryfasttree {
         bool walkServer = true;      /* the walks' steps go to resident workgroups through a mailbox (vft_walk_server_start); false: the
                                         two plain calls per step (tests compare) */
         int64_t sprSteps = 0;        /* chain steps evaluated by the SPR rounds */
+        bool walkValueNumbers = true;   /* value numbers for the walks' rows: redundant averages and repeated quartets are not computed again
+                                           (false: every average is recorded, every quartet evaluated; tests compare) */
 
         const std::vector<int64_t> &children() const { return child; }
         const std::vector<int64_t> &parents() const { return parent; }
@@ -1466,6 +1468,8 @@ namespace veryfasttree {
         struct MeTicket {
             uint32_t ticket = 0;
             bool pending = false;
+            bool keyed = false;     /* key = the value numbers of the quartet's rows: the distances go to the memo table */
+            uint64_t key[4];
             REAL d[6];
         };
         void meSubmit(int64_t node, std::vector<char> &upHave, int64_t q[4], MeTicket &t) {
@@ -1478,6 +1482,18 @@ namespace veryfasttree {
             }
             const int64_t q4[4] = {q[0], q[1], q[2], idD};
             t.pending = false;
+            t.keyed = false;
+            if (vnActive) {   /* the same four values as an earlier quartet: its distances (see vnBegin) */
+                for (int i = 0; i < 4; i++) t.key[i] = verOf(q4[i]);
+                t.keyed = true;
+                const MemoEntry &m = memoTable[(size_t) (vnHash(vnHash(t.key[0], t.key[1]), vnHash(t.key[2], t.key[3])) & (memoTable.size() - 1))];
+                if (m.used && m.q[0] == t.key[0] && m.q[1] == t.key[1] && m.q[2] == t.key[2] && m.q[3] == t.key[3]) {
+                    for (int i = 0; i < 6; i++) t.d[i] = m.d[i];
+                    t.keyed = false;
+                    stepsMemoised++;
+                    return;
+                }
+            }
             schedule(q4, 4, false);   /* the recorded averages this quartet's rows depend on (see queueAverage) */
             sendLongHead(48);
             if (serverUp) {
@@ -1514,6 +1530,13 @@ namespace veryfasttree {
             if (t.pending) {
                 chk(vft_walk_collect(ctx, t.ticket, t.d));
                 t.pending = false;
+            }
+            if (t.keyed) {
+                MemoEntry &m = memoTable[(size_t) (vnHash(vnHash(t.key[0], t.key[1]), vnHash(t.key[2], t.key[3])) & (memoTable.size() - 1))];
+                for (int i = 0; i < 4; i++) m.q[i] = t.key[i];
+                for (int i = 0; i < 6; i++) m.d[i] = t.d[i];
+                m.used = true;
+                t.keyed = false;
             }
             double c[6];
             for (int i = 0; i < 6; i++) c[i] = logCorrect((double) t.d[i], scoredist);
@@ -1688,8 +1711,79 @@ namespace veryfasttree {
                 cur->lb.push_back(b);
                 return;
             }
+            if (vnActive) {
+                const uint64_t va = verOf(a), vb = verOf(b);
+                VnEntry &e = vnTable[(size_t) (vnHash(va, vb) & (vnTable.size() - 1))];
+                if (!(e.v != 0 && e.a == va && e.b == vb)) {
+                    e.a = va;
+                    e.b = vb;
+                    e.v = vnNext++;
+                }
+                if (verOf(out) == e.v) {   /* the row holds this very average already */
+                    avgRedundant++;
+                    return;
+                }
+                setVer(out, e.v);
+            }
             PendOp op = {out, a, b};
             pend.push_back(op);
+        }
+
+        /* VALUE NUMBERS for the rows of a host-driven walk.  Every row carries the number of the value it (logically) holds; an
+           average of two numbered values gets the number that the same two values got the last time they were averaged (a small
+           direct-mapped table; a miss hands out a fresh number, which is always safe).  Two consequences, both exact because the
+           device arithmetic is deterministic - equal numbers are equal bits:
+             * an average that would write the value its row already holds is not recorded at all - the unwinding of a rejected SPR
+               chain puts the tree back and recomputes the profiles around every undone step from the same children (NJ.tcc:1861-1879);
+             * a quartet whose four rows carry the numbers of an earlier evaluation takes that evaluation's six distances - the second
+               chain around a node (acFirst = 1) starts from the quartet the first one (acFirst = 0) started from, NJ.tcc:6240-6270 -
+               and no step goes to the device.
+           Numbers live for one walk (a WalkServerGuard): rows written by anything else have no number. */
+        struct VnEntry {
+            uint64_t a, b, v;
+        };
+        struct MemoEntry {
+            uint64_t q[4];
+            REAL d[6];
+            bool used;
+        };
+        std::vector<uint64_t> rowVer;
+        std::vector<uint32_t> rowVerEpoch;
+        std::vector<VnEntry> vnTable;
+        std::vector<MemoEntry> memoTable;
+        uint32_t vnEpoch = 0;
+        uint64_t vnNext = 0;
+        bool vnActive = false;
+        int64_t avgRedundant = 0, stepsMemoised = 0;   /* statistics */
+        static uint64_t vnHash(uint64_t x, uint64_t y) {
+            uint64_t h = x * 0x9E3779B97F4A7C15ull ^ (y + 0x7F4A7C159E3779B9ull + (x << 6) + (x >> 2));
+            h ^= h >> 29;
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 32;
+            return h;
+        }
+        void vnBegin() {
+            const size_t nIds = (size_t) (nNodes + nSeqs + 1);
+            if (rowVer.size() < nIds) {
+                rowVer.assign(nIds, 0);
+                rowVerEpoch.assign(nIds, 0);
+                vnTable.assign((size_t) 1 << 16, VnEntry{0, 0, 0});
+                memoTable.assign((size_t) 1 << 15, MemoEntry{{0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, false});
+                vnEpoch = 0;
+            }
+            if (++vnEpoch == 0) {
+                std::fill(rowVerEpoch.begin(), rowVerEpoch.end(), 0);
+                vnEpoch = 1;
+            }
+            for (VnEntry &e: vnTable) e.v = 0;
+            for (MemoEntry &e: memoTable) e.used = false;
+            vnNext = (uint64_t) nIds + 1;   /* numbers 1 ... nIds are the rows' own (the value a row held when the walk began) */
+            vnActive = true;
+        }
+        uint64_t verOf(int64_t row) const { return rowVerEpoch[(size_t) row] == vnEpoch ? rowVer[(size_t) row] : (uint64_t) row + 1; }
+        void setVer(int64_t row, uint64_t v) {
+            rowVer[(size_t) row] = v;
+            rowVerEpoch[(size_t) row] = vnEpoch;
         }
 
         /* The averages of a host-driven walk are evaluated LAZILY.  The reference recomputes profiles eagerly after every
@@ -1785,20 +1879,27 @@ namespace veryfasttree {
         struct WalkServerGuard {
             MLLengths &t;
             explicit WalkServerGuard(MLLengths &tree, bool enable = true) : t(tree) {
-                if (!enable || !t.walkServer || !t.walkStepFused || t.serverUp) return;
+                if (!enable) return;
                 t.flushAverages();
+                if (t.walkValueNumbers) t.vnBegin();
+                if (!t.walkServer || !t.walkStepFused || t.serverUp) return;
                 const int rc = vft_walk_server_start(t.ctx);
                 if (rc == VFT_OK) t.serverUp = true;
                 else if (rc != VFT_ERR_STATE) t.chk(rc);
             }
             void finish() {
                 t.flushAverages();
+                t.vnActive = false;
+                if (std::getenv("VFT_WALK_STATS"))
+                    fprintf(stderr, "walk: %lld averages run, %lld dropped unread, %lld redundant (same value), %lld steps from the memo table\n",
+                            (long long) (t.avgQueued - t.avgDropped), (long long) t.avgDropped, (long long) t.avgRedundant, (long long) t.stepsMemoised);
                 if (t.serverUp) {
                     t.serverUp = false;
                     t.chk(vft_walk_server_stop(t.ctx));
                 }
             }
             ~WalkServerGuard() {
+                t.vnActive = false;
                 if (t.serverUp) {
                     t.serverUp = false;
                     (void) vft_walk_server_stop(t.ctx);
