@@ -276,7 +276,7 @@ E2E_FULL = {
 }
 
 
-def end_to_end_full(which, device, one_thread):
+def end_to_end_full(which, device, one_thread, comm=None):
     """Wall-clock to the final tree of BASELINE config C2 (10 000 nt x 1 000, `-nt -gtr`, float32) or C5 (50 000 aa x 300, `-lg`, float64):
     everything `VeryFastTree <flags>` does, supports included.  one_thread: the reference's one-thread order (its deterministic path;
     C2's tree is compared with tests/golden/bb_c2_crc.npz, the reference binary's own output); otherwise the schedule of a T-thread
@@ -295,6 +295,9 @@ def end_to_end_full(which, device, one_thread):
         kw["aa_model"] = cfg["aa"]
     if cfg["gtr"]:
         kw["gtr"] = True
+    if comm is not None:   # sharded: the NJ sweeps and the lanes of the subtree schedule are split over the ranks
+        kw["comm"] = comm
+        comm.calls = comm.bytes = comm.device_calls = comm.device_bytes = 0
     t0 = time.perf_counter()
     tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, cfg["nc"], dt, max_nodes=3 * m, device=device), codes, names, **kw)
     wall = time.perf_counter() - t0
@@ -302,11 +305,26 @@ def end_to_end_full(which, device, one_thread):
                reference_flags=cfg["flags"] + " -threads %d" % T, schedule_threads=T, dtype=cfg["dtype"], wall_s=round(wall, 2),
                tree_loglk=[round(float(x), 4) for x in loglk], newick_bytes=len(tree), newick_crc=zlib.crc32(tree.encode()),
                stages_s=last_stage_seconds())
+    if comm is not None:
+        from veryfasttree_amd.backend import last_lane_exchange
+        lane_calls, lane_bytes = last_lane_exchange()
+        out["allgathers"] = int(comm.calls)
+        out["allgather_bytes_by_phase"] = {"sweep_lists_device": int(comm.device_bytes), "ml_lanes": int(lane_bytes),
+                                           "other_host": int(comm.bytes - comm.device_bytes - lane_bytes)}
+        out["ml_lane_allgathers"] = int(lane_calls)
+    # the compiled reference with the same flags on the host cores of a GPU box of this pool (tools/reference_walls.py; not this run's box)
+    walls = os.path.join(ROOT, "profiles", "r05_reference_walls_gpu_box.json")
+    if os.path.exists(walls):
+        w = json.load(open(walls))
+        rec = w.get("%s_threads_%d" % (which, T))
+        if rec:
+            out["reference_on_gpu_box_host"] = dict(wall_s=rec["wall_s"], threads=T, cpu=w.get("cpu"), cores=w.get("cores"),
+                                                    same_tree_as_this_run=bool(rec.get("newick_crc") == out["newick_crc"]))
     if one_thread and cfg["golden"] and os.path.exists(os.path.join(ROOT, "tests", "golden", cfg["golden"])):
         g = np.load(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
         out["reference_newick_crc"] = int(g["newick_crc"])
         out["identical_to_reference"] = bool(int(g["newick_crc"]) == out["newick_crc"])
-        out["reference_wall_s_1_thread"] = round(float(g["reference_wall_s"]), 1)
+        out["reference_wall_s_1_thread_build_container"] = round(float(g["reference_wall_s"]), 1)
         want = g["loglk"]
         if len(want) and len(loglk):
             out["final_loglk_rel_diff"] = float(abs(loglk[-1] - want[-1]) / abs(want[-1]))
@@ -582,6 +600,22 @@ def main():
                     line[key] = end_to_end_full(which, local_rank, one)
                 except Exception as exc:
                     line[key] = {"workload": which, "error": repr(exc)}
+        if not args.no_e2e_full and use_dist:
+            # sharded: config C2's complete pipeline on the 64-thread schedule with the lanes split over the ranks (host/MLLengths.h
+            # "lanes across ranks"); every rank runs it, the slowest rank's wall-clock counts
+            try:
+                leg = end_to_end_full("c2", local_rank, False, comm)
+            except Exception as exc:
+                print("bench.py: rank %d failed in the sharded complete pipeline (%r); ending the job" % (rank, exc), file=sys.stderr, flush=True)
+                os._exit(18)
+            gdev = "cuda" if backend == "nccl" else "cpu"
+            w = torch.tensor([float(leg["wall_s"])], dtype=torch.float64, device=gdev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            c2 = torch.tensor([float(leg["newick_crc"]), -float(leg["newick_crc"])], dtype=torch.float64, device=gdev)
+            dist.all_reduce(c2, op=dist.ReduceOp.MAX)
+            leg["wall_s"] = round(float(w.item()), 2)
+            leg["same_crc_on_all_ranks"] = bool(c2[0].item() == -c2[1].item())
+            line["e2e_c2_threads"] = leg
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

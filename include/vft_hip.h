@@ -375,6 +375,11 @@ int vft_get_max_nodes(vft_ctx *ctx, int64_t *max_nodes);
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */
 int vft_branch_lengths_set(vft_ctx *ctx, int64_t first, int64_t count, const void *values);
 int vft_branch_lengths_get(vft_ctx *ctx, int64_t first, int64_t count, void *values);
+/* the same by index list: values[k] = branchlength[idx[k]] (gather; waits) / branchlength[idx[k]] = values[k] (scatter; stream-ordered);
+   n <= 65536.  With several ranks the lanes of the subtree schedule exchange the lengths each rank's share of a batch optimised
+   (host/MLLengths.h). */
+int vft_branch_lengths_gather(vft_ctx *ctx, int64_t n, const int64_t *idx, void *values);
+int vft_branch_lengths_scatter(vft_ctx *ctx, int64_t n, const int64_t *idx, const void *values);
 /* vft_posterior_profiles with len1[k] = branchlength[len_idx_a[k]], len2[k] = branchlength[len_idx_b[k]] read on the
    device at execution time.  Stream-ordered (does not wait): recomputeMLProfiles' levels and the up-profiles of
    getUpProfile(useML = true) (NJ.tcc:3382-3434) queue behind the optimiser launches that produce their lengths. */

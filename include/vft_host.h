@@ -154,6 +154,13 @@ int vft_tree_partitioning(int64_t n_nodes, const int64_t *child, int64_t root, i
    the ML NNI rounds, the SH-like supports, the model fits (CAT rates, GTR).  counts[4]: lockstep steps of the subtree schedule
    (opt.threads > 1) and the quartets / splits judged in them, SPR chain steps evaluated, SPR moves made.  Either may be NULL. */
 int vft_nj_last_stage_seconds(double *seconds, int64_t *counts);
+/* out[2]: with a vft_comm of several ranks, what the lanes of the subtree schedule exchanged during the last tree of this process - the
+   number of all-gathers (one per lockstep step with a batch to judge) and the bytes this rank received in them */
+int vft_nj_last_lane_exchange(int64_t *out);
+/* the layout of that exchange (host/MLLengths.h laneShare / laneRecord), exported for the CPU test that runs it over gloo: out[0] = the
+   padded share every rank sends, out[1], out[2] = rank `rank`'s items [k0, k1) of n_items, out[3] = where item `item` sits in the gathered
+   buffer (in records) */
+int vft_nj_lane_share(int64_t n_items, int32_t world, int32_t rank, int64_t item, int64_t *out);
 
 /* out[3]: what `-gamma` (vft_nj_options.gamma) found for the last tree of this process - the Gamma(nCat) log-likelihood, the shape
    alpha, the factor every branch length was multiplied by (the reference's "Gamma(20) LogLk = .. alpha = .. rescaling lengths by ..") */

@@ -114,3 +114,28 @@ def test_spr_walk_without_the_walk_server_gives_the_reference_tree(name, dt, aa)
     st = last_stage_seconds()
     assert st["spr_steps"] > 0
     assert tree == bytes(d["newick"]).decode().strip()
+
+
+@pytest.mark.parametrize("name", ["thr_full_nt_1500_t32", "thr_menni_nt_400_t4", "thr_mllen_nt_300_t4"])
+def test_lanes_across_two_ranks_give_the_single_rank_tree(name):
+    """The lanes of the subtree schedule split over two ranks (host/MLLengths.h "lanes across ranks": every rank judges its share of a
+    lockstep step's quartets / splits / distances, the verdicts and the branch lengths the kernels wrote are all-gathered, the others'
+    lengths scattered; both ranks on this box's one GPU, gloo): every rank must print the reference's tree at T threads - the tree of
+    the single-rank run - byte for byte, and the exchange must really have run."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "run_pipeline_ranks.py")
+    d = G.load(name)
+    ref = bytes(d["newick"]).decode().strip()
+    env = dict(os.environ, VFT_SAME_DEVICE="1", VFT_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29547", script, name], check=True, stdout=subprocess.PIPE, env=env,
+                         timeout=900).stdout.decode()
+    got = re.findall(r"rank (\d) crc (\d+) bytes (\d+) lane_allgathers (\d+) lane_bytes (\d+)", two)
+    assert len(got) == 2, two
+    for r, crc, nb, calls, nbytes in got:
+        assert (int(crc), int(nb)) == (zlib.crc32(ref.encode()), len(ref)), (r, crc, nb)
+        assert int(calls) > 10 and int(nbytes) > 1000          # the exchange really ran

@@ -198,3 +198,49 @@ def test_nj_driver_join_order_does_not_depend_on_the_rank_count(tmp_path):
     want = G.load("bb_nt_200")["joins"]
     for r in range(2):
         assert np.array_equal(np.load(out % r), want)
+
+
+def _lane_worker(rank, world, port, out):
+    """The lanes-across-ranks exchange of host/MLLengths.h over gloo, with the C++ layout functions themselves (vft_nj_lane_share): a
+    batch of K verdict records, every rank fills in its share [k0, k1), sends its padded share, and finds item t of the batch at record
+    laneRecord(t, per) of what it received."""
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from veryfasttree_amd.backend import load_host_library
+    lib = load_host_library()
+    rec = 32 + 5 * 4   # a vft_quartet_nni + five float lengths, as runNNILanes packs them
+    ok = True
+    for K in (1, 2, 3, 5, 64, 65, 513):
+        o = np.zeros(4, np.int64)
+        assert lib.vft_nj_lane_share(C.c_int64(K), C.c_int32(world), C.c_int32(rank), C.c_int64(0), o.ctypes.data_as(C.c_void_p)) == 0
+        per, k0, k1 = int(o[0]), int(o[1]), int(o[2])
+        truth = np.arange(K * rec, dtype=np.int64).astype(np.uint8).reshape(K, rec) ^ np.uint8(K & 0xFF)   # the record every rank would compute for item t
+        send = np.zeros((per, rec), np.uint8)
+        send[:k1 - k0] = truth[k0:k1]
+        t_all = torch.zeros(world * per * rec, dtype=torch.uint8)
+        dist.all_gather_into_tensor(t_all, torch.from_numpy(send.reshape(-1).copy()))
+        got = t_all.numpy().reshape(world * per, rec)
+        covered = np.zeros(K, bool)
+        for r in range(world):   # the shares tile the batch
+            assert lib.vft_nj_lane_share(C.c_int64(K), C.c_int32(world), C.c_int32(r), C.c_int64(0), o.ctypes.data_as(C.c_void_p)) == 0
+            assert int(o[0]) == per and 0 <= o[1] <= o[2] <= K
+            covered[int(o[1]):int(o[2])] = True
+        ok &= bool(covered.all())
+        for t in range(K):
+            assert lib.vft_nj_lane_share(C.c_int64(K), C.c_int32(world), C.c_int32(rank), C.c_int64(t), o.ctypes.data_as(C.c_void_p)) == 0
+            ok &= bool(np.array_equal(got[int(o[3])], truth[t]))
+    if rank == 0:
+        np.save(out, np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lane_exchange_layout_over_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "lanes.npy")
+    mp.spawn(_lane_worker, args=(2, port, out), nprocs=2, join=True)
+    assert bool(np.load(out)[0])

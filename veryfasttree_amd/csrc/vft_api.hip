@@ -1490,12 +1490,6 @@ extern "C" int vft_walk_step(vft_ctx *c, int32_t n, const int64_t *out, const in
     return vft_walk_collect(c, ticket, dist);
 }
 
-#ifdef VFT_WALK_TIMING   // tools-only build (tools/walk_ticks.py): never in the product library
-extern "C" int vft_walk_ticks(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vftWalkTicks), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
-}
-#endif
-
 // differ[k] = 1 when the profiles of nodes a[k] and b[k] (rows or tile streams, internal or leaf) are not bit-identical.  Waits.
 extern "C" int vft_profiles_differ(vft_ctx *c, int64_t n, const int64_t *a, const int64_t *b, int32_t *differ) {
     if (!c || n < 0 || !a || !b || !differ) return VFT_ERR_INVALID;
@@ -3256,6 +3250,23 @@ extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int
     for (int64_t k = 0; k < n; k++)
         if (a[k] < 0 || a[k] >= c->d.maxNodes || b[k] < 0 || b[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_pair_loglk: pair %lld out of range", (long long) k);
     const size_t idB = (size_t) n * 8, sB = siteLk ? (size_t) n * c->d.nPos * 8 : 0;
+    if (4 * idB <= 2 * VFT_SMALL_BYTES && !siteLk) {
+        // a batch of a few thousand pairs (treeLogLk of a 10 000-taxon tree, the per-operator tables): ids and lengths travel through
+        // the host-mapped ring and the totals come back through it - three staged copies, a DMA read-back and a stream
+        // synchronisation were 80 of the call's 130 us at 8 192 pairs
+        char *h, *d;
+        if (int r = io_alloc(c, 4 * idB, &h, &d)) return r;
+        memcpy(h, a, idB);
+        memcpy(h + idB, b, idB);
+        memcpy(h + 2 * idB, length, idB);
+        VFT_DISPATCH(c, (launch((k_pair_loglk<REAL, NC>), dim3((unsigned) n), dim3(VFT_ML_WG), 0, c->stream,
+                                            arena<REAL>(c), (const int64_t *) d, (const int64_t *) (d + idB),
+                                            (const double *) (d + 2 * idB), n, c->minRel, (double *) (d + 3 * idB), (double *) nullptr)));
+        LAUNCHCHK(c);
+        if (int r = wait_stream(c)) return r;
+        memcpy(loglk, h + 3 * idB, idB);
+        return VFT_OK;
+    }
     if (int r = ensure_scratch(c, 4 * idB + sB + 64)) return r;
     char *s = (char *) c->scratch;
     HIPCHK(c, hipMemcpyAsync(s, a, idB, hipMemcpyHostToDevice, c->stream));
@@ -3289,11 +3300,24 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
     char *s = (char *) c->scratch;
     char *base = s + 5 * idB;
     base += (256 - ((uintptr_t) base & 255)) & 255;
+    const bool viaRing = 5 * idB <= 2 * VFT_SMALL_BYTES;   // (five staged copies cost more than the kernel at a few thousand nodes)
+    if (viaRing) {
+        char *h, *d;
+        if (int r = io_alloc(c, 5 * idB, &h, &d)) return r;
+        memcpy(h, out, idB);
+        memcpy(h + idB, a, idB);
+        memcpy(h + 2 * idB, b, idB);
+        memcpy(h + 3 * idB, len1, idB);
+        memcpy(h + 4 * idB, len2, idB);
+        launch(k_copy16x2, dim3(cdiv((int64_t) (5 * idB + 15) / 16, 256)), dim3(256), 0, c->stream, (uint4 *) s, (const uint4 *) d, (int64_t) (5 * idB + 15) / 16,
+               (uint4 *) nullptr, (const uint4 *) nullptr, (int64_t) 0);
+    } else {
     HIPCHK(c, hipMemcpyAsync(s, out, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + idB, a, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 2 * idB, b, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 3 * idB, len1, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 4 * idB, len2, idB, hipMemcpyHostToDevice, c->stream));
+    }
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
         VFT_DISPATCH(c, {
@@ -3306,6 +3330,7 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
         LAUNCHCHK(c);
         if (int r = commit_nodes(c, plan, out + k0, (const int64_t *) s + k0, cnt, base)) return r;
     }
+    if (viaRing) return wait_stream(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
 }
@@ -3334,6 +3359,48 @@ extern "C" int vft_branch_lengths_get(vft_ctx *c, int64_t first, int64_t count, 
     HIPCHK(c, hipMemcpyAsync(values, (char *) c->blen + (size_t) first * c->rs, (size_t) count * c->rs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VFT_OK;
+}
+
+// branchlength[] entries by index list, through the host-mapped ring (the lanes of the subtree schedule exchange the lengths their
+// rank's share of a batch optimised, host/MLLengths.h "lanes across ranks")
+template <typename REAL>
+__global__ void k_blen_gather(const REAL *blen, const int64_t *idx, REAL *out, int64_t n) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = blen[idx[k]];
+}
+template <typename REAL>
+__global__ void k_blen_scatter(REAL *blen, const int64_t *idx, const REAL *in, int64_t n) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) blen[idx[k]] = in[k];
+}
+static int blen_indexed(vft_ctx *c, int64_t n, const int64_t *idx, void *values, bool gather) {
+    if (!c || n < 0 || (n > 0 && (!idx || !values))) return VFT_ERR_INVALID;
+    if (n == 0) return VFT_OK;
+    if (n > 65536) return fail(c, VFT_ERR_INVALID, "vft_branch_lengths_%s: at most 65536 entries per call", gather ? "gather" : "scatter");
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= c->d.maxNodes) return fail(c, VFT_ERR_INVALID, "vft_branch_lengths_%s: index out of range", gather ? "gather" : "scatter");
+    if (int r = ensure_blen(c)) return r;
+    const size_t ib = ((size_t) n * 8 + 255) & ~(size_t) 255, vb = ((size_t) n * c->rs + 255) & ~(size_t) 255;
+    char *h, *d;
+    if (int r = io_alloc(c, ib + vb, &h, &d)) return r;
+    memcpy(h, idx, (size_t) n * 8);
+    if (!gather) memcpy(h + ib, values, (size_t) n * c->rs);
+    if (c->cfg.precision == 4) {
+        if (gather) launch((k_blen_gather<float>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float *) c->blen, (const int64_t *) d, (float *) (d + ib), n);
+        else launch((k_blen_scatter<float>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (float *) c->blen, (const int64_t *) d, (const float *) (d + ib), n);
+    } else {
+        if (gather) launch((k_blen_gather<double>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const double *) c->blen, (const int64_t *) d, (double *) (d + ib), n);
+        else launch((k_blen_scatter<double>), dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (double *) c->blen, (const int64_t *) d, (const double *) (d + ib), n);
+    }
+    LAUNCHCHK(c);
+    if (!gather) return VFT_OK;   // stream-ordered: the kernels that read the lengths queue behind it
+    if (int r = wait_stream(c)) return r;
+    memcpy(values, h + ib, (size_t) n * c->rs);
+    return VFT_OK;
+}
+extern "C" int vft_branch_lengths_gather(vft_ctx *c, int64_t n, const int64_t *idx, void *values) { return blen_indexed(c, n, idx, values, true); }
+extern "C" int vft_branch_lengths_scatter(vft_ctx *c, int64_t n, const int64_t *idx, const void *values) {
+    return blen_indexed(c, n, idx, const_cast<void *>(values), false);
 }
 
 template <typename REAL>

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "../../include/vft_hip.h"
+#include "../../include/vft_host.h"
 #include "GtrModel.h"
 
 namespace veryfasttree {
@@ -693,6 +695,36 @@ namespace veryfasttree {
             return nNNIThisRound;
         }
 
+        /* ---- lanes across ranks (include/vft_host.h, vft_comm; SURVEY 8e "ML phase").  Every rank runs the same walks on the same
+           tree and keeps the whole device state; what is split is the expensive part of a lockstep step - the batch of quartets to
+           judge (vft_ml_quartet_nni_flags: five Brent searches per pairing), of splits to optimise (vft_ml_optimize_splits), of
+           minimum-evolution distances.  Rank r evaluates items [r * per, (r + 1) * per) of the batch, the ranks all-gather the
+           verdicts together with the branch lengths the kernels wrote (the only device state a verdict kernel changes; the
+           splits' kernel also rewrites its node's profile, which the other ranks redo with the gathered lengths), and scatter the
+           others' lengths into their own branchlength[].  The same kernels judge the same inputs, whoever runs them: the tree is the
+           single-rank tree byte for byte (tests/test_gpu_threads.py).  One all-gather of a few hundred bytes per item and step. */
+        const vft_comm *comm = nullptr;
+        int64_t laneGathers = 0, laneGatherBytes = 0;
+        bool sharded() const { return comm != nullptr && comm->world > 1; }
+        /* rank r's share [k0, k1) of a batch of K items over W ranks, and the padded share `per` every rank sends; item t of the batch
+           is record laneRecord(t, per) of the gathered buffer (exported as vft_nj_lane_share for the CPU test of the exchange layout) */
+        static void laneShare(size_t K, size_t W, size_t r, size_t &per, size_t &k0, size_t &k1) {
+            per = (K + W - 1) / W;
+            k0 = std::min(K, r * per);
+            k1 = std::min(K, k0 + per);
+        }
+        static size_t laneRecord(size_t t, size_t per) { return (t / per) * per + t % per; }
+        void shareOf(size_t K, size_t &per, size_t &k0, size_t &k1) const { laneShare(K, (size_t) comm->world, (size_t) comm->rank, per, k0, k1); }
+        /* all-gather `per` records of `rec` bytes per rank: send = this rank's records (h_send), received in rank order (h_recv) */
+        const char *gatherRecords(size_t per, size_t rec) {
+            const int64_t bytes = (int64_t) (per * rec);
+            if (bytes > comm->h_cap) throw std::invalid_argument("MLLengths: vft_comm host buffers too small for a batch of lanes");
+            if (comm->allgather(comm->user, bytes, 0) != 0) throw std::runtime_error("MLLengths: all-gather of the lanes' verdicts failed");
+            laneGathers++;
+            laneGatherBytes += bytes * (int64_t) comm->world;
+            return (const char *) comm->h_recv;
+        }
+
         /* traverseNNI (NJ.tcc:5797-5990) for a set of independent walks in lockstep: every lane advances to its next
            quartet, the queued profile work of all lanes goes down as one launch, all quartets are judged in one batch, every
            lane applies its verdict - the statements are doNNI's, the evaluation is deferred */
@@ -726,10 +758,39 @@ namespace veryfasttree {
                         std::copy(l5, l5 + 5, li.begin() + (long) (5 * t));
                     }
                     const size_t maxBatch = 512;
-                    for (size_t k0 = 0; k0 < K; k0 += maxBatch) {
-                        const size_t cnt = std::min(maxBatch, K - k0);
+                    size_t per = K, m0 = 0, m1 = K;
+                    if (sharded()) shareOf(K, per, m0, m1);
+                    for (size_t k0 = m0; k0 < m1; k0 += maxBatch) {
+                        const size_t cnt = std::min(maxBatch, m1 - k0);
                         chk(vft_ml_quartet_nni_flags(ctx, (int64_t) cnt, ids.data() + 4 * k0, li.data() + 5 * k0, prm.ftol, prm.atol, /*closeLogLkLimit*/5.0,
                                                      prm.mlAccuracy, starTest ? 0 : VFT_QUARTET_NO_STAR_TEST, res.data() + k0));
+                    }
+                    if (sharded()) {   /* verdicts + the five lengths each verdict kernel wrote: gathered, the others' lengths scattered */
+                        const size_t rec = sizeof(vft_quartet_nni) + 5 * sizeof(REAL);
+                        std::vector<REAL> mine(5 * (m1 - m0));
+                        chk(vft_branch_lengths_gather(ctx, (int64_t) mine.size(), li.data() + 5 * m0, mine.data()));
+                        char *snd = (char *) comm->h_send;
+                        if ((int64_t) (per * rec) > comm->h_cap) throw std::invalid_argument("MLLengths: vft_comm host buffers too small for a batch of lanes");
+                        for (size_t t = m0; t < m1; t++) {
+                            std::memcpy(snd + (t - m0) * rec, &res[t], sizeof(vft_quartet_nni));
+                            std::memcpy(snd + (t - m0) * rec + sizeof(vft_quartet_nni), &mine[5 * (t - m0)], 5 * sizeof(REAL));
+                        }
+                        const char *rcv = gatherRecords(per, rec);
+                        std::vector<int64_t> si;
+                        std::vector<REAL> sv;
+                        for (size_t t = 0; t < K; t++) {
+                            if (t >= m0 && t < m1) continue;
+                            const char *src = rcv + laneRecord(t, per) * rec;
+                            std::memcpy(&res[t], src, sizeof(vft_quartet_nni));
+                            REAL five[5];
+                            std::memcpy(five, src + sizeof(vft_quartet_nni), sizeof(five));
+                            for (int j = 0; j < 5; j++) {
+                                si.push_back(li[5 * t + (size_t) j]);
+                                sv.push_back(five[j]);
+                            }
+                        }
+                        for (size_t f = 0; f < si.size(); f += 65536)
+                            chk(vft_branch_lengths_scatter(ctx, (int64_t) std::min<size_t>(65536, si.size() - f), si.data() + f, sv.data() + f));
                     }
                 } else {
                     pi.resize(6 * K);
@@ -742,6 +803,17 @@ namespace veryfasttree {
                         std::copy(a, a + 6, pi.begin() + (long) (6 * t));
                         std::copy(b, b + 6, pj.begin() + (long) (6 * t));
                     }
+                    if (sharded()) {   /* six distances per quartet: this rank's share computed, all shares gathered */
+                        size_t per, m0, m1;
+                        shareOf(K, per, m0, m1);
+                        if (m1 > m0) chk(vft_profile_distances(ctx, (int64_t) (6 * (m1 - m0)), pi.data() + 6 * m0, pj.data() + 6 * m0, d.data() + 6 * m0, w.data() + 6 * m0));
+                        const size_t rec = 6 * sizeof(REAL);
+                        if ((int64_t) (per * rec) > comm->h_cap) throw std::invalid_argument("MLLengths: vft_comm host buffers too small for a batch of lanes");
+                        std::memcpy(comm->h_send, d.data() + 6 * m0, (m1 - m0) * rec);
+                        const char *rcv = gatherRecords(per, rec);
+                        for (size_t t = 0; t < K; t++)
+                            if (t < m0 || t >= m1) std::memcpy(&d[6 * t], rcv + laneRecord(t, per) * rec, rec);
+                    } else
                     chk(vft_profile_distances(ctx, (int64_t) (6 * K), pi.data(), pj.data(), d.data(), w.data()));
                 }
                 for (size_t t = 0; t < K; t++) {
@@ -1211,10 +1283,42 @@ namespace veryfasttree {
                 }
                 runShared(true);
                 runChains(lanes, true);
-                const size_t maxBatch = 2048;
-                for (size_t k0 = 0; k0 < rec.size(); k0 += maxBatch) {
-                    const size_t cnt = std::min(maxBatch, rec.size() - k0);
+                const size_t maxBatch = 2048, K = rec.size();
+                size_t per = K, m0 = 0, m1 = K;
+                if (sharded()) shareOf(K, per, m0, m1);
+                for (size_t k0 = m0; k0 < m1; k0 += maxBatch) {
+                    const size_t cnt = std::min(maxBatch, m1 - k0);
                     chk(vft_ml_optimize_splits(ctx, (int64_t) cnt, ids.data() + 3 * k0, li.data() + 3 * k0, rec.data() + k0, ftol, atol));
+                }
+                if (sharded() && K > 0) {
+                    /* the three lengths of every split: gathered, the others' scattered; the splits' kernel also leaves its node's
+                       profile recomputed from the two lengths below it (k_ml_node_lengths' tail) - the same posterior, here for the
+                       splits the other ranks optimised */
+                    const size_t recB = 3 * sizeof(REAL);
+                    std::vector<REAL> mine(3 * (m1 - m0));
+                    chk(vft_branch_lengths_gather(ctx, (int64_t) mine.size(), li.data() + 3 * m0, mine.data()));
+                    if ((int64_t) (per * recB) > comm->h_cap) throw std::invalid_argument("MLLengths: vft_comm host buffers too small for a batch of lanes");
+                    std::memcpy(comm->h_send, mine.data(), mine.size() * sizeof(REAL));
+                    const char *rcv = gatherRecords(per, recB);
+                    std::vector<int64_t> si, po, pa, pb, pla, plb;
+                    std::vector<REAL> sv;
+                    for (size_t t = 0; t < K; t++) {
+                        if (t >= m0 && t < m1) continue;
+                        REAL three[3];
+                        std::memcpy(three, rcv + laneRecord(t, per) * recB, sizeof(three));
+                        for (int j = 0; j < 3; j++) {
+                            si.push_back(li[3 * t + (size_t) j]);
+                            sv.push_back(three[j]);
+                        }
+                        po.push_back(rec[t]);
+                        pa.push_back(ids[3 * t]);
+                        pb.push_back(ids[3 * t + 1]);
+                        pla.push_back(li[3 * t]);
+                        plb.push_back(li[3 * t + 1]);
+                    }
+                    for (size_t f = 0; f < si.size(); f += 65535)
+                        chk(vft_branch_lengths_scatter(ctx, (int64_t) std::min<size_t>(65535, si.size() - f), si.data() + f, sv.data() + f));
+                    if (!po.empty()) chk(vft_posterior_profiles_blen(ctx, (int64_t) po.size(), po.data(), pa.data(), pb.data(), pla.data(), plb.data()));
                 }
                 laneSteps++;
                 laneWork += (int64_t) rec.size();

@@ -726,6 +726,7 @@ namespace veryfasttree {
             treeArrays(par, ch);
             MLLengths<REAL> tree(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             tree.walkServer = opt.walkServer;
+            tree.comm = opt.comm;
             typename MLLengths<REAL>::NNIParams prm;
             prm.useML = false;
             prm.scoredist = opt.scoredist;
@@ -765,11 +766,14 @@ namespace veryfasttree {
                 sprRemaining--;
             }
             meSPRSteps = tree.sprSteps;
+            laneGathers += tree.laneGathers;
+            laneGatherBytes += tree.laneGatherBytes;
             adoptTree(tree.parents(), tree.children());
             return total;
         }
 
         int64_t meSPRs = 0, meSPRSteps = 0;
+        int64_t laneGathers = 0, laneGatherBytes = 0;   /* lanes across ranks: all-gathers of verdicts + lengths, bytes received */
         double meSPRSeconds = 0, mlNNISeconds = 0, mlSupportSeconds = 0, mlModelSeconds = 0;   /* stage timers (vft_nj_last_stage_seconds) */
         int64_t meNNIRoundsDone = 0;
 
@@ -802,6 +806,7 @@ namespace veryfasttree {
             }
             mlNNISeconds = mlSupportSeconds = mlModelSeconds = 0;
             MLLengths<REAL> ml(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
+            ml.comm = opt.comm;
             upReady = false;   /* the up-profile slots now hold ML up-profiles */
             ml.setLengths(branchlength.data());
             /* recomputeProfiles(tmatAsDist) (VeryFastTreeImpl.tcc:253-256): plain re-averaging under Jukes-Cantor - the
@@ -913,6 +918,8 @@ namespace veryfasttree {
             mlEvaluations = ml.evaluations();
             mlLaneSteps = ml.laneSteps;
             mlLaneWork = ml.laneWork;
+            laneGathers += ml.laneGathers;
+            laneGatherBytes += ml.laneGatherBytes;
             return loglk;
         }
 

@@ -67,6 +67,7 @@ extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *
 /* wall-clock of the stages of the last vft_nj_newick / vft_nj_ml_newick of this process (vft_nj_last_stage_seconds) */
 static double gStage[8];
 static int64_t gLanes[4];
+static int64_t gLaneExchange[2];   /* lanes across ranks of the last tree: all-gathers, bytes received (vft_nj_last_lane_exchange) */
 static double gGamma[3];   /* `-gamma` of the last tree: Gamma(nCat) log-likelihood, alpha, length factor (vft_nj_last_gamma) */
 
 /* treePartitioning (NJ.tcc:5540-5750) on a tree given as arrays: pure host code, no context (tests pin it to the reference's own
@@ -105,6 +106,26 @@ extern "C" int vft_tree_partitioning(int64_t nNodes, const int64_t *childIn, int
     *nOut = (int64_t) res.size();
     if (speedup) *speedup = sp;
     for (int64_t k = 0; out && k < cap && k < (int64_t) res.size(); k++) out[k] = res[(size_t) k];
+    return VFT_OK;
+}
+
+/* the exchange layout of the lanes across ranks (MLLengths::laneShare / laneRecord), for the CPU test that runs it over gloo:
+   out[0] = per, out[1] = k0, out[2] = k1 for rank `rank` of `world`; out[3] = the record index of item `item` in the gathered buffer */
+extern "C" int vft_nj_lane_share(int64_t nItems, int32_t world, int32_t rank, int64_t item, int64_t *out) {
+    if (nItems < 0 || world < 1 || rank < 0 || rank >= world || !out) return VFT_ERR_INVALID;
+    size_t per, k0, k1;
+    veryfasttree::MLLengths<float>::laneShare((size_t) nItems, (size_t) world, (size_t) rank, per, k0, k1);
+    out[0] = (int64_t) per;
+    out[1] = (int64_t) k0;
+    out[2] = (int64_t) k1;
+    out[3] = per > 0 && item >= 0 ? (int64_t) veryfasttree::MLLengths<float>::laneRecord((size_t) item, per) : -1;
+    return VFT_OK;
+}
+
+extern "C" int vft_nj_last_lane_exchange(int64_t *out) {
+    if (!out) return VFT_ERR_INVALID;
+    out[0] = gLaneExchange[0];
+    out[1] = gLaneExchange[1];
     return VFT_OK;
 }
 
@@ -196,6 +217,8 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     gLanes[1] = drv.mlLaneWork;
     gLanes[2] = drv.meSPRSteps;
     gLanes[3] = drv.meSPRs;
+    gLaneExchange[0] = drv.laneGathers;
+    gLaneExchange[1] = drv.laneGatherBytes;
     drv.report();
     std::vector<std::string> nm;
     const char *p = names;
