@@ -59,11 +59,11 @@ def kern(prefix):
 line = json.load(open(os.path.join(src, "bench_line.json")))
 traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_bench_pmc.txt, bench.py --steps 3): FETCH_SIZE(KB) x 2 "
                        "(gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE(KB), x 1024. Workload "
-                       "c4_1M_x200_nt_tophits, 1 GPU, tile streams; same commit as profiles/%s_bench_line.json. k_sweep_nt is the mean of its "
-                       "two instantiations (<float,2> leaf seeds: all targets; <float,0> profile seeds: internal targets), 4 launches each "
-                       "per step." % (name, name)}
-sw = kern("void k_sweep_nt<float, ")
-inst = {k: v for k, v in sw.items() if "k_sweep_nt<float, 2>" in k or "k_sweep_nt<float, 0>" in k}   # (<float, 1> is the MODE_OUTDIST pre-pass)
+                       "c4_1M_x200_nt_tophits, 1 GPU, tile streams; same commit as profiles/%s_bench_line.json. A sweep is one launch: "
+                       "k_sweep_nt<float, 2> for a leaf seed, k_sweep_nt_both<float> for a profile seed (internal targets + the table walk "
+                       "over the leaf targets), 4 launches each per step; sweep_launch_average is their mean." % (name, name)}
+sw = kern("void k_sweep_nt")
+inst = {k: v for k, v in sw.items() if "k_sweep_nt<float, 2>" in k or "k_sweep_nt_both<float>" in k}   # (<float, 1> / k_sweep_nt_table are the MODE_OUTDIST pre-pass)
 if inst:
     fk = sum(v["FETCH_SIZE"] for v in inst.values()) / len(inst)
     wk = sum(v["WRITE_SIZE"] for v in inst.values()) / len(inst)
@@ -71,14 +71,9 @@ if inst:
              "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"]}
     for k, v in inst.items():
         entry["leaf_seed_instance" if "<float, 2>" in k else "profile_seed_instance"] = {
-            "fetch_size_kb": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1)}
-    traffic["k_sweep_nt<float,MODE_CRIT>"] = entry
-tb = kern("void k_sweep_nt_table<float, 0>")
-if tb:
-    fk = sum(v["FETCH_SIZE"] for v in tb.values()) / len(tb)
-    wk = sum(v["WRITE_SIZE"] for v in tb.values()) / len(tb)
-    traffic["k_sweep_nt_table<float,MODE_CRIT>"] = {"fetch_size_kb": round(fk, 1), "write_size_kb": round(wk, 1),
-                                                     "bytes_per_launch": int((2 * fk + wk) * 1024), "algorithmic_bytes_per_launch": 110000000}
+            "fetch_size_kb": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1),
+            "bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
+    traffic["sweep_launch_average"] = entry
 # the figure belongs to the sweep kernels as they were when the counters were read: bench.py prints it only while these files are unchanged
 sys.path.insert(0, ROOT)
 from bench import sweep_kernel_hash

@@ -2,11 +2,11 @@
 # Runs on the GPU box (gpurun): the bench line, the rocprofv3 kernel statistics of the same command, the two PMC passes the
 # HBM-traffic figure comes from (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md), and the per-operator
 # tables.  Everything lands in gpurun_out/$1/; tools/profile_collect.py turns it into profiles/$1_* afterwards.
-tag=${1:-r03}
+tag=${1:-r05}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 10 --warmup 2 > $out/bench_line.json 2> $out/bench_stderr.txt
+python3 bench.py --steps 10 --warmup 2 --no-e2e > $out/bench_line.json 2> $out/bench_stderr.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-e2e --no-cpu-baseline > $out/bench_line_under_rocprof.json 2> /dev/null
 cp /tmp/prof_stats/bench_kernel_stats.csv $out/bench_kernel_stats.csv 2>/dev/null
