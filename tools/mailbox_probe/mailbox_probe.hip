@@ -67,6 +67,26 @@ __global__ __launch_bounds__(256) void k_pingpong(const u64 *cmd, u64 *res, int 
     }
 }
 
+// W: the walk server's own poll - 64 granules of 8 bytes (one per lane) per slot, a command of `cnt` granules is there when the first
+// cnt tags match; the host writes cnt granules per round
+__global__ __launch_bounds__(256) void k_widepoll(const u64 *cmd, u64 *res, int rounds, int stride, int cnt) {
+    if (blockIdx.x % stride) return;
+    const int w = blockIdx.x / stride;
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const u64 t0 = wall_clock64();
+    const u64 need = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    for (u64 seq = 1; seq <= (u64) rounds; seq++) {
+        for (;;) {
+            const u64 g = ld_sys(cmd + lane);
+            const u64 ok = __ballot((g >> 32) == seq);
+            if ((ok & need) == need) break;
+            if (wall_clock64() - t0 > LIMIT_TICKS) return;
+        }
+        if (threadIdx.x == 0) st_sys(&res[8 * w], (seq << 32) | 1u);
+    }
+}
+
 // D: block 0 = producer, blocks `stride`, 2*stride ... 5*stride = consumers (the rest exit)
 __global__ __launch_bounds__(256) void k_hop(const u64 *cmd, u64 *res, uint4 *payload, u64 *flag, int rounds, int stride, int payloadVec) {
     if (blockIdx.x % stride) return;
@@ -125,6 +145,20 @@ __global__ __launch_bounds__(256) void k_hop(const u64 *cmd, u64 *res, uint4 *pa
 static sigjmp_buf faultJmp;
 static void on_fault(int) { siglongjmp(faultJmp, 1); }
 
+static double drive_wide(volatile u64 *cmd, volatile u64 *res, int nRes, int rounds, int cnt, bool wc) {
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    for (u64 seq = 1; seq <= (u64) rounds; seq++) {
+        for (int g = cnt - 1; g >= 0; g--) cmd[g] = (seq << 32) | (u64) g;
+        if (wc) __builtin_ia32_sfence();
+        for (int w = 0; w < nRes; w++) {
+            long spins = 0;
+            while ((res[8 * w] >> 32) != seq)
+                if (++spins > 400000000L) return -1.0;
+        }
+    }
+    return (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e6 / rounds;
+}
+
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // host side of a ping-pong over nRes answering blocks; returns microseconds per round, < 0 on timeout
@@ -145,6 +179,11 @@ static double drive(volatile u64 *cmd, volatile u64 *res, int nRes, int rounds, 
 int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 20000;
     CHK(hipSetDevice(0));
+    {
+        int largeBar = -1;
+        (void) hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, 0);
+        printf("hipDeviceAttributeIsLargeBar = %d\n", largeBar);
+    }
     u64 *hCmd, *hRes, *dCmd, *dRes;
     CHK(hipHostMalloc((void **) &hCmd, 4096, hipHostMallocMapped));
     CHK(hipHostMalloc((void **) &hRes, 4096, hipHostMallocMapped));
@@ -178,6 +217,12 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_pingpong<3>, dim3(41), dim3(256), 0, st, dCmd, dRes, rounds, 8);
     printf("C3 host mailbox, 6 workgroups (one XCD), 3 polls: %.2f us per round trip\n", drive(hCmd, hRes, 6, rounds, false));
     CHK(hipStreamSynchronize(st));
+    for (int cnt : {1, 14, 22, 62}) {
+        reset();
+        hipLaunchKernelGGL(k_widepoll, dim3(41), dim3(256), 0, st, dCmd, dRes, rounds, 8, cnt);
+        printf("W  host mailbox, 6 workgroups (one XCD), 64-lane poll, command of %2d granules: %.2f us per round trip\n", cnt, drive_wide(hCmd, hRes, 6, rounds, cnt, false));
+        CHK(hipStreamSynchronize(st));
+    }
     // for comparison: an empty launch + wait
     {
         reset();
@@ -243,6 +288,13 @@ int main(int argc, char **argv) {
                 hipLaunchKernelGGL(k_pingpong<1>, dim3(6), dim3(256), 0, st, dMail, dRes, rounds, 1);
                 printf("B6 device mailbox, 6 workgroups: %.2f us per round trip\n", drive(dMail, hRes, 6, rounds, true));
                 CHK(hipStreamSynchronize(st));
+                for (int cnt : {1, 14, 22, 62}) {
+                    CHK(hipMemset(dMail, 0, 4096));
+                    reset();
+                    hipLaunchKernelGGL(k_widepoll, dim3(41), dim3(256), 0, st, dMail, dRes, rounds, 8, cnt);
+                    printf("BW device mailbox, 6 workgroups (one XCD), 64-lane poll, command of %2d granules: %.2f us per round trip\n", cnt, drive_wide(dMail, hRes, 6, rounds, cnt, true));
+                    CHK(hipStreamSynchronize(st));
+                }
             } else {
                 printf("B  device mailbox: the CPU cannot touch device memory on this box (child status %d)\n", status);
             }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -1632,6 +1633,12 @@ namespace veryfasttree {
         }
         void meCollect(MeTicket &t, bool scoredist, double criteria[3]) {
             if (t.pending) {
+                if (walkStats) {
+                    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                    chk(vft_walk_collect(ctx, t.ticket, t.d));
+                    walkWaitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    walkDeviceSteps++;
+                } else
                 chk(vft_walk_collect(ctx, t.ticket, t.d));
                 t.pending = false;
             }
@@ -1859,6 +1866,9 @@ namespace veryfasttree {
         uint64_t vnNext = 0;
         bool vnActive = false;
         int64_t avgRedundant = 0, stepsMemoised = 0;   /* statistics */
+        double walkWaitSeconds = 0, walkSeconds = 0;    /* (VFT_WALK_STATS) waiting for the device's answers / the walks in all */
+        int64_t walkDeviceSteps = 0;
+        bool walkStats = std::getenv("VFT_WALK_STATS") != nullptr;
         static uint64_t vnHash(uint64_t x, uint64_t y) {
             uint64_t h = x * 0x9E3779B97F4A7C15ull ^ (y + 0x7F4A7C159E3779B9ull + (x << 6) + (x >> 2));
             h ^= h >> 29;
@@ -1982,7 +1992,9 @@ namespace veryfasttree {
            exception is on its way). */
         struct WalkServerGuard {
             MLLengths &t;
+            std::chrono::steady_clock::time_point born;
             explicit WalkServerGuard(MLLengths &tree, bool enable = true) : t(tree) {
+                born = std::chrono::steady_clock::now();
                 if (!enable) return;
                 t.flushAverages();
                 if (t.walkValueNumbers) t.vnBegin();
@@ -1994,9 +2006,13 @@ namespace veryfasttree {
             void finish() {
                 t.flushAverages();
                 t.vnActive = false;
-                if (std::getenv("VFT_WALK_STATS"))
-                    fprintf(stderr, "walk: %lld averages run, %lld dropped unread, %lld redundant (same value), %lld steps from the memo table\n",
-                            (long long) (t.avgQueued - t.avgDropped), (long long) t.avgDropped, (long long) t.avgRedundant, (long long) t.stepsMemoised);
+                if (t.walkStats) {
+                    t.walkSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - born).count();
+                    fprintf(stderr, "walk: %lld averages run, %lld dropped unread, %lld redundant (same value), %lld steps from the memo table; %lld device steps, "
+                            "%.3f s waiting for their answers, %.3f s of walks in all\n",
+                            (long long) (t.avgQueued - t.avgDropped), (long long) t.avgDropped, (long long) t.avgRedundant, (long long) t.stepsMemoised,
+                            (long long) t.walkDeviceSteps, t.walkWaitSeconds, t.walkSeconds);
+                }
                 if (t.serverUp) {
                     t.serverUp = false;
                     t.chk(vft_walk_server_stop(t.ctx));
