@@ -424,7 +424,8 @@ def main():
         # the S seeds of a step go down in one call (vft_sweep_batch): S sweeps back to back on the stream, one batched
         # top-k selection, one host wait - how the NJ driver refreshes the top-hit lists of a batch of seeds
         if not use_dist:
-            hits, _ = ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k)
+            # (the records are read where the selection leaves them - the host-mapped result blocks - as NJDriver::sweep reads them)
+            hits, _ = ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k, view=not os.environ.get("VFT_BENCH_COPY_HITS"))
             return hits
         ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k, d_hits=d_mine.data_ptr(),
                             want_hits=False)
@@ -451,6 +452,7 @@ def main():
         last = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    last = [np.array(h) for h in last]   # (views of the result blocks: the passes below sweep again)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

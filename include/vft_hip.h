@@ -265,6 +265,10 @@ int vft_sweep(vft_ctx *ctx, int64_t query, int64_t n_active, int64_t n_diff_allo
    the speculative next seeds of setAllLeafTopHits (NJ.tcc:3772-3800), a multi-GPU exchange per batch. */
 int vft_sweep_batch(vft_ctx *ctx, int32_t n_seeds, const int64_t *queries, int64_t n_active, int64_t n_diff_allow,
                     double totdiam, int32_t k, void *hits, void *d_hits, int64_t *best_j);
+/* The k records of seed number `slot` of the last vft_sweep_batch (slot 0: of the last vft_sweep) where the selection left them - the
+   host-mapped result block, no copy; *hits is valid until the context's next sweep.  For callers that pass hits = NULL above and read
+   the records in place (bench.py's step, NJDriver::sweep). */
+int vft_sweep_batch_view(vft_ctx *ctx, int32_t slot, const void **hits, int64_t *best_j);
 /* Restrict sweeps/out-distance passes to node ids [lo, hi): the shard a rank owns in a multi-GPU run
    (default [0, max_nodes)).  Hits keep global ids. */
 int vft_set_shard(vft_ctx *ctx, int64_t lo, int64_t hi);

@@ -2081,6 +2081,16 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
     return VFT_OK;
 }
 
+// the k records of slot `slot`'s last selection where the device left them: the host-mapped result block (no copy); valid until the
+// context's next sweep
+extern "C" int vft_sweep_batch_view(vft_ctx *c, int32_t slot, const void **hits, int64_t *bestJ) {
+    if (!c || slot < 0 || (size_t) slot >= c->slots.size() || !hits) return VFT_ERR_INVALID;
+    const vft_ctx::SweepSlotHost &h = c->slots[(size_t) slot];
+    *hits = h.hRes + sizeof(SelectHeader);
+    if (bestJ) *bestJ = (int64_t) ((const SelectHeader *) h.hRes)->bestJ;
+    return VFT_OK;
+}
+
 // nSeeds == 1: the single-list entry point (results through slot 0's blocks); nSeeds > 1: [lists][nSeeds][k] in,
 // [nSeeds][k] out through the batch blocks
 template <typename REAL, typename HIT>
