@@ -64,7 +64,8 @@ def init_scratch(ops_list, free):
 
 
 @pytest.mark.parametrize("stride", [8, 1])
-@pytest.mark.parametrize("dt,nc,L", [(np.float32, 4, 137), (np.float32, 4, 1000), (np.float64, 4, 200), (np.float32, 20, 90), (np.float64, 20, 300)])
+@pytest.mark.parametrize("dt,nc,L", [(np.float32, 4, 137), (np.float32, 4, 1000), (np.float64, 4, 200), (np.float32, 20, 90), (np.float64, 20, 300),
+                                      (np.float32, 4, 3500), (np.float64, 20, 1700)])   # (the last two: several slices per wavefront, several trips of the pair loop, more than 48 KB of staging)
 def test_server_steps_equal_plain_calls(dt, nc, L, stride):
     s_ops, rng, free = make_state(dt, nc, L=L, seed=21)
     p_ops, _, _ = make_state(dt, nc, L=L, seed=21)
