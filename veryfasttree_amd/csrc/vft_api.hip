@@ -1393,7 +1393,7 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
     S.tol = c->fpostTol;
     S.firstSeq = W.seq + 1;
     S.stride = W.stride;
-    S.idleTicks = 3000000000ll;   // 30 s without a command: the host has gone away
+    S.idleTicks = 60000000000ll;  // ten minutes without a command: the host is stuck (a host that has gone away takes its queues with it)
     S.flagTicks = 500000000ll;    // 5 s for another workgroup's flag
     W.acked = W.seq;
     VFT_DISPATCH(c, {
