@@ -1323,12 +1323,8 @@ static int ws_command(vft_ctx *c, int32_t nOps, const int64_t *out, const int64_
     const uint32_t seq = ++c->ws.seq;
     const bool wide = c->rs == 8;
     // the slot of seq is the slot of seq - RING, and the answers share a ring of the same length: stay well inside it
-    while ((int32_t) (seq - c->ws.acked) > VFT_WS_RING / 2) {
-        // (answers of commands without distances are one granule per workgroup)
-        const volatile unsigned long long *slot = c->ws.hRes + (size_t) ((c->ws.acked + 1) % VFT_WS_RING) * VFT_WS_RESG;
-        (void) slot;
+    while ((int32_t) (seq - c->ws.acked) > VFT_WS_RING / 2)   // (the first granule of every workgroup's answer carries the tag, with or without distances)
         if (int r = ws_wait(c, c->ws.acked + 1, false)) return r;
-    }
     const bool noWait = c->ws.acked == seq - 1;   // every earlier answer has been seen: no workgroup is still reading rows
     for (int t = 0; t < 4; t++) ws_put(c, seq, 1 + t, q ? (uint32_t) (int32_t) q[t] : 0u);
     for (int32_t k = 0; k < nOps; k++) {
@@ -1354,6 +1350,7 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
     const size_t staticLds = (c->d.nCodes == 20 ? (size_t) 840 * c->rs : 8) + 1024;
     if (lds + staticLds > (160u << 10)) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: alignment too long for one workgroup per pair");
     vft_ctx::WalkServerHost &W = c->ws;
+    if (W.stream && !W.dFlags) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: an earlier start failed half-way (the walks keep the plain calls)");
     if (!W.stream) {
         HIPCHK(c, hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
         HIPCHK(c, hipHostMalloc((void **) &W.hRes, (size_t) VFT_WS_RING * VFT_WS_RESG * 8 + 512, hipHostMallocMapped));
