@@ -472,21 +472,26 @@ def main():
         ops.timer_start()
         ops.setBestHitBatch(which, state.n_active, state.n_diff_allow, state.totdiam, k)
         ops.timer_stop_ms()
-        return ops.sweep_kernel_ms()
+        return ops.sweep_kernel_ms() + (ops.sweep_kernel_sweeps(),)
 
-    leaf_ms, n_leaf_launches = timed_pass(seeds_leaf) if len(seeds_leaf) and not use_dist else (0.0, 0)
-    prof_ms, n_prof_launches = timed_pass(seeds_prof) if len(seeds_prof) and not use_dist else (0.0, 0)
+    # (a launch can stand for several sweeps: runs of leaf seeds share a pass over the targets, k_sweep_nt_leafq_multi)
+    leaf_ms, n_leaf_launches, n_leaf_sweeps = timed_pass(seeds_leaf) if len(seeds_leaf) and not use_dist else (0.0, 0, 0)
+    prof_ms, n_prof_launches, n_prof_sweeps = timed_pass(seeds_prof) if len(seeds_prof) and not use_dist else (0.0, 0, 0)
     if use_dist:   # (sharded: one instrumented step as it is)
         ops.timer_start()
         one_step()
         ops.timer_stop_ms()
         kern_ms, launches = ops.sweep_kernel_ms()
+        sweeps = ops.sweep_kernel_sweeps()
     else:
         launches = n_leaf_launches + n_prof_launches
+        sweeps = n_leaf_sweeps + n_prof_sweeps
         kern_ms = (leaf_ms * n_leaf_launches + prof_ms * n_prof_launches) / max(launches, 1)
     ab = state.algorithmic_bytes_per_sweep(lo, hi)
-    alg_main = float(ab["leaf"] + ab["internal"])
-    moved_main = float(ab["moved_leaf"] + ab["moved_internal"])
+    sweeps_per_launch = sweeps / max(launches, 1)
+    alg_sweep = float(ab["leaf"] + ab["internal"])            # the algorithm's bytes of ONE seed's sweep
+    alg_main = alg_sweep * sweeps_per_launch                  # ... times the sweeps an average launch processes
+    moved_main = float(ab["moved_leaf"] + ab["moved_internal"])   # what one pass over the targets moves, however many seeds ride on it
     achieved = alg_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # HBM traffic of the same kernels from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
     # process): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, bytes per launch
@@ -496,18 +501,22 @@ def main():
         t = json.load(open(tpath))
         if t.get("kernel_sources_sha256") == sweep_kernel_hash():   # (counters read from other kernel sources say nothing: null)
             traffic = t.get("sweep_launch_average", {}).get("bytes_per_launch")
-    per_kind = lambda ms: dict(avg_launch_ms=ms, achieved_gbs=alg_main / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                               frac=alg_main / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0)
+    def per_kind(ms, nl, ns):
+        spl = ns / max(nl, 1)
+        return dict(avg_launch_ms=ms, sweeps_per_launch=spl, achieved_gbs=alg_sweep * spl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    frac=alg_sweep * spl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                    moved_gbs=moved_main / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="k_sweep_nt_both<float> (profile seeds) / k_sweep_nt<float,MODE_CRIT_LEAFQ> (leaf seeds)", launches=int(launches),
-                    avg_launch_ms=kern_ms, algorithmic_bytes_per_launch=int(alg_main),
+                    traffic=traffic, kernel="k_sweep_nt_both<float> (a profile seed per launch) / k_sweep_nt_leafq_multi<float,4> (four leaf seeds per launch)", launches=int(launches),
+                    sweeps=int(sweeps), avg_launch_ms=kern_ms, algorithmic_bytes_per_sweep=int(alg_sweep), algorithmic_bytes_per_launch=int(alg_main),
                     moved_bytes_per_launch=int(moved_main),
                     achieved_moved_gbs=moved_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
                     frac_moved=moved_main / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0,
                     phi=ab["phi"],
-                    profile_seed_launch=per_kind(prof_ms), leaf_seed_launch=per_kind(leaf_ms),
-                    step=dict(algorithmic_bytes=int(alg_main * len(seeds)), achieved_gbs=alg_main * len(seeds) / (elapsed / args.steps) / 1e9,
-                              frac=alg_main * len(seeds) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS))
+                    profile_seed_launch=per_kind(prof_ms, n_prof_launches, n_prof_sweeps) if not use_dist else None,
+                    leaf_seed_launch=per_kind(leaf_ms, n_leaf_launches, n_leaf_sweeps) if not use_dist else None,
+                    step=dict(algorithmic_bytes=int(alg_sweep * len(seeds)), achieved_gbs=alg_sweep * len(seeds) / (elapsed / args.steps) / 1e9,
+                              frac=alg_sweep * len(seeds) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS))
 
     line = dict(metric="profile-ops/sec", value=value, unit="profile-ops/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,

@@ -461,6 +461,7 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_NO_WALK_SERVER 9      /* value != 0: vft_walk_server_start answers VFT_ERR_STATE - the walks keep one launch per step (tests compare) */
 #define VFT_DEBUG_WALK_DEVICE_MAILBOX 10 /* value != 0: the server's mailbox in device memory written through the PCIe aperture (large-BAR boxes) instead of pinned host memory */
 #define VFT_DEBUG_WALK_SERVER_STRIDE 11 /* 1: the server's six workgroups on six XCDs instead of one (placement is for speed only; tests run both) */
+#define VFT_DEBUG_NO_MULTI_SWEEP 12     /* value != 0: vft_sweep_batch sweeps its leaf seeds one launch each instead of four per pass over the targets (tests compare) */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */
@@ -471,6 +472,9 @@ int vft_timer_stop_ms(vft_ctx *ctx, float *ms);
 int vft_sweep_kernel_ms(vft_ctx *ctx, float *avg_ms, int64_t *launches);
 /* same for the sweep's second launch, k_sweep_nt_table (leaf targets of a profile seed; 0 ms when it did not run) */
 int vft_sweep_table_kernel_ms(vft_ctx *ctx, float *avg_ms, int64_t *launches);
+/* the sweeps those launches stand for: vft_sweep_batch takes consecutive leaf seeds four (two) per pass over the targets
+   (k_sweep_nt_leafq_multi), so a launch can be several seeds' sweeps (setAllLeafTopHits, NJ.tcc:3798-3880) */
+int vft_sweep_kernel_sweeps(vft_ctx *ctx, int64_t *sweeps);
 
 #ifdef __cplusplus
 }

@@ -210,6 +210,52 @@ def test_sweep_batch_equals_single_sweeps(n_codes, dt):
     assert np.array_equal(merged, hits)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_leaf_seeds_sharing_a_pass_over_the_targets_equal_single_sweeps(dt):
+    """vft_sweep_batch takes runs of leaf seeds four (two) per pass over the targets (k_sweep_nt_leafq_multi): every record equals
+    the one-launch-per-seed sweeps' (VFT_DEBUG_NO_MULTI_SWEEP) and the single vft_sweep calls', runs of 1 ... 6 leaf seeds between
+    internal ones, a gappy alignment, every criterion of the first seed of a group, and a target range that starts inside the leaves."""
+    import ctypes
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.workload import TopHitsState
+    n, L = 5000, 173
+    codes = synth.random_descent_codes(n, L, 4, 0.05, 0.08, seed=17)
+
+    def fresh(no_multi):
+        ops = HipProfileOps(n, L, 4, dt)
+        assert ops.lib.vft_debug_option(ops.ctx, ctypes.c_int32(12), ctypes.c_int64(1 if no_multi else 0)) == 0
+        return ops, TopHitsState(ops, codes, 1800)
+
+    ops1, st = fresh(True)
+    ops2, _ = fresh(False)
+    rng = np.random.default_rng(5)
+    leaves = rng.choice(st.active[st.active < n], 18, replace=False)
+    inner = rng.choice(st.active[st.active >= n], 4, replace=False)
+    # runs of 6, 1, 4, 2, 5 leaf seeds (4 + 2, 1, 4, 2, 4 + 1 per pass)
+    seeds = np.concatenate([leaves[:6], inner[:1], leaves[6:7], inner[1:2], leaves[7:11], inner[2:3], leaves[11:13], inner[3:4], leaves[13:18]])
+    k = 300
+    single = [ops1.setBestHit(int(q), st.n_active, st.n_diff_allow, st.totdiam, k) for q in seeds]
+    h1, b1 = ops1.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    h2, b2 = ops2.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    assert np.array_equal(b1, b2) and np.array_equal(h1, h2)
+    for s, (h, b) in enumerate(single):
+        assert b == b2[s] and np.array_equal(h, h2[s])
+    # all criteria of a group's first seed (slot 0 of the batch) against the single sweep's
+    ops1.setBestHit(int(seeds[0]), st.n_active, st.n_diff_allow, st.totdiam, k)
+    ops2.setBestHitBatch(seeds[:4], st.n_active, st.n_diff_allow, st.totdiam, k)
+    r1, r2 = ops1.sweep_results(0, st.maxnode), ops2.sweep_results(0, st.maxnode)
+    for a, b in zip(r1, r2):
+        assert np.array_equal(a, b)
+    lo, hi = 1984, st.maxnode - 77
+    lo -= lo % 64
+    ops1.set_shard(lo, hi)
+    ops2.set_shard(lo, hi)
+    p1 = ops1.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    p2 = ops2.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    assert np.array_equal(p1[0], p2[0]) and np.array_equal(p1[1], p2[1])
+
+
 def G_load(name):
     import golden_util as G
     return G.load(name)

@@ -186,6 +186,8 @@ struct vft_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
     size_t kevUsed = 0;
+    int64_t kevSweeps = 0;       // sweeps beyond one per timed launch (a pass of k_sweep_nt_leafq_multi covers several)
+    bool noMultiSweep = false;   // VFT_DEBUG_NO_MULTI_SWEEP
     bool timeKernels = false;
 };
 
@@ -1994,6 +1996,36 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
     return VFT_OK;
 }
 
+// S leaf seeds of a batch (the seeds at positions slotOf[0 .. S-1] of it) in ONE pass over the targets (k_sweep_nt_leafq_multi): results in
+// the buffers of those slots, bit for bit those of S sweep_one calls.  The caller has checked that no lazy refresh is due (sweep_one's step 1) and has staged the queries.
+template <typename REAL, int S>
+static int sweep_leaf_group(vft_ctx *c, const int *slotOf, const int64_t *queries, int64_t nActive, int64_t nDiffAllow, double totdiam) {
+    SweepArgs s{};
+    s.query = queries[slotOf[0]];
+    s.lo = c->shardLo;
+    s.hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
+    s.nActive = nActive;
+    s.nDiffAllow = nDiffAllow;
+    s.totdiam = totdiam;
+    s.queryIsLeaf = 1;
+    const unsigned grid = sweep_nt_grid(c, s, false);
+    MultiLeafQ<REAL, S> M;
+    for (int q = 0; q < S; q++) {
+        M.Q[q] = qbuf_slot<REAL>(c, slotOf[q]);
+        M.O[q] = sweepout<REAL>(c, slotOf[q]);
+        M.query[q] = queries[slotOf[q]];
+        c->slots[(size_t) slotOf[q]].nPart = (int) grid;
+    }
+    c->nPart = (int) grid;
+    kernel_event(c);
+    if (grid) launch((k_sweep_nt_leafq_multi<REAL, S>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
+    kernel_event(c);
+    kernel_event(c);
+    if (c->timeKernels) c->kevSweeps += S - 1;   // (every triple of events counts as one sweep; this one covers S)
+    LAUNCHCHK(c);
+    return VFT_OK;
+}
+
 static int sweep_args_ok(vft_ctx *c, int64_t query, int64_t nActive, int32_t k) {
     if (!c->leavesUp) return fail(c, VFT_ERR_STATE, "vft_sweep before vft_upload_leaves");
     if (query < 0 || query >= c->maxnode || nActive < 3 || k < 0 || k > c->hitsCap)
@@ -2060,8 +2092,32 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
         }
         LAUNCHCHK(c);
     }
+    // The leaf seeds of the batch share passes over the targets, four (or two) per launch - every seed has buffers of its own, so the
+    // order the sweeps run in does not matter as long as no lazy refresh is due (sweep_one's step 1 changes out-distances that later
+    // sweeps read: then the seeds go one by one, in order).
+    std::vector<char> done((size_t) nSeeds, 0);
+    if (staged && !c->noMultiSweep && !(c->maxStamp - nActive > nDiffAllow)) {
+        bool fresh = true;
+        for (int s = 0; s < nSeeds && fresh; s++) fresh = !((int64_t) c->hNOut[queries[s]] - nActive > nDiffAllow);
+        int grp[4], nGrp = 0, nLeaf = 0;
+        for (int s = 0; s < nSeeds && fresh; s++) nLeaf += queries[s] < c->d.nSeqs;
+        for (int s = 0; s < nSeeds && fresh; s++) {
+            if (queries[s] >= c->d.nSeqs) continue;
+            grp[nGrp++] = s;
+            nLeaf--;
+            const int S = nGrp == 4 ? 4 : (nGrp == 2 && nLeaf < 2) ? 2 : 0;   // (fours while they last, then a pair; a last single goes alone)
+            if (!S) continue;
+            int r;
+            if (c->cfg.precision == 4) r = S == 4 ? sweep_leaf_group<float, 4>(c, grp, queries, nActive, nDiffAllow, totdiam) : sweep_leaf_group<float, 2>(c, grp, queries, nActive, nDiffAllow, totdiam);
+            else r = S == 4 ? sweep_leaf_group<double, 4>(c, grp, queries, nActive, nDiffAllow, totdiam) : sweep_leaf_group<double, 2>(c, grp, queries, nActive, nDiffAllow, totdiam);
+            if (r) return r;
+            for (int q = 0; q < S; q++) done[(size_t) grp[q]] = 1;
+            nGrp = 0;
+        }
+    }
     for (int s = 0; s < nSeeds; s++)
-        if (int r = sweep_one(c, s, queries[s], nActive, nDiffAllow, totdiam, staged)) return r;
+        if (!done[(size_t) s])
+            if (int r = sweep_one(c, s, queries[s], nActive, nDiffAllow, totdiam, staged)) return r;
     const int64_t lo = c->shardLo, hi = c->shardHi < c->maxnode ? c->shardHi : c->maxnode;
     int r;
     if (c->cfg.precision == 4) r = run_select<float, vft_hit_f32>(c, nSeeds, queries, lo, hi, k);
@@ -3891,6 +3947,7 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_NO_WALK_SERVER: c->ws.disabled = value != 0; break;
         case VFT_DEBUG_WALK_DEVICE_MAILBOX: c->ws.wantDeviceMail = value != 0; break;
         case VFT_DEBUG_WALK_SERVER_STRIDE: c->ws.stride = value == 1 ? 1 : 8; break;
+        case VFT_DEBUG_NO_MULTI_SWEEP: c->noMultiSweep = value != 0; break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }
     return VFT_OK;
@@ -3913,6 +3970,7 @@ extern "C" int vft_debug_log(vft_ctx *c, int64_t n, const double *x, double *out
 extern "C" int vft_timer_start(vft_ctx *c) {
     if (!c) return VFT_ERR_INVALID;
     c->kevUsed = 0;
+    c->kevSweeps = 0;
     c->timeKernels = true;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return VFT_OK;
@@ -3943,6 +4001,12 @@ static int sweep_kernel_ms(vft_ctx *c, int which, float *avgMs, int64_t *launche
     return VFT_OK;
 }
 extern "C" int vft_sweep_kernel_ms(vft_ctx *c, float *avgMs, int64_t *launches) { return sweep_kernel_ms(c, 0, avgMs, launches); }
+// the sweeps the launches timed since vft_timer_start stand for (a multi-seed pass is one launch for several sweeps)
+extern "C" int vft_sweep_kernel_sweeps(vft_ctx *c, int64_t *sweeps) {
+    if (!c || !sweeps) return VFT_ERR_INVALID;
+    *sweeps = (int64_t) (c->kevUsed / 3) + c->kevSweeps;
+    return VFT_OK;
+}
 extern "C" int vft_sweep_table_kernel_ms(vft_ctx *c, float *avgMs, int64_t *launches) {
     return sweep_kernel_ms(c, 1, avgMs, launches);
 }

@@ -579,6 +579,220 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_both(Arena<REAL> A, QueryBu
     vft_sweep_heavy_wg<REAL, MODE_CRIT>(A, Q, s, O, nHeavy - 1 - h);   // ... take the highest ids first, as in k_sweep_nt
 }
 
+// ---- S leaf seeds in ONE pass over the targets (vft_sweep_batch: setAllLeafTopHits sweeps seed after seed and nothing changes
+// in between, NJ.tcc:3798-3880).  A leaf seed's sweep is bound by the target stream (0.86 of the HBM peak by algorithmic bytes), and
+// most of what a lane does per column does not depend on the query: the tile's masks and stream offsets, the lane's slots in
+// the packed streams, its code byte, its weight, its vector.  Here a lane does that once and evaluates S queries on it - the
+// arithmetic of every (query, target) pair is MODE_CRIT_LEAFQ's, operation for operation (same bits): one pass streams the targets
+// for S sweeps.
+//     piece = 1 - f2[cq]   (NJ.tcc:924; f2 of a plain target code is the one-hot of the code)
+//     wgt   = the target's weight, or 0 at a gap of the query (the leaf's weight is 1: w1 * w2 is w2 exactly, NJ.tcc:1176)
+template <typename REAL, int S>
+struct MultiLeafQ {
+    QueryBuf<REAL> Q[S];
+    SweepOut<REAL> O[S];
+    int64_t query[S];
+};
+
+template <typename REAL, int SUB>
+struct IntChunkAll {
+    REAL w[SUB];
+    typename UVec4<REAL>::type f[SUB];
+};
+
+// (Measured and dropped: the same loads as always-issued buffer loads - lanes without a vector asking beyond the stream, the answer
+// OR-ed onto the implied value - so that no load sits in a branch and two column groups can alternate with exact wait counters:
+// 142 -> 172-220 us per pass of four seeds.  Most (tile, column) pairs have no vector lane at all and the branch skips the
+// instruction; issued unconditionally, the 128-bit loads cost the texture path more than the exposed latency they hide.)
+template <typename REAL, int SUB>
+__device__ __forceinline__ void vft_int_chunk_load_all(IntChunkAll<REAL, SUB> &r, int c, int sub, const uint4 codes, const REAL *wT,
+                                                       vft_smask_t mM, vft_soff_t mO, const REAL *fT) {
+    const int64_t p0 = (int64_t) c * VFT_CHUNK + sub * SUB;
+    vft_u4_t mk[SUB];
+    vft_u2_t of[SUB];
+#pragma unroll
+    for (int b = 0; b < SUB; b++) {   // wave-uniform: scalar loads
+        mk[b] = mM[p0 + b];
+        of[b] = mO[p0 + b];
+    }
+#pragma unroll
+    for (int b = 0; b < SUB; b++) {
+        const unsigned long long mv = ((unsigned long long) mk[b].y << 32) | mk[b].x;
+        const unsigned long long mw = ((unsigned long long) mk[b].w << 32) | mk[b].z;
+        const bool hv = __builtin_amdgcn_inverse_ballot_w64(mv);
+        const bool hw = __builtin_amdgcn_inverse_ballot_w64(mw);
+        const uint32_t slotV = __builtin_amdgcn_mbcnt_hi(mk[b].y, __builtin_amdgcn_mbcnt_lo(mk[b].x, of[b].x));
+        const uint32_t slotW = __builtin_amdgcn_mbcnt_hi(mk[b].w, __builtin_amdgcn_mbcnt_lo(mk[b].z, of[b].y));
+        const uint32_t cd = vft_byte(codes, sub * SUB + b);
+        r.w[b] = (hv || cd != VFT_NOCODE_) ? (REAL) 1 : (REAL) 0;   // implicit weight (vft_layout.h)
+        const char *wB = (const char *) wT, *fB = (const char *) fT;
+        if (hw) r.w[b] = *(const REAL *) (wB + slotW * (uint32_t) sizeof(REAL));
+        // a plain code as its one-hot vector: f[k] = (cd == k); entry cq of it is MODE_CRIT_LEAFQ's (cd == cq) for every code
+        // cq, and at a gap of the query (cq = 127 reads entry 3) the value does not matter: the weight is 0 there
+        uint32_t oh;   // (asm: keeps the compiler from turning the byte reads back into compare + select)
+        asm("v_lshlrev_b32 %0, %1, 1" : "=v"(oh) : "v"((cd & 3u) * 8u));
+        if (cd == VFT_NOCODE_) oh = 0;   // (a target's gap or vector column: no code equals it; MODE_CRIT_LEAFQ's cd == cq is false too)
+        r.f[b].x = (REAL) (oh & 0xFFu);
+        r.f[b].y = (REAL) ((oh >> 8) & 0xFFu);
+        r.f[b].z = (REAL) ((oh >> 16) & 0xFFu);
+        r.f[b].w = (REAL) ((oh >> 24) & 0xFFu);
+        // the column's whole vector: the 16 (32) bytes a leaf query's single frequency sits in
+        if (hv) r.f[b] = *(const typename UVec4<REAL>::type *) (fB + slotV * 4u * (uint32_t) sizeof(REAL));
+    }
+}
+
+// per-workgroup (min, max) of S queries' criteria at once
+template <typename REAL, int S>
+__device__ __forceinline__ void vft_block_minmax_multi(REAL *cmin, REAL *cmax, const SweepOut<REAL> *O, int part) {
+    constexpr int NW = VFT_WG / 64;
+    __shared__ REAL smin[S][NW], smax[S][NW];
+#pragma unroll
+    for (int q = 0; q < S; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const REAL a = __shfl_xor(cmin[q], off, 64), b = __shfl_xor(cmax[q], off, 64);
+            cmin[q] = a < cmin[q] ? a : cmin[q];
+            cmax[q] = b > cmax[q] ? b : cmax[q];
+        }
+        if ((threadIdx.x & 63) == 0) {
+            smin[q][threadIdx.x >> 6] = cmin[q];
+            smax[q][threadIdx.x >> 6] = cmax[q];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < S) {
+        const int q = threadIdx.x;
+        REAL lo = smin[q][0], hi = smax[q][0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            lo = smin[q][w] < lo ? smin[q][w] : lo;
+            hi = smax[q][w] > hi ? smax[q][w] : hi;
+        }
+        O[q].partMin[part] = lo;
+        O[q].partMax[part] = hi;
+    }
+}
+
+// cond ? b : a for a wave-uniform condition, as ONE v_cndmask on a scalar lane mask.  (Written in C the compiler either branches
+// on the scalar condition - a taken branch is ~40 cycles and every one of them ended in s_waitcnt vmcnt(0) - or, for an indexed
+// vector, goes through scratch memory.)
+__device__ __forceinline__ uint32_t vft_usel_b32(uint32_t a, uint32_t b, unsigned long long mask) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ float vft_usel(float a, float b, unsigned long long mask) {
+    return __uint_as_float(vft_usel_b32(__float_as_uint(a), __float_as_uint(b), mask));
+}
+__device__ __forceinline__ double vft_usel(double a, double b, unsigned long long mask) {
+    return __hiloint2double((int) vft_usel_b32((uint32_t) __double2hiint(a), (uint32_t) __double2hiint(b), mask),
+                            (int) vft_usel_b32((uint32_t) __double2loint(a), (uint32_t) __double2loint(b), mask));
+}
+
+// S queries on one group of SUB columns
+template <typename REAL, int S, int SUB>
+__device__ __forceinline__ void vft_int_chunk_consume_all(const IntChunkAll<REAL, SUB> &ca, int64_t p0, const MultiLeafQ<REAL, S> &M, double *top, double *denom) {
+#pragma unroll
+    for (int b = 0; b < SUB; b++) {
+        const double wd = (double) ca.w[b];
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            const uint32_t cq = vft_query_code<REAL>(M.Q[q], p0, b);   // wave-uniform
+            const unsigned long long m0 = (cq & 1u) ? ~0ull : 0ull, m1 = (cq & 2u) ? ~0ull : 0ull;
+            const REAL fsel = vft_usel(vft_usel(ca.f[b].x, ca.f[b].y, m0), vft_usel(ca.f[b].z, ca.f[b].w, m0), m1);   // f2[cq & 3]
+            // the target's weight, or +0.0 at a gap of the query: a product with a scalar 1.0 / 0.0 (exact: weights are finite and
+            // not negative) - written as a select on the uniform condition the compiler branches around it
+            const double wgt = wd * (cq != VFT_NOCODE_ ? 1.0 : 0.0);
+            const double piece = 1.0 - (double) fsel;
+            denom[q] += wgt;
+            top[q] += wgt * piece;
+        }
+    }
+}
+
+template <typename REAL, int S>
+__global__ __launch_bounds__(VFT_WG) void k_sweep_nt_leafq_multi(Arena<REAL> A, MultiLeafQ<REAL, S> M, SweepArgs s) {
+    constexpr int SUB = 8;   // (groups of 4 columns: 142 -> 152 us per pass of four seeds)
+    REAL cmin[S], cmax[S];
+#pragma unroll
+    for (int q = 0; q < S; q++) {
+        cmin[q] = (REAL) 1e30;
+        cmax[q] = (REAL) -1e30;
+    }
+    const int wg = (int) gridDim.x - 1 - (int) blockIdx.x;   // highest ids first, as in k_sweep_nt
+    const int64_t j = s.heavyLo + (int64_t) wg * VFT_WG + threadIdx.x;
+    const int lane = (int) (j & 63);
+    const int64_t tile = j >> 6;
+    bool work = false;
+    if (j < s.hi) {
+        work = A.parent[j] < 0;
+        if (!work) {   // the reference's "illegal join" sentinel (NJ.tcc:3586-3590), as vft_sweep_wants
+#pragma unroll
+            for (int q = 0; q < S; q++) {
+                M.O[q].dist[j] = (REAL) 1e20;
+                M.O[q].crit[j] = (REAL) 1e20;
+                M.O[q].weight[j] = 0;
+            }
+        }
+    }
+    if (work) {
+        const bool targetLeaf = j < A.d.nSeqs;
+        REAL dist[S], weight[S];
+        if (targetLeaf) {
+            int nUse[S], nSame[S];
+#pragma unroll
+            for (int q = 0; q < S; q++) nUse[q] = nSame[q] = 0;
+            for (int c = 0; c < A.d.nChunk; c++) {
+                const uint4 t = A.leafT[vft_leaf_idx(A.d, tile, c, lane)];
+#pragma unroll
+                for (int q = 0; q < S; q++) vft_seq_counts(t, M.Q[q].enc[c], nUse[q], nSame[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < S; q++) {
+                const double top = (double) (nUse[q] - nSame[q]);
+                weight[q] = (REAL) (double) nUse[q];
+                dist[q] = (REAL) (nUse[q] > 0 ? top / (double) nUse[q] : 1.0);
+            }
+        } else {
+            double top[S], denom[S];
+#pragma unroll
+            for (int q = 0; q < S; q++) top[q] = denom[q] = 0;
+            const int64_t pt = (int64_t) __builtin_amdgcn_readfirstlane((int) (tile - A.d.firstProfTile));
+            const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, 0);
+            const vft_smask_t mM = (vft_smask_t) (A.colMask + vft_meta_idx(A.d, pt, 0));
+            const vft_soff_t mO = (vft_soff_t) (A.colOff + vft_meta_idx(A.d, pt, 0));
+            const REAL *wT = A.profW + vft_wstream_base(A.d, pt);
+            const REAL *fT = A.profF + vft_fstream_base(A.d, pt);
+            uint4 cur = cT[lane];
+            const int nChunk = A.d.nChunk;
+            constexpr int NSUB = VFT_CHUNK / SUB;
+            IntChunkAll<REAL, SUB> ca;
+            for (int c = 0; c < nChunk; c++) {
+                uint4 nxt;
+#pragma unroll
+                for (int sub = 0; sub < NSUB; sub++) {
+                    vft_int_chunk_load_all<REAL, SUB>(ca, c, sub, cur, wT, mM, mO, fT);
+                    if (sub == 0) nxt = cT[(int64_t) (c + 1 < nChunk ? c + 1 : c) * VFT_TILE + lane];
+                    vft_int_chunk_consume_all<REAL, S, SUB>(ca, (int64_t) c * VFT_CHUNK + sub * SUB, M, top, denom);
+                }
+                cur = nxt;
+            }
+#pragma unroll
+            for (int q = 0; q < S; q++) {
+                weight[q] = (REAL) (denom[q] > 0 ? denom[q] : 0.01);
+                dist[q] = (REAL) (denom[q] > 0 ? top[q] / denom[q] : 1.0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            SweepArgs sq = s;
+            sq.query = M.query[q];
+            vft_sweep_finish<REAL, MODE_CRIT>(A, sq, M.O[q], j, dist[q], weight[q], targetLeaf, cmin[q], cmax[q]);
+        }
+    }
+    vft_block_minmax_multi<REAL, S>(cmin, cmax, M.O, wg);
+}
+
 // ------------------------------------------------------------------------------------------------ generic pair
 // profileDist / seqDist for an arbitrary (i, j), any alphabet, with or without a distance matrix.
 // cdOut: the pair's second profile is the out-profile (row-major arrays in A.out*), used by setOutDistance.
