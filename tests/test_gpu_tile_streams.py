@@ -212,10 +212,11 @@ def test_sweep_batch_equals_single_sweeps(n_codes, dt):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-def test_leaf_seeds_sharing_a_pass_over_the_targets_equal_single_sweeps(dt):
-    """vft_sweep_batch takes runs of leaf seeds four (two) per pass over the targets (k_sweep_nt_leafq_multi): every record equals
-    the one-launch-per-seed sweeps' (VFT_DEBUG_NO_MULTI_SWEEP) and the single vft_sweep calls', runs of 1 ... 6 leaf seeds between
-    internal ones, a gappy alignment, every criterion of the first seed of a group, and a target range that starts inside the leaves."""
+def test_seeds_sharing_a_pass_over_the_targets_equal_single_sweeps(dt):
+    """vft_sweep_batch takes its leaf seeds four (two) per pass over the targets (k_sweep_nt_leafq_multi) and its profile seeds likewise
+    (k_sweep_nt_profq_multi): every record equals the one-launch-per-seed sweeps' (VFT_DEBUG_NO_MULTI_SWEEP) and the single vft_sweep
+    calls', leaf and internal seeds mixed, a gappy alignment, every criterion of the first seed of a group (leaf, then profile), and a
+    target range that starts inside the leaves."""
     import ctypes
     from veryfasttree_amd import HipProfileOps, synth
     from veryfasttree_amd.workload import TopHitsState
@@ -231,9 +232,9 @@ def test_leaf_seeds_sharing_a_pass_over_the_targets_equal_single_sweeps(dt):
     ops2, _ = fresh(False)
     rng = np.random.default_rng(5)
     leaves = rng.choice(st.active[st.active < n], 18, replace=False)
-    inner = rng.choice(st.active[st.active >= n], 4, replace=False)
-    # runs of 6, 1, 4, 2, 5 leaf seeds (4 + 2, 1, 4, 2, 4 + 1 per pass)
-    seeds = np.concatenate([leaves[:6], inner[:1], leaves[6:7], inner[1:2], leaves[7:11], inner[2:3], leaves[11:13], inner[3:4], leaves[13:18]])
+    inner = rng.choice(st.active[st.active >= n], 7, replace=False)
+    # 18 leaf seeds (4 + 4 + 4 + 4 + 2 per pass) with 7 profile seeds (4 + 2 per launch of k_sweep_nt_profq_multi, the last one alone) in between
+    seeds = np.concatenate([leaves[:6], inner[:1], leaves[6:7], inner[1:2], leaves[7:11], inner[2:3], leaves[11:13], inner[3:7], leaves[13:18]])
     k = 300
     single = [ops1.setBestHit(int(q), st.n_active, st.n_diff_allow, st.totdiam, k) for q in seeds]
     h1, b1 = ops1.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
@@ -244,6 +245,11 @@ def test_leaf_seeds_sharing_a_pass_over_the_targets_equal_single_sweeps(dt):
     # all criteria of a group's first seed (slot 0 of the batch) against the single sweep's
     ops1.setBestHit(int(seeds[0]), st.n_active, st.n_diff_allow, st.totdiam, k)
     ops2.setBestHitBatch(seeds[:4], st.n_active, st.n_diff_allow, st.totdiam, k)
+    r1, r2 = ops1.sweep_results(0, st.maxnode), ops2.sweep_results(0, st.maxnode)
+    for a, b in zip(r1, r2):
+        assert np.array_equal(a, b)
+    ops1.setBestHit(int(inner[0]), st.n_active, st.n_diff_allow, st.totdiam, k)
+    ops2.setBestHitBatch(inner[:4], st.n_active, st.n_diff_allow, st.totdiam, k)
     r1, r2 = ops1.sweep_results(0, st.maxnode), ops2.sweep_results(0, st.maxnode)
     for a, b in zip(r1, r2):
         assert np.array_equal(a, b)

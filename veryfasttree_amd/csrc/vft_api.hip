@@ -1996,10 +1996,10 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
     return VFT_OK;
 }
 
-// S leaf seeds of a batch (the seeds at positions slotOf[0 .. S-1] of it) in ONE pass over the targets (k_sweep_nt_leafq_multi): results in
-// the buffers of those slots, bit for bit those of S sweep_one calls.  The caller has checked that no lazy refresh is due (sweep_one's step 1) and has staged the queries.
+// S leaf seeds - or S profile seeds - of a batch (the seeds at positions slotOf[0 .. S-1] of it) in ONE pass over the targets
+// (k_sweep_nt_leafq_multi / k_sweep_nt_profq_multi): results in the buffers of those slots, bit for bit those of S sweep_one calls.  The caller has checked that no lazy refresh is due (sweep_one's step 1) and has staged the queries.
 template <typename REAL, int S>
-static int sweep_leaf_group(vft_ctx *c, const int *slotOf, const int64_t *queries, int64_t nActive, int64_t nDiffAllow, double totdiam) {
+static int sweep_group(vft_ctx *c, bool leafSeeds, const int *slotOf, const int64_t *queries, int64_t nActive, int64_t nDiffAllow, double totdiam) {
     SweepArgs s{};
     s.query = queries[slotOf[0]];
     s.lo = c->shardLo;
@@ -2007,8 +2007,8 @@ static int sweep_leaf_group(vft_ctx *c, const int *slotOf, const int64_t *querie
     s.nActive = nActive;
     s.nDiffAllow = nDiffAllow;
     s.totdiam = totdiam;
-    s.queryIsLeaf = 1;
-    const unsigned grid = sweep_nt_grid(c, s, false);
+    s.queryIsLeaf = leafSeeds ? 1 : 0;
+    const unsigned grid = sweep_nt_grid(c, s, !leafSeeds);   // (= the workgroups, and min / max partials, of ONE seed's sweep)
     MultiLeafQ<REAL, S> M;
     for (int q = 0; q < S; q++) {
         M.Q[q] = qbuf_slot<REAL>(c, slotOf[q]);
@@ -2018,7 +2018,9 @@ static int sweep_leaf_group(vft_ctx *c, const int *slotOf, const int64_t *querie
     }
     c->nPart = (int) grid;
     kernel_event(c);
-    if (grid) launch((k_sweep_nt_leafq_multi<REAL, S>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
+    if (grid && leafSeeds) launch((k_sweep_nt_leafq_multi<REAL, S>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
+    // profile seeds: the heavy workgroups once for all S, the table workgroups (leaf targets) once per seed
+    if (grid && !leafSeeds) launch((k_sweep_nt_profq_multi<REAL, S>), dim3(grid + (unsigned) (S - 1) * (unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
     kernel_event(c);
     kernel_event(c);
     if (c->timeKernels) c->kevSweeps += S - 1;   // (every triple of events counts as one sweep; this one covers S)
@@ -2092,27 +2094,30 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
         }
         LAUNCHCHK(c);
     }
-    // The leaf seeds of the batch share passes over the targets, four (or two) per launch - every seed has buffers of its own, so the
-    // order the sweeps run in does not matter as long as no lazy refresh is due (sweep_one's step 1 changes out-distances that later
+    // The leaf seeds of the batch share passes over the targets, four (or two) per launch, and so do its profile seeds - every seed has
+    // buffers of its own, so the order the sweeps run in does not matter as long as no lazy refresh is due (sweep_one's step 1 changes out-distances that later
     // sweeps read: then the seeds go one by one, in order).
     std::vector<char> done((size_t) nSeeds, 0);
     if (staged && !c->noMultiSweep && !(c->maxStamp - nActive > nDiffAllow)) {
         bool fresh = true;
         for (int s = 0; s < nSeeds && fresh; s++) fresh = !((int64_t) c->hNOut[queries[s]] - nActive > nDiffAllow);
-        int grp[4], nGrp = 0, nLeaf = 0;
-        for (int s = 0; s < nSeeds && fresh; s++) nLeaf += queries[s] < c->d.nSeqs;
-        for (int s = 0; s < nSeeds && fresh; s++) {
-            if (queries[s] >= c->d.nSeqs) continue;
-            grp[nGrp++] = s;
-            nLeaf--;
-            const int S = nGrp == 4 ? 4 : (nGrp == 2 && nLeaf < 2) ? 2 : 0;   // (fours while they last, then a pair; a last single goes alone)
-            if (!S) continue;
-            int r;
-            if (c->cfg.precision == 4) r = S == 4 ? sweep_leaf_group<float, 4>(c, grp, queries, nActive, nDiffAllow, totdiam) : sweep_leaf_group<float, 2>(c, grp, queries, nActive, nDiffAllow, totdiam);
-            else r = S == 4 ? sweep_leaf_group<double, 4>(c, grp, queries, nActive, nDiffAllow, totdiam) : sweep_leaf_group<double, 2>(c, grp, queries, nActive, nDiffAllow, totdiam);
-            if (r) return r;
-            for (int q = 0; q < S; q++) done[(size_t) grp[q]] = 1;
-            nGrp = 0;
+        for (int kind = 0; kind < 2 && fresh; kind++) {   // the leaf seeds, then the profile seeds: fours while they last, then a pair; a last single goes alone
+            int grp[4], nGrp = 0, nLeft = 0;
+            auto isKind = [&](int s) { return (queries[s] < c->d.nSeqs) == (kind == 0); };
+            for (int s = 0; s < nSeeds; s++) nLeft += isKind(s);
+            for (int s = 0; s < nSeeds; s++) {
+                if (!isKind(s)) continue;
+                grp[nGrp++] = s;
+                nLeft--;
+                const int S = nGrp == 4 ? 4 : (nGrp == 2 && nLeft < 2) ? 2 : 0;
+                if (!S) continue;
+                int r;
+                if (c->cfg.precision == 4) r = S == 4 ? sweep_group<float, 4>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam) : sweep_group<float, 2>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam);
+                else r = S == 4 ? sweep_group<double, 4>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam) : sweep_group<double, 2>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam);
+                if (r) return r;
+                for (int q = 0; q < S; q++) done[(size_t) grp[q]] = 1;
+                nGrp = 0;
+            }
         }
     }
     for (int s = 0; s < nSeeds; s++)

@@ -793,6 +793,108 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_leafq_multi(Arena<REAL> A, 
     vft_block_minmax_multi<REAL, S>(cmin, cmax, M.O, wg);
 }
 
+// ---- S PROFILE seeds (internal nodes) in one launch: the heavy workgroups stream the internal targets once and evaluate the S
+// queries' profile x profile distances on every column they decode (MODE_CRIT's arithmetic, operation for operation: numeric_t
+// products, double subtractions, NJ.tcc:933-937, :1172-1183); behind them S x nLeafWG table workgroups, one query each, walk the
+// leaf targets as k_sweep_nt_table does.
+template <typename REAL, int S, int SUB>
+__device__ __forceinline__ void vft_int_chunk_consume_prof(const IntChunkAll<REAL, SUB> &ca, int64_t p0, const MultiLeafQ<REAL, S> &M, double *top, double *denom) {
+#pragma unroll
+    for (int b = 0; b < SUB; b++) {
+        const int64_t p = p0 + b;
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            const REAL wq = vft_uniform_load<REAL>(M.Q[q].w + p);
+            const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(M.Q[q].f + p * 4);
+            const REAL ww = wq * ca.w[b];   // numeric_t product, NJ.tcc:1176
+            const double wgt = (double) ww;
+            const REAL q0 = fq.x * ca.f[b].x, q1 = fq.y * ca.f[b].y, q2 = fq.z * ca.f[b].z, q3 = fq.w * ca.f[b].w;
+            double piece = 1.0 - (double) q0;
+            piece -= (double) q1;
+            piece -= (double) q2;
+            piece -= (double) q3;
+            denom[q] += wgt;
+            top[q] += wgt * piece;
+        }
+    }
+}
+
+// (four wavefronts per SIMD: every heavy workgroup of a million-sequence sweep is resident at once - the column loop of the float
+// instance fits, the table walk's epilogue gives up six registers to scratch)
+template <typename REAL, int S>
+__global__ __launch_bounds__(VFT_WG, sizeof(REAL) == 4 ? 4 : 2) void k_sweep_nt_profq_multi(Arena<REAL> A, MultiLeafQ<REAL, S> M, SweepArgs s) {
+    constexpr int SUB = 8;
+    const int nT = s.nLeafWG, nHeavy = (int) gridDim.x - S * nT, blk = (int) blockIdx.x;
+    if (blk >= nHeavy) {   // a table workgroup: span t % nT of the leaves against query t / nT
+        const int t = blk - nHeavy, span = t % nT, qi = t / nT;
+        REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
+#pragma unroll
+        for (int q = 0; q < S; q++) {   // (the query's buffers by a constant index: a runtime one would copy the argument block to scratch)
+            if (q != qi) continue;
+            SweepArgs sq = s;
+            sq.query = M.query[q];
+            vft_leaf_table_wg<REAL, MODE_CRIT>(A, M.Q[q], sq, M.O[q], s.lo + (int64_t) span * VFT_LEAF_SPAN, cmin, cmax);
+            vft_block_minmax<REAL>(cmin, cmax, M.O[q].partMin, M.O[q].partMax, span);
+        }
+        return;
+    }
+    REAL cmin[S], cmax[S];
+#pragma unroll
+    for (int q = 0; q < S; q++) {
+        cmin[q] = (REAL) 1e30;
+        cmax[q] = (REAL) -1e30;
+    }
+    const int wg = nHeavy - 1 - blk;   // highest ids first, as in k_sweep_nt
+    const int64_t j = s.heavyLo + (int64_t) wg * VFT_WG + threadIdx.x;
+    const int lane = (int) (j & 63);
+    const int64_t tile = j >> 6;
+    bool work = false;
+    if (j < s.hi && !(nT && j < s.leafEnd)) {
+        work = A.parent[j] < 0;
+        if (!work) {   // the reference's "illegal join" sentinel (NJ.tcc:3586-3590), as vft_sweep_wants
+#pragma unroll
+            for (int q = 0; q < S; q++) {
+                M.O[q].dist[j] = (REAL) 1e20;
+                M.O[q].crit[j] = (REAL) 1e20;
+                M.O[q].weight[j] = 0;
+            }
+        }
+    }
+    if (work) {   // (an internal node: the leaves of a profile query belong to the table workgroups - or, without any, do not exist in [heavyLo, hi))
+        double top[S], denom[S];
+#pragma unroll
+        for (int q = 0; q < S; q++) top[q] = denom[q] = 0;
+        const int64_t pt = (int64_t) __builtin_amdgcn_readfirstlane((int) (tile - A.d.firstProfTile));
+        const uint4 *cT = A.profC + vft_c_idx(A.d, pt, 0, 0);
+        const vft_smask_t mM = (vft_smask_t) (A.colMask + vft_meta_idx(A.d, pt, 0));
+        const vft_soff_t mO = (vft_soff_t) (A.colOff + vft_meta_idx(A.d, pt, 0));
+        const REAL *wT = A.profW + vft_wstream_base(A.d, pt);
+        const REAL *fT = A.profF + vft_fstream_base(A.d, pt);
+        uint4 cur = cT[lane];
+        const int nChunk = A.d.nChunk;
+        IntChunkAll<REAL, SUB> ca;
+        for (int c = 0; c < nChunk; c++) {
+            uint4 nxt;
+#pragma unroll
+            for (int sub = 0; sub < VFT_CHUNK / SUB; sub++) {
+                vft_int_chunk_load_all<REAL, SUB>(ca, c, sub, cur, wT, mM, mO, fT);
+                if (sub == 0) nxt = cT[(int64_t) (c + 1 < nChunk ? c + 1 : c) * VFT_TILE + lane];
+                vft_int_chunk_consume_prof<REAL, S, SUB>(ca, (int64_t) c * VFT_CHUNK + sub * SUB, M, top, denom);
+            }
+            cur = nxt;
+        }
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            const REAL weight = (REAL) (denom[q] > 0 ? denom[q] : 0.01);
+            const REAL dist = (REAL) (denom[q] > 0 ? top[q] / denom[q] : 1.0);
+            SweepArgs sq = s;
+            sq.query = M.query[q];
+            vft_sweep_finish<REAL, MODE_CRIT>(A, sq, M.O[q], j, dist, weight, false, cmin[q], cmax[q]);
+        }
+    }
+    vft_block_minmax_multi<REAL, S>(cmin, cmax, M.O, nT + wg);
+}
+
 // ------------------------------------------------------------------------------------------------ generic pair
 // profileDist / seqDist for an arbitrary (i, j), any alphabet, with or without a distance matrix.
 // cdOut: the pair's second profile is the out-profile (row-major arrays in A.out*), used by setOutDistance.
