@@ -88,7 +88,9 @@ typedef struct {
                                    VFT_NJ_DEBUG_LEVEL_LENGTHS 16  ML length rounds as one batch per tree height - NOT the reference's
                                                               order in any of its modes (measurements only)
                                    VFT_NJ_DEBUG_NO_WALK_SERVER 128  the SPR / one-thread NNI walks with one launch per step
-                                                              (vft_walk_step) instead of the resident walk server (same tree) */
+                                                              (vft_walk_step) instead of the resident walk server (same tree)
+                                   VFT_NJ_DEBUG_SEED_BY_SEED 256  setAllLeafTopHits' seed sweeps one vft_sweep each instead of eight
+                                                              unvisited seeds ahead per vft_sweep_batch (same lists) */
     int32_t gamma;              /* `-gamma` (VeryFastTreeImpl.tcc:391-394, NJ.tcc:297-308, :5261-5357): after the CAT tree and its supports
                                    are final, fit the shape of a discretised Gamma over the ml_nni / mllen rate categories and a
                                    multiplier of the rates to the per-site likelihoods, and multiply every branch length by
@@ -99,6 +101,7 @@ typedef struct {
 #define VFT_NJ_DEBUG_HOST_RESET 4
 #define VFT_NJ_DEBUG_LEVEL_LENGTHS 16
 #define VFT_NJ_DEBUG_NO_WALK_SERVER 128
+#define VFT_NJ_DEBUG_SEED_BY_SEED 256
 #define VFT_NJ_SHARD_LEAF_BLOCKS 64   /* with comm: split the close-neighbour blocks by rows and all-gather the results (see vft_comm) */
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.

@@ -180,3 +180,21 @@ def test_join_engine_equals_the_host_driven_loop(fastest, wide, monkeypatch):
         ops.close()
     assert np.array_equal(runs[0][0], runs[1][0])
     assert np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_seed_sweeps_taken_ahead_give_the_seed_by_seed_lists():
+    """setAllLeafTopHits asks for the sweeps of the next eight unvisited seeds in one vft_sweep_batch (its leaf seeds share passes over
+    the targets); a sweep taken ahead whose seed becomes a close neighbour first is dropped.  Every join and criterion equals the run
+    with one vft_sweep per seed (vft_nj_options.debug_flags & VFT_NJ_DEBUG_SEED_BY_SEED), with and without second-level lists."""
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_run
+    codes = synth.random_descent_codes(5000, 150, 4, 0.04, 0.02, seed=78)
+    codes = codes[np.sort(np.unique(codes, axis=0, return_index=True)[1])]
+    for fastest, second in ((False, False), (True, True)):
+        runs = []
+        for flags in (0, 256):
+            ops = HipProfileOps(codes.shape[0], codes.shape[1], 4, np.float32)
+            runs.append(nj_run(ops, codes, fastest=fastest, second_level=second, debug_flags=flags))
+            ops.close()
+        assert np.array_equal(runs[0][0], runs[1][0])
+        assert np.array_equal(runs[0][1], runs[1][1])

@@ -64,6 +64,7 @@ namespace veryfasttree {
         /* with comm: split the close-neighbour blocks of setAllLeafTopHits by rows and all-gather the results (round 3); off: every
            rank computes them whole - 25 GB of gathers at a million sequences cost more than the ~5 s of integer counts they split */
         bool shardLeafBlocks = false;
+        int seedBatch = 8;         /* setAllLeafTopHits: sweeps of this many unvisited seeds per device call (vft_sweep_batch); 1: a call per seed */
         bool walkServer = true;    /* refinement walks through the resident walk server (vft_walk_server_start); false: a launch per step */
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
@@ -1899,6 +1900,48 @@ namespace veryfasttree {
             return out;
         }
 
+        /* setAllLeafTopHits' seed sweeps, several seeds per device call (vft_sweep_batch: its leaf seeds share passes over the targets,
+           four per launch, and one batched selection).  Nothing on the device changes between the seeds of that loop - every
+           out-distance carries the stamp n, the lists live on the host - so a seed's sweep is the same whenever it runs: the sweeps
+           of the next unvisited seeds are taken ahead, and one is wasted only when its seed turns out to be a close neighbour of
+           an earlier seed of the batch (a seed covers ~m of n leaves).  One rank only: sharded runs keep a sweep + exchange per seed. */
+        std::vector<std::pair<int64_t, std::vector<Besthit>>> seedAhead;
+        int64_t seedSweepsWasted = 0;
+        std::vector<Besthit> seedSweep(const std::vector<int64_t> &seeds, int64_t s, const std::vector<uint8_t> &visited, int64_t n, int32_t k) {
+            const int64_t seed = seeds[(size_t) s];
+            for (size_t t = 0; t < seedAhead.size(); t++)
+                if (seedAhead[t].first == seed) {
+                    std::vector<Besthit> out;
+                    out.swap(seedAhead[t].second);
+                    seedAhead.erase(seedAhead.begin() + (long) t);
+                    return out;
+                }
+            if ((opt.comm && opt.comm->world > 1) || opt.seedBatch < 2) return sweep(seed, n, k);
+            seedSweepsWasted += (int64_t) seedAhead.size();   /* (taken ahead, their seeds visited since) */
+            seedAhead.clear();
+            std::vector<int64_t> batch(1, seed);
+            for (int64_t t = s + 1; t < (int64_t) seeds.size() && (int) batch.size() < opt.seedBatch; t++)
+                if (!visited[(size_t) seeds[(size_t) t]]) batch.push_back(seeds[(size_t) t]);
+            std::vector<DevHit> dev(batch.size() * (size_t) k);
+            chkT("vft_sweep_batch", [&]() { return vft_sweep_batch(ctx, (int32_t) batch.size(), batch.data(), n, nDiffAllow(n), totdiam, k, dev.data(), nullptr, nullptr); });
+            pending = false;
+            std::vector<Besthit> first;
+            for (size_t b = 0; b < batch.size(); b++) {
+                std::vector<Besthit> out((size_t) k);
+                for (int32_t t = 0; t < k; t++) {
+                    const DevHit &h = dev[b * (size_t) k + (size_t) t];
+                    out[t].i = h.j >= 0 ? batch[b] : -1;
+                    out[t].j = h.j;
+                    out[t].weight = (REAL) h.weight;
+                    out[t].dist = (REAL) h.dist;
+                    out[t].criterion = (REAL) h.criterion;
+                }
+                if (b == 0) first.swap(out);
+                else seedAhead.emplace_back(batch[b], std::move(out));
+            }
+            return first;
+        }
+
         /* vft_leaf_block_distances for nA x nB pairs; with several ranks the rows are split and the three result arrays
            all-gathered through the host buffers (whole rows, padded to equal shares).  Returns the device's code. */
         int leafBlock(int64_t nA, const int64_t *a, int64_t nB, const int64_t *b, int64_t n, REAL *pd, REAL *pw, REAL *pc) {
@@ -1978,7 +2021,7 @@ namespace veryfasttree {
                 std::vector<Besthit> best;
                 {
                     Section s2(this, "[host]   setAllLeafTopHits: seed sweep (incl. device)");
-                    best = sweep(seed, n, (int32_t) (2 * m));
+                    best = seedSweep(seeds, s, visited, n, (int32_t) (2 * m));
                 }
                 std::vector<Besthit> copy(best);
                 sortSaveBestHits(seed, copy, (int64_t) copy.size(), m, false);
@@ -2119,6 +2162,8 @@ namespace veryfasttree {
                     }
                 }
             }
+            seedSweepsWasted += (int64_t) seedAhead.size();
+            seedAhead.clear();
             for (int64_t node = 0; node < n; node++) visible[node] = hits[node][0];
             /* checking phase, NJ.tcc:4052-4119 */
             const int64_t nCheck = q > 0 ? q : (int64_t) (0.5 + 2.0 * std::sqrt((double) m));

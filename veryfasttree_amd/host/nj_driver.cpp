@@ -167,6 +167,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_LISTS) opt.deviceLists = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_RESET) opt.deviceReset = false;
         if (o->debug_flags & VFT_NJ_DEBUG_NO_WALK_SERVER) opt.walkServer = false;
+        if (o->debug_flags & VFT_NJ_DEBUG_SEED_BY_SEED) opt.seedBatch = 1;
         if (o->debug_flags & VFT_NJ_DEBUG_LEVEL_LENGTHS) opt.parallelLengths = true;
         if (o->debug_flags & VFT_NJ_SHARD_LEAF_BLOCKS) opt.shardLeafBlocks = true;
     }
