@@ -59,18 +59,20 @@ def kern(prefix):
 line = json.load(open(os.path.join(src, "bench_line.json")))
 traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_bench_pmc.txt, bench.py --steps 3): FETCH_SIZE(KB) x 2 "
                        "(gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE(KB), x 1024. Workload "
-                       "c4_1M_x200_nt_tophits, 1 GPU, tile streams; same commit as profiles/%s_bench_line.json. A sweep is one launch: "
-                       "k_sweep_nt<float, 2> for a leaf seed, k_sweep_nt_both<float> for a profile seed (internal targets + the table walk "
-                       "over the leaf targets), 4 launches each per step; sweep_launch_average is their mean." % (name, name)}
+                       "c4_1M_x200_nt_tophits, 1 GPU, tile streams; same commit as profiles/%s_bench_line.json. A step's sweeps are two launches: "
+                       "k_sweep_nt_leafq_multi<float, 4> for its four leaf seeds (ONE pass over the targets for four sweeps) and "
+                       "k_sweep_nt_profq_multi<float, 4> for its four profile seeds (one pass over the internal targets + a table walk over the leaf "
+                       "targets per seed); sweep_launch_average is their mean, i.e. the traffic of FOUR sweeps." % (name, name)}
 sw = kern("void k_sweep_nt")
-inst = {k: v for k, v in sw.items() if "k_sweep_nt<float, 2>" in k or "k_sweep_nt_both<float>" in k}   # (<float, 1> / k_sweep_nt_table are the MODE_OUTDIST pre-pass)
+inst = {k: v for k, v in sw.items() if "k_sweep_nt_leafq_multi<float, 4>" in k or "k_sweep_nt_profq_multi<float, 4>" in k}
 if inst:
     fk = sum(v["FETCH_SIZE"] for v in inst.values()) / len(inst)
     wk = sum(v["WRITE_SIZE"] for v in inst.values()) / len(inst)
     entry = {"fetch_size_kb": round(fk, 1), "write_size_kb": round(wk, 1), "bytes_per_launch": int((2 * fk + wk) * 1024),
+             "sweeps_per_launch": 4,
              "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"]}
     for k, v in inst.items():
-        entry["leaf_seed_instance" if "<float, 2>" in k else "profile_seed_instance"] = {
+        entry["leaf_seed_instance" if "leafq" in k else "profile_seed_instance"] = {
             "fetch_size_kb": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1),
             "bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
     traffic["sweep_launch_average"] = entry
