@@ -286,3 +286,26 @@ def test_c2_shape_on_the_64_thread_schedule_equals_the_reference_run():
                          check=True, stdout=subprocess.PIPE, timeout=1200).stdout.decode()
     print(out)
     assert "byte-identical output: YES" in out
+
+
+@pytest.mark.parametrize("n,L,seed,mu,gap", [(100000, 500, 3, 0.03, 0.01), (1000000, 200, 4, 0.02, 0.01)])
+def test_seeds_sharing_passes_at_full_size(n, L, seed, mu, gap):
+    """BASELINE configs C3 and C4: a batch of 5 leaf + 5 profile seeds through the multi-seed passes (k_sweep_nt_leafq_multi,
+    k_sweep_nt_profq_multi: 4 + 1 of each kind) gives the records of one launch per seed (VFT_DEBUG_NO_MULTI_SWEEP), every criterion of a
+    seed of each kind equals the single sweep's, and every list is sorted under (criterion asc, id desc) without duplicates."""
+    import ctypes
+    codes, ops, st, _ = _state(n, L, seed, mu, gap)
+    rng = np.random.default_rng(seed + 1)
+    seeds = np.concatenate([rng.choice(st.active[st.active < n], 5, replace=False), rng.choice(st.active[st.active >= n], 5, replace=False)])
+    rng.shuffle(seeds)
+    k = 2 * int(0.5 + np.sqrt(n))
+    hm, bm = ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    crit_first = ops.sweep_results(0, st.maxnode)
+    assert ops.lib.vft_debug_option(ops.ctx, ctypes.c_int32(12), ctypes.c_int64(1)) == 0
+    hs, bs = ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    assert np.array_equal(bm, bs) and np.array_equal(hm, hs)
+    for a, b in zip(crit_first, ops.sweep_results(0, st.maxnode)):
+        assert np.array_equal(a, b)
+    for h in hm:
+        key = np.lexsort((-h["j"].astype(np.int64), h["criterion"]))
+        assert np.array_equal(key, np.arange(k)) and len(np.unique(h["j"])) == k
