@@ -262,7 +262,10 @@ int vft_sweep(vft_ctx *ctx, int64_t query, int64_t n_active, int64_t n_diff_allo
 /* n_seeds sweeps in one call: hits = n_seeds x k records (host, may be NULL), d_hits likewise in device memory,
    best_j[n_seeds].  Results are exactly those of n_seeds vft_sweep calls in this order; the top-k selections of the
    batch share their launches and the call synchronises once.  For seeds that are independent of each other's results:
-   the speculative next seeds of setAllLeafTopHits (NJ.tcc:3772-3800), a multi-GPU exchange per batch. */
+   the speculative next seeds of setAllLeafTopHits (NJ.tcc:3772-3800; NJDriver::seedSweep takes eight ahead), a multi-GPU exchange per
+   batch.  Nucleotides without a distance matrix: while no lazy out-distance refresh is due, the leaf seeds of the batch share passes
+   over the targets - four (two) seeds per launch, every (query, target) pair evaluated with vft_sweep's operations - and so do its
+   profile seeds (csrc/vft_kernels_nj.h: k_sweep_nt_leafq_multi, k_sweep_nt_profq_multi; VFT_DEBUG_NO_MULTI_SWEEP: a launch per seed). */
 int vft_sweep_batch(vft_ctx *ctx, int32_t n_seeds, const int64_t *queries, int64_t n_active, int64_t n_diff_allow,
                     double totdiam, int32_t k, void *hits, void *d_hits, int64_t *best_j);
 /* The k records of seed number `slot` of the last vft_sweep_batch (slot 0: of the last vft_sweep) where the selection left them - the
