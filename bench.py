@@ -568,6 +568,8 @@ def main():
             if which == "c4" and args.no_e2e_c4:
                 continue
             e2e, ok = None, 1.0
+            if rank == 0:
+                print("bench.py: %.0f s - end-to-end tree %s" % (time.perf_counter() - T_START, which), file=sys.stderr, flush=True)
             try:
                 e2e = end_to_end(which, local_rank, comm)
             except Exception as exc:   # the headline line must still be printed
@@ -607,6 +609,7 @@ def main():
                 if time.perf_counter() - T_START > args.time_budget:
                     line[key] = {"workload": which, "skipped": "time budget of %.0f s used up" % args.time_budget}
                     continue
+                print("bench.py: %.0f s - complete pipeline %s" % (time.perf_counter() - T_START, key), file=sys.stderr, flush=True)
                 try:
                     line[key] = end_to_end_full(which, local_rank, one)
                 except Exception as exc:

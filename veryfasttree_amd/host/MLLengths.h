@@ -736,11 +736,33 @@ namespace veryfasttree {
             std::vector<int64_t> ids, li, pi, pj;
             std::vector<vft_quartet_nni> res;
             std::vector<REAL> d, w;
+            /* (VFT_LANE_STATS: where a lockstep step's wall-clock goes - the lanes' host walks, the chain launches, the batch of quartets
+               with its wait, the verdicts applied on the host) */
+            static const bool laneStats = std::getenv("VFT_LANE_STATS") != nullptr;
+            double tAdvance = 0, tChains = 0, tBatch = 0, tApply = 0;
+            int64_t steps0 = laneSteps;
+            auto now = []() { return std::chrono::steady_clock::now(); };
+            auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+            struct Report {
+                const bool on;
+                const double &a, &c, &b, &p;
+                const int64_t &s0, &s1;
+                const size_t nLanes;
+                const bool ml;
+                ~Report() {
+                    if (on && s1 > s0)
+                        fprintf(stderr, "lanes (%s, %zu lanes): %lld lockstep steps; host walks %.3f s, chains %.3f s, quartet batches %.3f s, verdicts %.3f s\n", ml ? "ML" : "ME", nLanes,
+                                (long long) (s1 - s0), a, c, b, p);
+                }
+            } report{laneStats, tAdvance, tChains, tBatch, tApply, steps0, laneSteps, lanes.size(), prm.useML};
             for (;;) {
+                std::chrono::steady_clock::time_point t0 = now();
                 for (Lane &ln: lanes)
                     if (!ln.finished && !ln.hasRequest) advanceNNILane(ln, prm, traversal, upHave);
+                if (laneStats) { tAdvance += since(t0); t0 = now(); }
                 runShared(prm.useML);
                 runChains(lanes, prm.useML);
+                if (laneStats) { tChains += since(t0); t0 = now(); }
                 asking.clear();
                 for (Lane &ln: lanes)
                     if (ln.hasRequest) asking.push_back(&ln);
@@ -817,6 +839,7 @@ namespace veryfasttree {
                     } else
                     chk(vft_profile_distances(ctx, (int64_t) (6 * K), pi.data(), pj.data(), d.data(), w.data()));
                 }
+                if (laneStats) { tBatch += since(t0); t0 = now(); }
                 for (size_t t = 0; t < K; t++) {
                     Lane &ln = *asking[t];
                     int choice = 0;
@@ -840,6 +863,7 @@ namespace veryfasttree {
                     cur = nullptr;
                     ln.hasRequest = false;
                 }
+                if (laneStats) tApply += since(t0);
             }
         }
 
