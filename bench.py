@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-e2e-c4-full", action="store_true", help="skip the complete -nt pipeline of config C4 (1M x 200; ~9 minutes on one GPU)")
     ap.add_argument("--no-e2e-c5-one-thread", action="store_true", help="skip config C5's complete pipeline in the reference's one-thread order (~6 minutes)")
     ap.add_argument("--time-budget", type=float, default=1500.0, help="seconds after which the remaining complete pipelines are skipped (and reported as skipped)")
+    ap.add_argument("--child", default=None, help=argparse.SUPPRESS)   # (internal: "main" = the step measurement alone, or the key of one end-to-end leg)
+    ap.add_argument("--in-process", action="store_true", help="run the end-to-end legs inside this process instead of one child process each")
     return ap.parse_args()
 
 
@@ -346,6 +348,56 @@ def launch_ranks(args):
     sys.exit(res.returncode)
 
 
+# the end-to-end legs of a single-GPU run: key -> (kind, config, one-thread order)
+LEGS = [("e2e", "tree", "c3", False), ("e2e_c4", "tree", "c4", False), ("e2e_c2", "full", "c2", True), ("e2e_c2_threads", "full", "c2", False),
+        ("e2e_c5_threads", "full", "c5", False), ("e2e_c4_full_threads", "full", "c4", False), ("e2e_c5", "full", "c5", True)]
+
+
+def wanted_legs(args):
+    out = []
+    for key, kind, which, one in LEGS:
+        if kind == "tree" and which == "c4" and args.no_e2e_c4:
+            continue
+        if kind == "full" and (args.no_e2e_full or (key == "e2e_c4_full_threads" and args.no_e2e_c4_full) or (key == "e2e_c5" and args.no_e2e_c5_one_thread)):
+            continue
+        out.append((key, kind, which, one))
+    return out
+
+
+def run_leg(key):
+    """one end-to-end leg in this process; its record as a JSON line on stdout (the child of launch_legs)"""
+    kind, which, one = next((k, w, o) for kk, k, w, o in LEGS if kk == key)
+    rec = end_to_end(which, 0) if kind == "tree" else end_to_end_full(which, 0, one)
+    print(json.dumps(rec))
+
+
+def launch_legs(args):
+    """N = 1 with end-to-end legs: this process never touches the GPU.  The step measurement runs as one child process, every end-to-end
+    tree / complete pipeline as a child of its own (a fresh process per tree, as a user would run them; a leg that fails - or takes the
+    process down with it - costs its own record, not the line), and the records are merged into the ONE JSON line printed here."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    passed = [a for a in sys.argv[1:]]
+    res = subprocess.run([sys.executable, me] + passed + ["--child", "main"], stdout=subprocess.PIPE)
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    if res.returncode != 0 or not lines:
+        sys.stdout.write(res.stdout.decode())
+        sys.exit(res.returncode or 1)
+    line = json.loads(lines[-1])
+    for key, kind, which, one in wanted_legs(args):
+        if kind == "full" and time.perf_counter() - T_START > args.time_budget:
+            line[key] = {"workload": which, "skipped": "time budget of %.0f s used up" % args.time_budget}
+            continue
+        print("bench.py: %.0f s - %s" % (time.perf_counter() - T_START, key), file=sys.stderr, flush=True)
+        r = subprocess.run([sys.executable, me, "--child", key], stdout=subprocess.PIPE)
+        recs = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if r.returncode == 0 and recs:
+            line[key] = json.loads(recs[-1])
+        else:
+            line[key] = {"workload": which, "error": "the leg's process ended with code %d" % r.returncode}
+    print(json.dumps(line))
+
+
 def launch_only(args, world, rank):
     """test hook (VFT_BENCH_LAUNCH_ONLY=1, CPU): the launcher, the rendezvous and one collective, no GPU work"""
     import torch
@@ -369,6 +421,13 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if os.environ.get("VFT_BENCH_LAUNCH_ONLY"):
         return launch_only(args, world, int(os.environ.get("RANK", "0")))
+    single = world == 1 and not os.environ.get("VFT_BENCH_FORCE_DIST")
+    if args.child and args.child != "main":
+        return run_leg(args.child)
+    if single and args.child is None and not args.in_process and not args.no_e2e and wanted_legs(args):
+        return launch_legs(args)
+    if args.child == "main":
+        args.no_e2e = True
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1071,8 +1071,12 @@ namespace veryfasttree {
             }
             int64_t nSPR = 0;
             WalkServerGuard server(*this);
-            for (int64_t node: nodeList)
+            static const bool stageTrace = std::getenv("VFT_STAGE_TRACE") != nullptr;
+            int64_t nDone = 0;
+            for (int64_t node: nodeList) {
                 if (sprAttempt(node, scoredist, maxSPRLength, upHave)) nSPR++;
+                if (stageTrace && (++nDone % 100000) == 0) fprintf(stderr, "[stage]   SPR: %lld of %zu nodes, %lld steps, %lld moves\n", (long long) nDone, nodeList.size(), (long long) sprSteps, (long long) nSPR);
+            }
             server.finish();
             rebuildOrder();
             return nSPR;

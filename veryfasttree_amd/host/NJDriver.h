@@ -751,8 +751,10 @@ namespace veryfasttree {
                 if (sprRemaining > 0 && nniToDo / (spr + 1) > 0 && ((i + 1) % (nniToDo / (spr + 1))) == 0) {
                     {
                         const std::chrono::steady_clock::time_point ts = std::chrono::steady_clock::now();
+                        if (std::getenv("VFT_STAGE_TRACE")) fprintf(stderr, "[stage] SPR round begins after %lld NNI rounds\n", (long long) (i + 1));
                         meSPRs += tree.doSPR(opt.scoredist);
                         meSPRSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+                        if (std::getenv("VFT_STAGE_TRACE")) fprintf(stderr, "[stage] SPR round done: %.1f s of SPR so far, %lld moves\n", meSPRSeconds, (long long) meSPRs);
                     }
                     sprRemaining--;
                     bConverged = false;

@@ -187,9 +187,12 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     recordJoinCrc(drv.run(-1));
     drv.finishRoot();
     gStage[0] = since(t0);
+    static const bool stageTrace = std::getenv("VFT_STAGE_TRACE") != nullptr;   /* tools: the stages as they end, on stderr */
+    if (stageTrace) fprintf(stderr, "[stage] NJ phase done after %.1f s\n", gStage[0]);
     t0 = now();
     if (o && o->me_nni) drv.meNNIRounds(o->spr);
     gStage[1] = since(t0);
+    if (stageTrace) fprintf(stderr, "[stage] minimum-evolution NNIs + SPR done after %.1f s\n", gStage[1]);
     gStage[2] = drv.meSPRSeconds;
     t0 = now();
     if (meLengths) drv.updateBranchLengths();
