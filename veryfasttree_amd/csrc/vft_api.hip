@@ -1,6 +1,8 @@
 // C-ABI implementation (include/vft_hip.h): context, arena allocation, launches.
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
+#include <csignal>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -331,8 +333,23 @@ static SweepOut<REAL> sweepout(const vft_ctx *c, int slot = 0) {
 static vft_ctx *g_walkServerOwner = nullptr;   // the context whose walk server is resident (one per process)
 static unsigned long long *g_wsTicks = nullptr;   // phase clock ticks of the walk server's workgroup 0 (written by -DVFT_WALK_TIMING builds only)
 static int walk_server_retire(vft_ctx *c);
+// tools (VFT_LAUNCH_TRACE=1, with AMD_SERIALIZE_KERNEL=3 so that a launch has finished before the next one is recorded): the kernel
+// launched last, printed when the process is aborted - a GPU memory fault ends the process without saying whose it was
+static const bool g_launchTrace = getenv("VFT_LAUNCH_TRACE") != nullptr;
+static const void *volatile g_lastKernel = nullptr;
+static volatile unsigned long long g_launchCount = 0;
+static void launch_trace_abort(int) {
+    const char *name = g_lastKernel ? hipKernelNameRefByPtr((const void *) g_lastKernel, nullptr) : "(none)";
+    fprintf(stderr, "[launch trace] aborted; last kernel launched: %s (launch %llu); walk server %s\n", name ? name : "?", (unsigned long long) g_launchCount,
+            g_walkServerOwner ? "resident" : "not running");
+    _exit(134);
+}
 template <typename... KArgs, typename... Args>
 static inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args... args) {
+    if (g_launchTrace) {
+        g_lastKernel = (const void *) k;
+        g_launchCount = g_launchCount + 1;
+    }
     // a context whose walk server is resident owns its rows through the server: anything else launched on that context's stream
     // first retires the server (the refinement code stops it itself; this is the safety net)
     if (g_walkServerOwner && g_walkServerOwner->stream == s) walk_server_retire(g_walkServerOwner);
@@ -410,6 +427,7 @@ static int raise_pair_kernel_lds(vft_ctx *c);   // defined next to the kernels i
 extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     if (!out || !cfg) return VFT_ERR_INVALID;
     *out = nullptr;
+    if (g_launchTrace) signal(SIGABRT, launch_trace_abort);
     vft_ctx *c = new (std::nothrow) vft_ctx();
     if (!c) return VFT_ERR_INVALID;
     c->cfg = *cfg;
