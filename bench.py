@@ -422,6 +422,11 @@ def main():
     if os.environ.get("VFT_BENCH_LAUNCH_ONLY"):
         return launch_only(args, world, int(os.environ.get("RANK", "0")))
     single = world == 1 and not os.environ.get("VFT_BENCH_FORCE_DIST")
+    if args.child and os.environ.get("VFT_BENCH_FAKE_CHILD"):   # test hook (CPU): canned records, the leg named by the variable dies
+        if args.child == os.environ["VFT_BENCH_FAKE_CHILD"]:
+            os._exit(139)
+        print(json.dumps({"metric": "profile-ops/sec", "value": 1.0} if args.child == "main" else {"workload": args.child, "wall_s": 1.0}))
+        return
     if args.child and args.child != "main":
         return run_leg(args.child)
     if single and args.child is None and not args.in_process and not args.no_e2e and wanted_legs(args):
@@ -623,8 +628,11 @@ def main():
             from veryfasttree_amd.backend import TorchComm
             comm = TorchComm(dist, local_rank)
             barrier()
+        only = [k for k in os.environ.get("VFT_BENCH_ONLY_LEGS", "").split(",") if k]   # (tools: a subset of the legs, in-process runs)
         for which, key in (("c3", "e2e"), ("c4", "e2e_c4")):
             if which == "c4" and args.no_e2e_c4:
+                continue
+            if only and key not in only:
                 continue
             e2e, ok = None, 1.0
             if rank == 0:
@@ -665,6 +673,8 @@ def main():
             if not args.no_e2e_c5_one_thread:
                 legs.append(("e2e_c5", "c5", True))
             for key, which, one in legs:
+                if only and key not in only:
+                    continue
                 if time.perf_counter() - T_START > args.time_budget:
                     line[key] = {"workload": which, "skipped": "time budget of %.0f s used up" % args.time_budget}
                     continue

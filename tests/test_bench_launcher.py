@@ -40,3 +40,19 @@ def test_a_failing_rank_fails_the_launcher():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=600)
     assert res.returncode != 0
+
+
+def test_single_gpu_launcher_merges_its_children_and_survives_a_dying_leg():
+    """At N = 1 bench.py is a launcher that never touches the GPU: the step measurement and every end-to-end leg are child processes,
+    their records are merged into one line, and a leg whose process dies (here: killed by the test hook) costs its own record only."""
+    env = dict(os.environ, VFT_BENCH_FAKE_CHILD="e2e_c2_threads")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-e2e-c5-one-thread"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["metric"] == "profile-ops/sec"
+    assert [k for k in line if k.startswith("e2e")] == ["e2e", "e2e_c4", "e2e_c2", "e2e_c2_threads", "e2e_c5_threads", "e2e_c4_full_threads"]
+    assert "error" in line["e2e_c2_threads"] and line["e2e_c5_threads"]["wall_s"] == 1.0
