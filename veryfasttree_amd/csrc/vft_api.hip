@@ -532,7 +532,9 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(dalloc(&c->sel, 1));
     CR(dalloc(&c->slices, (size_t) VFT_SEL_WGS * VFT_NBINS));
     CR(dalloc(&c->candKey, (size_t) VFT_CAND_CAP));
+    CR(hipMemset(c->candKey, 0, (size_t) VFT_CAND_CAP * 8));
     CR(dalloc(&c->candId, (size_t) VFT_CAND_CAP));
+    CR(hipMemset(c->candId, 0, (size_t) VFT_CAND_CAP * 4));
     c->hitsCap = VFT_CAND_CAP;
     CR(dallocb((void **) &c->dRes, sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64)));
     CR(hipHostMalloc((void **) &c->hRes, sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64), hipHostMallocMapped));
@@ -1836,6 +1838,9 @@ static int ensure_slots(vft_ctx *c, int count) {
         HIPCHK(c, hipMalloc((void **) &h.slices, (size_t) VFT_SEL_WGS * VFT_NBINS * 4));
         HIPCHK(c, hipMalloc((void **) &h.candKey, (size_t) VFT_CAND_CAP * 8));
         HIPCHK(c, hipMalloc((void **) &h.candId, (size_t) VFT_CAND_CAP * 4));
+        HIPCHK(c, hipMemset(h.candKey, 0, (size_t) VFT_CAND_CAP * 8));   // (never read before written since k_select_rank skips overflowed collections; zeroed all the same)
+        HIPCHK(c, hipMemset(h.candId, 0, (size_t) VFT_CAND_CAP * 4));
+        HIPCHK(c, hipMemset(h.sel, 0, sizeof(SelectState)));
         const size_t resB = sizeof(SelectHeader) + (size_t) c->hitsCap * sizeof(vft_hit_f64);
         HIPCHK(c, hipMalloc((void **) &h.dRes, resB));
         HIPCHK(c, hipHostMalloc((void **) &h.hRes, resB, hipHostMallocMapped));

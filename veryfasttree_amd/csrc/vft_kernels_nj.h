@@ -1936,7 +1936,11 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     HIT *hits = (HIT *) sl.hits;
     __shared__ uint64_t sk[VFT_RANK_TILE];
     __shared__ int32_t si[VFT_RANK_TILE];
-    const unsigned int n = S->nCand < VFT_CAND_CAP ? S->nCand : VFT_CAND_CAP;
+    // An overflowed collection (more candidates than the buffer takes: the host narrows the key range and repeats) has counted
+    // candidates it never stored - those entries hold whatever the memory held before, and an id read from there indexed the
+    // result arrays (a memory access fault once the allocator handed out recycled blocks: the seed batches of a second tree in
+    // one process).  Its records are discarded anyway: rank nothing, publish empty records and the overflow flag.
+    const unsigned int n = S->overflow ? 0u : (S->nCand < VFT_CAND_CAP ? S->nCand : VFT_CAND_CAP);
     const unsigned int perWg = VFT_WG / VFT_RANK_LANES;
     const unsigned int span = n > (unsigned int) k ? n : (unsigned int) k;
     if (blockIdx.x * perWg >= span) return;   // whole workgroup idle (not counted below)
