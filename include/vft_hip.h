@@ -464,6 +464,7 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_NO_WALK_SERVER 9      /* value != 0: vft_walk_server_start answers VFT_ERR_STATE - the walks keep one launch per step (tests compare) */
 #define VFT_DEBUG_WALK_DEVICE_MAILBOX 10 /* value != 0: the server's mailbox in device memory written through the PCIe aperture (large-BAR boxes) instead of pinned host memory */
 #define VFT_DEBUG_WALK_SERVER_STRIDE 11 /* 1: the server's six workgroups on six XCDs instead of one (placement is for speed only; tests run both) */
+#define VFT_DEBUG_POISON_SELECTION 14    /* fills the selection's candidate buffers of every slot with 0x7f bytes - what a recycled allocation holds - before the next sweep (tests: a collection that overflows must not look at entries it never stored) */
 #define VFT_DEBUG_NO_MULTI_SWEEP 12     /* value != 0: vft_sweep_batch sweeps its leaf seeds one launch each instead of four per pass over the targets (tests compare) */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 

@@ -467,3 +467,38 @@ def test_pair_list_with_refreshes_in_one_call(fused, monkeypatch):
             assert np.array_equal(mo[far], o2.get_out_distances(0, n + nj)[0][far]), rep
         o1.close()
         o2.close()
+
+
+@pytest.mark.gpu
+def test_a_selection_that_overflows_does_not_look_at_what_it_never_stored():
+    """More candidates below the threshold digit than the candidate buffer takes (16 000 sequences one substitution away from a common
+    ancestor among 24 000 leaves of 800 columns: their criteria crowd into a sliver of the key range): the collection overflows, the host narrows the key range and repeats.  The
+    overflowed round counted candidates it never stored; ranking them read ids from whatever the buffer held (round 5: a GPU memory fault
+    in the second tree of a process, when the allocator handed out recycled blocks).  With the buffers poisoned the selection must still
+    return the k smallest records in the reference's order, one launch per seed and four seeds per pass alike."""
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.workload import TopHitsState
+    n, L, n_copies = 24000, 800, 16000
+    rng = np.random.default_rng(12)
+    codes = synth.random_descent_codes(n, L, 4, 0.3, 0.0, seed=3)
+    base = codes[0].copy()
+    for i in range(n_copies):   # near-copies of one sequence: one substitution each
+        row = base.copy()
+        pos = rng.choice(L, 1, replace=False)
+        row[pos] = (row[pos] + rng.integers(1, 4, len(pos))) % 4
+        codes[i] = row
+    ops = HipProfileOps(n, L, 4, np.float32)
+    st = TopHitsState(ops, codes, 64)
+    k = 2000
+    seeds = st.active[st.active < n_copies][:4]
+    ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)   # (the slots exist now)
+    ops.debug_option(14, 1)
+    hits, best = ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k)
+    ops.debug_option(14, 1)
+    h0, b0 = ops.setBestHit(int(seeds[0]), st.n_active, st.n_diff_allow, st.totdiam, k)
+    assert ops.sweep_info()[1] > 0, "the key range was not narrowed: this alignment no longer overflows the candidate buffer"
+    dist, weight, crit = ops.sweep_results(0, st.maxnode)
+    ids = np.nonzero(st.parent < 0)[0]
+    order = ids[np.lexsort((-ids, crit[ids]))][:k]
+    assert np.array_equal(h0["j"], order) and np.array_equal(h0["criterion"], crit[order])
+    assert b0 == best[0] and np.array_equal(h0, hits[0])

@@ -3976,6 +3976,12 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_WALK_DEVICE_MAILBOX: c->ws.wantDeviceMail = value != 0; break;
         case VFT_DEBUG_WALK_SERVER_STRIDE: c->ws.stride = value == 1 ? 1 : 8; break;
         case VFT_DEBUG_NO_MULTI_SWEEP: c->noMultiSweep = value != 0; break;
+        case VFT_DEBUG_POISON_SELECTION:   // the candidate buffers of every slot filled with 0x7f bytes: what recycled memory looks like
+            for (vft_ctx::SweepSlotHost &h: c->slots) {
+                HIPCHK(c, hipMemset(h.candKey, 0x7f, (size_t) VFT_CAND_CAP * 8));
+                HIPCHK(c, hipMemset(h.candId, 0x7f, (size_t) VFT_CAND_CAP * 4));
+            }
+            break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }
     return VFT_OK;
