@@ -1120,21 +1120,25 @@ namespace veryfasttree {
                 }
             }
             /* the weight of a candidate: the nodes `penalty` levels below it and deeper (what a walk may touch), 0 for
-               candidates too close to the deepest level */
-            std::vector<int64_t> weight(N, 0), frontier, next;
-            for (size_t i = 0; i < N; i++) {
-                if (deepest - depth[i] < penalty) continue;
-                frontier.assign(1, (int64_t) i);
-                for (int lv = 0; lv < penalty; lv++) {
-                    next.clear();
-                    for (int64_t v: frontier)
-                        for (int k = 0; k < 3 && child[3 * v + k] >= 0; k++) next.push_back(child[3 * v + k]);
-                    frontier.swap(next);
-                }
+               candidates too close to the deepest level.  Worked out when a node becomes a candidate (a few thousand of two million
+               nodes do: filling the table for every node was a third of a partition, and a round of a million-sequence tree partitions
+               once) */
+            std::vector<int64_t> weight(N, -1), frontier, next;
+            auto weigh = [&](int64_t i) {
+                if (weight[(size_t) i] >= 0) return;
                 int64_t w = 0;
-                for (int64_t v: frontier) w += size[(size_t) v];
-                weight[i] = w;
-            }
+                if (deepest - depth[(size_t) i] >= penalty) {
+                    frontier.assign(1, i);
+                    for (int lv = 0; lv < penalty; lv++) {
+                        next.clear();
+                        for (int64_t v: frontier)
+                            for (int k = 0; k < 3 && child[3 * v + k] >= 0; k++) next.push_back(child[3 * v + k]);
+                        frontier.swap(next);
+                    }
+                    for (int64_t v: frontier) w += size[(size_t) v];
+                }
+                weight[(size_t) i] = w;
+            };
             const size_t T = (size_t) threads;
             auto speedup = [&](const std::vector<int64_t> &sol) -> double {
                 int64_t denom;
@@ -1161,6 +1165,7 @@ namespace veryfasttree {
             std::vector<int64_t> sol, best;   /* ascending weight; a newcomer goes in front of its equals */
             auto lighter = [&](int64_t x, int64_t y) { return weight[(size_t) x] < weight[(size_t) y]; };
             auto put = [&](int64_t v) {
+                weigh(v);
                 if (weight[(size_t) v] > 0) sol.insert(std::lower_bound(sol.begin(), sol.end(), v, lighter), v);
             };
             for (int k = 0; k < 3; k++) put(child[3 * root + k]);
