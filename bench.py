@@ -429,7 +429,8 @@ def main():
         return
     if args.child and args.child != "main":
         return run_leg(args.child)
-    if single and args.child is None and not args.in_process and not args.no_e2e and wanted_legs(args):
+    # (the end-to-end legs belong to the headline workload: a reduced --n-seqs / --n-pos run is the step measurement alone, in this process)
+    if single and args.child is None and not args.in_process and not args.no_e2e and (args.n_seqs, args.n_pos) == (1000000, 200) and wanted_legs(args):
         return launch_legs(args)
     if args.child == "main":
         args.no_e2e = True
