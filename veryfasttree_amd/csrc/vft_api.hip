@@ -1830,7 +1830,10 @@ static int ensure_slots(vft_ctx *c, int count) {
     while ((int) c->slots.size() < count) {
         vft_ctx::SweepSlotHost h;
         void **reals[] = {&h.swDist, &h.swWeight, &h.swCrit};
-        for (void **p: reals) HIPCHK(c, hipMalloc(p, (size_t) N * rs));
+        for (void **p: reals) {
+            HIPCHK(c, hipMalloc(p, (size_t) N * rs));
+            HIPCHK(c, hipMemset(*p, 0, (size_t) N * rs));   // (as slot 0's arrays in vft_create)
+        }
         const size_t nPartCap = (size_t) cdiv(N, VFT_WG);
         HIPCHK(c, hipMalloc(&h.partMin, nPartCap * 8));
         HIPCHK(c, hipMalloc(&h.partMax, nPartCap * 8));
