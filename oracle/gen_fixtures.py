@@ -660,12 +660,26 @@ def gen_c4_prefix(tmp):
     phase takes it more than half a day at one thread): CRC-32 per 10 000 complete `Join` lines.  Pins the join order of
     config C4 up to the join the reference had reached when this was written."""
     import zlib
-    joins = []
-    for line in open(os.path.join(HERE, "_ref", "c4_joins.txt")):
-        f = line.rstrip("\n").split("\t")
-        if len(f) < 11 or not line.endswith("\n"):
-            break
-        joins.append((int(f[1]), int(f[2]), int(f[10])))
+    # the longest trace there is: round 3's (c4_joins.txt, the reference binary at -verbose 3) or a later run of oracle/njtrace at one
+    # thread (c4_joins_t1_r05.txt: its log keeps the progress lines too) - the same joins line for line as far as both go
+    best = []
+    for name in ("c4_joins.txt", "c4_joins_t1_r05.txt"):
+        path = os.path.join(HERE, "_ref", name)
+        if not os.path.exists(path):
+            continue
+        joins = []
+        for line in open(path):
+            if not line.startswith("Join"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            if len(f) < 11 or not line.endswith("\n"):
+                break
+            joins.append((int(f[1]), int(f[2]), int(f[10])))
+        if best and joins[:min(len(best), len(joins))] != best[:min(len(best), len(joins))]:
+            raise SystemExit("the two traces of the one-thread reference disagree: %s" % name)
+        if len(joins) > len(best):
+            best = joins
+    joins = best
     chunk = 10000
     ja = np.array(joins[:len(joins) // chunk * chunk], dtype=np.int64)
     crcs = np.array([zlib.crc32(ja[k:k + chunk].astype("<i4").tobytes()) for k in range(0, len(ja), chunk)], dtype=np.int64)
