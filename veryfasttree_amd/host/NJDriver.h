@@ -2166,6 +2166,7 @@ namespace veryfasttree {
             }
             seedSweepsWasted += (int64_t) seedAhead.size();
             seedAhead.clear();
+            if (profiling) acc["[count]  setAllLeafTopHits: seed sweeps taken ahead and dropped (their seed became a close neighbour first)"].calls += seedSweepsWasted;
             for (int64_t node = 0; node < n; node++) visible[node] = hits[node][0];
             /* checking phase, NJ.tcc:4052-4119 */
             const int64_t nCheck = q > 0 ? q : (int64_t) (0.5 + 2.0 * std::sqrt((double) m));
