@@ -1104,6 +1104,11 @@ namespace veryfasttree {
         static std::vector<int64_t> partitionTree(int64_t nNodes, const std::vector<int64_t> &child, int64_t root, const std::vector<int64_t> &order,
                                                   int penalty, int threads, int window, double *speedupOut) {
             const size_t N = (size_t) nNodes;
+            const bool ptTrace = std::getenv("VFT_PARTITION_TRACE") != nullptr;
+            const std::chrono::steady_clock::time_point pt0 = std::chrono::steady_clock::now();
+            auto ptMark = [&](const char *what) {
+                if (ptTrace) fprintf(stderr, "[partition] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - pt0).count());
+            };
             std::vector<int64_t> size(N, 1), depth(N, 0);
             for (int64_t v: order) {   /* children before parents */
                 int64_t w = 1;
@@ -1119,6 +1124,7 @@ namespace veryfasttree {
                     if (depth[(size_t) c] > deepest) deepest = depth[(size_t) c];
                 }
             }
+            ptMark("sizes and depths");
             /* the weight of a candidate: the nodes `penalty` levels below it and deeper (what a walk may touch), 0 for
                candidates too close to the deepest level.  Worked out when a node becomes a candidate (a few thousand of two million
                nodes do: filling the table for every node was a third of a partition, and a round of a million-sequence tree partitions
@@ -1193,6 +1199,7 @@ namespace veryfasttree {
                     bestSpeedup = cur;
                 }
             }
+            ptMark("splitting loop");
             /* the hand-out: lightest first, each to the least loaded thread (ties: the thread that was touched longest ago,
                initially the last); the list is read thread-major per round, which is the order returned */
             std::vector<std::vector<int64_t>> mine(T);
