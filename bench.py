@@ -272,7 +272,8 @@ E2E_FULL = {
     # fit, SH-like supports).  threads: the reference's `-threads T` schedule this backend follows for the refinement stages
     # (host/MLLengths.h "the subtree schedule": the walks of T-thread partitions advanced in lockstep, batches of quartets on the GPU).
     "c2": dict(n=10000, L=1000, nc=4, seed=2, dtype="float32", gtr=True, aa=None, threads=64, flags="-nt -gtr", golden="bb_c2_crc.npz"),
-    "c5": dict(n=50000, L=300, nc=20, seed=2, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden="bb_c5_crc.npz"),
+    # (C5 = SURVEY.md 8(d)'s alignment: mu 0.08, gaps 0.02, seed 5; rounds 4-5 ran C2's generator parameters here by mistake)
+    "c5": dict(n=50000, L=300, nc=20, seed=5, mu=0.08, gap=0.02, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden="bb_c5_crc.npz"),
     # config C4 with its real flags (9 minutes)
     "c4": dict(n=1000000, L=200, nc=4, seed=4, mu=0.02, dtype="float32", gtr=False, aa=None, threads=1024, flags="-nt", golden=None),
 }
@@ -289,7 +290,7 @@ def end_to_end_full(which, device, one_thread, comm=None):
     from veryfasttree_amd.backend import nj_newick, last_stage_seconds
     cfg = E2E_FULL[which]
     dt = np.float64 if cfg["dtype"] == "float64" else np.float32
-    codes = synth.random_descent_codes(cfg["n"], cfg["L"], cfg["nc"], cfg.get("mu", 0.03), 0.01, seed=cfg["seed"])
+    codes = synth.random_descent_codes(cfg["n"], cfg["L"], cfg["nc"], cfg.get("mu", 0.03), cfg.get("gap", 0.01), seed=cfg["seed"])
     names = ["s%d" % k for k in range(cfg["n"])]
     T = 1 if one_thread else cfg["threads"]
     kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True, threads=T)
@@ -314,14 +315,16 @@ def end_to_end_full(which, device, one_thread, comm=None):
         out["allgather_bytes_by_phase"] = {"sweep_lists_device": int(comm.device_bytes), "ml_lanes": int(lane_bytes),
                                            "other_host": int(comm.bytes - comm.device_bytes - lane_bytes)}
         out["ml_lane_allgathers"] = int(lane_calls)
-    # the compiled reference with the same flags on the host cores of a GPU box of this pool (tools/reference_walls.py; not this run's box)
+    # The compiled reference with the same flags, timed by the builder on the host cores of ANOTHER box of this pool (tools/reference_walls.py
+    # in round 5 -> the file named in `source`): a record carried along, not a measurement of this run.
     walls = os.path.join(ROOT, "profiles", "r05_reference_walls_gpu_box.json")
     if os.path.exists(walls):
         w = json.load(open(walls))
         rec = w.get("%s_threads_%d" % (which, T))
-        if rec:
-            out["reference_on_gpu_box_host"] = dict(wall_s=rec["wall_s"], threads=T, cpu=w.get("cpu"), cores=w.get("cores"),
-                                                    same_tree_as_this_run=bool(rec.get("newick_crc") == out["newick_crc"]))
+        if rec and not (which == "c5" and w.get("c5_alignment") != "random_descent_codes(50000, 300, 20, 0.08, 0.02, seed=5)"):
+            out["reference_on_a_pool_box_builder_run"] = dict(wall_s=rec["wall_s"], threads=T, cpu=w.get("cpu"), cores=w.get("cores"),
+                                                              source="profiles/r05_reference_walls_gpu_box.json (not measured in this run)",
+                                                              same_tree_as_this_run=bool(rec.get("newick_crc") == out["newick_crc"]))
     if one_thread and cfg["golden"] and os.path.exists(os.path.join(ROOT, "tests", "golden", cfg["golden"])):
         g = np.load(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
         out["reference_newick_crc"] = int(g["newick_crc"])
@@ -371,10 +374,17 @@ def run_leg(key):
     print(json.dumps(rec))
 
 
+# what a leg took on the driver's box last round (BENCH_r05.json; C5's legs are on SURVEY 8(d)'s alignment from round 6 on and cost more):
+# a leg is skipped when the time used so far plus this figure would pass --time-budget, so that the driver's clock cannot run out inside it
+LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 60.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 90.0, "e2e_c4_full_threads": 470.0, "e2e_c5": 520.0}
+
+
 def launch_legs(args):
     """N = 1 with end-to-end legs: this process never touches the GPU.  The step measurement runs as one child process, every end-to-end
     tree / complete pipeline as a child of its own (a fresh process per tree, as a user would run them; a leg that fails - or takes the
-    process down with it - costs its own record, not the line), and the records are merged into the ONE JSON line printed here."""
+    process down with it - costs its own record, not the line).  The merged JSON line is printed after the step measurement and AGAIN
+    after every leg, each time a superset of the one before (the last complete line is the result): whatever ends this process early,
+    the headline and every leg finished by then are on stdout."""
     import subprocess
     me = os.path.abspath(__file__)
     passed = [a for a in sys.argv[1:]]
@@ -384,18 +394,24 @@ def launch_legs(args):
         sys.stdout.write(res.stdout.decode())
         sys.exit(res.returncode or 1)
     line = json.loads(lines[-1])
-    for key, kind, which, one in wanted_legs(args):
-        if kind == "full" and time.perf_counter() - T_START > args.time_budget:
-            line[key] = {"workload": which, "skipped": "time budget of %.0f s used up" % args.time_budget}
+    legs = wanted_legs(args)
+    line["legs_pending"] = [k for k, _, _, _ in legs]
+    print(json.dumps(line), flush=True)
+    for key, kind, which, one in legs:
+        line["legs_pending"].remove(key)
+        used = time.perf_counter() - T_START
+        if used + LEG_WALL_S.get(key, 60.0) > args.time_budget:
+            line[key] = {"workload": which, "skipped": "%.0f s used, the leg needs ~%.0f s, time budget %.0f s" % (used, LEG_WALL_S.get(key, 60.0), args.time_budget)}
+            print(json.dumps(line), flush=True)
             continue
-        print("bench.py: %.0f s - %s" % (time.perf_counter() - T_START, key), file=sys.stderr, flush=True)
+        print("bench.py: %.0f s - %s" % (used, key), file=sys.stderr, flush=True)
         r = subprocess.run([sys.executable, me, "--child", key], stdout=subprocess.PIPE)
         recs = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
         if r.returncode == 0 and recs:
             line[key] = json.loads(recs[-1])
         else:
             line[key] = {"workload": which, "error": "the leg's process ended with code %d" % r.returncode}
-    print(json.dumps(line))
+        print(json.dumps(line), flush=True)
 
 
 def launch_only(args, world, rank):
@@ -557,31 +573,63 @@ def main():
     alg_sweep = float(ab["leaf"] + ab["internal"])            # the algorithm's bytes of ONE seed's sweep
     alg_main = alg_sweep * sweeps_per_launch                  # ... times the sweeps an average launch processes
     moved_main = float(ab["moved_leaf"] + ab["moved_internal"])   # what one pass over the targets moves, however many seeds ride on it
-    achieved = alg_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    # HBM traffic of the same kernels from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
-    # process): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, bytes per launch
+    # Counters of the same kernels from the rocprofv3 PMC passes kept under profiles/ (rocprofv3 cannot run inside this process;
+    # tools/profile_round.sh + tools/profile_collect.py -> profiles/traffic.json, used only while the hash of the sweep kernels'
+    # sources recorded there still matches - counters read from other kernel sources say nothing: null):
+    #   HBM bytes per launch = FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE
+    #   VALU instructions per launch = SQ_INSTS_VALU (wavefront instructions; x 64 lanes)
     traffic = None
+    pmc = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (n, L, world) == (1000000, 200, 1):
         t = json.load(open(tpath))
-        if t.get("kernel_sources_sha256") == sweep_kernel_hash():   # (counters read from other kernel sources say nothing: null)
-            traffic = t.get("sweep_launch_average", {}).get("bytes_per_launch")
-    def per_kind(ms, nl, ns):
+        if t.get("kernel_sources_sha256") == sweep_kernel_hash():
+            pmc = t.get("sweep_launch_average", {})
+            traffic = pmc.get("bytes_per_launch")
+    # peak VALU issue: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz (MI355X_MICROARCH.md) = 3.93e13 lane-instructions/s
+    VALU_PEAK = 256 * 64 * 2.4e9
+
+    def per_kind(ms, nl, ns, key):
         spl = ns / max(nl, 1)
-        return dict(avg_launch_ms=ms, sweeps_per_launch=spl, achieved_gbs=alg_sweep * spl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                    frac=alg_sweep * spl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
-                    moved_gbs=moved_main / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
+        rec = pmc.get(key, {})
+        out = dict(avg_launch_ms=ms, sweeps_per_launch=spl,
+                   algorithmic_equiv_gbs=alg_sweep * spl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                   moved_model_gbs=moved_main / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
+        if rec.get("bytes_per_launch") and ms > 0:
+            out["hbm_bytes_per_launch_pmc"] = int(rec["bytes_per_launch"])
+            out["hbm_frac_physical"] = rec["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if rec.get("valu_wave_insts_per_launch") and ms > 0:
+            out["valu_lane_insts_per_launch"] = int(rec["valu_wave_insts_per_launch"] * 64)
+            out["valu_frac"] = rec["valu_wave_insts_per_launch"] * 64 / (ms * 1e-3) / VALU_PEAK
+            if rec.get("valu_busy_frac_pmc") is not None:
+                out["valu_busy_frac_pmc"] = rec["valu_busy_frac_pmc"]
+        return out
+
+    # `achieved` / `frac` price what the memory system SEES: the bytes one launch moves (the PMC figure while it belongs to these
+    # kernel sources, else the layout model of workload.py) / the launch's duration - never above the peak.  With S seeds sharing a
+    # pass (vft_sweep_batch) the algorithm's own byte count, SURVEY 8(d)'s per-sweep figure x the sweeps a launch carries, is an
+    # EQUIVALENT rate only (`algorithmic_equiv_gbs`: what a seed-by-seed stream would have to sustain) and is not divided by the peak.
+    phys = float(traffic) if traffic else moved_main
+    achieved = phys / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    valu = None
+    if pmc.get("valu_wave_insts_per_launch") and kern_ms > 0:
+        li = pmc["valu_wave_insts_per_launch"] * 64.0
+        valu = dict(lane_insts_per_launch=int(li), achieved_lane_insts_per_s=li / (kern_ms * 1e-3), peak_lane_insts_per_s=VALU_PEAK,
+                    frac=li / (kern_ms * 1e-3) / VALU_PEAK, source="profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)")
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="k_sweep_nt_both<float> (a profile seed per launch) / k_sweep_nt_leafq_multi<float,4> (four leaf seeds per launch)", launches=int(launches),
-                    sweeps=int(sweeps), avg_launch_ms=kern_ms, algorithmic_bytes_per_sweep=int(alg_sweep), algorithmic_bytes_per_launch=int(alg_main),
-                    moved_bytes_per_launch=int(moved_main),
-                    achieved_moved_gbs=moved_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
-                    frac_moved=moved_main / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0,
+                    traffic=traffic, bytes_source="pmc" if traffic else "layout_model",
+                    limited_by="valu (instruction issue: S seeds share one pass over the targets, the stream is read once per S sweeps)",
+                    valu=valu,
+                    kernel="k_sweep_nt_profq_multi<float,4> (four profile seeds per launch) / k_sweep_nt_leafq_multi<float,4> (four leaf seeds per launch)",
+                    launches=int(launches), sweeps=int(sweeps), sweeps_per_launch=sweeps_per_launch, avg_launch_ms=kern_ms,
+                    algorithmic_bytes_per_sweep=int(alg_sweep), algorithmic_bytes_per_launch=int(alg_main),
+                    algorithmic_equiv_gbs=alg_main / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
+                    moved_bytes_per_launch_model=int(moved_main),
                     phi=ab["phi"],
-                    profile_seed_launch=per_kind(prof_ms, n_prof_launches, n_prof_sweeps) if not use_dist else None,
-                    leaf_seed_launch=per_kind(leaf_ms, n_leaf_launches, n_leaf_sweeps) if not use_dist else None,
-                    step=dict(algorithmic_bytes=int(alg_sweep * len(seeds)), achieved_gbs=alg_sweep * len(seeds) / (elapsed / args.steps) / 1e9,
-                              frac=alg_sweep * len(seeds) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS))
+                    profile_seed_launch=per_kind(prof_ms, n_prof_launches, n_prof_sweeps, "profile_seed_instance") if not use_dist else None,
+                    leaf_seed_launch=per_kind(leaf_ms, n_leaf_launches, n_leaf_sweeps, "leaf_seed_instance") if not use_dist else None,
+                    step=dict(algorithmic_bytes=int(alg_sweep * len(seeds)), algorithmic_equiv_gbs=alg_sweep * len(seeds) / (elapsed / args.steps) / 1e9))
+    assert roofline["frac"] <= 1.0, "a physical fraction above the peak: the byte count is wrong"
 
     line = dict(metric="profile-ops/sec", value=value, unit="profile-ops/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,

@@ -291,6 +291,8 @@ int vft_merge_hits_batch(vft_ctx *ctx, const void *d_all, int32_t n_lists, int32
 /* Diagnostics of the last sweep's top-k selection: info[0] = candidates that were rank-sorted, info[1] = extra
    refinement rounds that were needed (0 in the common case). */
 int vft_sweep_info(vft_ctx *ctx, int64_t info[2]);
+/* the same for slot `slot` of the last vft_sweep_batch */
+int vft_sweep_batch_info(vft_ctx *ctx, int32_t slot, int64_t info[2]);
 /* The full, unsorted result of the last sweep for ids [first, first+count): what `allhits[]` holds. */
 int vft_sweep_results(vft_ctx *ctx, int64_t first, int64_t count, void *dist, void *weight, void *criterion);
 /* setDistCriterion on an explicit pair list — transferBestHits / uniqueBestHits / getBestFromTopHits

@@ -426,6 +426,42 @@ def gen_threads(tmp, only=None):
                                                                                       "differs from" if one.stdout != res2.stdout else "EQUALS"))
 
 
+def gen_threads_big(tmp, n=200000, threads=64):
+    """The subtree schedule far beyond toy size: config C4's generator at n sequences, `VeryFastTree -nt -threads T -seed 1` (the whole
+    default pipeline, Jukes-Cantor + CAT, SH-like supports; under Jukes-Cantor the reference's threaded runs are reproducible, see
+    THREADS_CASES).  Kept: CRC-32 and length of the tree, the TreeLogLk lines -> thr_c4_<n/1000>k_t<T>_crc.npz.  The files are written under
+    oracle/_ref/ first (`thrbigh:<n>:<T>` harvests a finished run)."""
+    import time
+    codes = synth.random_descent_codes(n, 200, 4, 0.02, 0.01, seed=4)
+    tag = "thr_c4_%dk_t%d" % (n // 1000, threads)
+    fa = os.path.join(HERE, "_ref", tag + ".fa")
+    synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+    del codes
+    env = dict(os.environ, OMP_WAIT_POLICY="passive")
+    log = os.path.join(HERE, "_ref", tag + ".log")
+    t0 = time.time()
+    with open(os.path.join(HERE, "_ref", tag + ".tree"), "wb") as out, open(os.path.join(HERE, "_ref", tag + ".err"), "wb") as err:
+        subprocess.run([REFBIN, "-nt", "-threads", str(threads), "-seed", "1", "-log", log, fa], check=True, stdout=out, stderr=err, env=env)
+    open(os.path.join(HERE, "_ref", tag + ".wall"), "w").write("%.1f" % (time.time() - t0))
+    os.remove(fa)
+    harvest_threads_big(n, threads)
+
+
+def harvest_threads_big(n, threads):
+    import zlib
+    tag = "thr_c4_%dk_t%d" % (n // 1000, threads)
+    tree = open(os.path.join(HERE, "_ref", tag + ".tree"), "rb").read().decode().strip()
+    assert tree.endswith(";"), "the reference has not finished"
+    wall = float(open(os.path.join(HERE, "_ref", tag + ".wall")).read())
+    ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", open(os.path.join(HERE, "_ref", tag + ".log")).read(), re.M)]
+    flags = ["-nt", "-threads", str(threads), "-seed", "1"]
+    np.savez_compressed(os.path.join(GOLDEN, tag + "_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+                        loglk=np.array(ll), threads=np.int64(threads), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(("random_descent_codes(%d, 200, 4, 0.02, 0.01, seed=4)" % n).encode(), dtype=np.uint8),
+                        reference_wall_s=np.float64(wall))
+    print("%s_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (tag, len(tree), zlib.crc32(tree.encode()), len(ll), wall))
+
+
 GAMMA_CASES = [
     # name, alphabet size, flags, n, L, mu, gap, seed
     ("gamma_nt_200", 4, ["-nt", "-gamma"], 200, 120, 0.05, 0.02, 21),
@@ -498,15 +534,28 @@ def gen_c2(tmp):
     print("bb_c2_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ll), wall))
 
 
-def gen_c5(tmp, n=50000):
-    """BASELINE config C5 (50 000 aa x 300, `-lg -double-precision`, one thread, the complete default pipeline with supports), or the
-    same generator at a smaller n: CRC-32 and length of the reference's tree and its TreeLogLk lines - what bench.py's e2e_c5 leg and
-    tests/test_gpu_fullsize.py compare the one-thread-order run with.  bb_c5_crc.npz for n = 50 000, bb_c5_<n/1000>k_crc.npz otherwise.
-    Hours of one core at full size; the files are written under oracle/_ref/ first so that a run that outlives this script can be
-    harvested (`c5h:<n>`)."""
+C5_PARAMS = {
+    # tag prefix -> (mu, gap, seed): "c5" is SURVEY.md 8(d)'s config C5; "c5mu03" are rounds 4-5's fixtures, made on C2's generator
+    # parameters by mistake (less divergence, half the gaps) and kept as extra cases
+    "c5": (0.08, 0.02, 5),
+    "c5mu03": (0.03, 0.01, 2),
+}
+
+
+def c5_tag(n, kind="c5"):
+    return kind if n == 50000 else "%s_%dk" % (kind, n // 1000)
+
+
+def gen_c5(tmp, n=50000, kind="c5"):
+    """BASELINE config C5 (50 000 aa x 300, mu = 0.08, g = 0.02, seed 5; `-lg -double-precision`, one thread, the complete default
+    pipeline with supports), or the same generator at a smaller n: CRC-32 and length of the reference's tree and its TreeLogLk lines -
+    what bench.py's e2e_c5 leg and tests/test_gpu_fullsize.py compare the one-thread-order run with.  bb_c5_crc.npz for n = 50 000,
+    bb_c5_<n/1000>k_crc.npz otherwise (kind "c5mu03": the earlier rounds' parameters, bb_c5mu03_*).  Tens of minutes of one core at
+    full size; the files are written under oracle/_ref/ first so that a run that outlives this script can be harvested (`c5h:<n>`)."""
     import time
-    codes = synth.random_descent_codes(n, 300, 20, 0.03, 0.01, seed=2)
-    tag = "c5" if n == 50000 else "c5_%dk" % (n // 1000)
+    mu, gap, seed = C5_PARAMS[kind]
+    codes = synth.random_descent_codes(n, 300, 20, mu, gap, seed=seed)
+    tag = c5_tag(n, kind)
     fa = os.path.join(HERE, "_ref", tag + ".fa")
     synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA)
     del codes
@@ -517,12 +566,13 @@ def gen_c5(tmp, n=50000):
         subprocess.run([REFBIN] + flags + ["-log", log, fa], check=True, stdout=out, stderr=err)
     open(os.path.join(HERE, "_ref", tag + ".wall"), "w").write("%.1f" % (time.time() - t0))
     os.remove(fa)
-    harvest_c5(n)
+    harvest_c5(n, kind)
 
 
-def harvest_c5(n):
+def harvest_c5(n, kind="c5"):
     import zlib
-    tag = "c5" if n == 50000 else "c5_%dk" % (n // 1000)
+    mu, gap, seed = C5_PARAMS[kind]
+    tag = c5_tag(n, kind)
     tree = open(os.path.join(HERE, "_ref", tag + ".tree"), "rb").read().decode().strip()
     assert tree.endswith(";"), "the reference has not finished"
     wall = float(open(os.path.join(HERE, "_ref", tag + ".wall")).read())
@@ -530,7 +580,7 @@ def harvest_c5(n):
     flags = ["-lg", "-double-precision", "-threads", "1", "-seed", "1"]
     np.savez_compressed(os.path.join(GOLDEN, "bb_%s_crc.npz" % tag), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
                         loglk=np.array(ll), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
-                        alignment=np.frombuffer(("random_descent_codes(%d, 300, 20, 0.03, 0.01, seed=2)" % n).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(("random_descent_codes(%d, 300, 20, %g, %g, seed=%d)" % (n, mu, gap, seed)).encode(), dtype=np.uint8),
                         reference_wall_s=np.float64(wall))
     print("bb_%s_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (tag, len(tree), zlib.crc32(tree.encode()), len(ll), wall))
 
@@ -731,6 +781,14 @@ def main():
                 gen_c5(tmp, int(w[3:]))
             if w.startswith("c5h:"):
                 harvest_c5(int(w[4:]))
+            if w.startswith("thrbig:"):      # `thrbig:<n>:<T>`: the threaded schedule at config C4's generator (an hour or more)
+                gen_threads_big(tmp, *[int(x) for x in w.split(":")[1:]])
+            if w.startswith("thrbigh:"):
+                harvest_threads_big(*[int(x) for x in w.split(":")[1:]])
+            if w.startswith("c5mu03:"):
+                gen_c5(tmp, int(w[7:]), "c5mu03")
+            if w.startswith("c5mu03h:"):
+                harvest_c5(int(w[8:]), "c5mu03")
         if "c4" in which:   # not part of the default set: hours
             gen_c4(tmp)
         if "c4_tree" in which:   # from the files a finished reference run left under oracle/_ref/

@@ -502,3 +502,4 @@ def test_a_selection_that_overflows_does_not_look_at_what_it_never_stored():
     order = ids[np.lexsort((-ids, crit[ids]))][:k]
     assert np.array_equal(h0["j"], order) and np.array_equal(h0["criterion"], crit[order])
     assert b0 == best[0] and np.array_equal(h0, hits[0])
+

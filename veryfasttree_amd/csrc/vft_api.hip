@@ -530,7 +530,9 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(dallocb(&c->partMin, (size_t) c->nPart * 8));
     CR(dallocb(&c->partMax, (size_t) c->nPart * 8));
     CR(dalloc(&c->sel, 1));
-    CR(dalloc(&c->slices, (size_t) VFT_SEL_WGS * VFT_NBINS));
+    CR(hipMemset(c->sel, 0, sizeof(SelectState)));
+    CR(dalloc(&c->slices, (size_t) VFT_NBINS));
+    CR(hipMemset(c->slices, 0, (size_t) VFT_NBINS * 4));   // (the selection's histogram is zero between selections: k_select_rank's last workgroup leaves it so)
     CR(dalloc(&c->candKey, (size_t) VFT_CAND_CAP));
     CR(hipMemset(c->candKey, 0, (size_t) VFT_CAND_CAP * 8));
     CR(dalloc(&c->candId, (size_t) VFT_CAND_CAP));
@@ -592,6 +594,9 @@ extern "C" int vft_create(vft_ctx **out, const vft_config *cfg) {
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
     if (int r = raise_pair_kernel_lds(c)) return bail(r);
+    // The hipMemsets above run on the NULL stream and need not have finished when they return (device memory), and the context's own
+    // stream is a non-blocking one: nothing orders them before its first kernel.  Wait here, once.
+    CR(hipDeviceSynchronize());
 #undef CR
     *out = c;
     return VFT_OK;
@@ -1827,6 +1832,7 @@ static void kernel_event(vft_ctx *c) {   // three per sweep: before / between / 
 static int ensure_slots(vft_ctx *c, int count) {
     const size_t rs = c->rs;
     const int64_t N = ((c->d.maxNodes + VFT_TILE - 1) / VFT_TILE + 4) * VFT_TILE;   // same padding as vft_create
+    bool added = false;
     while ((int) c->slots.size() < count) {
         vft_ctx::SweepSlotHost h;
         void **reals[] = {&h.swDist, &h.swWeight, &h.swCrit};
@@ -1838,7 +1844,8 @@ static int ensure_slots(vft_ctx *c, int count) {
         HIPCHK(c, hipMalloc(&h.partMin, nPartCap * 8));
         HIPCHK(c, hipMalloc(&h.partMax, nPartCap * 8));
         HIPCHK(c, hipMalloc((void **) &h.sel, sizeof(SelectState)));
-        HIPCHK(c, hipMalloc((void **) &h.slices, (size_t) VFT_SEL_WGS * VFT_NBINS * 4));
+        HIPCHK(c, hipMalloc((void **) &h.slices, (size_t) VFT_NBINS * 4));
+        HIPCHK(c, hipMemset(h.slices, 0, (size_t) VFT_NBINS * 4));
         HIPCHK(c, hipMalloc((void **) &h.candKey, (size_t) VFT_CAND_CAP * 8));
         HIPCHK(c, hipMalloc((void **) &h.candId, (size_t) VFT_CAND_CAP * 4));
         HIPCHK(c, hipMemset(h.candKey, 0, (size_t) VFT_CAND_CAP * 8));   // (never read before written since k_select_rank skips overflowed collections; zeroed all the same)
@@ -1858,7 +1865,12 @@ static int ensure_slots(vft_ctx *c, int count) {
             HIPCHK(c, hipMalloc((void **) &h.qTab, nPosPad * 5 * sizeof(double2)));
         }
         c->slots.push_back(h);
+        added = true;
     }
+    // The hipMemsets of the new slots run on the NULL stream; the context's stream is non-blocking, so nothing orders them before the
+    // sweep that is about to write into those arrays.  (Found in round 6 under `rocprofv3 --pmc`, whose serialised kernels let a
+    // late memset zero a slot's criteria AFTER its first sweep: "more than 8192 hits tied at the k-th criterion".)
+    if (added) HIPCHK(c, hipDeviceSynchronize());
     return VFT_OK;
 }
 
@@ -1921,13 +1933,12 @@ static int run_select(vft_ctx *c, int K, const int64_t *queries, int64_t lo, int
     if (int r = io_alloc(c, hs.size() * sizeof(SelSlot), &hS, &dS)) return r;
     memcpy(hS, hs.data(), hs.size() * sizeof(SelSlot));
     const SelSlot *slots = (const SelSlot *) dS;
-    // hist (round one: with the key range) -> thresh -> collect -> rank; the rank sort's last workgroup of every seed finishes the
+    // hist (round one: with the key range) -> collect (every workgroup finds the threshold digit in the seed's histogram itself) -> rank; the rank sort's last workgroup of every seed finishes the
     // selection and writes `seq` into the seed's host header - the host waits for those words, no kernel behind the rank sort
     auto round = [&](const SelSlot *sl, unsigned ny, int first, int s0) -> int {
         const unsigned long long seq = ++c->signalSeq;
         launch((k_select_hist<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi, first);
-        launch(k_select_thresh, dim3(1, ny), dim3(VFT_NBINS), 0, c->stream, sl, VFT_SEL_WGS, (unsigned int) k);
-        launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi);
+        launch((k_select_collect<REAL>), dim3(VFT_SEL_WGS, ny), dim3(VFT_WG), 0, c->stream, sl, lo, hi, (unsigned int) k);
         launch((k_select_rank<REAL, HIT>), dim3(VFT_CAND_CAP * VFT_RANK_LANES / VFT_WG, ny), dim3(VFT_WG), 0, c->stream, sl, k, lo, hi, (long long) seq);
         LAUNCHCHK(c);
         return wait_headers(c, s0, (int) ny, seq);
@@ -2045,8 +2056,8 @@ static int sweep_group(vft_ctx *c, bool leafSeeds, const int *slotOf, const int6
     c->nPart = (int) grid;
     kernel_event(c);
     if (grid && leafSeeds) launch((k_sweep_nt_leafq_multi<REAL, S>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
-    // profile seeds: the heavy workgroups once for all S, the table workgroups (leaf targets) once per seed
-    if (grid && !leafSeeds) launch((k_sweep_nt_profq_multi<REAL, S>), dim3(grid + (unsigned) (S - 1) * (unsigned) s.nLeafWG), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
+    // profile seeds: heavy and table workgroups alike take all S seeds
+    if (grid && !leafSeeds) launch((k_sweep_nt_profq_multi<REAL, S>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
     kernel_event(c);
     kernel_event(c);
     if (c->timeKernels) c->kevSweeps += S - 1;   // (every triple of events counts as one sweep; this one covers S)
@@ -2233,6 +2244,15 @@ extern "C" int vft_merge_hits_batch(vft_ctx *c, const void *dAll, int32_t nLists
 extern "C" int vft_sweep_info(vft_ctx *c, int64_t info[2]) {
     if (!c || !info) return VFT_ERR_INVALID;
     const SelectHeader *h = (const SelectHeader *) c->hRes;
+    info[0] = h->nCand;
+    info[1] = h->shift;
+    return VFT_OK;
+}
+
+// the same two numbers for slot `slot` of the last vft_sweep_batch (diagnostics: how many candidates its selection ranked)
+extern "C" int vft_sweep_batch_info(vft_ctx *c, int32_t slot, int64_t info[2]) {
+    if (!c || !info || slot < 0 || (size_t) slot >= c->slots.size()) return VFT_ERR_INVALID;
+    const SelectHeader *h = (const SelectHeader *) c->slots[(size_t) slot].hRes;
     info[0] = h->nCand;
     info[1] = h->shift;
     return VFT_OK;
@@ -3984,6 +4004,7 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
                 HIPCHK(c, hipMemset(h.candKey, 0x7f, (size_t) VFT_CAND_CAP * 8));
                 HIPCHK(c, hipMemset(h.candId, 0x7f, (size_t) VFT_CAND_CAP * 4));
             }
+            HIPCHK(c, hipDeviceSynchronize());   // (NULL-stream memsets vs the context's non-blocking stream)
             break;
         default: return fail(c, VFT_ERR_INVALID, "vft_debug_option: unknown option %d", (int) option);
     }

@@ -795,8 +795,8 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_leafq_multi(Arena<REAL> A, 
 
 // ---- S PROFILE seeds (internal nodes) in one launch: the heavy workgroups stream the internal targets once and evaluate the S
 // queries' profile x profile distances on every column they decode (MODE_CRIT's arithmetic, operation for operation: numeric_t
-// products, double subtractions, NJ.tcc:933-937, :1172-1183); behind them S x nLeafWG table workgroups, one query each, walk the
-// leaf targets as k_sweep_nt_table does.
+// products, double subtractions, NJ.tcc:933-937, :1172-1183); behind them nLeafWG table workgroups walk the leaf targets for all S
+// queries at once (vft_leaf_table_wg_multi below; until round 6: S x nLeafWG workgroups, one query each).
 template <typename REAL, int S, int SUB>
 __device__ __forceinline__ void vft_int_chunk_consume_prof(const IntChunkAll<REAL, SUB> &ca, int64_t p0, const MultiLeafQ<REAL, S> &M, double *top, double *denom) {
 #pragma unroll
@@ -819,30 +819,165 @@ __device__ __forceinline__ void vft_int_chunk_consume_prof(const IntChunkAll<REA
     }
 }
 
+// ---- the leaf targets of S profile seeds in one walk (round 6): what vft_leaf_table_wg does for one seed - compaction of the span's
+// active leaves, the (column, code) addend table in LDS, one LDS read and two double adds per column - with the compaction, the
+// leaves' bytes and the table index of every (leaf, column) shared by the S seeds: per column a lane computes the index once and
+// reads S tables.  Same addends in the same order per (seed, leaf) as the one-seed walk: same bits.  The S tables are staged
+// VFT_PTILE_M positions at a time (S x 112 x 5 x 16 B = 35 KB: four workgroups of this kernel still share a CU's LDS), the span's
+// compacted leaves are walked 2 x VFT_WG at a time (two leaves per lane: S x 2 reads in flight per column).
+#define VFT_PTILE_M 112
+template <int NBT, int S>
+__device__ __forceinline__ void vft_leaf_table_chunk_multi(const double2 *row, const uint4 *t, double (*top)[S], double (*denom)[S]) {
+    constexpr int GC = NBT * S >= 8 ? 1 : NBT * S >= 4 ? 2 : 4;
+#pragma unroll
+    for (int g = 0; g < VFT_CHUNK; g += GC) {
+        double2 v[NBT][GC][S];
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++)
+#pragma unroll
+            for (int q = 0; q < GC; q++) {
+                const int idx = __ffs((int) (vft_byte(t[bt], g + q) | 0x10u)) - 1;   // table column 0..3, or 4 for a gap (vft_leaf_table_chunk)
+#pragma unroll
+                for (int sd = 0; sd < S; sd++) v[bt][q][sd] = row[sd * (VFT_PTILE_M * 5) + (g + q) * 5 + idx];
+            }
+#pragma unroll
+        for (int q = 0; q < GC; q++)
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++)
+#pragma unroll
+                for (int sd = 0; sd < S; sd++) {
+                    denom[bt][sd] += v[bt][q][sd].y;
+                    top[bt][sd] += v[bt][q][sd].x;
+                }
+    }
+}
+
+template <typename REAL, int NBT, int S>
+__device__ __forceinline__ void vft_leaf_table_walk_multi(const Arena<REAL> &A, const MultiLeafQ<REAL, S> &M, double2 *tab, const int64_t *tj,
+                                                          double (*top)[S], double (*denom)[S]) {
+    const int tid = threadIdx.x;
+    const int64_t nPos = A.d.nPos;
+    const uint4 *lp[NBT];
+#pragma unroll
+    for (int bt = 0; bt < NBT; bt++) lp[bt] = A.leafT + vft_leaf_idx(A.d, tj[bt] >> 6, 0, (int) (tj[bt] & 63));
+    for (int64_t p0 = 0; p0 < nPos; p0 += VFT_PTILE_M) {
+        __syncthreads();
+        {
+            const int64_t nTab = ((int64_t) A.d.nChunk * VFT_CHUNK - p0) * 5;
+#pragma unroll
+            for (int sd = 0; sd < S; sd++)
+                for (int e = tid; e < VFT_PTILE_M * 5; e += VFT_WG)
+                    tab[sd * (VFT_PTILE_M * 5) + e] = e < nTab ? M.Q[sd].tab[p0 * 5 + e] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        const int c0 = (int) (p0 / VFT_CHUNK);
+        const int c1 = (int) (((p0 + VFT_PTILE_M < nPos ? p0 + VFT_PTILE_M : nPos) + VFT_CHUNK - 1) / VFT_CHUNK);
+        uint4 ta[NBT], tb[NBT];   // the leaves' bytes one chunk ahead, ping-pong (vft_leaf_table_walk)
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++) ta[bt] = lp[bt][(int64_t) c0 * VFT_TILE];
+        for (int c = c0; c < c1; c += 2) {
+            const int cb = c + 1 < c1 ? c + 1 : c, ca = c + 2 < c1 ? c + 2 : c;
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) tb[bt] = lp[bt][(int64_t) cb * VFT_TILE];
+            __builtin_amdgcn_sched_barrier(0);
+            vft_leaf_table_chunk_multi<NBT, S>(tab + (int64_t) (c - c0) * VFT_CHUNK * 5, ta, top, denom);
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) ta[bt] = lp[bt][(int64_t) ca * VFT_TILE];
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < c1) vft_leaf_table_chunk_multi<NBT, S>(tab + (int64_t) (c + 1 - c0) * VFT_CHUNK * 5, tb, top, denom);
+        }
+    }
+}
+
+template <typename REAL, int S>
+__device__ __forceinline__ void vft_leaf_table_wg_multi(const Arena<REAL> &A, const MultiLeafQ<REAL, S> &M, const SweepArgs &s, int64_t base,
+                                                        REAL *cmin, REAL *cmax) {
+    constexpr int NB = VFT_LEAF_SPAN / VFT_WG, NW = VFT_WG / 64, NBT = 2;
+    __shared__ double2 tab[S * VFT_PTILE_M * 5];
+    __shared__ unsigned short list[VFT_LEAF_SPAN];
+    __shared__ int segCnt[NB * NW];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // 1. compaction of the span's active leaves (order-preserving); the others get the "illegal join" sentinel of every seed
+    unsigned long long bal[NB];
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        const int64_t j = base + r * VFT_WG + tid;
+        bool active = false;
+        if (j < s.leafEnd) {
+            active = A.parent[j] < 0;
+            if (!active) {
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    M.O[q].dist[j] = (REAL) 1e20;
+                    M.O[q].crit[j] = (REAL) 1e20;
+                    M.O[q].weight[j] = 0;
+                }
+            }
+        }
+        bal[r] = __ballot(active);
+        if ((tid & 63) == 0) segCnt[r * NW + wave] = __popcll(bal[r]);
+    }
+    __syncthreads();
+    int nAct = 0, off[NB];
+#pragma unroll
+    for (int seg = 0; seg < NB * NW; seg++) {
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (seg == r * NW + wave) off[r] = nAct;
+        nAct += segCnt[seg];
+    }
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (bal[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) bal[r], 0u));
+        if ((bal[r] >> (tid & 63)) & 1ull) list[off[r] + rank] = (unsigned short) (r * VFT_WG + tid);
+    }
+    __syncthreads();
+    // 2. two leaves per lane at a time
+    for (int r0 = 0; r0 < nAct; r0 += NBT * VFT_WG) {   // workgroup-uniform
+        int64_t tj[NBT];
+        double top[NBT][S], denom[NBT][S];
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++) {
+            const int idx = r0 + bt * VFT_WG + tid;
+            tj[bt] = base + list[idx < nAct ? idx : 0];   // lanes beyond the list redo entry 0 and drop the result
+#pragma unroll
+            for (int q = 0; q < S; q++) top[bt][q] = denom[bt][q] = 0;
+        }
+        if (nAct - r0 <= VFT_WG) vft_leaf_table_walk_multi<REAL, 1, S>(A, M, tab, tj, top, denom);
+        else vft_leaf_table_walk_multi<REAL, NBT, S>(A, M, tab, tj, top, denom);
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++) {
+            if (r0 + bt * VFT_WG + tid < nAct) {
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    const REAL weight = (REAL) (denom[bt][q] > 0 ? denom[bt][q] : 0.01);
+                    const REAL dist = (REAL) (denom[bt][q] > 0 ? top[bt][q] / denom[bt][q] : 1.0);
+                    SweepArgs sq = s;
+                    sq.query = M.query[q];
+                    vft_sweep_finish<REAL, MODE_CRIT>(A, sq, M.O[q], tj[bt], dist, weight, false, cmin[q], cmax[q]);
+                }
+            }
+        }
+    }
+}
+
 // (four wavefronts per SIMD: every heavy workgroup of a million-sequence sweep is resident at once - the column loop of the float
 // instance fits, the table walk's epilogue gives up six registers to scratch)
 template <typename REAL, int S>
 __global__ __launch_bounds__(VFT_WG, sizeof(REAL) == 4 ? 4 : 2) void k_sweep_nt_profq_multi(Arena<REAL> A, MultiLeafQ<REAL, S> M, SweepArgs s) {
     constexpr int SUB = 8;
-    const int nT = s.nLeafWG, nHeavy = (int) gridDim.x - S * nT, blk = (int) blockIdx.x;
-    if (blk >= nHeavy) {   // a table workgroup: span t % nT of the leaves against query t / nT
-        const int t = blk - nHeavy, span = t % nT, qi = t / nT;
-        REAL cmin = (REAL) 1e30, cmax = (REAL) -1e30;
-#pragma unroll
-        for (int q = 0; q < S; q++) {   // (the query's buffers by a constant index: a runtime one would copy the argument block to scratch)
-            if (q != qi) continue;
-            SweepArgs sq = s;
-            sq.query = M.query[q];
-            vft_leaf_table_wg<REAL, MODE_CRIT>(A, M.Q[q], sq, M.O[q], s.lo + (int64_t) span * VFT_LEAF_SPAN, cmin, cmax);
-            vft_block_minmax<REAL>(cmin, cmax, M.O[q].partMin, M.O[q].partMax, span);
-        }
-        return;
-    }
+    const int nT = s.nLeafWG, nHeavy = (int) gridDim.x - nT, blk = (int) blockIdx.x;
     REAL cmin[S], cmax[S];
 #pragma unroll
     for (int q = 0; q < S; q++) {
         cmin[q] = (REAL) 1e30;
         cmax[q] = (REAL) -1e30;
+    }
+    if (blk >= nHeavy) {   // a table workgroup: span blk - nHeavy of the leaves against all S queries
+        const int span = blk - nHeavy;
+        vft_leaf_table_wg_multi<REAL, S>(A, M, s, s.lo + (int64_t) span * VFT_LEAF_SPAN, cmin, cmax);
+        vft_block_minmax_multi<REAL, S>(cmin, cmax, M.O, span);
+        return;
     }
     const int wg = nHeavy - 1 - blk;   // highest ids first, as in k_sweep_nt
     const int64_t j = s.heavyLo + (int64_t) wg * VFT_WG + threadIdx.x;
@@ -1665,7 +1800,7 @@ struct SelSlot {
     const void *crit, *dist, *weight;   // the seed's sweep results, indexed by target id
     const void *partMin, *partMax;      // per-workgroup min / max criteria of its sweep
     SelectState *sel;
-    unsigned int *slices;               // [VFT_SEL_WGS][VFT_NBINS]
+    unsigned int *slices;               // [VFT_NBINS]: the seed's histogram of the current round (zero between selections)
     uint64_t *candKey;                  // [VFT_CAND_CAP]
     int32_t *candId;
     void *hits;                         // device: the k records
@@ -1785,51 +1920,17 @@ __global__ __launch_bounds__(VFT_WG) void k_select_hist(const SelSlot *slots, in
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) slices[(int64_t) blockIdx.x * VFT_NBINS + t] = lh4[0][t] + lh4[1][t] + lh4[2][t] + lh4[3][t];
-}
-
-// one workgroup of VFT_NBINS threads: column sums, scan, the digit that holds the need-th smallest value
-__global__ __launch_bounds__(VFT_NBINS) void k_select_thresh(const SelSlot *slots, int nSlices, unsigned int k) {
-    SelectState *S = slots[blockIdx.y].sel;
-    const unsigned int *slices = slots[blockIdx.y].slices;
-    __shared__ unsigned int part[VFT_NBINS];
-    const int t = threadIdx.x;
-    unsigned int mine = 0;
-    int w = 0;
-    for (; w + 8 <= nSlices; w += 8) {   // eight independent loads in flight per thread
-        unsigned int v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = slices[(int64_t) (w + u) * VFT_NBINS + t];
-#pragma unroll
-        for (int u = 0; u < 8; u++) mine += v[u];
-    }
-    for (; w < nSlices; w++) mine += slices[(int64_t) w * VFT_NBINS + t];
-    part[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < VFT_NBINS; off <<= 1) {   // inclusive scan
-        const unsigned int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    const unsigned int total = part[VFT_NBINS - 1];
-    unsigned int need = k > S->nIn ? k - S->nIn : 0;
-    if (need > total) need = total;
-    const unsigned int before = t ? part[t - 1] : 0;
-    if (need > 0 && before < need && before + mine >= need) {
-        S->threshBin = (unsigned int) t;
-        S->nBelow = before;
-        S->nThresh = mine;
-    }
-    if (t == 0 && need == 0) {   // nothing (more) to pick from this range
-        S->threshBin = VFT_NBINS;
-        S->nBelow = 0;
-        S->nThresh = 0;
+    // into the seed's ONE histogram (round 6; zero on entry: k_select_rank's last workgroup leaves it so): the bins this workgroup touched,
+    // one global atomic each - the threshold digit is then found by every workgroup of k_select_collect for itself (4 KB, one scan)
+    // instead of by a one-workgroup launch over VFT_SEL_WGS slices in between
+    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) {
+        const unsigned int v = lh4[0][t] + lh4[1][t] + lh4[2][t] + lh4[3][t];
+        if (v) atomicAdd(&slices[t], v);
     }
 }
 
 template <typename REAL>
-__global__ __launch_bounds__(VFT_WG) void k_select_collect(const SelSlot *slots, int64_t lo, int64_t hi) {
+__global__ __launch_bounds__(VFT_WG) void k_select_collect(const SelSlot *slots, int64_t lo, int64_t hi, unsigned int k) {
     const SelSlot &sl = slots[blockIdx.y];
     const REAL *crit = (const REAL *) sl.crit;
     SelectState *S = sl.sel;
@@ -1839,10 +1940,64 @@ __global__ __launch_bounds__(VFT_WG) void k_select_collect(const SelSlot *slots,
     __shared__ uint64_t lkey[VFT_CAND_CAP / 8];
     __shared__ int32_t lid[VFT_CAND_CAP / 8];
     if (threadIdx.x == 0) lcount = 0;
-    __syncthreads();
+    // ---- the digit that holds the need-th smallest value, from the seed's histogram (every workgroup for itself: the same 1 024
+    //      numbers, the same answer; workgroup 0 leaves it in the state for a refinement round and the diagnostics)
+    __shared__ unsigned int wsum[VFT_WG / 64], sTb, sBelow, sThresh;
+    unsigned int tb;
+    {
+        constexpr int PER = VFT_NBINS / VFT_WG;
+        const unsigned int *gh = sl.slices;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned int v[PER], mine = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            v[u] = gh[threadIdx.x * PER + u];
+            mine += v[u];
+        }
+        unsigned int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        if (threadIdx.x == 0) {
+            sTb = VFT_NBINS;   // need == 0: nothing (more) to pick from this range
+            sBelow = 0;
+            sThresh = 0;
+        }
+        __syncthreads();
+        unsigned int before = incl - mine, total = 0;
+#pragma unroll
+        for (int w = 0; w < VFT_WG / 64; w++) {
+            if (w < wave) before += wsum[w];
+            total += wsum[w];
+        }
+        unsigned int need = k > S->nIn ? k - S->nIn : 0;
+        if (need > total) need = total;
+        if (need > 0 && before < need && before + mine >= need) {   // exactly one thread
+            unsigned int b = before;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                if (b < need && b + v[u] >= need) {
+                    sTb = (unsigned int) (threadIdx.x * PER + u);
+                    sBelow = b;
+                    sThresh = v[u];
+                }
+                b += v[u];
+            }
+        }
+        __syncthreads();
+        tb = sTb;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            S->threshBin = tb;
+            S->nBelow = sBelow;
+            S->nThresh = sThresh;
+        }
+    }
     const double vlo = S->lo, scale = S->scale;
     const unsigned long long prefix = S->prefix;
-    const unsigned int shift = vft_level_shift(S->level), tb = S->threshBin;
+    const unsigned int shift = vft_level_shift(S->level);
     const int64_t stride = (int64_t) gridDim.x * VFT_WG;
     auto take = [&](int64_t j, REAL c) {
         if (!(c < (REAL) 1e20)) return;
@@ -1934,6 +2089,7 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     const int32_t *candId = sl.candId;
     const REAL *dist = (const REAL *) sl.dist, *weight = (const REAL *) sl.weight, *crit = (const REAL *) sl.crit;
     HIT *hits = (HIT *) sl.hits;
+    HIT *hostHits = (HIT *) sl.hostHits;
     __shared__ uint64_t sk[VFT_RANK_TILE];
     __shared__ int32_t si[VFT_RANK_TILE];
     // An overflowed collection (more candidates than the buffer takes: the host narrows the key range and repeats) has counted
@@ -2000,10 +2156,13 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     if (!sLast) return;
     const int64_t query = sl.query;
     SelectHeader *hdr = sl.hdr, *hostHdr = sl.hostHdr;
-    HIT *hostHits = (HIT *) sl.hostHits;
     __shared__ long long sBest;
     __shared__ REAL sCrit;
     __shared__ int sTruncatedTie;
+    // the seed's histogram back to zero for the next selection's (or refinement round's) k_select_hist
+    for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) sl.slices[t] = 0;
+    // The records into the host's block, whole lines per wavefront.  (Measured and dropped in round 6: every workgroup writing its own
+    // records there as it ranks them - 2 000 scattered 16-byte writes per seed over PCIe - took the kernel from 40 to 120 us.)
     for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = vft_hit_fetch<HIT>(hits + t);
     if (threadIdx.x == 0) {
         const unsigned int nn = n < (unsigned int) k ? n : (unsigned int) k;
@@ -2038,9 +2197,10 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
         for (int64_t j = lo + threadIdx.x; j < hi; j += VFT_WG)
             if (j != query && crit[j] == bc && j < mineJ) mineJ = j;
         atomicMin((unsigned long long *) &sBest, (unsigned long long) mineJ);
+        __syncthreads();
     }
     // the host copies of the records must have LEFT the chip before the completion word moves (the explicit wait: see
-    // vft_publish_staged)
+    // vft_publish_staged); the header then rides in front of the completion word's own release - no second fence for it
     __threadfence_system();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2058,8 +2218,6 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     hostHdr->shift = h.shift;
     hostHdr->pad = 0;
     hostHdr->bestJ = h.bestJ;
-    __threadfence_system();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&hostHdr->pad2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
