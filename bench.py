@@ -261,9 +261,15 @@ def end_to_end(which, device, comm=None):
         from veryfasttree_amd.backend import last_join_crcs
         g = np.load(pre)
         chunk, n_joins, crcs = last_join_crcs()
+        complete = bool(int(g["complete"])) if "complete" in g else False   # the finished trace: its last, shorter chunk is there too
         k = min(len(crcs), len(g["join_chunk_crc"])) if chunk == int(g["join_chunk"]) else 0
-        out["reference_joins_compared"] = int(k * chunk)
+        if not complete and n_joins % chunk:   # (a prefix holds complete chunks only; this run's last entry is its shorter tail)
+            k = min(k, len(crcs) - 1)
+        out["reference_joins_compared"] = int(min(k * chunk, int(g["n_joins"])))
+        out["reference_trace_complete"] = complete
         out["join_order_identical_to_reference_prefix"] = bool(k > 0 and np.array_equal(crcs[:k].astype(np.int64), g["join_chunk_crc"][:k]))
+        if complete:
+            out["join_order_identical_to_reference"] = bool(out["join_order_identical_to_reference_prefix"] and n_joins == int(g["n_joins"]))
     return out
 
 

@@ -140,7 +140,8 @@ int vft_nj_ml_newick(vft_ctx *ctx, const uint8_t *codes, int64_t n_seqs, int64_t
                      int32_t rates_cap, int32_t *n_rates, int32_t *ratecat, double *gtr_out, char *err, int32_t err_len);
 
 /* CRC-32 (zlib's) of the join order of the last vft_nj_run / vft_nj_newick / vft_nj_ml_newick of this process, one value per
-   complete chunk of *chunk (10 000) joins, each join as three little-endian int32 (i, j, new node) - the reference's `Join`
+   chunk of *chunk (10 000) joins - the joins behind the last complete chunk, if any, as one shorter chunk at the end -, each join as
+   three little-endian int32 (i, j, new node) - the reference's `Join`
    trace lines (-verbose 3, NJ.tcc:2925) reduced the same way pin the join order of a run whose tree is all the caller asked
    for (tests/golden/bb_c4_prefix.npz).  crcs[cap] may be NULL. */
 int vft_nj_last_join_crcs(int64_t *chunk, int64_t *n_joins, uint32_t *crcs, int64_t cap, int64_t *n_crcs);

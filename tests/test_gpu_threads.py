@@ -84,6 +84,27 @@ def test_matrix_models_stay_within_the_references_own_spread(name):
     assert again == tree
 
 
+def test_the_64_thread_schedule_at_200_000_sequences_gives_the_references_tree():
+    """The subtree schedule 100 times beyond the toy fixtures: config C4's generator at 200 000 sequences, `VeryFastTree -nt -threads 64
+    -seed 1` - the whole default pipeline (NJ, ME NNIs + SPRs, ML NNIs under Jukes-Cantor + CAT, SH-like supports; the reference's
+    threaded runs are reproducible under Jukes-Cantor), 2 273 s on the build container's eight cores (oracle/gen_fixtures.py
+    thrbig:200000:64 -> thr_c4_200k_t64_crc.npz: CRC-32 and length of the 6 MB tree, every TreeLogLk line)."""
+    import zlib
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick
+    d = G.load("thr_c4_200k_t64_crc")
+    assert bytes(d["alignment"]).decode() == "random_descent_codes(200000, 200, 4, 0.02, 0.01, seed=4)"
+    codes = synth.random_descent_codes(200000, 200, 4, 0.02, 0.01, seed=4)
+    names = ["s%d" % k for k in range(len(codes))]
+    tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m), codes, names, me_lengths=True, me_nni=True, spr=2,
+                            ml_nni=20, n_bootstrap=1000, return_loglk=True, threads=int(d["threads"]))
+    want = d["loglk"]
+    print("TreeLogLk", list(loglk), "reference", list(want))
+    assert len(loglk) == len(want) and np.allclose(loglk, want, rtol=1e-4, atol=0)
+    assert len(tree) == int(d["newick_bytes"])
+    assert zlib.crc32(tree.encode()) == int(d["newick_crc"])
+
+
 def test_one_thread_is_untouched_by_the_option():
     """threads = 1 is the one-thread order: the fixture of the sequential walk, through the same entry point"""
     from veryfasttree_amd import HipProfileOps

@@ -320,7 +320,8 @@ def last_lane_exchange():
 
 
 def last_join_crcs():
-    """(chunk, n_joins, crcs): CRC-32 per complete chunk of joins of the last NJ run of this process (vft_nj_last_join_crcs)"""
+    """(chunk, n_joins, crcs): CRC-32 per chunk of joins of the last NJ run of this process, the joins behind the last complete chunk as
+    one shorter chunk at the end (vft_nj_last_join_crcs)"""
     lib = load_host_library()
     chunk, nj, nc = I64(0), I64(0), I64(0)
     lib.vft_nj_last_join_crcs(C.byref(chunk), C.byref(nj), None, I64(0), C.byref(nc))

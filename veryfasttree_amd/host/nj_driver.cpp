@@ -52,6 +52,16 @@ static void recordJoinCrc(const JOINS &js) {
         }
         gJoinCrc.push_back(crc32Bytes((const unsigned char *) buf.data(), buf.size() * 4));
     }
+    /* the joins behind the last complete chunk, as one shorter chunk (a finished run is compared to its last join) */
+    const size_t done = js.size() / (size_t) gJoinCrcChunk * (size_t) gJoinCrcChunk;
+    if (done < js.size()) {
+        for (size_t k = 0; done + k < js.size(); k++) {
+            buf[3 * k] = (int32_t) js[done + k].i;
+            buf[3 * k + 1] = (int32_t) js[done + k].j;
+            buf[3 * k + 2] = (int32_t) js[done + k].newnode;
+        }
+        gJoinCrc.push_back(crc32Bytes((const unsigned char *) buf.data(), (js.size() - done) * 3 * 4));
+    }
 }
 
 extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *crcs, int64_t cap, int64_t *nCrcs) {
