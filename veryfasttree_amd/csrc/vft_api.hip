@@ -105,6 +105,8 @@ struct vft_ctx {
         double2 *qTab = nullptr;
     };
     std::vector<SweepSlotHost> slots;
+    void *mqBuf = nullptr;        // interleaved queries of the profile-seed groups of a batch (QuerySlot::mq): VFT_MQ_GROUPS groups
+    size_t mqGroupBytes = 0;
     char *dMerge = nullptr, *hMerge = nullptr, *hMergeDev = nullptr;   // result blocks of vft_merge_hits_batch
     size_t mergeBytes = 0;
     int32_t hitsCap = 0;
@@ -624,6 +626,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
     if (c->mlEvals) hipFree(c->mlEvals);
     if (c->dMerge) hipFree(c->dMerge);
     if (c->hMerge) hipHostFree(c->hMerge);
+    if (c->mqBuf) hipFree(c->mqBuf);
     for (size_t i = 1; i < c->slots.size(); i++) {   // slot 0 aliases members freed below
         vft_ctx::SweepSlotHost &h = c->slots[i];
         void *dev[] = {h.swDist, h.swWeight, h.swCrit, h.partMin, h.partMax, h.sel, h.slices, h.candKey, h.candId, h.dRes, h.qW, h.qF, h.qC, h.qEnc, h.qTab};
@@ -2036,7 +2039,7 @@ static int sweep_one(vft_ctx *c, int slot, int64_t query, int64_t nActive, int64
 // S leaf seeds - or S profile seeds - of a batch (the seeds at positions slotOf[0 .. S-1] of it) in ONE pass over the targets
 // (k_sweep_nt_leafq_multi / k_sweep_nt_profq_multi): results in the buffers of those slots, bit for bit those of S sweep_one calls.  The caller has checked that no lazy refresh is due (sweep_one's step 1) and has staged the queries.
 template <typename REAL, int S>
-static int sweep_group(vft_ctx *c, bool leafSeeds, const int *slotOf, const int64_t *queries, int64_t nActive, int64_t nDiffAllow, double totdiam) {
+static int sweep_group(vft_ctx *c, bool leafSeeds, const int *slotOf, const int64_t *queries, int64_t nActive, int64_t nDiffAllow, double totdiam, const void *mq) {
     SweepArgs s{};
     s.query = queries[slotOf[0]];
     s.lo = c->shardLo;
@@ -2053,6 +2056,7 @@ static int sweep_group(vft_ctx *c, bool leafSeeds, const int *slotOf, const int6
         M.query[q] = queries[slotOf[q]];
         c->slots[(size_t) slotOf[q]].nPart = (int) grid;
     }
+    M.mq = (const REAL *) mq;
     c->nPart = (int) grid;
     kernel_event(c);
     if (grid && leafSeeds) launch((k_sweep_nt_leafq_multi<REAL, S>), dim3(grid), dim3(VFT_WG), 0, c->stream, arena<REAL>(c), M, s);
@@ -2097,6 +2101,13 @@ extern "C" int vft_sweep(vft_ctx *c, int64_t query, int64_t nActive, int64_t nDi
 // can run the next unvisited seeds speculatively; a multi-GPU run then needs one exchange per batch instead of one per
 // seed - SURVEY section 8e).  The same kernels as vft_sweep, seed after seed on the stream, then ONE batched top-k
 // selection and ONE host synchronisation.  Results are exactly those of n_seeds vft_sweep calls.
+// the seeds of a batch that share a pass over the targets: `n` batch positions (2 or 4) of one kind
+struct SeedGroup {
+    int pos[4];
+    int n;
+    bool leaf;
+};
+
 extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *queries, int64_t nActive, int64_t nDiffAllow,
                                double totdiam, int32_t k, void *hits, void *dHitsOut, int64_t *bestJ) {
     if (!c || !queries || nSeeds < 1 || nSeeds > 64 || k < 1) return VFT_ERR_INVALID;
@@ -2106,9 +2117,48 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
     if (int r = ensure_slots(c, nSeeds)) return r;
     // nucleotides without a distance matrix: the queries of all seeds are staged by ONE launch, each into its slot's buffers
     const bool staged = c->cfg.n_codes == 4 && !c->hasDm && nSeeds > 1;
+    // The leaf seeds of the batch share passes over the targets, four (or two) per launch, and so do its profile seeds - every seed has
+    // buffers of its own, so the order the sweeps run in does not matter as long as no lazy refresh is due (sweep_one's step 1 changes out-distances that later
+    // sweeps read: then the seeds go one by one, in order).  The groups are made before the staging launch: the profile seeds of a
+    // group are also staged into the group's interleaved buffer (QuerySlot::mq).
+    std::vector<SeedGroup> groups;
+    if (staged && !c->noMultiSweep && !(c->maxStamp - nActive > nDiffAllow)) {
+        bool fresh = true;
+        for (int s = 0; s < nSeeds && fresh; s++) fresh = !((int64_t) c->hNOut[queries[s]] - nActive > nDiffAllow);
+        for (int kind = 0; kind < 2 && fresh; kind++) {   // the leaf seeds, then the profile seeds: fours while they last, then a pair; a last single goes alone
+            SeedGroup g{};
+            g.leaf = kind == 0;
+            int nLeft = 0;
+            auto isKind = [&](int s) { return (queries[s] < c->d.nSeqs) == (kind == 0); };
+            for (int s = 0; s < nSeeds; s++) nLeft += isKind(s);
+            for (int s = 0; s < nSeeds; s++) {
+                if (!isKind(s)) continue;
+                g.pos[g.n++] = s;
+                nLeft--;
+                if (g.n == 4 || (g.n == 2 && nLeft < 2)) {
+                    groups.push_back(g);
+                    g.n = 0;
+                }
+            }
+        }
+    }
+    const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+    const size_t mqGroupBytes = (size_t) nPosPad * VFT_MQ_STRIDE(4) * c->rs;
+    if (!groups.empty() && !c->mqBuf) {   // (32 groups: the profile seeds of the largest batch, two per group)
+        HIPCHK(c, hipMalloc(&c->mqBuf, 32 * mqGroupBytes));
+        c->mqGroupBytes = mqGroupBytes;
+    }
     if (staged) {
         if (int r = flush_pending(c)) return r;
-        const int64_t nPosPad = (int64_t) c->d.nChunk * VFT_CHUNK;
+        // where a seed's query goes in its group's interleaved buffer (profile-seed groups only)
+        std::vector<int> mqGroup((size_t) nSeeds, -1), mqIdx((size_t) nSeeds, 0), mqS((size_t) nSeeds, 0);
+        for (size_t g = 0; g < groups.size(); g++)
+            if (!groups[g].leaf)
+                for (int q = 0; q < groups[g].n; q++) {
+                    mqGroup[(size_t) groups[g].pos[q]] = (int) g;
+                    mqIdx[(size_t) groups[g].pos[q]] = q;
+                    mqS[(size_t) groups[g].pos[q]] = groups[g].n;
+                }
         char *hQ, *dQ;
         if (c->cfg.precision == 4) {
             if (int r = io_alloc(c, (size_t) nSeeds * sizeof(QuerySlot<float>), &hQ, &dQ)) return r;
@@ -2116,6 +2166,9 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
                 QuerySlot<float> qs;
                 qs.node = queries[s];
                 qs.q = qbuf_slot<float>(c, s);
+                qs.mq = mqGroup[(size_t) s] >= 0 ? (float *) ((char *) c->mqBuf + (size_t) mqGroup[(size_t) s] * c->mqGroupBytes) : nullptr;
+                qs.mqIdx = mqIdx[(size_t) s];
+                qs.mqS = mqS[(size_t) s];
                 memcpy(hQ + (size_t) s * sizeof(qs), &qs, sizeof(qs));
             }
             launch((k_extract_query_batch<float, 4>), dim3(cdiv(nPosPad, 256), (unsigned) nSeeds), dim3(256), 0, c->stream, arena<float>(c), (const QuerySlot<float> *) dQ);
@@ -2125,37 +2178,24 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
                 QuerySlot<double> qs;
                 qs.node = queries[s];
                 qs.q = qbuf_slot<double>(c, s);
+                qs.mq = mqGroup[(size_t) s] >= 0 ? (double *) ((char *) c->mqBuf + (size_t) mqGroup[(size_t) s] * c->mqGroupBytes) : nullptr;
+                qs.mqIdx = mqIdx[(size_t) s];
+                qs.mqS = mqS[(size_t) s];
                 memcpy(hQ + (size_t) s * sizeof(qs), &qs, sizeof(qs));
             }
             launch((k_extract_query_batch<double, 4>), dim3(cdiv(nPosPad, 256), (unsigned) nSeeds), dim3(256), 0, c->stream, arena<double>(c), (const QuerySlot<double> *) dQ);
         }
         LAUNCHCHK(c);
     }
-    // The leaf seeds of the batch share passes over the targets, four (or two) per launch, and so do its profile seeds - every seed has
-    // buffers of its own, so the order the sweeps run in does not matter as long as no lazy refresh is due (sweep_one's step 1 changes out-distances that later
-    // sweeps read: then the seeds go one by one, in order).
     std::vector<char> done((size_t) nSeeds, 0);
-    if (staged && !c->noMultiSweep && !(c->maxStamp - nActive > nDiffAllow)) {
-        bool fresh = true;
-        for (int s = 0; s < nSeeds && fresh; s++) fresh = !((int64_t) c->hNOut[queries[s]] - nActive > nDiffAllow);
-        for (int kind = 0; kind < 2 && fresh; kind++) {   // the leaf seeds, then the profile seeds: fours while they last, then a pair; a last single goes alone
-            int grp[4], nGrp = 0, nLeft = 0;
-            auto isKind = [&](int s) { return (queries[s] < c->d.nSeqs) == (kind == 0); };
-            for (int s = 0; s < nSeeds; s++) nLeft += isKind(s);
-            for (int s = 0; s < nSeeds; s++) {
-                if (!isKind(s)) continue;
-                grp[nGrp++] = s;
-                nLeft--;
-                const int S = nGrp == 4 ? 4 : (nGrp == 2 && nLeft < 2) ? 2 : 0;
-                if (!S) continue;
-                int r;
-                if (c->cfg.precision == 4) r = S == 4 ? sweep_group<float, 4>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam) : sweep_group<float, 2>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam);
-                else r = S == 4 ? sweep_group<double, 4>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam) : sweep_group<double, 2>(c, kind == 0, grp, queries, nActive, nDiffAllow, totdiam);
-                if (r) return r;
-                for (int q = 0; q < S; q++) done[(size_t) grp[q]] = 1;
-                nGrp = 0;
-            }
-        }
+    for (size_t g = 0; g < groups.size(); g++) {
+        const SeedGroup &G = groups[g];
+        const void *mq = G.leaf ? nullptr : (const void *) ((char *) c->mqBuf + g * c->mqGroupBytes);
+        int r;
+        if (c->cfg.precision == 4) r = G.n == 4 ? sweep_group<float, 4>(c, G.leaf, G.pos, queries, nActive, nDiffAllow, totdiam, mq) : sweep_group<float, 2>(c, G.leaf, G.pos, queries, nActive, nDiffAllow, totdiam, mq);
+        else r = G.n == 4 ? sweep_group<double, 4>(c, G.leaf, G.pos, queries, nActive, nDiffAllow, totdiam, mq) : sweep_group<double, 2>(c, G.leaf, G.pos, queries, nActive, nDiffAllow, totdiam, mq);
+        if (r) return r;
+        for (int q = 0; q < G.n; q++) done[(size_t) G.pos[q]] = 1;
     }
     for (int s = 0; s < nSeeds; s++)
         if (!done[(size_t) s])

@@ -75,14 +75,31 @@ __global__ void k_extract_query(Arena<REAL> A, int64_t node, QueryBuf<REAL> q) {
     vft_extract_query<REAL, NC>(A, node, q);
 }
 // the queries of a batch of seeds in ONE launch (vft_sweep_batch): blockIdx.y = seed, each into its own staging buffers
+// mq (optional): the seed is one of mqS profile seeds that share a pass over the targets (k_sweep_nt_profq_multi) - its weights and
+// vectors also go, as query number mqIdx, into the group's INTERLEAVED buffer: per column VFT_MQ_STRIDE(S) = 4 S + 4 numbers,
+// [f of query 0 (4)] ... [f of query S-1 (4)] [w of queries 0..S-1, padded to 4] - one base pointer and two or three scalar loads
+// per column for all S queries, where S separate buffers took 2 S pointers (SGPR pairs the kernel has no room for) and 2 S loads.
+#define VFT_MQ_STRIDE(S) (4 * (S) + 4)
 template <typename REAL>
 struct QuerySlot {
     int64_t node;
     QueryBuf<REAL> q;
+    REAL *mq;
+    int32_t mqIdx, mqS;
 };
 template <typename REAL, int NC>
 __global__ void k_extract_query_batch(Arena<REAL> A, const QuerySlot<REAL> *qs) {
-    vft_extract_query<REAL, NC>(A, qs[blockIdx.y].node, qs[blockIdx.y].q);
+    const QuerySlot<REAL> &sl = qs[blockIdx.y];
+    vft_extract_query<REAL, NC>(A, sl.node, sl.q);
+    if (NC == 4 && sl.mq) {   // (the thread re-reads what it has just written: its own column)
+        const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < (int64_t) A.d.nChunk * VFT_CHUNK) {
+            REAL *dst = sl.mq + p * VFT_MQ_STRIDE(sl.mqS);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[4 * sl.mqIdx + k] = sl.q.f[p * 4 + k];
+            dst[4 * sl.mqS + sl.mqIdx] = sl.q.w[p];
+        }
+    }
 }
 
 // The out-profile as a query (every column NOCODE with a vector, NJ.tcc:743-747).
@@ -592,6 +609,7 @@ struct MultiLeafQ {
     QueryBuf<REAL> Q[S];
     SweepOut<REAL> O[S];
     int64_t query[S];
+    const REAL *mq;   // profile seeds: the S queries' weights and vectors interleaved by column (QuerySlot)
 };
 
 template <typename REAL, int SUB>
@@ -797,25 +815,50 @@ __global__ __launch_bounds__(VFT_WG) void k_sweep_nt_leafq_multi(Arena<REAL> A, 
 // queries' profile x profile distances on every column they decode (MODE_CRIT's arithmetic, operation for operation: numeric_t
 // products, double subtractions, NJ.tcc:933-937, :1172-1183); behind them nLeafWG table workgroups walk the leaf targets for all S
 // queries at once (vft_leaf_table_wg_multi below; until round 6: S x nLeafWG workgroups, one query each).
+// The S queries' columns are wave-uniform: scalar loads, 5 dwords per (query, column), from the group's interleaved buffer (QuerySlot).  Written as one loop over SUB x S the compiler
+// hoists every load of the group to the front - 160 SGPRs at S = 4 - and spills them through v_writelane / v_readlane: 382 of the
+// 1 781 VALU instructions of a 16-column chunk were that traffic (tools/isa_loops.py, round 6).  Here a column's scalars are loaded
+// while the column before it is being consumed and the scheduler may not move anything across the column boundaries: two columns'
+// scalars live, no spill.  The four products of a column are one vector multiply (v_pk_mul_f32 in single precision: two instructions,
+// each lane's product IEEE as before).
+template <typename REAL, int S>
+struct QueryCol {
+    REAL w[S];
+    typename UVec4<REAL>::type f[S];
+};
+template <typename REAL, int S>
+__device__ __forceinline__ void vft_query_col_load(QueryCol<REAL, S> &c, const MultiLeafQ<REAL, S> &M, int64_t p) {
+    const REAL *src = M.mq + p * VFT_MQ_STRIDE(S);
+    const typename UVec4<REAL>::type wv = vft_uniform_load4<REAL>(src + 4 * S);
+#pragma unroll
+    for (int q = 0; q < S; q++) {
+        c.w[q] = q == 0 ? wv.x : q == 1 ? wv.y : q == 2 ? wv.z : wv.w;
+        c.f[q] = vft_uniform_load4<REAL>(src + 4 * q);
+    }
+}
+
 template <typename REAL, int S, int SUB>
 __device__ __forceinline__ void vft_int_chunk_consume_prof(const IntChunkAll<REAL, SUB> &ca, int64_t p0, const MultiLeafQ<REAL, S> &M, double *top, double *denom) {
+    QueryCol<REAL, S> cur, nxt;
+    vft_query_col_load<REAL, S>(cur, M, p0);
 #pragma unroll
     for (int b = 0; b < SUB; b++) {
-        const int64_t p = p0 + b;
+        if (b + 1 < SUB) vft_query_col_load<REAL, S>(nxt, M, p0 + b + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < S; q++) {
-            const REAL wq = vft_uniform_load<REAL>(M.Q[q].w + p);
-            const typename UVec4<REAL>::type fq = vft_uniform_load4<REAL>(M.Q[q].f + p * 4);
-            const REAL ww = wq * ca.w[b];   // numeric_t product, NJ.tcc:1176
+            const REAL ww = cur.w[q] * ca.w[b];   // numeric_t product, NJ.tcc:1176
             const double wgt = (double) ww;
-            const REAL q0 = fq.x * ca.f[b].x, q1 = fq.y * ca.f[b].y, q2 = fq.z * ca.f[b].z, q3 = fq.w * ca.f[b].w;
-            double piece = 1.0 - (double) q0;
-            piece -= (double) q1;
-            piece -= (double) q2;
-            piece -= (double) q3;
+            const typename UVec4<REAL>::type pr = cur.f[q] * ca.f[b];   // the four numeric_t products of NJ.tcc:933-937
+            double piece = 1.0 - (double) pr.x;
+            piece -= (double) pr.y;
+            piece -= (double) pr.z;
+            piece -= (double) pr.w;
             denom[q] += wgt;
             top[q] += wgt * piece;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < SUB) cur = nxt;
     }
 }
 
