@@ -511,7 +511,7 @@ def main():
         # the S seeds of a step go down in one call (vft_sweep_batch): S sweeps back to back on the stream, one batched
         # top-k selection, one host wait - how the NJ driver refreshes the top-hit lists of a batch of seeds
         if not use_dist:
-            # (the records are read where the selection leaves them - the host-mapped result blocks - as NJDriver::sweep reads them)
+            # (the records are read where the selection leaves them - the host-mapped result blocks - as NJDriver::seedSweep reads them)
             hits, _ = ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k, view=not os.environ.get("VFT_BENCH_COPY_HITS"))
             return hits
         ops.setBestHitBatch(seeds_arr, state.n_active, state.n_diff_allow, state.totdiam, k, d_hits=d_mine.data_ptr(),

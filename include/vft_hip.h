@@ -232,6 +232,15 @@ int vft_average_profiles(vft_ctx *ctx, int64_t n, const int64_t *out, const int6
 
 /* ---- out-profile (NJ.tcc:729-815, 943-1010) */
 int vft_out_profile_full(vft_ctx *ctx, int64_t n_active, const int64_t *active_ids);
+/* outProfile in parts - the multi-GPU shard of the one true reduction of the NJ phase (the reference's threaded
+   outProfile sums per-thread partials and merges them with vector_add, NJ.tcc:763-783).  vft_out_profile_partial: the raw sums over
+   `ids` (one block of the active list, n of its n_total nodes; weights with the in-weight 1 / n_total) as n_pos x (1 + n_codes)
+   numbers of the context's precision - per column the weight, then the frequencies - written to the HOST buffer `part`.
+   vft_out_profile_finish: n_parts such blocks (host memory, block after block) added in block order with numeric_t additions, the
+   weight floored, the frequencies normalised, codeDist filled: the new out-profile.  The result depends on the partition (as the
+   reference's does on its thread count), not on which rank computed which block. */
+int vft_out_profile_partial(vft_ctx *ctx, int64_t n_total, int64_t n, const int64_t *ids, void *part);
+int vft_out_profile_finish(vft_ctx *ctx, int32_t n_parts, const void *parts);
 int vft_out_profile_update(vft_ctx *ctx, int64_t old1, int64_t old2, int64_t newnode, int64_t n_active_old);
 int vft_out_profile_upload(vft_ctx *ctx, const void *w, const void *f, const void *codedist);
 int vft_out_profile_download(vft_ctx *ctx, void *w, void *f, void *codedist);
@@ -379,6 +388,8 @@ int vft_walk_server_ticks(int64_t *out, int32_t n);
 int vft_profiles_differ(vft_ctx *ctx, int64_t n, const int64_t *a, const int64_t *b, int32_t *differ);
 /* the max_nodes the context was created with (rows beyond the tree's nodes and up-profile slots serve as private scratch) */
 int vft_get_max_nodes(vft_ctx *ctx, int64_t *max_nodes);
+/* the alphabet size the context was created with (vft_config.n_codes: 4 or 20) */
+int vft_get_n_codes(vft_ctx *ctx, int32_t *n_codes);
 
 /* ---- ML branch lengths (optimizeAllBranchLengths, NJ.tcc:5006-5113)
  * branchlength[] (NJ.h) lives on the device as numeric_t[max_nodes]; set / get copy a range (get waits). */

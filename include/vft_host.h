@@ -95,6 +95,15 @@ typedef struct {
                                    are final, fit the shape of a discretised Gamma over the ml_nni / mllen rate categories and a
                                    multiplier of the rates to the per-site likelihoods, and multiply every branch length by
                                    1 / multiplier; vft_nj_last_gamma returns the "Gamma(20) LogLk" line's three numbers */
+    int32_t out_profile_parts;  /* 0 = every full out-profile recomputation (NJ.tcc:3012-3033) adds the active nodes up in id order on one
+                                   GPU, as the reference's one-thread run does; P >= 2 = in P blocks of the active list (the
+                                   one true reduction of the NJ phase) - block b is summed by rank b % world (vft_out_profile_partial), the
+                                   raw sums are all-gathered through vft_comm's host buffers and added in block order on every rank
+                                   (vft_out_profile_finish).  Like the reference's threaded outProfile (per-thread partial sums merged with
+                                   vector_add, NJ.tcc:763-783) this rounds differently from the one-thread order - the join order may
+                                   differ from the one-thread reference's in the last bits' wake - but it depends on P only: the same tree
+                                   on 1, 2, 4 or 8 ranks. */
+    int32_t pad_;
 } vft_nj_options;
 #define VFT_NJ_DEBUG_HOST_JOINS 1
 #define VFT_NJ_DEBUG_HOST_LISTS 2

@@ -28,9 +28,9 @@ EXPORTS = [
     "vft_device_malloc", "vft_device_free", "vft_device_upload", "vft_create", "vft_destroy", "vft_last_error", "vft_set_stream", "vft_synchronize", "vft_upload_leaves",
     "vft_set_distance_matrix", "vft_set_transition_matrix", "vft_set_rates", "vft_set_ml_limits", "vft_set_parents",
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
-    "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full",
+    "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full", "vft_out_profile_partial", "vft_out_profile_finish",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_sweep_batch", "vft_sweep_batch_view", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_batch_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_profiles_differ", "vft_get_max_nodes", "vft_walk_step", "vft_walk_server_start", "vft_walk_server_stop", "vft_walk_submit", "vft_walk_collect", "vft_walk_server_ticks", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_branch_lengths_gather", "vft_branch_lengths_scatter", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
+    "vft_sweep_batch", "vft_sweep_batch_view", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_batch_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_profiles_differ", "vft_get_max_nodes", "vft_get_n_codes", "vft_walk_step", "vft_walk_server_start", "vft_walk_server_stop", "vft_walk_submit", "vft_walk_collect", "vft_walk_server_ticks", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_branch_lengths_gather", "vft_branch_lengths_scatter", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms", "vft_sweep_kernel_sweeps",
     "vft_debug_log", "vft_debug_option", "vft_tophits_create", "vft_tophits_upload", "vft_tophits_download", "vft_tophits_best", "vft_tophits_join", "vft_tophits_refresh", "vft_nj_engine_create", "vft_nj_engine_set_state", "vft_nj_engine_get_state", "vft_nj_engine_visible_set", "vft_nj_engine_visible_get", "vft_nj_engine_nodes_set", "vft_nj_engine_topvisible_set", "vft_nj_engine_topvisible_get", "vft_nj_engine_reset_candidates", "vft_nj_engine_enqueue", "vft_nj_engine_poll", "vft_nj_engine_resume", "vft_nj_engine_log", "vft_nj_engine_adopt", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
 ]
@@ -57,7 +57,7 @@ class _NJOptions(C.Structure):
     _fields_ = [("fastest", I32), ("use_tophits_2nd", I32), ("tophits_mult", C.c_double), ("tophits_close", C.c_double),
                 ("tophits_refresh", C.c_double), ("topvisible_mult", C.c_double), ("stale_out_limit", C.c_double),
                 ("f_reset_out_profile", C.c_double), ("n_reset_out_profile", I32), ("tophits2_safety", I32),
-                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P), ("threads", I32), ("debug_flags", I32), ("gamma", I32)]
+                ("tophits2_mult", C.c_double), ("tophits2_refresh", C.c_double), ("scoredist", I32), ("mllen", I32), ("me_nni", I32), ("ml_nni", I32), ("spr", I32), ("gtr", I32), ("aa_model", I32), ("comm", P), ("threads", I32), ("debug_flags", I32), ("gamma", I32), ("out_profile_parts", I32), ("pad_", I32)]
 
 
 _lib = None
@@ -141,7 +141,7 @@ class TorchComm:
 
 
 def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second_level=None, scoredist=False, aa_model=None,
-           tophits_mult=1.0, comm=None, debug_flags=0):
+           tophits_mult=1.0, comm=None, debug_flags=0, out_profile_parts=0):
     """fastNJ through the C++ host driver.  Returns (joins[n,3], criterion[n]).
     second_level defaults to `fastest`, as in the reference at one thread (-fastest turns -2nd on)."""
     lib = load_host_library()
@@ -152,7 +152,7 @@ def nj_run(ops, codes, fastest=False, max_joins=-1, tophits_refresh=None, second
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, float(tophits_mult), -1.0,
                      tophits_refresh if tophits_refresh is not None else (0.5 if fastest else 0.8), 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, 0, 0, 0, 0, 0, AA_MODELS[aa_model],
-                     comm.pointer() if comm is not None else None, 1, int(debug_flags))
+                     comm.pointer() if comm is not None else None, 1, int(debug_flags), 0, int(out_profile_parts), 0)
     joins = np.zeros((max(n - 3, 1), 3), np.int64)
     crit = np.zeros(max(n - 3, 1), np.float64)
     nj = I64(0)
@@ -245,7 +245,7 @@ def uniquify(codes):
 
 def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtype=np.float32, me_lengths=False,
               unique=None, scoredist=False, n_bootstrap=0, mllen=0, return_loglk=False, return_rates=False, me_nni=False, ml_nni=0, spr=0, gtr=False, return_gtr=False,
-              aa_model=None, comm=None, threads=1, debug_flags=0, gamma=False):
+              aa_model=None, comm=None, threads=1, debug_flags=0, gamma=False, out_profile_parts=0):
     """The NJ phase of the whole alignment `codes_all` (duplicates included) as the reference's "NJ" tree string.
     make_ops(n_unique, n_pos) -> HipProfileOps for the unique sequences (max_nodes >= 3 * n_unique with me_lengths:
     then the tree carries the minimum-evolution branch lengths, the final output of -noml -nome -nosupport)."""
@@ -263,7 +263,7 @@ def nj_newick(make_ops, codes_all, names, fastest=False, second_level=None, dtyp
         second_level = fastest
     opt = _NJOptions(1 if fastest else 0, 1 if second_level else 0, 1.0, -1.0, 0.5 if fastest else 0.8, 1.5, 0.01, 0.02,
                      200, 3, 1.0, 0.6, 1 if scoredist else 0, int(mllen), 1 if me_nni else 0, int(ml_nni), int(spr), 1 if gtr else 0,
-                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None, int(threads), int(debug_flags), 1 if gamma else 0)
+                     AA_MODELS[aa_model], comm.pointer() if comm is not None else None, int(threads), int(debug_flags), 1 if gamma else 0, int(out_profile_parts), 0)
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     cap = 64 * len(names) + len(blob) + 1024
     out = C.create_string_buffer(cap)
@@ -499,6 +499,19 @@ class HipProfileOps:
         """NJ.tcc:729: out-profile of the listed nodes, accumulated in list order."""
         ids = _i64(active_ids)
         self._chk(self.lib.vft_out_profile_full(self.ctx, I64(len(ids)), _ptr(ids)))
+
+
+    def out_profile_partial(self, n_total, ids):
+        """raw sums of one block of the active list (vft_out_profile_partial): (n_pos, 1 + n_codes) array"""
+        ids = _i64(ids)
+        part = np.zeros((self.n_pos, 1 + self.n_codes), self.dt)
+        self._chk(self.lib.vft_out_profile_partial(self.ctx, I64(n_total), I64(len(ids)), _ptr(ids), _ptr(part)))
+        return part
+
+    def out_profile_finish(self, parts):
+        """the blocks added in order, normalised, installed (vft_out_profile_finish)"""
+        parts = np.ascontiguousarray(np.stack(parts), self.dt)
+        self._chk(self.lib.vft_out_profile_finish(self.ctx, I32(len(parts)), _ptr(parts)))
 
     def updateOutProfile(self, old1, old2, new, n_active_old):
         """NJ.tcc:943."""

@@ -171,6 +171,7 @@ struct vft_ctx {
         uint32_t acked = 0;     // every command up to this one has been answered by all six workgroups
         int stride = 8;         // VFT_DEBUG_WALK_SERVER_STRIDE: 8 = the six workgroups on one XCD, 1 = on six
         bool disabled = false;  // VFT_DEBUG_NO_WALK_SERVER
+        bool allocated = false; // every buffer of the server exists (set behind the last allocation of the first start)
     } ws;
     // the join loop on the device (vft_kernels_njengine.h)
     void *njState = nullptr, *njVisD = nullptr;
@@ -1380,7 +1381,9 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
     const size_t staticLds = (c->d.nCodes == 20 ? (size_t) 840 * c->rs : 8) + 1024;
     if (lds + staticLds > (160u << 10)) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: alignment too long for one workgroup per pair");
     vft_ctx::WalkServerHost &W = c->ws;
-    if (W.stream && !W.dFlags) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: an earlier start failed half-way (the walks keep the plain calls)");
+    // (`allocated` is raised behind the LAST allocation and the synchronisation below: a start that failed anywhere before that -
+    // the flags, the tick block, the mailbox, its device pointer - must not be launched on null pointers by the next call)
+    if (W.stream && !W.allocated) return fail(c, VFT_ERR_STATE, "vft_walk_server_start: an earlier start failed half-way (the walks keep the plain calls)");
     if (!W.stream) {
         HIPCHK(c, hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
         HIPCHK(c, hipHostMalloc((void **) &W.hRes, (size_t) VFT_WS_RING * VFT_WS_RESG * 8 + 512, hipHostMallocMapped));
@@ -1408,6 +1411,7 @@ extern "C" int vft_walk_server_start(vft_ctx *c) {
             memset(W.hMail, 0, mailBytes);
         }
         HIPCHK(c, hipDeviceSynchronize());
+        W.allocated = true;
     }
     if (int r = wait_stream(c)) return r;   // everything queued on the context's stream has written its rows
     for (int w = 0; w < VFT_WS_NWG; w++) W.hStatus[w] = 0;
@@ -1483,6 +1487,12 @@ extern "C" int vft_walk_submit(vft_ctx *c, int32_t n, const int64_t *out, const 
 extern "C" int vft_walk_collect(vft_ctx *c, uint32_t ticket, void *dist) {
     if (!c) return VFT_ERR_INVALID;
     const bool wide = c->rs == 8 && dist != nullptr;
+    // The answers share a ring of VFT_WS_RING slots: a ticket that old has had its slot rewritten (ws_command's flow control runs the
+    // sequence numbers at most VFT_WS_RING / 2 ahead of the acknowledged ones, not of the tickets a caller still holds) - say so at
+    // once instead of spinning for a tag that will never show again.
+    if ((int32_t) (c->ws.seq - ticket) >= VFT_WS_RING)
+        return fail(c, VFT_ERR_STATE, "vft_walk_collect: ticket %u is %d commands old, its answer slot has been reused (collect within %d submissions)",
+                    ticket, (int) (c->ws.seq - ticket), VFT_WS_RING - 1);
     if (int r = ws_wait(c, ticket, wide)) return r;
     if (dist) {
         const volatile unsigned long long *slot = c->ws.hRes + (size_t) (ticket % VFT_WS_RING) * VFT_WS_RESG;
@@ -1535,6 +1545,12 @@ extern "C" int vft_profiles_differ(vft_ctx *c, int64_t n, const int64_t *a, cons
     LAUNCHCHK(c);
     if (int w = wait_stream(c)) return w;
     memcpy(differ, h + 2 * idB, (size_t) n * 4);
+    return VFT_OK;
+}
+
+extern "C" int vft_get_n_codes(vft_ctx *c, int32_t *nCodes) {
+    if (!c || !nCodes) return VFT_ERR_INVALID;
+    *nCodes = c->cfg.n_codes;
     return VFT_OK;
 }
 
@@ -1648,6 +1664,38 @@ extern "C" int vft_out_profile_full(vft_ctx *c, int64_t n, const int64_t *ids) {
                                         arena<REAL>(c), (const int64_t *) c->scratch, n, c->fpostTol)));
     LAUNCHCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+// outProfile in parts (vft_kernels_profile.h: k_outprofile_partial / k_outprofile_finish).  vft_out_profile_partial: the raw sums of
+// `ids` (one block of the active list) with the in-weight of a list of n_total nodes, nPos x (1 + nCodes) numbers, to the host.
+// vft_out_profile_finish: n_parts such blocks (host, block after block) added in order, normalised, installed as the out-profile.
+extern "C" int vft_out_profile_partial(vft_ctx *c, int64_t nTotal, int64_t n, const int64_t *ids, void *part) {
+    if (!c || nTotal < 1 || n < 0 || n > nTotal || (n > 0 && !ids) || !part) return VFT_ERR_INVALID;
+    if (int r = flush_pending(c)) return r;
+    for (int64_t k = 0; k < n; k++)
+        if (ids[k] < 0 || ids[k] >= c->maxnode) return fail(c, VFT_ERR_INVALID, "vft_out_profile_partial: node %lld out of range", (long long) ids[k]);
+    const size_t pb = (size_t) c->d.nPos * (size_t) (1 + c->d.nCodes) * c->rs;
+    if (int r = ensure_scratch(c, (size_t) (n > 0 ? n : 1) * 8 + pb + 64)) return r;
+    char *dIds = (char *) c->scratch, *dPart = dIds + (((size_t) (n > 0 ? n : 1) * 8 + 63) / 64) * 64;
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(dIds, ids, (size_t) n * 8, hipMemcpyHostToDevice, c->stream));
+    VFT_DISPATCH(c, (launch((k_outprofile_partial<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,
+                            arena<REAL>(c), (const int64_t *) dIds, n, nTotal, (REAL *) dPart)));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(part, dPart, pb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VFT_OK;
+}
+
+extern "C" int vft_out_profile_finish(vft_ctx *c, int32_t nParts, const void *parts) {
+    if (!c || nParts < 1 || !parts) return VFT_ERR_INVALID;
+    const size_t pb = (size_t) c->d.nPos * (size_t) (1 + c->d.nCodes) * c->rs;
+    if (int r = ensure_scratch(c, (size_t) nParts * pb)) return r;
+    HIPCHK(c, hipMemcpyAsync(c->scratch, parts, (size_t) nParts * pb, hipMemcpyHostToDevice, c->stream));
+    VFT_DISPATCH(c, (launch((k_outprofile_finish<REAL, NC>), dim3(cdiv(c->d.nPos, 64)), dim3(64), 0, c->stream,
+                            arena<REAL>(c), (const REAL *) c->scratch, nParts, c->fpostTol)));
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the scratch block may be reused by the next call)
     return VFT_OK;
 }
 

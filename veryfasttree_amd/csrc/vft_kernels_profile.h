@@ -477,6 +477,56 @@ __device__ __forceinline__ void vft_out_codedist(const Arena<REAL> &A, int64_t p
     }
 }
 
+// outProfile in PARTS (the multi-GPU shard of SURVEY 8e: "per-GPU partial sums -> all-gather -> fixed-order sum"; the reference's
+// threaded outProfile is the same idea with per-thread partials over a dynamic schedule, NJ.tcc:763-783).  The active list is cut into
+// nParts blocks; k_outprofile_partial adds up one block exactly as k_outprofile_full adds up the whole list (weights with the in-weight
+// 1 / nTotal of the WHOLE list, frequencies by vft_add_to_freq) and leaves the raw sums - part[p * (1 + NC)] = weight, then the NC
+// frequencies; k_outprofile_finish adds the parts in block order (numeric_t additions: the reference merges its partials with
+// vector_add, NJ.tcc:782), then floors the weight, normalises and fills codeDist as k_outprofile_full's tail does.  The result depends
+// on nParts (as the reference's depends on its thread count) and on nothing else: not on how many ranks computed the parts.
+template <typename REAL, int NC>
+__global__ void k_outprofile_partial(Arena<REAL> A, const int64_t *ids, int64_t n, int64_t nTotal, REAL *part) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    const double inweight = 1.0 / (double) nTotal;
+    REAL wo = 0;
+    REAL f[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) f[k] = 0;
+    for (int64_t t = 0; t < n; t++) {
+        Col<REAL, NC> c;
+        vft_load_col<REAL, NC>(A, ids[t], p, c);
+        wo = (REAL) ((double) wo + (double) c.w * inweight);
+        if (c.w > 0) vft_add_to_freq<REAL, NC>(A, f, (double) c.w, c);
+    }
+    part[p * (1 + NC)] = wo;
+#pragma unroll
+    for (int k = 0; k < NC; k++) part[p * (1 + NC) + 1 + k] = f[k];
+}
+
+template <typename REAL, int NC>
+__global__ void k_outprofile_finish(Arena<REAL> A, const REAL *parts, int32_t nParts, double tol) {
+    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.d.nPos) return;
+    const int64_t stride = A.d.nPos * (1 + NC);
+    REAL wo = 0;
+    REAL f[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) f[k] = 0;
+    for (int32_t b = 0; b < nParts; b++) {
+        const REAL *src = parts + (int64_t) b * stride + p * (1 + NC);
+        wo = wo + src[0];
+#pragma unroll
+        for (int k = 0; k < NC; k++) f[k] = f[k] + src[1 + k];
+    }
+    if (wo <= 0) wo = (REAL) 1e-20;
+    vft_normalize_freq<REAL, NC>(A, f, tol);
+    A.outW[p] = wo;
+#pragma unroll
+    for (int k = 0; k < NC; k++) A.outF[p * NC + k] = f[k];
+    vft_out_codedist<REAL, NC>(A, p, f);
+}
+
 // outProfile (NJ.tcc:729-815), one thread per column, profiles accumulated in list order
 template <typename REAL, int NC>
 __global__ void k_outprofile_full(Arena<REAL> A, const int64_t *ids, int64_t n, double tol) {

@@ -1660,11 +1660,11 @@ namespace veryfasttree {
                     qOut.clear();
                     qA.clear();
                     qB.clear();
-                } else if (rc == VFT_ERR_TIMEOUT) {
-                    chk(rc);
-                } else {
-                    walkStepFused = false;   /* (no walk server - VFT_ERR_STATE - or it cannot take this step: the two calls from here on) */
+                } else if (rc != VFT_ERR_STATE) {
+                    chk(rc);   /* (a HIP error, a bad argument, a timeout: not a reason to go on another way) */
                 }
+                /* VFT_ERR_STATE: no walk server - or it cannot take this step -: the two plain calls for THIS step; the next guard tries
+                   to start the server again (one refused step does not switch it off for the rest of the tree) */
             }
             if (!fused) {
                 flushAverages();

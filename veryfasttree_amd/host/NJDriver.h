@@ -64,6 +64,7 @@ namespace veryfasttree {
         /* with comm: split the close-neighbour blocks of setAllLeafTopHits by rows and all-gather the results (round 3); off: every
            rank computes them whole - 25 GB of gathers at a million sequences cost more than the ~5 s of integer counts they split */
         bool shardLeafBlocks = false;
+        int outProfileParts = 0;   /* vft_nj_options.out_profile_parts: full out-profile recomputations as P blocks of the active list, split over the ranks */
         int seedBatch = 8;         /* setAllLeafTopHits: sweeps of this many unvisited seeds per device call (vft_sweep_batch); 1: a call per seed */
         bool walkServer = true;    /* refinement walks through the resident walk server (vft_walk_server_start); false: a launch per step */
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
@@ -216,7 +217,7 @@ namespace veryfasttree {
                             tot += diameter[v];
                         }
                     totdiam = tot;
-                    chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, (int64_t) active.size(), active.data()); });
+                    outProfileFull(active);
                     nActiveReset = nActive - 1;
                 } else {
                     const REAL dd = diameter[newnode] - diameter[i] - diameter[j];
@@ -481,7 +482,7 @@ namespace veryfasttree {
                             tot += diameter[v];
                         }
                     totdiam = tot;
-                    chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, (int64_t) active.size(), active.data()); });
+                    outProfileFull(active);
                     chkT("vft_nj_engine_set_state", [&]() { return vft_nj_engine_set_state(ctx, -1, -1, totdiam, -1); });
                     nActiveReset = nSeqs - enq - 1;
                 }
@@ -1902,6 +1903,46 @@ namespace veryfasttree {
             return out;
         }
 
+        /* outProfile over the active list (NJ.tcc:729-815).  opt.outProfileParts = 0: one pass in id order on this GPU (the one-thread
+           order).  P >= 2: the list in P blocks of ceil(n / P) consecutive entries; block b is summed by rank b % world
+           (vft_out_profile_partial, raw sums to the host), the ranks' blocks are all-gathered through vft_comm's host buffers
+           (rank r sends its blocks b = r, r + world, ... as slots 0, 1, ...), put back in block order and added up on every rank
+           (vft_out_profile_finish): the result depends on P, not on the number of ranks. */
+        int64_t outProfilePartCalls = 0;
+        void outProfileFull(const std::vector<int64_t> &active) {
+            const int P = opt.outProfileParts;
+            const int64_t n = (int64_t) active.size();
+            if (P < 2) {
+                chkT("vft_out_profile_full", [&]() { return vft_out_profile_full(ctx, n, active.data()); });
+                return;
+            }
+            const vft_comm *cm = opt.comm && opt.comm->world > 1 ? opt.comm : nullptr;
+            const int64_t W = cm ? cm->world : 1, rank = cm ? cm->rank : 0;
+            const int64_t per = (n + P - 1) / P;
+            int32_t nCodes = 0;
+            chk(vft_get_n_codes(ctx, &nCodes));
+            const size_t pb = (size_t) nPos * (size_t) (1 + nCodes) * sizeof(REAL);
+            const int64_t slots = (P + W - 1) / W;   /* blocks per rank (the last ranks' last slot may be empty) */
+            if (cm && (int64_t) (slots * pb) > cm->h_cap) throw std::invalid_argument("NJDriver: the out-profile blocks of a rank do not fit vft_comm's host buffer");
+            std::vector<char> mine((size_t) slots * pb, 0), all((size_t) P * pb);
+            for (int64_t k = 0; k < slots; k++) {
+                const int64_t b = k * W + rank;
+                if (b >= P) break;
+                const int64_t i0 = std::min(n, b * per), i1 = std::min(n, (b + 1) * per);
+                chkT("vft_out_profile_partial", [&]() { return vft_out_profile_partial(ctx, n, i1 - i0, active.data() + i0, mine.data() + (size_t) k * pb); });
+                outProfilePartCalls++;
+            }
+            if (cm) {
+                memcpy(cm->h_send, mine.data(), mine.size());
+                if (cm->allgather(cm->user, (int64_t) mine.size(), 0) != 0) throw std::runtime_error("NJDriver: all-gather of the out-profile blocks failed");
+                for (int64_t b = 0; b < P; b++)
+                    memcpy(all.data() + (size_t) b * pb, (const char *) cm->h_recv + (size_t) (b % W) * mine.size() + (size_t) (b / W) * pb, pb);
+            } else {
+                memcpy(all.data(), mine.data(), all.size());   /* (one rank: slot k is block k) */
+            }
+            chkT("vft_out_profile_finish", [&]() { return vft_out_profile_finish(ctx, P, all.data()); });
+        }
+
         /* setAllLeafTopHits' seed sweeps, several seeds per device call (vft_sweep_batch: its leaf seeds share passes over the targets,
            four per launch, and one batched selection).  Nothing on the device changes between the seeds of that loop - every
            out-distance carries the stamp n, the lists live on the host - so a seed's sweep is the same whenever it runs: the sweeps
@@ -1924,14 +1965,18 @@ namespace veryfasttree {
             std::vector<int64_t> batch(1, seed);
             for (int64_t t = s + 1; t < (int64_t) seeds.size() && (int) batch.size() < opt.seedBatch; t++)
                 if (!visited[(size_t) seeds[(size_t) t]]) batch.push_back(seeds[(size_t) t]);
-            std::vector<DevHit> dev(batch.size() * (size_t) k);
-            chkT("vft_sweep_batch", [&]() { return vft_sweep_batch(ctx, (int32_t) batch.size(), batch.data(), n, nDiffAllow(n), totdiam, k, dev.data(), nullptr, nullptr); });
+            /* the records are read where the selection left them - the host-mapped result block of each slot (vft_sweep_batch_view) -
+               and converted record by record: no copy in between (what bench.py's step times) */
+            chkT("vft_sweep_batch", [&]() { return vft_sweep_batch(ctx, (int32_t) batch.size(), batch.data(), n, nDiffAllow(n), totdiam, k, nullptr, nullptr, nullptr); });
             pending = false;
             std::vector<Besthit> first;
             for (size_t b = 0; b < batch.size(); b++) {
+                const void *view = nullptr;
+                chk(vft_sweep_batch_view(ctx, (int32_t) b, &view, nullptr));
+                const DevHit *dev = (const DevHit *) view;
                 std::vector<Besthit> out((size_t) k);
                 for (int32_t t = 0; t < k; t++) {
-                    const DevHit &h = dev[b * (size_t) k + (size_t) t];
+                    const DevHit &h = dev[(size_t) t];
                     out[t].i = h.j >= 0 ? batch[b] : -1;
                     out[t].j = h.j;
                     out[t].weight = (REAL) h.weight;

@@ -173,6 +173,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         opt.comm = o->comm;
         opt.threads = o->threads > 1 ? o->threads : 1;
         opt.gamma = o->gamma != 0;
+        opt.outProfileParts = o->out_profile_parts >= 2 ? o->out_profile_parts : 0;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_JOINS) opt.deviceJoins = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_LISTS) opt.deviceLists = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_RESET) opt.deviceReset = false;
