@@ -174,6 +174,10 @@ int vft_nj_last_lane_exchange(int64_t *out);
    padded share every rank sends, out[1], out[2] = rank `rank`'s items [k0, k1) of n_items, out[3] = where item `item` sits in the gathered
    buffer (in records) */
 int vft_nj_lane_share(int64_t n_items, int32_t world, int32_t rank, int64_t item, int64_t *out);
+/* the layout of the out-profile blocks' exchange (vft_nj_options.out_profile_parts; host/NJDriver.h outProfileBlock), exported for the CPU
+   test that runs it over gloo: out[0] = the rank that sums block `block` of `parts`, out[1] = the block's slot in that rank's share,
+   out[2] = slots per share, out[3], out[4] = the block's entries [i0, i1) of an active list of n nodes */
+int vft_nj_out_profile_block(int32_t parts, int32_t world, int32_t block, int64_t n, int64_t *out);
 
 /* out[3]: what `-gamma` (vft_nj_options.gamma) found for the last tree of this process - the Gamma(nCat) log-likelihood, the shape
    alpha, the factor every branch length was multiplied by (the reference's "Gamma(20) LogLk = .. alpha = .. rescaling lengths by ..") */

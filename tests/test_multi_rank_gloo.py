@@ -244,3 +244,65 @@ def test_lane_exchange_layout_over_two_ranks(tmp_path):
     out = str(tmp_path / "lanes.npy")
     mp.spawn(_lane_worker, args=(2, port, out), nprocs=2, join=True)
     assert bool(np.load(out)[0])
+
+
+def _out_profile_worker(rank, world, port, out):
+    """The out-profile in P blocks over gloo (vft_nj_options.out_profile_parts; SURVEY.md 8e: per-GPU partial sums, all-gather, fixed-order
+    sum) with the C++ layout function itself (vft_nj_out_profile_block): every rank sums the blocks it owns - numpy restatement of
+    k_outprofile_partial's running sums, one numeric_t rounding per step -, sends its share, puts the blocks back in block order and adds
+    them up as k_outprofile_finish does."""
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from veryfasttree_amd.backend import load_host_library
+    lib = load_host_library()
+    rng = np.random.default_rng(5)
+    n, width = 1037, 40
+    addends = rng.random((n, width)).astype(np.float32)   # what each active node adds per (column, weight / frequency) cell
+
+    def block_sum(i0, i1):
+        acc = np.zeros(width, np.float32)
+        for t in range(i0, i1):
+            acc = (acc + addends[t]).astype(np.float32)
+        return acc
+
+    results = {}
+    for P in (2, 3, 4, 7):
+        o = np.zeros(5, np.int64)
+        lay = []
+        for b in range(P):
+            assert lib.vft_nj_out_profile_block(C.c_int32(P), C.c_int32(world), C.c_int32(b), C.c_int64(n), o.ctypes.data_as(C.c_void_p)) == 0
+            lay.append(tuple(int(x) for x in o))
+        slots = lay[0][2]
+        mine = np.zeros((slots, width), np.float32)
+        for b, (owner, slot, _, i0, i1) in enumerate(lay):
+            if owner == rank:
+                mine[slot] = block_sum(i0, i1)
+        t_all = torch.zeros(world * slots * width, dtype=torch.float32)
+        dist.all_gather_into_tensor(t_all, torch.from_numpy(mine.reshape(-1).copy()))
+        got = t_all.numpy().reshape(world, slots, width)
+        total = np.zeros(width, np.float32)
+        for b, (owner, slot, _, i0, i1) in enumerate(lay):
+            total = (total + got[owner, slot]).astype(np.float32)
+        # what ONE rank computes for the same partition
+        want = np.zeros(width, np.float32)
+        covered = 0
+        for b, (_, _, _, i0, i1) in enumerate(lay):
+            want = (want + block_sum(i0, i1)).astype(np.float32)
+            covered += i1 - i0
+        assert covered == n and lay[0][3] == 0 and lay[-1][4] == n
+        results[P] = bool(np.array_equal(total, want))
+    if rank == 0:
+        np.save(out, np.array([all(results.values())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_out_profile_blocks_over_two_ranks_equal_one_rank(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "outprofile.npy")
+    mp.spawn(_out_profile_worker, args=(2, port, out), nprocs=2, join=True)
+    assert bool(np.load(out)[0])

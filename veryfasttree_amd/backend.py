@@ -49,7 +49,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_nj_last_lane_exchange", "vft_nj_lane_share", "vft_nj_last_gamma", "vft_tree_partitioning", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_nj_last_lane_exchange", "vft_nj_lane_share", "vft_nj_out_profile_block", "vft_nj_last_gamma", "vft_tree_partitioning", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
                 "vft_aa_model_tables", "vft_blosum45_tables", "vft_aa_model_as_distance_tables"]
 
 

@@ -1909,6 +1909,18 @@ namespace veryfasttree {
            (rank r sends its blocks b = r, r + world, ... as slots 0, 1, ...), put back in block order and added up on every rank
            (vft_out_profile_finish): the result depends on P, not on the number of ranks. */
         int64_t outProfilePartCalls = 0;
+        /* the layout of that exchange: block b of P is summed by rank b % world and travels as slot b / world of that rank's share of
+           ceil(P / world) slots; entries [i0, i1) of a list of n */
+    public:
+        static void outProfileBlock(int64_t P, int64_t world, int64_t b, int64_t n, int64_t &owner, int64_t &slot, int64_t &slots, int64_t &i0, int64_t &i1) {
+            const int64_t per = (n + P - 1) / P;
+            owner = b % world;
+            slot = b / world;
+            slots = (P + world - 1) / world;
+            i0 = std::min(n, b * per);
+            i1 = std::min(n, (b + 1) * per);
+        }
+    private:
         void outProfileFull(const std::vector<int64_t> &active) {
             const int P = opt.outProfileParts;
             const int64_t n = (int64_t) active.size();
@@ -1918,27 +1930,28 @@ namespace veryfasttree {
             }
             const vft_comm *cm = opt.comm && opt.comm->world > 1 ? opt.comm : nullptr;
             const int64_t W = cm ? cm->world : 1, rank = cm ? cm->rank : 0;
-            const int64_t per = (n + P - 1) / P;
             int32_t nCodes = 0;
             chk(vft_get_n_codes(ctx, &nCodes));
             const size_t pb = (size_t) nPos * (size_t) (1 + nCodes) * sizeof(REAL);
-            const int64_t slots = (P + W - 1) / W;   /* blocks per rank (the last ranks' last slot may be empty) */
+            int64_t owner, slot, slots, i0, i1;
+            outProfileBlock(P, W, 0, n, owner, slot, slots, i0, i1);
             if (cm && (int64_t) (slots * pb) > cm->h_cap) throw std::invalid_argument("NJDriver: the out-profile blocks of a rank do not fit vft_comm's host buffer");
             std::vector<char> mine((size_t) slots * pb, 0), all((size_t) P * pb);
-            for (int64_t k = 0; k < slots; k++) {
-                const int64_t b = k * W + rank;
-                if (b >= P) break;
-                const int64_t i0 = std::min(n, b * per), i1 = std::min(n, (b + 1) * per);
-                chkT("vft_out_profile_partial", [&]() { return vft_out_profile_partial(ctx, n, i1 - i0, active.data() + i0, mine.data() + (size_t) k * pb); });
+            for (int64_t b = 0; b < P; b++) {
+                outProfileBlock(P, W, b, n, owner, slot, slots, i0, i1);
+                if (owner != rank) continue;
+                chkT("vft_out_profile_partial", [&]() { return vft_out_profile_partial(ctx, n, i1 - i0, active.data() + i0, mine.data() + (size_t) slot * pb); });
                 outProfilePartCalls++;
             }
             if (cm) {
                 memcpy(cm->h_send, mine.data(), mine.size());
                 if (cm->allgather(cm->user, (int64_t) mine.size(), 0) != 0) throw std::runtime_error("NJDriver: all-gather of the out-profile blocks failed");
-                for (int64_t b = 0; b < P; b++)
-                    memcpy(all.data() + (size_t) b * pb, (const char *) cm->h_recv + (size_t) (b % W) * mine.size() + (size_t) (b / W) * pb, pb);
+                for (int64_t b = 0; b < P; b++) {
+                    outProfileBlock(P, W, b, n, owner, slot, slots, i0, i1);
+                    memcpy(all.data() + (size_t) b * pb, (const char *) cm->h_recv + (size_t) owner * mine.size() + (size_t) slot * pb, pb);
+                }
             } else {
-                memcpy(all.data(), mine.data(), all.size());   /* (one rank: slot k is block k) */
+                memcpy(all.data(), mine.data(), all.size());   /* (one rank: slot b is block b) */
             }
             chkT("vft_out_profile_finish", [&]() { return vft_out_profile_finish(ctx, P, all.data()); });
         }

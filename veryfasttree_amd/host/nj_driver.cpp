@@ -132,6 +132,15 @@ extern "C" int vft_nj_lane_share(int64_t nItems, int32_t world, int32_t rank, in
     return VFT_OK;
 }
 
+/* the layout of the out-profile blocks' exchange (NJDriver::outProfileBlock), for the CPU test that runs it over gloo:
+   out[0] = owner rank of block `block` of `parts`, out[1] = its slot in that rank's share, out[2] = slots per share, out[3], out[4] = the
+   block's entries [i0, i1) of a list of n */
+extern "C" int vft_nj_out_profile_block(int32_t parts, int32_t world, int32_t block, int64_t n, int64_t *out) {
+    if (parts < 1 || world < 1 || block < 0 || block >= parts || n < 0 || !out) return VFT_ERR_INVALID;
+    veryfasttree::NJDriver<float>::outProfileBlock(parts, world, block, n, out[0], out[1], out[2], out[3], out[4]);
+    return VFT_OK;
+}
+
 extern "C" int vft_nj_last_lane_exchange(int64_t *out) {
     if (!out) return VFT_ERR_INVALID;
     out[0] = gLaneExchange[0];
