@@ -16,8 +16,12 @@ def _ulps(a, b):
     return np.abs(a.view(it).astype(np.int64) - b.view(it).astype(np.int64))
 
 
+@pytest.mark.parametrize("rows", [False, True])
 @pytest.mark.parametrize("name", ["wb_nt_f32", "wb_nt_f64", "wb_aa_f32", "wb_aa_f64"])
-def test_matrix_model_operators_bit_census(name):
+def test_matrix_model_operators_bit_census(name, rows):
+    """rows: the context in row mode (vft_set_profile_rows, the ML stage's layout) - posteriors write dense rows directly, proteins through
+    the quad-of-lanes kernels (k_posterior_quad, k_pair_loglk_quad); otherwise tile streams through stash + commit and the whole-column
+    kernels for the posteriors."""
     from veryfasttree_amd import HipProfileOps
     d = G.load(name)
     dt = G.dtype_of(d)
@@ -40,6 +44,8 @@ def test_matrix_model_operators_bit_census(name):
     ops = HipProfileOps(n_seqs, n_pos, n_codes, dt)
     ops.upload_leaves(d["leaf.codes"])
     ops.set_max_node(min(root + 1, ops.max_nodes))
+    if rows:
+        ops.set_profile_rows(True)
     ops.set_rates(d["ml.rates"], d["ml.ratecat"])
     ops.set_ml_limits(*tolerances(dt))
     k = model + ".tm."

@@ -77,13 +77,17 @@ timed("outProfile, all active nodes", st.n_active, b_leaf + b_int, lambda: ops.o
 # ML operators.  ML profiles live in the transition matrix's eigenbasis, so they are built here the way the reference
 # does (posterior of the children, NJ.tcc:3516-3539): level 1 from leaf pairs, level 2 from level-1 pairs; the timed
 # posterior is level 2 (both children carry vectors), the timed pairLogLk runs between level-1 profiles.
+# Row mode (vft_set_profile_rows), as the ML stage of the pipeline runs (host/MLLengths.h): every internal profile a dense row, posteriors
+# write rows.  (Until round 6 this table timed the tile-stream path - stash, tile commit - which no ML stage takes.)
+ops.set_profile_rows(True)
 blk = min(16384, (nj // 3) * 2)
 half = blk // 2
 lv1 = n + np.arange(blk, dtype=np.int64)
 ops.posteriorProfile(lv1, 2 * np.arange(blk, dtype=np.int64), 2 * np.arange(blk, dtype=np.int64) + 1,
                      np.full(blk, 0.05), np.full(blk, 0.07))
-nv1 = ops.profile_nvectors(n, blk)
-phi1 = float(nv1.mean()) / L
+# (vector density of the level-1 posteriors from the rows themselves: vft_profile_nvectors reads the tile streams' masks)
+samp = [ops.profile_download(int(v)) for v in lv1[:: max(1, blk // 64)][:64]]
+phi1 = float(np.mean([((w > 0) & (cc == 127)).mean() for w, cc, f in samp]))
 side = L * (S + 1) + phi1 * L * V
 model = "JC" if which == "nt" else "LG"
 lv2 = n + blk + np.arange(half, dtype=np.int64)

@@ -701,6 +701,10 @@ class HipProfileOps:
         self._chk(self.lib.vft_pair_loglk(self.ctx, I64(len(a)), _ptr(a), _ptr(b), _ptr(length), _ptr(out), _ptr(site)))
         return (out, site) if site_lk else out
 
+    def set_profile_rows(self, on=True):
+        """vft_set_profile_rows: every internal profile as a dense row (what the ML stage works on); posteriors then write rows"""
+        self._chk(self.lib.vft_set_profile_rows(self.ctx, I32(1 if on else 0)))
+
     def posteriorProfile(self, out, a, b, len1, len2):
         """NJ.tcc:2137 for a batch of triples."""
         out, a, b = _i64(out), _i64(a), _i64(b)

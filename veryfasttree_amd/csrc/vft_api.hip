@@ -3444,6 +3444,37 @@ extern "C" int vft_nj_engine_adopt(vft_ctx *c, int64_t from, int64_t to) {
 }
 
 // ---------------------------------------------------------------------------------------------- likelihood
+// the batch operators under a 20-state matrix model: a quad of lanes per column (vft_kernels_ml.h, k_pair_loglk_quad / k_posterior_quad)
+static bool quad_pair_ok(const vft_ctx *c) { return c->d.nCodes == 20 && c->hasTm && c->d.nPos <= 512; }
+static bool quad_posterior_ok(const vft_ctx *c) { return c->d.nCodes == 20 && c->hasTm; }
+template <typename REAL>
+static void launch_pair_loglk_quad(vft_ctx *c, int64_t n, const int64_t *dA, const int64_t *dB, const double *dLen, double *dOut, double *dSite) {
+    if (c->d.nPos <= 320)
+        launch((k_pair_loglk_quad<REAL, 5>), dim3((unsigned) n), dim3(256), 0, c->stream, arena<REAL>(c), dA, dB, dLen, n, c->minRel, dOut, dSite);
+    else
+        launch((k_pair_loglk_quad<REAL, 8>), dim3((unsigned) n), dim3(256), 0, c->stream, arena<REAL>(c), dA, dB, dLen, n, c->minRel, dOut, dSite);
+}
+static void launch_pair_loglk_any(vft_ctx *c, int64_t n, const int64_t *dA, const int64_t *dB, const double *dLen, double *dOut, double *dSite) {
+    if (quad_pair_ok(c)) {
+        if (c->cfg.precision == 4) launch_pair_loglk_quad<float>(c, n, dA, dB, dLen, dOut, dSite);
+        else launch_pair_loglk_quad<double>(c, n, dA, dB, dLen, dOut, dSite);
+        return;
+    }
+    VFT_DISPATCH(c, (launch((k_pair_loglk<REAL, NC>), dim3((unsigned) n), dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), dA, dB, dLen, n, c->minRel, dOut, dSite)));
+}
+// posteriors into dense ML rows (stash-free): one workgroup per node with quads, or the whole-column kernel
+static void launch_posterior_rows(vft_ctx *c, int64_t cnt, const int64_t *dOut, const int64_t *dA, const int64_t *dB, const double *dL1, const double *dL2) {
+    if (quad_posterior_ok(c)) {
+        if (c->cfg.precision == 4) launch((k_posterior_quad<float>), dim3((unsigned) cnt), dim3(256), 0, c->stream, arena<float>(c), dOut, dA, dB, dL1, dL2, c->minLen, c->minRel);
+        else launch((k_posterior_quad<double>), dim3((unsigned) cnt), dim3(256), 0, c->stream, arena<double>(c), dOut, dA, dB, dL1, dL2, c->minLen, c->minRel);
+        return;
+    }
+    VFT_DISPATCH(c, {
+        const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
+        launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), dOut, dA, dB, dL1, dL2, c->minLen, c->minRel, (REAL *) nullptr);
+    });
+}
+
 extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int64_t *b, const double *length,
                               double *loglk, double *siteLk) {
     if (!c || n < 0 || !a || !b || !length || !loglk) return VFT_ERR_INVALID;
@@ -3461,9 +3492,7 @@ extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int
         memcpy(h, a, idB);
         memcpy(h + idB, b, idB);
         memcpy(h + 2 * idB, length, idB);
-        VFT_DISPATCH(c, (launch((k_pair_loglk<REAL, NC>), dim3((unsigned) n), dim3(VFT_ML_WG), 0, c->stream,
-                                            arena<REAL>(c), (const int64_t *) d, (const int64_t *) (d + idB),
-                                            (const double *) (d + 2 * idB), n, c->minRel, (double *) (d + 3 * idB), (double *) nullptr)));
+        launch_pair_loglk_any(c, n, (const int64_t *) d, (const int64_t *) (d + idB), (const double *) (d + 2 * idB), (double *) (d + 3 * idB), (double *) nullptr);
         LAUNCHCHK(c);
         if (int r = wait_stream(c)) return r;
         memcpy(loglk, h + 3 * idB, idB);
@@ -3476,9 +3505,7 @@ extern "C" int vft_pair_loglk(vft_ctx *c, int64_t n, const int64_t *a, const int
     HIPCHK(c, hipMemcpyAsync(s + 2 * idB, length, idB, hipMemcpyHostToDevice, c->stream));
     double *dOut = (double *) (s + 3 * idB);
     double *dSite = siteLk ? (double *) (s + 4 * idB) : nullptr;
-    VFT_DISPATCH(c, (launch((k_pair_loglk<REAL, NC>), dim3((unsigned) n), dim3(VFT_ML_WG), 0, c->stream,
-                                        arena<REAL>(c), (const int64_t *) s, (const int64_t *) (s + idB),
-                                        (const double *) (s + 2 * idB), n, c->minRel, dOut, dSite)));
+    launch_pair_loglk_any(c, n, (const int64_t *) s, (const int64_t *) (s + idB), (const double *) (s + 2 * idB), dOut, dSite);
     LAUNCHCHK(c);
     HIPCHK(c, hipMemcpyAsync(loglk, dOut, idB, hipMemcpyDeviceToHost, c->stream));
     if (siteLk) HIPCHK(c, hipMemcpyAsync(siteLk, dSite, sB, hipMemcpyDeviceToHost, c->stream));
@@ -3520,8 +3547,17 @@ extern "C" int vft_posterior_profiles(vft_ctx *c, int64_t n, const int64_t *out,
     HIPCHK(c, hipMemcpyAsync(s + 3 * idB, len1, idB, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s + 4 * idB, len2, idB, hipMemcpyHostToDevice, c->stream));
     }
+    // Row mode with every internal profile a row (the ML stage, vft_set_profile_rows): the results go to the nodes' dense rows - what every
+    // reader takes from then on - with no stash and no tile commit, as vft_posterior_profiles_blen writes them
+    const bool rows = c->rowMode && c->allRows && c->mlIs != nullptr;
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
+        if (rows) {
+            launch_posterior_rows(c, cnt, (const int64_t *) s + k0, (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0,
+                                  (const double *) (s + 3 * idB) + k0, (const double *) (s + 4 * idB) + k0);
+            LAUNCHCHK(c);
+            continue;
+        }
         VFT_DISPATCH(c, {
             const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
             launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
@@ -3659,12 +3695,8 @@ extern "C" int vft_posterior_profiles_blen(vft_ctx *c, int64_t n, const int64_t 
     const int64_t chunk = 32768;
     for (int64_t k0 = 0; k0 < n; k0 += chunk) {
         const int64_t cnt = n - k0 < chunk ? n - k0 : chunk;
-        VFT_DISPATCH(c, {
-            const dim3 grid(cdiv(c->d.nPos, VFT_ML_WG), (unsigned) cnt);
-            launch((k_posterior<REAL, NC>), grid, dim3(VFT_ML_WG), 0, c->stream, arena<REAL>(c), (const int64_t *) s + k0,
-                   (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0, (const double *) l1 + k0,
-                   (const double *) l2 + k0, c->minLen, c->minRel, (REAL *) nullptr);
-        });
+        launch_posterior_rows(c, cnt, (const int64_t *) s + k0, (const int64_t *) (s + idB) + k0, (const int64_t *) (s + 2 * idB) + k0, (const double *) l1 + k0,
+                              (const double *) l2 + k0);
         LAUNCHCHK(c);
     }
     if (!smallIds) HIPCHK(c, hipStreamSynchronize(c->stream));

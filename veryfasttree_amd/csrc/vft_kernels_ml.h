@@ -1204,6 +1204,87 @@ __device__ __forceinline__ void vft_sel_set(T (&a)[N], int idx, T v) {
     for (int i = 0; i < N; i++) a[i] = i == idx ? v : a[i];
 }
 
+// ---- The batch operators under a 20-state matrix model with a quad of lanes per column (round 6).  k_pair_loglk / k_posterior give a
+// lane whole columns: 160-byte vectors per lane behind loads that each touch 64 cache lines, every load inside the branches of the
+// column's case analysis and therefore waited for one by one (rocprofv3 PMC, LG at 4 166 pairs x 300 columns: 85 vector loads per
+// wavefront, 72 % of the wave cycles waiting, VALU busy 0.07), and k_pair_loglk's ordered total as the plain chain on one lane.  Here:
+// the line-search kernels' quad layout (lane l of a quad owns the states l, l + 4, ... of its column - the reference's four strided
+// accumulators, vft_quad_*), 64 columns per pass of a 256-thread workgroup, a quad's loads side by side in 32-byte pieces, the model's
+// tables in LDS, and the ordered total from the workgroup-wide scans (vft_lk_total_staged: the reference's sequence of roundings
+// at ~7 cycles per column).  Same operations on the same operands in the same order as the whole-column kernels: same bits.
+//   k_pair_loglk_quad<REAL, CPT>: one workgroup per pair, up to CPT * 64 columns (the host takes the whole-column kernel beyond).
+//   k_posterior_quad<REAL>: one workgroup per node, any length; dense ML rows only (the caller's context is in row mode).
+template <typename REAL, int CPT>
+__global__ __launch_bounds__(256) void k_pair_loglk_quad(Arena<REAL> A, const int64_t *aN, const int64_t *bN, const double *length, int64_t n,
+                                                         double minRel, double *loglkOut, double *siteLk) {
+    constexpr int WG = 256, CW = WG / 4, COLS = CPT * CW;
+    typedef Col<REAL, VFT_QS> ColT;
+    __shared__ REAL ee[VFT_MAXRATES * 20];
+    __shared__ double stage[COLS];
+    __shared__ double stageLog[COLS];
+    __shared__ double stageList[COLS * 3 / 2 + 64];
+    __shared__ signed char stageEvents[COLS / 2 + 16];
+    __shared__ LkOrderedShared ordSh;
+    __shared__ MlQuadTables<REAL> quadTab;
+    const int64_t k = blockIdx.x;
+    const int64_t a = aN[k], b = bN[k], nPos = A.d.nPos;
+    const double len = length[k];
+    const int ql = (int) (threadIdx.x & 3), qc = (int) threadIdx.x >> 2;
+    vft_quad_tables_load<REAL>(A, &quadTab);
+    __syncthreads();
+    vft_quad_exp_eigen_rates<REAL>(&quadTab, A.nRates, len, minRel, ee);
+    __syncthreads();
+    double col[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t p = (int64_t) qc + (int64_t) c * CW;
+        col[c] = VFT_LK_SKIP;
+        if (p < nPos) {
+            ColT c1, c2;
+            vft_quad_load_col_ml<REAL>(A, a, p, ql, c1);
+            vft_quad_load_col_ml<REAL>(A, b, p, ql, c2);
+            const int r = A.ratecat[p];
+            double lkAB;
+            const bool has = vft_quad_pair_lk_col<REAL>(&quadTab, c1, c2, ee + r * 20, ql, lkAB);
+            if (has) col[c] = lkAB;
+            if (siteLk && ql == 0) siteLk[k * nPos + p] = has ? lkAB : 1.0;
+        }
+    }
+    vft_lk_stage_cols<CPT, 4>(stage, stageLog, col, qc, ql, CW, (int) nPos);
+    const double tot = vft_lk_total_staged<WG, COLS>(stage, stageLog, stageList, stageEvents, &ordSh, (int) nPos, false);
+    if (threadIdx.x == 0) loglkOut[k] = tot;
+}
+
+template <typename REAL>
+__global__ __launch_bounds__(256) void k_posterior_quad(Arena<REAL> A, const int64_t *outN, const int64_t *aN, const int64_t *bN,
+                                                        const double *len1A, const double *len2A, double minLen, double minRel) {
+    constexpr int CW = 64;
+    typedef Col<REAL, VFT_QS> ColT;
+    __shared__ REAL ee1[VFT_MAXRATES * 20], ee2[VFT_MAXRATES * 20];
+    __shared__ MlQuadTables<REAL> quadTab;
+    const int64_t k = blockIdx.x;
+    const int64_t out = outN[k], a = aN[k], b = bN[k], nPos = A.d.nPos;
+    double len1 = len1A[k], len2 = len2A[k];
+    if (len1 < minLen) len1 = minLen;   // NJ.tcc:2150-2155
+    if (len2 < minLen) len2 = minLen;
+    const int ql = (int) (threadIdx.x & 3), qc = (int) threadIdx.x >> 2;
+    vft_quad_tables_load<REAL>(A, &quadTab);
+    __syncthreads();
+    vft_quad_exp_eigen_rates<REAL>(&quadTab, A.nRates, len1, minRel, ee1);
+    vft_quad_exp_eigen_rates<REAL>(&quadTab, A.nRates, len2, minRel, ee2);
+    __syncthreads();
+#pragma unroll 1
+    for (int64_t p = qc; p < nPos; p += CW) {
+        ColT c1, c2, o;
+        vft_quad_load_col_ml<REAL>(A, a, p, ql, c1);
+        vft_quad_load_col_ml<REAL>(A, b, p, ql, c2);
+        const int r = A.ratecat[p];
+        vft_quad_posterior_col<REAL>(&quadTab, c1, c2, ee1 + r * 20, ee2 + r * 20, ql, o);
+        vft_quad_store_col_ml<REAL>(A, out, p, ql, o.w, o.code, o.f);
+    }
+    if (threadIdx.x == 0) A.mlIs[out - A.d.nSeqs] = 1;
+}
+
 #define VFT_MLOPT_WG 256
 // Threads per workgroup of the two line-search kernels.  20-state alphabets: 512, so that alignments up to 512 columns
 // run with ONE column per thread - a thread keeps its columns of the three / four profiles in registers, 160 VGPRs per
