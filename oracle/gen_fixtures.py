@@ -455,7 +455,16 @@ def harvest_threads_big(n, threads):
     wall = float(open(os.path.join(HERE, "_ref", tag + ".wall")).read())
     ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", open(os.path.join(HERE, "_ref", tag + ".log")).read(), re.M)]
     flags = ["-nt", "-threads", str(threads), "-seed", "1"]
+    # Does the reference's NJ phase at T threads give its one-thread NJ tree for this alignment?  (`VeryFastTree -nt -noml -nome -nosupport
+    # -threads T` against `-threads 1`, both kept under oracle/_ref/ as <tag>_nj.tree / <tag>_nj_t1.tree; -1: not run.)  At 200 000 sequences
+    # and 64 threads it does NOT (one split and 22 branch lengths differ: its threaded outProfile sums per-thread partials, NJ.tcc:763-783),
+    # and a tree that starts from another NJ tree cannot be this backend's, whose NJ phase follows the one-thread order.
+    nj_equal = -1
+    pT, p1 = os.path.join(HERE, "_ref", tag + "_nj.tree"), os.path.join(HERE, "_ref", tag + "_nj_t1.tree")
+    if os.path.exists(pT) and os.path.exists(p1):
+        nj_equal = 1 if open(pT, "rb").read().strip() == open(p1, "rb").read().strip() else 0
     np.savez_compressed(os.path.join(GOLDEN, tag + "_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+                        reference_nj_equals_its_one_thread_nj=np.int64(nj_equal),
                         loglk=np.array(ll), threads=np.int64(threads), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
                         alignment=np.frombuffer(("random_descent_codes(%d, 200, 4, 0.02, 0.01, seed=4)" % n).encode(), dtype=np.uint8),
                         reference_wall_s=np.float64(wall))
