@@ -48,6 +48,32 @@ with open(os.path.join(dst, name + "_bench_pmc.txt"), "w") as f:
             f.write("%-110s %-11s %7d %16.1f %12.0f\n" % (k[:110], cn, n, v, ns))
 
 
+# instruction issue of the same kernels (profile_round.sh's third and fourth passes): per-kernel averages as text, and for the two
+# multi-seed sweep kernels the figures bench.py prints (roofline.valu)
+valu = pmc_avg(os.path.join(src, "bench_pmc_valu.csv")) if os.path.exists(os.path.join(src, "bench_pmc_valu.csv")) else {}
+mix = pmc_avg(os.path.join(src, "bench_pmc_mix.csv")) if os.path.exists(os.path.join(src, "bench_pmc_mix.csv")) else {}
+if valu:
+    with open(os.path.join(dst, name + "_bench_pmc_valu.txt"), "w") as f:
+        f.write("# python3 bench.py --steps 3 --warmup 1 --no-e2e --no-dense --no-cpu-baseline under rocprofv3 --pmc, two passes:\n"
+                "# SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY\n"
+                "# GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS\n"
+                "# (averages per dispatch; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles summed over the wavefronts;\n"
+                "#  valu_lane_frac = SQ_INSTS_VALU x 64 lanes / duration / (256 CUs x 64 lanes x 2.4 GHz);\n"
+                "#  valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs))\n")
+        kernels = sorted({k for k, _ in valu}, key=lambda k: -max(v[2] * v[1] for (kk, c), v in valu.items() if kk == k))
+        for k in kernels:
+            row = {c: v for (kk, c), v in valu.items() if kk == k}
+            row.update({c: v for (kk, c), v in mix.items() if kk == k})
+            calls, ns = row["SQ_WAVES"][1], row["SQ_WAVES"][2]
+            f.write("%s\n    calls %d  avg_us %.1f\n" % (k[:150], calls, ns / 1e3))
+            for cn in sorted(row):
+                f.write("    %-22s %.5g\n" % (cn, row[cn][0]))
+            iv, av, wc = row["SQ_INSTS_VALU"][0], row["SQ_ACTIVE_INST_VALU"][0], max(row["SQ_WAVE_CYCLES"][0], 1.0)
+            busy = av * 4 / (1024 * row["GRBM_GUI_ACTIVE"][0] / 8) if "GRBM_GUI_ACTIVE" in row and row["GRBM_GUI_ACTIVE"][0] > 0 else float("nan")
+            f.write("    -> valu_lane_frac %.3f  valu_busy %.3f  wave cycles: issuing %.2f  waiting (waitcnt / barrier) %.2f  issue-stalled %.2f\n" % (
+                iv * 64 / (ns * 1e-9) / (256 * 64 * 2.4e9), busy, row["SQ_ACTIVE_INST_ANY"][0] / wc, row["SQ_WAIT_ANY"][0] / wc, row["SQ_WAIT_INST_ANY"][0] / wc))
+
+
 def kern(prefix):
     out = {}
     for (k, cn), (v, n, ns) in list(fetch.items()) + list(write.items()):
@@ -71,10 +97,19 @@ if inst:
     entry = {"fetch_size_kb": round(fk, 1), "write_size_kb": round(wk, 1), "bytes_per_launch": int((2 * fk + wk) * 1024),
              "sweeps_per_launch": 4,
              "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"]}
+    vsum, vn = 0.0, 0
     for k, v in inst.items():
-        entry["leaf_seed_instance" if "leafq" in k else "profile_seed_instance"] = {
-            "fetch_size_kb": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1),
-            "bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
+        rec = {"fetch_size_kb": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1),
+               "bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
+        if (k, "SQ_INSTS_VALU") in valu:   # wavefront-level VALU instructions per launch; the busy fraction from the counters themselves
+            rec["valu_wave_insts_per_launch"] = round(valu[(k, "SQ_INSTS_VALU")][0], 1)
+            vsum += valu[(k, "SQ_INSTS_VALU")][0]
+            vn += 1
+            if (k, "GRBM_GUI_ACTIVE") in mix and mix[(k, "GRBM_GUI_ACTIVE")][0] > 0:
+                rec["valu_busy_frac_pmc"] = round(valu[(k, "SQ_ACTIVE_INST_VALU")][0] * 4 / (1024 * mix[(k, "GRBM_GUI_ACTIVE")][0] / 8), 4)
+        entry["leaf_seed_instance" if "leafq" in k else "profile_seed_instance"] = rec
+    if vn:
+        entry["valu_wave_insts_per_launch"] = round(vsum / vn, 1)
     traffic["sweep_launch_average"] = entry
 # the figure belongs to the sweep kernels as they were when the counters were read: bench.py prints it only while these files are unchanged
 sys.path.insert(0, ROOT)

@@ -1004,10 +1004,11 @@ __device__ __forceinline__ void vft_leaf_table_wg_multi(const Arena<REAL> &A, co
     }
 }
 
-// (four wavefronts per SIMD: every heavy workgroup of a million-sequence sweep is resident at once - the column loop of the float
-// instance fits, the table walk's epilogue gives up six registers to scratch)
+// (three wavefronts per SIMD in single precision: at four - 128 VGPRs - 23 registers of the column loop went to scratch, nine scratch
+// accesses per 16-column chunk and 120 MB of extra write traffic per launch (rocprofv3 WRITE_SIZE 181 MB against 60 MB of results);
+// with 137 registers nothing spills: 240 -> 215 us per launch of four profile seeds)
 template <typename REAL, int S>
-__global__ __launch_bounds__(VFT_WG, sizeof(REAL) == 4 ? 4 : 2) void k_sweep_nt_profq_multi(Arena<REAL> A, MultiLeafQ<REAL, S> M, SweepArgs s) {
+__global__ __launch_bounds__(VFT_WG, sizeof(REAL) == 4 ? 3 : 2) void k_sweep_nt_profq_multi(Arena<REAL> A, MultiLeafQ<REAL, S> M, SweepArgs s) {
     constexpr int SUB = 8;
     const int nT = s.nLeafWG, nHeavy = (int) gridDim.x - nT, blk = (int) blockIdx.x;
     REAL cmin[S], cmax[S];
@@ -2206,7 +2207,19 @@ __global__ __launch_bounds__(VFT_WG) void k_select_rank(const SelSlot *slots, in
     for (int t = threadIdx.x; t < VFT_NBINS; t += VFT_WG) sl.slices[t] = 0;
     // The records into the host's block, whole lines per wavefront.  (Measured and dropped in round 6: every workgroup writing its own
     // records there as it ranks them - 2 000 scattered 16-byte writes per seed over PCIe - took the kernel from 40 to 120 us.)
-    for (int t = threadIdx.x; t < k; t += VFT_WG) hostHits[t] = vft_hit_fetch<HIT>(hits + t);
+    for (int t0 = 0; t0 < k; t0 += 8 * VFT_WG) {   // (eight records per thread in flight: the fetches are L2 round trips)
+        HIT tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = t0 + u * VFT_WG + (int) threadIdx.x;
+            tmp[u] = vft_hit_fetch<HIT>(hits + (t < k ? t : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = t0 + u * VFT_WG + (int) threadIdx.x;
+            if (t < k) hostHits[t] = tmp[u];
+        }
+    }
     if (threadIdx.x == 0) {
         const unsigned int nn = n < (unsigned int) k ? n : (unsigned int) k;
         long long best = -1;
