@@ -376,6 +376,18 @@ int vft_walk_step(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a,
 int vft_walk_server_start(vft_ctx *ctx);
 int vft_walk_server_stop(vft_ctx *ctx);
 int vft_walk_submit(vft_ctx *ctx, int32_t n, const int64_t *out, const int64_t *a, const int64_t *b, const int64_t *q, uint32_t *ticket);
+/* Both continuations of an SPR chain in one command (csrc/vft_kernels_walk.h "DUAL command"; findSPRSteps NJ.tcc:1805-1859): which NNI
+   follows a chain step is one comparison of that step's own distances, so the step after it is built for either outcome and handed over
+   while the step is still running; the resident workgroups evaluate `criteria[1] < criteria[2]` themselves (logCorrect, NJ.tcc:322-330,
+   with glibc's log bit for bit) and take alternative 0 (B and C swapped) or 1 without a host round trip.  q0 / q1 == NULL: that
+   alternative is not a device step; taken, the command is an empty one.  At most 18 averages in both alternatives together.  The command
+   before it must be a step with distances.  vft_walk_dual_choice: what the workgroups chose (the caller, who makes the same
+   comparison on the distances it collects, checks it). */
+#define VFT_WALK_DUAL_MAX_AVERAGES 18
+int vft_walk_submit_dual(vft_ctx *ctx, int32_t n0, const int64_t *out0, const int64_t *a0, const int64_t *b0, const int64_t *q0,
+                         int32_t n1, const int64_t *out1, const int64_t *a1, const int64_t *b1, const int64_t *q1, int32_t scoredist,
+                         uint32_t *ticket);
+int vft_walk_dual_choice(vft_ctx *ctx, uint32_t ticket, int32_t *alt, int32_t *skipped);
 int vft_walk_collect(vft_ctx *ctx, uint32_t ticket, void *dist);
 /* tools builds (-DVFT_WALK_TIMING): clock ticks (100 MHz) workgroup 0 of the servers of this process spent per phase -
    [0] waiting for a command, [1] averages, [2] waiting for the other workgroups' averages, [3] the pair's columns, [4] the ordered

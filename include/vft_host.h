@@ -111,6 +111,8 @@ typedef struct {
 #define VFT_NJ_DEBUG_LEVEL_LENGTHS 16
 #define VFT_NJ_DEBUG_NO_WALK_SERVER 128
 #define VFT_NJ_DEBUG_SEED_BY_SEED 256
+#define VFT_NJ_DEBUG_NO_WALK_DUAL 512   /* SPR chains: every step waits for the host's verdict instead of handing both continuations of a step
+                                           to the walk server (vft_walk_submit_dual); same tree (tests compare) */
 #define VFT_NJ_SHARD_LEAF_BLOCKS 64   /* with comm: split the close-neighbour blocks by rows and all-gather the results (see vft_comm) */
 
 /* Runs the NJ phase on a context created for (n_seqs, n_pos, nt, max_nodes = 2*n_seqs) with nothing uploaded yet.
@@ -167,6 +169,9 @@ int vft_tree_partitioning(int64_t n_nodes, const int64_t *child, int64_t root, i
    the ML NNI rounds, the SH-like supports, the model fits (CAT rates, GTR).  counts[4]: lockstep steps of the subtree schedule
    (opt.threads > 1) and the quartets / splits judged in them, SPR chain steps evaluated, SPR moves made.  Either may be NULL. */
 int vft_nj_last_stage_seconds(double *seconds, int64_t *counts);
+/* out[2]: the SPR chains of the last tree - dual commands sent (both continuations of a chain step handed to the walk server,
+   vft_walk_submit_dual) and continuations the resident workgroups ran without waiting for the host's verdict */
+int vft_nj_last_walk_dual(int64_t *out);
 /* out[2]: with a vft_comm of several ranks, what the lanes of the subtree schedule exchanged during the last tree of this process - the
    number of all-gathers (one per lockstep step with a batch to judge) and the bytes this rank received in them */
 int vft_nj_last_lane_exchange(int64_t *out);

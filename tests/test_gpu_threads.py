@@ -148,6 +148,34 @@ def test_spr_walk_without_the_walk_server_gives_the_reference_tree(name, dt, aa)
     assert tree == bytes(d["newick"]).decode().strip()
 
 
+@pytest.mark.parametrize("name,dt,aa", [("spr_nt_500", np.float32, None), ("spr_nt_300_double", np.float64, None), ("nni_aa_150", np.float32, "jtt")])
+def test_spr_chains_with_both_continuations_on_the_device_give_the_reference_tree(name, dt, aa):
+    """SPR chains hand BOTH continuations of a chain step to the walk server (vft_walk_submit_dual; host/MLLengths.h specContinuations): the
+    resident workgroups compare the step's six distances themselves (logCorrect with glibc's log) and run the continuation that the
+    host - making the same comparison when the answer arrives - moves its state to; a disagreement throws.  `VeryFastTree [-nt] -noml`
+    with the default two SPR rounds, byte for byte, with the dual commands (the default: they must really have been taken) and with every
+    step waiting for the host's verdict (VFT_NJ_DEBUG_NO_WALK_DUAL)."""
+    from veryfasttree_amd import HipProfileOps
+    from veryfasttree_amd.backend import nj_newick, DEBUG_NO_WALK_DUAL, last_stage_seconds
+    d = G.load(name)
+    codes_all = d["codes"]
+    names = ["s%d" % k for k in range(len(codes_all))]
+    make = lambda n, L: HipProfileOps(n, L, 20 if aa else 4, dt, max_nodes=3 * n)
+    kw = dict(dtype=dt, me_lengths=True, me_nni=True, spr=2)
+    if aa:
+        kw["aa_model"] = aa
+    ref = bytes(d["newick"]).decode().strip()
+    tree = nj_newick(make, codes_all, names, **kw)
+    st = last_stage_seconds()
+    print(name, "SPR steps", st["spr_steps"], "dual commands", st["spr_dual_commands"], "continuations run by the device", st["spr_dual_continuations"])
+    assert tree == ref
+    assert st["spr_dual_commands"] > 100 and st["spr_dual_continuations"] > 50
+    tree = nj_newick(make, codes_all, names, debug_flags=DEBUG_NO_WALK_DUAL, **kw)
+    st = last_stage_seconds()
+    assert tree == ref
+    assert st["spr_dual_commands"] == 0
+
+
 @pytest.mark.parametrize("name", ["thr_full_nt_1500_t32", "thr_menni_nt_400_t4", "thr_mllen_nt_300_t4"])
 def test_lanes_across_two_ranks_give_the_single_rank_tree(name):
     """The lanes of the subtree schedule split over two ranks (host/MLLengths.h "lanes across ranks": every rank judges its share of a

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("VFT_HIP_LIB") or os.path.join(LIB_DIR, "libvft_hip.so
 NOCODE = 127
 # vft_nj_options.debug_flags (include/vft_host.h): tests and tools choose between equivalent loops explicitly
 DEBUG_HOST_JOINS, DEBUG_HOST_LISTS, DEBUG_HOST_RESET, DEBUG_LEVEL_LENGTHS, DEBUG_NO_WALK_SERVER = 1, 2, 4, 16, 128
+DEBUG_NO_WALK_DUAL = 512
 SHARD_LEAF_BLOCKS = 64
 
 P = C.c_void_p
@@ -30,7 +31,7 @@ EXPORTS = [
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full", "vft_out_profile_partial", "vft_out_profile_finish",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_sweep_batch", "vft_sweep_batch_view", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_batch_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_profiles_differ", "vft_get_max_nodes", "vft_get_n_codes", "vft_walk_step", "vft_walk_server_start", "vft_walk_server_stop", "vft_walk_submit", "vft_walk_collect", "vft_walk_server_ticks", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_branch_lengths_gather", "vft_branch_lengths_scatter", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
+    "vft_sweep_batch", "vft_sweep_batch_view", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_batch_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_profiles_differ", "vft_get_max_nodes", "vft_get_n_codes", "vft_walk_step", "vft_walk_server_start", "vft_walk_server_stop", "vft_walk_submit", "vft_walk_submit_dual", "vft_walk_dual_choice", "vft_walk_collect", "vft_walk_server_ticks", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_branch_lengths_gather", "vft_branch_lengths_scatter", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms", "vft_sweep_kernel_sweeps",
     "vft_debug_log", "vft_debug_option", "vft_tophits_create", "vft_tophits_upload", "vft_tophits_download", "vft_tophits_best", "vft_tophits_join", "vft_tophits_refresh", "vft_nj_engine_create", "vft_nj_engine_set_state", "vft_nj_engine_get_state", "vft_nj_engine_visible_set", "vft_nj_engine_visible_get", "vft_nj_engine_nodes_set", "vft_nj_engine_topvisible_set", "vft_nj_engine_topvisible_get", "vft_nj_engine_reset_candidates", "vft_nj_engine_enqueue", "vft_nj_engine_poll", "vft_nj_engine_resume", "vft_nj_engine_log", "vft_nj_engine_adopt", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
 ]
@@ -49,7 +50,7 @@ HIT_F32 = np.dtype([("j", np.int32), ("dist", np.float32), ("weight", np.float32
 HIT_F64 = np.dtype([("j", np.int64), ("dist", np.float64), ("weight", np.float64), ("criterion", np.float64)])
 
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libvft_host.so")
-HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_nj_last_lane_exchange", "vft_nj_lane_share", "vft_nj_out_profile_block", "vft_nj_last_gamma", "vft_tree_partitioning", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
+HOST_EXPORTS = ["vft_nj_run", "vft_nj_newick", "vft_nj_ml_newick", "vft_nj_last_join_crcs", "vft_nj_last_stage_seconds", "vft_nj_last_walk_dual", "vft_nj_last_lane_exchange", "vft_nj_lane_share", "vft_nj_out_profile_block", "vft_nj_last_gamma", "vft_tree_partitioning", "vft_knuth_stream", "vft_ml_lengths", "vft_gtr_tables",
                 "vft_aa_model_tables", "vft_blosum45_tables", "vft_aa_model_as_distance_tables"]
 
 
@@ -308,6 +309,9 @@ def last_stage_seconds():
     lib.vft_nj_last_stage_seconds(_ptr(sec), _ptr(cnt))
     out = {k: round(float(v), 2) for k, v in zip(STAGES, sec)}
     out.update(lane_steps=int(cnt[0]), lane_work=int(cnt[1]), spr_steps=int(cnt[2]), spr_moves=int(cnt[3]))
+    dual = np.zeros(2, np.int64)
+    lib.vft_nj_last_walk_dual(_ptr(dual))
+    out.update(spr_dual_commands=int(dual[0]), spr_dual_continuations=int(dual[1]))
     return out
 
 

@@ -45,7 +45,7 @@ ML_HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_profile.h", "vft_iter
 OBJ_DIR = os.path.join(HERE, "..", "build", "obj")   # git-ignored; objects are kept so that a header change recompiles only its units
 
 
-WALK_HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_profile.h", "vft_iterate_add.h", "vft_kernels_walk.h"]   # deps of vft_walk_kernels.hip
+WALK_HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_profile.h", "vft_iterate_add.h", "vft_kernels_walk.h", "vft_glibc_log.h", "vft_glibc_log_data.h"]   # deps of vft_walk_kernels.hip
 
 
 def unit_deps(src):

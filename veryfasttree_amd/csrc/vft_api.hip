@@ -1483,6 +1483,60 @@ extern "C" int vft_walk_submit(vft_ctx *c, int32_t n, const int64_t *out, const 
     *ticket = seq;
     return VFT_OK;
 }
+// Both continuations of an SPR chain behind the step that is running (vft_kernels_walk.h "DUAL command"): alternative 0 is taken when the
+// comparison of the PREVIOUS command's distances says "swap B and C" (criteria[1] < criteria[2]), alternative 1 otherwise.  q0 / q1 == NULL:
+// that alternative is not a device step - if it is the one taken the command counts as an empty one.  n0 + n1 <= VFT_WS_DUAL_MAXOPS
+// (VFT_ERR_INVALID beyond: the caller waits for the answer instead).  The command before must be a step with distances.
+extern "C" int vft_walk_submit_dual(vft_ctx *c, int32_t n0, const int64_t *out0, const int64_t *a0, const int64_t *b0, const int64_t *q0,
+                                    int32_t n1, const int64_t *out1, const int64_t *a1, const int64_t *b1, const int64_t *q1,
+                                    int32_t scoredist, uint32_t *ticket) {
+    if (!c || n0 < 0 || n1 < 0 || !ticket || (n0 > 0 && (!out0 || !a0 || !b0)) || (n1 > 0 && (!out1 || !a1 || !b1))) return VFT_ERR_INVALID;
+    if (!c->ws.up) return fail(c, VFT_ERR_STATE, "vft_walk_submit_dual: the walk server is not running (vft_walk_server_start)");
+    if (!q0) n0 = 0;
+    if (!q1) n1 = 0;
+    if (n0 + n1 > VFT_WS_DUAL_MAXOPS) return fail(c, VFT_ERR_INVALID, "vft_walk_submit_dual: %d + %d averages do not fit one command", (int) n0, (int) n1);
+    if (q0)
+        if (int r = walk_ids_ok(c, n0, out0, a0, b0, q0, "vft_walk_submit_dual")) return r;
+    if (q1)
+        if (int r = walk_ids_ok(c, n1, out1, a1, b1, q1, "vft_walk_submit_dual")) return r;
+    const uint32_t seq = ++c->ws.seq;
+    while ((int32_t) (seq - c->ws.acked) > VFT_WS_RING / 2)
+        if (int r = ws_wait(c, c->ws.acked + 1, false)) return r;
+    int g = 1;
+    for (int t = 0; t < 4; t++) ws_put(c, seq, g++, q0 ? (uint32_t) (int32_t) q0[t] : 0u);
+    for (int32_t k = 0; k < n0; k++) {
+        ws_put(c, seq, g++, (uint32_t) (int32_t) out0[k]);
+        ws_put(c, seq, g++, (uint32_t) (int32_t) a0[k]);
+        ws_put(c, seq, g++, (uint32_t) (int32_t) b0[k]);
+    }
+    for (int t = 0; t < 4; t++) ws_put(c, seq, g++, q1 ? (uint32_t) (int32_t) q1[t] : 0u);
+    for (int32_t k = 0; k < n1; k++) {
+        ws_put(c, seq, g++, (uint32_t) (int32_t) out1[k]);
+        ws_put(c, seq, g++, (uint32_t) (int32_t) a1[k]);
+        ws_put(c, seq, g++, (uint32_t) (int32_t) b1[k]);
+    }
+    // (bit 17 - "no workgroup is still reading rows" - stays clear: the step before is running)
+    ws_put(c, seq, 0, VFT_WS_CMD_WORK | ((uint32_t) n0 << 8) | (1u << VFT_WS_DUAL_BIT) | (q0 ? 0u : 1u << 19) | (q1 ? 0u : 1u << 20) |
+                      (scoredist ? 1u << 21 : 0u) | ((uint32_t) n1 << 24));
+    if (c->ws.mailOnDevice) __builtin_ia32_sfence();
+    *ticket = seq;
+    return VFT_OK;
+}
+// which alternative the workgroups took for the dual command `ticket` (waits for its first answers): *alt = 0 / 1, *skipped = 1 when
+// that alternative was not a device step
+extern "C" int vft_walk_dual_choice(vft_ctx *c, uint32_t ticket, int32_t *alt, int32_t *skipped) {
+    if (!c || !alt || !skipped) return VFT_ERR_INVALID;
+    if ((int32_t) (c->ws.seq - ticket) >= VFT_WS_RING) return fail(c, VFT_ERR_STATE, "vft_walk_dual_choice: ticket %u is too old", ticket);
+    if (int r = ws_wait(c, ticket, false)) return r;
+    const volatile unsigned long long *slot = c->ws.hRes + (size_t) (ticket % VFT_WS_RING) * VFT_WS_RESG;
+    for (long spins = 0; (uint32_t) (slot[VFT_WS_RES_CHOICE] >> 32) != ticket; spins++)   // (workgroup 0 writes it before its answer: a few polls at most)
+        if (spins > 100000000) return fail(c, VFT_ERR_TIMEOUT, "vft_walk_dual_choice: command %u carries no choice (not a dual command?)", ticket);
+    const uint32_t v = (uint32_t) slot[VFT_WS_RES_CHOICE];
+    *alt = (int32_t) ((v >> 1) & 1u);
+    *skipped = (int32_t) ((v >> 2) & 1u);
+    return VFT_OK;
+}
+
 // waits for the answer to a ticket; dist[6] (numeric_t) when the step asked for distances (NULL: an acknowledgement is waited for)
 extern "C" int vft_walk_collect(vft_ctx *c, uint32_t ticket, void *dist) {
     if (!c) return VFT_ERR_INVALID;

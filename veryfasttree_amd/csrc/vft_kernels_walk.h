@@ -25,6 +25,7 @@
 // Every spin is bounded: a workgroup that sees no command for idleTicks, or no flag for flagTicks, reports a status and exits.
 #ifndef VFT_KERNELS_WALK_H
 #define VFT_KERNELS_WALK_H
+#include "vft_glibc_log.h"
 
 #define VFT_WS_WG_OF(NC) ((NC) == 4 ? 512 : 256)   // threads per workgroup: 8 wavefronts for 4-state columns, 4 for 20-state ones (a pair of
                                                   // columns of four 20-state profiles does not fit 256 registers), each owning column slices
@@ -35,6 +36,19 @@
 #define VFT_WS_RESG 16       // result granules per slot: workgroup w writes [2 w] (and [2 w + 1]: the high half of a double)
 #define VFT_WS_CMD_WORK 1u
 #define VFT_WS_CMD_STOP 2u
+// A DUAL command (round 6) carries BOTH continuations of an SPR chain: which NNI follows step k is one comparison of step k's own
+// distances (findSPRSteps, NJ.tcc:1805-1859: "criteria[1] < criteria[2]"), so the host - which cannot know the outcome yet - builds
+// the next step for either outcome and hands both over while step k is still running; the workgroups exchange step k's six distances
+// through device memory, evaluate the comparison themselves (logCorrect with glibc's log, bit for bit: vft_glibc_log.h) and take
+// their alternative without a host round trip.  Header: bit 18 = dual, bits 8-15 = averages of alternative 0 (B and C swapped:
+// criteria[1] < criteria[2]), bits 24-31 = averages of alternative 1, bit 19 / 20 = alternative 0 / 1 is NOT a device step (the chain
+// ends there, the quartet is answered from the host's memo table, too many averages): the command then counts as an empty one;
+// bit 21 = logCorrect's scoredist flavour (NJ.tcc:322-330).
+// Granules: [0] header, [1..4] quartet 0, [5 .. 5 + 3 n0) averages 0, then quartet 1 (4) and averages 1 (3 n1): n0 + n1 <= 18.
+#define VFT_WS_DUAL_BIT 18
+#define VFT_WS_DUAL_MAXOPS 18
+#define VFT_WS_RES_CHOICE 12   // result granule of a dual command: {seq, 1 | alternative << 1 | not-a-device-step << 2} (workgroup 0)
+#define VFT_WS_FLAG_DIST 16    // flags[16 + 16 * (seq & 1) + 2 w (+ 1)]: workgroup w's distance of command seq, tagged (low / high half)
 #define VFT_WS_SC1 16        // aux bits of the buffer intrinsics on gfx950: write-through stores / L1-bypassing loads
 
 struct WalkServerArgs {
@@ -289,7 +303,8 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
                 const unsigned long long ok = __ballot((uint32_t) (g >> 32) == seq);
                 if (ok & 1ull) {
                     const uint32_t hdr = (uint32_t) __shfl(g, 0, 64);
-                    const int cnt = (hdr & 0xFFu) == VFT_WS_CMD_STOP ? 1 : 5 + 3 * (int) ((hdr >> 8) & 0xFFu);
+                    const bool dual = (hdr >> VFT_WS_DUAL_BIT) & 1u;
+                    const int cnt = (hdr & 0xFFu) == VFT_WS_CMD_STOP ? 1 : dual ? 9 + 3 * (int) (((hdr >> 8) & 0xFFu) + ((hdr >> 24) & 0xFFu)) : 5 + 3 * (int) ((hdr >> 8) & 0xFFu);
                     const unsigned long long need = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
                     if ((ok & need) == need) {
                         sCmd[lane] = (uint32_t) g;
@@ -300,6 +315,60 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
                 if ((long long) wall_clock64() - t0 > S.idleTicks) {
                     end = 2;
                     break;
+                }
+            }
+            // ---- a dual command: the comparison of the command before (its six distances, from the workgroups' device-memory words),
+            //      then this command becomes the plain command of the alternative taken
+            if (!end && ((sCmd[0] >> VFT_WS_DUAL_BIT) & 1u)) {
+                const unsigned long long *dw = S.flags + VFT_WS_FLAG_DIST + 16 * ((seq - 1u) & 1u);
+                constexpr int NG = sizeof(REAL) == 4 ? 1 : 2;
+                const long long t1 = wall_clock64();
+                unsigned long long g = 0;
+                for (;;) {
+                    const int idx = sizeof(REAL) == 4 ? 2 * lane : lane;   // float: word 2 w; double: words 2 w and 2 w + 1
+                    g = lane < NG * VFT_WS_NWG ? vft_ws_ld_dev(dw + idx) : ((unsigned long long) (seq - 1u) << 32);
+                    if (__all((uint32_t) (g >> 32) == seq - 1u)) break;
+                    if ((long long) wall_clock64() - t1 > S.flagTicks) {
+                        end = 3;
+                        break;
+                    }
+                }
+                if (!end) {
+                    double c[6];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) {
+                        double d;
+                        if constexpr (sizeof(REAL) == 4) {
+                            d = (double) __uint_as_float((uint32_t) __shfl(g, t, 64));
+                        } else {
+                            const uint32_t lo = (uint32_t) __shfl(g, 2 * t, 64), hi = (uint32_t) __shfl(g, 2 * t + 1, 64);
+                            d = __hiloint2double((int) hi, (int) lo);
+                        }
+                        // logCorrect (NJ.tcc:322-330; host/MLLengths.h logCorrect): Jukes-Cantor or scoredist-like, capped at 3
+                        const double maxscore = 3.0;
+                        double x;
+                        if (!((sCmd[0] >> 21) & 1u)) x = d < 0.74 ? -0.75 * vft_glibc_log(1.0 - d * 4.0 / 3.0) : maxscore;
+                        else x = d < 0.99 ? -1.3 * vft_glibc_log(1.0 - d) : maxscore;
+                        c[t] = x < maxscore ? x : maxscore;
+                    }
+                    // criteria AB+CD, AC+BD, AD+BC over the distances AB AC AD BC BD CD (meCollect)
+                    const double c1 = c[1] + c[4], c2 = c[2] + c[3];
+                    const int alt = c1 < c2 ? 0 : 1;
+                    const uint32_t hdr = sCmd[0];
+                    const int n0 = (int) ((hdr >> 8) & 0xFFu), n1 = (int) ((hdr >> 24) & 0xFFu);
+                    const bool skip = (hdr >> (19 + alt)) & 1u;
+                    const int nAlt = skip ? 0 : (alt ? n1 : n0);
+                    // alternative 1's granules move down to where a plain command has them (alternative 0's are there already)
+                    const int src = alt ? 5 + 3 * n0 + lane : 1 + lane;
+                    const uint32_t v = src < VFT_WS_GRAN ? sCmd[src] : 0u;
+                    if (lane < 4 + 3 * nAlt) sCmd[1 + lane] = v;   // (one wavefront: every lane has read before any lane writes)
+                    if (lane == 0) {
+                        sCmd[0] = (hdr & 0xFFu) | ((uint32_t) nAlt << 8) | (skip ? 0u : 1u << 16) | (hdr & (1u << 17));
+                        if (w == 0)
+                            __hip_atomic_store(S.res + (size_t) (seq % VFT_WS_RING) * VFT_WS_RESG + VFT_WS_RES_CHOICE,
+                                               ((unsigned long long) seq << 32) | 1ull | ((unsigned long long) alt << 1) | ((unsigned long long) (skip ? 1 : 0) << 2),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                 }
             }
             // the rows the chain is about to overwrite may still be read by a slower workgroup's pair phase of the command before
@@ -432,6 +501,15 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
         if (threadIdx.x == 0) {
             const double top = sSum[0], denom = sSum[1];
             const REAL d = (REAL) (denom > 0 ? top / denom : 1.0);   // profileDist / seqDist (NJ.tcc:1183-1189, :1621-1623)
+            {   // ... and to the other workgroups (a dual command that follows compares the six distances on the device)
+                unsigned long long *dw = S.flags + VFT_WS_FLAG_DIST + 16 * (seq & 1u) + 2 * w;
+                if constexpr (sizeof(REAL) == 4) {
+                    __hip_atomic_store(dw, ((unsigned long long) seq << 32) | (unsigned long long) __float_as_uint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __hip_atomic_store(dw, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2loint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dw + 1, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2hiint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             if constexpr (sizeof(REAL) == 4) {
                 __hip_atomic_store(out, ((unsigned long long) seq << 32) | (unsigned long long) __float_as_uint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {

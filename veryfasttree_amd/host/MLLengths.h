@@ -986,15 +986,33 @@ namespace veryfasttree {
                     int64_t around = nodeAround[iAround], chainLength = 0;
                     MeTicket first;
                     bool firstOpen = false;
+                    /* round 6: from the second step of a chain on, the step AFTER the one that is running is built for both outcomes of
+                       its comparison and handed over as a dual command (specContinuations): `adopt` = the next step is already on the
+                       device - the alternative the workgroups took - and the host state has been moved to it (txnRedo) */
+                    bool adopt = false;
+                    SprAlt adopted;
                     for (; chainLength < maxSPRLength; chainLength++) {
                         if (around < nSeqs || around == root) break;   /* nChild != 2 */
                         int64_t q[4];
                         double criteria[3];
                         MeTicket tk;
-                        meSubmit(around, upHave, q, tk);
+                        bool verifyDual = false;
+                        if (adopt) {
+                            for (int i = 0; i < 4; i++) q[i] = adopted.q[i];
+                            tk = adopted.t;
+                            tk.pending = true;
+                            tk.ticket = adopted.ticket;
+                            verifyDual = true;
+                            adopt = false;
+                        } else {
+                            meSubmit(around, upHave, q, tk);
+                        }
                         sprSteps++;
                         Step &st = steps[(size_t) chainLength];
                         bool swapBC;
+                        /* both continuations of THIS step, before its distances are waited for (the forced first step has one) */
+                        bool dualSent = false;
+                        if (chainLength >= 1 && walkDual && serverUp && tk.pending) dualSent = specContinuations(node, around, q, (int) chainLength, maxSPRLength, scoredist, upHave);
                         if (chainLength == 0) {
                             swapBC = acFirst != 0;
                             first = tk;
@@ -1007,6 +1025,11 @@ namespace veryfasttree {
                                 firstOpen = false;
                             }
                             meCollect(tk, scoredist, criteria);
+                            if (verifyDual) {   /* the workgroups made the same comparison on the same six numbers */
+                                int32_t alt = -1, skipped = -1;
+                                chk(vft_walk_dual_choice(ctx, tk.ticket, &alt, &skipped));
+                                if (alt != adopted.alt || skipped) throw std::logic_error("MLLengths::sprAttempt: the walk server took another continuation than the host");
+                            }
                             swapBC = criteria[1] < criteria[2];
                             st.deltaLength = (swapBC ? criteria[1] : criteria[2]) - criteria[0];
                         }
@@ -1018,12 +1041,31 @@ namespace veryfasttree {
                             st.nodes[0] = q[0];
                             st.nodes[1] = q[2];
                         }
+                        if (dualSent && specAlt[swapBC ? 0 : 1].valid) {
+                            /* the device is running the next step already: move the host state to where building it had left it */
+                            SprAlt &A = specAlt[swapBC ? 0 : 1];
+                            txnRedo(A.log);
+                            walkDualTaken++;
+                            adopted = A;
+                            adopted.alt = swapBC ? 0 : 1;
+                            adopt = true;
+                            around = A.aroundNext;
+                            continue;
+                        }
                         replaceChild(around, st.nodes[0], st.nodes[1]);
                         replaceChild(parent[(size_t) around], st.nodes[1], st.nodes[0]);
                         updateForNNI(around, false, upHave);
                         int64_t next[2];
                         movePivots(node, next);
                         around = next[next[0] == around ? 1 : 0];
+                    }
+                    if (adopt) {   /* (cannot happen: a continuation is only valid while the chain goes on - but a step on the device must be collected) */
+                        MeTicket tk = adopted.t;
+                        tk.pending = true;
+                        tk.ticket = adopted.ticket;
+                        double c[3];
+                        meCollect(tk, scoredist, c);
+                        throw std::logic_error("MLLengths::sprAttempt: a continuation was adopted beyond the chain's end");
                     }
                     if (firstOpen) {
                         double c0[3];
@@ -1372,6 +1414,9 @@ namespace veryfasttree {
 
         int64_t nStarTests = 0;
         bool walkStepFused = true;   /* meSubmit: averages + distances as one step of the walk server (false: the two plain calls) */
+        int64_t walkDualSent = 0, walkDualTaken = 0;   /* statistics: dual commands sent / continuations the walk server ran on its own */
+        bool walkDual = true;        /* SPR chains hand both continuations of a step to the walk server (specContinuations); false: every step waits
+                                        for the host's verdict (vft_nj_options.debug_flags & VFT_NJ_DEBUG_NO_WALK_DUAL) */
         bool walkServer = true;      /* the walks' steps go to resident workgroups through a mailbox (vft_walk_server_start); false: the
                                         two plain calls per step (tests compare) */
         int64_t sprSteps = 0;        /* chain steps evaluated by the SPR rounds */
@@ -1565,29 +1610,121 @@ namespace veryfasttree {
         }
 
         void replaceChild(int64_t par, int64_t oldChild, int64_t newChild) {   /* NJ.tcc:1929-1940 */
-            parent[(size_t) newChild] = par;
+            put8(&parent[(size_t) newChild], par);
             for (int k = 0; k < 3; k++)
                 if (child[3 * par + k] == oldChild) {
-                    child[3 * par + k] = newChild;
+                    put8(&child[3 * par + k], newChild);
                     return;
                 }
             throw std::logic_error("MLLengths::replaceChild: not a child");
         }
 
+        /* ---- A TRANSACTION over the host state of a walk (round 6: both continuations of an SPR chain step are built before the step's
+           own distances say which one it will be, see sprAttempt).  While `txn.on` every write of the functions a chain step runs
+           through - the tree arrays (replaceChild), the up-profile flags (updateForNNI, ensureUpProfile), the rows' value numbers
+           (setVer), the record of pending averages (queueAverage, schedule: kept as whole copies, a few dozen entries) and the
+           walk's counters - is logged with its old and its new value.  txnEnd() puts everything back and hands the log over; txnRedo()
+           applies a log forwards: the state the transaction had reached, without running it again.  NOT logged, on purpose: the
+           value-number and memo tables and the next fresh number (facts about values: an entry made by a continuation that is never
+           taken is still true, and a number is never handed out twice), the scratch stamps of schedule(). */
+        struct PendOp {   /* a recorded average (see schedule()) */
+            int64_t out, a, b;
+        };
+        struct WalkTxnLog {
+            struct W8 { int64_t *p; int64_t oldV, newV; };
+            struct WC { char *p; char oldV, newV; };
+            struct WV { size_t row; uint64_t oldVer, newVer; uint32_t oldEp, newEp; };
+            std::vector<W8> w8;
+            std::vector<WC> wc;
+            std::vector<WV> wv;
+            std::vector<PendOp> pendOld, pendNew;
+            int64_t cntOld[4], cntNew[4];   /* avgRedundant, avgQueued, avgDropped, stepsMemoised */
+            void clear() {
+                w8.clear();
+                wc.clear();
+                wv.clear();
+            }
+        };
+        struct WalkTxn {
+            bool on = false;
+            WalkTxnLog *log = nullptr;
+        } txn;
+        void put8(int64_t *p, int64_t v) {
+            if (txn.on) {
+                typename WalkTxnLog::W8 e = {p, *p, v};
+                txn.log->w8.push_back(e);
+            }
+            *p = v;
+        }
+        void putc(char *p, char v) {
+            if (txn.on) {
+                typename WalkTxnLog::WC e = {p, *p, v};
+                txn.log->wc.push_back(e);
+            }
+            *p = v;
+        }
+        void txnBegin(WalkTxnLog &log) {
+            if (txn.on || cur || !qOut.empty()) throw std::logic_error("MLLengths::txnBegin: not at a step boundary of a single walk");
+            log.clear();
+            log.pendOld = pend;
+            log.cntOld[0] = avgRedundant;
+            log.cntOld[1] = avgQueued;
+            log.cntOld[2] = avgDropped;
+            log.cntOld[3] = stepsMemoised;
+            txn.log = &log;
+            txn.on = true;
+        }
+        void txnEnd() {   /* roll back; the log keeps both directions */
+            WalkTxnLog &log = *txn.log;
+            txn.on = false;
+            log.pendNew.swap(pend);
+            pend = log.pendOld;
+            log.cntNew[0] = avgRedundant;
+            log.cntNew[1] = avgQueued;
+            log.cntNew[2] = avgDropped;
+            log.cntNew[3] = stepsMemoised;
+            avgRedundant = log.cntOld[0];
+            avgQueued = log.cntOld[1];
+            avgDropped = log.cntOld[2];
+            stepsMemoised = log.cntOld[3];
+            for (size_t k = log.wv.size(); k-- > 0;) {
+                rowVer[log.wv[k].row] = log.wv[k].oldVer;
+                rowVerEpoch[log.wv[k].row] = log.wv[k].oldEp;
+            }
+            for (size_t k = log.wc.size(); k-- > 0;) *log.wc[k].p = log.wc[k].oldV;
+            for (size_t k = log.w8.size(); k-- > 0;) *log.w8[k].p = log.w8[k].oldV;
+            qOut.clear();
+            qA.clear();
+            qB.clear();
+        }
+        void txnRedo(const WalkTxnLog &log) {
+            for (const typename WalkTxnLog::W8 &e: log.w8) *e.p = e.newV;
+            for (const typename WalkTxnLog::WC &e: log.wc) *e.p = e.newV;
+            for (const typename WalkTxnLog::WV &e: log.wv) {
+                rowVer[e.row] = e.newVer;
+                rowVerEpoch[e.row] = e.newEp;
+            }
+            pend = log.pendNew;
+            avgRedundant += log.cntNew[0] - log.cntOld[0];
+            avgQueued += log.cntNew[1] - log.cntOld[1];
+            avgDropped += log.cntNew[2] - log.cntOld[2];
+            stepsMemoised += log.cntNew[3] - log.cntOld[3];
+        }
+
         /* updateForNNI, fast flavour (NJ.tcc:1902-1926): drop the up-profiles around the rearranged node, refresh its
            profile and its parent's */
         void updateForNNI(int64_t node, bool useML, std::vector<char> &upHave) {
-            upHave[(size_t) node] = 0;
-            for (int k = 0; k < 2; k++) upHave[(size_t) child[3 * node + k]] = 0;
+            putc(&upHave[(size_t) node], 0);
+            for (int k = 0; k < 2; k++) putc(&upHave[(size_t) child[3 * node + k]], 0);
             const int64_t ip = parent[(size_t) node];
             if (ip == root) {
                 for (int k = 0; k < 3; k++)
-                    if (child[3 * root + k] != node) upHave[(size_t) child[3 * root + k]] = 0;
+                    if (child[3 * root + k] != node) putc(&upHave[(size_t) child[3 * root + k]], 0);
             } else {
-                upHave[(size_t) ip] = 0;
-                upHave[(size_t) siblingOf(node)] = 0;
+                putc(&upHave[(size_t) ip], 0);
+                putc(&upHave[(size_t) siblingOf(node)], 0);
             }
-            if (ip != root && parent[(size_t) ip] != root) upHave[(size_t) siblingOf(ip)] = 0;   /* the uncle */
+            if (ip != root && parent[(size_t) ip] != root) putc(&upHave[(size_t) siblingOf(ip)], 0);   /* the uncle */
             recomputeProfile(node, useML);
             recomputeProfile(ip, useML);
         }
@@ -1617,7 +1754,70 @@ namespace veryfasttree {
             uint64_t key[4];
             REAL d[6];
         };
-        void meSubmit(int64_t node, std::vector<char> &upHave, int64_t q[4], MeTicket &t) {
+        /* ---- Both continuations of a chain step (round 6; csrc/vft_kernels_walk.h "DUAL command").  Step k of a chain (k >= 1) is on
+           the device; which NNI it leads to - swap B and C, or A and C (findSPRSteps, NJ.tcc:1805-1859) - is one comparison of its own
+           distances.  For either outcome: inside a transaction, make the swap (replaceChild x 2, updateForNNI), find the next pivot
+           and, if the chain goes on there, build step k + 1 (meBuild: up-profile, memo table, the averages its rows depend on);
+           keep the command and the transaction's log, put the state back.  The two commands go down as ONE dual command behind step
+           k; the workgroups compare step k's distances themselves and run their alternative at once - the ~2.4 us in which they
+           used to wait for the host's verdict are gone for every step whose continuation is a plain device step.  A continuation
+           that is not one (the chain ends, the quartet is in the memo table, too many averages for one command) is sent as "not a
+           device step"; taken, it costs an empty command and the host goes on as before.  When the step's answer arrives the host
+           makes the comparison too, applies the log of the continuation taken (txnRedo) and checks the workgroups' choice against
+           its own (vft_walk_dual_choice). */
+        struct SprAlt {
+            bool valid = false;
+            int alt = 0;
+            int64_t aroundNext = -1;
+            int64_t q[4], q4[4];
+            MeTicket t;
+            uint32_t ticket = 0;
+            std::vector<int64_t> out, a, b;
+            WalkTxnLog log;
+        };
+        SprAlt specAlt[2];
+        bool specContinuations(int64_t node, int64_t around, const int64_t q[4], int chainLength, int maxSPRLength, bool scoredist, std::vector<char> &upHave) {
+            for (int alt = 0; alt < 2; alt++) {
+                SprAlt &A = specAlt[alt];
+                A.valid = false;
+                A.out.clear();
+                A.a.clear();
+                A.b.clear();
+                const int64_t n0 = alt == 0 ? q[1] : q[0], n1 = q[2];   /* alternative 0: swap B and C; 1: swap A and C */
+                txnBegin(A.log);
+                replaceChild(around, n0, n1);
+                replaceChild(parent[(size_t) around], n1, n0);
+                updateForNNI(around, false, upHave);
+                int64_t next[2];
+                movePivots(node, next);
+                A.aroundNext = next[next[0] == around ? 1 : 0];
+                if (chainLength + 1 < maxSPRLength && A.aroundNext >= nSeqs && A.aroundNext != root) {
+                    if (meBuild(A.aroundNext, upHave, A.q, A.t, A.q4, true) && qOut.size() <= (size_t) VFT_WALK_DUAL_MAX_AVERAGES) {
+                        A.valid = true;
+                        A.out = qOut;
+                        A.a = qA;
+                        A.b = qB;
+                    }
+                }
+                txnEnd();
+            }
+            if (specAlt[0].valid && specAlt[1].valid && specAlt[0].out.size() + specAlt[1].out.size() > (size_t) VFT_WALK_DUAL_MAX_AVERAGES)
+                specAlt[specAlt[0].out.size() > specAlt[1].out.size() ? 0 : 1].valid = false;   /* (both do not fit one command: the shorter one) */
+            if (!specAlt[0].valid && !specAlt[1].valid) return false;
+            uint32_t ticket = 0;
+            const SprAlt &A0 = specAlt[0], &A1 = specAlt[1];
+            chk(vft_walk_submit_dual(ctx, (int32_t) A0.out.size(), A0.out.data(), A0.a.data(), A0.b.data(), A0.valid ? A0.q4 : nullptr,
+                                     (int32_t) A1.out.size(), A1.out.data(), A1.a.data(), A1.b.data(), A1.valid ? A1.q4 : nullptr, scoredist ? 1 : 0, &ticket));
+            specAlt[0].ticket = specAlt[1].ticket = ticket;
+            walkDualSent++;
+            return true;
+        }
+
+        /* the host half of a step up to the hand-over: the quartet, its up-profile, the memo table, the averages the quartet's rows
+           depend on (left in qOut / qA / qB).  False: the distances came from the memo table, nothing goes to the device.  spec:
+           inside a transaction - nothing may be sent: a step whose averages do not fit a command leaves qOut longer than that and
+           the caller gives the continuation up. */
+        bool meBuild(int64_t node, std::vector<char> &upHave, int64_t q[4], MeTicket &t, int64_t q4[4], bool spec) {
             quartetNodes(node, q);
             const int64_t par = parent[(size_t) node];
             int64_t idD = q[3];
@@ -1625,7 +1825,10 @@ namespace veryfasttree {
                 ensureUpProfile(par, false, upHave);
                 idD = par + nSeqs;
             }
-            const int64_t q4[4] = {q[0], q[1], q[2], idD};
+            q4[0] = q[0];
+            q4[1] = q[1];
+            q4[2] = q[2];
+            q4[3] = idD;
             t.pending = false;
             t.keyed = false;
             if (vnActive) {   /* the same four values as an earlier quartet: its distances (see vnBegin) */
@@ -1636,11 +1839,17 @@ namespace veryfasttree {
                     for (int i = 0; i < 6; i++) t.d[i] = m.d[i];
                     t.keyed = false;
                     stepsMemoised++;
-                    return;
+                    return false;
                 }
             }
             schedule(q4, 4, false);   /* the recorded averages this quartet's rows depend on (see queueAverage) */
-            sendLongHead(48);
+            if (!spec) sendLongHead(48);
+            return true;
+        }
+        void meSubmit(int64_t node, std::vector<char> &upHave, int64_t q[4], MeTicket &t) {
+            int64_t q4[4];
+            if (!meBuild(node, upHave, q, t, q4, false)) return;
+            const int64_t idD = q4[3];
             if (serverUp) {
                 chk(vft_walk_submit(ctx, (int32_t) qOut.size(), qOut.data(), qA.data(), qB.data(), q4, &t.ticket));
                 qOut.clear();
@@ -1750,7 +1959,7 @@ namespace veryfasttree {
                     sharedOps.push_back(op);
                 } else if (useML) queuePosterior(out, cd[0], cd[1], lcd[0], lcd[1]);
                 else queueAverage(out, cd[0], cd[1]);
-                upHave[(size_t) x] = 1;
+                putc(&upHave[(size_t) x], 1);
             }
         }
 
@@ -1936,6 +2145,10 @@ namespace veryfasttree {
         }
         uint64_t verOf(int64_t row) const { return rowVerEpoch[(size_t) row] == vnEpoch ? rowVer[(size_t) row] : (uint64_t) row + 1; }
         void setVer(int64_t row, uint64_t v) {
+            if (txn.on) {
+                typename WalkTxnLog::WV e = {(size_t) row, rowVer[(size_t) row], v, rowVerEpoch[(size_t) row], vnEpoch};
+                txn.log->wv.push_back(e);
+            }
             rowVer[(size_t) row] = v;
             rowVerEpoch[(size_t) row] = vnEpoch;
         }
@@ -1952,9 +2165,6 @@ namespace veryfasttree {
            everything else stays recorded.  Picked averages run in program order, so every value that is ever read - by a
            distance, by a later average, by whoever looks at the rows after the walk - is the value the eager order computes:
            the same operations on the same operands, fewer of them. */
-        struct PendOp {
-            int64_t out, a, b;
-        };
         std::vector<PendOp> pend;
         std::vector<uint32_t> needStamp, writeStamp;
         std::vector<unsigned char> pendSel;

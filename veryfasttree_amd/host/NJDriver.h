@@ -67,6 +67,7 @@ namespace veryfasttree {
         int outProfileParts = 0;   /* vft_nj_options.out_profile_parts: full out-profile recomputations as P blocks of the active list, split over the ranks */
         int seedBatch = 8;         /* setAllLeafTopHits: sweeps of this many unvisited seeds per device call (vft_sweep_batch); 1: a call per seed */
         bool walkServer = true;    /* refinement walks through the resident walk server (vft_walk_server_start); false: a launch per step */
+        bool walkDual = true;      /* SPR chains hand both continuations of a step to the walk server (MLLengths::specContinuations); false: every step waits for the host's verdict */
         /* > 1: the refinement stages follow the reference's `-threads T` schedule (MLLengths.h "the subtree schedule") */
         int threads = 1;
         bool gamma = false;          /* `-gamma`: rescale the final lengths to a fitted discrete Gamma (MLLengths::branchlengthScale) */
@@ -728,6 +729,7 @@ namespace veryfasttree {
             treeArrays(par, ch);
             MLLengths<REAL> tree(ctx, nSeqs, maxnode, par.data(), ch.data(), root);
             tree.walkServer = opt.walkServer;
+            tree.walkDual = opt.walkDual;
             tree.comm = opt.comm;
             typename MLLengths<REAL>::NNIParams prm;
             prm.useML = false;
@@ -770,6 +772,8 @@ namespace veryfasttree {
                 sprRemaining--;
             }
             meSPRSteps = tree.sprSteps;
+            meSPRDualSent = tree.walkDualSent;
+            meSPRDualTaken = tree.walkDualTaken;
             laneGathers += tree.laneGathers;
             laneGatherBytes += tree.laneGatherBytes;
             adoptTree(tree.parents(), tree.children());
@@ -777,6 +781,7 @@ namespace veryfasttree {
         }
 
         int64_t meSPRs = 0, meSPRSteps = 0;
+        int64_t meSPRDualSent = 0, meSPRDualTaken = 0;   /* SPR chains: dual commands sent / continuations the walk server ran without waiting for the host */
         int64_t laneGathers = 0, laneGatherBytes = 0;   /* lanes across ranks: all-gathers of verdicts + lengths, bytes received */
         double meSPRSeconds = 0, mlNNISeconds = 0, mlSupportSeconds = 0, mlModelSeconds = 0;   /* stage timers (vft_nj_last_stage_seconds) */
         int64_t meNNIRoundsDone = 0;

@@ -77,6 +77,7 @@ extern "C" int vft_nj_last_join_crcs(int64_t *chunk, int64_t *nJoins, uint32_t *
 /* wall-clock of the stages of the last vft_nj_newick / vft_nj_ml_newick of this process (vft_nj_last_stage_seconds) */
 static double gStage[8];
 static int64_t gLanes[4];
+static int64_t gWalkDual[2];   /* SPR chains of the last tree: dual commands sent, continuations the walk server ran on its own (vft_nj_last_walk_dual) */
 static int64_t gLaneExchange[2];   /* lanes across ranks of the last tree: all-gathers, bytes received (vft_nj_last_lane_exchange) */
 static double gGamma[3];   /* `-gamma` of the last tree: Gamma(nCat) log-likelihood, alpha, length factor (vft_nj_last_gamma) */
 
@@ -148,6 +149,13 @@ extern "C" int vft_nj_last_lane_exchange(int64_t *out) {
     return VFT_OK;
 }
 
+extern "C" int vft_nj_last_walk_dual(int64_t *out) {
+    if (!out) return VFT_ERR_INVALID;
+    out[0] = gWalkDual[0];
+    out[1] = gWalkDual[1];
+    return VFT_OK;
+}
+
 extern "C" int vft_nj_last_gamma(double *out) {
     if (!out) return VFT_ERR_INVALID;
     for (int i = 0; i < 3; i++) out[i] = gGamma[i];
@@ -187,6 +195,7 @@ static veryfasttree::NJOptions toOptions(const vft_nj_options *o) {
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_LISTS) opt.deviceLists = false;
         if (o->debug_flags & VFT_NJ_DEBUG_HOST_RESET) opt.deviceReset = false;
         if (o->debug_flags & VFT_NJ_DEBUG_NO_WALK_SERVER) opt.walkServer = false;
+        if (o->debug_flags & VFT_NJ_DEBUG_NO_WALK_DUAL) opt.walkDual = false;
         if (o->debug_flags & VFT_NJ_DEBUG_SEED_BY_SEED) opt.seedBatch = 1;
         if (o->debug_flags & VFT_NJ_DEBUG_LEVEL_LENGTHS) opt.parallelLengths = true;
         if (o->debug_flags & VFT_NJ_SHARD_LEAF_BLOCKS) opt.shardLeafBlocks = true;
@@ -241,6 +250,8 @@ static std::string runTree(vft_ctx *ctx, const uint8_t *codes, int64_t nSeqs, in
     gLanes[1] = drv.mlLaneWork;
     gLanes[2] = drv.meSPRSteps;
     gLanes[3] = drv.meSPRs;
+    gWalkDual[0] = drv.meSPRDualSent;
+    gWalkDual[1] = drv.meSPRDualTaken;
     gLaneExchange[0] = drv.laneGathers;
     gLaneExchange[1] = drv.laneGatherBytes;
     drv.report();
