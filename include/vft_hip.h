@@ -388,6 +388,9 @@ int vft_walk_submit_dual(vft_ctx *ctx, int32_t n0, const int64_t *out0, const in
                          int32_t n1, const int64_t *out1, const int64_t *a1, const int64_t *b1, const int64_t *q1, int32_t scoredist,
                          uint32_t *ticket);
 int vft_walk_dual_choice(vft_ctx *ctx, uint32_t ticket, int32_t *alt, int32_t *skipped);
+/* logCorrect's flavour (NJ.tcc:322-330) of the steps that follow: 0 Jukes-Cantor, 1 scoredist-like.  Call before the first step of a walk
+   that sends dual commands (the workgroups log-correct every step's distance for the comparison of a dual command behind it). */
+int vft_walk_scoredist(vft_ctx *ctx, int32_t scoredist);
 int vft_walk_collect(vft_ctx *ctx, uint32_t ticket, void *dist);
 /* tools builds (-DVFT_WALK_TIMING): clock ticks (100 MHz) workgroup 0 of the servers of this process spent per phase -
    [0] waiting for a command, [1] averages, [2] waiting for the other workgroups' averages, [3] the pair's columns, [4] the ordered

@@ -31,7 +31,7 @@ EXPORTS = [
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full", "vft_out_profile_partial", "vft_out_profile_finish",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",
-    "vft_sweep_batch", "vft_sweep_batch_view", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_batch_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_profiles_differ", "vft_get_max_nodes", "vft_get_n_codes", "vft_walk_step", "vft_walk_server_start", "vft_walk_server_stop", "vft_walk_submit", "vft_walk_submit_dual", "vft_walk_dual_choice", "vft_walk_collect", "vft_walk_server_ticks", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_branch_lengths_gather", "vft_branch_lengths_scatter", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
+    "vft_sweep_batch", "vft_sweep_batch_view", "vft_set_shard", "vft_merge_hits", "vft_merge_hits_batch", "vft_sweep_info", "vft_sweep_batch_info", "vft_sweep_results", "vft_pair_distances", "vft_pair_loglk", "vft_posterior_profiles", "vft_set_profile_rows", "vft_average_chain", "vft_average_chains", "vft_profiles_differ", "vft_get_max_nodes", "vft_get_n_codes", "vft_walk_step", "vft_walk_server_start", "vft_walk_server_stop", "vft_walk_submit", "vft_walk_submit_dual", "vft_walk_dual_choice", "vft_walk_scoredist", "vft_walk_collect", "vft_walk_server_ticks", "vft_posterior_chains_blen", "vft_ml_quartet_nni_flags", "vft_branch_lengths_set", "vft_branch_lengths_get", "vft_branch_lengths_gather", "vft_branch_lengths_scatter", "vft_posterior_profiles_blen", "vft_posterior_chain_blen", "vft_ml_optimize_splits", "vft_ml_split_tests", "vft_ml_quartet_nni", "vft_ml_eval_count",
     "vft_join_nodes", "vft_profile_distances", "vft_split_supports", "vft_timer_start", "vft_timer_stop_ms", "vft_sweep_kernel_ms", "vft_sweep_table_kernel_ms", "vft_sweep_kernel_sweeps",
     "vft_debug_log", "vft_debug_option", "vft_tophits_create", "vft_tophits_upload", "vft_tophits_download", "vft_tophits_best", "vft_tophits_join", "vft_tophits_refresh", "vft_nj_engine_create", "vft_nj_engine_set_state", "vft_nj_engine_get_state", "vft_nj_engine_visible_set", "vft_nj_engine_visible_get", "vft_nj_engine_nodes_set", "vft_nj_engine_topvisible_set", "vft_nj_engine_topvisible_get", "vft_nj_engine_reset_candidates", "vft_nj_engine_enqueue", "vft_nj_engine_poll", "vft_nj_engine_resume", "vft_nj_engine_log", "vft_nj_engine_adopt", "vft_leaf_block_distances", "vft_set_shard_mode", "vft_join_fused", "vft_block_distances", "vft_pair_distances_refresh",
 ]

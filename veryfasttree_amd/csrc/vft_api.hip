@@ -172,6 +172,7 @@ struct vft_ctx {
         int stride = 8;         // VFT_DEBUG_WALK_SERVER_STRIDE: 8 = the six workgroups on one XCD, 1 = on six
         bool disabled = false;  // VFT_DEBUG_NO_WALK_SERVER
         bool allocated = false; // every buffer of the server exists (set behind the last allocation of the first start)
+        bool scoredist = false; // logCorrect's flavour of the walk (bit 21 of every command: the workgroups log-correct their distance for a dual command that may follow)
     } ws;
     // the join loop on the device (vft_kernels_njengine.h)
     void *njState = nullptr, *njVisD = nullptr;
@@ -1363,7 +1364,7 @@ static int ws_command(vft_ctx *c, int32_t nOps, const int64_t *out, const int64_
         ws_put(c, seq, 6 + 3 * k, (uint32_t) (int32_t) a[k]);
         ws_put(c, seq, 7 + 3 * k, (uint32_t) (int32_t) b[k]);
     }
-    ws_put(c, seq, 0, VFT_WS_CMD_WORK | ((uint32_t) nOps << 8) | (q ? 1u << 16 : 0u) | (noWait ? 1u << 17 : 0u));
+    ws_put(c, seq, 0, VFT_WS_CMD_WORK | ((uint32_t) nOps << 8) | (q ? 1u << 16 : 0u) | (noWait ? 1u << 17 : 0u) | (c->ws.scoredist ? 1u << 21 : 0u));
     if (c->ws.mailOnDevice) __builtin_ia32_sfence();
     *seqOut = seq;
     return VFT_OK;
@@ -1492,6 +1493,7 @@ extern "C" int vft_walk_submit_dual(vft_ctx *c, int32_t n0, const int64_t *out0,
                                     int32_t scoredist, uint32_t *ticket) {
     if (!c || n0 < 0 || n1 < 0 || !ticket || (n0 > 0 && (!out0 || !a0 || !b0)) || (n1 > 0 && (!out1 || !a1 || !b1))) return VFT_ERR_INVALID;
     if (!c->ws.up) return fail(c, VFT_ERR_STATE, "vft_walk_submit_dual: the walk server is not running (vft_walk_server_start)");
+    c->ws.scoredist = scoredist != 0;   // (the step in front was sent with the flavour of the call before: the caller announces it with vft_walk_scoredist)
     if (!q0) n0 = 0;
     if (!q1) n1 = 0;
     if (n0 + n1 > VFT_WS_DUAL_MAXOPS) return fail(c, VFT_ERR_INVALID, "vft_walk_submit_dual: %d + %d averages do not fit one command", (int) n0, (int) n1);
@@ -1520,6 +1522,13 @@ extern "C" int vft_walk_submit_dual(vft_ctx *c, int32_t n0, const int64_t *out0,
                       (scoredist ? 1u << 21 : 0u) | ((uint32_t) n1 << 24));
     if (c->ws.mailOnDevice) __builtin_ia32_sfence();
     *ticket = seq;
+    return VFT_OK;
+}
+// logCorrect's flavour of the walk that follows (0: Jukes-Cantor, 1: scoredist-like): every step's workgroups log-correct their distance
+// with it for a dual command that may follow
+extern "C" int vft_walk_scoredist(vft_ctx *c, int32_t scoredist) {
+    if (!c) return VFT_ERR_INVALID;
+    c->ws.scoredist = scoredist != 0;
     return VFT_OK;
 }
 // which alternative the workgroups took for the dual command `ticket` (waits for its first answers): *alt = 0 / 1, *skipped = 1 when

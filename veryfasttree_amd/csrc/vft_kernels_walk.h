@@ -48,7 +48,7 @@
 #define VFT_WS_DUAL_BIT 18
 #define VFT_WS_DUAL_MAXOPS 18
 #define VFT_WS_RES_CHOICE 12   // result granule of a dual command: {seq, 1 | alternative << 1 | not-a-device-step << 2} (workgroup 0)
-#define VFT_WS_FLAG_DIST 16    // flags[16 + 16 * (seq & 1) + 2 w (+ 1)]: workgroup w's distance of command seq, tagged (low / high half)
+#define VFT_WS_FLAG_DIST 16    // flags[16 + 16 * (seq & 1) + 2 w (+ 1)]: workgroup w's LOG-CORRECTED distance of command seq (a double), tagged low / high half
 #define VFT_WS_SC1 16        // aux bits of the buffer intrinsics on gfx950: write-through stores / L1-bypassing loads
 
 struct WalkServerArgs {
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
     const int w = (int) (blockIdx.x / S.stride);
     if (w >= VFT_WS_NWG) return;
     __shared__ uint32_t sCmd[VFT_WS_GRAN];
+    __shared__ unsigned long long sPre[VFT_WS_GRAN];   // the next slot as the last wavefront saw it during this step's pair phase (dual commands arrive that early)
     __shared__ double sSum[2];
     __shared__ int sStop;
     // amino acids: the distance-matrix tables (distances, codeFreq, eigenval, eigentot) in LDS: a table read from global memory between the chain's stores is a wait for the stores
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
     double *sW = pwLds, *sT = pwLds + nPosPad;
     for (int32_t t = nPos + (int32_t) threadIdx.x; t < nPosPad; t += WG) sW[t] = sT[t] = 0.0;   // +0.0 beyond the alignment, for good
     if (threadIdx.x == 0) sStop = 0;
+    if (threadIdx.x < VFT_WS_GRAN) sPre[threadIdx.x] = 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t nSlices = (nPos + 63) >> 6;
@@ -298,8 +300,12 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
             const unsigned long long *slot = S.mail + (size_t) (seq % VFT_WS_RING) * VFT_WS_GRAN;
             const long long t0 = wall_clock64();
             int end = 0;
+            // A poll is a read over PCIe (~1.2 us).  A dual command is in the mailbox long before the step in front of it ends: the last
+            // wavefront read this slot while that step's pairs were summed (sPre) - complete there, no poll at all.
+            bool first = true;
             for (;;) {
-                const unsigned long long g = vft_ws_ld_sys(slot + lane);
+                const unsigned long long g = first ? sPre[lane] : vft_ws_ld_sys(slot + lane);
+                first = false;
                 const unsigned long long ok = __ballot((uint32_t) (g >> 32) == seq);
                 if (ok & 1ull) {
                     const uint32_t hdr = (uint32_t) __shfl(g, 0, 64);
@@ -321,12 +327,10 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
             //      then this command becomes the plain command of the alternative taken
             if (!end && ((sCmd[0] >> VFT_WS_DUAL_BIT) & 1u)) {
                 const unsigned long long *dw = S.flags + VFT_WS_FLAG_DIST + 16 * ((seq - 1u) & 1u);
-                constexpr int NG = sizeof(REAL) == 4 ? 1 : 2;
                 const long long t1 = wall_clock64();
                 unsigned long long g = 0;
-                for (;;) {
-                    const int idx = sizeof(REAL) == 4 ? 2 * lane : lane;   // float: word 2 w; double: words 2 w and 2 w + 1
-                    g = lane < NG * VFT_WS_NWG ? vft_ws_ld_dev(dw + idx) : ((unsigned long long) (seq - 1u) << 32);
+                for (;;) {   // words 2 w and 2 w + 1: the halves of workgroup w's log-corrected distance of the command before
+                    g = lane < 2 * VFT_WS_NWG ? vft_ws_ld_dev(dw + lane) : ((unsigned long long) (seq - 1u) << 32);
                     if (__all((uint32_t) (g >> 32) == seq - 1u)) break;
                     if ((long long) wall_clock64() - t1 > S.flagTicks) {
                         end = 3;
@@ -337,19 +341,8 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
                     double c[6];
 #pragma unroll
                     for (int t = 0; t < 6; t++) {
-                        double d;
-                        if constexpr (sizeof(REAL) == 4) {
-                            d = (double) __uint_as_float((uint32_t) __shfl(g, t, 64));
-                        } else {
-                            const uint32_t lo = (uint32_t) __shfl(g, 2 * t, 64), hi = (uint32_t) __shfl(g, 2 * t + 1, 64);
-                            d = __hiloint2double((int) hi, (int) lo);
-                        }
-                        // logCorrect (NJ.tcc:322-330; host/MLLengths.h logCorrect): Jukes-Cantor or scoredist-like, capped at 3
-                        const double maxscore = 3.0;
-                        double x;
-                        if (!((sCmd[0] >> 21) & 1u)) x = d < 0.74 ? -0.75 * vft_glibc_log(1.0 - d * 4.0 / 3.0) : maxscore;
-                        else x = d < 0.99 ? -1.3 * vft_glibc_log(1.0 - d) : maxscore;
-                        c[t] = x < maxscore ? x : maxscore;
+                        const uint32_t lo = (uint32_t) __shfl(g, 2 * t, 64), hi = (uint32_t) __shfl(g, 2 * t + 1, 64);
+                        c[t] = __hiloint2double((int) hi, (int) lo);
                     }
                     // criteria AB+CD, AC+BD, AD+BC over the distances AB AC AD BC BD CD (meCollect)
                     const double c1 = c[1] + c[4], c2 = c[2] + c[3];
@@ -363,7 +356,7 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
                     const uint32_t v = src < VFT_WS_GRAN ? sCmd[src] : 0u;
                     if (lane < 4 + 3 * nAlt) sCmd[1 + lane] = v;   // (one wavefront: every lane has read before any lane writes)
                     if (lane == 0) {
-                        sCmd[0] = (hdr & 0xFFu) | ((uint32_t) nAlt << 8) | (skip ? 0u : 1u << 16) | (hdr & (1u << 17));
+                        sCmd[0] = (hdr & 0xFFu) | ((uint32_t) nAlt << 8) | (skip ? 0u : 1u << 16) | (hdr & (1u << 17)) | (hdr & (1u << 21));
                         if (w == 0)
                             __hip_atomic_store(S.res + (size_t) (seq % VFT_WS_RING) * VFT_WS_RESG + VFT_WS_RES_CHOICE,
                                                ((unsigned long long) seq << 32) | 1ull | ((unsigned long long) alt << 1) | ((unsigned long long) (skip ? 1 : 0) << 2),
@@ -495,27 +488,37 @@ __global__ __launch_bounds__(VFT_WS_WG_OF(NC)) void k_walk_server(Arena<REAL> A,
         __syncthreads();
         VFT_WS_TICK(3);
         if (threadIdx.x == 0) __hip_atomic_store(S.flags + 8 + w, (unsigned long long) seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the last wavefront, idle while two lanes add the columns up, reads the next slot of the mailbox: a PCIe read, ~1.2 us, under
+        //  the ~1.6 us of the sums - a dual command is there by now and the next step starts without a poll)
+        if (wave == WG / 64 - 1) sPre[lane] = vft_ws_ld_sys(S.mail + (size_t) ((seq + 1u) % VFT_WS_RING) * VFT_WS_GRAN + lane);
         if (threadIdx.x < 2) sSum[threadIdx.x] = vft_ws_ordered_sum(threadIdx.x == 0 ? sT : sW, nPosPad);   // `top`, `denom`: each in column order
         __syncthreads();
         VFT_WS_TICK(4);
         if (threadIdx.x == 0) {
             const double top = sSum[0], denom = sSum[1];
             const REAL d = (REAL) (denom > 0 ? top / denom : 1.0);   // profileDist / seqDist (NJ.tcc:1183-1189, :1621-1623)
-            {   // ... and to the other workgroups (a dual command that follows compares the six distances on the device)
-                unsigned long long *dw = S.flags + VFT_WS_FLAG_DIST + 16 * (seq & 1u) + 2 * w;
-                if constexpr (sizeof(REAL) == 4) {
-                    __hip_atomic_store(dw, ((unsigned long long) seq << 32) | (unsigned long long) __float_as_uint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    __hip_atomic_store(dw, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2loint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dw + 1, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2hiint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
             if constexpr (sizeof(REAL) == 4) {
                 __hip_atomic_store(out, ((unsigned long long) seq << 32) | (unsigned long long) __float_as_uint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 __hip_atomic_store(out, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2loint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(out + 1, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2hiint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+        }
+        if (threadIdx.x == 0) {
+            // ... and, log-corrected (logCorrect, NJ.tcc:322-330; host/MLLengths.h: Jukes-Cantor or scoredist-like by bit 21 of the command,
+            // capped at 3; glibc's log bit for bit, vft_glibc_log.h), to the other workgroups: a dual command that follows compares the six
+            // numbers on the device.  After the answer has gone out - the host does not wait for this - and one logarithm per workgroup,
+            // side by side, instead of six in front of the next step's chain.
+            const double top = sSum[0], denom = sSum[1];
+            const double dd = (double) (REAL) (denom > 0 ? top / denom : 1.0);
+            const double maxscore = 3.0;
+            double x;
+            if (!((hdr >> 21) & 1u)) x = dd < 0.74 ? -0.75 * vft_glibc_log(1.0 - dd * 4.0 / 3.0) : maxscore;
+            else x = dd < 0.99 ? -1.3 * vft_glibc_log(1.0 - dd) : maxscore;
+            x = x < maxscore ? x : maxscore;
+            unsigned long long *dw = S.flags + VFT_WS_FLAG_DIST + 16 * (seq & 1u) + 2 * w;
+            __hip_atomic_store(dw, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2loint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dw + 1, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) __double2hiint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         VFT_WS_TICK(5);
 #ifdef VFT_WALK_TIMING

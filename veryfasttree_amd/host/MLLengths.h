@@ -990,7 +990,14 @@ namespace veryfasttree {
                        its comparison and handed over as a dual command (specContinuations): `adopt` = the next step is already on the
                        device - the alternative the workgroups took - and the host state has been moved to it (txnRedo) */
                     bool adopt = false;
-                    SprAlt adopted;
+                    struct {
+                        int64_t q[4];
+                        MeTicket t;
+                        uint32_t ticket;
+                        int alt;
+                    } adopted;
+                    adopted.ticket = 0;
+                    adopted.alt = 0;
                     for (; chainLength < maxSPRLength; chainLength++) {
                         if (around < nSeqs || around == root) break;   /* nChild != 2 */
                         int64_t q[4];
@@ -1012,7 +1019,14 @@ namespace veryfasttree {
                         bool swapBC;
                         /* both continuations of THIS step, before its distances are waited for (the forced first step has one) */
                         bool dualSent = false;
-                        if (chainLength >= 1 && walkDual && serverUp && tk.pending) dualSent = specContinuations(node, around, q, (int) chainLength, maxSPRLength, scoredist, upHave);
+                        if (chainLength >= 1 && walkDual && serverUp && tk.pending) {
+                            if (walkStats) {
+                                const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                                dualSent = specContinuations(node, around, q, (int) chainLength, maxSPRLength, scoredist, upHave);
+                                walkSpecSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                            } else
+                            dualSent = specContinuations(node, around, q, (int) chainLength, maxSPRLength, scoredist, upHave);
+                        }
                         if (chainLength == 0) {
                             swapBC = acFirst != 0;
                             first = tk;
@@ -1046,7 +1060,9 @@ namespace veryfasttree {
                             SprAlt &A = specAlt[swapBC ? 0 : 1];
                             txnRedo(A.log);
                             walkDualTaken++;
-                            adopted = A;
+                            for (int i = 0; i < 4; i++) adopted.q[i] = A.q[i];
+                            adopted.t = A.t;
+                            adopted.ticket = A.ticket;
                             adopted.alt = swapBC ? 0 : 1;
                             adopt = true;
                             around = A.aroundNext;
@@ -1113,6 +1129,7 @@ namespace veryfasttree {
             }
             int64_t nSPR = 0;
             WalkServerGuard server(*this);
+            if (serverUp) chk(vft_walk_scoredist(ctx, scoredist ? 1 : 0));
             static const bool stageTrace = std::getenv("VFT_STAGE_TRACE") != nullptr;
             int64_t nDone = 0;
             for (int64_t node: nodeList) {
@@ -1940,7 +1957,8 @@ namespace veryfasttree {
         /* getUpProfile (NJ.tcc:3382-3434): cached; missing ones are built from the root down */
         void ensureUpProfile(int64_t node, bool useML, std::vector<char> &upHave) {
             if (upHave[(size_t) node]) return;
-            std::vector<int64_t> path;
+            std::vector<int64_t> &path = upPathScratch;   /* (a member: this runs three times per SPR chain step) */
+            path.clear();
             for (int64_t x = node; x != root; x = parent[(size_t) x]) path.push_back(x);
             /* a lane: the up-profiles of its subtree root and above do not change during the parallel phase and belong to
                every lane below them - they are built once, level by level, before the lanes' chains (runShared) */
@@ -2059,6 +2077,7 @@ namespace veryfasttree {
         }
 
         std::vector<int64_t> pOut, pA, pB, pLa, pLb;
+        std::vector<int64_t> upPathScratch;
 
         /* Minimum-evolution averages are queued and go down as one chain launch (vft_average_chain) right before
            something reads profiles: a step of an NNI / SPR walk is then two launches (chain, distances) and one wait */
@@ -2116,6 +2135,7 @@ namespace veryfasttree {
         bool vnActive = false;
         int64_t avgRedundant = 0, stepsMemoised = 0;   /* statistics */
         double walkWaitSeconds = 0, walkSeconds = 0;    /* (VFT_WALK_STATS) waiting for the device's answers / the walks in all */
+        double walkSpecSeconds = 0;                     /* ... building both continuations of chain steps (specContinuations) */
         int64_t walkDeviceSteps = 0;
         bool walkStats = std::getenv("VFT_WALK_STATS") != nullptr;
         static uint64_t vnHash(uint64_t x, uint64_t y) {
@@ -2259,9 +2279,9 @@ namespace veryfasttree {
                 if (t.walkStats) {
                     t.walkSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - born).count();
                     fprintf(stderr, "walk: %lld averages run, %lld dropped unread, %lld redundant (same value), %lld steps from the memo table; %lld device steps, "
-                            "%.3f s waiting for their answers, %.3f s of walks in all\n",
+                            "%.3f s waiting for their answers, %.3f s building continuations (%lld dual commands, %lld taken), %.3f s of walks in all\n",
                             (long long) (t.avgQueued - t.avgDropped), (long long) t.avgDropped, (long long) t.avgRedundant, (long long) t.stepsMemoised,
-                            (long long) t.walkDeviceSteps, t.walkWaitSeconds, t.walkSeconds);
+                            (long long) t.walkDeviceSteps, t.walkWaitSeconds, t.walkSpecSeconds, (long long) t.walkDualSent, (long long) t.walkDualTaken, t.walkSeconds);
                 }
                 if (t.serverUp) {
                     t.serverUp = false;
