@@ -672,10 +672,20 @@ def gen_c4_tree(tmp):
         tree1 = open(t1, "rb").read().decode().strip()
         if tree1.endswith(";"):
             f1 = ["-nt", "-noml", "-nome", "-nosupport", "-threads", "1", "-seed", "1"]
+            # (round 6's run is oracle/_ref/njtrace - the reference's sources with the `Join` lines switched on, oracle/njtrace.cpp - which
+            #  prints the same tree on stdout and the trace on stderr; its last progress line is the NJ phase's wall-clock)
+            wall = 0.0
+            trace = os.path.join(HERE, "_ref", "c4_joins_t1_r05.txt")
+            if os.path.exists(trace):
+                with open(trace, "rb") as fh:
+                    fh.seek(max(0, os.path.getsize(trace) - 4096))
+                    for line in fh.read().decode(errors="replace").splitlines():
+                        if "seconds: Joined" in line:
+                            wall = float(line.split()[0])
             np.savez_compressed(os.path.join(GOLDEN, "bb_c4_crc.npz"), newick_crc=np.int64(zlib.crc32(tree1.encode())), newick_bytes=np.int64(len(tree1)),
-                                flags=np.frombuffer(" ".join(f1).encode(), dtype=np.uint8),
+                                flags=np.frombuffer(" ".join(f1).encode(), dtype=np.uint8), reference_wall_s=np.float64(wall),
                                 alignment=np.frombuffer(b"random_descent_codes(1000000, 200, 4, 0.02, 0.01, seed=4)", dtype=np.uint8))
-            print("bb_c4_crc: %d bytes of Newick, crc %d (the one-thread reference)" % (len(tree1), zlib.crc32(tree1.encode())))
+            print("bb_c4_crc: %d bytes of Newick, crc %d (the one-thread reference, %.0f s)" % (len(tree1), zlib.crc32(tree1.encode()), wall))
 
 
 def gen_c4_scaled(tmp, sizes=(200000, 400000)):
