@@ -90,6 +90,14 @@ int vft_set_transition_matrix(vft_ctx *ctx, const void *stat, const void *statin
 /* Rate categories (NJ.h Rates: rates[n_rates], ratecat[n_pos]). */
 int vft_set_rates(vft_ctx *ctx, const void *rates, int32_t n_rates, const int64_t *ratecat);
 /* ML tolerances that the reference reads from Options inside the hot loops (Constants.h:26-39). */
+/* Jukes-Cantor likelihoods the reference's way to the last bit (NJ.tcc:1203-1262: `exp` of libm in pSame / pDiff, ONE running product over
+   the columns in column order with the underflow rescaling, one `log` of libm at the end) - what the matrix models always get
+   (vft_kernels_ml.h "ordered total").  ON by default since round 6: with it `VeryFastTree -nt -threads 64` on 100 000 sequences comes
+   out byte for byte (tests/golden/thr_c4_100k_t64_crc.npz).  on = 0: per-thread running products summed over the threads, rounds 1-5's
+   arithmetic - every column the same number, the total differs from the reference's in the last bits (every TreeLogLk line still to the
+   printed digit; near-tie NNIs may fall the other way: 24 leaf placements of zero length among those 100 000 sequences); the ML NNI
+   stage of a nucleotide run is ~2x faster that way (2.6 s instead of 5.6 s of a 46 s pipeline at that size). */
+int vft_set_jc_exact(vft_ctx *ctx, int32_t on);
 int vft_set_ml_limits(vft_ctx *ctx, double min_branch_length, double min_rel_branch_length,
                       double fpost_total_tolerance);
 
@@ -493,6 +501,7 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_WALK_DEVICE_MAILBOX 10 /* value != 0: the server's mailbox in device memory written through the PCIe aperture (large-BAR boxes) instead of pinned host memory */
 #define VFT_DEBUG_WALK_SERVER_STRIDE 11 /* 1: the server's six workgroups on six XCDs instead of one (placement is for speed only; tests run both) */
 #define VFT_DEBUG_POISON_SELECTION 14    /* fills the selection's candidate buffers of every slot with 0x7f bytes - what a recycled allocation holds - before the next sweep (tests: a collection that overflows must not look at entries it never stored) */
+#define VFT_DEBUG_ML_LONG 16            /* value != 0: the ML line searches (vft_ml_optimize_splits, vft_ml_quartet_nni*, vft_ml_split_tests) run the workspace kernels of alignments beyond 2 048 columns at any length (tests compare with the register-resident kernels) */
 #define VFT_DEBUG_NO_MULTI_SWEEP 12     /* value != 0: vft_sweep_batch sweeps its leaf seeds one launch each instead of four per pass over the targets (tests compare) */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 

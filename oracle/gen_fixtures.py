@@ -280,6 +280,10 @@ MLNNI_CASES = [
     # 16S-like length: more than 1024 columns (eight columns per thread in the quartet kernels)
     ("full_nt_40_x1500", ["-nt"], 40, 1500, 0.05, 0.02, 71),
     ("full_nt_30_x1300_gtr_double", ["-nt", "-gtr", "-double-precision"], 30, 1300, 0.06, 0.02, 72),
+    # beyond the register-resident line-search kernels (2 048 columns): the workspace kernels (csrc/vft_kernels_ml_long.h)
+    ("full_nt_40_x3000", ["-nt"], 40, 3000, 0.05, 0.02, 73),
+    ("full_nt_30_x2500_gtr", ["-nt", "-gtr"], 30, 2500, 0.06, 0.02, 74),
+    ("full_nt_24_x5000_double", ["-nt", "-double-precision"], 24, 5000, 0.05, 0.02, 75),
 ]
 
 
@@ -320,12 +324,15 @@ AA_CASES = [
     ("full_aa_150_lg", "mlnni", ["-lg"], 150, 80, 0.12, 0.04, 66),
     ("full_aa_100_jtt", "mlnni", [], 100, 90, 0.10, 0.03, 67),                              # the reference's protein default
     ("full_aa_90_wag_double", "mlnni", ["-wag", "-double-precision"], 90, 70, 0.08, 0.05, 68),
+    ("full_aa_30_x2200_lg_double", "mlnni", ["-lg", "-double-precision"], 30, 2200, 0.10, 0.03, 69),   # > 2 048 columns: the workspace line searches
 ]
 
 
-def gen_aa(tmp):
+def gen_aa(tmp, only=None):
     """Black box, proteins: the same three kinds of runs as gen_menni / gen_mllen / gen_mlnni."""
     for name, kind, flags, n, L, mu, gap, seed in AA_CASES:
+        if only and name not in only:
+            continue
         codes = synth.random_descent_codes(n, L, 20, mu, gap, seed)
         fa = os.path.join(tmp, name + ".fa")
         synth.codes_to_fasta(codes, fa, synth.ALPHABET_AA)
@@ -788,6 +795,8 @@ def main():
             gen_mlnni(tmp, [w[6:] for w in which if w.startswith("mlnni:")])
         if "aa" in which:
             gen_aa(tmp)
+        if any(w.startswith("aa:") for w in which):
+            gen_aa(tmp, [w[3:] for w in which if w.startswith("aa:")])
         if "threads" in which:
             gen_threads(tmp)
         if any(w.startswith("threads:") for w in which):

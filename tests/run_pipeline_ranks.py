@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE: a complete pipeline of a fixture on WORLD_SIZE ranks (torch.distributed; all ranks may share GPU 0 with gloo:
 VFT_SAME_DEVICE=1) - the NJ sweeps AND the lanes of the subtree schedule split over the ranks (vft_comm).  Every rank prints
-`rank crc32(tree) bytes lane_allgathers lane_bytes`.  run_pipeline_ranks.py <fixture name>"""
+`rank crc32(tree) bytes lane_allgathers lane_bytes loglk <the TreeLogLk lines as hex floats: treeLogLk's pair likelihoods are split over the ranks too>`.  run_pipeline_ranks.py <fixture name>"""
 import os
 import sys
 import zlib
@@ -44,9 +44,14 @@ def main():
         kw.update(mllen=20)
     else:
         kw.update(me_nni="-nome" not in flags, spr=0 if "-nome" in flags else 2, ml_nni=20, gtr="-gtr" in flags)
-    tree = nj_newick(make, codes_all, names, **kw)
+    ml = "-noml" not in flags
+    tree = nj_newick(make, codes_all, names, return_loglk=ml, **kw)
+    loglk = []
+    if ml:
+        tree, loglk = tree
     calls, nbytes = last_lane_exchange()
-    print("rank %d crc %d bytes %d lane_allgathers %d lane_bytes %d" % (comm.rank if comm else 0, zlib.crc32(tree.encode()), len(tree), calls, nbytes), flush=True)
+    print("rank %d crc %d bytes %d lane_allgathers %d lane_bytes %d loglk %s" % (comm.rank if comm else 0, zlib.crc32(tree.encode()), len(tree), calls, nbytes,
+                                                                                 ",".join(float(x).hex() for x in loglk)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -194,8 +194,13 @@ def test_lanes_across_two_ranks_give_the_single_rank_tree(name):
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29547", script, name], check=True, stdout=subprocess.PIPE, env=env,
                          timeout=900).stdout.decode()
-    got = re.findall(r"rank (\d) crc (\d+) bytes (\d+) lane_allgathers (\d+) lane_bytes (\d+)", two)
+    got = re.findall(r"rank (\d) crc (\d+) bytes (\d+) lane_allgathers (\d+) lane_bytes (\d+) loglk (\S*)", two)
     assert len(got) == 2, two
-    for r, crc, nb, calls, nbytes in got:
+    for r, crc, nb, calls, nbytes, ll in got:
         assert (int(crc), int(nb)) == (zlib.crc32(ref.encode()), len(ref)), (r, crc, nb)
         assert int(calls) > 10 and int(nbytes) > 1000          # the exchange really ran
+    # treeLogLk with its pair likelihoods split over the ranks (MLLengths::treeLogLk): the same doubles on both ranks, the reference's lines
+    assert got[0][5] == got[1][5]
+    if got[0][5] and "loglk" in d:
+        mine = [float.fromhex(x) for x in got[0][5].split(",")]
+        assert len(mine) == len(d["loglk"]) and np.allclose(mine, d["loglk"], rtol=0, atol=1e-3), (mine, list(d["loglk"]))

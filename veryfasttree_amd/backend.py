@@ -27,7 +27,7 @@ I32 = C.c_int32
 
 EXPORTS = [
     "vft_device_malloc", "vft_device_free", "vft_device_upload", "vft_create", "vft_destroy", "vft_last_error", "vft_set_stream", "vft_synchronize", "vft_upload_leaves",
-    "vft_set_distance_matrix", "vft_set_transition_matrix", "vft_set_rates", "vft_set_ml_limits", "vft_set_parents",
+    "vft_set_distance_matrix", "vft_set_transition_matrix", "vft_set_rates", "vft_set_ml_limits", "vft_set_jc_exact", "vft_set_parents",
     "vft_set_node_scalars", "vft_get_node_scalars", "vft_set_out_distances", "vft_get_out_distances", "vft_out_distance_mirror", "vft_set_max_node",
     "vft_profile_upload", "vft_profile_download", "vft_profile_nvectors", "vft_average_profiles", "vft_out_profile_full", "vft_out_profile_partial", "vft_out_profile_finish",
     "vft_out_profile_update", "vft_out_profile_upload", "vft_out_profile_download", "vft_out_distances", "vft_sweep",

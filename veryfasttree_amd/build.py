@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvft_hip.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("vft_api.hip", "vft_ml_kernels_lengths.hip", "vft_ml_kernels_quartet32.hip",
-                                             "vft_ml_kernels_quartet64.hip", "vft_walk_kernels.hip")]
-HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_aa.h", "vft_kernels_profile.h", "vft_kernels_tophits.h", "vft_kernels_njengine.h", "vft_kernels_walk.h", "vft_kernels_ml.h", "vft_iterate_add.h", "vft_glibc_log.h",
+                                             "vft_ml_kernels_quartet64.hip", "vft_ml_kernels_long.hip", "vft_walk_kernels.hip")]
+HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_nj.h", "vft_kernels_aa.h", "vft_kernels_profile.h", "vft_kernels_tophits.h", "vft_kernels_njengine.h", "vft_kernels_walk.h", "vft_kernels_ml.h", "vft_kernels_ml_long.h", "vft_iterate_add.h", "vft_glibc_log.h",
            "vft_glibc_log_data.h"]   # deps of every unit
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 # Tools only (e.g. -DVFT_ABLATE, -DVFT_ML_TIMING, -DVFT_NJ_TIMING): a VARIANT build.  Its objects and its libraries live in
@@ -51,6 +51,8 @@ WALK_HEADERS = ["vft_layout.h", "vft_device.h", "vft_kernels_profile.h", "vft_it
 def unit_deps(src):
     if os.path.basename(src) == "vft_walk_kernels.hip":
         return [src] + [os.path.join(CSRC, h) for h in WALK_HEADERS]
+    if os.path.basename(src) == "vft_ml_kernels_long.hip":
+        return [src] + [os.path.join(CSRC, h) for h in ML_HEADERS + ["vft_kernels_ml_long.h"]]
     if os.path.basename(src) != "vft_api.hip":   # the explicit-instantiation units see the ML kernels only
         return [src] + [os.path.join(CSRC, h) for h in ML_HEADERS]
     return [src] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "vft_hip.h")]

@@ -21,6 +21,8 @@
 #include "vft_kernels_ml.h"
 
 VFT_ML_HEAVY_INSTANCES(extern)   // compiled in vft_ml_kernels_*.hip
+#include "vft_kernels_ml_long.h"
+VFT_ML_LONG_INSTANCES(extern)    // compiled in vft_ml_kernels_long.hip
 #include "vft_kernels_nj.h"
 #include "vft_kernels_aa.h"
 #include "vft_kernels_profile.h"
@@ -65,6 +67,11 @@ struct vft_ctx {
     bool faultNoFlag = false;      // VFT_DEBUG_FAULT_NO_FLAG: the next wait for a completion flag waits for one that never comes
     double waitLimitS = 120.0;     // how long a wait for a completion flag may last while the stream is busy
     bool wideGlue = false;         // test hook: the 1 024-thread instance of k_nj_glue_scan at any size
+    bool jcExact = true;           // vft_set_jc_exact: Jukes-Cantor likelihoods bit for bit the reference's (glibc exp, ordered totals) - the default
+    bool mlLong = false;           // test hook: the line searches through the workspace kernels (vft_kernels_ml_long.h) at any length
+    char *mlLongWs = nullptr;      // their workspaces (one per workgroup of a launch)
+    size_t mlLongWsBytes = 0;
+    size_t shLdsSet = 0;           // the largest dynamic LDS k_sh_support has been configured for
     unsigned int *opHist = nullptr;            // k_leaf_hist: per-(column, code) counts of the active leaves
     int32_t *parent = nullptr, *nOutActive = nullptr;
     void *diameter = nullptr, *selfweight = nullptr, *selfdist = nullptr, *outDist = nullptr;
@@ -275,6 +282,7 @@ static Arena<REAL> arena(const vft_ctx *c) {
     A.rates = (const REAL *) c->rates;
     A.ratecat = c->ratecat;
     A.nRates = c->nRates;
+    A.jcExact = c->jcExact ? 1 : 0;
     A.mlIs = c->mlIs;
     A.mlW = (REAL *) c->mlW;
     A.mlC = c->mlC;
@@ -617,6 +625,7 @@ extern "C" int vft_destroy(vft_ctx *c) {
         hipFree(c->ws.dFlags);
     }
     if (c->blen) hipFree(c->blen);
+    if (c->mlLongWs) hipFree(c->mlLongWs);
     if (c->opHist) hipFree(c->opHist);
     if (c->refDone) hipFree(c->refDone);
     if (c->pendBase) hipFree(c->pendBase);
@@ -780,6 +789,12 @@ extern "C" int vft_set_rates(vft_ctx *c, const void *rates, int32_t nRates, cons
     HIPCHK(c, hipMemcpyAsync(c->ratecat, rc.data(), rc.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nRates = nRates;
+    return VFT_OK;
+}
+
+extern "C" int vft_set_jc_exact(vft_ctx *c, int32_t on) {
+    if (!c) return VFT_ERR_INVALID;
+    c->jcExact = on != 0;
     return VFT_OK;
 }
 
@@ -3840,9 +3855,32 @@ static inline int mlopt_cpt(const vft_ctx *c, bool &quad) {
     return per <= 1 ? 1 : per <= 4 ? 4 : per <= 8 ? 8 : 0;   // (two columns per thread run the four-column kernel: fewer instantiations)
 }
 
+// workspaces of the line-search kernels for long alignments (vft_kernels_ml_long.h): nWG x stride bytes, grown as needed
+static int ensure_ml_long_ws(vft_ctx *c, size_t nWG, int nRows, size_t *stride) {
+    *stride = (vft_ml_long_ws_bytes(c->d.nPos, c->d.nCodes, c->rs, nRows) + 255) & ~(size_t) 255;
+    const size_t bytes = nWG * *stride;
+    if (bytes <= c->mlLongWsBytes) return VFT_OK;
+    if (c->mlLongWs) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->mlLongWs));
+        c->mlLongWs = nullptr;
+        c->mlLongWsBytes = 0;
+    }
+    HIPCHK(c, hipMalloc((void **) &c->mlLongWs, bytes));
+    c->mlLongWsBytes = bytes;
+    return VFT_OK;
+}
+
 template <typename REAL, int NC>
 static int ml_optimize_launch(vft_ctx *c, int64_t n, int cpt, bool quad, const int64_t *dIds, const int64_t *dLi, const int64_t *dRec,
                               double ftol, double atol) {
+    if (cpt == 0 || c->mlLong) {   // more columns than the register-resident instances hold: the workspace kernel
+        size_t stride;
+        if (int r = ensure_ml_long_ws(c, (size_t) n, 1, &stride)) return r;
+        launch((k_ml_node_lengths_long<REAL, NC>), dim3((unsigned) n), dim3(MlOptWG<NC>::value), 0, c->stream, arena<REAL>(c), dIds, dLi, dRec,
+               (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals, c->mlLongWs, stride);
+        return VFT_OK;
+    }
 #define VFT_MLOPT_GO(CPT, QUAD)                                                                                         \
     launch((k_ml_node_lengths<REAL, NC, CPT, QUAD>), dim3((unsigned) n), dim3(MlLineWG<NC, QUAD>::value), 0, c->stream, arena<REAL>(c), \
            dIds, dLi, dRec, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, c->mlEvals)
@@ -3907,6 +3945,15 @@ template <typename REAL, int NC>
 static int ml_quartet_launch(vft_ctx *c, int64_t n, int cpt, bool quad, const int64_t *dIds, const int64_t *dLi, double ftol, double atol,
                              double closeLimit, int mlAccuracy, int mode, double *dLoglk, double *dSite, double *dLen,
                              QuartetNNIResult *dNni, QuartetNNIState *dState = nullptr) {
+    if (cpt == 0 || c->mlLong) {   // more columns than the register-resident instances hold: the workspace kernel
+        const unsigned gy = mode == 2 ? 3u : 1u;
+        size_t stride;
+        if (int r = ensure_ml_long_ws(c, (size_t) n * gy, 3, &stride)) return r;
+        launch((k_ml_quartet_long<REAL, NC>), dim3((unsigned) n, gy), dim3(MlOptWG<NC>::value), 0, c->stream, arena<REAL>(c), dIds, dLi,
+               (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode, dLoglk, dSite, dLen, dNni, dState, c->mlEvals,
+               c->mlLongWs, stride);
+        return VFT_OK;
+    }
 #define VFT_MLQ_GO(CPT, QUAD)                                                                                           \
     launch((k_ml_quartet<REAL, NC, CPT, QUAD>), dim3((unsigned) n, mode == 2 ? 3u : 1u), dim3(MlLineWG<NC, QUAD>::value), 0, c->stream, \
            arena<REAL>(c), dIds, dLi, (REAL *) c->blen, c->minLen, c->minRel, ftol, atol, closeLimit, mlAccuracy, mode,  \
@@ -4019,7 +4066,14 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
     const int64_t nPos = c->d.nPos;
     bool quad;
     const int cpt = mlopt_cpt(c, quad);
-    if (nBoot > 0 && (nPos > 65535 || (size_t) 3 * nPos * sizeof(double) > 60000)) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the SH resampling kernel");
+    if (nBoot > 0 && nPos > 65535) return fail(c, VFT_ERR_INVALID, "vft_ml_split_tests: alignment too long for the SH resampling kernel");
+    // k_sh_support keeps a split's 3 x nPos per-site log-likelihoods in the LDS while they fit (160 KB per workgroup on gfx950: 6 800 columns)
+    const size_t shBytes = (size_t) 3 * nPos * sizeof(double);
+    const bool shLds = shBytes <= (size_t) 150 << 10;
+    if (nBoot > 0 && shLds && shBytes > 48000 && shBytes > c->shLdsSet) {
+        HIPCHK(c, hipFuncSetAttribute((const void *) k_sh_support, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shBytes));
+        c->shLdsSet = shBytes;
+    }
     // chunks of splits: per split 3 x nPos site log-likelihoods
     int64_t chunk = (int64_t) ((512u << 20) / ((size_t) 3 * nPos * sizeof(double)));
     chunk = chunk < 1 ? 1 : chunk > n ? n : chunk;
@@ -4056,8 +4110,8 @@ extern "C" int vft_ml_split_tests(vft_ctx *c, int64_t n, const int64_t *ids, con
         if (r) return r;
         LAUNCHCHK(c);
         if (nBoot > 0) {
-            launch(k_sh_support, dim3((unsigned) cnt), dim3(256), (size_t) 3 * nPos * sizeof(double), c->stream, (const double *) dSite,
-                   (const double *) dLoglk, (const uint16_t *) dCol, nPos, nBoot, dSup);
+            launch(k_sh_support, dim3((unsigned) cnt), dim3(256), shLds ? shBytes : (size_t) 0, c->stream, (const double *) dSite,
+                   (const double *) dLoglk, (const uint16_t *) dCol, nPos, nBoot, dSup, shLds ? 1 : 0);
             LAUNCHCHK(c);
             HIPCHK(c, hipMemcpyAsync(support + k0, dSup, cB, hipMemcpyDeviceToHost, c->stream));
         }
@@ -4178,6 +4232,7 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_FAULT_NO_FLAG: c->faultNoFlag = value != 0; break;
         case VFT_DEBUG_WAIT_LIMIT_MS: c->waitLimitS = value > 0 ? (double) value / 1000.0 : 120.0; break;
         case VFT_DEBUG_WIDE_GLUE: c->wideGlue = value != 0; break;
+        case VFT_DEBUG_ML_LONG: c->mlLong = value != 0; break;
         case VFT_DEBUG_NO_WALK_SERVER: c->ws.disabled = value != 0; break;
         case VFT_DEBUG_WALK_DEVICE_MAILBOX: c->ws.wantDeviceMail = value != 0; break;
         case VFT_DEBUG_WALK_SERVER_STRIDE: c->ws.stride = value == 1 ? 1 : 8; break;

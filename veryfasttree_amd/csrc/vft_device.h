@@ -31,6 +31,7 @@ struct Arena {
     const REAL *rates;
     const int32_t *ratecat;
     int32_t nRates;
+    int32_t jcExact;   // Jukes-Cantor likelihoods the reference's way to the last bit: glibc's exp in P(t), the ordered total (vft_kernels_ml.h)
     // ML-phase profiles (vft_layout.h, "dense ML rows"): a node whose mlIs byte is set lives in mlW/mlC/mlF instead of
     // the tile streams.  Indexed by (node - nSeqs) * nPos + p; NULL until the ML phase allocates them.
     uint8_t *mlIs;

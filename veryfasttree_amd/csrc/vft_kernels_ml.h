@@ -45,8 +45,10 @@ __device__ __forceinline__ void vft_exp_eigen_rates(const Arena<REAL> &A, double
     }
 }
 
-__device__ __forceinline__ void vft_psame_pdiff(double length, double rate, double &pSame, double &pDiff) {
-    pSame = 0.25 + 0.75 * exp((-4.0 / 3.0) * fabs(length * rate));
+// exact: libm's exp bit for bit (vft_glibc_log.h), as the matrix models' tables take it - Arena::jcExact
+__device__ __forceinline__ void vft_psame_pdiff(double length, double rate, double &pSame, double &pDiff, bool exact = false) {
+    const double x = (-4.0 / 3.0) * fabs(length * rate);
+    pSame = 0.25 + 0.75 * (exact ? vft_glibc_exp(x) : exp(x));
     pDiff = (1.0 - pSame) / 3.0;
 }
 
@@ -649,14 +651,14 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_pair_loglk(Arena<REAL> A, const i
     const double len = length[k];
     const bool jc = A.tmStat == nullptr;
     if (jc) {
-        for (int r = threadIdx.x; r < A.nRates; r += blockDim.x) vft_psame_pdiff(len, (double) A.rates[r], pS[r], pD[r]);
+        for (int r = threadIdx.x; r < A.nRates; r += blockDim.x) vft_psame_pdiff(len, (double) A.rates[r], pS[r], pD[r], A.jcExact != 0);
     } else {
         vft_exp_eigen_rates<REAL, NC>(A, len, minRel, expeig);
     }
     __syncthreads();
     double lk = 1.0, loglk = 0.0;
-    if (!jc) {
-        // matrix model: the reference's ordered total (vft_lk_chain), VFT_ML_STAGE columns at a time
+    if (!jc || (NC == 4 && A.jcExact)) {
+        // matrix model (and Jukes-Cantor to the last bit, Arena::jcExact): the reference's ordered total (vft_lk_chain), VFT_ML_STAGE columns at a time
         __shared__ double stage[VFT_ML_STAGE];
         for (int64_t p0 = 0; p0 < A.d.nPos; p0 += VFT_ML_STAGE) {
             const int64_t cnt = A.d.nPos - p0 < VFT_ML_STAGE ? A.d.nPos - p0 : VFT_ML_STAGE;
@@ -859,8 +861,8 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior(Arena<REAL> A, const in
     const bool jc = A.tmStat == nullptr;
     if (jc) {
         for (int r = threadIdx.x; r < A.nRates; r += blockDim.x) {
-            vft_psame_pdiff(len1, (double) A.rates[r], pS1[r], pD1[r]);
-            vft_psame_pdiff(len2, (double) A.rates[r], pS2[r], pD2[r]);
+            vft_psame_pdiff(len1, (double) A.rates[r], pS1[r], pD1[r], A.jcExact != 0);
+            vft_psame_pdiff(len2, (double) A.rates[r], pS2[r], pD2[r], A.jcExact != 0);
         }
     } else {
         vft_exp_eigen_rates<REAL, NC>(A, len1, minRel, ee1);
@@ -909,8 +911,8 @@ __global__ __launch_bounds__(VFT_ML_WG) void k_posterior_chain(Arena<REAL> A, co
         __syncthreads();
         if (jc) {
             for (int q = threadIdx.x; q < A.nRates; q += blockDim.x) {
-                vft_psame_pdiff(len1, (double) A.rates[q], pS1[q], pD1[q]);
-                vft_psame_pdiff(len2, (double) A.rates[q], pS2[q], pD2[q]);
+                vft_psame_pdiff(len1, (double) A.rates[q], pS1[q], pD1[q], A.jcExact != 0);
+                vft_psame_pdiff(len2, (double) A.rates[q], pS2[q], pD2[q], A.jcExact != 0);
             }
         } else {
             vft_exp_eigen_rates<REAL, NC>(A, len1, minRel, ee1);
@@ -1466,8 +1468,8 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_node_lengths
         if (l2 < minLen) l2 = minLen;
         if (jc) {
             for (int r = threadIdx.x; r < A.nRates; r += WG) {
-                vft_psame_pdiff(l1, (double) A.rates[r], pS1[r], pD1[r]);
-                vft_psame_pdiff(l2, (double) A.rates[r], pS2[r], pD2[r]);
+                vft_psame_pdiff(l1, (double) A.rates[r], pS1[r], pD1[r], A.jcExact != 0);
+                vft_psame_pdiff(l2, (double) A.rates[r], pS2[r], pD2[r], A.jcExact != 0);
             }
         } else {
             eigenTable(l1, ee1);
@@ -1512,12 +1514,12 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_node_lengths
         __syncthreads();
         auto negLogLk = [&](double x) -> double {
             if (jc) {
-                for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r]);
+                for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(x, (double) A.rates[r], pS1[r], pD1[r], A.jcExact != 0);
             } else {
                 eigenTable(x, ee1);
             }
             __syncthreads();
-            if (!jc) {   // matrix model: the reference's ordered total
+            if (!jc || (NC == 4 && A.jcExact)) {   // matrix model (and Jukes-Cantor to the last bit, Arena::jcExact): the reference's ordered total
                 double col[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; c++) {
@@ -1656,7 +1658,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
     auto table = [&](int s, double len, bool clamp) {
         if (clamp && len < minLen) len = minLen;
         if (jc) {
-            for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(len, (double) A.rates[r], pS[s][r], pD[s][r]);
+            for (int r = threadIdx.x; r < A.nRates; r += WG) vft_psame_pdiff(len, (double) A.rates[r], pS[s][r], pD[s][r], A.jcExact != 0);
         } else {
             if constexpr (QUAD) vft_quad_exp_eigen_rates<REAL>(&quadTab, A.nRates, len, minRel, ee[s]);
             else vft_exp_eigen_rates<REAL, NC>(A, len, minRel, ee[s]);
@@ -1681,7 +1683,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
         table(0, len, false);
         __syncthreads();
         VFT_ML_TICK(1);   // tables
-        if (!jc) {   // matrix model: the reference's ordered total
+        if (!jc || (NC == 4 && A.jcExact)) {   // matrix model (and Jukes-Cantor to the last bit, Arena::jcExact): the reference's ordered total
             double col[CPT];
 #pragma unroll
             for (int c = 0; c < CPT; c++) {
@@ -1747,7 +1749,7 @@ __global__ __launch_bounds__((MlLineWG<NC, QUAD>::value)) void k_ml_quartet(Aren
         for (int c = 0; c < CPT; c++) {
             const int64_t p = (int64_t) qc + (int64_t) c * CW;
             if (p < nPos && ql == 0)   // SHSupport takes the logs, NJ.tcc:1134-1137 (glibc's log where the totals are the reference's)
-                siteOut[(k * 3 + topo) * nPos + p] = (!jc && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
+                siteOut[(k * 3 + topo) * nPos + p] = ((!jc || (NC == 4 && A.jcExact)) && site[c] > 0.0) ? vft_glibc_log(site[c]) : log(site[c]);
         }
     };
     const int64_t nA = ids[4 * k], nB = ids[4 * k + 1], nC = ids[4 * k + 2], nD = ids[4 * k + 3];
@@ -2071,12 +2073,15 @@ __global__ void k_ml_nni_verdict(const QuartetNNIState *state, const int64_t *le
 // One workgroup per split; its 3 x nPos site log-likelihoods sit in LDS, a thread per resample walks the resample's
 // columns in order (the reference's sequence of additions).  colT: [nPos][nBoot] (transposed, so that the threads of
 // a wavefront read consecutive entries).
+// inLds = 0 (alignments whose 3 x nPos doubles do not fit the LDS, > 6 800 columns): the site values are read where they are.
 static __global__ __launch_bounds__(256) void k_sh_support(const double *siteLoglk, const double *loglk, const uint16_t *colT,
-                                                    int64_t nPos, int32_t nBoot, double *support) {
-    extern __shared__ double sSite[];   // [3][nPos]
+                                                    int64_t nPos, int32_t nBoot, double *support, int inLds) {
+    extern __shared__ double sSiteLds[];   // [3][nPos]
     __shared__ unsigned int sCount;
     const int64_t k = blockIdx.x;
-    for (int64_t i = threadIdx.x; i < 3 * nPos; i += blockDim.x) sSite[i] = siteLoglk[k * 3 * nPos + i];
+    if (inLds)
+        for (int64_t i = threadIdx.x; i < 3 * nPos; i += blockDim.x) sSiteLds[i] = siteLoglk[k * 3 * nPos + i];
+    const double *sSite = inLds ? sSiteLds : siteLoglk + k * 3 * nPos;
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
     const double l0 = loglk[3 * k], l1 = loglk[3 * k + 1], l2 = loglk[3 * k + 2];

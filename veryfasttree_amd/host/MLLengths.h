@@ -213,6 +213,21 @@ namespace veryfasttree {
                 len.push_back((double) sum);
             }
             std::vector<double> ll(a.size());
+            if (sharded()) {
+                /* SURVEY 8e "ML level batches", the treeLogLk part: the nodes' pair likelihoods are independent reads of the
+                   (replicated) profiles - rank r evaluates its share of the post-order list, one all-gather of 8 bytes per node,
+                   and every rank adds the same doubles in the same order below.  (recomputeMLProfiles stays replicated: sharing
+                   a level's posteriors means all-gathering one row per node where recomputing it moves three rows through the
+                   local HBM - the arithmetic is in DESIGN.md section 5.) */
+                size_t per, k0, k1;
+                shareOf(a.size(), per, k0, k1);
+                if (k1 > k0) chk(vft_pair_loglk(ctx, (int64_t) (k1 - k0), a.data() + k0, b.data() + k0, len.data() + k0, ll.data() + k0, nullptr));
+                if ((int64_t) (per * sizeof(double)) > comm->h_cap) throw std::invalid_argument("MLLengths: vft_comm host buffers too small for a tree's pair likelihoods");
+                std::memcpy(comm->h_send, ll.data() + k0, (k1 - k0) * sizeof(double));
+                const char *rcv = gatherRecords(per, sizeof(double));
+                for (size_t t = 0; t < a.size(); t++) std::memcpy(&ll[t], rcv + laneRecord(t, per) * sizeof(double), sizeof(double));
+                treeLogLkSharded++;
+            } else
             chk(vft_pair_loglk(ctx, (int64_t) a.size(), a.data(), b.data(), len.data(), ll.data(), nullptr));
             /* the third branch of the root against the posterior of the first two (NJ.tcc:5138-5151); the root's own
                slot holds that temporary */
@@ -705,7 +720,7 @@ namespace veryfasttree {
            others' lengths into their own branchlength[].  The same kernels judge the same inputs, whoever runs them: the tree is the
            single-rank tree byte for byte (tests/test_gpu_threads.py).  One all-gather of a few hundred bytes per item and step. */
         const vft_comm *comm = nullptr;
-        int64_t laneGathers = 0, laneGatherBytes = 0;
+        int64_t laneGathers = 0, laneGatherBytes = 0, treeLogLkSharded = 0;
         bool sharded() const { return comm != nullptr && comm->world > 1; }
         /* rank r's share [k0, k1) of a batch of K items over W ranks, and the padded share `per` every rank sends; item t of the batch
            is record laneRecord(t, per) of the gathered buffer (exported as vft_nj_lane_share for the CPU test of the exchange layout) */
