@@ -382,7 +382,7 @@ def run_leg(key):
 
 # what a leg took on the driver's box last round (BENCH_r05.json; C5's legs are on SURVEY 8(d)'s alignment from round 6 on and cost more):
 # a leg is skipped when the time used so far plus this figure would pass --time-budget, so that the driver's clock cannot run out inside it
-LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 60.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 90.0, "e2e_c4_full_threads": 470.0, "e2e_c5": 520.0}
+LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 60.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 70.0, "e2e_c4_full_threads": 540.0, "e2e_c5": 430.0}
 
 
 def launch_legs(args):

@@ -440,7 +440,8 @@ int vft_posterior_chains_blen(vft_ctx *ctx, int32_t n_chains, const int32_t *cha
    MLPairOptimize(P_i, posteriorProfile(P_i+1, P_i+2)) = onedimenmin/Brent on pairLogLk (NJ.tcc:1790-1803, 7025-7178)
    with ftol = MLFTolBranchLength, atol = MLMinBranchLengthTolerance, limits [MLMinBranchLength (vft_set_ml_limits), 6].
    recompute[k] >= 0: afterwards that node's profile = posteriorProfile(ids[3k], ids[3k+1]) with the new lengths
-   (recomputeProfile, NJ.tcc:3436); -1 for the root (all entries of one call alike).  n_pos <= 2048 (nt) / 1024 (aa).
+   (recomputeProfile, NJ.tcc:3436); -1 for the root (all entries of one call alike).  Any n_pos the context was created for: up to 2 048 columns
+   the search keeps its profiles in registers, beyond that in a workspace in device memory (csrc/vft_kernels_ml_long.h; the same numbers).
    Stream-ordered. */
 int vft_ml_optimize_splits(vft_ctx *ctx, int64_t n, const int64_t *ids, const int64_t *len_idx, const int64_t *recompute,
                            double ftol, double atol);
@@ -502,7 +503,7 @@ int vft_debug_log(vft_ctx *ctx, int64_t n, const double *x, double *out);
 #define VFT_DEBUG_WALK_SERVER_STRIDE 11 /* 1: the server's six workgroups on six XCDs instead of one (placement is for speed only; tests run both) */
 #define VFT_DEBUG_POISON_SELECTION 14    /* fills the selection's candidate buffers of every slot with 0x7f bytes - what a recycled allocation holds - before the next sweep (tests: a collection that overflows must not look at entries it never stored) */
 #define VFT_DEBUG_ML_LONG 16            /* value != 0: the ML line searches (vft_ml_optimize_splits, vft_ml_quartet_nni*, vft_ml_split_tests) run the workspace kernels of alignments beyond 2 048 columns at any length (tests compare with the register-resident kernels) */
-#define VFT_DEBUG_NO_MULTI_SWEEP 12     /* value != 0: vft_sweep_batch sweeps its leaf seeds one launch each instead of four per pass over the targets (tests compare) */
+#define VFT_DEBUG_NO_MULTI_SWEEP 12     /* 1: vft_sweep_batch sweeps its seeds one launch each instead of four per pass over the targets (tests compare); 2 / 4: that many seeds per pass whatever the shard; 0: the built-in choice */
 int vft_debug_option(vft_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- measurement helpers used by bench.py (HIP events on the context's stream) */

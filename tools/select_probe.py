@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""How many candidates the top-k selection ranks per seed on bench.py's workload, through the one-launch front (the bound from the
-sweep's per-wavefront minimum criteria) and through the histogram rounds, and what one batch of 8 seeds costs each way."""
+"""How many candidates the top-k selection ranks per seed on bench.py's workload (the histogram rounds: k_select_hist / collect / rank) and
+what one batch of 8 seeds costs.  (Round 6 also tried a histogram-free front - a bound from the sweep's per-wavefront minimum criteria -
+behind a debug option that is gone with it: 3 500-5 700 candidates per seed instead of ~2 030)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,15 +18,12 @@ for s in range(4):
     seeds.append(int(leaf_act[(s * 7919 + 13) % len(leaf_act)]))
     seeds.append(int(int_act[(s * 104729 + 7) % len(int_act)]))
 seeds = np.asarray(seeds, np.int64)
-for no_ub in (1, 0):
-    ops.debug_option(15, no_ub)
-    for _ in range(3):
-        ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k, view=True)
-    ops.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k, view=True)
-    ops.synchronize()
-    dt = (time.perf_counter() - t0) / 20
-    print("%s: %.1f us per batch of 8 seeds; candidates per seed (k = %d): %s" % ("histogram rounds" if no_ub else "bound from part minima", dt * 1e6, k,
-          [ops.sweep_batch_info(s)[0] for s in range(len(seeds))]))
+for _ in range(3):
+    ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k, view=True)
+ops.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    ops.setBestHitBatch(seeds, st.n_active, st.n_diff_allow, st.totdiam, k, view=True)
+ops.synchronize()
+dt = (time.perf_counter() - t0) / 20
+print("%.1f us per batch of 8 seeds; candidates per seed (k = %d): %s" % (dt * 1e6, k, [ops.sweep_batch_info(s)[0] for s in range(len(seeds))]))

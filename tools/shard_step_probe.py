@@ -30,6 +30,10 @@ for s in range(4):
     seeds.append(int(int_act[(s * 104729 + 7) % len(int_act)]))
 seeds = np.asarray(seeds, np.int64)
 weights = sweep_cost_weights(state.parent, n)
+if os.environ.get("VFT_PROBE_MULTI"):   # VFT_DEBUG_NO_MULTI_SWEEP: 1 = a launch per seed, 2 / 4 = that many seeds per shared pass
+    import ctypes
+    assert ops.lib.vft_debug_option(ops.ctx, ctypes.c_int32(12), ctypes.c_int64(int(os.environ["VFT_PROBE_MULTI"]))) == 0
+    print("# seeds per shared pass forced: VFT_DEBUG_NO_MULTI_SWEEP =", os.environ["VFT_PROBE_MULTI"])
 print("# %d x %d, %d active, %d seeds per step, k = %d; us per step of one rank's local work (sweeps + selection, records left in the result blocks)" % (n, L, state.n_active, len(seeds), k))
 print("%5s %5s %12s %12s %10s" % ("world", "rank", "lo", "hi", "us/step"))
 for world in (1, 2, 4, 8):

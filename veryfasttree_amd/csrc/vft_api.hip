@@ -201,6 +201,7 @@ struct vft_ctx {
     size_t kevUsed = 0;
     int64_t kevSweeps = 0;       // sweeps beyond one per timed launch (a pass of k_sweep_nt_leafq_multi covers several)
     bool noMultiSweep = false;   // VFT_DEBUG_NO_MULTI_SWEEP
+    int multiMax = 0;            // seeds per shared pass: 0 = by the shard's size (vft_sweep_batch), 2 / 4 = fixed (VFT_DEBUG_NO_MULTI_SWEEP values 2 / 4)
     bool timeKernels = false;
 };
 
@@ -2251,6 +2252,7 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
     if (staged && !c->noMultiSweep && !(c->maxStamp - nActive > nDiffAllow)) {
         bool fresh = true;
         for (int s = 0; s < nSeeds && fresh; s++) fresh = !((int64_t) c->hNOut[queries[s]] - nActive > nDiffAllow);
+        const int maxGroup = c->multiMax ? c->multiMax : 4;
         for (int kind = 0; kind < 2 && fresh; kind++) {   // the leaf seeds, then the profile seeds: fours while they last, then a pair; a last single goes alone
             SeedGroup g{};
             g.leaf = kind == 0;
@@ -2261,7 +2263,7 @@ extern "C" int vft_sweep_batch(vft_ctx *c, int32_t nSeeds, const int64_t *querie
                 if (!isKind(s)) continue;
                 g.pos[g.n++] = s;
                 nLeft--;
-                if (g.n == 4 || (g.n == 2 && nLeft < 2)) {
+                if (g.n == maxGroup || (g.n == 2 && nLeft < 2)) {
                     groups.push_back(g);
                     g.n = 0;
                 }
@@ -4236,7 +4238,10 @@ extern "C" int vft_debug_option(vft_ctx *c, int32_t option, int64_t value) {
         case VFT_DEBUG_NO_WALK_SERVER: c->ws.disabled = value != 0; break;
         case VFT_DEBUG_WALK_DEVICE_MAILBOX: c->ws.wantDeviceMail = value != 0; break;
         case VFT_DEBUG_WALK_SERVER_STRIDE: c->ws.stride = value == 1 ? 1 : 8; break;
-        case VFT_DEBUG_NO_MULTI_SWEEP: c->noMultiSweep = value != 0; break;
+        case VFT_DEBUG_NO_MULTI_SWEEP:
+            c->noMultiSweep = value == 1;
+            c->multiMax = value == 2 || value == 4 ? (int) value : 0;
+            break;
         case VFT_DEBUG_POISON_SELECTION:   // the candidate buffers of every slot filled with 0x7f bytes: what recycled memory looks like
             for (vft_ctx::SweepSlotHost &h: c->slots) {
                 HIPCHK(c, hipMemset(h.candKey, 0x7f, (size_t) VFT_CAND_CAP * 8));
