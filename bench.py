@@ -280,6 +280,10 @@ E2E_FULL = {
     "c2": dict(n=10000, L=1000, nc=4, seed=2, dtype="float32", gtr=True, aa=None, threads=64, flags="-nt -gtr", golden="bb_c2_crc.npz"),
     # (C5 = SURVEY.md 8(d)'s alignment: mu 0.08, gaps 0.02, seed 5; rounds 4-5 ran C2's generator parameters here by mistake)
     "c5": dict(n=50000, L=300, nc=20, seed=5, mu=0.08, gap=0.02, dtype="float64", gtr=False, aa="lg", threads=128, flags="-lg -double-precision", golden="bb_c5_crc.npz"),
+    # config C4's generator at 100 000 sequences with its real flags on the 64-thread schedule: the largest complete pipeline of the reference
+    # this backend is pinned to byte for byte (tests/golden/thr_c4_100k_t64_crc.npz: `VeryFastTree -nt -threads 64`, 985 s on eight cores)
+    "c4s": dict(n=100000, L=200, nc=4, seed=4, mu=0.02, dtype="float32", gtr=False, aa=None, threads=64, flags="-nt", golden=None,
+                golden_threads="thr_c4_100k_t64_crc.npz"),
     # config C4 with its real flags (9 minutes)
     "c4": dict(n=1000000, L=200, nc=4, seed=4, mu=0.02, dtype="float32", gtr=False, aa=None, threads=1024, flags="-nt", golden=None),
 }
@@ -331,6 +335,17 @@ def end_to_end_full(which, device, one_thread, comm=None):
             out["reference_on_a_pool_box_builder_run"] = dict(wall_s=rec["wall_s"], threads=T, cpu=w.get("cpu"), cores=w.get("cores"),
                                                               source="profiles/r05_reference_walls_gpu_box.json (not measured in this run)",
                                                               same_tree_as_this_run=bool(rec.get("newick_crc") == out["newick_crc"]))
+    gt = cfg.get("golden_threads")
+    if not one_thread and gt and os.path.exists(os.path.join(ROOT, "tests", "golden", gt)):   # a complete run of the reference at T threads
+        g = np.load(os.path.join(ROOT, "tests", "golden", gt))
+        if int(g["threads"]) == T:
+            out["reference_newick_crc"] = int(g["newick_crc"])
+            out["identical_to_reference"] = bool(int(g["newick_crc"]) == out["newick_crc"] and int(g["newick_bytes"]) == len(tree))
+            out["reference_wall_s_%d_threads_build_container_8_cores" % T] = round(float(g["reference_wall_s"]), 1)
+            out["reference_nj_equals_its_one_thread_nj"] = bool(int(g["reference_nj_equals_its_one_thread_nj"]))
+            want = g["loglk"]
+            if len(want) and len(loglk):
+                out["final_loglk_rel_diff"] = float(abs(loglk[-1] - want[-1]) / abs(want[-1]))
     if one_thread and cfg["golden"] and os.path.exists(os.path.join(ROOT, "tests", "golden", cfg["golden"])):
         g = np.load(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
         out["reference_newick_crc"] = int(g["newick_crc"])
@@ -359,7 +374,8 @@ def launch_ranks(args):
 
 # the end-to-end legs of a single-GPU run: key -> (kind, config, one-thread order)
 LEGS = [("e2e", "tree", "c3", False), ("e2e_c4", "tree", "c4", False), ("e2e_c2", "full", "c2", True), ("e2e_c2_threads", "full", "c2", False),
-        ("e2e_c5_threads", "full", "c5", False), ("e2e_c4_full_threads", "full", "c4", False), ("e2e_c5", "full", "c5", True)]
+        ("e2e_c5_threads", "full", "c5", False), ("e2e_c4s_threads", "full", "c4s", False), ("e2e_c4_full_threads", "full", "c4", False),
+        ("e2e_c5", "full", "c5", True)]
 
 
 def wanted_legs(args):
@@ -382,7 +398,7 @@ def run_leg(key):
 
 # what a leg took on the driver's box last round (BENCH_r05.json; C5's legs are on SURVEY 8(d)'s alignment from round 6 on and cost more):
 # a leg is skipped when the time used so far plus this figure would pass --time-budget, so that the driver's clock cannot run out inside it
-LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 60.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 70.0, "e2e_c4_full_threads": 540.0, "e2e_c5": 430.0}
+LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 60.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 70.0, "e2e_c4s_threads": 55.0, "e2e_c4_full_threads": 540.0, "e2e_c5": 430.0}
 
 
 def launch_legs(args):
@@ -722,7 +738,7 @@ def main():
             # the complete pipelines (refinement + maximum likelihood + supports): not sharded, rank 0 only.  C2 and C5 in the
             # reference's one-thread order (its deterministic path: trees compared with the reference binary's own output) and on
             # the schedule of a T-thread run; C4 with its real flags on the schedule of 1 024 threads.
-            legs = [("e2e_c2", "c2", True), ("e2e_c2_threads", "c2", False), ("e2e_c5_threads", "c5", False)]
+            legs = [("e2e_c2", "c2", True), ("e2e_c2_threads", "c2", False), ("e2e_c5_threads", "c5", False), ("e2e_c4s_threads", "c4s", False)]
             if not args.no_e2e_c4_full:
                 legs.append(("e2e_c4_full_threads", "c4", False))
             if not args.no_e2e_c5_one_thread:

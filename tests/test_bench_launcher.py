@@ -53,7 +53,7 @@ def test_single_gpu_launcher_merges_its_children_and_survives_a_dying_leg():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-e2e-c5-one-thread"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     lines = [json.loads(ln) for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
-    legs = ["e2e", "e2e_c4", "e2e_c2", "e2e_c2_threads", "e2e_c5_threads", "e2e_c4_full_threads"]
+    legs = ["e2e", "e2e_c4", "e2e_c2", "e2e_c2_threads", "e2e_c5_threads", "e2e_c4s_threads", "e2e_c4_full_threads"]
     assert len(lines) == 1 + len(legs)
     assert lines[0]["legs_pending"] == legs and not [k for k in lines[0] if k.startswith("e2e")]
     for a, b in zip(lines, lines[1:]):   # every line a superset of the one before
