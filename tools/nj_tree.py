@@ -5,6 +5,7 @@ or - with -mllen - the tree of `VeryFastTree -nt -nome -mllen [-nocat | -cat N] 
     python tools/nj_tree.py in.fasta [-fastest] [-double] [-nosupport] [-nj-lengths] [-mllen [-nocat | -cat N]] > tree.nwk
     python tools/nj_tree.py in.fasta -full [-gtr] [-double] [-nosupport] > tree.nwk     # what plain `VeryFastTree -nt [-gtr]` prints
     python tools/nj_tree.py in.fasta -full -lg -double > tree.nwk     # proteins: `VeryFastTree -lg -double-precision` (-aa / -jtt, -wag, -lg)
+    python tools/nj_tree.py in.fasta -full -threads 64 [-gamma] [-spr N] > tree.nwk   # the schedule of `VeryFastTree -threads 64`; -gamma; -spr N rounds
 
 Neighbour joining with top hits on the device (veryfasttree_amd/host/NJDriver.h), the root, minimum-evolution branch
 lengths (updateBranchLengths), local-bootstrap supports (1000 resamples, reliabilityNJ) and printNJ; -nj-lengths keeps
@@ -51,6 +52,12 @@ def main():
     extra = dict(me_nni=True, spr=2, ml_nni=20) if "-full" in args else {}
     if "-gtr" in args:
         extra["gtr"] = True   # ME NNIs + SPRs, ML NNIs, CAT, SH supports
+    if "-spr" in args and extra:
+        extra["spr"] = int(args[args.index("-spr") + 1])
+    if "-threads" in args:   # the refinement stages on the schedule of a T-thread run of the reference (include/vft_host.h, vft_nj_options.threads)
+        extra["threads"] = int(args[args.index("-threads") + 1])
+    if "-gamma" in args and extra:
+        extra["gamma"] = True
     names, seqs = read_fasta(args[0])
     if len({len(s) for s in seqs}) != 1:
         sys.exit("sequences have different lengths: not an alignment")
