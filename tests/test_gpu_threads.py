@@ -93,7 +93,8 @@ def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n):
     agree to 1e-4 relative (observed: to the printed digit) and the tree must have the reference's length; byte identity is asked for
     where it can hold - where the reference's threaded NJ phase joins in its one-thread order, which this backend's NJ phase follows: at
     100 000 sequences (it holds since the Jukes-Cantor totals are the reference's ordered product, vft_set_jc_exact: the per-thread sums of
-    rounds 1-5 flipped 24 exact ties there).  At
+    rounds 1-5 flipped 24 exact ties there), and the same alignment in the one-thread order (thr_c4_100k_t1_crc: the reference's complete
+    default pipeline at one thread, 950 s; 228 s here).  At
     200 000 sequences it does not (one split of its NJ tree differs: its threaded outProfile adds per-thread partial sums,
     NJ.tcc:763-783), and the two final trees differ in 44 of 199 997 splits with all four log-likelihoods equal to the printed digit."""
     import os
