@@ -311,6 +311,24 @@ def end_to_end_full(which, device, one_thread, comm=None):
     if comm is not None:   # sharded: the NJ sweeps and the lanes of the subtree schedule are split over the ranks
         kw["comm"] = comm
         comm.calls = comm.bytes = comm.device_calls = comm.device_bytes = 0
+    # C2 in the one-thread order: the compiled reference itself (oracle/_ref/VeryFastTree, when the box has it) runs the same alignment with
+    # the same flags on ONE host core beside this leg - a wall-clock of the reference measured in this run, on this box (~110 s)
+    ref_run = None
+    refbin = os.path.join(ROOT, "oracle", "_ref", "VeryFastTree")
+    if one_thread and which == "c2" and comm is None and os.path.exists(refbin) and not os.environ.get("VFT_BENCH_NO_REFERENCE_RUN"):
+        import subprocess, tempfile, threading
+        tmpd = tempfile.mkdtemp(prefix="vft_bench_ref_")
+        fa = os.path.join(tmpd, "c2.fa")
+        synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+        ref_run = dict(t0=time.perf_counter(), t1=None, tmpd=tmpd, out=os.path.join(tmpd, "c2.tree"))
+        ref_run["proc"] = subprocess.Popen([refbin] + cfg["flags"].split() + ["-threads", "1", "-seed", "1", fa], stdout=open(ref_run["out"], "wb"),
+                                           stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+        def _wait():
+            ref_run["proc"].wait()
+            ref_run["t1"] = time.perf_counter()
+        ref_run["thread"] = threading.Thread(target=_wait, daemon=True)
+        ref_run["thread"].start()
     t0 = time.perf_counter()
     tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, cfg["nc"], dt, max_nodes=3 * m, device=device), codes, names, **kw)
     wall = time.perf_counter() - t0
@@ -335,6 +353,18 @@ def end_to_end_full(which, device, one_thread, comm=None):
             out["reference_on_a_pool_box_builder_run"] = dict(wall_s=rec["wall_s"], threads=T, cpu=w.get("cpu"), cores=w.get("cores"),
                                                               source="profiles/r05_reference_walls_gpu_box.json (not measured in this run)",
                                                               same_tree_as_this_run=bool(rec.get("newick_crc") == out["newick_crc"]))
+    if ref_run is not None:
+        import shutil
+        ref_run["thread"].join(timeout=900)
+        if ref_run["t1"] is not None and ref_run["proc"].returncode == 0:
+            rtree = open(ref_run["out"], "rb").read().decode().strip()
+            out["reference_measured_in_this_run"] = dict(wall_s=round(ref_run["t1"] - ref_run["t0"], 1), threads=1, cpu=cpu_model(),
+                                                         binary="oracle/_ref/VeryFastTree " + cfg["flags"] + " -threads 1 -seed 1",
+                                                         beside="this leg's own run (one host core)",
+                                                         same_tree_as_this_run=bool(zlib.crc32(rtree.encode()) == out["newick_crc"]))
+        else:
+            ref_run["proc"].kill()
+        shutil.rmtree(ref_run["tmpd"], ignore_errors=True)
     gt = cfg.get("golden_threads")
     if not one_thread and gt and os.path.exists(os.path.join(ROOT, "tests", "golden", gt)):   # a complete run of the reference at T threads
         g = np.load(os.path.join(ROOT, "tests", "golden", gt))
@@ -398,7 +428,7 @@ def run_leg(key):
 
 # what a leg took on the driver's box last round (BENCH_r05.json; C5's legs are on SURVEY 8(d)'s alignment from round 6 on and cost more):
 # a leg is skipped when the time used so far plus this figure would pass --time-budget, so that the driver's clock cannot run out inside it
-LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 60.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 70.0, "e2e_c4s_threads": 55.0, "e2e_c4_full_threads": 540.0, "e2e_c5": 430.0}
+LEG_WALL_S = {"e2e": 25.0, "e2e_c4": 130.0, "e2e_c2": 130.0, "e2e_c2_threads": 15.0, "e2e_c5_threads": 70.0, "e2e_c4s_threads": 55.0, "e2e_c4_full_threads": 540.0, "e2e_c5": 430.0}
 
 
 def launch_legs(args):

@@ -478,6 +478,31 @@ def harvest_threads_big(n, threads):
     print("%s_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (tag, len(tree), zlib.crc32(tree.encode()), len(ll), wall))
 
 
+def gen_c3_full(tmp):
+    """Config C3's alignment (100 000 x 500 nt) through the COMPLETE default pipeline with its own flag: `VeryFastTree -nt -fastest -threads 1
+    -seed 1` - top hits with the second-level lists in the NJ phase (the reference's one-thread `-fastest`), then ME NNIs + SPRs, ML NNIs
+    under Jukes-Cantor + CAT, SH-like supports.  Kept: CRC-32 and length of the tree, the TreeLogLk lines -> bb_c3_full_crc.npz."""
+    import time, zlib
+    codes = synth.random_descent_codes(100000, 500, 4, 0.03, 0.01, seed=3)
+    fa = os.path.join(HERE, "_ref", "c3_full.fa")
+    synth.codes_to_fasta(codes, fa, synth.ALPHABET_NT)
+    del codes
+    log = os.path.join(HERE, "_ref", "c3_full.log")
+    flags = ["-nt", "-fastest", "-threads", "1", "-seed", "1"]
+    t0 = time.time()
+    with open(os.path.join(HERE, "_ref", "c3_full.tree"), "wb") as out, open(os.path.join(HERE, "_ref", "c3_full.err"), "wb") as err:
+        subprocess.run([REFBIN] + flags + ["-log", log, fa], check=True, stdout=out, stderr=err)
+    wall = time.time() - t0
+    os.remove(fa)
+    tree = open(os.path.join(HERE, "_ref", "c3_full.tree"), "rb").read().decode().strip()
+    ll = [float(x.group(1)) for x in re.finditer(r"^TreeLogLk\t\S+\t(\S+)", open(log).read(), re.M)]
+    np.savez_compressed(os.path.join(GOLDEN, "bb_c3_full_crc.npz"), newick_crc=np.int64(zlib.crc32(tree.encode())), newick_bytes=np.int64(len(tree)),
+                        loglk=np.array(ll), flags=np.frombuffer(" ".join(flags).encode(), dtype=np.uint8),
+                        alignment=np.frombuffer(b"random_descent_codes(100000, 500, 4, 0.03, 0.01, seed=3)", dtype=np.uint8),
+                        reference_wall_s=np.float64(wall))
+    print("bb_c3_full_crc: %d bytes of Newick, crc %d, %d TreeLogLk lines, %.0f s" % (len(tree), zlib.crc32(tree.encode()), len(ll), wall))
+
+
 GAMMA_CASES = [
     # name, alphabet size, flags, n, L, mu, gap, seed
     ("gamma_nt_200", 4, ["-nt", "-gamma"], 200, 120, 0.05, 0.02, 21),
@@ -805,6 +830,8 @@ def main():
             gen_gamma(tmp)
         if "c3" in which:   # not part of the default set: ~11 minutes
             gen_c3(tmp)
+        if "c3_full" in which:   # not part of the default set: an hour of one core
+            gen_c3_full(tmp)
         if "c2" in which:   # not part of the default set: minutes
             gen_c2(tmp)
         for w in which:     # `c5:<n>`: config C5's generator at n sequences (50000 = the config itself, hours); `c5h:<n>` harvests a finished run

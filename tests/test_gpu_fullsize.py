@@ -233,6 +233,28 @@ def test_c4_join_order_equals_the_reference_trace():
     assert len(tree) == int(r["newick_bytes"]) and zlib.crc32(tree.encode()) == int(r["newick_crc"])
 
 
+def test_c3_complete_pipeline_equals_the_reference_tree():
+    """Config C3's alignment (100 000 x 500 nt) through the complete default pipeline with its own flag, `VeryFastTree -nt -fastest` at one
+    thread: the NJ phase with the second-level top-hit lists, ME NNIs + SPRs, ML NNIs under Jukes-Cantor + CAT, SH-like supports
+    (oracle/gen_fixtures.py c3_full -> bb_c3_full_crc.npz).  Every TreeLogLk line within 1e-4 relative, the tree byte for byte."""
+    import os, zlib
+    from veryfasttree_amd import HipProfileOps, synth
+    from veryfasttree_amd.backend import nj_newick
+    ref = os.path.join(os.path.dirname(__file__), "golden", "bb_c3_full_crc.npz")
+    if not os.path.exists(ref):
+        pytest.skip("fixture not generated")
+    g = np.load(ref)
+    assert bytes(g["alignment"]).decode() == "random_descent_codes(100000, 500, 4, 0.03, 0.01, seed=3)"
+    codes = synth.random_descent_codes(100000, 500, 4, 0.03, 0.01, seed=3)
+    names = ["s%d" % k for k in range(len(codes))]
+    tree, loglk = nj_newick(lambda m, Lp: HipProfileOps(m, Lp, 4, np.float32, max_nodes=3 * m), codes, names, fastest=True, me_lengths=True,
+                            me_nni=True, spr=2, ml_nni=20, n_bootstrap=1000, return_loglk=True)
+    want = g["loglk"]
+    print("TreeLogLk", list(loglk), "reference", list(want))
+    assert len(loglk) == len(want) and np.allclose(loglk, want, rtol=1e-4, atol=0)
+    assert len(tree) == int(g["newick_bytes"]) and zlib.crc32(tree.encode()) == int(g["newick_crc"])
+
+
 def _c2_alignment():
     from veryfasttree_amd import synth
     return synth.random_descent_codes(10000, 1000, 4, 0.03, 0.01, seed=2)
