@@ -3,6 +3,7 @@ against the oracle on sampled pairs (the oracle cannot sweep 10^5..10^6 targets 
 import numpy as np
 import pytest
 
+from conftest import heavy
 from oracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -233,6 +234,7 @@ def test_c4_join_order_equals_the_reference_trace():
     assert len(tree) == int(r["newick_bytes"]) and zlib.crc32(tree.encode()) == int(r["newick_crc"])
 
 
+@heavy
 def test_c3_complete_pipeline_equals_the_reference_tree():
     """Config C3's alignment (100 000 x 500 nt) through the complete default pipeline with its own flag, `VeryFastTree -nt -fastest` at one
     thread: the NJ phase with the second-level top-hit lists, ME NNIs + SPRs, ML NNIs under Jukes-Cantor + CAT, SH-like supports
@@ -279,7 +281,7 @@ def test_c2_tree_equals_the_reference_tree():
     assert zlib.crc32(tree.encode()) == int(ref["newick_crc"])
 
 
-@pytest.mark.parametrize("fixture,mu,gap,seed", [("bb_c5_20k_crc", 0.08, 0.02, 5), ("bb_c5mu03_20k_crc", 0.03, 0.01, 2)])
+@pytest.mark.parametrize("fixture,mu,gap,seed", [("bb_c5_20k_crc", 0.08, 0.02, 5), pytest.param("bb_c5mu03_20k_crc", 0.03, 0.01, 2, marks=heavy)])
 def test_c5_generator_tree_equals_the_reference_tree(fixture, mu, gap, seed):
     """BASELINE config C5's generator (mu 0.08, gaps 0.02, seed 5) and flags at 20 000 sequences (amino acids x 300, `-lg
     -double-precision`, one-thread order - the reference's deterministic path): the complete default pipeline must print the reference

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import golden_util as G
+from conftest import heavy
 
 pytestmark = pytest.mark.gpu
 
@@ -84,7 +85,8 @@ def test_matrix_models_stay_within_the_references_own_spread(name):
     assert again == tree
 
 
-@pytest.mark.parametrize("fixture,n", [("thr_c4_200k_t64_crc", 200000), ("thr_c4_100k_t64_crc", 100000), ("thr_c4_100k_t1_crc", 100000)])
+@pytest.mark.parametrize("fixture,n", [pytest.param("thr_c4_200k_t64_crc", 200000, marks=heavy), ("thr_c4_100k_t64_crc", 100000),
+                                       pytest.param("thr_c4_100k_t1_crc", 100000, marks=heavy), pytest.param("thr_c4_200k_t1_crc", 200000, marks=heavy)])
 def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n):
     """The subtree schedule 100 times beyond the toy fixtures: config C4's generator at n sequences, `VeryFastTree -nt -threads 64 -seed 1` -
     the whole default pipeline (NJ, ME NNIs + SPRs, ML NNIs under Jukes-Cantor + CAT, SH-like supports), 2 273 s on the build container's
