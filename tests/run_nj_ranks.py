@@ -33,8 +33,10 @@ def main():
     codes = codes[np.sort(first)]
     ops = HipProfileOps(codes.shape[0], L, 4, np.float32, device=local)
     joins, crit = nj_run(ops, codes, fastest=fastest, second_level=second, comm=comm, out_profile_parts=parts)
-    print("rank %d crc %d joins %d allgathers %d" % (comm.rank if comm else 0, zlib.crc32(joins.tobytes()), len(joins),
-                                                     comm.calls if comm else 0), flush=True)
+    # (one write per rank: the ranks share a pipe)
+    sys.stdout.write("rank %d crc %d joins %d allgathers %d\n" % (comm.rank if comm else 0, zlib.crc32(joins.tobytes()), len(joins),
+                                                                  comm.calls if comm else 0))
+    sys.stdout.flush()
     ops.close()
     if world > 1:
         dist.barrier()

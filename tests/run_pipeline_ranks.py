@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE: a complete pipeline of a fixture on WORLD_SIZE ranks (torch.distributed; all ranks may share GPU 0 with gloo:
 VFT_SAME_DEVICE=1) - the NJ sweeps AND the lanes of the subtree schedule split over the ranks (vft_comm).  Every rank prints
-`rank crc32(tree) bytes lane_allgathers lane_bytes loglk <the TreeLogLk lines as hex floats: treeLogLk's pair likelihoods are split over the ranks too>`.  run_pipeline_ranks.py <fixture name>"""
+`rank crc32(tree) bytes lane_allgathers lane_bytes loglk <the TreeLogLk lines as hex floats: treeLogLk's pair likelihoods are split over the ranks too> end`.  run_pipeline_ranks.py <fixture name>"""
 import os
 import sys
 import zlib
@@ -50,8 +50,10 @@ def main():
     if ml:
         tree, loglk = tree
     calls, nbytes = last_lane_exchange()
-    print("rank %d crc %d bytes %d lane_allgathers %d lane_bytes %d loglk %s" % (comm.rank if comm else 0, zlib.crc32(tree.encode()), len(tree), calls, nbytes,
-                                                                                 ",".join(float(x).hex() for x in loglk)), flush=True)
+    # (one write per rank: the ranks share a pipe, and print() hands text and newline over separately - lines interleaved mid-way)
+    sys.stdout.write("rank %d crc %d bytes %d lane_allgathers %d lane_bytes %d loglk %s end\n" % (comm.rank if comm else 0, zlib.crc32(tree.encode()), len(tree), calls, nbytes,
+                                                                                                ",".join(float(x).hex() for x in loglk)))
+    sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

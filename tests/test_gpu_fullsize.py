@@ -3,7 +3,7 @@ against the oracle on sampled pairs (the oracle cannot sweep 10^5..10^6 targets 
 import numpy as np
 import pytest
 
-from conftest import heavy
+from conftest import free_port, heavy
 from oracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -192,7 +192,7 @@ def test_nj_driver_join_order_is_rank_count_independent(mode):
     one = subprocess.run([sys.executable, script] + args, check=True, stdout=subprocess.PIPE, timeout=600).stdout.decode()
     env = dict(os.environ, VFT_SAME_DEVICE="1", VFT_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29541", script] + args, check=True, stdout=subprocess.PIPE, env=env,
+                          "127.0.0.1", "--master-port", str(free_port()), script] + args, check=True, stdout=subprocess.PIPE, env=env,
                          timeout=900).stdout.decode()
     want = re.search(r"rank 0 crc (\d+) joins (\d+)", one).groups()
     got = re.findall(r"rank (\d) crc (\d+) joins (\d+) allgathers (\d+)", two)

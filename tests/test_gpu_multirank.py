@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -81,7 +83,7 @@ def test_out_profile_in_parts_depends_on_the_partition_only():
     one = subprocess.run([sys.executable, script] + args, check=True, stdout=subprocess.PIPE, timeout=600).stdout.decode()
     env = dict(os.environ, VFT_SAME_DEVICE="1", VFT_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29549", script] + args, check=True, stdout=subprocess.PIPE, env=env,
+                          "127.0.0.1", "--master-port", str(free_port()), script] + args, check=True, stdout=subprocess.PIPE, env=env,
                          timeout=900).stdout.decode()
     want = re.search(r"rank 0 crc (\d+) joins (\d+)", one).groups()
     got = re.findall(r"rank (\d) crc (\d+) joins (\d+) allgathers (\d+)", two)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import golden_util as G
-from conftest import heavy
+from conftest import free_port, heavy
 
 pytestmark = pytest.mark.gpu
 
@@ -195,9 +195,9 @@ def test_lanes_across_two_ranks_give_the_single_rank_tree(name):
     ref = bytes(d["newick"]).decode().strip()
     env = dict(os.environ, VFT_SAME_DEVICE="1", VFT_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29547", script, name], check=True, stdout=subprocess.PIPE, env=env,
+                          "127.0.0.1", "--master-port", str(free_port()), script, name], check=True, stdout=subprocess.PIPE, env=env,
                          timeout=900).stdout.decode()
-    got = re.findall(r"rank (\d) crc (\d+) bytes (\d+) lane_allgathers (\d+) lane_bytes (\d+) loglk (\S*)", two)
+    got = re.findall(r"rank (\d) crc (\d+) bytes (\d+) lane_allgathers (\d+) lane_bytes (\d+) loglk (\S*) end", two)
     assert len(got) == 2, two
     for r, crc, nb, calls, nbytes, ll in got:
         assert (int(crc), int(nb)) == (zlib.crc32(ref.encode()), len(ref)), (r, crc, nb)
