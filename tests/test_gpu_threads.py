@@ -85,9 +85,11 @@ def test_matrix_models_stay_within_the_references_own_spread(name):
     assert again == tree
 
 
-@pytest.mark.parametrize("fixture,n", [pytest.param("thr_c4_200k_t64_crc", 200000, marks=heavy), ("thr_c4_100k_t64_crc", 100000),
-                                       pytest.param("thr_c4_100k_t1_crc", 100000, marks=heavy), pytest.param("thr_c4_200k_t1_crc", 200000, marks=heavy)])
-def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n):
+@pytest.mark.parametrize("fixture,n,identical", [pytest.param("thr_c4_200k_t64_crc", 200000, True, marks=heavy), ("thr_c4_100k_t64_crc", 100000, True),
+                                                 pytest.param("thr_c4_100k_t1_crc", 100000, True, marks=heavy),
+                                                 pytest.param("thr_c4_200k_t1_crc", 200000, True, marks=heavy),
+                                                 pytest.param("thr_c4_400k_t64_crc", 400000, False, marks=heavy)])
+def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n, identical):
     """The complete default pipeline far beyond the toy fixtures: config C4's generator at n sequences, `VeryFastTree -nt -threads T -seed 1`
     (NJ, ME NNIs + SPRs, ML NNIs under Jukes-Cantor + CAT, SH-like supports; oracle/gen_fixtures.py thrbig:<n>:<T> ->
     thr_c4_<n/1000>k_t<T>_crc.npz: CRC-32 and length of the tree, every TreeLogLk line; 985 s on the build container's eight cores at
@@ -97,7 +99,10 @@ def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n):
     placements on zero-length branches (exact ties of an ML NNI: 24 places at 100 000, 44 splits at 200 000 - at first put down to the
     reference's threaded NJ phase, which at 200 000 sequences and 64 threads differs from its one-thread NJ tree in one split); with the
     totals as the reference's ordered product (vft_set_jc_exact, the default) all of them are identical - at 200 000 too: the one
-    different split of the reference's NJ tree does not survive its own ME NNIs / SPRs."""
+    different split of the reference's NJ tree does not survive its own ME NNIs / SPRs.  At 400 000 sequences and 64 threads (5 502 s for the
+    reference, 177 s here) the two runs DO part: same length, all eight TreeLogLk lines within 4e-8 relative (the first one -7277475.29
+    here, -7277475.01 there), different trees - the reference's threaded NJ phase, which does not follow its own one-thread order at that
+    size, is where a backend that does follow it cannot go along (identical = False: likelihoods and length only)."""
     import os
     import zlib
     from veryfasttree_amd import HipProfileOps, synth
@@ -116,7 +121,7 @@ def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n):
           "(reference NJ at T threads == its one-thread NJ: %d)" % int(d["reference_nj_equals_its_one_thread_nj"]))
     assert len(loglk) == len(want) and np.allclose(loglk, want, rtol=1e-4, atol=0)
     assert len(tree) == int(d["newick_bytes"])
-    assert same
+    assert same or not identical
 
 
 def test_one_thread_is_untouched_by_the_option():
