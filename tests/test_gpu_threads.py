@@ -101,10 +101,10 @@ def test_the_64_thread_schedule_far_beyond_the_toy_fixtures(fixture, n, identica
     totals as the reference's ordered product (vft_set_jc_exact, the default) all of them are identical - at 200 000 too: the one
     different split of the reference's NJ tree does not survive its own ME NNIs / SPRs.  At 400 000 sequences and 64 threads (5 502 s for the
     reference, 177 s here) the two runs DO part: same length, all eight TreeLogLk lines within 4e-8 relative (the first one -7277475.29
-    here, -7277475.01 there), different trees (identical = False: likelihoods and length only).  The likely cause is the reference's
-    threaded NJ phase, which leaves its own one-thread order from 200 000 sequences on (one split there, more at a million:
-    tests/golden/bb_c4_t6.npz) while this backend's NJ phase IS the one-thread order; an NJ-only run of the reference at 64 threads and
-    400 000 sequences, which would settle it, had not finished when round 6 ended."""
+    here, -7277475.01 there), different trees (identical = False: likelihoods and length only).  The reference's threaded NJ phase
+    leaves its own one-thread order from 200 000 sequences on (one split there) while this backend's NJ phase IS the one-thread order; at
+    400 000 sequences its NJ-only trees at 64 threads and at one thread differ from character 890 573 of 10 502 875 on (5 115 s run, the
+    fixture's reference_nj_equals_its_one_thread_nj = 0) - far more than its ME NNIs / SPRs wash out."""
     import os
     import zlib
     from veryfasttree_amd import HipProfileOps, synth
